@@ -1,0 +1,143 @@
+/*
+ * pyrodigal_amd.h -- C-ABI of the MI355X-native Prodigal gene-finding core.
+ *
+ * Plain C linkage, plain pointers and sizes, no exceptions cross this boundary.
+ * Every entry point returns 0 on success or a negative PGA_E* code; the message
+ * for the last failure on a context is available through pga_last_error().
+ * All "ref:" citations are relative to /root/reference/src/pyrodigal.
+ *
+ * Two levels, both replacing reference plug points:
+ *
+ *  1. scorer level  -- pga_score_connections(): whole-array drop-in for
+ *     ConnectionScorer.index() + score_connections()  (ref: lib.pyx:1126-1237,
+ *     1336-1357; _connection.h:386-408; impl/generic.h:13-49).
+ *  2. finder level  -- pga_find_genes_batch(): whole-batch drop-in for
+ *     GeneFinder.find_genes() in meta or single mode  (ref: lib.pyx:5281-5469).
+ */
+#ifndef PYRODIGAL_AMD_H
+#define PYRODIGAL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGA_OK          0
+#define PGA_EINVAL     (-1)   /* bad argument (maps to ValueError)  */
+#define PGA_ENOMEM     (-2)   /* host or device allocation failed (MemoryError) */
+#define PGA_EDEVICE    (-3)   /* HIP runtime error (RuntimeError) */
+#define PGA_ENODEVICE  (-4)   /* no gfx950 device visible (RuntimeError) */
+
+typedef struct pga_ctx pga_ctx;
+
+/* Byte layout of the reference's `struct _training` (ref: prodigal/training.pxd:3-14),
+ * 558 392 bytes; TrainingInfo.dump() files can be passed as-is. */
+typedef struct pga_training {
+    double  gc;
+    int32_t trans_table;
+    int32_t _pad0;
+    double  st_wt;
+    double  bias[3];
+    double  type_wt[3];
+    int32_t uses_sd;
+    int32_t _pad1;
+    double  rbs_wt[28];
+    double  ups_comp[32][4];
+    double  mot_wt[4][4][4096];
+    double  no_mot;
+    double  gene_dc[4096];
+} pga_training;
+
+/* GeneFinder constructor options (ref: lib.pyx:5102-5115). */
+typedef struct pga_params {
+    int32_t closed;         /* default 0  */
+    int32_t min_gene;       /* default 90 */
+    int32_t min_edge_gene;  /* default 60 */
+    int32_t max_overlap;    /* default 60 */
+    int32_t meta;           /* 1: meta mode over all loaded models; 0: single mode with model 0 */
+    int32_t want_nodes;     /* 1: also return the winning model's full node arrays */
+} pga_params;
+
+/* One predicted gene (ref: lib.pxd:274-278 `_gene` + the start/stop node fields Gene reads,
+ * lib.pyx:2644-2830). Coordinates are 1-based inclusive like the reference. */
+typedef struct pga_gene {
+    int32_t contig;        /* index into the batch */
+    int32_t begin, end;
+    int32_t start_ndx, stop_ndx;
+    int8_t  strand;
+    uint8_t partial_begin, partial_end;
+    uint8_t start_type;    /* 0 ATG, 1 GTG, 2 TTG, 3 Edge */
+    uint8_t rbs[2];
+    uint8_t mot_len, mot_spacer;
+    int32_t mot_ndx;
+    float   gc_cont;
+    double  cscore, sscore, rscore, uscore, tscore, mot_score;
+} pga_gene;
+
+/* Node arrays of one contig for its winning model (SoA; ref: src/Prodigal/node.h:40-76). */
+typedef struct pga_nodes {
+    int32_t  n;
+    int32_t *ndx, *stop_val, *traceb, *tracef, *star_ptr /* [n][3] */;
+    uint8_t *type, *edge, *elim, *rbs /* [n][2] */;
+    int8_t  *strand, *ov_mark;
+    float   *gc_cont;
+    double  *cscore, *sscore, *rscore, *uscore, *tscore, *score, *mot_score;
+    int32_t *mot_ndx;
+    uint8_t *mot_len, *mot_spacer, *mot_spacendx;
+} pga_nodes;
+
+typedef struct pga_contig_result {
+    int32_t model;        /* winning model index, -1 if none (ref: lib.pyx:5317-5396) */
+    int32_t n_nodes;
+    int64_t gene_begin;   /* genes[gene_begin .. gene_begin + n_genes) */
+    int32_t n_genes;
+    int32_t _pad;
+    double  gc;
+    double  score;        /* nodes[ipath].score of the winning DP pass */
+} pga_contig_result;
+
+typedef struct pga_result {
+    int32_t            n_contigs;
+    int64_t            n_genes;
+    pga_contig_result* contigs;
+    pga_gene*          genes;
+    pga_nodes*         nodes;     /* NULL unless want_nodes */
+    double             t_total_ms, t_dp_ms;   /* device time of the whole batch / of the DP kernel */
+    int64_t            node_passes;           /* sum over (contig, model) DP passes of node count */
+} pga_result;
+
+/* ---- context ---------------------------------------------------------- */
+int         pga_create(int device, pga_ctx** out);
+void        pga_destroy(pga_ctx*);
+const char* pga_last_error(const pga_ctx*);
+int         pga_device_info(const pga_ctx*, char* name, int name_len, int* cus, int64_t* hbm_bytes);
+
+/* ---- models (MetagenomicBins / TrainingInfo, ref: lib.pyx:4888-5069, 3898-3953) ---- */
+int pga_set_models(pga_ctx*, const pga_training* const* models, int n_models);
+
+/* ---- scorer level ------------------------------------------------------ */
+/* Whole-array connection scoring of one sorted node list (final=1: gene prediction pass).
+ * Inputs are the node fields _score_connections reads; outputs are the fields it writes. */
+int pga_score_connections(pga_ctx*, int32_t n,
+                          const int32_t* ndx, const int32_t* stop_val,
+                          const uint8_t* type, const int8_t* strand,
+                          const double* cscore, const double* sscore,
+                          const double* rscore, const double* uscore,
+                          const int32_t* star_ptr /* [n][3] */,
+                          double st_wt, int final,
+                          double* score, int32_t* traceb, int8_t* ov_mark,
+                          int32_t* max_index /* _find_max_index, may be NULL */,
+                          double* kernel_ms /* may be NULL */);
+
+/* ---- finder level ------------------------------------------------------ */
+/* `seqs[c]` points at `lens[c]` ASCII nucleotides (any case, non-ACGT = unknown). */
+int  pga_find_genes_batch(pga_ctx*, int32_t n_contigs, const char* const* seqs, const int64_t* lens,
+                          const pga_params*, pga_result** out);
+void pga_result_free(pga_result*);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -73,6 +73,8 @@ def lib():
         L.po_score_nodes.argtypes = [vp, vp, i32, i32]
         L.po_overlapping_starts.argtypes = [vp, vp, i32, i32]
         L.po_dprog.restype = i32; L.po_dprog.argtypes = [vp, vp, i32, i32]
+        L.po_dprog_raw.restype = None; L.po_dprog_raw.argtypes = [vp, vp, i32]
+        L.po_find_max_index.restype = i32; L.po_find_max_index.argtypes = [vp]
         L.po_eliminate_bad_genes.argtypes = [vp, i32, vp]
         L.po_extract_genes.restype = i32; L.po_extract_genes.argtypes = [vp, i32]
         L.po_tweak_final_starts.argtypes = [vp, vp, i32]
@@ -191,6 +193,13 @@ class Oracle:
 
     def dprog(self, tinf, final=True):
         return self.L.po_dprog(self.h, tinf.ptr, int(final), 1)
+
+    def dprog_raw(self, tinf, final=True):
+        """Connection loop only (no traceback fix-ups): nodes keep the raw score/traceb/ov_mark."""
+        self.L.po_dprog_raw(self.h, tinf.ptr, int(final))
+
+    def find_max_index(self):
+        return self.L.po_find_max_index(self.h)
 
     def eliminate_bad_genes(self, ipath, tinf):
         self.L.po_eliminate_bad_genes(self.h, ipath, tinf.ptr)

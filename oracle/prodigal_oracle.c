@@ -725,10 +725,11 @@ static void skippable(const uint8_t* restrict st, const uint8_t* restrict ty, co
 
 /* ref: lib.pyx:1205-1311 (_score_connections, _find_max_index, _disentangle_overlaps,
  * _max_forward_pointers, _dynamic_programming) and _connection.h:386-408 */
-int po_dprog(po_ctx* c, const po_training* t, int final, int use_filter) {
-    (void)use_filter;   /* the split scorers are only defined on filtered pairs (SURVEY fact 7) */
+/* the connection loop alone: node score / traceb / ov_mark before any traceback fix-up
+ * (ref: lib.pyx:1205-1237 `_score_connections`) */
+void po_dprog_raw(po_ctx* c, const po_training* t, int final) {
     const int nn = c->nn; po_node* nod = c->nod;
-    if (nn == 0) return -1;
+    if (nn == 0) return;
     index_nodes(c);
     for (int i = 0; i < nn; i++) { nod[i].score = 0; nod[i].traceb = -1; nod[i].tracef = -1; }
     for (int i = 0; i < nn; i++) {
@@ -740,12 +741,26 @@ int po_dprog(po_ctx* c, const po_training* t, int final, int use_filter) {
         skippable(c->k_strand, c->k_type, c->k_frame, lo, i, c->k_skip);
         for (int j = lo; j < i; j++) if (!c->k_skip[j]) connect(nod, j, i, kind, t, final);
     }
+}
+
+/* ref: lib.pyx:1239-1251 (_find_max_index) */
+int po_find_max_index(const po_ctx* c) {
+    const po_node* nod = c->nod;
     int mx = -1; double best = -1.0;
-    for (int i = nn - 1; i >= 0; i--) {
+    for (int i = c->nn - 1; i >= 0; i--) {
         if (nod[i].strand == 1 && nod[i].type != T_STOP) continue;
         if (nod[i].strand == -1 && nod[i].type == T_STOP) continue;
         if (nod[i].score > best) { best = nod[i].score; mx = i; }
     }
+    return mx;
+}
+
+int po_dprog(po_ctx* c, const po_training* t, int final, int use_filter) {
+    (void)use_filter;   /* the split scorers are only defined on filtered pairs (SURVEY fact 7) */
+    const int nn = c->nn; po_node* nod = c->nod;
+    if (nn == 0) return -1;
+    po_dprog_raw(c, t, final);
+    int mx = po_find_max_index(c);
     if (mx < 0) return -1;   /* guarded; the reference would read nodes[-1] here */
     /* first pass: triple overlaps (ov_mark) */
     for (int p = mx; nod[p].traceb != -1; p = nod[p].traceb) {

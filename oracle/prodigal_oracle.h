@@ -92,6 +92,8 @@ void po_reset_scores(po_ctx*);
 void po_score_nodes(po_ctx*, const po_training*, int closed, int is_meta);
 void po_overlapping_starts(po_ctx*, const po_training*, int flag, int max_overlap);
 int  po_dprog(po_ctx*, const po_training*, int final, int use_filter);
+void po_dprog_raw(po_ctx*, const po_training*, int final);   /* connection loop only, no fix-ups */
+int  po_find_max_index(const po_ctx*);
 void po_eliminate_bad_genes(po_ctx*, int ipath, const po_training*);
 int  po_extract_genes(po_ctx*, int ipath);
 void po_tweak_final_starts(po_ctx*, const po_training*, int max_overlap);

@@ -1,0 +1,171 @@
+"""ctypes binding of ``libpyrodigal_amd.so`` (the C-ABI declared in ``include/pyrodigal_amd.h``).
+
+There is no CPU implementation behind this module: if the shared library is missing, or no
+gfx950 device is visible, calls raise instead of silently computing elsewhere.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpyrodigal_amd.so")
+
+PGA_OK, PGA_EINVAL, PGA_ENOMEM, PGA_EDEVICE, PGA_ENODEVICE = 0, -1, -2, -3, -4
+TRAINING_SIZE = 558392
+
+EXPORTS = [
+    "pga_create", "pga_destroy", "pga_last_error", "pga_device_info", "pga_set_models",
+    "pga_score_connections", "pga_find_genes_batch", "pga_result_free",
+]
+
+
+class Params(ctypes.Structure):
+    _fields_ = [("closed", ctypes.c_int32), ("min_gene", ctypes.c_int32), ("min_edge_gene", ctypes.c_int32),
+                ("max_overlap", ctypes.c_int32), ("meta", ctypes.c_int32), ("want_nodes", ctypes.c_int32)]
+
+
+class Gene(ctypes.Structure):
+    _fields_ = [("contig", ctypes.c_int32), ("begin", ctypes.c_int32), ("end", ctypes.c_int32),
+                ("start_ndx", ctypes.c_int32), ("stop_ndx", ctypes.c_int32), ("strand", ctypes.c_int8),
+                ("partial_begin", ctypes.c_uint8), ("partial_end", ctypes.c_uint8), ("start_type", ctypes.c_uint8),
+                ("rbs", ctypes.c_uint8 * 2), ("mot_len", ctypes.c_uint8), ("mot_spacer", ctypes.c_uint8),
+                ("mot_ndx", ctypes.c_int32), ("gc_cont", ctypes.c_float),
+                ("cscore", ctypes.c_double), ("sscore", ctypes.c_double), ("rscore", ctypes.c_double),
+                ("uscore", ctypes.c_double), ("tscore", ctypes.c_double), ("mot_score", ctypes.c_double)]
+
+
+_P = ctypes.POINTER
+
+
+class Nodes(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int32),
+                ("ndx", _P(ctypes.c_int32)), ("stop_val", _P(ctypes.c_int32)), ("traceb", _P(ctypes.c_int32)),
+                ("tracef", _P(ctypes.c_int32)), ("star_ptr", _P(ctypes.c_int32)),
+                ("type", _P(ctypes.c_uint8)), ("edge", _P(ctypes.c_uint8)), ("elim", _P(ctypes.c_uint8)),
+                ("rbs", _P(ctypes.c_uint8)), ("strand", _P(ctypes.c_int8)), ("ov_mark", _P(ctypes.c_int8)),
+                ("gc_cont", _P(ctypes.c_float)),
+                ("cscore", _P(ctypes.c_double)), ("sscore", _P(ctypes.c_double)), ("rscore", _P(ctypes.c_double)),
+                ("uscore", _P(ctypes.c_double)), ("tscore", _P(ctypes.c_double)), ("score", _P(ctypes.c_double)),
+                ("mot_score", _P(ctypes.c_double)), ("mot_ndx", _P(ctypes.c_int32)),
+                ("mot_len", _P(ctypes.c_uint8)), ("mot_spacer", _P(ctypes.c_uint8)), ("mot_spacendx", _P(ctypes.c_uint8))]
+
+
+class ContigResult(ctypes.Structure):
+    _fields_ = [("model", ctypes.c_int32), ("n_nodes", ctypes.c_int32), ("gene_begin", ctypes.c_int64),
+                ("n_genes", ctypes.c_int32), ("_pad", ctypes.c_int32), ("gc", ctypes.c_double),
+                ("score", ctypes.c_double)]
+
+
+class Result(ctypes.Structure):
+    _fields_ = [("n_contigs", ctypes.c_int32), ("n_genes", ctypes.c_int64), ("contigs", _P(ContigResult)),
+                ("genes", _P(Gene)), ("nodes", _P(Nodes)), ("t_total_ms", ctypes.c_double),
+                ("t_dp_ms", ctypes.c_double), ("node_passes", ctypes.c_int64)]
+
+
+GENE_DTYPE = np.dtype(Gene)
+CONTIG_DTYPE = np.dtype(ContigResult)
+
+_lib = None
+
+
+def load():
+    """Load the C-ABI library; raises ``RuntimeError`` when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950); pyrodigal_amd has no CPU fallback")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
+    L.pga_create.restype = ctypes.c_int; L.pga_create.argtypes = [ctypes.c_int, _P(vp)]
+    L.pga_destroy.restype = None; L.pga_destroy.argtypes = [vp]
+    L.pga_last_error.restype = ctypes.c_char_p; L.pga_last_error.argtypes = [vp]
+    L.pga_device_info.restype = ctypes.c_int
+    L.pga_device_info.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, _P(ctypes.c_int), _P(i64)]
+    L.pga_set_models.restype = ctypes.c_int; L.pga_set_models.argtypes = [vp, _P(vp), ctypes.c_int]
+    L.pga_score_connections.restype = ctypes.c_int
+    L.pga_score_connections.argtypes = [vp, i32] + [vp] * 9 + [f64, ctypes.c_int, vp, vp, vp, _P(i32), _P(f64)]
+    L.pga_find_genes_batch.restype = ctypes.c_int
+    L.pga_find_genes_batch.argtypes = [vp, i32, _P(ctypes.c_char_p), _P(i64), _P(Params), _P(_P(Result))]
+    L.pga_result_free.restype = None; L.pga_result_free.argtypes = [_P(Result)]
+    _lib = L
+    return L
+
+
+class PgaError(RuntimeError):
+    pass
+
+
+def _raise(L, ctx, code, what):
+    msg = L.pga_last_error(ctx).decode("utf-8", "replace") if ctx else ""
+    if code == PGA_EINVAL:
+        raise ValueError(f"{what}: {msg}")
+    if code == PGA_ENOMEM:
+        raise MemoryError(f"{what}: {msg}")
+    if code == PGA_ENODEVICE:
+        raise PgaError(f"{what}: no gfx950 (MI355X) device visible; pyrodigal_amd has no CPU fallback")
+    raise PgaError(f"{what}: {msg} (code {code})")
+
+
+class Context:
+    """Owns a ``pga_ctx`` bound to one GPU."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        h = ctypes.c_void_p()
+        rc = self.L.pga_create(int(device), ctypes.byref(h))
+        if rc != PGA_OK:
+            _raise(self.L, None, rc, "pga_create")
+        self.h = h
+        self._models = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pga_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def device_info(self):
+        name = ctypes.create_string_buffer(256)
+        cus, mem = ctypes.c_int(), ctypes.c_int64()
+        rc = self.L.pga_device_info(self.h, name, 256, ctypes.byref(cus), ctypes.byref(mem))
+        if rc != PGA_OK:
+            _raise(self.L, self.h, rc, "pga_device_info")
+        return {"name": name.value.decode(), "cus": cus.value, "hbm_bytes": mem.value}
+
+    def set_models(self, blobs):
+        """``blobs``: iterable of 558 392-byte ``struct _training`` buffers (bytes / uint8 arrays)."""
+        arrs = []
+        for b in blobs:
+            a = np.frombuffer(bytes(b), dtype=np.uint8).copy() if not isinstance(b, np.ndarray) else np.ascontiguousarray(b, np.uint8)
+            if a.size != TRAINING_SIZE:
+                raise ValueError(f"training info must be {TRAINING_SIZE} bytes, got {a.size}")
+            arrs.append(a)
+        ptrs = (ctypes.c_void_p * max(1, len(arrs)))(*[a.ctypes.data for a in arrs])
+        rc = self.L.pga_set_models(self.h, ptrs, len(arrs))
+        if rc != PGA_OK:
+            _raise(self.L, self.h, rc, "pga_set_models")
+        self._models = arrs
+
+    def score_connections(self, ndx, stop_val, type_, strand, cscore, sscore, rscore, uscore, star_ptr, st_wt, final=True):
+        """Whole-array ``ConnectionScorer.index`` + ``score_connections``. Returns (score, traceb, ov_mark, max_index, kernel_ms)."""
+        n = len(ndx)
+        c = lambda a, t: np.ascontiguousarray(a, dtype=t)
+        ndx, stop_val = c(ndx, np.int32), c(stop_val, np.int32)
+        type_, strand = c(type_, np.uint8), c(strand, np.int8)
+        cscore, sscore, rscore, uscore = (c(x, np.float64) for x in (cscore, sscore, rscore, uscore))
+        star_ptr = c(star_ptr, np.int32).reshape(-1)
+        score = np.zeros(n, np.float64); traceb = np.zeros(n, np.int32); ov = np.zeros(n, np.int8)
+        mi, ms = ctypes.c_int32(-1), ctypes.c_double(0)
+        p = lambda a: a.ctypes.data
+        rc = self.L.pga_score_connections(self.h, n, p(ndx), p(stop_val), p(type_), p(strand), p(cscore), p(sscore),
+                                          p(rscore), p(uscore), p(star_ptr), float(st_wt), int(final),
+                                          p(score), p(traceb), p(ov), ctypes.byref(mi), ctypes.byref(ms))
+        if rc != PGA_OK:
+            _raise(self.L, self.h, rc, "pga_score_connections")
+        return score, traceb, ov, mi.value, ms.value

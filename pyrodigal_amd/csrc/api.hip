@@ -1,0 +1,170 @@
+// C-ABI entry points (include/pyrodigal_amd.h): context, models, scorer-level call.
+// Host code only; no CPU compute path exists here -- without a gfx950 device every call fails.
+#include "pga_internal.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+static int fail(pga_ctx* c, int code, const char* fmt, ...) {
+    if (c) {
+        char buf[512];
+        va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+        c->err = buf;
+    }
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                           \
+    do {                                                                                             \
+        hipError_t e__ = (expr);                                                                     \
+        if (e__ != hipSuccess)                                                                       \
+            return fail(ctx, e__ == hipErrorOutOfMemory ? PGA_ENOMEM : PGA_EDEVICE, "%s failed: %s", \
+                        #expr, hipGetErrorString(e__));                                              \
+    } while (0)
+
+int pga_hip_try_(pga_ctx* c, hipError_t e, const char* what) {
+    if (e == hipSuccess) return PGA_OK;
+    return fail(c, e == hipErrorOutOfMemory ? PGA_ENOMEM : PGA_EDEVICE, "%s failed: %s", what, hipGetErrorString(e));
+}
+
+extern "C" int pga_create(int device, pga_ctx** out) {
+    if (!out) return PGA_EINVAL;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return PGA_ENODEVICE;
+    if (device < 0 || device >= count) return PGA_EINVAL;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return PGA_EDEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return PGA_ENODEVICE;   // this library is built for CDNA4 only
+    pga_ctx* c = new (std::nothrow) pga_ctx();
+    if (!c) return PGA_ENOMEM;
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return PGA_EDEVICE;
+    }
+    *out = c;
+    return PGA_OK;
+}
+
+extern "C" void pga_destroy(pga_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    pga_finder_release(c);
+    if (c->d_models_raw) hipFree(c->d_models_raw);
+    if (c->d_model_const) hipFree(c->d_model_const);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char* pga_last_error(const pga_ctx* c) { return c ? c->err.c_str() : "no context"; }
+
+extern "C" int pga_device_info(const pga_ctx* c, char* name, int name_len, int* cus, int64_t* hbm_bytes) {
+    if (!c) return PGA_EINVAL;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return PGA_EDEVICE;
+    if (name && name_len > 0) snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    if (cus) *cus = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return PGA_OK;
+}
+
+void pga_fill_model_const(ModelConst* mc, double st_wt) {
+    memset(mc, 0, sizeof *mc);
+    mc->st_wt = st_wt;
+    mc->negc = -0.15 * st_wt;                                               // ref: _connection.h:43-49
+    for (int d = 0; d <= PGA_OPER_DIST; d++)
+        mc->igm[d] = (2.0 - ((double)d / PGA_OPER_DIST)) * 0.15 * st_wt;    // ref: _connection.h:73-75
+}
+
+extern "C" int pga_set_models(pga_ctx* c, const pga_training* const* models, int n_models) {
+    if (!c || n_models < 0 || (n_models > 0 && !models)) return fail(c, PGA_EINVAL, "pga_set_models: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->d_models_raw) { hipFree(c->d_models_raw); c->d_models_raw = nullptr; }
+    if (c->d_model_const) { hipFree(c->d_model_const); c->d_model_const = nullptr; }
+    c->models.clear();
+    c->n_models = 0;
+    if (n_models == 0) return PGA_OK;
+    std::vector<ModelConst> mcs(n_models);
+    for (int i = 0; i < n_models; i++) {
+        if (!models[i]) return fail(c, PGA_EINVAL, "pga_set_models: model %d is NULL", i);
+        c->models.push_back(*models[i]);
+        pga_fill_model_const(&mcs[i], models[i]->st_wt);
+    }
+    HIP_TRY(c, hipMalloc(&c->d_models_raw, sizeof(pga_training) * (size_t)n_models));
+    HIP_TRY(c, hipMalloc((void**)&c->d_model_const, sizeof(ModelConst) * (size_t)n_models));
+    HIP_TRY(c, hipMemcpy(c->d_models_raw, c->models.data(), sizeof(pga_training) * (size_t)n_models, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_model_const, mcs.data(), sizeof(ModelConst) * (size_t)n_models, hipMemcpyHostToDevice));
+    c->n_models = n_models;
+    return pga_finder_models_changed(c);
+}
+
+namespace {
+struct DevBuf {     // frees everything it allocated when the call returns
+    std::vector<void*> ptrs;
+    ~DevBuf() { for (void* p : ptrs) hipFree(p); }
+    template <typename T> hipError_t alloc(T** p, size_t count) {
+        hipError_t e = hipMalloc((void**)p, sizeof(T) * (count ? count : 1));
+        if (e == hipSuccess) ptrs.push_back(*p);
+        return e;
+    }
+};
+}  // namespace
+
+extern "C" int pga_score_connections(pga_ctx* c, int32_t n, const int32_t* ndx, const int32_t* stop_val,
+                                     const uint8_t* type, const int8_t* strand, const double* cscore,
+                                     const double* sscore, const double* rscore, const double* uscore,
+                                     const int32_t* star_ptr, double st_wt, int final, double* score,
+                                     int32_t* traceb, int8_t* ov_mark, int32_t* max_index, double* kernel_ms) {
+    if (!c) return PGA_EINVAL;
+    if (n < 0) return fail(c, PGA_EINVAL, "pga_score_connections: negative node count");
+    if (!final) return fail(c, PGA_EINVAL, "pga_score_connections: only the final (gene prediction) pass is on the device; "
+                                           "the training pass (final=0) is not implemented");
+    if (max_index) *max_index = -1;
+    if (kernel_ms) *kernel_ms = 0.0;
+    if (n == 0) return PGA_OK;
+    if (!ndx || !stop_val || !type || !strand || !cscore || !sscore || !rscore || !uscore || !star_ptr || !score || !traceb || !ov_mark)
+        return fail(c, PGA_EINVAL, "pga_score_connections: NULL array");
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf db;
+    NodeArrays nd{};
+    DpBuffers buf{};
+    ChainDesc* d_chain; ModelConst* d_mc;
+    const size_t N = (size_t)n;
+    HIP_TRY(c, db.alloc(&nd.ndx, N)); HIP_TRY(c, db.alloc(&nd.stop_val, N)); HIP_TRY(c, db.alloc(&nd.type, N));
+    HIP_TRY(c, db.alloc(&nd.strand, N)); HIP_TRY(c, db.alloc(&nd.cscore, N)); HIP_TRY(c, db.alloc(&nd.sscore, N));
+    HIP_TRY(c, db.alloc(&nd.rscore, N)); HIP_TRY(c, db.alloc(&nd.uscore, N)); HIP_TRY(c, db.alloc(&nd.star_ptr, 3 * N));
+    HIP_TRY(c, db.alloc(&buf.src, N)); HIP_TRY(c, db.alloc(&buf.tgt, N)); HIP_TRY(c, db.alloc(&buf.score, N));
+    HIP_TRY(c, db.alloc(&buf.traceb, N)); HIP_TRY(c, db.alloc(&buf.tbn, N)); HIP_TRY(c, db.alloc(&buf.ov_mark, N));
+    HIP_TRY(c, db.alloc(&buf.max_index, 1)); HIP_TRY(c, db.alloc(&buf.max_score, 1));
+    HIP_TRY(c, db.alloc(&d_chain, 1)); HIP_TRY(c, db.alloc(&d_mc, 1));
+    hipStream_t st = c->stream;
+#define UP(dst, srcp, bytes) HIP_TRY(c, hipMemcpyAsync(dst, srcp, bytes, hipMemcpyHostToDevice, st))
+    UP(nd.ndx, ndx, 4 * N); UP(nd.stop_val, stop_val, 4 * N); UP(nd.type, type, N); UP(nd.strand, strand, N);
+    UP(nd.cscore, cscore, 8 * N); UP(nd.sscore, sscore, 8 * N); UP(nd.rscore, rscore, 8 * N); UP(nd.uscore, uscore, 8 * N);
+    UP(nd.star_ptr, star_ptr, 12 * N);
+    ChainDesc ch{0, n, 0};
+    ModelConst mc; pga_fill_model_const(&mc, st_wt);
+    UP(d_chain, &ch, sizeof ch); UP(d_mc, &mc, sizeof mc);
+#undef UP
+    pga_launch_dp_prepare(d_chain, 1, n, nd, d_mc, buf, st);
+    HIP_TRY(c, hipEventRecord(c->ev0, st));
+    pga_launch_dp(d_chain, 1, d_mc, buf, final, st);
+    HIP_TRY(c, hipEventRecord(c->ev1, st));
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(score, buf.score, 8 * N, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(traceb, buf.traceb, 4 * N, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(ov_mark, buf.ov_mark, N, hipMemcpyDeviceToHost, st));
+    int32_t mi = -1;
+    HIP_TRY(c, hipMemcpyAsync(&mi, buf.max_index, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (max_index) *max_index = mi;
+    if (kernel_ms) { float ms = 0; HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1)); *kernel_ms = ms; }
+    return PGA_OK;
+}

@@ -1,0 +1,94 @@
+"""GPU parity: connection-scoring DP kernel vs the CPU oracle, through the C-ABI scorer-level call
+(`pga_score_connections`, the whole-array drop-in for ConnectionScorer.index + score_connections,
+ref: lib.pyx:1126-1237).  Scores must be bit-identical, traceb / ov_mark / max index equal."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests.util import golden_path, read_fasta, synthetic_contig
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from pyrodigal_amd import _cabi
+    c = _cabi.Context(0)
+    yield c
+    c.close()
+
+
+def oracle_dp(seq, tinf, closed=False, is_meta=False):
+    """Scored nodes + raw DP state (before the traceback fix-ups) from the oracle."""
+    o = orc.Oracle(seq)
+    o.extract(tinf.trans_table, orc.Params(closed=closed)); o.sort(); o.reset_scores()
+    o.score_nodes(tinf, closed, is_meta)
+    o.overlapping_starts(tinf, 1, 60)
+    o.dprog_raw(tinf, True)
+    return o.nodes(), o.find_max_index()
+
+
+def check(ctx, seq, tinf, **kw):
+    ref, ref_max = oracle_dp(seq, tinf, **kw)
+    n = len(ref)
+    score, traceb, ov, mi, ms = ctx.score_connections(
+        ref["ndx"], ref["stop_val"], ref["type"], ref["strand"], ref["cscore"], ref["sscore"],
+        ref["rscore"], ref["uscore"], ref["star_ptr"], tinf.st_wt, True)
+    assert np.array_equal(traceb, ref["traceb"])
+    assert np.array_equal(score.view(np.uint64), ref["score"].view(np.uint64)), "score not bit-identical"
+    reached = ref["traceb"] != -1      # ov_mark is only defined once a connection was made
+    assert np.array_equal(ov[reached], ref["ov_mark"][reached])
+    assert mi == ref_max
+    return n, ms
+
+
+def test_dp_srr492066(ctx):
+    seq = read_fasta("SRR492066.fna.gz")[0][1]
+    tinf = orc.Training.load(golden_path("SRR492066.training.bin.gz"))
+    n, _ = check(ctx, seq, tinf)
+    assert n == 2293
+
+
+def test_dp_nonsd_model_kk037166(ctx):
+    seq = read_fasta("KK037166.fna.gz")[0][1]
+    tinf = orc.Oracle(seq).train()
+    assert tinf.uses_sd == 0
+    check(ctx, seq, tinf)
+
+
+def test_dp_miij(ctx):
+    seq = read_fasta("MIIJ01000039.fna.gz")[0][1]
+    tinf = orc.Oracle(seq).train()
+    check(ctx, seq, tinf)
+
+
+def test_dp_giant_orf_windows_full_genome(ctx):
+    # 153k nodes; the window walk-back for giant ORFs fires ~100 times here
+    seq = read_fasta("GCF_001457455.1_NCTC11397_genomic.fna.gz")[0][1]
+    tinf = orc.Training.load(golden_path("GCF_001457455.1_NCTC11397_genomic.tinf_closed.bin.gz"))
+    n, ms = check(ctx, seq, tinf, closed=True)
+    assert n == 153296
+    print(f"full genome DP kernel: {ms:.2f} ms for {n} nodes")
+
+
+@pytest.mark.parametrize("gc,seed", [(0.3, 11), (0.5, 12), (0.7, 13)])
+def test_dp_synthetic_meta_scoring(ctx, gc, seed):
+    seq = synthetic_contig(60000, gc, seed)
+    tinf = orc.Training.load(golden_path("GCF_001457455.1_NCTC11397_genomic_100kb.tinf_closed.bin.gz"))
+    check(ctx, seq, tinf, is_meta=True)
+
+
+def test_dp_tiny_and_empty_inputs(ctx):
+    tinf = orc.Training.load(golden_path("SRR492066.training.bin.gz"))
+    s, t, v, mi, _ = ctx.score_connections([], [], [], [], [], [], [], [], np.zeros((0, 3)), tinf.st_wt)
+    assert len(s) == 0 and mi == -1
+    for L in (100, 130, 200, 400, 1000, 5000):
+        seq = synthetic_contig(L, 0.45, 100 + L)
+        ref, _ = oracle_dp(seq, tinf, is_meta=True)
+        if len(ref):
+            check(ctx, seq, tinf, is_meta=True)
+
+
+def test_training_pass_is_rejected_loudly(ctx):
+    with pytest.raises(ValueError):
+        ctx.score_connections([0], [0], [0], [1], [0.0], [0.0], [0.0], [0.0], np.zeros((1, 3)), 4.35, final=False)
