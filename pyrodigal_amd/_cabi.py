@@ -169,3 +169,65 @@ class Context:
         if rc != PGA_OK:
             _raise(self.L, self.h, rc, "pga_score_connections")
         return score, traceb, ov, mi.value, ms.value
+
+
+_NODE_FIELDS = [
+    ("ndx", np.int32, 1), ("stop_val", np.int32, 1), ("traceb", np.int32, 1), ("tracef", np.int32, 1),
+    ("star_ptr", np.int32, 3), ("type", np.uint8, 1), ("edge", np.uint8, 1), ("elim", np.uint8, 1),
+    ("rbs", np.uint8, 2), ("strand", np.int8, 1), ("ov_mark", np.int8, 1), ("gc_cont", np.float32, 1),
+    ("cscore", np.float64, 1), ("sscore", np.float64, 1), ("rscore", np.float64, 1), ("uscore", np.float64, 1),
+    ("tscore", np.float64, 1), ("score", np.float64, 1), ("mot_score", np.float64, 1), ("mot_ndx", np.int32, 1),
+    ("mot_len", np.uint8, 1), ("mot_spacer", np.uint8, 1), ("mot_spacendx", np.uint8, 1),
+]
+
+
+class BatchResult:
+    """Host copy of a ``pga_result``: ``contigs`` / ``genes`` structured arrays (+ per-contig node dicts)."""
+
+    def __init__(self, contigs, genes, nodes, t_total_ms, t_dp_ms, node_passes):
+        self.contigs, self.genes, self.nodes = contigs, genes, nodes
+        self.t_total_ms, self.t_dp_ms, self.node_passes = t_total_ms, t_dp_ms, node_passes
+
+    def genes_of(self, i):
+        c = self.contigs[i]
+        return self.genes[c["gene_begin"]:c["gene_begin"] + c["n_genes"]]
+
+
+def _find_genes_batch(self, seqs, meta=True, closed=False, min_gene=90, min_edge_gene=60, max_overlap=60, want_nodes=False):
+    """Whole-batch ``GeneFinder.find_genes``: ``seqs`` is a list of ASCII ``bytes`` contigs."""
+    seqs = [s.encode("ascii") if isinstance(s, str) else bytes(s) for s in seqs]
+    n = len(seqs)
+    ptrs = (ctypes.c_char_p * max(1, n))(*seqs)
+    lens = (ctypes.c_int64 * max(1, n))(*[len(s) for s in seqs])
+    p = Params(int(closed), min_gene, min_edge_gene, max_overlap, int(meta), int(want_nodes))
+    res = _P(Result)()
+    rc = self.L.pga_find_genes_batch(self.h, n, ptrs, lens, ctypes.byref(p), ctypes.byref(res))
+    if rc != PGA_OK:
+        _raise(self.L, self.h, rc, "pga_find_genes_batch")
+    try:
+        r = res.contents
+        contigs = np.ctypeslib.as_array(r.contigs, (r.n_contigs,)).copy() if r.n_contigs else np.zeros(0, CONTIG_DTYPE)
+        contigs = contigs.view(CONTIG_DTYPE) if contigs.dtype != CONTIG_DTYPE else contigs
+        genes = np.ctypeslib.as_array(r.genes, (r.n_genes,)).copy() if r.n_genes else np.zeros(0, GENE_DTYPE)
+        nodes = None
+        if want_nodes and r.nodes:
+            nodes = []
+            for i in range(r.n_contigs):
+                nd = r.nodes[i]
+                d = {"n": nd.n}
+                for name, dt, mult in _NODE_FIELDS:
+                    ptr = getattr(nd, name)
+                    if nd.n == 0 or not ptr:
+                        a = np.zeros((0, mult) if mult > 1 else 0, dt)
+                    else:
+                        a = np.ctypeslib.as_array(ptr, (nd.n * mult,)).copy()
+                        if mult > 1:
+                            a = a.reshape(nd.n, mult)
+                    d[name] = a
+                nodes.append(d)
+        return BatchResult(contigs, genes, nodes, r.t_total_ms, r.t_dp_ms, r.node_passes)
+    finally:
+        self.L.pga_result_free(res)
+
+
+Context.find_genes_batch = _find_genes_batch

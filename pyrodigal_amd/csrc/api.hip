@@ -133,7 +133,7 @@ extern "C" int pga_score_connections(pga_ctx* c, int32_t n, const int32_t* ndx, 
         return fail(c, PGA_EINVAL, "pga_score_connections: NULL array");
     HIP_TRY(c, hipSetDevice(c->device));
     DevBuf db;
-    NodeArrays nd{};
+    struct { int32_t* ndx; int32_t* stop_val; uint8_t* type; int8_t* strand; double* cscore; double* sscore; double* rscore; double* uscore; int32_t* star_ptr; } nd{};
     DpBuffers buf{};
     ChainDesc* d_chain; ModelConst* d_mc;
     const size_t N = (size_t)n;
@@ -142,18 +142,19 @@ extern "C" int pga_score_connections(pga_ctx* c, int32_t n, const int32_t* ndx, 
     HIP_TRY(c, db.alloc(&nd.rscore, N)); HIP_TRY(c, db.alloc(&nd.uscore, N)); HIP_TRY(c, db.alloc(&nd.star_ptr, 3 * N));
     HIP_TRY(c, db.alloc(&buf.src, N)); HIP_TRY(c, db.alloc(&buf.tgt, N)); HIP_TRY(c, db.alloc(&buf.score, N));
     HIP_TRY(c, db.alloc(&buf.traceb, N)); HIP_TRY(c, db.alloc(&buf.tbn, N)); HIP_TRY(c, db.alloc(&buf.ov_mark, N));
-    HIP_TRY(c, db.alloc(&buf.max_index, 1)); HIP_TRY(c, db.alloc(&buf.max_score, 1));
+    HIP_TRY(c, db.alloc(&buf.max_index, 1)); HIP_TRY(c, db.alloc(&buf.max_score, 1)); HIP_TRY(c, db.alloc(&buf.ipath, 1));
     HIP_TRY(c, db.alloc(&d_chain, 1)); HIP_TRY(c, db.alloc(&d_mc, 1));
     hipStream_t st = c->stream;
 #define UP(dst, srcp, bytes) HIP_TRY(c, hipMemcpyAsync(dst, srcp, bytes, hipMemcpyHostToDevice, st))
     UP(nd.ndx, ndx, 4 * N); UP(nd.stop_val, stop_val, 4 * N); UP(nd.type, type, N); UP(nd.strand, strand, N);
     UP(nd.cscore, cscore, 8 * N); UP(nd.sscore, sscore, 8 * N); UP(nd.rscore, rscore, 8 * N); UP(nd.uscore, uscore, 8 * N);
     UP(nd.star_ptr, star_ptr, 12 * N);
-    ChainDesc ch{0, n, 0};
+    ChainDesc ch{0, 0, n, 0, 0, 1};
     ModelConst mc; pga_fill_model_const(&mc, st_wt);
     UP(d_chain, &ch, sizeof ch); UP(d_mc, &mc, sizeof mc);
 #undef UP
-    pga_launch_dp_prepare(d_chain, 1, n, nd, d_mc, buf, st);
+    NodeArrays na{nd.ndx, nd.stop_val, nd.type, nd.strand, nd.cscore, nd.sscore, nd.rscore, nd.uscore, nd.star_ptr};
+    pga_launch_dp_prepare(d_chain, 1, 0, n, na, d_mc, buf, st);
     HIP_TRY(c, hipEventRecord(c->ev0, st));
     pga_launch_dp(d_chain, 1, d_mc, buf, final, st);
     HIP_TRY(c, hipEventRecord(c->ev1, st));

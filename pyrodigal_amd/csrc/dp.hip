@@ -26,6 +26,7 @@
 // reference; (2 - d/60)*0.15*st_wt comes from a host-computed 61-entry table.
 
 #include "pga_internal.h"
+#include "dev_common.h"
 
 #include <limits.h>
 
@@ -55,43 +56,20 @@ __device__ __forceinline__ double igm_apart(int d, double negc, const double* s_
     return r;
 }
 
-// General _intergenic_mod_same (ref: _connection.h:52-78); a = n1, b = n2.
-__device__ double igm_same_dev(int a_ndx, int a_strand, double a_r, double a_u,
-                               int b_ndx, double b_r, double b_u, double st_wt, const double* igm_tab) {
-    int dist = abs(a_ndx - b_ndx);
-    bool ovl = a_ndx + 2 * a_strand >= b_ndx;
-    double r = 0.0;
-    if (a_ndx + 2 == b_ndx || a_ndx == b_ndx + 1) {
-        if (a_strand == 1) { if (b_r < 0) r -= b_r; if (b_u < 0) r -= b_u; }
-        else               { if (a_r < 0) r -= a_r; if (a_u < 0) r -= a_u; }
-    }
-    if (dist > 3 * PGA_OPER_DIST) r -= 0.15 * st_wt;
-    else if ((dist <= PGA_OPER_DIST && !ovl) || dist * 4 < PGA_OPER_DIST) r += igm_tab[dist];
-    return r;
-}
-
-__device__ __forceinline__ int find_chain(const ChainDesc* chains, int n_chains, int64_t g) {
-    int lo = 0, hi = n_chains - 1;
-    while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (chains[mid].off <= g) lo = mid; else hi = mid - 1;
-    }
-    return lo;
-}
-
 // One thread per node: build DpSrc / DpTgt (ref: lib.pyx:1126-1162 `_index`, 1221-1233 window,
 // and the n3 terms of _connection.h:166-176, 296-325, 345-356).
 __global__ void __launch_bounds__(256)
-k_dp_prepare(const ChainDesc* __restrict__ chains, int n_chains, int64_t total,
+k_dp_prepare(const ChainDesc* __restrict__ chains, int n_chains, int64_t node_begin, int64_t total,
              NodeArrays nd, const ModelConst* __restrict__ models, DpSrc* __restrict__ src, DpTgt* __restrict__ tgt) {
     int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
+    g += node_begin;
     const int c = find_chain(chains, n_chains, g);
-    const int64_t off = chains[c].off;
+    const int64_t off = chains[c].off, toff = chains[c].topo_off;
     const int i = (int)(g - off);
     const ModelConst* mc = &models[chains[c].model];
-    const int32_t* ndx = nd.ndx + off; const int32_t* stopv = nd.stop_val + off;
-    const uint8_t* type = nd.type + off; const int8_t* strand = nd.strand + off;
+    const int32_t* ndx = nd.ndx + toff; const int32_t* stopv = nd.stop_val + toff;
+    const uint8_t* type = nd.type + toff; const int8_t* strand = nd.strand + toff;
     const double* cs_c = nd.cscore + off; const double* cs_s = nd.sscore + off;
     const double* rsc = nd.rscore + off; const double* usc = nd.uscore + off;
     const int32_t* sp = nd.star_ptr + off * 3;
@@ -203,7 +181,7 @@ __device__ __forceinline__ void eval_source(const int j, const int s_ndx, const 
 __global__ void __launch_bounds__(64)
 k_dp_wave(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src, const DpTgt* __restrict__ g_tgt,
           const ModelConst* __restrict__ models, double* g_score, int32_t* g_traceb, int32_t* g_tbn, int8_t* g_ov,
-          int32_t* __restrict__ max_index, double* __restrict__ max_score) {
+          int32_t* __restrict__ max_index, double* __restrict__ max_score, int32_t* __restrict__ ipath) {
     __shared__ double s_igm[64];
     const ChainDesc cd = chains[blockIdx.x];
     const int lane = threadIdx.x;
@@ -217,7 +195,7 @@ k_dp_wave(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src,
     double* score = g_score + cd.off; int32_t* traceb = g_traceb + cd.off;
     int32_t* tbn = g_tbn + cd.off; int8_t* ovm = g_ov + cd.off;
 
-    double end_best = -1.0; int end_idx = -1;     // _find_max_index (ref: lib.pyx:1239-1251)
+    double end_best = -1.0; int end_idx = -1, end_tb = -1;     // _find_max_index (ref: lib.pyx:1239-1251)
 
     for (int i0 = 0; i0 < n; i0 += 64) {
         Target T;
@@ -272,7 +250,7 @@ k_dp_wave(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src,
         if (act) {
             score[T.i] = best; traceb[T.i] = tb; ovm[T.i] = (int8_t)ov;
             tbn[T.i] = tb < 0 ? -1 : src[tb].ndx;
-            if ((T.kind == 1 || T.kind == 2) && best >= end_best) { end_best = best; end_idx = T.i; }
+            if ((T.kind == 1 || T.kind == 2) && best >= end_best) { end_best = best; end_idx = T.i; end_tb = tb; }
         }
     }
     // highest score among gene-end nodes, ties to the largest index (the reference scans from the end with '>')
@@ -280,20 +258,24 @@ k_dp_wave(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src,
     for (int m = 32; m >= 1; m >>= 1) {
         const double ob = __shfl_xor(end_best, m, 64);
         const int oi = __shfl_xor(end_idx, m, 64);
-        if (ob > end_best || (ob == end_best && oi > end_idx)) { end_best = ob; end_idx = oi; }
+        const int ot = __shfl_xor(end_tb, m, 64);
+        if (ob > end_best || (ob == end_best && oi > end_idx)) { end_best = ob; end_idx = oi; end_tb = ot; }
     }
-    if (lane == 0) { max_index[blockIdx.x] = end_idx; max_score[blockIdx.x] = end_idx >= 0 ? end_best : 0.0; }
+    if (lane == 0) {
+        max_index[blockIdx.x] = end_idx; max_score[blockIdx.x] = end_idx >= 0 ? end_best : 0.0;
+        ipath[blockIdx.x] = (end_idx >= 0 && end_tb != -1) ? end_idx : -1;
+    }
 }
 
 }  // namespace
 
-void pga_launch_dp_prepare(const ChainDesc* d_chains, int n_chains, int64_t total_nodes,
+void pga_launch_dp_prepare(const ChainDesc* d_chains, int n_chains, int64_t node_begin, int64_t total_nodes,
                            const NodeArrays& nodes, const ModelConst* d_models, DpBuffers buf, hipStream_t st) {
     if (total_nodes <= 0) return;
     const int threads = 256;
     const int64_t blocks = (total_nodes + threads - 1) / threads;
     hipLaunchKernelGGL(k_dp_prepare, dim3((unsigned)blocks), dim3(threads), 0, st,
-                       d_chains, n_chains, total_nodes, nodes, d_models, buf.src, buf.tgt);
+                       d_chains, n_chains, node_begin, total_nodes, nodes, d_models, buf.src, buf.tgt);
 }
 
 void pga_launch_dp(const ChainDesc* d_chains, int n_chains, const ModelConst* d_models, DpBuffers buf,
@@ -302,5 +284,5 @@ void pga_launch_dp(const ChainDesc* d_chains, int n_chains, const ModelConst* d_
     if (n_chains <= 0) return;
     hipLaunchKernelGGL(k_dp_wave, dim3(n_chains), dim3(64), 0, st,
                        d_chains, buf.src, buf.tgt, d_models, buf.score, buf.traceb, buf.tbn, buf.ov_mark,
-                       buf.max_index, buf.max_score);
+                       buf.max_index, buf.max_score, buf.ipath);
 }

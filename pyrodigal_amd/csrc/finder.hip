@@ -1,13 +1,707 @@
-// Finder-level entry point (whole-batch GeneFinder.find_genes drop-in).  Placeholder until the
-// extraction / scoring kernels land: fails loudly instead of computing anything on the CPU.
+// Finder-level entry point: whole-batch drop-in for GeneFinder.find_genes() in meta or single
+// mode (ref: lib.pyx:5281-5469).  Host orchestration only; every per-base / per-node stage runs in
+// the HIP kernels of pipeline.hip and dp.hip.  The O(path) tail of the reference's
+// _dynamic_programming (traceback untangling), eliminate_bad_genes, Genes._extract and
+// Genes._tweak_final_starts runs here on the host over the winning model's nodes (SURVEY.md
+// section 2 #9: "host-side or tiny kernel"), one contig per worker thread.
 #include "pga_internal.h"
+#include "pipeline.h"
 
-void pga_finder_release(pga_ctx*) {}
-int pga_finder_models_changed(pga_ctx*) { return PGA_OK; }
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 
-extern "C" int pga_find_genes_batch(pga_ctx* c, int32_t, const char* const*, const int64_t*, const pga_params*, pga_result** out) {
-    if (out) *out = nullptr;
-    if (c) c->err = "pga_find_genes_batch: not implemented yet";
-    return PGA_EDEVICE;
+#include <algorithm>
+#include <atomic>
+#include <map>
+#include <new>
+#include <thread>
+
+namespace {
+
+struct Buf { void* p = nullptr; size_t cap = 0; };
+
+}  // namespace
+
+struct FinderState {
+    std::map<std::string, Buf> dev, pin;
+    std::vector<int> model_group;   // model -> translation-table group
+    std::vector<int> group_tt;
+    ModelScoreConst* d_msc = nullptr;
+    hipEvent_t e_start = nullptr, e_stop = nullptr, e_dp0[4] = {}, e_dp1[4] = {};
+};
+
+namespace {
+
+#define HT(ctx, expr) do { int rc__ = pga_hip_try_(ctx, (expr), #expr); if (rc__ != PGA_OK) return rc__; } while (0)
+
+int ensure_dev(pga_ctx* c, const char* name, size_t bytes, void** out) {
+    Buf& b = c->finder->dev[name];
+    if (b.cap < bytes || !b.p) {
+        if (b.p) { hipFree(b.p); b.p = nullptr; b.cap = 0; }
+        size_t want = bytes + bytes / 4 + 256;
+        HT(c, hipMalloc(&b.p, want));
+        b.cap = want;
+    }
+    *out = b.p;
+    return PGA_OK;
 }
-extern "C" void pga_result_free(pga_result*) {}
+int ensure_pin(pga_ctx* c, const char* name, size_t bytes, void** out) {
+    Buf& b = c->finder->pin[name];
+    if (b.cap < bytes || !b.p) {
+        if (b.p) { hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
+        size_t want = bytes + bytes / 4 + 256;
+        HT(c, hipHostMalloc(&b.p, want, hipHostMallocDefault));
+        b.cap = want;
+    }
+    *out = b.p;
+    return PGA_OK;
+}
+#define DEVBUF(var, type, name, count) type* var; { void* p__; int rc__ = ensure_dev(c, name, sizeof(type) * (size_t)(count) + 64, &p__); if (rc__) return rc__; var = (type*)p__; }
+#define PINBUF(var, type, name, count) type* var; { void* p__; int rc__ = ensure_pin(c, name, sizeof(type) * (size_t)(count) + 64, &p__); if (rc__) return rc__; var = (type*)p__; }
+
+// ---- host tail: nodes of one contig for its winning model ----------------------------------
+struct NodeView {
+    int n;
+    const int32_t* ndx; const int32_t* stop_val; const uint8_t* type; const int8_t* strand; const uint8_t* edge;
+    double* cscore; double* sscore; const double* rscore; const double* uscore; const double* tscore;
+    const int32_t* star_ptr; int32_t* traceb; int32_t* tracef; int8_t* ov_mark; const double* score; uint8_t* elim;
+};
+struct GeneRec { int begin, end, start_ndx, stop_ndx; };
+
+inline bool is_stop_n(const NodeView& v, int i) { return v.type[i] == PGA_T_STOP; }
+
+// ref: _connection.h:52-78
+double igm_same_h(const NodeView& v, int a, int b, double st_wt) {
+    const int dist = abs(v.ndx[a] - v.ndx[b]);
+    const bool ovl = v.ndx[a] + 2 * v.strand[a] >= v.ndx[b];
+    double r = 0.0;
+    if (v.ndx[a] + 2 == v.ndx[b] || v.ndx[a] == v.ndx[b] + 1) {
+        if (v.strand[a] == 1) { if (v.rscore[b] < 0) r -= v.rscore[b]; if (v.uscore[b] < 0) r -= v.uscore[b]; }
+        else                  { if (v.rscore[a] < 0) r -= v.rscore[a]; if (v.uscore[a] < 0) r -= v.uscore[a]; }
+    }
+    if (dist > 3 * PGA_OPER_DIST) r -= 0.15 * st_wt;
+    else if ((dist <= PGA_OPER_DIST && !ovl) || dist * 4 < PGA_OPER_DIST) r += (2.0 - (double)dist / PGA_OPER_DIST) * 0.15 * st_wt;
+    return r;
+}
+inline double igm_h(const NodeView& v, int a, int b, double st_wt) {   // ref: _connection.h:81-91
+    return v.strand[a] == v.strand[b] ? igm_same_h(v, a, b, st_wt) : -0.15 * st_wt;
+}
+
+// ref: lib.pyx:1253-1295 (_disentangle_overlaps, _max_forward_pointers)
+void untangle(NodeView& v, int mx) {
+    for (int p = mx; v.traceb[p] != -1; p = v.traceb[p]) {
+        const int nx = v.traceb[p];
+        if (v.strand[p] == -1 && is_stop_n(v, p) && v.strand[nx] == 1 && is_stop_n(v, nx) && v.ov_mark[p] != -1 && v.ndx[p] > v.ndx[nx]) {
+            const int tmp = v.star_ptr[3 * p + v.ov_mark[p]];
+            int k = tmp;
+            while (v.ndx[k] != v.stop_val[tmp]) k--;
+            v.traceb[p] = tmp; v.traceb[tmp] = k; v.ov_mark[k] = -1; v.traceb[k] = nx;
+        }
+    }
+    for (int p = mx; v.traceb[p] != -1; p = v.traceb[p]) {
+        const int nx = v.traceb[p];
+        const bool p_rb = v.strand[p] == -1 && !is_stop_n(v, p), p_fs = v.strand[p] == 1 && is_stop_n(v, p), p_rs = v.strand[p] == -1 && is_stop_n(v, p);
+        const bool n_fs = v.strand[nx] == 1 && is_stop_n(v, nx), n_rs = v.strand[nx] == -1 && is_stop_n(v, nx);
+        if (p_rb && n_fs) { int k = p; while (v.ndx[k] != v.stop_val[p]) k--; v.traceb[p] = k; v.traceb[k] = nx; }
+        if (p_fs && n_fs) { v.traceb[p] = v.star_ptr[3 * nx + v.ndx[p] % 3]; v.traceb[v.traceb[p]] = nx; }
+        if (p_rs && n_rs) { v.traceb[p] = v.star_ptr[3 * p + v.ndx[nx] % 3]; v.traceb[v.traceb[p]] = nx; }
+    }
+    for (int p = mx; v.traceb[p] != -1; p = v.traceb[p]) v.tracef[v.traceb[p]] = p;
+}
+
+// Prodigal dprog.c eliminate_bad_genes (call sites ref: lib.pyx:5308, 5369)
+void eliminate_bad_genes(NodeView& v, int ipath, double st_wt) {
+    if (ipath == -1) return;
+    int p = ipath;
+    while (v.traceb[p] != -1) p = v.traceb[p];
+    const int head = p;
+    for (; v.tracef[p] != -1; p = v.tracef[p]) {
+        const int f = v.tracef[p];
+        if (v.strand[p] == 1 && is_stop_n(v, p)) v.sscore[f] += igm_h(v, p, f, st_wt);
+        if (v.strand[p] == -1 && !is_stop_n(v, p)) v.sscore[p] += igm_h(v, p, f, st_wt);
+    }
+    for (p = head; v.tracef[p] != -1; p = v.tracef[p]) {
+        const int f = v.tracef[p];
+        if (v.strand[p] == 1 && !is_stop_n(v, p) && v.cscore[p] + v.sscore[p] < 0) { v.elim[p] = 1; v.elim[f] = 1; }
+        if (v.strand[p] == -1 && is_stop_n(v, p) && v.cscore[f] + v.sscore[f] < 0) { v.elim[p] = 1; v.elim[f] = 1; }
+    }
+}
+
+// ref: lib.pyx:3231-3270 (Genes._extract)
+void extract_genes(const NodeView& v, int ipath, std::vector<GeneRec>& out) {
+    out.clear();
+    if (ipath == -1) return;
+    int p = ipath, b = 0, e = 0, s = 0, t = 0;
+    while (v.traceb[p] != -1) p = v.traceb[p];
+    for (; p != -1; p = v.tracef[p]) {
+        if (v.elim[p] == 1) continue;
+        if (v.strand[p] == 1) {
+            if (!is_stop_n(v, p)) { b = v.ndx[p] + 1; s = p; }
+            else { e = v.ndx[p] + 3; t = p; out.push_back({b, e, s, t}); }
+        } else {
+            if (!is_stop_n(v, p)) { e = v.ndx[p] + 1; s = p; out.push_back({b, e, s, t}); }
+            else { b = v.ndx[p] - 1; t = p; }
+        }
+    }
+}
+
+// ref: lib.pyx:3272-3401 (Genes._tweak_final_starts)
+void tweak_final_starts(const NodeView& v, std::vector<GeneRec>& g, double w, int maxov) {
+    const int nn = v.n, ng = (int)g.size();
+    for (int i = 0; i < ng; i++) {
+        const int ndx = g[i].start_ndx;
+        const double sc = v.sscore[ndx] + v.cscore[ndx];
+        double ig = 0.0;
+        const bool prev_fwd = i > 0 && v.strand[g[i - 1].start_ndx] == 1, prev_rev = i > 0 && v.strand[g[i - 1].start_ndx] == -1;
+        const bool next_fwd = i < ng - 1 && v.strand[g[i + 1].start_ndx] == 1, next_rev = i < ng - 1 && v.strand[g[i + 1].start_ndx] == -1;
+        if (v.strand[ndx] == 1 && prev_fwd) ig = igm_same_h(v, g[i - 1].stop_ndx, ndx, w);
+        if (v.strand[ndx] == 1 && prev_rev) ig = -0.15 * w;
+        if (v.strand[ndx] == -1 && next_fwd) ig = -0.15 * w;
+        if (v.strand[ndx] == -1 && next_rev) ig = igm_same_h(v, ndx, g[i + 1].stop_ndx, w);
+        int mi[2] = {-1, -1}; double ms[2] = {0, 0}, mg[2] = {0, 0};
+        for (int j = ndx - 100; j < ndx + 100; j++) {
+            if (j < 0 || j >= nn || j == ndx) continue;
+            if (is_stop_n(v, j) || v.stop_val[j] != v.stop_val[ndx]) continue;
+            double tg = 0.0;
+            if (v.strand[j] == 1 && prev_fwd) {
+                if (v.ndx[g[i - 1].stop_ndx] - v.ndx[j] > maxov) continue;
+                tg = igm_same_h(v, g[i - 1].stop_ndx, j, w);
+            }
+            if (v.strand[j] == 1 && prev_rev) { if (v.ndx[g[i - 1].start_ndx] - v.ndx[j] >= 0) continue; tg = -0.15 * w; }
+            if (v.strand[j] == -1 && next_fwd) { if (v.ndx[j] - v.ndx[g[i + 1].start_ndx] >= 0) continue; tg = -0.15 * w; }
+            if (v.strand[j] == -1 && next_rev) {
+                if (v.ndx[j] - v.ndx[g[i + 1].stop_ndx] > maxov) continue;
+                tg = igm_same_h(v, j, g[i + 1].stop_ndx, w);
+            }
+            const double cs = v.cscore[j] + v.sscore[j];
+            if (mi[0] == -1) { mi[0] = j; ms[0] = cs; mg[0] = tg; }
+            else if (cs + tg > ms[0]) { mi[1] = mi[0]; ms[1] = ms[0]; mg[1] = mg[0]; mi[0] = j; ms[0] = cs; mg[0] = tg; }
+            else if (mi[1] == -1 || cs + tg > ms[1]) { mi[1] = j; ms[1] = cs; mg[1] = tg; }
+        }
+        for (int k = 0; k < 2; k++) {
+            const int m = mi[k];
+            if (m == -1) continue;
+            if (v.tscore[m] < v.tscore[ndx] && ms[k] - v.tscore[m] >= sc - v.tscore[ndx] + w && v.rscore[m] > v.rscore[ndx] &&
+                v.uscore[m] > v.uscore[ndx] && v.cscore[m] > v.cscore[ndx] && abs(v.ndx[m] - v.ndx[ndx]) > 15) {
+                ms[k] += v.tscore[ndx] - v.tscore[m];
+            } else if (abs(v.ndx[m] - v.ndx[ndx]) <= 15 && v.rscore[m] + v.tscore[m] > v.rscore[ndx] + v.tscore[ndx] &&
+                       v.edge[ndx] == 0 && v.edge[m] == 0) {
+                if (v.cscore[ndx] > v.cscore[m]) ms[k] += v.cscore[ndx] - v.cscore[m];
+                if (v.uscore[ndx] > v.uscore[m]) ms[k] += v.uscore[ndx] - v.uscore[m];
+                if (ig > mg[k]) ms[k] += ig - mg[k];
+            } else ms[k] = -1000.0;
+        }
+        int pick = -1;
+        for (int k = 0; k < 2; k++) {
+            if (mi[k] == -1) continue;
+            if (pick == -1 && ms[k] + mg[k] > sc + ig) pick = k;
+            else if (pick >= 0 && ms[k] + mg[k] > ms[pick] + mg[pick]) pick = k;
+        }
+        if (pick != -1 && v.strand[mi[pick]] == 1) { g[i].start_ndx = mi[pick]; g[i].begin = v.ndx[mi[pick]] + 1; }
+        else if (pick != -1 && v.strand[mi[pick]] == -1) { g[i].start_ndx = mi[pick]; g[i].end = v.ndx[mi[pick]] + 1; }
+    }
+}
+
+// ---- gather kernel: pack the winning chains' node fields contiguously for one D2H per field ----
+struct WinDesc {
+    int64_t out_off;     // first output node
+    int64_t dp_off;      // chain offset of the pass that won (scores as seen by the DP)
+    int64_t fin_off;     // chain offset of the fresh re-score (== dp_off when the winner was `first`)
+    int64_t topo_off;
+    int32_t n;
+    int32_t _pad;
+};
+struct OutArrays {
+    int32_t* ndx; int32_t* stop_val; uint8_t* type; int8_t* strand; float* gc_cont;
+    uint8_t* edge_dp; double* cscore_dp; double* sscore_dp; double* rscore_dp; double* uscore_dp; double* tscore_dp;
+    int32_t* star_ptr; int32_t* traceb; int8_t* ov_mark; double* score;
+    uint8_t* edge; double* cscore; double* sscore; double* rscore; double* uscore; double* tscore; double* mot_score;
+    int32_t* mot_ndx; uint8_t* rbs; uint8_t* mot_len; uint8_t* mot_spacer; uint8_t* mot_spacendx;
+};
+
+__global__ void __launch_bounds__(256)
+k_gather_winners(const WinDesc* __restrict__ wd, int n_win, int64_t out_begin, int64_t total, GroupArrays ga, ChainArrays ca,
+                 DpBuffers dp, OutArrays o) {
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    g += out_begin;
+    int lo = 0, hi = n_win - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (wd[mid].out_off <= g) lo = mid; else hi = mid - 1; }
+    const WinDesc w = wd[lo];
+    const int i = (int)(g - w.out_off);
+    const int64_t t = w.topo_off + i, a = w.dp_off + i, f = w.fin_off + i;
+    o.ndx[g] = ga.ndx[t]; o.stop_val[g] = ga.stop_val[t]; o.type[g] = ga.type[t]; o.strand[g] = ga.strand[t]; o.gc_cont[g] = ga.gc_cont[t];
+    o.edge_dp[g] = ca.edge[a]; o.cscore_dp[g] = ca.cscore[a]; o.sscore_dp[g] = ca.sscore[a]; o.rscore_dp[g] = ca.rscore[a];
+    o.uscore_dp[g] = ca.uscore[a]; o.tscore_dp[g] = ca.tscore[a];
+    o.star_ptr[3 * g] = ca.star_ptr[3 * a]; o.star_ptr[3 * g + 1] = ca.star_ptr[3 * a + 1]; o.star_ptr[3 * g + 2] = ca.star_ptr[3 * a + 2];
+    o.traceb[g] = dp.traceb[a]; o.ov_mark[g] = dp.ov_mark[a]; o.score[g] = dp.score[a];
+    o.edge[g] = ca.edge[f]; o.cscore[g] = ca.cscore[f]; o.sscore[g] = ca.sscore[f]; o.rscore[g] = ca.rscore[f];
+    o.uscore[g] = ca.uscore[f]; o.tscore[g] = ca.tscore[f]; o.mot_score[g] = ca.mot_score[f]; o.mot_ndx[g] = ca.mot_ndx[f];
+    o.rbs[2 * g] = ca.rbs[2 * f]; o.rbs[2 * g + 1] = ca.rbs[2 * f + 1];
+    o.mot_len[g] = ca.mot_len[f]; o.mot_spacer[g] = ca.mot_spacer[f]; o.mot_spacendx[g] = ca.mot_spacendx[f];
+}
+
+__global__ void k_contig_node_base(const ContigDesc* __restrict__ ct, int n_contigs, int64_t total, const int32_t* __restrict__ pre_nodes,
+                                   int32_t* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n_contigs) return;
+    out[c] = pre_nodes[c < n_contigs ? ct[c].base : total];
+}
+
+struct ResultOwner {
+    pga_result pub;
+    std::vector<pga_contig_result> contigs;
+    std::vector<pga_gene> genes;
+    std::vector<pga_nodes> nodes;
+    std::vector<void*> blocks;
+    ~ResultOwner() { for (void* b : blocks) free(b); }
+};
+
+void fill_model_score_const(ModelScoreConst* m, const pga_training* t) {   // ref: lib.pyx:2136-2147, 2209-2210
+    double no_stop;
+    if (t->trans_table != 11) {
+        no_stop = ((1 - t->gc) * (1 - t->gc) * t->gc) / 8.0;
+        no_stop += ((1 - t->gc) * (1 - t->gc) * (1 - t->gc)) / 8.0;
+    } else {
+        no_stop = ((1 - t->gc) * (1 - t->gc) * t->gc) / 4.0;
+        no_stop += ((1 - t->gc) * (1 - t->gc) * (1 - t->gc)) / 8.0;
+    }
+    no_stop = 1 - no_stop;
+    m->lfac_max = log((1 - pow(no_stop, 1000.0)) / pow(no_stop, 1000.0));
+    m->lfac_min = log((1 - pow(no_stop, 80)) / pow(no_stop, 80));
+    for (int n = 0; n <= 1000; n++) {
+        const double tmp = pow(no_stop, (double)n);
+        m->lfac_tab[n] = log((1 - tmp) / tmp) - m->lfac_min;
+    }
+}
+
+}  // namespace
+
+void pga_finder_release(pga_ctx* c) {
+    if (!c->finder) return;
+    for (auto& kv : c->finder->dev) if (kv.second.p) hipFree(kv.second.p);
+    for (auto& kv : c->finder->pin) if (kv.second.p) hipHostFree(kv.second.p);
+    if (c->finder->d_msc) hipFree(c->finder->d_msc);
+    if (c->finder->e_start) hipEventDestroy(c->finder->e_start);
+    if (c->finder->e_stop) hipEventDestroy(c->finder->e_stop);
+    for (int i = 0; i < 4; i++) { if (c->finder->e_dp0[i]) hipEventDestroy(c->finder->e_dp0[i]); if (c->finder->e_dp1[i]) hipEventDestroy(c->finder->e_dp1[i]); }
+    delete c->finder;
+    c->finder = nullptr;
+}
+
+int pga_finder_models_changed(pga_ctx* c) {
+    if (!c->finder) {
+        c->finder = new (std::nothrow) FinderState();
+        if (!c->finder) return PGA_ENOMEM;
+        HT(c, hipEventCreate(&c->finder->e_start)); HT(c, hipEventCreate(&c->finder->e_stop));
+        for (int i = 0; i < 4; i++) { HT(c, hipEventCreate(&c->finder->e_dp0[i])); HT(c, hipEventCreate(&c->finder->e_dp1[i])); }
+    }
+    FinderState* f = c->finder;
+    f->model_group.clear(); f->group_tt.clear();
+    if (f->d_msc) { hipFree(f->d_msc); f->d_msc = nullptr; }
+    const int nm = c->n_models;
+    if (nm == 0) return PGA_OK;
+    std::vector<ModelScoreConst> msc(nm);
+    for (int m = 0; m < nm; m++) {
+        const int tt = c->models[m].trans_table;
+        int g = -1;
+        for (size_t k = 0; k < f->group_tt.size(); k++) if (f->group_tt[k] == tt) g = (int)k;
+        if (g < 0) { g = (int)f->group_tt.size(); f->group_tt.push_back(tt); }
+        f->model_group.push_back(g);
+        fill_model_score_const(&msc[m], &c->models[m]);
+    }
+    if (f->group_tt.size() > 4) { c->err = "pga_set_models: more than 4 distinct translation tables"; return PGA_EINVAL; }
+    HT(c, hipMalloc((void**)&f->d_msc, sizeof(ModelScoreConst) * nm));
+    HT(c, hipMemcpy(f->d_msc, msc.data(), sizeof(ModelScoreConst) * nm, hipMemcpyHostToDevice));
+    return PGA_OK;
+}
+
+extern "C" void pga_result_free(pga_result* r) {
+    if (r) delete reinterpret_cast<ResultOwner*>(r);
+}
+
+extern "C" int pga_find_genes_batch(pga_ctx* c, int32_t n_contigs, const char* const* seqs, const int64_t* lens,
+                                    const pga_params* pp, pga_result** out) {
+    if (out) *out = nullptr;
+    if (!c || !out || !pp || n_contigs < 0 || (n_contigs > 0 && (!seqs || !lens))) {
+        if (c) c->err = "pga_find_genes_batch: bad arguments";
+        return PGA_EINVAL;
+    }
+    if (c->n_models <= 0 || !c->finder) { c->err = "pga_find_genes_batch: no model loaded (call pga_set_models first)"; return PGA_EINVAL; }
+    const pga_params P = *pp;
+    if (P.min_gene <= 0 || P.min_edge_gene <= 0 || P.max_overlap < 0 || P.max_overlap > P.min_gene) {
+        c->err = "pga_find_genes_batch: invalid min_gene / min_edge_gene / max_overlap";   // ref: lib.pyx:5169-5181
+        return PGA_EINVAL;
+    }
+    HT(c, hipSetDevice(c->device));
+    FinderState* f = c->finder;
+    hipStream_t st = c->stream;
+    const int NC = n_contigs, NM = c->n_models, NG = P.meta ? (int)f->group_tt.size() : 1;
+
+    ResultOwner* R = new (std::nothrow) ResultOwner();
+    if (!R) return PGA_ENOMEM;
+    struct Guard { ResultOwner* r; ~Guard() { delete r; } } guard{R};
+    R->contigs.assign(NC, pga_contig_result{-1, 0, 0, 0, 0, 0.0, 0.0});
+    memset(&R->pub, 0, sizeof R->pub);
+    R->pub.n_contigs = NC;
+
+    // ---- pack the batch ---------------------------------------------------------------------
+    std::vector<ContigDesc> ct(NC + 1);
+    int64_t total = 0;
+    for (int i = 0; i < NC; i++) {
+        if (lens[i] < 0 || lens[i] > 0x7fff0000LL || (lens[i] > 0 && !seqs[i])) { c->err = "pga_find_genes_batch: bad contig length"; return PGA_EINVAL; }
+        ct[i].base = total; ct[i].len = (int32_t)lens[i]; ct[i]._pad = 0;
+        total += lens[i];
+    }
+    ct[NC].base = total; ct[NC].len = 0; ct[NC]._pad = 0;
+    if (total >= 0x7fffffffLL) { c->err = "pga_find_genes_batch: batch larger than 2^31 bases; split it"; return PGA_EINVAL; }
+
+    if (NC > 0 && total > 0) {
+        PINBUF(h_seq, char, "h_seq", total + 16);
+        for (int i = 0; i < NC; i++) if (lens[i] > 0) memcpy(h_seq + ct[i].base, seqs[i], (size_t)lens[i]);
+        DEVBUF(d_seq, char, "d_seq", total + 16);
+        DEVBUF(d_dig, uint8_t, "d_dig", total + 16);
+        DEVBUF(d_ct, ContigDesc, "d_ct", NC + 1);
+        DEVBUF(d_cnt, int32_t, "d_cnt", 2 * (size_t)NC);
+        DEVBUF(d_pre_gc, int32_t, "d_pre_gc", total + 1);
+        const int64_t tiles = pga_scan_tiles(total);
+        DEVBUF(d_tile, int2, "d_tile", tiles);
+        DEVBUF(d_cbase, int32_t, "d_cbase", (size_t)NG * (NC + 1));
+        PINBUF(h_cnt, int32_t, "h_cnt", 2 * (size_t)NC);
+        PINBUF(h_cbase, int32_t, "h_cbase", (size_t)NG * (NC + 1));
+
+        GroupArrays ga[4];
+        for (int g = 0; g < NG; g++) {
+            char nm[32];
+#define GBUF(field, type, count) { snprintf(nm, sizeof nm, #field "%d", g); void* p__; int rc__ = ensure_dev(c, nm, sizeof(type) * (size_t)(count) + 64, &p__); if (rc__) return rc__; ga[g].field = (type*)p__; }
+            GBUF(nf_fwd, uint8_t, total + 1) GBUF(nf_rev, uint8_t, total + 1)
+            GBUF(tsv_fwd, int32_t, total + 1) GBUF(tsv_rev, int32_t, total + 1)
+            GBUF(tinfo_fwd, uint8_t, total + 1) GBUF(tinfo_rev, uint8_t, total + 1)
+            GBUF(pre_nodes, int32_t, total + 2)
+            ga[g].ndx = nullptr; ga[g].stop_val = nullptr; ga[g].type = nullptr; ga[g].strand = nullptr; ga[g].edge0 = nullptr; ga[g].gc_cont = nullptr;
+        }
+
+        HT(c, hipEventRecord(f->e_start, st));
+        HT(c, hipMemcpyAsync(d_seq, h_seq, (size_t)total, hipMemcpyHostToDevice, st));
+        HT(c, hipMemcpyAsync(d_ct, ct.data(), sizeof(ContigDesc) * (NC + 1), hipMemcpyHostToDevice, st));
+        HT(c, hipMemsetAsync(d_cnt, 0, sizeof(int32_t) * 2 * (size_t)NC, st));
+        pga_launch_digitize(d_seq, d_dig, total, d_ct, NC, d_cnt, d_cnt + NC, st);
+        for (int g = 0; g < NG; g++) {
+            const int tt = P.meta ? f->group_tt[g] : c->models[0].trans_table;
+            HT(c, hipMemsetAsync(ga[g].nf_fwd, 0, (size_t)total + 1, st));
+            HT(c, hipMemsetAsync(ga[g].nf_rev, 0, (size_t)total + 1, st));
+            pga_launch_extract(d_dig, total, d_ct, NC, tt, P, ga[g], d_tile, d_pre_gc, g == 0, st);
+            hipLaunchKernelGGL(k_contig_node_base, dim3((NC + 1 + 255) / 256), dim3(256), 0, st, d_ct, NC, total, ga[g].pre_nodes, d_cbase + (size_t)g * (NC + 1));
+        }
+        HT(c, hipMemcpyAsync(h_cnt, d_cnt, sizeof(int32_t) * 2 * (size_t)NC, hipMemcpyDeviceToHost, st));
+        HT(c, hipMemcpyAsync(h_cbase, d_cbase, sizeof(int32_t) * (size_t)NG * (NC + 1), hipMemcpyDeviceToHost, st));
+        HT(c, hipGetLastError());
+        HT(c, hipStreamSynchronize(st));
+
+        // ---- plan the (contig, model) chains (ref: lib.pyx:5335-5362) ------------------------
+        std::vector<std::vector<ChainDesc>> gch(NG);     // per group, in (contig, model) order
+        for (int i = 0; i < NC; i++) {
+            const int L = ct[i].len;
+            const double gc = L > 0 ? (double)h_cnt[i] / (double)L : 0.0;
+            R->contigs[i].gc = gc;
+            if (!P.meta) {
+                const int32_t* cb = h_cbase;
+                ChainDesc ch{0, cb[i], cb[i + 1] - cb[i], 0, i, 1};
+                gch[0].push_back(ch);
+                continue;
+            }
+            const double low = fmin(0.65, 0.88495 * gc - 0.0102337), high = fmax(0.35, 0.86596 * gc + 0.1131991);
+            int tt_prev = -1;
+            for (int m = 0; m < NM; m++) {
+                const pga_training& t = c->models[m];
+                if (t.gc < low || t.gc > high) continue;
+                const int g = f->model_group[m];
+                const int32_t* cb = h_cbase + (size_t)g * (NC + 1);
+                ChainDesc ch{0, cb[i], cb[i + 1] - cb[i], m, i, t.trans_table != tt_prev ? 1 : 0};
+                tt_prev = t.trans_table;
+                gch[g].push_back(ch);
+            }
+        }
+        std::vector<ChainDesc> chains;
+        std::vector<int> g_c0(NG + 1, 0);
+        std::vector<int64_t> g_n0(NG + 1, 0);
+        int64_t tot_chain_nodes = 0;
+        for (int g = 0; g < NG; g++) {
+            g_c0[g] = (int)chains.size(); g_n0[g] = tot_chain_nodes;
+            for (ChainDesc ch : gch[g]) { ch.off = tot_chain_nodes; tot_chain_nodes += ch.n; chains.push_back(ch); }
+        }
+        g_c0[NG] = (int)chains.size(); g_n0[NG] = tot_chain_nodes;
+        const int NCH = (int)chains.size();
+        R->pub.node_passes = tot_chain_nodes;
+        // space for the fresh re-scores of winners that were not `first` (at most one per contig)
+        int64_t max_rescore = 0;
+        if (P.meta) for (int g = 0; g < NG; g++) max_rescore += h_cbase[(size_t)g * (NC + 1) + NC];   // loose bound: every node once per group
+        const int64_t chain_cap = tot_chain_nodes + max_rescore + 64;
+
+        // ---- topology + chain buffers ----------------------------------------------------------
+        int64_t group_nodes[4] = {0, 0, 0, 0};
+        for (int g = 0; g < NG; g++) {
+            char nm[32];
+            group_nodes[g] = h_cbase[(size_t)g * (NC + 1) + NC];
+            const int64_t n = group_nodes[g] + 1;
+            GBUF(ndx, int32_t, n) GBUF(stop_val, int32_t, n) GBUF(type, uint8_t, n) GBUF(strand, int8_t, n) GBUF(edge0, uint8_t, n) GBUF(gc_cont, float, n)
+        }
+        ChainArrays ca;
+        {
+            DEVBUF(a0, double, "ca_cscore", chain_cap) DEVBUF(a1, double, "ca_sscore", chain_cap) DEVBUF(a2, double, "ca_rscore", chain_cap)
+            DEVBUF(a3, double, "ca_uscore", chain_cap) DEVBUF(a4, double, "ca_tscore", chain_cap) DEVBUF(a5, double, "ca_mot_score", chain_cap)
+            DEVBUF(a6, int32_t, "ca_star_ptr", 3 * chain_cap) DEVBUF(a7, int32_t, "ca_mot_ndx", chain_cap) DEVBUF(a8, uint8_t, "ca_rbs", 2 * chain_cap)
+            DEVBUF(a9, uint8_t, "ca_edge", chain_cap) DEVBUF(a10, uint8_t, "ca_mot_len", chain_cap) DEVBUF(a11, uint8_t, "ca_mot_spacer", chain_cap)
+            DEVBUF(a12, uint8_t, "ca_mot_spacendx", chain_cap)
+            ca = ChainArrays{a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12};
+        }
+        DpBuffers dp;
+        {
+            DEVBUF(b0, DpSrc, "dp_src", tot_chain_nodes + 1) DEVBUF(b1, DpTgt, "dp_tgt", tot_chain_nodes + 1)
+            DEVBUF(b2, double, "dp_score", tot_chain_nodes + 1) DEVBUF(b3, int32_t, "dp_traceb", tot_chain_nodes + 1)
+            DEVBUF(b4, int32_t, "dp_tbn", tot_chain_nodes + 1) DEVBUF(b5, int8_t, "dp_ov", tot_chain_nodes + 1)
+            DEVBUF(b6, int32_t, "dp_maxidx", NCH + 1) DEVBUF(b7, double, "dp_maxscore", NCH + 1) DEVBUF(b8, int32_t, "dp_ipath", NCH + 1)
+            dp = DpBuffers{b0, b1, b2, b3, b4, b5, b6, b7, b8};
+        }
+        DEVBUF(d_chains, ChainDesc, "d_chains", NCH + NC + 1);
+        PINBUF(h_maxidx, int32_t, "h_maxidx", NCH + 1);
+        PINBUF(h_ipath, int32_t, "h_ipath", NCH + 1);
+        PINBUF(h_maxscore, double, "h_maxscore", NCH + 1);
+        HT(c, hipMemcpyAsync(d_chains, chains.data(), sizeof(ChainDesc) * NCH, hipMemcpyHostToDevice, st));
+
+        const ScoreParams sp{P.closed, P.meta, P.max_overlap, 0};
+        const pga_training* d_models = (const pga_training*)c->d_models_raw;
+        for (int g = 0; g < NG; g++) {
+            pga_launch_compact(total, d_ct, NC, ga[g], st);
+            pga_launch_orf_gc(d_ct, NC, d_pre_gc, ga[g], (int)group_nodes[g], d_cbase + (size_t)g * (NC + 1), st);
+            const int nch = g_c0[g + 1] - g_c0[g];
+            const int64_t nn = g_n0[g + 1] - g_n0[g];
+            if (nch == 0 || nn == 0) continue;
+            pga_launch_score(d_chains + g_c0[g], nch, g_n0[g], nn, d_dig, d_ct, ga[g], d_models, f->d_msc, c->d_model_const, ca, sp, st);
+            NodeArrays na{ga[g].ndx, ga[g].stop_val, ga[g].type, ga[g].strand, ca.cscore, ca.sscore, ca.rscore, ca.uscore, ca.star_ptr};
+            pga_launch_dp_prepare(d_chains + g_c0[g], nch, g_n0[g], nn, na, c->d_model_const, dp, st);
+            DpBuffers dg = dp; dg.max_index += g_c0[g]; dg.max_score += g_c0[g]; dg.ipath += g_c0[g];
+            HT(c, hipEventRecord(f->e_dp0[g], st));
+            pga_launch_dp(d_chains + g_c0[g], nch, c->d_model_const, dg, 1, st);
+            HT(c, hipEventRecord(f->e_dp1[g], st));
+        }
+        HT(c, hipMemcpyAsync(h_maxidx, dp.max_index, sizeof(int32_t) * NCH, hipMemcpyDeviceToHost, st));
+        HT(c, hipMemcpyAsync(h_ipath, dp.ipath, sizeof(int32_t) * NCH, hipMemcpyDeviceToHost, st));
+        HT(c, hipMemcpyAsync(h_maxscore, dp.max_score, sizeof(double) * NCH, hipMemcpyDeviceToHost, st));
+        HT(c, hipGetLastError());
+        HT(c, hipStreamSynchronize(st));
+        for (int g = 0; g < NG; g++) {
+            if (g_c0[g + 1] - g_c0[g] == 0 || g_n0[g + 1] - g_n0[g] == 0) continue;
+            float ms = 0; HT(c, hipEventElapsedTime(&ms, f->e_dp0[g], f->e_dp1[g])); R->pub.t_dp_ms += ms;
+        }
+
+        // ---- pick the winning model per contig (ref: lib.pyx:5364-5367, strict '>' from -100) ---
+        std::vector<int> win_chain(NC, -1);
+        {
+            // chains of a contig sit in several groups; visit them in model order
+            std::vector<std::vector<int>> per_contig(NC);
+            for (int k = 0; k < NCH; k++) per_contig[chains[k].contig].push_back(k);
+            for (int i = 0; i < NC; i++) {
+                auto& v = per_contig[i];
+                std::sort(v.begin(), v.end(), [&](int a, int b) { return chains[a].model < chains[b].model; });
+                if (!P.meta) { if (!v.empty()) win_chain[i] = v[0]; continue; }
+                double best = -100.0;
+                for (int k : v) {
+                    if (chains[k].n > 0 && h_ipath[k] >= 0 && h_maxscore[k] > best) { best = h_maxscore[k]; win_chain[i] = k; }
+                }
+            }
+        }
+        // ---- fresh re-score of winners that were not the first model of their group (ref: lib.pyx:5380-5394)
+        std::vector<ChainDesc> rescore;
+        std::vector<std::vector<ChainDesc>> rs_g(NG);
+        std::vector<int64_t> fin_off(NC, -1);
+        int64_t rs_nodes = 0;
+        for (int i = 0; i < NC; i++) {
+            const int k = win_chain[i];
+            if (k < 0) continue;
+            if (!P.meta || chains[k].first) { fin_off[i] = chains[k].off; continue; }
+            ChainDesc ch = chains[k]; ch.first = 1;
+            rs_g[f->model_group[ch.model]].push_back(ch);
+        }
+        std::vector<int> r_c0(NG + 1, 0); std::vector<int64_t> r_n0(NG + 1, 0);
+        for (int g = 0; g < NG; g++) {
+            r_c0[g] = (int)rescore.size(); r_n0[g] = tot_chain_nodes + rs_nodes;
+            for (ChainDesc ch : rs_g[g]) { ch.off = tot_chain_nodes + rs_nodes; fin_off[ch.contig] = ch.off; rs_nodes += ch.n; rescore.push_back(ch); }
+        }
+        r_c0[NG] = (int)rescore.size(); r_n0[NG] = tot_chain_nodes + rs_nodes;
+        if (!rescore.empty()) {
+            HT(c, hipMemcpyAsync(d_chains + NCH, rescore.data(), sizeof(ChainDesc) * rescore.size(), hipMemcpyHostToDevice, st));
+            for (int g = 0; g < NG; g++) {
+                const int nch = r_c0[g + 1] - r_c0[g]; const int64_t nn = r_n0[g + 1] - r_n0[g];
+                if (nch == 0 || nn == 0) continue;
+                pga_launch_score(d_chains + NCH + r_c0[g], nch, r_n0[g], nn, d_dig, d_ct, ga[g], d_models, f->d_msc, c->d_model_const, ca, sp, st);
+            }
+        }
+        // ---- gather the winners and bring them home ------------------------------------------------
+        std::vector<std::vector<WinDesc>> wg(NG);
+        std::vector<int64_t> out_off(NC, 0);
+        int64_t out_nodes = 0;
+        std::vector<int64_t> w_o0(NG + 1, 0);
+        // output order: group-major then contig, so each group's launch covers a contiguous output range
+        for (int g = 0; g < NG; g++) {
+            w_o0[g] = out_nodes;
+            for (int i = 0; i < NC; i++) {
+                const int k = win_chain[i];
+                if (k < 0 || (P.meta ? f->model_group[chains[k].model] : 0) != g) continue;
+                out_off[i] = out_nodes;
+                wg[g].push_back(WinDesc{out_nodes, chains[k].off, fin_off[i], chains[k].topo_off, chains[k].n, 0});
+                out_nodes += chains[k].n;
+            }
+        }
+        w_o0[NG] = out_nodes;
+        OutArrays o, h;
+        {
+            const int64_t n = out_nodes + 1;
+#define OB(field, type, mult) { void* p__; int rc__ = ensure_dev(c, "o_" #field, sizeof(type) * (size_t)(mult) * n + 64, &p__); if (rc__) return rc__; o.field = (type*)p__; \
+                                rc__ = ensure_pin(c, "h_" #field, sizeof(type) * (size_t)(mult) * n + 64, &p__); if (rc__) return rc__; h.field = (type*)p__; }
+            OB(ndx, int32_t, 1) OB(stop_val, int32_t, 1) OB(type, uint8_t, 1) OB(strand, int8_t, 1) OB(gc_cont, float, 1)
+            OB(edge_dp, uint8_t, 1) OB(cscore_dp, double, 1) OB(sscore_dp, double, 1) OB(rscore_dp, double, 1) OB(uscore_dp, double, 1) OB(tscore_dp, double, 1)
+            OB(star_ptr, int32_t, 3) OB(traceb, int32_t, 1) OB(ov_mark, int8_t, 1) OB(score, double, 1)
+            OB(edge, uint8_t, 1) OB(cscore, double, 1) OB(sscore, double, 1) OB(rscore, double, 1) OB(uscore, double, 1) OB(tscore, double, 1) OB(mot_score, double, 1)
+            OB(mot_ndx, int32_t, 1) OB(rbs, uint8_t, 2) OB(mot_len, uint8_t, 1) OB(mot_spacer, uint8_t, 1) OB(mot_spacendx, uint8_t, 1)
+        }
+        size_t nwin = 0; for (int g = 0; g < NG; g++) nwin += wg[g].size();
+        DEVBUF(d_win, WinDesc, "d_win", nwin + 1);
+        {
+            size_t k0 = 0;
+            for (int g = 0; g < NG; g++) {
+                if (wg[g].empty()) continue;
+                HT(c, hipMemcpyAsync(d_win + k0, wg[g].data(), sizeof(WinDesc) * wg[g].size(), hipMemcpyHostToDevice, st));
+                const int64_t nn = w_o0[g + 1] - w_o0[g];
+                if (nn > 0)
+                    hipLaunchKernelGGL(k_gather_winners, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, d_win + k0, (int)wg[g].size(), w_o0[g], nn, ga[g], ca, dp, o);
+                k0 += wg[g].size();
+            }
+        }
+        if (out_nodes > 0) {
+            const size_t n = (size_t)out_nodes;
+#define DL(field, type, mult) HT(c, hipMemcpyAsync(h.field, o.field, sizeof(type) * (size_t)(mult) * n, hipMemcpyDeviceToHost, st));
+            DL(ndx, int32_t, 1) DL(stop_val, int32_t, 1) DL(type, uint8_t, 1) DL(strand, int8_t, 1) DL(gc_cont, float, 1)
+            DL(edge_dp, uint8_t, 1) DL(cscore_dp, double, 1) DL(sscore_dp, double, 1) DL(rscore_dp, double, 1) DL(uscore_dp, double, 1) DL(tscore_dp, double, 1)
+            DL(star_ptr, int32_t, 3) DL(traceb, int32_t, 1) DL(ov_mark, int8_t, 1) DL(score, double, 1)
+            DL(edge, uint8_t, 1) DL(cscore, double, 1) DL(sscore, double, 1) DL(rscore, double, 1) DL(uscore, double, 1) DL(tscore, double, 1) DL(mot_score, double, 1)
+            DL(mot_ndx, int32_t, 1) DL(rbs, uint8_t, 2) DL(mot_len, uint8_t, 1) DL(mot_spacer, uint8_t, 1) DL(mot_spacendx, uint8_t, 1)
+        }
+        HT(c, hipEventRecord(f->e_stop, st));
+        HT(c, hipGetLastError());
+        HT(c, hipStreamSynchronize(st));
+        { float ms = 0; HT(c, hipEventElapsedTime(&ms, f->e_start, f->e_stop)); R->pub.t_total_ms = ms; }
+
+        // ---- host tail per contig ------------------------------------------------------------------
+        std::vector<int32_t> tracef((size_t)out_nodes + 1, -1);
+        std::vector<uint8_t> elim((size_t)out_nodes + 1, 0);
+        std::vector<std::vector<GeneRec>> cg(NC);
+        std::atomic<int> next(0);
+        auto worker = [&]() {
+            for (;;) {
+                const int i = next.fetch_add(1);
+                if (i >= NC) break;
+                const int k = win_chain[i];
+                if (k < 0) continue;
+                const int64_t oo = out_off[i];
+                NodeView v{chains[k].n, h.ndx + oo, h.stop_val + oo, h.type + oo, h.strand + oo, h.edge_dp + oo,
+                           h.cscore_dp + oo, h.sscore_dp + oo, h.rscore_dp + oo, h.uscore_dp + oo, h.tscore_dp + oo,
+                           h.star_ptr + 3 * oo, h.traceb + oo, tracef.data() + oo, h.ov_mark + oo, h.score + oo, elim.data() + oo};
+                const int mx = h_maxidx[k];
+                int ipath = -1;
+                if (v.n > 0 && mx >= 0) { untangle(v, mx); ipath = v.traceb[mx] == -1 ? -1 : mx; }
+                const double st_wt = c->models[chains[k].model].st_wt;
+                if (v.n > 0) eliminate_bad_genes(v, ipath, st_wt);
+                extract_genes(v, ipath, cg[i]);
+                tweak_final_starts(v, cg[i], st_wt, P.max_overlap);
+            }
+        };
+        {
+            int nt = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+            if (NC < 4) nt = 1;
+            std::vector<std::thread> th;
+            for (int t = 1; t < nt; t++) th.emplace_back(worker);
+            worker();
+            for (auto& t : th) t.join();
+        }
+        // ---- results -----------------------------------------------------------------------------------
+        int64_t ngenes = 0;
+        for (int i = 0; i < NC; i++) ngenes += (int64_t)cg[i].size();
+        R->genes.resize((size_t)ngenes);
+        int64_t gi = 0;
+        for (int i = 0; i < NC; i++) {
+            pga_contig_result& cr = R->contigs[i];
+            const int k = win_chain[i];
+            cr.gene_begin = gi; cr.n_genes = (int32_t)cg[i].size();
+            if (k < 0) { cr.model = -1; continue; }
+            cr.model = chains[k].model; cr.n_nodes = chains[k].n;
+            cr.score = P.meta ? 0.0 : (h_ipath[k] >= 0 ? h_maxscore[k] : 0.0);
+            const int64_t oo = out_off[i];
+            const bool single = !P.meta;
+            for (const GeneRec& gr : cg[i]) {
+                pga_gene& G = R->genes[(size_t)gi++];
+                memset(&G, 0, sizeof G);
+                const int64_t s = oo + gr.start_ndx, e = oo + gr.stop_ndx;
+                G.contig = i; G.begin = gr.begin; G.end = gr.end; G.start_ndx = gr.start_ndx; G.stop_ndx = gr.stop_ndx;
+                G.strand = h.strand[s];
+                const uint8_t se = single ? h.edge_dp[s] : h.edge[s], ee = single ? h.edge_dp[e] : h.edge[e];
+                G.partial_begin = G.strand == 1 ? se : ee; G.partial_end = G.strand == 1 ? ee : se;
+                G.start_type = se ? 3 : h.type[s];
+                G.rbs[0] = h.rbs[2 * s]; G.rbs[1] = h.rbs[2 * s + 1];
+                G.mot_len = h.mot_len[s]; G.mot_spacer = h.mot_spacer[s]; G.mot_ndx = h.mot_ndx[s]; G.mot_score = h.mot_score[s];
+                G.gc_cont = h.gc_cont[s];
+                G.cscore = single ? h.cscore_dp[s] : h.cscore[s]; G.sscore = single ? h.sscore_dp[s] : h.sscore[s];
+                G.rscore = single ? h.rscore_dp[s] : h.rscore[s]; G.uscore = single ? h.uscore_dp[s] : h.uscore[s];
+                G.tscore = single ? h.tscore_dp[s] : h.tscore[s];
+            }
+        }
+        if (P.want_nodes) {
+            R->nodes.resize(NC);
+            for (int i = 0; i < NC; i++) {
+                pga_nodes& N = R->nodes[i];
+                memset(&N, 0, sizeof N);
+                const int k = win_chain[i];
+                if (k < 0) continue;
+                const int n = chains[k].n; const int64_t oo = out_off[i];
+                const bool single = !P.meta;
+                N.n = n;
+                const size_t bytes = (size_t)n * (4 * 8 + 10 + 4 + 8 * 7) + 8 * 32;   // 8 int32, 10 bytes, 1 float, 7 doubles per node + padding
+                char* blk = (char*)calloc(1, bytes);
+                if (!blk) return PGA_ENOMEM;
+                R->blocks.push_back(blk);
+                char* q = blk;
+                auto take = [&](size_t b) { char* r = q; q += (b + 7) & ~(size_t)7; return (void*)r; };
+                N.ndx = (int32_t*)take(4 * n); N.stop_val = (int32_t*)take(4 * n); N.traceb = (int32_t*)take(4 * n); N.tracef = (int32_t*)take(4 * n);
+                N.star_ptr = (int32_t*)take(12 * n); N.mot_ndx = (int32_t*)take(4 * n);
+                N.type = (uint8_t*)take(n); N.edge = (uint8_t*)take(n); N.elim = (uint8_t*)take(n); N.rbs = (uint8_t*)take(2 * n);
+                N.strand = (int8_t*)take(n); N.ov_mark = (int8_t*)take(n); N.mot_len = (uint8_t*)take(n); N.mot_spacer = (uint8_t*)take(n); N.mot_spacendx = (uint8_t*)take(n);
+                N.gc_cont = (float*)take(4 * n);
+                N.cscore = (double*)take(8 * n); N.sscore = (double*)take(8 * n); N.rscore = (double*)take(8 * n); N.uscore = (double*)take(8 * n);
+                N.tscore = (double*)take(8 * n); N.score = (double*)take(8 * n); N.mot_score = (double*)take(8 * n);
+                memcpy(N.ndx, h.ndx + oo, 4 * n); memcpy(N.stop_val, h.stop_val + oo, 4 * n); memcpy(N.type, h.type + oo, n); memcpy(N.strand, h.strand + oo, n);
+                memcpy(N.gc_cont, h.gc_cont + oo, 4 * n); memcpy(N.rbs, h.rbs + 2 * oo, 2 * n); memcpy(N.mot_ndx, h.mot_ndx + oo, 4 * n);
+                memcpy(N.mot_len, h.mot_len + oo, n); memcpy(N.mot_spacer, h.mot_spacer + oo, n); memcpy(N.mot_spacendx, h.mot_spacendx + oo, n);
+                memcpy(N.mot_score, h.mot_score + oo, 8 * n);
+                if (single) {   // nodes as left by the DP + eliminate_bad_genes (ref: lib.pyx:5296-5311)
+                    memcpy(N.edge, h.edge_dp + oo, n); memcpy(N.cscore, h.cscore_dp + oo, 8 * n); memcpy(N.sscore, h.sscore_dp + oo, 8 * n);
+                    memcpy(N.rscore, h.rscore_dp + oo, 8 * n); memcpy(N.uscore, h.uscore_dp + oo, 8 * n); memcpy(N.tscore, h.tscore_dp + oo, 8 * n);
+                    memcpy(N.score, h.score + oo, 8 * n); memcpy(N.traceb, h.traceb + oo, 4 * n); memcpy(N.tracef, tracef.data() + oo, 4 * n);
+                    memcpy(N.ov_mark, h.ov_mark + oo, n); memcpy(N.elim, elim.data() + oo, n); memcpy(N.star_ptr, h.star_ptr + 3 * oo, 12 * n);
+                } else {        // fresh re-score, DP fields reset (ref: lib.pyx:5380-5394)
+                    memcpy(N.edge, h.edge + oo, n); memcpy(N.cscore, h.cscore + oo, 8 * n); memcpy(N.sscore, h.sscore + oo, 8 * n);
+                    memcpy(N.rscore, h.rscore + oo, 8 * n); memcpy(N.uscore, h.uscore + oo, 8 * n); memcpy(N.tscore, h.tscore + oo, 8 * n);
+                    for (int j = 0; j < n; j++) { N.traceb[j] = -1; N.tracef[j] = -1; N.ov_mark[j] = -1; }
+                }
+            }
+        }
+    }
+    R->pub.contigs = R->contigs.data();
+    R->pub.genes = R->genes.data();
+    R->pub.n_genes = (int64_t)R->genes.size();
+    R->pub.nodes = P.want_nodes && !R->nodes.empty() ? R->nodes.data() : nullptr;
+    guard.r = nullptr;
+    *out = &R->pub;
+    return PGA_OK;
+}

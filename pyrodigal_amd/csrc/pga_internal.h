@@ -43,32 +43,41 @@ struct ModelConst {
 };
 // One DP chain = one (contig, model) pass.
 struct ChainDesc {
-    int64_t off;        // element offset of the chain's nodes in the per-batch arrays
-    int32_t n;
+    int64_t off;        // first element of the chain in the per-chain arrays (scores, DP records)
+    int64_t topo_off;   // first element of the contig's nodes in the topology arrays of its group
+    int32_t n;          // node count
     int32_t model;
+    int32_t contig;
+    int32_t first;      // 1: first model scored after (re-)extraction (edge flags not yet converted;
+                        //    ref: lib.pyx:2424-2434 mutates node.edge, which persists to the next bin)
 };
 
 // Node fields in device memory (struct of arrays; each pointer covers the whole batch).
 struct NodeArrays {
-    int32_t* ndx; int32_t* stop_val; uint8_t* type; int8_t* strand; uint8_t* edge;
-    double* cscore; double* sscore; double* rscore; double* uscore; double* tscore;
-    int32_t* star_ptr;   // [n][3]
+    const int32_t* ndx; const int32_t* stop_val; const uint8_t* type; const int8_t* strand;   // indexed by topo_off + i
+    const double* cscore; const double* sscore; const double* rscore; const double* uscore;   // indexed by off + i
+    const int32_t* star_ptr;   // [n][3], indexed by off + i
 };
 
 struct DpBuffers {
     DpSrc* src; DpTgt* tgt;
     double* score; int32_t* traceb; int32_t* tbn; int8_t* ov_mark;
-    int32_t* max_index; double* max_score;    // per chain
+    int32_t* max_index; double* max_score;    // per chain: _find_max_index and its score
+    int32_t* ipath;                           // per chain: max_index, or -1 when that node has no traceb (ref: lib.pyx:1311)
 };
 
 // kernel launchers (dp.hip)
-void pga_launch_dp_prepare(const ChainDesc* d_chains, int n_chains, int64_t total_nodes,
+// chains[0..n_chains) must be contiguous in `off`; node_begin = chains[0].off, total_nodes = their node count
+void pga_launch_dp_prepare(const ChainDesc* d_chains, int n_chains, int64_t node_begin, int64_t total_nodes,
                            const NodeArrays& nodes, const ModelConst* d_models, DpBuffers buf, hipStream_t st);
 void pga_launch_dp(const ChainDesc* d_chains, int n_chains, const ModelConst* d_models, DpBuffers buf,
                    int final, hipStream_t st);
 
+struct FinderState;   // finder.hip
+
 struct pga_ctx {
     int device = 0;
+    FinderState* finder = nullptr;
     std::string err;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -1,0 +1,57 @@
+// Device-side data layout of the finder pipeline (see DESIGN.md "Data layout in HBM").
+#pragma once
+#include "pga_internal.h"
+
+// One contig of the batch: `len` bases starting at byte `base` of the concatenated batch buffers.
+struct ContigDesc {
+    int64_t base;
+    int32_t len;
+    int32_t _pad;
+};
+
+// Per translation-table group: per-position scratch of the extraction and the node topology
+// (fields that do not depend on the model), indexed by global node number.
+struct GroupArrays {
+    // per position (whole batch)
+    uint8_t* nf_fwd;  uint8_t* nf_rev;       // 1 = a forward / reverse node has its ndx here
+    int32_t* tsv_fwd; int32_t* tsv_rev;      // stop_val of that node
+    uint8_t* tinfo_fwd; uint8_t* tinfo_rev;  // type | edge << 2
+    int32_t* pre_nodes;                      // [total+1] exclusive prefix of nf_fwd + nf_rev
+    // per node, in (contig, ndx, strand) order
+    int32_t* ndx; int32_t* stop_val; uint8_t* type; int8_t* strand; uint8_t* edge0; float* gc_cont;
+};
+
+// Per (contig, model) chain node fields (SoA over all chains of the batch).
+struct ChainArrays {
+    double* cscore; double* sscore; double* rscore; double* uscore; double* tscore; double* mot_score;
+    int32_t* star_ptr;     // [n][3]
+    int32_t* mot_ndx;
+    uint8_t* rbs;          // [n][2]
+    uint8_t* edge;         // edge flag after Nodes._score's conversion
+    uint8_t* mot_len; uint8_t* mot_spacer; uint8_t* mot_spacendx;
+};
+
+// Host-computed per-model constants of the node scorer (libm log/pow stay on the host).
+struct ModelScoreConst {
+    double lfac_min, lfac_max;          // ref: lib.pyx:2146-2147
+    double lfac_tab[1001];              // log((1-p^n)/p^n) - lfac_min for n = 0..1000 codons (ref: lib.pyx:2209-2210)
+};
+
+struct ScoreParams {
+    int32_t closed, is_meta, max_overlap, _pad;
+};
+
+void pga_launch_digitize(const char* d_seq, uint8_t* d_dig, int64_t total, const ContigDesc* d_ct, int n_contigs,
+                         int32_t* d_gc, int32_t* d_unk, hipStream_t st);
+void pga_launch_extract(const uint8_t* d_dig, int64_t total, const ContigDesc* d_ct, int n_contigs, int tt,
+                        const pga_params& p, const GroupArrays& ga, int2* d_tile_sum, int32_t* d_pre_gc, int write_gc,
+                        hipStream_t st);
+void pga_launch_compact(int64_t total, const ContigDesc* d_ct, int n_contigs, const GroupArrays& ga, hipStream_t st);
+void pga_launch_orf_gc(const ContigDesc* d_ct, int n_contigs, const int32_t* d_pre_gc, const GroupArrays& ga,
+                       int n_nodes_total, const int32_t* d_node_contig_base, hipStream_t st);
+// chains[0..n_chains): the chains of ONE translation-table group, contiguous in `off` from node_begin
+void pga_launch_score(const ChainDesc* d_chains, int n_chains, int64_t node_begin, int64_t total, const uint8_t* d_dig,
+                      const ContigDesc* d_ct, const GroupArrays& ga, const pga_training* d_models,
+                      const ModelScoreConst* d_msc, const ModelConst* d_mc, const ChainArrays& ca, ScoreParams sp,
+                      hipStream_t st);
+int64_t pga_scan_tiles(int64_t total);

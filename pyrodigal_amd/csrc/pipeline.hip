@@ -1,0 +1,651 @@
+// Sequence digitising, node extraction (Prodigal add_nodes) and node scoring (score_nodes,
+// record_overlapping_starts) kernels for gfx950.  All "ref:" citations are relative to
+// /root/reference/src/pyrodigal.
+//
+// Parallel decomposition (the reference is a chain of sequential scans):
+//   * extraction: an ORF (the codons between two in-frame stops) is independent of every other
+//     ORF.  Each stop codon (plus three virtual stops at the sequence end) "owns" the ORF to its
+//     left in the scan direction and walks it once, applying the per-frame state machine of
+//     Nodes._extract to that ORF alone.  Nodes are flagged per position; an exclusive prefix sum
+//     over the flags gives every node its index in (ndx, strand) order directly -- no sort.
+//   * coding score: the hexamer log-odds sum is an ordered floating-point sum from the stop
+//     outwards, so one thread per stop node walks its ORF and adds in the reference's order.
+//   * everything else (RBS / motif search, upstream composition, start scoring, overlapping
+//     starts) is one thread per node.
+// These kernels are byte/integer work with a few ordered f64 sums: no MFMA, coalesced reads of
+// the 1-byte digit array, per-node SoA writes.
+
+#include "pga_internal.h"
+#include "pipeline.h"
+#include "dev_common.h"
+
+namespace {
+
+enum { NA = 0, NG = 1, NC = 2, NT = 3, NN = 6 };   // ref: _sequence.h:8-14
+
+__device__ __forceinline__ int find_contig(const ContigDesc* __restrict__ ct, int n, int64_t g) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (ct[mid].base <= g) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
+// strand-local base i of a contig (reverse strand is virtual; ref: _sequence.h:45-55)
+__device__ __forceinline__ int sbase(const uint8_t* __restrict__ d, int L, int i, int strand) {
+    return strand == 1 ? d[i] : (d[L - 1 - i] ^ 3);
+}
+__device__ __forceinline__ int comp2(int d) { return d <= 3 ? (d ^ 3) : NN; }
+__device__ __forceinline__ int is_gc_n(int d) { return d != NA && d != NT; }   // ref: _sequence.h:35-43
+
+// ref: _sequence.h:117-157
+__device__ __forceinline__ bool codon_is_stop(int x0, int x1, int x2, int tt) {
+    if (x0 != NT) {
+        if (tt == 2) return x0 == NA && x1 == NG && (x2 == NA || x2 == NG);
+        return false;
+    }
+    // sets of translation tables in which TAA / TAG / TGA terminate
+    const unsigned long long taa = (1ULL<<1)|(1ULL<<2)|(1ULL<<3)|(1ULL<<4)|(1ULL<<5)|(1ULL<<9)|(1ULL<<10)|(1ULL<<11)|(1ULL<<12)|(1ULL<<13)
+                                 | (1ULL<<15)|(1ULL<<16)|(1ULL<<21)|(1ULL<<22)|(1ULL<<23)|(1ULL<<24)|(1ULL<<25)|(1ULL<<26)|(1ULL<<32);
+    const unsigned long long tag = (1ULL<<1)|(1ULL<<2)|(1ULL<<3)|(1ULL<<4)|(1ULL<<5)|(1ULL<<9)|(1ULL<<10)|(1ULL<<11)|(1ULL<<12)|(1ULL<<13)
+                                 | (1ULL<<14)|(1ULL<<21)|(1ULL<<23)|(1ULL<<24)|(1ULL<<25)|(1ULL<<26)|(1ULL<<33);
+    const unsigned long long tga = (1ULL<<1)|(1ULL<<6)|(1ULL<<11)|(1ULL<<12)|(1ULL<<15)|(1ULL<<16)|(1ULL<<22)|(1ULL<<23)|(1ULL<<26)
+                                 | (1ULL<<29)|(1ULL<<30)|(1ULL<<32);
+    if (x1 == NA && x2 == NG) return (tag >> tt) & 1;
+    if (x1 == NG && x2 == NA) return (tga >> tt) & 1;
+    if (x1 == NA && x2 == NA) return (taa >> tt) & 1;
+    if (tt == 22) return x1 == NC && x2 == NA;
+    if (tt == 23) return x1 == NT && x2 == NA;
+    return false;
+}
+// ref: _sequence.h:45-73
+__device__ __forceinline__ bool codon_is_start(int x0, int x1, int x2, int tt) {
+    if (x1 != NT || x2 != NG) return false;
+    if (x0 == NA) return true;
+    if (tt == 6 || tt == 10 || tt == 14 || tt == 15 || tt == 16 || tt == 2) return false;
+    if (x0 == NG) return !(tt == 1 || tt == 3 || tt == 12 || tt == 2);
+    if (x0 == NT) return !(tt < 4 || tt == 9 || (tt >= 21 && tt < 25));
+    return false;
+}
+__device__ __forceinline__ bool is_stop_at(const uint8_t* __restrict__ d, int L, int i, int strand, int tt) {
+    return codon_is_stop(sbase(d, L, i, strand), sbase(d, L, i + 1, strand), sbase(d, L, i + 2, strand), tt);
+}
+
+// ---------------------------------------------------------------------------------- digitise
+// ref: lib.pyx:664-697 (Sequence._build)
+__global__ void __launch_bounds__(256)
+k_digitize(const char* __restrict__ seq, uint8_t* __restrict__ dig, int64_t total,
+           const ContigDesc* __restrict__ ct, int n_contigs, int32_t* __restrict__ gc_count, int32_t* __restrict__ unk_count) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = g < total;
+    int c = 0, isgc = 0, isunk = 0;
+    if (in) {
+        c = find_contig(ct, n_contigs, g);
+        int d;
+        switch (seq[g]) {
+            case 'A': case 'a': d = NA; break;
+            case 'T': case 't': d = NT; break;
+            case 'G': case 'g': d = NG; isgc = 1; break;
+            case 'C': case 'c': d = NC; isgc = 1; break;
+            default: d = NN; isunk = 1;
+        }
+        dig[g] = (uint8_t)d;
+    }
+    // wave-level counting: one atomic per wave when all its lanes sit in one contig
+    const int c0 = __builtin_amdgcn_readfirstlane(c);
+    const bool uniform = __all(!in || c == c0);
+    if (uniform) {
+        const unsigned long long mg = __ballot(in && isgc), mu = __ballot(in && isunk);
+        if ((threadIdx.x & 63) == 0) {
+            if (mg) atomicAdd(&gc_count[c0], __popcll(mg));
+            if (mu) atomicAdd(&unk_count[c0], __popcll(mu));
+        }
+    } else if (in) {
+        if (isgc) atomicAdd(&gc_count[c], 1);
+        if (isunk) atomicAdd(&unk_count[c], 1);
+    }
+}
+
+// ------------------------------------------------------------------------- node extraction
+// One thread per (position, strand).  A thread that sits on a stop codon -- or on one of the three
+// virtual right ends of an open contig -- owns the ORF to its left and replays the reference's
+// per-frame automaton on it.   ref: lib.pyx:1905-2117 (Nodes._extract)
+__global__ void __launch_bounds__(256)
+k_extract_orfs(const uint8_t* __restrict__ dig, int64_t total, const ContigDesc* __restrict__ ct, int n_contigs,
+               int tt, int closed, int min_gene, int min_edge_gene, GroupArrays ga) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= 2 * total) return;
+    const int strand = gid < total ? 1 : -1;
+    const int64_t g = gid < total ? gid : gid - total;
+    const int c = find_contig(ct, n_contigs, g);
+    const int L = ct[c].len;
+    const int64_t base = ct[c].base;
+    const uint8_t* __restrict__ d = dig + base;
+    const int p = (int)(g - base);           // strand-local codon position
+    if (L < 3 || p > L - 3) return;
+    const bool real_stop = is_stop_at(d, L, p, strand, tt);
+    // virtual right end of frame p%3 in open mode: the last full codon position of the frame
+    const bool virt = !real_stop && !closed && p + 3 > L - 3;
+    if (!real_stop && !virt) return;
+    const int last = p;
+    const int mind = real_stop ? min_gene : min_edge_gene;
+    uint8_t* __restrict__ nf = strand == 1 ? ga.nf_fwd : ga.nf_rev;
+    int32_t* __restrict__ tsv = strand == 1 ? ga.tsv_fwd : ga.tsv_rev;
+    uint8_t* __restrict__ tinfo = strand == 1 ? ga.tinfo_fwd : ga.tinfo_rev;
+    bool saw = false;
+    int left_stop = -1;                        // position of the in-frame stop that ends the walk
+    // a real stop is not a start candidate itself; a virtual end is (ref: the scan visits i == last)
+    for (int i = real_stop ? p - 3 : p; i >= 0; i -= 3) {
+        const int x0 = sbase(d, L, i, strand), x1 = sbase(d, L, i + 1, strand), x2 = sbase(d, L, i + 2, strand);
+        if (codon_is_stop(x0, x1, x2, tt)) { left_stop = i; break; }
+        int type = -1, edge = 0;
+        if (last - i + 3 >= mind && codon_is_start(x0, x1, x2, tt)) type = x0 == NA ? 0 : (x0 == NT ? 2 : 1);
+        else if (i <= 2 && !closed && last - i > min_edge_gene) { type = 0; edge = 1; }
+        if (type < 0) continue;
+        saw = true;
+        const int pos = strand == 1 ? i : L - 1 - i;                 // node ndx on forward coordinates
+        nf[base + pos] = 1;
+        tsv[base + pos] = strand == 1 ? last : L - 1 - last;         // stop_val of a start = ndx of its stop
+        tinfo[base + pos] = (uint8_t)(type | (edge << 2));
+    }
+    if (saw) {
+        const int pos = strand == 1 ? last : L - 1 - last;
+        const int fr = p % 3;
+        int sv;
+        if (strand == 1) sv = left_stop >= 0 ? left_stop : fr - 6;
+        else sv = left_stop >= 0 ? L - 1 - left_stop : L - fr + 5;
+        nf[base + pos] = 1;
+        tsv[base + pos] = sv;
+        tinfo[base + pos] = (uint8_t)(PGA_T_STOP | ((real_stop ? 0 : 1) << 2));
+    }
+}
+
+// --------------------------------------------------------------------------- prefix sums
+// Exclusive scan of (node count, GC-or-unknown count) per position over the whole batch.
+// 3 passes: per-block totals, scan of block totals (single block), final write.
+constexpr int SCAN_TILE = 2048;   // positions per block (256 threads x 8)
+
+__device__ __forceinline__ void tile_counts(const uint8_t* __restrict__ nf_fwd, const uint8_t* __restrict__ nf_rev,
+                                            const uint8_t* __restrict__ dig, int64_t start, int64_t total,
+                                            int cn[8], int cg[8]) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int64_t g = start + k;
+        if (g < total) { cn[k] = nf_fwd[g] + nf_rev[g]; cg[k] = is_gc_n(dig[g]); }
+        else { cn[k] = 0; cg[k] = 0; }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_scan_tiles(const uint8_t* __restrict__ nf_fwd, const uint8_t* __restrict__ nf_rev, const uint8_t* __restrict__ dig,
+             int64_t total, int2* __restrict__ tile_sum) {
+    __shared__ int2 s_w[4];
+    int cn[8], cg[8];
+    tile_counts(nf_fwd, nf_rev, dig, (int64_t)blockIdx.x * SCAN_TILE + threadIdx.x * 8, total, cn, cg);
+    int a = 0, b = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { a += cn[k]; b += cg[k]; }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = make_int2(a, b);
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = make_int2(s_w[0].x + s_w[1].x + s_w[2].x + s_w[3].x, s_w[0].y + s_w[1].y + s_w[2].y + s_w[3].y);
+}
+
+__global__ void __launch_bounds__(1024)
+k_scan_tile_sums(int2* __restrict__ tile_sum, int n_tiles) {
+    __shared__ int2 s_part[1024];
+    __shared__ int2 s_carry;
+    if (threadIdx.x == 0) s_carry = make_int2(0, 0);
+    __syncthreads();
+    for (int base = 0; base < n_tiles; base += 1024) {
+        const int i = base + threadIdx.x;
+        int2 v = i < n_tiles ? tile_sum[i] : make_int2(0, 0);
+        s_part[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            int2 t = make_int2(0, 0);
+            if ((int)threadIdx.x >= off) t = s_part[threadIdx.x - off];
+            __syncthreads();
+            s_part[threadIdx.x].x += t.x; s_part[threadIdx.x].y += t.y;
+            __syncthreads();
+        }
+        const int2 incl = s_part[threadIdx.x], carry = s_carry;
+        if (i < n_tiles) tile_sum[i] = make_int2(carry.x + incl.x - v.x, carry.y + incl.y - v.y);   // exclusive
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = make_int2(carry.x + incl.x, carry.y + incl.y);
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_scan_final(const uint8_t* __restrict__ nf_fwd, const uint8_t* __restrict__ nf_rev, const uint8_t* __restrict__ dig,
+             int64_t total, const int2* __restrict__ tile_sum, int32_t* __restrict__ pre_nodes, int32_t* __restrict__ pre_gc,
+             int write_gc) {
+    __shared__ int2 s_w[4];
+    int cn[8], cg[8];
+    const int64_t start = (int64_t)blockIdx.x * SCAN_TILE + threadIdx.x * 8;
+    tile_counts(nf_fwd, nf_rev, dig, start, total, cn, cg);
+    int a = 0, b = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { a += cn[k]; b += cg[k]; }
+    // inclusive scan of the per-thread sums across the wave, then across the 4 waves
+    int ia = a, ib = b;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int ta = __shfl_up(ia, off, 64), tb = __shfl_up(ib, off, 64);
+        if (lane >= off) { ia += ta; ib += tb; }
+    }
+    if (lane == 63) s_w[w] = make_int2(ia, ib);
+    __syncthreads();
+    int ca = tile_sum[blockIdx.x].x, cb = tile_sum[blockIdx.x].y;
+    for (int k = 0; k < w; k++) { ca += s_w[k].x; cb += s_w[k].y; }
+    int ra = ca + ia - a, rb = cb + ib - b;     // exclusive prefix at this thread's first position
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int64_t g = start + k;
+        if (g <= total) { pre_nodes[g] = ra; if (write_gc) pre_gc[g] = rb; }
+        ra += cn[k]; rb += cg[k];
+    }
+}
+
+// ------------------------------------------------------------------------- compaction
+// Writes the topology arrays in (ndx, strand) order; forward sorts before reverse at equal ndx
+// (Prodigal compare_nodes; ref: lib.pyx:2489-2493).
+__global__ void __launch_bounds__(256)
+k_compact_nodes(int64_t total, const ContigDesc* __restrict__ ct, int n_contigs, GroupArrays ga) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const int f = ga.nf_fwd[g], r = ga.nf_rev[g];
+    if (!(f | r)) return;
+    const int c = find_contig(ct, n_contigs, g);
+    const int pos = (int)(g - ct[c].base);
+    const int idx = ga.pre_nodes[g];
+    if (f) {
+        const int info = ga.tinfo_fwd[g];
+        ga.ndx[idx] = pos; ga.stop_val[idx] = ga.tsv_fwd[g]; ga.type[idx] = info & 3; ga.strand[idx] = 1; ga.edge0[idx] = (info >> 2) & 1;
+    }
+    if (r) {
+        const int info = ga.tinfo_rev[g], k = idx + f;
+        ga.ndx[k] = pos; ga.stop_val[k] = ga.tsv_rev[g]; ga.type[k] = info & 3; ga.strand[k] = -1; ga.edge0[k] = (info >> 2) & 1;
+    }
+}
+
+// ------------------------------------------------------------------------- ORF GC content
+// ref: lib.pyx:1846-1896 (Nodes._calc_orf_gc).  The reference accumulates integer counts along
+// the ORF; with a prefix count of GC-or-unknown bases every start reads its count in O(1).
+// The reverse strand keeps the reference's shifted range (codons counted at j..j+2).
+__global__ void __launch_bounds__(256)
+k_orf_gc(const ContigDesc* __restrict__ ct, int n_contigs, const int32_t* __restrict__ pre_gc, GroupArrays ga, int n_nodes_total,
+         const int32_t* __restrict__ node_contig_base /* per contig: first node idx */) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes_total) return;
+    if (ga.type[i] == PGA_T_STOP) { ga.gc_cont[i] = 0.f; return; }
+    // contig of this node: binary search on first-node offsets
+    int lo = 0, hi = n_contigs - 1;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (node_contig_base[mid] <= i) lo = mid; else hi = mid - 1; }
+    const int L = ct[lo].len;
+    const int32_t* __restrict__ P = pre_gc + ct[lo].base;
+    const int ndx = ga.ndx[i], sv = ga.stop_val[i];
+    int cnt;
+    if (ga.strand[i] == 1) {
+        cnt = P[sv + 3] - P[ndx];
+    } else {
+        const int hi2 = min(ndx + 2, L - 1);
+        cnt = (P[sv + 1] - P[sv - 2]) + (hi2 >= sv + 3 ? P[hi2 + 1] - P[sv + 3] : 0);
+    }
+    const double gsize = abs(sv - ndx) + 3.0;
+    ga.gc_cont[i] = (float)((double)cnt / gsize);
+}
+
+// -------------------------------------------------------------------------- coding score
+// One thread per stop node: pass 1 walks the ORF from the stop outwards adding gene_dc[hexamer]
+// in the reference's order; passes 2 and 3 revisit the ORF's starts from the outermost one
+// inwards.   ref: lib.pyx:2119-2239 (Nodes._raw_coding_score)
+__device__ __forceinline__ int hexamer(const uint8_t* __restrict__ d, int pos, int strand) {
+    int v = 0;   // ref: _sequence.h:207-220; pos = forward coordinate of the first base read
+    if (strand == 1) { for (int j = 0; j < 6; j++) v |= (d[pos + j] & 3) << (2 * j); }
+    else             { for (int j = 0; j < 6; j++) v |= (comp2(d[pos - j]) & 3) << (2 * j); }
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+k_coding_score(const ChainDesc* __restrict__ chains, int n_chains, int64_t node_begin, int64_t total,
+               const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct, GroupArrays ga,
+               const pga_training* __restrict__ models, const ModelScoreConst* __restrict__ msc, ChainArrays ca) {
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    g += node_begin;
+    const int c = find_chain(chains, n_chains, g);
+    const ChainDesc ch = chains[c];
+    const int64_t t = ch.topo_off + (g - ch.off);
+    if (ga.type[t] != PGA_T_STOP) return;
+    const ContigDesc cd = ct[ch.contig];
+    const uint8_t* __restrict__ d = dig + cd.base;
+    const int strand = ga.strand[t];
+    const uint8_t* __restrict__ nf = (strand == 1 ? ga.nf_fwd : ga.nf_rev) + cd.base;
+    const uint8_t* __restrict__ nf_f = ga.nf_fwd + cd.base;
+    const int32_t* __restrict__ pre = ga.pre_nodes + cd.base;
+    const double* __restrict__ gene_dc = models[ch.model].gene_dc;
+    const ModelScoreConst* __restrict__ mc = &msc[ch.model];
+    double* __restrict__ cscore = ca.cscore + ch.off;
+    const int64_t tbase = ch.topo_off;
+    const int p = ga.ndx[t], q = ga.stop_val[t], L = cd.len;
+    const int step = strand == 1 ? -3 : 3;
+    double sum = 0.0; int far = p;
+    for (int j = p + step; strand == 1 ? (j >= 0 && j > q) : (j <= L - 1 && j < q); j += step) {
+        sum += gene_dc[hexamer(d, j, strand)];
+        if (nf[j]) { cscore[(int)(pre[j] + (strand == 1 ? 0 : nf_f[j]) - tbase)] = sum; far = j; }
+    }
+    if (far == p) return;
+    double run_c = -10000.0, run_l = -10000.0;
+    for (int j = far; j != p; j -= step) {
+        if (!nf[j]) continue;
+        const int k = (int)(pre[j] + (strand == 1 ? 0 : nf_f[j]) - tbase);
+        double cs = cscore[k];
+        if (cs > run_c) run_c = cs; else cs -= (run_c - cs);
+        const int ncod = (abs(p - j) + 3) / 3;
+        const double gsize = (double)ncod;
+        double lfac;
+        if (gsize > 1000.0) lfac = (mc->lfac_max - mc->lfac_min) * (gsize - 80) / 920.0;
+        else lfac = mc->lfac_tab[ncod];
+        if (lfac > run_l) run_l = lfac; else lfac -= fmax(fmin(run_l - lfac, lfac), 0.0);
+        if (lfac > 3.0 && cs < 0.5 * lfac) cs = 0.5 * lfac;
+        cs += lfac;
+        cscore[k] = cs;
+    }
+}
+
+// ---------------------------------------------------------------- ribosome binding site search
+// ref: lib.pyx:791-881 (exact) / 883-979 (one mismatch); mm selects the variant.  As in the
+// reference the mismatch variant keeps the previous cur_val when no table row matches.
+__device__ int shine_dalgarno(const uint8_t* __restrict__ d, int L, int pos, int start, const double* __restrict__ w, int strand, int mm) {
+    int match[6], limit, maxv = 0, cur = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) match[i] = -10;
+    limit = min(6, start - 4 - pos);
+    for (int i = 0; i < limit; i++) {
+        const bool in = pos + i >= 0 && pos + i < L;
+        const int b = in ? sbase(d, L, pos + i, strand) : -1;
+        if (!mm) {
+            if (!in) continue;
+            if (i % 3 == 0) { if (b == NA) match[i] = 2; } else { if (b == NG) match[i] = 3; }
+        } else {
+            if (i % 3 == 0) match[i] = (b == NA) ? 2 : -3; else match[i] = (b == NG) ? 3 : -2;
+        }
+    }
+    for (int i = limit; i > (mm ? 4 : 2); i--) {
+        for (int j = 0; j < limit + 1 - i; j++) {
+            int ctr = -2, mism = 0, flag;
+            for (int k = j; k < j + i; k++) {
+                ctr += match[k];
+                if (mm && match[k] < 0) { mism++; if (k <= j + 1 || k >= j + i - 2) ctr -= 10; }
+            }
+            if (mm ? (mism != 1 || ctr < 6) : (ctr < 6)) continue;
+            const int rdis = start - (pos + j + i);
+            if (!mm) {
+                if (rdis < 5) flag = i < 5 ? 2 : 1;
+                else if (rdis < 11) flag = 0;
+                else if (rdis < 13) flag = i < 5 ? 1 : 2;
+                else if (rdis < 16) flag = 3;
+                else continue;
+                // rows: GGA, AGGA, GGAG, AGGAG, GGAGG, AGGAGG by distance class
+                switch (ctr) {
+                    case 6:  cur = flag == 0 ? 13 : flag == 1 ? 6 : flag == 2 ? 1 : 2; break;
+                    case 8:  cur = flag == 0 ? 15 : flag == 1 ? 12 : flag == 2 ? 11 : 3; break;
+                    case 9:  cur = flag == 0 ? 16 : flag == 1 ? 12 : flag == 2 ? 11 : 3; break;
+                    case 11: cur = flag == 0 ? 22 : flag == 1 ? 21 : flag == 2 ? 20 : 10; break;
+                    case 12: cur = flag == 0 ? 24 : flag == 1 ? 23 : flag == 2 ? 20 : 10; break;
+                    case 14: cur = flag == 0 ? 27 : flag == 1 ? 26 : flag == 2 ? 25 : 10; break;
+                    default: cur = 0;
+                }
+            } else {
+                if (rdis < 5) flag = 1;
+                else if (rdis < 11) flag = 0;
+                else if (rdis < 13) flag = 2;
+                else if (rdis < 16) flag = 3;
+                else continue;
+                switch (ctr) {
+                    case 6: cur = flag == 0 ? 9 : flag == 1 ? 5 : flag == 2 ? 4 : 2; break;
+                    case 7: cur = flag == 0 ? 14 : flag == 1 ? 8 : flag == 2 ? 7 : 2; break;
+                    case 9: cur = flag == 0 ? 19 : flag == 1 ? 18 : flag == 2 ? 17 : 3; break;
+                    default: break;
+                }
+            }
+            if (w[cur] < w[maxv]) continue;
+            if (w[cur] == w[maxv] && cur < maxv) continue;
+            maxv = cur;
+        }
+    }
+    return maxv;
+}
+
+// k-mer index at strand-local position i (ref: _sequence.h:207-220)
+__device__ __forceinline__ int mer_local(const uint8_t* __restrict__ d, int L, int i, int len, int strand) {
+    int v = 0;
+    if (strand == 1) { for (int j = 0; j < len; j++) v |= (d[i + j] & 3) << (2 * j); }
+    else { const int k = L - 1 - i; for (int j = 0; j < len; j++) v |= (comp2(d[k - j]) & 3) << (2 * j); }
+    return v;
+}
+
+// ------------------------------------------------------------------------- start scoring
+// One thread per chain node.  ref: lib.pyx:2331-2487 (Nodes._score), 2241-2277 (_rbs_score),
+// 1556-1616 (_find_best_upstream_motif, stage 2), 1618-1650 (_score_upstream_composition).
+// The reference mutates node.edge while it scans (lib.pyx:2424-2434) and the flag survives into
+// the next model of a meta run; `first` and the index comparisons below reproduce the value each
+// read would have seen.
+__global__ void __launch_bounds__(256)
+k_score_starts(const ChainDesc* __restrict__ chains, int n_chains, int64_t node_begin, int64_t total,
+               const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct, GroupArrays ga,
+               const pga_training* __restrict__ models, ChainArrays ca, ScoreParams sp) {
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    g += node_begin;
+    const int c = find_chain(chains, n_chains, g);
+    const ChainDesc ch = chains[c];
+    const int i = (int)(g - ch.off), n = ch.n;
+    const int64_t tb = ch.topo_off;
+    const int type = ga.type[tb + i];
+    const int e0 = ga.edge0[tb + i];
+    if (type == PGA_T_STOP) {      // stop nodes carry no start scores (reset_node_scores)
+        ca.edge[g] = (uint8_t)e0;
+        ca.cscore[g] = 0.0; ca.sscore[g] = 0.0; ca.rscore[g] = 0.0; ca.uscore[g] = 0.0; ca.tscore[g] = 0.0; ca.mot_score[g] = 0.0;
+        ca.mot_ndx[g] = 0; ca.mot_len[g] = 0; ca.mot_spacer[g] = 0; ca.mot_spacendx[g] = 0; ca.rbs[2 * g] = 0; ca.rbs[2 * g + 1] = 0;
+        return;
+    }
+    const ContigDesc cd = ct[ch.contig];
+    const int L = cd.len;
+    const uint8_t* __restrict__ d = dig + cd.base;
+    const pga_training* __restrict__ tm = &models[ch.model];
+    const double st_wt = tm->st_wt;
+    const int tt = tm->trans_table;
+    const int ndx = ga.ndx[tb + i], sv = ga.stop_val[tb + i], strand = ga.strand[tb + i];
+    const bool closed = sp.closed != 0, is_meta = sp.is_meta != 0;
+    auto convertible = [&](int k) -> bool {
+        if (closed || ga.type[tb + k] == PGA_T_STOP || ga.edge0[tb + k]) return false;
+        const int x = ga.ndx[tb + k], s = ga.strand[tb + k];
+        return (x <= 2 && s == 1) || (x >= L - 3 && s == -1);
+    };
+    const bool conv = convertible(i);
+    const bool edge_in = e0 || (conv && !ch.first);
+
+    int rbs0 = 0, rbs1 = 0, m_ndx = 0, m_len = 0, m_sp = 0, m_si = 0;
+    double m_score = 0.0;
+    const int start = strand == 1 ? ndx : L - 1 - ndx;     // strand-local start position
+    if (!edge_in) {
+        if (tm->uses_sd) {
+            for (int j = start - 20; j < start - 5; j++) {
+                if (strand == 1 ? j < 0 : j >= L) continue;
+                const int a = shine_dalgarno(d, L, j, start, tm->rbs_wt, strand, 0);
+                const int b = shine_dalgarno(d, L, j, start, tm->rbs_wt, strand, 1);
+                if (a > rbs0) rbs0 = a;
+                if (b > rbs1) rbs1 = b;
+            }
+        } else {
+            double bsc = -100.0; int bsp = 0, bsi = 0, blen = 0, bndx = 0;
+            for (int k = 3; k >= 0; k--) {
+                for (int j = start - 18 - k; j < start - 5 - k; j++) {
+                    if (j < 0) continue;
+                    int si;
+                    if (j <= start - 16 - k) si = 3; else if (j <= start - 14 - k) si = 2; else if (j >= start - 7 - k) si = 1; else si = 0;
+                    const int idx = mer_local(d, L, j, k + 3, strand);
+                    const double s = tm->mot_wt[k][si][idx];
+                    if (s > bsc) { bsc = s; bsi = si; bsp = start - j - k - 3; bndx = idx; blen = k + 3; }
+                }
+            }
+            if (bsc == -4.0 || bsc < tm->no_mot + 0.69) { m_score = tm->no_mot; }
+            else { m_ndx = bndx; m_len = blen; m_si = bsi; m_sp = bsp & 15; m_score = bsc; }
+        }
+    }
+
+    const long orf = ndx > sv ? ndx - sv : sv - ndx;
+    double edge_gene = 0;
+    if (edge_in) edge_gene += 1;
+    if ((strand == 1 && !is_stop_at(d, L, sv, 1, tt)) || (strand == -1 && !is_stop_at(d, L, L - 1 - sv, -1, tt))) edge_gene += 1;
+
+    double tscore, uscore, rscore, sscore, cscore = ca.cscore[g];
+    if (edge_in) {
+        tscore = 0.74 * st_wt / edge_gene; uscore = 0.0; rscore = 0.0;
+    } else {
+        tscore = tm->type_wt[type] * st_wt;
+        const double r1 = tm->rbs_wt[rbs0], r2 = tm->rbs_wt[rbs1];
+        const double sd = fmax(r1, r2) * st_wt;
+        if (tm->uses_sd) rscore = sd;
+        else { rscore = st_wt * m_score; if (rscore < sd && tm->no_mot > -0.5) rscore = sd; }
+        // upstream composition
+        int cnt = 0; double u = 0.0;
+        for (int k = 1; k < 3; k++) { if (k > start) break; u += 0.4 * st_wt * tm->ups_comp[cnt][mer_local(d, L, start - k, 1, strand)]; cnt++; }
+        for (int k = 15; k < 45; k++) { if (k > start) break; u += 0.4 * st_wt * tm->ups_comp[cnt][mer_local(d, L, start - k, 1, strand)]; cnt++; }
+        uscore = u;
+        if (!closed && ndx <= 2 && strand == 1) uscore += -1.00 * st_wt;
+        else if (!closed && ndx >= L - 3 && strand == -1) uscore += -1.00 * st_wt;
+        else if (i < 500 && strand == 1) {
+            for (int j = i - 1; j >= 0; j--)
+                if ((ga.edge0[tb + j] || convertible(j)) && sv == ga.stop_val[tb + j]) { uscore += -1.00 * st_wt; break; }
+        } else if (i + 500 >= n && strand == -1) {
+            for (int j = i + 1; j < n; j++)
+                if ((ga.edge0[tb + j] || (convertible(j) && !ch.first)) && sv == ga.stop_val[tb + j]) { uscore += -1.00 * st_wt; break; }
+        }
+    }
+    bool edge_now = edge_in;
+    if (conv && !edge_in) {
+        edge_gene += 1; edge_now = true; tscore = 0.0;
+        uscore = 0.74 * st_wt / edge_gene; rscore = 0.0;
+    }
+    if (!edge_now && edge_gene == 1) uscore -= 0.5 * 0.74 * st_wt;
+    if (edge_gene == 0 && orf < 250) {
+        const double negf = 250.0 / (float)orf, posf = (float)orf / 250.0;
+        rscore *= rscore < 0 ? negf : posf;
+        uscore *= uscore < 0 ? negf : posf;
+        tscore *= tscore < 0 ? negf : posf;
+    }
+    if (is_meta && L < 3000 && edge_gene == 0 && (cscore < 5.0 || orf < 120))
+        cscore -= 7.5 * fmax(0.0, (3000.0 - L) / 2700.0);
+    sscore = tscore + rscore + uscore;
+    if (cscore < 0.0) {
+        if (edge_gene > 0 && !edge_now) {
+            if (!is_meta || L > 1500) sscore -= st_wt; else sscore -= 10.31 - 0.004 * L;
+        } else if (is_meta && L < 3000 && edge_now) {
+            const double mml = sqrt((double)L) * 5.0;
+            if (orf >= mml) { if (cscore >= 0) cscore = -1.0; sscore = 0.0; uscore = 0.0; }
+        } else sscore -= 0.5;
+    } else if (is_meta && cscore < 5.0 && orf < 120 && sscore < 0.0) sscore -= st_wt;
+
+    ca.cscore[g] = cscore; ca.sscore[g] = sscore; ca.rscore[g] = rscore; ca.uscore[g] = uscore; ca.tscore[g] = tscore;
+    ca.mot_score[g] = m_score; ca.mot_ndx[g] = m_ndx;
+    ca.mot_len[g] = (uint8_t)m_len; ca.mot_spacer[g] = (uint8_t)m_sp; ca.mot_spacendx[g] = (uint8_t)m_si;
+    ca.rbs[2 * g] = (uint8_t)rbs0; ca.rbs[2 * g + 1] = (uint8_t)rbs1;
+    ca.edge[g] = (uint8_t)edge_now;
+}
+
+// ------------------------------------------------------------------- overlapping starts
+// ref: lib.pyx:2279-2329 (Nodes._record_overlapping_starts with flag = 1)
+__global__ void __launch_bounds__(256)
+k_overlapping_starts(const ChainDesc* __restrict__ chains, int n_chains, int64_t node_begin, int64_t total,
+                     GroupArrays ga, const ModelConst* __restrict__ mcs, ChainArrays ca, int maxov) {
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    g += node_begin;
+    const int c = find_chain(chains, n_chains, g);
+    const ChainDesc ch = chains[c];
+    const int i = (int)(g - ch.off), n = ch.n;
+    const int64_t tb = ch.topo_off;
+    int sp0 = -1, sp1 = -1, sp2 = -1;
+    if (ga.type[tb + i] == PGA_T_STOP && ga.edge0[tb + i] != 1) {
+        const ModelConst* __restrict__ mc = &mcs[ch.model];
+        const int32_t* __restrict__ ndx = ga.ndx + tb; const int32_t* __restrict__ stv = ga.stop_val + tb;
+        const uint8_t* __restrict__ typ = ga.type + tb; const int8_t* __restrict__ str = ga.strand + tb;
+        const double* __restrict__ cs = ca.cscore + ch.off; const double* __restrict__ ss = ca.sscore + ch.off;
+        const double* __restrict__ rs = ca.rscore + ch.off; const double* __restrict__ us = ca.uscore + ch.off;
+        const int my = ndx[i];
+        double best = -100;
+        if (str[i] == 1) {
+            for (int j = i + 3; j >= 0; j--) {
+                if (j >= n || ndx[j] > my + 2) continue;
+                if (ndx[j] + maxov < my) break;
+                if (str[j] != 1 || typ[j] == PGA_T_STOP) continue;
+                if (stv[j] <= my) continue;
+                const double v = cs[j] + ss[j] + igm_same_dev(my, 1, rs[i], us[i], ndx[j], rs[j], us[j], mc->st_wt, mc->igm);
+                if (v > best) { const int f = ndx[j] % 3; if (f == 0) sp0 = j; else if (f == 1) sp1 = j; else sp2 = j; best = v; }
+            }
+        } else {
+            for (int j = i - 3; j < n; j++) {
+                if (j < 0 || ndx[j] < my - 2) continue;
+                if (ndx[j] - maxov > my) break;
+                if (str[j] != -1 || typ[j] == PGA_T_STOP) continue;
+                if (stv[j] >= my) continue;
+                const double v = cs[j] + ss[j] + igm_same_dev(ndx[j], -1, rs[j], us[j], my, rs[i], us[i], mc->st_wt, mc->igm);
+                if (v > best) { const int f = ndx[j] % 3; if (f == 0) sp0 = j; else if (f == 1) sp1 = j; else sp2 = j; best = v; }
+            }
+        }
+    }
+    ca.star_ptr[3 * g] = sp0; ca.star_ptr[3 * g + 1] = sp1; ca.star_ptr[3 * g + 2] = sp2;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------ launchers
+static inline unsigned nblocks(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
+
+int64_t pga_scan_tiles(int64_t total) { return (total + 1 + SCAN_TILE - 1) / SCAN_TILE; }
+
+void pga_launch_digitize(const char* d_seq, uint8_t* d_dig, int64_t total, const ContigDesc* d_ct, int n_contigs,
+                         int32_t* d_gc, int32_t* d_unk, hipStream_t st) {
+    if (total <= 0) return;
+    hipLaunchKernelGGL(k_digitize, dim3(nblocks(total, 256)), dim3(256), 0, st, d_seq, d_dig, total, d_ct, n_contigs, d_gc, d_unk);
+}
+
+void pga_launch_extract(const uint8_t* d_dig, int64_t total, const ContigDesc* d_ct, int n_contigs, int tt,
+                        const pga_params& p, const GroupArrays& ga, int2* d_tile_sum, int32_t* d_pre_gc, int write_gc,
+                        hipStream_t st) {
+    if (total <= 0) return;
+    hipLaunchKernelGGL(k_extract_orfs, dim3(nblocks(2 * total, 256)), dim3(256), 0, st, d_dig, total, d_ct, n_contigs, tt,
+                       p.closed, p.min_gene, p.min_edge_gene, ga);
+    const int tiles = (int)pga_scan_tiles(total);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(256), 0, st, ga.nf_fwd, ga.nf_rev, d_dig, total, d_tile_sum);
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(1024), 0, st, d_tile_sum, tiles);
+    hipLaunchKernelGGL(k_scan_final, dim3(tiles), dim3(256), 0, st, ga.nf_fwd, ga.nf_rev, d_dig, total, d_tile_sum,
+                       ga.pre_nodes, d_pre_gc, write_gc);
+}
+
+void pga_launch_compact(int64_t total, const ContigDesc* d_ct, int n_contigs, const GroupArrays& ga, hipStream_t st) {
+    if (total <= 0) return;
+    hipLaunchKernelGGL(k_compact_nodes, dim3(nblocks(total, 256)), dim3(256), 0, st, total, d_ct, n_contigs, ga);
+}
+
+void pga_launch_orf_gc(const ContigDesc* d_ct, int n_contigs, const int32_t* d_pre_gc, const GroupArrays& ga,
+                       int n_nodes_total, const int32_t* d_node_contig_base, hipStream_t st) {
+    if (n_nodes_total <= 0) return;
+    hipLaunchKernelGGL(k_orf_gc, dim3(nblocks(n_nodes_total, 256)), dim3(256), 0, st, d_ct, n_contigs, d_pre_gc, ga,
+                       n_nodes_total, d_node_contig_base);
+}
+
+void pga_launch_score(const ChainDesc* d_chains, int n_chains, int64_t node_begin, int64_t total, const uint8_t* d_dig,
+                      const ContigDesc* d_ct, const GroupArrays& ga, const pga_training* d_models,
+                      const ModelScoreConst* d_msc, const ModelConst* d_mc, const ChainArrays& ca, ScoreParams sp,
+                      hipStream_t st) {
+    if (total <= 0 || n_chains <= 0) return;
+    const dim3 grid(nblocks(total, 256)), blk(256);
+    hipLaunchKernelGGL(k_coding_score, grid, blk, 0, st, d_chains, n_chains, node_begin, total, d_dig, d_ct, ga, d_models, d_msc, ca);
+    hipLaunchKernelGGL(k_score_starts, grid, blk, 0, st, d_chains, n_chains, node_begin, total, d_dig, d_ct, ga, d_models, ca, sp);
+    hipLaunchKernelGGL(k_overlapping_starts, grid, blk, 0, st, d_chains, n_chains, node_begin, total, ga, d_mc, ca, sp.max_overlap);
+}

@@ -1,0 +1,142 @@
+"""GPU parity of the finder-level C-ABI call (`pga_find_genes_batch`) against the CPU oracle:
+gene calls bit-identical, winning model identical, every returned node field bit-identical
+(north_star tolerance is 1e-6 on scores; we assert exact equality)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests.util import golden_path, read_fasta, synthetic_contig
+
+pytestmark = pytest.mark.gpu
+
+NODE_F64 = ["cscore", "sscore", "rscore", "uscore", "tscore", "mot_score", "score"]
+NODE_INT = ["ndx", "stop_val", "type", "strand", "edge", "traceb", "tracef", "ov_mark", "elim", "mot_ndx", "mot_len",
+            "mot_spacer", "mot_spacendx"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from pyrodigal_amd import _cabi
+    c = _cabi.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def models():
+    m = [orc.Training.load(golden_path("SRR492066.training.bin.gz")),
+         orc.Training.load(golden_path("GCF_001457455.1_NCTC11397_genomic_100kb.tinf_closed.bin.gz")),
+         orc.Training.load(golden_path("GCF_001457455.1_NCTC11397_genomic.tinf_closed.bin.gz"))]
+    kk = orc.Oracle(read_fasta("KK037166.fna.gz")[0][1]).train()      # a non-SD model (uses_sd == 0)
+    assert kk.uses_sd == 0
+    m.append(kk)
+    # same statistics under other GC labels / translation table so that several bins land in every GC window
+    for src, gc, tt in [(0, 0.36, 11), (1, 0.47, 11), (3, 0.60, 11), (2, 0.42, 4), (0, 0.33, 4), (1, 0.64, 11)]:
+        t = m[src].copy(); t.set_gc(gc); t.set_trans_table(tt); m.append(t)
+    return m
+
+
+def compare_contig(res, i, seq, o, models, meta, closed=False):
+    cr = res.contigs[i]
+    if meta:
+        phase = o.find_genes_meta(models, orc.Params(closed=closed))
+        assert cr["model"] == phase
+    else:
+        o.find_genes_single(models[0], orc.Params(closed=closed))
+    og, on = o.genes(), o.nodes()
+    gg = res.genes_of(i)
+    assert len(gg) == len(og)
+    for k in ("begin", "end", "start_ndx", "stop_ndx"):
+        assert np.array_equal(gg[k], og[k]), k
+    if res.nodes is not None and (not meta or cr["model"] >= 0):
+        nd = res.nodes[i]
+        assert nd["n"] == len(on)
+        for k in NODE_INT:
+            assert np.array_equal(nd[k].astype(np.int64), on[k].astype(np.int64)), k
+        for k in NODE_F64:
+            assert np.array_equal(nd[k].view(np.uint64), on[k].view(np.uint64)), k
+        assert np.array_equal(nd["gc_cont"].view(np.uint32), on["gc_cont"].view(np.uint32))
+        assert np.array_equal(nd["rbs"], on["rbs"])
+        if not meta:
+            assert np.array_equal(nd["star_ptr"], on["star_ptr"])
+    # gene attributes as Gene properties would read them
+    if len(gg):
+        s = on[og["start_ndx"]]
+        assert np.array_equal(gg["strand"], s["strand"])
+        assert np.array_equal(gg["cscore"].view(np.uint64), s["cscore"].view(np.uint64))
+        assert np.array_equal(gg["sscore"].view(np.uint64), s["sscore"].view(np.uint64))
+        assert np.array_equal(gg["start_type"], np.where(s["edge"] != 0, 3, s["type"]))
+    return len(gg)
+
+
+def test_single_mode_goldens_through_gpu(ctx):
+    # same goldens the oracle is pinned on (ref: tests/test_gene_finder.py:101-130), now via the HIP path
+    from tests.util import parse_prodigal_header
+    for name in ["SRR492066", "KK037166", "MIIJ01000039"]:
+        seq = read_fasta(name + ".fna.gz")[0][1]
+        tinf = orc.Oracle(seq).train()
+        ctx.set_models([tinf.buf])
+        res = ctx.find_genes_batch([seq], meta=False, want_nodes=True)
+        want = [parse_prodigal_header(h) for h, _ in read_fasta(name + ".single.faa.gz")]
+        gg = res.genes_of(0)
+        assert len(gg) == len(want)
+        for g, w in zip(gg, want):
+            assert (g["begin"], g["end"], g["strand"]) == w[:3]
+            assert "%d%d" % (g["partial_begin"], g["partial_end"]) == w[3]
+            assert orc.NODE_TYPE[g["start_type"]] == w[4]
+            assert "%.3f" % g["gc_cont"] == w[7]
+        compare_contig(res, 0, seq, orc.Oracle(seq), [tinf], meta=False)
+
+
+def test_single_mode_full_genome_closed(ctx):
+    seq = read_fasta("GCF_001457455.1_NCTC11397_genomic.fna.gz")[0][1]
+    tinf = orc.Training.load(golden_path("GCF_001457455.1_NCTC11397_genomic.tinf_closed.bin.gz"))
+    ctx.set_models([tinf.buf])
+    res = ctx.find_genes_batch([seq], meta=False, closed=True, want_nodes=True)
+    n = compare_contig(res, 0, seq, orc.Oracle(seq), [tinf], meta=False, closed=True)
+    assert n > 2000
+
+
+def test_meta_mode_fixture_contigs(ctx, models):
+    ctx.set_models([m.buf for m in models])
+    seqs = [read_fasta(n + ".fna.gz")[0][1] for n in ("SRR492066", "KK037166", "GCF_001457455.1_NCTC11397_genomic_100kb")]
+    res = ctx.find_genes_batch(seqs, meta=True, want_nodes=True)
+    for i, s in enumerate(seqs):
+        assert compare_contig(res, i, s, orc.Oracle(s), models, meta=True) > 0
+
+
+def test_meta_mode_synthetic_batch_mixed_gc(ctx, models):
+    ctx.set_models([m.buf for m in models])
+    seqs = [synthetic_contig(20000 + 997 * c, 0.30 + 0.40 * (c % 41) / 40, 10000 + c) for c in range(48)]
+    res = ctx.find_genes_batch(seqs, meta=True, want_nodes=True)
+    total = sum(compare_contig(res, i, s, orc.Oracle(s), models, meta=True) for i, s in enumerate(seqs))
+    assert total > 0
+    assert res.node_passes > 0 and res.t_dp_ms > 0
+
+
+def test_meta_mode_short_fragments_and_edge_cases(ctx, models):
+    # short fragments exercise the < 3000 bp meta penalties, edge genes, empty and sub-codon inputs
+    # (ref: tests/test_gene_finder.py:198-234)
+    ctx.set_models([m.buf for m in models])
+    seqs = [b"", b"A", b"AT", b"ATG", b"ATGTAA", synthetic_contig(61, 0.5, 1), synthetic_contig(130, 0.4, 2)]
+    seqs += [synthetic_contig(L, gc, 500 + L) for L in (300, 700, 1400, 1600, 2900, 3100) for gc in (0.35, 0.55)]
+    seqs += [b"N" * 500, synthetic_contig(900, 0.5, 7) + b"NNNNNNNNNN" * 12 + synthetic_contig(900, 0.5, 8)]
+    for closed in (False, True):
+        res = ctx.find_genes_batch(seqs, meta=True, closed=closed, want_nodes=True)
+        for i, s in enumerate(seqs):
+            compare_contig(res, i, s, orc.Oracle(s), models, meta=True, closed=closed)
+
+
+def test_no_model_in_gc_window(ctx, models):
+    ctx.set_models([models[0].buf])            # gc 0.30 only
+    seq = synthetic_contig(5000, 0.70, 3)
+    res = ctx.find_genes_batch([seq], meta=True)
+    assert res.contigs[0]["model"] == -1 and res.contigs[0]["n_genes"] == 0
+
+
+def test_invalid_arguments_raise(ctx, models):
+    ctx.set_models([models[0].buf])
+    with pytest.raises(ValueError):
+        ctx.find_genes_batch([b"ACGT"], min_gene=0)
+    with pytest.raises(ValueError):
+        ctx.find_genes_batch([b"ACGT"], max_overlap=100, min_gene=90)
