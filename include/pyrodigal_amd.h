@@ -132,10 +132,19 @@ int pga_score_connections(pga_ctx*, int32_t n,
                           double* kernel_ms /* may be NULL */);
 
 /* ---- finder level ------------------------------------------------------ */
-/* `seqs[c]` points at `lens[c]` ASCII nucleotides (any case, non-ACGT = unknown). */
+/* `seqs[c]` points at `lens[c]` ASCII nucleotides (any case, non-ACGT = unknown).
+ * One call = GeneFinder.find_genes() on every contig of the batch (ref: lib.pyx:5400-5469). */
 int  pga_find_genes_batch(pga_ctx*, int32_t n_contigs, const char* const* seqs, const int64_t* lens,
                           const pga_params*, pga_result** out);
 void pga_result_free(pga_result*);
+
+/* The same in two steps, for callers that keep a batch resident in HBM (repeated passes over the
+ * same contigs with different options/models, benchmarking without the PCIe upload):
+ * pga_batch_create packs and uploads the contigs once, pga_find_genes runs the whole path on it. */
+typedef struct pga_batch pga_batch;
+int  pga_batch_create(pga_ctx*, int32_t n_contigs, const char* const* seqs, const int64_t* lens, pga_batch** out);
+void pga_batch_free(pga_batch*);
+int  pga_find_genes(pga_ctx*, const pga_batch*, const pga_params*, pga_result** out);
 
 #ifdef __cplusplus
 }

@@ -17,6 +17,7 @@ TRAINING_SIZE = 558392
 EXPORTS = [
     "pga_create", "pga_destroy", "pga_last_error", "pga_device_info", "pga_set_models",
     "pga_score_connections", "pga_find_genes_batch", "pga_result_free",
+    "pga_batch_create", "pga_batch_free", "pga_find_genes",
 ]
 
 
@@ -91,6 +92,10 @@ def load():
     L.pga_find_genes_batch.restype = ctypes.c_int
     L.pga_find_genes_batch.argtypes = [vp, i32, _P(ctypes.c_char_p), _P(i64), _P(Params), _P(_P(Result))]
     L.pga_result_free.restype = None; L.pga_result_free.argtypes = [_P(Result)]
+    L.pga_batch_create.restype = ctypes.c_int
+    L.pga_batch_create.argtypes = [vp, i32, _P(ctypes.c_char_p), _P(i64), _P(vp)]
+    L.pga_batch_free.restype = None; L.pga_batch_free.argtypes = [vp]
+    L.pga_find_genes.restype = ctypes.c_int; L.pga_find_genes.argtypes = [vp, vp, _P(Params), _P(_P(Result))]
     _lib = L
     return L
 
@@ -193,22 +198,44 @@ class BatchResult:
         return self.genes[c["gene_begin"]:c["gene_begin"] + c["n_genes"]]
 
 
-def _find_genes_batch(self, seqs, meta=True, closed=False, min_gene=90, min_edge_gene=60, max_overlap=60, want_nodes=False):
-    """Whole-batch ``GeneFinder.find_genes``: ``seqs`` is a list of ASCII ``bytes`` contigs."""
-    seqs = [s.encode("ascii") if isinstance(s, str) else bytes(s) for s in seqs]
-    n = len(seqs)
-    ptrs = (ctypes.c_char_p * max(1, n))(*seqs)
-    lens = (ctypes.c_int64 * max(1, n))(*[len(s) for s in seqs])
-    p = Params(int(closed), min_gene, min_edge_gene, max_overlap, int(meta), int(want_nodes))
-    res = _P(Result)()
-    rc = self.L.pga_find_genes_batch(self.h, n, ptrs, lens, ctypes.byref(p), ctypes.byref(res))
-    if rc != PGA_OK:
-        _raise(self.L, self.h, rc, "pga_find_genes_batch")
+class Batch:
+    """Contigs packed and resident in HBM (``pga_batch``)."""
+
+    def __init__(self, ctx, seqs):
+        self.ctx = ctx
+        seqs = [s.encode("ascii") if isinstance(s, str) else bytes(s) for s in seqs]
+        self.n = len(seqs)
+        self.total = sum(len(s) for s in seqs)
+        ptrs = (ctypes.c_char_p * max(1, self.n))(*seqs)
+        lens = (ctypes.c_int64 * max(1, self.n))(*[len(s) for s in seqs])
+        h = ctypes.c_void_p()
+        rc = ctx.L.pga_batch_create(ctx.h, self.n, ptrs, lens, ctypes.byref(h))
+        if rc != PGA_OK:
+            _raise(ctx.L, ctx.h, rc, "pga_batch_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.L.pga_batch_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+def _unpack_result(L, res, want_nodes):
     try:
         r = res.contents
-        contigs = np.ctypeslib.as_array(r.contigs, (r.n_contigs,)).copy() if r.n_contigs else np.zeros(0, CONTIG_DTYPE)
-        contigs = contigs.view(CONTIG_DTYPE) if contigs.dtype != CONTIG_DTYPE else contigs
-        genes = np.ctypeslib.as_array(r.genes, (r.n_genes,)).copy() if r.n_genes else np.zeros(0, GENE_DTYPE)
+        if r.n_contigs:
+            buf = ctypes.string_at(r.contigs, r.n_contigs * ctypes.sizeof(ContigResult))
+            contigs = np.frombuffer(buf, dtype=CONTIG_DTYPE).copy()
+        else:
+            contigs = np.zeros(0, CONTIG_DTYPE)
+        if r.n_genes:
+            buf = ctypes.string_at(r.genes, r.n_genes * ctypes.sizeof(Gene))
+            genes = np.frombuffer(buf, dtype=GENE_DTYPE).copy()
+        else:
+            genes = np.zeros(0, GENE_DTYPE)
         nodes = None
         if want_nodes and r.nodes:
             nodes = []
@@ -227,7 +254,32 @@ def _find_genes_batch(self, seqs, meta=True, closed=False, min_gene=90, min_edge
                 nodes.append(d)
         return BatchResult(contigs, genes, nodes, r.t_total_ms, r.t_dp_ms, r.node_passes)
     finally:
-        self.L.pga_result_free(res)
+        L.pga_result_free(res)
 
 
+def _upload(self, seqs):
+    return Batch(self, seqs)
+
+
+def _find_genes(self, batch, meta=True, closed=False, min_gene=90, min_edge_gene=60, max_overlap=60, want_nodes=False):
+    """``GeneFinder.find_genes`` over every contig of a resident :class:`Batch`."""
+    p = Params(int(closed), min_gene, min_edge_gene, max_overlap, int(meta), int(want_nodes))
+    res = _P(Result)()
+    rc = self.L.pga_find_genes(self.h, batch.h, ctypes.byref(p), ctypes.byref(res))
+    if rc != PGA_OK:
+        _raise(self.L, self.h, rc, "pga_find_genes")
+    return _unpack_result(self.L, res, want_nodes)
+
+
+def _find_genes_batch(self, seqs, **kw):
+    """Upload + find + free: ``seqs`` is a list of ASCII ``bytes``/``str`` contigs."""
+    b = Batch(self, seqs)
+    try:
+        return _find_genes(self, b, **kw)
+    finally:
+        b.close()
+
+
+Context.upload = _upload
+Context.find_genes = _find_genes
 Context.find_genes_batch = _find_genes_batch

@@ -1,0 +1,54 @@
+"""Synthetic workloads and the 16-model metagenomic bin set used by bench.py and the batch tests.
+
+Generators follow SURVEY.md section 8(d): i.i.d. bases with P(G)=P(C)=gc/2 from
+``numpy.random.default_rng(seed)``.  The reference's 50 built-in Prodigal models are not part of
+its checkout, so meta mode runs on 16 custom bins: the 3 TrainingInfo fixtures of the reference's
+test-suite plus 13 models trained on synthetic planted-ORF genomes (tests/golden/make_models.py).
+"""
+import glob
+import gzip
+import os
+
+import numpy as np
+
+_GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def synthetic_contig(length, gc, seed):
+    rng = np.random.default_rng(seed)
+    p = [(1 - gc) / 2, gc / 2, gc / 2, (1 - gc) / 2]
+    return _ACGT[rng.choice(4, size=length, p=p)].tobytes()
+
+
+def config2(rank=0):
+    """One 5 Mbp contig, 50 % GC (BASELINE.json configs[1]); other ranks get their own seed."""
+    return [synthetic_contig(5_000_000, 0.50, 1234 + rank)]
+
+
+def config3(n=1000, length=50_000, seed0=10_000, first=0):
+    """n x 50 kbp contigs, GC 30..70 % (BASELINE.json configs[2])."""
+    return [synthetic_contig(length, 0.30 + 0.40 * ((first + c) % 41) / 40, seed0 + first + c) for c in range(n)]
+
+
+def config4_shard(rank, world, n_total=100_000, length=20_000):
+    """This rank's contigs of the 100 000 x 20 kbp metagenome-like set (BASELINE.json configs[3])."""
+    return [synthetic_contig(length, 0.30 + 0.40 * (c % 41) / 40, 1_000_000 + c) for c in range(rank, n_total, world)]
+
+
+def _read(path):
+    opener = gzip.open if path.endswith(".gz") else open
+    with opener(path, "rb") as f:
+        return f.read()
+
+
+def load_model_set():
+    """16 ``struct _training`` blobs sorted by GC, as (name, bytes) pairs."""
+    files = [
+        os.path.join(_GOLDEN, "SRR492066.training.bin.gz"),
+        os.path.join(_GOLDEN, "GCF_001457455.1_NCTC11397_genomic_100kb.tinf_closed.bin.gz"),
+        os.path.join(_GOLDEN, "GCF_001457455.1_NCTC11397_genomic.tinf_closed.bin.gz"),
+    ] + sorted(glob.glob(os.path.join(_GOLDEN, "models", "*.tinf.bin.gz")))
+    models = [(os.path.basename(f), _read(f)) for f in files]
+    models.sort(key=lambda m: np.frombuffer(m[1][:8], np.float64)[0])
+    return models

@@ -318,21 +318,77 @@ int pga_finder_models_changed(pga_ctx* c) {
     return PGA_OK;
 }
 
-extern "C" void pga_result_free(pga_result* r) {
-    if (r) delete reinterpret_cast<ResultOwner*>(r);
+struct pga_batch {
+    pga_ctx* ctx;
+    int32_t n;
+    int64_t total;
+    std::vector<ContigDesc> ct;   // n + 1 entries
+    char* d_seq;                  // packed ASCII, resident in HBM
+};
+
+extern "C" int pga_batch_create(pga_ctx* c, int32_t n_contigs, const char* const* seqs, const int64_t* lens, pga_batch** out) {
+    if (out) *out = nullptr;
+    if (!c || !out || n_contigs < 0 || (n_contigs > 0 && (!seqs || !lens))) { if (c) c->err = "pga_batch_create: bad arguments"; return PGA_EINVAL; }
+    if (!c->finder) { int rc = pga_finder_models_changed(c); if (rc) return rc; }
+    HT(c, hipSetDevice(c->device));
+    pga_batch* b = new (std::nothrow) pga_batch();
+    if (!b) return PGA_ENOMEM;
+    b->ctx = c; b->n = n_contigs; b->d_seq = nullptr; b->ct.resize((size_t)n_contigs + 1);
+    int64_t total = 0;
+    for (int i = 0; i < n_contigs; i++) {
+        if (lens[i] < 0 || lens[i] > 0x7fff0000LL || (lens[i] > 0 && !seqs[i])) { delete b; c->err = "pga_batch_create: bad contig length"; return PGA_EINVAL; }
+        b->ct[i].base = total; b->ct[i].len = (int32_t)lens[i]; b->ct[i]._pad = 0;
+        total += lens[i];
+    }
+    b->ct[n_contigs].base = total; b->ct[n_contigs].len = 0; b->ct[n_contigs]._pad = 0;
+    b->total = total;
+    if (total >= 0x7fffffffLL) { delete b; c->err = "pga_batch_create: batch larger than 2^31 bases; split it"; return PGA_EINVAL; }
+    if (total > 0) {
+        void* hp; int rc = ensure_pin(c, "h_seq", (size_t)total + 16, &hp);
+        if (rc) { delete b; return rc; }
+        char* h_seq = (char*)hp;
+        for (int i = 0; i < n_contigs; i++) if (lens[i] > 0) memcpy(h_seq + b->ct[i].base, seqs[i], (size_t)lens[i]);
+        if (hipMalloc((void**)&b->d_seq, (size_t)total + 16) != hipSuccess) { delete b; c->err = "pga_batch_create: hipMalloc failed"; return PGA_ENOMEM; }
+        hipError_t e = hipMemcpyAsync(b->d_seq, h_seq, (size_t)total, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { hipFree(b->d_seq); delete b; return pga_hip_try_(c, e, "upload of the batch"); }
+    }
+    *out = b;
+    return PGA_OK;
+}
+
+extern "C" void pga_batch_free(pga_batch* b) {
+    if (!b) return;
+    if (b->d_seq) { hipSetDevice(b->ctx->device); hipFree(b->d_seq); }
+    delete b;
 }
 
 extern "C" int pga_find_genes_batch(pga_ctx* c, int32_t n_contigs, const char* const* seqs, const int64_t* lens,
                                     const pga_params* pp, pga_result** out) {
     if (out) *out = nullptr;
-    if (!c || !out || !pp || n_contigs < 0 || (n_contigs > 0 && (!seqs || !lens))) {
-        if (c) c->err = "pga_find_genes_batch: bad arguments";
+    pga_batch* b = nullptr;
+    int rc = pga_batch_create(c, n_contigs, seqs, lens, &b);
+    if (rc != PGA_OK) return rc;
+    rc = pga_find_genes(c, b, pp, out);
+    pga_batch_free(b);
+    return rc;
+}
+
+extern "C" void pga_result_free(pga_result* r) {
+    if (r) delete reinterpret_cast<ResultOwner*>(r);
+}
+
+extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_params* pp, pga_result** out) {
+    if (out) *out = nullptr;
+    if (!c || !out || !pp || !batch || batch->ctx != c) {
+        if (c) c->err = "pga_find_genes: bad arguments";
         return PGA_EINVAL;
     }
-    if (c->n_models <= 0 || !c->finder) { c->err = "pga_find_genes_batch: no model loaded (call pga_set_models first)"; return PGA_EINVAL; }
+    const int32_t n_contigs = batch->n;
+    if (c->n_models <= 0 || !c->finder) { c->err = "pga_find_genes: no model loaded (call pga_set_models first)"; return PGA_EINVAL; }
     const pga_params P = *pp;
     if (P.min_gene <= 0 || P.min_edge_gene <= 0 || P.max_overlap < 0 || P.max_overlap > P.min_gene) {
-        c->err = "pga_find_genes_batch: invalid min_gene / min_edge_gene / max_overlap";   // ref: lib.pyx:5169-5181
+        c->err = "pga_find_genes: invalid min_gene / min_edge_gene / max_overlap";   // ref: lib.pyx:5169-5181
         return PGA_EINVAL;
     }
     HT(c, hipSetDevice(c->device));
@@ -347,21 +403,11 @@ extern "C" int pga_find_genes_batch(pga_ctx* c, int32_t n_contigs, const char* c
     memset(&R->pub, 0, sizeof R->pub);
     R->pub.n_contigs = NC;
 
-    // ---- pack the batch ---------------------------------------------------------------------
-    std::vector<ContigDesc> ct(NC + 1);
-    int64_t total = 0;
-    for (int i = 0; i < NC; i++) {
-        if (lens[i] < 0 || lens[i] > 0x7fff0000LL || (lens[i] > 0 && !seqs[i])) { c->err = "pga_find_genes_batch: bad contig length"; return PGA_EINVAL; }
-        ct[i].base = total; ct[i].len = (int32_t)lens[i]; ct[i]._pad = 0;
-        total += lens[i];
-    }
-    ct[NC].base = total; ct[NC].len = 0; ct[NC]._pad = 0;
-    if (total >= 0x7fffffffLL) { c->err = "pga_find_genes_batch: batch larger than 2^31 bases; split it"; return PGA_EINVAL; }
+    const std::vector<ContigDesc>& ct = batch->ct;
+    const int64_t total = batch->total;
 
     if (NC > 0 && total > 0) {
-        PINBUF(h_seq, char, "h_seq", total + 16);
-        for (int i = 0; i < NC; i++) if (lens[i] > 0) memcpy(h_seq + ct[i].base, seqs[i], (size_t)lens[i]);
-        DEVBUF(d_seq, char, "d_seq", total + 16);
+        const char* d_seq = batch->d_seq;
         DEVBUF(d_dig, uint8_t, "d_dig", total + 16);
         DEVBUF(d_ct, ContigDesc, "d_ct", NC + 1);
         DEVBUF(d_cnt, int32_t, "d_cnt", 2 * (size_t)NC);
@@ -384,7 +430,6 @@ extern "C" int pga_find_genes_batch(pga_ctx* c, int32_t n_contigs, const char* c
         }
 
         HT(c, hipEventRecord(f->e_start, st));
-        HT(c, hipMemcpyAsync(d_seq, h_seq, (size_t)total, hipMemcpyHostToDevice, st));
         HT(c, hipMemcpyAsync(d_ct, ct.data(), sizeof(ContigDesc) * (NC + 1), hipMemcpyHostToDevice, st));
         HT(c, hipMemsetAsync(d_cnt, 0, sizeof(int32_t) * 2 * (size_t)NC, st));
         pga_launch_digitize(d_seq, d_dig, total, d_ct, NC, d_cnt, d_cnt + NC, st);
