@@ -99,7 +99,7 @@ def main():
                        "genes_all_ranks": int(len(all_genes)), "parallelism": "contig-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                         "kernel": "k_dp_wave", "kernel_ms_per_step": round(dp_ms / args.steps, 3),
+                         "kernel": "k_dp_chain", "kernel_ms_per_step": round(dp_ms / args.steps, 3),
                          "bytes_per_node_pass": BYTES_PER_NODE_PASS},
         }
         # PCIe-inclusive rate (upload + find), reported next to `value`, never as `value`

@@ -5,22 +5,21 @@
 // order, the best predecessor j in the window [lo_i, i):
 //     score[i] = max(0, max_j (score[j] + w(j, i))),  ties -> largest j,  traceb[i] = that j.
 //
-// Mapping onto CDNA4 -- one 64-wide wavefront per (contig, model) chain:
-//   * lane t owns target node i0+t of the current 64-node batch and keeps (best, traceb, ov_mark)
-//     in registers; candidates j are visited in ascending order, wave-uniformly, so the per-lane
-//     ">=" update reproduces the reference's sequential scan bit for bit (no cross-lane
-//     reduction, no reassociation of floating-point adds);
-//   * the source record of candidate j is wave-uniform (one 64-byte DpSrc, scalar-loaded), its
-//     dynamic fields (score, ndx of its traceb) are read once per 64-source tile as a coalesced
-//     vector load and broadcast with v_readlane;
-//   * a __ballot over the tile builds the visit mask: gene-end sources that were never reached
-//     (traceb == -1) can connect to nothing (ref: _connection.h:110-114) and are skipped for the
-//     whole wave, and a second __ballot over the targets skips a source no lane can use
-//     (the six conditions of impl/generic.h:29-36 folded into the per-kind predicates);
-//   * the 63 candidates inside the batch itself are the other lanes: when the loop reaches
-//     source i0+k, lane k has already seen every j < i0+k, so its registers hold final values.
+// Mapping onto CDNA4 -- W wavefronts (1, 4 or 16) per (contig, model) chain, 64 targets at a time:
+//   * lane t owns target node i0+t of the current batch and keeps (best, traceb, ov_mark) in
+//     registers; a candidate source is wave-uniform: its fields sit in the registers of one lane
+//     of a coalesced 64-source tile and are broadcast with v_readlane;
+//   * a __ballot over the tile builds the visit mask (gene ends that were never reached connect
+//     to nothing, ref: _connection.h:110-114) and a wave vote (__any) on the folded skip
+//     conditions of impl/generic.h:29-36 drops a source before any f64 work;
+//   * the reference's ascending ">=" scan is a lexicographic (value, index) maximum, so the W waves
+//     scan disjoint tiles of the already-final sources concurrently and merge exactly in LDS;
+//   * the 63 candidates inside the batch are the other lanes: when the walk reaches source i0+k,
+//     lane k has met every j < i0+k, so its registers hold final values (this walk is the serial
+//     critical path of a chain: one step per node);
 //   * third-node indirections (star_ptr -> n3) never happen in the loop: dp_prepare folds
-//     cs(n3)+igm(.,.) and n3.{ndx,stop_val} into the source/target records.
+//     cs(n3)+igm(.,.) and n3.{ndx,stop_val} into the source/target records, and every lane tracks
+//     the ndx of its own traceb node, which later pairs need (ref: _connection.h:249, 318).
 //
 // Arithmetic: IEEE double, compiled with -ffp-contract=off, same operation order as the
 // reference; (2 - d/60)*0.15*st_wt comes from a host-computed 61-entry table.
@@ -29,6 +28,7 @@
 #include "dev_common.h"
 
 #include <limits.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -117,40 +117,64 @@ struct Target {
     double cs, csd, x0, x1, x2;
     int n3n0, n3n1, n3n2, n3s0, n3s1, n3s2;
 };
+// Per-lane copy of one candidate source (lane k holds source t0+k); fields are broadcast with
+// v_readlane when the wave visits that source.
+struct SrcLane {
+    int ndx, stop_val, meta, tbn;     // tbn: ndx of the source's own traceb node, -1 if it has none
+    double cs, x0, x1, x2, score;
+};
+struct Best { double val; int tb, ov, tbn; };   // running result of a target + ndx of its traceb node
 
-// Score candidate source j (wave-uniform fields s_*, sj, tbnj) against this lane's target.
-// One call = one iteration of the loop in _connection.h:386-408 for all 64 lanes.
-__device__ __forceinline__ void eval_source(const int j, const int s_ndx, const int s_stop, const int s_meta,
-                                            const double s_cs, const double s_x0, const double s_x1, const double s_x2,
-                                            const double sj, const int tbnj, const Target& T, const double negc,
-                                            const double* s_igm, double& best, int& tb, int& ov) {
+// "val >= best" of the reference's ascending scan (ref: _connection.h:135-139), written as a
+// lexicographic (value, index) maximum so that partial results over disjoint source sets merge exactly.
+__device__ __forceinline__ void take(Best& b, bool ok, double val, int j, int mf, int s_ndx) {
+    if (ok && (val > b.val || (val == b.val && j > b.tb))) { b.val = val; b.tb = j; b.ov = mf; b.tbn = s_ndx; }
+}
+
+// Visit source j = lane k of S for all 64 targets of the wave.
+// One call = one iteration of the loop in _connection.h:386-408, with the six skip conditions of
+// impl/generic.h:29-36 folded into the per-kind predicates; a wave-wide vote (__any, i.e. a ballot)
+// drops the source before any floating-point work when no lane can connect to it.
+__device__ __forceinline__ void visit_source(const int k, const int j, const SrcLane& S, const Target& T,
+                                             const double negc, const double* s_igm, Best& B) {
+    const int s_meta = __builtin_amdgcn_readlane(S.meta, k);
+    const int s_ndx = __builtin_amdgcn_readlane(S.ndx, k);
     const int sk = PGA_KIND(s_meta), sf = PGA_FRAME(s_meta);
-    bool ok = (j >= T.lo) && (j < T.i);
-    double w = 0.0; int mf = -1;
+    const bool inwin = (j >= T.lo) && (j < T.i);
     if (sk == 0) {
         // 5'fwd -> 3'fwd: a gene (ref: _connection.h:166-174; skip condition 5: same frame only)
-        ok = ok && T.kind == 1 && T.frame == sf && T.stop_val < s_ndx;
-        w = s_cs;
+        const bool ok = inwin && T.kind == 1 && T.frame == sf && T.stop_val < s_ndx;
+        if (!__any(ok)) return;
+        const double val = readlane_f64(S.score, k) + readlane_f64(S.cs, k);
+        take(B, ok, val, j, -1, s_ndx);
     } else if (sk == 2) {
         // 5'rev -> 5'fwd (ref: :125-130) and 5'rev -> 3'rev (ref: :337-342)
         const bool a = T.kind == 0 && s_ndx < T.ndx;
         const bool b = T.kind == 3 && s_ndx < T.ndx - 2;
-        ok = ok && (a || b);
-        w = b ? igm_apart(T.ndx - s_ndx, negc, s_igm) : negc;
+        const bool ok = inwin && (a || b);
+        if (!__any(ok)) return;
+        const double w = b ? igm_apart(T.ndx - s_ndx, negc, s_igm) : negc;
+        take(B, ok, readlane_f64(S.score, k) + w, j, -1, s_ndx);
     } else if (sk == 3) {
         // 3'rev -> 5'rev: a gene (ref: :228-235; skip condition 6) and 3'rev -> 3'rev operon (ref: :345-356)
+        const int s_stop = __builtin_amdgcn_readlane(S.stop_val, k);
         const bool a = T.kind == 2 && T.frame == sf && s_stop > T.ndx;
         const bool b = T.kind == 3 && s_stop > T.ndx && PGA_SPVALID(T.meta, sf);
-        ok = ok && (a || b);
-        w = a ? T.cs : sel3(sf, T.x0, T.x1, T.x2);
+        const bool ok = inwin && (a || b);
+        if (!__any(ok)) return;
+        const double w = a ? T.cs : sel3(sf, T.x0, T.x1, T.x2);
+        take(B, ok, readlane_f64(S.score, k) + w, j, -1, s_ndx);
     } else {
         // forward stop as source: connects to all four target kinds
+        const int tbnj = __builtin_amdgcn_readlane(S.tbn, k);
+        const double sj = readlane_f64(S.score, k);
+        bool ok = inwin; double w; int mf = -1;
         if (T.kind == 0) {            // 3'fwd -> 5'fwd intergenic (ref: :117-124)
             ok = ok && (s_ndx + 2 < T.ndx);
             w = igm_apart(T.ndx - s_ndx, negc, s_igm);
         } else if (T.kind == 1) {     // 3'fwd -> 3'fwd operon through j's overlapping start (ref: :177-188)
             ok = ok && T.stop_val < s_ndx && PGA_SPVALID(s_meta, T.frame);
-            w = sel3(T.frame, s_x0, s_x1, s_x2);
+            w = sel3(T.frame, readlane_f64(S.x0, k), readlane_f64(S.x1, k), readlane_f64(S.x2, k));
         } else if (T.kind == 2) {     // 3'fwd -> 5'rev overlapping opposite 3' ends (ref: :238-254)
             const int ovlp = (s_ndx + 2) - (T.stop_val - 2) + 1;
             ok = ok && !(T.stop_val - 2 >= s_ndx + 2) && ovlp < PGA_MAX_OPP_OVLP
@@ -162,32 +186,40 @@ __device__ __forceinline__ void eval_source(const int j, const int s_ndx, const 
             ok = ok && left < right;
             double maxval = 0.0;
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const int n3s = sel3i(k, T.n3s0, T.n3s1, T.n3s2), n3n = sel3i(k, T.n3n0, T.n3n1, T.n3n2);
-                const double cur = sel3(k, T.x0, T.x1, T.x2);
+            for (int q = 0; q < 3; q++) {
+                const int n3s = sel3i(q, T.n3s0, T.n3s1, T.n3s2), n3n = sel3i(q, T.n3n0, T.n3n1, T.n3n2);
+                const double cur = sel3(q, T.x0, T.x1, T.x2);
                 const int ovlp = left - n3s + 3;
-                const bool take = PGA_SPVALID(T.meta, k) && ovlp > 0 && ovlp < PGA_MAX_OPP_OVLP && ovlp < n3n - left
-                                  && ovlp < n3s - tbnj - 2 && cur > maxval;
-                if (take) { mf = k; maxval = cur; }
+                const bool tk = PGA_SPVALID(T.meta, q) && ovlp > 0 && ovlp < PGA_MAX_OPP_OVLP && ovlp < n3n - left
+                                && ovlp < n3s - tbnj - 2 && cur > maxval;
+                if (tk) { mf = q; maxval = cur; }
             }
             w = mf != -1 ? maxval : negc;
         }
+        take(B, ok, sj + w, j, mf, s_ndx);
     }
-    const double val = sj + w;
-    if (ok && val >= best) { best = val; tb = j; ov = mf; }
 }
 
-// One wavefront per chain.
-__global__ void __launch_bounds__(64)
-k_dp_wave(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src, const DpTgt* __restrict__ g_tgt,
-          const ModelConst* __restrict__ models, double* g_score, int32_t* g_traceb, int32_t* g_tbn, int8_t* g_ov,
-          int32_t* __restrict__ max_index, double* __restrict__ max_score, int32_t* __restrict__ ipath) {
+// W wavefronts per chain.  Per 64-target batch:
+//   phase F  every wave scans its share of the already-final sources (tiles of 64, coalesced loads,
+//            ballot-built visit mask) against the same 64 targets;
+//   merge    the W partial (value, index) maxima meet in LDS, wave 0 folds them;
+//   phase I  wave 0 walks the 63 in-batch sources: lane k is final once the walk reaches source
+//            i0+k, because by then it has met every j < i0+k;
+//   wave 0 stores the batch (score, traceb, ov_mark, ndx-of-traceb) and the next batch starts.
+template <int W>
+__global__ void __launch_bounds__(64 * W)
+k_dp_chain(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src, const DpTgt* __restrict__ g_tgt,
+           const ModelConst* __restrict__ models, double* g_score, int32_t* g_traceb, int32_t* g_tbn, int8_t* g_ov,
+           int32_t* __restrict__ max_index, double* __restrict__ max_score, int32_t* __restrict__ ipath) {
     __shared__ double s_igm[64];
+    __shared__ double s_pval[W > 1 ? W : 1][64];
+    __shared__ int s_ptb[W > 1 ? W : 1][64], s_pov[W > 1 ? W : 1][64], s_ptbn[W > 1 ? W : 1][64];
     const ChainDesc cd = chains[blockIdx.x];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = cd.n;
     const ModelConst* mc = &models[cd.model];
-    s_igm[lane] = mc->igm[lane];
+    if (wave == 0) s_igm[lane] = mc->igm[lane];
     __syncthreads();
     const double negc = mc->negc;
     const DpSrc* __restrict__ src = g_src + cd.off;
@@ -201,9 +233,10 @@ k_dp_wave(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src,
         Target T;
         T.i = i0 + lane;
         const bool act = T.i < n;
+        DpSrc me;
         {
             const int ii = act ? T.i : n - 1;
-            const DpSrc me = src[ii]; const DpTgt mt = tgt[ii];
+            me = src[ii]; const DpTgt mt = tgt[ii];
             T.kind = PGA_KIND(me.meta); T.frame = PGA_FRAME(me.meta); T.meta = me.meta;
             T.ndx = me.ndx; T.stop_val = me.stop_val; T.cs = me.cs; T.csd = me.cs + negc;
             T.x0 = me.x[0]; T.x1 = me.x[1]; T.x2 = me.x[2];
@@ -212,47 +245,58 @@ k_dp_wave(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src,
             T.lo = act ? mt.lo : INT_MAX;
             if (!act) T.i = -1;       // j < T.i is never true: lane stays idle
         }
-        double best = 0.0; int tb = -1, ov = -1;
+        Best B{0.0, -1, -1, -1};
         const int wlo = wave_min_i32(T.lo);
 
-        // ---- candidates from earlier batches, one 64-source tile at a time
-        for (int t0 = wlo & ~63; t0 < i0; t0 += 64) {
-            const int sidx = t0 + lane;
-            const double tsc = score[sidx];
-            const int ttb = tbn[sidx];
-            const int smeta = src[sidx].meta;
-            const int sk = PGA_KIND(smeta);
-            const bool dead = (sk == 1 || sk == 2) && ttb == -1;   // gene end never reached: connects to nothing
+        // ---- phase F: sources of earlier batches, tiles dealt round-robin to the W waves
+        for (int t0 = (wlo & ~63) + 64 * wave; t0 < i0; t0 += 64 * W) {
+            const int sidx = t0 + lane;                       // < i0 <= n
+            SrcLane S;
+            {
+                const DpSrc r = src[sidx];
+                S.ndx = r.ndx; S.stop_val = r.stop_val; S.meta = r.meta; S.cs = r.cs; S.x0 = r.x[0]; S.x1 = r.x[1]; S.x2 = r.x[2];
+                S.score = score[sidx]; S.tbn = tbn[sidx];
+            }
+            const int sk = PGA_KIND(S.meta);
+            const bool dead = (sk == 1 || sk == 2) && S.tbn == -1;   // gene end never reached: connects to nothing (ref: :110-114)
             unsigned long long visit = __ballot(sidx >= wlo && !dead);
             while (visit) {
                 const int k = __builtin_ctzll(visit);
                 visit &= visit - 1;
-                const int j = t0 + k;
-                const DpSrc s = src[j];
-                const double sj = readlane_f64(tsc, k);
-                const int tbnj = __builtin_amdgcn_readlane(ttb, k);
-                eval_source(j, s.ndx, s.stop_val, s.meta, s.cs, s.x[0], s.x[1], s.x[2], sj, tbnj, T, negc, s_igm, best, tb, ov);
+                visit_source(k, t0 + k, S, T, negc, s_igm, B);
             }
         }
-        // ---- candidates inside this batch: lane k is final once the loop reaches source i0+k
-        const int kmax = min(63, n - 1 - i0);
-        for (int k = 0; k < kmax; k++) {
-            const int j = i0 + k;
-            const DpSrc s = src[j];
-            const int sk = PGA_KIND(s.meta);
-            const int tbk = __builtin_amdgcn_readlane(tb, k);
-            if ((sk == 1 || sk == 2) && tbk == -1) continue;
-            const double sj = readlane_f64(best, k);
-            int tbnj = 0;
-            if (sk == 1) tbnj = src[tbk].ndx;
-            eval_source(j, s.ndx, s.stop_val, s.meta, s.cs, s.x[0], s.x[1], s.x[2], sj, tbnj, T, negc, s_igm, best, tb, ov);
+        if (W > 1) {
+            s_pval[wave][lane] = B.val; s_ptb[wave][lane] = B.tb; s_pov[wave][lane] = B.ov; s_ptbn[wave][lane] = B.tbn;
+            __syncthreads();
         }
-        if (act) {
-            score[T.i] = best; traceb[T.i] = tb; ovm[T.i] = (int8_t)ov;
-            tbn[T.i] = tb < 0 ? -1 : src[tb].ndx;
-            if ((T.kind == 1 || T.kind == 2) && best >= end_best) { end_best = best; end_idx = T.i; end_tb = tb; }
+        if (wave == 0) {
+            if (W > 1) {
+#pragma unroll 4
+                for (int w = 1; w < W; w++) {
+                    const double v = s_pval[w][lane]; const int t = s_ptb[w][lane];
+                    if (t != -1 && (v > B.val || (v == B.val && t > B.tb))) { B.val = v; B.tb = t; B.ov = s_pov[w][lane]; B.tbn = s_ptbn[w][lane]; }
+                }
+            }
+            // ---- phase I: sources inside this batch are the lanes themselves
+            const int kmax = min(63, n - 1 - i0);
+            for (int k = 0; k < kmax; k++) {
+                const int sk = PGA_KIND(__builtin_amdgcn_readlane(T.meta, k));
+                const int tbk = __builtin_amdgcn_readlane(B.tb, k);
+                if ((sk == 1 || sk == 2) && tbk == -1) continue;
+                SrcLane S;
+                S.ndx = T.ndx; S.stop_val = T.stop_val; S.meta = T.meta; S.tbn = B.tbn;
+                S.cs = T.cs; S.x0 = T.x0; S.x1 = T.x1; S.x2 = T.x2; S.score = B.val;
+                visit_source(k, i0 + k, S, T, negc, s_igm, B);
+            }
+            if (act) {
+                score[T.i] = B.val; traceb[T.i] = B.tb; ovm[T.i] = (int8_t)B.ov; tbn[T.i] = B.tb < 0 ? -1 : B.tbn;
+                if ((T.kind == 1 || T.kind == 2) && B.val >= end_best) { end_best = B.val; end_idx = T.i; end_tb = B.tb; }
+            }
         }
+        if (W > 1) __syncthreads();      // the batch's stores are visible to the whole workgroup from here on
     }
+    if (wave != 0) return;
     // highest score among gene-end nodes, ties to the largest index (the reference scans from the end with '>')
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
@@ -282,7 +326,13 @@ void pga_launch_dp(const ChainDesc* d_chains, int n_chains, const ModelConst* d_
                    int final, hipStream_t st) {
     (void)final;
     if (n_chains <= 0) return;
-    hipLaunchKernelGGL(k_dp_wave, dim3(n_chains), dim3(64), 0, st,
-                       d_chains, buf.src, buf.tgt, d_models, buf.score, buf.traceb, buf.tbn, buf.ov_mark,
-                       buf.max_index, buf.max_score, buf.ipath);
+#define PGA_DP_LAUNCH(WAVES) hipLaunchKernelGGL(k_dp_chain<WAVES>, dim3(n_chains), dim3(64 * WAVES), 0, st, d_chains, buf.src, buf.tgt, \
+        d_models, buf.score, buf.traceb, buf.tbn, buf.ov_mark, buf.max_index, buf.max_score, buf.ipath)
+    // few chains: latency-bound, give each chain a whole workgroup; many chains: one wave each fills the chip
+    int waves = n_chains >= 4096 ? 1 : (n_chains >= 1024 ? 4 : 16);
+    if (const char* e = getenv("PGA_DP_WAVES")) { const int v = atoi(e); if (v == 1 || v == 4 || v == 16) waves = v; }   // tuning / tests
+    if (waves == 1) PGA_DP_LAUNCH(1);
+    else if (waves == 4) PGA_DP_LAUNCH(4);
+    else PGA_DP_LAUNCH(16);
+#undef PGA_DP_LAUNCH
 }

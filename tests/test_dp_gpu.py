@@ -92,3 +92,14 @@ def test_dp_tiny_and_empty_inputs(ctx):
 def test_training_pass_is_rejected_loudly(ctx):
     with pytest.raises(ValueError):
         ctx.score_connections([0], [0], [0], [1], [0.0], [0.0], [0.0], [0.0], np.zeros((1, 3)), 4.35, final=False)
+
+
+@pytest.mark.parametrize("waves", ["1", "4", "16"])
+def test_dp_every_wave_count(ctx, waves, monkeypatch):
+    # the launcher picks 1, 4 or 16 wavefronts per chain from the chain count; force each variant
+    monkeypatch.setenv("PGA_DP_WAVES", waves)
+    seq = read_fasta("MIIJ01000039.fna.gz")[0][1]
+    tinf = orc.Training.load(golden_path("SRR492066.training.bin.gz"))
+    check(ctx, seq, tinf, is_meta=True)
+    seq = synthetic_contig(150000, 0.62, 5)
+    check(ctx, seq, tinf, is_meta=True)
