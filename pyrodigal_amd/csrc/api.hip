@@ -143,6 +143,8 @@ extern "C" int pga_score_connections(pga_ctx* c, int32_t n, const int32_t* ndx, 
     HIP_TRY(c, db.alloc(&buf.src, N)); HIP_TRY(c, db.alloc(&buf.tgt, N)); HIP_TRY(c, db.alloc(&buf.score, N));
     HIP_TRY(c, db.alloc(&buf.traceb, N)); HIP_TRY(c, db.alloc(&buf.tbn, N)); HIP_TRY(c, db.alloc(&buf.ov_mark, N));
     HIP_TRY(c, db.alloc(&buf.max_index, 1)); HIP_TRY(c, db.alloc(&buf.max_score, 1)); HIP_TRY(c, db.alloc(&buf.ipath, 1));
+    HIP_TRY(c, db.alloc(&buf.A, N)); HIP_TRY(c, db.alloc(&buf.V[0], N)); HIP_TRY(c, db.alloc(&buf.V[1], N)); HIP_TRY(c, db.alloc(&buf.V[2], N));
+    HIP_TRY(c, db.alloc(&buf.hv, N)); HIP_TRY(c, db.alloc(&buf.hi, N));
     HIP_TRY(c, db.alloc(&d_chain, 1)); HIP_TRY(c, db.alloc(&d_mc, 1));
     hipStream_t st = c->stream;
 #define UP(dst, srcp, bytes) HIP_TRY(c, hipMemcpyAsync(dst, srcp, bytes, hipMemcpyHostToDevice, st))

@@ -29,6 +29,7 @@
 
 #include <limits.h>
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -108,12 +109,40 @@ k_dp_prepare(const ChainDesc* __restrict__ chains, int n_chains, int64_t node_be
         lo = (a > 0 && ndx[a - 1] == my_stop) ? a - 1 : 0;
     }
     lo = lo < PGA_MAX_NODE_DIST ? 0 : lo - PGA_MAX_NODE_DIST;
-    t.lo = lo; t._pad = 0;
+    t.lo = lo; t.p_near = lo;
+    for (int k = 0; k < 3; k++) { t.a[k] = 0; t.b[k] = 0; t.c[k] = -1; t._pad[k] = 0; }
+    // static index ranges over the sorted positions of nodes [0, i)
+    auto lower = [&](int v) { int a = 0, b = i; while (a < b) { const int m = (a + b) >> 1; if (ndx[m] < v) a = m + 1; else b = m; } return a; };   // first ndx >= v
+    auto upper = [&](int v) { int a = 0, b = i; while (a < b) { const int m = (a + b) >> 1; if (ndx[m] <= v) a = m + 1; else b = m; } return a; };  // first ndx > v
+    if (kind == 0 || kind == 3) t.p_near = max(lo, lower(my_ndx - 3 * PGA_OPER_DIST));
+    if (kind == 1) t.a[0] = max(lo, upper(my_stop));
+    if (kind == 2) {
+        const int u = upper(my_stop) - 1;     // last node at position stop_val: the reverse one if both strands have a node there
+        t.a[0] = (u >= lo && ndx[u] == my_stop && strand[u] != 1 && type[u] == PGA_T_STOP) ? u : -1;
+        t.a[1] = max(lo, upper(my_stop - 4)); t.a[2] = max(t.a[1], lower(my_stop + PGA_MAX_OPP_OVLP - 5));
+    }
+    if (kind == 3) {
+        for (int k = 0; k < 3; k++) {
+            if (!((meta >> (4 + k)) & 1)) continue;
+            t.a[k] = max(lo, upper(t.n3stop[k] - 5));
+            t.b[k] = min(t.p_near, max(t.a[k], lower(t.n3stop[k] + PGA_MAX_OPP_OVLP - 5)));
+            if (t.b[k] < t.a[k]) t.b[k] = t.a[k];
+        }
+        int seen = 0;                          // latest reverse stop of each frame before i
+        for (int j = i - 1; j >= lo && seen != 7; j--) {
+            if (strand[j] == 1 || type[j] != PGA_T_STOP) continue;
+            const int fj = ndx[j] % 3;
+            if (seen & (1 << fj)) continue;
+            seen |= 1 << fj;
+            if (stopv[j] > my_ndx && ((meta >> (4 + fj)) & 1)) t.c[fj] = j;
+        }
+    }
     src[g] = s; tgt[g] = t;
 }
 
 struct Target {
-    int kind, frame, ndx, stop_val, meta, lo, i;
+    int kind, frame, ndx, stop_val, meta, lo, i, p_near;
+    int a0, a1, a2, b0, b1, b2, c0, c1, c2;
     double cs, csd, x0, x1, x2;
     int n3n0, n3n1, n3n2, n3s0, n3s1, n3s2;
 };
@@ -197,6 +226,253 @@ __device__ __forceinline__ void visit_source(const int k, const int j, const Src
             w = mf != -1 ? maxval : negc;
         }
         take(B, ok, sj + w, j, mf, s_ndx);
+    }
+}
+
+// Per-lane (non-uniform) evaluation of one (source j, target) pair: same arithmetic as visit_source,
+// every field loaded by the lane itself.  Used for the few pairs that need the exact pairwise term.
+__device__ __forceinline__ void pair_eval(const int j, const DpSrc* __restrict__ src, const double* score, const int* tbn,
+                                          const Target& T, const double negc, const double* s_igm, Best& B) {
+    const int s_meta = src[j].meta, s_ndx = src[j].ndx;
+    const int sk = PGA_KIND(s_meta), sf = PGA_FRAME(s_meta);
+    const int tbnj = tbn[j];
+    if ((sk == 1 || sk == 2) && tbnj == -1) return;
+    const double sj = score[j];
+    bool ok = (j >= T.lo) && (j < T.i);
+    double w = 0.0; int mf = -1;
+    if (sk == 0) {
+        ok = ok && T.kind == 1 && T.frame == sf && T.stop_val < s_ndx;
+        w = src[j].cs;
+    } else if (sk == 2) {
+        const bool a = T.kind == 0 && s_ndx < T.ndx;
+        const bool b = T.kind == 3 && s_ndx < T.ndx - 2;
+        ok = ok && (a || b);
+        w = b ? igm_apart(T.ndx - s_ndx, negc, s_igm) : negc;
+    } else if (sk == 3) {
+        const int s_stop = src[j].stop_val;
+        const bool a = T.kind == 2 && T.frame == sf && s_stop > T.ndx;
+        const bool b = T.kind == 3 && s_stop > T.ndx && PGA_SPVALID(T.meta, sf);
+        ok = ok && (a || b);
+        w = a ? T.cs : sel3(sf, T.x0, T.x1, T.x2);
+    } else {
+        if (T.kind == 0) {
+            ok = ok && (s_ndx + 2 < T.ndx);
+            w = igm_apart(T.ndx - s_ndx, negc, s_igm);
+        } else if (T.kind == 1) {
+            ok = ok && T.stop_val < s_ndx && PGA_SPVALID(s_meta, T.frame);
+            w = src[j].x[T.frame];
+        } else if (T.kind == 2) {
+            const int ovlp = (s_ndx + 2) - (T.stop_val - 2) + 1;
+            ok = ok && !(T.stop_val - 2 >= s_ndx + 2) && ovlp < PGA_MAX_OPP_OVLP
+                    && (s_ndx - T.stop_val) < (T.ndx - s_ndx + 3)
+                    && (s_ndx - T.stop_val) < (T.stop_val - 3 - tbnj);
+            w = T.csd;
+        } else {
+            const int left = s_ndx + 2, right = T.ndx - 2;
+            ok = ok && left < right;
+            double maxval = 0.0;
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const int n3s = sel3i(q, T.n3s0, T.n3s1, T.n3s2), n3n = sel3i(q, T.n3n0, T.n3n1, T.n3n2);
+                const double cur = sel3(q, T.x0, T.x1, T.x2);
+                const int ovlp = left - n3s + 3;
+                const bool tk = PGA_SPVALID(T.meta, q) && ovlp > 0 && ovlp < PGA_MAX_OPP_OVLP && ovlp < n3n - left
+                                && ovlp < n3s - tbnj - 2 && cur > maxval;
+                if (tk) { mf = q; maxval = cur; }
+            }
+            w = mf != -1 ? maxval : negc;
+        }
+    }
+    take(B, ok, sj + w, j, mf, s_ndx);
+}
+
+// One wavefront per chain; the far field of the window is never scanned source by source.
+//
+// Every candidate value score[j] + w(j, i) whose w does not depend on the target is stored once,
+// when node j becomes final:
+//     A[j]    = score[j] + igm_diff          gene end j  -> any gene begin further than 3*OPER_DIST
+//     V[f][j] = score[j] + cs[j]             forward start j of frame f -> the forward stop of its ORF
+//             = score[j] + x[j][f]           forward stop j -> forward stop of frame f (operon)
+// and the ascending ">=" scan of the reference equals a lexicographic (value, index) maximum, so
+//   * a gene-begin target (F5 / R3) takes the maximum of A over [lo, p_near) from an 8-ary max tree
+//     (O(log) block reads instead of ~1000 pair evaluations) and evaluates exactly only the sources
+//     within 3*OPER_DIST bases, plus -- for R3 -- the forward stops that can overlap one of its
+//     overlapping starts and the one reverse stop per frame whose ORF covers it;
+//   * a forward stop scans V[frame] over its own ORF; a reverse start reads its own stop and the few
+//     forward stops that can overlap its 3' end;
+//   * sources inside the current 64-node batch are not final yet: they are walked in order, one
+//     wave-uniform source at a time (visit_source), which is the serial critical path of a chain.
+// For an R3 target the tree may also return A[j] of a forward stop whose exact term is larger
+// (the overlapping-start case adds a positive score): the exact pair is evaluated as well and wins.
+__global__ void __launch_bounds__(64)
+k_dp_tree(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src, const DpTgt* __restrict__ g_tgt,
+          const ModelConst* __restrict__ models, DpBuffers buf) {
+    __shared__ double s_igm[64];
+    __shared__ int s_levbase[12];
+    const ChainDesc cd = chains[blockIdx.x];
+    const int lane = threadIdx.x;
+    const int n = cd.n;
+    const ModelConst* mc = &models[cd.model];
+    s_igm[lane] = mc->igm[lane];
+    if (lane == 0) {
+        int base = 0;
+        for (int lev = 1; lev < 12; lev++) { s_levbase[lev] = base; base += (lev * 3 < 31) ? (n >> (3 * lev)) : 0; }
+        s_levbase[0] = 0;
+    }
+    __syncthreads();
+    const double negc = mc->negc;
+    const double NEG_INF = -__builtin_huge_val();
+    const DpSrc* __restrict__ src = g_src + cd.off;
+    const DpTgt* __restrict__ tgt = g_tgt + cd.off;
+    double* score = buf.score + cd.off; int32_t* traceb = buf.traceb + cd.off;
+    int32_t* tbn = buf.tbn + cd.off; int8_t* ovm = buf.ov_mark + cd.off;
+    double* A = buf.A + cd.off; double* V0 = buf.V[0] + cd.off; double* V1 = buf.V[1] + cd.off; double* V2 = buf.V[2] + cd.off;
+    double* hv = buf.hv + cd.off; int32_t* hi = buf.hi + cd.off;
+
+    double end_best = -1.0; int end_idx = -1, end_tb = -1;     // _find_max_index (ref: lib.pyx:1239-1251)
+
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        Target T;
+        T.i = i0 + lane;
+        const bool act = T.i < n;
+        {
+            const int ii = act ? T.i : n - 1;
+            const DpSrc me = src[ii]; const DpTgt mt = tgt[ii];
+            T.kind = PGA_KIND(me.meta); T.frame = PGA_FRAME(me.meta); T.meta = me.meta;
+            T.ndx = me.ndx; T.stop_val = me.stop_val; T.cs = me.cs; T.csd = me.cs + negc;
+            T.x0 = me.x[0]; T.x1 = me.x[1]; T.x2 = me.x[2];
+            T.n3n0 = mt.n3ndx[0]; T.n3n1 = mt.n3ndx[1]; T.n3n2 = mt.n3ndx[2];
+            T.n3s0 = mt.n3stop[0]; T.n3s1 = mt.n3stop[1]; T.n3s2 = mt.n3stop[2];
+            T.lo = act ? mt.lo : INT_MAX; T.p_near = mt.p_near;
+            T.a0 = mt.a[0]; T.a1 = mt.a[1]; T.a2 = mt.a[2]; T.b0 = mt.b[0]; T.b1 = mt.b[1]; T.b2 = mt.b[2];
+            T.c0 = mt.c[0]; T.c1 = mt.c[1]; T.c2 = mt.c[2];
+            if (!act) T.i = -1;
+        }
+        Best B{0.0, -1, -1, -1};
+        // ---- final sources (index < i0): per-lane work, no pair enumeration of the far field
+        if (act && i0 > 0) {
+            const int lim = min(T.i, i0);          // == i0
+            if (T.kind == 0 || T.kind == 3) {
+                // (1) far gene ends: 8-ary max tree over A on [lo, min(p_near, i0))
+                int lo = T.lo, hi2 = min(T.p_near, lim), lev = 0;
+                while (lo < hi2) {
+                    while (lo < hi2 && (lo & 7)) {
+                        const double v = lev == 0 ? A[lo] : hv[s_levbase[lev] + lo];
+                        const int ix = lev == 0 ? lo : hi[s_levbase[lev] + lo];
+                        take(B, true, v, ix, -1, 0);
+                        lo++;
+                    }
+                    while (lo < hi2 && (hi2 & 7)) {
+                        hi2--;
+                        const double v = lev == 0 ? A[hi2] : hv[s_levbase[lev] + hi2];
+                        const int ix = lev == 0 ? hi2 : hi[s_levbase[lev] + hi2];
+                        take(B, true, v, ix, -1, 0);
+                    }
+                    lo >>= 3; hi2 >>= 3; lev++;
+                }
+                // (2) sources within 3*OPER_DIST bases: exact pairs
+                for (int j = max(T.p_near, T.lo); j < lim; j++) pair_eval(j, src, score, tbn, T, negc, s_igm, B);
+                if (T.kind == 3) {
+                    // (3) forward stops that can overlap one of this node's overlapping starts (ref: _connection.h:296-325)
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        if (!PGA_SPVALID(T.meta, k)) continue;
+                        const int zb = min(sel3i(k, T.b0, T.b1, T.b2), lim);
+                        for (int j = sel3i(k, T.a0, T.a1, T.a2); j < zb; j++)
+                            if (PGA_KIND(src[j].meta) == 1) pair_eval(j, src, score, tbn, T, negc, s_igm, B);
+                    }
+                    // (4) the reverse stop of each frame whose ORF covers this node (ref: _connection.h:345-356)
+#pragma unroll
+                    for (int f = 0; f < 3; f++) {
+                        const int j = sel3i(f, T.c0, T.c1, T.c2);
+                        if (j >= 0 && j < lim) pair_eval(j, src, score, tbn, T, negc, s_igm, B);
+                    }
+                }
+            } else if (T.kind == 1) {
+                // forward stop: starts of its own ORF and operon partners, precomputed per target frame
+                const double* __restrict__ V = T.frame == 0 ? V0 : (T.frame == 1 ? V1 : V2);
+                for (int j = T.a0; j < lim; j++) take(B, true, V[j], j, -1, 0);
+            } else {
+                // reverse start: its own stop, then forward stops overlapping its 3' end (ref: _connection.h:228-254)
+                if (T.a0 >= 0 && T.a0 < lim) pair_eval(T.a0, src, score, tbn, T, negc, s_igm, B);
+                const int zb = min(T.a2, lim);
+                for (int j = T.a1; j < zb; j++)
+                    if (PGA_KIND(src[j].meta) == 1) pair_eval(j, src, score, tbn, T, negc, s_igm, B);
+            }
+            if (B.tb >= 0) B.tbn = src[B.tb].ndx;
+            else { B.val = 0.0; B.ov = -1; B.tbn = -1; }
+        }
+        // ---- sources inside this batch: the lanes themselves, in order
+        const int kmax = min(63, n - 1 - i0);
+        for (int k = 0; k < kmax; k++) {
+            const int sk = PGA_KIND(__builtin_amdgcn_readlane(T.meta, k));
+            const int tbk = __builtin_amdgcn_readlane(B.tb, k);
+            if ((sk == 1 || sk == 2) && tbk == -1) continue;
+            SrcLane S;
+            S.ndx = T.ndx; S.stop_val = T.stop_val; S.meta = T.meta; S.tbn = B.tbn;
+            S.cs = T.cs; S.x0 = T.x0; S.x1 = T.x1; S.x2 = T.x2; S.score = B.val;
+            visit_source(k, i0 + k, S, T, negc, s_igm, B);
+        }
+        // ---- the batch is final: store it with its far-field candidate values and extend the tree
+        double a_val = NEG_INF;
+        if (act) {
+            const bool alive = B.tb != -1;
+            score[T.i] = B.val; traceb[T.i] = B.tb; ovm[T.i] = (int8_t)B.ov; tbn[T.i] = alive ? B.tbn : -1;
+            double v0 = NEG_INF, v1 = NEG_INF, v2 = NEG_INF;
+            if (T.kind == 0) {
+                const double g = B.val + T.cs;
+                if (T.frame == 0) v0 = g; else if (T.frame == 1) v1 = g; else v2 = g;
+            } else if (T.kind == 1 && alive) {
+                a_val = B.val + negc;
+                if (PGA_SPVALID(T.meta, 0)) v0 = B.val + T.x0;
+                if (PGA_SPVALID(T.meta, 1)) v1 = B.val + T.x1;
+                if (PGA_SPVALID(T.meta, 2)) v2 = B.val + T.x2;
+            } else if (T.kind == 2 && alive) {
+                a_val = B.val + negc;
+            }
+            A[T.i] = a_val; V0[T.i] = v0; V1[T.i] = v1; V2[T.i] = v2;
+            if ((T.kind == 1 || T.kind == 2) && B.val >= end_best) { end_best = B.val; end_idx = T.i; end_tb = B.tb; }
+        }
+        if (i0 + 64 <= n) {
+            double rv = a_val; int ri = T.i;
+#pragma unroll
+            for (int m = 1; m <= 4; m <<= 1) {
+                const double ov2 = __shfl_xor(rv, m, 64); const int oi = __shfl_xor(ri, m, 64);
+                if (ov2 > rv || (ov2 == rv && oi > ri)) { rv = ov2; ri = oi; }
+            }
+            const int tile = i0 >> 6;
+            if ((lane & 7) == 0 && (n >> 3) > 0) { hv[s_levbase[1] + (i0 >> 3) + (lane >> 3)] = rv; hi[s_levbase[1] + (i0 >> 3) + (lane >> 3)] = ri; }
+#pragma unroll
+            for (int m = 8; m <= 32; m <<= 1) {
+                const double ov2 = __shfl_xor(rv, m, 64); const int oi = __shfl_xor(ri, m, 64);
+                if (ov2 > rv || (ov2 == rv && oi > ri)) { rv = ov2; ri = oi; }
+            }
+            if (lane == 0) { hv[s_levbase[2] + tile] = rv; hi[s_levbase[2] + tile] = ri; }
+            // higher levels: a block of 8 children closes when its last child does
+            int child = tile, lev = 2;
+            while ((child & 7) == 7 && (lev + 1) * 3 < 31 && (n >> (3 * (lev + 1))) > 0) {
+                double cv = NEG_INF; int ci = -1;
+                if (lane < 8) { cv = hv[s_levbase[lev] + child - 7 + lane]; ci = hi[s_levbase[lev] + child - 7 + lane]; }
+#pragma unroll
+                for (int m = 1; m <= 4; m <<= 1) {
+                    const double ov2 = __shfl_xor(cv, m, 64); const int oi = __shfl_xor(ci, m, 64);
+                    if (ov2 > cv || (ov2 == cv && oi > ci)) { cv = ov2; ci = oi; }
+                }
+                child >>= 3; lev++;
+                if (lane == 0) { hv[s_levbase[lev] + child] = cv; hi[s_levbase[lev] + child] = ci; }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double ob = __shfl_xor(end_best, m, 64);
+        const int oi = __shfl_xor(end_idx, m, 64);
+        const int ot = __shfl_xor(end_tb, m, 64);
+        if (ob > end_best || (ob == end_best && oi > end_idx)) { end_best = ob; end_idx = oi; end_tb = ot; }
+    }
+    if (lane == 0) {
+        buf.max_index[blockIdx.x] = end_idx; buf.max_score[blockIdx.x] = end_idx >= 0 ? end_best : 0.0;
+        buf.ipath[blockIdx.x] = (end_idx >= 0 && end_tb != -1) ? end_idx : -1;
     }
 }
 
@@ -328,6 +604,12 @@ void pga_launch_dp(const ChainDesc* d_chains, int n_chains, const ModelConst* d_
     if (n_chains <= 0) return;
 #define PGA_DP_LAUNCH(WAVES) hipLaunchKernelGGL(k_dp_chain<WAVES>, dim3(n_chains), dim3(64 * WAVES), 0, st, d_chains, buf.src, buf.tgt, \
         d_models, buf.score, buf.traceb, buf.tbn, buf.ov_mark, buf.max_index, buf.max_score, buf.ipath)
+    const char* kern = getenv("PGA_DP_KERNEL");
+    if (!kern || strcmp(kern, "scan") != 0) {
+        hipLaunchKernelGGL(k_dp_tree, dim3(n_chains), dim3(64), 0, st, d_chains, buf.src, buf.tgt, d_models, buf);
+        return;
+    }
+    // PGA_DP_KERNEL=scan: the window-scanning kernels (kept as an independent cross-check of the tree kernel)
     // few chains: latency-bound, give each chain a whole workgroup; many chains: one wave each fills the chip
     int waves = n_chains >= 4096 ? 1 : (n_chains >= 1024 ? 4 : 16);
     if (const char* e = getenv("PGA_DP_WAVES")) { const int v = atoi(e); if (v == 1 || v == 4 || v == 16) waves = v; }   // tuning / tests

@@ -508,7 +508,9 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
             DEVBUF(b2, double, "dp_score", tot_chain_nodes + 1) DEVBUF(b3, int32_t, "dp_traceb", tot_chain_nodes + 1)
             DEVBUF(b4, int32_t, "dp_tbn", tot_chain_nodes + 1) DEVBUF(b5, int8_t, "dp_ov", tot_chain_nodes + 1)
             DEVBUF(b6, int32_t, "dp_maxidx", NCH + 1) DEVBUF(b7, double, "dp_maxscore", NCH + 1) DEVBUF(b8, int32_t, "dp_ipath", NCH + 1)
-            dp = DpBuffers{b0, b1, b2, b3, b4, b5, b6, b7, b8};
+            DEVBUF(b9, double, "dp_A", tot_chain_nodes + 1) DEVBUF(b10, double, "dp_V0", tot_chain_nodes + 1) DEVBUF(b11, double, "dp_V1", tot_chain_nodes + 1)
+            DEVBUF(b12, double, "dp_V2", tot_chain_nodes + 1) DEVBUF(b13, double, "dp_hv", tot_chain_nodes + 1) DEVBUF(b14, int32_t, "dp_hi", tot_chain_nodes + 1)
+            dp = DpBuffers{b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, {b10, b11, b12}, b13, b14};
         }
         DEVBUF(d_chains, ChainDesc, "d_chains", NCH + NC + 1);
         PINBUF(h_maxidx, int32_t, "h_maxidx", NCH + 1);

@@ -28,12 +28,18 @@ struct __attribute__((aligned(64))) DpSrc {
     double  x[3];    // F3: cs(n3_k) + igm(j, n3_k);  R3: cs(n3_k) + igm(n3_k, i)   (n3_k = nodes[star_ptr[k]])
     double  _pad2[2];
 };
-// Per-node record only needed when the node is the target i. 32 bytes.
-struct __attribute__((aligned(32))) DpTgt {
+// Per-node record only needed when the node is the target i. 80 bytes.
+// The index ranges are static (positions only) and found by binary search in dp_prepare.
+struct __attribute__((aligned(16))) DpTgt {
     int32_t n3ndx[3];
     int32_t n3stop[3];
     int32_t lo;      // first candidate index of the window (ref: lib.pyx:1221-1233)
-    int32_t _pad;
+    int32_t p_near;  // F5 / R3 targets: first index whose ndx >= ndx - 3*OPER_DIST (closer sources need the exact intergenic term)
+    int32_t a[3];    // F3: a[0] = first index with ndx > stop_val (own ORF).  R5: a[0] = index of its own stop node,
+                     //     a[1], a[2] = index range of forward stops that can overlap its 3' end.  R3: a[k] = begin of zone k
+    int32_t b[3];    // R3: b[k] = end of the index range of forward stops that can overlap overlapping-start k
+    int32_t c[3];    // R3: c[f] = the one reverse stop of frame f whose ORF covers this node (operon candidate) or -1
+    int32_t _pad[3];
 };
 // Per-model constants of the connection scorer.
 struct ModelConst {
@@ -64,6 +70,10 @@ struct DpBuffers {
     double* score; int32_t* traceb; int32_t* tbn; int8_t* ov_mark;
     int32_t* max_index; double* max_score;    // per chain: _find_max_index and its score
     int32_t* ipath;                           // per chain: max_index, or -1 when that node has no traceb (ref: lib.pyx:1311)
+    // far-field candidate values of finalized nodes (see dp.hip)
+    double* A;                                // gene ends:  score + igm_diff                       (-inf when unusable)
+    double* V[3];                             // per target frame f: forward start of frame f: score + cs; forward stop: score + x[f]
+    double* hv; int32_t* hi;                  // 8-ary max tree over A: (value, index) of every complete block
 };
 
 // kernel launchers (dp.hip)

@@ -94,10 +94,13 @@ def test_training_pass_is_rejected_loudly(ctx):
         ctx.score_connections([0], [0], [0], [1], [0.0], [0.0], [0.0], [0.0], np.zeros((1, 3)), 4.35, final=False)
 
 
-@pytest.mark.parametrize("waves", ["1", "4", "16"])
-def test_dp_every_wave_count(ctx, waves, monkeypatch):
-    # the launcher picks 1, 4 or 16 wavefronts per chain from the chain count; force each variant
-    monkeypatch.setenv("PGA_DP_WAVES", waves)
+@pytest.mark.parametrize("variant", ["tree", "scan1", "scan4", "scan16"])
+def test_dp_kernel_variants_agree_with_oracle(ctx, variant, monkeypatch):
+    # default = tree kernel (far field from the max tree); PGA_DP_KERNEL=scan selects the window-scanning
+    # kernels with 1, 4 or 16 wavefronts per chain, kept as an independent cross-check
+    if variant.startswith("scan"):
+        monkeypatch.setenv("PGA_DP_KERNEL", "scan")
+        monkeypatch.setenv("PGA_DP_WAVES", variant[4:])
     seq = read_fasta("MIIJ01000039.fna.gz")[0][1]
     tinf = orc.Training.load(golden_path("SRR492066.training.bin.gz"))
     check(ctx, seq, tinf, is_meta=True)
