@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include <new>
 
@@ -145,6 +146,8 @@ extern "C" int pga_score_connections(pga_ctx* c, int32_t n, const int32_t* ndx, 
     HIP_TRY(c, db.alloc(&buf.max_index, 1)); HIP_TRY(c, db.alloc(&buf.max_score, 1)); HIP_TRY(c, db.alloc(&buf.ipath, 1));
     HIP_TRY(c, db.alloc(&buf.A, N)); HIP_TRY(c, db.alloc(&buf.V[0], N)); HIP_TRY(c, db.alloc(&buf.V[1], N)); HIP_TRY(c, db.alloc(&buf.V[2], N));
     HIP_TRY(c, db.alloc(&buf.hv, N)); HIP_TRY(c, db.alloc(&buf.hi, N));
+    buf.prof = nullptr;
+    if (getenv("PGA_DP_PROFILE")) { HIP_TRY(c, db.alloc(&buf.prof, 8)); HIP_TRY(c, hipMemsetAsync(buf.prof, 0, 64, c->stream)); }
     HIP_TRY(c, db.alloc(&d_chain, 1)); HIP_TRY(c, db.alloc(&d_mc, 1));
     hipStream_t st = c->stream;
 #define UP(dst, srcp, bytes) HIP_TRY(c, hipMemcpyAsync(dst, srcp, bytes, hipMemcpyHostToDevice, st))
@@ -167,6 +170,11 @@ extern "C" int pga_score_connections(pga_ctx* c, int32_t n, const int32_t* ndx, 
     int32_t mi = -1;
     HIP_TRY(c, hipMemcpyAsync(&mi, buf.max_index, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
+    if (buf.prof) {
+        unsigned long long pr[8]; HIP_TRY(c, hipMemcpy(pr, buf.prof, 64, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[pga dp profile] batches=%llu cycles/batch: far+near+zones=%.0f (tree<=%.0f near<=%.0f) in-batch=%.0f finalize=%.0f\n", pr[5],
+                (double)pr[0] / pr[5], (double)pr[3] / pr[5], (double)pr[4] / pr[5], (double)pr[1] / pr[5], (double)pr[2] / pr[5]);
+    }
     if (max_index) *max_index = mi;
     if (kernel_ms) { float ms = 0; HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1)); *kernel_ms = ms; }
     return PGA_OK;

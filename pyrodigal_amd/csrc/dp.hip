@@ -349,6 +349,8 @@ k_dp_tree(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src,
             if (!act) T.i = -1;
         }
         Best B{0.0, -1, -1, -1};
+        const bool prof = buf.prof != nullptr && blockIdx.x == 0;
+        unsigned long long tp0 = prof ? __builtin_readcyclecounter() : 0, tp1 = 0, tp2 = 0, tp3 = 0, tp4 = 0;
         // ---- final sources (index < i0): per-lane work, no pair enumeration of the far field
         if (act && i0 > 0) {
             const int lim = min(T.i, i0);          // == i0
@@ -370,8 +372,10 @@ k_dp_tree(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src,
                     }
                     lo >>= 3; hi2 >>= 3; lev++;
                 }
+                if (prof) tp1 = __builtin_readcyclecounter();
                 // (2) sources within 3*OPER_DIST bases: exact pairs
                 for (int j = max(T.p_near, T.lo); j < lim; j++) pair_eval(j, src, score, tbn, T, negc, s_igm, B);
+                if (prof) tp2 = __builtin_readcyclecounter();
                 if (T.kind == 3) {
                     // (3) forward stops that can overlap one of this node's overlapping starts (ref: _connection.h:296-325)
 #pragma unroll
@@ -402,6 +406,7 @@ k_dp_tree(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src,
             if (B.tb >= 0) B.tbn = src[B.tb].ndx;
             else { B.val = 0.0; B.ov = -1; B.tbn = -1; }
         }
+        if (prof) tp3 = __builtin_readcyclecounter();
         // ---- sources inside this batch: the lanes themselves, in order
         const int kmax = min(63, n - 1 - i0);
         for (int k = 0; k < kmax; k++) {
@@ -413,6 +418,7 @@ k_dp_tree(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src,
             S.cs = T.cs; S.x0 = T.x0; S.x1 = T.x1; S.x2 = T.x2; S.score = B.val;
             visit_source(k, i0 + k, S, T, negc, s_igm, B);
         }
+        if (prof) tp4 = __builtin_readcyclecounter();
         // ---- the batch is final: store it with its far-field candidate values and extend the tree
         double a_val = NEG_INF;
         if (act) {
@@ -461,6 +467,18 @@ k_dp_tree(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src,
                 child >>= 3; lev++;
                 if (lane == 0) { hv[s_levbase[lev] + child] = cv; hi[s_levbase[lev] + child] = ci; }
             }
+        }
+        if (prof) {
+            // wave-level: the slowest lane of each per-lane section bounds the wave; report the maxima
+            const unsigned long long tp5 = __builtin_readcyclecounter();
+            unsigned long long d_tree = tp1 > tp0 ? tp1 - tp0 : 0, d_near = tp2 > tp1 && tp1 ? tp2 - tp1 : 0;
+            unsigned long long d_f = tp3 - tp0, d_i = tp4 - tp3, d_fin = tp5 - tp4;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                d_tree = max(d_tree, (unsigned long long)__shfl_xor((long long)d_tree, m, 64));
+                d_near = max(d_near, (unsigned long long)__shfl_xor((long long)d_near, m, 64));
+            }
+            if (lane == 0) { buf.prof[0] += d_f; buf.prof[1] += d_i; buf.prof[2] += d_fin; buf.prof[3] += d_tree; buf.prof[4] += d_near; buf.prof[5] += 1; }
         }
     }
 #pragma unroll

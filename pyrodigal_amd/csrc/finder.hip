@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <map>
 #include <new>
 #include <thread>
@@ -33,6 +34,17 @@ struct FinderState {
 };
 
 namespace {
+
+struct StageTimer {
+    bool on; std::chrono::steady_clock::time_point t0; const char* names[32]; double ms[32]; int n = 0;
+    StageTimer() : on(getenv("PGA_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char* name) {
+        if (!on || n >= 32) return;
+        auto t1 = std::chrono::steady_clock::now();
+        names[n] = name; ms[n++] = std::chrono::duration<double, std::milli>(t1 - t0).count(); t0 = t1;
+    }
+    ~StageTimer() { if (on) { fprintf(stderr, "[pga timing]"); for (int i = 0; i < n; i++) fprintf(stderr, " %s=%.2fms", names[i], ms[i]); fprintf(stderr, "\n"); } }
+};
 
 #define HT(ctx, expr) do { int rc__ = pga_hip_try_(ctx, (expr), #expr); if (rc__ != PGA_OK) return rc__; } while (0)
 
@@ -405,6 +417,7 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
 
     const std::vector<ContigDesc>& ct = batch->ct;
     const int64_t total = batch->total;
+    StageTimer tm;
 
     if (NC > 0 && total > 0) {
         const char* d_seq = batch->d_seq;
@@ -445,6 +458,7 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
         HT(c, hipGetLastError());
         HT(c, hipStreamSynchronize(st));
 
+        tm.mark("extract+sync");
         // ---- plan the (contig, model) chains (ref: lib.pyx:5335-5362) ------------------------
         std::vector<std::vector<ChainDesc>> gch(NG);     // per group, in (contig, model) order
         for (int i = 0; i < NC; i++) {
@@ -510,7 +524,7 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
             DEVBUF(b6, int32_t, "dp_maxidx", NCH + 1) DEVBUF(b7, double, "dp_maxscore", NCH + 1) DEVBUF(b8, int32_t, "dp_ipath", NCH + 1)
             DEVBUF(b9, double, "dp_A", tot_chain_nodes + 1) DEVBUF(b10, double, "dp_V0", tot_chain_nodes + 1) DEVBUF(b11, double, "dp_V1", tot_chain_nodes + 1)
             DEVBUF(b12, double, "dp_V2", tot_chain_nodes + 1) DEVBUF(b13, double, "dp_hv", tot_chain_nodes + 1) DEVBUF(b14, int32_t, "dp_hi", tot_chain_nodes + 1)
-            dp = DpBuffers{b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, {b10, b11, b12}, b13, b14};
+            dp = DpBuffers{b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, {b10, b11, b12}, b13, b14, nullptr};
         }
         DEVBUF(d_chains, ChainDesc, "d_chains", NCH + NC + 1);
         PINBUF(h_maxidx, int32_t, "h_maxidx", NCH + 1);
@@ -518,6 +532,7 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
         PINBUF(h_maxscore, double, "h_maxscore", NCH + 1);
         HT(c, hipMemcpyAsync(d_chains, chains.data(), sizeof(ChainDesc) * NCH, hipMemcpyHostToDevice, st));
 
+        tm.mark("plan+alloc");
         const ScoreParams sp{P.closed, P.meta, P.max_overlap, 0};
         const pga_training* d_models = (const pga_training*)c->d_models_raw;
         for (int g = 0; g < NG; g++) {
@@ -541,6 +556,7 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
         HT(c, hipStreamSynchronize(st));
         { float ms = 0; HT(c, hipEventElapsedTime(&ms, f->e_dp0[0], f->e_dp1[0])); R->pub.t_dp_ms = NCH > 0 ? ms : 0.0; }
 
+        tm.mark("score+dp+sync");
         // ---- pick the winning model per contig (ref: lib.pyx:5364-5367, strict '>' from -100) ---
         std::vector<int> win_chain(NC, -1);
         {
@@ -583,6 +599,7 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
                 pga_launch_score(d_chains + NCH + r_c0[g], nch, r_n0[g], nn, d_dig, d_ct, ga[g], d_models, f->d_msc, c->d_model_const, ca, sp, st);
             }
         }
+        tm.mark("winners+rescore_launch");
         // ---- gather the winners and bring them home ------------------------------------------------
         std::vector<std::vector<WinDesc>> wg(NG);
         std::vector<int64_t> out_off(NC, 0);
@@ -638,6 +655,7 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
         HT(c, hipStreamSynchronize(st));
         { float ms = 0; HT(c, hipEventElapsedTime(&ms, f->e_start, f->e_stop)); R->pub.t_total_ms = ms; }
 
+        tm.mark("gather+d2h+sync");
         // ---- host tail per contig ------------------------------------------------------------------
         std::vector<int32_t> tracef((size_t)out_nodes + 1, -1);
         std::vector<uint8_t> elim((size_t)out_nodes + 1, 0);
@@ -670,6 +688,7 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
             worker();
             for (auto& t : th) t.join();
         }
+        tm.mark("host_tail");
         // ---- results -----------------------------------------------------------------------------------
         int64_t ngenes = 0;
         for (int i = 0; i < NC; i++) ngenes += (int64_t)cg[i].size();
@@ -741,6 +760,7 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
             }
         }
     }
+    tm.mark("results");
     R->pub.contigs = R->contigs.data();
     R->pub.genes = R->genes.data();
     R->pub.n_genes = (int64_t)R->genes.size();

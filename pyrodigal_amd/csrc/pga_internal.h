@@ -74,6 +74,7 @@ struct DpBuffers {
     double* A;                                // gene ends:  score + igm_diff                       (-inf when unusable)
     double* V[3];                             // per target frame f: forward start of frame f: score + cs; forward stop: score + x[f]
     double* hv; int32_t* hi;                  // 8-ary max tree over A: (value, index) of every complete block
+    unsigned long long* prof;                 // optional [8] phase cycle counters of chain 0 (PGA_DP_PROFILE), else NULL
 };
 
 // kernel launchers (dp.hip)

@@ -29,6 +29,23 @@ __device__ __forceinline__ int find_contig(const ContigDesc* __restrict__ ct, in
     return lo;
 }
 
+// Contig / chain of element g for a block whose first element is block_first: one binary search per
+// block (thread 0), then a short forward walk per thread (blocks rarely span more than two contigs).
+__device__ __forceinline__ int block_contig(const ContigDesc* __restrict__ ct, int n, int64_t block_first, int64_t g, int* s_slot) {
+    if (threadIdx.x == 0) *s_slot = find_contig(ct, n, block_first);
+    __syncthreads();
+    int c = *s_slot;
+    while (c + 1 < n && ct[c + 1].base <= g) c++;
+    return c;
+}
+__device__ __forceinline__ int block_chain(const ChainDesc* __restrict__ ch, int n, int64_t block_first, int64_t g, int* s_slot) {
+    if (threadIdx.x == 0) *s_slot = find_chain(ch, n, block_first);
+    __syncthreads();
+    int c = *s_slot;
+    while (c + 1 < n && ch[c + 1].off <= g) c++;
+    return c;
+}
+
 // strand-local base i of a contig (reverse strand is virtual; ref: _sequence.h:45-55)
 __device__ __forceinline__ int sbase(const uint8_t* __restrict__ d, int L, int i, int strand) {
     return strand == 1 ? d[i] : (d[L - 1 - i] ^ 3);
@@ -71,36 +88,64 @@ __device__ __forceinline__ bool is_stop_at(const uint8_t* __restrict__ d, int L,
 
 // ---------------------------------------------------------------------------------- digitise
 // ref: lib.pyx:664-697 (Sequence._build)
+__device__ __forceinline__ int digit_of(int ch, int& gc, int& unk) {
+    switch (ch) {
+        case 'A': case 'a': return NA;
+        case 'T': case 't': return NT;
+        case 'G': case 'g': gc++; return NG;
+        case 'C': case 'c': gc++; return NC;
+        default: unk++; return NN;
+    }
+}
+
+// 16 bases per thread (one 16-byte load and store per lane); GC / unknown counts are reduced per
+// wave and added with one atomic when the whole wave sits inside one contig.
 __global__ void __launch_bounds__(256)
 k_digitize(const char* __restrict__ seq, uint8_t* __restrict__ dig, int64_t total,
            const ContigDesc* __restrict__ ct, int n_contigs, int32_t* __restrict__ gc_count, int32_t* __restrict__ unk_count) {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = g < total;
-    int c = 0, isgc = 0, isunk = 0;
+    __shared__ int s_c0;
+    const int64_t blk0 = (int64_t)blockIdx.x * 4096;
+    const int64_t g0 = blk0 + (int64_t)threadIdx.x * 16;
+    const bool in = g0 < total;
+    int c = block_contig(ct, n_contigs, blk0, in ? g0 : blk0, &s_c0);
+    int gc = 0, unk = 0;
+    bool one_contig = true;
     if (in) {
-        c = find_contig(ct, n_contigs, g);
-        int d;
-        switch (seq[g]) {
-            case 'A': case 'a': d = NA; break;
-            case 'T': case 't': d = NT; break;
-            case 'G': case 'g': d = NG; isgc = 1; break;
-            case 'C': case 'c': d = NC; isgc = 1; break;
-            default: d = NN; isunk = 1;
+        const int64_t next = ct[c + 1 <= n_contigs ? c + 1 : n_contigs].base;     // ct has n_contigs + 1 entries
+        if (g0 + 16 <= total && g0 + 16 <= next) {
+            const uint4 v = *reinterpret_cast<const uint4*>(seq + g0);
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+            unsigned o[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                unsigned r = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) r |= (unsigned)digit_of((w[q] >> (8 * k)) & 0xff, gc, unk) << (8 * k);
+                o[q] = r;
+            }
+            *reinterpret_cast<uint4*>(dig + g0) = make_uint4(o[0], o[1], o[2], o[3]);
+        } else {
+            one_contig = false;
+            for (int k = 0; k < 16 && g0 + k < total; k++) {
+                const int64_t g = g0 + k;
+                while (c + 1 < n_contigs && ct[c + 1].base <= g) c++;
+                int a = 0, u = 0;
+                dig[g] = (uint8_t)digit_of(seq[g], a, u);
+                if (a) atomicAdd(&gc_count[c], 1);
+                if (u) atomicAdd(&unk_count[c], 1);
+            }
         }
-        dig[g] = (uint8_t)d;
     }
-    // wave-level counting: one atomic per wave when all its lanes sit in one contig
     const int c0 = __builtin_amdgcn_readfirstlane(c);
-    const bool uniform = __all(!in || c == c0);
+    const bool uniform = __all(!in || (one_contig && c == c0));
     if (uniform) {
-        const unsigned long long mg = __ballot(in && isgc), mu = __ballot(in && isunk);
-        if ((threadIdx.x & 63) == 0) {
-            if (mg) atomicAdd(&gc_count[c0], __popcll(mg));
-            if (mu) atomicAdd(&unk_count[c0], __popcll(mu));
-        }
-    } else if (in) {
-        if (isgc) atomicAdd(&gc_count[c], 1);
-        if (isunk) atomicAdd(&unk_count[c], 1);
+        int a = in ? gc : 0, u = in ? unk : 0;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m, 64); u += __shfl_xor(u, m, 64); }
+        if ((threadIdx.x & 63) == 0) { if (a) atomicAdd(&gc_count[c0], a); if (u) atomicAdd(&unk_count[c0], u); }
+    } else if (in && one_contig) {
+        if (gc) atomicAdd(&gc_count[c], gc);
+        if (unk) atomicAdd(&unk_count[c], unk);
     }
 }
 
@@ -111,11 +156,12 @@ k_digitize(const char* __restrict__ seq, uint8_t* __restrict__ dig, int64_t tota
 __global__ void __launch_bounds__(256)
 k_extract_orfs(const uint8_t* __restrict__ dig, int64_t total, const ContigDesc* __restrict__ ct, int n_contigs,
                int tt, int closed, int min_gene, int min_edge_gene, GroupArrays ga) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= 2 * total) return;
-    const int strand = gid < total ? 1 : -1;
-    const int64_t g = gid < total ? gid : gid - total;
-    const int c = find_contig(ct, n_contigs, g);
+    __shared__ int s_c0;
+    const int strand = blockIdx.y == 0 ? 1 : -1;
+    const int64_t blk0 = (int64_t)blockIdx.x * blockDim.x;
+    const int64_t g = blk0 + threadIdx.x;
+    const int c = block_contig(ct, n_contigs, blk0, g < total ? g : blk0, &s_c0);
+    if (g >= total) return;
     const int L = ct[c].len;
     const int64_t base = ct[c].base;
     const uint8_t* __restrict__ d = dig + base;
@@ -253,11 +299,13 @@ k_scan_final(const uint8_t* __restrict__ nf_fwd, const uint8_t* __restrict__ nf_
 // (Prodigal compare_nodes; ref: lib.pyx:2489-2493).
 __global__ void __launch_bounds__(256)
 k_compact_nodes(int64_t total, const ContigDesc* __restrict__ ct, int n_contigs, GroupArrays ga) {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ int s_c0;
+    const int64_t blk0 = (int64_t)blockIdx.x * blockDim.x;
+    const int64_t g = blk0 + threadIdx.x;
+    const int c = block_contig(ct, n_contigs, blk0, g < total ? g : blk0, &s_c0);
     if (g >= total) return;
     const int f = ga.nf_fwd[g], r = ga.nf_rev[g];
     if (!(f | r)) return;
-    const int c = find_contig(ct, n_contigs, g);
     const int pos = (int)(g - ct[c].base);
     const int idx = ga.pre_nodes[g];
     if (f) {
@@ -312,10 +360,12 @@ __global__ void __launch_bounds__(256)
 k_coding_score(const ChainDesc* __restrict__ chains, int n_chains, int64_t node_begin, int64_t total,
                const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct, GroupArrays ga,
                const pga_training* __restrict__ models, const ModelScoreConst* __restrict__ msc, ChainArrays ca) {
-    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= total) return;
-    g += node_begin;
-    const int c = find_chain(chains, n_chains, g);
+    __shared__ int s_c0;
+    const int64_t blk0 = node_begin + (int64_t)blockIdx.x * blockDim.x;
+    const int64_t g = blk0 + threadIdx.x;
+    const bool in_range = g < node_begin + total;
+    const int c = block_chain(chains, n_chains, blk0, in_range ? g : blk0, &s_c0);
+    if (!in_range) return;
     const ChainDesc ch = chains[c];
     const int64_t t = ch.topo_off + (g - ch.off);
     if (ga.type[t] != PGA_T_STOP) return;
@@ -437,10 +487,12 @@ __global__ void __launch_bounds__(256)
 k_score_starts(const ChainDesc* __restrict__ chains, int n_chains, int64_t node_begin, int64_t total,
                const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct, GroupArrays ga,
                const pga_training* __restrict__ models, ChainArrays ca, ScoreParams sp) {
-    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= total) return;
-    g += node_begin;
-    const int c = find_chain(chains, n_chains, g);
+    __shared__ int s_c0;
+    const int64_t blk0 = node_begin + (int64_t)blockIdx.x * blockDim.x;
+    const int64_t g = blk0 + threadIdx.x;
+    const bool in_range = g < node_begin + total;
+    const int c = block_chain(chains, n_chains, blk0, in_range ? g : blk0, &s_c0);
+    if (!in_range) return;
     const ChainDesc ch = chains[c];
     const int i = (int)(g - ch.off), n = ch.n;
     const int64_t tb = ch.topo_off;
@@ -562,10 +614,12 @@ k_score_starts(const ChainDesc* __restrict__ chains, int n_chains, int64_t node_
 __global__ void __launch_bounds__(256)
 k_overlapping_starts(const ChainDesc* __restrict__ chains, int n_chains, int64_t node_begin, int64_t total,
                      GroupArrays ga, const ModelConst* __restrict__ mcs, ChainArrays ca, int maxov) {
-    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= total) return;
-    g += node_begin;
-    const int c = find_chain(chains, n_chains, g);
+    __shared__ int s_c0;
+    const int64_t blk0 = node_begin + (int64_t)blockIdx.x * blockDim.x;
+    const int64_t g = blk0 + threadIdx.x;
+    const bool in_range = g < node_begin + total;
+    const int c = block_chain(chains, n_chains, blk0, in_range ? g : blk0, &s_c0);
+    if (!in_range) return;
     const ChainDesc ch = chains[c];
     const int i = (int)(g - ch.off), n = ch.n;
     const int64_t tb = ch.topo_off;
@@ -611,14 +665,14 @@ int64_t pga_scan_tiles(int64_t total) { return (total + 1 + SCAN_TILE - 1) / SCA
 void pga_launch_digitize(const char* d_seq, uint8_t* d_dig, int64_t total, const ContigDesc* d_ct, int n_contigs,
                          int32_t* d_gc, int32_t* d_unk, hipStream_t st) {
     if (total <= 0) return;
-    hipLaunchKernelGGL(k_digitize, dim3(nblocks(total, 256)), dim3(256), 0, st, d_seq, d_dig, total, d_ct, n_contigs, d_gc, d_unk);
+    hipLaunchKernelGGL(k_digitize, dim3(nblocks(total, 4096)), dim3(256), 0, st, d_seq, d_dig, total, d_ct, n_contigs, d_gc, d_unk);
 }
 
 void pga_launch_extract(const uint8_t* d_dig, int64_t total, const ContigDesc* d_ct, int n_contigs, int tt,
                         const pga_params& p, const GroupArrays& ga, int2* d_tile_sum, int32_t* d_pre_gc, int write_gc,
                         hipStream_t st) {
     if (total <= 0) return;
-    hipLaunchKernelGGL(k_extract_orfs, dim3(nblocks(2 * total, 256)), dim3(256), 0, st, d_dig, total, d_ct, n_contigs, tt,
+    hipLaunchKernelGGL(k_extract_orfs, dim3(nblocks(total, 256), 2), dim3(256), 0, st, d_dig, total, d_ct, n_contigs, tt,
                        p.closed, p.min_gene, p.min_edge_gene, ga);
     const int tiles = (int)pga_scan_tiles(total);
     hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(256), 0, st, ga.nf_fwd, ga.nf_rev, d_dig, total, d_tile_sum);

@@ -1,0 +1,59 @@
+"""CPU-only checks of the boundary: the shared library loads and exports every symbol that
+include/pyrodigal_amd.h declares; no compute call is made (there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "pyrodigal_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pga_[a-z_]+)\s*\(", text)))
+
+
+def test_header_declares_expected_entry_points():
+    names = declared_functions()
+    for must in ("pga_create", "pga_set_models", "pga_score_connections", "pga_find_genes_batch",
+                 "pga_batch_create", "pga_find_genes", "pga_result_free"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from pyrodigal_amd import _cabi
+    if not os.path.exists(_cabi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(_cabi.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(lib, name), name
+    assert sorted(_cabi.EXPORTS) == declared_functions()
+
+
+def test_struct_sizes_match_the_header():
+    from pyrodigal_amd import _cabi
+    assert ctypes.sizeof(_cabi.Params) == 24
+    assert ctypes.sizeof(_cabi.Gene) == 88
+    assert ctypes.sizeof(_cabi.ContigResult) == 40
+    assert _cabi.TRAINING_SIZE == 558392
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from pyrodigal_amd import _cabi
+    with pytest.raises(RuntimeError):
+        _cabi.Context(0)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "pyrodigal_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".pyx", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in text.lower() or f == "benchdata.py" and "oracle" in text.lower() and "import oracle" not in text, f
