@@ -91,7 +91,7 @@ extern "C" int pga_set_models(pga_ctx* c, const pga_training* const* models, int
     if (c->d_model_const) { hipFree(c->d_model_const); c->d_model_const = nullptr; }
     c->models.clear();
     c->n_models = 0;
-    if (n_models == 0) return PGA_OK;
+    if (n_models == 0) return pga_finder_models_changed(c);
     std::vector<ModelConst> mcs(n_models);
     for (int i = 0; i < n_models; i++) {
         if (!models[i]) return fail(c, PGA_EINVAL, "pga_set_models: model %d is NULL", i);

@@ -397,7 +397,9 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
         return PGA_EINVAL;
     }
     const int32_t n_contigs = batch->n;
-    if (c->n_models <= 0 || !c->finder) { c->err = "pga_find_genes: no model loaded (call pga_set_models first)"; return PGA_EINVAL; }
+    if (!c->finder) { int rc0 = pga_finder_models_changed(c); if (rc0) return rc0; }
+    // meta mode over an empty bin collection is legal and finds nothing (ref: tests/test_gene_finder.py:316-324)
+    if (c->n_models <= 0 && !pp->meta) { c->err = "pga_find_genes: no model loaded (call pga_set_models first)"; return PGA_EINVAL; }
     const pga_params P = *pp;
     if (P.min_gene <= 0 || P.min_edge_gene <= 0 || P.max_overlap < 0 || P.max_overlap > P.min_gene) {
         c->err = "pga_find_genes: invalid min_gene / min_edge_gene / max_overlap";   // ref: lib.pyx:5169-5181

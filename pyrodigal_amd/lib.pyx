@@ -1,0 +1,702 @@
+# cython: language_level=3, boundscheck=False, wraparound=False, cdivision=True
+"""Cython host layer: pyrodigal's `GeneFinder.find_genes()` / `Genes` API over the HIP C-ABI.
+
+Same names, arguments, defaults, validation and error types as the reference
+(/root/reference/src/pyrodigal/lib.pyx; citations below are into that file), but every
+per-base / per-node computation happens in `libpyrodigal_amd.so` on an MI355X.  There is no
+CPU path: without the library or a gfx950 device, calls raise `RuntimeError`.
+
+Not provided this round (raise `NotImplementedError`): `GeneFinder.train`, `mask=True`,
+`Gene.translate` and the GFF / GenBank / FASTA writers.
+"""
+import gzip
+import threading
+
+import numpy as np
+
+from cpython.bytes cimport PyBytes_FromStringAndSize, PyBytes_AS_STRING
+from libc.stdint cimport int8_t, uint8_t, int32_t, int64_t
+from libc.stdlib cimport malloc, free
+from libc.math cimport exp, fmax
+
+cdef extern from "pyrodigal_amd.h" nogil:
+    ctypedef struct pga_ctx
+    ctypedef struct pga_batch
+    ctypedef struct pga_training
+    ctypedef struct pga_params:
+        int32_t closed
+        int32_t min_gene
+        int32_t min_edge_gene
+        int32_t max_overlap
+        int32_t meta
+        int32_t want_nodes
+    ctypedef struct pga_gene:
+        int32_t contig
+        int32_t begin
+        int32_t end
+        int32_t start_ndx
+        int32_t stop_ndx
+        int8_t strand
+        uint8_t partial_begin
+        uint8_t partial_end
+        uint8_t start_type
+        uint8_t rbs[2]
+        uint8_t mot_len
+        uint8_t mot_spacer
+        int32_t mot_ndx
+        float gc_cont
+        double cscore
+        double sscore
+        double rscore
+        double uscore
+        double tscore
+        double mot_score
+    ctypedef struct pga_nodes:
+        int32_t n
+        int32_t* ndx
+        int32_t* stop_val
+        int32_t* traceb
+        int32_t* tracef
+        int32_t* star_ptr
+        uint8_t* type
+        uint8_t* edge
+        uint8_t* elim
+        uint8_t* rbs
+        int8_t* strand
+        int8_t* ov_mark
+        float* gc_cont
+        double* cscore
+        double* sscore
+        double* rscore
+        double* uscore
+        double* tscore
+        double* score
+        double* mot_score
+        int32_t* mot_ndx
+        uint8_t* mot_len
+        uint8_t* mot_spacer
+        uint8_t* mot_spacendx
+    ctypedef struct pga_contig_result:
+        int32_t model
+        int32_t n_nodes
+        int64_t gene_begin
+        int32_t n_genes
+        double gc
+        double score
+    ctypedef struct pga_result:
+        int32_t n_contigs
+        int64_t n_genes
+        pga_contig_result* contigs
+        pga_gene* genes
+        pga_nodes* nodes
+        double t_total_ms
+        double t_dp_ms
+        int64_t node_passes
+    int PGA_OK, PGA_EINVAL, PGA_ENOMEM, PGA_EDEVICE, PGA_ENODEVICE
+    int pga_create(int device, pga_ctx** out)
+    void pga_destroy(pga_ctx*)
+    const char* pga_last_error(const pga_ctx*)
+    int pga_set_models(pga_ctx*, const pga_training* const* models, int n_models)
+    int pga_find_genes_batch(pga_ctx*, int32_t n, const char* const* seqs, const int64_t* lens,
+                             const pga_params*, pga_result** out)
+    void pga_result_free(pga_result*)
+
+# --- constants (ref: lib.pyx:166-228) ------------------------------------------------------
+MIN_SINGLE_GENOME = 20000
+IDEAL_SINGLE_GENOME = 100000
+TRANSLATION_TABLES = frozenset(set(range(1, 7)) | set(range(9, 17)) | set(range(21, 27)) | {29, 30, 32, 33})
+PRODIGAL_VERSION = "v2.6.3+c1e2d36"
+TRAINING_INFO_SIZE = 558392
+
+_RBS_MOTIF = [
+    None, "GGA/GAG/AGG", "3Base/5BMM", "4Base/6BMM", "AGxAG", "AGxAG", "GGA/GAG/AGG", "GGxGG", "GGxGG",
+    "AGxAG", "AGGAG(G)/GGAGG", "AGGA/GGAG/GAGG", "AGGA/GGAG/GAGG", "GGA/GAG/AGG", "GGxGG", "AGGA",
+    "GGAG/GAGG", "AGxAGG/AGGxGG", "AGxAGG/AGGxGG", "AGxAGG/AGGxGG", "AGGAG/GGAGG", "AGGAG", "AGGAG",
+    "GGAGG", "GGAGG", "AGGAGG", "AGGAGG", "AGGAGG",
+]
+_RBS_SPACER = [
+    None, "3-4bp", "13-15bp", "13-15bp", "11-12bp", "3-4bp", "11-12bp", "11-12bp", "3-4bp", "5-10bp",
+    "13-15bp", "3-4bp", "11-12bp", "5-10bp", "5-10bp", "5-10bp", "5-10bp", "11-12bp", "3-4bp", "5-10bp",
+    "11-12bp", "3-4bp", "5-10bp", "3-4bp", "5-10bp", "11-12bp", "3-4bp", "5-10bp",
+]
+_NODE_TYPE = ["ATG", "GTG", "TTG", "Edge"]
+_COMPLEMENT = bytes.maketrans(b"ACGTN", b"TGCAN")
+
+
+cdef object _raise_for(pga_ctx* ctx, int rc, str what):
+    cdef bytes msg = pga_last_error(ctx) if ctx != NULL else b""
+    text = "%s: %s" % (what, msg.decode("utf-8", "replace"))
+    if rc == PGA_EINVAL:
+        raise ValueError(text)
+    if rc == PGA_ENOMEM:
+        raise MemoryError(text)
+    if rc == PGA_ENODEVICE:
+        raise RuntimeError(what + ": no gfx950 (MI355X) device visible; pyrodigal_amd has no CPU fallback")
+    raise RuntimeError(text)
+
+
+# --- TrainingInfo / MetagenomicBins (ref: lib.pyx:3898-4282, 4888-5069) -------------------
+cdef class TrainingInfo:
+    """The parameters of one gene model: the reference's 558 392-byte ``struct _training``."""
+    cdef readonly object raw      # numpy uint8[558392]
+
+    def __init__(self, double gc=0.5, *, int translation_table=11, double start_weight=4.35, object raw=None):
+        if raw is not None:
+            arr = np.frombuffer(bytes(raw), dtype=np.uint8).copy()
+            if arr.size != TRAINING_INFO_SIZE:
+                raise ValueError("a raw training info must be %d bytes (got %d)" % (TRAINING_INFO_SIZE, arr.size))
+            self.raw = arr
+        else:
+            if translation_table not in TRANSLATION_TABLES:
+                raise ValueError("%d is not a valid translation table index" % translation_table)
+            self.raw = np.zeros(TRAINING_INFO_SIZE, dtype=np.uint8)
+            self._f64(0)[0] = gc
+            self._i32(8)[0] = translation_table
+            self._f64(16)[0] = start_weight
+            self._i32(72)[0] = 1
+
+    @classmethod
+    def load(cls, fp):
+        """Load a training info from a file object or path (raw dump, optionally gzipped) -- ref: lib.pyx:3910-3953."""
+        if hasattr(fp, "read"):
+            data = fp.read()
+        else:
+            opener = gzip.open if str(fp).endswith(".gz") else open
+            with opener(fp, "rb") as f:
+                data = f.read()
+        if len(data) != TRAINING_INFO_SIZE:
+            raise EOFError("Expected %d bytes, only read %d" % (TRAINING_INFO_SIZE, len(data)))
+        return cls(raw=data)
+
+    def dump(self, fp):
+        """Write the raw structure to a file object -- ref: lib.pyx:4865-4885."""
+        fp.write(self.raw.tobytes())
+
+    def _f64(self, int off, int n=1):
+        return self.raw[off:off + 8 * n].view(np.float64)
+
+    def _i32(self, int off):
+        return self.raw[off:off + 4].view(np.int32)
+
+    def __repr__(self):
+        return "<pyrodigal_amd.lib.TrainingInfo gc=%r start_weight=%r translation_table=%r uses_sd=%r>" % (
+            self.gc, self.start_weight, self.translation_table, self.uses_sd)
+
+    @property
+    def gc(self):
+        return float(self._f64(0)[0])
+
+    @gc.setter
+    def gc(self, double v):
+        if v < 0 or v > 1:
+            raise ValueError("Invalid GC percent: %r" % v)
+        self._f64(0)[0] = v
+
+    @property
+    def translation_table(self):
+        return int(self._i32(8)[0])
+
+    @translation_table.setter
+    def translation_table(self, int v):
+        if v not in TRANSLATION_TABLES:
+            raise ValueError("%d is not a valid translation table index" % v)
+        self._i32(8)[0] = v
+
+    @property
+    def start_weight(self):
+        return float(self._f64(16)[0])
+
+    @property
+    def bias(self):
+        return tuple(self._f64(24, 3))
+
+    @property
+    def type_weights(self):
+        return tuple(self._f64(48, 3))
+
+    @property
+    def uses_sd(self):
+        return bool(self._i32(72)[0])
+
+    @property
+    def rbs_weights(self):
+        return self._f64(80, 28).copy()
+
+    @property
+    def missing_motif_weight(self):
+        return float(self._f64(525616)[0])
+
+    @property
+    def coding_statistics(self):
+        return self._f64(525624, 4096).copy()
+
+
+cdef class MetagenomicBin:
+    """A pre-trained model with a description (ref: lib.pyx:4888-4946)."""
+    cdef readonly TrainingInfo training_info
+    cdef readonly str description
+
+    def __init__(self, TrainingInfo training_info not None, str description=""):
+        self.training_info = training_info
+        self.description = description
+
+    def __repr__(self):
+        return "<pyrodigal_amd.lib.MetagenomicBin description=%r>" % self.description
+
+
+cdef class MetagenomicBins:
+    """An immutable collection of `MetagenomicBin` (ref: lib.pyx:4950-5066)."""
+    cdef readonly tuple _bins
+
+    def __init__(self, object iterable=()):
+        bins = tuple(iterable)
+        for b in bins:
+            if not isinstance(b, MetagenomicBin):
+                raise TypeError("expected MetagenomicBin, got %s" % type(b).__name__)
+        self._bins = bins
+
+    def __len__(self):
+        return len(self._bins)
+
+    def __getitem__(self, index):
+        if isinstance(index, slice):
+            return MetagenomicBins(self._bins[index])
+        return self._bins[index]
+
+    def __iter__(self):
+        return iter(self._bins)
+
+
+# Prodigal's 50 built-in models are not part of the reference checkout (un-vendored submodule), so the
+# default collection is empty: meta mode needs `metagenomic_bins=`.
+METAGENOMIC_BINS = MetagenomicBins()
+
+
+# --- Sequence / Nodes / Gene / Genes ----------------------------------------------------------
+cdef class Sequence:
+    """The input as ASCII bytes with its GC content (digitising itself happens on the device)."""
+    cdef readonly bytes data
+    cdef readonly double gc
+
+    def __init__(self, object sequence, bint mask=False, size_t mask_size=50):
+        if mask:
+            raise NotImplementedError("region masking is not available in the HIP path yet")
+        if isinstance(sequence, Sequence):
+            self.data = (<Sequence> sequence).data
+        elif isinstance(sequence, str):
+            self.data = sequence.encode("ascii", "replace")
+        else:
+            self.data = bytes(memoryview(sequence))
+        self.gc = 0.0
+
+    def __len__(self):
+        return len(self.data)
+
+    def __str__(self):
+        up = self.data.upper()
+        return "".join(chr(c) if c in b"ACGT" else "N" for c in up)
+
+
+cdef class Node:
+    """A read-only view of one node (ref: lib.pyx:1437-1552)."""
+    cdef readonly Nodes owner
+    cdef readonly ssize_t i
+
+    def __getattr__(self, name):
+        arr = self.owner._f.get(name)
+        if arr is None:
+            raise AttributeError(name)
+        v = arr[self.i]
+        return v.item() if hasattr(v, "item") and getattr(v, "ndim", 0) == 0 else v
+
+    @property
+    def index(self):
+        return int(self.owner._f["ndx"][self.i])
+
+    @property
+    def type(self):
+        return _NODE_TYPE[3 if self.owner._f["edge"][self.i] else int(self.owner._f["type"][self.i])] if self.owner._f["type"][self.i] != 3 else "Stop"
+
+
+cdef class Nodes:
+    """The nodes of one sequence for its final model, as struct-of-arrays (ref: lib.pyx:1652-1795)."""
+    cdef readonly dict _f
+
+    def __init__(self):
+        self._f = {}
+
+    def __len__(self):
+        return len(self._f["ndx"]) if "ndx" in self._f else 0
+
+    def __getitem__(self, ssize_t i):
+        cdef ssize_t n = len(self)
+        if i < 0:
+            i += n
+        if i < 0 or i >= n:
+            raise IndexError("node index out of range")
+        cdef Node nd = Node.__new__(Node)
+        nd.owner = self
+        nd.i = i
+        return nd
+
+    def array(self, str name):
+        """The numpy array of one field (ndx, stop_val, type, strand, edge, cscore, sscore, ...)."""
+        return self._f[name]
+
+
+cdef double _confidence(double score, double st_wt) noexcept nogil:   # Prodigal gene.c calculate_confidence
+    cdef double r = score / st_wt, conf
+    if r < 41:
+        conf = exp(r)
+        conf = (conf / (conf + 1)) * 100.0
+    else:
+        conf = 99.99
+    return fmax(conf, 50.0)
+
+
+cdef class Gene:
+    """A single predicted gene (ref: lib.pyx:2610-3047)."""
+    cdef readonly Genes owner
+    cdef pga_gene g
+
+    @property
+    def begin(self):
+        return self.g.begin
+
+    @property
+    def end(self):
+        return self.g.end
+
+    @property
+    def strand(self):
+        return self.g.strand
+
+    @property
+    def partial_begin(self):
+        return bool(self.g.partial_begin)
+
+    @property
+    def partial_end(self):
+        return bool(self.g.partial_end)
+
+    @property
+    def start_type(self):
+        return _NODE_TYPE[self.g.start_type]
+
+    cdef tuple _rbs(self):
+        cdef TrainingInfo t = self.owner.training_info
+        w = t._f64(80, 28)
+        cdef double st = t.start_weight
+        cdef double r1 = w[self.g.rbs[0]] * st, r2 = w[self.g.rbs[1]] * st
+        cdef double ms = self.g.mot_score * st
+        if t.uses_sd:
+            k = self.g.rbs[0] if r1 > r2 else self.g.rbs[1]
+            return _RBS_MOTIF[k], _RBS_SPACER[k]
+        elif t.missing_motif_weight > -0.5 and r1 > r2 and r1 > ms:
+            return _RBS_MOTIF[self.g.rbs[0]], _RBS_SPACER[self.g.rbs[0]]
+        elif t.missing_motif_weight > -0.5 and r2 >= r1 and r2 > ms:
+            return _RBS_MOTIF[self.g.rbs[1]], _RBS_SPACER[self.g.rbs[1]]
+        elif self.g.mot_len == 0:
+            return None, None
+        else:
+            motif = "".join("AGCT"[(self.g.mot_ndx >> (2 * i)) & 3] for i in range(self.g.mot_len))
+            return motif, "%dbp" % self.g.mot_spacer
+
+    @property
+    def rbs_motif(self):
+        return self._rbs()[0]
+
+    @property
+    def rbs_spacer(self):
+        return self._rbs()[1]
+
+    @property
+    def gc_cont(self):
+        return self.g.gc_cont
+
+    @property
+    def translation_table(self):
+        return self.owner.training_info.translation_table
+
+    @property
+    def cscore(self):
+        return self.g.cscore
+
+    @property
+    def rscore(self):
+        return self.g.rscore
+
+    @property
+    def sscore(self):
+        return self.g.sscore
+
+    @property
+    def tscore(self):
+        return self.g.tscore
+
+    @property
+    def uscore(self):
+        return self.g.uscore
+
+    @property
+    def score(self):
+        return self.g.cscore + self.g.sscore
+
+    @property
+    def start_node(self):
+        return self.owner.nodes[self.g.start_ndx] if self.owner.nodes is not None else None
+
+    @property
+    def stop_node(self):
+        return self.owner.nodes[self.g.stop_ndx] if self.owner.nodes is not None else None
+
+    cpdef double confidence(self):
+        return _confidence(self.g.cscore + self.g.sscore, self.owner.training_info.start_weight)
+
+    def sequence(self):
+        """The nucleotide sequence of the gene (reverse-complemented on the reverse strand)."""
+        cdef bytes s = self.owner.sequence.data[self.g.begin - 1:self.g.end].upper()
+        s = bytes(c if c in b"ACGT" else 78 for c in s)
+        if self.g.strand != 1:
+            s = s.translate(_COMPLEMENT)[::-1]
+        return s.decode("ascii")
+
+    def translate(self, *args, **kwargs):
+        raise NotImplementedError("translation is host-side output code, not part of the HIP path")
+
+    cpdef str _gene_data(self, object sequence_id, ssize_t index):
+        motif, spacer = self._rbs()
+        return "ID={}_{};partial={}{};start_type={};rbs_motif={};rbs_spacer={};gc_cont={:.3f}".format(
+            sequence_id, index + 1, int(self.g.partial_begin), int(self.g.partial_end),
+            _NODE_TYPE[self.g.start_type], motif, spacer, self.g.gc_cont)
+
+    cpdef str _score_data(self):
+        return "conf={:.2f};score={:.2f};cscore={:.2f};sscore={:.2f};rscore={:.2f};uscore={:.2f};tscore={:.2f};".format(
+            self.confidence(), self.score, self.cscore, self.sscore, self.rscore, self.uscore, self.tscore)
+
+
+cdef class Genes:
+    """The genes of one sequence (ref: lib.pyx:3049-3186)."""
+    cdef readonly Sequence sequence
+    cdef readonly object nodes              # Nodes, or None when the finder was created with keep_nodes=False
+    cdef readonly object training_info
+    cdef readonly object metagenomic_bin
+    cdef readonly bint meta
+    cdef readonly double score
+    cdef readonly ssize_t _num_seq
+    cdef list _genes
+
+    def __len__(self):
+        return len(self._genes)
+
+    def __getitem__(self, index):
+        return self._genes[index]
+
+    def __iter__(self):
+        return iter(self._genes)
+
+    def __bool__(self):
+        return len(self._genes) > 0
+
+
+# --- GeneFinder (ref: lib.pyx:5073-5575) ------------------------------------------------------
+cdef class GeneFinder:
+    """A configurable gene finder for genomes and metagenomes, running on one MI355X."""
+    cdef readonly bint meta
+    cdef readonly bint closed
+    cdef readonly bint mask
+    cdef readonly int min_mask
+    cdef readonly int min_gene
+    cdef readonly int min_edge_gene
+    cdef readonly int max_overlap
+    cdef readonly str backend
+    cdef readonly object training_info
+    cdef readonly MetagenomicBins metagenomic_bins
+    cdef readonly int device
+    cdef readonly bint keep_nodes
+    cdef object lock
+    cdef ssize_t _num_seq
+    cdef pga_ctx* ctx
+    cdef bint models_loaded
+
+    def __cinit__(self):
+        self.ctx = NULL
+        self._num_seq = 1
+        self.models_loaded = False
+
+    def __init__(self, TrainingInfo training_info=None, *, bint meta=False, MetagenomicBins metagenomic_bins=None,
+                 bint closed=False, bint mask=False, int min_mask=50, int min_gene=90, int min_edge_gene=60,
+                 int max_overlap=60, str backend="detect", int device=0, bint keep_nodes=True):
+        # argument validation as in the reference (lib.pyx:5169-5181)
+        if meta and training_info is not None:
+            raise ValueError("cannot use a training info in meta mode.")
+        if min_gene <= 0:
+            raise ValueError("`min_gene` must be strictly positive")
+        if min_edge_gene <= 0:
+            raise ValueError("`min_edge_gene` must be strictly positive")
+        if min_mask < 0:
+            raise ValueError("`min_mask` must be positive")
+        if max_overlap < 0:
+            raise ValueError("`max_overlap` must be positive")
+        elif max_overlap > min_gene:
+            raise ValueError("`max_overlap` must be lower than `min_gene`")
+        if backend not in ("detect", "hip"):
+            raise ValueError("unsupported backend %r: this build only has the HIP (gfx950) backend" % backend)
+        if mask:
+            raise NotImplementedError("region masking is not available in the HIP path yet")
+        self.meta = meta
+        self.closed = closed
+        self.mask = mask
+        self.min_mask = min_mask
+        self.min_gene = min_gene
+        self.min_edge_gene = min_edge_gene
+        self.max_overlap = max_overlap
+        self.backend = backend
+        self.training_info = training_info
+        self.metagenomic_bins = METAGENOMIC_BINS if metagenomic_bins is None else metagenomic_bins
+        self.device = device
+        self.keep_nodes = keep_nodes
+        self.lock = threading.Lock()
+
+    def __dealloc__(self):
+        if self.ctx != NULL:
+            pga_destroy(self.ctx)
+            self.ctx = NULL
+
+    def __repr__(self):
+        parts = []
+        if self.training_info is not None:
+            parts.append("training_info=%r" % self.training_info)
+        if self.meta:
+            parts.append("meta=True")
+        if self.closed:
+            parts.append("closed=True")
+        return "pyrodigal_amd.lib.GeneFinder(%s)" % ", ".join(parts)
+
+    cdef int _ensure_models(self) except -1:
+        cdef int rc, n, i
+        cdef const pga_training** ptrs
+        cdef list blobs
+        if self.ctx == NULL:
+            rc = pga_create(self.device, &self.ctx)
+            if rc != PGA_OK:
+                self.ctx = NULL
+                _raise_for(NULL, rc, "pga_create")
+        if self.models_loaded:
+            return 0
+        if self.meta:
+            blobs = [(<MetagenomicBin> b).training_info.raw for b in self.metagenomic_bins]
+        else:
+            blobs = [(<TrainingInfo> self.training_info).raw]
+        n = len(blobs)
+        ptrs = <const pga_training**> malloc(sizeof(void*) * max(n, 1))
+        if ptrs == NULL:
+            raise MemoryError()
+        try:
+            for i in range(n):
+                ptrs[i] = <const pga_training*> <size_t> blobs[i].ctypes.data
+            rc = pga_set_models(self.ctx, ptrs, n)
+        finally:
+            free(ptrs)
+        if rc != PGA_OK:
+            _raise_for(self.ctx, rc, "pga_set_models")
+        self.models_loaded = True
+        return 0
+
+    def find_genes(self, object sequence):
+        """Find all the genes in the input DNA sequence (ref: lib.pyx:5400-5469)."""
+        return self.find_genes_batch([sequence])[0]
+
+    def find_genes_batch(self, object sequences):
+        """`find_genes` for many sequences in one device pass; returns one `Genes` per input, in order."""
+        if not self.meta and self.training_info is None:
+            raise RuntimeError("cannot find genes without having trained in single mode")
+        cdef list seqs = [s if isinstance(s, Sequence) else Sequence(s) for s in sequences]
+        cdef int n = len(seqs), i, j, rc
+        cdef const char** ptrs = <const char**> malloc(sizeof(char*) * max(n, 1))
+        cdef int64_t* lens = <int64_t*> malloc(sizeof(int64_t) * max(n, 1))
+        cdef pga_params p
+        cdef pga_result* res = NULL
+        cdef list out = []
+        cdef Genes genes
+        cdef Gene gene
+        cdef pga_contig_result* cr
+        if ptrs == NULL or lens == NULL:
+            free(ptrs); free(lens)
+            raise MemoryError()
+        p.closed = self.closed; p.min_gene = self.min_gene; p.min_edge_gene = self.min_edge_gene
+        p.max_overlap = self.max_overlap; p.meta = self.meta; p.want_nodes = self.keep_nodes
+        try:
+            for i in range(n):
+                ptrs[i] = PyBytes_AS_STRING((<Sequence> seqs[i]).data)
+                lens[i] = len((<Sequence> seqs[i]).data)
+            with self.lock:       # one context = one stream and one set of scratch buffers
+                self._ensure_models()
+                first_id = self._num_seq
+                self._num_seq += n
+                with nogil:
+                    rc = pga_find_genes_batch(self.ctx, n, ptrs, lens, &p, &res)
+                if rc != PGA_OK:
+                    _raise_for(self.ctx, rc, "pga_find_genes_batch")
+            for i in range(n):
+                cr = &res.contigs[i]
+                genes = Genes.__new__(Genes)
+                genes.sequence = seqs[i]
+                (<Sequence> seqs[i]).gc = cr.gc
+                genes.meta = self.meta
+                genes._num_seq = first_id + i
+                genes.score = cr.score
+                if self.meta:
+                    if cr.model >= 0:
+                        genes.metagenomic_bin = self.metagenomic_bins[cr.model]
+                        genes.training_info = genes.metagenomic_bin.training_info
+                    else:
+                        genes.metagenomic_bin = genes.training_info = None
+                else:
+                    genes.metagenomic_bin = None
+                    genes.training_info = self.training_info
+                genes.nodes = _copy_nodes(&res.nodes[i]) if (self.keep_nodes and res.nodes != NULL) else None
+                genes._genes = []
+                for j in range(cr.n_genes):
+                    gene = Gene.__new__(Gene)
+                    gene.owner = genes
+                    gene.g = res.genes[cr.gene_begin + j]
+                    genes._genes.append(gene)
+                out.append(genes)
+        finally:
+            free(ptrs); free(lens)
+            if res != NULL:
+                pga_result_free(res)
+        return out
+
+    def train(self, object sequence, *sequences, bint force_nonsd=False, double start_weight=4.35, int translation_table=11):
+        """Training (ref: lib.pyx:5471-5575) is not part of the device path; load a `TrainingInfo` instead."""
+        if self.meta:
+            raise RuntimeError("cannot use training sequence in metagenomic mode")
+        if translation_table not in TRANSLATION_TABLES:
+            raise ValueError("%d is not a valid translation table index" % translation_table)
+        raise NotImplementedError("GeneFinder.train is not implemented on the HIP path; "
+                                  "pass a TrainingInfo (TrainingInfo.load) to the constructor")
+
+
+cdef object _arr(const void* ptr, ssize_t nbytes, object dtype):
+    if ptr == NULL or nbytes == 0:
+        return np.zeros(0, dtype=dtype)
+    return np.frombuffer(PyBytes_FromStringAndSize(<const char*> ptr, nbytes), dtype=dtype)
+
+
+cdef Nodes _copy_nodes(const pga_nodes* nd):
+    cdef Nodes out = Nodes()
+    cdef ssize_t n = nd.n
+    f = out._f
+    f["ndx"] = _arr(nd.ndx, 4 * n, np.int32); f["stop_val"] = _arr(nd.stop_val, 4 * n, np.int32)
+    f["traceb"] = _arr(nd.traceb, 4 * n, np.int32); f["tracef"] = _arr(nd.tracef, 4 * n, np.int32)
+    f["star_ptr"] = _arr(nd.star_ptr, 12 * n, np.int32).reshape(-1, 3)
+    f["type"] = _arr(nd.type, n, np.uint8); f["edge"] = _arr(nd.edge, n, np.uint8); f["elim"] = _arr(nd.elim, n, np.uint8)
+    f["rbs"] = _arr(nd.rbs, 2 * n, np.uint8).reshape(-1, 2)
+    f["strand"] = _arr(nd.strand, n, np.int8); f["ov_mark"] = _arr(nd.ov_mark, n, np.int8)
+    f["gc_cont"] = _arr(nd.gc_cont, 4 * n, np.float32)
+    f["cscore"] = _arr(nd.cscore, 8 * n, np.float64); f["sscore"] = _arr(nd.sscore, 8 * n, np.float64)
+    f["rscore"] = _arr(nd.rscore, 8 * n, np.float64); f["uscore"] = _arr(nd.uscore, 8 * n, np.float64)
+    f["tscore"] = _arr(nd.tscore, 8 * n, np.float64); f["score"] = _arr(nd.score, 8 * n, np.float64)
+    return out
