@@ -172,8 +172,9 @@ extern "C" int pga_score_connections(pga_ctx* c, int32_t n, const int32_t* ndx, 
     HIP_TRY(c, hipStreamSynchronize(st));
     if (buf.prof) {
         unsigned long long pr[8]; HIP_TRY(c, hipMemcpy(pr, buf.prof, 64, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[pga dp profile] batches=%llu cycles/batch: far+near+zones=%.0f (tree<=%.0f near<=%.0f) in-batch=%.0f finalize=%.0f\n", pr[5],
-                (double)pr[0] / pr[5], (double)pr[3] / pr[5], (double)pr[4] / pr[5], (double)pr[1] / pr[5], (double)pr[2] / pr[5]);
+        const double nbp = pr[5] ? (double)pr[5] : 1.0;
+        fprintf(stderr, "[pga dp profile] batches=%llu cycles/batch: serial wave: far=%.0f walk=%.0f finalize=%.0f | helper weights=%.0f helper far=%.0f | iteration=%.0f | dynamic steps/batch=%.1f\n",
+                pr[5], pr[0] / nbp, pr[1] / nbp, pr[2] / nbp, pr[3] / nbp, pr[4] / nbp, pr[6] / nbp, pr[7] / nbp);
     }
     if (max_index) *max_index = mi;
     if (kernel_ms) { float ms = 0; HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1)); *kernel_ms = ms; }

@@ -231,25 +231,54 @@ __device__ __forceinline__ void visit_source(const int k, const int j, const Src
 
 // Per-lane (non-uniform) evaluation of one (source j, target) pair: same arithmetic as visit_source,
 // every field loaded by the lane itself.  Used for the few pairs that need the exact pairwise term.
-__device__ __forceinline__ void pair_eval(const int j, const DpSrc* __restrict__ src, const double* score, const int* tbn,
-                                          const Target& T, const double negc, const double* s_igm, Best& B) {
-    const int s_meta = src[j].meta, s_ndx = src[j].ndx;
+// Source fields of final nodes, read from global memory (GlobalAcc) or from the LDS copy of the last
+// finalized tile (TileAcc).
+struct GlobalAcc {
+    const DpSrc* __restrict__ src; const double* score; const int* tbn;
+    __device__ __forceinline__ int meta(int j) const { return src[j].meta; }
+    __device__ __forceinline__ int ndx(int j) const { return src[j].ndx; }
+    __device__ __forceinline__ int stop_val(int j) const { return src[j].stop_val; }
+    __device__ __forceinline__ double cs(int j) const { return src[j].cs; }
+    __device__ __forceinline__ double x(int j, int f) const { return src[j].x[f]; }
+    __device__ __forceinline__ double sc(int j) const { return score[j]; }
+    __device__ __forceinline__ int tb_ndx(int j) const { return tbn[j]; }
+};
+struct TileLds {     // the most recently finalized 64 nodes of a chain, kept in LDS by the serial wave
+    int ndx[64], stop_val[64], meta[64], tbn[64];
+    double score[64], cs[64], x0[64], x1[64], x2[64], A[64], V0[64], V1[64], V2[64];
+    double l1v[8]; int l1i[8];       // lexicographic maxima of A over the 8 blocks of 8
+    double l2v; int l2i;             // ... and over the whole tile
+};
+struct TileAcc {
+    const TileLds* t; int base;
+    __device__ __forceinline__ int meta(int j) const { return t->meta[j - base]; }
+    __device__ __forceinline__ int ndx(int j) const { return t->ndx[j - base]; }
+    __device__ __forceinline__ int stop_val(int j) const { return t->stop_val[j - base]; }
+    __device__ __forceinline__ double cs(int j) const { return t->cs[j - base]; }
+    __device__ __forceinline__ double x(int j, int f) const { const int q = j - base; return f == 0 ? t->x0[q] : (f == 1 ? t->x1[q] : t->x2[q]); }
+    __device__ __forceinline__ double sc(int j) const { return t->score[j - base]; }
+    __device__ __forceinline__ int tb_ndx(int j) const { return t->tbn[j - base]; }
+};
+
+template <class Acc>
+__device__ __forceinline__ void pair_eval(const int j, const Acc& S, const Target& T, const double negc, const double* s_igm, Best& B) {
+    const int s_meta = S.meta(j), s_ndx = S.ndx(j);
     const int sk = PGA_KIND(s_meta), sf = PGA_FRAME(s_meta);
-    const int tbnj = tbn[j];
+    const int tbnj = S.tb_ndx(j);
     if ((sk == 1 || sk == 2) && tbnj == -1) return;
-    const double sj = score[j];
+    const double sj = S.sc(j);
     bool ok = (j >= T.lo) && (j < T.i);
     double w = 0.0; int mf = -1;
     if (sk == 0) {
         ok = ok && T.kind == 1 && T.frame == sf && T.stop_val < s_ndx;
-        w = src[j].cs;
+        w = S.cs(j);
     } else if (sk == 2) {
         const bool a = T.kind == 0 && s_ndx < T.ndx;
         const bool b = T.kind == 3 && s_ndx < T.ndx - 2;
         ok = ok && (a || b);
         w = b ? igm_apart(T.ndx - s_ndx, negc, s_igm) : negc;
     } else if (sk == 3) {
-        const int s_stop = src[j].stop_val;
+        const int s_stop = S.stop_val(j);
         const bool a = T.kind == 2 && T.frame == sf && s_stop > T.ndx;
         const bool b = T.kind == 3 && s_stop > T.ndx && PGA_SPVALID(T.meta, sf);
         ok = ok && (a || b);
@@ -260,7 +289,7 @@ __device__ __forceinline__ void pair_eval(const int j, const DpSrc* __restrict__
             w = igm_apart(T.ndx - s_ndx, negc, s_igm);
         } else if (T.kind == 1) {
             ok = ok && T.stop_val < s_ndx && PGA_SPVALID(s_meta, T.frame);
-            w = src[j].x[T.frame];
+            w = S.x(j, T.frame);
         } else if (T.kind == 2) {
             const int ovlp = (s_ndx + 2) - (T.stop_val - 2) + 1;
             ok = ok && !(T.stop_val - 2 >= s_ndx + 2) && ovlp < PGA_MAX_OPP_OVLP
@@ -286,7 +315,8 @@ __device__ __forceinline__ void pair_eval(const int j, const DpSrc* __restrict__
     take(B, ok, sj + w, j, mf, s_ndx);
 }
 
-// One wavefront per chain; the far field of the window is never scanned source by source.
+// ---------------------------------------------------------------------------------------------
+// Tree kernels: the far field of the window is never scanned source by source.
 //
 // Every candidate value score[j] + w(j, i) whose w does not depend on the target is stored once,
 // when node j becomes final:
@@ -301,9 +331,304 @@ __device__ __forceinline__ void pair_eval(const int j, const DpSrc* __restrict__
 //   * a forward stop scans V[frame] over its own ORF; a reverse start reads its own stop and the few
 //     forward stops that can overlap its 3' end;
 //   * sources inside the current 64-node batch are not final yet: they are walked in order, one
-//     wave-uniform source at a time (visit_source), which is the serial critical path of a chain.
+//     wave-uniform source at a time, which is the serial critical path of a chain.
 // For an R3 target the tree may also return A[j] of a forward stop whose exact term is larger
 // (the overlapping-start case adds a positive score): the exact pair is evaluated as well and wins.
+struct ChainPtrs {
+    const DpSrc* __restrict__ src; const DpTgt* __restrict__ tgt;
+    double* score; int32_t* traceb; int32_t* tbn; int8_t* ovm;
+    double* A; double* V0; double* V1; double* V2; double* hv; int32_t* hi;
+};
+
+__device__ __forceinline__ ChainPtrs chain_ptrs(const ChainDesc& cd, const DpSrc* g_src, const DpTgt* g_tgt, const DpBuffers& buf) {
+    ChainPtrs P;
+    P.src = g_src + cd.off; P.tgt = g_tgt + cd.off;
+    P.score = buf.score + cd.off; P.traceb = buf.traceb + cd.off; P.tbn = buf.tbn + cd.off; P.ovm = buf.ov_mark + cd.off;
+    P.A = buf.A + cd.off; P.V0 = buf.V[0] + cd.off; P.V1 = buf.V[1] + cd.off; P.V2 = buf.V[2] + cd.off;
+    P.hv = buf.hv + cd.off; P.hi = buf.hi + cd.off;
+    return P;
+}
+
+__device__ __forceinline__ void load_target(Target& T, const ChainPtrs& P, int i0, int lane, int n, double negc) {
+    T.i = i0 + lane;
+    const bool act = T.i < n;
+    const int ii = act ? T.i : n - 1;
+    const DpSrc me = P.src[ii]; const DpTgt mt = P.tgt[ii];
+    T.kind = PGA_KIND(me.meta); T.frame = PGA_FRAME(me.meta); T.meta = me.meta;
+    T.ndx = me.ndx; T.stop_val = me.stop_val; T.cs = me.cs; T.csd = me.cs + negc;
+    T.x0 = me.x[0]; T.x1 = me.x[1]; T.x2 = me.x[2];
+    T.n3n0 = mt.n3ndx[0]; T.n3n1 = mt.n3ndx[1]; T.n3n2 = mt.n3ndx[2];
+    T.n3s0 = mt.n3stop[0]; T.n3s1 = mt.n3stop[1]; T.n3s2 = mt.n3stop[2];
+    T.lo = act ? mt.lo : INT_MAX; T.p_near = mt.p_near;
+    T.a0 = mt.a[0]; T.a1 = mt.a[1]; T.a2 = mt.a[2]; T.b0 = mt.b[0]; T.b1 = mt.b[1]; T.b2 = mt.b[2];
+    T.c0 = mt.c[0]; T.c1 = mt.c[1]; T.c2 = mt.c[2];
+    if (!act) T.i = -1;          // j < T.i is never true: the lane stays idle
+}
+
+// lexicographic maximum of A over [l, r) from the 8-ary tree; the (up to 7 + 7) ragged entries of a
+// level are loaded together so that a level costs one memory round trip.
+__device__ __forceinline__ void tree_range(int l, int r, const ChainPtrs& P, const int* s_levbase, Best& B) {
+    int lev = 0;
+    while (l < r) {
+        const int l_end = min(r, (l + 7) & ~7);
+        const int r_beg = max(l_end, r & ~7);
+        const int base = s_levbase[lev];
+        const double* __restrict__ vp = lev == 0 ? P.A : P.hv + base;
+        const int* __restrict__ ip = P.hi + base;
+        double v[14]; int ix[14];
+#pragma unroll
+        for (int q = 0; q < 7; q++) {
+            const int pl = l + q, pr = r_beg + q;
+            const bool okl = pl < l_end, okr = pr < r;
+            const int cl = okl ? pl : l, cr = okr ? pr : l;
+            v[q] = vp[cl]; v[7 + q] = vp[cr];
+            ix[q] = lev == 0 ? cl : ip[cl]; ix[7 + q] = lev == 0 ? cr : ip[cr];
+            if (!okl) v[q] = -__builtin_huge_val();
+            if (!okr) v[7 + q] = -__builtin_huge_val();
+        }
+#pragma unroll
+        for (int q = 0; q < 14; q++) take(B, true, v[q], ix[q], -1, 0);
+        l = l_end >> 3; r = r_beg >> 3; lev++;
+    }
+}
+
+// Everything target T can take from final sources j in [clo, chi): tree + exact near pairs + special
+// ranges.  chi must not exceed the number of final nodes.
+__device__ __forceinline__ void far_field(const Target& T, int clo, int chi, const ChainPtrs& P, const int* s_levbase,
+                                          const double negc, const double* s_igm, Best& B) {
+    if (T.i < 0) return;
+    chi = min(chi, T.i);
+    clo = max(clo, T.lo);
+    if (clo >= chi) return;
+    const GlobalAcc G{P.src, P.score, P.tbn};
+    if (T.kind == 0 || T.kind == 3) {
+        tree_range(clo, min(T.p_near, chi), P, s_levbase, B);                                   // (1) far gene ends
+        for (int j = max(T.p_near, clo); j < chi; j++) pair_eval(j, G, T, negc, s_igm, B);   // (2) near: exact pairs
+        if (T.kind == 3) {
+            // (3) forward stops that can overlap one of this node's overlapping starts (ref: _connection.h:296-325)
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (!PGA_SPVALID(T.meta, k)) continue;
+                const int zb = min(sel3i(k, T.b0, T.b1, T.b2), chi);
+                for (int j = max(sel3i(k, T.a0, T.a1, T.a2), clo); j < zb; j++)
+                    if (PGA_KIND(P.src[j].meta) == 1) pair_eval(j, G, T, negc, s_igm, B);
+            }
+            // (4) the reverse stop of each frame whose ORF covers this node (ref: _connection.h:345-356)
+#pragma unroll
+            for (int f = 0; f < 3; f++) {
+                const int j = sel3i(f, T.c0, T.c1, T.c2);
+                if (j >= clo && j < chi) pair_eval(j, G, T, negc, s_igm, B);
+            }
+        }
+    } else if (T.kind == 1) {
+        // forward stop: starts of its own ORF and operon partners, precomputed per target frame
+        for (int j = max(T.a0, clo); j < chi; j++) {
+            const double v = T.frame == 0 ? P.V0[j] : (T.frame == 1 ? P.V1[j] : P.V2[j]);
+            take(B, true, v, j, -1, 0);
+        }
+    } else {
+        // reverse start: its own stop, then forward stops overlapping its 3' end (ref: _connection.h:228-254)
+        if (T.a0 >= clo && T.a0 < chi) pair_eval(T.a0, G, T, negc, s_igm, B);
+        const int zb = min(T.a2, chi);
+        for (int j = max(T.a1, clo); j < zb; j++)
+            if (PGA_KIND(P.src[j].meta) == 1) pair_eval(j, G, T, negc, s_igm, B);
+    }
+}
+
+// Forward-stop source (position s_ndx, ndx of its traceb node tbnj) against a reverse target: the only
+// in-batch pairs whose admissibility depends on the source's running state.  Written with selects so
+// that the lanes do not diverge.  Returns the weight, sets ok / mf.   (ref: _connection.h:238-254, 288-336)
+__device__ __forceinline__ double f3_to_reverse(const int s_ndx, const int tbnj, const Target& T, const bool inwin,
+                                                const double negc, bool& ok, int& mf) {
+    // reverse start target: overlapping opposite 3' ends
+    const int ovlp5 = (s_ndx + 2) - (T.stop_val - 2) + 1;
+    const bool ok5 = (T.stop_val - 2 < s_ndx + 2) & (ovlp5 < PGA_MAX_OPP_OVLP) & ((s_ndx - T.stop_val) < (T.ndx - s_ndx + 3)) &
+                     ((s_ndx - T.stop_val) < (T.stop_val - 3 - tbnj));
+    // reverse stop target: possibly through one of its overlapping starts
+    const int left = s_ndx + 2;
+    double maxval = 0.0; int m = -1;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const int n3s = sel3i(q, T.n3s0, T.n3s1, T.n3s2), n3n = sel3i(q, T.n3n0, T.n3n1, T.n3n2);
+        const double cur = sel3(q, T.x0, T.x1, T.x2);
+        const int ovlp = left - n3s + 3;
+        const bool tk = (PGA_SPVALID(T.meta, q) != 0) & (ovlp > 0) & (ovlp < PGA_MAX_OPP_OVLP) & (ovlp < n3n - left) &
+                        (ovlp < n3s - tbnj - 2) & (cur > maxval);
+        maxval = tk ? cur : maxval; m = tk ? q : m;
+    }
+    const bool is3 = T.kind == 3;
+    ok = inwin & (is3 ? (left < T.ndx - 2) : ok5);
+    mf = is3 ? m : -1;
+    return is3 ? (m != -1 ? maxval : negc) : T.csd;
+}
+
+// far_field for the one tile [base, base + 64) that the serial wave keeps in LDS (the tile it finalized last).
+__device__ __forceinline__ void late_field(const Target& T, const TileLds* tile, const int base, const double negc,
+                                           const double* s_igm, Best& B) {
+    if (T.i < 0) return;
+    const int chi = min(base + 64, T.i);
+    const int clo = max(base, T.lo);
+    if (clo >= chi) return;
+    const TileAcc S{tile, base};
+    if (T.kind == 0 || T.kind == 3) {
+        const int fr = min(T.p_near, chi);
+        if (clo == base && fr == base + 64) take(B, true, tile->l2v, tile->l2i, -1, 0);
+        else if (clo < fr) {
+            const int l = clo - base, r = fr - base;
+            const int l_end = min(r, (l + 7) & ~7), r_beg = max(l_end, r & ~7);
+            for (int q = l; q < l_end; q++) take(B, true, tile->A[q], base + q, -1, 0);
+            for (int q = r_beg; q < r; q++) take(B, true, tile->A[q], base + q, -1, 0);
+            for (int q = l_end >> 3; q < (r_beg >> 3); q++) take(B, true, tile->l1v[q], tile->l1i[q], -1, 0);
+        }
+        for (int j = max(T.p_near, clo); j < chi; j++) {
+            // only alive gene ends (A != -inf) connect to a gene begin; a reverse start towards a forward start
+            // is worth exactly A (ref: _connection.h:125-130)
+            const int q = j - base;
+            const double aj = tile->A[q];
+            if (aj == -__builtin_huge_val()) continue;
+            const int s_ndx = tile->ndx[q];
+            const bool s_rev = PGA_KIND(tile->meta[q]) == 2;
+            if (T.kind == 0) {
+                if (s_rev) take(B, true, aj, j, -1, 0);
+                else take(B, s_ndx + 2 < T.ndx, tile->score[q] + igm_apart(T.ndx - s_ndx, negc, s_igm), j, -1, 0);
+            } else if (s_rev) {
+                take(B, s_ndx < T.ndx - 2, tile->score[q] + igm_apart(T.ndx - s_ndx, negc, s_igm), j, -1, 0);
+            } else {
+                bool okd; int mf;
+                const double wd = f3_to_reverse(s_ndx, tile->tbn[q], T, true, negc, okd, mf);
+                take(B, okd, tile->score[q] + wd, j, mf, 0);
+            }
+        }
+        if (T.kind == 3) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (!PGA_SPVALID(T.meta, k)) continue;
+                const int zb = min(sel3i(k, T.b0, T.b1, T.b2), chi);
+                for (int j = max(sel3i(k, T.a0, T.a1, T.a2), clo); j < zb; j++)
+                    if (PGA_KIND(S.meta(j)) == 1) pair_eval(j, S, T, negc, s_igm, B);
+            }
+#pragma unroll
+            for (int f = 0; f < 3; f++) {
+                const int j = sel3i(f, T.c0, T.c1, T.c2);
+                if (j >= clo && j < chi) pair_eval(j, S, T, negc, s_igm, B);
+            }
+        }
+    } else if (T.kind == 1) {
+        for (int j = max(T.a0, clo); j < chi; j++) {
+            const int q = j - base;
+            const double v = T.frame == 0 ? tile->V0[q] : (T.frame == 1 ? tile->V1[q] : tile->V2[q]);
+            take(B, true, v, j, -1, 0);
+        }
+    } else {
+        if (T.a0 >= clo && T.a0 < chi) pair_eval(T.a0, S, T, negc, s_igm, B);
+        const int zb = min(T.a2, chi);
+        for (int j = max(T.a1, clo); j < zb; j++)
+            if (PGA_KIND(S.meta(j)) == 1) pair_eval(j, S, T, negc, s_igm, B);
+    }
+}
+
+// The batch [i0, i0+64) is final in wave registers: store it with its far-field candidate values and
+// extend the tree.  Returns nothing; updates the running _find_max_index state.
+__device__ __forceinline__ void finalize_batch(const Target& T, const Best& B, int i0, int lane, int n, const ChainPtrs& P,
+                                               const int* s_levbase, const double negc,
+                                               double& end_best, int& end_idx, int& end_tb, TileLds* tile = nullptr) {
+    const double NEG_INF = -__builtin_huge_val();
+    const bool act = T.i >= 0;
+    double a_val = NEG_INF;
+    if (act) {
+        const bool alive = B.tb != -1;
+        P.score[T.i] = B.val; P.traceb[T.i] = B.tb; P.ovm[T.i] = (int8_t)B.ov; P.tbn[T.i] = alive ? B.tbn : -1;
+        double v0 = NEG_INF, v1 = NEG_INF, v2 = NEG_INF;
+        if (T.kind == 0) {
+            const double g = B.val + T.cs;
+            if (T.frame == 0) v0 = g; else if (T.frame == 1) v1 = g; else v2 = g;
+        } else if (T.kind == 1 && alive) {
+            a_val = B.val + negc;
+            if (PGA_SPVALID(T.meta, 0)) v0 = B.val + T.x0;
+            if (PGA_SPVALID(T.meta, 1)) v1 = B.val + T.x1;
+            if (PGA_SPVALID(T.meta, 2)) v2 = B.val + T.x2;
+        } else if (T.kind == 2 && alive) {
+            a_val = B.val + negc;
+        }
+        P.A[T.i] = a_val; P.V0[T.i] = v0; P.V1[T.i] = v1; P.V2[T.i] = v2;
+        if ((T.kind == 1 || T.kind == 2) && B.val >= end_best) { end_best = B.val; end_idx = T.i; end_tb = B.tb; }
+        if (tile) {
+            tile->ndx[lane] = T.ndx; tile->stop_val[lane] = T.stop_val; tile->meta[lane] = T.meta; tile->tbn[lane] = alive ? B.tbn : -1;
+            tile->score[lane] = B.val; tile->cs[lane] = T.cs; tile->x0[lane] = T.x0; tile->x1[lane] = T.x1; tile->x2[lane] = T.x2;
+            tile->A[lane] = a_val; tile->V0[lane] = v0; tile->V1[lane] = v1; tile->V2[lane] = v2;
+        }
+    }
+    if (i0 + 64 > n) return;
+    double rv = a_val; int ri = i0 + lane;
+#pragma unroll
+    for (int m = 1; m <= 4; m <<= 1) {
+        const double ov2 = __shfl_xor(rv, m, 64); const int oi = __shfl_xor(ri, m, 64);
+        if (ov2 > rv || (ov2 == rv && oi > ri)) { rv = ov2; ri = oi; }
+    }
+    const int tile_no = i0 >> 6;
+    if ((lane & 7) == 0) {
+        P.hv[s_levbase[1] + (i0 >> 3) + (lane >> 3)] = rv; P.hi[s_levbase[1] + (i0 >> 3) + (lane >> 3)] = ri;
+        if (tile) { tile->l1v[lane >> 3] = rv; tile->l1i[lane >> 3] = ri; }
+    }
+#pragma unroll
+    for (int m = 8; m <= 32; m <<= 1) {
+        const double ov2 = __shfl_xor(rv, m, 64); const int oi = __shfl_xor(ri, m, 64);
+        if (ov2 > rv || (ov2 == rv && oi > ri)) { rv = ov2; ri = oi; }
+    }
+    if (lane == 0) {
+        P.hv[s_levbase[2] + tile_no] = rv; P.hi[s_levbase[2] + tile_no] = ri;
+        if (tile) { tile->l2v = rv; tile->l2i = ri; }
+    }
+    // higher levels: a block of 8 children closes when its last child does
+    int child = tile_no, lev = 2;
+    while ((child & 7) == 7 && (lev + 1) * 3 < 31 && (n >> (3 * (lev + 1))) > 0) {
+        double cv = NEG_INF; int ci = -1;
+        if (lane < 8) { cv = P.hv[s_levbase[lev] + child - 7 + lane]; ci = P.hi[s_levbase[lev] + child - 7 + lane]; }
+#pragma unroll
+        for (int m = 1; m <= 4; m <<= 1) {
+            const double ov2 = __shfl_xor(cv, m, 64); const int oi = __shfl_xor(ci, m, 64);
+            if (ov2 > cv || (ov2 == cv && oi > ci)) { cv = ov2; ci = oi; }
+        }
+        child >>= 3; lev++;
+        if (lane == 0) { P.hv[s_levbase[lev] + child] = cv; P.hi[s_levbase[lev] + child] = ci; }
+    }
+}
+
+__device__ __forceinline__ void init_levbase(int* s_levbase, int n) {
+    int base = 0;
+    s_levbase[0] = 0;
+    for (int lev = 1; lev < 12; lev++) { s_levbase[lev] = base; base += (lev * 3 < 31) ? (n >> (3 * lev)) : 0; }
+}
+
+__device__ __forceinline__ void publish_max(double end_best, int end_idx, int end_tb, int lane, const DpBuffers& buf) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double ob = __shfl_xor(end_best, m, 64);
+        const int oi = __shfl_xor(end_idx, m, 64);
+        const int ot = __shfl_xor(end_tb, m, 64);
+        if (ob > end_best || (ob == end_best && oi > end_idx)) { end_best = ob; end_idx = oi; end_tb = ot; }
+    }
+    if (lane == 0) {   // highest score among gene ends, ties to the largest index (ref: lib.pyx:1239-1251, 1311)
+        buf.max_index[blockIdx.x] = end_idx; buf.max_score[blockIdx.x] = end_idx >= 0 ? end_best : 0.0;
+        buf.ipath[blockIdx.x] = (end_idx >= 0 && end_tb != -1) ? end_idx : -1;
+    }
+}
+
+// In-batch walk, general form: source k's registers are broadcast and every pair is evaluated in full.
+__device__ __forceinline__ void walk_batch(const Target& T, Best& B, int i0, int n, const double negc, const double* s_igm) {
+    const int kmax = min(63, n - 1 - i0);
+    for (int k = 0; k < kmax; k++) {
+        const int sk = PGA_KIND(__builtin_amdgcn_readlane(T.meta, k));
+        const int tbk = __builtin_amdgcn_readlane(B.tb, k);
+        if ((sk == 1 || sk == 2) && tbk == -1) continue;
+        SrcLane S;
+        S.ndx = T.ndx; S.stop_val = T.stop_val; S.meta = T.meta; S.tbn = B.tbn;
+        S.cs = T.cs; S.x0 = T.x0; S.x1 = T.x1; S.x2 = T.x2; S.score = B.val;
+        visit_source(k, i0 + k, S, T, negc, s_igm, B);
+    }
+}
+
+// One wavefront per chain: used when there are enough chains to fill the chip.
 __global__ void __launch_bounds__(64)
 k_dp_tree(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src, const DpTgt* __restrict__ g_tgt,
           const ModelConst* __restrict__ models, DpBuffers buf) {
@@ -314,184 +639,171 @@ k_dp_tree(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src,
     const int n = cd.n;
     const ModelConst* mc = &models[cd.model];
     s_igm[lane] = mc->igm[lane];
-    if (lane == 0) {
-        int base = 0;
-        for (int lev = 1; lev < 12; lev++) { s_levbase[lev] = base; base += (lev * 3 < 31) ? (n >> (3 * lev)) : 0; }
-        s_levbase[0] = 0;
-    }
+    if (lane == 0) init_levbase(s_levbase, n);
     __syncthreads();
     const double negc = mc->negc;
-    const double NEG_INF = -__builtin_huge_val();
-    const DpSrc* __restrict__ src = g_src + cd.off;
-    const DpTgt* __restrict__ tgt = g_tgt + cd.off;
-    double* score = buf.score + cd.off; int32_t* traceb = buf.traceb + cd.off;
-    int32_t* tbn = buf.tbn + cd.off; int8_t* ovm = buf.ov_mark + cd.off;
-    double* A = buf.A + cd.off; double* V0 = buf.V[0] + cd.off; double* V1 = buf.V[1] + cd.off; double* V2 = buf.V[2] + cd.off;
-    double* hv = buf.hv + cd.off; int32_t* hi = buf.hi + cd.off;
-
-    double end_best = -1.0; int end_idx = -1, end_tb = -1;     // _find_max_index (ref: lib.pyx:1239-1251)
-
+    const ChainPtrs P = chain_ptrs(cd, g_src, g_tgt, buf);
+    double end_best = -1.0; int end_idx = -1, end_tb = -1;
     for (int i0 = 0; i0 < n; i0 += 64) {
         Target T;
-        T.i = i0 + lane;
-        const bool act = T.i < n;
-        {
-            const int ii = act ? T.i : n - 1;
-            const DpSrc me = src[ii]; const DpTgt mt = tgt[ii];
-            T.kind = PGA_KIND(me.meta); T.frame = PGA_FRAME(me.meta); T.meta = me.meta;
-            T.ndx = me.ndx; T.stop_val = me.stop_val; T.cs = me.cs; T.csd = me.cs + negc;
-            T.x0 = me.x[0]; T.x1 = me.x[1]; T.x2 = me.x[2];
-            T.n3n0 = mt.n3ndx[0]; T.n3n1 = mt.n3ndx[1]; T.n3n2 = mt.n3ndx[2];
-            T.n3s0 = mt.n3stop[0]; T.n3s1 = mt.n3stop[1]; T.n3s2 = mt.n3stop[2];
-            T.lo = act ? mt.lo : INT_MAX; T.p_near = mt.p_near;
-            T.a0 = mt.a[0]; T.a1 = mt.a[1]; T.a2 = mt.a[2]; T.b0 = mt.b[0]; T.b1 = mt.b[1]; T.b2 = mt.b[2];
-            T.c0 = mt.c[0]; T.c1 = mt.c[1]; T.c2 = mt.c[2];
-            if (!act) T.i = -1;
-        }
+        load_target(T, P, i0, lane, n, negc);
         Best B{0.0, -1, -1, -1};
         const bool prof = buf.prof != nullptr && blockIdx.x == 0;
-        unsigned long long tp0 = prof ? __builtin_readcyclecounter() : 0, tp1 = 0, tp2 = 0, tp3 = 0, tp4 = 0;
-        // ---- final sources (index < i0): per-lane work, no pair enumeration of the far field
-        if (act && i0 > 0) {
-            const int lim = min(T.i, i0);          // == i0
-            if (T.kind == 0 || T.kind == 3) {
-                // (1) far gene ends: 8-ary max tree over A on [lo, min(p_near, i0))
-                int lo = T.lo, hi2 = min(T.p_near, lim), lev = 0;
-                while (lo < hi2) {
-                    while (lo < hi2 && (lo & 7)) {
-                        const double v = lev == 0 ? A[lo] : hv[s_levbase[lev] + lo];
-                        const int ix = lev == 0 ? lo : hi[s_levbase[lev] + lo];
-                        take(B, true, v, ix, -1, 0);
-                        lo++;
+        const unsigned long long tp0 = prof ? __builtin_readcyclecounter() : 0;
+        far_field(T, 0, i0, P, s_levbase, negc, s_igm, B);
+        if (B.tb >= 0) B.tbn = P.src[B.tb].ndx;
+        const unsigned long long tp1 = prof ? __builtin_readcyclecounter() : 0;
+        walk_batch(T, B, i0, n, negc, s_igm);
+        const unsigned long long tp2 = prof ? __builtin_readcyclecounter() : 0;
+        finalize_batch(T, B, i0, lane, n, P, s_levbase, negc, end_best, end_idx, end_tb);
+        if (prof && lane == 0) {
+            const unsigned long long tp3 = __builtin_readcyclecounter();
+            buf.prof[0] += tp1 - tp0; buf.prof[1] += tp2 - tp1; buf.prof[2] += tp3 - tp2; buf.prof[5] += 1;
+        }
+    }
+    publish_max(end_best, end_idx, end_tb, lane, buf);
+}
+
+// Static part of an in-batch pair (source k = lane k of the same batch, target = this lane):
+// weight and admissibility that do not depend on the source's running state.  Forward-stop sources
+// towards reverse targets need the ndx of the source's traceb node: those pairs are flagged dynamic.
+__device__ __forceinline__ void static_pair(const int k, const int i0, const Target& T, const double negc, const double* s_igm,
+                                            bool& ok, double& w, bool& dyn) {
+    const int s_meta = __builtin_amdgcn_readlane(T.meta, k);
+    const int s_ndx = __builtin_amdgcn_readlane(T.ndx, k);
+    const int sk = PGA_KIND(s_meta), sf = PGA_FRAME(s_meta);
+    const int j = i0 + k;
+    const bool inwin = (j >= T.lo) && (j < T.i);
+    ok = false; dyn = false; w = 0.0;
+    if (sk == 0) {
+        ok = inwin && T.kind == 1 && T.frame == sf && T.stop_val < s_ndx;
+        w = readlane_f64(T.cs, k);
+    } else if (sk == 2) {
+        const bool a = T.kind == 0 && s_ndx < T.ndx;
+        const bool b = T.kind == 3 && s_ndx < T.ndx - 2;
+        ok = inwin && (a || b);
+        w = b ? igm_apart(T.ndx - s_ndx, negc, s_igm) : negc;
+    } else if (sk == 3) {
+        const int s_stop = __builtin_amdgcn_readlane(T.stop_val, k);
+        const bool a = T.kind == 2 && T.frame == sf && s_stop > T.ndx;
+        const bool b = T.kind == 3 && s_stop > T.ndx && PGA_SPVALID(T.meta, sf);
+        ok = inwin && (a || b);
+        w = a ? T.cs : sel3(sf, T.x0, T.x1, T.x2);
+    } else {
+        const double sx0 = readlane_f64(T.x0, k), sx1 = readlane_f64(T.x1, k), sx2 = readlane_f64(T.x2, k);
+        if (T.kind == 0) { ok = inwin && (s_ndx + 2 < T.ndx); w = igm_apart(T.ndx - s_ndx, negc, s_igm); }
+        else if (T.kind == 1) { ok = inwin && T.stop_val < s_ndx && PGA_SPVALID(s_meta, T.frame); w = sel3(T.frame, sx0, sx1, sx2); }
+        else dyn = inwin;
+    }
+}
+
+// Five wavefronts per chain, for the latency-bound case of few long chains:
+//   wave 0     the serial wave: far field of the tile it finalized last (read back from LDS), lean
+//              in-batch walk that takes the static pair weights from LDS, store + tree update;
+//   waves 1-3  precompute the static pair weights of the NEXT batch into LDS (no dependence on scores);
+//   wave 4     computes the far field of the NEXT batch over every older tile (global memory, tree).
+// One __syncthreads per batch.
+#define PGA_MW_WAVES 5
+__global__ void __launch_bounds__(64 * PGA_MW_WAVES)
+k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src, const DpTgt* __restrict__ g_tgt,
+             const ModelConst* __restrict__ models, DpBuffers buf) {
+    __shared__ double s_igm[64];
+    __shared__ int s_levbase[12];
+    __shared__ double s_w[2][64][64];                 // static pair weights [slot][source k][target lane], NaN = pair not allowed
+    __shared__ unsigned long long s_dyn[2][64];       // per source: lanes whose pair needs the dynamic evaluation
+    __shared__ double s_eval[2][64];                  // early far-field result of the next batch
+    __shared__ int s_etb[2][64], s_eov[2][64];
+    __shared__ TileLds s_tile;
+    const ChainDesc cd = chains[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = cd.n;
+    const ModelConst* mc = &models[cd.model];
+    if (wave == 0) { s_igm[lane] = mc->igm[lane]; if (lane == 0) init_levbase(s_levbase, n); }
+    __syncthreads();
+    const double negc = mc->negc;
+    const ChainPtrs P = chain_ptrs(cd, g_src, g_tgt, buf);
+    const double QNAN = __builtin_nan("");
+    double end_best = -1.0; int end_idx = -1, end_tb = -1;
+    const int nb = (n + 63) >> 6;
+    const bool prof = buf.prof != nullptr && blockIdx.x == 0;
+    if (wave == 0) __builtin_amdgcn_s_setprio(3);   // the serial wave is the critical path of the chain
+
+    for (int b = -1; b < nb; b++) {                 // iteration -1: only the helpers work (for batch 0)
+        const int i0 = b << 6;                      // this batch (wave 0)
+        const int nx = (b + 1) << 6, pb = (b + 1) & 1;    // next batch (helpers) and its LDS slot
+        const unsigned long long tq0 = prof ? __builtin_readcyclecounter() : 0;
+        if (wave == 0) {
+            if (b >= 0) {
+                const int slot = b & 1;
+                Target T;
+                load_target(T, P, i0, lane, n, negc);
+                Best B{s_eval[slot][lane], s_etb[slot][lane], s_eov[slot][lane], -1};
+                if (i0 > 0) late_field(T, &s_tile, i0 - 64, negc, s_igm, B);
+                if (B.tb >= 0) B.tbn = P.src[B.tb].ndx;
+                const unsigned long long tq1 = prof ? __builtin_readcyclecounter() : 0;
+                // lean in-batch walk: w(k, lane) comes from LDS eight sources at a time; only the recurrence
+                // (broadcast score of lane k, add, compare, select) is left on the serial path
+                const int kmax = min(63, n - 1 - i0);
+                const unsigned long long endmask = __ballot(T.kind == 1 || T.kind == 2);
+                const unsigned long long dynany = __ballot(s_dyn[slot][lane] != 0ull);
+                double wn = s_w[slot][0][lane];
+                for (int k = 0; k < kmax; k++) {
+                    const double w = wn;
+                    wn = s_w[slot][k + 1][lane];             // next step's weight is in flight while this one is used
+                    const int tbk = __builtin_amdgcn_readlane(B.tb, k);
+                    const bool alive = !(((endmask >> k) & 1ull) && tbk == -1);
+                    if (!alive) continue;
+                    if ((dynany >> k) & 1ull) {
+                        if (prof && lane == 0) buf.prof[7] += 1;
+                        // forward-stop source: forward targets use the static weight, reverse targets the dynamic rule
+                        const int s_ndx = __builtin_amdgcn_readlane(T.ndx, k);
+                        const int tbnj = __builtin_amdgcn_readlane(B.tbn, k);
+                        const int j = i0 + k;
+                        bool okd; int mf;
+                        const double wd = f3_to_reverse(s_ndx, tbnj, T, (j >= T.lo) & (j < T.i), negc, okd, mf);
+                        const bool rev = T.kind >= 2;
+                        const double wk = rev ? (okd ? wd : QNAN) : w;
+                        const double val = readlane_f64(B.val, k) + wk;
+                        if (val >= B.val) { B.val = val; B.tb = j; B.ov = rev ? mf : -1; B.tbn = s_ndx; }
+                        continue;
                     }
-                    while (lo < hi2 && (hi2 & 7)) {
-                        hi2--;
-                        const double v = lev == 0 ? A[hi2] : hv[s_levbase[lev] + hi2];
-                        const int ix = lev == 0 ? hi2 : hi[s_levbase[lev] + hi2];
-                        take(B, true, v, ix, -1, 0);
-                    }
-                    lo >>= 3; hi2 >>= 3; lev++;
+                    // in-batch sources come in ascending order, so the lexicographic test is the reference's plain ">=";
+                    // a NaN weight (pair not allowed) makes the comparison false
+                    const double val = readlane_f64(B.val, k) + w;
+                    const int s_ndx = __builtin_amdgcn_readlane(T.ndx, k);
+                    if (val >= B.val) { B.val = val; B.tb = i0 + k; B.ov = -1; B.tbn = s_ndx; }
                 }
-                if (prof) tp1 = __builtin_readcyclecounter();
-                // (2) sources within 3*OPER_DIST bases: exact pairs
-                for (int j = max(T.p_near, T.lo); j < lim; j++) pair_eval(j, src, score, tbn, T, negc, s_igm, B);
-                if (prof) tp2 = __builtin_readcyclecounter();
-                if (T.kind == 3) {
-                    // (3) forward stops that can overlap one of this node's overlapping starts (ref: _connection.h:296-325)
-#pragma unroll
-                    for (int k = 0; k < 3; k++) {
-                        if (!PGA_SPVALID(T.meta, k)) continue;
-                        const int zb = min(sel3i(k, T.b0, T.b1, T.b2), lim);
-                        for (int j = sel3i(k, T.a0, T.a1, T.a2); j < zb; j++)
-                            if (PGA_KIND(src[j].meta) == 1) pair_eval(j, src, score, tbn, T, negc, s_igm, B);
-                    }
-                    // (4) the reverse stop of each frame whose ORF covers this node (ref: _connection.h:345-356)
-#pragma unroll
-                    for (int f = 0; f < 3; f++) {
-                        const int j = sel3i(f, T.c0, T.c1, T.c2);
-                        if (j >= 0 && j < lim) pair_eval(j, src, score, tbn, T, negc, s_igm, B);
-                    }
+                const unsigned long long tq2 = prof ? __builtin_readcyclecounter() : 0;
+                finalize_batch(T, B, i0, lane, n, P, s_levbase, negc, end_best, end_idx, end_tb, &s_tile);
+                if (prof && lane == 0) {
+                    const unsigned long long tq3 = __builtin_readcyclecounter();
+                    buf.prof[0] += tq1 - tq0; buf.prof[1] += tq2 - tq1; buf.prof[2] += tq3 - tq2; buf.prof[5] += 1;
                 }
-            } else if (T.kind == 1) {
-                // forward stop: starts of its own ORF and operon partners, precomputed per target frame
-                const double* __restrict__ V = T.frame == 0 ? V0 : (T.frame == 1 ? V1 : V2);
-                for (int j = T.a0; j < lim; j++) take(B, true, V[j], j, -1, 0);
+            }
+        } else if (nx < n) {
+            Target T;
+            load_target(T, P, nx, lane, n, negc);
+            if (wave <= 3) {
+                const int kmax = min(63, n - 1 - nx);
+                for (int k = wave - 1; k < 64; k += 3) {
+                    bool ok = false, dyn = false; double w = 0.0;
+                    if (k < kmax) static_pair(k, nx, T, negc, s_igm, ok, w, dyn);
+                    s_w[pb][k][lane] = ok ? w : QNAN;
+                    const unsigned long long dm = __ballot(dyn);
+                    if (lane == 0) s_dyn[pb][k] = dm;
+                }
+                if (prof && lane == 0 && wave == 1) buf.prof[3] += __builtin_readcyclecounter() - tq0;
             } else {
-                // reverse start: its own stop, then forward stops overlapping its 3' end (ref: _connection.h:228-254)
-                if (T.a0 >= 0 && T.a0 < lim) pair_eval(T.a0, src, score, tbn, T, negc, s_igm, B);
-                const int zb = min(T.a2, lim);
-                for (int j = T.a1; j < zb; j++)
-                    if (PGA_KIND(src[j].meta) == 1) pair_eval(j, src, score, tbn, T, negc, s_igm, B);
-            }
-            if (B.tb >= 0) B.tbn = src[B.tb].ndx;
-            else { B.val = 0.0; B.ov = -1; B.tbn = -1; }
-        }
-        if (prof) tp3 = __builtin_readcyclecounter();
-        // ---- sources inside this batch: the lanes themselves, in order
-        const int kmax = min(63, n - 1 - i0);
-        for (int k = 0; k < kmax; k++) {
-            const int sk = PGA_KIND(__builtin_amdgcn_readlane(T.meta, k));
-            const int tbk = __builtin_amdgcn_readlane(B.tb, k);
-            if ((sk == 1 || sk == 2) && tbk == -1) continue;
-            SrcLane S;
-            S.ndx = T.ndx; S.stop_val = T.stop_val; S.meta = T.meta; S.tbn = B.tbn;
-            S.cs = T.cs; S.x0 = T.x0; S.x1 = T.x1; S.x2 = T.x2; S.score = B.val;
-            visit_source(k, i0 + k, S, T, negc, s_igm, B);
-        }
-        if (prof) tp4 = __builtin_readcyclecounter();
-        // ---- the batch is final: store it with its far-field candidate values and extend the tree
-        double a_val = NEG_INF;
-        if (act) {
-            const bool alive = B.tb != -1;
-            score[T.i] = B.val; traceb[T.i] = B.tb; ovm[T.i] = (int8_t)B.ov; tbn[T.i] = alive ? B.tbn : -1;
-            double v0 = NEG_INF, v1 = NEG_INF, v2 = NEG_INF;
-            if (T.kind == 0) {
-                const double g = B.val + T.cs;
-                if (T.frame == 0) v0 = g; else if (T.frame == 1) v1 = g; else v2 = g;
-            } else if (T.kind == 1 && alive) {
-                a_val = B.val + negc;
-                if (PGA_SPVALID(T.meta, 0)) v0 = B.val + T.x0;
-                if (PGA_SPVALID(T.meta, 1)) v1 = B.val + T.x1;
-                if (PGA_SPVALID(T.meta, 2)) v2 = B.val + T.x2;
-            } else if (T.kind == 2 && alive) {
-                a_val = B.val + negc;
-            }
-            A[T.i] = a_val; V0[T.i] = v0; V1[T.i] = v1; V2[T.i] = v2;
-            if ((T.kind == 1 || T.kind == 2) && B.val >= end_best) { end_best = B.val; end_idx = T.i; end_tb = B.tb; }
-        }
-        if (i0 + 64 <= n) {
-            double rv = a_val; int ri = T.i;
-#pragma unroll
-            for (int m = 1; m <= 4; m <<= 1) {
-                const double ov2 = __shfl_xor(rv, m, 64); const int oi = __shfl_xor(ri, m, 64);
-                if (ov2 > rv || (ov2 == rv && oi > ri)) { rv = ov2; ri = oi; }
-            }
-            const int tile = i0 >> 6;
-            if ((lane & 7) == 0 && (n >> 3) > 0) { hv[s_levbase[1] + (i0 >> 3) + (lane >> 3)] = rv; hi[s_levbase[1] + (i0 >> 3) + (lane >> 3)] = ri; }
-#pragma unroll
-            for (int m = 8; m <= 32; m <<= 1) {
-                const double ov2 = __shfl_xor(rv, m, 64); const int oi = __shfl_xor(ri, m, 64);
-                if (ov2 > rv || (ov2 == rv && oi > ri)) { rv = ov2; ri = oi; }
-            }
-            if (lane == 0) { hv[s_levbase[2] + tile] = rv; hi[s_levbase[2] + tile] = ri; }
-            // higher levels: a block of 8 children closes when its last child does
-            int child = tile, lev = 2;
-            while ((child & 7) == 7 && (lev + 1) * 3 < 31 && (n >> (3 * (lev + 1))) > 0) {
-                double cv = NEG_INF; int ci = -1;
-                if (lane < 8) { cv = hv[s_levbase[lev] + child - 7 + lane]; ci = hi[s_levbase[lev] + child - 7 + lane]; }
-#pragma unroll
-                for (int m = 1; m <= 4; m <<= 1) {
-                    const double ov2 = __shfl_xor(cv, m, 64); const int oi = __shfl_xor(ci, m, 64);
-                    if (ov2 > cv || (ov2 == cv && oi > ci)) { cv = ov2; ci = oi; }
-                }
-                child >>= 3; lev++;
-                if (lane == 0) { hv[s_levbase[lev] + child] = cv; hi[s_levbase[lev] + child] = ci; }
+                Best B{0.0, -1, -1, -1};
+                if (b >= 1) far_field(T, 0, i0 - 64 + 64, P, s_levbase, negc, s_igm, B);   // every tile finalized before this iteration
+                s_eval[pb][lane] = B.val; s_etb[pb][lane] = B.tb; s_eov[pb][lane] = B.ov;
+                if (prof && lane == 0) buf.prof[4] += __builtin_readcyclecounter() - tq0;
             }
         }
-        if (prof) {
-            // wave-level: the slowest lane of each per-lane section bounds the wave; report the maxima
-            const unsigned long long tp5 = __builtin_readcyclecounter();
-            unsigned long long d_tree = tp1 > tp0 ? tp1 - tp0 : 0, d_near = tp2 > tp1 && tp1 ? tp2 - tp1 : 0;
-            unsigned long long d_f = tp3 - tp0, d_i = tp4 - tp3, d_fin = tp5 - tp4;
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) {
-                d_tree = max(d_tree, (unsigned long long)__shfl_xor((long long)d_tree, m, 64));
-                d_near = max(d_near, (unsigned long long)__shfl_xor((long long)d_near, m, 64));
-            }
-            if (lane == 0) { buf.prof[0] += d_f; buf.prof[1] += d_i; buf.prof[2] += d_fin; buf.prof[3] += d_tree; buf.prof[4] += d_near; buf.prof[5] += 1; }
-        }
+        __syncthreads();
+        if (prof && threadIdx.x == 0) buf.prof[6] += __builtin_readcyclecounter() - tq0;
     }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const double ob = __shfl_xor(end_best, m, 64);
-        const int oi = __shfl_xor(end_idx, m, 64);
-        const int ot = __shfl_xor(end_tb, m, 64);
-        if (ob > end_best || (ob == end_best && oi > end_idx)) { end_best = ob; end_idx = oi; end_tb = ot; }
-    }
-    if (lane == 0) {
-        buf.max_index[blockIdx.x] = end_idx; buf.max_score[blockIdx.x] = end_idx >= 0 ? end_best : 0.0;
-        buf.ipath[blockIdx.x] = (end_idx >= 0 && end_tb != -1) ? end_idx : -1;
-    }
+    if (wave == 0) publish_max(end_best, end_idx, end_tb, lane, buf);
 }
 
 // W wavefronts per chain.  Per 64-target batch:
@@ -624,7 +936,12 @@ void pga_launch_dp(const ChainDesc* d_chains, int n_chains, const ModelConst* d_
         d_models, buf.score, buf.traceb, buf.tbn, buf.ov_mark, buf.max_index, buf.max_score, buf.ipath)
     const char* kern = getenv("PGA_DP_KERNEL");
     if (!kern || strcmp(kern, "scan") != 0) {
-        hipLaunchKernelGGL(k_dp_tree, dim3(n_chains), dim3(64), 0, st, d_chains, buf.src, buf.tgt, d_models, buf);
+        // many chains: one wave each fills the chip; few chains: latency-bound, 3 cooperating waves per chain
+        bool mw = n_chains < 2048;
+        if (kern && strcmp(kern, "tree1") == 0) mw = false;
+        if (kern && strcmp(kern, "tree3") == 0) mw = true;
+        if (mw) hipLaunchKernelGGL(k_dp_tree_mw, dim3(n_chains), dim3(64 * PGA_MW_WAVES), 0, st, d_chains, buf.src, buf.tgt, d_models, buf);
+        else hipLaunchKernelGGL(k_dp_tree, dim3(n_chains), dim3(64), 0, st, d_chains, buf.src, buf.tgt, d_models, buf);
         return;
     }
     // PGA_DP_KERNEL=scan: the window-scanning kernels (kept as an independent cross-check of the tree kernel)

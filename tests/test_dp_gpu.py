@@ -94,15 +94,21 @@ def test_training_pass_is_rejected_loudly(ctx):
         ctx.score_connections([0], [0], [0], [1], [0.0], [0.0], [0.0], [0.0], np.zeros((1, 3)), 4.35, final=False)
 
 
-@pytest.mark.parametrize("variant", ["tree", "scan1", "scan4", "scan16"])
+@pytest.mark.parametrize("variant", ["tree1", "tree3", "scan1", "scan4", "scan16"])
 def test_dp_kernel_variants_agree_with_oracle(ctx, variant, monkeypatch):
     # default = tree kernel (far field from the max tree); PGA_DP_KERNEL=scan selects the window-scanning
     # kernels with 1, 4 or 16 wavefronts per chain, kept as an independent cross-check
     if variant.startswith("scan"):
         monkeypatch.setenv("PGA_DP_KERNEL", "scan")
         monkeypatch.setenv("PGA_DP_WAVES", variant[4:])
+    else:
+        monkeypatch.setenv("PGA_DP_KERNEL", variant)     # tree1: one wave per chain; tree3: three cooperating waves
     seq = read_fasta("MIIJ01000039.fna.gz")[0][1]
     tinf = orc.Training.load(golden_path("SRR492066.training.bin.gz"))
     check(ctx, seq, tinf, is_meta=True)
     seq = synthetic_contig(150000, 0.62, 5)
     check(ctx, seq, tinf, is_meta=True)
+    for L in (100, 700, 4000):                        # chains shorter than / around one 64-node batch
+        s2 = synthetic_contig(L, 0.5, 900 + L)
+        if len(oracle_dp(s2, tinf, is_meta=True)[0]):
+            check(ctx, s2, tinf, is_meta=True)
