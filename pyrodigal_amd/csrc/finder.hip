@@ -336,6 +336,8 @@ struct pga_batch {
     int64_t total;
     std::vector<ContigDesc> ct;   // n + 1 entries
     char* d_seq;                  // packed ASCII, resident in HBM
+    TileDesc* d_tiles;            // extraction tiles of every contig
+    int32_t n_tiles;
 };
 
 extern "C" int pga_batch_create(pga_ctx* c, int32_t n_contigs, const char* const* seqs, const int64_t* lens, pga_batch** out) {
@@ -345,7 +347,7 @@ extern "C" int pga_batch_create(pga_ctx* c, int32_t n_contigs, const char* const
     HT(c, hipSetDevice(c->device));
     pga_batch* b = new (std::nothrow) pga_batch();
     if (!b) return PGA_ENOMEM;
-    b->ctx = c; b->n = n_contigs; b->d_seq = nullptr; b->ct.resize((size_t)n_contigs + 1);
+    b->ctx = c; b->n = n_contigs; b->d_seq = nullptr; b->d_tiles = nullptr; b->n_tiles = 0; b->ct.resize((size_t)n_contigs + 1);
     int64_t total = 0;
     for (int i = 0; i < n_contigs; i++) {
         if (lens[i] < 0 || lens[i] > 0x7fff0000LL || (lens[i] > 0 && !seqs[i])) { delete b; c->err = "pga_batch_create: bad contig length"; return PGA_EINVAL; }
@@ -364,6 +366,16 @@ extern "C" int pga_batch_create(pga_ctx* c, int32_t n_contigs, const char* const
         hipError_t e = hipMemcpyAsync(b->d_seq, h_seq, (size_t)total, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { hipFree(b->d_seq); delete b; return pga_hip_try_(c, e, "upload of the batch"); }
+        std::vector<TileDesc> tiles;
+        const int TS = pga_extract_tile_size();
+        for (int i = 0; i < n_contigs; i++)
+            for (int64_t s0 = 0; s0 + 2 < lens[i]; s0 += TS) tiles.push_back(TileDesc{i, (int32_t)s0});
+        b->n_tiles = (int32_t)tiles.size();
+        if (!tiles.empty()) {
+            if (hipMalloc((void**)&b->d_tiles, sizeof(TileDesc) * tiles.size()) != hipSuccess) { hipFree(b->d_seq); delete b; c->err = "pga_batch_create: hipMalloc failed"; return PGA_ENOMEM; }
+            e = hipMemcpy(b->d_tiles, tiles.data(), sizeof(TileDesc) * tiles.size(), hipMemcpyHostToDevice);
+            if (e != hipSuccess) { hipFree(b->d_tiles); hipFree(b->d_seq); delete b; return pga_hip_try_(c, e, "upload of the tile list"); }
+        }
     }
     *out = b;
     return PGA_OK;
@@ -372,6 +384,7 @@ extern "C" int pga_batch_create(pga_ctx* c, int32_t n_contigs, const char* const
 extern "C" void pga_batch_free(pga_batch* b) {
     if (!b) return;
     if (b->d_seq) { hipSetDevice(b->ctx->device); hipFree(b->d_seq); }
+    if (b->d_tiles) hipFree(b->d_tiles);
     delete b;
 }
 
@@ -430,6 +443,8 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
         const int64_t tiles = pga_scan_tiles(total);
         DEVBUF(d_tile, int2, "d_tile", tiles);
         DEVBUF(d_cbase, int32_t, "d_cbase", (size_t)NG * (NC + 1));
+        DEVBUF(d_tile_first, int32_t, "d_tile_first", (size_t)6 * batch->n_tiles);
+        DEVBUF(d_tile_last, int32_t, "d_tile_last", (size_t)6 * batch->n_tiles);
         PINBUF(h_cnt, int32_t, "h_cnt", 2 * (size_t)NC);
         PINBUF(h_cbase, int32_t, "h_cbase", (size_t)NG * (NC + 1));
 
@@ -452,7 +467,7 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
             const int tt = P.meta ? f->group_tt[g] : c->models[0].trans_table;
             HT(c, hipMemsetAsync(ga[g].nf_fwd, 0, (size_t)total + 1, st));
             HT(c, hipMemsetAsync(ga[g].nf_rev, 0, (size_t)total + 1, st));
-            pga_launch_extract(d_dig, total, d_ct, NC, tt, P, ga[g], d_tile, d_pre_gc, g == 0, st);
+            pga_launch_extract(d_dig, total, d_ct, NC, tt, P, ga[g], d_tile, d_pre_gc, g == 0, batch->d_tiles, batch->n_tiles, d_tile_first, d_tile_last, st);
             hipLaunchKernelGGL(k_contig_node_base, dim3((NC + 1 + 255) / 256), dim3(256), 0, st, d_ct, NC, total, ga[g].pre_nodes, d_cbase + (size_t)g * (NC + 1));
         }
         HT(c, hipMemcpyAsync(h_cnt, d_cnt, sizeof(int32_t) * 2 * (size_t)NC, hipMemcpyDeviceToHost, st));

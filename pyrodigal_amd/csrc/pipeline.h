@@ -9,6 +9,12 @@ struct ContigDesc {
     int32_t _pad;
 };
 
+// One 3072-position tile of one contig (strand-local coordinates) for the extraction kernels.
+struct TileDesc {
+    int32_t contig;
+    int32_t start;
+};
+
 // Per translation-table group: per-position scratch of the extraction and the node topology
 // (fields that do not depend on the model), indexed by global node number.
 struct GroupArrays {
@@ -45,7 +51,8 @@ void pga_launch_digitize(const char* d_seq, uint8_t* d_dig, int64_t total, const
                          int32_t* d_gc, int32_t* d_unk, hipStream_t st);
 void pga_launch_extract(const uint8_t* d_dig, int64_t total, const ContigDesc* d_ct, int n_contigs, int tt,
                         const pga_params& p, const GroupArrays& ga, int2* d_tile_sum, int32_t* d_pre_gc, int write_gc,
-                        hipStream_t st);
+                        const TileDesc* d_tiles, int n_tiles, int32_t* d_tile_first, int32_t* d_tile_last, hipStream_t st);
+int pga_extract_tile_size();
 void pga_launch_compact(int64_t total, const ContigDesc* d_ct, int n_contigs, const GroupArrays& ga, hipStream_t st);
 void pga_launch_orf_gc(const ContigDesc* d_ct, int n_contigs, const int32_t* d_pre_gc, const GroupArrays& ga,
                        int n_nodes_total, const int32_t* d_node_contig_base, hipStream_t st);

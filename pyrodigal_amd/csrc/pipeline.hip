@@ -150,57 +150,171 @@ k_digitize(const char* __restrict__ seq, uint8_t* __restrict__ dig, int64_t tota
 }
 
 // ------------------------------------------------------------------------- node extraction
-// One thread per (position, strand).  A thread that sits on a stop codon -- or on one of the three
-// virtual right ends of an open contig -- owns the ORF to its left and replays the reference's
-// per-frame automaton on it.   ref: lib.pyx:1905-2117 (Nodes._extract)
+// ref: lib.pyx:1905-2117 (Nodes._extract).  The reference sweeps each strand right to left with three
+// per-frame automata whose whole state is "position of the next in-frame stop to the right" (`last`),
+// plus "was a start seen in this ORF".  Both are scans:
+//   NS(i) = next in-frame stop to the right of i (or the virtual right end of an open contig),
+//   PS(i) = previous in-frame stop to the left of i,
+// so every position decides on its own whether it is a start node, and every start also writes the
+// stop node of its ORF (all starts of an ORF write identical values).  No walk, no divergence:
+// tiles of 3072 positions, 12 consecutive positions per thread, coalesced byte reads.
+constexpr int EX_TILE = 3072;          // positions per tile (256 threads x 12)
+constexpr int EX_PER_THREAD = 12;
+constexpr int EX_NONE_HI = 0x7fffffff; // "no stop to the right"
+
+// pass 1: first / last stop position of every tile, per frame
 __global__ void __launch_bounds__(256)
-k_extract_orfs(const uint8_t* __restrict__ dig, int64_t total, const ContigDesc* __restrict__ ct, int n_contigs,
-               int tt, int closed, int min_gene, int min_edge_gene, GroupArrays ga) {
-    __shared__ int s_c0;
+k_tile_stops(const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct, const TileDesc* __restrict__ tiles, int n_tiles,
+             int tt, int32_t* __restrict__ tile_first, int32_t* __restrict__ tile_last) {
+    __shared__ int s_min[3][4], s_max[3][4];
+    const TileDesc td = tiles[blockIdx.x];
     const int strand = blockIdx.y == 0 ? 1 : -1;
-    const int64_t blk0 = (int64_t)blockIdx.x * blockDim.x;
-    const int64_t g = blk0 + threadIdx.x;
-    const int c = block_contig(ct, n_contigs, blk0, g < total ? g : blk0, &s_c0);
-    if (g >= total) return;
-    const int L = ct[c].len;
-    const int64_t base = ct[c].base;
+    const ContigDesc cd = ct[td.contig];
+    const int L = cd.len;
+    const uint8_t* __restrict__ d = dig + cd.base;
+    const int i0 = td.start + threadIdx.x * EX_PER_THREAD;
+    int mn[3] = {EX_NONE_HI, EX_NONE_HI, EX_NONE_HI}, mx[3] = {-1, -1, -1};
+    if (i0 <= L - 3) {
+        int c[EX_PER_THREAD + 2];
+#pragma unroll
+        for (int q = 0; q < EX_PER_THREAD + 2; q++) c[q] = (i0 + q < L) ? sbase(d, L, i0 + q, strand) : NN;
+#pragma unroll
+        for (int q = 0; q < EX_PER_THREAD; q++) {
+            const int i = i0 + q;
+            if (i <= L - 3 && codon_is_stop(c[q], c[q + 1], c[q + 2], tt)) {
+                const int f = i % 3;
+                mn[f] = min(mn[f], i); mx[f] = max(mx[f], i);
+            }
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < 3; f++) {
+        int a = mn[f], b = mx[f];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { a = min(a, __shfl_xor(a, m, 64)); b = max(b, __shfl_xor(b, m, 64)); }
+        if ((threadIdx.x & 63) == 0) { s_min[f][threadIdx.x >> 6] = a; s_max[f][threadIdx.x >> 6] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int f = threadIdx.x;
+        const int64_t o = ((int64_t)blockIdx.y * n_tiles + blockIdx.x) * 3 + f;
+        tile_first[o] = min(min(s_min[f][0], s_min[f][1]), min(s_min[f][2], s_min[f][3]));
+        tile_last[o] = max(max(s_max[f][0], s_max[f][1]), max(s_max[f][2], s_max[f][3]));
+    }
+}
+
+// pass 2: every position decides
+__global__ void __launch_bounds__(256)
+k_extract_scan(const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct, const TileDesc* __restrict__ tiles, int n_tiles,
+               const int32_t* __restrict__ tile_first, const int32_t* __restrict__ tile_last,
+               int tt, int closed, int min_gene, int min_edge_gene, GroupArrays ga) {
+    __shared__ int s_first[3][256], s_last[3][256];
+    __shared__ int s_carry_ns[3], s_carry_ps[3];
+    const TileDesc td = tiles[blockIdx.x];
+    const int strand = blockIdx.y == 0 ? 1 : -1;
+    const ContigDesc cd = ct[td.contig];
+    const int L = cd.len;
+    const int64_t base = cd.base;
     const uint8_t* __restrict__ d = dig + base;
-    const int p = (int)(g - base);           // strand-local codon position
-    if (L < 3 || p > L - 3) return;
-    const bool real_stop = is_stop_at(d, L, p, strand, tt);
-    // virtual right end of frame p%3 in open mode: the last full codon position of the frame
-    const bool virt = !real_stop && !closed && p + 3 > L - 3;
-    if (!real_stop && !virt) return;
-    const int last = p;
-    const int mind = real_stop ? min_gene : min_edge_gene;
+    const int t = threadIdx.x;
+    const int i0 = td.start + t * EX_PER_THREAD;
+    // tile carries: nearest stop of each frame in the following / preceding tiles of the same contig
+    if (t < 6) {
+        const int f = t % 3;
+        const int64_t so = (int64_t)blockIdx.y * n_tiles;
+        if (t < 3) {
+            int v = EX_NONE_HI;
+            for (int k = blockIdx.x + 1; k < n_tiles && tiles[k].contig == td.contig; k++) {
+                v = tile_first[(so + k) * 3 + f];
+                if (v != EX_NONE_HI) break;
+            }
+            s_carry_ns[f] = v;
+        } else {
+            int v = -1;
+            for (int k = (int)blockIdx.x - 1; k >= 0 && tiles[k].contig == td.contig; k--) {
+                v = tile_last[(so + k) * 3 + f];
+                if (v != -1) break;
+            }
+            s_carry_ps[f] = v;
+        }
+    }
+    int c[EX_PER_THREAD + 2];
+    bool st[EX_PER_THREAD];
+    int mn[3] = {EX_NONE_HI, EX_NONE_HI, EX_NONE_HI}, mx[3] = {-1, -1, -1};
+#pragma unroll
+    for (int q = 0; q < EX_PER_THREAD + 2; q++) c[q] = (i0 + q < L) ? sbase(d, L, i0 + q, strand) : NN;
+#pragma unroll
+    for (int q = 0; q < EX_PER_THREAD; q++) {
+        const int i = i0 + q;
+        st[q] = i <= L - 3 && codon_is_stop(c[q], c[q + 1], c[q + 2], tt);
+        if (st[q]) { const int f = i % 3; mn[f] = min(mn[f], i); mx[f] = max(mx[f], i); }
+    }
+#pragma unroll
+    for (int f = 0; f < 3; f++) { s_first[f][t] = mn[f]; s_last[f][t] = mx[f]; }
+    __syncthreads();
+    // exclusive suffix-min of s_first / exclusive prefix-max of s_last over the 256 threads (Hillis-Steele in LDS)
+    for (int off = 1; off < 256; off <<= 1) {
+        int a[3], b[3];
+#pragma unroll
+        for (int f = 0; f < 3; f++) {
+            a[f] = t + off < 256 ? s_first[f][t + off] : EX_NONE_HI;
+            b[f] = t - off >= 0 ? s_last[f][t - off] : -1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int f = 0; f < 3; f++) { s_first[f][t] = min(s_first[f][t], a[f]); s_last[f][t] = max(s_last[f][t], b[f]); }
+        __syncthreads();
+    }
+    int nxt[3], prv[3];
+#pragma unroll
+    for (int f = 0; f < 3; f++) {
+        nxt[f] = t + 1 < 256 ? s_first[f][t + 1] : EX_NONE_HI;       // inclusive scans shifted by one thread
+        prv[f] = t >= 1 ? s_last[f][t - 1] : -1;
+        if (nxt[f] == EX_NONE_HI) nxt[f] = s_carry_ns[f];
+        if (prv[f] == -1) prv[f] = s_carry_ps[f];
+    }
+    if (i0 > L - 3) return;
+    // previous stop of every position (ascending), then decisions (descending, tracking the next stop)
+    int ps[EX_PER_THREAD];
+#pragma unroll
+    for (int q = 0; q < EX_PER_THREAD; q++) {
+        const int f = (i0 + q) % 3;
+        ps[q] = prv[f];
+        if (st[q]) prv[f] = i0 + q;
+    }
     uint8_t* __restrict__ nf = strand == 1 ? ga.nf_fwd : ga.nf_rev;
     int32_t* __restrict__ tsv = strand == 1 ? ga.tsv_fwd : ga.tsv_rev;
     uint8_t* __restrict__ tinfo = strand == 1 ? ga.tinfo_fwd : ga.tinfo_rev;
-    bool saw = false;
-    int left_stop = -1;                        // position of the in-frame stop that ends the walk
-    // a real stop is not a start candidate itself; a virtual end is (ref: the scan visits i == last)
-    for (int i = real_stop ? p - 3 : p; i >= 0; i -= 3) {
-        const int x0 = sbase(d, L, i, strand), x1 = sbase(d, L, i + 1, strand), x2 = sbase(d, L, i + 2, strand);
-        if (codon_is_stop(x0, x1, x2, tt)) { left_stop = i; break; }
+#pragma unroll
+    for (int q = EX_PER_THREAD - 1; q >= 0; q--) {
+        const int i = i0 + q, f = i % 3;
+        if (i > L - 3) continue;
+        if (st[q]) { nxt[f] = i; continue; }
+        int last = nxt[f];
+        bool real = last != EX_NONE_HI;
+        if (!real) {
+            if (closed) continue;                       // closed ends: nothing runs off the right edge
+            last = L - 3 - ((L - 3 - f) % 3);           // virtual right end: last full codon position of the frame
+            if (last < i) continue;
+        }
+        const int mind = real ? min_gene : min_edge_gene;
         int type = -1, edge = 0;
-        if (last - i + 3 >= mind && codon_is_start(x0, x1, x2, tt)) type = x0 == NA ? 0 : (x0 == NT ? 2 : 1);
+        if (last - i + 3 >= mind && codon_is_start(c[q], c[q + 1], c[q + 2], tt)) type = c[q] == NA ? 0 : (c[q] == NT ? 2 : 1);
         else if (i <= 2 && !closed && last - i > min_edge_gene) { type = 0; edge = 1; }
         if (type < 0) continue;
-        saw = true;
-        const int pos = strand == 1 ? i : L - 1 - i;                 // node ndx on forward coordinates
+        const int pos = strand == 1 ? i : L - 1 - i;
         nf[base + pos] = 1;
-        tsv[base + pos] = strand == 1 ? last : L - 1 - last;         // stop_val of a start = ndx of its stop
+        tsv[base + pos] = strand == 1 ? last : L - 1 - last;
         tinfo[base + pos] = (uint8_t)(type | (edge << 2));
-    }
-    if (saw) {
-        const int pos = strand == 1 ? last : L - 1 - last;
-        const int fr = p % 3;
+        // the stop node of this ORF (every start of the ORF writes the same bytes)
+        const int lpos = strand == 1 ? last : L - 1 - last;
+        const int left = ps[q];
         int sv;
-        if (strand == 1) sv = left_stop >= 0 ? left_stop : fr - 6;
-        else sv = left_stop >= 0 ? L - 1 - left_stop : L - fr + 5;
-        nf[base + pos] = 1;
-        tsv[base + pos] = sv;
-        tinfo[base + pos] = (uint8_t)(PGA_T_STOP | ((real_stop ? 0 : 1) << 2));
+        if (strand == 1) sv = left >= 0 ? left : f - 6;
+        else sv = left >= 0 ? L - 1 - left : L - f + 5;
+        nf[base + lpos] = 1;
+        tsv[base + lpos] = sv;
+        tinfo[base + lpos] = (uint8_t)(PGA_T_STOP | ((real ? 0 : 1) << 2));
     }
 }
 
@@ -670,16 +784,21 @@ void pga_launch_digitize(const char* d_seq, uint8_t* d_dig, int64_t total, const
 
 void pga_launch_extract(const uint8_t* d_dig, int64_t total, const ContigDesc* d_ct, int n_contigs, int tt,
                         const pga_params& p, const GroupArrays& ga, int2* d_tile_sum, int32_t* d_pre_gc, int write_gc,
-                        hipStream_t st) {
+                        const TileDesc* d_tiles, int n_tiles, int32_t* d_tile_first, int32_t* d_tile_last, hipStream_t st) {
     if (total <= 0) return;
-    hipLaunchKernelGGL(k_extract_orfs, dim3(nblocks(total, 256), 2), dim3(256), 0, st, d_dig, total, d_ct, n_contigs, tt,
-                       p.closed, p.min_gene, p.min_edge_gene, ga);
+    if (n_tiles > 0) {
+        hipLaunchKernelGGL(k_tile_stops, dim3(n_tiles, 2), dim3(256), 0, st, d_dig, d_ct, d_tiles, n_tiles, tt, d_tile_first, d_tile_last);
+        hipLaunchKernelGGL(k_extract_scan, dim3(n_tiles, 2), dim3(256), 0, st, d_dig, d_ct, d_tiles, n_tiles, d_tile_first, d_tile_last, tt,
+                           p.closed, p.min_gene, p.min_edge_gene, ga);
+    }
     const int tiles = (int)pga_scan_tiles(total);
     hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(256), 0, st, ga.nf_fwd, ga.nf_rev, d_dig, total, d_tile_sum);
     hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(1024), 0, st, d_tile_sum, tiles);
     hipLaunchKernelGGL(k_scan_final, dim3(tiles), dim3(256), 0, st, ga.nf_fwd, ga.nf_rev, d_dig, total, d_tile_sum,
                        ga.pre_nodes, d_pre_gc, write_gc);
 }
+
+int pga_extract_tile_size() { return EX_TILE; }
 
 void pga_launch_compact(int64_t total, const ContigDesc* d_ct, int n_contigs, const GroupArrays& ga, hipStream_t st) {
     if (total <= 0) return;
