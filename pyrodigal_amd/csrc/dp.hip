@@ -462,9 +462,13 @@ __device__ __forceinline__ double f3_to_reverse(const int s_ndx, const int tbnj,
     return is3 ? (m != -1 ? maxval : negc) : T.csd;
 }
 
-// far_field for the one tile [base, base + 64) that the serial wave keeps in LDS (the tile it finalized last).
+// far_field for the one tile [base, base + 64) that the serial wave keeps in LDS (the tile it finalized
+// last).  The sources are dealt round-robin to `mod` waves (this call handles j % mod == rem); the partial
+// results are merged with the lexicographic maximum.  `tree` selects who takes the block maxima.
+__device__ __forceinline__ int first_at_or_after(int lo, int rem, int mod) { return lo + ((rem - lo) % mod + mod) % mod; }
+
 __device__ __forceinline__ void late_field(const Target& T, const TileLds* tile, const int base, const double negc,
-                                           const double* s_igm, Best& B) {
+                                           const double* s_igm, Best& B, const int rem = 0, const int mod = 1, const bool tree = true) {
     if (T.i < 0) return;
     const int chi = min(base + 64, T.i);
     const int clo = max(base, T.lo);
@@ -472,15 +476,17 @@ __device__ __forceinline__ void late_field(const Target& T, const TileLds* tile,
     const TileAcc S{tile, base};
     if (T.kind == 0 || T.kind == 3) {
         const int fr = min(T.p_near, chi);
-        if (clo == base && fr == base + 64) take(B, true, tile->l2v, tile->l2i, -1, 0);
-        else if (clo < fr) {
-            const int l = clo - base, r = fr - base;
-            const int l_end = min(r, (l + 7) & ~7), r_beg = max(l_end, r & ~7);
-            for (int q = l; q < l_end; q++) take(B, true, tile->A[q], base + q, -1, 0);
-            for (int q = r_beg; q < r; q++) take(B, true, tile->A[q], base + q, -1, 0);
-            for (int q = l_end >> 3; q < (r_beg >> 3); q++) take(B, true, tile->l1v[q], tile->l1i[q], -1, 0);
+        if (tree) {
+            if (clo == base && fr == base + 64) take(B, true, tile->l2v, tile->l2i, -1, 0);
+            else if (clo < fr) {
+                const int l = clo - base, r = fr - base;
+                const int l_end = min(r, (l + 7) & ~7), r_beg = max(l_end, r & ~7);
+                for (int q = l; q < l_end; q++) take(B, true, tile->A[q], base + q, -1, 0);
+                for (int q = r_beg; q < r; q++) take(B, true, tile->A[q], base + q, -1, 0);
+                for (int q = l_end >> 3; q < (r_beg >> 3); q++) take(B, true, tile->l1v[q], tile->l1i[q], -1, 0);
+            }
         }
-        for (int j = max(T.p_near, clo); j < chi; j++) {
+        for (int j = first_at_or_after(max(T.p_near, clo), rem, mod); j < chi; j += mod) {
             // only alive gene ends (A != -inf) connect to a gene begin; a reverse start towards a forward start
             // is worth exactly A (ref: _connection.h:125-130)
             const int q = j - base;
@@ -504,25 +510,25 @@ __device__ __forceinline__ void late_field(const Target& T, const TileLds* tile,
             for (int k = 0; k < 3; k++) {
                 if (!PGA_SPVALID(T.meta, k)) continue;
                 const int zb = min(sel3i(k, T.b0, T.b1, T.b2), chi);
-                for (int j = max(sel3i(k, T.a0, T.a1, T.a2), clo); j < zb; j++)
+                for (int j = first_at_or_after(max(sel3i(k, T.a0, T.a1, T.a2), clo), rem, mod); j < zb; j += mod)
                     if (PGA_KIND(S.meta(j)) == 1) pair_eval(j, S, T, negc, s_igm, B);
             }
 #pragma unroll
             for (int f = 0; f < 3; f++) {
                 const int j = sel3i(f, T.c0, T.c1, T.c2);
-                if (j >= clo && j < chi) pair_eval(j, S, T, negc, s_igm, B);
+                if (j >= clo && j < chi && (j % mod) == rem) pair_eval(j, S, T, negc, s_igm, B);
             }
         }
     } else if (T.kind == 1) {
-        for (int j = max(T.a0, clo); j < chi; j++) {
+        for (int j = first_at_or_after(max(T.a0, clo), rem, mod); j < chi; j += mod) {
             const int q = j - base;
             const double v = T.frame == 0 ? tile->V0[q] : (T.frame == 1 ? tile->V1[q] : tile->V2[q]);
             take(B, true, v, j, -1, 0);
         }
     } else {
-        if (T.a0 >= clo && T.a0 < chi) pair_eval(T.a0, S, T, negc, s_igm, B);
+        if (T.a0 >= clo && T.a0 < chi && (T.a0 % mod) == rem) pair_eval(T.a0, S, T, negc, s_igm, B);
         const int zb = min(T.a2, chi);
-        for (int j = max(T.a1, clo); j < zb; j++)
+        for (int j = first_at_or_after(max(T.a1, clo), rem, mod); j < zb; j += mod)
             if (PGA_KIND(S.meta(j)) == 1) pair_eval(j, S, T, negc, s_igm, B);
     }
 }
@@ -726,78 +732,121 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
     double end_best = -1.0; int end_idx = -1, end_tb = -1;
     const int nb = (n + 63) >> 6;
     const bool prof = buf.prof != nullptr && blockIdx.x == 0;
-    if (wave == 0) __builtin_amdgcn_s_setprio(3);   // the serial wave is the critical path of the chain
+    __shared__ double s_lval[4][64];                  // partial results of the late field (waves 0-3)
+    __shared__ int s_ltb[4][64], s_lov[4][64];
 
-    for (int b = -1; b < nb; b++) {                 // iteration -1: only the helpers work (for batch 0)
-        const int i0 = b << 6;                      // this batch (wave 0)
-        const int nx = (b + 1) << 6, pb = (b + 1) & 1;    // next batch (helpers) and its LDS slot
+    if (n <= 0) {                                    // empty chain (contig without nodes): nothing to walk
+        if (wave == 0) publish_max(end_best, end_idx, end_tb, lane, buf);
+        return;
+    }
+    // prologue: static weights of batch 0; its far field is empty
+    Target Tn;
+    load_target(Tn, P, 0, lane, n, negc);
+    if (wave >= 1 && wave <= 3) {
+        const int kmax = min(63, n - 1);
+        for (int k = wave - 1; k < 64; k += 3) {
+            bool ok = false, dyn = false; double w = 0.0;
+            if (k < kmax) static_pair(k, 0, Tn, negc, s_igm, ok, w, dyn);
+            s_w[0][k][lane] = ok ? w : QNAN;
+            const unsigned long long dm = __ballot(dyn);
+            if (lane == 0) s_dyn[0][k] = dm;
+        }
+    } else if (wave == 4) { s_eval[0][lane] = 0.0; s_etb[0][lane] = -1; s_eov[0][lane] = -1; }
+    __syncthreads();
+
+    for (int b = 0; b < nb; b++) {
+        const int i0 = b << 6, slot = b & 1;
+        const int nx = i0 + 64, pb = slot ^ 1;
         const unsigned long long tq0 = prof ? __builtin_readcyclecounter() : 0;
+        const Target T = Tn;                                   // this batch; every wave holds the same 64 targets
+        if (nx < n) load_target(Tn, P, nx, lane, n, negc);     // next batch, needed after the first barrier
+        // ---- phase L: the tile finalized last (LDS), its sources dealt to waves 0-3
+        if (wave < 4) {
+            Best Bl{0.0, -1, -1, -1};
+            if (i0 > 0) late_field(T, &s_tile, i0 - 64, negc, s_igm, Bl, wave, 4, wave == 0);
+            s_lval[wave][lane] = Bl.val; s_ltb[wave][lane] = Bl.tb; s_lov[wave][lane] = Bl.ov;
+        }
+        __syncthreads();
+        const unsigned long long tq1 = prof ? __builtin_readcyclecounter() : 0;
         if (wave == 0) {
-            if (b >= 0) {
-                const int slot = b & 1;
-                Target T;
-                load_target(T, P, i0, lane, n, negc);
-                Best B{s_eval[slot][lane], s_etb[slot][lane], s_eov[slot][lane], -1};
-                if (i0 > 0) late_field(T, &s_tile, i0 - 64, negc, s_igm, B);
-                if (B.tb >= 0) B.tbn = P.src[B.tb].ndx;
-                const unsigned long long tq1 = prof ? __builtin_readcyclecounter() : 0;
-                // lean in-batch walk: w(k, lane) comes from LDS eight sources at a time; only the recurrence
-                // (broadcast score of lane k, add, compare, select) is left on the serial path
-                const int kmax = min(63, n - 1 - i0);
-                const unsigned long long endmask = __ballot(T.kind == 1 || T.kind == 2);
-                const unsigned long long dynany = __ballot(s_dyn[slot][lane] != 0ull);
-                double wn = s_w[slot][0][lane];
-                for (int k = 0; k < kmax; k++) {
-                    const double w = wn;
-                    wn = s_w[slot][k + 1][lane];             // next step's weight is in flight while this one is used
-                    const int tbk = __builtin_amdgcn_readlane(B.tb, k);
-                    const bool alive = !(((endmask >> k) & 1ull) && tbk == -1);
-                    if (!alive) continue;
-                    if ((dynany >> k) & 1ull) {
-                        if (prof && lane == 0) buf.prof[7] += 1;
-                        // forward-stop source: forward targets use the static weight, reverse targets the dynamic rule
-                        const int s_ndx = __builtin_amdgcn_readlane(T.ndx, k);
-                        const int tbnj = __builtin_amdgcn_readlane(B.tbn, k);
-                        const int j = i0 + k;
-                        bool okd; int mf;
-                        const double wd = f3_to_reverse(s_ndx, tbnj, T, (j >= T.lo) & (j < T.i), negc, okd, mf);
-                        const bool rev = T.kind >= 2;
-                        const double wk = rev ? (okd ? wd : QNAN) : w;
-                        const double val = readlane_f64(B.val, k) + wk;
-                        if (val >= B.val) { B.val = val; B.tb = j; B.ov = rev ? mf : -1; B.tbn = s_ndx; }
-                        continue;
-                    }
-                    // in-batch sources come in ascending order, so the lexicographic test is the reference's plain ">=";
-                    // a NaN weight (pair not allowed) makes the comparison false
-                    const double val = readlane_f64(B.val, k) + w;
+            Best B{s_eval[slot][lane], s_etb[slot][lane], s_eov[slot][lane], -1};
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const double v = s_lval[w][lane]; const int t = s_ltb[w][lane];
+                if (t != -1 && (v > B.val || (v == B.val && t > B.tb))) { B.val = v; B.tb = t; B.ov = s_lov[w][lane]; }
+            }
+            // lean in-batch walk: the static weight w(k, lane) comes from LDS one step ahead; only the recurrence
+            // (broadcast score of lane k, add, compare, select) is left on the serial path.  The running result
+            // is (bv, tbx) with tbx = traceb | (ov_mark + 1) << 28, or -1 when nothing connected yet.
+            const int kmax = min(63, n - 1 - i0);
+            const unsigned long long endmask = __ballot(T.kind == 1 || T.kind == 2);
+            const unsigned long long dynany = __ballot(s_dyn[slot][lane] != 0ull);
+            double bv = B.val;
+            int tbx = B.tb < 0 ? -1 : (B.tb | ((B.ov + 1) << 28));
+            double wn = s_w[slot][0][lane];
+#pragma unroll 4
+            for (int k = 0; k < kmax; k++) {
+                const double w = wn;
+                wn = s_w[slot][k + 1][lane];
+                const int tbk = __builtin_amdgcn_readlane(tbx, k);
+                const bool dead = ((endmask >> k) & 1ull) && tbk < 0;    // gene end never reached: connects to nothing
+                const int j = i0 + k;
+                if (((dynany >> k) & 1ull) && !dead) {
+                    // forward-stop source: forward targets use the static weight, reverse targets the dynamic rule,
+                    // which needs the position of the source's own traceb node
                     const int s_ndx = __builtin_amdgcn_readlane(T.ndx, k);
-                    if (val >= B.val) { B.val = val; B.tb = i0 + k; B.ov = -1; B.tbn = s_ndx; }
+                    const int tbj = tbk & 0x0fffffff;
+                    int tbnj;
+                    if (tbj >= i0) tbnj = __builtin_amdgcn_readlane(T.ndx, tbj - i0);
+                    else if (tbj >= i0 - 64) tbnj = s_tile.ndx[tbj - (i0 - 64)];
+                    else tbnj = P.src[tbj].ndx;
+                    bool okd; int mf;
+                    const double wd = f3_to_reverse(s_ndx, tbnj, T, (j >= T.lo) & (j < T.i), negc, okd, mf);
+                    const bool rev = T.kind >= 2;
+                    const double val = readlane_f64(bv, k) + (rev ? (okd ? wd : QNAN) : w);
+                    const bool c = val >= bv;
+                    bv = c ? val : bv; tbx = c ? (j | (rev ? ((mf + 1) << 28) : 0)) : tbx;
+                    continue;
                 }
-                const unsigned long long tq2 = prof ? __builtin_readcyclecounter() : 0;
-                finalize_batch(T, B, i0, lane, n, P, s_levbase, negc, end_best, end_idx, end_tb, &s_tile);
-                if (prof && lane == 0) {
-                    const unsigned long long tq3 = __builtin_readcyclecounter();
-                    buf.prof[0] += tq1 - tq0; buf.prof[1] += tq2 - tq1; buf.prof[2] += tq3 - tq2; buf.prof[5] += 1;
-                }
+                // Branch-free step.  Ascending order makes the lexicographic test the reference's plain ">=";
+                // a NaN (pair not allowed, or dead source) fails it.
+                double sck = readlane_f64(bv, k);
+                sck = dead ? QNAN : sck;
+                const double val = sck + w;
+                const bool c = val >= bv;
+                bv = c ? val : bv; tbx = c ? j : tbx;
+            }
+            B.val = bv;
+            if (tbx < 0) { B.tb = -1; B.ov = -1; B.tbn = -1; }
+            else {
+                B.tb = tbx & 0x0fffffff; B.ov = (tbx >> 28) - 1;
+                // position of the traceb node, wherever it lives
+                const int rel = B.tb - i0;
+                const int in_batch = __shfl(T.ndx, rel >= 0 ? rel : 0, 64);
+                B.tbn = rel >= 0 ? in_batch : (rel >= -64 && i0 > 0 ? s_tile.ndx[rel + 64] : P.src[B.tb].ndx);
+            }
+            const unsigned long long tq2 = prof ? __builtin_readcyclecounter() : 0;
+            finalize_batch(T, B, i0, lane, n, P, s_levbase, negc, end_best, end_idx, end_tb, &s_tile);
+            if (prof && lane == 0) {
+                const unsigned long long tq3 = __builtin_readcyclecounter();
+                buf.prof[0] += tq1 - tq0; buf.prof[1] += tq2 - tq1; buf.prof[2] += tq3 - tq2; buf.prof[5] += 1;
             }
         } else if (nx < n) {
-            Target T;
-            load_target(T, P, nx, lane, n, negc);
             if (wave <= 3) {
                 const int kmax = min(63, n - 1 - nx);
                 for (int k = wave - 1; k < 64; k += 3) {
                     bool ok = false, dyn = false; double w = 0.0;
-                    if (k < kmax) static_pair(k, nx, T, negc, s_igm, ok, w, dyn);
+                    if (k < kmax) static_pair(k, nx, Tn, negc, s_igm, ok, w, dyn);
                     s_w[pb][k][lane] = ok ? w : QNAN;
                     const unsigned long long dm = __ballot(dyn);
                     if (lane == 0) s_dyn[pb][k] = dm;
                 }
-                if (prof && lane == 0 && wave == 1) buf.prof[3] += __builtin_readcyclecounter() - tq0;
+                if (prof && lane == 0 && wave == 1) buf.prof[3] += __builtin_readcyclecounter() - tq1;
             } else {
                 Best B{0.0, -1, -1, -1};
-                if (b >= 1) far_field(T, 0, i0 - 64 + 64, P, s_levbase, negc, s_igm, B);   // every tile finalized before this iteration
+                if (i0 > 0) far_field(Tn, 0, i0, P, s_levbase, negc, s_igm, B);    // every tile finalized before this iteration
                 s_eval[pb][lane] = B.val; s_etb[pb][lane] = B.tb; s_eov[pb][lane] = B.ov;
-                if (prof && lane == 0) buf.prof[4] += __builtin_readcyclecounter() - tq0;
+                if (prof && lane == 0) buf.prof[4] += __builtin_readcyclecounter() - tq1;
             }
         }
         __syncthreads();
