@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <functional>
 #include <map>
 #include <new>
 #include <thread>
@@ -253,6 +254,26 @@ k_gather_winners(const WinDesc* __restrict__ wd, int n_win, int64_t out_begin, i
     o.uscore[g] = ca.uscore[f]; o.tscore[g] = ca.tscore[f]; o.mot_score[g] = ca.mot_score[f]; o.mot_ndx[g] = ca.mot_ndx[f];
     o.rbs[2 * g] = ca.rbs[2 * f]; o.rbs[2 * g + 1] = ca.rbs[2 * f + 1];
     o.mot_len[g] = ca.mot_len[f]; o.mot_spacer[g] = ca.mot_spacer[f]; o.mot_spacendx[g] = ca.mot_spacendx[f];
+}
+
+// Final-pass fields of the two nodes of every gene (start, stop), fetched after the host tail so that
+// the full per-node arrays of the re-score need not cross PCIe unless the caller asks for nodes.
+struct GeneNodeAttr {
+    double cscore, sscore, rscore, uscore, tscore, mot_score;
+    float gc_cont; int32_t mot_ndx;
+    uint8_t edge, rbs0, rbs1, mot_len, mot_spacer, _pad[3];
+};
+__global__ void __launch_bounds__(256)
+k_gather_gene_nodes(const int64_t* __restrict__ idx, int n, OutArrays o, GeneNodeAttr* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int64_t g = idx[t];
+    GeneNodeAttr a;
+    a.cscore = o.cscore[g]; a.sscore = o.sscore[g]; a.rscore = o.rscore[g]; a.uscore = o.uscore[g]; a.tscore = o.tscore[g];
+    a.mot_score = o.mot_score[g]; a.gc_cont = o.gc_cont[g]; a.mot_ndx = o.mot_ndx[g];
+    a.edge = o.edge[g]; a.rbs0 = o.rbs[2 * g]; a.rbs1 = o.rbs[2 * g + 1]; a.mot_len = o.mot_len[g]; a.mot_spacer = o.mot_spacer[g];
+    a._pad[0] = a._pad[1] = a._pad[2] = 0;
+    out[t] = a;
 }
 
 __global__ void k_contig_node_base(const ContigDesc* __restrict__ ct, int n_contigs, int64_t total, const int32_t* __restrict__ pre_nodes,
@@ -661,11 +682,14 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
         if (out_nodes > 0) {
             const size_t n = (size_t)out_nodes;
 #define DL(field, type, mult) HT(c, hipMemcpyAsync(h.field, o.field, sizeof(type) * (size_t)(mult) * n, hipMemcpyDeviceToHost, st));
-            DL(ndx, int32_t, 1) DL(stop_val, int32_t, 1) DL(type, uint8_t, 1) DL(strand, int8_t, 1) DL(gc_cont, float, 1)
+            DL(ndx, int32_t, 1) DL(stop_val, int32_t, 1) DL(type, uint8_t, 1) DL(strand, int8_t, 1)
             DL(edge_dp, uint8_t, 1) DL(cscore_dp, double, 1) DL(sscore_dp, double, 1) DL(rscore_dp, double, 1) DL(uscore_dp, double, 1) DL(tscore_dp, double, 1)
             DL(star_ptr, int32_t, 3) DL(traceb, int32_t, 1) DL(ov_mark, int8_t, 1) DL(score, double, 1)
-            DL(edge, uint8_t, 1) DL(cscore, double, 1) DL(sscore, double, 1) DL(rscore, double, 1) DL(uscore, double, 1) DL(tscore, double, 1) DL(mot_score, double, 1)
-            DL(mot_ndx, int32_t, 1) DL(rbs, uint8_t, 2) DL(mot_len, uint8_t, 1) DL(mot_spacer, uint8_t, 1) DL(mot_spacendx, uint8_t, 1)
+            if (P.want_nodes) {
+                DL(gc_cont, float, 1)
+                DL(edge, uint8_t, 1) DL(cscore, double, 1) DL(sscore, double, 1) DL(rscore, double, 1) DL(uscore, double, 1) DL(tscore, double, 1) DL(mot_score, double, 1)
+                DL(mot_ndx, int32_t, 1) DL(rbs, uint8_t, 2) DL(mot_len, uint8_t, 1) DL(mot_spacer, uint8_t, 1) DL(mot_spacendx, uint8_t, 1)
+            }
         }
         HT(c, hipEventRecord(f->e_stop, st));
         HT(c, hipGetLastError());
@@ -697,46 +721,77 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
                 tweak_final_starts(v, cg[i], st_wt, P.max_overlap);
             }
         };
-        {
+        auto run_parallel = [&](const std::function<void()>& fn) {
             int nt = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
             if (NC < 4) nt = 1;
             std::vector<std::thread> th;
-            for (int t = 1; t < nt; t++) th.emplace_back(worker);
-            worker();
+            for (int t = 1; t < nt; t++) th.emplace_back(fn);
+            fn();
             for (auto& t : th) t.join();
-        }
+        };
+        run_parallel(worker);
         tm.mark("host_tail");
         // ---- results -----------------------------------------------------------------------------------
         int64_t ngenes = 0;
-        for (int i = 0; i < NC; i++) ngenes += (int64_t)cg[i].size();
-        R->genes.resize((size_t)ngenes);
-        int64_t gi = 0;
         for (int i = 0; i < NC; i++) {
             pga_contig_result& cr = R->contigs[i];
             const int k = win_chain[i];
-            cr.gene_begin = gi; cr.n_genes = (int32_t)cg[i].size();
+            cr.gene_begin = ngenes; cr.n_genes = (int32_t)cg[i].size();
+            ngenes += cr.n_genes;
             if (k < 0) { cr.model = -1; continue; }
             cr.model = chains[k].model; cr.n_nodes = chains[k].n;
             cr.score = P.meta ? 0.0 : (h_ipath[k] >= 0 ? h_maxscore[k] : 0.0);
-            const int64_t oo = out_off[i];
-            const bool single = !P.meta;
-            for (const GeneRec& gr : cg[i]) {
-                pga_gene& G = R->genes[(size_t)gi++];
-                memset(&G, 0, sizeof G);
-                const int64_t s = oo + gr.start_ndx, e = oo + gr.stop_ndx;
-                G.contig = i; G.begin = gr.begin; G.end = gr.end; G.start_ndx = gr.start_ndx; G.stop_ndx = gr.stop_ndx;
-                G.strand = h.strand[s];
-                const uint8_t se = single ? h.edge_dp[s] : h.edge[s], ee = single ? h.edge_dp[e] : h.edge[e];
-                G.partial_begin = G.strand == 1 ? se : ee; G.partial_end = G.strand == 1 ? ee : se;
-                G.start_type = se ? 3 : h.type[s];
-                G.rbs[0] = h.rbs[2 * s]; G.rbs[1] = h.rbs[2 * s + 1];
-                G.mot_len = h.mot_len[s]; G.mot_spacer = h.mot_spacer[s]; G.mot_ndx = h.mot_ndx[s]; G.mot_score = h.mot_score[s];
-                G.gc_cont = h.gc_cont[s];
-                G.cscore = single ? h.cscore_dp[s] : h.cscore[s]; G.sscore = single ? h.sscore_dp[s] : h.sscore[s];
-                G.rscore = single ? h.rscore_dp[s] : h.rscore[s]; G.uscore = single ? h.uscore_dp[s] : h.uscore[s];
-                G.tscore = single ? h.tscore_dp[s] : h.tscore[s];
-            }
         }
+        R->genes.resize((size_t)ngenes);
+        // fields of the gene's start / stop nodes as of the final pass: a second, small gather
+        PINBUF(h_gidx, int64_t, "h_gidx", 2 * ngenes + 1);
+        PINBUF(h_attr, GeneNodeAttr, "h_attr", 2 * ngenes + 1);
+        if (ngenes > 0) {
+            DEVBUF(d_gidx, int64_t, "d_gidx", 2 * ngenes + 1);
+            DEVBUF(d_attr, GeneNodeAttr, "d_attr", 2 * ngenes + 1);
+            for (int i = 0; i < NC; i++) {
+                int64_t gi = R->contigs[i].gene_begin;
+                for (const GeneRec& gr : cg[i]) { h_gidx[2 * gi] = out_off[i] + gr.start_ndx; h_gidx[2 * gi + 1] = out_off[i] + gr.stop_ndx; gi++; }
+            }
+            HT(c, hipMemcpyAsync(d_gidx, h_gidx, sizeof(int64_t) * 2 * ngenes, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_gather_gene_nodes, dim3((unsigned)((2 * ngenes + 255) / 256)), dim3(256), 0, st, d_gidx, (int)(2 * ngenes), o, d_attr);
+            HT(c, hipMemcpyAsync(h_attr, d_attr, sizeof(GeneNodeAttr) * 2 * ngenes, hipMemcpyDeviceToHost, st));
+            HT(c, hipGetLastError());
+            HT(c, hipStreamSynchronize(st));
+        }
+        tm.mark("gene_attrs");
+        std::atomic<int> next2(0);
+        auto filler = [&]() {
+            for (;;) {
+                const int i = next2.fetch_add(1);
+                if (i >= NC) break;
+                const int k = win_chain[i];
+                if (k < 0) continue;
+                const int64_t oo = out_off[i];
+                const bool single = !P.meta;
+                int64_t gi = R->contigs[i].gene_begin;
+                for (const GeneRec& gr : cg[i]) {
+                    pga_gene& G = R->genes[(size_t)gi];
+                    const GeneNodeAttr& as = h_attr[2 * gi]; const GeneNodeAttr& ae = h_attr[2 * gi + 1];
+                    gi++;
+                    memset(&G, 0, sizeof G);
+                    const int64_t sn = oo + gr.start_ndx, en = oo + gr.stop_ndx;
+                    G.contig = i; G.begin = gr.begin; G.end = gr.end; G.start_ndx = gr.start_ndx; G.stop_ndx = gr.stop_ndx;
+                    G.strand = h.strand[sn];
+                    // single mode keeps the nodes of the DP pass (ref: lib.pyx:5296-5311); meta mode re-scores (5380-5394)
+                    const uint8_t se = single ? h.edge_dp[sn] : as.edge, ee = single ? h.edge_dp[en] : ae.edge;
+                    G.partial_begin = G.strand == 1 ? se : ee; G.partial_end = G.strand == 1 ? ee : se;
+                    G.start_type = se ? 3 : h.type[sn];
+                    G.rbs[0] = as.rbs0; G.rbs[1] = as.rbs1;
+                    G.mot_len = as.mot_len; G.mot_spacer = as.mot_spacer; G.mot_ndx = as.mot_ndx; G.mot_score = as.mot_score;
+                    G.gc_cont = as.gc_cont;
+                    G.cscore = single ? h.cscore_dp[sn] : as.cscore; G.sscore = single ? h.sscore_dp[sn] : as.sscore;
+                    G.rscore = single ? h.rscore_dp[sn] : as.rscore; G.uscore = single ? h.uscore_dp[sn] : as.uscore;
+                    G.tscore = single ? h.tscore_dp[sn] : as.tscore;
+                }
+            }
+        };
+        run_parallel(filler);
         if (P.want_nodes) {
             R->nodes.resize(NC);
             for (int i = 0; i < NC; i++) {
