@@ -99,9 +99,11 @@ def main():
                        "genes_all_ranks": int(len(all_genes)), "parallelism": "contig-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                         "kernel": "k_dp_chain", "kernel_ms_per_step": round(dp_ms / args.steps, 3),
+                         "kernel": "k_dp_tree_mw" if res.n_chains < 2048 else "k_dp_tree",
+                         "kernel_ms_per_step": round(dp_ms / args.steps, 3), "chains": res.n_chains,
                          "bytes_per_node_pass": BYTES_PER_NODE_PASS},
         }
+        out["roofline"]["traffic"] = pmc_traffic(wname)
         # PCIe-inclusive rate (upload + find), reported next to `value`, never as `value`
         t1 = time.perf_counter()
         ctx.find_genes_batch(seqs, meta=True)
@@ -115,6 +117,16 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def pmc_traffic(workload):
+    """HBM bytes per launch of the DP kernel from the separate rocprofv3 --pmc passes of this round
+    (profiles/r01_pmc_traffic.json: FETCH_SIZE x 2 (gfx950 correction for wide loads) + WRITE_SIZE, in bytes)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+    except OSError:
+        return None
 
 
 def cpu_baseline(seqs, models, gpu_res):

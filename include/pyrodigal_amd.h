@@ -106,6 +106,8 @@ typedef struct pga_result {
     pga_nodes*         nodes;     /* NULL unless want_nodes */
     double             t_total_ms, t_dp_ms;   /* device time of the whole batch / of the DP kernel */
     int64_t            node_passes;           /* sum over (contig, model) DP passes of node count */
+    int32_t            n_chains;              /* number of (contig, model) DP passes */
+    int32_t            _pad;
 } pga_result;
 
 /* ---- context ---------------------------------------------------------- */

@@ -61,7 +61,8 @@ class ContigResult(ctypes.Structure):
 class Result(ctypes.Structure):
     _fields_ = [("n_contigs", ctypes.c_int32), ("n_genes", ctypes.c_int64), ("contigs", _P(ContigResult)),
                 ("genes", _P(Gene)), ("nodes", _P(Nodes)), ("t_total_ms", ctypes.c_double),
-                ("t_dp_ms", ctypes.c_double), ("node_passes", ctypes.c_int64)]
+                ("t_dp_ms", ctypes.c_double), ("node_passes", ctypes.c_int64), ("n_chains", ctypes.c_int32),
+                ("_pad", ctypes.c_int32)]
 
 
 GENE_DTYPE = np.dtype(Gene)
@@ -189,9 +190,9 @@ _NODE_FIELDS = [
 class BatchResult:
     """Host copy of a ``pga_result``: ``contigs`` / ``genes`` structured arrays (+ per-contig node dicts)."""
 
-    def __init__(self, contigs, genes, nodes, t_total_ms, t_dp_ms, node_passes):
+    def __init__(self, contigs, genes, nodes, t_total_ms, t_dp_ms, node_passes, n_chains=0):
         self.contigs, self.genes, self.nodes = contigs, genes, nodes
-        self.t_total_ms, self.t_dp_ms, self.node_passes = t_total_ms, t_dp_ms, node_passes
+        self.t_total_ms, self.t_dp_ms, self.node_passes, self.n_chains = t_total_ms, t_dp_ms, node_passes, n_chains
 
     def genes_of(self, i):
         c = self.contigs[i]
@@ -252,7 +253,7 @@ def _unpack_result(L, res, want_nodes):
                             a = a.reshape(nd.n, mult)
                     d[name] = a
                 nodes.append(d)
-        return BatchResult(contigs, genes, nodes, r.t_total_ms, r.t_dp_ms, r.node_passes)
+        return BatchResult(contigs, genes, nodes, r.t_total_ms, r.t_dp_ms, r.node_passes, r.n_chains)
     finally:
         L.pga_result_free(res)
 

@@ -532,6 +532,7 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
         g_c0[NG] = (int)chains.size(); g_n0[NG] = tot_chain_nodes;
         const int NCH = (int)chains.size();
         R->pub.node_passes = tot_chain_nodes;
+        R->pub.n_chains = NCH;
         // space for the fresh re-scores of winners that were not `first` (at most one per contig)
         int64_t max_rescore = 0;
         if (P.meta) for (int g = 0; g < NG; g++) max_rescore += h_cbase[(size_t)g * (NC + 1) + NC];   // loose bound: every node once per group

@@ -92,6 +92,7 @@ cdef extern from "pyrodigal_amd.h" nogil:
         double t_total_ms
         double t_dp_ms
         int64_t node_passes
+        int32_t n_chains
     int PGA_OK, PGA_EINVAL, PGA_ENOMEM, PGA_EDEVICE, PGA_ENODEVICE
     int pga_create(int device, pga_ctx** out)
     void pga_destroy(pga_ctx*)
