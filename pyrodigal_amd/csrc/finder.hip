@@ -570,6 +570,17 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
         PINBUF(h_ipath, int32_t, "h_ipath", NCH + 1);
         PINBUF(h_maxscore, double, "h_maxscore", NCH + 1);
         HT(c, hipMemcpyAsync(d_chains, chains.data(), sizeof(ChainDesc) * NCH, hipMemcpyHostToDevice, st));
+        // per group and contig: the contiguous run of chains (models) scored on that contig
+        DEVBUF(d_cc, int2, "d_cc", (size_t)2 * NG * NC + 1);
+        PINBUF(h_cc, int2, "h_cc", (size_t)2 * NG * NC + 1);
+        for (size_t k = 0; k < (size_t)2 * NG * NC; k++) h_cc[k] = make_int2(0, 0);
+        for (int k = 0; k < NCH; k++) {
+            const int g = P.meta ? f->model_group[chains[k].model] : 0;
+            int2& e = h_cc[(size_t)g * NC + chains[k].contig];
+            if (e.y == 0) e.x = k;
+            e.y++;
+        }
+        HT(c, hipMemcpyAsync(d_cc, h_cc, sizeof(int2) * (size_t)NG * NC, hipMemcpyHostToDevice, st));
 
         tm.mark("plan+alloc");
         const ScoreParams sp{P.closed, P.meta, P.max_overlap, 0};
@@ -580,7 +591,8 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
             const int nch = g_c0[g + 1] - g_c0[g];
             const int64_t nn = g_n0[g + 1] - g_n0[g];
             if (nch == 0 || nn == 0) continue;
-            pga_launch_score(d_chains + g_c0[g], nch, g_n0[g], nn, d_dig, d_ct, ga[g], d_models, f->d_msc, c->d_model_const, ca, sp, st);
+            pga_launch_score(d_chains + g_c0[g], nch, g_n0[g], nn, d_dig, d_ct, ga[g], d_models, f->d_msc, c->d_model_const, ca, sp,
+                             d_chains, d_cc + (size_t)g * NC, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], st);
             NodeArrays na{ga[g].ndx, ga[g].stop_val, ga[g].type, ga[g].strand, ca.cscore, ca.sscore, ca.rscore, ca.uscore, ca.star_ptr};
             pga_launch_dp_prepare(d_chains + g_c0[g], nch, g_n0[g], nn, na, c->d_model_const, dp, st);
         }
@@ -632,10 +644,15 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
         r_c0[NG] = (int)rescore.size(); r_n0[NG] = tot_chain_nodes + rs_nodes;
         if (!rescore.empty()) {
             HT(c, hipMemcpyAsync(d_chains + NCH, rescore.data(), sizeof(ChainDesc) * rescore.size(), hipMemcpyHostToDevice, st));
+            int2* h_cc2 = h_cc + (size_t)NG * NC;
+            for (size_t k = 0; k < rescore.size(); k++)
+                h_cc2[(size_t)f->model_group[rescore[k].model] * NC + rescore[k].contig] = make_int2(NCH + (int)k, 1);
+            HT(c, hipMemcpyAsync(d_cc + (size_t)NG * NC, h_cc2, sizeof(int2) * (size_t)NG * NC, hipMemcpyHostToDevice, st));
             for (int g = 0; g < NG; g++) {
                 const int nch = r_c0[g + 1] - r_c0[g]; const int64_t nn = r_n0[g + 1] - r_n0[g];
                 if (nch == 0 || nn == 0) continue;
-                pga_launch_score(d_chains + NCH + r_c0[g], nch, r_n0[g], nn, d_dig, d_ct, ga[g], d_models, f->d_msc, c->d_model_const, ca, sp, st);
+                pga_launch_score(d_chains + NCH + r_c0[g], nch, r_n0[g], nn, d_dig, d_ct, ga[g], d_models, f->d_msc, c->d_model_const, ca, sp,
+                                 d_chains, d_cc + (size_t)NG * NC + (size_t)g * NC, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], st);
             }
         }
         tm.mark("winners+rescore_launch");

@@ -60,5 +60,6 @@ void pga_launch_orf_gc(const ContigDesc* d_ct, int n_contigs, const int32_t* d_p
 void pga_launch_score(const ChainDesc* d_chains, int n_chains, int64_t node_begin, int64_t total, const uint8_t* d_dig,
                       const ContigDesc* d_ct, const GroupArrays& ga, const pga_training* d_models,
                       const ModelScoreConst* d_msc, const ModelConst* d_mc, const ChainArrays& ca, ScoreParams sp,
-                      hipStream_t st);
+                      const ChainDesc* d_all_chains /* indexed by contig_chains[].x */, const int2* d_contig_chains /* per contig: first chain, count */,
+                      const int32_t* d_node_contig_base, int n_contigs, int group_nodes, hipStream_t st);
 int64_t pga_scan_tiles(int64_t total);

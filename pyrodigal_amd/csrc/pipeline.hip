@@ -470,52 +470,106 @@ __device__ __forceinline__ int hexamer(const uint8_t* __restrict__ d, int pos, i
     return v;
 }
 
+// One thread per stop node of the TOPOLOGY (not per chain): the ORF walk -- hexamer index, start flags --
+// is identical for every model scored on this contig, so one walk accumulates the ordered sums of up to
+// CS_MODELS models at once (independent f64 chains interleave).  The block first compacts its stop nodes
+// into the leading lanes so that walking wavefronts are full.
+constexpr int CS_MODELS = 8;
+
 __global__ void __launch_bounds__(256)
-k_coding_score(const ChainDesc* __restrict__ chains, int n_chains, int64_t node_begin, int64_t total,
+k_coding_score(const ChainDesc* __restrict__ chains, const int2* __restrict__ contig_chains /* per contig: first chain, count */,
+               const int32_t* __restrict__ node_contig_base, int n_contigs, int node_begin, int n_nodes,
                const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct, GroupArrays ga,
                const pga_training* __restrict__ models, const ModelScoreConst* __restrict__ msc, ChainArrays ca) {
-    __shared__ int s_c0;
-    const int64_t blk0 = node_begin + (int64_t)blockIdx.x * blockDim.x;
-    const int64_t g = blk0 + threadIdx.x;
-    const bool in_range = g < node_begin + total;
-    const int c = block_chain(chains, n_chains, blk0, in_range ? g : blk0, &s_c0);
-    if (!in_range) return;
-    const ChainDesc ch = chains[c];
-    const int64_t t = ch.topo_off + (g - ch.off);
-    if (ga.type[t] != PGA_T_STOP) return;
-    const ContigDesc cd = ct[ch.contig];
+    __shared__ int s_list[256];
+    __shared__ int s_wtot[4];
+    const int blk0 = node_begin + blockIdx.x * blockDim.x;
+    const int me = blk0 + threadIdx.x;
+    const bool is_stop = me < node_begin + n_nodes && ga.type[me] == PGA_T_STOP;
+    const unsigned long long bm = __ballot(is_stop);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) s_wtot[wv] = __popcll(bm);
+    __syncthreads();
+    int off = 0;
+    for (int k = 0; k < wv; k++) off += s_wtot[k];
+    if (is_stop) s_list[off + __popcll(bm & ((1ull << lane) - 1ull))] = me;
+    __syncthreads();
+    const int cnt = s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
+    if ((int)threadIdx.x >= cnt) return;
+    const int t = s_list[threadIdx.x];                 // topology index of my stop node
+    // its contig
+    int c;
+    {
+        int lo = 0, hi = n_contigs - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (node_contig_base[mid] <= t) lo = mid; else hi = mid - 1; }
+        c = lo;
+    }
+    const int2 cc = contig_chains[c];
+    if (cc.y <= 0) return;
+    const ContigDesc cd = ct[c];
     const uint8_t* __restrict__ d = dig + cd.base;
     const int strand = ga.strand[t];
     const uint8_t* __restrict__ nf = (strand == 1 ? ga.nf_fwd : ga.nf_rev) + cd.base;
     const uint8_t* __restrict__ nf_f = ga.nf_fwd + cd.base;
     const int32_t* __restrict__ pre = ga.pre_nodes + cd.base;
-    const double* __restrict__ gene_dc = models[ch.model].gene_dc;
-    const ModelScoreConst* __restrict__ mc = &msc[ch.model];
-    double* __restrict__ cscore = ca.cscore + ch.off;
-    const int64_t tbase = ch.topo_off;
+    const int tbase = node_contig_base[c];
     const int p = ga.ndx[t], q = ga.stop_val[t], L = cd.len;
     const int step = strand == 1 ? -3 : 3;
-    double sum = 0.0; int far = p;
-    for (int j = p + step; strand == 1 ? (j >= 0 && j > q) : (j <= L - 1 && j < q); j += step) {
-        sum += gene_dc[hexamer(d, j, strand)];
-        if (nf[j]) { cscore[(int)(pre[j] + (strand == 1 ? 0 : nf_f[j]) - tbase)] = sum; far = j; }
-    }
-    if (far == p) return;
-    double run_c = -10000.0, run_l = -10000.0;
-    for (int j = far; j != p; j -= step) {
-        if (!nf[j]) continue;
-        const int k = (int)(pre[j] + (strand == 1 ? 0 : nf_f[j]) - tbase);
-        double cs = cscore[k];
-        if (cs > run_c) run_c = cs; else cs -= (run_c - cs);
-        const int ncod = (abs(p - j) + 3) / 3;
-        const double gsize = (double)ncod;
-        double lfac;
-        if (gsize > 1000.0) lfac = (mc->lfac_max - mc->lfac_min) * (gsize - 80) / 920.0;
-        else lfac = mc->lfac_tab[ncod];
-        if (lfac > run_l) run_l = lfac; else lfac -= fmax(fmin(run_l - lfac, lfac), 0.0);
-        if (lfac > 3.0 && cs < 0.5 * lfac) cs = 0.5 * lfac;
-        cs += lfac;
-        cscore[k] = cs;
+    for (int m0 = 0; m0 < cc.y; m0 += CS_MODELS) {
+        const int nm = min(CS_MODELS, cc.y - m0);
+        const double* gdc[CS_MODELS]; double* csp[CS_MODELS]; const ModelScoreConst* mcp[CS_MODELS];
+#pragma unroll
+        for (int m = 0; m < CS_MODELS; m++) {
+            const ChainDesc ch = chains[cc.x + m0 + (m < nm ? m : 0)];
+            gdc[m] = models[ch.model].gene_dc; csp[m] = ca.cscore + ch.off; mcp[m] = &msc[ch.model];
+        }
+        // pass 1: ordered hexamer log-odds sums from the stop outwards
+        double sum[CS_MODELS];
+#pragma unroll
+        for (int m = 0; m < CS_MODELS; m++) sum[m] = 0.0;
+        int far = p, mer = 0;
+        bool first = true;
+        for (int j = p + step; strand == 1 ? (j >= 0 && j > q) : (j <= L - 1 && j < q); j += step) {
+            if (first) { mer = hexamer(d, j, strand); first = false; }
+            else {      // rolling update: the three bases nearest to the walk direction are new (ref: _sequence.h:207-220)
+                int lo3;
+                if (strand == 1) lo3 = (d[j] & 3) | ((d[j + 1] & 3) << 2) | ((d[j + 2] & 3) << 4);
+                else lo3 = (comp2(d[j]) & 3) | ((comp2(d[j - 1]) & 3) << 2) | ((comp2(d[j - 2]) & 3) << 4);
+                mer = ((mer << 6) & 0xfc0) | lo3;
+            }
+#pragma unroll
+            for (int m = 0; m < CS_MODELS; m++) sum[m] += gdc[m][mer];
+            if (nf[j]) {
+                const int k = pre[j] + (strand == 1 ? 0 : nf_f[j]) - tbase;
+#pragma unroll
+                for (int m = 0; m < CS_MODELS; m++) if (m < nm) csp[m][k] = sum[m];
+                far = j;
+            }
+        }
+        if (far == p) continue;
+        // passes 2 + 3, outermost start first (ascending index on the forward strand, descending on the reverse)
+        double run_c[CS_MODELS], run_l[CS_MODELS];
+#pragma unroll
+        for (int m = 0; m < CS_MODELS; m++) { run_c[m] = -10000.0; run_l[m] = -10000.0; }
+        for (int j = far; j != p; j -= step) {
+            if (!nf[j]) continue;
+            const int k = pre[j] + (strand == 1 ? 0 : nf_f[j]) - tbase;
+            const int ncod = (abs(p - j) + 3) / 3;
+            const double gsize = (double)ncod;
+#pragma unroll
+            for (int m = 0; m < CS_MODELS; m++) {
+                if (m >= nm) continue;
+                double cs = csp[m][k];
+                if (cs > run_c[m]) run_c[m] = cs; else cs -= (run_c[m] - cs);
+                double lfac;
+                if (gsize > 1000.0) lfac = (mcp[m]->lfac_max - mcp[m]->lfac_min) * (gsize - 80) / 920.0;
+                else lfac = mcp[m]->lfac_tab[ncod];
+                if (lfac > run_l[m]) run_l[m] = lfac; else lfac -= fmax(fmin(run_l[m] - lfac, lfac), 0.0);
+                if (lfac > 3.0 && cs < 0.5 * lfac) cs = 0.5 * lfac;
+                cs += lfac;
+                csp[m][k] = cs;
+            }
+        }
     }
 }
 
@@ -815,10 +869,13 @@ void pga_launch_orf_gc(const ContigDesc* d_ct, int n_contigs, const int32_t* d_p
 void pga_launch_score(const ChainDesc* d_chains, int n_chains, int64_t node_begin, int64_t total, const uint8_t* d_dig,
                       const ContigDesc* d_ct, const GroupArrays& ga, const pga_training* d_models,
                       const ModelScoreConst* d_msc, const ModelConst* d_mc, const ChainArrays& ca, ScoreParams sp,
-                      hipStream_t st) {
+                      const ChainDesc* d_all_chains, const int2* d_contig_chains, const int32_t* d_node_contig_base, int n_contigs,
+                      int group_nodes, hipStream_t st) {
     if (total <= 0 || n_chains <= 0) return;
     const dim3 grid(nblocks(total, 256)), blk(256);
-    hipLaunchKernelGGL(k_coding_score, grid, blk, 0, st, d_chains, n_chains, node_begin, total, d_dig, d_ct, ga, d_models, d_msc, ca);
+    if (group_nodes > 0)
+        hipLaunchKernelGGL(k_coding_score, dim3(nblocks(group_nodes, 256)), blk, 0, st, d_all_chains, d_contig_chains, d_node_contig_base,
+                           n_contigs, 0, group_nodes, d_dig, d_ct, ga, d_models, d_msc, ca);
     hipLaunchKernelGGL(k_score_starts, grid, blk, 0, st, d_chains, n_chains, node_begin, total, d_dig, d_ct, ga, d_models, ca, sp);
     hipLaunchKernelGGL(k_overlapping_starts, grid, blk, 0, st, d_chains, n_chains, node_begin, total, ga, d_mc, ca, sp.max_overlap);
 }
