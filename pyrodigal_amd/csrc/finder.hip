@@ -161,32 +161,34 @@ void extract_genes(const NodeView& v, int ipath, std::vector<GeneRec>& out) {
 }
 
 // ref: lib.pyx:3272-3401 (Genes._tweak_final_starts)
-void tweak_final_starts(const NodeView& v, std::vector<GeneRec>& g, double w, int maxov) {
-    const int nn = v.n, ng = (int)g.size();
-    for (int i = 0; i < ng; i++) {
-        const int ndx = g[i].start_ndx;
+// one gene; `prev` / `next` are its neighbours as the reference's in-order loop would see them
+// (prev already tweaked, next not yet)
+static void tweak_one(const NodeView& v, const GeneRec* prev, GeneRec& cur, const GeneRec* next, double w, int maxov) {
+    const int nn = v.n;
+    {
+        const int ndx = cur.start_ndx;
         const double sc = v.sscore[ndx] + v.cscore[ndx];
         double ig = 0.0;
-        const bool prev_fwd = i > 0 && v.strand[g[i - 1].start_ndx] == 1, prev_rev = i > 0 && v.strand[g[i - 1].start_ndx] == -1;
-        const bool next_fwd = i < ng - 1 && v.strand[g[i + 1].start_ndx] == 1, next_rev = i < ng - 1 && v.strand[g[i + 1].start_ndx] == -1;
-        if (v.strand[ndx] == 1 && prev_fwd) ig = igm_same_h(v, g[i - 1].stop_ndx, ndx, w);
+        const bool prev_fwd = prev && v.strand[prev->start_ndx] == 1, prev_rev = prev && v.strand[prev->start_ndx] == -1;
+        const bool next_fwd = next && v.strand[next->start_ndx] == 1, next_rev = next && v.strand[next->start_ndx] == -1;
+        if (v.strand[ndx] == 1 && prev_fwd) ig = igm_same_h(v, prev->stop_ndx, ndx, w);
         if (v.strand[ndx] == 1 && prev_rev) ig = -0.15 * w;
         if (v.strand[ndx] == -1 && next_fwd) ig = -0.15 * w;
-        if (v.strand[ndx] == -1 && next_rev) ig = igm_same_h(v, ndx, g[i + 1].stop_ndx, w);
+        if (v.strand[ndx] == -1 && next_rev) ig = igm_same_h(v, ndx, next->stop_ndx, w);
         int mi[2] = {-1, -1}; double ms[2] = {0, 0}, mg[2] = {0, 0};
         for (int j = ndx - 100; j < ndx + 100; j++) {
             if (j < 0 || j >= nn || j == ndx) continue;
             if (is_stop_n(v, j) || v.stop_val[j] != v.stop_val[ndx]) continue;
             double tg = 0.0;
             if (v.strand[j] == 1 && prev_fwd) {
-                if (v.ndx[g[i - 1].stop_ndx] - v.ndx[j] > maxov) continue;
-                tg = igm_same_h(v, g[i - 1].stop_ndx, j, w);
+                if (v.ndx[prev->stop_ndx] - v.ndx[j] > maxov) continue;
+                tg = igm_same_h(v, prev->stop_ndx, j, w);
             }
-            if (v.strand[j] == 1 && prev_rev) { if (v.ndx[g[i - 1].start_ndx] - v.ndx[j] >= 0) continue; tg = -0.15 * w; }
-            if (v.strand[j] == -1 && next_fwd) { if (v.ndx[j] - v.ndx[g[i + 1].start_ndx] >= 0) continue; tg = -0.15 * w; }
+            if (v.strand[j] == 1 && prev_rev) { if (v.ndx[prev->start_ndx] - v.ndx[j] >= 0) continue; tg = -0.15 * w; }
+            if (v.strand[j] == -1 && next_fwd) { if (v.ndx[j] - v.ndx[next->start_ndx] >= 0) continue; tg = -0.15 * w; }
             if (v.strand[j] == -1 && next_rev) {
-                if (v.ndx[j] - v.ndx[g[i + 1].stop_ndx] > maxov) continue;
-                tg = igm_same_h(v, j, g[i + 1].stop_ndx, w);
+                if (v.ndx[j] - v.ndx[next->stop_ndx] > maxov) continue;
+                tg = igm_same_h(v, j, next->stop_ndx, w);
             }
             const double cs = v.cscore[j] + v.sscore[j];
             if (mi[0] == -1) { mi[0] = j; ms[0] = cs; mg[0] = tg; }
@@ -212,8 +214,38 @@ void tweak_final_starts(const NodeView& v, std::vector<GeneRec>& g, double w, in
             if (pick == -1 && ms[k] + mg[k] > sc + ig) pick = k;
             else if (pick >= 0 && ms[k] + mg[k] > ms[pick] + mg[pick]) pick = k;
         }
-        if (pick != -1 && v.strand[mi[pick]] == 1) { g[i].start_ndx = mi[pick]; g[i].begin = v.ndx[mi[pick]] + 1; }
-        else if (pick != -1 && v.strand[mi[pick]] == -1) { g[i].start_ndx = mi[pick]; g[i].end = v.ndx[mi[pick]] + 1; }
+        if (pick != -1 && v.strand[mi[pick]] == 1) { cur.start_ndx = mi[pick]; cur.begin = v.ndx[mi[pick]] + 1; }
+        else if (pick != -1 && v.strand[mi[pick]] == -1) { cur.start_ndx = mi[pick]; cur.end = v.ndx[mi[pick]] + 1; }
+    }
+}
+
+// In-order semantics of the reference loop, evaluated in parallel when a contig has many genes: every
+// gene is first tweaked against its ORIGINAL neighbours; a gene whose predecessor did change is then
+// redone in order against the predecessor's final record (tweaks are rare, so few are redone).
+void tweak_final_starts(const NodeView& v, std::vector<GeneRec>& g, double w, int maxov, int inner_threads = 1) {
+    const int ng = (int)g.size();
+    if (inner_threads <= 1 || ng < 2048) {
+        for (int i = 0; i < ng; i++) tweak_one(v, i > 0 ? &g[i - 1] : nullptr, g[i], i < ng - 1 ? &g[i + 1] : nullptr, w, maxov);
+        return;
+    }
+    const std::vector<GeneRec> orig(g);
+    std::atomic<int> next(0);
+    auto work = [&]() {
+        for (;;) {
+            const int i0 = next.fetch_add(256);
+            if (i0 >= ng) break;
+            for (int i = i0; i < std::min(ng, i0 + 256); i++)
+                tweak_one(v, i > 0 ? &orig[i - 1] : nullptr, g[i], i < ng - 1 ? &orig[i + 1] : nullptr, w, maxov);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < inner_threads; t++) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    for (int i = 1; i < ng; i++) {
+        if (g[i - 1].start_ndx == orig[i - 1].start_ndx) continue;       // predecessor unchanged: the parallel result stands
+        g[i] = orig[i];
+        tweak_one(v, &g[i - 1], g[i], i < ng - 1 ? &orig[i + 1] : nullptr, w, maxov);
     }
 }
 
@@ -736,7 +768,7 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
                 const double st_wt = c->models[chains[k].model].st_wt;
                 if (v.n > 0) eliminate_bad_genes(v, ipath, st_wt);
                 extract_genes(v, ipath, cg[i]);
-                tweak_final_starts(v, cg[i], st_wt, P.max_overlap);
+                tweak_final_starts(v, cg[i], st_wt, P.max_overlap, NC < 4 ? 16 : 1);
             }
         };
         auto run_parallel = [&](const std::function<void()>& fn) {
