@@ -40,16 +40,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus must equal WORLD_SIZE")
-    torch.cuda.set_device(local_rank)
+    ndev = max(1, torch.cuda.device_count())
+    dev_index = local_rank % ndev                      # one process per GPU (ranks wrap only in single-GPU smoke tests)
+    torch.cuda.set_device(dev_index)
+    backend = os.environ.get("PGA_BENCH_BACKEND", "nccl")    # "nccl" is RCCL on ROCm; "gloo" for a single-GPU dry run
+    xdev = torch.device("cuda", dev_index) if backend == "nccl" else torch.device("cpu")
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=xdev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from pyrodigal_amd import _cabi, benchdata, distributed
     models = benchdata.load_model_set()
-    ctx = _cabi.Context(local_rank)
+    ctx = _cabi.Context(dev_index)
     ctx.set_models([m[1] for m in models])
     if args.workload == "config2":
         seqs = benchdata.config2(rank)
@@ -69,19 +76,19 @@ def main():
     res = None
     for _ in range(args.warmup):
         res = ctx.find_genes(batch, meta=True)
-        distributed.gather_genes(res.genes, dist, device=torch.device("cuda", local_rank))
+        distributed.gather_genes(res.genes, dist, device=xdev)
     sync()
     t0 = time.perf_counter()
     dp_ms, passes = 0.0, 0
     for _ in range(args.steps):
         res = ctx.find_genes(batch, meta=True)
-        all_genes = distributed.gather_genes(res.genes, dist, device=torch.device("cuda", local_rank))
+        all_genes = distributed.gather_genes(res.genes, dist, device=xdev)
         dp_ms += res.t_dp_ms
         passes += res.node_passes
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
