@@ -574,27 +574,58 @@ k_coding_score(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
 }
 
 // ---------------------------------------------------------------- ribosome binding site search
+// The 45 bases upstream of a start (strand-local positions start-1 .. start-45) are read once into
+// bit masks; bit u describes the base at position start - u.  Every model scored on the contig then
+// searches the same registers.
+struct UpWin {
+    unsigned long long lo, hi;     // 2-bit code of the base (digit & 3 after strand mapping; unknown -> 2 as in the reference)
+    unsigned long long isA, isG;   // exact identity on this strand (unknown bases match nothing)
+    unsigned long long inr;        // position exists (>= 0)
+    __device__ __forceinline__ int code(int u) const { return (int)(((hi >> u) & 1ull) << 1 | ((lo >> u) & 1ull)); }
+};
+
+__device__ __forceinline__ UpWin load_upwin(const uint8_t* __restrict__ d, int L, int start, int strand) {
+    UpWin w{0, 0, 0, 0, 0};
+#pragma unroll 9
+    for (int u = 1; u <= 45; u++) {
+        const int p = start - u;
+        if (p < 0) break;
+        const int raw = strand == 1 ? d[p] : d[L - 1 - p];
+        const int b = strand == 1 ? raw : (raw ^ 3);                       // ref: _sequence.h:45-55
+        const int c2 = (strand == 1 ? raw : comp2(raw)) & 3;               // ref: _sequence.h:207-220
+        w.inr |= 1ull << u;
+        w.lo |= (unsigned long long)(c2 & 1) << u; w.hi |= (unsigned long long)(c2 >> 1) << u;
+        w.isA |= (unsigned long long)(b == NA) << u; w.isG |= (unsigned long long)(b == NG) << u;
+    }
+    return w;
+}
+
 // ref: lib.pyx:791-881 (exact) / 883-979 (one mismatch); mm selects the variant.  As in the
 // reference the mismatch variant keeps the previous cur_val when no table row matches.
-__device__ int shine_dalgarno(const uint8_t* __restrict__ d, int L, int pos, int start, const double* __restrict__ w, int strand, int mm) {
+__device__ int shine_dalgarno(const UpWin& W, int pos, int start, const double* __restrict__ w, int mm) {
     int match[6], limit, maxv = 0, cur = 0;
 #pragma unroll
     for (int i = 0; i < 6; i++) match[i] = -10;
     limit = min(6, start - 4 - pos);
-    for (int i = 0; i < limit; i++) {
-        const bool in = pos + i >= 0 && pos + i < L;
-        const int b = in ? sbase(d, L, pos + i, strand) : -1;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        if (i >= limit) break;
+        const int u = start - (pos + i);
+        const bool in = (W.inr >> u) & 1ull;
+        const bool a = (W.isA >> u) & 1ull, g = (W.isG >> u) & 1ull;
         if (!mm) {
             if (!in) continue;
-            if (i % 3 == 0) { if (b == NA) match[i] = 2; } else { if (b == NG) match[i] = 3; }
+            if (i % 3 == 0) { if (a) match[i] = 2; } else { if (g) match[i] = 3; }
         } else {
-            if (i % 3 == 0) match[i] = (b == NA) ? 2 : -3; else match[i] = (b == NG) ? 3 : -2;
+            if (i % 3 == 0) match[i] = (in && a) ? 2 : -3; else match[i] = (in && g) ? 3 : -2;
         }
     }
     for (int i = limit; i > (mm ? 4 : 2); i--) {
         for (int j = 0; j < limit + 1 - i; j++) {
             int ctr = -2, mism = 0, flag;
-            for (int k = j; k < j + i; k++) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                if (k < j || k >= j + i) continue;
                 ctr += match[k];
                 if (mm && match[k] < 0) { mism++; if (k <= j + 1 || k >= j + i - 2) ctr -= 10; }
             }
@@ -637,144 +668,165 @@ __device__ int shine_dalgarno(const uint8_t* __restrict__ d, int L, int pos, int
     return maxv;
 }
 
-// k-mer index at strand-local position i (ref: _sequence.h:207-220)
-__device__ __forceinline__ int mer_local(const uint8_t* __restrict__ d, int L, int i, int len, int strand) {
-    int v = 0;
-    if (strand == 1) { for (int j = 0; j < len; j++) v |= (d[i + j] & 3) << (2 * j); }
-    else { const int k = L - 1 - i; for (int j = 0; j < len; j++) v |= (comp2(d[k - j]) & 3) << (2 * j); }
-    return v;
-}
-
 // ------------------------------------------------------------------------- start scoring
-// One thread per chain node.  ref: lib.pyx:2331-2487 (Nodes._score), 2241-2277 (_rbs_score),
+// One thread per node of the TOPOLOGY; it loads the upstream window once and scores the node for
+// every model (chain) of its contig.  ref: lib.pyx:2331-2487 (Nodes._score), 2241-2277 (_rbs_score),
 // 1556-1616 (_find_best_upstream_motif, stage 2), 1618-1650 (_score_upstream_composition).
 // The reference mutates node.edge while it scans (lib.pyx:2424-2434) and the flag survives into
 // the next model of a meta run; `first` and the index comparisons below reproduce the value each
 // read would have seen.
 __global__ void __launch_bounds__(256)
-k_score_starts(const ChainDesc* __restrict__ chains, int n_chains, int64_t node_begin, int64_t total,
+k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ contig_chains,
+               const int32_t* __restrict__ node_contig_base, int n_contigs, int n_nodes,
                const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct, GroupArrays ga,
                const pga_training* __restrict__ models, ChainArrays ca, ScoreParams sp) {
     __shared__ int s_c0;
-    const int64_t blk0 = node_begin + (int64_t)blockIdx.x * blockDim.x;
-    const int64_t g = blk0 + threadIdx.x;
-    const bool in_range = g < node_begin + total;
-    const int c = block_chain(chains, n_chains, blk0, in_range ? g : blk0, &s_c0);
-    if (!in_range) return;
-    const ChainDesc ch = chains[c];
-    const int i = (int)(g - ch.off), n = ch.n;
-    const int64_t tb = ch.topo_off;
-    const int type = ga.type[tb + i];
-    const int e0 = ga.edge0[tb + i];
+    const int blk0 = blockIdx.x * blockDim.x;
+    const int t = blk0 + threadIdx.x;
+    // contig of the block's first node, then a short forward walk
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = n_contigs - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (node_contig_base[mid] <= blk0) lo = mid; else hi = mid - 1; }
+        s_c0 = lo;
+    }
+    __syncthreads();
+    if (t >= n_nodes) return;
+    int c = s_c0;
+    while (c + 1 < n_contigs && node_contig_base[c + 1] <= t) c++;
+    const int2 cc = contig_chains[c];
+    if (cc.y <= 0) return;
+    const int tbase = node_contig_base[c];
+    const int i = t - tbase, n = node_contig_base[c + 1] - tbase;
+    const int type = ga.type[t];
+    const int e0 = ga.edge0[t];
     if (type == PGA_T_STOP) {      // stop nodes carry no start scores (reset_node_scores)
-        ca.edge[g] = (uint8_t)e0;
-        ca.cscore[g] = 0.0; ca.sscore[g] = 0.0; ca.rscore[g] = 0.0; ca.uscore[g] = 0.0; ca.tscore[g] = 0.0; ca.mot_score[g] = 0.0;
-        ca.mot_ndx[g] = 0; ca.mot_len[g] = 0; ca.mot_spacer[g] = 0; ca.mot_spacendx[g] = 0; ca.rbs[2 * g] = 0; ca.rbs[2 * g + 1] = 0;
+        for (int m = 0; m < cc.y; m++) {
+            const int64_t g = chains[cc.x + m].off + i;
+            ca.edge[g] = (uint8_t)e0;
+            ca.cscore[g] = 0.0; ca.sscore[g] = 0.0; ca.rscore[g] = 0.0; ca.uscore[g] = 0.0; ca.tscore[g] = 0.0; ca.mot_score[g] = 0.0;
+            ca.mot_ndx[g] = 0; ca.mot_len[g] = 0; ca.mot_spacer[g] = 0; ca.mot_spacendx[g] = 0; ca.rbs[2 * g] = 0; ca.rbs[2 * g + 1] = 0;
+        }
         return;
     }
-    const ContigDesc cd = ct[ch.contig];
+    const ContigDesc cd = ct[c];
     const int L = cd.len;
     const uint8_t* __restrict__ d = dig + cd.base;
-    const pga_training* __restrict__ tm = &models[ch.model];
-    const double st_wt = tm->st_wt;
-    const int tt = tm->trans_table;
-    const int ndx = ga.ndx[tb + i], sv = ga.stop_val[tb + i], strand = ga.strand[tb + i];
+    const int ndx = ga.ndx[t], sv = ga.stop_val[t], strand = ga.strand[t];
     const bool closed = sp.closed != 0, is_meta = sp.is_meta != 0;
     auto convertible = [&](int k) -> bool {
-        if (closed || ga.type[tb + k] == PGA_T_STOP || ga.edge0[tb + k]) return false;
-        const int x = ga.ndx[tb + k], s = ga.strand[tb + k];
+        if (closed || ga.type[tbase + k] == PGA_T_STOP || ga.edge0[tbase + k]) return false;
+        const int x = ga.ndx[tbase + k], s = ga.strand[tbase + k];
         return (x <= 2 && s == 1) || (x >= L - 3 && s == -1);
     };
     const bool conv = convertible(i);
-    const bool edge_in = e0 || (conv && !ch.first);
-
-    int rbs0 = 0, rbs1 = 0, m_ndx = 0, m_len = 0, m_sp = 0, m_si = 0;
-    double m_score = 0.0;
     const int start = strand == 1 ? ndx : L - 1 - ndx;     // strand-local start position
-    if (!edge_in) {
-        if (tm->uses_sd) {
-            for (int j = start - 20; j < start - 5; j++) {
-                if (strand == 1 ? j < 0 : j >= L) continue;
-                const int a = shine_dalgarno(d, L, j, start, tm->rbs_wt, strand, 0);
-                const int b = shine_dalgarno(d, L, j, start, tm->rbs_wt, strand, 1);
-                if (a > rbs0) rbs0 = a;
-                if (b > rbs1) rbs1 = b;
-            }
-        } else {
-            double bsc = -100.0; int bsp = 0, bsi = 0, blen = 0, bndx = 0;
-            for (int k = 3; k >= 0; k--) {
-                for (int j = start - 18 - k; j < start - 5 - k; j++) {
-                    if (j < 0) continue;
-                    int si;
-                    if (j <= start - 16 - k) si = 3; else if (j <= start - 14 - k) si = 2; else if (j >= start - 7 - k) si = 1; else si = 0;
-                    const int idx = mer_local(d, L, j, k + 3, strand);
-                    const double s = tm->mot_wt[k][si][idx];
-                    if (s > bsc) { bsc = s; bsi = si; bsp = start - j - k - 3; bndx = idx; blen = k + 3; }
-                }
-            }
-            if (bsc == -4.0 || bsc < tm->no_mot + 0.69) { m_score = tm->no_mot; }
-            else { m_ndx = bndx; m_len = blen; m_si = bsi; m_sp = bsp & 15; m_score = bsc; }
-        }
-    }
-
+    const UpWin W = load_upwin(d, L, start, strand);
     const long orf = ndx > sv ? ndx - sv : sv - ndx;
-    double edge_gene = 0;
-    if (edge_in) edge_gene += 1;
-    if ((strand == 1 && !is_stop_at(d, L, sv, 1, tt)) || (strand == -1 && !is_stop_at(d, L, L - 1 - sv, -1, tt))) edge_gene += 1;
-
-    double tscore, uscore, rscore, sscore, cscore = ca.cscore[g];
-    if (edge_in) {
-        tscore = 0.74 * st_wt / edge_gene; uscore = 0.0; rscore = 0.0;
-    } else {
-        tscore = tm->type_wt[type] * st_wt;
-        const double r1 = tm->rbs_wt[rbs0], r2 = tm->rbs_wt[rbs1];
-        const double sd = fmax(r1, r2) * st_wt;
-        if (tm->uses_sd) rscore = sd;
-        else { rscore = st_wt * m_score; if (rscore < sd && tm->no_mot > -0.5) rscore = sd; }
-        // upstream composition
-        int cnt = 0; double u = 0.0;
-        for (int k = 1; k < 3; k++) { if (k > start) break; u += 0.4 * st_wt * tm->ups_comp[cnt][mer_local(d, L, start - k, 1, strand)]; cnt++; }
-        for (int k = 15; k < 45; k++) { if (k > start) break; u += 0.4 * st_wt * tm->ups_comp[cnt][mer_local(d, L, start - k, 1, strand)]; cnt++; }
-        uscore = u;
-        if (!closed && ndx <= 2 && strand == 1) uscore += -1.00 * st_wt;
-        else if (!closed && ndx >= L - 3 && strand == -1) uscore += -1.00 * st_wt;
-        else if (i < 500 && strand == 1) {
-            for (int j = i - 1; j >= 0; j--)
-                if ((ga.edge0[tb + j] || convertible(j)) && sv == ga.stop_val[tb + j]) { uscore += -1.00 * st_wt; break; }
-        } else if (i + 500 >= n && strand == -1) {
-            for (int j = i + 1; j < n; j++)
-                if ((ga.edge0[tb + j] || (convertible(j) && !ch.first)) && sv == ga.stop_val[tb + j]) { uscore += -1.00 * st_wt; break; }
+    // does an edge node share this ORF?  (lib.pyx:2413-2422; the answer depends on whether the edge
+    // conversion of this pass has already reached that node, hence the two variants)
+    bool ups_first = false, ups_later = false, ups_near_edge = false;
+    if (!closed && ndx <= 2 && strand == 1) ups_near_edge = true;
+    else if (!closed && ndx >= L - 3 && strand == -1) ups_near_edge = true;
+    else if (i < 500 && strand == 1) {
+        for (int j = i - 1; j >= 0; j--)
+            if ((ga.edge0[tbase + j] || convertible(j)) && sv == ga.stop_val[tbase + j]) { ups_first = ups_later = true; break; }
+    } else if (i + 500 >= n && strand == -1) {
+        for (int j = i + 1; j < n; j++) {
+            if (sv != ga.stop_val[tbase + j]) continue;
+            if (ga.edge0[tbase + j]) { ups_first = ups_later = true; break; }
+            if (convertible(j)) ups_later = true;                  // counts only once an earlier model of the run converted it
         }
     }
-    bool edge_now = edge_in;
-    if (conv && !edge_in) {
-        edge_gene += 1; edge_now = true; tscore = 0.0;
-        uscore = 0.74 * st_wt / edge_gene; rscore = 0.0;
-    }
-    if (!edge_now && edge_gene == 1) uscore -= 0.5 * 0.74 * st_wt;
-    if (edge_gene == 0 && orf < 250) {
-        const double negf = 250.0 / (float)orf, posf = (float)orf / 250.0;
-        rscore *= rscore < 0 ? negf : posf;
-        uscore *= uscore < 0 ? negf : posf;
-        tscore *= tscore < 0 ? negf : posf;
-    }
-    if (is_meta && L < 3000 && edge_gene == 0 && (cscore < 5.0 || orf < 120))
-        cscore -= 7.5 * fmax(0.0, (3000.0 - L) / 2700.0);
-    sscore = tscore + rscore + uscore;
-    if (cscore < 0.0) {
-        if (edge_gene > 0 && !edge_now) {
-            if (!is_meta || L > 1500) sscore -= st_wt; else sscore -= 10.31 - 0.004 * L;
-        } else if (is_meta && L < 3000 && edge_now) {
-            const double mml = sqrt((double)L) * 5.0;
-            if (orf >= mml) { if (cscore >= 0) cscore = -1.0; sscore = 0.0; uscore = 0.0; }
-        } else sscore -= 0.5;
-    } else if (is_meta && cscore < 5.0 && orf < 120 && sscore < 0.0) sscore -= st_wt;
+    int tt_cached = -1; bool stop_missing = false;
 
-    ca.cscore[g] = cscore; ca.sscore[g] = sscore; ca.rscore[g] = rscore; ca.uscore[g] = uscore; ca.tscore[g] = tscore;
-    ca.mot_score[g] = m_score; ca.mot_ndx[g] = m_ndx;
-    ca.mot_len[g] = (uint8_t)m_len; ca.mot_spacer[g] = (uint8_t)m_sp; ca.mot_spacendx[g] = (uint8_t)m_si;
-    ca.rbs[2 * g] = (uint8_t)rbs0; ca.rbs[2 * g + 1] = (uint8_t)rbs1;
-    ca.edge[g] = (uint8_t)edge_now;
+    for (int m = 0; m < cc.y; m++) {
+        const ChainDesc ch = chains[cc.x + m];
+        const int64_t g = ch.off + i;
+        const pga_training* __restrict__ tm = &models[ch.model];
+        const double st_wt = tm->st_wt;
+        const int tt = tm->trans_table;
+        if (tt != tt_cached) {
+            tt_cached = tt;
+            stop_missing = (strand == 1 && !is_stop_at(d, L, sv, 1, tt)) || (strand == -1 && !is_stop_at(d, L, L - 1 - sv, -1, tt));
+        }
+        const bool edge_in = e0 || (conv && !ch.first);
+        int rbs0 = 0, rbs1 = 0, m_ndx = 0, m_len = 0, m_sp = 0, m_si = 0;
+        double m_score = 0.0;
+        if (!edge_in) {
+            if (tm->uses_sd) {
+                for (int j = start - 20; j < start - 5; j++) {
+                    if (j < 0) continue;         // (on the reverse strand the reference tests j >= slen, never true here)
+                    const int a = shine_dalgarno(W, j, start, tm->rbs_wt, 0);
+                    const int b = shine_dalgarno(W, j, start, tm->rbs_wt, 1);
+                    if (a > rbs0) rbs0 = a;
+                    if (b > rbs1) rbs1 = b;
+                }
+            } else {
+                double bsc = -100.0; int bsp = 0, bsi = 0, blen = 0, bndx = 0;
+                for (int k = 3; k >= 0; k--) {
+                    for (int j = start - 18 - k; j < start - 5 - k; j++) {
+                        if (j < 0) continue;
+                        int si;
+                        if (j <= start - 16 - k) si = 3; else if (j <= start - 14 - k) si = 2; else if (j >= start - 7 - k) si = 1; else si = 0;
+                        int idx = 0;
+                        for (int q = 0; q < k + 3; q++) idx |= W.code(start - j - q) << (2 * q);
+                        const double sc = tm->mot_wt[k][si][idx];
+                        if (sc > bsc) { bsc = sc; bsi = si; bsp = start - j - k - 3; bndx = idx; blen = k + 3; }
+                    }
+                }
+                if (bsc == -4.0 || bsc < tm->no_mot + 0.69) { m_score = tm->no_mot; }
+                else { m_ndx = bndx; m_len = blen; m_si = bsi; m_sp = bsp & 15; m_score = bsc; }
+            }
+        }
+        double edge_gene = 0;
+        if (edge_in) edge_gene += 1;
+        if (stop_missing) edge_gene += 1;
+
+        double tscore, uscore, rscore, sscore, cscore = ca.cscore[g];
+        if (edge_in) {
+            tscore = 0.74 * st_wt / edge_gene; uscore = 0.0; rscore = 0.0;
+        } else {
+            tscore = tm->type_wt[type] * st_wt;
+            const double r1 = tm->rbs_wt[rbs0], r2 = tm->rbs_wt[rbs1];
+            const double sd = fmax(r1, r2) * st_wt;
+            if (tm->uses_sd) rscore = sd;
+            else { rscore = st_wt * m_score; if (rscore < sd && tm->no_mot > -0.5) rscore = sd; }
+            int cnt = 0; double u = 0.0;
+            for (int k = 1; k < 3; k++) { if (k > start) break; u += 0.4 * st_wt * tm->ups_comp[cnt][W.code(k)]; cnt++; }
+            for (int k = 15; k < 45; k++) { if (k > start) break; u += 0.4 * st_wt * tm->ups_comp[cnt][W.code(k)]; cnt++; }
+            uscore = u;
+            if (ups_near_edge || (ch.first ? ups_first : ups_later)) uscore += -1.00 * st_wt;
+        }
+        bool edge_now = edge_in;
+        if (conv && !edge_in) {
+            edge_gene += 1; edge_now = true; tscore = 0.0;
+            uscore = 0.74 * st_wt / edge_gene; rscore = 0.0;
+        }
+        if (!edge_now && edge_gene == 1) uscore -= 0.5 * 0.74 * st_wt;
+        if (edge_gene == 0 && orf < 250) {
+            const double negf = 250.0 / (float)orf, posf = (float)orf / 250.0;
+            rscore *= rscore < 0 ? negf : posf;
+            uscore *= uscore < 0 ? negf : posf;
+            tscore *= tscore < 0 ? negf : posf;
+        }
+        if (is_meta && L < 3000 && edge_gene == 0 && (cscore < 5.0 || orf < 120))
+            cscore -= 7.5 * fmax(0.0, (3000.0 - L) / 2700.0);
+        sscore = tscore + rscore + uscore;
+        if (cscore < 0.0) {
+            if (edge_gene > 0 && !edge_now) {
+                if (!is_meta || L > 1500) sscore -= st_wt; else sscore -= 10.31 - 0.004 * L;
+            } else if (is_meta && L < 3000 && edge_now) {
+                const double mml = sqrt((double)L) * 5.0;
+                if (orf >= mml) { if (cscore >= 0) cscore = -1.0; sscore = 0.0; uscore = 0.0; }
+            } else sscore -= 0.5;
+        } else if (is_meta && cscore < 5.0 && orf < 120 && sscore < 0.0) sscore -= st_wt;
+
+        ca.cscore[g] = cscore; ca.sscore[g] = sscore; ca.rscore[g] = rscore; ca.uscore[g] = uscore; ca.tscore[g] = tscore;
+        ca.mot_score[g] = m_score; ca.mot_ndx[g] = m_ndx;
+        ca.mot_len[g] = (uint8_t)m_len; ca.mot_spacer[g] = (uint8_t)m_sp; ca.mot_spacendx[g] = (uint8_t)m_si;
+        ca.rbs[2 * g] = (uint8_t)rbs0; ca.rbs[2 * g + 1] = (uint8_t)rbs1;
+        ca.edge[g] = (uint8_t)edge_now;
+    }
 }
 
 // ------------------------------------------------------------------- overlapping starts
@@ -876,6 +928,8 @@ void pga_launch_score(const ChainDesc* d_chains, int n_chains, int64_t node_begi
     if (group_nodes > 0)
         hipLaunchKernelGGL(k_coding_score, dim3(nblocks(group_nodes, 256)), blk, 0, st, d_all_chains, d_contig_chains, d_node_contig_base,
                            n_contigs, 0, group_nodes, d_dig, d_ct, ga, d_models, d_msc, ca);
-    hipLaunchKernelGGL(k_score_starts, grid, blk, 0, st, d_chains, n_chains, node_begin, total, d_dig, d_ct, ga, d_models, ca, sp);
+    if (group_nodes > 0)
+        hipLaunchKernelGGL(k_score_starts, dim3(nblocks(group_nodes, 256)), blk, 0, st, d_all_chains, d_contig_chains, d_node_contig_base, n_contigs,
+                           group_nodes, d_dig, d_ct, ga, d_models, ca, sp);
     hipLaunchKernelGGL(k_overlapping_starts, grid, blk, 0, st, d_chains, n_chains, node_begin, total, ga, d_mc, ca, sp.max_overlap);
 }
