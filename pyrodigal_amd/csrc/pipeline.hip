@@ -46,6 +46,12 @@ __device__ __forceinline__ int block_chain(const ChainDesc* __restrict__ ch, int
     return c;
 }
 
+__device__ __forceinline__ double readlane_f64_pl(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
 // strand-local base i of a contig (reverse strand is virtual; ref: _sequence.h:45-55)
 __device__ __forceinline__ int sbase(const uint8_t* __restrict__ d, int L, int i, int strand) {
     return strand == 1 ? d[i] : (d[L - 1 - i] ^ 3);
@@ -470,11 +476,173 @@ __device__ __forceinline__ int hexamer(const uint8_t* __restrict__ d, int pos, i
     return v;
 }
 
-// One thread per stop node of the TOPOLOGY (not per chain): the ORF walk -- hexamer index, start flags --
-// is identical for every model scored on this contig, so one walk accumulates the ordered sums of up to
-// CS_MODELS models at once (independent f64 chains interleave).  The block first compacts its stop nodes
-// into the leading lanes so that walking wavefronts are full.
+// Coding score of every start, for every model scored on the contig (ref: lib.pyx:2119-2239).
+// The hexamer log-odds sum is an ordered f64 sum from the stop outwards (no reassociation allowed).
+// One thread per stop node of the TOPOLOGY walks a short ORF on its own and accumulates the sums of up
+// to CS_MODELS models at once (the walk -- rolling hexamer, start flags -- is model-independent).
+// ORFs longer than CS_LONG codons would make one lane a long serial chain of dependent loads, so they are
+// handed to the whole wavefront instead: 64 codons at a time every lane loads the table values of its own
+// codon, the ordered sum then runs through the wave with v_readlane broadcasts (every lane adds the same
+// values in the same order and keeps the prefix of its codon), and passes 2 / 3 -- which only need the
+// running maximum of the ORIGINAL values of the starts further out, exact in any order -- are wave scans.
+// A block first compacts its stop nodes into the leading lanes.
 constexpr int CS_MODELS = 8;
+constexpr int CS_LONG = 192;
+
+struct OrfCtx {
+    const uint8_t* d; const uint8_t* nf; const uint8_t* nf_f; const int32_t* pre;
+    int tbase, p, q, L, strand, step, ncod;
+    int2 cc;
+};
+
+__device__ __forceinline__ double wave_incl_max(double v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double o = __shfl_up(v, off, 64);
+        if (lane >= off) v = fmax(v, o);
+    }
+    return v;
+}
+
+__device__ __forceinline__ double length_factor(const ModelScoreConst* mc, int ncodons) {   // ref: lib.pyx:2203-2210
+    const double gsize = (double)ncodons;
+    if (gsize > 1000.0) return (mc->lfac_max - mc->lfac_min) * (gsize - 80) / 920.0;
+    return mc->lfac_tab[ncodons];
+}
+
+// one lane, one (short) ORF
+__device__ __forceinline__ void orf_serial(const OrfCtx& o, const ChainDesc* __restrict__ chains, const pga_training* __restrict__ models,
+                           const ModelScoreConst* __restrict__ msc, const ChainArrays& ca) {
+    const uint8_t* __restrict__ d = o.d;
+    const int strand = o.strand, step = o.step, p = o.p;
+    for (int m0 = 0; m0 < o.cc.y; m0 += CS_MODELS) {
+        const int nm = min(CS_MODELS, o.cc.y - m0);
+        const double* gdc[CS_MODELS]; double* csp[CS_MODELS]; const ModelScoreConst* mcp[CS_MODELS];
+#pragma unroll
+        for (int m = 0; m < CS_MODELS; m++) {
+            const ChainDesc ch = chains[o.cc.x + m0 + (m < nm ? m : 0)];
+            gdc[m] = models[ch.model].gene_dc; csp[m] = ca.cscore + ch.off; mcp[m] = &msc[ch.model];
+        }
+        double sum[CS_MODELS];
+#pragma unroll
+        for (int m = 0; m < CS_MODELS; m++) sum[m] = 0.0;
+        int far = -1, mer = 0;
+        for (int ci = 0; ci < o.ncod; ci++) {
+            const int j = p + step * (ci + 1);
+            if (ci == 0) mer = hexamer(d, j, strand);
+            else {      // rolling update: the three bases nearest to the walk direction are new (ref: _sequence.h:207-220)
+                int lo3;
+                if (strand == 1) lo3 = (d[j] & 3) | ((d[j + 1] & 3) << 2) | ((d[j + 2] & 3) << 4);
+                else lo3 = (comp2(d[j]) & 3) | ((comp2(d[j - 1]) & 3) << 2) | ((comp2(d[j - 2]) & 3) << 4);
+                mer = ((mer << 6) & 0xfc0) | lo3;
+            }
+#pragma unroll
+            for (int m = 0; m < CS_MODELS; m++) sum[m] += gdc[m][mer];
+            if (o.nf[j]) {
+                const int k = o.pre[j] + (strand == 1 ? 0 : o.nf_f[j]) - o.tbase;
+#pragma unroll
+                for (int m = 0; m < CS_MODELS; m++) if (m < nm) csp[m][k] = sum[m];
+                far = ci;
+            }
+        }
+        if (far < 0) continue;
+        double run_c[CS_MODELS], run_l[CS_MODELS];
+#pragma unroll
+        for (int m = 0; m < CS_MODELS; m++) { run_c[m] = -10000.0; run_l[m] = -10000.0; }
+        for (int ci = far; ci >= 0; ci--) {                     // outermost start first
+            const int j = p + step * (ci + 1);
+            if (!o.nf[j]) continue;
+            const int k = o.pre[j] + (strand == 1 ? 0 : o.nf_f[j]) - o.tbase;
+#pragma unroll
+            for (int m = 0; m < CS_MODELS; m++) {
+                if (m >= nm) continue;
+                double cs = csp[m][k];
+                if (cs > run_c[m]) run_c[m] = cs; else cs -= (run_c[m] - cs);
+                double lfac = length_factor(mcp[m], ci + 2);
+                if (lfac > run_l[m]) run_l[m] = lfac; else lfac -= fmax(fmin(run_l[m] - lfac, lfac), 0.0);
+                if (lfac > 3.0 && cs < 0.5 * lfac) cs = 0.5 * lfac;
+                cs += lfac;
+                csp[m][k] = cs;
+            }
+        }
+    }
+}
+
+// the whole wavefront, one (long) ORF; `o` is wave-uniform
+__device__ __forceinline__ void orf_wave(const OrfCtx& o, const int lane, const ChainDesc* __restrict__ chains, const pga_training* __restrict__ models,
+                         const ModelScoreConst* __restrict__ msc, const ChainArrays& ca) {
+    const double NEG_INF = -__builtin_huge_val();
+    const int strand = o.strand, step = o.step, p = o.p, ncod = o.ncod;
+    for (int m0 = 0; m0 < o.cc.y; m0 += CS_MODELS) {
+        const int nm = min(CS_MODELS, o.cc.y - m0);
+        const double* gdc[CS_MODELS]; double* csp[CS_MODELS]; const ModelScoreConst* mcp[CS_MODELS];
+#pragma unroll
+        for (int m = 0; m < CS_MODELS; m++) {
+            const ChainDesc ch = chains[o.cc.x + m0 + (m < nm ? m : 0)];
+            gdc[m] = models[ch.model].gene_dc; csp[m] = ca.cscore + ch.off; mcp[m] = &msc[ch.model];
+        }
+        double sum[CS_MODELS];
+#pragma unroll
+        for (int m = 0; m < CS_MODELS; m++) sum[m] = 0.0;
+        bool any_start = false;
+        for (int c0 = 0; c0 < ncod; c0 += 64) {
+            const int ci = c0 + lane;
+            const bool valid = ci < ncod;
+            const int x = p + step * (ci + 1);
+            const int mer = valid ? hexamer(o.d, x, strand) : 0;
+            const bool fl = valid && o.nf[x] != 0;
+            const int k = fl ? o.pre[x] + (strand == 1 ? 0 : o.nf_f[x]) - o.tbase : 0;
+            double v[CS_MODELS], pref[CS_MODELS];
+#pragma unroll
+            for (int m = 0; m < CS_MODELS; m++) { v[m] = (valid && m < nm) ? gdc[m][mer] : 0.0; pref[m] = 0.0; }
+            const int nv = min(64, ncod - c0);
+            for (int l = 0; l < nv; l++) {
+#pragma unroll
+                for (int m = 0; m < CS_MODELS; m++) {
+                    if (m >= nm) break;
+                    sum[m] += readlane_f64_pl(v[m], l);
+                    pref[m] = lane == l ? sum[m] : pref[m];
+                }
+            }
+            if (fl) {
+#pragma unroll
+                for (int m = 0; m < CS_MODELS; m++) if (m < nm) csp[m][k] = pref[m];
+            }
+            any_start = any_start || __any(fl);
+        }
+        if (!any_start) continue;
+        double carry_c[CS_MODELS], carry_l[CS_MODELS];
+#pragma unroll
+        for (int m = 0; m < CS_MODELS; m++) { carry_c[m] = -10000.0; carry_l[m] = -10000.0; }
+        for (int c0 = ((ncod - 1) >> 6) << 6; c0 >= 0; c0 -= 64) {
+            const int ci = c0 + (63 - lane);            // lane order = outermost first
+            const bool valid = ci < ncod;
+            const int x = p + step * (ci + 1);
+            const bool fl = valid && o.nf[x] != 0;
+            const int k = fl ? o.pre[x] + (strand == 1 ? 0 : o.nf_f[x]) - o.tbase : 0;
+#pragma unroll
+            for (int m = 0; m < CS_MODELS; m++) {
+                if (m >= nm) break;
+                const double cs0 = fl ? csp[m][k] : NEG_INF;
+                const double lf0 = fl ? length_factor(mcp[m], ci + 2) : NEG_INF;
+                const double inc_c = wave_incl_max(cs0, lane), inc_l = wave_incl_max(lf0, lane);
+                double ex_c = __shfl_up(inc_c, 1, 64), ex_l = __shfl_up(inc_l, 1, 64);
+                if (lane == 0) { ex_c = NEG_INF; ex_l = NEG_INF; }
+                const double run_c = fmax(ex_c, carry_c[m]), run_l = fmax(ex_l, carry_l[m]);
+                if (fl) {
+                    double cs = cs0, lfac = lf0;
+                    if (!(cs > run_c)) cs -= (run_c - cs);
+                    if (!(lfac > run_l)) lfac -= fmax(fmin(run_l - lfac, lfac), 0.0);
+                    if (lfac > 3.0 && cs < 0.5 * lfac) cs = 0.5 * lfac;
+                    cs += lfac;
+                    csp[m][k] = cs;
+                }
+                carry_c[m] = fmax(carry_c[m], readlane_f64_pl(inc_c, 63));
+                carry_l[m] = fmax(carry_l[m], readlane_f64_pl(inc_l, 63));
+            }
+        }
+    }
+}
 
 __global__ void __launch_bounds__(256)
 k_coding_score(const ChainDesc* __restrict__ chains, const int2* __restrict__ contig_chains /* per contig: first chain, count */,
@@ -495,81 +663,55 @@ k_coding_score(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
     if (is_stop) s_list[off + __popcll(bm & ((1ull << lane) - 1ull))] = me;
     __syncthreads();
     const int cnt = s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
-    if ((int)threadIdx.x >= cnt) return;
-    const int t = s_list[threadIdx.x];                 // topology index of my stop node
-    // its contig
-    int c;
-    {
+    if (wv * 64 >= cnt) return;                        // this wave has no stop node after compaction
+    const bool mine = (int)threadIdx.x < cnt;
+    OrfCtx o{};
+    if (mine) {
+        const int t = s_list[threadIdx.x];             // topology index of my stop node
         int lo = 0, hi = n_contigs - 1;
         while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (node_contig_base[mid] <= t) lo = mid; else hi = mid - 1; }
-        c = lo;
+        const int c = lo;
+        o.cc = contig_chains[c];
+        const ContigDesc cd = ct[c];
+        o.d = dig + cd.base;
+        o.strand = ga.strand[t];
+        o.nf = (o.strand == 1 ? ga.nf_fwd : ga.nf_rev) + cd.base; o.nf_f = ga.nf_fwd + cd.base;
+        o.pre = ga.pre_nodes + cd.base;
+        o.tbase = node_contig_base[c];
+        o.p = ga.ndx[t]; o.q = ga.stop_val[t]; o.L = cd.len;
+        o.step = o.strand == 1 ? -3 : 3;
+        // codons of the ORF in walk order: x(ci) = p + step * (ci + 1), ci = 0 .. ncod-1
+        if (o.strand == 1) {
+            const int lowb = max(o.q + 1, 0);
+            const int xmin = lowb + (((o.p - lowb) % 3) + 3) % 3;
+            o.ncod = xmin <= o.p - 3 ? (o.p - 3 - xmin) / 3 + 1 : 0;
+        } else {
+            const int highb = min(o.q - 1, o.L - 1);
+            const int xmax = highb - (((highb - o.p) % 3) + 3) % 3;
+            o.ncod = xmax >= o.p + 3 ? (xmax - (o.p + 3)) / 3 + 1 : 0;
+        }
+        if (o.cc.y <= 0) o.ncod = 0;
     }
-    const int2 cc = contig_chains[c];
-    if (cc.y <= 0) return;
-    const ContigDesc cd = ct[c];
-    const uint8_t* __restrict__ d = dig + cd.base;
-    const int strand = ga.strand[t];
-    const uint8_t* __restrict__ nf = (strand == 1 ? ga.nf_fwd : ga.nf_rev) + cd.base;
-    const uint8_t* __restrict__ nf_f = ga.nf_fwd + cd.base;
-    const int32_t* __restrict__ pre = ga.pre_nodes + cd.base;
-    const int tbase = node_contig_base[c];
-    const int p = ga.ndx[t], q = ga.stop_val[t], L = cd.len;
-    const int step = strand == 1 ? -3 : 3;
-    for (int m0 = 0; m0 < cc.y; m0 += CS_MODELS) {
-        const int nm = min(CS_MODELS, cc.y - m0);
-        const double* gdc[CS_MODELS]; double* csp[CS_MODELS]; const ModelScoreConst* mcp[CS_MODELS];
-#pragma unroll
-        for (int m = 0; m < CS_MODELS; m++) {
-            const ChainDesc ch = chains[cc.x + m0 + (m < nm ? m : 0)];
-            gdc[m] = models[ch.model].gene_dc; csp[m] = ca.cscore + ch.off; mcp[m] = &msc[ch.model];
-        }
-        // pass 1: ordered hexamer log-odds sums from the stop outwards
-        double sum[CS_MODELS];
-#pragma unroll
-        for (int m = 0; m < CS_MODELS; m++) sum[m] = 0.0;
-        int far = p, mer = 0;
-        bool first = true;
-        for (int j = p + step; strand == 1 ? (j >= 0 && j > q) : (j <= L - 1 && j < q); j += step) {
-            if (first) { mer = hexamer(d, j, strand); first = false; }
-            else {      // rolling update: the three bases nearest to the walk direction are new (ref: _sequence.h:207-220)
-                int lo3;
-                if (strand == 1) lo3 = (d[j] & 3) | ((d[j + 1] & 3) << 2) | ((d[j + 2] & 3) << 4);
-                else lo3 = (comp2(d[j]) & 3) | ((comp2(d[j - 1]) & 3) << 2) | ((comp2(d[j - 2]) & 3) << 4);
-                mer = ((mer << 6) & 0xfc0) | lo3;
-            }
-#pragma unroll
-            for (int m = 0; m < CS_MODELS; m++) sum[m] += gdc[m][mer];
-            if (nf[j]) {
-                const int k = pre[j] + (strand == 1 ? 0 : nf_f[j]) - tbase;
-#pragma unroll
-                for (int m = 0; m < CS_MODELS; m++) if (m < nm) csp[m][k] = sum[m];
-                far = j;
-            }
-        }
-        if (far == p) continue;
-        // passes 2 + 3, outermost start first (ascending index on the forward strand, descending on the reverse)
-        double run_c[CS_MODELS], run_l[CS_MODELS];
-#pragma unroll
-        for (int m = 0; m < CS_MODELS; m++) { run_c[m] = -10000.0; run_l[m] = -10000.0; }
-        for (int j = far; j != p; j -= step) {
-            if (!nf[j]) continue;
-            const int k = pre[j] + (strand == 1 ? 0 : nf_f[j]) - tbase;
-            const int ncod = (abs(p - j) + 3) / 3;
-            const double gsize = (double)ncod;
-#pragma unroll
-            for (int m = 0; m < CS_MODELS; m++) {
-                if (m >= nm) continue;
-                double cs = csp[m][k];
-                if (cs > run_c[m]) run_c[m] = cs; else cs -= (run_c[m] - cs);
-                double lfac;
-                if (gsize > 1000.0) lfac = (mcp[m]->lfac_max - mcp[m]->lfac_min) * (gsize - 80) / 920.0;
-                else lfac = mcp[m]->lfac_tab[ncod];
-                if (lfac > run_l[m]) run_l[m] = lfac; else lfac -= fmax(fmin(run_l[m] - lfac, lfac), 0.0);
-                if (lfac > 3.0 && cs < 0.5 * lfac) cs = 0.5 * lfac;
-                cs += lfac;
-                csp[m][k] = cs;
-            }
-        }
+    const bool is_long = mine && o.ncod > CS_LONG;
+    if (mine && !is_long && o.ncod > 0) orf_serial(o, chains, models, msc, ca);
+    // long ORFs of this wave, one after the other, all 64 lanes on each
+    unsigned long long longs = __ballot(is_long);
+    while (longs) {
+        const int src = __builtin_ctzll(longs);
+        longs &= longs - 1ull;
+        OrfCtx w;
+        const unsigned long long pd = (unsigned long long)o.d, pn = (unsigned long long)o.nf, pf = (unsigned long long)o.nf_f, pp = (unsigned long long)o.pre;
+        auto bc64 = [&](unsigned long long v) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
+            return ((unsigned long long)hi << 32) | lo;
+        };
+        w.d = (const uint8_t*)bc64(pd); w.nf = (const uint8_t*)bc64(pn); w.nf_f = (const uint8_t*)bc64(pf); w.pre = (const int32_t*)bc64(pp);
+        w.tbase = __builtin_amdgcn_readlane(o.tbase, src); w.p = __builtin_amdgcn_readlane(o.p, src); w.q = __builtin_amdgcn_readlane(o.q, src);
+        w.L = __builtin_amdgcn_readlane(o.L, src); w.strand = __builtin_amdgcn_readlane(o.strand, src); w.step = __builtin_amdgcn_readlane(o.step, src);
+        w.ncod = __builtin_amdgcn_readlane(o.ncod, src);
+        w.cc.x = __builtin_amdgcn_readlane(o.cc.x, src); w.cc.y = __builtin_amdgcn_readlane(o.cc.y, src);
+        orf_wave(w, lane, chains, models, msc, ca);
     }
 }
 
