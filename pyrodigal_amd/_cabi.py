@@ -227,16 +227,12 @@ class Batch:
 def _unpack_result(L, res, want_nodes):
     try:
         r = res.contents
+        contigs = np.empty(r.n_contigs, CONTIG_DTYPE)          # one copy each, straight out of the C result
         if r.n_contigs:
-            buf = ctypes.string_at(r.contigs, r.n_contigs * ctypes.sizeof(ContigResult))
-            contigs = np.frombuffer(buf, dtype=CONTIG_DTYPE).copy()
-        else:
-            contigs = np.zeros(0, CONTIG_DTYPE)
+            ctypes.memmove(contigs.ctypes.data, r.contigs, r.n_contigs * ctypes.sizeof(ContigResult))
+        genes = np.empty(r.n_genes, GENE_DTYPE)
         if r.n_genes:
-            buf = ctypes.string_at(r.genes, r.n_genes * ctypes.sizeof(Gene))
-            genes = np.frombuffer(buf, dtype=GENE_DTYPE).copy()
-        else:
-            genes = np.zeros(0, GENE_DTYPE)
+            ctypes.memmove(genes.ctypes.data, r.genes, r.n_genes * ctypes.sizeof(Gene))
         nodes = None
         if want_nodes and r.nodes:
             nodes = []

@@ -705,16 +705,32 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
             }
         }
         w_o0[NG] = out_nodes;
+        // one device arena and one pinned arena, DP-pass fields first: the part every call needs is a single DMA
         OutArrays o, h;
+        size_t arena_dp = 0, arena_all = 0;
         {
-            const int64_t n = out_nodes + 1;
-#define OB(field, type, mult) { void* p__; int rc__ = ensure_dev(c, "o_" #field, sizeof(type) * (size_t)(mult) * n + 64, &p__); if (rc__) return rc__; o.field = (type*)p__; \
-                                rc__ = ensure_pin(c, "h_" #field, sizeof(type) * (size_t)(mult) * n + 64, &p__); if (rc__) return rc__; h.field = (type*)p__; }
-            OB(ndx, int32_t, 1) OB(stop_val, int32_t, 1) OB(type, uint8_t, 1) OB(strand, int8_t, 1) OB(gc_cont, float, 1)
-            OB(edge_dp, uint8_t, 1) OB(cscore_dp, double, 1) OB(sscore_dp, double, 1) OB(rscore_dp, double, 1) OB(uscore_dp, double, 1) OB(tscore_dp, double, 1)
-            OB(star_ptr, int32_t, 3) OB(traceb, int32_t, 1) OB(ov_mark, int8_t, 1) OB(score, double, 1)
-            OB(edge, uint8_t, 1) OB(cscore, double, 1) OB(sscore, double, 1) OB(rscore, double, 1) OB(uscore, double, 1) OB(tscore, double, 1) OB(mot_score, double, 1)
-            OB(mot_ndx, int32_t, 1) OB(rbs, uint8_t, 2) OB(mot_len, uint8_t, 1) OB(mot_spacer, uint8_t, 1) OB(mot_spacendx, uint8_t, 1)
+            const size_t n = (size_t)out_nodes + 1;
+            size_t off = 0;
+            auto reserve = [&](size_t elem, size_t mult) { const size_t at = off; off += ((elem * mult * n + 255) / 256) * 256; return at; };
+#define OFFS(field, type, mult) const size_t at_##field = reserve(sizeof(type), mult);
+            OFFS(ndx, int32_t, 1) OFFS(stop_val, int32_t, 1) OFFS(type, uint8_t, 1) OFFS(strand, int8_t, 1)
+            OFFS(edge_dp, uint8_t, 1) OFFS(cscore_dp, double, 1) OFFS(sscore_dp, double, 1) OFFS(rscore_dp, double, 1) OFFS(uscore_dp, double, 1) OFFS(tscore_dp, double, 1)
+            OFFS(star_ptr, int32_t, 3) OFFS(traceb, int32_t, 1) OFFS(ov_mark, int8_t, 1) OFFS(score, double, 1)
+            arena_dp = off;
+            OFFS(gc_cont, float, 1)
+            OFFS(edge, uint8_t, 1) OFFS(cscore, double, 1) OFFS(sscore, double, 1) OFFS(rscore, double, 1) OFFS(uscore, double, 1) OFFS(tscore, double, 1) OFFS(mot_score, double, 1)
+            OFFS(mot_ndx, int32_t, 1) OFFS(rbs, uint8_t, 2) OFFS(mot_len, uint8_t, 1) OFFS(mot_spacer, uint8_t, 1) OFFS(mot_spacendx, uint8_t, 1)
+            arena_all = off;
+            void* dp__; void* hp__;
+            { int rc__ = ensure_dev(c, "o_arena", arena_all + 256, &dp__); if (rc__) return rc__; }
+            { int rc__ = ensure_pin(c, "h_arena", arena_all + 256, &hp__); if (rc__) return rc__; }
+            char* db = (char*)dp__; char* hb = (char*)hp__;
+#define OB(field, type) o.field = (type*)(db + at_##field); h.field = (type*)(hb + at_##field);
+            OB(ndx, int32_t) OB(stop_val, int32_t) OB(type, uint8_t) OB(strand, int8_t) OB(gc_cont, float)
+            OB(edge_dp, uint8_t) OB(cscore_dp, double) OB(sscore_dp, double) OB(rscore_dp, double) OB(uscore_dp, double) OB(tscore_dp, double)
+            OB(star_ptr, int32_t) OB(traceb, int32_t) OB(ov_mark, int8_t) OB(score, double)
+            OB(edge, uint8_t) OB(cscore, double) OB(sscore, double) OB(rscore, double) OB(uscore, double) OB(tscore, double) OB(mot_score, double)
+            OB(mot_ndx, int32_t) OB(rbs, uint8_t) OB(mot_len, uint8_t) OB(mot_spacer, uint8_t) OB(mot_spacendx, uint8_t)
         }
         size_t nwin = 0; for (int g = 0; g < NG; g++) nwin += wg[g].size();
         DEVBUF(d_win, WinDesc, "d_win", nwin + 1);
@@ -729,18 +745,8 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
                 k0 += wg[g].size();
             }
         }
-        if (out_nodes > 0) {
-            const size_t n = (size_t)out_nodes;
-#define DL(field, type, mult) HT(c, hipMemcpyAsync(h.field, o.field, sizeof(type) * (size_t)(mult) * n, hipMemcpyDeviceToHost, st));
-            DL(ndx, int32_t, 1) DL(stop_val, int32_t, 1) DL(type, uint8_t, 1) DL(strand, int8_t, 1)
-            DL(edge_dp, uint8_t, 1) DL(cscore_dp, double, 1) DL(sscore_dp, double, 1) DL(rscore_dp, double, 1) DL(uscore_dp, double, 1) DL(tscore_dp, double, 1)
-            DL(star_ptr, int32_t, 3) DL(traceb, int32_t, 1) DL(ov_mark, int8_t, 1) DL(score, double, 1)
-            if (P.want_nodes) {
-                DL(gc_cont, float, 1)
-                DL(edge, uint8_t, 1) DL(cscore, double, 1) DL(sscore, double, 1) DL(rscore, double, 1) DL(uscore, double, 1) DL(tscore, double, 1) DL(mot_score, double, 1)
-                DL(mot_ndx, int32_t, 1) DL(rbs, uint8_t, 2) DL(mot_len, uint8_t, 1) DL(mot_spacer, uint8_t, 1) DL(mot_spacendx, uint8_t, 1)
-            }
-        }
+        if (out_nodes > 0)
+            HT(c, hipMemcpyAsync(h.ndx, o.ndx, P.want_nodes ? arena_all : arena_dp, hipMemcpyDeviceToHost, st));   // arena starts at `ndx`
         HT(c, hipEventRecord(f->e_stop, st));
         HT(c, hipGetLastError());
         HT(c, hipStreamSynchronize(st));
