@@ -718,7 +718,7 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
     __shared__ double s_w[2][64][64];                 // static pair weights [slot][source k][target lane], NaN = pair not allowed
     __shared__ unsigned long long s_dyn[2][64];       // per source: lanes whose pair needs the dynamic evaluation
     __shared__ double s_eval[2][64];                  // early far-field result of the next batch
-    __shared__ int s_etb[2][64], s_eov[2][64];
+    __shared__ int s_etb[2][64], s_eov[2][64], s_etbn[2][64];
     __shared__ TileLds s_tile;
     const ChainDesc cd = chains[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -751,7 +751,7 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
             const unsigned long long dm = __ballot(dyn);
             if (lane == 0) s_dyn[0][k] = dm;
         }
-    } else if (wave == 4) { s_eval[0][lane] = 0.0; s_etb[0][lane] = -1; s_eov[0][lane] = -1; }
+    } else if (wave == 4) { s_eval[0][lane] = 0.0; s_etb[0][lane] = -1; s_eov[0][lane] = -1; s_etbn[0][lane] = -1; }
     __syncthreads();
 
     for (int b = 0; b < nb; b++) {
@@ -775,55 +775,59 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
                 const double v = s_lval[w][lane]; const int t = s_ltb[w][lane];
                 if (t != -1 && (v > B.val || (v == B.val && t > B.tb))) { B.val = v; B.tb = t; B.ov = s_lov[w][lane]; }
             }
-            // lean in-batch walk: the static weight w(k, lane) comes from LDS one step ahead; only the recurrence
-            // (broadcast score of lane k, add, compare, select) is left on the serial path.  The running result
-            // is (bv, tbx) with tbx = traceb | (ov_mark + 1) << 28, or -1 when nothing connected yet.
-            const int kmax = min(63, n - 1 - i0);
-            const unsigned long long endmask = __ballot(T.kind == 1 || T.kind == 2);
-            const unsigned long long dynany = __ballot(s_dyn[slot][lane] != 0ull);
+            // lean in-batch walk: the static weight w(k, lane) comes from LDS one chunk (4 steps) ahead; only the
+            // recurrence (broadcast value of lane k, add, compare, select) is left on the serial path.
+            //   bv  running score of the target lane (what gets stored)
+            //   sv  the same seen as a SOURCE: NaN while a gene end has no traceb yet (it connects to nothing;
+            //       ref: impl/generic.h:29-36), so a dead source fails every ">=" without a test
+            //   lk  in-batch source taken last (| (ov_mark + 1) << 8), -1 while the pre-walk result stands
+            // Rows k >= kmax of the weight tile are NaN, so every batch runs the same 64 steps.
+            const unsigned long long dynm = __ballot(s_dyn[slot][lane] != 0ull);
+            const bool endlane = T.kind == 1 || T.kind == 2;
+            // ndx of the pre-walk traceb node: in the LDS tile, or found by the early far-field wave
+            const int tbn_pre = B.tb < 0 ? -1 : (B.tb >= i0 - 64 ? s_tile.ndx[B.tb - (i0 - 64)] : s_etbn[slot][lane]);
             double bv = B.val;
-            int tbx = B.tb < 0 ? -1 : (B.tb | ((B.ov + 1) << 28));
-            double wn = s_w[slot][0][lane];
-#pragma unroll 4
-            for (int k = 0; k < kmax; k++) {
-                const double w = wn;
-                wn = s_w[slot][k + 1][lane];
-                const int tbk = __builtin_amdgcn_readlane(tbx, k);
-                const bool dead = ((endmask >> k) & 1ull) && tbk < 0;    // gene end never reached: connects to nothing
-                const int j = i0 + k;
-                if (((dynany >> k) & 1ull) && !dead) {
+            double sv = (endlane && B.tb < 0) ? QNAN : bv;
+            int lk = -1;
+            const double* wp = &s_w[slot][0][lane];
+            auto step = [&](const int k, const double w) {
+                if ((dynm >> k) & 1ull) {
                     // forward-stop source: forward targets use the static weight, reverse targets the dynamic rule,
                     // which needs the position of the source's own traceb node
                     const int s_ndx = __builtin_amdgcn_readlane(T.ndx, k);
-                    const int tbj = tbk & 0x0fffffff;
-                    int tbnj;
-                    if (tbj >= i0) tbnj = __builtin_amdgcn_readlane(T.ndx, tbj - i0);
-                    else if (tbj >= i0 - 64) tbnj = s_tile.ndx[tbj - (i0 - 64)];
-                    else tbnj = P.src[tbj].ndx;
+                    const int lkk = __builtin_amdgcn_readlane(lk, k);
+                    const int tbnj = lkk >= 0 ? __builtin_amdgcn_readlane(T.ndx, lkk & 63) : __builtin_amdgcn_readlane(tbn_pre, k);
+                    const int j = i0 + k;
                     bool okd; int mf;
                     const double wd = f3_to_reverse(s_ndx, tbnj, T, (j >= T.lo) & (j < T.i), negc, okd, mf);
                     const bool rev = T.kind >= 2;
-                    const double val = readlane_f64(bv, k) + (rev ? (okd ? wd : QNAN) : w);
+                    const double val = readlane_f64(sv, k) + (rev ? (okd ? wd : QNAN) : w);
                     const bool c = val >= bv;
-                    bv = c ? val : bv; tbx = c ? (j | (rev ? ((mf + 1) << 28) : 0)) : tbx;
-                    continue;
+                    bv = c ? val : bv; sv = c ? val : sv; lk = c ? (k | (rev ? ((mf + 1) << 8) : 0)) : lk;
+                } else {
+                    // Ascending order makes the lexicographic test the reference's plain ">="; a NaN (pair not
+                    // allowed, or dead source) fails it.
+                    const double val = readlane_f64(sv, k) + w;
+                    const bool c = val >= bv;
+                    bv = c ? val : bv; sv = c ? val : sv; lk = c ? k : lk;
                 }
-                // Branch-free step.  Ascending order makes the lexicographic test the reference's plain ">=";
-                // a NaN (pair not allowed, or dead source) fails it.
-                double sck = readlane_f64(bv, k);
-                sck = dead ? QNAN : sck;
-                const double val = sck + w;
-                const bool c = val >= bv;
-                bv = c ? val : bv; tbx = c ? j : tbx;
+            };
+            double w0 = wp[0], w1 = wp[64], w2 = wp[128], w3 = wp[192];
+#pragma unroll 1
+            for (int k0 = 0; k0 < 64; k0 += 4) {
+                const int kn = k0 + 4 < 64 ? k0 + 4 : 60;
+                const double n0 = wp[kn * 64], n1 = wp[kn * 64 + 64], n2 = wp[kn * 64 + 128], n3 = wp[kn * 64 + 192];
+                step(k0, w0); step(k0 + 1, w1); step(k0 + 2, w2); step(k0 + 3, w3);
+                w0 = n0; w1 = n1; w2 = n2; w3 = n3;
             }
             B.val = bv;
-            if (tbx < 0) { B.tb = -1; B.ov = -1; B.tbn = -1; }
-            else {
-                B.tb = tbx & 0x0fffffff; B.ov = (tbx >> 28) - 1;
-                // position of the traceb node, wherever it lives
-                const int rel = B.tb - i0;
-                const int in_batch = __shfl(T.ndx, rel >= 0 ? rel : 0, 64);
-                B.tbn = rel >= 0 ? in_batch : (rel >= -64 && i0 > 0 ? s_tile.ndx[rel + 64] : P.src[B.tb].ndx);
+            const int ndx_lk = __shfl(T.ndx, lk & 63, 64);     // all lanes take part: a source lane may itself have lk < 0
+            if (lk >= 0) {
+                B.tb = i0 + (lk & 63); B.ov = (lk >> 8) - 1;
+                B.tbn = ndx_lk;
+            } else {
+                B.tbn = tbn_pre;
+                if (B.tb < 0) { B.tb = -1; B.ov = -1; B.tbn = -1; }
             }
             const unsigned long long tq2 = prof ? __builtin_readcyclecounter() : 0;
             finalize_batch(T, B, i0, lane, n, P, s_levbase, negc, end_best, end_idx, end_tb, &s_tile);
@@ -846,6 +850,7 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
                 Best B{0.0, -1, -1, -1};
                 if (i0 > 0) far_field(Tn, 0, i0, P, s_levbase, negc, s_igm, B);    // every tile finalized before this iteration
                 s_eval[pb][lane] = B.val; s_etb[pb][lane] = B.tb; s_eov[pb][lane] = B.ov;
+                s_etbn[pb][lane] = B.tb >= 0 ? P.src[B.tb].ndx : -1;
                 if (prof && lane == 0) buf.prof[4] += __builtin_readcyclecounter() - tq1;
             }
         }
