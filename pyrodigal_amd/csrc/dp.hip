@@ -673,8 +673,17 @@ k_dp_tree(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src,
 // Static part of an in-batch pair (source k = lane k of the same batch, target = this lane):
 // weight and admissibility that do not depend on the source's running state.  Forward-stop sources
 // towards reverse targets need the ndx of the source's traceb node: those pairs are flagged dynamic.
+//
+// A dynamic pair (forward stop at s_ndx, its traceb node at tbnj, reverse target) is admissible through
+// candidate q when "tbnj - s_ndx < d[q]"; everything else about it is static and folded into d[q]
+// (PGA_DYN_NEVER = never) and into the base weight w (NaN = pair not allowed at all):
+//   reverse start target   one candidate, the overlapping 3' ends rule       (ref: _connection.h:238-254)
+//   reverse stop target    one candidate per overlapping start of the target (ref: _connection.h:296-325)
+// The deltas are small because an opposite-strand overlap is shorter than PGA_MAX_OPP_OVLP.
+#define PGA_DYN_NEVER ((short)-32768)
 __device__ __forceinline__ void static_pair(const int k, const int i0, const Target& T, const double negc, const double* s_igm,
-                                            bool& ok, double& w, bool& dyn) {
+                                            bool& ok, double& w, bool& dyn, short& d0, short& d1, short& d2) {
+    d0 = d1 = d2 = PGA_DYN_NEVER;
     const int s_meta = __builtin_amdgcn_readlane(T.meta, k);
     const int s_ndx = __builtin_amdgcn_readlane(T.ndx, k);
     const int sk = PGA_KIND(s_meta), sf = PGA_FRAME(s_meta);
@@ -699,7 +708,31 @@ __device__ __forceinline__ void static_pair(const int k, const int i0, const Tar
         const double sx0 = readlane_f64(T.x0, k), sx1 = readlane_f64(T.x1, k), sx2 = readlane_f64(T.x2, k);
         if (T.kind == 0) { ok = inwin && (s_ndx + 2 < T.ndx); w = igm_apart(T.ndx - s_ndx, negc, s_igm); }
         else if (T.kind == 1) { ok = inwin && T.stop_val < s_ndx && PGA_SPVALID(s_meta, T.frame); w = sel3(T.frame, sx0, sx1, sx2); }
-        else dyn = inwin;
+        else {
+            dyn = inwin;
+            if (T.kind == 2) {
+                const int ovlp5 = (s_ndx + 2) - (T.stop_val - 2) + 1;
+                const bool st5 = inwin & (T.stop_val - 2 < s_ndx + 2) & (ovlp5 < PGA_MAX_OPP_OVLP) &
+                                 ((s_ndx - T.stop_val) < (T.ndx - s_ndx + 3));
+                // (s_ndx - stop_val) < (stop_val - 3 - tbnj)  <=>  tbnj - s_ndx < 2 (stop_val - s_ndx) - 3
+                if (st5) d0 = (short)(2 * (T.stop_val - s_ndx) - 3);
+                ok = false;                         // admissible only through its candidate
+            } else {
+                const int left = s_ndx + 2;
+                ok = inwin & (left < T.ndx - 2);
+                w = negc;
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    const int n3s = sel3i(q, T.n3s0, T.n3s1, T.n3s2), n3n = sel3i(q, T.n3n0, T.n3n1, T.n3n2);
+                    const int ovlp = left - n3s + 3;
+                    const bool stq = ok & (PGA_SPVALID(T.meta, q) != 0) & (ovlp > 0) & (ovlp < PGA_MAX_OPP_OVLP) & (ovlp < n3n - left) &
+                                     (sel3(q, T.x0, T.x1, T.x2) > 0.0);
+                    // ovlp < n3s - tbnj - 2  <=>  tbnj - s_ndx < 2 (n3s - s_ndx) - 7
+                    const short dq = stq ? (short)(2 * (n3s - s_ndx) - 7) : PGA_DYN_NEVER;
+                    if (q == 0) d0 = dq; else if (q == 1) d1 = dq; else d2 = dq;
+                }
+            }
+        }
     }
 }
 
@@ -717,6 +750,7 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
     __shared__ int s_levbase[12];
     __shared__ double s_w[2][64][64];                 // static pair weights [slot][source k][target lane], NaN = pair not allowed
     __shared__ unsigned long long s_dyn[2][64];       // per source: lanes whose pair needs the dynamic evaluation
+    __shared__ short s_thr[2][64][3][64];             // dynamic pairs: admission thresholds [slot][source k][candidate][target lane]
     __shared__ double s_eval[2][64];                  // early far-field result of the next batch
     __shared__ int s_etb[2][64], s_eov[2][64], s_etbn[2][64];
     __shared__ TileLds s_tile;
@@ -745,10 +779,11 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
     if (wave >= 1 && wave <= 3) {
         const int kmax = min(63, n - 1);
         for (int k = wave - 1; k < 64; k += 3) {
-            bool ok = false, dyn = false; double w = 0.0;
-            if (k < kmax) static_pair(k, 0, Tn, negc, s_igm, ok, w, dyn);
+            bool ok = false, dyn = false; double w = 0.0; short d0, d1, d2;
+            if (k < kmax) static_pair(k, 0, Tn, negc, s_igm, ok, w, dyn, d0, d1, d2);
             s_w[0][k][lane] = ok ? w : QNAN;
             const unsigned long long dm = __ballot(dyn);
+            if (dm) { s_thr[0][k][0][lane] = dyn ? d0 : PGA_DYN_NEVER; s_thr[0][k][1][lane] = dyn ? d1 : PGA_DYN_NEVER; s_thr[0][k][2][lane] = dyn ? d2 : PGA_DYN_NEVER; }
             if (lane == 0) s_dyn[0][k] = dm;
         }
     } else if (wave == 4) { s_eval[0][lane] = 0.0; s_etb[0][lane] = -1; s_eov[0][lane] = -1; s_etbn[0][lane] = -1; }
@@ -777,40 +812,48 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
             }
             // lean in-batch walk: the static weight w(k, lane) comes from LDS one chunk (4 steps) ahead; only the
             // recurrence (broadcast value of lane k, add, compare, select) is left on the serial path.
-            //   bv  running score of the target lane (what gets stored)
-            //   sv  the same seen as a SOURCE: NaN while a gene end has no traceb yet (it connects to nothing;
-            //       ref: impl/generic.h:29-36), so a dead source fails every ">=" without a test
-            //   lk  in-batch source taken last (| (ov_mark + 1) << 8), -1 while the pre-walk result stands
+            //   bv    running score of the target lane
+            //   lk    in-batch source taken last (| (ov_mark + 1) << 8), -1 while the pre-walk result stands
+            //   dead  gene ends without a traceb so far: they connect to nothing (ref: impl/generic.h:29-36),
+            //         their step is skipped; a lane leaves the set the first time it takes a source
             // Rows k >= kmax of the weight tile are NaN, so every batch runs the same 64 steps.
             const unsigned long long dynm = __ballot(s_dyn[slot][lane] != 0ull);
             const bool endlane = T.kind == 1 || T.kind == 2;
+            unsigned long long dead = __ballot(endlane && B.tb < 0);
             // ndx of the pre-walk traceb node: in the LDS tile, or found by the early far-field wave
             const int tbn_pre = B.tb < 0 ? -1 : (B.tb >= i0 - 64 ? s_tile.ndx[B.tb - (i0 - 64)] : s_etbn[slot][lane]);
             double bv = B.val;
-            double sv = (endlane && B.tb < 0) ? QNAN : bv;
             int lk = -1;
             const double* wp = &s_w[slot][0][lane];
+            const short* tp = &s_thr[slot][0][0][lane];
+            // dynamic pairs: candidate values of this target lane and the floor they must beat
+            const bool is_r3 = T.kind == 3;
+            const double cur0 = is_r3 ? T.x0 : T.csd;
+            const double floor0 = is_r3 ? 0.0 : -__builtin_huge_val();
             auto step = [&](const int k, const double w) {
-                if ((dynm >> k) & 1ull) {
-                    // forward-stop source: forward targets use the static weight, reverse targets the dynamic rule,
-                    // which needs the position of the source's own traceb node
+                if ((dead >> k) & 1ull) return;
+                double wk = w; int tag = k;
+                if (__builtin_expect((int)((dynm >> k) & 1ull), 0)) {
+                    // forward-stop source towards reverse targets: the admission depends on where the source's
+                    // own traceb node lies
                     const int s_ndx = __builtin_amdgcn_readlane(T.ndx, k);
                     const int lkk = __builtin_amdgcn_readlane(lk, k);
                     const int tbnj = lkk >= 0 ? __builtin_amdgcn_readlane(T.ndx, lkk & 63) : __builtin_amdgcn_readlane(tbn_pre, k);
-                    const int j = i0 + k;
-                    bool okd; int mf;
-                    const double wd = f3_to_reverse(s_ndx, tbnj, T, (j >= T.lo) & (j < T.i), negc, okd, mf);
-                    const bool rev = T.kind >= 2;
-                    const double val = readlane_f64(sv, k) + (rev ? (okd ? wd : QNAN) : w);
-                    const bool c = val >= bv;
-                    bv = c ? val : bv; sv = c ? val : sv; lk = c ? (k | (rev ? ((mf + 1) << 8) : 0)) : lk;
-                } else {
-                    // Ascending order makes the lexicographic test the reference's plain ">="; a NaN (pair not
-                    // allowed, or dead source) fails it.
-                    const double val = readlane_f64(sv, k) + w;
-                    const bool c = val >= bv;
-                    bv = c ? val : bv; sv = c ? val : sv; lk = c ? k : lk;
+                    const int rel = max(tbnj - s_ndx, -32767);
+                    const int d0 = tp[k * 192], d1 = tp[k * 192 + 64], d2 = tp[k * 192 + 128];
+                    double mv = floor0; int m = -1;
+                    if ((rel < d0) & (cur0 > mv)) { mv = cur0; m = 0; }
+                    if ((rel < d1) & (T.x1 > mv)) { mv = T.x1; m = 1; }
+                    if ((rel < d2) & (T.x2 > mv)) { mv = T.x2; m = 2; }
+                    wk = m >= 0 ? mv : w;
+                    tag = k | ((is_r3 ? m + 1 : 0) << 8);
                 }
+                // Ascending order makes the lexicographic test the reference's plain ">="; a NaN (pair not allowed)
+                // fails it.
+                const double val = readlane_f64(bv, k) + wk;
+                const bool c = val >= bv;
+                bv = c ? val : bv; lk = c ? tag : lk;
+                dead &= ~__ballot(c);
             };
             double w0 = wp[0], w1 = wp[64], w2 = wp[128], w3 = wp[192];
 #pragma unroll 1
@@ -839,10 +882,11 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
             if (wave <= 3) {
                 const int kmax = min(63, n - 1 - nx);
                 for (int k = wave - 1; k < 64; k += 3) {
-                    bool ok = false, dyn = false; double w = 0.0;
-                    if (k < kmax) static_pair(k, nx, Tn, negc, s_igm, ok, w, dyn);
+                    bool ok = false, dyn = false; double w = 0.0; short d0, d1, d2;
+                    if (k < kmax) static_pair(k, nx, Tn, negc, s_igm, ok, w, dyn, d0, d1, d2);
                     s_w[pb][k][lane] = ok ? w : QNAN;
                     const unsigned long long dm = __ballot(dyn);
+                    if (dm) { s_thr[pb][k][0][lane] = dyn ? d0 : PGA_DYN_NEVER; s_thr[pb][k][1][lane] = dyn ? d1 : PGA_DYN_NEVER; s_thr[pb][k][2][lane] = dyn ? d2 : PGA_DYN_NEVER; }
                     if (lane == 0) s_dyn[pb][k] = dm;
                 }
                 if (prof && lane == 0 && wave == 1) buf.prof[3] += __builtin_readcyclecounter() - tq1;
