@@ -670,90 +670,116 @@ k_dp_tree(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src,
     publish_max(end_best, end_idx, end_tb, lane, buf);
 }
 
-// Static part of an in-batch pair (source k = lane k of the same batch, target = this lane):
-// weight and admissibility that do not depend on the source's running state.  Forward-stop sources
-// towards reverse targets need the ndx of the source's traceb node: those pairs are flagged dynamic.
-//
-// A dynamic pair (forward stop at s_ndx, its traceb node at tbnj, reverse target) is admissible through
-// candidate q when "tbnj - s_ndx < d[q]"; everything else about it is static and folded into d[q]
-// (PGA_DYN_NEVER = never) and into the base weight w (NaN = pair not allowed at all):
+// Static part of a pair: source = lane k of batch S (chain index j), target = this lane of batch T.
+// Weight and admissibility that do not depend on the source's running state.  What remains dynamic is
+// a forward-stop source (position s_ndx, its traceb node at tbnj) towards a reverse target: it goes
+// through candidate q only when "tbnj + s_ndx + 7 < rhs[q]" (DynRegs), and `flags` bit q says whether
+// candidate q passes every static condition:
 //   reverse start target   one candidate, the overlapping 3' ends rule       (ref: _connection.h:238-254)
 //   reverse stop target    one candidate per overlapping start of the target (ref: _connection.h:296-325)
-// The deltas are small because an opposite-strand overlap is shorter than PGA_MAX_OPP_OVLP.
-#define PGA_DYN_NEVER ((short)-32768)
-__device__ __forceinline__ void static_pair(const int k, const int i0, const Target& T, const double negc, const double* s_igm,
-                                            bool& ok, double& w, bool& dyn, short& d0, short& d1, short& d2) {
-    d0 = d1 = d2 = PGA_DYN_NEVER;
-    const int s_meta = __builtin_amdgcn_readlane(T.meta, k);
-    const int s_ndx = __builtin_amdgcn_readlane(T.ndx, k);
+// ok/w describe the pair when no candidate is taken (w = NaN-able base weight).
+__device__ __forceinline__ void static_pair(const int k, const int j, const Target& S, const Target& T, const double negc,
+                                            const double* s_igm, bool& ok, double& w, int& flags) {
+    const int s_meta = __builtin_amdgcn_readlane(S.meta, k);
+    const int s_ndx = __builtin_amdgcn_readlane(S.ndx, k);
     const int sk = PGA_KIND(s_meta), sf = PGA_FRAME(s_meta);
-    const int j = i0 + k;
     const bool inwin = (j >= T.lo) && (j < T.i);
-    ok = false; dyn = false; w = 0.0;
+    ok = false; w = 0.0; flags = 0;
     if (sk == 0) {
         ok = inwin && T.kind == 1 && T.frame == sf && T.stop_val < s_ndx;
-        w = readlane_f64(T.cs, k);
+        w = readlane_f64(S.cs, k);
     } else if (sk == 2) {
         const bool a = T.kind == 0 && s_ndx < T.ndx;
         const bool b = T.kind == 3 && s_ndx < T.ndx - 2;
         ok = inwin && (a || b);
         w = b ? igm_apart(T.ndx - s_ndx, negc, s_igm) : negc;
     } else if (sk == 3) {
-        const int s_stop = __builtin_amdgcn_readlane(T.stop_val, k);
+        const int s_stop = __builtin_amdgcn_readlane(S.stop_val, k);
         const bool a = T.kind == 2 && T.frame == sf && s_stop > T.ndx;
         const bool b = T.kind == 3 && s_stop > T.ndx && PGA_SPVALID(T.meta, sf);
         ok = inwin && (a || b);
         w = a ? T.cs : sel3(sf, T.x0, T.x1, T.x2);
     } else {
-        const double sx0 = readlane_f64(T.x0, k), sx1 = readlane_f64(T.x1, k), sx2 = readlane_f64(T.x2, k);
+        const double sx0 = readlane_f64(S.x0, k), sx1 = readlane_f64(S.x1, k), sx2 = readlane_f64(S.x2, k);
         if (T.kind == 0) { ok = inwin && (s_ndx + 2 < T.ndx); w = igm_apart(T.ndx - s_ndx, negc, s_igm); }
         else if (T.kind == 1) { ok = inwin && T.stop_val < s_ndx && PGA_SPVALID(s_meta, T.frame); w = sel3(T.frame, sx0, sx1, sx2); }
-        else {
-            dyn = inwin;
-            if (T.kind == 2) {
-                const int ovlp5 = (s_ndx + 2) - (T.stop_val - 2) + 1;
-                const bool st5 = inwin & (T.stop_val - 2 < s_ndx + 2) & (ovlp5 < PGA_MAX_OPP_OVLP) &
-                                 ((s_ndx - T.stop_val) < (T.ndx - s_ndx + 3));
-                // (s_ndx - stop_val) < (stop_val - 3 - tbnj)  <=>  tbnj - s_ndx < 2 (stop_val - s_ndx) - 3
-                if (st5) d0 = (short)(2 * (T.stop_val - s_ndx) - 3);
-                ok = false;                         // admissible only through its candidate
-            } else {
-                const int left = s_ndx + 2;
-                ok = inwin & (left < T.ndx - 2);
-                w = negc;
+        else if (T.kind == 2) {
+            const int ovlp5 = (s_ndx + 2) - (T.stop_val - 2) + 1;
+            const bool st5 = inwin & (T.stop_val - 2 < s_ndx + 2) & (ovlp5 < PGA_MAX_OPP_OVLP) &
+                             ((s_ndx - T.stop_val) < (T.ndx - s_ndx + 3));
+            flags = st5 ? 1 : 0;                // admissible only through its candidate
+        } else {
+            const int left = s_ndx + 2;
+            ok = inwin & (left < T.ndx - 2);
+            w = negc;
 #pragma unroll
-                for (int q = 0; q < 3; q++) {
-                    const int n3s = sel3i(q, T.n3s0, T.n3s1, T.n3s2), n3n = sel3i(q, T.n3n0, T.n3n1, T.n3n2);
-                    const int ovlp = left - n3s + 3;
-                    const bool stq = ok & (PGA_SPVALID(T.meta, q) != 0) & (ovlp > 0) & (ovlp < PGA_MAX_OPP_OVLP) & (ovlp < n3n - left) &
-                                     (sel3(q, T.x0, T.x1, T.x2) > 0.0);
-                    // ovlp < n3s - tbnj - 2  <=>  tbnj - s_ndx < 2 (n3s - s_ndx) - 7
-                    const short dq = stq ? (short)(2 * (n3s - s_ndx) - 7) : PGA_DYN_NEVER;
-                    if (q == 0) d0 = dq; else if (q == 1) d1 = dq; else d2 = dq;
-                }
+            for (int q = 0; q < 3; q++) {
+                const int n3s = sel3i(q, T.n3s0, T.n3s1, T.n3s2), n3n = sel3i(q, T.n3n0, T.n3n1, T.n3n2);
+                const int ovlp = left - n3s + 3;
+                const bool stq = ok & (PGA_SPVALID(T.meta, q) != 0) & (ovlp > 0) & (ovlp < PGA_MAX_OPP_OVLP) & (ovlp < n3n - left) &
+                                 (sel3(q, T.x0, T.x1, T.x2) > 0.0);
+                flags |= stq ? (1 << q) : 0;
             }
         }
     }
 }
 
-// Five wavefronts per chain, for the latency-bound case of few long chains:
-//   wave 0     the serial wave: far field of the tile it finalized last (read back from LDS), lean
-//              in-batch walk that takes the static pair weights from LDS, store + tree update;
-//   waves 1-3  precompute the static pair weights of the NEXT batch into LDS (no dependence on scores);
-//   wave 4     computes the far field of the NEXT batch over every older tile (global memory, tree).
-// One __syncthreads per batch.
-#define PGA_MW_WAVES 5
+// Per-target registers of the dynamic rule (see static_pair):
+//   reverse stop   ovlp < n3s - tbnj - 2,  ovlp = s_ndx + 5 - n3s       <=>  tbnj + s_ndx + 7 < 2 n3s
+//   reverse start  (s_ndx - stop_val) < (stop_val - 3 - tbnj)            <=>  tbnj + s_ndx + 7 < 2 stop_val + 4
+struct DynRegs { int rhs0, rhs1, rhs2; double cur0, floor0; bool is_r3; };
+__device__ __forceinline__ DynRegs dyn_regs(const Target& T) {
+    DynRegs D;
+    D.is_r3 = T.kind == 3;
+    D.rhs0 = D.is_r3 ? 2 * T.n3s0 : 2 * T.stop_val + 4; D.rhs1 = 2 * T.n3s1; D.rhs2 = 2 * T.n3s2;
+    D.cur0 = D.is_r3 ? T.x0 : T.csd;
+    D.floor0 = D.is_r3 ? 0.0 : -__builtin_huge_val();   // a reverse start takes its candidate whatever its value
+    return D;
+}
+// weight of a dynamic pair: the best admitted candidate, else the base weight; ov1 = ov_mark + 1
+__device__ __forceinline__ void dyn_weight(const int s_ndx, const int tbnj, const int flags, const Target& T, const DynRegs& D,
+                                           double& w, int& ov1) {
+    const int lhs = tbnj + s_ndx + 7;
+    double mv = D.floor0; int m = -1;
+    if (((flags & 1) != 0) & (lhs < D.rhs0) & (D.cur0 > mv)) { mv = D.cur0; m = 0; }
+    if (((flags & 2) != 0) & (lhs < D.rhs1) & (T.x1 > mv)) { mv = T.x1; m = 1; }
+    if (((flags & 4) != 0) & (lhs < D.rhs2) & (T.x2 > mv)) { mv = T.x2; m = 2; }
+    w = m >= 0 ? mv : w;
+    ov1 = D.is_r3 ? m + 1 : 0;
+}
+
+// What the other waves need of the batch the serial wave finalized last.
+struct TileFin {
+    double score[64];
+    int ndx[64], tbn[64];               // tbn: ndx of the node's traceb node, -1 if none
+    unsigned long long dead;            // gene ends without a traceb: they connect to nothing
+};
+
+// Eight wavefronts per chain, for the latency-bound case of few long chains.  Every pair inside the
+// last 128 nodes is reduced to "score[j] + w(j, i)" with w precomputed off the critical path:
+//   wave 0      the serial wave: merges the partial results, walks the batch (lane k is final once the
+//               walk reaches source i0+k), stores it and extends the tree;
+//   waves 1-6   precompute, for the NEXT batch, the weights of its in-batch pairs and of the pairs
+//               from this batch into it (no dependence on scores);
+//   wave 7      computes the far field of the NEXT batch over every older tile (global memory, tree);
+//   all waves   once a batch is final, each applies a slice of its 64 nodes to the next batch's targets.
+// Two __syncthreads per batch.
+#define PGA_MW_WAVES 8
+#define PGA_MW_HELPERS 6
 __global__ void __launch_bounds__(64 * PGA_MW_WAVES)
 k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src, const DpTgt* __restrict__ g_tgt,
              const ModelConst* __restrict__ models, DpBuffers buf) {
     __shared__ double s_igm[64];
     __shared__ int s_levbase[12];
-    __shared__ double s_w[2][64][64];                 // static pair weights [slot][source k][target lane], NaN = pair not allowed
-    __shared__ unsigned long long s_dyn[2][64];       // per source: lanes whose pair needs the dynamic evaluation
-    __shared__ short s_thr[2][64][3][64];             // dynamic pairs: admission thresholds [slot][source k][candidate][target lane]
+    __shared__ double s_w[2][64][64];                 // in-batch weights [slot][source k][target lane], NaN = pair not allowed
+    __shared__ double s_wp[64][64];                   // weights from the previous batch's sources into this batch
+    __shared__ unsigned char s_fl[2][64][64], s_flp[64][64];      // candidate flags of the dynamic pairs
+    __shared__ unsigned long long s_dyn[2][64], s_dynp[64];       // per source: lanes with a dynamic pair
     __shared__ double s_eval[2][64];                  // early far-field result of the next batch
     __shared__ int s_etb[2][64], s_eov[2][64], s_etbn[2][64];
-    __shared__ TileLds s_tile;
+    __shared__ double s_pval[PGA_MW_WAVES][64];       // partial results over the previous batch, one slice per wave
+    __shared__ int s_ptbx[PGA_MW_WAVES][64];
+    __shared__ TileFin s_fin;
     const ChainDesc cd = chains[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = cd.n;
@@ -766,27 +792,38 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
     double end_best = -1.0; int end_idx = -1, end_tb = -1;
     const int nb = (n + 63) >> 6;
     const bool prof = buf.prof != nullptr && blockIdx.x == 0;
-    __shared__ double s_lval[4][64];                  // partial results of the late field (waves 0-3)
-    __shared__ int s_ltb[4][64], s_lov[4][64];
+    constexpr int SLICE = 64 / PGA_MW_WAVES;
 
     if (n <= 0) {                                    // empty chain (contig without nodes): nothing to walk
         if (wave == 0) publish_max(end_best, end_idx, end_tb, lane, buf);
         return;
     }
-    // prologue: static weights of batch 0; its far field is empty
+    // weights of batch `bn` (targets Tq at chain index iq) in slot `sl`, and of the pairs from batch Tp into it
+    auto helper_weights = [&](const Target& Tp, const Target& Tq, const int iq, const int sl, const bool with_prev) {
+        const int kmax = min(63, n - 1 - iq);
+        for (int r = wave - 1; r < (with_prev ? 128 : 64); r += PGA_MW_HELPERS) {
+            bool ok = false; double w = 0.0; int fl = 0;
+            if (r < 64) {
+                if (r < kmax) static_pair(r, iq + r, Tq, Tq, negc, s_igm, ok, w, fl);
+                s_w[sl][r][lane] = ok ? w : QNAN;
+                const unsigned long long dm = __ballot(fl != 0);
+                if (dm) s_fl[sl][r][lane] = (unsigned char)fl;
+                if (lane == 0) s_dyn[sl][r] = dm;
+            } else {
+                const int k = r - 64;
+                static_pair(k, iq - 64 + k, Tp, Tq, negc, s_igm, ok, w, fl);
+                s_wp[k][lane] = ok ? w : QNAN;
+                const unsigned long long dm = __ballot(fl != 0);
+                if (dm) s_flp[k][lane] = (unsigned char)fl;
+                if (lane == 0) s_dynp[k] = dm;
+            }
+        }
+    };
+    // prologue: weights of batch 0; its far field is empty
     Target Tn;
     load_target(Tn, P, 0, lane, n, negc);
-    if (wave >= 1 && wave <= 3) {
-        const int kmax = min(63, n - 1);
-        for (int k = wave - 1; k < 64; k += 3) {
-            bool ok = false, dyn = false; double w = 0.0; short d0, d1, d2;
-            if (k < kmax) static_pair(k, 0, Tn, negc, s_igm, ok, w, dyn, d0, d1, d2);
-            s_w[0][k][lane] = ok ? w : QNAN;
-            const unsigned long long dm = __ballot(dyn);
-            if (dm) { s_thr[0][k][0][lane] = dyn ? d0 : PGA_DYN_NEVER; s_thr[0][k][1][lane] = dyn ? d1 : PGA_DYN_NEVER; s_thr[0][k][2][lane] = dyn ? d2 : PGA_DYN_NEVER; }
-            if (lane == 0) s_dyn[0][k] = dm;
-        }
-    } else if (wave == 4) { s_eval[0][lane] = 0.0; s_etb[0][lane] = -1; s_eov[0][lane] = -1; s_etbn[0][lane] = -1; }
+    if (wave >= 1 && wave <= PGA_MW_HELPERS) helper_weights(Tn, Tn, 0, 0, false);
+    else if (wave == PGA_MW_WAVES - 1) { s_eval[0][lane] = 0.0; s_etb[0][lane] = -1; s_eov[0][lane] = -1; s_etbn[0][lane] = -1; }
     __syncthreads();
 
     for (int b = 0; b < nb; b++) {
@@ -794,22 +831,52 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
         const int nx = i0 + 64, pb = slot ^ 1;
         const unsigned long long tq0 = prof ? __builtin_readcyclecounter() : 0;
         const Target T = Tn;                                   // this batch; every wave holds the same 64 targets
-        if (nx < n) load_target(Tn, P, nx, lane, n, negc);     // next batch, needed after the first barrier
-        // ---- phase L: the tile finalized last (LDS), its sources dealt to waves 0-3
-        if (wave < 4) {
-            Best Bl{0.0, -1, -1, -1};
-            if (i0 > 0) late_field(T, &s_tile, i0 - 64, negc, s_igm, Bl, wave, 4, wave == 0);
-            s_lval[wave][lane] = Bl.val; s_ltb[wave][lane] = Bl.tb; s_lov[wave][lane] = Bl.ov;
+        if (nx < n) load_target(Tn, P, nx, lane, n, negc);     // next batch, needed after the barrier
+        const DynRegs D = dyn_regs(T);
+        // ---- the batch finalized last, one slice of its sources per wave (ascending inside the slice)
+        {
+            double pv = 0.0; int ptx = -1;
+            if (i0 > 0) {
+                const unsigned long long deadp = s_fin.dead;
+                const unsigned long long dynp = __ballot(s_dynp[lane] != 0ull);
+                const int q0 = wave * SLICE;
+                double wq[SLICE];
+#pragma unroll
+                for (int u = 0; u < SLICE; u++) wq[u] = s_wp[q0 + u][lane];
+#pragma unroll
+                for (int u = 0; u < SLICE; u++) {
+                    const int q = q0 + u;
+                    if ((deadp >> q) & 1ull) continue;
+                    double wk = wq[u]; int tag = i0 - 64 + q;
+                    if ((dynp >> q) & 1ull) {
+                        const int s_ndx = __builtin_amdgcn_readfirstlane(s_fin.ndx[q]);
+                        const int tbnj = __builtin_amdgcn_readfirstlane(s_fin.tbn[q]);
+                        int ov1;
+                        dyn_weight(s_ndx, tbnj, s_flp[q][lane], T, D, wk, ov1);
+                        tag |= ov1 << 28;
+                    }
+                    const double val = s_fin.score[q] + wk;
+                    const bool c = val >= pv;
+                    pv = c ? val : pv; ptx = c ? tag : ptx;
+                }
+            }
+            s_pval[wave][lane] = pv; s_ptbx[wave][lane] = ptx;
         }
         __syncthreads();
         const unsigned long long tq1 = prof ? __builtin_readcyclecounter() : 0;
         if (wave == 0) {
-            Best B{s_eval[slot][lane], s_etb[slot][lane], s_eov[slot][lane], -1};
+            // merge, oldest sources first: the early far field, then the slices in order.  Ascending order makes
+            // the lexicographic test the reference's plain ">=" (ref: _connection.h:135-139).
+            double bv = s_eval[slot][lane];
+            int tbx = s_etb[slot][lane] < 0 ? -1 : (s_etb[slot][lane] | ((s_eov[slot][lane] + 1) << 28));
 #pragma unroll
-            for (int w = 0; w < 4; w++) {
-                const double v = s_lval[w][lane]; const int t = s_ltb[w][lane];
-                if (t != -1 && (v > B.val || (v == B.val && t > B.tb))) { B.val = v; B.tb = t; B.ov = s_lov[w][lane]; }
+            for (int w = 0; w < PGA_MW_WAVES; w++) {
+                const double v = s_pval[w][lane]; const int t = s_ptbx[w][lane];
+                const bool c = t >= 0 && v >= bv;
+                bv = c ? v : bv; tbx = c ? t : tbx;
             }
+            Best B;
+            B.val = bv; B.tb = tbx < 0 ? -1 : (tbx & 0x0fffffff); B.ov = tbx < 0 ? -1 : (tbx >> 28) - 1; B.tbn = -1;
             // lean in-batch walk: the static weight w(k, lane) comes from LDS one chunk (4 steps) ahead; only the
             // recurrence (broadcast value of lane k, add, compare, select) is left on the serial path.
             //   bv    running score of the target lane
@@ -820,16 +887,11 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
             const unsigned long long dynm = __ballot(s_dyn[slot][lane] != 0ull);
             const bool endlane = T.kind == 1 || T.kind == 2;
             unsigned long long dead = __ballot(endlane && B.tb < 0);
-            // ndx of the pre-walk traceb node: in the LDS tile, or found by the early far-field wave
-            const int tbn_pre = B.tb < 0 ? -1 : (B.tb >= i0 - 64 ? s_tile.ndx[B.tb - (i0 - 64)] : s_etbn[slot][lane]);
-            double bv = B.val;
+            // ndx of the pre-walk traceb node: in the previous batch (LDS), or found by the early far-field wave
+            const int tbn_pre = B.tb < 0 ? -1 : (B.tb >= i0 - 64 ? s_fin.ndx[B.tb - (i0 - 64)] : s_etbn[slot][lane]);
             int lk = -1;
             const double* wp = &s_w[slot][0][lane];
-            const short* tp = &s_thr[slot][0][0][lane];
-            // dynamic pairs: candidate values of this target lane and the floor they must beat
-            const bool is_r3 = T.kind == 3;
-            const double cur0 = is_r3 ? T.x0 : T.csd;
-            const double floor0 = is_r3 ? 0.0 : -__builtin_huge_val();
+            const unsigned char* fp = &s_fl[slot][0][lane];
             auto step = [&](const int k, const double w) {
                 if ((dead >> k) & 1ull) return;
                 double wk = w; int tag = k;
@@ -839,17 +901,10 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
                     const int s_ndx = __builtin_amdgcn_readlane(T.ndx, k);
                     const int lkk = __builtin_amdgcn_readlane(lk, k);
                     const int tbnj = lkk >= 0 ? __builtin_amdgcn_readlane(T.ndx, lkk & 63) : __builtin_amdgcn_readlane(tbn_pre, k);
-                    const int rel = max(tbnj - s_ndx, -32767);
-                    const int d0 = tp[k * 192], d1 = tp[k * 192 + 64], d2 = tp[k * 192 + 128];
-                    double mv = floor0; int m = -1;
-                    if ((rel < d0) & (cur0 > mv)) { mv = cur0; m = 0; }
-                    if ((rel < d1) & (T.x1 > mv)) { mv = T.x1; m = 1; }
-                    if ((rel < d2) & (T.x2 > mv)) { mv = T.x2; m = 2; }
-                    wk = m >= 0 ? mv : w;
-                    tag = k | ((is_r3 ? m + 1 : 0) << 8);
+                    int ov1;
+                    dyn_weight(s_ndx, tbnj, fp[k * 64], T, D, wk, ov1);
+                    tag = k | (ov1 << 8);
                 }
-                // Ascending order makes the lexicographic test the reference's plain ">="; a NaN (pair not allowed)
-                // fails it.
                 const double val = readlane_f64(bv, k) + wk;
                 const bool c = val >= bv;
                 bv = c ? val : bv; lk = c ? tag : lk;
@@ -873,22 +928,17 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
                 if (B.tb < 0) { B.tb = -1; B.ov = -1; B.tbn = -1; }
             }
             const unsigned long long tq2 = prof ? __builtin_readcyclecounter() : 0;
-            finalize_batch(T, B, i0, lane, n, P, s_levbase, negc, end_best, end_idx, end_tb, &s_tile);
+            finalize_batch(T, B, i0, lane, n, P, s_levbase, negc, end_best, end_idx, end_tb);
+            s_fin.score[lane] = B.val; s_fin.ndx[lane] = T.ndx; s_fin.tbn[lane] = B.tb != -1 ? B.tbn : -1;
+            const unsigned long long dm = __ballot(endlane && B.tb == -1);
+            if (lane == 0) s_fin.dead = dm;
             if (prof && lane == 0) {
                 const unsigned long long tq3 = __builtin_readcyclecounter();
                 buf.prof[0] += tq1 - tq0; buf.prof[1] += tq2 - tq1; buf.prof[2] += tq3 - tq2; buf.prof[5] += 1;
             }
         } else if (nx < n) {
-            if (wave <= 3) {
-                const int kmax = min(63, n - 1 - nx);
-                for (int k = wave - 1; k < 64; k += 3) {
-                    bool ok = false, dyn = false; double w = 0.0; short d0, d1, d2;
-                    if (k < kmax) static_pair(k, nx, Tn, negc, s_igm, ok, w, dyn, d0, d1, d2);
-                    s_w[pb][k][lane] = ok ? w : QNAN;
-                    const unsigned long long dm = __ballot(dyn);
-                    if (dm) { s_thr[pb][k][0][lane] = dyn ? d0 : PGA_DYN_NEVER; s_thr[pb][k][1][lane] = dyn ? d1 : PGA_DYN_NEVER; s_thr[pb][k][2][lane] = dyn ? d2 : PGA_DYN_NEVER; }
-                    if (lane == 0) s_dyn[pb][k] = dm;
-                }
+            if (wave <= PGA_MW_HELPERS) {
+                helper_weights(T, Tn, nx, pb, true);
                 if (prof && lane == 0 && wave == 1) buf.prof[3] += __builtin_readcyclecounter() - tq1;
             } else {
                 Best B{0.0, -1, -1, -1};
