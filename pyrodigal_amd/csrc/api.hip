@@ -147,7 +147,7 @@ extern "C" int pga_score_connections(pga_ctx* c, int32_t n, const int32_t* ndx, 
     HIP_TRY(c, db.alloc(&buf.A, N)); HIP_TRY(c, db.alloc(&buf.V[0], N)); HIP_TRY(c, db.alloc(&buf.V[1], N)); HIP_TRY(c, db.alloc(&buf.V[2], N));
     HIP_TRY(c, db.alloc(&buf.hv, N)); HIP_TRY(c, db.alloc(&buf.hi, N));
     buf.prof = nullptr;
-    if (getenv("PGA_DP_PROFILE")) { HIP_TRY(c, db.alloc(&buf.prof, 8)); HIP_TRY(c, hipMemsetAsync(buf.prof, 0, 64, c->stream)); }
+    if (getenv("PGA_DP_PROFILE")) { HIP_TRY(c, db.alloc(&buf.prof, 16)); HIP_TRY(c, hipMemsetAsync(buf.prof, 0, 128, c->stream)); }
     HIP_TRY(c, db.alloc(&d_chain, 1)); HIP_TRY(c, db.alloc(&d_mc, 1));
     hipStream_t st = c->stream;
 #define UP(dst, srcp, bytes) HIP_TRY(c, hipMemcpyAsync(dst, srcp, bytes, hipMemcpyHostToDevice, st))
@@ -171,10 +171,12 @@ extern "C" int pga_score_connections(pga_ctx* c, int32_t n, const int32_t* ndx, 
     HIP_TRY(c, hipMemcpyAsync(&mi, buf.max_index, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     if (buf.prof) {
-        unsigned long long pr[8]; HIP_TRY(c, hipMemcpy(pr, buf.prof, 64, hipMemcpyDeviceToHost));
+        unsigned long long pr[16]; HIP_TRY(c, hipMemcpy(pr, buf.prof, 128, hipMemcpyDeviceToHost));
         const double nbp = pr[5] ? (double)pr[5] : 1.0;
-        fprintf(stderr, "[pga dp profile] batches=%llu cycles/batch: serial wave: far=%.0f walk=%.0f finalize=%.0f | helper weights=%.0f helper far=%.0f | iteration=%.0f | dynamic steps/batch=%.1f\n",
-                pr[5], pr[0] / nbp, pr[1] / nbp, pr[2] / nbp, pr[3] / nbp, pr[4] / nbp, pr[6] / nbp, pr[7] / nbp);
+        fprintf(stderr, "[pga dp profile] batches=%llu cycles/batch: serial wave: previous batch=%.0f walk=%.0f publish=%.0f | weight helper=%.0f | "
+                        "far field by target kind=%.0f/%.0f/%.0f/%.0f store=%.0f | iteration=%.0f\n",
+                pr[5], pr[0] / nbp, pr[1] / nbp, pr[2] / nbp, pr[3] / nbp, pr[8] / nbp, pr[9] / nbp, pr[10] / nbp, pr[11] / nbp, pr[12] / nbp, pr[6] / nbp);
+        fprintf(stderr, "[pga dp profile] kind0 far wave: after suffix build=%.0f, far_field done (last batch)=%llu\n", pr[13] / nbp, pr[14]);
     }
     if (max_index) *max_index = mi;
     if (kernel_ms) { float ms = 0; HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1)); *kernel_ms = ms; }

@@ -365,6 +365,49 @@ __device__ __forceinline__ void load_target(Target& T, const ChainPtrs& P, int i
     if (!act) T.i = -1;          // j < T.i is never true: the lane stays idle
 }
 
+// A and its block-of-8 maxima for the most recent PGA_RING nodes of a chain, kept in LDS by the wave that
+// stores the batches.
+#define PGA_RING 1024
+#define PGA_RING_BLOCKS (PGA_RING / 8)
+struct RingLds {
+    double A[PGA_RING];
+    double l1v[PGA_RING_BLOCKS]; int l1i[PGA_RING_BLOCKS];
+};
+// Suffix maxima over the ring's blocks: v/i[e - ebase] = lexicographic (value, index) maximum of A over the
+// blocks [e, eend).  Nearly every far-field range of a batch ends at the batch boundary 8 * eend, so one
+// scan per batch replaces a tree descent per target: a range [p, 8 eend) is its ragged head (ring A) plus
+// one suffix entry.  Built and read by one wave.
+struct SuffixLds { double v[PGA_RING_BLOCKS]; int i[PGA_RING_BLOCKS]; };
+__device__ __forceinline__ void suffix_build(const RingLds* ring, SuffixLds* sfx, const int ebase, const int eend, const int lane) {
+    const double NEG_INF = -__builtin_huge_val();
+    constexpr int PER = PGA_RING_BLOCKS / 64;
+    double sv[PER]; int si[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int e = ebase + PER * lane + u;
+        const bool in = e < eend;
+        sv[u] = in ? ring->l1v[e & (PGA_RING_BLOCKS - 1)] : NEG_INF; si[u] = in ? ring->l1i[e & (PGA_RING_BLOCKS - 1)] : -1;
+    }
+#pragma unroll
+    for (int u = PER - 2; u >= 0; u--)      // inside the lane: a later node wins a tie
+        if (sv[u + 1] >= sv[u]) { sv[u] = sv[u + 1]; si[u] = si[u + 1]; }
+    double tv = sv[0]; int ti = si[0];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {      // inclusive suffix scan over the lanes
+        const double xv = __shfl_down(tv, d, 64); const int xi = __shfl_down(ti, d, 64);
+        if (lane + d < 64 && xv >= tv) { tv = xv; ti = xi; }
+    }
+    double ev = __shfl_down(tv, 1, 64); int ei = __shfl_down(ti, 1, 64);
+    if (lane == 63) { ev = NEG_INF; ei = -1; }
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const bool c = ev >= sv[u];
+        sfx->v[PER * lane + u] = c ? ev : sv[u]; sfx->i[PER * lane + u] = c ? ei : si[u];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // lexicographic maximum of A over [l, r) from the 8-ary tree; the (up to 7 + 7) ragged entries of a
 // level are loaded together so that a level costs one memory round trip.
 __device__ __forceinline__ void tree_range(int l, int r, const ChainPtrs& P, const int* s_levbase, Best& B) {
@@ -395,14 +438,23 @@ __device__ __forceinline__ void tree_range(int l, int r, const ChainPtrs& P, con
 // Everything target T can take from final sources j in [clo, chi): tree + exact near pairs + special
 // ranges.  chi must not exceed the number of final nodes.
 __device__ __forceinline__ void far_field(const Target& T, int clo, int chi, const ChainPtrs& P, const int* s_levbase,
-                                          const double negc, const double* s_igm, Best& B) {
+                                          const double negc, const double* s_igm, Best& B,
+                                          const RingLds* ring = nullptr, const SuffixLds* sfx = nullptr, const int ebase = 0, const int eend = 0) {
     if (T.i < 0) return;
     chi = min(chi, T.i);
     clo = max(clo, T.lo);
     if (clo >= chi) return;
     const GlobalAcc G{P.src, P.score, P.tbn};
     if (T.kind == 0 || T.kind == 3) {
-        tree_range(clo, min(T.p_near, chi), P, s_levbase, B);                                   // (1) far gene ends
+        // (1) far gene ends
+        const int fhi = min(T.p_near, chi);
+        if (sfx != nullptr && fhi == 8 * eend) {
+            int p = clo;
+            if (p < 8 * ebase) { tree_range(p, 8 * ebase, P, s_levbase, B); p = 8 * ebase; }
+            const int e0 = (p + 7) >> 3;
+            for (; p < min(8 * e0, fhi); p++) take(B, true, ring->A[p & (PGA_RING - 1)], p, -1, 0);      // ragged head
+            if (e0 < eend) take(B, true, sfx->v[e0 - ebase], sfx->i[e0 - ebase], -1, 0);
+        } else tree_range(clo, fhi, P, s_levbase, B);
         for (int j = max(T.p_near, clo); j < chi; j++) pair_eval(j, G, T, negc, s_igm, B);   // (2) near: exact pairs
         if (T.kind == 3) {
             // (3) forward stops that can overlap one of this node's overlapping starts (ref: _connection.h:296-325)
@@ -537,7 +589,8 @@ __device__ __forceinline__ void late_field(const Target& T, const TileLds* tile,
 // extend the tree.  Returns nothing; updates the running _find_max_index state.
 __device__ __forceinline__ void finalize_batch(const Target& T, const Best& B, int i0, int lane, int n, const ChainPtrs& P,
                                                const int* s_levbase, const double negc,
-                                               double& end_best, int& end_idx, int& end_tb, TileLds* tile = nullptr) {
+                                               double& end_best, int& end_idx, int& end_tb, TileLds* tile = nullptr,
+                                               RingLds* ring = nullptr) {
     const double NEG_INF = -__builtin_huge_val();
     const bool act = T.i >= 0;
     double a_val = NEG_INF;
@@ -557,6 +610,7 @@ __device__ __forceinline__ void finalize_batch(const Target& T, const Best& B, i
             a_val = B.val + negc;
         }
         P.A[T.i] = a_val; P.V0[T.i] = v0; P.V1[T.i] = v1; P.V2[T.i] = v2;
+        if (ring) ring->A[T.i & (PGA_RING - 1)] = a_val;
         if ((T.kind == 1 || T.kind == 2) && B.val >= end_best) { end_best = B.val; end_idx = T.i; end_tb = B.tb; }
         if (tile) {
             tile->ndx[lane] = T.ndx; tile->stop_val[lane] = T.stop_val; tile->meta[lane] = T.meta; tile->tbn[lane] = alive ? B.tbn : -1;
@@ -575,6 +629,7 @@ __device__ __forceinline__ void finalize_batch(const Target& T, const Best& B, i
     if ((lane & 7) == 0) {
         P.hv[s_levbase[1] + (i0 >> 3) + (lane >> 3)] = rv; P.hi[s_levbase[1] + (i0 >> 3) + (lane >> 3)] = ri;
         if (tile) { tile->l1v[lane >> 3] = rv; tile->l1i[lane >> 3] = ri; }
+        if (ring) { ring->l1v[((i0 >> 3) + (lane >> 3)) & (PGA_RING_BLOCKS - 1)] = rv; ring->l1i[((i0 >> 3) + (lane >> 3)) & (PGA_RING_BLOCKS - 1)] = ri; }
     }
 #pragma unroll
     for (int m = 8; m <= 32; m <<= 1) {
@@ -670,6 +725,35 @@ k_dp_tree(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src,
     publish_max(end_best, end_idx, end_tb, lane, buf);
 }
 
+// Reverse targets against a forward-stop source at s_ndx: every static condition of the dynamic rule is an
+// interval test on s_ndx, precomputed once per batch (candidate q is possible iff lo[q] < s_ndx < hi[q]).
+//   reverse stop, candidate q  (ref: _connection.h:296-325), ovlp = s_ndx + 5 - n3s:
+//       ovlp > 0  <=>  s_ndx > n3s - 5;   ovlp < MAX_OPP_OVLP  <=>  s_ndx < n3s + MAX_OPP_OVLP - 5;
+//       ovlp < n3n - (s_ndx + 2)  <=>  2 s_ndx < n3n + n3s - 7;   left < ndx - 2  <=>  s_ndx < ndx - 4
+//   reverse start, its one candidate  (ref: _connection.h:238-254):
+//       stop_val - 2 < s_ndx + 2;   s_ndx - stop_val + 5 < MAX_OPP_OVLP;   2 s_ndx < ndx + stop_val + 3
+struct RevRegs { int lo0, hi0, lo1, hi1, lo2, hi2, okhi; };
+__device__ __forceinline__ RevRegs rev_regs(const Target& T) {
+    RevRegs R;
+    R.lo0 = R.lo1 = R.lo2 = INT_MAX; R.hi0 = R.hi1 = R.hi2 = INT_MIN; R.okhi = INT_MIN;
+    if (T.kind == 3) {
+        R.okhi = T.ndx - 4;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int n3s = sel3i(q, T.n3s0, T.n3s1, T.n3s2), n3n = sel3i(q, T.n3n0, T.n3n1, T.n3n2);
+            if (PGA_SPVALID(T.meta, q) && sel3(q, T.x0, T.x1, T.x2) > 0.0) {
+                const int lo = n3s - 5;
+                const int hi = min(min(n3s + PGA_MAX_OPP_OVLP - 5, (n3n + n3s - 6) >> 1), R.okhi);
+                if (q == 0) { R.lo0 = lo; R.hi0 = hi; } else if (q == 1) { R.lo1 = lo; R.hi1 = hi; } else { R.lo2 = lo; R.hi2 = hi; }
+            }
+        }
+    } else if (T.kind == 2) {
+        R.lo0 = T.stop_val - 4;
+        R.hi0 = min(T.stop_val + PGA_MAX_OPP_OVLP - 5, (T.ndx + T.stop_val + 4) >> 1);
+    }
+    return R;
+}
+
 // Static part of a pair: source = lane k of batch S (chain index j), target = this lane of batch T.
 // Weight and admissibility that do not depend on the source's running state.  What remains dynamic is
 // a forward-stop source (position s_ndx, its traceb node at tbnj) towards a reverse target: it goes
@@ -678,49 +762,50 @@ k_dp_tree(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src,
 //   reverse start target   one candidate, the overlapping 3' ends rule       (ref: _connection.h:238-254)
 //   reverse stop target    one candidate per overlapping start of the target (ref: _connection.h:296-325)
 // ok/w describe the pair when no candidate is taken (w = NaN-able base weight).
-__device__ __forceinline__ void static_pair(const int k, const int j, const Target& S, const Target& T, const double negc,
-                                            const double* s_igm, bool& ok, double& w, int& flags) {
+// Written with selects only: the source kind is uniform (one scalar branch per row), everything per target
+// lane is branch-free.
+__device__ __forceinline__ double igm_apart_sel(const int d, const double negc, const double* s_igm) {
+    const double tab = s_igm[min(max(d, 0), PGA_OPER_DIST)];
+    const double r = (unsigned)d <= (unsigned)PGA_OPER_DIST ? tab : 0.0;
+    return d > 3 * PGA_OPER_DIST ? negc : r;
+}
+__device__ __forceinline__ void static_pair(const int k, const int j, const Target& S, const Target& T, const RevRegs& R,
+                                            const double negc, const double* s_igm, bool& ok, double& w, int& flags) {
     const int s_meta = __builtin_amdgcn_readlane(S.meta, k);
     const int s_ndx = __builtin_amdgcn_readlane(S.ndx, k);
     const int sk = PGA_KIND(s_meta), sf = PGA_FRAME(s_meta);
-    const bool inwin = (j >= T.lo) && (j < T.i);
-    ok = false; w = 0.0; flags = 0;
+    const bool inwin = (j >= T.lo) & (j < T.i);
+    flags = 0;
     if (sk == 0) {
-        ok = inwin && T.kind == 1 && T.frame == sf && T.stop_val < s_ndx;
+        ok = inwin & (T.kind == 1) & (T.frame == sf) & (T.stop_val < s_ndx);
         w = readlane_f64(S.cs, k);
     } else if (sk == 2) {
-        const bool a = T.kind == 0 && s_ndx < T.ndx;
-        const bool b = T.kind == 3 && s_ndx < T.ndx - 2;
-        ok = inwin && (a || b);
-        w = b ? igm_apart(T.ndx - s_ndx, negc, s_igm) : negc;
+        const bool a = (T.kind == 0) & (s_ndx < T.ndx);
+        const bool b = (T.kind == 3) & (s_ndx < T.ndx - 2);
+        ok = inwin & (a | b);
+        const double g = igm_apart_sel(T.ndx - s_ndx, negc, s_igm);
+        w = b ? g : negc;
     } else if (sk == 3) {
         const int s_stop = __builtin_amdgcn_readlane(S.stop_val, k);
-        const bool a = T.kind == 2 && T.frame == sf && s_stop > T.ndx;
-        const bool b = T.kind == 3 && s_stop > T.ndx && PGA_SPVALID(T.meta, sf);
-        ok = inwin && (a || b);
-        w = a ? T.cs : sel3(sf, T.x0, T.x1, T.x2);
+        const bool a = (T.kind == 2) & (T.frame == sf) & (s_stop > T.ndx);
+        const bool b = (T.kind == 3) & (s_stop > T.ndx) & (PGA_SPVALID(T.meta, sf) != 0);
+        ok = inwin & (a | b);
+        const double tx0 = T.x0, tx1 = T.x1, tx2 = T.x2;
+        const double xs = sel3(sf, tx0, tx1, tx2);      // uniform choice
+        w = a ? T.cs : xs;
     } else {
         const double sx0 = readlane_f64(S.x0, k), sx1 = readlane_f64(S.x1, k), sx2 = readlane_f64(S.x2, k);
-        if (T.kind == 0) { ok = inwin && (s_ndx + 2 < T.ndx); w = igm_apart(T.ndx - s_ndx, negc, s_igm); }
-        else if (T.kind == 1) { ok = inwin && T.stop_val < s_ndx && PGA_SPVALID(s_meta, T.frame); w = sel3(T.frame, sx0, sx1, sx2); }
-        else if (T.kind == 2) {
-            const int ovlp5 = (s_ndx + 2) - (T.stop_val - 2) + 1;
-            const bool st5 = inwin & (T.stop_val - 2 < s_ndx + 2) & (ovlp5 < PGA_MAX_OPP_OVLP) &
-                             ((s_ndx - T.stop_val) < (T.ndx - s_ndx + 3));
-            flags = st5 ? 1 : 0;                // admissible only through its candidate
-        } else {
-            const int left = s_ndx + 2;
-            ok = inwin & (left < T.ndx - 2);
-            w = negc;
-#pragma unroll
-            for (int q = 0; q < 3; q++) {
-                const int n3s = sel3i(q, T.n3s0, T.n3s1, T.n3s2), n3n = sel3i(q, T.n3n0, T.n3n1, T.n3n2);
-                const int ovlp = left - n3s + 3;
-                const bool stq = ok & (PGA_SPVALID(T.meta, q) != 0) & (ovlp > 0) & (ovlp < PGA_MAX_OPP_OVLP) & (ovlp < n3n - left) &
-                                 (sel3(q, T.x0, T.x1, T.x2) > 0.0);
-                flags |= stq ? (1 << q) : 0;
-            }
-        }
+        const double g = igm_apart_sel(T.ndx - s_ndx, negc, s_igm);
+        const double sxf = sel3(T.frame, sx0, sx1, sx2);
+        const bool ok0 = s_ndx + 2 < T.ndx;
+        const bool ok1 = (T.stop_val < s_ndx) & (((s_meta >> (4 + T.frame)) & 1) != 0);
+        const bool ok2 = s_ndx < R.okhi;         // a reverse start is admissible only through its candidate
+        const bool rev = T.kind >= 2;
+        ok = inwin & (T.kind == 0 ? ok0 : (T.kind == 1 ? ok1 : ok2));
+        w = T.kind == 0 ? g : (T.kind == 1 ? sxf : negc);
+        const int f = ((s_ndx > R.lo0) & (s_ndx < R.hi0) ? 1 : 0) | ((s_ndx > R.lo1) & (s_ndx < R.hi1) ? 2 : 0) |
+                      ((s_ndx > R.lo2) & (s_ndx < R.hi2) ? 4 : 0);
+        flags = (inwin & rev) ? f : 0;
     }
 }
 
@@ -752,6 +837,7 @@ __device__ __forceinline__ void dyn_weight(const int s_ndx, const int tbnj, cons
 struct TileFin {
     double score[64];
     int ndx[64], tbn[64];               // tbn: ndx of the node's traceb node, -1 if none
+    int tb[64], ov[64];
     unsigned long long dead;            // gene ends without a traceb: they connect to nothing
 };
 
@@ -764,8 +850,10 @@ struct TileFin {
 //   wave 7      computes the far field of the NEXT batch over every older tile (global memory, tree);
 //   all waves   once a batch is final, each applies a slice of its 64 nodes to the next batch's targets.
 // Two __syncthreads per batch.
-#define PGA_MW_WAVES 8
-#define PGA_MW_HELPERS 6
+#define PGA_MW_WAVES 16
+#define PGA_MW_HELPERS 11
+#define PGA_MW_SLICES 8        // waves that take a slice of the previous batch
+#define PGA_MW_FLUSH (PGA_MW_HELPERS + 1)   // the far-field wave that also stores the finalized batches
 __global__ void __launch_bounds__(64 * PGA_MW_WAVES)
 k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src, const DpTgt* __restrict__ g_tgt,
              const ModelConst* __restrict__ models, DpBuffers buf) {
@@ -777,9 +865,11 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
     __shared__ unsigned long long s_dyn[2][64], s_dynp[64];       // per source: lanes with a dynamic pair
     __shared__ double s_eval[2][64];                  // early far-field result of the next batch
     __shared__ int s_etb[2][64], s_eov[2][64], s_etbn[2][64];
-    __shared__ double s_pval[PGA_MW_WAVES][64];       // partial results over the previous batch, one slice per wave
-    __shared__ int s_ptbx[PGA_MW_WAVES][64];
+    __shared__ double s_pval[PGA_MW_SLICES][64];      // partial results over the previous batch, one slice per wave
+    __shared__ int s_ptbx[PGA_MW_SLICES][64];
     __shared__ TileFin s_fin;
+    __shared__ RingLds s_ring;
+    __shared__ SuffixLds s_sfx[2];                    // one per far-field wave that queries far gene ends
     const ChainDesc cd = chains[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = cd.n;
@@ -792,7 +882,7 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
     double end_best = -1.0; int end_idx = -1, end_tb = -1;
     const int nb = (n + 63) >> 6;
     const bool prof = buf.prof != nullptr && blockIdx.x == 0;
-    constexpr int SLICE = 64 / PGA_MW_WAVES;
+    constexpr int SLICE = 64 / PGA_MW_SLICES;
 
     if (n <= 0) {                                    // empty chain (contig without nodes): nothing to walk
         if (wave == 0) publish_max(end_best, end_idx, end_tb, lane, buf);
@@ -801,17 +891,18 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
     // weights of batch `bn` (targets Tq at chain index iq) in slot `sl`, and of the pairs from batch Tp into it
     auto helper_weights = [&](const Target& Tp, const Target& Tq, const int iq, const int sl, const bool with_prev) {
         const int kmax = min(63, n - 1 - iq);
+        const RevRegs R = rev_regs(Tq);
         for (int r = wave - 1; r < (with_prev ? 128 : 64); r += PGA_MW_HELPERS) {
             bool ok = false; double w = 0.0; int fl = 0;
             if (r < 64) {
-                if (r < kmax) static_pair(r, iq + r, Tq, Tq, negc, s_igm, ok, w, fl);
+                if (r < kmax) static_pair(r, iq + r, Tq, Tq, R, negc, s_igm, ok, w, fl);
                 s_w[sl][r][lane] = ok ? w : QNAN;
                 const unsigned long long dm = __ballot(fl != 0);
                 if (dm) s_fl[sl][r][lane] = (unsigned char)fl;
                 if (lane == 0) s_dyn[sl][r] = dm;
             } else {
                 const int k = r - 64;
-                static_pair(k, iq - 64 + k, Tp, Tq, negc, s_igm, ok, w, fl);
+                static_pair(k, iq - 64 + k, Tp, Tq, R, negc, s_igm, ok, w, fl);
                 s_wp[k][lane] = ok ? w : QNAN;
                 const unsigned long long dm = __ballot(fl != 0);
                 if (dm) s_flp[k][lane] = (unsigned char)fl;
@@ -819,139 +910,212 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
             }
         }
     };
-    // prologue: weights of batch 0; its far field is empty
-    Target Tn;
-    load_target(Tn, P, 0, lane, n, negc);
-    if (wave >= 1 && wave <= PGA_MW_HELPERS) helper_weights(Tn, Tn, 0, 0, false);
-    else if (wave == PGA_MW_WAVES - 1) { s_eval[0][lane] = 0.0; s_etb[0][lane] = -1; s_eov[0][lane] = -1; s_etbn[0][lane] = -1; }
-    __syncthreads();
-
-    for (int b = 0; b < nb; b++) {
-        const int i0 = b << 6, slot = b & 1;
-        const int nx = i0 + 64, pb = slot ^ 1;
-        const unsigned long long tq0 = prof ? __builtin_readcyclecounter() : 0;
-        const Target T = Tn;                                   // this batch; every wave holds the same 64 targets
-        if (nx < n) load_target(Tn, P, nx, lane, n, negc);     // next batch, needed after the barrier
-        const DynRegs D = dyn_regs(T);
-        // ---- the batch finalized last, one slice of its sources per wave (ascending inside the slice)
-        {
-            double pv = 0.0; int ptx = -1;
-            if (i0 > 0) {
-                const unsigned long long deadp = s_fin.dead;
-                const unsigned long long dynp = __ballot(s_dynp[lane] != 0ull);
-                const int q0 = wave * SLICE;
-                double wq[SLICE];
+    // store the batch at chain index ib (final in s_fin) with its far-field candidate values, extend the tree,
+    // track _find_max_index
+    auto flush = [&](const int ib) {
+        Target Tf;
+        Tf.i = ib + lane;
+        const bool act = Tf.i < n;
+        const DpSrc me = P.src[act ? Tf.i : n - 1];
+        Tf.kind = PGA_KIND(me.meta); Tf.frame = PGA_FRAME(me.meta); Tf.meta = me.meta;
+        Tf.cs = me.cs; Tf.x0 = me.x[0]; Tf.x1 = me.x[1]; Tf.x2 = me.x[2];
+        if (!act) Tf.i = -1;
+        const Best Bf{s_fin.score[lane], s_fin.tb[lane], s_fin.ov[lane], s_fin.tbn[lane]};
+        finalize_batch(Tf, Bf, ib, lane, n, P, s_levbase, negc, end_best, end_idx, end_tb, nullptr, &s_ring);
+    };
+    // one slice of the batch finalized last, applied to this batch's targets (ascending inside the slice)
+    auto consume = [&](const Target& T, const DynRegs& D, const int i0) {
+        double pv = 0.0; int ptx = -1;
+        if (i0 > 0) {
+            const unsigned long long deadp = s_fin.dead;
+            const unsigned long long dynp = __ballot(s_dynp[lane] != 0ull);
+            const int q0 = wave * SLICE;
+            double wq[SLICE];
 #pragma unroll
-                for (int u = 0; u < SLICE; u++) wq[u] = s_wp[q0 + u][lane];
+            for (int u = 0; u < SLICE; u++) wq[u] = s_wp[q0 + u][lane];
 #pragma unroll
-                for (int u = 0; u < SLICE; u++) {
-                    const int q = q0 + u;
-                    if ((deadp >> q) & 1ull) continue;
-                    double wk = wq[u]; int tag = i0 - 64 + q;
-                    if ((dynp >> q) & 1ull) {
-                        const int s_ndx = __builtin_amdgcn_readfirstlane(s_fin.ndx[q]);
-                        const int tbnj = __builtin_amdgcn_readfirstlane(s_fin.tbn[q]);
-                        int ov1;
-                        dyn_weight(s_ndx, tbnj, s_flp[q][lane], T, D, wk, ov1);
-                        tag |= ov1 << 28;
-                    }
-                    const double val = s_fin.score[q] + wk;
-                    const bool c = val >= pv;
-                    pv = c ? val : pv; ptx = c ? tag : ptx;
+            for (int u = 0; u < SLICE; u++) {
+                const int q = q0 + u;
+                if ((deadp >> q) & 1ull) continue;
+                double wk = wq[u]; int tag = i0 - 64 + q;
+                if ((dynp >> q) & 1ull) {
+                    const int s_ndx = __builtin_amdgcn_readfirstlane(s_fin.ndx[q]);
+                    const int tbnj = __builtin_amdgcn_readfirstlane(s_fin.tbn[q]);
+                    int ov1;
+                    dyn_weight(s_ndx, tbnj, s_flp[q][lane], T, D, wk, ov1);
+                    tag |= ov1 << 28;
                 }
+                const double val = s_fin.score[q] + wk;
+                const bool c = val >= pv;
+                pv = c ? val : pv; ptx = c ? tag : ptx;
             }
-            s_pval[wave][lane] = pv; s_ptbx[wave][lane] = ptx;
         }
+        s_pval[wave][lane] = pv; s_ptbx[wave][lane] = ptx;
+    };
+
+    // Each role runs its own loop (its own register budget); all of them meet at the same two barriers per batch:
+    //   barrier B  the slices of the previous batch are in LDS, the previous batch is in global memory
+    //   barrier A  this batch is final in s_fin, the next batch's weights and early far field are in LDS
+    if (wave == 0) {
+        // ---------------------------------------------------------------- the serial wave
+        Target T;
+        load_target(T, P, 0, lane, n, negc);
         __syncthreads();
-        const unsigned long long tq1 = prof ? __builtin_readcyclecounter() : 0;
-        if (wave == 0) {
+        for (int b = 0; b < nb; b++) {
+            const int i0 = b << 6, slot = b & 1, nx = i0 + 64;
+            const unsigned long long tq0 = prof ? __builtin_readcyclecounter() : 0;
+            const DynRegs D = dyn_regs(T);
+            consume(T, D, i0);
+            __syncthreads();
+            const unsigned long long tq1 = prof ? __builtin_readcyclecounter() : 0;
             // merge, oldest sources first: the early far field, then the slices in order.  Ascending order makes
             // the lexicographic test the reference's plain ">=" (ref: _connection.h:135-139).
             double bv = s_eval[slot][lane];
             int tbx = s_etb[slot][lane] < 0 ? -1 : (s_etb[slot][lane] | ((s_eov[slot][lane] + 1) << 28));
 #pragma unroll
-            for (int w = 0; w < PGA_MW_WAVES; w++) {
+            for (int w = 0; w < PGA_MW_SLICES; w++) {
                 const double v = s_pval[w][lane]; const int t = s_ptbx[w][lane];
                 const bool c = t >= 0 && v >= bv;
                 bv = c ? v : bv; tbx = c ? t : tbx;
             }
             Best B;
             B.val = bv; B.tb = tbx < 0 ? -1 : (tbx & 0x0fffffff); B.ov = tbx < 0 ? -1 : (tbx >> 28) - 1; B.tbn = -1;
-            // lean in-batch walk: the static weight w(k, lane) comes from LDS one chunk (4 steps) ahead; only the
-            // recurrence (broadcast value of lane k, add, compare, select) is left on the serial path.
-            //   bv    running score of the target lane
-            //   lk    in-batch source taken last (| (ov_mark + 1) << 8), -1 while the pre-walk result stands
-            //   dead  gene ends without a traceb so far: they connect to nothing (ref: impl/generic.h:29-36),
-            //         their step is skipped; a lane leaves the set the first time it takes a source
+            // lean in-batch walk, fully unrolled: the static weight w(k, lane) comes from LDS one chunk (4 steps)
+            // ahead; only the recurrence (broadcast value of lane k, add, compare, select) is left on the serial path.
+            //   bv   running score of the target lane.  A gene end without a traceb connects to nothing
+            //        (ref: impl/generic.h:29-36): while it has none its bv is -inf, so that as a source it loses every
+            //        comparison without a test; what a target has to beat is therefore max(bv, 0)
+            //   lk   in-batch source taken last (| (ov_mark + 1) << 8), -1 while the pre-walk result stands
             // Rows k >= kmax of the weight tile are NaN, so every batch runs the same 64 steps.
             const unsigned long long dynm = __ballot(s_dyn[slot][lane] != 0ull);
             const bool endlane = T.kind == 1 || T.kind == 2;
-            unsigned long long dead = __ballot(endlane && B.tb < 0);
             // ndx of the pre-walk traceb node: in the previous batch (LDS), or found by the early far-field wave
             const int tbn_pre = B.tb < 0 ? -1 : (B.tb >= i0 - 64 ? s_fin.ndx[B.tb - (i0 - 64)] : s_etbn[slot][lane]);
+            if (endlane && B.tb < 0) bv = -__builtin_huge_val();
+            // thr = max(bv, 0); bv is never NaN, so the plain instruction is exact (fmax() would add a canonicalisation)
+            auto floor0 = [](const double v) { double r; asm("v_max_f64 %0, %1, 0" : "=v"(r) : "v"(v)); return r; };
+            double thr = floor0(bv);
             int lk = -1;
             const double* wp = &s_w[slot][0][lane];
             const unsigned char* fp = &s_fl[slot][0][lane];
             auto step = [&](const int k, const double w) {
-                if ((dead >> k) & 1ull) return;
-                double wk = w; int tag = k;
+                double wk = w;
                 if (__builtin_expect((int)((dynm >> k) & 1ull), 0)) {
                     // forward-stop source towards reverse targets: the admission depends on where the source's
                     // own traceb node lies
                     const int s_ndx = __builtin_amdgcn_readlane(T.ndx, k);
                     const int lkk = __builtin_amdgcn_readlane(lk, k);
-                    const int tbnj = lkk >= 0 ? __builtin_amdgcn_readlane(T.ndx, lkk & 63) : __builtin_amdgcn_readlane(tbn_pre, k);
+                    const int tbnj = lkk >= 0 ? __builtin_amdgcn_readlane(T.ndx, lkk) : __builtin_amdgcn_readlane(tbn_pre, k);
                     int ov1;
                     dyn_weight(s_ndx, tbnj, fp[k * 64], T, D, wk, ov1);
-                    tag = k | (ov1 << 8);
                 }
                 const double val = readlane_f64(bv, k) + wk;
-                const bool c = val >= bv;
-                bv = c ? val : bv; lk = c ? tag : lk;
-                dead &= ~__ballot(c);
+                const bool c = val >= thr;
+                bv = c ? val : bv; lk = c ? k : lk;
+                thr = floor0(bv);
             };
             double w0 = wp[0], w1 = wp[64], w2 = wp[128], w3 = wp[192];
-#pragma unroll 1
+#pragma unroll
             for (int k0 = 0; k0 < 64; k0 += 4) {
                 const int kn = k0 + 4 < 64 ? k0 + 4 : 60;
                 const double n0 = wp[kn * 64], n1 = wp[kn * 64 + 64], n2 = wp[kn * 64 + 128], n3 = wp[kn * 64 + 192];
                 step(k0, w0); step(k0 + 1, w1); step(k0 + 2, w2); step(k0 + 3, w3);
                 w0 = n0; w1 = n1; w2 = n2; w3 = n3;
             }
-            B.val = bv;
-            const int ndx_lk = __shfl(T.ndx, lk & 63, 64);     // all lanes take part: a source lane may itself have lk < 0
+            // after the walk (every lane takes part in the shuffles): ndx of the traceb node, and the ov_mark of a
+            // connection taken through a dynamic pair, re-derived from the source's final state
+            const int lkc = lk & 63;
+            const int ndx_lk = __shfl(T.ndx, lkc, 64);
+            const int tbn_fin = lk >= 0 ? ndx_lk : tbn_pre;
+            const int tbn_src = __shfl(tbn_fin, lkc, 64);
             if (lk >= 0) {
-                B.tb = i0 + (lk & 63); B.ov = (lk >> 8) - 1;
-                B.tbn = ndx_lk;
+                B.val = bv; B.tb = i0 + lk; B.ov = -1; B.tbn = ndx_lk;
+                if (D.is_r3 && ((dynm >> lk) & 1ull)) {
+                    double wk = 0.0; int ov1;
+                    dyn_weight(ndx_lk, tbn_src, fp[lk * 64], T, D, wk, ov1);
+                    B.ov = ov1 - 1;
+                }
             } else {
-                B.tbn = tbn_pre;
+                B.tbn = tbn_pre;               // B.val stands: the walk changed nothing for this lane
                 if (B.tb < 0) { B.tb = -1; B.ov = -1; B.tbn = -1; }
             }
             const unsigned long long tq2 = prof ? __builtin_readcyclecounter() : 0;
-            finalize_batch(T, B, i0, lane, n, P, s_levbase, negc, end_best, end_idx, end_tb);
             s_fin.score[lane] = B.val; s_fin.ndx[lane] = T.ndx; s_fin.tbn[lane] = B.tb != -1 ? B.tbn : -1;
+            s_fin.tb[lane] = B.tb; s_fin.ov[lane] = B.ov;
             const unsigned long long dm = __ballot(endlane && B.tb == -1);
             if (lane == 0) s_fin.dead = dm;
+            if (nx < n) load_target(T, P, nx, lane, n, negc);
             if (prof && lane == 0) {
                 const unsigned long long tq3 = __builtin_readcyclecounter();
                 buf.prof[0] += tq1 - tq0; buf.prof[1] += tq2 - tq1; buf.prof[2] += tq3 - tq2; buf.prof[5] += 1;
             }
-        } else if (nx < n) {
-            if (wave <= PGA_MW_HELPERS) {
-                helper_weights(T, Tn, nx, pb, true);
-                if (prof && lane == 0 && wave == 1) buf.prof[3] += __builtin_readcyclecounter() - tq1;
-            } else {
-                Best B{0.0, -1, -1, -1};
-                if (i0 > 0) far_field(Tn, 0, i0, P, s_levbase, negc, s_igm, B);    // every tile finalized before this iteration
-                s_eval[pb][lane] = B.val; s_etb[pb][lane] = B.tb; s_eov[pb][lane] = B.ov;
-                s_etbn[pb][lane] = B.tb >= 0 ? P.src[B.tb].ndx : -1;
-                if (prof && lane == 0) buf.prof[4] += __builtin_readcyclecounter() - tq1;
-            }
+            __syncthreads();
+            if (prof && lane == 0) buf.prof[6] += __builtin_readcyclecounter() - tq0;
         }
+    } else if (wave <= PGA_MW_HELPERS) {
+        // ---------------------------------------------------------------- the weight helpers
+        Target Tq;
+        load_target(Tq, P, 0, lane, n, negc);
+        helper_weights(Tq, Tq, 0, 0, false);
         __syncthreads();
-        if (prof && threadIdx.x == 0) buf.prof[6] += __builtin_readcyclecounter() - tq0;
+        for (int b = 0; b < nb; b++) {
+            const int i0 = b << 6, slot = b & 1, nx = i0 + 64, pb = slot ^ 1;
+            Target Tn;
+            if (nx < n) load_target(Tn, P, nx, lane, n, negc);     // needed after the barrier
+            if (wave < PGA_MW_SLICES) {
+                const DynRegs D = dyn_regs(Tq);
+                consume(Tq, D, i0);
+            }
+            __syncthreads();
+            const unsigned long long tq1 = prof ? __builtin_readcyclecounter() : 0;
+            if (nx < n) {
+                helper_weights(Tq, Tn, nx, pb, true);
+                Tq = Tn;
+                if (prof && lane == 0 && wave == 1) buf.prof[3] += __builtin_readcyclecounter() - tq1;
+            }
+            __syncthreads();
+        }
+    } else {
+        // ---------------------------------------------------------------- the far-field waves, one per target kind
+        const int mykind = wave - (PGA_MW_HELPERS + 1);
+        if (mykind == 0) { s_eval[0][lane] = 0.0; s_etb[0][lane] = -1; s_eov[0][lane] = -1; s_etbn[0][lane] = -1; }
+        __syncthreads();
+        for (int b = 0; b < nb; b++) {
+            const int i0 = b << 6, slot = b & 1, nx = i0 + 64, pb = slot ^ 1;
+            Target Tn;
+            if (nx < n) load_target(Tn, P, nx, lane, n, negc);
+            // the batch finalized last is stored by one of these waves, idle in this phase; the far fields that
+            // read it start after the barrier
+            if (wave == PGA_MW_FLUSH && i0 > 0) {
+                const unsigned long long tf0 = prof ? __builtin_readcyclecounter() : 0;
+                flush(i0 - 64);
+                if (prof && lane == 0) buf.prof[12] += __builtin_readcyclecounter() - tf0;
+            }
+            __syncthreads();
+            const unsigned long long tq1 = prof ? __builtin_readcyclecounter() : 0;
+            if (nx < n) {
+                // a single wave would run the four kinds' paths one after the other
+                // forward starts and reverse stops look for far gene ends: their ranges nearly always end at i0
+                SuffixLds* sfx = mykind == 0 ? &s_sfx[0] : (mykind == 3 ? &s_sfx[1] : nullptr);
+                const int eend = i0 >> 3, ebase = max(0, eend - PGA_RING_BLOCKS);
+                if (sfx != nullptr && i0 > 0) suffix_build(&s_ring, sfx, ebase, eend, lane);
+                if (prof && lane == 0 && mykind == 0) buf.prof[13] += __builtin_readcyclecounter() - tq1;
+                if (Tn.kind == mykind) {
+                    Best B{0.0, -1, -1, -1};
+                    if (i0 > 0) far_field(Tn, 0, i0, P, s_levbase, negc, s_igm, B, &s_ring, sfx, ebase, eend);   // every tile finalized before this iteration
+                    s_eval[pb][lane] = B.val; s_etb[pb][lane] = B.tb; s_eov[pb][lane] = B.ov;
+                    if (prof && mykind == 0) buf.prof[14] = __builtin_readcyclecounter() - tq1;
+                    s_etbn[pb][lane] = B.tb >= 0 ? P.src[B.tb].ndx : -1;
+                }
+                if (prof && lane == 0) buf.prof[8 + mykind] += __builtin_readcyclecounter() - tq1;
+            }
+            __syncthreads();
+        }
+        if (wave == PGA_MW_FLUSH) {
+            flush((nb - 1) << 6);
+            publish_max(end_best, end_idx, end_tb, lane, buf);
+        }
     }
-    if (wave == 0) publish_max(end_best, end_idx, end_tb, lane, buf);
 }
 
 // W wavefronts per chain.  Per 64-target batch:
