@@ -176,7 +176,7 @@ extern "C" int pga_score_connections(pga_ctx* c, int32_t n, const int32_t* ndx, 
         fprintf(stderr, "[pga dp profile] batches=%llu cycles/batch: serial wave: previous batch=%.0f walk=%.0f publish=%.0f | weight helper=%.0f | "
                         "far field by target kind=%.0f/%.0f/%.0f/%.0f store=%.0f | iteration=%.0f\n",
                 pr[5], pr[0] / nbp, pr[1] / nbp, pr[2] / nbp, pr[3] / nbp, pr[8] / nbp, pr[9] / nbp, pr[10] / nbp, pr[11] / nbp, pr[12] / nbp, pr[6] / nbp);
-        fprintf(stderr, "[pga dp profile] kind0 far wave: after suffix build=%.0f, far_field done (last batch)=%llu\n", pr[13] / nbp, pr[14]);
+        fprintf(stderr, "[pga dp profile] kind0 far wave: suffix build=%.0f | previous-batch slice: serial wave=%.0f helper wave=%.0f\n", pr[13] / nbp, pr[14] / nbp, pr[15] / nbp);
     }
     if (max_index) *max_index = mi;
     if (kernel_ms) { float ms = 0; HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1)); *kernel_ms = ms; }

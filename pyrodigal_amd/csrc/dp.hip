@@ -587,16 +587,23 @@ __device__ __forceinline__ void late_field(const Target& T, const TileLds* tile,
 
 // The batch [i0, i0+64) is final in wave registers: store it with its far-field candidate values and
 // extend the tree.  Returns nothing; updates the running _find_max_index state.
+// PART selects what this call stores (the chain kernel deals the parts to different waves):
+//   1  score, traceb, ov_mark, ndx of the traceb node; the running _find_max_index state
+//   2  A (far gene-end candidate value), the LDS ring and the tree above it
+//   4  V0..V2 (candidate values towards forward stops)
+template <int PART = 7>
 __device__ __forceinline__ void finalize_batch(const Target& T, const Best& B, int i0, int lane, int n, const ChainPtrs& P,
                                                const int* s_levbase, const double negc,
-                                               double& end_best, int& end_idx, int& end_tb, TileLds* tile = nullptr,
-                                               RingLds* ring = nullptr) {
+                                               double& end_best, int& end_idx, int& end_tb, RingLds* ring = nullptr) {
     const double NEG_INF = -__builtin_huge_val();
     const bool act = T.i >= 0;
     double a_val = NEG_INF;
     if (act) {
         const bool alive = B.tb != -1;
-        P.score[T.i] = B.val; P.traceb[T.i] = B.tb; P.ovm[T.i] = (int8_t)B.ov; P.tbn[T.i] = alive ? B.tbn : -1;
+        if (PART & 1) {
+            P.score[T.i] = B.val; P.traceb[T.i] = B.tb; P.ovm[T.i] = (int8_t)B.ov; P.tbn[T.i] = alive ? B.tbn : -1;
+            if ((T.kind == 1 || T.kind == 2) && B.val >= end_best) { end_best = B.val; end_idx = T.i; end_tb = B.tb; }
+        }
         double v0 = NEG_INF, v1 = NEG_INF, v2 = NEG_INF;
         if (T.kind == 0) {
             const double g = B.val + T.cs;
@@ -609,16 +616,13 @@ __device__ __forceinline__ void finalize_batch(const Target& T, const Best& B, i
         } else if (T.kind == 2 && alive) {
             a_val = B.val + negc;
         }
-        P.A[T.i] = a_val; P.V0[T.i] = v0; P.V1[T.i] = v1; P.V2[T.i] = v2;
-        if (ring) ring->A[T.i & (PGA_RING - 1)] = a_val;
-        if ((T.kind == 1 || T.kind == 2) && B.val >= end_best) { end_best = B.val; end_idx = T.i; end_tb = B.tb; }
-        if (tile) {
-            tile->ndx[lane] = T.ndx; tile->stop_val[lane] = T.stop_val; tile->meta[lane] = T.meta; tile->tbn[lane] = alive ? B.tbn : -1;
-            tile->score[lane] = B.val; tile->cs[lane] = T.cs; tile->x0[lane] = T.x0; tile->x1[lane] = T.x1; tile->x2[lane] = T.x2;
-            tile->A[lane] = a_val; tile->V0[lane] = v0; tile->V1[lane] = v1; tile->V2[lane] = v2;
+        if (PART & 4) { P.V0[T.i] = v0; P.V1[T.i] = v1; P.V2[T.i] = v2; }
+        if (PART & 2) {
+            P.A[T.i] = a_val;
+            if (ring) ring->A[T.i & (PGA_RING - 1)] = a_val;
         }
     }
-    if (i0 + 64 > n) return;
+    if (!(PART & 2) || i0 + 64 > n) return;
     double rv = a_val; int ri = i0 + lane;
 #pragma unroll
     for (int m = 1; m <= 4; m <<= 1) {
@@ -628,7 +632,6 @@ __device__ __forceinline__ void finalize_batch(const Target& T, const Best& B, i
     const int tile_no = i0 >> 6;
     if ((lane & 7) == 0) {
         P.hv[s_levbase[1] + (i0 >> 3) + (lane >> 3)] = rv; P.hi[s_levbase[1] + (i0 >> 3) + (lane >> 3)] = ri;
-        if (tile) { tile->l1v[lane >> 3] = rv; tile->l1i[lane >> 3] = ri; }
         if (ring) { ring->l1v[((i0 >> 3) + (lane >> 3)) & (PGA_RING_BLOCKS - 1)] = rv; ring->l1i[((i0 >> 3) + (lane >> 3)) & (PGA_RING_BLOCKS - 1)] = ri; }
     }
 #pragma unroll
@@ -636,10 +639,7 @@ __device__ __forceinline__ void finalize_batch(const Target& T, const Best& B, i
         const double ov2 = __shfl_xor(rv, m, 64); const int oi = __shfl_xor(ri, m, 64);
         if (ov2 > rv || (ov2 == rv && oi > ri)) { rv = ov2; ri = oi; }
     }
-    if (lane == 0) {
-        P.hv[s_levbase[2] + tile_no] = rv; P.hi[s_levbase[2] + tile_no] = ri;
-        if (tile) { tile->l2v = rv; tile->l2i = ri; }
-    }
+    if (lane == 0) { P.hv[s_levbase[2] + tile_no] = rv; P.hi[s_levbase[2] + tile_no] = ri; }
     // higher levels: a block of 8 children closes when its last child does
     int child = tile_no, lev = 2;
     while ((child & 7) == 7 && (lev + 1) * 3 < 31 && (n >> (3 * (lev + 1))) > 0) {
@@ -833,11 +833,20 @@ __device__ __forceinline__ void dyn_weight(const int s_ndx, const int tbnj, cons
     ov1 = D.is_r3 ? m + 1 : 0;
 }
 
+// Workgroup barrier that orders LDS traffic only: global loads issued before it (next batch's records) stay in
+// flight across it instead of being waited for, as __syncthreads() would.
+__device__ __forceinline__ void barrier_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // What the other waves need of the batch the serial wave finalized last.
 struct TileFin {
     double score[64];
     int ndx[64], tbn[64];               // tbn: ndx of the node's traceb node, -1 if none
     int tb[64], ov[64];
+    int meta[64]; double cs[64], x0[64], x1[64], x2[64];    // static fields the storing waves need
     unsigned long long dead;            // gene ends without a traceb: they connect to nothing
 };
 
@@ -853,7 +862,6 @@ struct TileFin {
 #define PGA_MW_WAVES 16
 #define PGA_MW_HELPERS 11
 #define PGA_MW_SLICES 8        // waves that take a slice of the previous batch
-#define PGA_MW_FLUSH (PGA_MW_HELPERS + 1)   // the far-field wave that also stores the finalized batches
 __global__ void __launch_bounds__(64 * PGA_MW_WAVES)
 k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src, const DpTgt* __restrict__ g_tgt,
              const ModelConst* __restrict__ models, DpBuffers buf) {
@@ -912,16 +920,16 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
     };
     // store the batch at chain index ib (final in s_fin) with its far-field candidate values, extend the tree,
     // track _find_max_index
-    auto flush = [&](const int ib) {
+    auto flush = [&](const int ib, const int part) {
         Target Tf;
-        Tf.i = ib + lane;
-        const bool act = Tf.i < n;
-        const DpSrc me = P.src[act ? Tf.i : n - 1];
-        Tf.kind = PGA_KIND(me.meta); Tf.frame = PGA_FRAME(me.meta); Tf.meta = me.meta;
-        Tf.cs = me.cs; Tf.x0 = me.x[0]; Tf.x1 = me.x[1]; Tf.x2 = me.x[2];
-        if (!act) Tf.i = -1;
+        Tf.i = ib + lane < n ? ib + lane : -1;
+        const int meta = s_fin.meta[lane];
+        Tf.kind = PGA_KIND(meta); Tf.frame = PGA_FRAME(meta); Tf.meta = meta;
+        Tf.cs = s_fin.cs[lane]; Tf.x0 = s_fin.x0[lane]; Tf.x1 = s_fin.x1[lane]; Tf.x2 = s_fin.x2[lane];
         const Best Bf{s_fin.score[lane], s_fin.tb[lane], s_fin.ov[lane], s_fin.tbn[lane]};
-        finalize_batch(Tf, Bf, ib, lane, n, P, s_levbase, negc, end_best, end_idx, end_tb, nullptr, &s_ring);
+        if (part == 0) finalize_batch<1>(Tf, Bf, ib, lane, n, P, s_levbase, negc, end_best, end_idx, end_tb);
+        else if (part == 1) finalize_batch<2>(Tf, Bf, ib, lane, n, P, s_levbase, negc, end_best, end_idx, end_tb, &s_ring);
+        else if (part == 2) finalize_batch<4>(Tf, Bf, ib, lane, n, P, s_levbase, negc, end_best, end_idx, end_tb);
     };
     // one slice of the batch finalized last, applied to this batch's targets (ascending inside the slice)
     auto consume = [&](const Target& T, const DynRegs& D, const int i0) {
@@ -958,6 +966,7 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
     //   barrier A  this batch is final in s_fin, the next batch's weights and early far field are in LDS
     if (wave == 0) {
         // ---------------------------------------------------------------- the serial wave
+        __builtin_amdgcn_s_setprio(3);           // it shares its SIMD with three helper waves: issue it first
         Target T;
         load_target(T, P, 0, lane, n, negc);
         __syncthreads();
@@ -966,7 +975,10 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
             const unsigned long long tq0 = prof ? __builtin_readcyclecounter() : 0;
             const DynRegs D = dyn_regs(T);
             consume(T, D, i0);
-            __syncthreads();
+            if (prof && lane == 0) buf.prof[14] += __builtin_readcyclecounter() - tq0;
+            barrier_lds();
+            Target Tnext;
+            if (nx < n) load_target(Tnext, P, nx, lane, n, negc);      // in flight during the walk
             const unsigned long long tq1 = prof ? __builtin_readcyclecounter() : 0;
             // merge, oldest sources first: the early far field, then the slices in order.  Ascending order makes
             // the lexicographic test the reference's plain ">=" (ref: _connection.h:135-139).
@@ -1042,14 +1054,15 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
             const unsigned long long tq2 = prof ? __builtin_readcyclecounter() : 0;
             s_fin.score[lane] = B.val; s_fin.ndx[lane] = T.ndx; s_fin.tbn[lane] = B.tb != -1 ? B.tbn : -1;
             s_fin.tb[lane] = B.tb; s_fin.ov[lane] = B.ov;
+            s_fin.meta[lane] = T.meta; s_fin.cs[lane] = T.cs; s_fin.x0[lane] = T.x0; s_fin.x1[lane] = T.x1; s_fin.x2[lane] = T.x2;
             const unsigned long long dm = __ballot(endlane && B.tb == -1);
             if (lane == 0) s_fin.dead = dm;
-            if (nx < n) load_target(T, P, nx, lane, n, negc);
+            if (nx < n) T = Tnext;
             if (prof && lane == 0) {
                 const unsigned long long tq3 = __builtin_readcyclecounter();
                 buf.prof[0] += tq1 - tq0; buf.prof[1] += tq2 - tq1; buf.prof[2] += tq3 - tq2; buf.prof[5] += 1;
             }
-            __syncthreads();
+            barrier_lds();
             if (prof && lane == 0) buf.prof[6] += __builtin_readcyclecounter() - tq0;
         }
     } else if (wave <= PGA_MW_HELPERS) {
@@ -1062,18 +1075,20 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
             const int i0 = b << 6, slot = b & 1, nx = i0 + 64, pb = slot ^ 1;
             Target Tn;
             if (nx < n) load_target(Tn, P, nx, lane, n, negc);     // needed after the barrier
+            const unsigned long long th0 = prof ? __builtin_readcyclecounter() : 0;
             if (wave < PGA_MW_SLICES) {
                 const DynRegs D = dyn_regs(Tq);
                 consume(Tq, D, i0);
             }
-            __syncthreads();
+            if (prof && lane == 0 && wave == 1) buf.prof[15] += __builtin_readcyclecounter() - th0;
+            barrier_lds();
             const unsigned long long tq1 = prof ? __builtin_readcyclecounter() : 0;
             if (nx < n) {
                 helper_weights(Tq, Tn, nx, pb, true);
                 Tq = Tn;
                 if (prof && lane == 0 && wave == 1) buf.prof[3] += __builtin_readcyclecounter() - tq1;
             }
-            __syncthreads();
+            barrier_lds();
         }
     } else {
         // ---------------------------------------------------------------- the far-field waves, one per target kind
@@ -1082,18 +1097,18 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
         __syncthreads();
         for (int b = 0; b < nb; b++) {
             const int i0 = b << 6, slot = b & 1, nx = i0 + 64, pb = slot ^ 1;
-            Target Tn;
-            if (nx < n) load_target(Tn, P, nx, lane, n, negc);
-            // the batch finalized last is stored by one of these waves, idle in this phase; the far fields that
-            // read it start after the barrier
-            if (wave == PGA_MW_FLUSH && i0 > 0) {
+            // the batch finalized last is stored by these waves, idle in this phase (a part each); the far fields
+            // that read it start after the barrier
+            if (i0 > 0) {
                 const unsigned long long tf0 = prof ? __builtin_readcyclecounter() : 0;
-                flush(i0 - 64);
-                if (prof && lane == 0) buf.prof[12] += __builtin_readcyclecounter() - tf0;
+                flush(i0 - 64, mykind);
+                if (prof && lane == 0 && mykind == 1) buf.prof[12] += __builtin_readcyclecounter() - tf0;
             }
             __syncthreads();
             const unsigned long long tq1 = prof ? __builtin_readcyclecounter() : 0;
             if (nx < n) {
+                Target Tn;
+                load_target(Tn, P, nx, lane, n, negc);      // in flight during the suffix scan
                 // a single wave would run the four kinds' paths one after the other
                 // forward starts and reverse stops look for far gene ends: their ranges nearly always end at i0
                 SuffixLds* sfx = mykind == 0 ? &s_sfx[0] : (mykind == 3 ? &s_sfx[1] : nullptr);
@@ -1104,17 +1119,14 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
                     Best B{0.0, -1, -1, -1};
                     if (i0 > 0) far_field(Tn, 0, i0, P, s_levbase, negc, s_igm, B, &s_ring, sfx, ebase, eend);   // every tile finalized before this iteration
                     s_eval[pb][lane] = B.val; s_etb[pb][lane] = B.tb; s_eov[pb][lane] = B.ov;
-                    if (prof && mykind == 0) buf.prof[14] = __builtin_readcyclecounter() - tq1;
                     s_etbn[pb][lane] = B.tb >= 0 ? P.src[B.tb].ndx : -1;
                 }
                 if (prof && lane == 0) buf.prof[8 + mykind] += __builtin_readcyclecounter() - tq1;
             }
-            __syncthreads();
+            barrier_lds();
         }
-        if (wave == PGA_MW_FLUSH) {
-            flush((nb - 1) << 6);
-            publish_max(end_best, end_idx, end_tb, lane, buf);
-        }
+        flush((nb - 1) << 6, mykind);
+        if (mykind == 0) publish_max(end_best, end_idx, end_tb, lane, buf);
     }
 }
 
