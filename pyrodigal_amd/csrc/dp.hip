@@ -231,8 +231,7 @@ __device__ __forceinline__ void visit_source(const int k, const int j, const Src
 
 // Per-lane (non-uniform) evaluation of one (source j, target) pair: same arithmetic as visit_source,
 // every field loaded by the lane itself.  Used for the few pairs that need the exact pairwise term.
-// Source fields of final nodes, read from global memory (GlobalAcc) or from the LDS copy of the last
-// finalized tile (TileAcc).
+// Source fields of final nodes, read from global memory.
 struct GlobalAcc {
     const DpSrc* __restrict__ src; const double* score; const int* tbn;
     __device__ __forceinline__ int meta(int j) const { return src[j].meta; }
@@ -243,23 +242,6 @@ struct GlobalAcc {
     __device__ __forceinline__ double sc(int j) const { return score[j]; }
     __device__ __forceinline__ int tb_ndx(int j) const { return tbn[j]; }
 };
-struct TileLds {     // the most recently finalized 64 nodes of a chain, kept in LDS by the serial wave
-    int ndx[64], stop_val[64], meta[64], tbn[64];
-    double score[64], cs[64], x0[64], x1[64], x2[64], A[64], V0[64], V1[64], V2[64];
-    double l1v[8]; int l1i[8];       // lexicographic maxima of A over the 8 blocks of 8
-    double l2v; int l2i;             // ... and over the whole tile
-};
-struct TileAcc {
-    const TileLds* t; int base;
-    __device__ __forceinline__ int meta(int j) const { return t->meta[j - base]; }
-    __device__ __forceinline__ int ndx(int j) const { return t->ndx[j - base]; }
-    __device__ __forceinline__ int stop_val(int j) const { return t->stop_val[j - base]; }
-    __device__ __forceinline__ double cs(int j) const { return t->cs[j - base]; }
-    __device__ __forceinline__ double x(int j, int f) const { const int q = j - base; return f == 0 ? t->x0[q] : (f == 1 ? t->x1[q] : t->x2[q]); }
-    __device__ __forceinline__ double sc(int j) const { return t->score[j - base]; }
-    __device__ __forceinline__ int tb_ndx(int j) const { return t->tbn[j - base]; }
-};
-
 template <class Acc>
 __device__ __forceinline__ void pair_eval(const int j, const Acc& S, const Target& T, const double negc, const double* s_igm, Best& B) {
     const int s_meta = S.meta(j), s_ndx = S.ndx(j);
@@ -487,111 +469,14 @@ __device__ __forceinline__ void far_field(const Target& T, int clo, int chi, con
     }
 }
 
-// Forward-stop source (position s_ndx, ndx of its traceb node tbnj) against a reverse target: the only
-// in-batch pairs whose admissibility depends on the source's running state.  Written with selects so
-// that the lanes do not diverge.  Returns the weight, sets ok / mf.   (ref: _connection.h:238-254, 288-336)
-__device__ __forceinline__ double f3_to_reverse(const int s_ndx, const int tbnj, const Target& T, const bool inwin,
-                                                const double negc, bool& ok, int& mf) {
-    // reverse start target: overlapping opposite 3' ends
-    const int ovlp5 = (s_ndx + 2) - (T.stop_val - 2) + 1;
-    const bool ok5 = (T.stop_val - 2 < s_ndx + 2) & (ovlp5 < PGA_MAX_OPP_OVLP) & ((s_ndx - T.stop_val) < (T.ndx - s_ndx + 3)) &
-                     ((s_ndx - T.stop_val) < (T.stop_val - 3 - tbnj));
-    // reverse stop target: possibly through one of its overlapping starts
-    const int left = s_ndx + 2;
-    double maxval = 0.0; int m = -1;
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-        const int n3s = sel3i(q, T.n3s0, T.n3s1, T.n3s2), n3n = sel3i(q, T.n3n0, T.n3n1, T.n3n2);
-        const double cur = sel3(q, T.x0, T.x1, T.x2);
-        const int ovlp = left - n3s + 3;
-        const bool tk = (PGA_SPVALID(T.meta, q) != 0) & (ovlp > 0) & (ovlp < PGA_MAX_OPP_OVLP) & (ovlp < n3n - left) &
-                        (ovlp < n3s - tbnj - 2) & (cur > maxval);
-        maxval = tk ? cur : maxval; m = tk ? q : m;
-    }
-    const bool is3 = T.kind == 3;
-    ok = inwin & (is3 ? (left < T.ndx - 2) : ok5);
-    mf = is3 ? m : -1;
-    return is3 ? (m != -1 ? maxval : negc) : T.csd;
-}
-
-// far_field for the one tile [base, base + 64) that the serial wave keeps in LDS (the tile it finalized
-// last).  The sources are dealt round-robin to `mod` waves (this call handles j % mod == rem); the partial
-// results are merged with the lexicographic maximum.  `tree` selects who takes the block maxima.
-__device__ __forceinline__ int first_at_or_after(int lo, int rem, int mod) { return lo + ((rem - lo) % mod + mod) % mod; }
-
-__device__ __forceinline__ void late_field(const Target& T, const TileLds* tile, const int base, const double negc,
-                                           const double* s_igm, Best& B, const int rem = 0, const int mod = 1, const bool tree = true) {
-    if (T.i < 0) return;
-    const int chi = min(base + 64, T.i);
-    const int clo = max(base, T.lo);
-    if (clo >= chi) return;
-    const TileAcc S{tile, base};
-    if (T.kind == 0 || T.kind == 3) {
-        const int fr = min(T.p_near, chi);
-        if (tree) {
-            if (clo == base && fr == base + 64) take(B, true, tile->l2v, tile->l2i, -1, 0);
-            else if (clo < fr) {
-                const int l = clo - base, r = fr - base;
-                const int l_end = min(r, (l + 7) & ~7), r_beg = max(l_end, r & ~7);
-                for (int q = l; q < l_end; q++) take(B, true, tile->A[q], base + q, -1, 0);
-                for (int q = r_beg; q < r; q++) take(B, true, tile->A[q], base + q, -1, 0);
-                for (int q = l_end >> 3; q < (r_beg >> 3); q++) take(B, true, tile->l1v[q], tile->l1i[q], -1, 0);
-            }
-        }
-        for (int j = first_at_or_after(max(T.p_near, clo), rem, mod); j < chi; j += mod) {
-            // only alive gene ends (A != -inf) connect to a gene begin; a reverse start towards a forward start
-            // is worth exactly A (ref: _connection.h:125-130)
-            const int q = j - base;
-            const double aj = tile->A[q];
-            if (aj == -__builtin_huge_val()) continue;
-            const int s_ndx = tile->ndx[q];
-            const bool s_rev = PGA_KIND(tile->meta[q]) == 2;
-            if (T.kind == 0) {
-                if (s_rev) take(B, true, aj, j, -1, 0);
-                else take(B, s_ndx + 2 < T.ndx, tile->score[q] + igm_apart(T.ndx - s_ndx, negc, s_igm), j, -1, 0);
-            } else if (s_rev) {
-                take(B, s_ndx < T.ndx - 2, tile->score[q] + igm_apart(T.ndx - s_ndx, negc, s_igm), j, -1, 0);
-            } else {
-                bool okd; int mf;
-                const double wd = f3_to_reverse(s_ndx, tile->tbn[q], T, true, negc, okd, mf);
-                take(B, okd, tile->score[q] + wd, j, mf, 0);
-            }
-        }
-        if (T.kind == 3) {
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                if (!PGA_SPVALID(T.meta, k)) continue;
-                const int zb = min(sel3i(k, T.b0, T.b1, T.b2), chi);
-                for (int j = first_at_or_after(max(sel3i(k, T.a0, T.a1, T.a2), clo), rem, mod); j < zb; j += mod)
-                    if (PGA_KIND(S.meta(j)) == 1) pair_eval(j, S, T, negc, s_igm, B);
-            }
-#pragma unroll
-            for (int f = 0; f < 3; f++) {
-                const int j = sel3i(f, T.c0, T.c1, T.c2);
-                if (j >= clo && j < chi && (j % mod) == rem) pair_eval(j, S, T, negc, s_igm, B);
-            }
-        }
-    } else if (T.kind == 1) {
-        for (int j = first_at_or_after(max(T.a0, clo), rem, mod); j < chi; j += mod) {
-            const int q = j - base;
-            const double v = T.frame == 0 ? tile->V0[q] : (T.frame == 1 ? tile->V1[q] : tile->V2[q]);
-            take(B, true, v, j, -1, 0);
-        }
-    } else {
-        if (T.a0 >= clo && T.a0 < chi && (T.a0 % mod) == rem) pair_eval(T.a0, S, T, negc, s_igm, B);
-        const int zb = min(T.a2, chi);
-        for (int j = first_at_or_after(max(T.a1, clo), rem, mod); j < zb; j += mod)
-            if (PGA_KIND(S.meta(j)) == 1) pair_eval(j, S, T, negc, s_igm, B);
-    }
-}
-
 // The batch [i0, i0+64) is final in wave registers: store it with its far-field candidate values and
 // extend the tree.  Returns nothing; updates the running _find_max_index state.
 // PART selects what this call stores (the chain kernel deals the parts to different waves):
 //   1  score, traceb, ov_mark, ndx of the traceb node; the running _find_max_index state
-//   2  A (far gene-end candidate value), the LDS ring and the tree above it
+//   2  A (far gene-end candidate value), also into the LDS ring
 //   4  V0..V2 (candidate values towards forward stops)
-template <int PART = 7>
+//   8  the tree above A
+template <int PART = 15>
 __device__ __forceinline__ void finalize_batch(const Target& T, const Best& B, int i0, int lane, int n, const ChainPtrs& P,
                                                const int* s_levbase, const double negc,
                                                double& end_best, int& end_idx, int& end_tb, RingLds* ring = nullptr) {
@@ -622,7 +507,7 @@ __device__ __forceinline__ void finalize_batch(const Target& T, const Best& B, i
             if (ring) ring->A[T.i & (PGA_RING - 1)] = a_val;
         }
     }
-    if (!(PART & 2) || i0 + 64 > n) return;
+    if (!(PART & 8) || i0 + 64 > n) return;
     double rv = a_val; int ri = i0 + lane;
 #pragma unroll
     for (int m = 1; m <= 4; m <<= 1) {
@@ -803,8 +688,8 @@ __device__ __forceinline__ void static_pair(const int k, const int j, const Targ
         const bool rev = T.kind >= 2;
         ok = inwin & (T.kind == 0 ? ok0 : (T.kind == 1 ? ok1 : ok2));
         w = T.kind == 0 ? g : (T.kind == 1 ? sxf : negc);
-        const int f = ((s_ndx > R.lo0) & (s_ndx < R.hi0) ? 1 : 0) | ((s_ndx > R.lo1) & (s_ndx < R.hi1) ? 2 : 0) |
-                      ((s_ndx > R.lo2) & (s_ndx < R.hi2) ? 4 : 0);
+        const int f = (((s_ndx > R.lo0) & (s_ndx < R.hi0)) ? 1 : 0) | (((s_ndx > R.lo1) & (s_ndx < R.hi1)) ? 2 : 0) |
+                      (((s_ndx > R.lo2) & (s_ndx < R.hi2)) ? 4 : 0);
         flags = (inwin & rev) ? f : 0;
     }
 }
@@ -850,15 +735,18 @@ struct TileFin {
     unsigned long long dead;            // gene ends without a traceb: they connect to nothing
 };
 
-// Eight wavefronts per chain, for the latency-bound case of few long chains.  Every pair inside the
-// last 128 nodes is reduced to "score[j] + w(j, i)" with w precomputed off the critical path:
-//   wave 0      the serial wave: merges the partial results, walks the batch (lane k is final once the
-//               walk reaches source i0+k), stores it and extends the tree;
-//   waves 1-6   precompute, for the NEXT batch, the weights of its in-batch pairs and of the pairs
-//               from this batch into it (no dependence on scores);
-//   wave 7      computes the far field of the NEXT batch over every older tile (global memory, tree);
-//   all waves   once a batch is final, each applies a slice of its 64 nodes to the next batch's targets.
-// Two __syncthreads per batch.
+// Sixteen wavefronts per chain, for the latency-bound case of few long chains.  Every pair inside the
+// last 128 nodes is reduced to "score[j] + w(j, i)" with w precomputed off the critical path; each role
+// runs its own loop and all of them meet at two workgroup barriers per 64-node batch:
+//   wave 0        the serial wave: merges the partial results, walks the batch (lane k is final once the
+//                 walk reaches source i0+k) and leaves it in LDS;
+//   waves 1-11    precompute, for the NEXT batch, the weights of its in-batch pairs and of the pairs
+//                 from this batch into it (no dependence on scores);
+//   waves 12-15   one per target kind: far field of the NEXT batch over everything older than this
+//                 batch (block suffix maxima for far gene ends, exact pairs and V arrays from global
+//                 memory); before that, while the others wait for nothing else, they store the batch
+//                 the serial wave finalized last and extend the tree, one part each;
+//   waves 0-7     once a batch is final, each applies a slice of its 64 nodes to the next batch's targets.
 #define PGA_MW_WAVES 16
 #define PGA_MW_HELPERS 11
 #define PGA_MW_SLICES 8        // waves that take a slice of the previous batch
@@ -928,8 +816,9 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
         Tf.cs = s_fin.cs[lane]; Tf.x0 = s_fin.x0[lane]; Tf.x1 = s_fin.x1[lane]; Tf.x2 = s_fin.x2[lane];
         const Best Bf{s_fin.score[lane], s_fin.tb[lane], s_fin.ov[lane], s_fin.tbn[lane]};
         if (part == 0) finalize_batch<1>(Tf, Bf, ib, lane, n, P, s_levbase, negc, end_best, end_idx, end_tb);
-        else if (part == 1) finalize_batch<2>(Tf, Bf, ib, lane, n, P, s_levbase, negc, end_best, end_idx, end_tb, &s_ring);
+        else if (part == 1) finalize_batch<8>(Tf, Bf, ib, lane, n, P, s_levbase, negc, end_best, end_idx, end_tb, &s_ring);
         else if (part == 2) finalize_batch<4>(Tf, Bf, ib, lane, n, P, s_levbase, negc, end_best, end_idx, end_tb);
+        else finalize_batch<2>(Tf, Bf, ib, lane, n, P, s_levbase, negc, end_best, end_idx, end_tb, &s_ring);
     };
     // one slice of the batch finalized last, applied to this batch's targets (ascending inside the slice)
     auto consume = [&](const Target& T, const DynRegs& D, const int i0) {
