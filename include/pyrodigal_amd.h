@@ -148,6 +148,16 @@ int  pga_batch_create(pga_ctx*, int32_t n_contigs, const char* const* seqs, cons
 void pga_batch_free(pga_batch*);
 int  pga_find_genes(pga_ctx*, const pga_batch*, const pga_params*, pga_result** out);
 
+/* ---- stage level --------------------------------------------------------- */
+/* The node arrays as the reference's Nodes methods leave them, one pga_nodes per contig of the batch
+ * (pga_result.nodes; no genes).  Later stages include the earlier ones and use model 0 of the context;
+ * `params.meta` then selects the is_meta behaviour of Nodes.score, `translation_table` is only read
+ * by PGA_STAGE_EXTRACT. */
+#define PGA_STAGE_EXTRACT 1   /* Nodes.extract() + Nodes.sort()             (ref: lib.pyx:2501-2541, 2489-2493) */
+#define PGA_STAGE_SCORE   2   /* + Nodes.reset_scores() + Nodes.score()     (ref: lib.pyx:2543-2595)            */
+#define PGA_STAGE_OVERLAP 3   /* + _record_overlapping_starts(flag = 1)      (ref: lib.pyx:2279-2329, 5302)      */
+int pga_nodes_stage(pga_ctx*, const pga_batch*, const pga_params*, int stage, int translation_table, pga_result** out);
+
 #ifdef __cplusplus
 }
 #endif

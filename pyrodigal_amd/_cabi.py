@@ -17,8 +17,9 @@ TRAINING_SIZE = 558392
 EXPORTS = [
     "pga_create", "pga_destroy", "pga_last_error", "pga_device_info", "pga_set_models",
     "pga_score_connections", "pga_find_genes_batch", "pga_result_free",
-    "pga_batch_create", "pga_batch_free", "pga_find_genes",
+    "pga_batch_create", "pga_batch_free", "pga_find_genes", "pga_nodes_stage",
 ]
+STAGE_EXTRACT, STAGE_SCORE, STAGE_OVERLAP = 1, 2, 3
 
 
 class Params(ctypes.Structure):
@@ -97,6 +98,8 @@ def load():
     L.pga_batch_create.argtypes = [vp, i32, _P(ctypes.c_char_p), _P(i64), _P(vp)]
     L.pga_batch_free.restype = None; L.pga_batch_free.argtypes = [vp]
     L.pga_find_genes.restype = ctypes.c_int; L.pga_find_genes.argtypes = [vp, vp, _P(Params), _P(_P(Result))]
+    L.pga_nodes_stage.restype = ctypes.c_int
+    L.pga_nodes_stage.argtypes = [vp, vp, _P(Params), ctypes.c_int, ctypes.c_int, _P(_P(Result))]
     _lib = L
     return L
 
@@ -277,6 +280,25 @@ def _find_genes_batch(self, seqs, **kw):
         b.close()
 
 
+def _nodes_stage(self, seqs, stage, translation_table=11, closed=False, min_gene=90, min_edge_gene=60, max_overlap=60,
+                 is_meta=False):
+    """Node arrays after ``Nodes.extract`` (stage 1), ``Nodes.score`` (2) or overlapping starts (3), one dict per contig.
+
+    Stages 2 and 3 score with model 0 of the context (``set_models`` first)."""
+    b = seqs if isinstance(seqs, Batch) else Batch(self, seqs)
+    try:
+        p = Params(int(closed), min_gene, min_edge_gene, max_overlap, int(is_meta), 1)
+        res = _P(Result)()
+        rc = self.L.pga_nodes_stage(self.h, b.h, ctypes.byref(p), int(stage), int(translation_table), ctypes.byref(res))
+        if rc != PGA_OK:
+            _raise(self.L, self.h, rc, "pga_nodes_stage")
+        return _unpack_result(self.L, res, True).nodes
+    finally:
+        if b is not seqs:
+            b.close()
+
+
 Context.upload = _upload
+Context.nodes_stage = _nodes_stage
 Context.find_genes = _find_genes
 Context.find_genes_batch = _find_genes_batch

@@ -324,6 +324,26 @@ struct ResultOwner {
     ~ResultOwner() { for (void* b : blocks) free(b); }
 };
 
+// one zeroed block per contig for the SoA node arrays of a result
+int alloc_nodes(ResultOwner* R, pga_nodes& N, const int n) {
+    memset(&N, 0, sizeof N);
+    N.n = n;
+    const size_t bytes = (size_t)n * (4 * 8 + 10 + 4 + 8 * 7) + 8 * 32;   // 8 int32, 10 bytes, 1 float, 7 doubles per node + padding
+    char* blk = (char*)calloc(1, bytes);
+    if (!blk) return PGA_ENOMEM;
+    R->blocks.push_back(blk);
+    char* q = blk;
+    auto take = [&](size_t b) { char* r = q; q += (b + 7) & ~(size_t)7; return (void*)r; };
+    N.ndx = (int32_t*)take(4 * n); N.stop_val = (int32_t*)take(4 * n); N.traceb = (int32_t*)take(4 * n); N.tracef = (int32_t*)take(4 * n);
+    N.star_ptr = (int32_t*)take(12 * n); N.mot_ndx = (int32_t*)take(4 * n);
+    N.type = (uint8_t*)take(n); N.edge = (uint8_t*)take(n); N.elim = (uint8_t*)take(n); N.rbs = (uint8_t*)take(2 * n);
+    N.strand = (int8_t*)take(n); N.ov_mark = (int8_t*)take(n); N.mot_len = (uint8_t*)take(n); N.mot_spacer = (uint8_t*)take(n); N.mot_spacendx = (uint8_t*)take(n);
+    N.gc_cont = (float*)take(4 * n);
+    N.cscore = (double*)take(8 * n); N.sscore = (double*)take(8 * n); N.rscore = (double*)take(8 * n); N.uscore = (double*)take(8 * n);
+    N.tscore = (double*)take(8 * n); N.score = (double*)take(8 * n); N.mot_score = (double*)take(8 * n);
+    return PGA_OK;
+}
+
 void fill_model_score_const(ModelScoreConst* m, const pga_training* t) {   // ref: lib.pyx:2136-2147, 2209-2210
     double no_stop;
     if (t->trans_table != 11) {
@@ -456,7 +476,9 @@ extern "C" void pga_result_free(pga_result* r) {
     if (r) delete reinterpret_cast<ResultOwner*>(r);
 }
 
-extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_params* pp, pga_result** out) {
+// stage 0 = the whole path; PGA_STAGE_* = stop after that stage and return the node arrays (single chain per
+// contig scored with model 0; P.meta then only selects the meta-mode start penalties of Nodes.score)
+static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, const int stage, const int tt_override, pga_result** out) {
     if (out) *out = nullptr;
     if (!c || !out || !pp || !batch || batch->ctx != c) {
         if (c) c->err = "pga_find_genes: bad arguments";
@@ -464,8 +486,9 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
     }
     const int32_t n_contigs = batch->n;
     if (!c->finder) { int rc0 = pga_finder_models_changed(c); if (rc0) return rc0; }
+    const bool meta_run = pp->meta && stage == 0;
     // meta mode over an empty bin collection is legal and finds nothing (ref: tests/test_gene_finder.py:316-324)
-    if (c->n_models <= 0 && !pp->meta) { c->err = "pga_find_genes: no model loaded (call pga_set_models first)"; return PGA_EINVAL; }
+    if (c->n_models <= 0 && !meta_run && stage != PGA_STAGE_EXTRACT) { c->err = "pga_find_genes: no model loaded (call pga_set_models first)"; return PGA_EINVAL; }
     const pga_params P = *pp;
     if (P.min_gene <= 0 || P.min_edge_gene <= 0 || P.max_overlap < 0 || P.max_overlap > P.min_gene) {
         c->err = "pga_find_genes: invalid min_gene / min_edge_gene / max_overlap";   // ref: lib.pyx:5169-5181
@@ -474,7 +497,7 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
     HT(c, hipSetDevice(c->device));
     FinderState* f = c->finder;
     hipStream_t st = c->stream;
-    const int NC = n_contigs, NM = c->n_models, NG = P.meta ? (int)f->group_tt.size() : 1;
+    const int NC = n_contigs, NM = c->n_models, NG = meta_run ? (int)f->group_tt.size() : 1;
 
     ResultOwner* R = new (std::nothrow) ResultOwner();
     if (!R) return PGA_ENOMEM;
@@ -517,7 +540,7 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
         HT(c, hipMemsetAsync(d_cnt, 0, sizeof(int32_t) * 2 * (size_t)NC, st));
         pga_launch_digitize(d_seq, d_dig, total, d_ct, NC, d_cnt, d_cnt + NC, st);
         for (int g = 0; g < NG; g++) {
-            const int tt = P.meta ? f->group_tt[g] : c->models[0].trans_table;
+            const int tt = meta_run ? f->group_tt[g] : (stage == PGA_STAGE_EXTRACT ? tt_override : c->models[0].trans_table);
             HT(c, hipMemsetAsync(ga[g].nf_fwd, 0, (size_t)total + 1, st));
             HT(c, hipMemsetAsync(ga[g].nf_rev, 0, (size_t)total + 1, st));
             pga_launch_extract(d_dig, total, d_ct, NC, tt, P, ga[g], d_tile, d_pre_gc, g == 0, batch->d_tiles, batch->n_tiles, d_tile_first, d_tile_last, st);
@@ -535,7 +558,7 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
             const int L = ct[i].len;
             const double gc = L > 0 ? (double)h_cnt[i] / (double)L : 0.0;
             R->contigs[i].gc = gc;
-            if (!P.meta) {
+            if (!meta_run) {
                 const int32_t* cb = h_cbase;
                 ChainDesc ch{0, cb[i], cb[i + 1] - cb[i], 0, i, 1};
                 gch[0].push_back(ch);
@@ -567,7 +590,7 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
         R->pub.n_chains = NCH;
         // space for the fresh re-scores of winners that were not `first` (at most one per contig)
         int64_t max_rescore = 0;
-        if (P.meta) for (int g = 0; g < NG; g++) max_rescore += h_cbase[(size_t)g * (NC + 1) + NC];   // loose bound: every node once per group
+        if (meta_run) for (int g = 0; g < NG; g++) max_rescore += h_cbase[(size_t)g * (NC + 1) + NC];   // loose bound: every node once per group
         const int64_t chain_cap = tot_chain_nodes + max_rescore + 64;
 
         // ---- topology + chain buffers ----------------------------------------------------------
@@ -607,7 +630,7 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
         PINBUF(h_cc, int2, "h_cc", (size_t)2 * NG * NC + 1);
         for (size_t k = 0; k < (size_t)2 * NG * NC; k++) h_cc[k] = make_int2(0, 0);
         for (int k = 0; k < NCH; k++) {
-            const int g = P.meta ? f->model_group[chains[k].model] : 0;
+            const int g = meta_run ? f->model_group[chains[k].model] : 0;
             int2& e = h_cc[(size_t)g * NC + chains[k].contig];
             if (e.y == 0) e.x = k;
             e.y++;
@@ -622,11 +645,63 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
             pga_launch_orf_gc(d_ct, NC, d_pre_gc, ga[g], (int)group_nodes[g], d_cbase + (size_t)g * (NC + 1), st);
             const int nch = g_c0[g + 1] - g_c0[g];
             const int64_t nn = g_n0[g + 1] - g_n0[g];
-            if (nch == 0 || nn == 0) continue;
+            if (nch == 0 || nn == 0 || stage == PGA_STAGE_EXTRACT) continue;
             pga_launch_score(d_chains + g_c0[g], nch, g_n0[g], nn, d_dig, d_ct, ga[g], d_models, f->d_msc, c->d_model_const, ca, sp,
                              d_chains, d_cc + (size_t)g * NC, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], st);
             NodeArrays na{ga[g].ndx, ga[g].stop_val, ga[g].type, ga[g].strand, ca.cscore, ca.sscore, ca.rscore, ca.uscore, ca.star_ptr};
-            pga_launch_dp_prepare(d_chains + g_c0[g], nch, g_n0[g], nn, na, c->d_model_const, dp, st);
+            if (stage == 0) pga_launch_dp_prepare(d_chains + g_c0[g], nch, g_n0[g], nn, na, c->d_model_const, dp, st);
+        }
+        if (stage != 0) {
+            // ---- stage-level call: bring the node arrays home as they are now and stop ---------------
+            const int64_t nn = group_nodes[0];
+            PINBUF(hs_i32, int32_t, "hs_i32", 6 * nn + 8);         // ndx, stop_val, mot_ndx, star_ptr[3]
+            PINBUF(hs_f64, double, "hs_f64", 6 * nn + 8);          // cscore, sscore, rscore, uscore, tscore, mot_score
+            PINBUF(hs_u8, uint8_t, "hs_u8", 10 * nn + 8);          // type, strand, edge, rbs[2], mot_len, mot_spacer, mot_spacendx
+            PINBUF(hs_f32, float, "hs_f32", nn + 8);
+            const bool scored = stage >= PGA_STAGE_SCORE;
+            if (nn > 0) {
+                HT(c, hipMemcpyAsync(hs_i32, ga[0].ndx, 4 * nn, hipMemcpyDeviceToHost, st));
+                HT(c, hipMemcpyAsync(hs_i32 + nn, ga[0].stop_val, 4 * nn, hipMemcpyDeviceToHost, st));
+                HT(c, hipMemcpyAsync(hs_u8, ga[0].type, nn, hipMemcpyDeviceToHost, st));
+                HT(c, hipMemcpyAsync(hs_u8 + nn, ga[0].strand, nn, hipMemcpyDeviceToHost, st));
+                HT(c, hipMemcpyAsync(hs_u8 + 2 * nn, scored ? ca.edge : ga[0].edge0, nn, hipMemcpyDeviceToHost, st));
+                if (scored) {
+                    HT(c, hipMemcpyAsync(hs_i32 + 2 * nn, ca.mot_ndx, 4 * nn, hipMemcpyDeviceToHost, st));
+                    HT(c, hipMemcpyAsync(hs_i32 + 3 * nn, ca.star_ptr, 12 * nn, hipMemcpyDeviceToHost, st));
+                    double* const src64[6] = {ca.cscore, ca.sscore, ca.rscore, ca.uscore, ca.tscore, ca.mot_score};
+                    for (int q = 0; q < 6; q++) HT(c, hipMemcpyAsync(hs_f64 + q * nn, src64[q], 8 * nn, hipMemcpyDeviceToHost, st));
+                    HT(c, hipMemcpyAsync(hs_u8 + 3 * nn, ca.rbs, 2 * nn, hipMemcpyDeviceToHost, st));
+                    HT(c, hipMemcpyAsync(hs_u8 + 5 * nn, ca.mot_len, nn, hipMemcpyDeviceToHost, st));
+                    HT(c, hipMemcpyAsync(hs_u8 + 6 * nn, ca.mot_spacer, nn, hipMemcpyDeviceToHost, st));
+                    HT(c, hipMemcpyAsync(hs_u8 + 7 * nn, ca.mot_spacendx, nn, hipMemcpyDeviceToHost, st));
+                    HT(c, hipMemcpyAsync(hs_f32, ga[0].gc_cont, 4 * nn, hipMemcpyDeviceToHost, st));
+                }
+            }
+            HT(c, hipGetLastError());
+            HT(c, hipStreamSynchronize(st));
+            R->nodes.resize(NC);
+            for (int i = 0; i < NC; i++) {
+                pga_nodes& N = R->nodes[i];
+                const int64_t oo = h_cbase[i]; const int n = h_cbase[i + 1] - h_cbase[i];
+                R->contigs[i].model = stage == PGA_STAGE_EXTRACT ? -1 : 0; R->contigs[i].n_nodes = n;
+                if (int rc = alloc_nodes(R, N, n)) return rc;
+                memcpy(N.ndx, hs_i32 + oo, 4 * (size_t)n); memcpy(N.stop_val, hs_i32 + nn + oo, 4 * (size_t)n);
+                memcpy(N.type, hs_u8 + oo, n); memcpy(N.strand, hs_u8 + nn + oo, n); memcpy(N.edge, hs_u8 + 2 * nn + oo, n);
+                for (int j = 0; j < n; j++) { N.traceb[j] = -1; N.tracef[j] = -1; N.ov_mark[j] = -1; }    // ref: reset_node_scores
+                if (!scored) continue;
+                memcpy(N.mot_ndx, hs_i32 + 2 * nn + oo, 4 * (size_t)n);
+                if (stage >= PGA_STAGE_OVERLAP) memcpy(N.star_ptr, hs_i32 + 3 * nn + 3 * oo, 12 * (size_t)n);
+                double* const dst64[6] = {N.cscore, N.sscore, N.rscore, N.uscore, N.tscore, N.mot_score};
+                for (int q = 0; q < 6; q++) memcpy(dst64[q], hs_f64 + q * nn + oo, 8 * (size_t)n);
+                memcpy(N.rbs, hs_u8 + 3 * nn + 2 * oo, 2 * (size_t)n); memcpy(N.mot_len, hs_u8 + 5 * nn + oo, n);
+                memcpy(N.mot_spacer, hs_u8 + 6 * nn + oo, n); memcpy(N.mot_spacendx, hs_u8 + 7 * nn + oo, n);
+                memcpy(N.gc_cont, hs_f32 + oo, 4 * (size_t)n);
+            }
+            R->pub.contigs = R->contigs.data();
+            R->pub.nodes = R->nodes.data();
+            guard.r = nullptr;
+            *out = &R->pub;
+            return PGA_OK;
         }
         // one DP launch over the chains of every group: chains are independent, the more in flight the better
         HT(c, hipEventRecord(f->e_dp0[0], st));
@@ -857,20 +932,7 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
                 if (k < 0) continue;
                 const int n = chains[k].n; const int64_t oo = out_off[i];
                 const bool single = !P.meta;
-                N.n = n;
-                const size_t bytes = (size_t)n * (4 * 8 + 10 + 4 + 8 * 7) + 8 * 32;   // 8 int32, 10 bytes, 1 float, 7 doubles per node + padding
-                char* blk = (char*)calloc(1, bytes);
-                if (!blk) return PGA_ENOMEM;
-                R->blocks.push_back(blk);
-                char* q = blk;
-                auto take = [&](size_t b) { char* r = q; q += (b + 7) & ~(size_t)7; return (void*)r; };
-                N.ndx = (int32_t*)take(4 * n); N.stop_val = (int32_t*)take(4 * n); N.traceb = (int32_t*)take(4 * n); N.tracef = (int32_t*)take(4 * n);
-                N.star_ptr = (int32_t*)take(12 * n); N.mot_ndx = (int32_t*)take(4 * n);
-                N.type = (uint8_t*)take(n); N.edge = (uint8_t*)take(n); N.elim = (uint8_t*)take(n); N.rbs = (uint8_t*)take(2 * n);
-                N.strand = (int8_t*)take(n); N.ov_mark = (int8_t*)take(n); N.mot_len = (uint8_t*)take(n); N.mot_spacer = (uint8_t*)take(n); N.mot_spacendx = (uint8_t*)take(n);
-                N.gc_cont = (float*)take(4 * n);
-                N.cscore = (double*)take(8 * n); N.sscore = (double*)take(8 * n); N.rscore = (double*)take(8 * n); N.uscore = (double*)take(8 * n);
-                N.tscore = (double*)take(8 * n); N.score = (double*)take(8 * n); N.mot_score = (double*)take(8 * n);
+                if (int rc = alloc_nodes(R, N, n)) return rc;
                 memcpy(N.ndx, h.ndx + oo, 4 * n); memcpy(N.stop_val, h.stop_val + oo, 4 * n); memcpy(N.type, h.type + oo, n); memcpy(N.strand, h.strand + oo, n);
                 memcpy(N.gc_cont, h.gc_cont + oo, 4 * n); memcpy(N.rbs, h.rbs + 2 * oo, 2 * n); memcpy(N.mot_ndx, h.mot_ndx + oo, 4 * n);
                 memcpy(N.mot_len, h.mot_len + oo, n); memcpy(N.mot_spacer, h.mot_spacer + oo, n); memcpy(N.mot_spacendx, h.mot_spacendx + oo, n);
@@ -896,4 +958,17 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
     guard.r = nullptr;
     *out = &R->pub;
     return PGA_OK;
+}
+
+extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_params* pp, pga_result** out) {
+    return find_impl(c, batch, pp, 0, 0, out);
+}
+
+extern "C" int pga_nodes_stage(pga_ctx* c, const pga_batch* batch, const pga_params* pp, int stage, int translation_table, pga_result** out) {
+    if (stage < PGA_STAGE_EXTRACT || stage > PGA_STAGE_OVERLAP) {
+        if (out) *out = nullptr;
+        if (c) c->err = "pga_nodes_stage: unknown stage";
+        return PGA_EINVAL;
+    }
+    return find_impl(c, batch, pp, stage, translation_table, out);
 }

@@ -6,6 +6,10 @@ Same names, arguments, defaults, validation and error types as the reference
 per-base / per-node computation happens in `libpyrodigal_amd.so` on an MI355X.  There is no
 CPU path: without the library or a gfx950 device, calls raise `RuntimeError`.
 
+`Nodes.extract / sort / reset_scores / score` and `ConnectionScorer` are the stage-level calls of the
+reference (lib.pyx:2501-2595, 1315-1357) over `pga_nodes_stage` / `pga_score_connections`; the scorer
+works on whole node arrays, not node by node (SURVEY 8b: per-node granularity is useless for a GPU).
+
 Not provided this round (raise `NotImplementedError`): `GeneFinder.train`, `mask=True`,
 `Gene.translate` and the GFF / GenBank / FASTA writers.
 """
@@ -101,6 +105,14 @@ cdef extern from "pyrodigal_amd.h" nogil:
     int pga_find_genes_batch(pga_ctx*, int32_t n, const char* const* seqs, const int64_t* lens,
                              const pga_params*, pga_result** out)
     void pga_result_free(pga_result*)
+    int pga_batch_create(pga_ctx*, int32_t n, const char* const* seqs, const int64_t* lens, pga_batch** out)
+    void pga_batch_free(pga_batch*)
+    int PGA_STAGE_EXTRACT, PGA_STAGE_SCORE, PGA_STAGE_OVERLAP
+    int pga_nodes_stage(pga_ctx*, const pga_batch*, const pga_params*, int stage, int translation_table, pga_result** out)
+    int pga_score_connections(pga_ctx*, int32_t n, const int32_t* ndx, const int32_t* stop_val, const uint8_t* type,
+                              const int8_t* strand, const double* cscore, const double* sscore, const double* rscore,
+                              const double* uscore, const int32_t* star_ptr, double st_wt, int final,
+                              double* score, int32_t* traceb, int8_t* ov_mark, int32_t* max_index, double* kernel_ms)
 
 # --- constants (ref: lib.pyx:166-228) ------------------------------------------------------
 MIN_SINGLE_GENOME = 20000
@@ -319,12 +331,54 @@ cdef class Node:
         return _NODE_TYPE[3 if self.owner._f["edge"][self.i] else int(self.owner._f["type"][self.i])] if self.owner._f["type"][self.i] != 3 else "Stop"
 
 
+cdef class _StageContext:
+    """One lazily created device context for the stage-level calls (`Nodes.*`, `ConnectionScorer`)."""
+    cdef pga_ctx* ctx
+    cdef object lock
+    cdef object loaded        # the TrainingInfo blob currently loaded as model 0
+
+    def __cinit__(self):
+        self.ctx = NULL
+        self.lock = threading.Lock()
+        self.loaded = None
+
+    def __dealloc__(self):
+        if self.ctx != NULL:
+            pga_destroy(self.ctx)
+            self.ctx = NULL
+
+    cdef int ensure(self) except -1:
+        cdef int rc
+        if self.ctx == NULL:
+            rc = pga_create(0, &self.ctx)
+            if rc != PGA_OK:
+                self.ctx = NULL
+                _raise_for(NULL, rc, "pga_create")
+        return 0
+
+    cdef int load(self, TrainingInfo tinf) except -1:
+        cdef const pga_training* ptr
+        cdef int rc
+        if self.loaded is tinf.raw:
+            return 0
+        ptr = <const pga_training*> <size_t> tinf.raw.ctypes.data
+        rc = pga_set_models(self.ctx, &ptr, 1)
+        if rc != PGA_OK:
+            _raise_for(self.ctx, rc, "pga_set_models")
+        self.loaded = tinf.raw
+        return 0
+
+cdef _StageContext _STAGE = _StageContext()
+
+
 cdef class Nodes:
-    """The nodes of one sequence for its final model, as struct-of-arrays (ref: lib.pyx:1652-1795)."""
+    """The nodes of one sequence as struct-of-arrays (ref: lib.pyx:1652-1795, 2501-2595)."""
     cdef readonly dict _f
+    cdef dict _extract_kw      # the arguments of the last extract(), which score() has to repeat
 
     def __init__(self):
         self._f = {}
+        self._extract_kw = None
 
     def __len__(self):
         return len(self._f["ndx"]) if "ndx" in self._f else 0
@@ -343,6 +397,151 @@ cdef class Nodes:
     def array(self, str name):
         """The numpy array of one field (ndx, stop_val, type, strand, edge, cscore, sscore, ...)."""
         return self._f[name]
+
+    def copy(self):
+        """A deep copy (ref: lib.pyx:2514-2526)."""
+        cdef Nodes out = Nodes()
+        out._f = {k: v.copy() for k, v in self._f.items()}
+        out._extract_kw = None if self._extract_kw is None else dict(self._extract_kw)
+        return out
+
+    def clear(self):
+        """Remove all nodes (ref: lib.pyx:2501-2512)."""
+        self._f = {}
+        self._extract_kw = None
+
+    cdef object _run_stage(self, Sequence seq, int stage, TrainingInfo tinf, bint is_meta):
+        cdef pga_params p
+        cdef pga_batch* batch = NULL
+        cdef pga_result* res = NULL
+        cdef const char* ptr = PyBytes_AS_STRING(seq.data)
+        cdef int64_t length = len(seq.data)
+        cdef int rc, tt
+        kw = self._extract_kw
+        p.closed = kw["closed"]; p.min_gene = kw["min_gene"]; p.min_edge_gene = kw["min_edge_gene"]
+        p.max_overlap = 60; p.meta = is_meta; p.want_nodes = 1
+        tt = kw["translation_table"]
+        with _STAGE.lock:
+            _STAGE.ensure()
+            if tinf is not None:
+                _STAGE.load(tinf)
+            rc = pga_batch_create(_STAGE.ctx, 1, &ptr, &length, &batch)
+            if rc != PGA_OK:
+                _raise_for(_STAGE.ctx, rc, "pga_batch_create")
+            try:
+                with nogil:
+                    rc = pga_nodes_stage(_STAGE.ctx, batch, &p, stage, tt, &res)
+                if rc != PGA_OK:
+                    _raise_for(_STAGE.ctx, rc, "pga_nodes_stage")
+                try:
+                    return _copy_nodes(&res.nodes[0])
+                finally:
+                    pga_result_free(res)
+            finally:
+                pga_batch_free(batch)
+
+    def extract(self, Sequence sequence not None, *, bint closed=False, int min_gene=90, int min_edge_gene=60,
+                int translation_table=11):
+        """Extract the nodes of `sequence`, in sorted order (ref: lib.pyx:2528-2560); returns how many were added."""
+        if translation_table not in TRANSLATION_TABLES:
+            raise ValueError("%d is not a valid translation table index" % translation_table)
+        self._extract_kw = dict(closed=closed, min_gene=min_gene, min_edge_gene=min_edge_gene, translation_table=translation_table)
+        cdef Nodes got = self._run_stage(sequence, PGA_STAGE_EXTRACT, None, False)
+        self._f = got._f
+        return len(self)
+
+    def sort(self):
+        """Sort by position then strand (ref: lib.pyx:2575-2580): the device extraction already emits that order."""
+        return None
+
+    def reset_scores(self):
+        """Reset every score and DP field (ref: lib.pyx:2562-2573)."""
+        cdef ssize_t n = len(self)
+        for k in ("cscore", "sscore", "rscore", "uscore", "tscore", "score", "mot_score"):
+            self._f[k] = np.zeros(n, np.float64)
+        self._f["star_ptr"] = np.zeros((n, 3), np.int32)
+        self._f["rbs"] = np.zeros((n, 2), np.uint8)
+        for k in ("traceb", "tracef"):
+            self._f[k] = np.full(n, -1, np.int32)
+        self._f["ov_mark"] = np.full(n, -1, np.int8)
+        self._f["elim"] = np.zeros(n, np.uint8)
+        self._f["mot_ndx"] = np.zeros(n, np.int32)
+        for k in ("mot_len", "mot_spacer", "mot_spacendx"):
+            self._f[k] = np.zeros(n, np.uint8)
+
+    def score(self, Sequence sequence not None, TrainingInfo training_info not None, *, bint closed=False, bint is_meta=False):
+        """Score the start nodes with `training_info` (ref: lib.pyx:2582-2595).
+
+        The device scores the nodes it extracts itself, so `sequence` and the extraction options must be
+        the ones `extract` was called with (the reference has the same precondition)."""
+        if self._extract_kw is None:
+            raise RuntimeError("Nodes.score needs nodes from Nodes.extract")
+        if self._extract_kw["translation_table"] != training_info.translation_table:
+            raise ValueError("nodes were extracted with translation table %d, the training info uses %d"
+                             % (self._extract_kw["translation_table"], training_info.translation_table))
+        if self._extract_kw["closed"] != closed:
+            raise ValueError("`closed` differs from the value used by Nodes.extract")
+        cdef Nodes got = self._run_stage(sequence, PGA_STAGE_SCORE, training_info, is_meta)
+        if len(got) != len(self) or not np.array_equal(got._f["ndx"], self._f["ndx"]):
+            raise ValueError("sequence does not match the nodes held by this object")
+        keep = {k: self._f[k] for k in ("traceb", "tracef", "ov_mark", "score", "elim", "star_ptr") if k in self._f}
+        self._f = got._f
+        self._f.update(keep)
+
+
+cdef class ConnectionScorer:
+    """Connection scoring of a whole sorted node list on the device (ref: lib.pyx:1297-1435).
+
+    The reference scores one node at a time (`compute_skippable(min, i)` + `score_connections(nodes, min,
+    i, tinf, final)`); a GPU needs the whole array, so `score_connections(nodes, tinf, final=True)` runs the
+    complete dynamic-programming pass with the reference's window rule and writes `score`, `traceb` and
+    `ov_mark` of every node.  `index` and `compute_skippable` are kept so that call sites read the same."""
+    cdef readonly str backend
+    cdef Nodes _indexed
+
+    def __init__(self, str backend="detect"):
+        if backend not in ("detect", "hip"):
+            raise ValueError("unsupported backend %r: this build only has the HIP (gfx950) backend" % backend)
+        self.backend = "hip"
+        self._indexed = None
+
+    def index(self, Nodes nodes not None):
+        self._indexed = nodes
+
+    def compute_skippable(self, int min, int i):
+        return None     # the skip conditions (impl/generic.h:29-36) are folded into the device scorer
+
+    def score_connections(self, Nodes nodes not None, TrainingInfo training_info not None, bint final=False):
+        cdef ssize_t n = len(nodes)
+        cdef int rc
+        cdef int32_t mi = -1
+        if not final:
+            raise NotImplementedError("the training pass (final=False) is not available on the HIP path")
+        f = nodes._f
+        if "cscore" not in f:
+            nodes.reset_scores()
+        cdef object ndx = np.ascontiguousarray(f["ndx"], np.int32), stop_val = np.ascontiguousarray(f["stop_val"], np.int32)
+        cdef object typ = np.ascontiguousarray(f["type"], np.uint8), strand = np.ascontiguousarray(f["strand"], np.int8)
+        cdef object cs = np.ascontiguousarray(f["cscore"], np.float64), ss = np.ascontiguousarray(f["sscore"], np.float64)
+        cdef object rs = np.ascontiguousarray(f["rscore"], np.float64), us = np.ascontiguousarray(f["uscore"], np.float64)
+        cdef object sp = np.ascontiguousarray(f["star_ptr"], np.int32)
+        cdef object score = np.zeros(n, np.float64), traceb = np.full(n, -1, np.int32), ov = np.full(n, -1, np.int8)
+        cdef size_t p_ndx = ndx.ctypes.data, p_stop = stop_val.ctypes.data, p_typ = typ.ctypes.data, p_strand = strand.ctypes.data
+        cdef size_t p_cs = cs.ctypes.data, p_ss = ss.ctypes.data, p_rs = rs.ctypes.data, p_us = us.ctypes.data, p_sp = sp.ctypes.data
+        cdef size_t p_score = score.ctypes.data, p_tb = traceb.ctypes.data, p_ov = ov.ctypes.data
+        cdef double st_wt = training_info.start_weight
+        with _STAGE.lock:
+            _STAGE.ensure()
+            with nogil:
+                rc = pga_score_connections(_STAGE.ctx, <int32_t> n, <const int32_t*> p_ndx, <const int32_t*> p_stop,
+                                           <const uint8_t*> p_typ, <const int8_t*> p_strand, <const double*> p_cs,
+                                           <const double*> p_ss, <const double*> p_rs, <const double*> p_us,
+                                           <const int32_t*> p_sp, st_wt, 1, <double*> p_score, <int32_t*> p_tb,
+                                           <int8_t*> p_ov, &mi, NULL)
+            if rc != PGA_OK:
+                _raise_for(_STAGE.ctx, rc, "pga_score_connections")
+        f["score"] = score; f["traceb"] = traceb; f["ov_mark"] = ov
+        return int(mi)
 
 
 cdef double _confidence(double score, double st_wt) noexcept nogil:   # Prodigal gene.c calculate_confidence
@@ -700,4 +899,7 @@ cdef Nodes _copy_nodes(const pga_nodes* nd):
     f["cscore"] = _arr(nd.cscore, 8 * n, np.float64); f["sscore"] = _arr(nd.sscore, 8 * n, np.float64)
     f["rscore"] = _arr(nd.rscore, 8 * n, np.float64); f["uscore"] = _arr(nd.uscore, 8 * n, np.float64)
     f["tscore"] = _arr(nd.tscore, 8 * n, np.float64); f["score"] = _arr(nd.score, 8 * n, np.float64)
+    f["mot_score"] = _arr(nd.mot_score, 8 * n, np.float64); f["mot_ndx"] = _arr(nd.mot_ndx, 4 * n, np.int32)
+    f["mot_len"] = _arr(nd.mot_len, n, np.uint8); f["mot_spacer"] = _arr(nd.mot_spacer, n, np.uint8)
+    f["mot_spacendx"] = _arr(nd.mot_spacendx, n, np.uint8)
     return out

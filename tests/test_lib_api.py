@@ -109,3 +109,52 @@ def test_find_genes_meta_custom_bins_and_results_outlive_finder(lib):
         assert genes.score == 0.0                       # reference quirk: DP fields are reset after the final re-score
     empty = lib.GeneFinder(meta=True, metagenomic_bins=lib.MetagenomicBins([])).find_genes("ATG" * 500)
     assert len(empty) == 0 and empty.metagenomic_bin is None
+
+
+def test_stage_level_classes_validate_like_the_reference(lib):
+    with pytest.raises(ValueError):
+        lib.ConnectionScorer(backend="sse")             # ref: lib.pyx:1418-1435 (unsupported backend)
+    assert lib.ConnectionScorer().backend == "hip"
+    nodes = lib.Nodes()
+    assert len(nodes) == 0 and nodes.sort() is None
+    with pytest.raises(ValueError):
+        nodes.extract(lib.Sequence("ATG" * 40), translation_table=7)
+    with pytest.raises(RuntimeError):
+        nodes.score(lib.Sequence("ATG" * 40), lib.TrainingInfo.load(golden_path("SRR492066.training.bin.gz")))
+
+
+@pytest.mark.gpu
+def test_nodes_extract_score_and_connection_scorer(lib):
+    """ref: tests/test_nodes.py:28-40 (node counts), tests/test_connection_scorer.py (scorer driven by hand)."""
+    from oracle import oracle as orc
+    text = read_fasta("SRR492066.fna.gz")[0][1]
+    seq = lib.Sequence(text)
+    t = lib.TrainingInfo.load(golden_path("SRR492066.training.bin.gz"))
+    nodes = lib.Nodes()
+    assert nodes.extract(seq, translation_table=11) == 2293
+    nodes.sort(); nodes.reset_scores()
+    nodes.score(seq, t, is_meta=True)
+    o = orc.Oracle(text)
+    ot = orc.Training.load(golden_path("SRR492066.training.bin.gz"))
+    o.extract(11, orc.Params()); o.sort(); o.reset_scores(); o.score_nodes(ot, False, True)
+    on = o.nodes()
+    for k in ("cscore", "sscore", "rscore", "uscore", "tscore"):
+        assert np.array_equal(nodes.array(k).view(np.uint64), on[k].view(np.uint64)), k
+    assert np.array_equal(nodes.array("rbs"), on["rbs"]) and np.array_equal(nodes.array("edge"), on["edge"])
+    # whole-array connection scoring of those nodes (star_ptr still zero, as after reset_scores)
+    scorer = lib.ConnectionScorer(backend="hip")
+    scorer.index(nodes)
+    scorer.compute_skippable(0, 500)
+    best = scorer.score_connections(nodes, t, final=True)
+    o.dprog_raw(ot, True)
+    on = o.nodes()
+    assert np.array_equal(nodes.array("traceb"), on["traceb"])
+    assert np.array_equal(nodes.array("score").view(np.uint64), on["score"].view(np.uint64))
+    assert best == o.find_max_index()
+    with pytest.raises(NotImplementedError):
+        scorer.score_connections(nodes, t, final=False)
+    other = nodes.copy()
+    other.clear()
+    assert len(other) == 0 and len(nodes) == 2293
+    with pytest.raises(ValueError):
+        nodes.score(lib.Sequence(text[:5000]), t)       # not the sequence the nodes came from

@@ -1,0 +1,92 @@
+"""Stage-level C-ABI (pga_nodes_stage) against the oracle's restatement of Nodes.extract / sort / score /
+_record_overlapping_starts (ref: lib.pyx:2501-2595, 2279-2329), bit for bit."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests.util import golden_path, read_fasta, synthetic_contig
+
+pytestmark = pytest.mark.gpu
+
+TOPO = ["ndx", "stop_val", "type", "strand", "edge"]
+SCORED_INT = ["mot_ndx", "mot_len", "mot_spacer", "mot_spacendx"]
+SCORED_F64 = ["cscore", "sscore", "rscore", "uscore", "tscore", "mot_score"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from pyrodigal_amd import _cabi
+    c = _cabi.Context(0)
+    yield c
+    c.close()
+
+
+def oracle_stage(seq, stage, tinf=None, tt=11, closed=False, is_meta=False, min_gene=90, min_edge_gene=60):
+    o = orc.Oracle(seq)
+    o.extract(tinf.trans_table if tinf is not None else tt, orc.Params(closed=closed, min_gene=min_gene, min_edge_gene=min_edge_gene))
+    o.sort()
+    if stage >= 2:
+        o.reset_scores()
+        o.score_nodes(tinf, closed, is_meta)
+    if stage >= 3:
+        o.overlapping_starts(tinf, 1, 60)
+    return o.nodes()
+
+
+def check(nd, on, stage):
+    assert nd["n"] == len(on)
+    for k in TOPO:
+        assert np.array_equal(nd[k].astype(np.int64), on[k].astype(np.int64)), k
+    assert np.all(nd["traceb"] == -1) and np.all(nd["tracef"] == -1) and np.all(nd["ov_mark"] == -1)
+    if stage >= 2:
+        for k in SCORED_INT:
+            assert np.array_equal(nd[k].astype(np.int64), on[k].astype(np.int64)), k
+        for k in SCORED_F64:
+            assert np.array_equal(nd[k].view(np.uint64), on[k].view(np.uint64)), k
+        assert np.array_equal(nd["gc_cont"].view(np.uint32), on["gc_cont"].view(np.uint32))
+        assert np.array_equal(nd["rbs"], on["rbs"])
+    assert np.array_equal(nd["star_ptr"], on["star_ptr"] if stage >= 3 else np.zeros_like(on["star_ptr"]))
+
+
+@pytest.mark.parametrize("tt", [11, 4])
+@pytest.mark.parametrize("closed", [False, True])
+def test_extract_stage_fixtures(ctx, tt, closed):
+    from pyrodigal_amd import _cabi
+    seqs = [read_fasta("SRR492066.fna.gz")[0][1], read_fasta("MIIJ01000039.fna.gz")[0][1], synthetic_contig(30000, 0.62, 5), "ATGAAATAA", ""]
+    out = ctx.nodes_stage(seqs, _cabi.STAGE_EXTRACT, translation_table=tt, closed=closed)
+    for seq, nd in zip(seqs, out):
+        check(nd, oracle_stage(seq, 1, tt=tt, closed=closed), 1)
+    if tt == 11 and not closed:
+        assert out[0]["n"] == 2293          # ref: tests/test_nodes.py:28-40
+
+
+def test_extract_stage_gene_length_options(ctx):
+    from pyrodigal_amd import _cabi
+    seq = synthetic_contig(50000, 0.45, 9)
+    out = ctx.nodes_stage([seq], _cabi.STAGE_EXTRACT, min_gene=120, min_edge_gene=90)
+    check(out[0], oracle_stage(seq, 1, min_gene=120, min_edge_gene=90), 1)
+
+
+@pytest.mark.parametrize("is_meta", [False, True])
+@pytest.mark.parametrize("stage", [2, 3])
+def test_score_stage_sd_and_nonsd_models(ctx, stage, is_meta):
+    seq_a = read_fasta("SRR492066.fna.gz")[0][1]
+    seq_b = read_fasta("KK037166.fna.gz")[0][1]
+    sd = orc.Training.load(golden_path("SRR492066.training.bin.gz"))
+    nonsd = orc.Oracle(seq_b).train()
+    assert sd.uses_sd == 1 and nonsd.uses_sd == 0
+    for tinf in (sd, nonsd):
+        ctx.set_models([tinf.tobytes()])
+        seqs = [seq_a, seq_b[:60000], synthetic_contig(20000, 0.38, 21)]
+        out = ctx.nodes_stage(seqs, stage, is_meta=is_meta)
+        for seq, nd in zip(seqs, out):
+            check(nd, oracle_stage(seq, stage, tinf=tinf, is_meta=is_meta), stage)
+
+
+def test_score_stage_needs_a_model(ctx):
+    from pyrodigal_amd import _cabi
+    ctx.set_models([])
+    with pytest.raises(ValueError):
+        ctx.nodes_stage(["ATGC" * 100], _cabi.STAGE_SCORE)
+    with pytest.raises(ValueError):
+        ctx.nodes_stage(["ATGC" * 100], 7)
