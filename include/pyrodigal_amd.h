@@ -58,6 +58,8 @@ typedef struct pga_params {
     int32_t max_overlap;    /* default 60 */
     int32_t meta;           /* 1: meta mode over all loaded models; 0: single mode with model 0 */
     int32_t want_nodes;     /* 1: also return the winning model's full node arrays */
+    int32_t mask;           /* 1: no gene may run across a masked region (runs of unknown bases), default 0 */
+    int32_t min_mask;       /* shortest run of unknown bases that is masked, default 50 (ref: lib.pyx:5102-5115, 699-713) */
 } pga_params;
 
 /* One predicted gene (ref: lib.pxd:274-278 `_gene` + the start/stop node fields Gene reads,
@@ -93,7 +95,7 @@ typedef struct pga_contig_result {
     int32_t n_nodes;
     int64_t gene_begin;   /* genes[gene_begin .. gene_begin + n_genes) */
     int32_t n_genes;
-    int32_t _pad;
+    int32_t n_unknown;    /* bases that are not A, C, G or T (ref: lib.pyx:664-697) */
     double  gc;
     double  score;        /* nodes[ipath].score of the winning DP pass */
 } pga_contig_result;
@@ -108,6 +110,10 @@ typedef struct pga_result {
     int64_t            node_passes;           /* sum over (contig, model) DP passes of node count */
     int32_t            n_chains;              /* number of (contig, model) DP passes */
     int32_t            _pad;
+    /* masked regions when params.mask is set, else NULL: contig i owns masks[2*k], masks[2*k+1] = [begin, end)
+     * for k in [mask_off[i], mask_off[i+1])   (ref: lib.pyx:699-713, `Sequence.masks`) */
+    int32_t*           mask_off;
+    int32_t*           masks;
 } pga_result;
 
 /* ---- context ---------------------------------------------------------- */
@@ -156,6 +162,7 @@ int  pga_find_genes(pga_ctx*, const pga_batch*, const pga_params*, pga_result** 
 #define PGA_STAGE_EXTRACT 1   /* Nodes.extract() + Nodes.sort()             (ref: lib.pyx:2501-2541, 2489-2493) */
 #define PGA_STAGE_SCORE   2   /* + Nodes.reset_scores() + Nodes.score()     (ref: lib.pyx:2543-2595)            */
 #define PGA_STAGE_OVERLAP 3   /* + _record_overlapping_starts(flag = 1)      (ref: lib.pyx:2279-2329, 5302)      */
+#define PGA_STAGE_SEQUENCE 4  /* Sequence.__init__ only: gc, n_unknown and masks per contig, no nodes (ref: lib.pyx:664-713) */
 int pga_nodes_stage(pga_ctx*, const pga_batch*, const pga_params*, int stage, int translation_table, pga_result** out);
 
 #ifdef __cplusplus

@@ -58,6 +58,8 @@ def lib():
         L.po_new.restype = vp
         L.po_new.argtypes = [ctypes.c_char_p, ctypes.c_int64, i32, i32]
         L.po_free.argtypes = [vp]
+        L.po_masks.restype = i32
+        L.po_masks.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), i32]
         for name in ("po_slen", "po_unknown", "po_num_nodes", "po_num_genes", "po_last_ipath"):
             getattr(L, name).restype = i32
             getattr(L, name).argtypes = [vp]
@@ -154,6 +156,14 @@ class Oracle:
     num_genes = property(lambda s: s.L.po_num_genes(s.h))
     path_score = property(lambda s: s.L.po_last_path_score(s.h))
     ipath = property(lambda s: s.L.po_last_ipath(s.h))
+
+    def masks(self):
+        """Masked regions as an (k, 2) array of [begin, end) (ref: lib.pyx:699-713)."""
+        k = self.L.po_masks(self.h, None, 0)
+        out = np.zeros((k, 2), np.int32)
+        if k:
+            self.L.po_masks(self.h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), k)
+        return out
 
     def digits(self):
         n = self.slen

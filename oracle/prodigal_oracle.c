@@ -80,6 +80,12 @@ po_ctx* po_new(const char* ascii, int64_t len, int mask, int mask_size) {
     return c;
 }
 
+/* masked regions as [begin, end) pairs; returns their number (ref: lib.pyx:699-713, Sequence.masks) */
+int po_masks(const po_ctx* c, int32_t* out, int cap) {
+    for (int k = 0; k < c->nmask && k < cap; k++) { out[2 * k] = c->mask[k][0]; out[2 * k + 1] = c->mask[k][1]; }
+    return c->nmask;
+}
+
 void po_free(po_ctx* c) {
     if (!c) return;
     free(c->dig); free(c->mask); free(c->nod); free(c->gen);

@@ -72,6 +72,7 @@ typedef struct po_params {
 typedef struct po_ctx po_ctx;
 
 po_ctx*  po_new(const char* ascii, int64_t len, int mask, int mask_size);
+int      po_masks(const po_ctx* c, int32_t* out, int cap);
 void     po_free(po_ctx*);
 
 int      po_slen(const po_ctx*);

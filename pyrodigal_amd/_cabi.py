@@ -19,12 +19,13 @@ EXPORTS = [
     "pga_score_connections", "pga_find_genes_batch", "pga_result_free",
     "pga_batch_create", "pga_batch_free", "pga_find_genes", "pga_nodes_stage",
 ]
-STAGE_EXTRACT, STAGE_SCORE, STAGE_OVERLAP = 1, 2, 3
+STAGE_EXTRACT, STAGE_SCORE, STAGE_OVERLAP, STAGE_SEQUENCE = 1, 2, 3, 4
 
 
 class Params(ctypes.Structure):
     _fields_ = [("closed", ctypes.c_int32), ("min_gene", ctypes.c_int32), ("min_edge_gene", ctypes.c_int32),
-                ("max_overlap", ctypes.c_int32), ("meta", ctypes.c_int32), ("want_nodes", ctypes.c_int32)]
+                ("max_overlap", ctypes.c_int32), ("meta", ctypes.c_int32), ("want_nodes", ctypes.c_int32),
+                ("mask", ctypes.c_int32), ("min_mask", ctypes.c_int32)]
 
 
 class Gene(ctypes.Structure):
@@ -55,7 +56,7 @@ class Nodes(ctypes.Structure):
 
 class ContigResult(ctypes.Structure):
     _fields_ = [("model", ctypes.c_int32), ("n_nodes", ctypes.c_int32), ("gene_begin", ctypes.c_int64),
-                ("n_genes", ctypes.c_int32), ("_pad", ctypes.c_int32), ("gc", ctypes.c_double),
+                ("n_genes", ctypes.c_int32), ("n_unknown", ctypes.c_int32), ("gc", ctypes.c_double),
                 ("score", ctypes.c_double)]
 
 
@@ -63,7 +64,7 @@ class Result(ctypes.Structure):
     _fields_ = [("n_contigs", ctypes.c_int32), ("n_genes", ctypes.c_int64), ("contigs", _P(ContigResult)),
                 ("genes", _P(Gene)), ("nodes", _P(Nodes)), ("t_total_ms", ctypes.c_double),
                 ("t_dp_ms", ctypes.c_double), ("node_passes", ctypes.c_int64), ("n_chains", ctypes.c_int32),
-                ("_pad", ctypes.c_int32)]
+                ("_pad", ctypes.c_int32), ("mask_off", _P(ctypes.c_int32)), ("masks", _P(ctypes.c_int32))]
 
 
 GENE_DTYPE = np.dtype(Gene)
@@ -193,8 +194,9 @@ _NODE_FIELDS = [
 class BatchResult:
     """Host copy of a ``pga_result``: ``contigs`` / ``genes`` structured arrays (+ per-contig node dicts)."""
 
-    def __init__(self, contigs, genes, nodes, t_total_ms, t_dp_ms, node_passes, n_chains=0):
+    def __init__(self, contigs, genes, nodes, t_total_ms, t_dp_ms, node_passes, n_chains=0, masks=None):
         self.contigs, self.genes, self.nodes = contigs, genes, nodes
+        self.masks = masks          # per contig an (k, 2) array of [begin, end) intervals, or None when masking is off
         self.t_total_ms, self.t_dp_ms, self.node_passes, self.n_chains = t_total_ms, t_dp_ms, node_passes, n_chains
 
     def genes_of(self, i):
@@ -252,7 +254,12 @@ def _unpack_result(L, res, want_nodes):
                             a = a.reshape(nd.n, mult)
                     d[name] = a
                 nodes.append(d)
-        return BatchResult(contigs, genes, nodes, r.t_total_ms, r.t_dp_ms, r.node_passes, r.n_chains)
+        masks = None
+        if r.mask_off:
+            off = np.ctypeslib.as_array(r.mask_off, (r.n_contigs + 1,)).copy()
+            iv = np.ctypeslib.as_array(r.masks, (2 * int(off[-1]),)).copy().reshape(-1, 2) if off[-1] else np.zeros((0, 2), np.int32)
+            masks = [iv[off[i]:off[i + 1]] for i in range(r.n_contigs)]
+        return BatchResult(contigs, genes, nodes, r.t_total_ms, r.t_dp_ms, r.node_passes, r.n_chains, masks)
     finally:
         L.pga_result_free(res)
 
@@ -261,9 +268,10 @@ def _upload(self, seqs):
     return Batch(self, seqs)
 
 
-def _find_genes(self, batch, meta=True, closed=False, min_gene=90, min_edge_gene=60, max_overlap=60, want_nodes=False):
+def _find_genes(self, batch, meta=True, closed=False, min_gene=90, min_edge_gene=60, max_overlap=60, want_nodes=False,
+                mask=False, min_mask=50):
     """``GeneFinder.find_genes`` over every contig of a resident :class:`Batch`."""
-    p = Params(int(closed), min_gene, min_edge_gene, max_overlap, int(meta), int(want_nodes))
+    p = Params(int(closed), min_gene, min_edge_gene, max_overlap, int(meta), int(want_nodes), int(mask), min_mask)
     res = _P(Result)()
     rc = self.L.pga_find_genes(self.h, batch.h, ctypes.byref(p), ctypes.byref(res))
     if rc != PGA_OK:
@@ -281,18 +289,19 @@ def _find_genes_batch(self, seqs, **kw):
 
 
 def _nodes_stage(self, seqs, stage, translation_table=11, closed=False, min_gene=90, min_edge_gene=60, max_overlap=60,
-                 is_meta=False):
+                 is_meta=False, mask=False, min_mask=50):
     """Node arrays after ``Nodes.extract`` (stage 1), ``Nodes.score`` (2) or overlapping starts (3), one dict per contig.
 
     Stages 2 and 3 score with model 0 of the context (``set_models`` first)."""
     b = seqs if isinstance(seqs, Batch) else Batch(self, seqs)
     try:
-        p = Params(int(closed), min_gene, min_edge_gene, max_overlap, int(is_meta), 1)
+        p = Params(int(closed), min_gene, min_edge_gene, max_overlap, int(is_meta), 1, int(mask), min_mask)
         res = _P(Result)()
         rc = self.L.pga_nodes_stage(self.h, b.h, ctypes.byref(p), int(stage), int(translation_table), ctypes.byref(res))
         if rc != PGA_OK:
             _raise(self.L, self.h, rc, "pga_nodes_stage")
-        return _unpack_result(self.L, res, True).nodes
+        out = _unpack_result(self.L, res, True)
+        return out if stage == STAGE_SEQUENCE else out.nodes
     finally:
         if b is not seqs:
             b.close()

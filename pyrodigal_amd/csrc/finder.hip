@@ -320,6 +320,7 @@ struct ResultOwner {
     std::vector<pga_contig_result> contigs;
     std::vector<pga_gene> genes;
     std::vector<pga_nodes> nodes;
+    std::vector<int32_t> mask_off, masks;
     std::vector<void*> blocks;
     ~ResultOwner() { for (void* b : blocks) free(b); }
 };
@@ -476,6 +477,19 @@ extern "C" void pga_result_free(pga_result* r) {
     if (r) delete reinterpret_cast<ResultOwner*>(r);
 }
 
+// hand the result over to the caller
+static int publish(ResultOwner* R, ResultOwner*& guarded, const pga_params& P, pga_result** out) {
+    R->pub.contigs = R->contigs.data();
+    R->pub.genes = R->genes.data();
+    R->pub.n_genes = (int64_t)R->genes.size();
+    R->pub.nodes = !R->nodes.empty() ? R->nodes.data() : nullptr;
+    R->pub.mask_off = P.mask ? R->mask_off.data() : nullptr;
+    R->pub.masks = P.mask ? R->masks.data() : nullptr;
+    guarded = nullptr;
+    *out = &R->pub;
+    return PGA_OK;
+}
+
 // stage 0 = the whole path; PGA_STAGE_* = stop after that stage and return the node arrays (single chain per
 // contig scored with model 0; P.meta then only selects the meta-mode start penalties of Nodes.score)
 static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, const int stage, const int tt_override, pga_result** out) {
@@ -488,8 +502,9 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
     if (!c->finder) { int rc0 = pga_finder_models_changed(c); if (rc0) return rc0; }
     const bool meta_run = pp->meta && stage == 0;
     // meta mode over an empty bin collection is legal and finds nothing (ref: tests/test_gene_finder.py:316-324)
-    if (c->n_models <= 0 && !meta_run && stage != PGA_STAGE_EXTRACT) { c->err = "pga_find_genes: no model loaded (call pga_set_models first)"; return PGA_EINVAL; }
+    if (c->n_models <= 0 && !meta_run && stage != PGA_STAGE_EXTRACT && stage != PGA_STAGE_SEQUENCE) { c->err = "pga_find_genes: no model loaded (call pga_set_models first)"; return PGA_EINVAL; }
     const pga_params P = *pp;
+    if (P.mask && P.min_mask < 0) { c->err = "pga_find_genes: min_mask must be positive"; return PGA_EINVAL; }   // ref: lib.pyx:5175-5176
     if (P.min_gene <= 0 || P.min_edge_gene <= 0 || P.max_overlap < 0 || P.max_overlap > P.min_gene) {
         c->err = "pga_find_genes: invalid min_gene / min_edge_gene / max_overlap";   // ref: lib.pyx:5169-5181
         return PGA_EINVAL;
@@ -503,6 +518,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
     if (!R) return PGA_ENOMEM;
     struct Guard { ResultOwner* r; ~Guard() { delete r; } } guard{R};
     R->contigs.assign(NC, pga_contig_result{-1, 0, 0, 0, 0, 0.0, 0.0});
+    R->mask_off.assign(NC + 1, 0);
     memset(&R->pub, 0, sizeof R->pub);
     R->pub.n_contigs = NC;
 
@@ -539,11 +555,48 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         HT(c, hipMemcpyAsync(d_ct, ct.data(), sizeof(ContigDesc) * (NC + 1), hipMemcpyHostToDevice, st));
         HT(c, hipMemsetAsync(d_cnt, 0, sizeof(int32_t) * 2 * (size_t)NC, st));
         pga_launch_digitize(d_seq, d_dig, total, d_ct, NC, d_cnt, d_cnt + NC, st);
+        MaskList masks{nullptr, nullptr};
+        if (P.mask) {
+            // masked regions: found on the device, ordered on the host (a handful of intervals)
+            const int cap = (int)std::min<int64_t>(total / std::max(1, P.min_mask) + NC + 1, (int64_t)1 << 28);
+            DEVBUF(d_runs, MaskRun, "d_mask_runs", cap + 1);
+            DEVBUF(d_nruns, int32_t, "d_mask_count", 4);
+            DEVBUF(d_moff, int32_t, "d_mask_off", NC + 2);
+            DEVBUF(d_miv, int2, "d_mask_iv", cap + 1);
+            pga_launch_find_masks(d_dig, d_ct, batch->d_tiles, batch->n_tiles, P.min_mask, d_runs, d_nruns, cap, st);
+            int32_t nruns = 0;
+            HT(c, hipMemcpyAsync(&nruns, d_nruns, 4, hipMemcpyDeviceToHost, st));
+            HT(c, hipStreamSynchronize(st));
+            nruns = std::min(nruns, cap);
+            std::vector<MaskRun> runs((size_t)nruns);
+            if (nruns > 0) HT(c, hipMemcpy(runs.data(), d_runs, sizeof(MaskRun) * nruns, hipMemcpyDeviceToHost));
+            std::sort(runs.begin(), runs.end(), [](const MaskRun& a, const MaskRun& b) { return a.contig != b.contig ? a.contig < b.contig : a.begin < b.begin; });
+            std::vector<int32_t> moff(NC + 1, 0);
+            std::vector<int2> miv((size_t)nruns + 1);
+            for (int k = 0; k < nruns; k++) { moff[runs[k].contig + 1]++; miv[k] = make_int2(runs[k].begin, runs[k].end); }
+            for (int i = 0; i < NC; i++) moff[i + 1] += moff[i];
+            R->mask_off = moff;
+            R->masks.resize(2 * (size_t)nruns);
+            for (int k = 0; k < nruns; k++) { R->masks[2 * k] = runs[k].begin; R->masks[2 * k + 1] = runs[k].end; }
+            HT(c, hipMemcpy(d_moff, moff.data(), sizeof(int32_t) * (NC + 1), hipMemcpyHostToDevice));
+            if (nruns > 0) HT(c, hipMemcpy(d_miv, miv.data(), sizeof(int2) * nruns, hipMemcpyHostToDevice));
+            masks = MaskList{d_moff, d_miv};
+        }
+        if (stage == PGA_STAGE_SEQUENCE) {
+            HT(c, hipMemcpyAsync(h_cnt, d_cnt, sizeof(int32_t) * 2 * (size_t)NC, hipMemcpyDeviceToHost, st));
+            HT(c, hipGetLastError());
+            HT(c, hipStreamSynchronize(st));
+            for (int i = 0; i < NC; i++) {
+                R->contigs[i].gc = ct[i].len > 0 ? (double)h_cnt[i] / (double)ct[i].len : 0.0;
+                R->contigs[i].n_unknown = h_cnt[NC + i];
+            }
+            return publish(R, guard.r, P, out);
+        }
         for (int g = 0; g < NG; g++) {
             const int tt = meta_run ? f->group_tt[g] : (stage == PGA_STAGE_EXTRACT ? tt_override : c->models[0].trans_table);
             HT(c, hipMemsetAsync(ga[g].nf_fwd, 0, (size_t)total + 1, st));
             HT(c, hipMemsetAsync(ga[g].nf_rev, 0, (size_t)total + 1, st));
-            pga_launch_extract(d_dig, total, d_ct, NC, tt, P, ga[g], d_tile, d_pre_gc, g == 0, batch->d_tiles, batch->n_tiles, d_tile_first, d_tile_last, st);
+            pga_launch_extract(d_dig, total, d_ct, NC, tt, P, ga[g], d_tile, d_pre_gc, g == 0, batch->d_tiles, batch->n_tiles, d_tile_first, d_tile_last, masks, st);
             hipLaunchKernelGGL(k_contig_node_base, dim3((NC + 1 + 255) / 256), dim3(256), 0, st, d_ct, NC, total, ga[g].pre_nodes, d_cbase + (size_t)g * (NC + 1));
         }
         HT(c, hipMemcpyAsync(h_cnt, d_cnt, sizeof(int32_t) * 2 * (size_t)NC, hipMemcpyDeviceToHost, st));
@@ -558,6 +611,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             const int L = ct[i].len;
             const double gc = L > 0 ? (double)h_cnt[i] / (double)L : 0.0;
             R->contigs[i].gc = gc;
+            R->contigs[i].n_unknown = h_cnt[NC + i];
             if (!meta_run) {
                 const int32_t* cb = h_cbase;
                 ChainDesc ch{0, cb[i], cb[i + 1] - cb[i], 0, i, 1};
@@ -697,11 +751,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                 memcpy(N.mot_spacer, hs_u8 + 6 * nn + oo, n); memcpy(N.mot_spacendx, hs_u8 + 7 * nn + oo, n);
                 memcpy(N.gc_cont, hs_f32 + oo, 4 * (size_t)n);
             }
-            R->pub.contigs = R->contigs.data();
-            R->pub.nodes = R->nodes.data();
-            guard.r = nullptr;
-            *out = &R->pub;
-            return PGA_OK;
+            return publish(R, guard.r, P, out);
         }
         // one DP launch over the chains of every group: chains are independent, the more in flight the better
         HT(c, hipEventRecord(f->e_dp0[0], st));
@@ -951,13 +1001,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         }
     }
     tm.mark("results");
-    R->pub.contigs = R->contigs.data();
-    R->pub.genes = R->genes.data();
-    R->pub.n_genes = (int64_t)R->genes.size();
-    R->pub.nodes = P.want_nodes && !R->nodes.empty() ? R->nodes.data() : nullptr;
-    guard.r = nullptr;
-    *out = &R->pub;
-    return PGA_OK;
+    return publish(R, guard.r, P, out);
 }
 
 extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_params* pp, pga_result** out) {
@@ -965,7 +1009,7 @@ extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_para
 }
 
 extern "C" int pga_nodes_stage(pga_ctx* c, const pga_batch* batch, const pga_params* pp, int stage, int translation_table, pga_result** out) {
-    if (stage < PGA_STAGE_EXTRACT || stage > PGA_STAGE_OVERLAP) {
+    if (stage < PGA_STAGE_EXTRACT || stage > PGA_STAGE_SEQUENCE) {
         if (out) *out = nullptr;
         if (c) c->err = "pga_nodes_stage: unknown stage";
         return PGA_EINVAL;

@@ -43,6 +43,13 @@ struct ModelScoreConst {
     double lfac_tab[1001];              // log((1-p^n)/p^n) - lfac_min for n = 0..1000 codons (ref: lib.pyx:2209-2210)
 };
 
+// Masked regions (ref: lib.pyx:699-713): per contig a sorted run of [begin, end) intervals.
+struct MaskList {
+    const int32_t* off;     // [n_contigs + 1] into iv, or nullptr when masking is off
+    const int2* iv;         // begin, end (contig coordinates)
+};
+struct MaskRun { int32_t contig, begin, end, _pad; };
+
 struct ScoreParams {
     int32_t closed, is_meta, max_overlap, _pad;
 };
@@ -51,7 +58,10 @@ void pga_launch_digitize(const char* d_seq, uint8_t* d_dig, int64_t total, const
                          int32_t* d_gc, int32_t* d_unk, hipStream_t st);
 void pga_launch_extract(const uint8_t* d_dig, int64_t total, const ContigDesc* d_ct, int n_contigs, int tt,
                         const pga_params& p, const GroupArrays& ga, int2* d_tile_sum, int32_t* d_pre_gc, int write_gc,
-                        const TileDesc* d_tiles, int n_tiles, int32_t* d_tile_first, int32_t* d_tile_last, hipStream_t st);
+                        const TileDesc* d_tiles, int n_tiles, int32_t* d_tile_first, int32_t* d_tile_last, MaskList masks, hipStream_t st);
+// runs of unknown bases of at least min_mask positions, unordered, at most `cap` of them; *d_count is reset first
+void pga_launch_find_masks(const uint8_t* d_dig, const ContigDesc* d_ct, const TileDesc* d_tiles, int n_tiles, int min_mask,
+                           MaskRun* d_runs, int32_t* d_count, int cap, hipStream_t st);
 int pga_extract_tile_size();
 void pga_launch_compact(int64_t total, const ContigDesc* d_ct, int n_contigs, const GroupArrays& ga, hipStream_t st);
 void pga_launch_orf_gc(const ContigDesc* d_ct, int n_contigs, const int32_t* d_pre_gc, const GroupArrays& ga,

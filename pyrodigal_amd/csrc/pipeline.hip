@@ -213,7 +213,7 @@ k_tile_stops(const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct,
 __global__ void __launch_bounds__(256)
 k_extract_scan(const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct, const TileDesc* __restrict__ tiles, int n_tiles,
                const int32_t* __restrict__ tile_first, const int32_t* __restrict__ tile_last,
-               int tt, int closed, int min_gene, int min_edge_gene, GroupArrays ga) {
+               int tt, int closed, int min_gene, int min_edge_gene, GroupArrays ga, MaskList masks) {
     __shared__ int s_first[3][256], s_last[3][256];
     __shared__ int s_carry_ns[3], s_carry_ps[3];
     const TileDesc td = tiles[blockIdx.x];
@@ -291,6 +291,8 @@ k_extract_scan(const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ c
     uint8_t* __restrict__ nf = strand == 1 ? ga.nf_fwd : ga.nf_rev;
     int32_t* __restrict__ tsv = strand == 1 ? ga.tsv_fwd : ga.tsv_rev;
     uint8_t* __restrict__ tinfo = strand == 1 ? ga.tinfo_fwd : ga.tinfo_rev;
+    const int n_masks = masks.off ? masks.off[td.contig + 1] - masks.off[td.contig] : 0;
+    const int2* __restrict__ mv = masks.off ? masks.iv + masks.off[td.contig] : nullptr;
 #pragma unroll
     for (int q = EX_PER_THREAD - 1; q >= 0; q--) {
         const int i = i0 + q, f = i % 3;
@@ -302,6 +304,23 @@ k_extract_scan(const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ c
             if (closed) continue;                       // closed ends: nothing runs off the right edge
             last = L - 3 - ((L - 3 - f) % 3);           // virtual right end: last full codon position of the frame
             if (last < i) continue;
+        }
+        // region masks (ref: lib.pyx:1959-1966, 2053-2061).  The reference keeps one mask pointer per frame that
+        // follows the ORF's stop and tests that single mask: forward, the last mask beginning at or before the stop;
+        // reverse, the first mask ending at or after the stop's forward coordinate.
+        if (n_masks > 0) {
+            bool hit = false;
+            if (strand == 1) {
+                int a = 0, b = n_masks;                 // first mask with begin > last
+                while (a < b) { const int m = (a + b) >> 1; if (mv[m].x <= last) a = m + 1; else b = m; }
+                if (a > 0) { const int2 m = mv[a - 1]; hit = m.x < last && i < m.y; }
+            } else {
+                const int x = L - last - 1, e = L - i - 1;
+                int a = 0, b = n_masks;                 // first mask with end >= x
+                while (a < b) { const int m = (a + b) >> 1; if (mv[m].y < x) a = m + 1; else b = m; }
+                if (a < n_masks) { const int2 m = mv[a]; hit = m.x < e && x < m.y; }
+            }
+            if (hit) continue;
         }
         const int mind = real ? min_gene : min_edge_gene;
         int type = -1, edge = 0;
@@ -1030,14 +1049,47 @@ void pga_launch_digitize(const char* d_seq, uint8_t* d_dig, int64_t total, const
     hipLaunchKernelGGL(k_digitize, dim3(nblocks(total, 4096)), dim3(256), 0, st, d_seq, d_dig, total, d_ct, n_contigs, d_gc, d_unk);
 }
 
+// Runs of unknown bases (ref: lib.pyx:699-713, Sequence._mask): the thread that sees the first N of a run walks to
+// its end, 8 bytes at a time, and records it when it is long enough.  Runs are rare and mostly short.
+__global__ void __launch_bounds__(256)
+k_find_masks(const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct, const TileDesc* __restrict__ tiles, int min_mask,
+             MaskRun* __restrict__ runs, int32_t* __restrict__ count, int cap) {
+    const TileDesc td = tiles[blockIdx.x];
+    const ContigDesc cd = ct[td.contig];
+    const int L = cd.len;
+    const uint8_t* __restrict__ d = dig + cd.base;
+    const int i0 = td.start + threadIdx.x * EX_PER_THREAD;
+    for (int q = 0; q < EX_PER_THREAD; q++) {
+        const int i = i0 + q;
+        if (i >= L || d[i] != NN || (i > 0 && d[i - 1] == NN)) continue;
+        int e = i + 1;
+        while (e + 8 <= L) {
+            uint64_t w; memcpy(&w, d + e, 8);
+            if (w != 0x0606060606060606ull) break;
+            e += 8;
+        }
+        while (e < L && d[e] == NN) e++;
+        if (e - i >= min_mask) {
+            const int k = atomicAdd(count, 1);
+            if (k < cap) runs[k] = MaskRun{td.contig, i, e, 0};
+        }
+    }
+}
+
+void pga_launch_find_masks(const uint8_t* d_dig, const ContigDesc* d_ct, const TileDesc* d_tiles, int n_tiles, int min_mask,
+                           MaskRun* d_runs, int32_t* d_count, int cap, hipStream_t st) {
+    (void)hipMemsetAsync(d_count, 0, sizeof(int32_t), st);
+    if (n_tiles > 0) hipLaunchKernelGGL(k_find_masks, dim3(n_tiles), dim3(256), 0, st, d_dig, d_ct, d_tiles, min_mask, d_runs, d_count, cap);
+}
+
 void pga_launch_extract(const uint8_t* d_dig, int64_t total, const ContigDesc* d_ct, int n_contigs, int tt,
                         const pga_params& p, const GroupArrays& ga, int2* d_tile_sum, int32_t* d_pre_gc, int write_gc,
-                        const TileDesc* d_tiles, int n_tiles, int32_t* d_tile_first, int32_t* d_tile_last, hipStream_t st) {
+                        const TileDesc* d_tiles, int n_tiles, int32_t* d_tile_first, int32_t* d_tile_last, MaskList masks, hipStream_t st) {
     if (total <= 0) return;
     if (n_tiles > 0) {
         hipLaunchKernelGGL(k_tile_stops, dim3(n_tiles, 2), dim3(256), 0, st, d_dig, d_ct, d_tiles, n_tiles, tt, d_tile_first, d_tile_last);
         hipLaunchKernelGGL(k_extract_scan, dim3(n_tiles, 2), dim3(256), 0, st, d_dig, d_ct, d_tiles, n_tiles, d_tile_first, d_tile_last, tt,
-                           p.closed, p.min_gene, p.min_edge_gene, ga);
+                           p.closed, p.min_gene, p.min_edge_gene, ga, masks);
     }
     const int tiles = (int)pga_scan_tiles(total);
     hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(256), 0, st, ga.nf_fwd, ga.nf_rev, d_dig, total, d_tile_sum);

@@ -10,8 +10,8 @@ CPU path: without the library or a gfx950 device, calls raise `RuntimeError`.
 reference (lib.pyx:2501-2595, 1315-1357) over `pga_nodes_stage` / `pga_score_connections`; the scorer
 works on whole node arrays, not node by node (SURVEY 8b: per-node granularity is useless for a GPU).
 
-Not provided this round (raise `NotImplementedError`): `GeneFinder.train`, `mask=True`,
-`Gene.translate` and the GFF / GenBank / FASTA writers.
+Not provided this round (raise `NotImplementedError`): `GeneFinder.train`, `Gene.translate` and the
+GFF / GenBank / FASTA writers.
 """
 import gzip
 import threading
@@ -34,6 +34,8 @@ cdef extern from "pyrodigal_amd.h" nogil:
         int32_t max_overlap
         int32_t meta
         int32_t want_nodes
+        int32_t mask
+        int32_t min_mask
     ctypedef struct pga_gene:
         int32_t contig
         int32_t begin
@@ -85,6 +87,7 @@ cdef extern from "pyrodigal_amd.h" nogil:
         int32_t n_nodes
         int64_t gene_begin
         int32_t n_genes
+        int32_t n_unknown
         double gc
         double score
     ctypedef struct pga_result:
@@ -97,6 +100,8 @@ cdef extern from "pyrodigal_amd.h" nogil:
         double t_dp_ms
         int64_t node_passes
         int32_t n_chains
+        int32_t* mask_off
+        int32_t* masks
     int PGA_OK, PGA_EINVAL, PGA_ENOMEM, PGA_EDEVICE, PGA_ENODEVICE
     int pga_create(int device, pga_ctx** out)
     void pga_destroy(pga_ctx*)
@@ -107,7 +112,7 @@ cdef extern from "pyrodigal_amd.h" nogil:
     void pga_result_free(pga_result*)
     int pga_batch_create(pga_ctx*, int32_t n, const char* const* seqs, const int64_t* lens, pga_batch** out)
     void pga_batch_free(pga_batch*)
-    int PGA_STAGE_EXTRACT, PGA_STAGE_SCORE, PGA_STAGE_OVERLAP
+    int PGA_STAGE_EXTRACT, PGA_STAGE_SCORE, PGA_STAGE_OVERLAP, PGA_STAGE_SEQUENCE
     int pga_nodes_stage(pga_ctx*, const pga_batch*, const pga_params*, int stage, int translation_table, pga_result** out)
     int pga_score_connections(pga_ctx*, int32_t n, const int32_t* ndx, const int32_t* stop_val, const uint8_t* type,
                               const int8_t* strand, const double* cscore, const double* sscore, const double* rscore,
@@ -286,51 +291,6 @@ METAGENOMIC_BINS = MetagenomicBins()
 
 
 # --- Sequence / Nodes / Gene / Genes ----------------------------------------------------------
-cdef class Sequence:
-    """The input as ASCII bytes with its GC content (digitising itself happens on the device)."""
-    cdef readonly bytes data
-    cdef readonly double gc
-
-    def __init__(self, object sequence, bint mask=False, size_t mask_size=50):
-        if mask:
-            raise NotImplementedError("region masking is not available in the HIP path yet")
-        if isinstance(sequence, Sequence):
-            self.data = (<Sequence> sequence).data
-        elif isinstance(sequence, str):
-            self.data = sequence.encode("ascii", "replace")
-        else:
-            self.data = bytes(memoryview(sequence))
-        self.gc = 0.0
-
-    def __len__(self):
-        return len(self.data)
-
-    def __str__(self):
-        up = self.data.upper()
-        return "".join(chr(c) if c in b"ACGT" else "N" for c in up)
-
-
-cdef class Node:
-    """A read-only view of one node (ref: lib.pyx:1437-1552)."""
-    cdef readonly Nodes owner
-    cdef readonly ssize_t i
-
-    def __getattr__(self, name):
-        arr = self.owner._f.get(name)
-        if arr is None:
-            raise AttributeError(name)
-        v = arr[self.i]
-        return v.item() if hasattr(v, "item") and getattr(v, "ndim", 0) == 0 else v
-
-    @property
-    def index(self):
-        return int(self.owner._f["ndx"][self.i])
-
-    @property
-    def type(self):
-        return _NODE_TYPE[3 if self.owner._f["edge"][self.i] else int(self.owner._f["type"][self.i])] if self.owner._f["type"][self.i] != 3 else "Stop"
-
-
 cdef class _StageContext:
     """One lazily created device context for the stage-level calls (`Nodes.*`, `ConnectionScorer`)."""
     cdef pga_ctx* ctx
@@ -369,6 +329,133 @@ cdef class _StageContext:
         return 0
 
 cdef _StageContext _STAGE = _StageContext()
+
+
+cdef class Mask:
+    """A masked region `[begin, end)` of a sequence (ref: lib.pyx:283-340)."""
+    cdef readonly int begin
+    cdef readonly int end
+
+    def __init__(self, int begin, int end):
+        self.begin = begin
+        self.end = end
+
+    def __repr__(self):
+        return "<pyrodigal_amd.lib.Mask begin=%d end=%d>" % (self.begin, self.end)
+
+    def __eq__(self, other):
+        return isinstance(other, Mask) and (self.begin, self.end) == ((<Mask> other).begin, (<Mask> other).end)
+
+
+cdef class Sequence:
+    """The input as ASCII bytes.  Digitising, GC content, the unknown-base count and the masked regions are
+    computed on the device (ref: lib.pyx:664-713), on first use."""
+    cdef readonly bytes data
+    cdef readonly bint mask
+    cdef readonly size_t mask_size
+    cdef double _gc
+    cdef ssize_t _unknown
+    cdef list _masks
+
+    def __init__(self, object sequence, bint mask=False, size_t mask_size=50):
+        if isinstance(sequence, Sequence):
+            self.data = (<Sequence> sequence).data
+        elif isinstance(sequence, str):
+            self.data = sequence.encode("ascii", "replace")
+        else:
+            self.data = bytes(memoryview(sequence))
+        self.mask = mask
+        self.mask_size = mask_size
+        self._gc = -1.0
+        self._unknown = -1
+        self._masks = None
+
+    def __len__(self):
+        return len(self.data)
+
+    def __str__(self):
+        up = self.data.upper()
+        return "".join(chr(c) if c in b"ACGT" else "N" for c in up)
+
+    cdef int _build(self) except -1:
+        cdef pga_params p
+        cdef pga_batch* batch = NULL
+        cdef pga_result* res = NULL
+        cdef const char* ptr = PyBytes_AS_STRING(self.data)
+        cdef int64_t length = len(self.data)
+        cdef int rc, k
+        if self._unknown >= 0:
+            return 0
+        p.closed = 0; p.min_gene = 90; p.min_edge_gene = 60; p.max_overlap = 60; p.meta = 0; p.want_nodes = 0
+        p.mask = self.mask; p.min_mask = <int32_t> self.mask_size
+        with _STAGE.lock:
+            _STAGE.ensure()
+            rc = pga_batch_create(_STAGE.ctx, 1, &ptr, &length, &batch)
+            if rc != PGA_OK:
+                _raise_for(_STAGE.ctx, rc, "pga_batch_create")
+            try:
+                with nogil:
+                    rc = pga_nodes_stage(_STAGE.ctx, batch, &p, PGA_STAGE_SEQUENCE, 11, &res)
+                if rc != PGA_OK:
+                    _raise_for(_STAGE.ctx, rc, "pga_nodes_stage")
+                try:
+                    self._gc = res.contigs[0].gc
+                    self._unknown = res.contigs[0].n_unknown
+                    self._masks = []
+                    if res.mask_off != NULL:
+                        for k in range(res.mask_off[0], res.mask_off[1]):
+                            self._masks.append(Mask(res.masks[2 * k], res.masks[2 * k + 1]))
+                finally:
+                    pga_result_free(res)
+            finally:
+                pga_batch_free(batch)
+        return 0
+
+    @property
+    def gc(self):
+        """GC fraction over all bases (ref: lib.pyx:596-600)."""
+        self._build()
+        return self._gc
+
+    @property
+    def unknown(self):
+        """Number of bases that are not A, C, G or T (ref: lib.pyx:602-606)."""
+        self._build()
+        return self._unknown
+
+    @property
+    def gc_known(self):
+        """GC fraction over the known bases (ref: lib.pyx:608-614)."""
+        self._build()
+        cdef ssize_t n = len(self.data)
+        return self._gc * n / (n - self._unknown) if n > self._unknown else 0.0
+
+    @property
+    def masks(self):
+        """The masked regions, empty unless `mask=True` (ref: lib.pyx:616-620)."""
+        self._build()
+        return list(self._masks)
+
+
+cdef class Node:
+    """A read-only view of one node (ref: lib.pyx:1437-1552)."""
+    cdef readonly Nodes owner
+    cdef readonly ssize_t i
+
+    def __getattr__(self, name):
+        arr = self.owner._f.get(name)
+        if arr is None:
+            raise AttributeError(name)
+        v = arr[self.i]
+        return v.item() if hasattr(v, "item") and getattr(v, "ndim", 0) == 0 else v
+
+    @property
+    def index(self):
+        return int(self.owner._f["ndx"][self.i])
+
+    @property
+    def type(self):
+        return _NODE_TYPE[3 if self.owner._f["edge"][self.i] else int(self.owner._f["type"][self.i])] if self.owner._f["type"][self.i] != 3 else "Stop"
 
 
 cdef class Nodes:
@@ -420,6 +507,7 @@ cdef class Nodes:
         kw = self._extract_kw
         p.closed = kw["closed"]; p.min_gene = kw["min_gene"]; p.min_edge_gene = kw["min_edge_gene"]
         p.max_overlap = 60; p.meta = is_meta; p.want_nodes = 1
+        p.mask = seq.mask; p.min_mask = <int32_t> seq.mask_size
         tt = kw["translation_table"]
         with _STAGE.lock:
             _STAGE.ensure()
@@ -742,8 +830,6 @@ cdef class GeneFinder:
             raise ValueError("`max_overlap` must be lower than `min_gene`")
         if backend not in ("detect", "hip"):
             raise ValueError("unsupported backend %r: this build only has the HIP (gfx950) backend" % backend)
-        if mask:
-            raise NotImplementedError("region masking is not available in the HIP path yet")
         self.meta = meta
         self.closed = closed
         self.mask = mask
@@ -811,7 +897,11 @@ cdef class GeneFinder:
         """`find_genes` for many sequences in one device pass; returns one `Genes` per input, in order."""
         if not self.meta and self.training_info is None:
             raise RuntimeError("cannot find genes without having trained in single mode")
-        cdef list seqs = [s if isinstance(s, Sequence) else Sequence(s) for s in sequences]
+        cdef list seqs = [s if isinstance(s, Sequence) else Sequence(s, mask=self.mask, mask_size=self.min_mask) for s in sequences]
+        for s in seqs:      # one device pass = one masking rule (ref: lib.pyx:5433-5438 builds the Sequence with the finder's)
+            if (<Sequence> s).mask != self.mask or (self.mask and <int> (<Sequence> s).mask_size != self.min_mask):
+                raise ValueError("sequence masking (mask=%r, mask_size=%d) differs from the GeneFinder's (mask=%r, min_mask=%d)"
+                                 % ((<Sequence> s).mask, (<Sequence> s).mask_size, self.mask, self.min_mask))
         cdef int n = len(seqs), i, j, rc
         cdef const char** ptrs = <const char**> malloc(sizeof(char*) * max(n, 1))
         cdef int64_t* lens = <int64_t*> malloc(sizeof(int64_t) * max(n, 1))
@@ -826,6 +916,7 @@ cdef class GeneFinder:
             raise MemoryError()
         p.closed = self.closed; p.min_gene = self.min_gene; p.min_edge_gene = self.min_edge_gene
         p.max_overlap = self.max_overlap; p.meta = self.meta; p.want_nodes = self.keep_nodes
+        p.mask = self.mask; p.min_mask = self.min_mask
         try:
             for i in range(n):
                 ptrs[i] = PyBytes_AS_STRING((<Sequence> seqs[i]).data)
@@ -842,7 +933,13 @@ cdef class GeneFinder:
                 cr = &res.contigs[i]
                 genes = Genes.__new__(Genes)
                 genes.sequence = seqs[i]
-                (<Sequence> seqs[i]).gc = cr.gc
+                (<Sequence> seqs[i])._gc = cr.gc
+                (<Sequence> seqs[i])._unknown = cr.n_unknown
+                if (<Sequence> seqs[i])._masks is None:
+                    (<Sequence> seqs[i])._masks = []
+                    if res.mask_off != NULL:
+                        for j in range(res.mask_off[i], res.mask_off[i + 1]):
+                            (<Sequence> seqs[i])._masks.append(Mask(res.masks[2 * j], res.masks[2 * j + 1]))
                 genes.meta = self.meta
                 genes._num_seq = first_id + i
                 genes.score = cr.score

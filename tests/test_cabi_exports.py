@@ -33,12 +33,27 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_cabi.EXPORTS) == declared_functions()
 
 
-def test_struct_sizes_match_the_header():
+def test_struct_sizes_match_the_header(tmp_path):
+    """The ctypes mirrors against the header itself: a C program prints sizeof / offsetof of what the binding copies."""
+    import subprocess
     from pyrodigal_amd import _cabi
-    assert ctypes.sizeof(_cabi.Params) == 24
-    assert ctypes.sizeof(_cabi.Gene) == 88
-    assert ctypes.sizeof(_cabi.ContigResult) == 40
-    assert _cabi.TRAINING_SIZE == 558392
+    src = tmp_path / "sizes.c"
+    src.write_text("""
+#include <stdio.h>
+#include <stddef.h>
+#include "pyrodigal_amd.h"
+int main(void) {
+    printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(pga_params), sizeof(pga_gene), sizeof(pga_contig_result), sizeof(pga_training),
+           sizeof(pga_result), sizeof(pga_nodes), offsetof(pga_result, mask_off), offsetof(pga_contig_result, gc));
+    return 0;
+}
+""")
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert got == [ctypes.sizeof(_cabi.Params), ctypes.sizeof(_cabi.Gene), ctypes.sizeof(_cabi.ContigResult), _cabi.TRAINING_SIZE,
+                   ctypes.sizeof(_cabi.Result), ctypes.sizeof(_cabi.Nodes), _cabi.Result.mask_off.offset, _cabi.ContigResult.gc.offset]
+    assert got[:4] == [32, 88, 40, 558392]
 
 
 def test_no_gpu_means_loud_failure():

@@ -127,6 +127,39 @@ def test_meta_mode_short_fragments_and_edge_cases(ctx, models):
             compare_contig(res, i, s, orc.Oracle(s), models, meta=True, closed=closed)
 
 
+def _with_unknown_runs(length, gc, seed, runs):
+    """A synthetic contig with runs of N written over it at fixed relative places."""
+    rng = np.random.default_rng(seed)
+    s = bytearray(synthetic_contig(length, gc, seed))
+    for k, n in enumerate(runs):
+        at = int(rng.integers(0, max(1, length - n)))
+        s[at:at + n] = b"N" * n
+    return bytes(s)
+
+
+@pytest.mark.parametrize("min_mask", [50, 10])
+def test_region_masking_single_and_meta(ctx, models, min_mask):
+    # ref: lib.pyx:699-713 (Sequence._mask), 1959-1966 / 2053-2061 (extraction); tests/test_gene_finder.py mask cases
+    seqs = [_with_unknown_runs(30000, 0.45, 70, [9, 10, 11, 49, 50, 51, 120, 400, 1500]),
+            _with_unknown_runs(12000, 0.6, 71, [50] * 12),
+            b"N" * 70 + synthetic_contig(4000, 0.5, 72) + b"N" * 55,          # masks touching both ends
+            synthetic_contig(3000, 0.5, 73),                                  # no unknown base at all
+            b"N" * 400, b""]
+    for meta in (True, False):
+        ctx.set_models([m.buf for m in models] if meta else [models[1].buf])
+        for closed in (False, True):
+            res = ctx.find_genes_batch(seqs, meta=meta, closed=closed, want_nodes=True, mask=True, min_mask=min_mask)
+            n = 0
+            for i, s in enumerate(seqs):
+                n += compare_contig(res, i, s, orc.Oracle(s, mask=True, mask_size=min_mask), models if meta else [models[1]], meta=meta, closed=closed)
+            assert n > 0
+    # masking changes the calls on these inputs (otherwise the test would prove nothing)
+    ctx.set_models([models[1].buf])
+    a = ctx.find_genes_batch(seqs[:1], meta=False, mask=True, min_mask=min_mask).genes
+    b = ctx.find_genes_batch(seqs[:1], meta=False).genes
+    assert len(a) != len(b) or not np.array_equal(a["begin"], b["begin"])
+
+
 def test_no_model_in_gc_window(ctx, models):
     ctx.set_models([models[0].buf])            # gc 0.30 only
     seq = synthetic_contig(5000, 0.70, 3)

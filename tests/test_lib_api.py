@@ -158,3 +158,31 @@ def test_nodes_extract_score_and_connection_scorer(lib):
     assert len(other) == 0 and len(nodes) == 2293
     with pytest.raises(ValueError):
         nodes.score(lib.Sequence(text[:5000]), t)       # not the sequence the nodes came from
+
+
+@pytest.mark.gpu
+def test_sequence_properties_and_region_masking(lib):
+    """ref: tests/test_sequence.py:8-52, tests/test_mask.py, tests/test_gene_finder.py:237-270 (mask=True)."""
+    from oracle import oracle as orc
+    from pyrodigal_amd import benchdata
+    s = lib.Sequence("ATGCNNNNNNNNNNATGCNNNNNNNNTGC", mask=True, mask_size=0)
+    assert [(m.begin, m.end) for m in s.masks] == [(4, 14), (18, 26)]
+    assert len(lib.Sequence("ATGCNNNNNNNNNNATGCNNNNNNNNTGC", mask=True, mask_size=10).masks) == 1
+    assert lib.Sequence("ATGCNNNNNNNNNNATGCNNNNNNNNTGC", mask=False).masks == []
+    assert s.unknown == 18 and s.gc == 6 / 29 and s.gc_known == pytest.approx(6 / 11)
+    assert repr(lib.Mask(1, 2)).endswith("Mask begin=1 end=2>")
+    text = bytearray(benchdata.synthetic_contig(40000, 0.5, 77))
+    for at, n in ((3000, 60), (12000, 400), (25000, 49), (31000, 1000)):
+        text[at:at + n] = b"N" * n
+    text = bytes(text)
+    t = lib.TrainingInfo.load(golden_path("GCF_001457455.1_NCTC11397_genomic_100kb.tinf_closed.bin.gz"))
+    genes = lib.GeneFinder(t, mask=True).find_genes(text)
+    assert [(m.begin, m.end) for m in genes.sequence.masks] == [(3000, 3060), (12000, 12400), (31000, 32000)]
+    o = orc.Oracle(text, mask=True, mask_size=50)
+    o.find_genes_single(orc.Training.load(golden_path("GCF_001457455.1_NCTC11397_genomic_100kb.tinf_closed.bin.gz")))
+    og = o.genes()
+    assert [(g.begin, g.end) for g in genes] == [(int(a), int(b)) for a, b in zip(og["begin"], og["end"])]
+    for g in genes:                                      # no gene runs across a masked region
+        assert not any(m.begin < g.end and g.begin - 1 < m.end for m in genes.sequence.masks)
+    with pytest.raises(ValueError):
+        lib.GeneFinder(t, mask=True).find_genes(lib.Sequence(text, mask=False))

@@ -86,3 +86,11 @@ def test_short_and_empty_sequences():
         assert o.find_genes_single(tinf) == 0
         assert o.find_genes_meta([tinf]) in (-1, 0)
         assert o.num_genes == 0
+
+
+def test_region_masks_match_reference_vectors():
+    """ref: tests/test_sequence.py:36-52 (mask=False / mask_size 0 and 10) -- pins Sequence._mask (lib.pyx:699-713)."""
+    s = "ATGCNNNNNNNNNNATGCNNNNNNNNTGC"
+    assert len(orc.Oracle(s, mask=False).masks()) == 0
+    assert orc.Oracle(s, mask=True, mask_size=0).masks().tolist() == [[4, 14], [18, 26]]
+    assert orc.Oracle(s, mask=True, mask_size=10).masks().tolist() == [[4, 14]]

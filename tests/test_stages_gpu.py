@@ -60,6 +60,38 @@ def test_extract_stage_fixtures(ctx, tt, closed):
         assert out[0]["n"] == 2293          # ref: tests/test_nodes.py:28-40
 
 
+def test_extract_stage_with_masks(ctx):
+    from pyrodigal_amd import _cabi
+    rng = np.random.default_rng(3)
+    s = bytearray(synthetic_contig(40000, 0.5, 33))
+    for n in (20, 50, 80, 200, 1000):
+        at = int(rng.integers(0, 39000)); s[at:at + n] = b"N" * n
+    seq = bytes(s)
+    for min_mask in (50, 0, 30):
+        out = ctx.nodes_stage([seq], _cabi.STAGE_EXTRACT, mask=True, min_mask=min_mask)
+        o = orc.Oracle(seq, mask=True, mask_size=min_mask)
+        o.extract(11, orc.Params()); o.sort()
+        check(out[0], o.nodes(), 1)
+    assert ctx.nodes_stage([seq], _cabi.STAGE_EXTRACT)[0]["n"] != out[0]["n"]
+
+
+def test_sequence_stage_gc_unknown_and_masks(ctx):
+    from pyrodigal_amd import _cabi
+    # ref: tests/test_sequence.py:36-52 (mask intervals), lib.pyx:664-697 (gc over all bases, unknown count)
+    s = "ATGCNNNNNNNNNNATGCNNNNNNNNTGC"
+    r = ctx.nodes_stage([s, s.lower(), "", "ACGTRYKM"], _cabi.STAGE_SEQUENCE, mask=True, min_mask=0)
+    assert r.masks[0].tolist() == [[4, 14], [18, 26]] and r.masks[1].tolist() == [[4, 14], [18, 26]]
+    assert len(r.masks[2]) == 0 and r.masks[3].tolist() == [[4, 8]]
+    assert r.contigs["n_unknown"].tolist() == [18, 18, 0, 4]
+    assert r.contigs["gc"][0] == 6 / 29 and r.contigs["gc"][3] == 2 / 8
+    r = ctx.nodes_stage([s], _cabi.STAGE_SEQUENCE, mask=True, min_mask=10)
+    assert r.masks[0].tolist() == [[4, 14]]
+    assert ctx.nodes_stage([s], _cabi.STAGE_SEQUENCE).masks is None          # ref: test_no_region_masking
+    big = synthetic_contig(5000, 0.5, 1) + b"N" * 3000 + synthetic_contig(100, 0.5, 2) + b"n" * 50
+    r = ctx.nodes_stage([big], _cabi.STAGE_SEQUENCE, mask=True)
+    assert r.masks[0].tolist() == [[5000, 8000], [8100, 8150]]
+
+
 def test_extract_stage_gene_length_options(ctx):
     from pyrodigal_amd import _cabi
     seq = synthetic_contig(50000, 0.45, 9)
