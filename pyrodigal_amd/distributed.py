@@ -13,6 +13,64 @@ def shard_contigs(n_contigs, rank, world):
     return list(range(rank, n_contigs, world))
 
 
+# nodes per bp of i.i.d. DNA at 30 / 40 / 50 / 60 / 65 / 70 % GC (probe): what the DP time follows
+_NODE_DENSITY_GC = np.array([0.30, 0.40, 0.50, 0.60, 0.65, 0.70])
+_NODE_DENSITY = np.array([0.014, 0.024, 0.037, 0.048, 0.052, 0.054])
+
+
+def estimate_work(seqs, model_gcs=None, sample=8192):
+    """Estimated node-passes of each contig: length x node density(gc) x models in its GC window.
+
+    GC comes from a strided sample of at most ``sample`` bases per contig, so the estimate costs O(sample)
+    per contig whatever its length.  ``model_gcs``: the GC of each loaded model (meta mode); None = 1 model."""
+    work = np.zeros(len(seqs))
+    mg = None if model_gcs is None else np.asarray(model_gcs, float)
+    for i, s in enumerate(seqs):
+        n = len(s)
+        if n == 0:
+            continue
+        b = np.frombuffer(s if isinstance(s, (bytes, bytearray)) else s.encode("ascii"), np.uint8)
+        if n > sample:
+            b = b[:: n // sample]
+        up = b & 0xDF                                       # upper case
+        gc = float(np.count_nonzero((up == ord("G")) | (up == ord("C")))) / len(b)
+        bins = 1
+        if mg is not None:                                  # ref: lib.pyx:5335-5336
+            low, high = min(0.65, 0.88495 * gc - 0.0102337), max(0.35, 0.86596 * gc + 0.1131991)
+            bins = max(1, int(np.count_nonzero((mg >= low) & (mg <= high))))
+        work[i] = n * float(np.interp(gc, _NODE_DENSITY_GC, _NODE_DENSITY)) * bins
+    return work
+
+
+def pack_contigs(work, world):
+    """Static greedy bin packing, largest first (LPT): returns, per rank, the ascending list of contig indices.
+
+    Deterministic (ties broken by index) so that every rank computes the same assignment without talking."""
+    work = np.asarray(work, float)
+    order = sorted(range(len(work)), key=lambda i: (-work[i], i))
+    load = [0.0] * world
+    parts = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        parts[r].append(i)
+        load[r] += work[i]
+    return [sorted(p) for p in parts]
+
+
+def find_genes_sharded(ctx, seqs, dist=None, device=None, model_gcs=None, **kw):
+    """``ctx.find_genes_batch`` over this rank's share of ``seqs`` (the same list on every rank), then one gather.
+
+    Returns (genes with global contig indices from every rank, this rank's BatchResult, this rank's contig indices)."""
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    mine = pack_contigs(estimate_work(seqs, model_gcs), world)[rank]
+    res = ctx.find_genes_batch([seqs[i] for i in mine], **kw)
+    genes = res.genes.copy()
+    if len(genes):
+        genes["contig"] = np.asarray(mine, np.int32)[genes["contig"]]
+    return gather_genes(genes, dist, device), res, mine
+
+
 def gather_genes(genes, dist=None, device=None):
     """All-gather a structured ``pga_gene`` array across ranks; returns the concatenation in rank order."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:

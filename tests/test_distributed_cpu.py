@@ -62,3 +62,29 @@ def test_benchdata_is_deterministic_and_matches_spec():
     assert len(models) == 16 and all(len(m[1]) == 558392 for m in models)
     gcs = [np.frombuffer(m[1][:8], np.float64)[0] for m in models]
     assert gcs == sorted(gcs) and 0.29 < gcs[0] < 0.32 and 0.69 < gcs[-1] < 0.72
+
+
+def test_pack_contigs_balances_by_estimated_work():
+    """static greedy bin packing of contigs by estimated work, largest first, identical on every rank."""
+    from pyrodigal_amd import benchdata, distributed
+    rng = np.random.default_rng(5)
+    lengths = (rng.pareto(1.5, 400) * 3000 + 500).astype(int)
+    seqs = [benchdata.synthetic_contig(int(n), 0.30 + 0.40 * (i % 41) / 40, 900 + i) for i, n in enumerate(lengths)]
+    seqs.append(b"")
+    model_gcs = np.linspace(0.30, 0.70, 16)
+    work = distributed.estimate_work(seqs, model_gcs)
+    assert work[-1] == 0 and np.all(work[:-1] > 0)
+    # more work for a GC-rich contig of the same length (denser nodes), and for more models in the window
+    a, b = benchdata.synthetic_contig(20000, 0.35, 1), benchdata.synthetic_contig(20000, 0.65, 2)
+    assert distributed.estimate_work([b])[0] > distributed.estimate_work([a])[0]
+    assert distributed.estimate_work([a], model_gcs)[0] > distributed.estimate_work([a], model_gcs[:2])[0]
+    for world in (1, 2, 4, 8):
+        parts = distributed.pack_contigs(work, world)
+        assert sorted(i for p in parts for i in p) == list(range(len(seqs)))
+        assert all(p == sorted(p) for p in parts)
+        loads = np.array([work[p].sum() for p in parts])
+        assert loads.max() <= work.sum() / world + work.max() + 1e-9          # the LPT guarantee
+        assert parts == distributed.pack_contigs(work, world)                  # deterministic
+    rr = np.array([work[distributed.shard_contigs(len(seqs), r, 8)].sum() for r in range(8)])
+    lpt = np.array([work[p].sum() for p in distributed.pack_contigs(work, 8)])
+    assert lpt.max() <= rr.max()
