@@ -10,8 +10,8 @@ CPU path: without the library or a gfx950 device, calls raise `RuntimeError`.
 reference (lib.pyx:2501-2595, 1315-1357) over `pga_nodes_stage` / `pga_score_connections`; the scorer
 works on whole node arrays, not node by node (SURVEY 8b: per-node granularity is useless for a GPU).
 
-Not provided this round (raise `NotImplementedError`): `GeneFinder.train`, `Gene.translate` and the
-GFF / GenBank / FASTA writers.
+`Gene.translate` and the `Genes.write_*` writers are host-side formatting, as in the reference.
+Not provided this round (raises `NotImplementedError`): `GeneFinder.train`.
 """
 import gzip
 import threading
@@ -124,6 +124,7 @@ MIN_SINGLE_GENOME = 20000
 IDEAL_SINGLE_GENOME = 100000
 TRANSLATION_TABLES = frozenset(set(range(1, 7)) | set(range(9, 17)) | set(range(21, 27)) | {29, 30, 32, 33})
 PRODIGAL_VERSION = "v2.6.3+c1e2d36"
+_VERSION = "0.1.0"
 TRAINING_INFO_SIZE = 558392
 
 _RBS_MOTIF = [
@@ -138,7 +139,84 @@ _RBS_SPACER = [
     "11-12bp", "3-4bp", "5-10bp", "3-4bp", "5-10bp", "11-12bp", "3-4bp", "5-10bp",
 ]
 _NODE_TYPE = ["ATG", "GTG", "TTG", "Edge"]
+
+# NCBI genetic codes: amino acids of the 64 codons in TCAG order (first base slowest).  Table numbers as in
+# the reference (_translation.h; TRANSLATION_TABLES above).
+_NCBI_CODES = {
+    1: "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG",
+    2: "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNKKSS**VVVVAAAADDEEGGGG",
+    3: "FFLLSSSSYY**CCWWTTTTPPPPHHQQRRRRIIMMTTTTNNKKSSRRVVVVAAAADDEEGGGG",
+    4: "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG",
+    5: "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNKKSSSSVVVVAAAADDEEGGGG",
+    6: "FFLLSSSSYYQQCC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG",
+    9: "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNNKSSSSVVVVAAAADDEEGGGG",
+    10: "FFLLSSSSYY**CCCWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG",
+    11: "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG",
+    12: "FFLLSSSSYY**CC*WLLLSPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG",
+    13: "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNKKSSGGVVVVAAAADDEEGGGG",
+    14: "FFLLSSSSYYY*CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNNKSSSSVVVVAAAADDEEGGGG",
+    15: "FFLLSSSSYY*QCC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG",
+    16: "FFLLSSSSYY*LCC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG",
+    21: "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNNKSSSSVVVVAAAADDEEGGGG",
+    22: "FFLLSS*SYY*LCC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG",
+    23: "FF*LSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG",
+    24: "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSSKVVVVAAAADDEEGGGG",
+    25: "FFLLSSSSYY**CCGWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG",
+    26: "FFLLSSSSYY**CC*WLLLAPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG",
+    29: "FFLLSSSSYYYYCC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG",
+    30: "FFLLSSSSYYEECC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG",
+    32: "FFLLSSSSYY*WCC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG",
+    33: "FFLLSSSSYYY*CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSSKVVVVAAAADDEEGGGG",
+}
+
+
+def _digit_order_table(str code):
+    """Re-index a TCAG-ordered code by the digit alphabet used on the device (A0 G1 C2 T3)."""
+    ncbi = (2, 3, 1, 0)     # digit -> position in TCAG
+    return "".join(code[ncbi[a] * 16 + ncbi[b] * 4 + ncbi[c]] for a in range(4) for b in range(4) for c in range(4)).encode("ascii")
+
+_CODE_BY_DIGITS = {tt: _digit_order_table(code) for tt, code in _NCBI_CODES.items()}
+_DIGIT_OF = bytes(0 if c in b"Aa" else 1 if c in b"Gg" else 2 if c in b"Cc" else 3 if c in b"Tt" else 6 for c in range(256))
+
+
+cdef bint _codon_is_stop(int x0, int x1, int x2, int tt) noexcept nogil:       # ref: _sequence.h:19-43
+    if x0 == 0 and tt == 2:
+        return x1 == 1 and (x2 == 0 or x2 == 1)                                  # AGA / AGG
+    if x0 != 3:
+        return False
+    if x1 == 0 and x2 == 1:                                                      # TAG
+        return tt in (1, 2, 3, 4, 5, 9, 10, 11, 12, 13, 14, 21, 23, 24, 25, 26, 33)
+    if x1 == 1 and x2 == 0:                                                      # TGA
+        return tt in (1, 6, 11, 12, 15, 16, 22, 23, 26, 29, 30, 32)
+    if x1 == 0 and x2 == 0:                                                      # TAA
+        return tt in (1, 2, 3, 4, 5, 9, 10, 11, 12, 13, 15, 16, 21, 22, 23, 24, 25, 26, 32)
+    if tt == 22:
+        return x1 == 2 and x2 == 0                                               # TCA
+    if tt == 23:
+        return x1 == 3 and x2 == 0                                               # TTA
+    return False
+
+
+cdef bint _codon_is_start(int x0, int x1, int x2, int tt) noexcept nogil:      # ref: _sequence.h:45-73
+    if x1 != 3 or x2 != 1:
+        return False
+    if x0 == 0:
+        return True
+    if tt in (6, 10, 14, 15, 16, 2):
+        return False
+    if x0 == 1:
+        return not (tt == 1 or tt == 3 or tt == 12 or tt == 2)
+    if x0 == 3:
+        return not (tt < 4 or tt == 9 or (21 <= tt < 25))
+    return False
+
+
+def _stop_codon_set(int tt):
+    return frozenset((a, b, c) for a in range(4) for b in range(4) for c in range(4) if _codon_is_stop(a, b, c, tt))
+
+_STOP_CODONS = {tt: _stop_codon_set(tt) for tt in _NCBI_CODES}
 _COMPLEMENT = bytes.maketrans(b"ACGTN", b"TGCAN")
+_COMPLEMENT_ANY = bytes.maketrans(b"ACGTacgt", b"TGCAtgca")
 
 
 cdef object _raise_for(pga_ctx* ctx, int rc, str what):
@@ -742,15 +820,71 @@ cdef class Gene:
         return _confidence(self.g.cscore + self.g.sscore, self.owner.training_info.start_weight)
 
     def sequence(self):
-        """The nucleotide sequence of the gene (reverse-complemented on the reverse strand)."""
+        """The nucleotide sequence of the gene, reverse-complemented on the reverse strand; unknown bases read N
+        (ref: lib.pyx:2874-2930)."""
         cdef bytes s = self.owner.sequence.data[self.g.begin - 1:self.g.end].upper()
         s = bytes(c if c in b"ACGT" else 78 for c in s)
         if self.g.strand != 1:
             s = s.translate(_COMPLEMENT)[::-1]
         return s.decode("ascii")
 
-    def translate(self, *args, **kwargs):
-        raise NotImplementedError("translation is host-side output code, not part of the HIP path")
+    def translate(self, object translation_table=None, object unknown_residue="X", bint include_stop=True, bint strict=True):
+        """Translate the gene into a protein sequence (ref: lib.pyx:2932-3047, `Sequence._amino` 770-789).
+
+        The first codon of a gene that does not start at an edge reads M when it is a start codon of the table;
+        a stop codon of the table reads `*`; a codon with an unknown base reads `unknown_residue`, unless
+        `strict=False` and every completion of the codon gives the same residue."""
+        cdef int tt, owner_tt = self.owner.training_info.translation_table
+        if translation_table is None:
+            tt = owner_tt
+        elif translation_table not in _CODE_BY_DIGITS:
+            raise ValueError("%r is not a valid translation table index" % (translation_table,))
+        else:
+            tt = translation_table
+            if _STOP_CODONS[tt] != _STOP_CODONS[owner_tt]:
+                import warnings
+                warnings.warn("requested translation table (%r) has different STOP codons than the one these genes "
+                              "were called with (%r), consider calling genes with the proper translation table instead."
+                              % (translation_table, owner_tt), stacklevel=2)
+        cdef bytes unk = unknown_residue.encode("ascii") if isinstance(unknown_residue, str) else bytes(unknown_residue)
+        if len(unk) != 1:
+            raise ValueError("`unknown_residue` must be a single character")
+        cdef bytes nuc = self.owner.sequence.data[self.g.begin - 1:self.g.end]
+        if self.g.strand != 1:
+            nuc = nuc.translate(_COMPLEMENT_ANY)[::-1]
+        cdef bytes dig = nuc.translate(_DIGIT_OF)
+        cdef const unsigned char* d = <const unsigned char*> PyBytes_AS_STRING(dig)
+        cdef const char* table = PyBytes_AS_STRING(_CODE_BY_DIGITS[tt])
+        cdef ssize_t n = len(dig) // 3, i, k
+        # partial flags are in sequence orientation; the gene's own first / last codon follow its strand
+        cdef bint start_edge = self.g.partial_begin if self.g.strand == 1 else self.g.partial_end
+        cdef bint stop_edge = self.g.partial_end if self.g.strand == 1 else self.g.partial_begin
+        if not stop_edge and not include_stop:
+            n -= 1
+        cdef bytearray out = bytearray(max(n, 0))
+        cdef int x0, x1, x2, y
+        cdef char aa, c2
+        for i in range(n):
+            x0 = d[3 * i]; x1 = d[3 * i + 1]; x2 = d[3 * i + 2]
+            if x0 <= 3 and x1 <= 3 and x2 <= 3:
+                if _codon_is_stop(x0, x1, x2, tt):
+                    aa = 42                                                      # '*'
+                elif i == 0 and not start_edge and _codon_is_start(x0, x1, x2, tt):
+                    aa = 77                                                      # 'M'
+                else:
+                    aa = table[(x0 << 4) + (x1 << 2) + x2]
+            else:
+                aa = 88                                                          # 'X'
+                if not strict and x0 <= 3 and (x1 <= 3) != (x2 <= 3):
+                    # one unknown base in second or third position: unambiguous when all four completions agree
+                    aa = table[(x0 << 4) + ((x1 if x1 <= 3 else 0) << 2) + (x2 if x2 <= 3 else 0)]
+                    for y in range(1, 4):
+                        c2 = table[(x0 << 4) + ((x1 if x1 <= 3 else y) << 2) + (x2 if x2 <= 3 else y)]
+                        if c2 != aa:
+                            aa = 88
+                            break
+            out[i] = unk[0] if aa == 88 else aa
+        return out.decode("ascii")
 
     cpdef str _gene_data(self, object sequence_id, ssize_t index):
         motif, spacer = self._rbs()
@@ -785,6 +919,170 @@ cdef class Genes:
 
     def __bool__(self):
         return len(self._genes) > 0
+
+    # --- writers (ref: lib.pyx:3405-3894): host-side formatting of the results, byte-compatible with the
+    #     reference except for the tool name and version strings -------------------------------------------
+
+    cdef tuple _model(self):
+        """(TrainingInfo, description) the header lines report (ref: lib.pyx:3575-3583)."""
+        if self.meta:
+            if self.metagenomic_bin is None:
+                raise RuntimeError("no metagenomic model was selected for this sequence")
+            return self.training_info, self.metagenomic_bin.description
+        return self.training_info, "Ab initio"
+
+    def write_gff(self, object file, str sequence_id, bint header=True, bint include_translation_table=False,
+                  bint full_id=True, str version_separator="_v"):
+        """Write the genes to `file` in General Feature Format (ref: lib.pyx:3534-3644)."""
+        cdef ssize_t n = 0, i
+        cdef Gene gene
+        tinf, desc = self._model()
+        run = "Metagenomic" if self.meta else "Single"
+        if header:
+            n += file.write("##gff-version  3\n")
+        n += file.write('# Sequence Data: seqnum=%d;seqlen=%d;seqhdr="%s"\n' % (self._num_seq, len(self.sequence), sequence_id))
+        n += file.write('# Model Data: version=pyrodigal_amd.v%s;run_type=%s;model="%s";gc_cont=%.2f;transl_table=%d;uses_sd=%d\n'
+                        % (_VERSION, run, desc, tinf.gc * 100, tinf.translation_table, int(tinf.uses_sd)))
+        for i, gene in enumerate(self._genes):
+            ident = gene._gene_data(sequence_id if full_id else self._num_seq, i)
+            n += file.write("%s\tpyrodigal_amd%s%s\tCDS\t%d\t%d\t%.1f\t%s\t0\t%s;" % (
+                sequence_id, version_separator, _VERSION, gene.g.begin, gene.g.end, gene.g.sscore + gene.g.cscore,
+                "+" if gene.g.strand > 0 else "-", ident))
+            if include_translation_table:
+                n += file.write("transl_table=%d;" % tinf.translation_table)
+            n += file.write(gene._score_data())
+            n += file.write("\n")
+        return n
+
+    def write_genes(self, object file, str sequence_id, object width=70, bint full_id=False):
+        """Write the nucleotide sequences of the genes to `file` in FASTA format (ref: lib.pyx:3646-3706)."""
+        cdef ssize_t n = 0, i, k
+        cdef Gene gene
+        for i, gene in enumerate(self._genes):
+            n += file.write(">%s_%d # %d # %d # %d # %s\n" % (sequence_id, i + 1, gene.g.begin, gene.g.end, gene.g.strand,
+                                                              gene._gene_data(sequence_id if full_id else self._num_seq, i)))
+            seq = gene.sequence()
+            for k in range(0, len(seq), width):
+                n += file.write(seq[k:k + width])
+                n += file.write("\n")
+        return n
+
+    def write_translations(self, object file, str sequence_id, object width=60, object translation_table=None,
+                           bint include_stop=True, bint strict_translation=True, bint full_id=False):
+        """Write the protein translations of the genes to `file` in FASTA format (ref: lib.pyx:3708-3792)."""
+        cdef ssize_t n = 0, i, k
+        cdef Gene gene
+        if translation_table is not None and translation_table not in _CODE_BY_DIGITS:
+            raise ValueError("%r is not a valid translation table index" % (translation_table,))
+        for i, gene in enumerate(self._genes):
+            n += file.write(">%s_%d # %d # %d # %d # %s\n" % (sequence_id, i + 1, gene.g.begin, gene.g.end, gene.g.strand,
+                                                              gene._gene_data(sequence_id if full_id else self._num_seq, i)))
+            prot = gene.translate(translation_table, include_stop=include_stop, strict=strict_translation)
+            for k in range(0, len(prot), width):
+                n += file.write(prot[k:k + width])
+                n += file.write("\n")
+        return n
+
+    def write_genbank(self, object file, str sequence_id, str division="BCT", object date=None, object translation_table=None,
+                      bint strict_translation=True):
+        """Write the genes and the sequence to `file` as a complete GenBank record (ref: lib.pyx:3405-3532)."""
+        import datetime
+        import textwrap
+        cdef ssize_t n = 0, i, j
+        cdef Gene gene
+        if translation_table is None:
+            if self.training_info is not None:
+                translation_table = self.training_info.translation_table
+        elif translation_table not in _CODE_BY_DIGITS:
+            raise ValueError("%r is not a valid translation table index" % (translation_table,))
+        if date is None:
+            date = datetime.date.today()
+        elif not isinstance(date, datetime.date):
+            raise TypeError("Expected datetime.date, found %s" % type(date).__name__)
+        slen = len(self.sequence)
+        n += file.write("LOCUS       {:<23} {} bp    DNA     linear   {} {}\n".format(sequence_id, slen, division, date.strftime("%d-%b-%y").upper()))
+        n += file.write("REFERENCE   1  (bases 1 to %d)\n" % slen)
+        n += file.write("  AUTHORS   Hyatt,D., Chen,G-L., LoCascio,P.F., Land,M.L., Larimer,F.W.\n")
+        n += file.write("            Hauser,L.J.\n")
+        n += file.write("  TITLE     Prodigal: prokaryotic gene recognition and translation initiation\n")
+        n += file.write("            site identification\n")
+        n += file.write("  JOURNAL   BMC Bioinformatics. 2010;11:119.\n")
+        n += file.write("   PUBMED   20211023\n")
+        n += file.write("FEATURES             Location/Qualifiers\n")
+        for i, gene in enumerate(self._genes):
+            start_edge = gene.g.partial_begin if gene.g.strand == 1 else gene.g.partial_end
+            stop_edge = gene.g.partial_end if gene.g.strand == 1 else gene.g.partial_begin
+            begin = "<%d" % gene.g.begin if start_edge else "%d" % gene.g.begin
+            end = ">%d" % gene.g.end if stop_edge else "%d" % gene.g.end
+            loc = "%s..%s" % (begin, end)
+            n += file.write("     CDS             %s\n" % (loc if gene.g.strand == 1 else "complement(%s)" % loc))
+            pad = " " * 21
+            n += file.write('%s/codon_start=1\n' % pad)
+            n += file.write('%s/inference="ab initio prediction:pyrodigal_amd:%s"\n' % (pad, _VERSION))
+            n += file.write('%s/locus_tag="%s_%d"\n' % (pad, sequence_id, i + 1))
+            n += file.write('%s/transl_table=%s\n' % (pad, translation_table))
+            tr = '/translation="%s"' % gene.translate(translation_table=translation_table, include_stop=False, strict=strict_translation)
+            for block in textwrap.wrap(tr, 59):
+                n += file.write(pad + block + "\n")
+        seq = str(self.sequence).lower()
+        n += file.write("ORIGIN\n")
+        for i in range(0, len(seq), 60):
+            n += file.write("{:>9}".format(i + 1))
+            for j in range(i, min(i + 60, len(seq)), 10):
+                n += file.write(" " + seq[j:j + 10])
+            n += file.write("\n")
+        n += file.write("//\n")
+        return n
+
+    def write_scores(self, object file, str sequence_id, bint header=True):
+        """Write the scores of every start node, grouped by stop codon, to `file` (ref: lib.pyx:3794-3894)."""
+        cdef ssize_t n = 0
+        if self.nodes is None:
+            raise RuntimeError("write_scores needs the nodes: create the GeneFinder with keep_nodes=True")
+        tinf, _ = self._model()
+        f = self.nodes._f
+        rbs_wt = tinf._f64(80, 28)
+        cdef double st_wt = tinf.start_weight, no_mot = tinf.missing_motif_weight, rbs1, rbs2
+        cdef bint uses_sd = tinf.uses_sd
+        # Prodigal's stopcmp_nodes: stop_val ascending, then strand descending, then ndx ascending
+        order = np.lexsort((f["ndx"], -f["strand"].astype(np.int32), f["stop_val"]))
+        if header:
+            n += file.write('# Sequence Data: seqnum=%d;seqlen=%d;seqhdr="%s"\n' % (self._num_seq, len(self.sequence), sequence_id))
+            n += file.write("# Run Data: version=pyrodigal_amd.v%s;gc_cont=%.2f;transl_table=%d;uses_sd=%d\n"
+                            % (_VERSION, tinf.gc * 100, tinf.translation_table, int(uses_sd)))
+            n += file.write("Beg\tEnd\tStd\tTotal\tCodPot\tStrtSc\tCodon\tRBSMot\tSpacer\tRBSScr\tUpsScr\tTypeScr\tGCCont\n")
+        prev_stop, prev_strand = -1, 0
+        for i in order:
+            if f["type"][i] == 3:
+                continue
+            ndx = int(f["ndx"][i]); stop_val = int(f["stop_val"][i]); strand = int(f["strand"][i])
+            if stop_val != prev_stop or strand != prev_strand:
+                prev_stop, prev_strand = stop_val, strand
+                n += file.write("\n")
+            if strand == 1:
+                n += file.write("%d\t%d\t+\t" % (ndx + 1, stop_val + 3))
+            else:
+                n += file.write("%d\t%d\t-\t" % (stop_val - 1, ndx + 1))
+            cs = float(f["cscore"][i]); ss = float(f["sscore"][i]); rs = float(f["rscore"][i])
+            n += file.write("%.2f\t%.2f\t%.2f\t%s\t" % (cs + ss, cs, ss, ["ATG", "GTG", "TTG", "Edge"][3 if f["edge"][i] else int(f["type"][i])]))
+            r0 = int(f["rbs"][i][0]); r1 = int(f["rbs"][i][1])
+            rbs1 = rbs_wt[r0] * st_wt; rbs2 = rbs_wt[r1] * st_wt
+            mot = float(f["mot_score"][i]) * st_wt
+            if uses_sd:
+                k = r0 if rbs1 > rbs2 else r1
+                n += file.write("%s\t%s\t%.2f\t" % (_RBS_MOTIF[k], _RBS_SPACER[k], rs))
+            elif no_mot > -0.5 and rbs1 > rbs2 and rbs1 > mot:
+                n += file.write("%s\t%s\t%.2f\t" % (_RBS_MOTIF[r0], _RBS_SPACER[r0], rs))
+            elif no_mot > -0.5 and rbs2 >= rbs1 and rbs2 > mot:
+                n += file.write("%s\t%s\t%.2f\t" % (_RBS_MOTIF[r1], _RBS_SPACER[r1], rs))
+            elif f["mot_len"][i] == 0:
+                n += file.write("None\tNone\t%.2f\t" % rs)
+            else:
+                motif = "".join("AGCT"[(int(f["mot_ndx"][i]) >> (2 * q)) & 3] for q in range(int(f["mot_len"][i])))
+                n += file.write("%s\t%dbp\t%.2f\t" % (motif, int(f["mot_spacer"][i]), rs))
+            n += file.write("%.2f\t%.2f\t%.3f\n" % (float(f["uscore"][i]), float(f["tscore"][i]), float(f["gc_cont"][i])))
+        n += file.write("\n")
+        return n
 
 
 # --- GeneFinder (ref: lib.pyx:5073-5575) ------------------------------------------------------

@@ -186,3 +186,69 @@ def test_sequence_properties_and_region_masking(lib):
         assert not any(m.begin < g.end and g.begin - 1 < m.end for m in genes.sequence.masks)
     with pytest.raises(ValueError):
         lib.GeneFinder(t, mask=True).find_genes(lib.Sequence(text, mask=False))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["SRR492066", "KK037166", "MIIJ01000039"])
+def test_writers_reproduce_reference_output_files(lib, name):
+    """Gene.translate / Genes.write_translations / write_genes against the reference's own golden files, byte for
+    byte (ref: tests/test_genes.py; goldens written by Prodigal: *.single.faa / *.single.fna)."""
+    import gzip
+    from oracle import oracle as orc
+    hdr, seq = read_fasta(name + ".fna.gz")[0]
+    seq_id = hdr.split()[0]
+    tinf = lib.TrainingInfo(raw=orc.Oracle(seq).train().tobytes())
+    genes = lib.GeneFinder(tinf).find_genes(seq)
+    out = io.StringIO()
+    n = genes.write_translations(out, seq_id)
+    assert out.getvalue() == gzip.open(golden_path(name + ".single.faa.gz"), "rt").read() and n == len(out.getvalue())
+    out = io.StringIO()
+    genes.write_genes(out, seq_id)
+    assert out.getvalue() == gzip.open(golden_path(name + ".single.fna.gz"), "rt").read()
+    # translate(): options (ref: lib.pyx:2932-3047)
+    g = next(x for x in genes if not x.partial_begin and not x.partial_end)
+    full = g.translate()
+    assert full.endswith("*") and g.translate(include_stop=False) == full[:-1] and full[0] == "M"
+    assert g.translate(translation_table=11) == full
+    with pytest.raises(ValueError):
+        g.translate(translation_table=7)
+    with pytest.warns(UserWarning):
+        g.translate(translation_table=4)                 # TGA is not a stop in table 4
+    # GFF / scores / GenBank: structure checks (the reference has no single-mode goldens for these)
+    out = io.StringIO(); genes.write_gff(out, seq_id)
+    lines = out.getvalue().splitlines()
+    assert lines[0] == "##gff-version  3" and lines[1].startswith("# Sequence Data: seqnum=1;seqlen=%d;" % len(seq))
+    assert 'run_type=Single;model="Ab initio"' in lines[2] and len(lines) == 3 + len(genes)
+    f = lines[3].split("\t")
+    assert f[0] == seq_id and f[2] == "CDS" and (int(f[3]), int(f[4])) == (genes[0].begin, genes[0].end)
+    assert f[5] == "%.1f" % genes[0].score and f[8].startswith("ID=%s_1;partial=" % seq_id) and ";conf=" in f[8]
+    out = io.StringIO(); genes.write_scores(out, seq_id)
+    rows = [r for r in out.getvalue().splitlines()[3:] if r]
+    starts = genes.nodes.array("type") != 3
+    assert len(rows) == int(starts.sum()) and all(len(r.split("\t")) == 13 for r in rows)
+    import datetime
+    out = io.StringIO(); genes.write_genbank(out, seq_id, date=datetime.date(2024, 1, 2))
+    gb = out.getvalue()
+    assert gb.startswith("LOCUS       %-23s %d bp    DNA     linear   BCT 02-JAN-24\n" % (seq_id, len(seq)))
+    assert gb.count("     CDS             ") == len(genes) and gb.rstrip().endswith("//")
+    assert '/translation="%s' % genes[0].translate(include_stop=False)[:30] in gb
+
+
+@pytest.mark.gpu
+def test_translate_unknown_bases_and_strictness(lib):
+    from pyrodigal_amd import benchdata
+    t = lib.TrainingInfo.load(golden_path("GCF_001457455.1_NCTC11397_genomic_100kb.tinf_closed.bin.gz"))
+    text = bytearray(benchdata.synthetic_contig(30000, 0.5, 5))
+    genes = lib.GeneFinder(t).find_genes(bytes(text))
+    g = max(genes, key=lambda x: x.end - x.begin)
+    # put one N in a third codon position and a whole unknown codon inside the longest gene, call again
+    at = g.begin - 1 + 3 * 20
+    codon_at = at if g.strand == 1 else at
+    text[codon_at + 2] = ord("N")
+    text[at + 30:at + 33] = b"NNN"
+    genes2 = lib.GeneFinder(t).find_genes(bytes(text))
+    g2 = next(x for x in genes2 if (x.begin, x.end) == (g.begin, g.end))
+    strict, loose = g2.translate(), g2.translate(strict=False)
+    assert strict.count("X") >= 1 and loose.count("X") <= strict.count("X") and len(strict) == len(loose)
+    assert g2.translate(unknown_residue="?").count("?") == strict.count("X")
+    assert "N" in g2.sequence()
