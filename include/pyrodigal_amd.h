@@ -165,6 +165,19 @@ int  pga_find_genes(pga_ctx*, const pga_batch*, const pga_params*, pga_result** 
 #define PGA_STAGE_SEQUENCE 4  /* Sequence.__init__ only: gc, n_unknown and masks per contig, no nodes (ref: lib.pyx:664-713) */
 int pga_nodes_stage(pga_ctx*, const pga_batch*, const pga_params*, int stage, int translation_table, pga_result** out);
 
+/* ---- FASTA ingest (host side) ---------------------------------------------- */
+/* Multi-record FASTA, plain or gzip, read in batches ready for pga_find_genes_batch / pga_batch_create
+ * (ref: src/pyrodigal/tests/fasta.py:59-86 `parse`, src/pyrodigal/cli.py:32-61).  headers[i] is the header line
+ * without '>' (id = first word, description = the rest); seqs[i] holds lens[i] letters with every blank
+ * removed, not NUL-terminated.  The arrays are valid until the next call on the same reader; a batch ends
+ * after max_records records or once max_bases bases are exceeded (0 = no limit); *n_records == 0 at end of file. */
+typedef struct pga_fasta pga_fasta;
+int         pga_fasta_open(const char* path, pga_fasta** out);
+int         pga_fasta_next(pga_fasta*, int64_t max_bases, int32_t max_records, int32_t* n_records,
+                           const char* const** headers, const char* const** seqs, const int64_t** lens);
+const char* pga_fasta_error(const pga_fasta*);
+void        pga_fasta_close(pga_fasta*);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,7 @@ EXPORTS = [
     "pga_create", "pga_destroy", "pga_last_error", "pga_device_info", "pga_set_models",
     "pga_score_connections", "pga_find_genes_batch", "pga_result_free",
     "pga_batch_create", "pga_batch_free", "pga_find_genes", "pga_nodes_stage",
+    "pga_fasta_open", "pga_fasta_next", "pga_fasta_error", "pga_fasta_close",
 ]
 STAGE_EXTRACT, STAGE_SCORE, STAGE_OVERLAP, STAGE_SEQUENCE = 1, 2, 3, 4
 
@@ -101,6 +102,11 @@ def load():
     L.pga_find_genes.restype = ctypes.c_int; L.pga_find_genes.argtypes = [vp, vp, _P(Params), _P(_P(Result))]
     L.pga_nodes_stage.restype = ctypes.c_int
     L.pga_nodes_stage.argtypes = [vp, vp, _P(Params), ctypes.c_int, ctypes.c_int, _P(_P(Result))]
+    L.pga_fasta_open.restype = ctypes.c_int; L.pga_fasta_open.argtypes = [ctypes.c_char_p, _P(vp)]
+    L.pga_fasta_next.restype = ctypes.c_int
+    L.pga_fasta_next.argtypes = [vp, i64, i32, _P(i32), _P(_P(ctypes.c_char_p)), _P(_P(vp)), _P(_P(i64))]
+    L.pga_fasta_error.restype = ctypes.c_char_p; L.pga_fasta_error.argtypes = [vp]
+    L.pga_fasta_close.restype = None; L.pga_fasta_close.argtypes = [vp]
     _lib = L
     return L
 
@@ -311,3 +317,49 @@ Context.upload = _upload
 Context.nodes_stage = _nodes_stage
 Context.find_genes = _find_genes
 Context.find_genes_batch = _find_genes_batch
+
+
+class FastaReader:
+    """Multi-record FASTA reader (plain or gzip) of the C library (ref: tests/fasta.py:59-86 `parse`).
+
+    ``batches()`` yields lists of ``(id, description, sequence_bytes)`` bounded by a base / record budget, the
+    shape ``Context.find_genes_batch`` takes; ``records()`` yields them one by one."""
+
+    def __init__(self, path):
+        self.L = load()
+        self.h = ctypes.c_void_p()
+        rc = self.L.pga_fasta_open(os.fsencode(path), ctypes.byref(self.h))
+        if rc != PGA_OK:
+            raise (MemoryError if rc == PGA_ENOMEM else OSError)("cannot open %r" % (path,))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pga_fasta_close(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def batches(self, max_bases=64 << 20, max_records=0):
+        n = ctypes.c_int32()
+        hdr = _P(ctypes.c_char_p)(); seq = _P(ctypes.c_void_p)(); lens = _P(ctypes.c_int64)()
+        while True:
+            rc = self.L.pga_fasta_next(self.h, max_bases, max_records, ctypes.byref(n), ctypes.byref(hdr), ctypes.byref(seq), ctypes.byref(lens))
+            if rc != PGA_OK:
+                raise ValueError(self.L.pga_fasta_error(self.h).decode("utf-8", "replace"))
+            if n.value == 0:
+                return
+            out = []
+            for i in range(n.value):
+                fields = hdr[i].decode("utf-8", "replace").split(maxsplit=1)
+                out.append((fields[0] if fields else "", fields[1] if len(fields) > 1 else "", ctypes.string_at(seq[i], lens[i])))
+            yield out
+
+    def records(self):
+        for batch in self.batches():
+            yield from batch
