@@ -74,7 +74,7 @@ int ensure_pin(pga_ctx* c, const char* name, size_t bytes, void** out) {
 #define DEVBUF(var, type, name, count) type* var; { void* p__; int rc__ = ensure_dev(c, name, sizeof(type) * (size_t)(count) + 64, &p__); if (rc__) return rc__; var = (type*)p__; }
 #define PINBUF(var, type, name, count) type* var; { void* p__; int rc__ = ensure_pin(c, name, sizeof(type) * (size_t)(count) + 64, &p__); if (rc__) return rc__; var = (type*)p__; }
 
-// ---- host tail: nodes of one contig for its winning model ----------------------------------
+// ---- tail: nodes of one contig for its winning model (device functions; one thread walks a contig's path) ----
 struct NodeView {
     int n;
     const int32_t* ndx; const int32_t* stop_val; const uint8_t* type; const int8_t* strand; const uint8_t* edge;
@@ -83,10 +83,10 @@ struct NodeView {
 };
 struct GeneRec { int begin, end, start_ndx, stop_ndx; };
 
-inline bool is_stop_n(const NodeView& v, int i) { return v.type[i] == PGA_T_STOP; }
+__host__ __device__ inline bool is_stop_n(const NodeView& v, int i) { return v.type[i] == PGA_T_STOP; }
 
 // ref: _connection.h:52-78
-double igm_same_h(const NodeView& v, int a, int b, double st_wt) {
+__host__ __device__ double igm_same_h(const NodeView& v, int a, int b, double st_wt) {
     const int dist = abs(v.ndx[a] - v.ndx[b]);
     const bool ovl = v.ndx[a] + 2 * v.strand[a] >= v.ndx[b];
     double r = 0.0;
@@ -98,72 +98,93 @@ double igm_same_h(const NodeView& v, int a, int b, double st_wt) {
     else if ((dist <= PGA_OPER_DIST && !ovl) || dist * 4 < PGA_OPER_DIST) r += (2.0 - (double)dist / PGA_OPER_DIST) * 0.15 * st_wt;
     return r;
 }
-inline double igm_h(const NodeView& v, int a, int b, double st_wt) {   // ref: _connection.h:81-91
+__host__ __device__ inline double igm_h(const NodeView& v, int a, int b, double st_wt) {   // ref: _connection.h:81-91
     return v.strand[a] == v.strand[b] ? igm_same_h(v, a, b, st_wt) : -0.15 * st_wt;
 }
 
+// The reference walks down from node `from` until it meets a node at position `pos` (the other end of the ORF, which
+// always exists): positions are sorted, so the first hit of that walk is the LAST node at or below `from` with
+// ndx == pos, which a binary search finds in O(log n) loads instead of one dependent load per node of the gene.
+__host__ __device__ inline int walk_down_to(const NodeView& v, int from, int pos) {
+    int a = 0, b = from + 1;                      // first index in [0, from] with ndx > pos
+    while (a < b) { const int m = (a + b) >> 1; if (v.ndx[m] <= pos) a = m + 1; else b = m; }
+    return a - 1;
+}
+
 // ref: lib.pyx:1253-1295 (_disentangle_overlaps, _max_forward_pointers)
-void untangle(NodeView& v, int mx) {
-    for (int p = mx; v.traceb[p] != -1; p = v.traceb[p]) {
-        const int nx = v.traceb[p];
-        if (v.strand[p] == -1 && is_stop_n(v, p) && v.strand[nx] == 1 && is_stop_n(v, nx) && v.ov_mark[p] != -1 && v.ndx[p] > v.ndx[nx]) {
-            const int tmp = v.star_ptr[3 * p + v.ov_mark[p]];
-            int k = tmp;
-            while (v.ndx[k] != v.stop_val[tmp]) k--;
+__host__ __device__ int untangle(NodeView& v, int mx, int32_t* __restrict__ path) {
+    // Every test reads its operands first, unconditionally: the loads of one step then leave together instead of one
+    // round trip per `&&`.
+    for (int p = mx, nx = v.traceb[p]; nx != -1; p = nx, nx = v.traceb[p]) {
+        const int sp = v.strand[p], sn = v.strand[nx], ov = v.ov_mark[p], np = v.ndx[p], nn = v.ndx[nx];
+        const bool stp = is_stop_n(v, p), stn = is_stop_n(v, nx);
+        if ((sp == -1) & stp & (sn == 1) & stn & (ov != -1) & (np > nn)) {
+            const int tmp = v.star_ptr[3 * p + ov];
+            const int k = walk_down_to(v, tmp, v.stop_val[tmp]);
             v.traceb[p] = tmp; v.traceb[tmp] = k; v.ov_mark[k] = -1; v.traceb[k] = nx;
+            nx = tmp;                                  // the walk continues through the nodes just spliced in
         }
     }
-    for (int p = mx; v.traceb[p] != -1; p = v.traceb[p]) {
-        const int nx = v.traceb[p];
-        const bool p_rb = v.strand[p] == -1 && !is_stop_n(v, p), p_fs = v.strand[p] == 1 && is_stop_n(v, p), p_rs = v.strand[p] == -1 && is_stop_n(v, p);
-        const bool n_fs = v.strand[nx] == 1 && is_stop_n(v, nx), n_rs = v.strand[nx] == -1 && is_stop_n(v, nx);
-        if (p_rb && n_fs) { int k = p; while (v.ndx[k] != v.stop_val[p]) k--; v.traceb[p] = k; v.traceb[k] = nx; }
-        if (p_fs && n_fs) { v.traceb[p] = v.star_ptr[3 * nx + v.ndx[p] % 3]; v.traceb[v.traceb[p]] = nx; }
-        if (p_rs && n_rs) { v.traceb[p] = v.star_ptr[3 * p + v.ndx[nx] % 3]; v.traceb[v.traceb[p]] = nx; }
+    for (int p = mx, nx = v.traceb[p]; nx != -1; p = nx, nx = v.traceb[p]) {
+        const int sp = v.strand[p], sn = v.strand[nx], np = v.ndx[p], nn = v.ndx[nx];
+        const bool stp = is_stop_n(v, p), stn = is_stop_n(v, nx);
+        const bool p_rb = sp == -1 && !stp, p_fs = sp == 1 && stp, p_rs = sp == -1 && stp;
+        const bool n_fs = sn == 1 && stn, n_rs = sn == -1 && stn;
+        int ins = -1;
+        if (p_rb && n_fs) ins = walk_down_to(v, p, v.stop_val[p]);
+        if (p_fs && n_fs) ins = v.star_ptr[3 * nx + np % 3];
+        if (p_rs && n_rs) ins = v.star_ptr[3 * p + nn % 3];
+        if (ins != -1) { v.traceb[p] = ins; v.traceb[ins] = nx; nx = ins; }
     }
-    for (int p = mx; v.traceb[p] != -1; p = v.traceb[p]) v.tracef[v.traceb[p]] = p;
+    // forward pointers; the nodes of the path are also listed (from mx back to its head) so that the later passes
+    // read them with independent loads instead of chasing pointers again
+    int cnt = 0;
+    int p = mx;
+    for (; v.traceb[p] != -1; p = v.traceb[p]) { path[cnt++] = p; v.tracef[v.traceb[p]] = p; }
+    path[cnt++] = p;
+    return cnt;
 }
 
-// Prodigal dprog.c eliminate_bad_genes (call sites ref: lib.pyx:5308, 5369)
-void eliminate_bad_genes(NodeView& v, int ipath, double st_wt) {
-    if (ipath == -1) return;
-    int p = ipath;
-    while (v.traceb[p] != -1) p = v.traceb[p];
-    const int head = p;
-    for (; v.tracef[p] != -1; p = v.tracef[p]) {
-        const int f = v.tracef[p];
-        if (v.strand[p] == 1 && is_stop_n(v, p)) v.sscore[f] += igm_h(v, p, f, st_wt);
-        if (v.strand[p] == -1 && !is_stop_n(v, p)) v.sscore[p] += igm_h(v, p, f, st_wt);
+// Prodigal dprog.c eliminate_bad_genes (call sites ref: lib.pyx:5308, 5369).  path[cnt-1] is the head of the path,
+// path[0] its last node (ipath).
+__host__ __device__ void eliminate_bad_genes(NodeView& v, const int32_t* __restrict__ path, int cnt, double st_wt) {
+    for (int q = cnt - 1; q >= 1; q--) {
+        const int p = path[q], f = path[q - 1];
+        const int sp = v.strand[p]; const bool stp = is_stop_n(v, p);
+        if (sp == 1 && stp) v.sscore[f] += igm_h(v, p, f, st_wt);
+        if (sp == -1 && !stp) v.sscore[p] += igm_h(v, p, f, st_wt);
     }
-    for (p = head; v.tracef[p] != -1; p = v.tracef[p]) {
-        const int f = v.tracef[p];
-        if (v.strand[p] == 1 && !is_stop_n(v, p) && v.cscore[p] + v.sscore[p] < 0) { v.elim[p] = 1; v.elim[f] = 1; }
-        if (v.strand[p] == -1 && is_stop_n(v, p) && v.cscore[f] + v.sscore[f] < 0) { v.elim[p] = 1; v.elim[f] = 1; }
+    for (int q = cnt - 1; q >= 1; q--) {
+        const int p = path[q], f = path[q - 1];
+        const int sp = v.strand[p]; const bool stp = is_stop_n(v, p);
+        const double gp = v.cscore[p] + v.sscore[p], gf = v.cscore[f] + v.sscore[f];
+        if (sp == 1 && !stp && gp < 0) { v.elim[p] = 1; v.elim[f] = 1; }
+        if (sp == -1 && stp && gf < 0) { v.elim[p] = 1; v.elim[f] = 1; }
     }
 }
 
-// ref: lib.pyx:3231-3270 (Genes._extract)
-void extract_genes(const NodeView& v, int ipath, std::vector<GeneRec>& out) {
-    out.clear();
-    if (ipath == -1) return;
-    int p = ipath, b = 0, e = 0, s = 0, t = 0;
-    while (v.traceb[p] != -1) p = v.traceb[p];
-    for (; p != -1; p = v.tracef[p]) {
-        if (v.elim[p] == 1) continue;
-        if (v.strand[p] == 1) {
-            if (!is_stop_n(v, p)) { b = v.ndx[p] + 1; s = p; }
-            else { e = v.ndx[p] + 3; t = p; out.push_back({b, e, s, t}); }
+// ref: lib.pyx:3231-3270 (Genes._extract); returns the number of genes written to `out`
+__host__ __device__ int extract_genes(const NodeView& v, const int32_t* __restrict__ path, int cnt, GeneRec* out) {
+    int b = 0, e = 0, s = 0, t = 0, ng = 0;
+    for (int q = cnt - 1; q >= 0; q--) {
+        const int p = path[q];
+        const int el = v.elim[p], sp = v.strand[p], np = v.ndx[p]; const bool stp = is_stop_n(v, p);
+        if (el == 1) continue;
+        if (sp == 1) {
+            if (!stp) { b = np + 1; s = p; }
+            else { e = np + 3; t = p; out[ng++] = GeneRec{b, e, s, t}; }
         } else {
-            if (!is_stop_n(v, p)) { e = v.ndx[p] + 1; s = p; out.push_back({b, e, s, t}); }
-            else { b = v.ndx[p] - 1; t = p; }
+            if (!stp) { e = np + 1; s = p; out[ng++] = GeneRec{b, e, s, t}; }
+            else { b = np - 1; t = p; }
         }
     }
+    return ng;
 }
 
 // ref: lib.pyx:3272-3401 (Genes._tweak_final_starts)
 // one gene; `prev` / `next` are its neighbours as the reference's in-order loop would see them
 // (prev already tweaked, next not yet)
-static void tweak_one(const NodeView& v, const GeneRec* prev, GeneRec& cur, const GeneRec* next, double w, int maxov) {
+__host__ __device__ void tweak_one(const NodeView& v, const GeneRec* prev, GeneRec& cur, const GeneRec* next, double w, int maxov) {
     const int nn = v.n;
     {
         const int ndx = cur.start_ndx;
@@ -176,9 +197,10 @@ static void tweak_one(const NodeView& v, const GeneRec* prev, GeneRec& cur, cons
         if (v.strand[ndx] == -1 && next_fwd) ig = -0.15 * w;
         if (v.strand[ndx] == -1 && next_rev) ig = igm_same_h(v, ndx, next->stop_ndx, w);
         int mi[2] = {-1, -1}; double ms[2] = {0, 0}, mg[2] = {0, 0};
+        const int sv_ndx = v.stop_val[ndx];
         for (int j = ndx - 100; j < ndx + 100; j++) {
             if (j < 0 || j >= nn || j == ndx) continue;
-            if (is_stop_n(v, j) || v.stop_val[j] != v.stop_val[ndx]) continue;
+            if (is_stop_n(v, j) | (v.stop_val[j] != sv_ndx)) continue;     // `|`: both loads leave together
             double tg = 0.0;
             if (v.strand[j] == 1 && prev_fwd) {
                 if (v.ndx[prev->stop_ndx] - v.ndx[j] > maxov) continue;
@@ -249,6 +271,15 @@ void tweak_final_starts(const NodeView& v, std::vector<GeneRec>& g, double w, in
     }
 }
 
+// ---- tail kernels --------------------------------------------------------------------------------------
+struct OutArrays;
+struct TailDesc {          // one per contig
+    int64_t out_off;       // first node of the contig's winning chain in the gathered arrays
+    int64_t gene_off;      // first slot of the contig's gene records (capacity n / 2 + 2)
+    int32_t n;             // nodes (0: no winning model)
+    int32_t mx;            // _find_max_index of the winning pass
+    double  st_wt;
+};
 // ---- gather kernel: pack the winning chains' node fields contiguously for one D2H per field ----
 struct WinDesc {
     int64_t out_off;     // first output node
@@ -306,6 +337,117 @@ k_gather_gene_nodes(const int64_t* __restrict__ idx, int n, OutArrays o, GeneNod
     a.edge = o.edge[g]; a.rbs0 = o.rbs[2 * g]; a.rbs1 = o.rbs[2 * g + 1]; a.mot_len = o.mot_len[g]; a.mot_spacer = o.mot_spacer[g];
     a._pad[0] = a._pad[1] = a._pad[2] = 0;
     out[t] = a;
+}
+
+__device__ inline NodeView node_view(const TailDesc& d, const OutArrays& o, int32_t* tracef, uint8_t* elim) {
+    const int64_t oo = d.out_off;
+    return NodeView{d.n, o.ndx + oo, o.stop_val + oo, o.type + oo, o.strand + oo, o.edge_dp + oo,
+                    o.cscore_dp + oo, o.sscore_dp + oo, o.rscore_dp + oo, o.uscore_dp + oo, o.tscore_dp + oo,
+                    o.star_ptr + 3 * oo, o.traceb + oo, tracef + oo, o.ov_mark + oo, o.score + oo, elim + oo};
+}
+
+// One thread per contig: untangle the traceback, eliminate bad genes, list the genes
+// (ref: lib.pyx:1253-1311, 5308 / 5369, 3231-3270).  A path is a pointer chase, so contigs are the parallel axis.
+__global__ void __launch_bounds__(64)
+k_tail_path(const TailDesc* __restrict__ td, int n_contigs, OutArrays o, int32_t* tracef, uint8_t* elim, int32_t* __restrict__ path,
+            GeneRec* __restrict__ genes, int32_t* __restrict__ n_genes) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_contigs) return;
+    const TailDesc d = td[i];
+    int ng = 0;
+    if (d.n > 0 && d.mx >= 0) {
+        NodeView v = node_view(d, o, tracef, elim);
+        int32_t* pl = path + d.out_off;                  // at most n entries
+        const int cnt = untangle(v, d.mx, pl);
+        if (v.traceb[d.mx] != -1) {                      // ipath != -1
+            eliminate_bad_genes(v, pl, cnt, d.st_wt);
+            ng = extract_genes(v, pl, cnt, genes + d.gene_off);
+        }
+    }
+    n_genes[i] = ng;
+}
+
+__device__ inline int contig_of_slot(const TailDesc* __restrict__ td, int n_contigs, int64_t slot) {
+    int lo = 0, hi = n_contigs - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (td[mid].gene_off <= slot) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
+// ref: lib.pyx:3272-3401 (Genes._tweak_final_starts).  The reference loop runs in gene order: gene i sees its
+// predecessor already tweaked and its successor untouched.  Here every gene is first tweaked against its ORIGINAL
+// neighbours (one thread per gene), then one thread per contig redoes, in order, the genes whose predecessor did
+// change (tweaks are rare).
+__global__ void __launch_bounds__(256)
+k_tail_tweak(const TailDesc* __restrict__ td, int n_contigs, int64_t n_slots, OutArrays o, int32_t* tracef, uint8_t* elim,
+             const GeneRec* __restrict__ orig, GeneRec* __restrict__ out, const int32_t* __restrict__ n_genes, int maxov,
+             uint8_t* __restrict__ changed, int32_t* __restrict__ n_changed) {
+    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_slots) return;
+    const int c = contig_of_slot(td, n_contigs, slot);
+    const TailDesc d = td[c];
+    const int g = (int)(slot - d.gene_off), ng = n_genes[c];
+    if (g >= ng) return;
+    const NodeView v = node_view(d, o, tracef, elim);
+    const GeneRec* base = orig + d.gene_off;
+    GeneRec cur = base[g];
+    tweak_one(v, g > 0 ? &base[g - 1] : nullptr, cur, g < ng - 1 ? &base[g + 1] : nullptr, d.st_wt, maxov);
+    out[slot] = cur;
+    // only a reverse-strand predecessor hands its START to the next gene's tweak (a forward one hands its stop, which
+    // never moves): that is the one case the in-order pass has to revisit
+    const bool moved = cur.start_ndx != base[g].start_ndx && v.strand[cur.start_ndx] == -1;
+    changed[slot] = moved ? 1 : 0;
+    if (moved) atomicAdd(&n_changed[c], 1);
+}
+__global__ void __launch_bounds__(64)
+k_tail_tweak_fixup(const TailDesc* __restrict__ td, int n_contigs, OutArrays o, int32_t* tracef, uint8_t* elim,
+                   const GeneRec* __restrict__ orig, GeneRec* __restrict__ out, const int32_t* __restrict__ n_genes, int maxov,
+                   uint8_t* __restrict__ changed, const int32_t* __restrict__ n_changed) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_contigs) return;
+    if (n_changed[c] == 0) return;
+    const TailDesc d = td[c];
+    const int ng = n_genes[c];
+    const NodeView v = node_view(d, o, tracef, elim);
+    const GeneRec* ob = orig + d.gene_off;
+    GeneRec* nb = out + d.gene_off;
+    uint8_t* ch = changed + d.gene_off;
+    for (int g = 1; g < ng; g++) {
+        if (!ch[g - 1]) continue;                                        // predecessor's start did not move: the parallel result stands
+        GeneRec cur = ob[g];
+        const GeneRec prev = nb[g - 1];
+        tweak_one(v, &prev, cur, g < ng - 1 ? &ob[g + 1] : nullptr, d.st_wt, maxov);
+        nb[g] = cur;
+        ch[g] = cur.start_ndx != ob[g].start_ndx && v.strand[cur.start_ndx] == -1;
+    }
+}
+
+// The public gene records, packed in (contig, gene) order (ref: lib.pyx:2644-2830 for what Gene reads).
+__global__ void __launch_bounds__(256)
+k_emit_genes(const TailDesc* __restrict__ td, int n_contigs, int64_t n_slots, OutArrays o, const GeneRec* __restrict__ fin,
+             const int32_t* __restrict__ n_genes, const int64_t* __restrict__ gene_begin, int single, pga_gene* __restrict__ out) {
+    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_slots) return;
+    const int c = contig_of_slot(td, n_contigs, slot);
+    const TailDesc d = td[c];
+    const int g = (int)(slot - d.gene_off);
+    if (g >= n_genes[c]) return;
+    const GeneRec gr = fin[slot];
+    const int64_t sn = d.out_off + gr.start_ndx, en = d.out_off + gr.stop_ndx;
+    pga_gene G;
+    memset(&G, 0, sizeof G);
+    G.contig = c; G.begin = gr.begin; G.end = gr.end; G.start_ndx = gr.start_ndx; G.stop_ndx = gr.stop_ndx;
+    G.strand = o.strand[sn];
+    // single mode keeps the nodes of the DP pass (ref: lib.pyx:5296-5311); meta mode re-scores (5380-5394)
+    const uint8_t se = single ? o.edge_dp[sn] : o.edge[sn], ee = single ? o.edge_dp[en] : o.edge[en];
+    G.partial_begin = G.strand == 1 ? se : ee; G.partial_end = G.strand == 1 ? ee : se;
+    G.start_type = se ? 3 : o.type[sn];
+    G.rbs[0] = o.rbs[2 * sn]; G.rbs[1] = o.rbs[2 * sn + 1];
+    G.mot_len = o.mot_len[sn]; G.mot_spacer = o.mot_spacer[sn]; G.mot_ndx = o.mot_ndx[sn]; G.mot_score = o.mot_score[sn];
+    G.gc_cont = o.gc_cont[sn];
+    G.cscore = single ? o.cscore_dp[sn] : o.cscore[sn]; G.sscore = single ? o.sscore_dp[sn] : o.sscore[sn];
+    G.rscore = single ? o.rscore_dp[sn] : o.rscore[sn]; G.uscore = single ? o.uscore_dp[sn] : o.uscore[sn];
+    G.tscore = single ? o.tscore_dp[sn] : o.tscore[sn];
+    out[gene_begin[c] + g] = G;
 }
 
 __global__ void k_contig_node_base(const ContigDesc* __restrict__ ct, int n_contigs, int64_t total, const int32_t* __restrict__ pre_nodes,
@@ -830,7 +972,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             }
         }
         w_o0[NG] = out_nodes;
-        // one device arena and one pinned arena, DP-pass fields first: the part every call needs is a single DMA
+        // one device arena (and a pinned mirror, used only when the caller asks for the node arrays)
         OutArrays o, h;
         size_t arena_dp = 0, arena_all = 0;
         {
@@ -870,109 +1012,196 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                 k0 += wg[g].size();
             }
         }
-        if (out_nodes > 0)
-            HT(c, hipMemcpyAsync(h.ndx, o.ndx, P.want_nodes ? arena_all : arena_dp, hipMemcpyDeviceToHost, st));   // arena starts at `ndx`
-        HT(c, hipEventRecord(f->e_stop, st));
-        HT(c, hipGetLastError());
-        HT(c, hipStreamSynchronize(st));
-        { float ms = 0; HT(c, hipEventElapsedTime(&ms, f->e_start, f->e_stop)); R->pub.t_total_ms = ms; }
-
-        tm.mark("gather+d2h+sync");
-        // ---- host tail per contig ------------------------------------------------------------------
-        std::vector<int32_t> tracef((size_t)out_nodes + 1, -1);
-        std::vector<uint8_t> elim((size_t)out_nodes + 1, 0);
-        std::vector<std::vector<GeneRec>> cg(NC);
-        std::atomic<int> next(0);
-        auto worker = [&]() {
-            for (;;) {
-                const int i = next.fetch_add(1);
-                if (i >= NC) break;
-                const int k = win_chain[i];
-                if (k < 0) continue;
-                const int64_t oo = out_off[i];
-                NodeView v{chains[k].n, h.ndx + oo, h.stop_val + oo, h.type + oo, h.strand + oo, h.edge_dp + oo,
-                           h.cscore_dp + oo, h.sscore_dp + oo, h.rscore_dp + oo, h.uscore_dp + oo, h.tscore_dp + oo,
-                           h.star_ptr + 3 * oo, h.traceb + oo, tracef.data() + oo, h.ov_mark + oo, h.score + oo, elim.data() + oo};
-                const int mx = h_maxidx[k];
-                int ipath = -1;
-                if (v.n > 0 && mx >= 0) { untangle(v, mx); ipath = v.traceb[mx] == -1 ? -1 : mx; }
-                const double st_wt = c->models[chains[k].model].st_wt;
-                if (v.n > 0) eliminate_bad_genes(v, ipath, st_wt);
-                extract_genes(v, ipath, cg[i]);
-                tweak_final_starts(v, cg[i], st_wt, P.max_overlap, NC < 4 ? 16 : 1);
-            }
-        };
-        auto run_parallel = [&](const std::function<void()>& fn) {
-            int nt = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
-            if (NC < 4) nt = 1;
-            std::vector<std::thread> th;
-            for (int t = 1; t < nt; t++) th.emplace_back(fn);
-            fn();
-            for (auto& t : th) t.join();
-        };
-        run_parallel(worker);
-        tm.mark("host_tail");
-        // ---- results -----------------------------------------------------------------------------------
-        int64_t ngenes = 0;
-        for (int i = 0; i < NC; i++) {
-            pga_contig_result& cr = R->contigs[i];
-            const int k = win_chain[i];
-            cr.gene_begin = ngenes; cr.n_genes = (int32_t)cg[i].size();
-            ngenes += cr.n_genes;
-            if (k < 0) { cr.model = -1; continue; }
-            cr.model = chains[k].model; cr.n_nodes = chains[k].n;
-            cr.score = P.meta ? 0.0 : (h_ipath[k] >= 0 ? h_maxscore[k] : 0.0);
-        }
-        R->genes.resize((size_t)ngenes);
-        // fields of the gene's start / stop nodes as of the final pass: a second, small gather
-        PINBUF(h_gidx, int64_t, "h_gidx", 2 * ngenes + 1);
-        PINBUF(h_attr, GeneNodeAttr, "h_attr", 2 * ngenes + 1);
-        if (ngenes > 0) {
-            DEVBUF(d_gidx, int64_t, "d_gidx", 2 * ngenes + 1);
-            DEVBUF(d_attr, GeneNodeAttr, "d_attr", 2 * ngenes + 1);
-            for (int i = 0; i < NC; i++) {
-                int64_t gi = R->contigs[i].gene_begin;
-                for (const GeneRec& gr : cg[i]) { h_gidx[2 * gi] = out_off[i] + gr.start_ndx; h_gidx[2 * gi + 1] = out_off[i] + gr.stop_ndx; gi++; }
-            }
-            HT(c, hipMemcpyAsync(d_gidx, h_gidx, sizeof(int64_t) * 2 * ngenes, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_gather_gene_nodes, dim3((unsigned)((2 * ngenes + 255) / 256)), dim3(256), 0, st, d_gidx, (int)(2 * ngenes), o, d_attr);
-            HT(c, hipMemcpyAsync(h_attr, d_attr, sizeof(GeneNodeAttr) * 2 * ngenes, hipMemcpyDeviceToHost, st));
+        // The tail (traceback untangling, bad-gene elimination, gene list, start tweaks) is a pointer chase per
+        // contig.  Many small contigs: one device thread each, only the genes come home.  Few or very long contigs:
+        // a single device thread would crawl (one memory round trip per step), so their DP-pass fields come home
+        // and host threads walk them.
+        int max_n = 0;
+        for (int i = 0; i < NC; i++) if (win_chain[i] >= 0) max_n = std::max(max_n, chains[win_chain[i]].n);
+        const bool device_tail = getenv("PGA_TAIL") ? strcmp(getenv("PGA_TAIL"), "device") == 0 : (NC >= 64 && max_n <= 16384);
+        std::vector<int32_t> tracef;
+        std::vector<uint8_t> elim;
+        if (!device_tail) {
+            tracef.assign((size_t)out_nodes + 1, -1);
+            elim.assign((size_t)out_nodes + 1, 0);
+            if (out_nodes > 0)
+                HT(c, hipMemcpyAsync(h.ndx, o.ndx, P.want_nodes ? arena_all : arena_dp, hipMemcpyDeviceToHost, st));   // arena starts at `ndx`
+            HT(c, hipEventRecord(f->e_stop, st));
             HT(c, hipGetLastError());
             HT(c, hipStreamSynchronize(st));
-        }
-        tm.mark("gene_attrs");
-        std::atomic<int> next2(0);
-        auto filler = [&]() {
-            for (;;) {
-                const int i = next2.fetch_add(1);
-                if (i >= NC) break;
-                const int k = win_chain[i];
-                if (k < 0) continue;
-                const int64_t oo = out_off[i];
-                const bool single = !P.meta;
-                int64_t gi = R->contigs[i].gene_begin;
-                for (const GeneRec& gr : cg[i]) {
-                    pga_gene& G = R->genes[(size_t)gi];
-                    const GeneNodeAttr& as = h_attr[2 * gi]; const GeneNodeAttr& ae = h_attr[2 * gi + 1];
-                    gi++;
-                    memset(&G, 0, sizeof G);
-                    const int64_t sn = oo + gr.start_ndx, en = oo + gr.stop_ndx;
-                    G.contig = i; G.begin = gr.begin; G.end = gr.end; G.start_ndx = gr.start_ndx; G.stop_ndx = gr.stop_ndx;
-                    G.strand = h.strand[sn];
-                    // single mode keeps the nodes of the DP pass (ref: lib.pyx:5296-5311); meta mode re-scores (5380-5394)
-                    const uint8_t se = single ? h.edge_dp[sn] : as.edge, ee = single ? h.edge_dp[en] : ae.edge;
-                    G.partial_begin = G.strand == 1 ? se : ee; G.partial_end = G.strand == 1 ? ee : se;
-                    G.start_type = se ? 3 : h.type[sn];
-                    G.rbs[0] = as.rbs0; G.rbs[1] = as.rbs1;
-                    G.mot_len = as.mot_len; G.mot_spacer = as.mot_spacer; G.mot_ndx = as.mot_ndx; G.mot_score = as.mot_score;
-                    G.gc_cont = as.gc_cont;
-                    G.cscore = single ? h.cscore_dp[sn] : as.cscore; G.sscore = single ? h.sscore_dp[sn] : as.sscore;
-                    G.rscore = single ? h.rscore_dp[sn] : as.rscore; G.uscore = single ? h.uscore_dp[sn] : as.uscore;
-                    G.tscore = single ? h.tscore_dp[sn] : as.tscore;
+            { float ms = 0; HT(c, hipEventElapsedTime(&ms, f->e_start, f->e_stop)); R->pub.t_total_ms = ms; }
+
+            tm.mark("gather+d2h+sync");
+            // ---- host tail per contig ------------------------------------------------------------------
+            std::vector<std::vector<GeneRec>> cg(NC);
+            std::vector<int32_t> pathbuf((size_t)out_nodes + 1);
+            std::atomic<int> next(0);
+            auto worker = [&]() {
+                for (;;) {
+                    const int i = next.fetch_add(1);
+                    if (i >= NC) break;
+                    const int k = win_chain[i];
+                    if (k < 0) continue;
+                    const int64_t oo = out_off[i];
+                    NodeView v{chains[k].n, h.ndx + oo, h.stop_val + oo, h.type + oo, h.strand + oo, h.edge_dp + oo,
+                               h.cscore_dp + oo, h.sscore_dp + oo, h.rscore_dp + oo, h.uscore_dp + oo, h.tscore_dp + oo,
+                               h.star_ptr + 3 * oo, h.traceb + oo, tracef.data() + oo, h.ov_mark + oo, h.score + oo, elim.data() + oo};
+                    const int mx = h_maxidx[k];
+                    const double st_wt = c->models[chains[k].model].st_wt;
+                    if (v.n > 0 && mx >= 0) {
+                        int32_t* pl = pathbuf.data() + oo;
+                        const int cnt = untangle(v, mx, pl);
+                        if (v.traceb[mx] != -1) {
+                            eliminate_bad_genes(v, pl, cnt, st_wt);
+                            cg[i].resize((size_t)v.n / 2 + 2);
+                            cg[i].resize((size_t)extract_genes(v, pl, cnt, cg[i].data()));
+                        }
+                    }
+                    tweak_final_starts(v, cg[i], st_wt, P.max_overlap, NC < 4 ? 16 : 1);
                 }
+            };
+            auto run_parallel = [&](const std::function<void()>& fn) {
+                int nt = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+                if (NC < 4) nt = 1;
+                std::vector<std::thread> th;
+                for (int t = 1; t < nt; t++) th.emplace_back(fn);
+                fn();
+                for (auto& t : th) t.join();
+            };
+            run_parallel(worker);
+            tm.mark("host_tail");
+            // ---- results -----------------------------------------------------------------------------------
+            int64_t ngenes = 0;
+            for (int i = 0; i < NC; i++) {
+                pga_contig_result& cr = R->contigs[i];
+                const int k = win_chain[i];
+                cr.gene_begin = ngenes; cr.n_genes = (int32_t)cg[i].size();
+                ngenes += cr.n_genes;
+                if (k < 0) { cr.model = -1; continue; }
+                cr.model = chains[k].model; cr.n_nodes = chains[k].n;
+                cr.score = P.meta ? 0.0 : (h_ipath[k] >= 0 ? h_maxscore[k] : 0.0);
             }
-        };
-        run_parallel(filler);
+            R->genes.resize((size_t)ngenes);
+            // fields of the gene's start / stop nodes as of the final pass: a second, small gather
+            PINBUF(h_gidx, int64_t, "h_gidx", 2 * ngenes + 1);
+            PINBUF(h_attr, GeneNodeAttr, "h_attr", 2 * ngenes + 1);
+            if (ngenes > 0) {
+                DEVBUF(d_gidx, int64_t, "d_gidx", 2 * ngenes + 1);
+                DEVBUF(d_attr, GeneNodeAttr, "d_attr", 2 * ngenes + 1);
+                for (int i = 0; i < NC; i++) {
+                    int64_t gi = R->contigs[i].gene_begin;
+                    for (const GeneRec& gr : cg[i]) { h_gidx[2 * gi] = out_off[i] + gr.start_ndx; h_gidx[2 * gi + 1] = out_off[i] + gr.stop_ndx; gi++; }
+                }
+                HT(c, hipMemcpyAsync(d_gidx, h_gidx, sizeof(int64_t) * 2 * ngenes, hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(k_gather_gene_nodes, dim3((unsigned)((2 * ngenes + 255) / 256)), dim3(256), 0, st, d_gidx, (int)(2 * ngenes), o, d_attr);
+                HT(c, hipMemcpyAsync(h_attr, d_attr, sizeof(GeneNodeAttr) * 2 * ngenes, hipMemcpyDeviceToHost, st));
+                HT(c, hipGetLastError());
+                HT(c, hipStreamSynchronize(st));
+            }
+            tm.mark("gene_attrs");
+            std::atomic<int> next2(0);
+            auto filler = [&]() {
+                for (;;) {
+                    const int i = next2.fetch_add(1);
+                    if (i >= NC) break;
+                    const int k = win_chain[i];
+                    if (k < 0) continue;
+                    const int64_t oo = out_off[i];
+                    const bool single = !P.meta;
+                    int64_t gi = R->contigs[i].gene_begin;
+                    for (const GeneRec& gr : cg[i]) {
+                        pga_gene& G = R->genes[(size_t)gi];
+                        const GeneNodeAttr& as = h_attr[2 * gi]; const GeneNodeAttr& ae = h_attr[2 * gi + 1];
+                        gi++;
+                        memset(&G, 0, sizeof G);
+                        const int64_t sn = oo + gr.start_ndx, en = oo + gr.stop_ndx;
+                        G.contig = i; G.begin = gr.begin; G.end = gr.end; G.start_ndx = gr.start_ndx; G.stop_ndx = gr.stop_ndx;
+                        G.strand = h.strand[sn];
+                        // single mode keeps the nodes of the DP pass (ref: lib.pyx:5296-5311); meta mode re-scores (5380-5394)
+                        const uint8_t se = single ? h.edge_dp[sn] : as.edge, ee = single ? h.edge_dp[en] : ae.edge;
+                        G.partial_begin = G.strand == 1 ? se : ee; G.partial_end = G.strand == 1 ? ee : se;
+                        G.start_type = se ? 3 : h.type[sn];
+                        G.rbs[0] = as.rbs0; G.rbs[1] = as.rbs1;
+                        G.mot_len = as.mot_len; G.mot_spacer = as.mot_spacer; G.mot_ndx = as.mot_ndx; G.mot_score = as.mot_score;
+                        G.gc_cont = as.gc_cont;
+                        G.cscore = single ? h.cscore_dp[sn] : as.cscore; G.sscore = single ? h.sscore_dp[sn] : as.sscore;
+                        G.rscore = single ? h.rscore_dp[sn] : as.rscore; G.uscore = single ? h.uscore_dp[sn] : as.uscore;
+                        G.tscore = single ? h.tscore_dp[sn] : as.tscore;
+                    }
+                }
+            };
+            run_parallel(filler);
+        } else {
+            tm.mark("gather");
+            // ---- tail on the device: traceback untangling, bad-gene elimination, gene list, start tweaks ----------
+            std::vector<TailDesc> tdv(NC);
+            int64_t n_slots = 0;
+            for (int i = 0; i < NC; i++) {
+                const int k = win_chain[i];
+                TailDesc& d = tdv[i];
+                d.out_off = k >= 0 ? out_off[i] : 0; d.gene_off = n_slots;
+                d.n = k >= 0 ? chains[k].n : 0; d.mx = k >= 0 ? h_maxidx[k] : -1;
+                d.st_wt = k >= 0 ? c->models[chains[k].model].st_wt : 0.0;
+                n_slots += d.n / 2 + 2;
+            }
+            DEVBUF(d_td, TailDesc, "d_taildesc", NC + 1);
+            DEVBUF(d_tracef, int32_t, "d_tracef", out_nodes + 1);
+            DEVBUF(d_elim, uint8_t, "d_elim", out_nodes + 1);
+            DEVBUF(d_gene0, GeneRec, "d_gene0", n_slots + 1);
+            DEVBUF(d_gene1, GeneRec, "d_gene1", n_slots + 1);
+            DEVBUF(d_ngenes, int32_t, "d_ngenes", NC + 1);
+            DEVBUF(d_gbegin, int64_t, "d_gbegin", NC + 1);
+            PINBUF(h_ngenes, int32_t, "h_ngenes", NC + 1);
+            PINBUF(h_gbegin, int64_t, "h_gbegin", NC + 1);
+            HT(c, hipMemcpyAsync(d_td, tdv.data(), sizeof(TailDesc) * NC, hipMemcpyHostToDevice, st));
+            HT(c, hipMemsetAsync(d_tracef, 0xff, sizeof(int32_t) * ((size_t)out_nodes + 1), st));
+            HT(c, hipMemsetAsync(d_elim, 0, (size_t)out_nodes + 1, st));
+            DEVBUF(d_path, int32_t, "d_path", out_nodes + 1);
+            DEVBUF(d_changed, uint8_t, "d_changed", n_slots + 1);
+            DEVBUF(d_nchanged, int32_t, "d_nchanged", NC + 1);
+            HT(c, hipMemsetAsync(d_nchanged, 0, sizeof(int32_t) * ((size_t)NC + 1), st));
+            hipLaunchKernelGGL(k_tail_path, dim3((NC + 63) / 64), dim3(64), 0, st, d_td, NC, o, d_tracef, d_elim, d_path, d_gene0, d_ngenes);
+            hipLaunchKernelGGL(k_tail_tweak, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, st, d_td, NC, n_slots, o, d_tracef, d_elim,
+                               d_gene0, d_gene1, d_ngenes, P.max_overlap, d_changed, d_nchanged);
+            hipLaunchKernelGGL(k_tail_tweak_fixup, dim3((NC + 63) / 64), dim3(64), 0, st, d_td, NC, o, d_tracef, d_elim, d_gene0, d_gene1, d_ngenes,
+                               P.max_overlap, d_changed, d_nchanged);
+            HT(c, hipMemcpyAsync(h_ngenes, d_ngenes, sizeof(int32_t) * NC, hipMemcpyDeviceToHost, st));
+            HT(c, hipGetLastError());
+            HT(c, hipStreamSynchronize(st));
+            tm.mark("tail");
+            // ---- results --------------------------------------------------------------------------------------
+            int64_t ngenes = 0;
+            for (int i = 0; i < NC; i++) {
+                pga_contig_result& cr = R->contigs[i];
+                const int k = win_chain[i];
+                h_gbegin[i] = ngenes;
+                cr.gene_begin = ngenes; cr.n_genes = h_ngenes[i];
+                ngenes += cr.n_genes;
+                if (k < 0) { cr.model = -1; continue; }
+                cr.model = chains[k].model; cr.n_nodes = chains[k].n;
+                cr.score = P.meta ? 0.0 : (h_ipath[k] >= 0 ? h_maxscore[k] : 0.0);
+            }
+            R->genes.resize((size_t)ngenes);
+            if (ngenes > 0) {
+                DEVBUF(d_genes, pga_gene, "d_genes_out", ngenes + 1);
+                HT(c, hipMemcpyAsync(d_gbegin, h_gbegin, sizeof(int64_t) * NC, hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(k_emit_genes, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, st, d_td, NC, n_slots, o, d_gene1, d_ngenes,
+                                   d_gbegin, P.meta ? 0 : 1, d_genes);
+                HT(c, hipMemcpyAsync(R->genes.data(), d_genes, sizeof(pga_gene) * (size_t)ngenes, hipMemcpyDeviceToHost, st));
+            }
+            if (P.want_nodes && out_nodes > 0) {
+                tracef.resize((size_t)out_nodes + 1); elim.resize((size_t)out_nodes + 1);
+                HT(c, hipMemcpyAsync(h.ndx, o.ndx, arena_all, hipMemcpyDeviceToHost, st));   // arena starts at `ndx`
+                HT(c, hipMemcpyAsync(tracef.data(), d_tracef, sizeof(int32_t) * (size_t)out_nodes, hipMemcpyDeviceToHost, st));
+                HT(c, hipMemcpyAsync(elim.data(), d_elim, (size_t)out_nodes, hipMemcpyDeviceToHost, st));
+            }
+            HT(c, hipEventRecord(f->e_stop, st));
+            HT(c, hipGetLastError());
+            HT(c, hipStreamSynchronize(st));
+            { float ms = 0; HT(c, hipEventElapsedTime(&ms, f->e_start, f->e_stop)); R->pub.t_total_ms = ms; }
+            tm.mark("genes+d2h");
+
+        }
         if (P.want_nodes) {
             R->nodes.resize(NC);
             for (int i = 0; i < NC; i++) {

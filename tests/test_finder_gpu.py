@@ -173,3 +173,18 @@ def test_invalid_arguments_raise(ctx, models):
         ctx.find_genes_batch([b"ACGT"], min_gene=0)
     with pytest.raises(ValueError):
         ctx.find_genes_batch([b"ACGT"], max_overlap=100, min_gene=90)
+
+
+@pytest.mark.parametrize("tail", ["device", "host"])
+def test_both_tails_give_the_same_result(ctx, models, tail, monkeypatch):
+    # the traceback tail runs on the device for many small contigs and on host threads for few / long ones; force each
+    monkeypatch.setenv("PGA_TAIL", tail)
+    ctx.set_models([m.buf for m in models])
+    seqs = [synthetic_contig(9000 + 611 * c, 0.32 + 0.36 * (c % 13) / 12, 7000 + c) for c in range(70)] + [b"", b"ATGAAATAA"]
+    for meta in (True, False):
+        if not meta:
+            ctx.set_models([models[2].buf])
+        for want_nodes in (True, False):
+            res = ctx.find_genes_batch(seqs, meta=meta, want_nodes=want_nodes)
+            n = sum(compare_contig(res, i, s, orc.Oracle(s), models if meta else [models[2]], meta=meta) for i, s in enumerate(seqs))
+            assert n > 0
