@@ -353,6 +353,7 @@ __device__ __forceinline__ void load_target(Target& T, const ChainPtrs& P, int i
 #define PGA_RING_BLOCKS (PGA_RING / 8)
 struct RingLds {
     double A[PGA_RING];
+    int ndx[PGA_RING];                 // position of the node, for the ndx-of-traceb of a far-field result
     double l1v[PGA_RING_BLOCKS]; int l1i[PGA_RING_BLOCKS];
 };
 // Suffix maxima over the ring's blocks: v/i[e - ebase] = lexicographic (value, index) maximum of A over the
@@ -475,8 +476,9 @@ __device__ __forceinline__ void far_field(const Target& T, int clo, int chi, con
 //   1  score, traceb, ov_mark, ndx of the traceb node; the running _find_max_index state
 //   2  A (far gene-end candidate value), also into the LDS ring
 //   4  V0..V2 (candidate values towards forward stops)
-//   8  the tree above A
-template <int PART = 15>
+//   8  the lowest tree level above A (blocks of 8, also into the LDS ring)
+//  16  the tree levels above that
+template <int PART = 31>
 __device__ __forceinline__ void finalize_batch(const Target& T, const Best& B, int i0, int lane, int n, const ChainPtrs& P,
                                                const int* s_levbase, const double negc,
                                                double& end_best, int& end_idx, int& end_tb, RingLds* ring = nullptr) {
@@ -504,10 +506,10 @@ __device__ __forceinline__ void finalize_batch(const Target& T, const Best& B, i
         if (PART & 4) { P.V0[T.i] = v0; P.V1[T.i] = v1; P.V2[T.i] = v2; }
         if (PART & 2) {
             P.A[T.i] = a_val;
-            if (ring) ring->A[T.i & (PGA_RING - 1)] = a_val;
+            if (ring) { ring->A[T.i & (PGA_RING - 1)] = a_val; ring->ndx[T.i & (PGA_RING - 1)] = T.ndx; }
         }
     }
-    if (!(PART & 8) || i0 + 64 > n) return;
+    if (!(PART & 24) || i0 + 64 > n) return;
     double rv = a_val; int ri = i0 + lane;
 #pragma unroll
     for (int m = 1; m <= 4; m <<= 1) {
@@ -515,10 +517,11 @@ __device__ __forceinline__ void finalize_batch(const Target& T, const Best& B, i
         if (ov2 > rv || (ov2 == rv && oi > ri)) { rv = ov2; ri = oi; }
     }
     const int tile_no = i0 >> 6;
-    if ((lane & 7) == 0) {
+    if ((PART & 8) && (lane & 7) == 0) {
         P.hv[s_levbase[1] + (i0 >> 3) + (lane >> 3)] = rv; P.hi[s_levbase[1] + (i0 >> 3) + (lane >> 3)] = ri;
         if (ring) { ring->l1v[((i0 >> 3) + (lane >> 3)) & (PGA_RING_BLOCKS - 1)] = rv; ring->l1i[((i0 >> 3) + (lane >> 3)) & (PGA_RING_BLOCKS - 1)] = ri; }
     }
+    if (!(PART & 16)) return;
 #pragma unroll
     for (int m = 8; m <= 32; m <<= 1) {
         const double ov2 = __shfl_xor(rv, m, 64); const int oi = __shfl_xor(ri, m, 64);
@@ -812,12 +815,14 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
         Target Tf;
         Tf.i = ib + lane < n ? ib + lane : -1;
         const int meta = s_fin.meta[lane];
-        Tf.kind = PGA_KIND(meta); Tf.frame = PGA_FRAME(meta); Tf.meta = meta;
+        Tf.kind = PGA_KIND(meta); Tf.frame = PGA_FRAME(meta); Tf.meta = meta; Tf.ndx = s_fin.ndx[lane];
         Tf.cs = s_fin.cs[lane]; Tf.x0 = s_fin.x0[lane]; Tf.x1 = s_fin.x1[lane]; Tf.x2 = s_fin.x2[lane];
         const Best Bf{s_fin.score[lane], s_fin.tb[lane], s_fin.ov[lane], s_fin.tbn[lane]};
+        // four waves, about the same work each: results + running maximum | upper tree levels | V arrays + lowest
+        // tree level | A with the ring
         if (part == 0) finalize_batch<1>(Tf, Bf, ib, lane, n, P, s_levbase, negc, end_best, end_idx, end_tb);
-        else if (part == 1) finalize_batch<8>(Tf, Bf, ib, lane, n, P, s_levbase, negc, end_best, end_idx, end_tb, &s_ring);
-        else if (part == 2) finalize_batch<4>(Tf, Bf, ib, lane, n, P, s_levbase, negc, end_best, end_idx, end_tb);
+        else if (part == 1) finalize_batch<16>(Tf, Bf, ib, lane, n, P, s_levbase, negc, end_best, end_idx, end_tb);
+        else if (part == 2) finalize_batch<4 | 8>(Tf, Bf, ib, lane, n, P, s_levbase, negc, end_best, end_idx, end_tb, &s_ring);
         else finalize_batch<2>(Tf, Bf, ib, lane, n, P, s_levbase, negc, end_best, end_idx, end_tb, &s_ring);
     };
     // one slice of the batch finalized last, applied to this batch's targets (ascending inside the slice)
@@ -1008,7 +1013,10 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
                     Best B{0.0, -1, -1, -1};
                     if (i0 > 0) far_field(Tn, 0, i0, P, s_levbase, negc, s_igm, B, &s_ring, sfx, ebase, eend);   // every tile finalized before this iteration
                     s_eval[pb][lane] = B.val; s_etb[pb][lane] = B.tb; s_eov[pb][lane] = B.ov;
-                    s_etbn[pb][lane] = B.tb >= 0 ? P.src[B.tb].ndx : -1;
+                    // ndx of the traceb node: from the ring when it is recent enough (nearly always), else from memory
+                    int tbn = -1;
+                    if (B.tb >= 0) tbn = B.tb >= i0 - PGA_RING ? s_ring.ndx[B.tb & (PGA_RING - 1)] : P.src[B.tb].ndx;
+                    s_etbn[pb][lane] = tbn;
                 }
                 if (prof && lane == 0) buf.prof[8 + mykind] += __builtin_readcyclecounter() - tq1;
             }
