@@ -252,3 +252,23 @@ def test_translate_unknown_bases_and_strictness(lib):
     assert strict.count("X") >= 1 and loose.count("X") <= strict.count("X") and len(strict) == len(loose)
     assert g2.translate(unknown_residue="?").count("?") == strict.count("X")
     assert "N" in g2.sequence()
+
+
+@pytest.mark.gpu
+def test_find_genes_is_thread_safe(lib):
+    """ref: README.md:105-122 / tests/test_gene_finder.py (ThreadPool use): one finder shared by threads, and one finder
+    per thread, give the single-threaded result."""
+    from concurrent.futures import ThreadPoolExecutor
+    from pyrodigal_amd import benchdata
+    t = lib.TrainingInfo.load(golden_path("GCF_001457455.1_NCTC11397_genomic_100kb.tinf_closed.bin.gz"))
+    seqs = [benchdata.synthetic_contig(15000 + 500 * i, 0.45 + 0.01 * i, 600 + i) for i in range(12)]
+    shared = lib.GeneFinder(t)
+    want = [[(g.begin, g.end, g.strand) for g in shared.find_genes(s)] for s in seqs]
+    with ThreadPoolExecutor(4) as ex:
+        got = list(ex.map(lambda s: [(g.begin, g.end, g.strand) for g in shared.find_genes(s)], seqs))
+    assert got == want
+    with ThreadPoolExecutor(4) as ex:
+        got = list(ex.map(lambda s: [(g.begin, g.end, g.strand) for g in lib.GeneFinder(t).find_genes(s)], seqs))
+    assert got == want
+    ids = sorted(shared.find_genes(s)._num_seq for s in seqs[:3])
+    assert ids == sorted(set(ids))                                   # every call gets its own sequence number
