@@ -37,14 +37,19 @@ struct FinderState {
 namespace {
 
 struct StageTimer {
-    bool on; std::chrono::steady_clock::time_point t0; const char* names[32]; double ms[32]; int n = 0;
-    StageTimer() : on(getenv("PGA_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    bool on; std::chrono::steady_clock::time_point t0, tbegin; const char* names[32]; double ms[32]; int n = 0;
+    StageTimer() : on(getenv("PGA_TIMING") != nullptr), t0(std::chrono::steady_clock::now()), tbegin(t0) {}
     void mark(const char* name) {
         if (!on || n >= 32) return;
         auto t1 = std::chrono::steady_clock::now();
         names[n] = name; ms[n++] = std::chrono::duration<double, std::milli>(t1 - t0).count(); t0 = t1;
     }
-    ~StageTimer() { if (on) { fprintf(stderr, "[pga timing]"); for (int i = 0; i < n; i++) fprintf(stderr, " %s=%.2fms", names[i], ms[i]); fprintf(stderr, "\n"); } }
+    ~StageTimer() {
+        if (!on) return;
+        fprintf(stderr, "[pga timing]");
+        for (int i = 0; i < n; i++) fprintf(stderr, " %s=%.2fms", names[i], ms[i]);
+        fprintf(stderr, " | total=%.2fms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tbegin).count());
+    }
 };
 
 #define HT(ctx, expr) do { int rc__ = pga_hip_try_(ctx, (expr), #expr); if (rc__ != PGA_OK) return rc__; } while (0)
@@ -1234,7 +1239,10 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
 }
 
 extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_params* pp, pga_result** out) {
-    return find_impl(c, batch, pp, 0, 0, out);
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = find_impl(c, batch, pp, 0, 0, out);
+    if (getenv("PGA_TIMING")) fprintf(stderr, "[pga timing] pga_find_genes wall=%.2fms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    return rc;
 }
 
 extern "C" int pga_nodes_stage(pga_ctx* c, const pga_batch* batch, const pga_params* pp, int stage, int translation_table, pga_result** out) {
