@@ -165,6 +165,15 @@ int  pga_find_genes(pga_ctx*, const pga_batch*, const pga_params*, pga_result** 
 #define PGA_STAGE_SEQUENCE 4  /* Sequence.__init__ only: gc, n_unknown and masks per contig, no nodes (ref: lib.pyx:664-713) */
 int pga_nodes_stage(pga_ctx*, const pga_batch*, const pga_params*, int stage, int translation_table, pga_result** out);
 
+/* ---- training --------------------------------------------------------------- */
+/* Single-genome training (ref: lib.pyx:5236-5279 `GeneFinder._train`): `batch` holds exactly ONE sequence (several
+ * training sequences are joined by the caller with the reference's TTAATTAATTAA spacer, lib.pyx:5510-5532); closed,
+ * min_gene, min_edge_gene, max_overlap and mask come from `params`.  On success `*out` is the complete TrainingInfo.
+ * `upto` = 0 trains completely; 1 / 2 / 3 stop after the GC frame bias / the hexamer statistics / the Shine-Dalgarno
+ * start training (partial structs, for validation). */
+int pga_train(pga_ctx*, const pga_batch*, const pga_params*, int translation_table, double start_weight, int force_nonsd,
+              int upto, pga_training* out);
+
 /* ---- FASTA ingest (host side) ---------------------------------------------- */
 /* Multi-record FASTA, plain or gzip, read in batches ready for pga_find_genes_batch / pga_batch_create
  * (ref: src/pyrodigal/tests/fasta.py:59-86 `parse`, src/pyrodigal/cli.py:32-61).  headers[i] is the header line

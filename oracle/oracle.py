@@ -83,6 +83,7 @@ def lib():
         L.po_find_genes_single.restype = i32; L.po_find_genes_single.argtypes = [vp, vp, vp]
         L.po_find_genes_meta.restype = i32; L.po_find_genes_meta.argtypes = [vp, vp, i32, vp]
         L.po_train.restype = i32; L.po_train.argtypes = [vp, vp, vp, i32, f64, i32]
+        L.po_train_upto.restype = i32; L.po_train_upto.argtypes = [vp, vp, vp, i32, f64, i32, i32]
         assert L.po_node_size() == NODE_DTYPE.itemsize, (L.po_node_size(), NODE_DTYPE.itemsize)
         _lib = L
     return _lib
@@ -230,10 +231,11 @@ class Oracle:
         arr = (ctypes.c_void_p * len(bins))(*[b.ptr for b in bins])
         return self.L.po_find_genes_meta(self.h, arr, len(bins), ctypes.addressof(p))
 
-    def train(self, params=None, force_nonsd=False, start_weight=4.35, tt=11):
+    def train(self, params=None, force_nonsd=False, start_weight=4.35, tt=11, upto=0):
+        """Single-genome training; ``upto`` = 1 / 2 / 3 stops after the GC bias / hexamer statistics / SD start training."""
         p = params or Params()
         t = Training()
-        self.L.po_train(self.h, t.ptr, ctypes.addressof(p), int(force_nonsd), start_weight, tt)
+        self.L.po_train_upto(self.h, t.ptr, ctypes.addressof(p), int(force_nonsd), start_weight, tt, upto)
         return t
 
 

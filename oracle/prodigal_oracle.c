@@ -1308,7 +1308,9 @@ static void train_starts_nonsd(po_ctx* c, po_training* t) {
 }
 
 /* ref: lib.pyx:5236-5279 (GeneFinder._train) and 3955-4003 (TrainingInfo.__init__) */
-int po_train(po_ctx* c, po_training* t, const po_params* p, int force_nonsd, double start_weight, int tt) {
+/* `upto` stops the training early, for step-by-step checks of other implementations:
+ * 1 after the GC frame bias, 2 after the hexamer statistics, 3 after the Shine-Dalgarno start training, else all of it */
+int po_train_upto(po_ctx* c, po_training* t, const po_params* p, int force_nonsd, double start_weight, int tt, int upto) {
     memset(t, 0, sizeof *t);
     t->gc = c->gc; t->trans_table = tt; t->st_wt = start_weight; t->uses_sd = 1;
     po_extract(c, tt, p);
@@ -1316,13 +1318,19 @@ int po_train(po_ctx* c, po_training* t, const po_params* p, int force_nonsd, dou
     int* gcf = gc_frame_plot(c);
     record_gc_bias(gcf, c, t);
     free(gcf);
+    if (upto == 1) return 0;
     po_overlapping_starts(c, t, 0, p->max_overlap);
     int ipath = po_dprog(c, t, 0, 1);
     calc_dicodon_gene(c, t, ipath);
+    if (upto == 2) return 0;
     raw_coding_score(c, t);
     rbs_score(c, t);
     train_starts_sd(c, t);
     if (force_nonsd) t->uses_sd = 0; else determine_sd_usage(t);
+    if (upto == 3) return 0;
     if (!t->uses_sd) train_starts_nonsd(c, t);
     return 0;
+}
+int po_train(po_ctx* c, po_training* t, const po_params* p, int force_nonsd, double start_weight, int tt) {
+    return po_train_upto(c, t, p, force_nonsd, start_weight, tt, 0);
 }

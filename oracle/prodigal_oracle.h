@@ -104,6 +104,8 @@ int  po_find_genes_single(po_ctx*, const po_training*, const po_params*);
 int  po_find_genes_meta(po_ctx*, const po_training* const* bins, int nbins, const po_params*);
 int  po_train(po_ctx*, po_training* out, const po_params*, int force_nonsd,
               double start_weight, int tt);
+int  po_train_upto(po_ctx*, po_training* out, const po_params*, int force_nonsd,
+              double start_weight, int tt, int upto);
 
 double po_last_path_score(const po_ctx*);  /* nodes[ipath].score of last winning DP */
 int    po_last_ipath(const po_ctx*);

@@ -18,7 +18,7 @@ EXPORTS = [
     "pga_create", "pga_destroy", "pga_last_error", "pga_device_info", "pga_set_models",
     "pga_score_connections", "pga_find_genes_batch", "pga_result_free",
     "pga_batch_create", "pga_batch_free", "pga_find_genes", "pga_nodes_stage",
-    "pga_fasta_open", "pga_fasta_next", "pga_fasta_error", "pga_fasta_close",
+    "pga_fasta_open", "pga_fasta_next", "pga_fasta_error", "pga_fasta_close", "pga_train",
 ]
 STAGE_EXTRACT, STAGE_SCORE, STAGE_OVERLAP, STAGE_SEQUENCE = 1, 2, 3, 4
 
@@ -102,6 +102,8 @@ def load():
     L.pga_find_genes.restype = ctypes.c_int; L.pga_find_genes.argtypes = [vp, vp, _P(Params), _P(_P(Result))]
     L.pga_nodes_stage.restype = ctypes.c_int
     L.pga_nodes_stage.argtypes = [vp, vp, _P(Params), ctypes.c_int, ctypes.c_int, _P(_P(Result))]
+    L.pga_train.restype = ctypes.c_int
+    L.pga_train.argtypes = [vp, vp, _P(Params), ctypes.c_int, f64, ctypes.c_int, ctypes.c_int, vp]
     L.pga_fasta_open.restype = ctypes.c_int; L.pga_fasta_open.argtypes = [ctypes.c_char_p, _P(vp)]
     L.pga_fasta_next.restype = ctypes.c_int
     L.pga_fasta_next.argtypes = [vp, i64, i32, _P(i32), _P(_P(ctypes.c_char_p)), _P(_P(vp)), _P(_P(i64))]
@@ -313,6 +315,22 @@ def _nodes_stage(self, seqs, stage, translation_table=11, closed=False, min_gene
             b.close()
 
 
+def _train(self, seq, translation_table=11, start_weight=4.35, force_nonsd=False, closed=False, min_gene=90, min_edge_gene=60,
+           max_overlap=60, mask=False, min_mask=50, upto=0):
+    """``GeneFinder.train`` on one sequence: returns the 558 392-byte ``struct _training`` as ``bytes``."""
+    b = Batch(self, [seq])
+    try:
+        p = Params(int(closed), min_gene, min_edge_gene, max_overlap, 0, 0, int(mask), min_mask)
+        out = ctypes.create_string_buffer(TRAINING_SIZE)
+        rc = self.L.pga_train(self.h, b.h, ctypes.byref(p), int(translation_table), float(start_weight), int(force_nonsd), int(upto), out)
+        if rc != PGA_OK:
+            _raise(self.L, self.h, rc, "pga_train")
+        return out.raw
+    finally:
+        b.close()
+
+
+Context.train = _train
 Context.upload = _upload
 Context.nodes_stage = _nodes_stage
 Context.find_genes = _find_genes

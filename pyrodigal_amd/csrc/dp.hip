@@ -61,7 +61,7 @@ __device__ __forceinline__ double igm_apart(int d, double negc, const double* s_
 // and the n3 terms of _connection.h:166-176, 296-325, 345-356).
 __global__ void __launch_bounds__(256)
 k_dp_prepare(const ChainDesc* __restrict__ chains, int n_chains, int64_t node_begin, int64_t total,
-             NodeArrays nd, const ModelConst* __restrict__ models, DpSrc* __restrict__ src, DpTgt* __restrict__ tgt) {
+             NodeArrays nd, const ModelConst* __restrict__ models, DpSrc* __restrict__ src, DpTgt* __restrict__ tgt, int final) {
     int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
     g += node_begin;
@@ -81,14 +81,17 @@ k_dp_prepare(const ChainDesc* __restrict__ chains, int n_chains, int64_t node_be
     int meta = kind | ((my_ndx % 3) << 2);
     DpSrc s; DpTgt t;
     s.ndx = my_ndx; s.stop_val = my_stop; s._pad = 0;
-    s.cs = cs_c[i] + cs_s[i];
-    s._pad2[0] = s._pad2[1] = 0.0;
+    // training pass (final = 0): a connection is worth (length) x (bias . gc_score) of one of its nodes, so the
+    // records carry that per-node factor where the gene-finding pass carries cscore + sscore  (ref: _connection.h:94-367)
+    s.cs = final ? cs_c[i] + cs_s[i] : nd.gcb[off + i];
+    s.n3src[0] = s.n3src[1] = s.n3src[2] = 0; s._pad2 = 0;
     for (int k = 0; k < 3; k++) {
         s.x[k] = 0.0; t.n3ndx[k] = 0; t.n3stop[k] = 0;
         if (!stop) continue;
         const int p = sp[i * 3 + k];
         if (p < 0) continue;
         meta |= 1 << (4 + k);
+        if (!final) { s.x[k] = nd.gcb[off + p]; s.n3src[k] = ndx[p]; t.n3ndx[k] = ndx[p]; t.n3stop[k] = stopv[p]; continue; }
         const double cs3 = cs_c[p] + cs_s[p];
         double ig;
         if (!rev)   // F3 source j = i, n3 = forward start: igm(j, n3)       (ref: _connection.h:170-174)
@@ -151,6 +154,7 @@ struct Target {
 struct SrcLane {
     int ndx, stop_val, meta, tbn;     // tbn: ndx of the source's own traceb node, -1 if it has none
     double cs, x0, x1, x2, score;
+    int n3a, n3b, n3c;                // training pass only: DpSrc::n3src
 };
 struct Best { double val; int tb, ov, tbn; };   // running result of a target + ndx of its traceb node
 
@@ -164,8 +168,12 @@ __device__ __forceinline__ void take(Best& b, bool ok, double val, int j, int mf
 // One call = one iteration of the loop in _connection.h:386-408, with the six skip conditions of
 // impl/generic.h:29-36 folded into the per-kind predicates; a wave-wide vote (__any, i.e. a ballot)
 // drops the source before any floating-point work when no lane can connect to it.
+// FINAL = false is the training pass (ref: the `final` flag of _connection.h:94-367): same admissibility, but a connection
+// is worth (right - left + 1 - 2 overlap) x (bias . gc_score of one of its nodes), 0 for intergenic steps.  In that
+// pass S.cs / T.cs hold the node's own factor, S.x* / T.x* those of its overlapping starts, S.n3* their positions.
+template <bool FINAL = true>
 __device__ __forceinline__ void visit_source(const int k, const int j, const SrcLane& S, const Target& T,
-                                             const double negc, const double* s_igm, Best& B) {
+                                             const double negc, const double* s_igm, Best& B, const double st_wt = 0.0) {
     const int s_meta = __builtin_amdgcn_readlane(S.meta, k);
     const int s_ndx = __builtin_amdgcn_readlane(S.ndx, k);
     const int sk = PGA_KIND(s_meta), sf = PGA_FRAME(s_meta);
@@ -174,15 +182,15 @@ __device__ __forceinline__ void visit_source(const int k, const int j, const Src
         // 5'fwd -> 3'fwd: a gene (ref: _connection.h:166-174; skip condition 5: same frame only)
         const bool ok = inwin && T.kind == 1 && T.frame == sf && T.stop_val < s_ndx;
         if (!__any(ok)) return;
-        const double val = readlane_f64(S.score, k) + readlane_f64(S.cs, k);
-        take(B, ok, val, j, -1, s_ndx);
+        const double w = FINAL ? readlane_f64(S.cs, k) : (double)(T.ndx + 2 - s_ndx + 1) * readlane_f64(S.cs, k);
+        take(B, ok, readlane_f64(S.score, k) + w, j, -1, s_ndx);
     } else if (sk == 2) {
         // 5'rev -> 5'fwd (ref: :125-130) and 5'rev -> 3'rev (ref: :337-342)
         const bool a = T.kind == 0 && s_ndx < T.ndx;
         const bool b = T.kind == 3 && s_ndx < T.ndx - 2;
         const bool ok = inwin && (a || b);
         if (!__any(ok)) return;
-        const double w = b ? igm_apart(T.ndx - s_ndx, negc, s_igm) : negc;
+        const double w = !FINAL ? 0.0 : (b ? igm_apart(T.ndx - s_ndx, negc, s_igm) : negc);
         take(B, ok, readlane_f64(S.score, k) + w, j, -1, s_ndx);
     } else if (sk == 3) {
         // 3'rev -> 5'rev: a gene (ref: :228-235; skip condition 6) and 3'rev -> 3'rev operon (ref: :345-356)
@@ -191,7 +199,8 @@ __device__ __forceinline__ void visit_source(const int k, const int j, const Src
         const bool b = T.kind == 3 && s_stop > T.ndx && PGA_SPVALID(T.meta, sf);
         const bool ok = inwin && (a || b);
         if (!__any(ok)) return;
-        const double w = a ? T.cs : sel3(sf, T.x0, T.x1, T.x2);
+        double w = a ? T.cs : sel3(sf, T.x0, T.x1, T.x2);
+        if (!FINAL) w = (double)((a ? T.ndx : sel3i(sf, T.n3n0, T.n3n1, T.n3n2)) - (s_ndx - 2) + 1) * w;
         take(B, ok, readlane_f64(S.score, k) + w, j, -1, s_ndx);
     } else {
         // forward stop as source: connects to all four target kinds
@@ -200,30 +209,41 @@ __device__ __forceinline__ void visit_source(const int k, const int j, const Src
         bool ok = inwin; double w; int mf = -1;
         if (T.kind == 0) {            // 3'fwd -> 5'fwd intergenic (ref: :117-124)
             ok = ok && (s_ndx + 2 < T.ndx);
-            w = igm_apart(T.ndx - s_ndx, negc, s_igm);
+            w = FINAL ? igm_apart(T.ndx - s_ndx, negc, s_igm) : 0.0;
         } else if (T.kind == 1) {     // 3'fwd -> 3'fwd operon through j's overlapping start (ref: :177-188)
             ok = ok && T.stop_val < s_ndx && PGA_SPVALID(s_meta, T.frame);
             w = sel3(T.frame, readlane_f64(S.x0, k), readlane_f64(S.x1, k), readlane_f64(S.x2, k));
+            if (!FINAL) {
+                const int n3 = sel3i(T.frame, __builtin_amdgcn_readlane(S.n3a, k), __builtin_amdgcn_readlane(S.n3b, k), __builtin_amdgcn_readlane(S.n3c, k));
+                w = (double)(T.ndx + 2 - n3 + 1) * w;
+            }
         } else if (T.kind == 2) {     // 3'fwd -> 5'rev overlapping opposite 3' ends (ref: :238-254)
             const int ovlp = (s_ndx + 2) - (T.stop_val - 2) + 1;
             ok = ok && !(T.stop_val - 2 >= s_ndx + 2) && ovlp < PGA_MAX_OPP_OVLP
                     && (s_ndx - T.stop_val) < (T.ndx - s_ndx + 3)
                     && (s_ndx - T.stop_val) < (T.stop_val - 3 - tbnj);
-            w = T.csd;
+            w = FINAL ? T.csd : (double)(T.ndx - (T.stop_val - 2) + 1 - ovlp * 2) * T.cs;
         } else {                      // 3'fwd -> 3'rev, possibly through one of i's overlapping starts (ref: :288-336)
             const int left = s_ndx + 2, right = T.ndx - 2;
             ok = ok && left < right;
             double maxval = 0.0;
+            int ovlp_last = 0;        // training pass: the reference's `ovlp` keeps the value of the last candidate it looked at
 #pragma unroll
             for (int q = 0; q < 3; q++) {
                 const int n3s = sel3i(q, T.n3s0, T.n3s1, T.n3s2), n3n = sel3i(q, T.n3n0, T.n3n1, T.n3n2);
-                const double cur = sel3(q, T.x0, T.x1, T.x2);
+                const double xq = sel3(q, T.x0, T.x1, T.x2);
                 const int ovlp = left - n3s + 3;
-                const bool tk = PGA_SPVALID(T.meta, q) && ovlp > 0 && ovlp < PGA_MAX_OPP_OVLP && ovlp < n3n - left
-                                && ovlp < n3s - tbnj - 2 && cur > maxval;
-                if (tk) { mf = q; maxval = cur; }
+                const bool valid = PGA_SPVALID(T.meta, q) != 0;
+                if (valid) ovlp_last = ovlp;
+                const bool adm = valid && ovlp > 0 && ovlp < PGA_MAX_OPP_OVLP && ovlp < n3n - left && ovlp < n3s - tbnj - 2;
+                if (FINAL) { if (adm && xq > maxval) { mf = q; maxval = xq; } }
+                else if (adm && xq > maxval) {
+                    // the reference compares the factor but remembers the gene-finding value, here the bare intergenic term
+                    mf = q; maxval = igm_same_dev(n3n, -1, 0.0, 0.0, T.ndx, 0.0, 0.0, st_wt, s_igm);
+                }
             }
-            w = mf != -1 ? maxval : negc;
+            if (FINAL) w = mf != -1 ? maxval : negc;
+            else w = (double)(right - left + 1 - ovlp_last * 2) * (mf != -1 ? sel3(mf, T.x0, T.x1, T.x2) : 0.0);
         }
         take(B, ok, sj + w, j, mf, s_ndx);
     }
@@ -1034,7 +1054,7 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
 //   phase I  wave 0 walks the 63 in-batch sources: lane k is final once the walk reaches source
 //            i0+k, because by then it has met every j < i0+k;
 //   wave 0 stores the batch (score, traceb, ov_mark, ndx-of-traceb) and the next batch starts.
-template <int W>
+template <int W, bool FINAL = true>
 __global__ void __launch_bounds__(64 * W)
 k_dp_chain(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src, const DpTgt* __restrict__ g_tgt,
            const ModelConst* __restrict__ models, double* g_score, int32_t* g_traceb, int32_t* g_tbn, int8_t* g_ov,
@@ -1048,7 +1068,7 @@ k_dp_chain(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src
     const ModelConst* mc = &models[cd.model];
     if (wave == 0) s_igm[lane] = mc->igm[lane];
     __syncthreads();
-    const double negc = mc->negc;
+    const double negc = mc->negc, st_wt = mc->st_wt;
     const DpSrc* __restrict__ src = g_src + cd.off;
     const DpTgt* __restrict__ tgt = g_tgt + cd.off;
     double* score = g_score + cd.off; int32_t* traceb = g_traceb + cd.off;
@@ -1070,6 +1090,7 @@ k_dp_chain(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src
             T.n3n0 = mt.n3ndx[0]; T.n3n1 = mt.n3ndx[1]; T.n3n2 = mt.n3ndx[2];
             T.n3s0 = mt.n3stop[0]; T.n3s1 = mt.n3stop[1]; T.n3s2 = mt.n3stop[2];
             T.lo = act ? mt.lo : INT_MAX;
+            T.a0 = me.n3src[0]; T.a1 = me.n3src[1]; T.a2 = me.n3src[2];     // carried for the in-batch walk of the training pass
             if (!act) T.i = -1;       // j < T.i is never true: lane stays idle
         }
         Best B{0.0, -1, -1, -1};
@@ -1082,6 +1103,7 @@ k_dp_chain(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src
             {
                 const DpSrc r = src[sidx];
                 S.ndx = r.ndx; S.stop_val = r.stop_val; S.meta = r.meta; S.cs = r.cs; S.x0 = r.x[0]; S.x1 = r.x[1]; S.x2 = r.x[2];
+                S.n3a = r.n3src[0]; S.n3b = r.n3src[1]; S.n3c = r.n3src[2];
                 S.score = score[sidx]; S.tbn = tbn[sidx];
             }
             const int sk = PGA_KIND(S.meta);
@@ -1090,7 +1112,7 @@ k_dp_chain(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src
             while (visit) {
                 const int k = __builtin_ctzll(visit);
                 visit &= visit - 1;
-                visit_source(k, t0 + k, S, T, negc, s_igm, B);
+                visit_source<FINAL>(k, t0 + k, S, T, negc, s_igm, B, st_wt);
             }
         }
         if (W > 1) {
@@ -1114,7 +1136,8 @@ k_dp_chain(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src
                 SrcLane S;
                 S.ndx = T.ndx; S.stop_val = T.stop_val; S.meta = T.meta; S.tbn = B.tbn;
                 S.cs = T.cs; S.x0 = T.x0; S.x1 = T.x1; S.x2 = T.x2; S.score = B.val;
-                visit_source(k, i0 + k, S, T, negc, s_igm, B);
+                S.n3a = T.a0; S.n3b = T.a1; S.n3c = T.a2;
+                visit_source<FINAL>(k, i0 + k, S, T, negc, s_igm, B, st_wt);
             }
             if (act) {
                 score[T.i] = B.val; traceb[T.i] = B.tb; ovm[T.i] = (int8_t)B.ov; tbn[T.i] = B.tb < 0 ? -1 : B.tbn;
@@ -1141,18 +1164,22 @@ k_dp_chain(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src
 }  // namespace
 
 void pga_launch_dp_prepare(const ChainDesc* d_chains, int n_chains, int64_t node_begin, int64_t total_nodes,
-                           const NodeArrays& nodes, const ModelConst* d_models, DpBuffers buf, hipStream_t st) {
+                           const NodeArrays& nodes, const ModelConst* d_models, DpBuffers buf, hipStream_t st, int final) {
     if (total_nodes <= 0) return;
     const int threads = 256;
     const int64_t blocks = (total_nodes + threads - 1) / threads;
     hipLaunchKernelGGL(k_dp_prepare, dim3((unsigned)blocks), dim3(threads), 0, st,
-                       d_chains, n_chains, node_begin, total_nodes, nodes, d_models, buf.src, buf.tgt);
+                       d_chains, n_chains, node_begin, total_nodes, nodes, d_models, buf.src, buf.tgt, final);
 }
 
 void pga_launch_dp(const ChainDesc* d_chains, int n_chains, const ModelConst* d_models, DpBuffers buf,
                    int final, hipStream_t st) {
-    (void)final;
     if (n_chains <= 0) return;
+    if (!final) {     // training pass: once per genome, the window-scanning kernel is plenty
+        hipLaunchKernelGGL((k_dp_chain<16, false>), dim3(n_chains), dim3(64 * 16), 0, st, d_chains, buf.src, buf.tgt, d_models,
+                           buf.score, buf.traceb, buf.tbn, buf.ov_mark, buf.max_index, buf.max_score, buf.ipath);
+        return;
+    }
 #define PGA_DP_LAUNCH(WAVES) hipLaunchKernelGGL(k_dp_chain<WAVES>, dim3(n_chains), dim3(64 * WAVES), 0, st, d_chains, buf.src, buf.tgt, \
         d_models, buf.score, buf.traceb, buf.tbn, buf.ov_mark, buf.max_index, buf.max_score, buf.ipath)
     const char* kern = getenv("PGA_DP_KERNEL");

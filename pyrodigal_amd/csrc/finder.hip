@@ -26,7 +26,16 @@ struct Buf { void* p = nullptr; size_t cap = 0; };
 
 }  // namespace
 
+// Device arrays of the last stage-level run (single contig), kept for the training driver, which continues from them.
+struct LastRun {
+    const uint8_t* d_dig = nullptr;
+    GroupArrays ga{};
+    ChainArrays ca{};
+    int n_nodes = 0;
+    int len = 0;
+};
 struct FinderState {
+    LastRun last;
     std::map<std::string, Buf> dev, pin;
     std::vector<int> model_group;   // model -> translation-table group
     std::vector<int> group_tt;
@@ -880,6 +889,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             }
             HT(c, hipGetLastError());
             HT(c, hipStreamSynchronize(st));
+            f->last.d_dig = d_dig; f->last.ga = ga[0]; f->last.ca = ca; f->last.n_nodes = (int)nn; f->last.len = ct[0].len;
             R->nodes.resize(NC);
             for (int i = 0; i < NC; i++) {
                 pga_nodes& N = R->nodes[i];
@@ -1238,6 +1248,8 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
     return publish(R, guard.r, P, out);
 }
 
+#include "train.inl"
+
 extern "C" int pga_find_genes(pga_ctx* c, const pga_batch* batch, const pga_params* pp, pga_result** out) {
     const auto t0 = std::chrono::steady_clock::now();
     const int rc = find_impl(c, batch, pp, 0, 0, out);
@@ -1252,4 +1264,9 @@ extern "C" int pga_nodes_stage(pga_ctx* c, const pga_batch* batch, const pga_par
         return PGA_EINVAL;
     }
     return find_impl(c, batch, pp, stage, translation_table, out);
+}
+
+extern "C" int pga_train(pga_ctx* c, const pga_batch* batch, const pga_params* pp, int translation_table, double start_weight,
+                         int force_nonsd, int upto, pga_training* out) {
+    return train_impl(c, batch, pp, translation_table, start_weight, force_nonsd, upto <= 0 ? TR_ALL : upto, out);
 }

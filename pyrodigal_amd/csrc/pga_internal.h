@@ -26,7 +26,8 @@ struct __attribute__((aligned(64))) DpSrc {
     int32_t ndx, stop_val, meta, _pad;
     double  cs;      // cscore + sscore
     double  x[3];    // F3: cs(n3_k) + igm(j, n3_k);  R3: cs(n3_k) + igm(n3_k, i)   (n3_k = nodes[star_ptr[k]])
-    double  _pad2[2];
+    int32_t n3src[3];   // training pass only, F3 nodes: ndx of the overlapping start of each frame (star_ptr)
+    int32_t _pad2;
 };
 // Per-node record only needed when the node is the target i. 80 bytes.
 // The index ranges are static (positions only) and found by binary search in dp_prepare.
@@ -63,6 +64,7 @@ struct NodeArrays {
     const int32_t* ndx; const int32_t* stop_val; const uint8_t* type; const int8_t* strand;   // indexed by topo_off + i
     const double* cscore; const double* sscore; const double* rscore; const double* uscore;   // indexed by off + i
     const int32_t* star_ptr;   // [n][3], indexed by off + i
+    const double* gcb;         // training pass (final = 0) only: bias . gc_score of each node, indexed by off + i
 };
 
 struct DpBuffers {
@@ -80,7 +82,7 @@ struct DpBuffers {
 // kernel launchers (dp.hip)
 // chains[0..n_chains) must be contiguous in `off`; node_begin = chains[0].off, total_nodes = their node count
 void pga_launch_dp_prepare(const ChainDesc* d_chains, int n_chains, int64_t node_begin, int64_t total_nodes,
-                           const NodeArrays& nodes, const ModelConst* d_models, DpBuffers buf, hipStream_t st);
+                           const NodeArrays& nodes, const ModelConst* d_models, DpBuffers buf, hipStream_t st, int final = 1);
 void pga_launch_dp(const ChainDesc* d_chains, int n_chains, const ModelConst* d_models, DpBuffers buf,
                    int final, hipStream_t st);
 

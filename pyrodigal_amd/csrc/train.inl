@@ -1,0 +1,258 @@
+// Single-genome training on the device (ref: lib.pyx:5236-5279 GeneFinder._train, TrainingInfo._calc_dicodon_gene
+// 4284-4358, _train_starts_sd 4391-4599, _train_starts_nonsd 4601-4827; Prodigal node.c record_gc_bias /
+// determine_sd_usage).  Included by finder.hip: the driver continues from the device arrays that the stage-level
+// runs (extraction, scoring) leave behind.  Everything per base / per node runs in kernels; every accumulation is
+// a count (an exact integer in a double, so the order of additions does not matter); libm's log stays on the host,
+// where the reference calls it.
+namespace {
+
+constexpr int TR_GC_HALF = 60;          // GC_WINDOW / 2 (ref: lib.pyx:171)
+
+__device__ inline int tr_is_gc(const uint8_t* __restrict__ d, int i) { const int x = d[i]; return x != 0 && x != 3; }   // unknown bases count as GC
+__device__ inline int tr_max_fr(int a, int b, int c) { return a > b ? (a > c ? 0 : 2) : (b > c ? 1 : 2); }
+__device__ inline int tr_comp(int d) { return d <= 3 ? (d ^ 3) : 6; }
+// 2-bit word of `len` bases starting at strand position i (ref: _sequence.h:207-220)
+__device__ inline int tr_mer(const uint8_t* __restrict__ d, int L, int i, int len, int strand) {
+    int v = 0;
+    if (strand == 1) { for (int j = 0; j < len; j++) v |= (d[i + j] & 3) << (2 * j); }
+    else { const int k = L - 1 - i; for (int j = 0; j < len; j++) v |= (tr_comp(d[k - j]) & 3) << (2 * j); }
+    return v;
+}
+
+// ref: lib.pyx:724-768 (Sequence._max_gc_frame_plot).  The running sums of the reference reduce to
+// tot[i] = sum of gc[i + 3 m] for |m| < 20 inside the sequence; the codon at i (i % 3 == 0) gets the frame with the most.
+__global__ void __launch_bounds__(256)
+k_gc_frame(const uint8_t* __restrict__ d, int L, int8_t* __restrict__ gp) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;       // codon index
+    const int i = 3 * c;
+    if (i >= L) return;
+    if (i >= L - 2) { for (int q = i; q < L; q++) gp[q] = -1; return; }
+    int tot[3];
+    for (int f = 0; f < 3; f++) {
+        int s = 0;
+        for (int m = -(TR_GC_HALF / 3 - 1); m <= TR_GC_HALF / 3 - 1; m++) {
+            const int p = i + f + 3 * m;
+            if (p >= 0 && p < L) s += tr_is_gc(d, p);
+        }
+        tot[f] = s;
+    }
+    const int w = tr_max_fr(tot[0], tot[1], tot[2]);
+    gp[i] = gp[i + 1] = gp[i + 2] = (int8_t)w;
+}
+
+// Prodigal node.c record_gc_bias: per start node, how often each codon position is the GC-richest one between the
+// start and its stop.
+__global__ void __launch_bounds__(256)
+k_gc_bias(int n, const int32_t* __restrict__ ndx, const int32_t* __restrict__ stop_val, const uint8_t* __restrict__ type,
+          const int8_t* __restrict__ strand, const int8_t* __restrict__ gp, double* __restrict__ gc_score, uint8_t* __restrict__ gc_bias) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    gc_score[3 * i] = gc_score[3 * i + 1] = gc_score[3 * i + 2] = 0.0; gc_bias[i] = 0;
+    if (type[i] == PGA_T_STOP) return;
+    int ctr[3] = {0, 0, 0};
+    const int fr = ndx[i] % 3;
+    if (strand[i] == 1) {
+        const int fm = 3 - fr;
+        for (int j = stop_val[i]; j >= ndx[i]; j -= 3) ctr[(gp[j] + fm) % 3]++;
+        for (int q = 0; q < 3; q++) { double g = 3.0 * ctr[q]; g /= 1.0 * (stop_val[i] - ndx[i] + 3); gc_score[3 * i + q] = g; }
+    } else {
+        const int fm = fr;
+        for (int j = stop_val[i]; j <= ndx[i]; j += 3) ctr[((3 - gp[j]) + fm) % 3]++;
+        for (int q = 0; q < 3; q++) { double g = 3.0 * ctr[q]; g /= 1.0 * (ndx[i] - stop_val[i] + 3); gc_score[3 * i + q] = g; }
+    }
+    gc_bias[i] = (uint8_t)tr_max_fr(ctr[0], ctr[1], ctr[2]);
+}
+// the one ordered floating-point sum of the training: node order, one thread
+__global__ void k_bias_sum(int n, const int32_t* __restrict__ ndx, const int32_t* __restrict__ stop_val, const uint8_t* __restrict__ type,
+                           const double* __restrict__ gc_score, const uint8_t* __restrict__ gc_bias, double* __restrict__ bias) {
+    double b[3] = {0.0, 0.0, 0.0};
+    for (int i = 0; i < n; i++) {
+        if (type[i] == PGA_T_STOP) continue;
+        const int len = abs(stop_val[i] - ndx[i]) + 1;
+        b[gc_bias[i]] += (gc_score[3 * i + gc_bias[i]] * len) / 1000.0;
+    }
+    const double tot = b[0] + b[1] + b[2];
+    for (int q = 0; q < 3; q++) bias[q] = b[q] * (3.0 / tot);
+}
+__global__ void __launch_bounds__(256)
+k_gcb(int n, const double* __restrict__ gc_score, const double* __restrict__ bias, double* __restrict__ gcb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) gcb[i] = bias[0] * gc_score[3 * i] + bias[1] * gc_score[3 * i + 1] + bias[2] * gc_score[3 * i + 2];
+}
+
+// ref: lib.pyx:2279-2329 with flag == 0: the first start of each frame met while walking away from the stop
+__global__ void __launch_bounds__(256)
+k_ovl_starts0(int n, const int32_t* __restrict__ ndx, const int32_t* __restrict__ stop_val, const uint8_t* __restrict__ type,
+              const int8_t* __restrict__ strand, const uint8_t* __restrict__ edge, int maxov, int32_t* __restrict__ star_ptr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int sp[3] = {-1, -1, -1};
+    if (type[i] == PGA_T_STOP && edge[i] != 1) {
+        const int me = ndx[i];
+        if (strand[i] == 1) {
+            for (int j = i + 3; j >= 0; j--) {
+                if (j >= n || ndx[j] > me + 2) continue;
+                if (ndx[j] + maxov < me) break;
+                if (strand[j] != 1 || type[j] == PGA_T_STOP) continue;
+                if (stop_val[j] <= me) continue;
+                const int f = ndx[j] % 3;
+                if (sp[f] == -1) sp[f] = j;
+            }
+        } else {
+            for (int j = i - 3; j < n; j++) {
+                if (j < 0 || ndx[j] < me - 2) continue;
+                if (ndx[j] - maxov > me) break;
+                if (strand[j] != -1 || type[j] == PGA_T_STOP) continue;
+                if (stop_val[j] >= me) continue;
+                const int f = ndx[j] % 3;
+                if (sp[f] == -1) sp[f] = j;
+            }
+        }
+    }
+    star_ptr[3 * i] = sp[0]; star_ptr[3 * i + 1] = sp[1]; star_ptr[3 * i + 2] = sp[2];
+}
+
+// hexamer statistics (ref: lib.pyx:4284-4358): every window of both strands, then the codons of the genes of the path
+__global__ void __launch_bounds__(256)
+k_hexamer_bg(const uint8_t* __restrict__ d, int L, unsigned int* __restrict__ counts) {
+    __shared__ unsigned int s_c[4096];
+    for (int q = threadIdx.x; q < 4096; q += blockDim.x) s_c[q] = 0;
+    __syncthreads();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L - 5; i += gridDim.x * blockDim.x) {
+        atomicAdd(&s_c[tr_mer(d, L, i, 6, 1)], 1u);
+        atomicAdd(&s_c[tr_mer(d, L, i, 6, -1)], 1u);
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < 4096; q += blockDim.x) if (s_c[q]) atomicAdd(&counts[q], s_c[q]);
+}
+struct TrGene { int left, right, strand; };     // strand-local [left, right - 5) step 3
+__global__ void __launch_bounds__(256)
+k_hexamer_genes(const uint8_t* __restrict__ d, int L, const TrGene* __restrict__ genes, int n_genes, unsigned int* __restrict__ counts) {
+    const int g = blockIdx.x;
+    if (g >= n_genes) return;
+    const TrGene G = genes[g];
+    for (int i = G.left + 3 * threadIdx.x; i < G.right - 5; i += 3 * blockDim.x) atomicAdd(&counts[tr_mer(d, L, i, 6, G.strand)], 1u);
+}
+
+
+// stages of the driver, for step-by-step validation against the oracle (PGA_TRAIN_* in the header)
+enum { TR_BIAS = 1, TR_DICODON = 2, TR_SD = 3, TR_ALL = 4 };
+
+// log-odds of the hexamer usage in genes against the whole sequence (ref: lib.pyx:4336-4358); libm on the host
+void tr_gene_dc(const unsigned int* bgc, const unsigned int* gc, pga_training* t) {
+    unsigned long long glob_bg = 0, glob = 0;
+    for (int i = 0; i < 4096; i++) { glob_bg += bgc[i]; glob += gc[i]; }
+    for (int i = 0; i < 4096; i++) {
+        const double bg = (double)(int)bgc[i] / (double)(int)glob_bg;
+        const double prob = (double)(int)gc[i] / (double)(int)glob;
+        double v;
+        if (prob == 0 && bg != 0) v = -5.0;
+        else if (bg == 0) v = 0.0;
+        else v = log(prob / bg);
+        if (v > 5.0) v = 5.0; else if (v < -5.0) v = -5.0;
+        t->gene_dc[i] = v;
+    }
+}
+
+}  // namespace
+
+static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, const int stage, const int tt_override, pga_result** out);
+
+// ref: lib.pyx:5236-5279 (GeneFinder._train) for ONE sequence (the host layer joins several with the reference's spacer)
+static int train_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, int tt, double start_weight, int force_nonsd,
+                      int upto, pga_training* t) {
+    if (!c || !batch || !pp || !t || batch->ctx != c || batch->n != 1) { if (c) c->err = "pga_train: needs a batch of exactly one sequence"; return PGA_EINVAL; }
+    memset(t, 0, sizeof *t);
+    t->trans_table = tt; t->st_wt = start_weight; t->uses_sd = 1;
+    pga_params P = *pp; P.meta = 0; P.want_nodes = 1;
+    hipStream_t st = c->stream;
+    // ---- nodes (ref: lib.pyx:5252-5257): extraction + sort through the stage-level path; its device arrays stay
+    pga_result* r1 = nullptr;
+    if (int rc = find_impl(c, batch, &P, PGA_STAGE_EXTRACT, tt, &r1)) return rc;
+    struct Free { pga_result* r; ~Free() { if (r) pga_result_free(r); } } fr1{r1};
+    t->gc = r1->contigs[0].gc;
+    const int n = r1->nodes[0].n, L = batch->ct[0].len;
+    if (n == 0) { c->err = "pga_train: no start / stop node in the sequence"; return PGA_EINVAL; }
+    const pga_nodes& H = r1->nodes[0];                 // host copies of the topology
+    FinderState* f = c->finder;
+    const LastRun lr = f->last;
+    const GroupArrays& ga = lr.ga;
+    // ---- GC frame bias (ref: lib.pyx:5259-5261)
+    DEVBUF(d_gp, int8_t, "tr_gp", L + 4);
+    DEVBUF(d_gcs, double, "tr_gc_score", 3 * (size_t)n + 3);
+    DEVBUF(d_gcbias, uint8_t, "tr_gc_bias", n + 1);
+    DEVBUF(d_bias, double, "tr_bias", 4);
+    DEVBUF(d_gcb, double, "tr_gcb", n + 1);
+    DEVBUF(d_star, int32_t, "tr_star", 3 * (size_t)n + 3);
+    const int nb = (n + 255) / 256;
+    hipLaunchKernelGGL(k_gc_frame, dim3((L / 3 + 256) / 256), dim3(256), 0, st, lr.d_dig, L, d_gp);
+    hipLaunchKernelGGL(k_gc_bias, dim3(nb), dim3(256), 0, st, n, ga.ndx, ga.stop_val, ga.type, ga.strand, d_gp, d_gcs, d_gcbias);
+    hipLaunchKernelGGL(k_bias_sum, dim3(1), dim3(1), 0, st, n, ga.ndx, ga.stop_val, ga.type, d_gcs, d_gcbias, d_bias);
+    HT(c, hipMemcpyAsync(t->bias, d_bias, sizeof(double) * 3, hipMemcpyDeviceToHost, st));
+    HT(c, hipGetLastError());
+    HT(c, hipStreamSynchronize(st));
+    if (upto == TR_BIAS) return PGA_OK;
+    // ---- training pass of the dynamic programme (ref: lib.pyx:5263-5267)
+    hipLaunchKernelGGL(k_gcb, dim3(nb), dim3(256), 0, st, n, d_gcs, d_bias, d_gcb);
+    hipLaunchKernelGGL(k_ovl_starts0, dim3(nb), dim3(256), 0, st, n, ga.ndx, ga.stop_val, ga.type, ga.strand, ga.edge0, P.max_overlap, d_star);
+    DpBuffers dp;
+    {
+        DEVBUF(b0, DpSrc, "dp_src", n + 1) DEVBUF(b1, DpTgt, "dp_tgt", n + 1) DEVBUF(b2, double, "dp_score", n + 1) DEVBUF(b3, int32_t, "dp_traceb", n + 1)
+        DEVBUF(b4, int32_t, "dp_tbn", n + 1) DEVBUF(b5, int8_t, "dp_ov", n + 1) DEVBUF(b6, int32_t, "dp_maxidx", 2) DEVBUF(b7, double, "dp_maxscore", 2)
+        DEVBUF(b8, int32_t, "dp_ipath", 2)
+        dp = DpBuffers{b0, b1, b2, b3, b4, b5, b6, b7, b8, nullptr, {nullptr, nullptr, nullptr}, nullptr, nullptr, nullptr};
+    }
+    DEVBUF(d_chain, ChainDesc, "tr_chain", 2);
+    DEVBUF(d_mc, ModelConst, "tr_mc", 2);
+    ChainDesc ch{0, 0, n, 0, 0, 1};
+    ModelConst mc; pga_fill_model_const(&mc, start_weight);
+    HT(c, hipMemcpyAsync(d_chain, &ch, sizeof ch, hipMemcpyHostToDevice, st));
+    HT(c, hipMemcpyAsync(d_mc, &mc, sizeof mc, hipMemcpyHostToDevice, st));
+    NodeArrays na{ga.ndx, ga.stop_val, ga.type, ga.strand, d_gcb, d_gcb, d_gcb, d_gcb, d_star, d_gcb};   // scores are not read when final = 0
+    pga_launch_dp_prepare(d_chain, 1, 0, n, na, d_mc, dp, st, 0);
+    pga_launch_dp(d_chain, 1, d_mc, dp, 0, st);
+    std::vector<int32_t> traceb((size_t)n), tracef((size_t)n, -1), star((size_t)3 * n), path((size_t)n + 1);
+    std::vector<int8_t> ovm((size_t)n);
+    std::vector<uint8_t> elim((size_t)n, 0);
+    int32_t mx = -1;
+    HT(c, hipMemcpyAsync(traceb.data(), dp.traceb, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+    HT(c, hipMemcpyAsync(ovm.data(), dp.ov_mark, n, hipMemcpyDeviceToHost, st));
+    HT(c, hipMemcpyAsync(star.data(), d_star, sizeof(int32_t) * 3 * n, hipMemcpyDeviceToHost, st));
+    HT(c, hipMemcpyAsync(&mx, dp.max_index, 4, hipMemcpyDeviceToHost, st));
+    HT(c, hipGetLastError());
+    HT(c, hipStreamSynchronize(st));
+    // ---- the genes of the best path (ref: lib.pyx:1253-1311 untangling; 4299-4334 walk from the path's end)
+    std::vector<TrGene> genes;
+    if (mx >= 0) {
+        NodeView v{n, H.ndx, H.stop_val, H.type, H.strand, H.edge, nullptr, nullptr, nullptr, nullptr, nullptr, star.data(), traceb.data(),
+                   tracef.data(), ovm.data(), nullptr, elim.data()};
+        untangle(v, mx, path.data());
+        const int ipath = traceb[mx] == -1 ? -1 : mx;
+        int in_gene = 0, left = -1, right = -1;
+        for (int p = ipath; p != -1; p = traceb[p]) {
+            if (H.strand[p] == 1) {
+                if (H.type[p] == PGA_T_STOP) { in_gene = 1; right = H.ndx[p] + 2; }
+                else if (in_gene == 1) { left = H.ndx[p]; genes.push_back(TrGene{left, right, 1}); in_gene = 0; }
+            } else {
+                if (H.type[p] != PGA_T_STOP) { in_gene = -1; left = L - H.ndx[p] - 1; }
+                else if (in_gene == -1) { right = L - H.ndx[p] + 1; genes.push_back(TrGene{left, right, -1}); in_gene = 0; }
+            }
+        }
+    }
+    // ---- hexamer statistics (ref: lib.pyx:5269, 4284-4358)
+    DEVBUF(d_cnt, unsigned int, "tr_hex", 2 * 4096);
+    DEVBUF(d_genes, TrGene, "tr_genes", genes.size() + 1);
+    HT(c, hipMemsetAsync(d_cnt, 0, sizeof(unsigned int) * 2 * 4096, st));
+    if (!genes.empty()) HT(c, hipMemcpyAsync(d_genes, genes.data(), sizeof(TrGene) * genes.size(), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_hexamer_bg, dim3(1024), dim3(256), 0, st, lr.d_dig, L, d_cnt);
+    if (!genes.empty()) hipLaunchKernelGGL(k_hexamer_genes, dim3((unsigned)genes.size()), dim3(64), 0, st, lr.d_dig, L, d_genes, (int)genes.size(), d_cnt + 4096);
+    std::vector<unsigned int> cnt(2 * 4096);
+    HT(c, hipMemcpyAsync(cnt.data(), d_cnt, sizeof(unsigned int) * 2 * 4096, hipMemcpyDeviceToHost, st));
+    HT(c, hipGetLastError());
+    HT(c, hipStreamSynchronize(st));
+    tr_gene_dc(cnt.data(), cnt.data() + 4096, t);
+    if (upto == TR_DICODON) return PGA_OK;
+    (void)force_nonsd;
+    c->err = "pga_train: start training not implemented yet";
+    return PGA_EINVAL;
+}
