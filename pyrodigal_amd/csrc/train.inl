@@ -135,6 +135,76 @@ k_hexamer_genes(const uint8_t* __restrict__ d, int L, const TrGene* __restrict__
 }
 
 
+// ---- start training (ref: lib.pyx:4391-4599 _train_starts_sd, 4601-4827 _train_starts_nonsd) ----------------------
+struct TrWeights {            // what changes from one iteration to the next
+    double rbs_wt[28], type_wt[3], st_wt, sthresh, no_mot;
+    int last_iter, stage, uses_sd;
+};
+struct TrCounts {             // everything counted in one iteration (integers)
+    unsigned int rbg[28], rreal[28], treal[3], tbg[3], ngenes, zero_bg, zero_real, _pad;
+    unsigned int ups[32][4];
+};
+__device__ inline int tr_pick_rbs(const double* __restrict__ w, int r0, int r1) {   // ref: lib.pyx:4441-4448
+    const double w0 = w[r0], w1 = w[r1];
+    if (w0 > w1 + 1.0 || r1 == 0) return r0;
+    if (w0 < w1 - 1.0 || r0 == 0) return r1;
+    return r0 > r1 ? r0 : r1;
+}
+// ref: lib.pyx:4360-4389 (TrainingInfo._count_upstream_composition)
+__device__ inline void tr_count_upstream(const uint8_t* __restrict__ d, int L, int pos, int strand, TrCounts* __restrict__ cn) {
+    int k = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        const int lo = pass ? 15 : 1, hi = pass ? 45 : 3;
+        for (int j = lo; j < hi; j++, k++) {
+            if (strand == 1) { if (pos >= j) atomicAdd(&cn->ups[k][d[pos - j] & 3], 1u); }
+            else { if (pos + j < L) atomicAdd(&cn->ups[k][tr_comp(d[pos + j]) & 3], 1u); }
+        }
+    }
+}
+// background of one iteration: start types (all starts) and the RBS bin each non-edge start would pick
+__global__ void __launch_bounds__(256)
+k_ts_background(int n, const uint8_t* __restrict__ type, const uint8_t* __restrict__ edge, const uint8_t* __restrict__ rbs,
+                const TrWeights* __restrict__ w, TrCounts* __restrict__ cn, int count_types) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || type[i] == PGA_T_STOP) return;
+    if (count_types) atomicAdd(&cn->tbg[type[i]], 1u);
+    if (edge[i]) return;
+    atomicAdd(&cn->rbg[tr_pick_rbs(w->rbs_wt, rbs[2 * i], rbs[2 * i + 1])], 1u);
+}
+// One thread per stop node: the best non-edge start of its ORF under the current weights; a confident one is counted.
+// The reference sweeps the nodes in strand order with ">=", i.e. among equal best starts the one met last wins:
+// the highest index on the forward strand, the lowest on the reverse strand.
+template <bool SD>
+__global__ void __launch_bounds__(256)
+k_ts_best(int n, const int32_t* __restrict__ ndx, const int32_t* __restrict__ stop_val, const uint8_t* __restrict__ type,
+          const int8_t* __restrict__ strand, const uint8_t* __restrict__ edge, const double* __restrict__ cscore,
+          const uint8_t* __restrict__ rbs, const double* __restrict__ mot_score, const uint8_t* __restrict__ d, int L,
+          const TrWeights* __restrict__ w, TrCounts* __restrict__ cn, int32_t* __restrict__ best_of_stop) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    if (best_of_stop) best_of_stop[s] = -1;
+    if (type[s] != PGA_T_STOP) return;
+    const int st = strand[s], ph = ndx[s] % 3, sv = stop_val[s];
+    const double wt = w->st_wt;
+    double best = 0.0; int bndx = -1, brbs = 0;
+    const int step = st == 1 ? -1 : 1;
+    for (int j = s + step; j >= 0 && j < n; j += step) {
+        if (st == 1 ? ndx[j] <= sv : ndx[j] >= sv) break;            // past the other end of the ORF
+        if (strand[j] != st || ndx[j] % 3 != ph) continue;
+        if (type[j] == PGA_T_STOP) break;                             // the neighbouring stop of this frame (defensive: sv marks it)
+        if (edge[j]) continue;
+        int mr = 0; double v;
+        if (SD) { mr = tr_pick_rbs(w->rbs_wt, rbs[2 * j], rbs[2 * j + 1]); v = cscore[j] + wt * w->rbs_wt[mr] + wt * w->type_wt[type[j]]; }
+        else v = cscore[j] + wt * mot_score[j] + wt * w->type_wt[type[j]];
+        if (bndx == -1 ? v >= 0.0 : v > best) { best = v; bndx = j; brbs = mr; }
+    }
+    if (bndx == -1 || !(best >= w->sthresh)) return;
+    if (SD) atomicAdd(&cn->rreal[brbs], 1u);
+    else { atomicAdd(&cn->ngenes, 1u); if (best_of_stop) best_of_stop[s] = bndx; }
+    atomicAdd(&cn->treal[type[bndx]], 1u);
+    if (w->last_iter) tr_count_upstream(d, L, ndx[bndx], st, cn);
+}
+
 // stages of the driver, for step-by-step validation against the oracle (PGA_TRAIN_* in the header)
 enum { TR_BIAS = 1, TR_DICODON = 2, TR_SD = 3, TR_ALL = 4 };
 
@@ -152,6 +222,41 @@ void tr_gene_dc(const unsigned int* bgc, const unsigned int* gc, pga_training* t
         if (v > 5.0) v = 5.0; else if (v < -5.0) v = -5.0;
         t->gene_dc[i] = v;
     }
+}
+
+
+void tr_log_odds(const unsigned int* real, const double* bgv, double* out, int nq) {     // ref: lib.pyx:4528-4569
+    double sum = 0.0;
+    for (int j = 0; j < nq; j++) sum += (double)real[j];
+    if (sum == 0.0) { for (int j = 0; j < nq; j++) out[j] = 0.0; return; }
+    for (int j = 0; j < nq; j++) {
+        const double r = (double)real[j] / sum;
+        out[j] = bgv[j] != 0 ? log(r / bgv[j]) : -4.0;
+        if (out[j] > 4.0) out[j] = 4.0; else if (out[j] < -4.0) out[j] = -4.0;
+    }
+}
+void tr_ups_to_log(const unsigned int (*ups)[4], pga_training* t) {     // ref: lib.pyx:4571-4599 / 4797-4827
+    for (int i = 0; i < 32; i++) {
+        double sum = 0.0;
+        for (int j = 0; j < 4; j++) { t->ups_comp[i][j] = (double)ups[i][j]; sum += t->ups_comp[i][j]; }
+        if (sum == 0.0) { for (int j = 0; j < 4; j++) t->ups_comp[i][j] = 0.0; continue; }
+        for (int j = 0; j < 4; j++) {
+            double* u = &t->ups_comp[i][j];
+            *u /= sum;
+            const bool at = (j == 0 || j == 3);
+            if (t->gc <= 0.1) *u = log(*u * 2.0 / (at ? 0.90 : 0.10));
+            else if (t->gc >= 0.9) *u = log(*u * 2.0 / (at ? 0.10 : 0.90));
+            else *u = at ? log(*u * 2.0 / (1.0 - t->gc)) : log(*u * 2.0 / t->gc);
+            if (*u > 4.0) *u = 4.0;
+            if (*u < -4.0) *u = -4.0;
+        }
+    }
+}
+void tr_determine_sd_usage(pga_training* t) {       // Prodigal node.c determine_sd_usage
+    t->uses_sd = 1;
+    if (t->rbs_wt[0] >= 0.0) t->uses_sd = 0;
+    if (t->rbs_wt[16] < 1.0 && t->rbs_wt[13] < 1.0 && t->rbs_wt[15] < 1.0 &&
+        (t->rbs_wt[0] >= -0.5 || (t->rbs_wt[22] < 2.0 && t->rbs_wt[24] < 2.0 && t->rbs_wt[27] < 2.0))) t->uses_sd = 0;
 }
 
 }  // namespace
@@ -252,7 +357,53 @@ static int train_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, 
     HT(c, hipStreamSynchronize(st));
     tr_gene_dc(cnt.data(), cnt.data() + 4096, t);
     if (upto == TR_DICODON) return PGA_OK;
-    (void)force_nonsd;
-    c->err = "pga_train: start training not implemented yet";
+    // ---- coding scores and RBS bins under the new statistics (ref: lib.pyx:5271-5273): the scoring stage of the path
+    {
+        const pga_training* tp = t;
+        if (int rc = pga_set_models(c, &tp, 1)) return rc;
+    }
+    pga_result* r2 = nullptr;
+    if (int rc = find_impl(c, batch, &P, PGA_STAGE_SCORE, tt, &r2)) return rc;
+    Free fr2{r2};
+    if (r2->nodes[0].n != n) { c->err = "pga_train: node count changed between the stages"; return PGA_EDEVICE; }
+    f = c->finder;
+    const LastRun ls = f->last;                       // topology (again) + chain arrays of the scoring stage
+    const GroupArrays& gs = ls.ga;
+    DEVBUF(d_w, TrWeights, "tr_weights", 2);
+    DEVBUF(d_cn, TrCounts, "tr_counts", 2);
+    TrWeights w; memset(&w, 0, sizeof w);
+    w.st_wt = t->st_wt; w.sthresh = 35.0; w.uses_sd = 1;
+    TrCounts cn;
+    double tbg[3] = {0, 0, 0};
+    memset(t->type_wt, 0, sizeof t->type_wt); memset(t->rbs_wt, 0, sizeof t->rbs_wt); memset(t->ups_comp, 0, sizeof t->ups_comp);
+    // ---- Shine-Dalgarno start training: 10 rounds (ref: lib.pyx:4391-4599)
+    for (int it = 0; it < 10; it++) {
+        memcpy(w.rbs_wt, t->rbs_wt, sizeof w.rbs_wt); memcpy(w.type_wt, t->type_wt, sizeof w.type_wt);
+        w.last_iter = it == 9;
+        HT(c, hipMemcpyAsync(d_w, &w, sizeof w, hipMemcpyHostToDevice, st));
+        HT(c, hipMemsetAsync(d_cn, 0, sizeof(TrCounts), st));
+        hipLaunchKernelGGL(k_ts_background, dim3(nb), dim3(256), 0, st, n, gs.type, gs.edge0, ls.ca.rbs, d_w, d_cn, 1);
+        hipLaunchKernelGGL(k_ts_best<true>, dim3(nb), dim3(256), 0, st, n, gs.ndx, gs.stop_val, gs.type, gs.strand, gs.edge0, ls.ca.cscore,
+                           ls.ca.rbs, (const double*)nullptr, ls.d_dig, L, d_w, d_cn, (int32_t*)nullptr);
+        HT(c, hipMemcpyAsync(&cn, d_cn, sizeof cn, hipMemcpyDeviceToHost, st));
+        HT(c, hipGetLastError());
+        HT(c, hipStreamSynchronize(st));
+        if (it == 0) {
+            double sum = 0.0;
+            for (int j = 0; j < 3; j++) { tbg[j] = (double)cn.tbg[j]; sum += tbg[j]; }
+            for (int j = 0; j < 3; j++) tbg[j] /= sum;
+        }
+        double rbg[28], sum = 0.0;
+        for (int j = 0; j < 28; j++) { rbg[j] = (double)cn.rbg[j]; sum += rbg[j]; }
+        for (int j = 0; j < 28; j++) rbg[j] /= sum;
+        tr_log_odds(cn.rreal, rbg, t->rbs_wt, 28);
+        sum = 0.0; for (int j = 0; j < 3; j++) sum += (double)cn.treal[j];
+        tr_log_odds(cn.treal, tbg, t->type_wt, 3);
+        if (sum * 2000.0 <= n) w.sthresh /= 2.0;
+    }
+    tr_ups_to_log(cn.ups, t);
+    if (force_nonsd) t->uses_sd = 0; else tr_determine_sd_usage(t);
+    if (upto == TR_SD || t->uses_sd) return PGA_OK;
+    c->err = "pga_train: non-SD start training not implemented yet";
     return PGA_EINVAL;
 }
