@@ -205,6 +205,74 @@ k_ts_best(int n, const int32_t* __restrict__ ndx, const int32_t* __restrict__ st
     if (w->last_iter) tr_count_upstream(d, L, ndx[bndx], st, cn);
 }
 
+// ---- motif statistics of the non-SD training -------------------------------------------------------------------------
+struct TrMotifs { int32_t* ndx; uint8_t* len; uint8_t* spacer; uint8_t* spacendx; double* score; };   // per node
+__device__ inline int tr_spacer_index(int j, int start, int i) {
+    if (j <= start - 16 - i) return 3;
+    if (j <= start - 14 - i) return 2;
+    if (j >= start - 7 - i) return 1;
+    return 0;
+}
+// ref: lib.pyx:1556-1616 (Node._find_best_upstream_motif) with the training stages
+__global__ void __launch_bounds__(256)
+k_mot_best(int n, const int32_t* __restrict__ ndx, const uint8_t* __restrict__ type, const int8_t* __restrict__ strand,
+           const uint8_t* __restrict__ edge, const uint8_t* __restrict__ d, int L, const double* __restrict__ mot_wt /* [4][4][4096] */,
+           const TrWeights* __restrict__ w, TrMotifs m) {
+    const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i0 >= n || type[i0] == PGA_T_STOP || edge[i0]) return;
+    const int st = strand[i0], start = st == 1 ? ndx[i0] : L - 1 - ndx[i0];
+    int bsp = 0, bsi = 0, blen = 0, bndx = 0; double bsc = -100.0;
+    for (int i = 3; i >= 0; i--) {
+        for (int j = start - 18 - i; j < start - 5 - i; j++) {
+            if (j < 0) continue;
+            const int si = tr_spacer_index(j, start, i);
+            const int idx = tr_mer(d, L, j, i + 3, st);
+            const double sc = mot_wt[(i * 4 + si) * 4096 + idx];
+            if (sc > bsc) { bsc = sc; bsi = si; bsp = start - j - i - 3; bndx = idx; blen = i + 3; }
+        }
+    }
+    if (w->stage == 2 && (bsc == -4.0 || bsc < w->no_mot + 0.69)) {
+        m.ndx[i0] = 0; m.len[i0] = 0; m.spacendx[i0] = 0; m.spacer[i0] = 0; m.score[i0] = w->no_mot;
+    } else {
+        m.ndx[i0] = bndx; m.len[i0] = (uint8_t)blen; m.spacendx[i0] = (uint8_t)bsi; m.spacer[i0] = (uint8_t)(bsp & 15); m.score[i0] = bsc;
+    }
+}
+// ref: lib.pyx:4225-4282 (TrainingInfo._update_motif_counts) for node i
+__device__ inline void tr_update_motif_counts(int i0, const int32_t* __restrict__ ndx, const int8_t* __restrict__ strand,
+                                              const uint8_t* __restrict__ d, int L, const TrMotifs& m, int stage,
+                                              unsigned int* __restrict__ cnt /* [4][4][4096] */, unsigned int* __restrict__ zero) {
+    if (m.len[i0] == 0) { atomicAdd(zero, 1u); return; }
+    const int st = strand[i0], start = st == 1 ? ndx[i0] : L - 1 - ndx[i0];
+    const int mlen = m.len[i0];
+    if (stage == 0) {
+        for (int i = 3; i >= 0; i--)
+            for (int j = start - 18 - i; j < start - 5 - i; j++) {
+                if (j < 0) continue;
+                const int mer = tr_mer(d, L, j, i + 3, st);
+                for (int k = 0; k < 4; k++) atomicAdd(&cnt[(i * 4 + k) * 4096 + mer], 1u);
+            }
+    } else if (stage == 1) {
+        atomicAdd(&cnt[((mlen - 3) * 4 + m.spacendx[i0]) * 4096 + m.ndx[i0]], 1u);
+        for (int i = 0; i < mlen - 3; i++)
+            for (int j = start - m.spacer[i0] - mlen; j < start - m.spacer[i0] - i - 2; j++) {
+                if (j < 0) continue;
+                atomicAdd(&cnt[(i * 4 + tr_spacer_index(j, start, i)) * 4096 + tr_mer(d, L, j, i + 3, st)], 1u);
+            }
+    } else atomicAdd(&cnt[((mlen - 3) * 4 + m.spacendx[i0]) * 4096 + m.ndx[i0]], 1u);
+}
+// background: every non-edge start; real: the start chosen for each confident ORF (best_of_stop from k_ts_best<false>)
+__global__ void __launch_bounds__(256)
+k_mot_counts(int n, const int32_t* __restrict__ ndx, const uint8_t* __restrict__ type, const int8_t* __restrict__ strand,
+             const uint8_t* __restrict__ edge, const uint8_t* __restrict__ d, int L, TrMotifs m, const TrWeights* __restrict__ w,
+             const int32_t* __restrict__ best_of_stop, unsigned int* __restrict__ cnt, unsigned int* __restrict__ zero) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int node = i;
+    if (best_of_stop) { node = best_of_stop[i]; if (node < 0) return; }
+    if (type[node] == PGA_T_STOP || edge[node] == 1) return;
+    tr_update_motif_counts(node, ndx, strand, d, L, m, w->stage, cnt, zero);
+}
+
 // stages of the driver, for step-by-step validation against the oracle (PGA_TRAIN_* in the header)
 enum { TR_BIAS = 1, TR_DICODON = 2, TR_SD = 3, TR_ALL = 4 };
 
@@ -257,6 +325,39 @@ void tr_determine_sd_usage(pga_training* t) {       // Prodigal node.c determine
     if (t->rbs_wt[0] >= 0.0) t->uses_sd = 0;
     if (t->rbs_wt[16] < 1.0 && t->rbs_wt[13] < 1.0 && t->rbs_wt[15] < 1.0 &&
         (t->rbs_wt[0] >= -0.5 || (t->rbs_wt[22] < 2.0 && t->rbs_wt[24] < 2.0 && t->rbs_wt[27] < 2.0))) t->uses_sd = 0;
+}
+
+
+// Prodigal node.c build_coverage_map: which motifs are frequent enough (and their one-mismatch neighbours) to be modelled
+void tr_build_coverage_map(const unsigned int* real /* [4][4][4096] */, int* good /* [4][4][4096] */, double ng) {
+    const double thresh = 0.2;
+#define RC(a, b, l) real[((a) * 4 + (b)) * 4096 + (l)]
+#define GD(a, b, l) good[((a) * 4 + (b)) * 4096 + (l)]
+    memset(good, 0, sizeof(int) * 4 * 4 * 4096);
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 64; j++)
+        if ((double)RC(0, i, j) / ng >= thresh) for (int k = 0; k < 4; k++) GD(0, k, j) = 1;
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 256; j++) {
+        const int d0 = (j & 252) >> 2, d1 = j & 63;
+        if (GD(0, i, d0) == 0 || GD(0, i, d1) == 0) continue;
+        GD(1, i, j) = 1;
+    }
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 1024; j++) {
+        const int d0 = (j & 1008) >> 4, d1 = (j & 252) >> 2, d2 = j & 63;
+        if (GD(0, i, d0) == 0 || GD(0, i, d1) == 0 || GD(0, i, d2) == 0) continue;
+        GD(2, i, j) = 1;
+        int tmp = j;
+        for (int k = 0; k <= 16; k += 16) {
+            tmp ^= k;
+            for (int l = 0; l <= 32; l += 32) { tmp ^= l; if (GD(2, i, tmp) == 0) GD(2, i, tmp) = 2; }
+        }
+    }
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4096; j++) {
+        const int d0 = (j & 4092) >> 2, d1 = j & 1023;
+        if (GD(2, i, d0) == 0 || GD(2, i, d1) == 0) continue;
+        GD(3, i, j) = (GD(2, i, d0) == 1 && GD(2, i, d1) == 1) ? 1 : 2;
+    }
+#undef RC
+#undef GD
 }
 
 }  // namespace
@@ -404,6 +505,76 @@ static int train_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, 
     tr_ups_to_log(cn.ups, t);
     if (force_nonsd) t->uses_sd = 0; else tr_determine_sd_usage(t);
     if (upto == TR_SD || t->uses_sd) return PGA_OK;
-    c->err = "pga_train: non-SD start training not implemented yet";
-    return PGA_EINVAL;
+    // ---- motif-based start training: 20 rounds in three stages (ref: lib.pyx:4601-4827)
+    const size_t MT = (size_t)4 * 4 * 4096;
+    DEVBUF(d_motwt, double, "tr_mot_wt", MT);
+    DEVBUF(d_mcnt, unsigned int, "tr_mot_counts", 2 * MT + 8);
+    DEVBUF(d_best, int32_t, "tr_best_of_stop", n + 1);
+    TrMotifs mot;
+    {
+        DEVBUF(m0, int32_t, "tr_mot_ndx", n + 1) DEVBUF(m1, uint8_t, "tr_mot_len", n + 1) DEVBUF(m2, uint8_t, "tr_mot_spacer", n + 1)
+        DEVBUF(m3, uint8_t, "tr_mot_spacendx", n + 1) DEVBUF(m4, double, "tr_mot_score", n + 1)
+        mot = TrMotifs{m0, m1, m2, m3, m4};
+        HT(c, hipMemsetAsync(m1, 0, (size_t)n + 1, st));
+    }
+    std::vector<unsigned int> hc(2 * MT);
+    std::vector<double> mbg(MT), mreal(MT);
+    std::vector<int> mgood(MT, 0);
+    memset(t->ups_comp, 0, sizeof t->ups_comp);
+    memset(t->type_wt, 0, sizeof t->type_wt);
+    w.sthresh = 35.0; w.uses_sd = 0;
+    for (int it = 0; it < 20; it++) {
+        const int stage = it < 4 ? 0 : (it < 12 ? 1 : 2);
+        memcpy(w.type_wt, t->type_wt, sizeof w.type_wt);
+        w.no_mot = t->no_mot; w.stage = stage; w.last_iter = it == 19;
+        HT(c, hipMemcpyAsync(d_w, &w, sizeof w, hipMemcpyHostToDevice, st));
+        HT(c, hipMemcpyAsync(d_motwt, &t->mot_wt[0][0][0], sizeof(double) * MT, hipMemcpyHostToDevice, st));
+        HT(c, hipMemsetAsync(d_cn, 0, sizeof(TrCounts), st));
+        HT(c, hipMemsetAsync(d_mcnt, 0, sizeof(unsigned int) * (2 * MT + 8), st));
+        unsigned int* d_zero = d_mcnt + 2 * MT;           // [0] background, [1] real
+        hipLaunchKernelGGL(k_mot_best, dim3(nb), dim3(256), 0, st, n, gs.ndx, gs.type, gs.strand, gs.edge0, ls.d_dig, L, d_motwt, d_w, mot);
+        hipLaunchKernelGGL(k_mot_counts, dim3(nb), dim3(256), 0, st, n, gs.ndx, gs.type, gs.strand, gs.edge0, ls.d_dig, L, mot, d_w,
+                           (const int32_t*)nullptr, d_mcnt, d_zero);
+        hipLaunchKernelGGL(k_ts_best<false>, dim3(nb), dim3(256), 0, st, n, gs.ndx, gs.stop_val, gs.type, gs.strand, gs.edge0, ls.ca.cscore,
+                           ls.ca.rbs, mot.score, ls.d_dig, L, d_w, d_cn, d_best);
+        hipLaunchKernelGGL(k_mot_counts, dim3(nb), dim3(256), 0, st, n, gs.ndx, gs.type, gs.strand, gs.edge0, ls.d_dig, L, mot, d_w,
+                           d_best, d_mcnt + MT, d_zero + 1);
+        unsigned int zeros[2];
+        HT(c, hipMemcpyAsync(hc.data(), d_mcnt, sizeof(unsigned int) * 2 * MT, hipMemcpyDeviceToHost, st));
+        HT(c, hipMemcpyAsync(zeros, d_zero, sizeof zeros, hipMemcpyDeviceToHost, st));
+        HT(c, hipMemcpyAsync(&cn, d_cn, sizeof cn, hipMemcpyDeviceToHost, st));
+        HT(c, hipGetLastError());
+        HT(c, hipStreamSynchronize(st));
+        // ---- the weights of the next round (host: sums of counts, libm log)
+        double zbg = (double)zeros[0], zreal = (double)zeros[1], sum = 0.0;
+        const double ngenes = (double)cn.ngenes;
+        for (size_t q = 0; q < MT; q++) { mbg[q] = (double)hc[q]; sum += mbg[q]; }
+        sum += zbg;
+        for (size_t q = 0; q < MT; q++) mbg[q] /= sum;
+        zbg /= sum;
+        if (stage < 2) tr_build_coverage_map(hc.data() + MT, mgood.data(), ngenes);
+        sum = 0.0;
+        for (size_t q = 0; q < MT; q++) { mreal[q] = (double)hc[MT + q]; sum += mreal[q]; }
+        sum += zreal;
+        if (sum == 0.0) {
+            memset(t->mot_wt, 0, sizeof t->mot_wt); t->no_mot = 0.0;
+        } else {
+            double* wt = &t->mot_wt[0][0][0];
+            for (size_t q = 0; q < MT; q++) {
+                if (mgood[q] == 0) { zreal += mreal[q]; zbg += mreal[q]; mreal[q] = 0.0; mbg[q] = 0.0; }
+                mreal[q] /= sum;
+                double v = mbg[q] != 0 ? log(mreal[q] / mbg[q]) : -4.0;
+                if (v > 4.0) v = 4.0; else if (v < -4.0) v = -4.0;
+                wt[q] = v;
+            }
+        }
+        zreal /= sum;
+        t->no_mot = zbg != 0 ? log(zreal / zbg) : -4.0;
+        if (t->no_mot > 4.0) t->no_mot = 4.0; else if (t->no_mot < -4.0) t->no_mot = -4.0;
+        sum = 0.0; for (int j = 0; j < 3; j++) sum += (double)cn.treal[j];
+        tr_log_odds(cn.treal, tbg, t->type_wt, 3);
+        if (sum * 2000.0 <= n) w.sthresh /= 2.0;
+    }
+    tr_ups_to_log(cn.ups, t);
+    return PGA_OK;
 }

@@ -11,7 +11,7 @@ reference (lib.pyx:2501-2595, 1315-1357) over `pga_nodes_stage` / `pga_score_con
 works on whole node arrays, not node by node (SURVEY 8b: per-node granularity is useless for a GPU).
 
 `Gene.translate` and the `Genes.write_*` writers are host-side formatting, as in the reference.
-Not provided this round (raises `NotImplementedError`): `GeneFinder.train`.
+`GeneFinder.train` runs on the device too (`pga_train`).
 """
 import gzip
 import threading
@@ -114,6 +114,8 @@ cdef extern from "pyrodigal_amd.h" nogil:
     void pga_batch_free(pga_batch*)
     int PGA_STAGE_EXTRACT, PGA_STAGE_SCORE, PGA_STAGE_OVERLAP, PGA_STAGE_SEQUENCE
     int pga_nodes_stage(pga_ctx*, const pga_batch*, const pga_params*, int stage, int translation_table, pga_result** out)
+    int pga_train(pga_ctx*, const pga_batch*, const pga_params*, int translation_table, double start_weight, int force_nonsd,
+                  int upto, pga_training* out)
     int pga_score_connections(pga_ctx*, int32_t n, const int32_t* ndx, const int32_t* stop_val, const uint8_t* type,
                               const int8_t* strand, const double* cscore, const double* sscore, const double* rscore,
                               const double* uscore, const int32_t* star_ptr, double st_wt, int final,
@@ -1265,13 +1267,64 @@ cdef class GeneFinder:
         return out
 
     def train(self, object sequence, *sequences, bint force_nonsd=False, double start_weight=4.35, int translation_table=11):
-        """Training (ref: lib.pyx:5471-5575) is not part of the device path; load a `TrainingInfo` instead."""
+        """Train on the given genome, on the device, and use the result for the next `find_genes` (ref: lib.pyx:5471-5575).
+
+        Several sequences (the contigs of one genome) are joined with `TTAATTAATTAA` linkers like in Prodigal."""
+        import warnings
+        cdef Sequence seq
+        cdef pga_params p
+        cdef pga_batch* batch = NULL
+        cdef const char* ptr
+        cdef int64_t length
+        cdef int rc
+        cdef object raw
         if self.meta:
             raise RuntimeError("cannot use training sequence in metagenomic mode")
         if translation_table not in TRANSLATION_TABLES:
             raise ValueError("%d is not a valid translation table index" % translation_table)
-        raise NotImplementedError("GeneFinder.train is not implemented on the HIP path; "
-                                  "pass a TrainingInfo (TrainingInfo.load) to the constructor")
+        if isinstance(sequence, Sequence):
+            if sequences:
+                raise NotImplementedError("cannot use more than one `Sequence` object in `GeneFinder.train`")
+            seq = Sequence(sequence, mask=self.mask, mask_size=self.min_mask)
+        elif isinstance(sequence, str):
+            if sequences:
+                sequence = "TTAATTAATTAA".join(list((sequence,) + sequences) + [""])
+            seq = Sequence(sequence, mask=self.mask, mask_size=self.min_mask)
+        else:
+            if sequences:
+                sequence = b"TTAATTAATTAA".join([bytes(memoryview(x)) for x in (sequence,) + sequences] + [b""])
+            seq = Sequence(sequence, mask=self.mask, mask_size=self.min_mask)
+        if len(seq) < MIN_SINGLE_GENOME:
+            raise ValueError("sequence must be at least %d characters (%d found)" % (MIN_SINGLE_GENOME, len(seq)))
+        elif len(seq) < IDEAL_SINGLE_GENOME:
+            warnings.warn("sequence should be at least %d characters (%d found)" % (IDEAL_SINGLE_GENOME, len(seq)))
+        p.closed = self.closed; p.min_gene = self.min_gene; p.min_edge_gene = self.min_edge_gene
+        p.max_overlap = self.max_overlap; p.meta = 0; p.want_nodes = 0
+        p.mask = self.mask; p.min_mask = self.min_mask
+        raw = np.zeros(TRAINING_INFO_SIZE, np.uint8)
+        cdef size_t out_ptr = raw.ctypes.data
+        ptr = PyBytes_AS_STRING(seq.data)
+        length = len(seq.data)
+        with self.lock:
+            if self.ctx == NULL:
+                rc = pga_create(self.device, &self.ctx)
+                if rc != PGA_OK:
+                    self.ctx = NULL
+                    _raise_for(NULL, rc, "pga_create")
+            self.models_loaded = False            # the training loads its own partial models into the context
+            rc = pga_batch_create(self.ctx, 1, &ptr, &length, &batch)
+            if rc != PGA_OK:
+                _raise_for(self.ctx, rc, "pga_batch_create")
+            try:
+                with nogil:
+                    rc = pga_train(self.ctx, batch, &p, translation_table, start_weight, force_nonsd, 0, <pga_training*> out_ptr)
+                if rc != PGA_OK:
+                    _raise_for(self.ctx, rc, "pga_train")
+            finally:
+                pga_batch_free(batch)
+            tinf = TrainingInfo(raw=raw)
+            self.training_info = tinf
+        return tinf
 
 
 cdef object _arr(const void* ptr, ssize_t nbytes, object dtype):
