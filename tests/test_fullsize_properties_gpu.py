@@ -1,0 +1,104 @@
+"""BASELINE.json's full-size workloads through properties that need no oracle run: every gene is a well-formed ORF of
+its contig under the winning model's genetic code, results do not depend on batch composition or order, repeated calls
+are identical, and a sample of contigs is compared with the oracle in full."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+STOPS_11 = {"TAA", "TAG", "TGA"}
+STARTS = {"ATG", "GTG", "TTG"}
+_COMP = bytes.maketrans(b"ACGT", b"TGCA")
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from pyrodigal_amd import _cabi, benchdata
+    models = benchdata.load_model_set()
+    ctx = _cabi.Context(0)
+    ctx.set_models([m[1] for m in models])
+    tts = [int(np.frombuffer(m[1][8:12], np.int32)[0]) for m in models]
+    yield ctx, models, tts
+    ctx.close()
+
+
+def gene_dna(seq, g):
+    s = seq[g["begin"] - 1:g["end"]]
+    return s if g["strand"] == 1 else s.translate(_COMP)[::-1]
+
+
+def check_contig(seq, genes, tt, min_gene=90):
+    L = len(seq)
+    for g in genes:
+        assert 1 <= g["begin"] < g["end"] <= L and g["strand"] in (1, -1)
+        dna = gene_dna(seq, g).decode()
+        n = g["end"] - g["begin"] + 1
+        first_edge = g["partial_begin"] if g["strand"] == 1 else g["partial_end"]
+        last_edge = g["partial_end"] if g["strand"] == 1 else g["partial_begin"]
+        if not first_edge and not last_edge:
+            assert n % 3 == 0 and n >= min_gene
+        if not first_edge:
+            assert dna[:3] in STARTS and ["ATG", "GTG", "TTG"][g["start_type"]] == dna[:3]
+        else:
+            assert g["start_type"] == 3
+        if not last_edge:
+            stop = dna[-3:]
+            assert stop in STOPS_11 and not (tt == 4 and stop == "TGA")
+        body = dna[3 if not first_edge else n % 3:-3 if not last_edge else None]
+        codons = {body[i:i + 3] for i in range(0, len(body) - 2, 3)}
+        assert not (codons & ({"TAA", "TAG"} if tt == 4 else STOPS_11))        # no stop inside the reading frame
+        assert np.isfinite(g["cscore"]) and np.isfinite(g["sscore"])
+    begins = genes["begin"]
+    assert np.all(np.diff(begins) >= 0)                                         # genes come in sequence order
+
+
+def test_config3_full_size(setup):
+    from pyrodigal_amd import benchdata
+    ctx, models, tts = setup
+    seqs = benchdata.config3(1000, 50_000)
+    res = ctx.find_genes_batch(seqs, meta=True)
+    assert len(res.genes) > 50_000 and res.n_chains > 1000
+    for i in range(0, 1000, 7):
+        c = res.contigs[i]
+        assert c["model"] >= 0
+        check_contig(seqs[i], res.genes_of(i), tts[c["model"]])
+    # idempotence
+    res2 = ctx.find_genes_batch(seqs, meta=True)
+    assert res2.genes.tobytes() == res.genes.tobytes() and np.array_equal(res2.contigs["model"], res.contigs["model"])
+    # batch composition and order do not matter: a shuffled subset gives the same per-contig genes
+    rng = np.random.default_rng(0)
+    pick = rng.permutation(1000)[:150]
+    sub = ctx.find_genes_batch([seqs[i] for i in pick], meta=True)
+    key = ["begin", "end", "strand", "start_ndx", "stop_ndx", "start_type", "cscore", "sscore", "rscore", "uscore", "tscore"]
+    for k, i in enumerate(pick):
+        a, b = sub.genes_of(k), res.genes_of(i)
+        assert sub.contigs[k]["model"] == res.contigs[i]["model"] and len(a) == len(b)
+        for name in key:
+            assert np.array_equal(a[name], b[name]), name
+    # a sample against the oracle, in full
+    bins = [orc.Training(m[1]) for m in models]
+    for i in pick[:12]:
+        o = orc.Oracle(seqs[i])
+        assert o.find_genes_meta(bins) == res.contigs[i]["model"]
+        og, gg = o.genes(), res.genes_of(i)
+        assert len(og) == len(gg) and all(np.array_equal(og[k], gg[k]) for k in ("begin", "end", "start_ndx", "stop_ndx"))
+
+
+def test_config2_full_size(setup):
+    from pyrodigal_amd import benchdata
+    ctx, models, tts = setup
+    seq = benchdata.config2(0)[0]
+    res = ctx.find_genes_batch([seq], meta=True)
+    genes = res.genes_of(0)
+    assert len(genes) > 5000
+    check_contig(seq, genes, tts[res.contigs[0]["model"]])
+    assert ctx.find_genes_batch([seq], meta=True).genes.tobytes() == res.genes.tobytes()
+    # the same contig inside a batch of others
+    others = benchdata.config3(5, 20_000)
+    mixed = ctx.find_genes_batch(others[:2] + [seq] + others[2:], meta=True)
+    assert mixed.contigs[2]["model"] == res.contigs[0]["model"]
+    a = mixed.genes_of(2)
+    for name in ("begin", "end", "strand", "start_ndx", "stop_ndx", "cscore", "sscore"):
+        assert np.array_equal(a[name], genes[name]), name
