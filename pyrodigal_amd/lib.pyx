@@ -328,6 +328,61 @@ cdef class TrainingInfo:
     def coding_statistics(self):
         return self._f64(525624, 4096).copy()
 
+    # the remaining fields and the setters of the reference (ref: lib.pyx:4067-4213)
+    @start_weight.setter
+    def start_weight(self, double v):
+        self._f64(16)[0] = v
+
+    @bias.setter
+    def bias(self, object v):
+        self._f64(24, 3)[:] = np.asarray(v, np.float64)
+
+    @type_weights.setter
+    def type_weights(self, object v):
+        self._f64(48, 3)[:] = np.asarray(v, np.float64)
+
+    @uses_sd.setter
+    def uses_sd(self, bint v):
+        self._i32(72)[0] = 1 if v else 0
+
+    @rbs_weights.setter
+    def rbs_weights(self, object v):
+        self._f64(80, 28)[:] = np.asarray(v, np.float64)
+
+    @property
+    def upstream_compositions(self):
+        return self._f64(304, 128).reshape(32, 4).copy()
+
+    @upstream_compositions.setter
+    def upstream_compositions(self, object v):
+        self._f64(304, 128)[:] = np.asarray(v, np.float64).reshape(-1)
+
+    @property
+    def motif_weights(self):
+        return self._f64(1328, 65536).reshape(4, 4, 4096).copy()
+
+    @motif_weights.setter
+    def motif_weights(self, object v):
+        self._f64(1328, 65536)[:] = np.asarray(v, np.float64).reshape(-1)
+
+    @missing_motif_weight.setter
+    def missing_motif_weight(self, double v):
+        self._f64(525616)[0] = v
+
+    @coding_statistics.setter
+    def coding_statistics(self, object v):
+        self._f64(525624, 4096)[:] = np.asarray(v, np.float64).reshape(-1)
+
+    def __eq__(self, other):
+        return isinstance(other, TrainingInfo) and np.array_equal(self.raw, (<TrainingInfo> other).raw)
+
+    def __reduce__(self):           # pickling (ref: lib.pyx:4024-4035)
+        return _training_info_from_bytes, (self.raw.tobytes(),)
+
+
+def _training_info_from_bytes(bytes raw):
+    return TrainingInfo(raw=raw)
+
 
 cdef class MetagenomicBin:
     """A pre-trained model with a description (ref: lib.pyx:4888-4946)."""
@@ -340,6 +395,9 @@ cdef class MetagenomicBin:
 
     def __repr__(self):
         return "<pyrodigal_amd.lib.MetagenomicBin description=%r>" % self.description
+
+    def __reduce__(self):
+        return MetagenomicBin, (self.training_info, self.description)
 
 
 cdef class MetagenomicBins:
@@ -364,6 +422,9 @@ cdef class MetagenomicBins:
     def __iter__(self):
         return iter(self._bins)
 
+    def __reduce__(self):
+        return MetagenomicBins, (list(self._bins),)
+
 
 # Prodigal's 50 built-in models are not part of the reference checkout (un-vendored submodule), so the
 # default collection is empty: meta mode needs `metagenomic_bins=`.
@@ -371,6 +432,7 @@ METAGENOMIC_BINS = MetagenomicBins()
 
 
 # --- Sequence / Nodes / Gene / Genes ----------------------------------------------------------
+
 cdef class _StageContext:
     """One lazily created device context for the stage-level calls (`Nodes.*`, `ConnectionScorer`)."""
     cdef pga_ctx* ctx
@@ -515,6 +577,9 @@ cdef class Sequence:
         """The masked regions, empty unless `mask=True` (ref: lib.pyx:616-620)."""
         self._build()
         return list(self._masks)
+
+    def __reduce__(self):
+        return Sequence, (self.data, self.mask, self.mask_size)
 
 
 cdef class Node:
@@ -1149,6 +1214,12 @@ cdef class GeneFinder:
             pga_destroy(self.ctx)
             self.ctx = NULL
 
+    def __reduce__(self):           # ref: lib.pyx:5219-5234
+        return _gene_finder_from_state, (self.training_info, dict(
+            meta=self.meta, metagenomic_bins=self.metagenomic_bins if self.meta else None, closed=self.closed, mask=self.mask,
+            min_mask=self.min_mask, min_gene=self.min_gene, min_edge_gene=self.min_edge_gene, max_overlap=self.max_overlap,
+            backend=self.backend, device=self.device, keep_nodes=self.keep_nodes))
+
     def __repr__(self):
         parts = []
         if self.training_info is not None:
@@ -1325,6 +1396,10 @@ cdef class GeneFinder:
             tinf = TrainingInfo(raw=raw)
             self.training_info = tinf
         return tinf
+
+
+def _gene_finder_from_state(training_info, dict kw):
+    return GeneFinder(training_info, **kw)
 
 
 cdef object _arr(const void* ptr, ssize_t nbytes, object dtype):

@@ -272,3 +272,24 @@ def test_find_genes_is_thread_safe(lib):
     assert got == want
     ids = sorted(shared.find_genes(s)._num_seq for s in seqs[:3])
     assert ids == sorted(set(ids))                                   # every call gets its own sequence number
+
+
+def test_training_info_fields_setters_and_pickling(lib):
+    """ref: tests/test_training_info.py (properties, setters, pickle round trip), tests/test_gene_finder.py (pickle)."""
+    import pickle
+    t = lib.TrainingInfo.load(golden_path("SRR492066.training.bin.gz"))
+    assert t.upstream_compositions.shape == (32, 4) and t.motif_weights.shape == (4, 4, 4096) and t.coding_statistics.shape == (4096,)
+    t2 = pickle.loads(pickle.dumps(t))
+    assert t2 == t and t2 is not t
+    t2.uses_sd = False; t2.start_weight = 3.0; t2.bias = (1, 2, 3); t2.missing_motif_weight = -1.5
+    t2.rbs_weights = np.arange(28); t2.type_weights = (0.5, 0.25, 0.125)
+    assert not t2.uses_sd and t2.start_weight == 3.0 and tuple(t2.bias) == (1.0, 2.0, 3.0) and t2.missing_motif_weight == -1.5
+    assert t2.rbs_weights[27] == 27.0 and tuple(t2.type_weights) == (0.5, 0.25, 0.125) and t2 != t
+    with pytest.raises(ValueError):
+        t2.gc = 1.5
+    bins = pickle.loads(pickle.dumps(lib.MetagenomicBins([lib.MetagenomicBin(t, "first"), lib.MetagenomicBin(t2, "second")])))
+    assert [b.description for b in bins] == ["first", "second"] and bins[0].training_info == t
+    f = pickle.loads(pickle.dumps(lib.GeneFinder(t, closed=True, min_gene=120, max_overlap=30, mask=True, min_mask=40)))
+    assert (f.closed, f.min_gene, f.max_overlap, f.mask, f.min_mask) == (True, 120, 30, True, 40) and f.training_info == t
+    s = pickle.loads(pickle.dumps(lib.Sequence("ACGTNN", mask=True, mask_size=1)))
+    assert str(s) == "ACGTNN" and s.mask and s.mask_size == 1
