@@ -126,7 +126,7 @@ int         pga_device_info(const pga_ctx*, char* name, int name_len, int* cus, 
 int pga_set_models(pga_ctx*, const pga_training* const* models, int n_models);
 
 /* ---- scorer level ------------------------------------------------------ */
-/* Whole-array connection scoring of one sorted node list (final=1: gene prediction pass).
+/* Whole-array connection scoring of one sorted node list (the gene prediction pass, final = 1).
  * Inputs are the node fields _score_connections reads; outputs are the fields it writes. */
 int pga_score_connections(pga_ctx*, int32_t n,
                           const int32_t* ndx, const int32_t* stop_val,
@@ -134,10 +134,21 @@ int pga_score_connections(pga_ctx*, int32_t n,
                           const double* cscore, const double* sscore,
                           const double* rscore, const double* uscore,
                           const int32_t* star_ptr /* [n][3] */,
-                          double st_wt, int final,
+                          double st_wt, int final /* must be 1: see pga_score_connections_training for the training pass */,
                           double* score, int32_t* traceb, int8_t* ov_mark,
                           int32_t* max_index /* _find_max_index, may be NULL */,
                           double* kernel_ms /* may be NULL */);
+
+/* The training pass of the same scorer (final = 0 in the reference, _connection.h:94-367): a connection is worth its length
+ * times bias . gc_score of one of its nodes.  gc_score is the [n][3] array of the nodes after Prodigal's record_gc_bias
+ * (call site lib.pyx:5261), bias = TrainingInfo.bias, star_ptr as left by _record_overlapping_starts(flag = 0). */
+int pga_score_connections_training(pga_ctx*, int32_t n,
+                                   const int32_t* ndx, const int32_t* stop_val,
+                                   const uint8_t* type, const int8_t* strand,
+                                   const double* gc_score /* [n][3] */, const double* bias /* [3] */,
+                                   const int32_t* star_ptr /* [n][3] */, double st_wt,
+                                   double* score, int32_t* traceb, int8_t* ov_mark,
+                                   int32_t* max_index /* may be NULL */, double* kernel_ms /* may be NULL */);
 
 /* ---- finder level ------------------------------------------------------ */
 /* `seqs[c]` points at `lens[c]` ASCII nucleotides (any case, non-ACGT = unknown).

@@ -58,6 +58,7 @@ def lib():
         L.po_new.restype = vp
         L.po_new.argtypes = [ctypes.c_char_p, ctypes.c_int64, i32, i32]
         L.po_free.argtypes = [vp]
+        L.po_record_gc_bias.restype = None; L.po_record_gc_bias.argtypes = [vp, vp]
         L.po_masks.restype = i32
         L.po_masks.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), i32]
         for name in ("po_slen", "po_unknown", "po_num_nodes", "po_num_genes", "po_last_ipath"):
@@ -204,6 +205,10 @@ class Oracle:
 
     def dprog(self, tinf, final=True):
         return self.L.po_dprog(self.h, tinf.ptr, int(final), 1)
+
+    def record_gc_bias(self, tinf):
+        """Training: fill gc_score / gc_bias of the nodes and ``tinf.bias`` (Prodigal record_gc_bias)."""
+        self.L.po_record_gc_bias(self.h, tinf.ptr)
 
     def dprog_raw(self, tinf, final=True):
         """Connection loop only (no traceback fix-ups): nodes keep the raw score/traceb/ov_mark."""

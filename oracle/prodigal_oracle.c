@@ -1308,6 +1308,13 @@ static void train_starts_nonsd(po_ctx* c, po_training* t) {
 }
 
 /* ref: lib.pyx:5236-5279 (GeneFinder._train) and 3955-4003 (TrainingInfo.__init__) */
+/* GC frame plot + record_gc_bias on the current nodes (fills gc_score / gc_bias of the nodes and t->bias) */
+void po_record_gc_bias(po_ctx* c, po_training* t) {
+    int* gcf = gc_frame_plot(c);
+    record_gc_bias(gcf, c, t);
+    free(gcf);
+}
+
 /* `upto` stops the training early, for step-by-step checks of other implementations:
  * 1 after the GC frame bias, 2 after the hexamer statistics, 3 after the Shine-Dalgarno start training, else all of it */
 int po_train_upto(po_ctx* c, po_training* t, const po_params* p, int force_nonsd, double start_weight, int tt, int upto) {

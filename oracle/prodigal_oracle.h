@@ -93,6 +93,7 @@ void po_reset_scores(po_ctx*);
 void po_score_nodes(po_ctx*, const po_training*, int closed, int is_meta);
 void po_overlapping_starts(po_ctx*, const po_training*, int flag, int max_overlap);
 int  po_dprog(po_ctx*, const po_training*, int final, int use_filter);
+void po_record_gc_bias(po_ctx*, po_training*);   /* training: GC frame plot + frame bias of every start */
 void po_dprog_raw(po_ctx*, const po_training*, int final);   /* connection loop only, no fix-ups */
 int  po_find_max_index(const po_ctx*);
 void po_eliminate_bad_genes(po_ctx*, int ipath, const po_training*);

@@ -16,7 +16,7 @@ TRAINING_SIZE = 558392
 
 EXPORTS = [
     "pga_create", "pga_destroy", "pga_last_error", "pga_device_info", "pga_set_models",
-    "pga_score_connections", "pga_find_genes_batch", "pga_result_free",
+    "pga_score_connections", "pga_score_connections_training", "pga_find_genes_batch", "pga_result_free",
     "pga_batch_create", "pga_batch_free", "pga_find_genes", "pga_nodes_stage",
     "pga_fasta_open", "pga_fasta_next", "pga_fasta_error", "pga_fasta_close", "pga_train",
 ]
@@ -93,6 +93,8 @@ def load():
     L.pga_set_models.restype = ctypes.c_int; L.pga_set_models.argtypes = [vp, _P(vp), ctypes.c_int]
     L.pga_score_connections.restype = ctypes.c_int
     L.pga_score_connections.argtypes = [vp, i32] + [vp] * 9 + [f64, ctypes.c_int, vp, vp, vp, _P(i32), _P(f64)]
+    L.pga_score_connections_training.restype = ctypes.c_int
+    L.pga_score_connections_training.argtypes = [vp, i32] + [vp] * 7 + [f64, vp, vp, vp, _P(i32), _P(f64)]
     L.pga_find_genes_batch.restype = ctypes.c_int
     L.pga_find_genes_batch.argtypes = [vp, i32, _P(ctypes.c_char_p), _P(i64), _P(Params), _P(_P(Result))]
     L.pga_result_free.restype = None; L.pga_result_free.argtypes = [_P(Result)]
@@ -186,6 +188,23 @@ class Context:
                                           p(score), p(traceb), p(ov), ctypes.byref(mi), ctypes.byref(ms))
         if rc != PGA_OK:
             _raise(self.L, self.h, rc, "pga_score_connections")
+        return score, traceb, ov, mi.value, ms.value
+
+    def score_connections_training(self, ndx, stop_val, type_, strand, gc_score, bias, star_ptr, st_wt):
+        """The training pass (``final=False``) of the same scorer, from the nodes' frame-bias scores."""
+        n = len(ndx)
+        c = lambda a, t: np.ascontiguousarray(a, dtype=t)
+        ndx, stop_val = c(ndx, np.int32), c(stop_val, np.int32)
+        type_, strand = c(type_, np.uint8), c(strand, np.int8)
+        gc_score, bias = c(gc_score, np.float64).reshape(-1), c(bias, np.float64)
+        star_ptr = c(star_ptr, np.int32).reshape(-1)
+        score = np.zeros(n, np.float64); traceb = np.zeros(n, np.int32); ov = np.zeros(n, np.int8)
+        mi, ms = ctypes.c_int32(-1), ctypes.c_double(0)
+        p = lambda a: a.ctypes.data
+        rc = self.L.pga_score_connections_training(self.h, n, p(ndx), p(stop_val), p(type_), p(strand), p(gc_score), p(bias),
+                                                   p(star_ptr), float(st_wt), p(score), p(traceb), p(ov), ctypes.byref(mi), ctypes.byref(ms))
+        if rc != PGA_OK:
+            _raise(self.L, self.h, rc, "pga_score_connections_training")
         return score, traceb, ov, mi.value, ms.value
 
 

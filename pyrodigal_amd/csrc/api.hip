@@ -118,15 +118,48 @@ struct DevBuf {     // frees everything it allocated when the call returns
 };
 }  // namespace
 
+namespace {
+// bias . gc_score per node, the factor of the training pass (ref: _connection.h, `final == false` branches)
+__global__ void k_gc_factor(int n, const double* __restrict__ gc_score, double b0, double b1, double b2, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = b0 * gc_score[3 * i] + b1 * gc_score[3 * i + 1] + b2 * gc_score[3 * i + 2];
+}
+}  // namespace
+
+static int score_connections_impl(pga_ctx* c, int32_t n, const int32_t* ndx, const int32_t* stop_val,
+                                  const uint8_t* type, const int8_t* strand, const double* cscore,
+                                  const double* sscore, const double* rscore, const double* uscore,
+                                  const int32_t* star_ptr, double st_wt, int final, const double* gc_score, const double* bias,
+                                  double* score, int32_t* traceb, int8_t* ov_mark, int32_t* max_index, double* kernel_ms);
+
 extern "C" int pga_score_connections(pga_ctx* c, int32_t n, const int32_t* ndx, const int32_t* stop_val,
                                      const uint8_t* type, const int8_t* strand, const double* cscore,
                                      const double* sscore, const double* rscore, const double* uscore,
                                      const int32_t* star_ptr, double st_wt, int final, double* score,
                                      int32_t* traceb, int8_t* ov_mark, int32_t* max_index, double* kernel_ms) {
     if (!c) return PGA_EINVAL;
+    if (!final) return fail(c, PGA_EINVAL, "pga_score_connections: the training pass (final=0) scores connections from the frame-bias "
+                                           "scores of the nodes: use pga_score_connections_training");
+    return score_connections_impl(c, n, ndx, stop_val, type, strand, cscore, sscore, rscore, uscore, star_ptr, st_wt, 1, nullptr, nullptr,
+                                  score, traceb, ov_mark, max_index, kernel_ms);
+}
+
+extern "C" int pga_score_connections_training(pga_ctx* c, int32_t n, const int32_t* ndx, const int32_t* stop_val,
+                                              const uint8_t* type, const int8_t* strand, const double* gc_score, const double* bias,
+                                              const int32_t* star_ptr, double st_wt, double* score, int32_t* traceb, int8_t* ov_mark,
+                                              int32_t* max_index, double* kernel_ms) {
+    if (!c) return PGA_EINVAL;
+    if (n > 0 && (!gc_score || !bias)) return fail(c, PGA_EINVAL, "pga_score_connections_training: NULL array");
+    return score_connections_impl(c, n, ndx, stop_val, type, strand, gc_score, gc_score, gc_score, gc_score, star_ptr, st_wt, 0, gc_score, bias,
+                                  score, traceb, ov_mark, max_index, kernel_ms);
+}
+
+static int score_connections_impl(pga_ctx* c, int32_t n, const int32_t* ndx, const int32_t* stop_val,
+                                  const uint8_t* type, const int8_t* strand, const double* cscore,
+                                  const double* sscore, const double* rscore, const double* uscore,
+                                  const int32_t* star_ptr, double st_wt, int final, const double* gc_score, const double* bias,
+                                  double* score, int32_t* traceb, int8_t* ov_mark, int32_t* max_index, double* kernel_ms) {
     if (n < 0) return fail(c, PGA_EINVAL, "pga_score_connections: negative node count");
-    if (!final) return fail(c, PGA_EINVAL, "pga_score_connections: only the final (gene prediction) pass is on the device; "
-                                           "the training pass (final=0) is not implemented");
     if (max_index) *max_index = -1;
     if (kernel_ms) *kernel_ms = 0.0;
     if (n == 0) return PGA_OK;
@@ -152,14 +185,21 @@ extern "C" int pga_score_connections(pga_ctx* c, int32_t n, const int32_t* ndx, 
     hipStream_t st = c->stream;
 #define UP(dst, srcp, bytes) HIP_TRY(c, hipMemcpyAsync(dst, srcp, bytes, hipMemcpyHostToDevice, st))
     UP(nd.ndx, ndx, 4 * N); UP(nd.stop_val, stop_val, 4 * N); UP(nd.type, type, N); UP(nd.strand, strand, N);
-    UP(nd.cscore, cscore, 8 * N); UP(nd.sscore, sscore, 8 * N); UP(nd.rscore, rscore, 8 * N); UP(nd.uscore, uscore, 8 * N);
+    double* d_gcb = nullptr;
+    if (final) { UP(nd.cscore, cscore, 8 * N); UP(nd.sscore, sscore, 8 * N); UP(nd.rscore, rscore, 8 * N); UP(nd.uscore, uscore, 8 * N); }
+    else {
+        double* d_gcs;
+        HIP_TRY(c, db.alloc(&d_gcs, 3 * N)); HIP_TRY(c, db.alloc(&d_gcb, N));
+        UP(d_gcs, gc_score, 24 * N);
+        hipLaunchKernelGGL(k_gc_factor, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, n, d_gcs, bias[0], bias[1], bias[2], d_gcb);
+    }
     UP(nd.star_ptr, star_ptr, 12 * N);
     ChainDesc ch{0, 0, n, 0, 0, 1};
     ModelConst mc; pga_fill_model_const(&mc, st_wt);
     UP(d_chain, &ch, sizeof ch); UP(d_mc, &mc, sizeof mc);
 #undef UP
-    NodeArrays na{nd.ndx, nd.stop_val, nd.type, nd.strand, nd.cscore, nd.sscore, nd.rscore, nd.uscore, nd.star_ptr};
-    pga_launch_dp_prepare(d_chain, 1, 0, n, na, d_mc, buf, st);
+    NodeArrays na{nd.ndx, nd.stop_val, nd.type, nd.strand, nd.cscore, nd.sscore, nd.rscore, nd.uscore, nd.star_ptr, d_gcb};
+    pga_launch_dp_prepare(d_chain, 1, 0, n, na, d_mc, buf, st, final);
     HIP_TRY(c, hipEventRecord(c->ev0, st));
     pga_launch_dp(d_chain, 1, d_mc, buf, final, st);
     HIP_TRY(c, hipEventRecord(c->ev1, st));

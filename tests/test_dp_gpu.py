@@ -89,6 +89,29 @@ def test_dp_tiny_and_empty_inputs(ctx):
             check(ctx, seq, tinf, is_meta=True)
 
 
+@pytest.mark.parametrize("name,closed", [("SRR492066", False), ("KK037166", False), ("GCF_001457455.1_NCTC11397_genomic", True)])
+def test_training_pass_of_the_scorer(ctx, name, closed):
+    # final = 0 (ref: _connection.h `final == false` branches, call site lib.pyx:5265): frame-bias factors instead of scores
+    seq = read_fasta(name + ".fna.gz")[0][1]
+    st_wt = 4.35
+    t = orc.Training()
+    t.set_trans_table(11); t._f64(16)[0] = st_wt
+    o = orc.Oracle(seq)
+    o.extract(11, orc.Params(closed=closed)); o.sort()
+    o.record_gc_bias(t)
+    bias = t.bias.copy()
+    o.overlapping_starts(t, 0, 60)
+    before = o.nodes()
+    o.dprog_raw(t, False)
+    ref = o.nodes()
+    score, traceb, ov, mi, ms = ctx.score_connections_training(before["ndx"], before["stop_val"], before["type"], before["strand"],
+                                                                before["gc_score"], bias, before["star_ptr"], st_wt)
+    assert np.array_equal(traceb, ref["traceb"])
+    assert np.array_equal(score.view(np.uint64), ref["score"].view(np.uint64))
+    reached = ref["traceb"] != -1
+    assert np.array_equal(ov[reached], ref["ov_mark"][reached]) and mi == o.find_max_index() and reached.sum() > 100
+
+
 def test_training_pass_is_rejected_loudly(ctx):
     with pytest.raises(ValueError):
         ctx.score_connections([0], [0], [0], [1], [0.0], [0.0], [0.0], [0.0], np.zeros((1, 3)), 4.35, final=False)
