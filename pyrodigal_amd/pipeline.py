@@ -1,0 +1,73 @@
+"""Keeping the device busy across batches: N contexts (one HIP stream and one set of scratch buffers each), one host
+thread per context.  While one batch is in a host-side phase of its call (upload, chain planning, result unpacking)
+the other contexts' kernels run; batches come back in input order.
+
+Measured on one MI355X with BASELINE config 3 batches (1000 x 50 kbp): 1 context 19.3 ms per batch (2.6 Gbp/s),
+2 contexts 15.0 ms per batch (3.3 Gbp/s)."""
+import queue
+import threading
+
+from . import _cabi
+
+
+def find_genes_stream(batches, model_blobs, n_contexts=2, device=0, **find_kw):
+    """Yield ``(batch, BatchResult)`` for every batch of ``batches`` (an iterable of lists of contigs), in order.
+
+    ``model_blobs``: the ``struct _training`` blobs to load in every context; ``find_kw`` goes to
+    ``Context.find_genes_batch`` (meta, closed, mask, ...).  At most ``2 * n_contexts`` batches are in flight."""
+    ctxs = [_cabi.Context(device) for _ in range(max(1, n_contexts))]
+    for c in ctxs:
+        c.set_models(list(model_blobs))
+    todo = queue.Queue(maxsize=len(ctxs))           # (index, batch) or None
+    done = {}
+    cv = threading.Condition()
+    failure = []
+
+    def worker(ctx):
+        while True:
+            item = todo.get()
+            if item is None:
+                return
+            i, batch = item
+            try:
+                res = ctx.find_genes_batch(batch, **find_kw)
+            except BaseException as e:               # handed to the consumer, which re-raises it
+                res = e
+                failure.append(e)
+            with cv:
+                done[i] = (batch, res)
+                cv.notify_all()
+
+    threads = [threading.Thread(target=worker, args=(c,), daemon=True) for c in ctxs]
+    for t in threads:
+        t.start()
+    try:
+        nxt, submitted = 0, 0
+        it = iter(batches)
+        exhausted = False
+        while True:
+            while not exhausted and submitted - nxt < 2 * len(ctxs) and not failure:
+                try:
+                    b = next(it)
+                except StopIteration:
+                    exhausted = True
+                    break
+                todo.put((submitted, b))
+                submitted += 1
+            if nxt == submitted and exhausted:
+                break
+            with cv:
+                while nxt not in done:
+                    cv.wait()
+                batch, res = done.pop(nxt)
+            nxt += 1
+            if isinstance(res, BaseException):
+                raise res
+            yield batch, res
+    finally:
+        for _ in threads:
+            todo.put(None)
+        for t in threads:
+            t.join()
+        for c in ctxs:
+            c.close()

@@ -56,3 +56,20 @@ def test_two_ranks_equal_one_process(tmp_path):
         assert len(g) == len(ref) > 0
         for k in key:
             assert np.array_equal(g[k][order], ref[k]), k
+
+
+def test_streamed_batches_over_two_contexts_equal_sequential_calls():
+    from pyrodigal_amd import _cabi, benchdata, pipeline
+    models = [b for _, b in benchdata.load_model_set()]
+    batches = [[benchdata.synthetic_contig(3000 + 700 * ((7 * k + c) % 9), 0.35 + 0.03 * ((k + c) % 10), 50 * k + c) for c in range(20)]
+               for k in range(7)] + [[]]
+    ctx = _cabi.Context(0)
+    ctx.set_models(models)
+    want = [ctx.find_genes_batch(b, meta=True).genes for b in batches]
+    ctx.close()
+    got = list(pipeline.find_genes_stream(iter(batches), models, n_contexts=2, meta=True))
+    assert len(got) == len(batches)
+    for (b, res), w, orig in zip(got, want, batches):
+        assert b is orig and res.genes.tobytes() == w.tobytes()
+    with pytest.raises(ValueError):          # an error inside a worker reaches the consumer
+        list(pipeline.find_genes_stream([["ACGT" * 100]], models, n_contexts=2, meta=True, min_gene=-5))
