@@ -916,7 +916,10 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
         if (!edge_in) {
             if (tm->uses_sd) {
                 for (int j = start - 20; j < start - 5; j++) {
-                    if (j < 0) continue;         // (on the reverse strand the reference tests j >= slen, never true here)
+                    // the reference skips windows starting before the sequence on the forward strand only; on the reverse
+                    // strand it tests "j >= slen", never true, so windows hanging off the end are searched with the missing
+                    // bases matching nothing (ref: lib.pyx:2256-2275)
+                    if (j < 0 && strand == 1) continue;
                     const int a = shine_dalgarno(W, j, start, tm->rbs_wt, 0);
                     const int b = shine_dalgarno(W, j, start, tm->rbs_wt, 1);
                     if (a > rbs0) rbs0 = a;

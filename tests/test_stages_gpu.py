@@ -115,6 +115,29 @@ def test_score_stage_sd_and_nonsd_models(ctx, stage, is_meta):
             check(nd, oracle_stage(seq, stage, tinf=tinf, is_meta=is_meta), stage)
 
 
+def test_rbs_search_next_to_the_sequence_ends(ctx):
+    """Starts within 20 bases of an end: the forward strand skips upstream windows that begin before the sequence, the reverse
+    strand searches them with the missing bases matching nothing (ref: lib.pyx:2256-2275)."""
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    tinf = orc.Training.load(golden_path("GCF_001457455.1_NCTC11397_genomic.tinf_closed.bin.gz"))
+    ctx.set_models([tinf.tobytes()])
+    body = synthetic_contig(600, 0.5, 77).replace(b"TAA", b"TCA").replace(b"TAG", b"TCG").replace(b"TGA", b"TCA")
+    orf = b"ATG" + body[:450] + b"TAA"
+    seqs = []
+    for k in range(0, 24, 3):
+        up = (b"GGAGGAAAACAT" + b"AGGAGGTTTAAC")[:k]                        # what lies upstream of the start, partly cut off
+        seqs.append(up[::-1][:k][::-1] + orf + synthetic_contig(300, 0.5, k))                            # forward start k bases from the left end
+        seqs.append(synthetic_contig(300, 0.5, 100 + k) + (up[::-1][:k][::-1] + orf).translate(comp)[::-1])   # reverse start k bases from the right end
+    for closed in (True, False):
+        out = ctx.nodes_stage(seqs, 2, closed=closed)
+        hits = 0
+        for seq, nd in zip(seqs, out):
+            on = oracle_stage(seq, 2, tinf=tinf, closed=closed)
+            check(nd, on, 2)
+            hits += int((on["rbs"] > 0).any())
+        assert hits > 0
+
+
 def test_score_stage_needs_a_model(ctx):
     from pyrodigal_amd import _cabi
     ctx.set_models([])
