@@ -26,14 +26,17 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
                 at = int(rng.integers(0, L - 200)); n = int(rng.choice([1, 3, 49, 50, 200]))
                 s[at:at + n] = b"N" * n
         seqs.append(bytes(s))
-    for meta, mask, closed in ((True, False, False), (False, True, True)):
+    for meta in (True, False):
+        mask, closed = bool(rng.random() < 0.4), bool(rng.random() < 0.5)
+        min_gene = int(rng.choice([60, 90, 150])); min_edge = int(rng.choice([30, 60, 90])); max_ov = int(rng.choice([0, 30, 60]))
         mi = int(rng.integers(0, 16))
-        ctx.set_models(models if meta else [models[mi]])
-        res = ctx.find_genes_batch(seqs, meta=meta, mask=mask, closed=closed)
+        single = orc.Training(models[mi]); single.set_trans_table(int(rng.choice([11, 4, 1, 25])))
+        ctx.set_models(models if meta else [single.tobytes()])
+        res = ctx.find_genes_batch(seqs, meta=meta, mask=mask, closed=closed, min_gene=min_gene, min_edge_gene=min_edge, max_overlap=max_ov)
         def one(i):
             o = orc.Oracle(seqs[i], mask=mask, mask_size=50)
-            p = orc.Params(closed=closed)
-            ph = o.find_genes_meta(bins, p) if meta else (o.find_genes_single(bins[mi], p), 0)[1]
+            p = orc.Params(closed=closed, min_gene=min_gene, min_edge_gene=min_edge, max_overlap=max_ov)
+            ph = o.find_genes_meta(bins, p) if meta else (o.find_genes_single(single, p), 0)[1]
             og, gg = o.genes(), res.genes_of(i)
             ok = (not meta or ph == res.contigs[i]["model"]) and len(og) == len(gg) and all(np.array_equal(og[k], gg[k]) for k in ("begin", "end", "start_ndx", "stop_ndx"))
             return ok, len(og)
@@ -41,6 +44,6 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
             out = list(ex.map(one, range(len(seqs))))
         bad = [i for i, (ok, _) in enumerate(out) if not ok]
         if bad:
-            print("MISMATCH vs oracle: seed", seed, "meta", meta, "contigs", bad[:5]); sys.exit(1)
+            print("MISMATCH vs oracle: seed", seed, "meta", meta, mask, closed, min_gene, min_edge, max_ov, single.trans_table, "contigs", bad[:5]); sys.exit(1)
         ngenes += sum(n for _, n in out)
 print("seeds", sys.argv[1], "-", sys.argv[2], "identical to the oracle;", ngenes, "genes; %.0f s" % (time.time() - t0))
