@@ -719,7 +719,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             DEVBUF(d_nruns, int32_t, "d_mask_count", 4);
             DEVBUF(d_moff, int32_t, "d_mask_off", NC + 2);
             DEVBUF(d_miv, int2, "d_mask_iv", cap + 1);
-            pga_launch_find_masks(d_dig, d_ct, batch->d_tiles, batch->n_tiles, P.min_mask, d_runs, d_nruns, cap, st);
+            pga_launch_find_masks(d_dig, d_ct, NC, batch->d_tiles, batch->n_tiles, P.min_mask, d_runs, d_nruns, cap, st);
             int32_t nruns = 0;
             HT(c, hipMemcpyAsync(&nruns, d_nruns, 4, hipMemcpyDeviceToHost, st));
             HT(c, hipStreamSynchronize(st));

@@ -60,7 +60,7 @@ void pga_launch_extract(const uint8_t* d_dig, int64_t total, const ContigDesc* d
                         const pga_params& p, const GroupArrays& ga, int2* d_tile_sum, int32_t* d_pre_gc, int write_gc,
                         const TileDesc* d_tiles, int n_tiles, int32_t* d_tile_first, int32_t* d_tile_last, MaskList masks, hipStream_t st);
 // runs of unknown bases of at least min_mask positions, unordered, at most `cap` of them; *d_count is reset first
-void pga_launch_find_masks(const uint8_t* d_dig, const ContigDesc* d_ct, const TileDesc* d_tiles, int n_tiles, int min_mask,
+void pga_launch_find_masks(const uint8_t* d_dig, const ContigDesc* d_ct, int n_contigs, const TileDesc* d_tiles, int n_tiles, int min_mask,
                            MaskRun* d_runs, int32_t* d_count, int cap, hipStream_t st);
 int pga_extract_tile_size();
 void pga_launch_compact(int64_t total, const ContigDesc* d_ct, int n_contigs, const GroupArrays& ga, hipStream_t st);

@@ -1055,8 +1055,23 @@ void pga_launch_digitize(const char* d_seq, uint8_t* d_dig, int64_t total, const
 // Runs of unknown bases (ref: lib.pyx:699-713, Sequence._mask): the thread that sees the first N of a run walks to
 // its end, 8 bytes at a time, and records it when it is long enough.  Runs are rare and mostly short.
 __global__ void __launch_bounds__(256)
-k_find_masks(const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct, const TileDesc* __restrict__ tiles, int min_mask,
-             MaskRun* __restrict__ runs, int32_t* __restrict__ count, int cap) {
+k_find_masks(const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct, const TileDesc* __restrict__ tiles, int n_tiles, int n_contigs,
+             int min_mask, MaskRun* __restrict__ runs, int32_t* __restrict__ count, int cap) {
+    if ((int)blockIdx.x >= n_tiles) {
+        // sequences of one or two bases have no extraction tile: one thread each
+        const int c = ((int)blockIdx.x - n_tiles) * blockDim.x + threadIdx.x;
+        if (c >= n_contigs) return;
+        const ContigDesc cd = ct[c];
+        if (cd.len < 1 || cd.len > 2) return;
+        const uint8_t* __restrict__ d = dig + cd.base;
+        for (int i = 0; i < cd.len; i++) {
+            if (d[i] != NN || (i > 0 && d[i - 1] == NN)) continue;
+            int e = i + 1;
+            while (e < cd.len && d[e] == NN) e++;
+            if (e - i >= min_mask || e == cd.len) { const int k = atomicAdd(count, 1); if (k < cap) runs[k] = MaskRun{c, i, e, 0}; }
+        }
+        return;
+    }
     const TileDesc td = tiles[blockIdx.x];
     const ContigDesc cd = ct[td.contig];
     const int L = cd.len;
@@ -1072,17 +1087,18 @@ k_find_masks(const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct,
             e += 8;
         }
         while (e < L && d[e] == NN) e++;
-        if (e - i >= min_mask) {
+        if (e - i >= min_mask || e == L) {          // a run that reaches the end of the sequence is masked whatever its length (ref: lib.pyx:711-712)
             const int k = atomicAdd(count, 1);
             if (k < cap) runs[k] = MaskRun{td.contig, i, e, 0};
         }
     }
 }
 
-void pga_launch_find_masks(const uint8_t* d_dig, const ContigDesc* d_ct, const TileDesc* d_tiles, int n_tiles, int min_mask,
+void pga_launch_find_masks(const uint8_t* d_dig, const ContigDesc* d_ct, int n_contigs, const TileDesc* d_tiles, int n_tiles, int min_mask,
                            MaskRun* d_runs, int32_t* d_count, int cap, hipStream_t st) {
     (void)hipMemsetAsync(d_count, 0, sizeof(int32_t), st);
-    if (n_tiles > 0) hipLaunchKernelGGL(k_find_masks, dim3(n_tiles), dim3(256), 0, st, d_dig, d_ct, d_tiles, min_mask, d_runs, d_count, cap);
+    hipLaunchKernelGGL(k_find_masks, dim3(n_tiles + (n_contigs + 255) / 256), dim3(256), 0, st, d_dig, d_ct, d_tiles, n_tiles, n_contigs, min_mask,
+                       d_runs, d_count, cap);
 }
 
 void pga_launch_extract(const uint8_t* d_dig, int64_t total, const ContigDesc* d_ct, int n_contigs, int tt,

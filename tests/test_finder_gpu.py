@@ -144,6 +144,7 @@ def test_region_masking_single_and_meta(ctx, models, min_mask):
             _with_unknown_runs(12000, 0.6, 71, [50] * 12),
             b"N" * 70 + synthetic_contig(4000, 0.5, 72) + b"N" * 55,          # masks touching both ends
             synthetic_contig(3000, 0.5, 73),                                  # no unknown base at all
+            synthetic_contig(5000, 0.5, 74) + b"NNN",                       # a short trailing run is a mask too
             b"N" * 400, b""]
     for meta in (True, False):
         ctx.set_models([m.buf for m in models] if meta else [models[1].buf])

@@ -87,6 +87,9 @@ def test_sequence_stage_gc_unknown_and_masks(ctx):
     r = ctx.nodes_stage([s], _cabi.STAGE_SEQUENCE, mask=True, min_mask=10)
     assert r.masks[0].tolist() == [[4, 14]]
     assert ctx.nodes_stage([s], _cabi.STAGE_SEQUENCE).masks is None          # ref: test_no_region_masking
+    # a run that reaches the end of the sequence is masked whatever its length (ref: lib.pyx:711-712)
+    r = ctx.nodes_stage([b"ACGTNNNACGTNN", b"ACGTNNN" + b"A" * 60 + b"N"], _cabi.STAGE_SEQUENCE, mask=True, min_mask=50)
+    assert r.masks[0].tolist() == [[11, 13]] and r.masks[1].tolist() == [[67, 68]]
     big = synthetic_contig(5000, 0.5, 1) + b"N" * 3000 + synthetic_contig(100, 0.5, 2) + b"n" * 50
     r = ctx.nodes_stage([big], _cabi.STAGE_SEQUENCE, mask=True)
     assert r.masks[0].tolist() == [[5000, 8000], [8100, 8150]]
