@@ -661,6 +661,12 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
     if (c->n_models <= 0 && !meta_run && stage != PGA_STAGE_EXTRACT && stage != PGA_STAGE_SEQUENCE) { c->err = "pga_find_genes: no model loaded (call pga_set_models first)"; return PGA_EINVAL; }
     const pga_params P = *pp;
     if (P.mask && P.min_mask < 0) { c->err = "pga_find_genes: min_mask must be positive"; return PGA_EINVAL; }   // ref: lib.pyx:5175-5176
+    if (!P.closed && P.min_edge_gene > 0 && P.min_edge_gene < 4) {
+        // with open ends and min_edge_gene <= 3 the reference emits a start node AND the virtual edge stop node at the same
+        // position and strand; the per-position node layout of this path holds one of them.  Nobody calls genes of one codon.
+        c->err = "pga_find_genes: min_edge_gene below 4 is not supported with open ends";
+        return PGA_EINVAL;
+    }
     if (P.min_gene <= 0 || P.min_edge_gene <= 0 || P.max_overlap < 0 || P.max_overlap > P.min_gene) {
         c->err = "pga_find_genes: invalid min_gene / min_edge_gene / max_overlap";   // ref: lib.pyx:5169-5181
         return PGA_EINVAL;

@@ -1187,6 +1187,8 @@ cdef class GeneFinder:
             raise ValueError("`min_gene` must be strictly positive")
         if min_edge_gene <= 0:
             raise ValueError("`min_edge_gene` must be strictly positive")
+        if min_edge_gene < 4 and not closed:
+            raise ValueError("`min_edge_gene` below 4 is not supported with open ends (one-codon edge genes)")
         if min_mask < 0:
             raise ValueError("`min_mask` must be positive")
         if max_overlap < 0:

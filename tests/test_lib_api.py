@@ -33,6 +33,9 @@ def test_constructor_validation_matches_reference(lib):
             lib.GeneFinder(t, **kw)
     with pytest.raises(ValueError):
         lib.GeneFinder(t, backend="avx")                # only the HIP backend exists here
+    with pytest.raises(ValueError):
+        lib.GeneFinder(t, min_edge_gene=3)              # one-codon edge genes: the one restriction against the reference
+    lib.GeneFinder(t, min_edge_gene=3, closed=True)
     with pytest.raises(RuntimeError):
         lib.GeneFinder().find_genes("ATGC")             # single mode without training info (ref: lib.pyx:5429-5430)
     with pytest.raises(RuntimeError):
