@@ -31,6 +31,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 namespace {
 
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
@@ -262,15 +264,16 @@ struct GlobalAcc {
     __device__ __forceinline__ double sc(int j) const { return score[j]; }
     __device__ __forceinline__ int tb_ndx(int j) const { return tbn[j]; }
 };
+// weight of the pair alone: ok = the connection is allowed, w its weight, mf the ov_mark it leaves; tbnj = ndx of the
+// source's own traceb node (-1: none)
 template <class Acc>
-__device__ __forceinline__ void pair_eval(const int j, const Acc& S, const Target& T, const double negc, const double* s_igm, Best& B) {
+__device__ __forceinline__ void pair_weight(const int j, const Acc& S, const int tbnj, const Target& T, const double negc, const double* s_igm,
+                                            bool& ok, double& w, int& mf) {
     const int s_meta = S.meta(j), s_ndx = S.ndx(j);
     const int sk = PGA_KIND(s_meta), sf = PGA_FRAME(s_meta);
-    const int tbnj = S.tb_ndx(j);
+    ok = false; w = 0.0; mf = -1;
     if ((sk == 1 || sk == 2) && tbnj == -1) return;
-    const double sj = S.sc(j);
-    bool ok = (j >= T.lo) && (j < T.i);
-    double w = 0.0; int mf = -1;
+    ok = (j >= T.lo) && (j < T.i);
     if (sk == 0) {
         ok = ok && T.kind == 1 && T.frame == sf && T.stop_val < s_ndx;
         w = S.cs(j);
@@ -314,7 +317,12 @@ __device__ __forceinline__ void pair_eval(const int j, const Acc& S, const Targe
             w = mf != -1 ? maxval : negc;
         }
     }
-    take(B, ok, sj + w, j, mf, s_ndx);
+}
+template <class Acc>
+__device__ __forceinline__ void pair_eval(const int j, const Acc& S, const Target& T, const double negc, const double* s_igm, Best& B) {
+    bool ok; double w; int mf;
+    pair_weight(j, S, S.tb_ndx(j), T, negc, s_igm, ok, w, mf);
+    if (ok) take(B, true, S.sc(j) + w, j, mf, S.ndx(j));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -569,7 +577,7 @@ __device__ __forceinline__ void init_levbase(int* s_levbase, int n) {
     for (int lev = 1; lev < 12; lev++) { s_levbase[lev] = base; base += (lev * 3 < 31) ? (n >> (3 * lev)) : 0; }
 }
 
-__device__ __forceinline__ void publish_max(double end_best, int end_idx, int end_tb, int lane, const DpBuffers& buf) {
+__device__ __forceinline__ void publish_max(double end_best, int end_idx, int end_tb, int lane, const DpBuffers& buf, const int slot) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         const double ob = __shfl_xor(end_best, m, 64);
@@ -578,8 +586,8 @@ __device__ __forceinline__ void publish_max(double end_best, int end_idx, int en
         if (ob > end_best || (ob == end_best && oi > end_idx)) { end_best = ob; end_idx = oi; end_tb = ot; }
     }
     if (lane == 0) {   // highest score among gene ends, ties to the largest index (ref: lib.pyx:1239-1251, 1311)
-        buf.max_index[blockIdx.x] = end_idx; buf.max_score[blockIdx.x] = end_idx >= 0 ? end_best : 0.0;
-        buf.ipath[blockIdx.x] = (end_idx >= 0 && end_tb != -1) ? end_idx : -1;
+        buf.max_index[slot] = end_idx; buf.max_score[slot] = end_idx >= 0 ? end_best : 0.0;
+        buf.ipath[slot] = (end_idx >= 0 && end_tb != -1) ? end_idx : -1;
     }
 }
 
@@ -630,7 +638,7 @@ k_dp_tree(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src,
             buf.prof[0] += tp1 - tp0; buf.prof[1] += tp2 - tp1; buf.prof[2] += tp3 - tp2; buf.prof[5] += 1;
         }
     }
-    publish_max(end_best, end_idx, end_tb, lane, buf);
+    publish_max(end_best, end_idx, end_tb, lane, buf, blockIdx.x);
 }
 
 // Reverse targets against a forward-stop source at s_ndx: every static condition of the dynamic rule is an
@@ -775,7 +783,7 @@ struct TileFin {
 #define PGA_MW_SLICES 8        // waves that take a slice of the previous batch
 __global__ void __launch_bounds__(64 * PGA_MW_WAVES)
 k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src, const DpTgt* __restrict__ g_tgt,
-             const ModelConst* __restrict__ models, DpBuffers buf) {
+             const ModelConst* __restrict__ models, DpBuffers buf, const int32_t* __restrict__ gate, const int32_t* __restrict__ slot_map) {
     __shared__ double s_igm[64];
     __shared__ int s_levbase[12];
     __shared__ double s_w[2][64][64];                 // in-batch weights [slot][source k][target lane], NaN = pair not allowed
@@ -789,6 +797,8 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
     __shared__ TileFin s_fin;
     __shared__ RingLds s_ring;
     __shared__ SuffixLds s_sfx[2];                    // one per far-field wave that queries far gene ends
+    if (gate != nullptr && gate[blockIdx.x] == 0) return;          // segmented launches: this chain is not (or no longer) wanted
+    const int slot = slot_map != nullptr ? slot_map[blockIdx.x] : (int)blockIdx.x;
     const ChainDesc cd = chains[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = cd.n;
@@ -804,7 +814,7 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
     constexpr int SLICE = 64 / PGA_MW_SLICES;
 
     if (n <= 0) {                                    // empty chain (contig without nodes): nothing to walk
-        if (wave == 0) publish_max(end_best, end_idx, end_tb, lane, buf);
+        if (wave == 0) publish_max(end_best, end_idx, end_tb, lane, buf, slot);
         return;
     }
     // weights of batch `bn` (targets Tq at chain index iq) in slot `sl`, and of the pairs from batch Tp into it
@@ -1043,7 +1053,7 @@ k_dp_tree_mw(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_s
             barrier_lds();
         }
         flush((nb - 1) << 6, mykind);
-        if (mykind == 0) publish_max(end_best, end_idx, end_tb, lane, buf);
+        if (mykind == 0) publish_max(end_best, end_idx, end_tb, lane, buf, slot);
     }
 }
 
@@ -1161,6 +1171,418 @@ k_dp_chain(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Segmented chains: speculate, re-score exactly, verify.
+//
+// The walk of a chain is serial, one node after the other, so a launch with few long chains (one genome, or
+// one genome x 16 metagenomic models) leaves the chip idle.  The choice of a node's predecessor only depends on
+// score DIFFERENCES inside its window, and those settle a few genes after any starting point, so:
+//   1  speculate  every segment [s, e) of a long chain is walked as an independent sub-chain that starts
+//                 `warm` nodes early from the empty state (the unchanged chain kernel, one workgroup per segment);
+//                 only the traceb of [s, e) is kept -- the CLAIM;
+//   2  re-score   the exact scores that belong to the claimed tracebs: score[i] = score[tb[i]] + w(tb[i], i), the
+//                 additions in chain order as the serial walk makes them (one wave per chain, no search);
+//   3  verify     with exact scores of ALL earlier nodes in memory, every node re-evaluates its whole window in
+//                 parallel (the far-field routine of the one-wave kernel over [lo, i)) and compares (score, traceb,
+//                 ov_mark) with the claim.  If every node of a chain agrees the claim IS the serial result, by
+//                 induction over the node index: node i's claim equals the recurrence applied to the exact values
+//                 of the nodes before it.
+// A mismatch (an unsettled warm-up, or a tie decided by the last bit of a score) makes the verified choice the
+// next claim and steps 2-3 run again; a chain that still disagrees after PGA_SEG_ROUNDS rounds is walked
+// serially.  Nothing here is approximate: a result is only ever published after a verification that found no
+// mismatch, or by the serial kernel.
+__global__ void __launch_bounds__(256)
+k_seg_records(const DpSeg* __restrict__ segs, const ChainDesc* __restrict__ chains, DpSrc* src, DpTgt* tgt) {
+    const DpSeg sd = segs[blockIdx.y];
+    const int li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= sd.e - sd.a) return;
+    const int64_t g = chains[sd.chain].off + sd.a + li, d = sd.off + li;
+    const DpSrc r = src[g];
+    DpTgt t = tgt[g];
+    const int a = sd.a;
+    if (a > 0) {
+        // chain indices -> sub-chain indices; what lies before the sub-chain does not exist for it
+        const int kind = PGA_KIND(r.meta);
+        auto rb = [a](const int v) { return v > a ? v - a : 0; };
+        auto one = [a](const int v) { return v >= a ? v - a : -1; };
+        t.lo = rb(t.lo); t.p_near = rb(t.p_near);
+        if (kind == 1) t.a[0] = rb(t.a[0]);
+        else if (kind == 2) { t.a[0] = one(t.a[0]); t.a[1] = rb(t.a[1]); t.a[2] = rb(t.a[2]); }
+        else if (kind == 3) {
+            for (int k = 0; k < 3; k++) { t.a[k] = rb(t.a[k]); t.b[k] = rb(t.b[k]); t.c[k] = one(t.c[k]); }
+        }
+    }
+    src[d] = r; tgt[d] = t;
+}
+
+__global__ void __launch_bounds__(256)
+k_seg_gather(const DpSeg* __restrict__ segs, const ChainDesc* __restrict__ chains, const int32_t* __restrict__ traceb, int32_t* __restrict__ ctb) {
+    const DpSeg sd = segs[blockIdx.y];
+    const int li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= sd.e - sd.s) return;
+    const int node = sd.s + li;
+    const int tb = traceb[sd.off + (node - sd.a)];
+    ctb[chains[sd.chain].off + node] = tb >= 0 ? tb + sd.a : -1;
+}
+
+// the claim of a round: traceb, the ov_mark and ndx-of-traceb that go with it, and the weight of the connection
+__global__ void __launch_bounds__(256)
+k_seg_weights(const ChainDesc* __restrict__ chains, const int32_t* __restrict__ big, const int32_t* __restrict__ gate,
+              const DpSrc* __restrict__ g_src, const DpTgt* __restrict__ g_tgt, const ModelConst* __restrict__ models, DpBuffers buf,
+              const int32_t* __restrict__ g_ctb, double* __restrict__ g_cw, uint32_t* __restrict__ g_hb) {
+    __shared__ double s_igm[64];
+    const int chain = big[blockIdx.y];
+    if (gate != nullptr && gate[chain] == 0) return;
+    const ChainDesc cd = chains[chain];
+    if ((int)(blockIdx.x * blockDim.x) >= cd.n) return;
+    const ModelConst* mc = &models[cd.model];
+    if (threadIdx.x < 64) s_igm[threadIdx.x] = mc->igm[threadIdx.x];
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cd.n) return;
+    const double negc = mc->negc;
+    const ChainPtrs P = chain_ptrs(cd, g_src, g_tgt, buf);
+    const int32_t* ctb = g_ctb + cd.off;
+    int tb = ctb[i];
+    if (tb >= i || tb < 0) tb = -1;
+    double w = 0.0; int mf = -1, tbn = -1;
+    if (tb >= 0) {
+        Target T;
+        load_target(T, P, i, 0, cd.n, negc);
+        int t2 = ctb[tb];
+        if (t2 >= tb || t2 < 0) t2 = -1;
+        const int tbnj = t2 >= 0 ? P.src[t2].ndx : -1;
+        const GlobalAcc G{P.src, nullptr, nullptr};
+        bool ok;
+        pair_weight(tb, G, tbnj, T, negc, s_igm, ok, w, mf);
+        if (ok) tbn = P.src[tb].ndx; else { tb = -1; w = 0.0; mf = -1; }
+    }
+    P.traceb[i] = tb; P.ovm[i] = (int8_t)mf; P.tbn[i] = tbn; g_cw[cd.off + i] = w;
+    if (tb >= 0 && !(g_hb[cd.off + tb] & 2u)) atomicOr(&g_hb[cd.off + tb], 2u);     // height >= 1: some node continues from tb
+}
+
+// Height classes of the claimed traceb forest (a node's height = the longest chain of nodes continuing from it):
+// bit k of hb[i] = "height >= k".  Pass k reads bit k-1 (final since the pass before) and sets bit k of the parent.
+__global__ void __launch_bounds__(256)
+k_seg_height(const ChainDesc* __restrict__ chains, const int32_t* __restrict__ big, const int32_t* __restrict__ gate,
+             const int32_t* __restrict__ g_traceb, uint32_t* __restrict__ g_hb, const int k) {
+    const int chain = big[blockIdx.y];
+    if (gate != nullptr && gate[chain] == 0) return;
+    const ChainDesc cd = chains[chain];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cd.n) return;
+    const int tb = g_traceb[cd.off + i];
+    if (tb < 0 || !(g_hb[cd.off + i] & (1u << (k - 1)))) return;
+    if (!(g_hb[cd.off + tb] & (1u << k))) atomicOr(&g_hb[cd.off + tb], 1u << k);
+}
+
+// scores of the nodes of height class c (exactly): their parents are higher and already final
+__global__ void __launch_bounds__(256)
+k_seg_leaves(const ChainDesc* __restrict__ chains, const int32_t* __restrict__ big, const int32_t* __restrict__ gate,
+             const int32_t* __restrict__ first_bad, DpBuffers buf, const double* __restrict__ g_cw, const uint32_t* __restrict__ g_hb, const int c) {
+    const int chain = big[blockIdx.y];
+    if (gate != nullptr && gate[chain] == 0) return;
+    const ChainDesc cd = chains[chain];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cd.n) return;
+    if (first_bad != nullptr && i < (first_bad[chain] & ~63)) return;
+    const uint32_t hb = g_hb[cd.off + i] | 1u;
+    if (31 - __builtin_clz(hb) != c) return;
+    const int tb = buf.traceb[cd.off + i];
+    buf.score[cd.off + i] = tb < 0 ? 0.0 : buf.score[cd.off + tb] + g_cw[cd.off + i];
+}
+
+// Exact scores of the claimed tracebs: score[i] = score[tb[i]] + w(tb[i], i), every addition as the serial walk
+// makes it.  Only the dependence parent -> child is left, and only long chains of it need a serial pass: the
+// SPINE = nodes of height >= PGA_SEG_HEIGHT (the path and what keeps up with it for a while; about 3% of the
+// nodes of a genome, each one's parent nearly always the spine node just before it).  The spine is compacted into
+// a list in index order (k_spine_count / _scan / _fill), one wave per chain walks the list 64 entries at a time
+// (parents in earlier batches come from an LDS ring, parents in the same batch are met one after the other through
+// v_readlane), and every other node is scored afterwards, one parallel pass per height class (k_seg_leaves).
+// A later round restarts at the first node the verification rejected: everything before it is already exact.
+#define PGA_SEG_HEIGHT 4
+#define PGA_RS_RING 4096
+#define PGA_RS_CHUNK 8          // batches loaded together: one memory round trip per 512 list entries
+
+__device__ __forceinline__ int64_t seg_tile(const ChainDesc& cd, const int chain, const int i) { return (cd.off >> 6) + chain + (i >> 6); }
+
+__global__ void __launch_bounds__(256)
+k_spine_count(const ChainDesc* __restrict__ chains, const int32_t* __restrict__ big, const int32_t* __restrict__ gate,
+              const uint32_t* __restrict__ g_hb, unsigned long long* __restrict__ g_tmask) {
+    const int chain = big[blockIdx.y];
+    if (gate != nullptr && gate[chain] == 0) return;
+    const ChainDesc cd = chains[chain];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i - (int)(threadIdx.x & 63) >= cd.n) return;
+    const bool spine = i < cd.n && ((g_hb[cd.off + i] >> PGA_SEG_HEIGHT) & 1u);
+    const unsigned long long m = __ballot(spine);
+    if ((threadIdx.x & 63) == 0) g_tmask[seg_tile(cd, chain, i)] = m;
+}
+
+// exclusive scan of the tiles' spine counts; one workgroup per chain
+__global__ void __launch_bounds__(1024)
+k_spine_scan(const ChainDesc* __restrict__ chains, const int32_t* __restrict__ big, const int32_t* __restrict__ gate,
+             const unsigned long long* __restrict__ g_tmask, int32_t* __restrict__ g_toff, int32_t* __restrict__ g_nsp) {
+    __shared__ int s_wsum[16];
+    __shared__ int s_base;
+    const int chain = big[blockIdx.x];
+    if (gate != nullptr && gate[chain] == 0) return;
+    const ChainDesc cd = chains[chain];
+    const int nt = (cd.n + 63) >> 6, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t tq0 = seg_tile(cd, chain, 0);
+    if (t == 0) s_base = 0;
+    __syncthreads();
+    for (int q0 = 0; q0 < nt; q0 += 1024) {
+        const int q = q0 + t;
+        const int c = q < nt ? __popcll(g_tmask[tq0 + q]) : 0;
+        int inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+        if (lane == 63) s_wsum[wave] = inc;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < wave; k++) woff += s_wsum[k];
+        const int base = s_base;
+        if (q < nt) g_toff[tq0 + q] = base + woff + inc - c;
+        __syncthreads();
+        if (t == 1023) s_base = base + woff + inc;
+        __syncthreads();
+    }
+    if (t == 0) g_nsp[chain] = s_base;
+}
+
+// the list: chain index, claimed traceb, list position of the traceb node, weight of the connection
+__global__ void __launch_bounds__(256)
+k_spine_fill(const ChainDesc* __restrict__ chains, const int32_t* __restrict__ big, const int32_t* __restrict__ gate,
+             const int32_t* __restrict__ g_traceb, const double* __restrict__ g_cw, const unsigned long long* __restrict__ g_tmask,
+             const int32_t* __restrict__ g_toff, int32_t* __restrict__ sp_idx, int32_t* __restrict__ sp_tb, int32_t* __restrict__ sp_pp,
+             double* __restrict__ sp_w) {
+    const int chain = big[blockIdx.y];
+    if (gate != nullptr && gate[chain] == 0) return;
+    const ChainDesc cd = chains[chain];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cd.n) return;
+    const int64_t tq = seg_tile(cd, chain, i);
+    const unsigned long long m = g_tmask[tq];
+    if (!((m >> (i & 63)) & 1ull)) return;
+    const int64_t pos = cd.off + g_toff[tq] + __popcll(m & ((1ull << (i & 63)) - 1ull));
+    const int tb = g_traceb[cd.off + i];
+    int pp = -1;
+    if (tb >= 0) {
+        const int64_t tp = seg_tile(cd, chain, tb);
+        pp = g_toff[tp] + __popcll(g_tmask[tp] & ((1ull << (tb & 63)) - 1ull));     // the parent of a spine node is a spine node
+    }
+    sp_idx[pos] = i; sp_tb[pos] = tb; sp_pp[pos] = pp; sp_w[pos] = g_cw[cd.off + i];
+}
+
+__global__ void __launch_bounds__(64)
+k_dp_rescore(const ChainDesc* __restrict__ chains, const int32_t* __restrict__ big, const int32_t* __restrict__ gate,
+             const int32_t* __restrict__ first_bad, DpBuffers buf, const int32_t* __restrict__ g_toff, const int32_t* __restrict__ g_nsp,
+             const int32_t* __restrict__ sp_idx, const int32_t* __restrict__ sp_tb, const int32_t* __restrict__ sp_pp,
+             const double* __restrict__ sp_w) {
+    __shared__ double s_ring[PGA_RS_RING];
+    const int chain = big[blockIdx.x];
+    if (gate != nullptr && gate[chain] == 0) return;
+    const ChainDesc cd = chains[chain];
+    const int lane = threadIdx.x;
+    const int m = g_nsp[chain];
+    double* score = buf.score + cd.off;
+    const int32_t* __restrict__ lidx = sp_idx + cd.off; const int32_t* __restrict__ ltb = sp_tb + cd.off;
+    const int32_t* __restrict__ lpp = sp_pp + cd.off; const double* __restrict__ lw = sp_w + cd.off;
+    int p0 = 0;
+    if (first_bad != nullptr) {
+        const int b0 = min(max(first_bad[chain], 0), cd.n) & ~63;
+        p0 = b0 >= cd.n ? m : g_toff[seg_tile(cd, chain, b0)];
+    }
+    int ixn[PGA_RS_CHUNK], tbn_[PGA_RS_CHUNK], ppn[PGA_RS_CHUNK]; double wn_[PGA_RS_CHUNK];
+    auto load_chunk = [&](const int c0) {
+#pragma unroll
+        for (int u = 0; u < PGA_RS_CHUNK; u++) {
+            const int e = c0 + 64 * u + lane;
+            const bool in = e < m;
+            ixn[u] = in ? lidx[e] : -1; tbn_[u] = in ? ltb[e] : -1; ppn[u] = in ? lpp[e] : -1; wn_[u] = in ? lw[e] : 0.0;
+        }
+    };
+    load_chunk(p0);
+    for (int c0 = p0; c0 < m; c0 += 64 * PGA_RS_CHUNK) {
+        int ix[PGA_RS_CHUNK], tbv[PGA_RS_CHUNK], ppv[PGA_RS_CHUNK]; double wv[PGA_RS_CHUNK];
+#pragma unroll
+        for (int u = 0; u < PGA_RS_CHUNK; u++) { ix[u] = ixn[u]; tbv[u] = tbn_[u]; ppv[u] = ppn[u]; wv[u] = wn_[u]; }
+        if (c0 + 64 * PGA_RS_CHUNK < m) load_chunk(c0 + 64 * PGA_RS_CHUNK);      // in flight during this chunk
+#pragma unroll
+        for (int u = 0; u < PGA_RS_CHUNK; u++) {
+            const int ps = c0 + 64 * u, e = ps + lane;
+            if (ps >= m) break;
+            const bool valid = e < m;
+            const int pp = ppv[u]; const double w = wv[u];
+            bool done = !valid || pp < 0;
+            double s = 0.0;
+            if (!done && pp < ps) {
+                double sj;
+                if (pp >= p0 && e - pp <= PGA_RS_RING) sj = s_ring[pp & (PGA_RS_RING - 1)];
+                else sj = __hip_atomic_load(&score[tbv[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // far back, or from the round before
+                s = sj + w; done = true;
+            }
+            const int srcl = (pp - ps) & 63;
+            unsigned long long pend = __ballot(!done);
+            while (pend) {
+                const int t = __builtin_ctzll(pend);
+                pend &= pend - 1ull;
+                const int src = __builtin_amdgcn_readlane(srcl, t);
+                const double sj = readlane_f64(s, src);
+                if (lane == t) s = sj + w;
+            }
+            if (valid) { score[ix[u]] = s; s_ring[e & (PGA_RS_RING - 1)] = s; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
+__device__ __forceinline__ int levbase_of(const int lev, const int n) {     // init_levbase, one entry
+    int base = 0;
+    for (int l = 1; l < lev; l++) base += (l * 3 < 31) ? (n >> (3 * l)) : 0;
+    return base;
+}
+
+// far-field candidate values of every node (finalize_batch's A and V) and the two lowest tree levels, from the
+// exact scores; one wave per 64 nodes
+__global__ void __launch_bounds__(256)
+k_seg_build_far(const ChainDesc* __restrict__ chains, const int32_t* __restrict__ big, const int32_t* __restrict__ gate,
+                const DpSrc* __restrict__ g_src, const DpTgt* __restrict__ g_tgt, const ModelConst* __restrict__ models, DpBuffers buf,
+                double* __restrict__ g_tv, int32_t* __restrict__ g_ti) {
+    const int chain = big[blockIdx.y];
+    if (gate != nullptr && gate[chain] == 0) return;
+    const ChainDesc cd = chains[chain];
+    const int n = cd.n;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    const int i0 = i - lane;
+    if (i0 >= n) return;
+    const double NEG_INF = -__builtin_huge_val();
+    const double negc = models[cd.model].negc;
+    const ChainPtrs P = chain_ptrs(cd, g_src, g_tgt, buf);
+    double a_val = NEG_INF;
+    double ev = -1.0; int ei = -1;              // _find_max_index over this tile: gene ends, ties to the larger index
+    if (i < n) {
+        const DpSrc me = P.src[i];
+        const int kind = PGA_KIND(me.meta), frame = PGA_FRAME(me.meta);
+        const double val = P.score[i];
+        if (kind == 1 || kind == 2) { ev = val; ei = i; }
+        const bool alive = P.traceb[i] != -1;
+        double v0 = NEG_INF, v1 = NEG_INF, v2 = NEG_INF;
+        if (kind == 0) {
+            const double g = val + me.cs;
+            if (frame == 0) v0 = g; else if (frame == 1) v1 = g; else v2 = g;
+        } else if (kind == 1 && alive) {
+            a_val = val + negc;
+            if (PGA_SPVALID(me.meta, 0)) v0 = val + me.x[0];
+            if (PGA_SPVALID(me.meta, 1)) v1 = val + me.x[1];
+            if (PGA_SPVALID(me.meta, 2)) v2 = val + me.x[2];
+        } else if (kind == 2 && alive) {
+            a_val = val + negc;
+        }
+        P.A[i] = a_val; P.V0[i] = v0; P.V1[i] = v1; P.V2[i] = v2;
+    }
+    double rv = a_val; int ri = i;
+#pragma unroll
+    for (int m = 1; m <= 4; m <<= 1) {
+        const double ov2 = __shfl_xor(rv, m, 64); const int oi = __shfl_xor(ri, m, 64);
+        if (ov2 > rv || (ov2 == rv && oi > ri)) { rv = ov2; ri = oi; }
+    }
+    if ((lane & 7) == 0 && i + 8 <= n) { P.hv[levbase_of(1, n) + (i >> 3)] = rv; P.hi[levbase_of(1, n) + (i >> 3)] = ri; }
+#pragma unroll
+    for (int m = 8; m <= 32; m <<= 1) {
+        const double ov2 = __shfl_xor(rv, m, 64); const int oi = __shfl_xor(ri, m, 64);
+        if (ov2 > rv || (ov2 == rv && oi > ri)) { rv = ov2; ri = oi; }
+    }
+    if (lane == 0 && i0 + 64 <= n) { P.hv[levbase_of(2, n) + (i0 >> 6)] = rv; P.hi[levbase_of(2, n) + (i0 >> 6)] = ri; }
+#pragma unroll
+    for (int m = 1; m <= 32; m <<= 1) {
+        const double ov2 = __shfl_xor(ev, m, 64); const int oi = __shfl_xor(ei, m, 64);
+        if (ov2 > ev || (ov2 == ev && oi > ei)) { ev = ov2; ei = oi; }
+    }
+    if (lane == 0) { const int64_t tq = (cd.off >> 6) + chain + (i0 >> 6); g_tv[tq] = ev; g_ti[tq] = ei; }
+}
+
+// the tree levels above that, and _find_max_index (ref: lib.pyx:1239-1251); one workgroup per chain
+__global__ void __launch_bounds__(256)
+k_seg_build_upper(const ChainDesc* __restrict__ chains, const int32_t* __restrict__ big, const int32_t* __restrict__ gate,
+                  const DpSrc* __restrict__ g_src, const DpTgt* __restrict__ g_tgt, DpBuffers buf,
+                  const double* __restrict__ g_tv, const int32_t* __restrict__ g_ti) {
+    __shared__ double s_v[256];
+    __shared__ int s_i[256];
+    const int chain = big[blockIdx.x];
+    if (gate != nullptr && gate[chain] == 0) return;
+    const ChainDesc cd = chains[chain];
+    const int n = cd.n, t = threadIdx.x;
+    const ChainPtrs P = chain_ptrs(cd, g_src, g_tgt, buf);
+    for (int lev = 3; lev * 3 < 31 && (n >> (3 * lev)) > 0; lev++) {
+        const int m = n >> (3 * lev), cb = levbase_of(lev - 1, n), ob = levbase_of(lev, n);
+        for (int e = t; e < m; e += 256) {
+            double bv = P.hv[cb + 8 * e]; int bi = P.hi[cb + 8 * e];
+            for (int q = 1; q < 8; q++) {
+                const double v = P.hv[cb + 8 * e + q]; const int ix = P.hi[cb + 8 * e + q];
+                if (v > bv || (v == bv && ix > bi)) { bv = v; bi = ix; }
+            }
+            P.hv[ob + e] = bv; P.hi[ob + e] = bi;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    double eb = -1.0; int ei = -1;
+    const int64_t tq0 = (cd.off >> 6) + chain;
+    for (int q = t; q < ((n + 63) >> 6); q += 256) {
+        const double v = g_tv[tq0 + q]; const int ix = g_ti[tq0 + q];
+        if (v > eb || (v == eb && ix > ei)) { eb = v; ei = ix; }
+    }
+    s_v[t] = eb; s_i[t] = ei;
+    __syncthreads();
+    for (int h = 128; h >= 1; h >>= 1) {
+        if (t < h) {
+            const double v = s_v[t + h]; const int ix = s_i[t + h];
+            if (v > s_v[t] || (v == s_v[t] && ix > s_i[t])) { s_v[t] = v; s_i[t] = ix; }
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const int end_idx = s_i[0];
+        const int end_tb = end_idx >= 0 ? P.traceb[end_idx] : -1;
+        buf.max_index[chain] = end_idx; buf.max_score[chain] = end_idx >= 0 ? s_v[0] : 0.0;
+        buf.ipath[chain] = (end_idx >= 0 && end_tb != -1) ? end_idx : -1;
+    }
+}
+
+// every node against its whole window, all earlier nodes taken as final
+__global__ void __launch_bounds__(256)
+k_dp_verify(const ChainDesc* __restrict__ chains, const int32_t* __restrict__ big, const int32_t* __restrict__ gate,
+            const DpSrc* __restrict__ g_src, const DpTgt* __restrict__ g_tgt, const ModelConst* __restrict__ models, DpBuffers buf,
+            int32_t* __restrict__ g_ctb, int32_t* __restrict__ flags, int32_t* __restrict__ first_bad) {
+    __shared__ double s_igm[64];
+    __shared__ int s_levbase[12];
+    const int chain = big[blockIdx.y];
+    if (gate != nullptr && gate[chain] == 0) return;
+    const ChainDesc cd = chains[chain];
+    const int n = cd.n;
+    if ((int)(blockIdx.x * blockDim.x) >= n) return;
+    const ModelConst* mc = &models[cd.model];
+    if (threadIdx.x < 64) s_igm[threadIdx.x] = mc->igm[threadIdx.x];
+    if (threadIdx.x == 64) init_levbase(s_levbase, n);
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double negc = mc->negc;
+    const ChainPtrs P = chain_ptrs(cd, g_src, g_tgt, buf);
+    Target T;
+    load_target(T, P, i, 0, n, negc);
+    Best B{0.0, -1, -1, -1};
+    far_field(T, 0, n, P, s_levbase, negc, s_igm, B);
+    if (B.tb < 0) { B.tb = -1; B.ov = -1; }
+    g_ctb[cd.off + i] = B.tb;
+    if (!(B.val == P.score[i]) || B.tb != P.traceb[i] || (int8_t)B.ov != P.ovm[i]) { atomicAdd(&flags[chain], 1); atomicMin(&first_bad[chain], i); }
+}
+
 }  // namespace
 
 void pga_launch_dp_prepare(const ChainDesc* d_chains, int n_chains, int64_t node_begin, int64_t total_nodes,
@@ -1172,9 +1594,93 @@ void pga_launch_dp_prepare(const ChainDesc* d_chains, int n_chains, int64_t node
                        d_chains, n_chains, node_begin, total_nodes, nodes, d_models, buf.src, buf.tgt, final);
 }
 
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+
+bool pga_dp_plan(const ChainDesc* h, int n_chains, int64_t tot_nodes, DpSegPlan& plan) {
+    plan = DpSegPlan();
+    if (n_chains <= 0 || n_chains >= 2048 || getenv("PGA_DP_KERNEL") || env_int("PGA_DP_SEG", 1) == 0) return false;
+    const int min_chain = std::max(256, env_int("PGA_DP_SEG_MIN", 16384));
+    const int warm = std::max(64, env_int("PGA_DP_SEG_WARM", 2048));
+    int64_t cand = 0;
+    for (int c = 0; c < n_chains; c++) if (h[c].n >= min_chain) cand += h[c].n;
+    if (cand == 0) return false;
+    // one workgroup per compute unit is what the chain kernel's LDS footprint allows: aim at 256 segments
+    int64_t len = env_int("PGA_DP_SEG_LEN", 0);
+    if (len <= 0) len = std::max<int64_t>(2048, (cand + 255) / 256);
+    len = (len + 63) & ~63ll;
+    int64_t cursor = tot_nodes;
+    for (int c = 0; c < n_chains; c++) {
+        const int n = h[c].n;
+        if (n < min_chain || n < 2 * len) continue;
+        plan.big.push_back(c);
+        plan.max_big_n = std::max(plan.max_big_n, n);
+        for (int64_t s0 = 0; s0 < n;) {
+            int64_t e = std::min<int64_t>(n, s0 + len);
+            if (n - e < len / 4) e = n;
+            DpSeg sd;
+            sd.chain = c; sd.s = (int32_t)s0; sd.e = (int32_t)e; sd.a = (int32_t)std::max<int64_t>(0, s0 - warm); sd.off = cursor;
+            cursor += sd.e - sd.a;
+            plan.max_seg_nodes = std::max(plan.max_seg_nodes, sd.e - sd.a);
+            plan.max_seg_len = std::max(plan.max_seg_len, sd.e - sd.s);
+            ChainDesc sc = h[c];
+            sc.off = sd.off; sc.n = sd.e - sd.a;
+            plan.p1_chains.push_back(sc);
+            plan.p1_slot.push_back(n_chains + (int32_t)plan.segs.size());
+            plan.segs.push_back(sd);
+            s0 = e;
+        }
+    }
+    if (plan.big.empty()) { plan = DpSegPlan(); return false; }
+    std::vector<char> is_big((size_t)n_chains, 0);
+    for (int c : plan.big) is_big[(size_t)c] = 1;
+    for (int c = 0; c < n_chains; c++) if (!is_big[(size_t)c]) { plan.p1_chains.push_back(h[c]); plan.p1_slot.push_back(c); }
+    plan.extra = cursor - tot_nodes;
+    return true;
+}
+
+static void launch_dp_segmented(const ChainDesc* d_chains, int n_chains, const ModelConst* d_models, DpBuffers buf, hipStream_t st,
+                                const DpSegDev& sg) {
+    const dim3 blk(256);
+    auto blocks = [](int n) { return (unsigned)((n + 255) / 256); };
+    hipMemsetAsync(sg.flags, 0, sizeof(int32_t) * PGA_SEG_ROUNDS * (size_t)n_chains, st);
+    hipMemsetAsync(sg.first_bad, 0x7f, sizeof(int32_t) * PGA_SEG_ROUNDS * (size_t)n_chains, st);
+    hipLaunchKernelGGL(k_seg_records, dim3(blocks(sg.max_seg_nodes), sg.n_segs), blk, 0, st, sg.segs, d_chains, buf.src, buf.tgt);
+    hipLaunchKernelGGL(k_dp_tree_mw, dim3(sg.n_p1), dim3(64 * PGA_MW_WAVES), 0, st, sg.p1_chains, buf.src, buf.tgt, d_models, buf,
+                       (const int32_t*)nullptr, sg.p1_slot);
+    hipLaunchKernelGGL(k_seg_gather, dim3(blocks(sg.max_seg_len), sg.n_segs), blk, 0, st, sg.segs, d_chains, buf.traceb, sg.ctb);
+    for (int r = 0; r < PGA_SEG_ROUNDS; r++) {
+        const int32_t* gate = r == 0 ? nullptr : sg.flags + (size_t)(r - 1) * n_chains;
+        const int32_t* from = r == 0 ? nullptr : sg.first_bad + (size_t)(r - 1) * n_chains;
+        const dim3 per_node(blocks(sg.max_big_n), sg.n_big);
+        hipMemsetAsync(sg.hb, 0, sizeof(uint32_t) * (size_t)sg.n_nodes, st);
+        hipLaunchKernelGGL(k_seg_weights, per_node, blk, 0, st, d_chains, sg.big, gate, buf.src, buf.tgt, d_models, buf, sg.ctb, sg.cw, sg.hb);
+        for (int k = 2; k <= PGA_SEG_HEIGHT; k++)
+            hipLaunchKernelGGL(k_seg_height, per_node, blk, 0, st, d_chains, sg.big, gate, (const int32_t*)buf.traceb, sg.hb, k);
+        hipLaunchKernelGGL(k_spine_count, per_node, blk, 0, st, d_chains, sg.big, gate, (const uint32_t*)sg.hb, sg.tmask);
+        hipLaunchKernelGGL(k_spine_scan, dim3(sg.n_big), dim3(1024), 0, st, d_chains, sg.big, gate, (const unsigned long long*)sg.tmask, sg.toff, sg.nsp);
+        hipLaunchKernelGGL(k_spine_fill, per_node, blk, 0, st, d_chains, sg.big, gate, (const int32_t*)buf.traceb, (const double*)sg.cw,
+                           (const unsigned long long*)sg.tmask, (const int32_t*)sg.toff, sg.sp_idx, sg.sp_tb, sg.sp_pp, sg.sp_w);
+        hipLaunchKernelGGL(k_dp_rescore, dim3(sg.n_big), dim3(64), 0, st, d_chains, sg.big, gate, from, buf, (const int32_t*)sg.toff,
+                           (const int32_t*)sg.nsp, (const int32_t*)sg.sp_idx, (const int32_t*)sg.sp_tb, (const int32_t*)sg.sp_pp, (const double*)sg.sp_w);
+        for (int cl = PGA_SEG_HEIGHT - 1; cl >= 0; cl--)
+            hipLaunchKernelGGL(k_seg_leaves, per_node, blk, 0, st, d_chains, sg.big, gate, from, buf, sg.cw, sg.hb, cl);
+        hipLaunchKernelGGL(k_seg_build_far, per_node, blk, 0, st, d_chains, sg.big, gate, buf.src, buf.tgt, d_models, buf, sg.tv, sg.ti);
+        hipLaunchKernelGGL(k_seg_build_upper, dim3(sg.n_big), blk, 0, st, d_chains, sg.big, gate, buf.src, buf.tgt, buf, sg.tv, sg.ti);
+        hipLaunchKernelGGL(k_dp_verify, per_node, blk, 0, st, d_chains, sg.big, gate, buf.src, buf.tgt, d_models, buf, sg.ctb,
+                           sg.flags + (size_t)r * n_chains, sg.first_bad + (size_t)r * n_chains);
+    }
+    // chains that never verified clean: the serial walk
+    hipLaunchKernelGGL(k_dp_tree_mw, dim3(n_chains), dim3(64 * PGA_MW_WAVES), 0, st, d_chains, buf.src, buf.tgt, d_models, buf,
+                       (const int32_t*)(sg.flags + (size_t)(PGA_SEG_ROUNDS - 1) * n_chains), (const int32_t*)nullptr);
+}
+
 void pga_launch_dp(const ChainDesc* d_chains, int n_chains, const ModelConst* d_models, DpBuffers buf,
-                   int final, hipStream_t st) {
+                   int final, hipStream_t st, const DpSegDev* seg) {
     if (n_chains <= 0) return;
+    if (final && seg != nullptr && seg->n_segs > 0) { launch_dp_segmented(d_chains, n_chains, d_models, buf, st, *seg); return; }
     if (!final) {     // training pass: once per genome, the window-scanning kernel is plenty
         hipLaunchKernelGGL((k_dp_chain<16, false>), dim3(n_chains), dim3(64 * 16), 0, st, d_chains, buf.src, buf.tgt, d_models,
                            buf.score, buf.traceb, buf.tbn, buf.ov_mark, buf.max_index, buf.max_score, buf.ipath);
@@ -1188,7 +1694,8 @@ void pga_launch_dp(const ChainDesc* d_chains, int n_chains, const ModelConst* d_
         bool mw = n_chains < 2048;
         if (kern && strcmp(kern, "tree1") == 0) mw = false;
         if (kern && strcmp(kern, "tree3") == 0) mw = true;
-        if (mw) hipLaunchKernelGGL(k_dp_tree_mw, dim3(n_chains), dim3(64 * PGA_MW_WAVES), 0, st, d_chains, buf.src, buf.tgt, d_models, buf);
+        if (mw) hipLaunchKernelGGL(k_dp_tree_mw, dim3(n_chains), dim3(64 * PGA_MW_WAVES), 0, st, d_chains, buf.src, buf.tgt, d_models, buf,
+                                   (const int32_t*)nullptr, (const int32_t*)nullptr);
         else hipLaunchKernelGGL(k_dp_tree, dim3(n_chains), dim3(64), 0, st, d_chains, buf.src, buf.tgt, d_models, buf);
         return;
     }

@@ -826,15 +826,38 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             DEVBUF(a12, uint8_t, "ca_mot_spacendx", chain_cap)
             ca = ChainArrays{a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12};
         }
+        // few long chains: their walks are cut into segments that run side by side (dp.hip "segmented chains")
+        DpSegPlan seg_plan;
+        const bool segmented = stage == 0 && pga_dp_plan(chains.data(), NCH, tot_chain_nodes, seg_plan);
+        const int64_t dp_cap = tot_chain_nodes + seg_plan.extra + 1;
+        const int64_t dp_slots = NCH + (int64_t)seg_plan.segs.size() + 1;
         DpBuffers dp;
         {
-            DEVBUF(b0, DpSrc, "dp_src", tot_chain_nodes + 1) DEVBUF(b1, DpTgt, "dp_tgt", tot_chain_nodes + 1)
-            DEVBUF(b2, double, "dp_score", tot_chain_nodes + 1) DEVBUF(b3, int32_t, "dp_traceb", tot_chain_nodes + 1)
-            DEVBUF(b4, int32_t, "dp_tbn", tot_chain_nodes + 1) DEVBUF(b5, int8_t, "dp_ov", tot_chain_nodes + 1)
-            DEVBUF(b6, int32_t, "dp_maxidx", NCH + 1) DEVBUF(b7, double, "dp_maxscore", NCH + 1) DEVBUF(b8, int32_t, "dp_ipath", NCH + 1)
-            DEVBUF(b9, double, "dp_A", tot_chain_nodes + 1) DEVBUF(b10, double, "dp_V0", tot_chain_nodes + 1) DEVBUF(b11, double, "dp_V1", tot_chain_nodes + 1)
-            DEVBUF(b12, double, "dp_V2", tot_chain_nodes + 1) DEVBUF(b13, double, "dp_hv", tot_chain_nodes + 1) DEVBUF(b14, int32_t, "dp_hi", tot_chain_nodes + 1)
+            DEVBUF(b0, DpSrc, "dp_src", dp_cap) DEVBUF(b1, DpTgt, "dp_tgt", dp_cap)
+            DEVBUF(b2, double, "dp_score", dp_cap) DEVBUF(b3, int32_t, "dp_traceb", dp_cap)
+            DEVBUF(b4, int32_t, "dp_tbn", dp_cap) DEVBUF(b5, int8_t, "dp_ov", dp_cap)
+            DEVBUF(b6, int32_t, "dp_maxidx", dp_slots) DEVBUF(b7, double, "dp_maxscore", dp_slots) DEVBUF(b8, int32_t, "dp_ipath", dp_slots)
+            DEVBUF(b9, double, "dp_A", dp_cap) DEVBUF(b10, double, "dp_V0", dp_cap) DEVBUF(b11, double, "dp_V1", dp_cap)
+            DEVBUF(b12, double, "dp_V2", dp_cap) DEVBUF(b13, double, "dp_hv", dp_cap) DEVBUF(b14, int32_t, "dp_hi", dp_cap)
             dp = DpBuffers{b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, {b10, b11, b12}, b13, b14, nullptr};
+        }
+        DpSegDev seg_dev{};
+        if (segmented) {
+            const size_t ns = seg_plan.segs.size(), np = seg_plan.p1_chains.size(), nb = seg_plan.big.size();
+            DEVBUF(s0, DpSeg, "seg_segs", ns) DEVBUF(s1, ChainDesc, "seg_p1_chains", np) DEVBUF(s2, int32_t, "seg_p1_slot", np)
+            DEVBUF(s3, int32_t, "seg_big", nb) DEVBUF(s4, int32_t, "seg_flags", (size_t)PGA_SEG_ROUNDS * NCH)
+            DEVBUF(s5, int32_t, "seg_ctb", tot_chain_nodes + 1) DEVBUF(s6, double, "seg_cw", tot_chain_nodes + 1)
+            DEVBUF(s7, int32_t, "seg_first", (size_t)PGA_SEG_ROUNDS * NCH) DEVBUF(s8, uint32_t, "seg_hb", tot_chain_nodes + 1)
+            DEVBUF(s9, double, "seg_tv", tot_chain_nodes / 64 + NCH + 2) DEVBUF(s10, int32_t, "seg_ti", tot_chain_nodes / 64 + NCH + 2)
+            DEVBUF(s11, unsigned long long, "seg_tmask", tot_chain_nodes / 64 + NCH + 2) DEVBUF(s12, int32_t, "seg_toff", tot_chain_nodes / 64 + NCH + 2)
+            DEVBUF(s13, int32_t, "seg_nsp", NCH + 1) DEVBUF(s14, int32_t, "seg_sp_idx", tot_chain_nodes + 1) DEVBUF(s15, int32_t, "seg_sp_tb", tot_chain_nodes + 1)
+            DEVBUF(s16, int32_t, "seg_sp_pp", tot_chain_nodes + 1) DEVBUF(s17, double, "seg_sp_w", tot_chain_nodes + 1)
+            HT(c, hipMemcpyAsync(s0, seg_plan.segs.data(), sizeof(DpSeg) * ns, hipMemcpyHostToDevice, st));
+            HT(c, hipMemcpyAsync(s1, seg_plan.p1_chains.data(), sizeof(ChainDesc) * np, hipMemcpyHostToDevice, st));
+            HT(c, hipMemcpyAsync(s2, seg_plan.p1_slot.data(), sizeof(int32_t) * np, hipMemcpyHostToDevice, st));
+            HT(c, hipMemcpyAsync(s3, seg_plan.big.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice, st));
+            seg_dev = DpSegDev{s0, s1, s2, s3, s4, s7, s5, s6, s8, s9, s10, s11, s12, s13, s14, s15, s16, s17, tot_chain_nodes, (int32_t)ns, (int32_t)np, (int32_t)nb,
+                               seg_plan.max_seg_nodes, seg_plan.max_seg_len, seg_plan.max_big_n};
         }
         DEVBUF(d_chains, ChainDesc, "d_chains", NCH + NC + 1);
         PINBUF(h_maxidx, int32_t, "h_maxidx", NCH + 1);
@@ -918,8 +941,21 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         }
         // one DP launch over the chains of every group: chains are independent, the more in flight the better
         HT(c, hipEventRecord(f->e_dp0[0], st));
-        pga_launch_dp(d_chains, NCH, c->d_model_const, dp, 1, st);
+        pga_launch_dp(d_chains, NCH, c->d_model_const, dp, 1, st, segmented ? &seg_dev : nullptr);
         HT(c, hipEventRecord(f->e_dp1[0], st));
+        if (segmented && getenv("PGA_DP_SEG_DEBUG")) {
+            std::vector<int32_t> fl((size_t)PGA_SEG_ROUNDS * NCH);
+            HT(c, hipMemcpyAsync(fl.data(), seg_dev.flags, sizeof(int32_t) * fl.size(), hipMemcpyDeviceToHost, st));
+            HT(c, hipStreamSynchronize(st));
+            fprintf(stderr, "[pga dp-seg] %d chains segmented into %d pieces (<= %d nodes each); mismatches per round:", seg_dev.n_big,
+                    seg_dev.n_segs, seg_dev.max_seg_nodes);
+            for (int r = 0; r < PGA_SEG_ROUNDS; r++) {
+                long long tot = 0; int nc = 0;
+                for (int k = 0; k < NCH; k++) { tot += fl[(size_t)r * NCH + k]; nc += fl[(size_t)r * NCH + k] != 0; }
+                fprintf(stderr, " r%d=%lld nodes in %d chains;", r, tot, nc);
+            }
+            fprintf(stderr, "\n");
+        }
         HT(c, hipMemcpyAsync(h_maxidx, dp.max_index, sizeof(int32_t) * NCH, hipMemcpyDeviceToHost, st));
         HT(c, hipMemcpyAsync(h_ipath, dp.ipath, sizeof(int32_t) * NCH, hipMemcpyDeviceToHost, st));
         HT(c, hipMemcpyAsync(h_maxscore, dp.max_score, sizeof(double) * NCH, hipMemcpyDeviceToHost, st));

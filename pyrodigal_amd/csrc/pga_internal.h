@@ -79,12 +79,47 @@ struct DpBuffers {
     unsigned long long* prof;                 // optional [8] phase cycle counters of chain 0 (PGA_DP_PROFILE), else NULL
 };
 
+// Segmented connection scoring of long chains (see dp.hip "segmented chains").
+// One segment = nodes [s, e) of a chain, walked speculatively as a sub-chain that starts `s - a` nodes early.
+struct DpSeg {
+    int32_t chain;      // index into the chain list of the launch
+    int32_t a, s, e;    // sub-chain [a, e) of the chain; its results are kept for [s, e)
+    int64_t off;        // first element of the sub-chain in the DP arrays (scratch region behind the real chains)
+};
+#define PGA_SEG_ROUNDS 3
+struct DpSegPlan {       // host side
+    std::vector<DpSeg> segs;
+    std::vector<ChainDesc> p1_chains;    // speculative launch: the sub-chains, then the chains that are not segmented
+    std::vector<int32_t> p1_slot;        // where each of them publishes its _find_max_index result
+    std::vector<int32_t> big;            // the segmented chains
+    int64_t extra = 0;                   // scratch elements needed behind the real chains in every per-node DP array
+    int32_t max_seg_nodes = 0, max_seg_len = 0, max_big_n = 0;
+};
+struct DpSegDev {        // device copies + workspace; all owned by the caller
+    const DpSeg* segs; const ChainDesc* p1_chains; const int32_t* p1_slot; const int32_t* big;
+    int32_t* flags;      // [PGA_SEG_ROUNDS][n_chains] mismatches found by each verification round
+    int32_t* first_bad;  // [PGA_SEG_ROUNDS][n_chains] lowest node index each round rejected
+    int32_t* ctb;        // claimed traceb of every node (chain indexing)
+    double* cw;          // weight of the claimed connection
+    uint32_t* hb;        // bit k: the node's height in the claimed traceb forest is >= k
+    double* tv; int32_t* ti;   // per 64-node tile: best gene-end score and its index (n_nodes / 64 + n_chains + 1 entries)
+    unsigned long long* tmask; int32_t* toff;   // per tile: its spine nodes, and how many come before them in the chain
+    int32_t* nsp;              // [n_chains] spine nodes of the chain
+    int32_t* sp_idx; int32_t* sp_tb; int32_t* sp_pp; double* sp_w;   // the spine lists (one element per node at most)
+    int64_t n_nodes;     // elements of the real chains in the per-node arrays
+    int32_t n_segs, n_p1, n_big, max_seg_nodes, max_seg_len, max_big_n;
+};
+// false: nothing to segment (plan left empty)
+bool pga_dp_plan(const ChainDesc* h_chains, int n_chains, int64_t tot_nodes, DpSegPlan& plan);
+
 // kernel launchers (dp.hip)
 // chains[0..n_chains) must be contiguous in `off`; node_begin = chains[0].off, total_nodes = their node count
 void pga_launch_dp_prepare(const ChainDesc* d_chains, int n_chains, int64_t node_begin, int64_t total_nodes,
                            const NodeArrays& nodes, const ModelConst* d_models, DpBuffers buf, hipStream_t st, int final = 1);
+// seg != nullptr (from a non-empty plan): max_index / max_score / ipath need n_chains + n_segs entries and every per-node
+// array plan.extra more elements
 void pga_launch_dp(const ChainDesc* d_chains, int n_chains, const ModelConst* d_models, DpBuffers buf,
-                   int final, hipStream_t st);
+                   int final, hipStream_t st, const DpSegDev* seg = nullptr);
 
 struct FinderState;   // finder.hip
 
