@@ -121,6 +121,12 @@ int         pga_create(int device, pga_ctx** out);
 void        pga_destroy(pga_ctx*);
 const char* pga_last_error(const pga_ctx*);
 int         pga_device_info(const pga_ctx*, char* name, int name_len, int* cus, int64_t* hbm_bytes);
+/* How the connection scoring of the last pga_find_genes / pga_find_genes_batch / pga_score_connections call on this
+ * context ran (diagnostics; no counterpart in the reference, whose dynamic programme is one serial loop):
+ *   out[0] chains that were cut into segments (0: every chain was walked serially)   out[1] segments
+ *   out[2..4] nodes whose speculative result the verification rounds 1..3 rejected
+ *   out[5] chains that were walked serially in the end because they never verified clean */
+int         pga_dp_stats(const pga_ctx*, int32_t out[8]);
 
 /* ---- models (MetagenomicBins / TrainingInfo, ref: lib.pyx:4888-5069, 3898-3953) ---- */
 int pga_set_models(pga_ctx*, const pga_training* const* models, int n_models);

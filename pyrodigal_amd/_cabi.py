@@ -18,7 +18,7 @@ EXPORTS = [
     "pga_create", "pga_destroy", "pga_last_error", "pga_device_info", "pga_set_models",
     "pga_score_connections", "pga_score_connections_training", "pga_find_genes_batch", "pga_result_free",
     "pga_batch_create", "pga_batch_free", "pga_find_genes", "pga_nodes_stage",
-    "pga_fasta_open", "pga_fasta_next", "pga_fasta_error", "pga_fasta_close", "pga_train",
+    "pga_fasta_open", "pga_fasta_next", "pga_fasta_error", "pga_fasta_close", "pga_train", "pga_dp_stats",
 ]
 STAGE_EXTRACT, STAGE_SCORE, STAGE_OVERLAP, STAGE_SEQUENCE = 1, 2, 3, 4
 
@@ -88,6 +88,7 @@ def load():
     L.pga_create.restype = ctypes.c_int; L.pga_create.argtypes = [ctypes.c_int, _P(vp)]
     L.pga_destroy.restype = None; L.pga_destroy.argtypes = [vp]
     L.pga_last_error.restype = ctypes.c_char_p; L.pga_last_error.argtypes = [vp]
+    L.pga_dp_stats.restype = ctypes.c_int; L.pga_dp_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
     L.pga_device_info.restype = ctypes.c_int
     L.pga_device_info.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, _P(ctypes.c_int), _P(i64)]
     L.pga_set_models.restype = ctypes.c_int; L.pga_set_models.argtypes = [vp, _P(vp), ctypes.c_int]
@@ -157,6 +158,15 @@ class Context:
         if rc != PGA_OK:
             _raise(self.L, self.h, rc, "pga_device_info")
         return {"name": name.value.decode(), "cus": cus.value, "hbm_bytes": mem.value}
+
+    def dp_stats(self):
+        """How the last connection scoring ran: segmented chains, segments, nodes rejected by each verification round,
+        chains walked serially in the end."""
+        out = (ctypes.c_int32 * 8)()
+        rc = self.L.pga_dp_stats(self.h, out)
+        if rc != PGA_OK:
+            _raise(self.L, self.h, rc, "pga_dp_stats")
+        return {"chains": out[0], "segments": out[1], "rejected": [out[2], out[3], out[4]], "serial": out[5]}
 
     def set_models(self, blobs):
         """``blobs``: iterable of 558 392-byte ``struct _training`` buffers (bytes / uint8 arrays)."""

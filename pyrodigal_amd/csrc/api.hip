@@ -2,6 +2,8 @@
 // Host code only; no CPU compute path exists here -- without a gfx950 device every call fails.
 #include "pga_internal.h"
 
+#include <algorithm>
+
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -65,6 +67,24 @@ extern "C" void pga_destroy(pga_ctx* c) {
 }
 
 extern "C" const char* pga_last_error(const pga_ctx* c) { return c ? c->err.c_str() : "no context"; }
+
+extern "C" int pga_dp_stats(const pga_ctx* c, int32_t out[8]) {
+    if (!c || !out) return PGA_EINVAL;
+    memcpy(out, c->dp_stats, sizeof c->dp_stats);
+    return PGA_OK;
+}
+
+void pga_dp_note_stats(pga_ctx* c, const DpSegPlan* plan, const int32_t* h_flags, int stride) {
+    memset(c->dp_stats, 0, sizeof c->dp_stats);
+    if (!plan || plan->segs.empty()) return;
+    c->dp_stats[0] = (int32_t)plan->big.size(); c->dp_stats[1] = (int32_t)plan->segs.size();
+    for (int r = 0; r < PGA_SEG_ROUNDS; r++) {
+        long long tot = 0; int left = 0;
+        for (int k : plan->big) { tot += h_flags[(size_t)r * stride + k]; left += h_flags[(size_t)r * stride + k] != 0; }
+        c->dp_stats[2 + r] = (int32_t)std::min<long long>(tot, 0x7fffffff);
+        if (r == PGA_SEG_ROUNDS - 1) c->dp_stats[5] = left;
+    }
+}
 
 extern "C" int pga_device_info(const pga_ctx* c, char* name, int name_len, int* cus, int64_t* hbm_bytes) {
     if (!c) return PGA_EINVAL;
@@ -170,13 +190,17 @@ static int score_connections_impl(pga_ctx* c, int32_t n, const int32_t* ndx, con
     struct { int32_t* ndx; int32_t* stop_val; uint8_t* type; int8_t* strand; double* cscore; double* sscore; double* rscore; double* uscore; int32_t* star_ptr; } nd{};
     DpBuffers buf{};
     ChainDesc* d_chain; ModelConst* d_mc;
-    const size_t N = (size_t)n;
+    ChainDesc ch{0, 0, n, 0, 0, 1};
+    // a long chain is cut into segments walked side by side (dp.hip "segmented chains")
+    DpSegPlan seg_plan;
+    const bool segmented = final && pga_dp_plan(&ch, 1, n, seg_plan);
+    const size_t N = (size_t)n + (size_t)seg_plan.extra, NS = 1 + seg_plan.segs.size();
     HIP_TRY(c, db.alloc(&nd.ndx, N)); HIP_TRY(c, db.alloc(&nd.stop_val, N)); HIP_TRY(c, db.alloc(&nd.type, N));
     HIP_TRY(c, db.alloc(&nd.strand, N)); HIP_TRY(c, db.alloc(&nd.cscore, N)); HIP_TRY(c, db.alloc(&nd.sscore, N));
     HIP_TRY(c, db.alloc(&nd.rscore, N)); HIP_TRY(c, db.alloc(&nd.uscore, N)); HIP_TRY(c, db.alloc(&nd.star_ptr, 3 * N));
     HIP_TRY(c, db.alloc(&buf.src, N)); HIP_TRY(c, db.alloc(&buf.tgt, N)); HIP_TRY(c, db.alloc(&buf.score, N));
     HIP_TRY(c, db.alloc(&buf.traceb, N)); HIP_TRY(c, db.alloc(&buf.tbn, N)); HIP_TRY(c, db.alloc(&buf.ov_mark, N));
-    HIP_TRY(c, db.alloc(&buf.max_index, 1)); HIP_TRY(c, db.alloc(&buf.max_score, 1)); HIP_TRY(c, db.alloc(&buf.ipath, 1));
+    HIP_TRY(c, db.alloc(&buf.max_index, NS)); HIP_TRY(c, db.alloc(&buf.max_score, NS)); HIP_TRY(c, db.alloc(&buf.ipath, NS));
     HIP_TRY(c, db.alloc(&buf.A, N)); HIP_TRY(c, db.alloc(&buf.V[0], N)); HIP_TRY(c, db.alloc(&buf.V[1], N)); HIP_TRY(c, db.alloc(&buf.V[2], N));
     HIP_TRY(c, db.alloc(&buf.hv, N)); HIP_TRY(c, db.alloc(&buf.hi, N));
     buf.prof = nullptr;
@@ -184,32 +208,41 @@ static int score_connections_impl(pga_ctx* c, int32_t n, const int32_t* ndx, con
     HIP_TRY(c, db.alloc(&d_chain, 1)); HIP_TRY(c, db.alloc(&d_mc, 1));
     hipStream_t st = c->stream;
 #define UP(dst, srcp, bytes) HIP_TRY(c, hipMemcpyAsync(dst, srcp, bytes, hipMemcpyHostToDevice, st))
-    UP(nd.ndx, ndx, 4 * N); UP(nd.stop_val, stop_val, 4 * N); UP(nd.type, type, N); UP(nd.strand, strand, N);
+    const size_t NN = (size_t)n;
+    UP(nd.ndx, ndx, 4 * NN); UP(nd.stop_val, stop_val, 4 * NN); UP(nd.type, type, NN); UP(nd.strand, strand, NN);
     double* d_gcb = nullptr;
-    if (final) { UP(nd.cscore, cscore, 8 * N); UP(nd.sscore, sscore, 8 * N); UP(nd.rscore, rscore, 8 * N); UP(nd.uscore, uscore, 8 * N); }
+    if (final) { UP(nd.cscore, cscore, 8 * NN); UP(nd.sscore, sscore, 8 * NN); UP(nd.rscore, rscore, 8 * NN); UP(nd.uscore, uscore, 8 * NN); }
     else {
         double* d_gcs;
-        HIP_TRY(c, db.alloc(&d_gcs, 3 * N)); HIP_TRY(c, db.alloc(&d_gcb, N));
-        UP(d_gcs, gc_score, 24 * N);
-        hipLaunchKernelGGL(k_gc_factor, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, n, d_gcs, bias[0], bias[1], bias[2], d_gcb);
+        HIP_TRY(c, db.alloc(&d_gcs, 3 * NN)); HIP_TRY(c, db.alloc(&d_gcb, NN));
+        UP(d_gcs, gc_score, 24 * NN);
+        hipLaunchKernelGGL(k_gc_factor, dim3((unsigned)((NN + 255) / 256)), dim3(256), 0, st, n, d_gcs, bias[0], bias[1], bias[2], d_gcb);
     }
-    UP(nd.star_ptr, star_ptr, 12 * N);
-    ChainDesc ch{0, 0, n, 0, 0, 1};
+    UP(nd.star_ptr, star_ptr, 12 * NN);
+    DpSegDev seg_dev{};
+    if (segmented) {
+        char* arena;
+        HIP_TRY(c, db.alloc(&arena, pga_dp_seg_bytes(seg_plan, 1, n)));
+        HIP_TRY(c, pga_dp_seg_bind(seg_plan, 1, n, arena, st, &seg_dev));
+    }
     ModelConst mc; pga_fill_model_const(&mc, st_wt);
     UP(d_chain, &ch, sizeof ch); UP(d_mc, &mc, sizeof mc);
 #undef UP
     NodeArrays na{nd.ndx, nd.stop_val, nd.type, nd.strand, nd.cscore, nd.sscore, nd.rscore, nd.uscore, nd.star_ptr, d_gcb};
     pga_launch_dp_prepare(d_chain, 1, 0, n, na, d_mc, buf, st, final);
     HIP_TRY(c, hipEventRecord(c->ev0, st));
-    pga_launch_dp(d_chain, 1, d_mc, buf, final, st);
+    pga_launch_dp(d_chain, 1, d_mc, buf, final, st, segmented ? &seg_dev : nullptr);
     HIP_TRY(c, hipEventRecord(c->ev1, st));
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(score, buf.score, 8 * N, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(traceb, buf.traceb, 4 * N, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(ov_mark, buf.ov_mark, N, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(score, buf.score, 8 * NN, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(traceb, buf.traceb, 4 * NN, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(ov_mark, buf.ov_mark, NN, hipMemcpyDeviceToHost, st));
     int32_t mi = -1;
     HIP_TRY(c, hipMemcpyAsync(&mi, buf.max_index, 4, hipMemcpyDeviceToHost, st));
+    int32_t h_flags[PGA_SEG_ROUNDS] = {};
+    if (segmented) HIP_TRY(c, hipMemcpyAsync(h_flags, seg_dev.flags, sizeof h_flags, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
+    pga_dp_note_stats(c, segmented ? &seg_plan : nullptr, h_flags, 1);
     if (buf.prof) {
         unsigned long long pr[16]; HIP_TRY(c, hipMemcpy(pr, buf.prof, 128, hipMemcpyDeviceToHost));
         const double nbp = pr[5] ? (double)pr[5] : 1.0;

@@ -1607,9 +1607,23 @@ bool pga_dp_plan(const ChainDesc* h, int n_chains, int64_t tot_nodes, DpSegPlan&
     int64_t cand = 0;
     for (int c = 0; c < n_chains; c++) if (h[c].n >= min_chain) cand += h[c].n;
     if (cand == 0) return false;
-    // one workgroup per compute unit is what the chain kernel's LDS footprint allows: aim at 256 segments
+    // one workgroup per compute unit is what the chain kernel's LDS footprint allows: every sub-chain and every chain that
+    // is not cut must be resident at once (256 CUs), a workgroup too many would wait for a free CU and double the time
+    auto count_segs = [&](const int64_t len) {
+        int64_t k = 0;
+        for (int c = 0; c < n_chains; c++) {
+            const int n = h[c].n;
+            if (n < min_chain || n < 2 * len) { k++; continue; }
+            for (int64_t s0 = 0; s0 < n;) { int64_t e = std::min<int64_t>(n, s0 + len); if (n - e < len / 4) e = n; k++; s0 = e; }
+        }
+        return k;
+    };
     int64_t len = env_int("PGA_DP_SEG_LEN", 0);
-    if (len <= 0) len = std::max<int64_t>(2048, (cand + 255) / 256);
+    if (len <= 0) {
+        const int64_t budget = std::max(64, env_int("PGA_DP_SEG_SLOTS", 256) - 4);
+        len = std::max<int64_t>(512, ((cand + budget - 1) / budget + 63) & ~63ll);
+        while (count_segs(len) > budget && len < cand) len += 64;
+    }
     len = (len + 63) & ~63ll;
     int64_t cursor = tot_nodes;
     for (int c = 0; c < n_chains; c++) {
@@ -1639,6 +1653,48 @@ bool pga_dp_plan(const ChainDesc* h, int n_chains, int64_t tot_nodes, DpSegPlan&
     for (int c = 0; c < n_chains; c++) if (!is_big[(size_t)c]) { plan.p1_chains.push_back(h[c]); plan.p1_slot.push_back(c); }
     plan.extra = cursor - tot_nodes;
     return true;
+}
+
+namespace {
+struct SegLayout {
+    size_t segs, p1_chains, p1_slot, big, flags, first_bad, ctb, cw, hb, tv, ti, tmask, toff, nsp, sp_idx, sp_tb, sp_pp, sp_w, total;
+};
+SegLayout seg_layout(const DpSegPlan& plan, int n_chains, int64_t tot_nodes) {
+    SegLayout L{};
+    size_t off = 0;
+    auto take = [&off](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+    const size_t n = (size_t)tot_nodes + 1, nt = (size_t)tot_nodes / 64 + (size_t)n_chains + 2, nc = (size_t)n_chains + 1;
+    L.segs = take(sizeof(DpSeg) * plan.segs.size()); L.p1_chains = take(sizeof(ChainDesc) * plan.p1_chains.size());
+    L.p1_slot = take(4 * plan.p1_slot.size()); L.big = take(4 * plan.big.size());
+    L.flags = take(4 * PGA_SEG_ROUNDS * nc); L.first_bad = take(4 * PGA_SEG_ROUNDS * nc);
+    L.ctb = take(4 * n); L.cw = take(8 * n); L.hb = take(4 * n);
+    L.tv = take(8 * nt); L.ti = take(4 * nt); L.tmask = take(8 * nt); L.toff = take(4 * nt); L.nsp = take(4 * nc);
+    L.sp_idx = take(4 * n); L.sp_tb = take(4 * n); L.sp_pp = take(4 * n); L.sp_w = take(8 * n);
+    L.total = off;
+    return L;
+}
+}  // namespace
+
+size_t pga_dp_seg_bytes(const DpSegPlan& plan, int n_chains, int64_t tot_nodes) { return seg_layout(plan, n_chains, tot_nodes).total; }
+
+hipError_t pga_dp_seg_bind(const DpSegPlan& plan, int n_chains, int64_t tot_nodes, void* arena, hipStream_t st, DpSegDev* out) {
+    const SegLayout L = seg_layout(plan, n_chains, tot_nodes);
+    char* b = (char*)arena;
+    DpSegDev d{};
+    d.segs = (const DpSeg*)(b + L.segs); d.p1_chains = (const ChainDesc*)(b + L.p1_chains); d.p1_slot = (const int32_t*)(b + L.p1_slot);
+    d.big = (const int32_t*)(b + L.big); d.flags = (int32_t*)(b + L.flags); d.first_bad = (int32_t*)(b + L.first_bad);
+    d.ctb = (int32_t*)(b + L.ctb); d.cw = (double*)(b + L.cw); d.hb = (uint32_t*)(b + L.hb);
+    d.tv = (double*)(b + L.tv); d.ti = (int32_t*)(b + L.ti); d.tmask = (unsigned long long*)(b + L.tmask); d.toff = (int32_t*)(b + L.toff);
+    d.nsp = (int32_t*)(b + L.nsp); d.sp_idx = (int32_t*)(b + L.sp_idx); d.sp_tb = (int32_t*)(b + L.sp_tb); d.sp_pp = (int32_t*)(b + L.sp_pp);
+    d.sp_w = (double*)(b + L.sp_w);
+    d.n_nodes = tot_nodes; d.n_segs = (int32_t)plan.segs.size(); d.n_p1 = (int32_t)plan.p1_chains.size(); d.n_big = (int32_t)plan.big.size();
+    d.max_seg_nodes = plan.max_seg_nodes; d.max_seg_len = plan.max_seg_len; d.max_big_n = plan.max_big_n;
+    hipError_t e = hipMemcpyAsync(b + L.segs, plan.segs.data(), sizeof(DpSeg) * plan.segs.size(), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(b + L.p1_chains, plan.p1_chains.data(), sizeof(ChainDesc) * plan.p1_chains.size(), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(b + L.p1_slot, plan.p1_slot.data(), 4 * plan.p1_slot.size(), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(b + L.big, plan.big.data(), 4 * plan.big.size(), hipMemcpyHostToDevice, st);
+    *out = d;
+    return e;
 }
 
 static void launch_dp_segmented(const ChainDesc* d_chains, int n_chains, const ModelConst* d_models, DpBuffers buf, hipStream_t st,

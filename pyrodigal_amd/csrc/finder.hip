@@ -15,8 +15,10 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <functional>
 #include <map>
+#include <mutex>
 #include <new>
 #include <thread>
 
@@ -34,8 +36,54 @@ struct LastRun {
     int n_nodes = 0;
     int len = 0;
 };
+// Host threads that stay around between calls (the per-contig tail work is short: starting threads for it every call
+// would cost more than the work).  run(fn, k): fn runs on the caller and on k - 1 pool threads, returns when all are done.
+class WorkerPool {
+public:
+    ~WorkerPool() {
+        { std::lock_guard<std::mutex> g(mu_); stop_ = true; gen_++; }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    void run(const std::function<void()>& fn, int k) {
+        k = std::max(1, k);
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            while ((int)th_.size() < k - 1) th_.emplace_back([this, id = (int)th_.size()] { loop(id); });
+            job_ = &fn; want_ = k - 1; left_ = k - 1; gen_++;
+        }
+        if (k > 1) cv_.notify_all();
+        fn();
+        std::unique_lock<std::mutex> g(mu_);
+        done_.wait(g, [this] { return left_ == 0; });
+        job_ = nullptr;
+    }
+private:
+    void loop(const int id) {
+        unsigned long long seen = 0;
+        for (;;) {
+            const std::function<void()>* job = nullptr;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                if (id < want_) job = job_;
+            }
+            if (!job) continue;
+            (*job)();
+            { std::lock_guard<std::mutex> g(mu_); if (--left_ == 0) done_.notify_all(); }
+        }
+    }
+    std::mutex mu_; std::condition_variable cv_, done_;
+    std::vector<std::thread> th_;
+    const std::function<void()>* job_ = nullptr;
+    int want_ = 0, left_ = 0; unsigned long long gen_ = 0; bool stop_ = false;
+};
+
 struct FinderState {
     LastRun last;
+    WorkerPool pool;
     std::map<std::string, Buf> dev, pin;
     std::vector<int> model_group;   // model -> translation-table group
     std::vector<int> group_tt;
@@ -258,9 +306,9 @@ __host__ __device__ void tweak_one(const NodeView& v, const GeneRec* prev, GeneR
 // In-order semantics of the reference loop, evaluated in parallel when a contig has many genes: every
 // gene is first tweaked against its ORIGINAL neighbours; a gene whose predecessor did change is then
 // redone in order against the predecessor's final record (tweaks are rare, so few are redone).
-void tweak_final_starts(const NodeView& v, std::vector<GeneRec>& g, double w, int maxov, int inner_threads = 1) {
+void tweak_final_starts(const NodeView& v, std::vector<GeneRec>& g, double w, int maxov, int inner_threads = 1, WorkerPool* pool = nullptr) {
     const int ng = (int)g.size();
-    if (inner_threads <= 1 || ng < 2048) {
+    if (inner_threads <= 1 || ng < 2048 || pool == nullptr) {
         for (int i = 0; i < ng; i++) tweak_one(v, i > 0 ? &g[i - 1] : nullptr, g[i], i < ng - 1 ? &g[i + 1] : nullptr, w, maxov);
         return;
     }
@@ -274,10 +322,7 @@ void tweak_final_starts(const NodeView& v, std::vector<GeneRec>& g, double w, in
                 tweak_one(v, i > 0 ? &orig[i - 1] : nullptr, g[i], i < ng - 1 ? &orig[i + 1] : nullptr, w, maxov);
         }
     };
-    std::vector<std::thread> th;
-    for (int t = 1; t < inner_threads; t++) th.emplace_back(work);
-    work();
-    for (auto& t : th) t.join();
+    pool->run(work, inner_threads);
     for (int i = 1; i < ng; i++) {
         if (g[i - 1].start_ndx == orig[i - 1].start_ndx) continue;       // predecessor unchanged: the parallel result stands
         g[i] = orig[i];
@@ -843,21 +888,8 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         }
         DpSegDev seg_dev{};
         if (segmented) {
-            const size_t ns = seg_plan.segs.size(), np = seg_plan.p1_chains.size(), nb = seg_plan.big.size();
-            DEVBUF(s0, DpSeg, "seg_segs", ns) DEVBUF(s1, ChainDesc, "seg_p1_chains", np) DEVBUF(s2, int32_t, "seg_p1_slot", np)
-            DEVBUF(s3, int32_t, "seg_big", nb) DEVBUF(s4, int32_t, "seg_flags", (size_t)PGA_SEG_ROUNDS * NCH)
-            DEVBUF(s5, int32_t, "seg_ctb", tot_chain_nodes + 1) DEVBUF(s6, double, "seg_cw", tot_chain_nodes + 1)
-            DEVBUF(s7, int32_t, "seg_first", (size_t)PGA_SEG_ROUNDS * NCH) DEVBUF(s8, uint32_t, "seg_hb", tot_chain_nodes + 1)
-            DEVBUF(s9, double, "seg_tv", tot_chain_nodes / 64 + NCH + 2) DEVBUF(s10, int32_t, "seg_ti", tot_chain_nodes / 64 + NCH + 2)
-            DEVBUF(s11, unsigned long long, "seg_tmask", tot_chain_nodes / 64 + NCH + 2) DEVBUF(s12, int32_t, "seg_toff", tot_chain_nodes / 64 + NCH + 2)
-            DEVBUF(s13, int32_t, "seg_nsp", NCH + 1) DEVBUF(s14, int32_t, "seg_sp_idx", tot_chain_nodes + 1) DEVBUF(s15, int32_t, "seg_sp_tb", tot_chain_nodes + 1)
-            DEVBUF(s16, int32_t, "seg_sp_pp", tot_chain_nodes + 1) DEVBUF(s17, double, "seg_sp_w", tot_chain_nodes + 1)
-            HT(c, hipMemcpyAsync(s0, seg_plan.segs.data(), sizeof(DpSeg) * ns, hipMemcpyHostToDevice, st));
-            HT(c, hipMemcpyAsync(s1, seg_plan.p1_chains.data(), sizeof(ChainDesc) * np, hipMemcpyHostToDevice, st));
-            HT(c, hipMemcpyAsync(s2, seg_plan.p1_slot.data(), sizeof(int32_t) * np, hipMemcpyHostToDevice, st));
-            HT(c, hipMemcpyAsync(s3, seg_plan.big.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice, st));
-            seg_dev = DpSegDev{s0, s1, s2, s3, s4, s7, s5, s6, s8, s9, s10, s11, s12, s13, s14, s15, s16, s17, tot_chain_nodes, (int32_t)ns, (int32_t)np, (int32_t)nb,
-                               seg_plan.max_seg_nodes, seg_plan.max_seg_len, seg_plan.max_big_n};
+            DEVBUF(seg_arena, char, "dp_seg_arena", pga_dp_seg_bytes(seg_plan, NCH, tot_chain_nodes));
+            HT(c, pga_dp_seg_bind(seg_plan, NCH, tot_chain_nodes, seg_arena, st, &seg_dev));
         }
         DEVBUF(d_chains, ChainDesc, "d_chains", NCH + NC + 1);
         PINBUF(h_maxidx, int32_t, "h_maxidx", NCH + 1);
@@ -943,24 +975,23 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         HT(c, hipEventRecord(f->e_dp0[0], st));
         pga_launch_dp(d_chains, NCH, c->d_model_const, dp, 1, st, segmented ? &seg_dev : nullptr);
         HT(c, hipEventRecord(f->e_dp1[0], st));
-        if (segmented && getenv("PGA_DP_SEG_DEBUG")) {
-            std::vector<int32_t> fl((size_t)PGA_SEG_ROUNDS * NCH);
-            HT(c, hipMemcpyAsync(fl.data(), seg_dev.flags, sizeof(int32_t) * fl.size(), hipMemcpyDeviceToHost, st));
-            HT(c, hipStreamSynchronize(st));
-            fprintf(stderr, "[pga dp-seg] %d chains segmented into %d pieces (<= %d nodes each); mismatches per round:", seg_dev.n_big,
-                    seg_dev.n_segs, seg_dev.max_seg_nodes);
-            for (int r = 0; r < PGA_SEG_ROUNDS; r++) {
-                long long tot = 0; int nc = 0;
-                for (int k = 0; k < NCH; k++) { tot += fl[(size_t)r * NCH + k]; nc += fl[(size_t)r * NCH + k] != 0; }
-                fprintf(stderr, " r%d=%lld nodes in %d chains;", r, tot, nc);
-            }
-            fprintf(stderr, "\n");
-        }
         HT(c, hipMemcpyAsync(h_maxidx, dp.max_index, sizeof(int32_t) * NCH, hipMemcpyDeviceToHost, st));
         HT(c, hipMemcpyAsync(h_ipath, dp.ipath, sizeof(int32_t) * NCH, hipMemcpyDeviceToHost, st));
         HT(c, hipMemcpyAsync(h_maxscore, dp.max_score, sizeof(double) * NCH, hipMemcpyDeviceToHost, st));
+        PINBUF(h_segflags, int32_t, "h_segflags", (size_t)PGA_SEG_ROUNDS * NCH + NCH + 1);
+        if (segmented) {
+            HT(c, hipMemcpyAsync(h_segflags, seg_dev.flags, sizeof(int32_t) * PGA_SEG_ROUNDS * NCH, hipMemcpyDeviceToHost, st));
+            HT(c, hipMemcpyAsync(h_segflags + (size_t)PGA_SEG_ROUNDS * NCH, seg_dev.nsp, sizeof(int32_t) * NCH, hipMemcpyDeviceToHost, st));
+        }
         HT(c, hipGetLastError());
         HT(c, hipStreamSynchronize(st));
+        pga_dp_note_stats(c, segmented ? &seg_plan : nullptr, h_segflags, NCH);
+        if (segmented && getenv("PGA_DP_SEG_DEBUG")) {
+            fprintf(stderr, "[pga dp-seg] %d chains cut into %d segments (<= %d nodes each); nodes rejected per round: %d %d %d; walked serially: %d; spine:",
+                    seg_dev.n_big, seg_dev.n_segs, seg_dev.max_seg_nodes, c->dp_stats[2], c->dp_stats[3], c->dp_stats[4], c->dp_stats[5]);
+            for (int k : seg_plan.big) fprintf(stderr, " %d/%d", h_segflags[(size_t)PGA_SEG_ROUNDS * NCH + k], chains[(size_t)k].n);
+            fprintf(stderr, "\n");
+        }
         { float ms = 0; HT(c, hipEventElapsedTime(&ms, f->e_dp0[0], f->e_dp1[0])); R->pub.t_dp_ms = NCH > 0 ? ms : 0.0; }
 
         tm.mark("score+dp+sync");
@@ -1105,25 +1136,32 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                                h.star_ptr + 3 * oo, h.traceb + oo, tracef.data() + oo, h.ov_mark + oo, h.score + oo, elim.data() + oo};
                     const int mx = h_maxidx[k];
                     const double st_wt = c->models[chains[k].model].st_wt;
+                    const bool sub = NC == 1 && getenv("PGA_TIMING");
+                    auto now = [] { return std::chrono::steady_clock::now(); };
+                    auto t0 = now(), t1 = t0, t2 = t0, t3 = t0;
                     if (v.n > 0 && mx >= 0) {
                         int32_t* pl = pathbuf.data() + oo;
                         const int cnt = untangle(v, mx, pl);
+                        t1 = now();
                         if (v.traceb[mx] != -1) {
                             eliminate_bad_genes(v, pl, cnt, st_wt);
+                            t2 = now();
                             cg[i].resize((size_t)v.n / 2 + 2);
                             cg[i].resize((size_t)extract_genes(v, pl, cnt, cg[i].data()));
                         }
                     }
-                    tweak_final_starts(v, cg[i], st_wt, P.max_overlap, NC < 4 ? 16 : 1);
+                    t3 = now();
+                    tweak_final_starts(v, cg[i], st_wt, P.max_overlap, NC < 4 ? 16 : 1, &f->pool);
+                    if (sub) {
+                        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+                        fprintf(stderr, "[pga timing] host tail: untangle=%.2f eliminate=%.2f extract=%.2f tweak=%.2f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
+                    }
                 }
             };
             auto run_parallel = [&](const std::function<void()>& fn) {
                 int nt = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
                 if (NC < 4) nt = 1;
-                std::vector<std::thread> th;
-                for (int t = 1; t < nt; t++) th.emplace_back(fn);
-                fn();
-                for (auto& t : th) t.join();
+                if (nt == 1) fn(); else f->pool.run(fn, nt);
             };
             run_parallel(worker);
             tm.mark("host_tail");

@@ -111,6 +111,10 @@ struct DpSegDev {        // device copies + workspace; all owned by the caller
 };
 // false: nothing to segment (plan left empty)
 bool pga_dp_plan(const ChainDesc* h_chains, int n_chains, int64_t tot_nodes, DpSegPlan& plan);
+// device workspace of a segmented launch: its size, and its layout inside `arena` + the upload of the plan (the plan must
+// stay alive until the copies on `st` are done)
+size_t pga_dp_seg_bytes(const DpSegPlan& plan, int n_chains, int64_t tot_nodes);
+hipError_t pga_dp_seg_bind(const DpSegPlan& plan, int n_chains, int64_t tot_nodes, void* arena, hipStream_t st, DpSegDev* out);
 
 // kernel launchers (dp.hip)
 // chains[0..n_chains) must be contiguous in `off`; node_begin = chains[0].off, total_nodes = their node count
@@ -133,7 +137,10 @@ struct pga_ctx {
     void* d_models_raw = nullptr;      // device copy of the pga_training structs
     ModelConst* d_model_const = nullptr;
     int n_models = 0;
+    int32_t dp_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // pga_dp_stats
 };
+// summary of a segmented launch's flags (host copy, [PGA_SEG_ROUNDS][stride]) into pga_ctx::dp_stats
+void pga_dp_note_stats(pga_ctx* c, const DpSegPlan* plan, const int32_t* h_flags, int stride);
 
 // finder.hip
 void pga_finder_release(pga_ctx*);
