@@ -116,6 +116,15 @@ def main():
                          "kernel_ms_per_step": round(dp_ms / args.steps, 3), "chains": res.n_chains,
                          "bytes_per_node_pass": BYTES_PER_NODE_PASS},
         }
+        seg = ctx.dp_stats()
+        if seg["chains"] > 0:
+            # few long chains: the connection scoring is one group of kernels (speculative segment walks, exact
+            # re-scoring, verification; dp.hip "segmented chains"), timed as a whole by the same pair of events
+            out["roofline"]["kernel"] = "connection scoring, segmented (k_dp_tree_mw + k_dp_rescore + k_dp_verify + helpers)"
+            out["roofline"]["kernels"] = SEGMENTED_DP_KERNELS
+            out["roofline"]["segments"] = seg["segments"]
+            out["roofline"]["rejected_by_verification"] = seg["rejected"]
+            out["roofline"]["chains_walked_serially"] = seg["serial"]
         out["roofline"]["traffic"] = pmc_traffic(wname)
         # PCIe-inclusive rate (upload + find), reported next to `value`, never as `value`
         t1 = time.perf_counter()
@@ -130,6 +139,12 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+# every kernel of a segmented connection-scoring launch (pga_launch_dp with a plan), for the rocprof summaries
+SEGMENTED_DP_KERNELS = ["k_seg_records", "k_dp_tree_mw", "k_seg_gather", "k_seg_weights", "k_seg_height", "k_spine_count",
+                        "k_spine_scan", "k_spine_fill", "k_dp_rescore", "k_seg_leaves", "k_seg_build_far", "k_seg_build_upper",
+                        "k_dp_verify"]
 
 
 def pmc_traffic(workload):

@@ -225,6 +225,44 @@ __host__ __device__ void eliminate_bad_genes(NodeView& v, const int32_t* __restr
     }
 }
 
+// The same on several host threads (long paths): every node's start score receives at most two terms, in path order
+// (as the node after a forward stop, then as a reverse start), so nodes are independent; the elimination pass reads the
+// finished scores.
+void eliminate_bad_genes_mt(NodeView& v, const int32_t* path, int cnt, double st_wt, WorkerPool& pool, int threads) {
+    if (cnt < 4096 || threads <= 1) { eliminate_bad_genes(v, path, cnt, st_wt); return; }
+    std::atomic<int> next(cnt - 1);
+    const std::function<void()> add = [&]() {
+        for (;;) {
+            const int hi = next.fetch_sub(512);
+            if (hi < 0) break;
+            for (int q = hi; q > hi - 512 && q >= 0; q--) {          // node x = path[q]
+                const int x = path[q];
+                if (q + 1 <= cnt - 1) {                               // x follows p = path[q + 1]
+                    const int p = path[q + 1];
+                    if (v.strand[p] == 1 && is_stop_n(v, p)) v.sscore[x] += igm_h(v, p, x, st_wt);
+                }
+                if (q >= 1 && v.strand[x] == -1 && !is_stop_n(v, x)) v.sscore[x] += igm_h(v, x, path[q - 1], st_wt);
+            }
+        }
+    };
+    pool.run(add, threads);
+    next.store(cnt - 1);
+    const std::function<void()> mark = [&]() {
+        for (;;) {
+            const int hi = next.fetch_sub(512);
+            if (hi < 1) break;
+            for (int q = hi; q > hi - 512 && q >= 1; q--) {
+                const int p = path[q], f = path[q - 1];
+                const int sp = v.strand[p]; const bool stp = is_stop_n(v, p);
+                const double gp = v.cscore[p] + v.sscore[p], gf = v.cscore[f] + v.sscore[f];
+                if (sp == 1 && !stp && gp < 0) { v.elim[p] = 1; v.elim[f] = 1; }
+                if (sp == -1 && stp && gf < 0) { v.elim[p] = 1; v.elim[f] = 1; }
+            }
+        }
+    };
+    pool.run(mark, threads);
+}
+
 // ref: lib.pyx:3231-3270 (Genes._extract); returns the number of genes written to `out`
 __host__ __device__ int extract_genes(const NodeView& v, const int32_t* __restrict__ path, int cnt, GeneRec* out) {
     int b = 0, e = 0, s = 0, t = 0, ng = 0;
@@ -1144,14 +1182,14 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                         const int cnt = untangle(v, mx, pl);
                         t1 = now();
                         if (v.traceb[mx] != -1) {
-                            eliminate_bad_genes(v, pl, cnt, st_wt);
+                            if (NC < 4) eliminate_bad_genes_mt(v, pl, cnt, st_wt, f->pool, 16); else eliminate_bad_genes(v, pl, cnt, st_wt);
                             t2 = now();
                             cg[i].resize((size_t)v.n / 2 + 2);
                             cg[i].resize((size_t)extract_genes(v, pl, cnt, cg[i].data()));
                         }
                     }
                     t3 = now();
-                    tweak_final_starts(v, cg[i], st_wt, P.max_overlap, NC < 4 ? 16 : 1, &f->pool);
+                    tweak_final_starts(v, cg[i], st_wt, P.max_overlap, NC < 4 ? 32 : 1, &f->pool);
                     if (sub) {
                         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
                         fprintf(stderr, "[pga timing] host tail: untangle=%.2f eliminate=%.2f extract=%.2f tweak=%.2f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
