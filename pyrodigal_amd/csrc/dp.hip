@@ -1303,7 +1303,6 @@ k_seg_leaves(const ChainDesc* __restrict__ chains, const int32_t* __restrict__ b
 // A later round restarts at the first node the verification rejected: everything before it is already exact.
 #define PGA_SEG_HEIGHT 4
 #define PGA_RS_RING 4096
-#define PGA_RS_CHUNK 8          // batches loaded together: one memory round trip per 512 list entries
 
 __device__ __forceinline__ int64_t seg_tile(const ChainDesc& cd, const int chain, const int i) { return (cd.off >> 6) + chain + (i >> 6); }
 
@@ -1395,49 +1394,62 @@ k_dp_rescore(const ChainDesc* __restrict__ chains, const int32_t* __restrict__ b
         const int b0 = min(max(first_bad[chain], 0), cd.n) & ~63;
         p0 = b0 >= cd.n ? m : g_toff[seg_tile(cd, chain, b0)];
     }
-    int ixn[PGA_RS_CHUNK], tbn_[PGA_RS_CHUNK], ppn[PGA_RS_CHUNK]; double wn_[PGA_RS_CHUNK];
-    auto load_chunk = [&](const int c0) {
-#pragma unroll
-        for (int u = 0; u < PGA_RS_CHUNK; u++) {
-            const int e = c0 + 64 * u + lane;
-            const bool in = e < m;
-            ixn[u] = in ? lidx[e] : -1; tbn_[u] = in ? ltb[e] : -1; ppn[u] = in ? lpp[e] : -1; wn_[u] = in ? lw[e] : 0.0;
-        }
+    if (m <= 0) return;
+    struct Ent { int ix, tb, pp; double w; };
+    // branch-free (clamped index, then a select): with the loads under a lane mask the compiler waits for every load in
+    // flight at each join, which would serialise a memory round trip per batch
+    auto load = [&](const int ps) {
+        const int e = ps + lane;
+        const bool in = e < m;
+        const int ec = min(e, m - 1);
+        Ent r;
+        const int a = lidx[ec], b = ltb[ec], c = lpp[ec]; const double d = lw[ec];
+        r.ix = in ? a : -1; r.tb = in ? b : -1; r.pp = in ? c : -1; r.w = in ? d : 0.0;
+        return r;
     };
-    load_chunk(p0);
-    for (int c0 = p0; c0 < m; c0 += 64 * PGA_RS_CHUNK) {
-        int ix[PGA_RS_CHUNK], tbv[PGA_RS_CHUNK], ppv[PGA_RS_CHUNK]; double wv[PGA_RS_CHUNK];
+    Ent nx1 = load(p0), nx2 = load(p0 + 64);
+    for (int ps = p0; ps < m; ps += 64) {
+        const Ent cur = nx1;
+        nx1 = nx2; nx2 = load(ps + 128);                 // two batches ahead: in flight during this one
+        const int e = ps + lane;
+        const bool valid = e < m;
+        const int pp = cur.pp; const double w = cur.w;
+        // entries whose parent lies in an earlier batch (or that have none) are final at once
+        const bool inb = valid && pp >= ps;
+        const bool early = valid && pp >= 0 && pp < ps;
+        const bool near = pp >= p0 && e - pp <= PGA_RS_RING;
+        double sj = s_ring[pp & (PGA_RS_RING - 1)];
+        if (__any(early && !near))                        // far back, or left by the round before: rare
+            if (early && !near) sj = __hip_atomic_load(&score[cur.tb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double s = early ? sj + w : 0.0;
+        if (__any(inb)) {
+            // the others in list order.  The parent is nearly always the entry just before, so a running value r (the same
+            // in every lane) carries the chain: per entry one dependent addition and a select (r restarts at an entry that is
+            // final already); lane numbers are compile-time constants.  An entry whose parent is another lane of the batch
+            // (rare) fetches that lane's value.
+            const int code = inb ? pp - ps : -1;
+            const double term = inb ? w : s;
+            const unsigned long long restart = __ballot(!inb);
+            const unsigned long long other = __ballot(inb && code != lane - 1);
+            double r = 0.0;
 #pragma unroll
-        for (int u = 0; u < PGA_RS_CHUNK; u++) { ix[u] = ixn[u]; tbv[u] = tbn_[u]; ppv[u] = ppn[u]; wv[u] = wn_[u]; }
-        if (c0 + 64 * PGA_RS_CHUNK < m) load_chunk(c0 + 64 * PGA_RS_CHUNK);      // in flight during this chunk
-#pragma unroll
-        for (int u = 0; u < PGA_RS_CHUNK; u++) {
-            const int ps = c0 + 64 * u, e = ps + lane;
-            if (ps >= m) break;
-            const bool valid = e < m;
-            const int pp = ppv[u]; const double w = wv[u];
-            bool done = !valid || pp < 0;
-            double s = 0.0;
-            if (!done && pp < ps) {
-                double sj;
-                if (pp >= p0 && e - pp <= PGA_RS_RING) sj = s_ring[pp & (PGA_RS_RING - 1)];
-                else sj = __hip_atomic_load(&score[tbv[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // far back, or from the round before
-                s = sj + w; done = true;
+            for (int t = 0; t < 64; t++) {
+                const double x = readlane_f64(term, t);
+                if (__builtin_expect((int)((other >> t) & 1ull), 0)) {
+                    r = readlane_f64(s, __builtin_amdgcn_readlane(code, t)) + x;
+                } else {
+                    const double sum = r + x;
+                    r = ((restart >> t) & 1ull) ? x : sum;
+                }
+                if (lane == t) s = r;
             }
-            const int srcl = (pp - ps) & 63;
-            unsigned long long pend = __ballot(!done);
-            while (pend) {
-                const int t = __builtin_ctzll(pend);
-                pend &= pend - 1ull;
-                const int src = __builtin_amdgcn_readlane(srcl, t);
-                const double sj = readlane_f64(s, src);
-                if (lane == t) s = sj + w;
-            }
-            if (valid) { score[ix[u]] = s; s_ring[e & (PGA_RS_RING - 1)] = s; }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+        if (valid) { score[cur.ix] = s; s_ring[e & (PGA_RS_RING - 1)] = s; }
+        // the ring is read by other lanes of this wave in a later batch: LDS operations of a wave execute in order, so only
+        // the compiler has to keep them in place (a memory fence here would also wait for the loads in flight)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     }
 }
 

@@ -18,6 +18,7 @@
 #include <condition_variable>
 #include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -1160,7 +1161,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             tm.mark("gather+d2h+sync");
             // ---- host tail per contig ------------------------------------------------------------------
             std::vector<std::vector<GeneRec>> cg(NC);
-            std::vector<int32_t> pathbuf((size_t)out_nodes + 1);
+            std::unique_ptr<int32_t[]> pathbuf(new int32_t[(size_t)out_nodes + 1]);      // written before it is read: no zero fill
             std::atomic<int> next(0);
             auto worker = [&]() {
                 for (;;) {
@@ -1178,13 +1179,13 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                     auto now = [] { return std::chrono::steady_clock::now(); };
                     auto t0 = now(), t1 = t0, t2 = t0, t3 = t0;
                     if (v.n > 0 && mx >= 0) {
-                        int32_t* pl = pathbuf.data() + oo;
+                        int32_t* pl = pathbuf.get() + oo;
                         const int cnt = untangle(v, mx, pl);
                         t1 = now();
                         if (v.traceb[mx] != -1) {
                             if (NC < 4) eliminate_bad_genes_mt(v, pl, cnt, st_wt, f->pool, 16); else eliminate_bad_genes(v, pl, cnt, st_wt);
                             t2 = now();
-                            cg[i].resize((size_t)v.n / 2 + 2);
+                            cg[i].resize((size_t)cnt / 2 + 2);           // two path nodes per gene
                             cg[i].resize((size_t)extract_genes(v, pl, cnt, cg[i].data()));
                         }
                     }

@@ -505,7 +505,7 @@ __device__ __forceinline__ int hexamer(const uint8_t* __restrict__ d, int pos, i
 // values in the same order and keeps the prefix of its codon), and passes 2 / 3 -- which only need the
 // running maximum of the ORIGINAL values of the starts further out, exact in any order -- are wave scans.
 // A block first compacts its stop nodes into the leading lanes.
-constexpr int CS_MODELS = 8;
+constexpr int CS_MODELS = 4;
 constexpr int CS_LONG = 192;
 
 struct OrfCtx {
