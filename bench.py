@@ -142,7 +142,7 @@ def main():
 
 
 # every kernel of a segmented connection-scoring launch (pga_launch_dp with a plan), for the rocprof summaries
-SEGMENTED_DP_KERNELS = ["k_seg_records", "k_dp_tree_mw", "k_seg_gather", "k_seg_weights", "k_seg_height", "k_spine_count",
+SEGMENTED_DP_KERNELS = ["k_dp_tree_mw", "k_seg_gather", "k_seg_weights", "k_seg_height", "k_spine_count",
                         "k_spine_scan", "k_spine_fill", "k_dp_rescore", "k_seg_leaves", "k_seg_build_far", "k_seg_build_upper",
                         "k_dp_verify"]
 

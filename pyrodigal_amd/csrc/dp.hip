@@ -346,13 +346,15 @@ __device__ __forceinline__ void pair_eval(const int j, const Acc& S, const Targe
 // (the overlapping-start case adds a positive score): the exact pair is evaluated as well and wins.
 struct ChainPtrs {
     const DpSrc* __restrict__ src; const DpTgt* __restrict__ tgt;
+    int rebase;        // > 0: a segment's sub-chain that starts at this node of its chain (see load_target)
     double* score; int32_t* traceb; int32_t* tbn; int8_t* ovm;
     double* A; double* V0; double* V1; double* V2; double* hv; int32_t* hi;
 };
 
 __device__ __forceinline__ ChainPtrs chain_ptrs(const ChainDesc& cd, const DpSrc* g_src, const DpTgt* g_tgt, const DpBuffers& buf) {
     ChainPtrs P;
-    P.src = g_src + cd.off; P.tgt = g_tgt + cd.off;
+    const int64_t rec = cd.rec_off >= 0 ? cd.rec_off : cd.off;
+    P.src = g_src + rec; P.tgt = g_tgt + rec; P.rebase = cd.rebase;
     P.score = buf.score + cd.off; P.traceb = buf.traceb + cd.off; P.tbn = buf.tbn + cd.off; P.ovm = buf.ov_mark + cd.off;
     P.A = buf.A + cd.off; P.V0 = buf.V[0] + cd.off; P.V1 = buf.V[1] + cd.off; P.V2 = buf.V[2] + cd.off;
     P.hv = buf.hv + cd.off; P.hi = buf.hi + cd.off;
@@ -369,10 +371,24 @@ __device__ __forceinline__ void load_target(Target& T, const ChainPtrs& P, int i
     T.x0 = me.x[0]; T.x1 = me.x[1]; T.x2 = me.x[2];
     T.n3n0 = mt.n3ndx[0]; T.n3n1 = mt.n3ndx[1]; T.n3n2 = mt.n3ndx[2];
     T.n3s0 = mt.n3stop[0]; T.n3s1 = mt.n3stop[1]; T.n3s2 = mt.n3stop[2];
-    T.lo = act ? mt.lo : INT_MAX; T.p_near = mt.p_near;
+    T.lo = mt.lo; T.p_near = mt.p_near;
     T.a0 = mt.a[0]; T.a1 = mt.a[1]; T.a2 = mt.a[2]; T.b0 = mt.b[0]; T.b1 = mt.b[1]; T.b2 = mt.b[2];
     T.c0 = mt.c[0]; T.c1 = mt.c[1]; T.c2 = mt.c[2];
-    if (!act) T.i = -1;          // j < T.i is never true: the lane stays idle
+    if (P.rebase > 0) {
+        // chain indices -> sub-chain indices; what lies before the sub-chain does not exist for it: a range starts at 0 at
+        // the earliest, a single node that lies before it becomes "none"
+        const int a = P.rebase;
+        auto rb = [a](const int v) { return v > a ? v - a : 0; };
+        auto one = [a](const int v) { return v >= a ? v - a : -1; };
+        T.lo = rb(T.lo); T.p_near = rb(T.p_near);
+        if (T.kind == 1) T.a0 = rb(T.a0);
+        else if (T.kind == 2) { T.a0 = one(T.a0); T.a1 = rb(T.a1); T.a2 = rb(T.a2); }
+        else if (T.kind == 3) {
+            T.a0 = rb(T.a0); T.a1 = rb(T.a1); T.a2 = rb(T.a2); T.b0 = rb(T.b0); T.b1 = rb(T.b1); T.b2 = rb(T.b2);
+            T.c0 = one(T.c0); T.c1 = one(T.c1); T.c2 = one(T.c2);
+        }
+    }
+    if (!act) { T.lo = INT_MAX; T.i = -1; }          // j < T.i is never true: the lane stays idle
 }
 
 // A and its block-of-8 maxima for the most recent PGA_RING nodes of a chain, kept in LDS by the wave that
@@ -1193,30 +1209,6 @@ k_dp_chain(const ChainDesc* __restrict__ chains, const DpSrc* __restrict__ g_src
 // serially.  Nothing here is approximate: a result is only ever published after a verification that found no
 // mismatch, or by the serial kernel.
 __global__ void __launch_bounds__(256)
-k_seg_records(const DpSeg* __restrict__ segs, const ChainDesc* __restrict__ chains, DpSrc* src, DpTgt* tgt) {
-    const DpSeg sd = segs[blockIdx.y];
-    const int li = blockIdx.x * blockDim.x + threadIdx.x;
-    if (li >= sd.e - sd.a) return;
-    const int64_t g = chains[sd.chain].off + sd.a + li, d = sd.off + li;
-    const DpSrc r = src[g];
-    DpTgt t = tgt[g];
-    const int a = sd.a;
-    if (a > 0) {
-        // chain indices -> sub-chain indices; what lies before the sub-chain does not exist for it
-        const int kind = PGA_KIND(r.meta);
-        auto rb = [a](const int v) { return v > a ? v - a : 0; };
-        auto one = [a](const int v) { return v >= a ? v - a : -1; };
-        t.lo = rb(t.lo); t.p_near = rb(t.p_near);
-        if (kind == 1) t.a[0] = rb(t.a[0]);
-        else if (kind == 2) { t.a[0] = one(t.a[0]); t.a[1] = rb(t.a[1]); t.a[2] = rb(t.a[2]); }
-        else if (kind == 3) {
-            for (int k = 0; k < 3; k++) { t.a[k] = rb(t.a[k]); t.b[k] = rb(t.b[k]); t.c[k] = one(t.c[k]); }
-        }
-    }
-    src[d] = r; tgt[d] = t;
-}
-
-__global__ void __launch_bounds__(256)
 k_seg_gather(const DpSeg* __restrict__ segs, const ChainDesc* __restrict__ chains, const int32_t* __restrict__ traceb, int32_t* __restrict__ ctb) {
     const DpSeg sd = segs[blockIdx.y];
     const int li = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1652,7 +1644,7 @@ bool pga_dp_plan(const ChainDesc* h, int n_chains, int64_t tot_nodes, DpSegPlan&
             plan.max_seg_nodes = std::max(plan.max_seg_nodes, sd.e - sd.a);
             plan.max_seg_len = std::max(plan.max_seg_len, sd.e - sd.s);
             ChainDesc sc = h[c];
-            sc.off = sd.off; sc.n = sd.e - sd.a;
+            sc.off = sd.off; sc.n = sd.e - sd.a; sc.rec_off = h[c].off + sd.a; sc.rebase = sd.a;
             plan.p1_chains.push_back(sc);
             plan.p1_slot.push_back(n_chains + (int32_t)plan.segs.size());
             plan.segs.push_back(sd);
@@ -1715,7 +1707,6 @@ static void launch_dp_segmented(const ChainDesc* d_chains, int n_chains, const M
     auto blocks = [](int n) { return (unsigned)((n + 255) / 256); };
     hipMemsetAsync(sg.flags, 0, sizeof(int32_t) * PGA_SEG_ROUNDS * (size_t)n_chains, st);
     hipMemsetAsync(sg.first_bad, 0x7f, sizeof(int32_t) * PGA_SEG_ROUNDS * (size_t)n_chains, st);
-    hipLaunchKernelGGL(k_seg_records, dim3(blocks(sg.max_seg_nodes), sg.n_segs), blk, 0, st, sg.segs, d_chains, buf.src, buf.tgt);
     hipLaunchKernelGGL(k_dp_tree_mw, dim3(sg.n_p1), dim3(64 * PGA_MW_WAVES), 0, st, sg.p1_chains, buf.src, buf.tgt, d_models, buf,
                        (const int32_t*)nullptr, sg.p1_slot);
     hipLaunchKernelGGL(k_seg_gather, dim3(blocks(sg.max_seg_len), sg.n_segs), blk, 0, st, sg.segs, d_chains, buf.traceb, sg.ctb);

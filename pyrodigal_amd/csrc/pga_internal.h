@@ -57,6 +57,11 @@ struct ChainDesc {
     int32_t contig;
     int32_t first;      // 1: first model scored after (re-)extraction (edge flags not yet converted;
                         //    ref: lib.pyx:2424-2434 mutates node.edge, which persists to the next bin)
+    // connection scoring of a SEGMENT of a chain (dp.hip "segmented chains"): the sub-chain reads the records of the
+    // chain it belongs to, from node `rebase` on, and keeps its own results at `off`
+    int64_t rec_off = -1;   // first DpSrc / DpTgt record of the sub-chain; -1: the chain's own, at `off`
+    int32_t rebase = 0;     // chain index of the sub-chain's node 0: index fields of DpTgt are shifted down by it
+    int32_t _pad = 0;
 };
 
 // Node fields in device memory (struct of arrays; each pointer covers the whole batch).
