@@ -496,11 +496,83 @@ k_tail_tweak(const TailDesc* __restrict__ td, int n_contigs, int64_t n_slots, Ou
     changed[slot] = moved ? 1 : 0;
     if (moved) atomicAdd(&n_changed[c], 1);
 }
+// tweak_one with the wavefront on ONE gene: the 200 candidate nodes are filtered and priced by the lanes (that is where the
+// memory traffic is), the few that pass are then merged one after the other in index order, as the reference's loop
+// meets them -- its two-best bookkeeping depends on that order.  Every lane returns the same record.
+__device__ void tweak_one_wave(const NodeView& v, const GeneRec* prev, GeneRec& cur, const GeneRec* next, double w, int maxov, const int lane) {
+    const int nn = v.n;
+    const int ndx = cur.start_ndx;
+    const double sc = v.sscore[ndx] + v.cscore[ndx];
+    double ig = 0.0;
+    const bool prev_fwd = prev && v.strand[prev->start_ndx] == 1, prev_rev = prev && v.strand[prev->start_ndx] == -1;
+    const bool next_fwd = next && v.strand[next->start_ndx] == 1, next_rev = next && v.strand[next->start_ndx] == -1;
+    if (v.strand[ndx] == 1 && prev_fwd) ig = igm_same_h(v, prev->stop_ndx, ndx, w);
+    if (v.strand[ndx] == 1 && prev_rev) ig = -0.15 * w;
+    if (v.strand[ndx] == -1 && next_fwd) ig = -0.15 * w;
+    if (v.strand[ndx] == -1 && next_rev) ig = igm_same_h(v, ndx, next->stop_ndx, w);
+    int mi[2] = {-1, -1}; double ms[2] = {0, 0}, mg[2] = {0, 0};
+    const int sv_ndx = v.stop_val[ndx];
+    for (int base = ndx - 100; base < ndx + 100; base += 64) {
+        const int j = base + lane;
+        bool cand = j >= 0 && j < nn && j != ndx && j < ndx + 100;
+        double tg = 0.0, cs = 0.0;
+        if (cand) cand = !(is_stop_n(v, j) | (v.stop_val[j] != sv_ndx));
+        if (cand) {
+            const int sj = v.strand[j];
+            if (sj == 1 && prev_fwd) {
+                if (v.ndx[prev->stop_ndx] - v.ndx[j] > maxov) cand = false;
+                else tg = igm_same_h(v, prev->stop_ndx, j, w);
+            }
+            if (cand && sj == 1 && prev_rev) { if (v.ndx[prev->start_ndx] - v.ndx[j] >= 0) cand = false; else tg = -0.15 * w; }
+            if (cand && sj == -1 && next_fwd) { if (v.ndx[j] - v.ndx[next->start_ndx] >= 0) cand = false; else tg = -0.15 * w; }
+            if (cand && sj == -1 && next_rev) {
+                if (v.ndx[j] - v.ndx[next->stop_ndx] > maxov) cand = false;
+                else tg = igm_same_h(v, j, next->stop_ndx, w);
+            }
+            if (cand) cs = v.cscore[j] + v.sscore[j];
+        }
+        unsigned long long m = __ballot(cand);
+        while (m) {
+            const int k = __builtin_ctzll(m);
+            m &= m - 1ull;
+            const int jk = base + k;
+            const double csk = __shfl(cs, k, 64), tgk = __shfl(tg, k, 64);
+            if (mi[0] == -1) { mi[0] = jk; ms[0] = csk; mg[0] = tgk; }
+            else if (csk + tgk > ms[0]) { mi[1] = mi[0]; ms[1] = ms[0]; mg[1] = mg[0]; mi[0] = jk; ms[0] = csk; mg[0] = tgk; }
+            else if (mi[1] == -1 || csk + tgk > ms[1]) { mi[1] = jk; ms[1] = csk; mg[1] = tgk; }
+        }
+    }
+    for (int k = 0; k < 2; k++) {
+        const int m = mi[k];
+        if (m == -1) continue;
+        if (v.tscore[m] < v.tscore[ndx] && ms[k] - v.tscore[m] >= sc - v.tscore[ndx] + w && v.rscore[m] > v.rscore[ndx] &&
+            v.uscore[m] > v.uscore[ndx] && v.cscore[m] > v.cscore[ndx] && abs(v.ndx[m] - v.ndx[ndx]) > 15) {
+            ms[k] += v.tscore[ndx] - v.tscore[m];
+        } else if (abs(v.ndx[m] - v.ndx[ndx]) <= 15 && v.rscore[m] + v.tscore[m] > v.rscore[ndx] + v.tscore[ndx] &&
+                   v.edge[ndx] == 0 && v.edge[m] == 0) {
+            if (v.cscore[ndx] > v.cscore[m]) ms[k] += v.cscore[ndx] - v.cscore[m];
+            if (v.uscore[ndx] > v.uscore[m]) ms[k] += v.uscore[ndx] - v.uscore[m];
+            if (ig > mg[k]) ms[k] += ig - mg[k];
+        } else ms[k] = -1000.0;
+    }
+    int pick = -1;
+    for (int k = 0; k < 2; k++) {
+        if (mi[k] == -1) continue;
+        if (pick == -1 && ms[k] + mg[k] > sc + ig) pick = k;
+        else if (pick >= 0 && ms[k] + mg[k] > ms[pick] + mg[pick]) pick = k;
+    }
+    if (pick != -1 && v.strand[mi[pick]] == 1) { cur.start_ndx = mi[pick]; cur.begin = v.ndx[mi[pick]] + 1; }
+    else if (pick != -1 && v.strand[mi[pick]] == -1) { cur.start_ndx = mi[pick]; cur.end = v.ndx[mi[pick]] + 1; }
+}
+
+// One wavefront per contig, in gene order, 64 genes at a time: a window in which no predecessor moved is skipped with one
+// coalesced load; a gene whose predecessor did move is redone by one lane, and what that does to the next gene's flag is
+// taken into account before going on (the reference's in-order semantics, ref: lib.pyx:3272-3401).
 __global__ void __launch_bounds__(64)
 k_tail_tweak_fixup(const TailDesc* __restrict__ td, int n_contigs, OutArrays o, int32_t* tracef, uint8_t* elim,
                    const GeneRec* __restrict__ orig, GeneRec* __restrict__ out, const int32_t* __restrict__ n_genes, int maxov,
                    uint8_t* __restrict__ changed, const int32_t* __restrict__ n_changed) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x, lane = threadIdx.x;
     if (c >= n_contigs) return;
     if (n_changed[c] == 0) return;
     const TailDesc d = td[c];
@@ -509,13 +581,32 @@ k_tail_tweak_fixup(const TailDesc* __restrict__ td, int n_contigs, OutArrays o, 
     const GeneRec* ob = orig + d.gene_off;
     GeneRec* nb = out + d.gene_off;
     uint8_t* ch = changed + d.gene_off;
-    for (int g = 1; g < ng; g++) {
-        if (!ch[g - 1]) continue;                                        // predecessor's start did not move: the parallel result stands
-        GeneRec cur = ob[g];
-        const GeneRec prev = nb[g - 1];
-        tweak_one(v, &prev, cur, g < ng - 1 ? &ob[g + 1] : nullptr, d.st_wt, maxov);
-        nb[g] = cur;
-        ch[g] = cur.start_ndx != ob[g].start_ndx && v.strand[cur.start_ndx] == -1;
+    int carry = 0;                                     // flag of the gene just before the window, as left by the window before
+    for (int g0 = 1; g0 < ng; g0 += 64) {
+        const int g = g0 + lane;
+        // predecessor's flag: from the parallel pass, except for the window's first gene (the previous window may have redone it)
+        int pf = g < ng ? ch[g - 1] : 0;
+        if (lane == 0 && g0 > 1) pf = carry;
+        unsigned long long mask = __ballot(pf != 0);
+        int last = g0 + 63 < ng ? ch[g0 + 63] : 0;     // flag of the window's last gene: the next window's first predecessor
+        while (mask) {
+            const int k = __builtin_ctzll(mask);
+            mask &= mask - 1ull;
+            const int gg = g0 + k;
+            GeneRec cur = ob[gg];
+            const GeneRec prev = nb[gg - 1];
+            GeneRec nxt{};
+            if (gg < ng - 1) nxt = ob[gg + 1];
+            tweak_one_wave(v, &prev, cur, gg < ng - 1 ? &nxt : nullptr, d.st_wt, maxov, lane);
+            const int nf = cur.start_ndx != ob[gg].start_ndx && v.strand[cur.start_ndx] == -1;
+            if (lane == 0) { nb[gg] = cur; ch[gg] = (uint8_t)nf; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the record is read back (nb[gg]) by all lanes if gg + 1 is redone
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // the next gene's predecessor flag is this gene's new flag
+            if (k + 1 < 64) { if (nf) mask |= 1ull << (k + 1); else mask &= ~(1ull << (k + 1)); }
+            if (k == 63) last = nf;
+        }
+        carry = last;
     }
 }
 
@@ -547,6 +638,8 @@ k_emit_genes(const TailDesc* __restrict__ td, int n_contigs, int64_t n_slots, Ou
     G.tscore = single ? o.tscore_dp[sn] : o.tscore[sn];
     out[gene_begin[c] + g] = G;
 }
+
+#include "tail.inl"
 
 __global__ void k_contig_node_base(const ContigDesc* __restrict__ ct, int n_contigs, int64_t total, const int32_t* __restrict__ pre_nodes,
                                    int32_t* __restrict__ out) {
@@ -1145,7 +1238,10 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         // and host threads walk them.
         int max_n = 0;
         for (int i = 0; i < NC; i++) if (win_chain[i] >= 0) max_n = std::max(max_n, chains[win_chain[i]].n);
-        const bool device_tail = getenv("PGA_TAIL") ? strcmp(getenv("PGA_TAIL"), "device") == 0 : (NC >= 64 && max_n <= 16384);
+        // PGA_TAIL = host | device (one thread per contig) | par (tail.inl, the default)
+        const char* tail_env = getenv("PGA_TAIL");
+        const bool device_tail = tail_env ? strcmp(tail_env, "host") != 0 : true;
+        const bool par_tail = device_tail && !(tail_env && strcmp(tail_env, "device") == 0);
         std::vector<int32_t> tracef;
         std::vector<uint8_t> elim;
         if (!device_tail) {
@@ -1294,10 +1390,45 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             DEVBUF(d_changed, uint8_t, "d_changed", n_slots + 1);
             DEVBUF(d_nchanged, int32_t, "d_nchanged", NC + 1);
             HT(c, hipMemsetAsync(d_nchanged, 0, sizeof(int32_t) * ((size_t)NC + 1), st));
-            hipLaunchKernelGGL(k_tail_path, dim3((NC + 63) / 64), dim3(64), 0, st, d_td, NC, o, d_tracef, d_elim, d_path, d_gene0, d_ngenes);
+            if (!par_tail) {
+                hipLaunchKernelGGL(k_tail_path, dim3((NC + 63) / 64), dim3(64), 0, st, d_td, NC, o, d_tracef, d_elim, d_path, d_gene0, d_ngenes);
+            } else {
+                HT(c, hipMemsetAsync(d_ngenes, 0, sizeof(int32_t) * ((size_t)NC + 1), st));
+                std::vector<TpSeg> segs;
+                for (int i = 0; i < NC; i++) if (win_chain[i] >= 0 && chains[win_chain[i]].n > 0) segs.push_back(TpSeg{out_off[i], chains[win_chain[i]].n, i});
+                std::sort(segs.begin(), segs.end(), [](const TpSeg& a, const TpSeg& b) { return a.off < b.off; });
+                if (!segs.empty() && out_nodes > 0) {
+                    if (out_nodes >= (1ll << 30)) { c->err = "pga_find_genes: more than 2^30 nodes in the winning chains of one batch"; return PGA_EINVAL; }
+                    int levels = 1;
+                    while ((1ll << levels) < max_n) levels++;
+                    const unsigned nblk = (unsigned)((out_nodes + 255) / 256);
+                    DEVBUF(tp_seg, TpSeg, "tp_seg", segs.size()) DEVBUF(tp_up, int32_t, "tp_up", (size_t)levels * out_nodes)
+                    DEVBUF(tp_mark, uint8_t, "tp_mark", out_nodes) DEVBUF(tp_slots, int32_t, "tp_slots", out_nodes)
+                    DEVBUF(tp_ins, int32_t, "tp_ins", 2 * out_nodes) DEVBUF(tp_excl, int32_t, "tp_excl", out_nodes + 1)
+                    DEVBUF(tp_bsum, int32_t, "tp_bsum", nblk + 1) DEVBUF(tp_cnt, int32_t, "tp_cnt", segs.size())
+                    HT(c, hipMemcpyAsync(tp_seg, segs.data(), sizeof(TpSeg) * segs.size(), hipMemcpyHostToDevice, st));
+                    HT(c, hipMemsetAsync(tp_cnt, 0, sizeof(int32_t) * segs.size(), st));
+                    const TpWork tw{tp_seg, (int)segs.size(), out_nodes, levels, tp_up, tp_mark, tp_slots, tp_ins, tp_excl, tp_bsum, tp_cnt};
+                    const dim3 grid(nblk), blk(256);
+                    hipLaunchKernelGGL(k_tp_init, grid, blk, 0, st, tw, d_td, o);
+                    for (int k = 0; k + 1 < levels; k++) hipLaunchKernelGGL(k_tp_level, grid, blk, 0, st, tw, k);
+                    for (int k = levels - 1; k >= 0; k--) hipLaunchKernelGGL(k_tp_mark, grid, blk, 0, st, tw, k);
+                    hipLaunchKernelGGL(k_tp_slots, grid, blk, 0, st, tw, d_td, o);
+                    hipLaunchKernelGGL(k_tp_scan1, grid, blk, 0, st, tw);
+                    hipLaunchKernelGGL(k_tp_scan2, dim3(1), dim3(1024), 0, st, tw, (int)nblk);
+                    hipLaunchKernelGGL(k_tp_scan3, grid, blk, 0, st, tw);
+                    hipLaunchKernelGGL(k_tp_fill, grid, blk, 0, st, tw, o, d_path);
+                    hipLaunchKernelGGL(k_tp_link, grid, blk, 0, st, tw, o, d_path, d_tracef);
+                    hipLaunchKernelGGL(k_tp_elim_a, grid, blk, 0, st, tw, d_td, o, d_path);
+                    hipLaunchKernelGGL(k_tp_elim_b, grid, blk, 0, st, tw, d_td, o, d_path, d_elim);
+                    // a workgroup per contig: wide for genomes, narrow when there are many short paths
+                    hipLaunchKernelGGL(k_tp_extract, dim3((unsigned)segs.size()), dim3(max_n >= 32768 ? 1024 : 256), 0, st, tw, d_td, o, d_path, d_elim,
+                                       d_gene0, d_ngenes);
+                }
+            }
             hipLaunchKernelGGL(k_tail_tweak, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, st, d_td, NC, n_slots, o, d_tracef, d_elim,
                                d_gene0, d_gene1, d_ngenes, P.max_overlap, d_changed, d_nchanged);
-            hipLaunchKernelGGL(k_tail_tweak_fixup, dim3((NC + 63) / 64), dim3(64), 0, st, d_td, NC, o, d_tracef, d_elim, d_gene0, d_gene1, d_ngenes,
+            hipLaunchKernelGGL(k_tail_tweak_fixup, dim3(NC), dim3(64), 0, st, d_td, NC, o, d_tracef, d_elim, d_gene0, d_gene1, d_ngenes,
                                P.max_overlap, d_changed, d_nchanged);
             HT(c, hipMemcpyAsync(h_ngenes, d_ngenes, sizeof(int32_t) * NC, hipMemcpyDeviceToHost, st));
             HT(c, hipGetLastError());
