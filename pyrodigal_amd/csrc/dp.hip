@@ -1373,6 +1373,8 @@ k_dp_rescore(const ChainDesc* __restrict__ chains, const int32_t* __restrict__ b
              const int32_t* __restrict__ sp_idx, const int32_t* __restrict__ sp_tb, const int32_t* __restrict__ sp_pp,
              const double* __restrict__ sp_w) {
     __shared__ double s_ring[PGA_RS_RING];
+    __shared__ double s_out[64], s_term[64];
+    __shared__ int s_code[64];
     const int chain = big[blockIdx.x];
     if (gate != nullptr && gate[chain] == 0) return;
     const ChainDesc cd = chains[chain];
@@ -1415,26 +1417,36 @@ k_dp_rescore(const ChainDesc* __restrict__ chains, const int32_t* __restrict__ b
             if (early && !near) sj = __hip_atomic_load(&score[cur.tb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         double s = early ? sj + w : 0.0;
         if (__any(inb)) {
-            // the others in list order.  The parent is nearly always the entry just before, so a running value r (the same
-            // in every lane) carries the chain: per entry one dependent addition and a select (r restarts at an entry that is
-            // final already); lane numbers are compile-time constants.  An entry whose parent is another lane of the batch
-            // (rare) fetches that lane's value.
+            // the others in list order, by ONE lane (a lone wavefront issues an instruction every four cycles whatever
+            // its width, so what counts is the instruction count per entry: here a scalar test, the addition, and half an LDS
+            // read and write).  The parent is nearly always the entry just before: r carries the chain.  `special` entries --
+            // final already (the chain restarts from their value), or with another lane of the batch as parent -- take the
+            // rare branch.  Every r is left in LDS, where each lane picks its own afterwards.
             const int code = inb ? pp - ps : -1;
-            const double term = inb ? w : s;
-            const unsigned long long restart = __ballot(!inb);
-            const unsigned long long other = __ballot(inb && code != lane - 1);
-            double r = 0.0;
+            const unsigned long long special = __ballot(!inb || code != lane - 1);
+            s_term[lane] = inb ? w : s; s_code[lane] = code;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+            if (lane == 0) {
+                double xs[64];                      // all terms first: the chain then never waits for LDS
 #pragma unroll
-            for (int t = 0; t < 64; t++) {
-                const double x = readlane_f64(term, t);
-                if (__builtin_expect((int)((other >> t) & 1ull), 0)) {
-                    r = readlane_f64(s, __builtin_amdgcn_readlane(code, t)) + x;
-                } else {
-                    const double sum = r + x;
-                    r = ((restart >> t) & 1ull) ? x : sum;
+                for (int t = 0; t < 64; t++) xs[t] = s_term[t];
+                double r = 0.0;
+#pragma unroll
+                for (int t = 0; t < 64; t++) {
+                    const double x = xs[t];
+                    if (__builtin_expect((int)((special >> t) & 1ull), 0)) {
+                        const int c = s_code[t];
+                        r = c < 0 ? x : s_out[c] + x;
+                    } else r = r + x;
+                    s_out[t] = r;
                 }
-                if (lane == t) s = r;
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+            s = s_out[lane];
         }
         if (valid) { score[cur.ix] = s; s_ring[e & (PGA_RS_RING - 1)] = s; }
         // the ring is read by other lanes of this wave in a later batch: LDS operations of a wave execute in order, so only
