@@ -1574,7 +1574,7 @@ k_seg_build_upper(const ChainDesc* __restrict__ chains, const int32_t* __restric
 __global__ void __launch_bounds__(256)
 k_dp_verify(const ChainDesc* __restrict__ chains, const int32_t* __restrict__ big, const int32_t* __restrict__ gate,
             const DpSrc* __restrict__ g_src, const DpTgt* __restrict__ g_tgt, const ModelConst* __restrict__ models, DpBuffers buf,
-            int32_t* __restrict__ g_ctb, int32_t* __restrict__ flags, int32_t* __restrict__ first_bad) {
+            int32_t* __restrict__ g_ctb, int32_t* __restrict__ flags, int32_t* __restrict__ first_bad, const int32_t* __restrict__ from) {
     __shared__ double s_igm[64];
     __shared__ int s_levbase[12];
     const int chain = big[blockIdx.y];
@@ -1588,6 +1588,8 @@ k_dp_verify(const ChainDesc* __restrict__ chains, const int32_t* __restrict__ bi
     __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    // a later round: everything before the first node the round before rejected was verified then and has not changed
+    if (from != nullptr && i < (from[chain] & ~63)) return;
     const double negc = mc->negc;
     const ChainPtrs P = chain_ptrs(cd, g_src, g_tgt, buf);
     Target T;
@@ -1741,7 +1743,7 @@ static void launch_dp_segmented(const ChainDesc* d_chains, int n_chains, const M
         hipLaunchKernelGGL(k_seg_build_far, per_node, blk, 0, st, d_chains, sg.big, gate, buf.src, buf.tgt, d_models, buf, sg.tv, sg.ti);
         hipLaunchKernelGGL(k_seg_build_upper, dim3(sg.n_big), blk, 0, st, d_chains, sg.big, gate, buf.src, buf.tgt, buf, sg.tv, sg.ti);
         hipLaunchKernelGGL(k_dp_verify, per_node, blk, 0, st, d_chains, sg.big, gate, buf.src, buf.tgt, d_models, buf, sg.ctb,
-                           sg.flags + (size_t)r * n_chains, sg.first_bad + (size_t)r * n_chains);
+                           sg.flags + (size_t)r * n_chains, sg.first_bad + (size_t)r * n_chains, from);
     }
     // chains that never verified clean: the serial walk
     hipLaunchKernelGGL(k_dp_tree_mw, dim3(n_chains), dim3(64 * PGA_MW_WAVES), 0, st, d_chains, buf.src, buf.tgt, d_models, buf,

@@ -568,10 +568,12 @@ __device__ void tweak_one_wave(const NodeView& v, const GeneRec* prev, GeneRec& 
 // One wavefront per contig, in gene order, 64 genes at a time: a window in which no predecessor moved is skipped with one
 // coalesced load; a gene whose predecessor did move is redone by one lane, and what that does to the next gene's flag is
 // taken into account before going on (the reference's in-order semantics, ref: lib.pyx:3272-3401).
+#define PGA_FIX_CHUNK 16384      // flags staged in LDS at a time
 __global__ void __launch_bounds__(64)
 k_tail_tweak_fixup(const TailDesc* __restrict__ td, int n_contigs, OutArrays o, int32_t* tracef, uint8_t* elim,
                    const GeneRec* __restrict__ orig, GeneRec* __restrict__ out, const int32_t* __restrict__ n_genes, int maxov,
                    uint8_t* __restrict__ changed, const int32_t* __restrict__ n_changed) {
+    __shared__ uint8_t s_ch[PGA_FIX_CHUNK];
     const int c = blockIdx.x, lane = threadIdx.x;
     if (c >= n_contigs) return;
     if (n_changed[c] == 0) return;
@@ -581,32 +583,42 @@ k_tail_tweak_fixup(const TailDesc* __restrict__ td, int n_contigs, OutArrays o, 
     const GeneRec* ob = orig + d.gene_off;
     GeneRec* nb = out + d.gene_off;
     uint8_t* ch = changed + d.gene_off;
-    int carry = 0;                                     // flag of the gene just before the window, as left by the window before
-    for (int g0 = 1; g0 < ng; g0 += 64) {
-        const int g = g0 + lane;
-        // predecessor's flag: from the parallel pass, except for the window's first gene (the previous window may have redone it)
-        int pf = g < ng ? ch[g - 1] : 0;
-        if (lane == 0 && g0 > 1) pf = carry;
-        unsigned long long mask = __ballot(pf != 0);
-        int last = g0 + 63 < ng ? ch[g0 + 63] : 0;     // flag of the window's last gene: the next window's first predecessor
-        while (mask) {
-            const int k = __builtin_ctzll(mask);
-            mask &= mask - 1ull;
-            const int gg = g0 + k;
-            GeneRec cur = ob[gg];
-            const GeneRec prev = nb[gg - 1];
-            GeneRec nxt{};
-            if (gg < ng - 1) nxt = ob[gg + 1];
-            tweak_one_wave(v, &prev, cur, gg < ng - 1 ? &nxt : nullptr, d.st_wt, maxov, lane);
-            const int nf = cur.start_ndx != ob[gg].start_ndx && v.strand[cur.start_ndx] == -1;
-            if (lane == 0) { nb[gg] = cur; ch[gg] = (uint8_t)nf; }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the record is read back (nb[gg]) by all lanes if gg + 1 is redone
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            // the next gene's predecessor flag is this gene's new flag
-            if (k + 1 < 64) { if (nf) mask |= 1ull << (k + 1); else mask &= ~(1ull << (k + 1)); }
-            if (k == 63) last = nf;
+    auto lds_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    };
+    int carry = 0;                                     // final flag of the last gene of the chunk before
+    for (int b0 = 0; b0 < ng; b0 += PGA_FIX_CHUNK) {
+        // the flags of the chunk's genes, as the parallel pass left them, into LDS: a window in which no predecessor moved
+        // then costs a few LDS instructions; a redo updates its flag there too
+        const int hi = min(ng, b0 + PGA_FIX_CHUNK);
+        for (int k = lane; k < hi - b0; k += 64) s_ch[k] = ch[b0 + k];
+        lds_sync();
+        for (int g0 = max(b0, 1); g0 < hi; g0 += 64) {
+            const int g = g0 + lane;
+            const int pf = g < hi ? (g - 1 >= b0 ? s_ch[g - 1 - b0] : carry) : 0;
+            unsigned long long mask = __ballot(pf != 0);
+            while (mask) {
+                const int k = __builtin_ctzll(mask);
+                mask &= mask - 1ull;
+                const int gg = g0 + k;
+                GeneRec cur = ob[gg];
+                const GeneRec prev = nb[gg - 1];
+                GeneRec nxt{};
+                if (gg < ng - 1) nxt = ob[gg + 1];
+                tweak_one_wave(v, &prev, cur, gg < ng - 1 ? &nxt : nullptr, d.st_wt, maxov, lane);
+                const int nf = cur.start_ndx != ob[gg].start_ndx && v.strand[cur.start_ndx] == -1;
+                if (lane == 0) { nb[gg] = cur; ch[gg] = (uint8_t)nf; s_ch[gg - b0] = (uint8_t)nf; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the record is read back (nb[gg]) by all lanes if gg + 1 is redone
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                // the next gene's predecessor flag is this gene's new flag
+                if (k + 1 < 64 && gg + 1 < hi) { if (nf) mask |= 1ull << (k + 1); else mask &= ~(1ull << (k + 1)); }
+            }
+            lds_sync();
         }
-        carry = last;
+        carry = s_ch[hi - 1 - b0];
+        lds_sync();
     }
 }
 
