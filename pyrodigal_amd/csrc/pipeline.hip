@@ -546,42 +546,78 @@ __device__ __forceinline__ void orf_serial(const OrfCtx& o, const ChainDesc* __r
 #pragma unroll
         for (int m = 0; m < CS_MODELS; m++) sum[m] = 0.0;
         int far = -1, mer = 0;
-        for (int ci = 0; ci < o.ncod; ci++) {
-            const int j = p + step * (ci + 1);
-            if (ci == 0) mer = hexamer(d, j, strand);
-            else {      // rolling update: the three bases nearest to the walk direction are new (ref: _sequence.h:207-220)
-                int lo3;
-                if (strand == 1) lo3 = (d[j] & 3) | ((d[j + 1] & 3) << 2) | ((d[j + 2] & 3) << 4);
-                else lo3 = (comp2(d[j]) & 3) | ((comp2(d[j - 1]) & 3) << 2) | ((comp2(d[j - 2]) & 3) << 4);
-                mer = ((mer << 6) & 0xfc0) | lo3;
-            }
+        unsigned long long sm0 = 0, sm1 = 0, sm2 = 0;           // codons that are start nodes (ncod <= CS_LONG = 192)
+        auto visit = [&](const int ci, const int j, const bool isnode) {
 #pragma unroll
             for (int m = 0; m < CS_MODELS; m++) sum[m] += gdc[m][mer];
-            if (o.nf[j]) {
+            if (isnode) {
                 const int k = o.pre[j] + (strand == 1 ? 0 : o.nf_f[j]) - o.tbase;
 #pragma unroll
                 for (int m = 0; m < CS_MODELS; m++) if (m < nm) csp[m][k] = sum[m];
                 far = ci;
+                if (ci < 64) sm0 |= 1ull << ci; else if (ci < 128) sm1 |= 1ull << (ci - 64); else sm2 |= 1ull << (ci - 128);
+            }
+        };
+        if (o.ncod > 0) { const int j = p + step; mer = hexamer(d, j, strand); visit(0, j, o.nf[j] != 0); }
+        // Five codons at a time: their 15 bases and the start flags of those positions are 16 contiguous bytes each, one
+        // (unaligned) load per array instead of four byte loads per codon -- every lane walks its own ORF, so each load
+        // instruction costs the address path 64 distinct lines whatever its width.
+        for (int c0 = 1; c0 < o.ncod; c0 += 5) {
+            const int lo = strand == 1 ? p - 3 * (c0 + 5) : p + 3 * c0 + 1;         // lowest position of the group
+            if (lo < 0) {
+                // the group hangs over the contig's first base (only codons beyond the ORF do): byte loads
+                for (int ci = c0; ci < min(c0 + 5, o.ncod); ci++) {
+                    const int j = p + step * (ci + 1);
+                    const int lo3 = (d[j] & 3) | ((d[j + 1] & 3) << 2) | ((d[j + 2] & 3) << 4);          // strand == 1 here
+                    mer = ((mer << 6) & 0xfc0) | lo3;
+                    visit(ci, j, o.nf[j] != 0);
+                }
+                continue;
+            }
+            struct W16 { unsigned long long a, b; } B, F;
+            __builtin_memcpy(&B, d + lo, 16);
+            __builtin_memcpy(&F, o.nf + lo, 16);
+            auto bytes_at = [](const W16& w, const int k) {          // the (up to 8) bytes from offset k on, k <= 13
+                return k < 8 ? (w.a >> (8 * k)) | (k ? w.b << (64 - 8 * k) : 0ull) : w.b >> (8 * (k - 8));
+            };
+#pragma unroll
+            for (int u = 0; u < 5; u++) {
+                const int ci = c0 + u;
+                if (ci >= o.ncod) break;
+                const int k = strand == 1 ? 12 - 3 * u : 3 * u;             // offset of the codon's lowest position
+                const unsigned t3 = (unsigned)bytes_at(B, k);
+                const int b0 = t3 & 0xff, b1 = (t3 >> 8) & 0xff, b2 = (t3 >> 16) & 0xff;
+                // rolling update: the three bases nearest to the walk direction are new (ref: _sequence.h:207-220)
+                const int lo3 = strand == 1 ? (b0 & 3) | ((b1 & 3) << 2) | ((b2 & 3) << 4)
+                                            : (comp2(b2) & 3) | ((comp2(b1) & 3) << 2) | ((comp2(b0) & 3) << 4);
+                mer = ((mer << 6) & 0xfc0) | lo3;
+                const int kn = strand == 1 ? k : k + 2;                        // offset of the position the node flag sits at
+                visit(ci, lo + kn, ((unsigned)bytes_at(F, kn) & 0xff) != 0);
             }
         }
         if (far < 0) continue;
         double run_c[CS_MODELS], run_l[CS_MODELS];
 #pragma unroll
         for (int m = 0; m < CS_MODELS; m++) { run_c[m] = -10000.0; run_l[m] = -10000.0; }
-        for (int ci = far; ci >= 0; ci--) {                     // outermost start first
-            const int j = p + step * (ci + 1);
-            if (!o.nf[j]) continue;
-            const int k = o.pre[j] + (strand == 1 ? 0 : o.nf_f[j]) - o.tbase;
+        for (int wsel = 2; wsel >= 0; wsel--) {                 // outermost start first
+            unsigned long long bits = wsel == 2 ? sm2 : (wsel == 1 ? sm1 : sm0);
+            while (bits) {
+                const int bp = 63 - __builtin_clzll(bits);
+                bits &= ~(1ull << bp);
+                const int ci = wsel * 64 + bp;
+                const int j = p + step * (ci + 1);
+                const int k = o.pre[j] + (strand == 1 ? 0 : o.nf_f[j]) - o.tbase;
 #pragma unroll
-            for (int m = 0; m < CS_MODELS; m++) {
-                if (m >= nm) continue;
-                double cs = csp[m][k];
-                if (cs > run_c[m]) run_c[m] = cs; else cs -= (run_c[m] - cs);
-                double lfac = length_factor(mcp[m], ci + 2);
-                if (lfac > run_l[m]) run_l[m] = lfac; else lfac -= fmax(fmin(run_l[m] - lfac, lfac), 0.0);
-                if (lfac > 3.0 && cs < 0.5 * lfac) cs = 0.5 * lfac;
-                cs += lfac;
-                csp[m][k] = cs;
+                for (int m = 0; m < CS_MODELS; m++) {
+                    if (m >= nm) continue;
+                    double cs = csp[m][k];
+                    if (cs > run_c[m]) run_c[m] = cs; else cs -= (run_c[m] - cs);
+                    double lfac = length_factor(mcp[m], ci + 2);
+                    if (lfac > run_l[m]) run_l[m] = lfac; else lfac -= fmax(fmin(run_l[m] - lfac, lfac), 0.0);
+                    if (lfac > 3.0 && cs < 0.5 * lfac) cs = 0.5 * lfac;
+                    cs += lfac;
+                    csp[m][k] = cs;
+                }
             }
         }
     }
