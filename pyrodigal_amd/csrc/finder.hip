@@ -89,6 +89,7 @@ struct FinderState {
     std::vector<int> model_group;   // model -> translation-table group
     std::vector<int> group_tt;
     ModelScoreConst* d_msc = nullptr;
+    unsigned* d_sd_lut = nullptr;   // RBS search table (pga_launch_sd_lut), filled when the context's finder state is created
     hipEvent_t e_start = nullptr, e_stop = nullptr, e_dp0[4] = {}, e_dp1[4] = {};
 };
 
@@ -715,6 +716,7 @@ void pga_finder_release(pga_ctx* c) {
     for (auto& kv : c->finder->dev) if (kv.second.p) hipFree(kv.second.p);
     for (auto& kv : c->finder->pin) if (kv.second.p) hipHostFree(kv.second.p);
     if (c->finder->d_msc) hipFree(c->finder->d_msc);
+    if (c->finder->d_sd_lut) hipFree(c->finder->d_sd_lut);
     if (c->finder->e_start) hipEventDestroy(c->finder->e_start);
     if (c->finder->e_stop) hipEventDestroy(c->finder->e_stop);
     for (int i = 0; i < 4; i++) { if (c->finder->e_dp0[i]) hipEventDestroy(c->finder->e_dp0[i]); if (c->finder->e_dp1[i]) hipEventDestroy(c->finder->e_dp1[i]); }
@@ -728,6 +730,9 @@ int pga_finder_models_changed(pga_ctx* c) {
         if (!c->finder) return PGA_ENOMEM;
         HT(c, hipEventCreate(&c->finder->e_start)); HT(c, hipEventCreate(&c->finder->e_stop));
         for (int i = 0; i < 4; i++) { HT(c, hipEventCreate(&c->finder->e_dp0[i])); HT(c, hipEventCreate(&c->finder->e_dp1[i])); }
+        HT(c, hipMalloc((void**)&c->finder->d_sd_lut, sizeof(unsigned) * 1920));
+        pga_launch_sd_lut(c->finder->d_sd_lut, c->stream);
+        HT(c, hipStreamSynchronize(c->stream));
     }
     FinderState* f = c->finder;
     f->model_group.clear(); f->group_tt.clear();
@@ -1062,7 +1067,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             const int64_t nn = g_n0[g + 1] - g_n0[g];
             if (nch == 0 || nn == 0 || stage == PGA_STAGE_EXTRACT) continue;
             pga_launch_score(d_chains + g_c0[g], nch, g_n0[g], nn, d_dig, d_ct, ga[g], d_models, f->d_msc, c->d_model_const, ca, sp,
-                             d_chains, d_cc + (size_t)g * NC, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], st);
+                             d_chains, d_cc + (size_t)g * NC, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], f->d_sd_lut, st);
             NodeArrays na{ga[g].ndx, ga[g].stop_val, ga[g].type, ga[g].strand, ca.cscore, ca.sscore, ca.rscore, ca.uscore, ca.star_ptr};
             if (stage == 0) pga_launch_dp_prepare(d_chains + g_c0[g], nch, g_n0[g], nn, na, c->d_model_const, dp, st);
         }
@@ -1183,7 +1188,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                 const int nch = r_c0[g + 1] - r_c0[g]; const int64_t nn = r_n0[g + 1] - r_n0[g];
                 if (nch == 0 || nn == 0) continue;
                 pga_launch_score(d_chains + NCH + r_c0[g], nch, r_n0[g], nn, d_dig, d_ct, ga[g], d_models, f->d_msc, c->d_model_const, ca, sp,
-                                 d_chains, d_cc + (size_t)NG * NC + (size_t)g * NC, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], st);
+                                 d_chains, d_cc + (size_t)NG * NC + (size_t)g * NC, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], f->d_sd_lut, st);
             }
         }
         tm.mark("winners+rescore_launch");

@@ -71,5 +71,7 @@ void pga_launch_score(const ChainDesc* d_chains, int n_chains, int64_t node_begi
                       const ContigDesc* d_ct, const GroupArrays& ga, const pga_training* d_models,
                       const ModelScoreConst* d_msc, const ModelConst* d_mc, const ChainArrays& ca, ScoreParams sp,
                       const ChainDesc* d_all_chains /* indexed by contig_chains[].x */, const int2* d_contig_chains /* per contig: first chain, count */,
-                      const int32_t* d_node_contig_base, int n_contigs, int group_nodes, hipStream_t st);
+                      const int32_t* d_node_contig_base, int n_contigs, int group_nodes, const unsigned* d_sd_lut, hipStream_t st);
+// the RBS search tabulated: 1920 words, filled once per context (see sd_hits in pipeline.hip)
+void pga_launch_sd_lut(unsigned* d_lut, hipStream_t st);
 int64_t pga_scan_tiles(int64_t total);

@@ -799,23 +799,24 @@ __device__ __forceinline__ UpWin load_upwin(const uint8_t* __restrict__ d, int L
 
 // ref: lib.pyx:791-881 (exact) / 883-979 (one mismatch); mm selects the variant.  As in the
 // reference the mismatch variant keeps the previous cur_val when no table row matches.
-__device__ int shine_dalgarno(const UpWin& W, int pos, int start, const double* __restrict__ w, int mm) {
-    int match[6], limit, maxv = 0, cur = 0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) match[i] = -10;
+// The search itself does not look at the model: which motif bins match in the window is a property of the sequence.  The
+// reference keeps, per window, the bin of greatest weight (ties to the larger bin) among bin 0 and the bins that match:
+// sd_hits returns those bins as a bit mask (once per node), sd_pick chooses among them with one model's weights.
+// A window is the six bases at strand-local positions pos .. pos + 5, pos = start - 20 + q for q = 0 .. 14; all the search
+// looks at is, per base, "is the A (bases 0 and 3) / the G (others) of AGGAGG there": six bits.  sd_hits therefore is a function
+// of (pattern, q, variant) alone and is tabulated once per context (k_sd_lut, 1920 words); the scoring kernel looks it up.
+__device__ unsigned sd_hits(const int pat, const int q, const int mm) {
+    int match[6], limit, cur = 0;
+    unsigned hits = 1u;
+    const int start = 20, pos = q;                      // only start - pos matters
     limit = min(6, start - 4 - pos);
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-        if (i >= limit) break;
-        const int u = start - (pos + i);
-        const bool in = (W.inr >> u) & 1ull;
-        const bool a = (W.isA >> u) & 1ull, g = (W.isG >> u) & 1ull;
-        if (!mm) {
-            if (!in) continue;
-            if (i % 3 == 0) { if (a) match[i] = 2; } else { if (g) match[i] = 3; }
-        } else {
-            if (i % 3 == 0) match[i] = (in && a) ? 2 : -3; else match[i] = (in && g) ? 3 : -2;
-        }
+        match[i] = -10;
+        if (i >= limit) continue;
+        const bool hit = (pat >> i) & 1;
+        if (!mm) { if (hit) match[i] = i % 3 == 0 ? 2 : 3; }
+        else match[i] = hit ? (i % 3 == 0 ? 2 : 3) : (i % 3 == 0 ? -3 : -2);
     }
     for (int i = limit; i > (mm ? 4 : 2); i--) {
         for (int j = 0; j < limit + 1 - i; j++) {
@@ -857,10 +858,25 @@ __device__ int shine_dalgarno(const UpWin& W, int pos, int start, const double* 
                     default: break;
                 }
             }
-            if (w[cur] < w[maxv]) continue;
-            if (w[cur] == w[maxv] && cur < maxv) continue;
-            maxv = cur;
+            hits |= 1u << cur;
         }
+    }
+    return hits;
+}
+#define PGA_SD_LUT 1920          // [variant 2][window 15][pattern 64]
+__global__ void k_sd_lut(unsigned* __restrict__ lut) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < PGA_SD_LUT) lut[t] = sd_hits(t & 63, (t >> 6) % 15, (t >> 6) / 15);
+}
+__device__ __forceinline__ int sd_pick(unsigned hits, const double* __restrict__ w) {
+    int maxv = 0;
+    hits &= ~1u;
+    while (hits) {
+        const int cur = __builtin_ctz(hits);
+        hits &= hits - 1u;
+        if (w[cur] < w[maxv]) continue;
+        if (w[cur] == w[maxv] && cur < maxv) continue;
+        maxv = cur;
     }
     return maxv;
 }
@@ -876,8 +892,10 @@ __global__ void __launch_bounds__(256)
 k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ contig_chains,
                const int32_t* __restrict__ node_contig_base, int n_contigs, int n_nodes,
                const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct, GroupArrays ga,
-               const pga_training* __restrict__ models, ChainArrays ca, ScoreParams sp) {
+               const pga_training* __restrict__ models, ChainArrays ca, ScoreParams sp, const unsigned* __restrict__ sd_lut) {
     __shared__ int s_c0;
+    __shared__ unsigned s_lut[PGA_SD_LUT];
+    for (int k = threadIdx.x; k < PGA_SD_LUT; k += blockDim.x) s_lut[k] = sd_lut[k];
     const int blk0 = blockIdx.x * blockDim.x;
     const int t = blk0 + threadIdx.x;
     // contig of the block's first node, then a short forward walk
@@ -924,18 +942,25 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
     bool ups_first = false, ups_later = false, ups_near_edge = false;
     if (!closed && ndx <= 2 && strand == 1) ups_near_edge = true;
     else if (!closed && ndx >= L - 3 && strand == -1) ups_near_edge = true;
-    else if (i < 500 && strand == 1) {
-        for (int j = i - 1; j >= 0; j--)
-            if ((ga.edge0[tbase + j] || convertible(j)) && sv == ga.stop_val[tbase + j]) { ups_first = ups_later = true; break; }
-    } else if (i + 500 >= n && strand == -1) {
-        for (int j = i + 1; j < n; j++) {
+    else if ((i < 500 && strand == 1) || (i + 500 >= n && strand == -1)) {
+        // The reference scans the 500 nodes before a forward start (after a reverse one) for an edge node, or one that this
+        // pass converts to an edge node, of the same ORF.  Such nodes sit on the first or last three positions of the contig
+        // (ref: lib.pyx:2413-2434, node.c add_nodes), i.e. among the first or last PGA_EDGE_SPAN nodes (one node per position
+        // and strand): those are the only candidates worth a look.
+        constexpr int PGA_EDGE_SPAN = 12;
+        for (int q = 0; q < 2 * PGA_EDGE_SPAN; q++) {
+            const int j = q < PGA_EDGE_SPAN ? q : n - 2 * PGA_EDGE_SPAN + q;
+            if (j < 0 || j >= n || (q >= PGA_EDGE_SPAN && j < PGA_EDGE_SPAN)) continue;       // short contig: each node once
+            if (strand == 1 ? j >= i : j <= i) continue;
             if (sv != ga.stop_val[tbase + j]) continue;
-            if (ga.edge0[tbase + j]) { ups_first = ups_later = true; break; }
-            if (convertible(j)) ups_later = true;                  // counts only once an earlier model of the run converted it
+            if (ga.edge0[tbase + j]) { ups_first = ups_later = true; }
+            else if (convertible(j)) { if (strand == 1) ups_first = true; ups_later = true; }   // after i: counts only once an earlier model of the run converted it
         }
     }
     int tt_cached = -1; bool stop_missing = false;
 
+    bool have_hits = false;
+    unsigned hit_e[15], hit_m[15];       // per search window: the RBS bins that match exactly / with one mismatch
     for (int m = 0; m < cc.y; m++) {
         const ChainDesc ch = chains[cc.x + m];
         const int64_t g = ch.off + i;
@@ -951,15 +976,28 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
         double m_score = 0.0;
         if (!edge_in) {
             if (tm->uses_sd) {
-                for (int j = start - 20; j < start - 5; j++) {
-                    // the reference skips windows starting before the sequence on the forward strand only; on the reverse
-                    // strand it tests "j >= slen", never true, so windows hanging off the end are searched with the missing
-                    // bases matching nothing (ref: lib.pyx:2256-2275)
-                    if (j < 0 && strand == 1) continue;
-                    const int a = shine_dalgarno(W, j, start, tm->rbs_wt, 0);
-                    const int b = shine_dalgarno(W, j, start, tm->rbs_wt, 1);
-                    if (a > rbs0) rbs0 = a;
-                    if (b > rbs1) rbs1 = b;
+                if (!have_hits) {
+                    have_hits = true;
+                    const unsigned long long hasA = W.isA & W.inr, hasG = W.isG & W.inr;
+#pragma unroll
+                    for (int q = 0; q < 15; q++) {
+                        const int j = start - 20 + q;
+                        // the reference skips windows starting before the sequence on the forward strand only; on the reverse
+                        // strand it tests "j >= slen", never true, so windows hanging off the end are searched with the missing
+                        // bases matching nothing (ref: lib.pyx:2256-2275)
+                        const bool skip = j < 0 && strand == 1;
+                        // base i of the window is bit 5 - i of the six bits from position start - (j + 5) up
+                        const unsigned a6 = (unsigned)(hasA >> (15 - q)) & 63u, g6 = (unsigned)(hasG >> (15 - q)) & 63u;
+                        const unsigned pat = ((a6 >> 5) & 1u) | (((g6 >> 4) & 1u) << 1) | (((g6 >> 3) & 1u) << 2) | (((a6 >> 2) & 1u) << 3) |
+                                             (((g6 >> 1) & 1u) << 4) | ((g6 & 1u) << 5);
+                        hit_e[q] = skip ? 0u : s_lut[(q << 6) | pat];
+                        hit_m[q] = skip ? 0u : s_lut[((15 + q) << 6) | pat];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 15; q++) {
+                    if (hit_e[q] > 1u) { const int a = sd_pick(hit_e[q], tm->rbs_wt); if (a > rbs0) rbs0 = a; }
+                    if (hit_m[q] > 1u) { const int b = sd_pick(hit_m[q], tm->rbs_wt); if (b > rbs1) rbs1 = b; }
                 }
             } else {
                 double bsc = -100.0; int bsp = 0, bsi = 0, blen = 0, bndx = 0;
@@ -1167,11 +1205,15 @@ void pga_launch_orf_gc(const ContigDesc* d_ct, int n_contigs, const int32_t* d_p
                        n_nodes_total, d_node_contig_base);
 }
 
+void pga_launch_sd_lut(unsigned* d_lut, hipStream_t st) {
+    hipLaunchKernelGGL(k_sd_lut, dim3((PGA_SD_LUT + 255) / 256), dim3(256), 0, st, d_lut);
+}
+
 void pga_launch_score(const ChainDesc* d_chains, int n_chains, int64_t node_begin, int64_t total, const uint8_t* d_dig,
                       const ContigDesc* d_ct, const GroupArrays& ga, const pga_training* d_models,
                       const ModelScoreConst* d_msc, const ModelConst* d_mc, const ChainArrays& ca, ScoreParams sp,
                       const ChainDesc* d_all_chains, const int2* d_contig_chains, const int32_t* d_node_contig_base, int n_contigs,
-                      int group_nodes, hipStream_t st) {
+                      int group_nodes, const unsigned* d_sd_lut, hipStream_t st) {
     if (total <= 0 || n_chains <= 0) return;
     const dim3 grid(nblocks(total, 256)), blk(256);
     if (group_nodes > 0)
@@ -1179,6 +1221,6 @@ void pga_launch_score(const ChainDesc* d_chains, int n_chains, int64_t node_begi
                            n_contigs, 0, group_nodes, d_dig, d_ct, ga, d_models, d_msc, ca);
     if (group_nodes > 0)
         hipLaunchKernelGGL(k_score_starts, dim3(nblocks(group_nodes, 256)), blk, 0, st, d_all_chains, d_contig_chains, d_node_contig_base, n_contigs,
-                           group_nodes, d_dig, d_ct, ga, d_models, ca, sp);
+                           group_nodes, d_dig, d_ct, ga, d_models, ca, sp, d_sd_lut);
     hipLaunchKernelGGL(k_overlapping_starts, grid, blk, 0, st, d_chains, n_chains, node_begin, total, ga, d_mc, ca, sp.max_overlap);
 }
