@@ -566,60 +566,74 @@ __device__ void tweak_one_wave(const NodeView& v, const GeneRec* prev, GeneRec& 
     else if (pick != -1 && v.strand[mi[pick]] == -1) { cur.start_ndx = mi[pick]; cur.end = v.ndx[mi[pick]] + 1; }
 }
 
-// One wavefront per contig, in gene order, 64 genes at a time: a window in which no predecessor moved is skipped with one
-// coalesced load; a gene whose predecessor did move is redone by one lane, and what that does to the next gene's flag is
-// taken into account before going on (the reference's in-order semantics, ref: lib.pyx:3272-3401).
-#define PGA_FIX_CHUNK 16384      // flags staged in LDS at a time
-__global__ void __launch_bounds__(64)
+// The in-order pass over the genes whose predecessor moved (the reference's loop semantics, ref: lib.pyx:3272-3401): one
+// workgroup per contig, windows of 64 genes.  A window only depends on the one before it through its first gene's
+// predecessor, and only if that predecessor -- the last gene of the window before -- was itself redone: so every wavefront
+// first runs its windows assuming it was not (phase 1, all windows side by side), then one wavefront goes over the
+// windows in order and redoes, from their parallel-pass state, those whose assumption failed (phase 2, rare).  Within a
+// window genes are taken in order; a redone gene's 200 candidates are priced by the lanes (tweak_one_wave).
+//   par / ch0   the parallel pass (k_tail_tweak): records against the ORIGINAL neighbours, "start moved on the reverse strand"
+//   fin / chf   the final records and flags
+#define PGA_FIX_MAXWIN 4096
+__global__ void __launch_bounds__(1024)
 k_tail_tweak_fixup(const TailDesc* __restrict__ td, int n_contigs, OutArrays o, int32_t* tracef, uint8_t* elim,
-                   const GeneRec* __restrict__ orig, GeneRec* __restrict__ out, const int32_t* __restrict__ n_genes, int maxov,
-                   uint8_t* __restrict__ changed, const int32_t* __restrict__ n_changed) {
-    __shared__ uint8_t s_ch[PGA_FIX_CHUNK];
-    const int c = blockIdx.x, lane = threadIdx.x;
+                   const GeneRec* __restrict__ orig, const GeneRec* __restrict__ par_all, const int32_t* __restrict__ n_genes, int maxov,
+                   const uint8_t* __restrict__ ch0_all, const int32_t* __restrict__ n_changed, GeneRec* __restrict__ fin_all,
+                   uint8_t* __restrict__ chf_all) {
+    __shared__ uint8_t s_redone[PGA_FIX_MAXWIN];
+    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     if (c >= n_contigs) return;
-    if (n_changed[c] == 0) return;
     const TailDesc d = td[c];
     const int ng = n_genes[c];
+    const GeneRec* ob = orig + d.gene_off; const GeneRec* par = par_all + d.gene_off; const uint8_t* ch0 = ch0_all + d.gene_off;
+    GeneRec* fin = fin_all + d.gene_off; uint8_t* chf = chf_all + d.gene_off;
+    for (int g = threadIdx.x; g < ng; g += blockDim.x) { fin[g] = par[g]; chf[g] = ch0[g]; }
+    if (n_changed[c] == 0 || ng < 2) return;
+    __threadfence_block();
+    __syncthreads();
     const NodeView v = node_view(d, o, tracef, elim);
-    const GeneRec* ob = orig + d.gene_off;
-    GeneRec* nb = out + d.gene_off;
-    uint8_t* ch = changed + d.gene_off;
-    auto lds_sync = [] {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-    };
-    int carry = 0;                                     // final flag of the last gene of the chunk before
-    for (int b0 = 0; b0 < ng; b0 += PGA_FIX_CHUNK) {
-        // the flags of the chunk's genes, as the parallel pass left them, into LDS: a window in which no predecessor moved
-        // then costs a few LDS instructions; a redo updates its flag there too
-        const int hi = min(ng, b0 + PGA_FIX_CHUNK);
-        for (int k = lane; k < hi - b0; k += 64) s_ch[k] = ch[b0 + k];
-        lds_sync();
-        for (int g0 = max(b0, 1); g0 < hi; g0 += 64) {
-            const int g = g0 + lane;
-            const int pf = g < hi ? (g - 1 >= b0 ? s_ch[g - 1 - b0] : carry) : 0;
-            unsigned long long mask = __ballot(pf != 0);
-            while (mask) {
-                const int k = __builtin_ctzll(mask);
-                mask &= mask - 1ull;
-                const int gg = g0 + k;
-                GeneRec cur = ob[gg];
-                const GeneRec prev = nb[gg - 1];
-                GeneRec nxt{};
-                if (gg < ng - 1) nxt = ob[gg + 1];
-                tweak_one_wave(v, &prev, cur, gg < ng - 1 ? &nxt : nullptr, d.st_wt, maxov, lane);
-                const int nf = cur.start_ndx != ob[gg].start_ndx && v.strand[cur.start_ndx] == -1;
-                if (lane == 0) { nb[gg] = cur; ch[gg] = (uint8_t)nf; s_ch[gg - b0] = (uint8_t)nf; }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the record is read back (nb[gg]) by all lanes if gg + 1 is redone
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                // the next gene's predecessor flag is this gene's new flag
-                if (k + 1 < 64 && gg + 1 < hi) { if (nf) mask |= 1ull << (k + 1); else mask &= ~(1ull << (k + 1)); }
-            }
-            lds_sync();
+    const int nwin = (ng - 1 + 63) >> 6;                  // genes 1 .. ng-1
+    // one window, in gene order; `assume`: its first gene's predecessor is as the parallel pass left it.  Returns whether the
+    // window's last gene was redone (then the next window may not assume that).
+    auto run_window = [&](const int w, const bool assume) -> bool {
+        const int g0 = 1 + (w << 6), g1 = min(ng, g0 + 64);
+        const int g = g0 + lane;
+        if (!assume) {
+            if (g < g1) { fin[g] = par[g]; chf[g] = ch0[g]; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-        carry = s_ch[hi - 1 - b0];
-        lds_sync();
+        const int pf = g < g1 ? ((lane == 0 && !assume) ? chf[g - 1] : ch0[g - 1]) : 0;
+        unsigned long long mask = __ballot(pf != 0);
+        bool last = false;
+        while (mask) {
+            const int k = __builtin_ctzll(mask);
+            mask &= mask - 1ull;
+            const int gg = g0 + k;
+            GeneRec cur = ob[gg];
+            const GeneRec prev = (k == 0 && assume) ? par[gg - 1] : fin[gg - 1];
+            GeneRec nxt{};
+            if (gg < ng - 1) nxt = ob[gg + 1];
+            tweak_one_wave(v, &prev, cur, gg < ng - 1 ? &nxt : nullptr, d.st_wt, maxov, lane);
+            const int nf = cur.start_ndx != ob[gg].start_ndx && v.strand[cur.start_ndx] == -1;
+            if (lane == 0) { fin[gg] = cur; chf[gg] = (uint8_t)nf; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // fin[gg] is read back by all lanes if gg + 1 is redone
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // the next gene's predecessor flag is this gene's new flag
+            if (gg + 1 < g1) { if (nf) mask |= 1ull << (k + 1); else mask &= ~(1ull << (k + 1)); }
+            if (gg == g1 - 1) last = true;
+        }
+        return last;
+    };
+    if (nwin <= PGA_FIX_MAXWIN) {
+        for (int w = wave; w < nwin; w += nwaves) { const bool r = run_window(w, true); if (lane == 0) s_redone[w] = r; }
+        __threadfence_block();
+        __syncthreads();
+        if (wave == 0)
+            for (int w = 1; w < nwin; w++)
+                if (s_redone[w - 1]) { const bool r = run_window(w, false); if (lane == 0) s_redone[w] = r; __builtin_amdgcn_wave_barrier(); }
+    } else if (wave == 0) {
+        for (int w = 0; w < nwin; w++) run_window(w, false);       // a contig of more than 262 k genes: plainly in order
     }
 }
 
@@ -1445,8 +1459,10 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             }
             hipLaunchKernelGGL(k_tail_tweak, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, st, d_td, NC, n_slots, o, d_tracef, d_elim,
                                d_gene0, d_gene1, d_ngenes, P.max_overlap, d_changed, d_nchanged);
-            hipLaunchKernelGGL(k_tail_tweak_fixup, dim3(NC), dim3(64), 0, st, d_td, NC, o, d_tracef, d_elim, d_gene0, d_gene1, d_ngenes,
-                               P.max_overlap, d_changed, d_nchanged);
+            DEVBUF(d_gene2, GeneRec, "d_gene2", n_slots + 1);
+            DEVBUF(d_chfin, uint8_t, "d_chfin", n_slots + 1);
+            hipLaunchKernelGGL(k_tail_tweak_fixup, dim3(NC), dim3(max_n >= 32768 ? 1024 : 128), 0, st, d_td, NC, o, d_tracef, d_elim, d_gene0, d_gene1,
+                               d_ngenes, P.max_overlap, d_changed, d_nchanged, d_gene2, d_chfin);
             HT(c, hipMemcpyAsync(h_ngenes, d_ngenes, sizeof(int32_t) * NC, hipMemcpyDeviceToHost, st));
             HT(c, hipGetLastError());
             HT(c, hipStreamSynchronize(st));
@@ -1467,7 +1483,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             if (ngenes > 0) {
                 DEVBUF(d_genes, pga_gene, "d_genes_out", ngenes + 1);
                 HT(c, hipMemcpyAsync(d_gbegin, h_gbegin, sizeof(int64_t) * NC, hipMemcpyHostToDevice, st));
-                hipLaunchKernelGGL(k_emit_genes, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, st, d_td, NC, n_slots, o, d_gene1, d_ngenes,
+                hipLaunchKernelGGL(k_emit_genes, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, st, d_td, NC, n_slots, o, d_gene2, d_ngenes,
                                    d_gbegin, P.meta ? 0 : 1, d_genes);
                 HT(c, hipMemcpyAsync(R->genes.data(), d_genes, sizeof(pga_gene) * (size_t)ngenes, hipMemcpyDeviceToHost, st));
             }
