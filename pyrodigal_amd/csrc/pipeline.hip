@@ -549,7 +549,7 @@ __device__ __forceinline__ void orf_serial(const OrfCtx& o, const ChainDesc* __r
         unsigned long long sm0 = 0, sm1 = 0, sm2 = 0;           // codons that are start nodes (ncod <= CS_LONG = 192)
         auto visit = [&](const int ci, const int j, const bool isnode) {
 #pragma unroll
-            for (int m = 0; m < CS_MODELS; m++) sum[m] += gdc[m][mer];
+            for (int m = 0; m < CS_MODELS; m++) if (m < nm) sum[m] += gdc[m][mer];      // a load only where the lane has a model m
             if (isnode) {
                 const int k = o.pre[j] + (strand == 1 ? 0 : o.nf_f[j]) - o.tbase;
 #pragma unroll
