@@ -1433,7 +1433,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                     int levels = 1;
                     while ((1ll << levels) < max_n) levels++;
                     const unsigned nblk = (unsigned)((out_nodes + 255) / 256);
-                    DEVBUF(tp_seg, TpSeg, "tp_seg", segs.size()) DEVBUF(tp_up, int32_t, "tp_up", (size_t)levels * out_nodes)
+                    DEVBUF(tp_seg, TpSeg, "tp_seg", segs.size()) DEVBUF(tp_up, int32_t, "tp_up", (size_t)2 * out_nodes)
                     DEVBUF(tp_mark, uint8_t, "tp_mark", out_nodes) DEVBUF(tp_slots, int32_t, "tp_slots", out_nodes)
                     DEVBUF(tp_ins, int32_t, "tp_ins", 2 * out_nodes) DEVBUF(tp_excl, int32_t, "tp_excl", out_nodes + 1)
                     DEVBUF(tp_bsum, int32_t, "tp_bsum", nblk + 1) DEVBUF(tp_cnt, int32_t, "tp_cnt", segs.size())
@@ -1442,8 +1442,9 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                     const TpWork tw{tp_seg, (int)segs.size(), out_nodes, levels, tp_up, tp_mark, tp_slots, tp_ins, tp_excl, tp_bsum, tp_cnt};
                     const dim3 grid(nblk), blk(256);
                     hipLaunchKernelGGL(k_tp_init, grid, blk, 0, st, tw, d_td, o);
-                    for (int k = 0; k + 1 < levels; k++) hipLaunchKernelGGL(k_tp_level, grid, blk, 0, st, tw, k);
-                    for (int k = levels - 1; k >= 0; k--) hipLaunchKernelGGL(k_tp_mark, grid, blk, 0, st, tw, k);
+                    for (int k = 0; k < levels; k++)
+                        hipLaunchKernelGGL(k_tp_jump, grid, blk, 0, st, tw, (const int32_t*)(tp_up + (size_t)(k & 1) * out_nodes),
+                                           tp_up + (size_t)((k + 1) & 1) * out_nodes);
                     hipLaunchKernelGGL(k_tp_slots, grid, blk, 0, st, tw, d_td, o);
                     hipLaunchKernelGGL(k_tp_scan1, grid, blk, 0, st, tw);
                     hipLaunchKernelGGL(k_tp_scan2, dim3(1), dim3(1024), 0, st, tw, (int)nblk);

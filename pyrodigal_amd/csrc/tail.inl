@@ -8,9 +8,9 @@
 // times (two untangling passes that splice nodes into the path, one pass that sets tracef), then walks the path twice
 // more.  One device thread per contig does the same at one memory round trip per step (k_tail_path): fine for a batch
 // of small contigs side by side, hopeless for a genome (18 k steps).  Here:
-//   * the nodes ON the path are found by pointer doubling: up[k][i] = the 2^k-th traceb ancestor of node i (one
-//     parallel pass per level), then marks spread from the best gene end over distances 2^(L-1), ..., 2, 1 -- every
-//     node an ancestor of a marked node is itself on the path, so the order inside a pass does not matter;
+//   * the nodes ON the path are found by pointer doubling: in round k every node's pointer reaches its 2^k-th traceb
+//     ancestor and every marked node marks that ancestor, starting from the best gene end -- every ancestor of a marked node
+//     is itself on the path, so the order inside a round does not matter; log2(longest chain) rounds;
 //   * traceb always points to a smaller index, so the path in walk order is simply the marked nodes in decreasing index
 //     order: a prefix sum over the marks gives every node its position;
 //   * both untangling passes only look at one path edge (p, traceb[p]) at a time and splice 0, 1 or 2 nodes into it; the
@@ -26,8 +26,8 @@ struct TpSeg { int64_t off; int32_t n; int32_t contig; };     // winning chains 
 struct TpWork {
     const TpSeg* seg; int n_seg;
     int64_t nw;                 // nodes of all winning chains
-    int levels;                 // 2^levels > longest chain
-    int32_t* up;                // [levels][nw] global index of the 2^k-th ancestor (a head points to itself)
+    int levels;                 // 2^levels >= longest chain
+    int32_t* up;                // [2][nw] global index of the 2^k-th ancestor in round k (a head points to itself), ping-pong
     uint8_t* mark;              // node is on the path
     int32_t* slots;             // path positions the node takes: itself + what the untangling splices in after it
     int32_t* ins;               // [nw][2] the spliced-in nodes (chain index), -1 = none
@@ -53,19 +53,16 @@ k_tp_init(TpWork w, const TailDesc* __restrict__ td, OutArrays o) {
     w.mark[g] = i == td[s.contig].mx ? 1 : 0;
 }
 
+// one round of pointer doubling: every marked node marks its 2^k-th ancestor, every node's pointer doubles its reach.
+// After round k the marks cover the first 2^(k+1) nodes of the path (a node marked during the round may already pass the
+// mark on: whatever it reaches is an ancestor of the best gene end, hence on the path).
 __global__ void __launch_bounds__(256)
-k_tp_level(TpWork w, const int k) {
+k_tp_jump(TpWork w, const int32_t* __restrict__ up_in, int32_t* __restrict__ up_out) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= w.nw) return;
-    const int32_t* __restrict__ cur = w.up + (int64_t)k * w.nw;
-    w.up[(int64_t)(k + 1) * w.nw + g] = cur[cur[g]];
-}
-
-__global__ void __launch_bounds__(256)
-k_tp_mark(TpWork w, const int k) {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= w.nw || !w.mark[g]) return;
-    w.mark[w.up[(int64_t)k * w.nw + g]] = 1;
+    const int a = up_in[g];
+    if (w.mark[g]) w.mark[a] = 1;
+    up_out[g] = up_in[a];
 }
 
 // what the two untangling passes splice in after path node p (edge p -> nx = traceb[p]); ref: lib.pyx:1253-1295
