@@ -21,6 +21,9 @@
 //     cs(n3)+igm(.,.) and n3.{ndx,stop_val} into the source/target records, and every lane tracks
 //     the ndx of its own traceb node, which later pairs need (ref: _connection.h:249, 318).
 //
+// Few long chains (one genome) do not fill the chip with one serial walk each: they are cut into segments that are
+// walked speculatively side by side, re-scored exactly and verified node by node -- see "Segmented chains" below.
+//
 // Arithmetic: IEEE double, compiled with -ffp-contract=off, same operation order as the
 // reference; (2 - d/60)*0.15*st_wt comes from a host-computed 61-entry table.
 

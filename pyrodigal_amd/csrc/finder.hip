@@ -1,9 +1,10 @@
 // Finder-level entry point: whole-batch drop-in for GeneFinder.find_genes() in meta or single
 // mode (ref: lib.pyx:5281-5469).  Host orchestration only; every per-base / per-node stage runs in
-// the HIP kernels of pipeline.hip and dp.hip.  The O(path) tail of the reference's
-// _dynamic_programming (traceback untangling), eliminate_bad_genes, Genes._extract and
-// Genes._tweak_final_starts runs here on the host over the winning model's nodes (SURVEY.md
-// section 2 #9: "host-side or tiny kernel"), one contig per worker thread.
+// the HIP kernels of pipeline.hip and dp.hip.  The tail of the reference's _dynamic_programming
+// (traceback untangling), eliminate_bad_genes, Genes._extract and Genes._tweak_final_starts runs on
+// the device as well (tail.inl and the k_tail_* kernels below); the same functions, compiled for the
+// host too, remain as a cross-check (PGA_TAIL=host: one contig per worker thread over the winning
+// models' nodes brought home).
 #include "pga_internal.h"
 #include "pipeline.h"
 
