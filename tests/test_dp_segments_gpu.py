@@ -137,3 +137,25 @@ def test_find_genes_reports_segments_and_matches_serial(ctx):
         assert np.array_equal(a.contigs["model"], b.contigs["model"])
     finally:
         c2.close()
+
+
+def test_mixed_launch_segmented_and_whole_chains(ctx):
+    """One launch holds segments of the long chains next to the short chains walked whole; every node field of every contig
+    against the oracle (the segment settings are shrunk so that a batch of modest contigs has both kinds)."""
+    from pyrodigal_amd import _cabi, benchdata
+    from tests.test_finder_gpu import compare_contig
+    models = benchdata.load_model_set()
+    bins = [orc.Training(b) for _, b in models]
+    c2 = _cabi.Context(0)
+    try:
+        c2.set_models([b for _, b in models])
+        seqs = [synthetic_contig(L, gc, 4000 + k) for k, (L, gc) in enumerate(
+            [(3_000, 0.5), (120_000, 0.45), (9_000, 0.6), (60_000, 0.5), (800, 0.4), (200_000, 0.55), (25_000, 0.35), (45_000, 0.65)])]
+        os.environ.update({"PGA_DP_SEG_MIN": "2500", "PGA_DP_SEG_LEN": "512", "PGA_DP_SEG_WARM": "768"})
+        res = c2.find_genes_batch(seqs, meta=True, want_nodes=True)
+        st = c2.dp_stats()
+        assert 0 < st["chains"] < res.n_chains and st["segments"] > st["chains"]       # some chains cut, others not
+        total = sum(compare_contig(res, i, s, orc.Oracle(s), bins, meta=True) for i, s in enumerate(seqs))
+        assert total > 300
+    finally:
+        c2.close()
