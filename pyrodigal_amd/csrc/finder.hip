@@ -567,6 +567,30 @@ __device__ void tweak_one_wave(const NodeView& v, const GeneRec* prev, GeneRec& 
     else if (pick != -1 && v.strand[mi[pick]] == -1) { cur.start_ndx = mi[pick]; cur.end = v.ndx[mi[pick]] + 1; }
 }
 
+// k_tail_tweak for long contigs: a genome has few thousand genes, too few for one thread each to hide the latency of a
+// 200-candidate scan, so every gene gets a wavefront (tweak_one_wave); blockIdx.y = contig, four genes per workgroup.
+__global__ void __launch_bounds__(256)
+k_tail_tweak_wave(const TailDesc* __restrict__ td, int n_contigs, OutArrays o, int32_t* tracef, uint8_t* elim,
+                  const GeneRec* __restrict__ orig, GeneRec* __restrict__ out, const int32_t* __restrict__ n_genes, int maxov,
+                  uint8_t* __restrict__ changed, int32_t* __restrict__ n_changed) {
+    const int c = blockIdx.y, lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), ng = n_genes[c];
+    if (g >= ng) return;
+    const TailDesc d = td[c];
+    const NodeView v = node_view(d, o, tracef, elim);
+    const GeneRec* base = orig + d.gene_off;
+    GeneRec cur = base[g];
+    GeneRec prev{}, nxt{};
+    if (g > 0) prev = base[g - 1];
+    if (g < ng - 1) nxt = base[g + 1];
+    tweak_one_wave(v, g > 0 ? &prev : nullptr, cur, g < ng - 1 ? &nxt : nullptr, d.st_wt, maxov, lane);
+    if (lane != 0) return;
+    out[d.gene_off + g] = cur;
+    const bool moved = cur.start_ndx != base[g].start_ndx && v.strand[cur.start_ndx] == -1;
+    changed[d.gene_off + g] = moved ? 1 : 0;
+    if (moved) atomicAdd(&n_changed[c], 1);
+}
+
 // The in-order pass over the genes whose predecessor moved (the reference's loop semantics, ref: lib.pyx:3272-3401): one
 // workgroup per contig, windows of 64 genes.  A window only depends on the one before it through its first gene's
 // predecessor, and only if that predecessor -- the last gene of the window before -- was itself redone: so every wavefront
@@ -1459,8 +1483,12 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                                        d_gene0, d_ngenes);
                 }
             }
-            hipLaunchKernelGGL(k_tail_tweak, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, st, d_td, NC, n_slots, o, d_tracef, d_elim,
-                               d_gene0, d_gene1, d_ngenes, P.max_overlap, d_changed, d_nchanged);
+            if (max_n >= 32768 && NC <= 1024)       // genomes: a wavefront per gene (at most n / 2 + 2 genes per contig)
+                hipLaunchKernelGGL(k_tail_tweak_wave, dim3((unsigned)((max_n / 2 + 2 + 3) / 4), (unsigned)NC), dim3(256), 0, st, d_td, NC, o, d_tracef,
+                                   d_elim, d_gene0, d_gene1, d_ngenes, P.max_overlap, d_changed, d_nchanged);
+            else
+                hipLaunchKernelGGL(k_tail_tweak, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, st, d_td, NC, n_slots, o, d_tracef, d_elim,
+                                   d_gene0, d_gene1, d_ngenes, P.max_overlap, d_changed, d_nchanged);
             DEVBUF(d_gene2, GeneRec, "d_gene2", n_slots + 1);
             DEVBUF(d_chfin, uint8_t, "d_chfin", n_slots + 1);
             hipLaunchKernelGGL(k_tail_tweak_fixup, dim3(NC), dim3(max_n >= 32768 ? 1024 : 128), 0, st, d_td, NC, o, d_tracef, d_elim, d_gene0, d_gene1,
