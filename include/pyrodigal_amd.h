@@ -127,6 +127,11 @@ int         pga_device_info(const pga_ctx*, char* name, int name_len, int* cus, 
  *   out[2..4] nodes whose speculative result the verification rounds 1..3 rejected
  *   out[5] chains that were walked serially in the end because they never verified clean */
 int         pga_dp_stats(const pga_ctx*, int32_t out[8]);
+/* How a connection-scoring launch over chains of these node counts would be cut (host arithmetic only, no device needed;
+ * the PGA_DP_SEG* environment variables of INTEGRATION.md apply):
+ *   out[0] chains cut into segments   out[1] segments   out[2] nodes of the longest sub-chain (segment + warm-up)
+ *   out[3] scratch elements behind the real chains in every per-node array */
+int         pga_dp_plan_summary(int32_t n_chains, const int32_t* nodes_per_chain, int64_t out[4]);
 
 /* ---- models (MetagenomicBins / TrainingInfo, ref: lib.pyx:4888-5069, 3898-3953) ---- */
 int pga_set_models(pga_ctx*, const pga_training* const* models, int n_models);

@@ -18,7 +18,7 @@ EXPORTS = [
     "pga_create", "pga_destroy", "pga_last_error", "pga_device_info", "pga_set_models",
     "pga_score_connections", "pga_score_connections_training", "pga_find_genes_batch", "pga_result_free",
     "pga_batch_create", "pga_batch_free", "pga_find_genes", "pga_nodes_stage",
-    "pga_fasta_open", "pga_fasta_next", "pga_fasta_error", "pga_fasta_close", "pga_train", "pga_dp_stats",
+    "pga_fasta_open", "pga_fasta_next", "pga_fasta_error", "pga_fasta_close", "pga_train", "pga_dp_stats", "pga_dp_plan_summary",
 ]
 STAGE_EXTRACT, STAGE_SCORE, STAGE_OVERLAP, STAGE_SEQUENCE = 1, 2, 3, 4
 
@@ -89,6 +89,8 @@ def load():
     L.pga_destroy.restype = None; L.pga_destroy.argtypes = [vp]
     L.pga_last_error.restype = ctypes.c_char_p; L.pga_last_error.argtypes = [vp]
     L.pga_dp_stats.restype = ctypes.c_int; L.pga_dp_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
+    L.pga_dp_plan_summary.restype = ctypes.c_int
+    L.pga_dp_plan_summary.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)]
     L.pga_device_info.restype = ctypes.c_int
     L.pga_device_info.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, _P(ctypes.c_int), _P(i64)]
     L.pga_set_models.restype = ctypes.c_int; L.pga_set_models.argtypes = [vp, _P(vp), ctypes.c_int]
@@ -114,6 +116,18 @@ def load():
     L.pga_fasta_close.restype = None; L.pga_fasta_close.argtypes = [vp]
     _lib = L
     return L
+
+
+def dp_plan_summary(nodes_per_chain):
+    """How a connection-scoring launch over chains of these node counts would be cut (host arithmetic, no device needed)."""
+    L = load()
+    n = len(nodes_per_chain)
+    arr = (ctypes.c_int32 * max(n, 1))(*[int(x) for x in nodes_per_chain])
+    out = (ctypes.c_int64 * 4)()
+    rc = L.pga_dp_plan_summary(n, arr, out)
+    if rc != PGA_OK:
+        raise ValueError("pga_dp_plan_summary failed (code %d)" % rc)
+    return {"chains": out[0], "segments": out[1], "max_sub_chain": out[2], "scratch": out[3]}
 
 
 class PgaError(RuntimeError):

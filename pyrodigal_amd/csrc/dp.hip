@@ -1718,6 +1718,30 @@ hipError_t pga_dp_seg_bind(const DpSegPlan& plan, int n_chains, int64_t tot_node
     return e;
 }
 
+// C-ABI view of the plan (include/pyrodigal_amd.h): pure host arithmetic, usable without a device
+extern "C" int pga_dp_plan_summary(int32_t n_chains, const int32_t* nodes_per_chain, int64_t out[4]) {
+    if (n_chains < 0 || (n_chains > 0 && !nodes_per_chain) || !out) return PGA_EINVAL;
+    std::vector<ChainDesc> h((size_t)n_chains);
+    int64_t tot = 0;
+    for (int c = 0; c < n_chains; c++) {
+        if (nodes_per_chain[c] < 0) return PGA_EINVAL;
+        h[(size_t)c] = ChainDesc{tot, 0, nodes_per_chain[c], 0, c, 1};
+        tot += nodes_per_chain[c];
+    }
+    DpSegPlan plan;
+    pga_dp_plan(h.data(), n_chains, tot, plan);
+    out[0] = (int64_t)plan.big.size(); out[1] = (int64_t)plan.segs.size(); out[2] = plan.max_seg_nodes; out[3] = plan.extra;
+    // every node of a cut chain belongs to exactly one segment, segments are in order and start their walk at most `warm` early
+    for (size_t k = 0; k < plan.segs.size(); k++) {
+        const DpSeg& s = plan.segs[k];
+        const bool first = k == 0 || plan.segs[k - 1].chain != s.chain;
+        if (s.a > s.s || s.s >= s.e || s.e > h[(size_t)s.chain].n || (first ? s.s != 0 : s.s != plan.segs[k - 1].e)) return PGA_EDEVICE;
+        const bool last = k + 1 == plan.segs.size() || plan.segs[k + 1].chain != s.chain;
+        if (last && s.e != h[(size_t)s.chain].n) return PGA_EDEVICE;
+    }
+    return PGA_OK;
+}
+
 static void launch_dp_segmented(const ChainDesc* d_chains, int n_chains, const ModelConst* d_models, DpBuffers buf, hipStream_t st,
                                 const DpSegDev& sg) {
     const dim3 blk(256);
