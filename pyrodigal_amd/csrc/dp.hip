@@ -1630,20 +1630,26 @@ bool pga_dp_plan(const ChainDesc* h, int n_chains, int64_t tot_nodes, DpSegPlan&
     if (cand == 0) return false;
     // one workgroup per compute unit is what the chain kernel's LDS footprint allows: every sub-chain and every chain that
     // is not cut must be resident at once (256 CUs), a workgroup too many would wait for a free CU and double the time
-    auto count_segs = [&](const int64_t len) {
+    int n_short = 0;                                      // chains that are walked whole whatever the segment length
+    for (int c = 0; c < n_chains; c++) n_short += h[c].n < min_chain;
+    auto count_segs = [&](const int64_t len) {            // workgroups of the candidates: segments, or 1 when left whole
         int64_t k = 0;
         for (int c = 0; c < n_chains; c++) {
             const int n = h[c].n;
-            if (n < min_chain || n < 2 * len) { k++; continue; }
+            if (n < min_chain) continue;
+            if (n < 2 * len) { k++; continue; }
             for (int64_t s0 = 0; s0 < n;) { int64_t e = std::min<int64_t>(n, s0 + len); if (n - e < len / 4) e = n; k++; s0 = e; }
         }
         return k;
     };
     int64_t len = env_int("PGA_DP_SEG_LEN", 0);
     if (len <= 0) {
-        const int64_t budget = std::max(64, env_int("PGA_DP_SEG_SLOTS", 256) - 4);
+        // what the short chains leave of the compute units, but never less than a quarter of them: a batch of one genome and
+        // hundreds of small contigs still cuts the genome (its segments then share the chip with the small chains' workgroups)
+        const int64_t slots = std::max(64, env_int("PGA_DP_SEG_SLOTS", 256) - 4);
+        const int64_t budget = std::max<int64_t>(slots / 4, slots - n_short);
         len = std::max<int64_t>(512, ((cand + budget - 1) / budget + 63) & ~63ll);
-        while (count_segs(len) > budget && len < cand) len += 64;
+        for (int it = 0; count_segs(len) > budget && len < cand; it++) len += it < 256 ? 64 : std::max<int64_t>(64, (len / 8) & ~63ll);
     }
     len = (len + 63) & ~63ll;
     int64_t cursor = tot_nodes;

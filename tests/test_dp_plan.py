@@ -60,3 +60,13 @@ def test_environment_overrides():
     assert p["max_sub_chain"] <= 256 + 64 + 64
     with pytest.raises(ValueError):
         _cabi.dp_plan_summary([-1])
+
+
+def test_a_genome_among_hundreds_of_small_contigs_is_still_cut_and_planned_quickly():
+    import time
+    t0 = time.time()
+    p = _cabi.dp_plan_summary([10_000_000] + [1500] * 2000)
+    assert time.time() - t0 < 0.5
+    assert p["chains"] == 1 and 16 <= p["segments"] <= 64 + 8
+    p = _cabi.dp_plan_summary([300_000] + [1500] * 100)
+    assert p["chains"] == 1 and p["segments"] + 100 <= 252 + 8
