@@ -106,6 +106,16 @@ void pga_fill_model_const(ModelConst* mc, double st_wt) {
 
 extern "C" int pga_set_models(pga_ctx* c, const pga_training* const* models, int n_models) {
     if (!c || n_models < 0 || (n_models > 0 && !models)) return fail(c, PGA_EINVAL, "pga_set_models: bad arguments");
+    // validate before touching the context: a rejected call leaves the loaded model set as it was
+    {
+        int tts[5]; int ntt = 0;
+        for (int i = 0; i < n_models; i++) {
+            if (!models[i]) return fail(c, PGA_EINVAL, "pga_set_models: model %d is NULL", i);
+            bool seen = false;
+            for (int k = 0; k < ntt; k++) seen = seen || tts[k] == models[i]->trans_table;
+            if (!seen) { if (ntt == 4) return fail(c, PGA_EINVAL, "pga_set_models: more than 4 distinct translation tables"); tts[ntt++] = models[i]->trans_table; }
+        }
+    }
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->d_models_raw) { hipFree(c->d_models_raw); c->d_models_raw = nullptr; }
     if (c->d_model_const) { hipFree(c->d_model_const); c->d_model_const = nullptr; }
@@ -114,7 +124,6 @@ extern "C" int pga_set_models(pga_ctx* c, const pga_training* const* models, int
     if (n_models == 0) return pga_finder_models_changed(c);
     std::vector<ModelConst> mcs(n_models);
     for (int i = 0; i < n_models; i++) {
-        if (!models[i]) return fail(c, PGA_EINVAL, "pga_set_models: model %d is NULL", i);
         c->models.push_back(*models[i]);
         pga_fill_model_const(&mcs[i], models[i]->st_wt);
     }

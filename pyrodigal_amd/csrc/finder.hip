@@ -908,6 +908,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
     FinderState* f = c->finder;
     hipStream_t st = c->stream;
     const int NC = n_contigs, NM = c->n_models, NG = meta_run ? (int)f->group_tt.size() : 1;
+    if (NG > 4) { c->err = "pga_find_genes: more than 4 distinct translation tables loaded"; return PGA_EINVAL; }
 
     ResultOwner* R = new (std::nothrow) ResultOwner();
     if (!R) return PGA_ENOMEM;

@@ -365,8 +365,8 @@ void tr_build_coverage_map(const unsigned int* real /* [4][4][4096] */, int* goo
 static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, const int stage, const int tt_override, pga_result** out);
 
 // ref: lib.pyx:5236-5279 (GeneFinder._train) for ONE sequence (the host layer joins several with the reference's spacer)
-static int train_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, int tt, double start_weight, int force_nonsd,
-                      int upto, pga_training* t) {
+static int train_body(pga_ctx* c, const pga_batch* batch, const pga_params* pp, int tt, double start_weight, int force_nonsd,
+                      int upto, pga_training* t, bool& models_replaced) {
     if (!c || !batch || !pp || !t || batch->ctx != c || batch->n != 1) { if (c) c->err = "pga_train: needs a batch of exactly one sequence"; return PGA_EINVAL; }
     memset(t, 0, sizeof *t);
     t->trans_table = tt; t->st_wt = start_weight; t->uses_sd = 1;
@@ -461,6 +461,7 @@ static int train_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, 
     // ---- coding scores and RBS bins under the new statistics (ref: lib.pyx:5271-5273): the scoring stage of the path
     {
         const pga_training* tp = t;
+        models_replaced = true;
         if (int rc = pga_set_models(c, &tp, 1)) return rc;
     }
     pga_result* r2 = nullptr;
@@ -577,4 +578,24 @@ static int train_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, 
     }
     tr_ups_to_log(cn.ups, t);
     return PGA_OK;
+}
+
+// The scoring stage of the training runs through the context's model slot (the half-trained model is loaded as model 0);
+// the caller's model set is put back afterwards, so that pga_set_models(bins) ... pga_train ... pga_find_genes keeps
+// scoring with the bins.
+static int train_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, int tt, double start_weight, int force_nonsd,
+                      int upto, pga_training* t) {
+    if (!c) return PGA_EINVAL;
+    const std::vector<pga_training> saved = c->models;
+    bool replaced = false;
+    const int rc = train_body(c, batch, pp, tt, start_weight, force_nonsd, upto, t, replaced);
+    if (replaced) {
+        const std::string err = c->err;
+        std::vector<const pga_training*> ptrs;
+        for (const pga_training& m : saved) ptrs.push_back(&m);
+        const int rc2 = pga_set_models(c, ptrs.data(), (int)ptrs.size());
+        if (rc != PGA_OK) { c->err = err; return rc; }
+        if (rc2 != PGA_OK) return rc2;
+    }
+    return rc;
 }

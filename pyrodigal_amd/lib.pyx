@@ -120,6 +120,10 @@ cdef extern from "pyrodigal_amd.h" nogil:
                               const int8_t* strand, const double* cscore, const double* sscore, const double* rscore,
                               const double* uscore, const int32_t* star_ptr, double st_wt, int final,
                               double* score, int32_t* traceb, int8_t* ov_mark, int32_t* max_index, double* kernel_ms)
+    int pga_score_connections_training(pga_ctx*, int32_t n, const int32_t* ndx, const int32_t* stop_val, const uint8_t* type,
+                                       const int8_t* strand, const double* gc_score, const double* bias, const int32_t* star_ptr,
+                                       double st_wt, double* score, int32_t* traceb, int8_t* ov_mark, int32_t* max_index,
+                                       double* kernel_ms)
 
 # --- constants (ref: lib.pyx:166-228) ------------------------------------------------------
 MIN_SINGLE_GENOME = 20000
@@ -237,6 +241,7 @@ cdef object _raise_for(pga_ctx* ctx, int rc, str what):
 cdef class TrainingInfo:
     """The parameters of one gene model: the reference's 558 392-byte ``struct _training``."""
     cdef readonly object raw      # numpy uint8[558392]
+    cdef readonly unsigned long long _version   # bumped by every setter: device copies of the model are reloaded when it moves
 
     def __init__(self, double gc=0.5, *, int translation_table=11, double start_weight=4.35, object raw=None):
         if raw is not None:
@@ -286,6 +291,7 @@ cdef class TrainingInfo:
 
     @gc.setter
     def gc(self, double v):
+        self._version += 1
         if v < 0 or v > 1:
             raise ValueError("Invalid GC percent: %r" % v)
         self._f64(0)[0] = v
@@ -296,6 +302,7 @@ cdef class TrainingInfo:
 
     @translation_table.setter
     def translation_table(self, int v):
+        self._version += 1
         if v not in TRANSLATION_TABLES:
             raise ValueError("%d is not a valid translation table index" % v)
         self._i32(8)[0] = v
@@ -331,22 +338,27 @@ cdef class TrainingInfo:
     # the remaining fields and the setters of the reference (ref: lib.pyx:4067-4213)
     @start_weight.setter
     def start_weight(self, double v):
+        self._version += 1
         self._f64(16)[0] = v
 
     @bias.setter
     def bias(self, object v):
+        self._version += 1
         self._f64(24, 3)[:] = np.asarray(v, np.float64)
 
     @type_weights.setter
     def type_weights(self, object v):
+        self._version += 1
         self._f64(48, 3)[:] = np.asarray(v, np.float64)
 
     @uses_sd.setter
     def uses_sd(self, bint v):
+        self._version += 1
         self._i32(72)[0] = 1 if v else 0
 
     @rbs_weights.setter
     def rbs_weights(self, object v):
+        self._version += 1
         self._f64(80, 28)[:] = np.asarray(v, np.float64)
 
     @property
@@ -355,6 +367,7 @@ cdef class TrainingInfo:
 
     @upstream_compositions.setter
     def upstream_compositions(self, object v):
+        self._version += 1
         self._f64(304, 128)[:] = np.asarray(v, np.float64).reshape(-1)
 
     @property
@@ -363,14 +376,17 @@ cdef class TrainingInfo:
 
     @motif_weights.setter
     def motif_weights(self, object v):
+        self._version += 1
         self._f64(1328, 65536)[:] = np.asarray(v, np.float64).reshape(-1)
 
     @missing_motif_weight.setter
     def missing_motif_weight(self, double v):
+        self._version += 1
         self._f64(525616)[0] = v
 
     @coding_statistics.setter
     def coding_statistics(self, object v):
+        self._version += 1
         self._f64(525624, 4096)[:] = np.asarray(v, np.float64).reshape(-1)
 
     def __eq__(self, other):
@@ -438,6 +454,7 @@ cdef class _StageContext:
     cdef pga_ctx* ctx
     cdef object lock
     cdef object loaded        # the TrainingInfo blob currently loaded as model 0
+    cdef unsigned long long loaded_version
 
     def __cinit__(self):
         self.ctx = NULL
@@ -461,13 +478,14 @@ cdef class _StageContext:
     cdef int load(self, TrainingInfo tinf) except -1:
         cdef const pga_training* ptr
         cdef int rc
-        if self.loaded is tinf.raw:
+        if self.loaded is tinf.raw and self.loaded_version == tinf._version:
             return 0
         ptr = <const pga_training*> <size_t> tinf.raw.ctypes.data
         rc = pga_set_models(self.ctx, &ptr, 1)
         if rc != PGA_OK:
             _raise_for(self.ctx, rc, "pga_set_models")
         self.loaded = tinf.raw
+        self.loaded_version = tinf._version
         return 0
 
 cdef _StageContext _STAGE = _StageContext()
@@ -570,7 +588,8 @@ cdef class Sequence:
         """GC fraction over the known bases (ref: lib.pyx:608-614)."""
         self._build()
         cdef ssize_t n = len(self.data)
-        return self._gc * n / (n - self._unknown) if n > self._unknown else 0.0
+        cdef double gc_count = round(self._gc * <double> n)      # the device returns count / length; the count is recovered exactly
+        return gc_count / (<double> n - <double> self._unknown) if n > self._unknown else 0.0
 
     @property
     def masks(self):
@@ -748,11 +767,11 @@ cdef class ConnectionScorer:
         cdef ssize_t n = len(nodes)
         cdef int rc
         cdef int32_t mi = -1
-        if not final:
-            raise NotImplementedError("the training pass (final=False) is not available on the HIP path")
         f = nodes._f
         if "cscore" not in f:
             nodes.reset_scores()
+        if not final:
+            return self._score_connections_training(nodes, training_info)
         cdef object ndx = np.ascontiguousarray(f["ndx"], np.int32), stop_val = np.ascontiguousarray(f["stop_val"], np.int32)
         cdef object typ = np.ascontiguousarray(f["type"], np.uint8), strand = np.ascontiguousarray(f["strand"], np.int8)
         cdef object cs = np.ascontiguousarray(f["cscore"], np.float64), ss = np.ascontiguousarray(f["sscore"], np.float64)
@@ -773,6 +792,38 @@ cdef class ConnectionScorer:
                                            <int8_t*> p_ov, &mi, NULL)
             if rc != PGA_OK:
                 _raise_for(_STAGE.ctx, rc, "pga_score_connections")
+        f["score"] = score; f["traceb"] = traceb; f["ov_mark"] = ov
+        return int(mi)
+
+    cdef object _score_connections_training(self, Nodes nodes, TrainingInfo training_info):
+        # final = False (the reference's default, ref: lib.pyx:1336-1357): a connection is worth its length times the
+        # frame-bias factor bias . gc_score of one of its nodes (ref: _connection.h, `final == false` branches).  Nodes that
+        # never went through the training carry gc_score = 0, as in the reference after reset_scores().
+        cdef ssize_t n = len(nodes)
+        cdef int rc
+        cdef int32_t mi = -1
+        f = nodes._f
+        cdef object ndx = np.ascontiguousarray(f["ndx"], np.int32), stop_val = np.ascontiguousarray(f["stop_val"], np.int32)
+        cdef object typ = np.ascontiguousarray(f["type"], np.uint8), strand = np.ascontiguousarray(f["strand"], np.int8)
+        cdef object gcs = np.ascontiguousarray(f["gc_score"] if "gc_score" in f else np.zeros((n, 3)), np.float64).reshape(-1)
+        cdef object bias = np.ascontiguousarray(training_info.bias, np.float64)
+        cdef object sp = np.ascontiguousarray(f["star_ptr"], np.int32)
+        cdef object score = np.zeros(n, np.float64), traceb = np.full(n, -1, np.int32), ov = np.full(n, -1, np.int8)
+        if gcs.size != 3 * n:
+            raise ValueError("`gc_score` must hold three frame scores per node")
+        cdef size_t p_ndx = ndx.ctypes.data, p_stop = stop_val.ctypes.data, p_typ = typ.ctypes.data, p_strand = strand.ctypes.data
+        cdef size_t p_gcs = gcs.ctypes.data, p_bias = bias.ctypes.data, p_sp = sp.ctypes.data
+        cdef size_t p_score = score.ctypes.data, p_tb = traceb.ctypes.data, p_ov = ov.ctypes.data
+        cdef double st_wt = training_info.start_weight
+        with _STAGE.lock:
+            _STAGE.ensure()
+            with nogil:
+                rc = pga_score_connections_training(_STAGE.ctx, <int32_t> n, <const int32_t*> p_ndx, <const int32_t*> p_stop,
+                                                    <const uint8_t*> p_typ, <const int8_t*> p_strand, <const double*> p_gcs,
+                                                    <const double*> p_bias, <const int32_t*> p_sp, st_wt, <double*> p_score,
+                                                    <int32_t*> p_tb, <int8_t*> p_ov, &mi, NULL)
+            if rc != PGA_OK:
+                _raise_for(_STAGE.ctx, rc, "pga_score_connections_training")
         f["score"] = score; f["traceb"] = traceb; f["ov_mark"] = ov
         return int(mi)
 
@@ -1171,6 +1222,7 @@ cdef class GeneFinder:
     cdef ssize_t _num_seq
     cdef pga_ctx* ctx
     cdef bint models_loaded
+    cdef object models_sig      # (id(raw), version) of every model as loaded: a TrainingInfo changed in place is reloaded
 
     def __cinit__(self):
         self.ctx = NULL
@@ -1241,12 +1293,16 @@ cdef class GeneFinder:
             if rc != PGA_OK:
                 self.ctx = NULL
                 _raise_for(NULL, rc, "pga_create")
-        if self.models_loaded:
-            return 0
+        cdef list tinfs
         if self.meta:
-            blobs = [(<MetagenomicBin> b).training_info.raw for b in self.metagenomic_bins]
+            tinfs = [(<MetagenomicBin> b).training_info for b in self.metagenomic_bins]
         else:
-            blobs = [(<TrainingInfo> self.training_info).raw]
+            tinfs = [self.training_info]
+        # the reference shares the struct by pointer, so a setter takes effect at the next call: reload when one moved
+        cdef tuple sig = tuple([(id((<TrainingInfo> t).raw), (<TrainingInfo> t)._version) for t in tinfs])
+        if self.models_loaded and sig == self.models_sig:
+            return 0
+        blobs = [(<TrainingInfo> t).raw for t in tinfs]
         n = len(blobs)
         ptrs = <const pga_training**> malloc(sizeof(void*) * max(n, 1))
         if ptrs == NULL:
@@ -1260,6 +1316,7 @@ cdef class GeneFinder:
         if rc != PGA_OK:
             _raise_for(self.ctx, rc, "pga_set_models")
         self.models_loaded = True
+        self.models_sig = sig
         return 0
 
     def find_genes(self, object sequence):
@@ -1270,11 +1327,16 @@ cdef class GeneFinder:
         """`find_genes` for many sequences in one device pass; returns one `Genes` per input, in order."""
         if not self.meta and self.training_info is None:
             raise RuntimeError("cannot find genes without having trained in single mode")
-        cdef list seqs = [s if isinstance(s, Sequence) else Sequence(s, mask=self.mask, mask_size=self.min_mask) for s in sequences]
-        for s in seqs:      # one device pass = one masking rule (ref: lib.pyx:5433-5438 builds the Sequence with the finder's)
-            if (<Sequence> s).mask != self.mask or (self.mask and <int> (<Sequence> s).mask_size != self.min_mask):
-                raise ValueError("sequence masking (mask=%r, mask_size=%d) differs from the GeneFinder's (mask=%r, min_mask=%d)"
-                                 % ((<Sequence> s).mask, (<Sequence> s).mask_size, self.mask, self.min_mask))
+        # the reference always re-wraps with the finder's masking rule (ref: lib.pyx:5433-5438); a Sequence that already
+        # follows it is used as it is
+        cdef list seqs = []
+        for s in sequences:
+            if isinstance(s, Sequence):
+                if (<Sequence> s).mask != self.mask or (self.mask and <int> (<Sequence> s).mask_size != self.min_mask):
+                    s = Sequence((<Sequence> s).data, mask=self.mask, mask_size=self.min_mask)
+            else:
+                s = Sequence(s, mask=self.mask, mask_size=self.min_mask)
+            seqs.append(s)
         cdef int n = len(seqs), i, j, rc
         cdef const char** ptrs = <const char**> malloc(sizeof(char*) * max(n, 1))
         cdef int64_t* lens = <int64_t*> malloc(sizeof(int64_t) * max(n, 1))

@@ -76,3 +76,21 @@ def test_train_then_find_through_the_host_layer():
         lib.GeneFinder().train(seq[:50000])                      # shorter than IDEAL_SINGLE_GENOME
     with pytest.raises(RuntimeError):
         lib.GeneFinder(meta=True).train(seq)
+
+
+def test_train_leaves_the_loaded_model_set_in_place():
+    """pga_set_models(bins) ... pga_train ... pga_find_genes(meta) keeps scoring with the bins: the training runs its
+    half-trained model through the context's model slot and puts the caller's set back."""
+    from pyrodigal_amd import _cabi, benchdata
+    models = [m[1] for m in benchdata.load_model_set()]
+    seqs = [benchdata.synthetic_contig(30000, gc, 40 + i) for i, gc in enumerate((0.4, 0.55))]
+    c = _cabi.Context(0)
+    try:
+        c.set_models(models)
+        want = c.find_genes_batch(seqs, meta=True)
+        c.train(read_fasta("SRR492066.fna.gz")[0][1])
+        got = c.find_genes_batch(seqs, meta=True)
+        assert np.array_equal(want.contigs["model"], got.contigs["model"])
+        assert want.genes.tobytes() == got.genes.tobytes()
+    finally:
+        c.close()
