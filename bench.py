@@ -1,14 +1,19 @@
 """Headline benchmark: Mbp/s gene-called in meta mode (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload config4|config3|config2|config5]
 
-One "step" = one full pass of the gene-finding path over this rank's batch, which is already
-resident in HBM (`pga_batch_create`): digitise -> node extraction -> node scoring -> connection
-scoring DP for every model in the contig's GC window -> winner -> genes in host memory.
-Workload (config.workload): BASELINE.json configs[1], one 5 Mbp synthetic contig at 50 % GC per
-rank (seed 1234 + rank), 16 custom metagenomic bins (see pyrodigal_amd/benchdata.py).
-N > 1 (launched by torch.distributed.run): contigs are independent, so ranks share nothing in the
-data path; rank 0 receives every rank's gene records through one RCCL all_gather ("weak" scaling).
+Workload (config.workload), the same fixed job at every N ("strong" scaling): BASELINE.json configs[3], the
+100 000 x 20 kbp metagenome-like contigs (seed 1 000 000 + c, GC 30..70 %), meta mode over 16 custom
+metagenomic bins (pyrodigal_amd/benchdata.py).  Every rank plans the whole job from the contigs' (length, GC) alone
+(static greedy packing by estimated node-passes, pyrodigal_amd/distributed.py), generates only its own contigs and keeps
+them resident in HBM (`pga_batch_create`, sub-batches of --sub-batch contigs).  One "step" = one full pass of the
+gene-finding path over the whole job: per sub-batch digitise -> node extraction -> node scoring -> connection scoring
+for every model in the contig's GC window -> winner -> genes in host memory, then ONE gather of the packed gene records
+to rank 0 (RCCL over xGMI; contigs are independent, so there is no collective in the data path).
+`value` = bases of the whole job / max-over-ranks step time.  `host_to_host` repeats the timed loop from ASCII contigs
+in host memory (upload inside the timed region, SURVEY 8d's definition of the metric), reported next to `value`.
+At N = 1 the other single-GPU configurations of BASELINE.json (configs[1], [2], [4]) are timed as well (`secondary`),
+each with its own connection-scoring roofline.
 """
 import argparse
 import json
@@ -23,23 +28,112 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_PER_NODE_PASS = 64.0     # compulsory SoA bytes per DP node-pass
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+
+# every kernel of a segmented connection-scoring launch (pga_launch_dp with a plan), for the rocprof summaries
+SEGMENTED_DP_KERNELS = ["k_dp_tree_mw", "k_seg_gather", "k_seg_weights", "k_seg_height", "k_spine_count",
+                        "k_spine_scan", "k_spine_fill", "k_dp_rescore", "k_seg_leaves", "k_seg_build_far", "k_seg_build_upper",
+                        "k_dp_verify"]
+
+
+def roofline(ctx, dp_ms, passes, calls, n_chains, wname):
+    """Connection scoring against the HBM roofline: 64 B x node-passes / kernel time (HIP events on the library's stream,
+    summed over the calls of the timed region)."""
+    achieved = BYTES_PER_NODE_PASS * passes / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
+    r = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(wname),
+         "kernel": "k_dp_tree_mw" if n_chains < 2048 else ctx.dp_kernel_name(),
+         "kernel_ms_per_launch": round(dp_ms / max(calls, 1), 4), "launches": calls,
+         "node_passes_per_launch": int(passes // max(calls, 1)), "chains_per_launch": n_chains,
+         "bytes_per_node_pass": BYTES_PER_NODE_PASS}
+    seg = ctx.dp_stats()
+    if seg["chains"] > 0:
+        # few long chains: the connection scoring is one group of kernels (speculative segment walks, exact
+        # re-scoring, verification; dp.hip "segmented chains"), timed as a whole by the same pair of events
+        r["kernel"] = "connection scoring, segmented (k_dp_tree_mw + k_dp_rescore + k_dp_verify + helpers)"
+        r["kernels"] = SEGMENTED_DP_KERNELS
+        r["segments"] = seg["segments"]
+        r["rejected_by_verification"] = seg["rejected"]
+        r["chains_walked_serially"] = seg["serial"]
+    return r
+
+
+def pmc_traffic(workload):
+    """HBM bytes per launch of the connection-scoring kernel from the separate rocprofv3 --pmc passes of this round
+    (profiles/r02_pmc_traffic.json; how it was collected and corrected is written in that file)."""
+    try:
+        with open(PMC_FILE) as f:
+            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+    except OSError:
+        return None
+
+
+def timed_steps(ctx, batches, steps, warmup, sync, gather, **kw):
+    """W untimed + K timed passes over the resident batches; returns (seconds, dp_ms, node_passes, calls, last results)."""
+    res = []
+    for _ in range(warmup):
+        res = [ctx.find_genes(b, **kw) for b in batches]
+        gather(res)
+    sync()
+    t0 = time.perf_counter()
+    dp_ms, passes, calls = 0.0, 0, 0
+    genes = None
+    for _ in range(steps):
+        res = [ctx.find_genes(b, **kw) for b in batches]
+        genes = gather(res)
+        for r in res:
+            dp_ms += r.t_dp_ms; passes += r.node_passes; calls += 1
+    sync()
+    return time.perf_counter() - t0, dp_ms, passes, calls, res, genes
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="config2", choices=["config2", "config3"])
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="config4", choices=["config4", "config3", "config2", "config5"])
+    ap.add_argument("--contigs", type=int, default=100_000, help="config4: contigs of the whole job")
+    ap.add_argument("--sub-batch", type=int, default=12_500, help="contigs per device call")
+    ap.add_argument("--gen-procs", type=int, default=0, help="worker processes generating the synthetic contigs (0: up to 32; 1: none, e.g. under rocprofv3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
 
-    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus must equal WORLD_SIZE")
+
+    # torch first: it brings its own copy of the HIP runtime, and the C-ABI library must bind to that one (the same
+    # process cannot run two)
+    import torch
+    from pyrodigal_amd import benchdata, distributed
+    models = benchdata.load_model_set()
+    model_gcs = [float(np.frombuffer(m[1][:8], np.float64)[0]) for m in models]
+    # ---- the job and this rank's share of it; generated by spawned worker processes
+    single = args.workload == "config5"
+    if args.workload == "config4":
+        lengths, gcs, seeds = benchdata.config4_spec(args.contigs)
+        wname = "%dx20kbp_gc30-70_meta" % args.contigs
+    elif args.workload == "config3":
+        c = np.arange(1000)
+        lengths, gcs, seeds = np.full(1000, 50_000), 0.30 + 0.40 * (c % 41) / 40, 10_000 + c
+        wname = "1000x50kbp_gc30-70_meta"
+    elif args.workload == "config2":
+        lengths, gcs, seeds = np.array([5_000_000]), np.array([0.50]), np.array([1234])
+        wname = "1x5Mbp_gc50_meta"
+    else:
+        lengths, gcs, seeds = np.array([200_000_000]), np.array([0.65]), np.array([5])
+        wname = "1x200Mbp_gc65_single"
+    work = distributed.estimate_work_known(lengths, gcs, None if single else model_gcs)
+    mine = distributed.pack_contigs(work, world)[rank]        # a single contig does not shard: ranks > 0 idle on configs 2 / 5
+    t_gen = time.perf_counter()
+    seqs = benchdata.generate(lengths[mine], gcs[mine], seeds[mine], procs=args.gen_procs or None)
+    t_gen = time.perf_counter() - t_gen
+    job_bases = int(np.sum(lengths))
+
     ndev = max(1, torch.cuda.device_count())
     dev_index = local_rank % ndev                      # one process per GPU (ranks wrap only in single-GPU smoke tests)
     torch.cuda.set_device(dev_index)
@@ -54,18 +148,22 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from pyrodigal_amd import _cabi, benchdata, distributed
-    models = benchdata.load_model_set()
+    from pyrodigal_amd import _cabi
     ctx = _cabi.Context(dev_index)
-    ctx.set_models([m[1] for m in models])
-    if args.workload == "config2":
-        seqs = benchdata.config2(rank)
-        wname = "1x5Mbp_gc50_meta_per_gpu"
+    if single:
+        from tests.util import golden_path
+        import gzip
+        with gzip.open(golden_path("GCF_001457455.1_NCTC11397_genomic.tinf_closed.bin.gz")) as f:
+            ctx.set_models([f.read()])
+        kw = dict(meta=False, closed=True)
     else:
-        seqs = benchdata.config3(1000, 50_000, first=1000 * rank)
-        wname = "1000x50kbp_gc30-70_meta_per_gpu"
-    bases = sum(len(s) for s in seqs)
-    batch = ctx.upload(seqs)
+        ctx.set_models([m[1] for m in models])
+        kw = dict(meta=True)
+    sub = max(1, args.sub_batch)
+    groups = [seqs[i:i + sub] for i in range(0, len(seqs), sub)]
+    batches = [ctx.upload(g) for g in groups]
+    base_of = np.cumsum([0] + [len(g) for g in groups])
+    mine_arr = np.asarray(mine, np.int32)
 
     def sync():
         torch.cuda.synchronize()
@@ -73,66 +171,69 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def gather(results):
+        """This rank's gene records with job-wide contig numbers, then the one exchange of the job: a gather to rank 0."""
+        parts = []
+        for k, r in enumerate(results):
+            g = r.genes
+            if len(g):
+                g = g.copy()
+                g["contig"] = mine_arr[base_of[k] + g["contig"]]
+            parts.append(g)
+        g = np.concatenate(parts) if parts else np.zeros(0, _cabi.GENE_DTYPE)
+        return distributed.gather_genes(g, dist, device=xdev, dst=0)
+
     # Bring the device out of its idle power state before the warmup steps proper: after a pause (the host was busy
-    # generating the synthetic contigs) the first ~100 ms of work run at ramping clocks and would otherwise leak into
-    # the timed steps when W is small.  Untimed, like the warmup.
+    # generating the synthetic contigs) the first ~100 ms of work run at ramping clocks.  Untimed, like the warmup.
     t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < 0.5:
-        ctx.find_genes(batch, meta=True)
-    res = None
-    for _ in range(args.warmup):
-        res = ctx.find_genes(batch, meta=True)
-        distributed.gather_genes(res.genes, dist, device=xdev)
-    sync()
-    t0 = time.perf_counter()
-    dp_ms, passes = 0.0, 0
-    for _ in range(args.steps):
-        res = ctx.find_genes(batch, meta=True)
-        all_genes = distributed.gather_genes(res.genes, dist, device=xdev)
-        dp_ms += res.t_dp_ms
-        passes += res.node_passes
-    sync()
-    elapsed = time.perf_counter() - t0
+    while batches and time.perf_counter() - t_pre < 0.5:
+        ctx.find_genes(batches[0], **kw)
+    elapsed, dp_ms, passes, calls, res, all_genes = timed_steps(ctx, batches, args.steps, args.warmup, sync, gather, **kw)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- the same loop from host memory: upload inside the timed region (SURVEY 8d's definition of the metric)
+    h2h_steps = max(1, min(args.steps, 3))
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(h2h_steps):
+        gather([ctx.find_genes_batch(g, **kw) for g in groups])
+    sync()
+    h2h = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([h2h], dtype=torch.float64, device=xdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        h2h = float(t.item())
+
     out = None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        value = world * bases * args.steps / elapsed / 1e6
-        achieved = BYTES_PER_NODE_PASS * passes / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
+        value = job_bases * args.steps / elapsed / 1e6
+        n_chains = max([r.n_chains for r in res], default=0)
         out = {
-            "metric": "Mbp/sec gene-called (meta mode)", "value": round(value, 3), "unit": "Mbp/s",
+            "metric": "Mbp/sec gene-called (meta mode)" if not single else "Mbp/sec gene-called (single mode)",
+            "value": round(value, 3), "unit": "Mbp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": wname, "contigs_per_gpu": len(seqs), "bases_per_gpu": bases, "models": len(models),
-                       "node_passes_per_step": res.node_passes, "genes_rank0": int(len(res.genes)),
-                       "genes_all_ranks": int(len(all_genes)), "parallelism": "contig-sharded x%d" % world},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                         "kernel": "k_dp_tree_mw" if res.n_chains < 2048 else "k_dp_tree",
-                         "kernel_ms_per_step": round(dp_ms / args.steps, 3), "chains": res.n_chains,
-                         "bytes_per_node_pass": BYTES_PER_NODE_PASS},
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": wname, "contigs": int(len(lengths)), "bases": job_bases, "models": 1 if single else len(models),
+                       "contigs_rank0": len(seqs), "device_calls_per_step_rank0": len(batches), "sub_batch_contigs": sub,
+                       "node_passes_per_step_rank0": int(passes // max(args.steps, 1)),
+                       "genes_all_ranks": int(len(all_genes)) if all_genes is not None else 0,
+                       "parallelism": "contigs packed by estimated work over %d GPU(s), one gather of gene records to rank 0" % world,
+                       "inputs": "resident in HBM before the timed region", "generate_s_rank0": round(t_gen, 2)},
+            "host_to_host": {"value": round(job_bases * h2h_steps / h2h / 1e6, 3), "unit": "Mbp/s", "steps": h2h_steps,
+                             "ms_per_step": round(1e3 * h2h / h2h_steps, 3),
+                             "what": "same loop from ASCII contigs in host memory: packing, H2D, path, genes in host memory, gather"},
+            "roofline": roofline(ctx, dp_ms, passes, calls, n_chains, wname),
         }
-        seg = ctx.dp_stats()
-        if seg["chains"] > 0:
-            # few long chains: the connection scoring is one group of kernels (speculative segment walks, exact
-            # re-scoring, verification; dp.hip "segmented chains"), timed as a whole by the same pair of events
-            out["roofline"]["kernel"] = "connection scoring, segmented (k_dp_tree_mw + k_dp_rescore + k_dp_verify + helpers)"
-            out["roofline"]["kernels"] = SEGMENTED_DP_KERNELS
-            out["roofline"]["segments"] = seg["segments"]
-            out["roofline"]["rejected_by_verification"] = seg["rejected"]
-            out["roofline"]["chains_walked_serially"] = seg["serial"]
-        out["roofline"]["traffic"] = pmc_traffic(wname)
-        # PCIe-inclusive rate (upload + find), reported next to `value`, never as `value`
-        t1 = time.perf_counter()
-        ctx.find_genes_batch(seqs, meta=True)
-        out["config"]["pcie_inclusive_Mbp_s"] = round(bases / (time.perf_counter() - t1) / 1e6, 3)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(seqs, models, res)
-    batch.close()
+        if world == 1 and not args.no_cpu_baseline and not single:
+            out["cpu_baseline"] = cpu_baseline(seqs, models, res[0] if res else None)
+    for b in batches:
+        b.close()
+    if rank == 0 and world == 1 and not args.no_secondary:
+        out["secondary"] = secondary(ctx, _cabi, benchdata, models, args.workload, sync)
     ctx.close()
     if dist is not None:
         dist.barrier()
@@ -141,29 +242,49 @@ def main():
         print(json.dumps(out))
 
 
-# every kernel of a segmented connection-scoring launch (pga_launch_dp with a plan), for the rocprof summaries
-SEGMENTED_DP_KERNELS = ["k_dp_tree_mw", "k_seg_gather", "k_seg_weights", "k_seg_height", "k_spine_count",
-                        "k_spine_scan", "k_spine_fill", "k_dp_rescore", "k_seg_leaves", "k_seg_build_far", "k_seg_build_upper",
-                        "k_dp_verify"]
+def secondary(ctx, _cabi, benchdata, models, headline, sync):
+    """The other single-GPU configurations of BASELINE.json, a few steps each, inputs resident in HBM."""
+    import gzip
+    from tests.util import golden_path
+    out = {}
+    plans = [("config2", "1x5Mbp_gc50_meta", lambda: benchdata.config2(0), dict(meta=True), 10),
+             ("config3", "1000x50kbp_gc30-70_meta", lambda: benchdata.generate(*_config3_spec()), dict(meta=True), 10),
+             ("config5", "1x200Mbp_gc65_single", benchdata.config5, dict(meta=False, closed=True), 3)]
+    for key, wname, make, kw, steps in plans:
+        if key == headline:
+            continue
+        seqs = make()
+        if key == "config5":
+            with gzip.open(golden_path("GCF_001457455.1_NCTC11397_genomic.tinf_closed.bin.gz")) as f:
+                ctx.set_models([f.read()])
+        else:
+            ctx.set_models([m[1] for m in models])
+        b = ctx.upload(seqs)
+        elapsed, dp_ms, passes, calls, res, _ = timed_steps(ctx, [b], steps, 2, sync, lambda r: None, **kw)
+        bases = sum(len(s) for s in seqs)
+        t1 = time.perf_counter()
+        ctx.find_genes_batch(seqs, **kw)
+        h2h = time.perf_counter() - t1
+        out[key] = {"workload": wname, "value": round(bases * steps / elapsed / 1e6, 3), "unit": "Mbp/s", "steps": steps,
+                    "ms_per_step": round(1e3 * elapsed / steps, 3), "genes": int(len(res[0].genes)),
+                    "host_to_host_Mbp_s": round(bases / h2h / 1e6, 3),
+                    "roofline": roofline(ctx, dp_ms, passes, calls, res[0].n_chains, wname)}
+        b.close()
+    return out
 
 
-def pmc_traffic(workload):
-    """HBM bytes per launch of the DP kernel from the separate rocprofv3 --pmc passes of this round
-    (profiles/r01_pmc_traffic.json: FETCH_SIZE x 2 (gfx950 correction for wide loads) + WRITE_SIZE, in bytes)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
-    except OSError:
-        return None
+def _config3_spec():
+    c = np.arange(1000)
+    return np.full(1000, 50_000), 0.30 + 0.40 * (c % 41) / 40, 10_000 + c
 
 
 def cpu_baseline(seqs, models, gpu_res):
-    """The CPU oracle (a C port of pyrodigal's CPU path: byte pre-filter + split scorers), one thread,
-    on a bounded sample of the same workload; also the gene-call parity check of this run."""
+    """The CPU oracle (a C port of pyrodigal's CPU path: byte pre-filter + split scorers) on a bounded sample of the same
+    workload: one thread (also the gene-call parity check of this run), then one contig per thread on every host core."""
     from oracle import oracle as orc
     bins = [orc.Training(m[1]) for m in models]
-    budget_bases = 5_000_000
-    done, t_cpu, match, total_genes = 0, 0.0, True, 0
+    budget_bases = 12_000_000 if len(seqs) > 1 else 5_000_000
+    done, t_cpu, match, total_genes, i = 0, 0.0, True, 0, -1
     for i, s in enumerate(seqs):
         if done >= budget_bases:
             break
@@ -172,11 +293,13 @@ def cpu_baseline(seqs, models, gpu_res):
         phase = o.find_genes_meta(bins)
         t_cpu += time.perf_counter() - t0
         done += len(s)
-        og, gg = o.genes(), gpu_res.genes_of(i)
+        og = o.genes()
         total_genes += len(og)
-        ok = gpu_res.contigs[i]["model"] == phase and len(og) == len(gg) and all(
-            np.array_equal(og[k], gg[k]) for k in ("begin", "end", "start_ndx", "stop_ndx"))
-        match = match and bool(ok)
+        if gpu_res is not None and i < len(gpu_res.contigs):
+            gg = gpu_res.genes_of(i)
+            ok = gpu_res.contigs[i]["model"] == phase and len(og) == len(gg) and all(
+                np.array_equal(og[k], gg[k]) for k in ("begin", "end", "start_ndx", "stop_ndx"))
+            match = match and bool(ok)
     out = {"value": round(done / t_cpu / 1e6, 3), "unit": "Mbp/s", "cores": 1, "kind": "port",
            "sample": "%d contig(s), %d bp, same 16 models, meta mode, 1 thread (%s)" % (i + (done >= budget_bases), done, _cpu_name()),
            "gene_calls_identical_to_gpu": match, "genes_in_sample": total_genes, "host_cpus": os.cpu_count()}
@@ -192,7 +315,7 @@ def cpu_baseline_all_cores(seqs, bins):
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as orc
     cores = os.cpu_count() or 1
-    sample = seqs[:min(len(seqs), 4 * cores)]
+    sample = seqs[:min(len(seqs), 8 * cores)]
 
     def one(s):
         o = orc.Oracle(s)            # ctypes releases the GIL inside the C calls

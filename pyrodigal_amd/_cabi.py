@@ -182,6 +182,11 @@ class Context:
             _raise(self.L, self.h, rc, "pga_dp_stats")
         return {"chains": out[0], "segments": out[1], "rejected": [out[2], out[3], out[4]], "serial": out[5]}
 
+    @staticmethod
+    def dp_kernel_name():
+        """The connection-scoring kernel a launch with many (>= 2048) chains runs (dp.hip, pga_launch_dp)."""
+        return {"tree1": "k_dp_tree", "scan": "k_dp_chain"}.get(os.environ.get("PGA_DP_KERNEL", ""), "k_dp_wave")
+
     def set_models(self, blobs):
         """``blobs``: iterable of 558 392-byte ``struct _training`` buffers (bytes / uint8 arrays)."""
         arrs = []

@@ -36,6 +36,38 @@ def config4_shard(rank, world, n_total=100_000, length=20_000):
     return [synthetic_contig(length, 0.30 + 0.40 * (c % 41) / 40, 1_000_000 + c) for c in range(rank, n_total, world)]
 
 
+def config4_spec(n_total=100_000, length=20_000):
+    """(length, gc, seed) of every contig of the 100 000 x 20 kbp job, known without generating a base."""
+    c = np.arange(n_total)
+    return np.full(n_total, length), 0.30 + 0.40 * (c % 41) / 40, 1_000_000 + c
+
+
+def config5():
+    """One 200 Mbp contig at 65 % GC (BASELINE.json configs[4]; run in single mode)."""
+    return [synthetic_contig(200_000_000, 0.65, 5)]
+
+
+def _gen_chunk(args):
+    return [synthetic_contig(int(n), float(gc), int(seed)) for n, gc, seed in args]
+
+
+def generate(lengths, gcs, seeds, procs=None):
+    """`synthetic_contig` for many contigs on several host cores (the generator itself is the spec's, one seed per contig,
+    so the result does not depend on how the work is split)."""
+    items = list(zip(lengths, gcs, seeds))
+    procs = procs or min(32, os.cpu_count() or 1)
+    if procs <= 1 or len(items) < 64:
+        return _gen_chunk(items)
+    # spawned workers (never forked: the parent may hold a HIP runtime, and a forked copy of one is not usable); they import
+    # this module only, which loads nothing but numpy
+    import multiprocessing as mp
+    step = max(16, len(items) // (procs * 8))
+    chunks = [items[i:i + step] for i in range(0, len(items), step)]
+    with mp.get_context("spawn").Pool(procs) as pool:
+        out = pool.map(_gen_chunk, chunks)
+    return [s for part in out for s in part]
+
+
 def _read(path):
     opener = gzip.open if path.endswith(".gz") else open
     with opener(path, "rb") as f:

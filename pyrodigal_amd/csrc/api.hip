@@ -1,6 +1,7 @@
 // C-ABI entry points (include/pyrodigal_amd.h): context, models, scorer-level call.
 // Host code only; no CPU compute path exists here -- without a gfx950 device every call fails.
 #include "pga_internal.h"
+#include "dpw_core.h"
 
 #include <algorithm>
 
@@ -202,7 +203,8 @@ static int score_connections_impl(pga_ctx* c, int32_t n, const int32_t* ndx, con
     ChainDesc ch{0, 0, n, 0, 0, 1};
     // a long chain is cut into segments walked side by side (dp.hip "segmented chains")
     DpSegPlan seg_plan;
-    const bool segmented = final && pga_dp_plan(&ch, 1, n, seg_plan);
+    const bool use_wave = final && pga_dp_use_wave(1);          // one chain: only when PGA_DP_KERNEL=wave asks for it
+    const bool segmented = final && !use_wave && pga_dp_plan(&ch, 1, n, seg_plan);
     const size_t N = (size_t)n + (size_t)seg_plan.extra, NS = 1 + seg_plan.segs.size();
     HIP_TRY(c, db.alloc(&nd.ndx, N)); HIP_TRY(c, db.alloc(&nd.stop_val, N)); HIP_TRY(c, db.alloc(&nd.type, N));
     HIP_TRY(c, db.alloc(&nd.strand, N)); HIP_TRY(c, db.alloc(&nd.cscore, N)); HIP_TRY(c, db.alloc(&nd.sscore, N));
@@ -238,10 +240,28 @@ static int score_connections_impl(pga_ctx* c, int32_t n, const int32_t* ndx, con
     UP(d_chain, &ch, sizeof ch); UP(d_mc, &mc, sizeof mc);
 #undef UP
     NodeArrays na{nd.ndx, nd.stop_val, nd.type, nd.strand, nd.cscore, nd.sscore, nd.rscore, nd.uscore, nd.star_ptr, d_gcb};
-    pga_launch_dp_prepare(d_chain, 1, 0, n, na, d_mc, buf, st, final);
-    HIP_TRY(c, hipEventRecord(c->ev0, st));
-    pga_launch_dp(d_chain, 1, d_mc, buf, final, st, segmented ? &seg_dev : nullptr);
-    HIP_TRY(c, hipEventRecord(c->ev1, st));
+    if (use_wave) {
+        DpwGroupPtrs wg{};
+        DpwBuffers wb{};
+        int32_t* d_cbase;
+        const int32_t h_cbase[2] = {0, n};
+        HIP_TRY(c, db.alloc(&wg.g[0].kf, N)); HIP_TRY(c, db.alloc(&wg.g[0].lo, N)); HIP_TRY(c, db.alloc(&wg.g[0].q1, N)); HIP_TRY(c, db.alloc(&wg.g[0].q2, N));
+        HIP_TRY(c, db.alloc(&wb.cs, N)); HIP_TRY(c, db.alloc(&wb.ext, N)); HIP_TRY(c, db.alloc(&wb.sfxv, N)); HIP_TRY(c, db.alloc(&wb.sfxi, N));
+        HIP_TRY(c, db.alloc(&d_cbase, 2));
+        HIP_TRY(c, hipMemcpyAsync(d_cbase, h_cbase, sizeof h_cbase, hipMemcpyHostToDevice, st));
+        wg.g[0].ndx = nd.ndx; wg.g[0].stop_val = nd.stop_val;
+        pga_launch_dpw_topo(wg.g[0], nd.type, nd.strand, d_cbase, 1, n, st);
+        pga_launch_dpw_chain(d_chain, 1, 0, n, na, wg.g[0], d_mc, wb, st);
+        HIP_TRY(c, hipEventRecord(c->ev0, st));
+        pga_launch_dp_wave(d_chain, 1, wg, d_mc, buf, wb, st);
+        HIP_TRY(c, hipEventRecord(c->ev1, st));
+        HIP_TRY(c, hipStreamSynchronize(st));                  // h_cbase lives on this stack frame
+    } else {
+        pga_launch_dp_prepare(d_chain, 1, 0, n, na, d_mc, buf, st, final);
+        HIP_TRY(c, hipEventRecord(c->ev0, st));
+        pga_launch_dp(d_chain, 1, d_mc, buf, final, st, segmented ? &seg_dev : nullptr);
+        HIP_TRY(c, hipEventRecord(c->ev1, st));
+    }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(score, buf.score, 8 * NN, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(traceb, buf.traceb, 4 * NN, hipMemcpyDeviceToHost, st));
@@ -252,7 +272,13 @@ static int score_connections_impl(pga_ctx* c, int32_t n, const int32_t* ndx, con
     if (segmented) HIP_TRY(c, hipMemcpyAsync(h_flags, seg_dev.flags, sizeof h_flags, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     pga_dp_note_stats(c, segmented ? &seg_plan : nullptr, h_flags, 1);
-    if (buf.prof) {
+    if (buf.prof && use_wave) {
+        unsigned long long pr[16]; HIP_TRY(c, hipMemcpy(pr, buf.prof, 128, hipMemcpyDeviceToHost));
+        const double nbp = pr[7] ? (double)pr[7] : 1.0;
+        fprintf(stderr, "[pga dp profile] k_dp_wave batches=%llu cycles/batch: load=%.0f near steps=%.0f far gene ends=%.0f carries=%.0f chains=%.0f "
+                        "walk=%.0f finalize=%.0f | total=%.0f\n", pr[7], pr[0] / nbp, pr[1] / nbp, pr[2] / nbp, pr[3] / nbp, pr[4] / nbp, pr[5] / nbp,
+                pr[6] / nbp, (pr[0] + pr[1] + pr[2] + pr[3] + pr[4] + pr[5] + pr[6]) / nbp);
+    } else if (buf.prof) {
         unsigned long long pr[16]; HIP_TRY(c, hipMemcpy(pr, buf.prof, 128, hipMemcpyDeviceToHost));
         const double nbp = pr[5] ? (double)pr[5] : 1.0;
         fprintf(stderr, "[pga dp profile] batches=%llu cycles/batch: serial wave: previous batch=%.0f walk=%.0f publish=%.0f | weight helper=%.0f | "

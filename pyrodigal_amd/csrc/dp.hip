@@ -1615,6 +1615,12 @@ void pga_launch_dp_prepare(const ChainDesc* d_chains, int n_chains, int64_t node
                        d_chains, n_chains, node_begin, total_nodes, nodes, d_models, buf.src, buf.tgt, final);
 }
 
+bool pga_dp_use_wave(int n_chains) {
+    const char* kern = getenv("PGA_DP_KERNEL");
+    if (kern && *kern) return strcmp(kern, "wave") == 0;
+    return n_chains >= 2048;
+}
+
 static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return (e && *e) ? atoi(e) : dflt;

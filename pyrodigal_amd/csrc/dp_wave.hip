@@ -1,0 +1,531 @@
+// Wave-batch connection scoring for launches with many chains (one wavefront per (contig, model) chain).
+//
+// Same recurrence as dp.hip (ref: lib.pyx:1205-1237, _connection.h:94-408, impl/generic.h:29-36); what changes is where a
+// target's candidates come from.  Lane t of the wave owns target node i0 + t of the current 64-node batch.  Sources older than
+// the batch never cost a per-lane search:
+//   * far gene ends (F5 / R3 targets): every finished node leaves a = score + the constant intergenic term; the wave keeps, in
+//     registers, the lexicographic maxima of `a` over the last 64 whole blocks ending at the batch (S1) and at the block before
+//     (S2), and the inclusive prefix maxima inside the previous block; a window that starts inside a block reads that block's
+//     suffix maximum, stored once per node when the block was finished.  A far range is then at most three pieces;
+//   * forward stops: the best start / operon partner of the ORF met so far is a per-frame running maximum that restarts at every
+//     forward stop of the frame (a static bit of each forward stop says whether it lies in the ORF of the next stop of a frame);
+//   * reverse starts and reverse stops: only the LAST reverse stop of a frame can hold a later node in its ORF, so "own stop" and
+//     "operon partner" are three uniform records;
+//   * forward stops overlapping the 3' end of a reverse gene: a short chain through the forward stops (static links);
+//   * the few sources within 3 * OPER_DIST bases before the batch are visited pair by pair like the sources inside the batch:
+//     one wave-uniform source at a time (v_readlane), the serial critical path of a chain.
+// Every scalar routine lives in dpw_core.h and also runs on the host in tests/dpw_model.cpp, which is compared with the plain
+// restatement of the reference's loop on the CPU (tests/test_dpw_model.py); this file adds the wave mechanics.
+//
+// Records are SoA: topology arrays shared by every model of a contig (ndx, stop_val, kf, lo, q1, q2), per-chain cs and a
+// 64-byte record of extras per STOP node; results score / traceb / ov_mark / position of the traceb node, plus the suffix
+// maxima of chains longer than one window.
+
+#include "pga_internal.h"
+#include "dev_common.h"
+#include "dpw_core.h"
+
+namespace {
+
+__device__ __forceinline__ double rl_f64(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ int rl_i32(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+
+// contig of group node g (first-node offsets, n_contigs + 1 entries)
+__device__ __forceinline__ int contig_of_node(const int32_t* __restrict__ cbase, int n_contigs, int g) {
+    int lo = 0, hi = n_contigs - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (cbase[mid] <= g) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
+__global__ void __launch_bounds__(256)
+k_dpw_topo(const int32_t* __restrict__ ndx, const int32_t* __restrict__ stopv, const uint8_t* __restrict__ type, const int8_t* __restrict__ strand,
+           const int32_t* __restrict__ cbase, int n_contigs, int n_nodes, DpwTopoArrays ta) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_nodes) return;
+    const int c = contig_of_node(cbase, n_contigs, g);
+    const int b0 = cbase[c], n = cbase[c + 1] - b0;
+    const DpwTopo t = dpw_topo_node(ndx + b0, stopv + b0, type + b0, strand + b0, n, g - b0);
+    ta.kf[g] = t.kf; ta.lo[g] = t.lo; ta.q1[g] = t.q1; ta.q2[g] = t.q2;
+}
+
+__global__ void __launch_bounds__(256)
+k_dpw_chain(const ChainDesc* __restrict__ chains, int n_chains, int64_t node_begin, int64_t total, NodeArrays nd, DpwTopoArrays ta,
+            const ModelConst* __restrict__ models, double* __restrict__ cs, DpwExt* __restrict__ ext) {
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    g += node_begin;
+    const int c = find_chain(chains, n_chains, g);
+    const int64_t off = chains[c].off, toff = chains[c].topo_off;
+    const int i = (int)(g - off);
+    cs[g] = nd.cscore[g] + nd.sscore[g];
+    const int kind = DPW_KIND(ta.kf[toff + i]);
+    if (!(kind & 1)) return;
+    const ModelConst* mc = &models[chains[c].model];
+    const DpwModel M{mc->st_wt, mc->negc, mc->igm};
+    DpwExt e;
+    dpw_chain_ext(nd.ndx + toff, nd.stop_val + toff, nd.strand + toff, ta.q2 + toff, nd.cscore + off, nd.sscore + off, nd.rscore + off,
+                  nd.uscore + off, nd.star_ptr + off * 3, i, kind == 3, M, e);
+    ext[g] = e;
+}
+
+// lexicographic (value, index) maximum: ties go to the larger index
+__device__ __forceinline__ void lex_max(double& v, int& i, const double ov, const int oi) {
+    const bool c = ov > v || (ov == v && oi > i);
+    v = c ? ov : v; i = c ? oi : i;
+}
+// inclusive prefix (lower lanes first) of the lexicographic maximum
+__device__ __forceinline__ void wave_prefix_lexmax(double& v, int& i, const int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double ov = __shfl_up(v, d, 64); const int oi = __shfl_up(i, d, 64);
+        if (lane >= d) lex_max(v, i, ov, oi);
+    }
+}
+__device__ __forceinline__ void wave_suffix_lexmax(double& v, int& i, const int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double ov = __shfl_down(v, d, 64); const int oi = __shfl_down(i, d, 64);
+        if (lane + d < 64) lex_max(v, i, ov, oi);
+    }
+}
+// wave-wide lexicographic maximum, the same in every lane
+__device__ __forceinline__ void wave_all_lexmax(double& v, int& i) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double ov = __shfl_xor(v, m, 64); const int oi = __shfl_xor(i, m, 64);
+        lex_max(v, i, ov, oi);
+    }
+}
+
+struct WavePtrs {
+    const int32_t* __restrict__ ndx; const int32_t* __restrict__ stopv; const uint8_t* __restrict__ kf;
+    const int32_t* __restrict__ lo; const int32_t* __restrict__ q1; const int32_t* __restrict__ q2;
+    const double* __restrict__ cs; const DpwExt* __restrict__ ext;
+    double* score; int32_t* traceb; int32_t* tbn; int8_t* ov; double* sfxv; int32_t* sfxi;
+};
+
+__device__ __forceinline__ void load_ext(const DpwExt* __restrict__ e, DpwT& T) {
+    // one 64-byte record: four 16-byte loads
+    const int4* p = reinterpret_cast<const int4*>(e);
+    const int4 a = p[0], b = p[1], c = p[2], d = p[3];
+    T.x0 = __hiloint2double(a.y, a.x); T.x1 = __hiloint2double(a.w, a.z); T.x2 = __hiloint2double(b.y, b.x);
+    T.n3n0 = b.z; T.n3n1 = b.w; T.n3n2 = c.x; T.n3s0 = c.y; T.n3s1 = c.z; T.n3s2 = c.w;
+    T.cq0 = d.x; T.cq1 = d.y; T.cq2 = d.z; T.vm = d.w;
+}
+
+__device__ __forceinline__ void load_target_w(DpwT& T, int& kfb, const WavePtrs& P, const int i0, const int lane, const int n, const double negc) {
+    const int i = i0 + lane;
+    const bool act = i < n;
+    const int ii = act ? i : n - 1;
+    kfb = P.kf[ii];
+    T.i = act ? i : -1;
+    T.kind = act ? DPW_KIND(kfb) : -1; T.frame = DPW_FRAME(kfb);
+    T.ndx = P.ndx[ii]; T.stop_val = P.stopv[ii]; T.lo = act ? P.lo[ii] : INT_MAX; T.q1 = P.q1[ii]; T.q2 = P.q2[ii];
+    T.cs = P.cs[ii]; T.csd = T.cs + negc;
+    T.vm = 0; T.x0 = T.x1 = T.x2 = 0.0;
+    T.n3n0 = T.n3n1 = T.n3n2 = T.n3s0 = T.n3s1 = T.n3s2 = 0; T.cq0 = T.cq1 = T.cq2 = DPW_NONE;
+    if (act && (T.kind & 1)) load_ext(P.ext + ii, T);
+}
+
+// a forward stop met through a chain of candidates, as a source (its operon terms are not needed towards reverse targets)
+__device__ __forceinline__ DpwS load_f3_source(const WavePtrs& P, const int j, const int s_ndx) {
+    DpwS S;
+    S.j = j; S.kind = 1; S.frame = 0; S.ndx = s_ndx; S.stop_val = 0; S.vm = 0;
+    S.tbn = P.tbn[j]; S.score = P.score[j]; S.cs = 0.0; S.x0 = S.x1 = S.x2 = 0.0;
+    return S;
+}
+
+// Sources as the wave holds them: lane u of these registers is source u of a tile (a tile of finished nodes read back from
+// memory for the near steps; the batch itself for the walk).
+struct SrcRegs { int pack /* kind | frame << 2 | vm << 4 */, ndx, stop_val; double score, cs, x0, x1, x2; };
+
+// Lane masks of the batch's targets that do not change from step to step.  They are wave-uniform 64-bit values, i.e. they
+// live in scalar registers and a step combines them with scalar instructions; what depends on the source is one vector
+// compare per condition (its result is a lane mask again).
+typedef unsigned long long lanemask;
+struct WaveMasks {
+    lanemask act, gb, k2, k3;      // lanes with a node; gene begins (F5 or R3); reverse starts; reverse stops
+    lanemask f3f0, f3f1, f3f2;     // forward stops of frame f
+    lanemask r5f0, r5f1, r5f2;     // reverse starts of frame f
+    lanemask r3v0, r3v1, r3v2;     // reverse stops with an overlapping start in frame f
+};
+__device__ __forceinline__ lanemask vote(const bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool in_mask(const lanemask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+__device__ __forceinline__ lanemask pick3m(const int f, const lanemask a, const lanemask b, const lanemask c) { return f == 0 ? a : (f == 1 ? b : c); }
+__device__ __forceinline__ WaveMasks wave_masks(const DpwLT& T) {
+    WaveMasks W;
+    const bool act = T.i >= 0;
+    const bool k1 = act && T.kind == 1, k2 = act && T.kind == 2, k3 = act && T.kind == 3;
+    W.act = vote(act); W.gb = vote(act && (T.kind == 0 || T.kind == 3)); W.k2 = vote(k2); W.k3 = vote(k3);
+    W.f3f0 = vote(k1 && T.frame == 0); W.f3f1 = vote(k1 && T.frame == 1); W.f3f2 = vote(k1 && T.frame == 2);
+    W.r5f0 = vote(k2 && T.frame == 0); W.r5f1 = vote(k2 && T.frame == 1); W.r5f2 = vote(k2 && T.frame == 2);
+    W.r3v0 = vote(k3 && (T.vm & 1)); W.r3v1 = vote(k3 && (T.vm & 2)); W.r3v2 = vote(k3 && (T.vm & 4));
+    return W;
+}
+
+// One step: source u of R (chain index j) onto this lane's target; same rules as dpw_step (dpw_core.h), which the host model
+// checks against the plain restatement of the reference's loop.  The source is wave-uniform, so its kind is a scalar branch and each kind reads (v_readlane)
+// only the fields it needs; the step returns as soon as no lane can take the source.  `win`: lanes for which the source lies
+// inside the window and before the lane's node.  key_r5: a reverse start at s_ndx precedes this gene begin when
+// s_ndx < key_r5.  TBN() yields the position of the source's own traceb node, only asked for a forward stop.
+template <class TBN>
+__device__ __forceinline__ void wave_step(const SrcRegs& R, const int u, const int j, const lanemask win, const DpwLT& T, const WaveMasks& W,
+                                          const int key_r5, DpwLane& L, const DpwModel& M, TBN tbn_of) {
+    const int sp = rl_i32(R.pack, u);
+    const int sk = sp & 3, sf = (sp >> 2) & 3;
+    if (sk == 0) {
+        // forward start: only the forward stop of its ORF (ref: _connection.h:166-174)
+        lanemask ok = win & pick3m(sf, W.f3f0, W.f3f1, W.f3f2);
+        if (!ok) return;
+        ok &= vote(T.stop_val < rl_i32(R.ndx, u));
+        if (!ok) return;
+        const double val = rl_f64(R.score, u) + rl_f64(R.cs, u);
+        ok &= vote(val >= L.val);
+        if (in_mask(ok)) { L.val = val; L.tag = j; }
+    } else if (sk == 2) {
+        // reverse start, a gene end: every later gene begin (ref: :125-130, 337-342)
+        lanemask ok = win & W.gb;
+        if (!ok) return;
+        const int s_ndx = rl_i32(R.ndx, u);
+        ok &= vote(s_ndx < key_r5);
+        if (!ok) return;
+        double val = rl_f64(R.score, u) + M.negc;
+        const lanemask tab = ok & W.k3 & vote(T.ndx - s_ndx <= 3 * DPW_OPER_DIST);     // reverse stops nearby: the distance term
+        if (tab) { if (in_mask(tab)) val = rl_f64(R.score, u) + dpw_igm_apart(T.ndx - s_ndx, M.negc, M.igm); }
+        ok &= vote(val >= L.val);
+        if (in_mask(ok)) { L.val = val; L.tag = j; }
+    } else if (sk == 3) {
+        // reverse stop: the reverse starts of its ORF; reverse stops inside its ORF, as an operon (ref: :228-235, 345-356)
+        lanemask ok = win & (pick3m(sf, W.r5f0, W.r5f1, W.r5f2) | pick3m(sf, W.r3v0, W.r3v1, W.r3v2));
+        if (!ok) return;
+        ok &= vote(rl_i32(R.stop_val, u) > T.ndx);
+        if (!ok) return;
+        const double s_score = rl_f64(R.score, u);
+        const bool r5t = in_mask(W.k2);
+        auto finish = [&](const double w) {
+            const double val = s_score + w;
+            const lanemask tk = ok & vote(val >= L.val);
+            if (in_mask(tk)) { L.val = val; L.tag = j; }
+        };
+        // sf is uniform: three scalar branches instead of a register-indexed select
+        if (sf == 0) finish(r5t ? T.cs : T.x0); else if (sf == 1) finish(r5t ? T.cs : T.x1); else finish(r5t ? T.cs : T.x2);
+    } else {
+        // forward stop, a gene end: all four kinds (ref: :117-124, 177-188, 238-254, 288-336); dpw_step_f3 with `win` for
+        // its window test
+        const int s_ndx = rl_i32(R.ndx, u), s_vm = sp >> 4;
+        const double s_score = rl_f64(R.score, u);
+        bool ok = in_mask(win);
+        double w; int ov1 = 0;
+        if (T.kind == 0) {
+            ok = ok && s_ndx + 2 < T.ndx;
+            w = dpw_igm_apart(T.ndx - s_ndx, M.negc, M.igm);
+        } else if (T.kind == 1) {
+            ok = ok && T.stop_val < s_ndx && ((s_vm >> T.frame) & 1) != 0;
+            w = dpw_sel3(T.frame, rl_f64(R.x0, u), rl_f64(R.x1, u), rl_f64(R.x2, u));
+        } else {
+            const int lhs = tbn_of() + s_ndx + 7;
+            const bool c0 = (s_ndx > T.dlo0) & (s_ndx < T.dhi0) & (lhs < T.drhs0);
+            if (T.kind == 2) { ok = ok && c0; w = T.csd; }
+            else {
+                ok = ok && s_ndx < T.okhi;
+                const bool c1 = (s_ndx > T.dlo1) & (s_ndx < T.dhi1) & (lhs < T.drhs1);
+                const bool c2 = (s_ndx > T.dlo2) & (s_ndx < T.dhi2) & (lhs < T.drhs2);
+                double mv = 0.0; int m = -1;
+                if (c0 & (T.x0 > mv)) { mv = T.x0; m = 0; }
+                if (c1 & (T.x1 > mv)) { mv = T.x1; m = 1; }
+                if (c2 & (T.x2 > mv)) { mv = T.x2; m = 2; }
+                w = m >= 0 ? mv : M.negc;
+                ov1 = m + 1;
+            }
+        }
+        const double val = s_score + w;
+        if (ok && val >= L.val) { L.val = val; L.tag = j | (ov1 << DPW_TAG_BITS); }
+    }
+}
+
+__global__ void __launch_bounds__(64, 4)
+k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const double* __restrict__ g_cs, const DpwExt* __restrict__ g_ext,
+          const ModelConst* __restrict__ models, DpBuffers buf, double* __restrict__ g_sfxv, int32_t* __restrict__ g_sfxi) {
+    __shared__ double s_igm[64];
+    const ChainDesc cd = chains[blockIdx.x];
+    const int lane = threadIdx.x;
+    const int n = cd.n;
+    const ModelConst* mc = &models[cd.model];
+    s_igm[lane] = mc->igm[lane];
+    __syncthreads();
+    const double NEG_INF = -__builtin_huge_val();
+    const DpwModel M{mc->st_wt, mc->negc, s_igm};
+    WavePtrs P;
+    {
+        const DpwTopoArrays& ta = groups.g[cd.group];
+        P.ndx = ta.ndx + cd.topo_off; P.stopv = ta.stop_val + cd.topo_off; P.kf = ta.kf + cd.topo_off;
+        P.lo = ta.lo + cd.topo_off; P.q1 = ta.q1 + cd.topo_off; P.q2 = ta.q2 + cd.topo_off;
+        P.cs = g_cs + cd.off; P.ext = g_ext + cd.off;
+        P.score = buf.score + cd.off; P.traceb = buf.traceb + cd.off; P.tbn = buf.tbn + cd.off; P.ov = buf.ov_mark + cd.off;
+        P.sfxv = g_sfxv + cd.off; P.sfxi = g_sfxi + cd.off;
+    }
+    const bool long_chain = n > 2 * DPW_MAX_NODE_DIST;         // only then can a window start past node 0
+    double end_best = -1.0; int end_idx = -1, end_tb = -1;
+    // block structures of `a` (see the head of the file): lane q of S1 = blocks [b-1-q, b-1], of S2 = blocks [b-2-q, b-2]
+    double s1v = NEG_INF, s2v = NEG_INF, ppv = NEG_INF; int s1i = -1, s2i = -1, ppi = -1;
+    // uniform carries
+    double rv0 = NEG_INF, rv1 = NEG_INF, rv2 = NEG_INF; int ri0 = -1, ri1 = -1, ri2 = -1, rn0 = -1, rn1 = -1, rn2 = -1;
+    int l3i0 = -1, l3i1 = -1, l3i2 = -1, l3s0 = 0, l3s1 = 0, l3s2 = 0, l3n0 = 0, l3n1 = 0, l3n2 = 0;
+    double l3v0 = 0.0, l3v1 = 0.0, l3v2 = 0.0;
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));      // lanes before this one
+
+    const int nb = (n + 63) >> 6;
+    // optional phase timing of chain 0 (PGA_DP_PROFILE through the scorer-level call): cycles per batch phase
+    const bool prof = buf.prof != nullptr && blockIdx.x == 0;
+    unsigned long long tp = prof ? __builtin_readcyclecounter() : 0;
+    auto mark = [&](const int slot) {
+        if (!prof) return;
+        const unsigned long long now = __builtin_readcyclecounter();
+        if (lane == 0) buf.prof[slot] += now - tp;
+        tp = now;
+    };
+    for (int b = 0; b < nb; b++) {
+        const int i0 = b << 6;
+        DpwT T; int kfb;
+        load_target_w(T, kfb, P, i0, lane, n, M.negc);
+        const DpwLT LT = dpw_lean(T);
+        const WaveMasks W = wave_masks(LT);
+        const int key_r5 = T.kind == 3 ? T.ndx - 2 : T.ndx;
+        const bool act = T.i >= 0;
+        mark(0);
+        DpwLane L{0.0, -1};
+        int tbn_pre = -1;                   // position of the traceb node while it is older than the batch
+        // a candidate older than the batch, in any order: the lexicographic (value, index) rule spelled out
+        auto take = [&](const bool ok, const double val, const int j, const int ov1, const int s_ndx) {
+            const int cur = dpw_tag_index(L.tag);
+            if (ok && (val > L.val || (val == L.val && j > cur))) { L.val = val; L.tag = j | (ov1 << DPW_TAG_BITS); tbn_pre = s_ndx; }
+        };
+
+        // ---- (2) near steps first (ascending sources onto an empty state: ">=" is the whole tie rule): from the earliest
+        //      p_near of a gene begin up to the batch, one wave-uniform source at a time
+        {
+            int jm = (act && (T.kind == 0 || T.kind == 3)) ? max(T.q1, T.lo) : i0;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) jm = min(jm, __shfl_xor(jm, m, 64));
+            for (int t0 = jm; t0 < i0; t0 += 64) {
+                const int j = t0 + lane;
+                const bool in = j < i0;
+                const int jj = in ? j : i0 - 1;
+                const int s_kf = P.kf[jj];
+                const int sk = DPW_KIND(s_kf);
+                SrcRegs R;
+                R.ndx = P.ndx[jj]; R.stop_val = P.stopv[jj]; R.score = P.score[jj]; R.cs = P.cs[jj];
+                const int s_tbn = P.tbn[jj];
+                int vm = 0; R.x0 = R.x1 = R.x2 = 0.0;
+                if (sk == 1) { const DpwExt* e = P.ext + jj; vm = e->vm; R.x0 = e->x[0]; R.x1 = e->x[1]; R.x2 = e->x[2]; }
+                R.pack = sk | (DPW_FRAME(s_kf) << 2) | (vm << 4);
+                const bool dead = (sk == 1 || sk == 2) && s_tbn == -1;
+                unsigned long long visit = __ballot(in && !dead);
+                while (visit) {
+                    const int u = __builtin_ctzll(visit);
+                    visit &= visit - 1;
+                    const int js = t0 + u;
+                    wave_step(R, u, js, W.act & vote(js >= T.lo), LT, W, key_r5, L, M, [&]() { return rl_i32(s_tbn, u); });
+                }
+            }
+            if (L.tag >= 0) tbn_pre = P.ndx[dpw_tag_index(L.tag)];
+        }
+        mark(1);
+        // ---- (1) gene begins: far gene ends, `a` over [lo, min(p_near, i0))
+        {
+            const bool gb = act && (T.kind == 0 || T.kind == 3);
+            const int lo = T.lo, hi = min(T.q1, i0);
+            const bool want = gb && hi > lo;
+            const int rb = hi >> 6, part = hi & 63, Bl = lo >> 6, lpart = lo & 63;
+            const int x = lpart ? Bl + 1 : Bl;                 // first whole block
+            bool generic = want && !(rb == b || (rb == b - 1 && !(Bl >= rb && part > 0 && lpart != 0)));
+            const int q = rb - 1 - x;                          // whole blocks [x, rb): lane q of S1 (rb == b) or S2 (rb == b - 1)
+            const bool whole = want && !generic && x < rb;
+            if (whole && q >= 64) generic = true;
+            const int qs = whole ? (q & 63) : 0;
+            const double w1v = __shfl(s1v, qs, 64), w2v = __shfl(s2v, qs, 64);
+            const int w1i = __shfl(s1i, qs, 64), w2i = __shfl(s2i, qs, 64);
+            const int ps = (part - 1) & 63;
+            const double pv = __shfl(ppv, ps, 64); const int pi = __shfl(ppi, ps, 64);
+            double rv = NEG_INF; int ri = -1;
+            if (want && !generic) {
+                if (whole) { if (rb == b) lex_max(rv, ri, w1v, w1i); else lex_max(rv, ri, w2v, w2i); }
+                if (rb == b - 1 && part > 0 && (Bl < rb || lpart == 0)) lex_max(rv, ri, pv, pi);
+                if (lpart != 0 && Bl < rb) lex_max(rv, ri, P.sfxv[lo], P.sfxi[lo]);
+            }
+            if (__any(generic)) {
+                // a window narrower than its blocks, or a near zone deeper than one block: never on real sequence; pair by pair
+                if (generic) {
+                    rv = NEG_INF; ri = -1;
+                    for (int j = lo; j < hi; j++) {
+                        const int k = DPW_KIND(P.kf[j]);
+                        if ((k == 1 || k == 2) && P.traceb[j] != -1) lex_max(rv, ri, P.score[j] + M.negc, j);
+                    }
+                }
+            }
+            if (ri >= 0) take(true, rv, ri, 0, P.ndx[ri]);
+        }
+        mark(2);
+        // ---- (3) forward stops: the running maximum of their frame, for the first forward stop of the frame in the batch
+        {
+            const bool f3 = act && T.kind == 1;
+            const unsigned long long m0 = __ballot(f3 && T.frame == 0), m1 = __ballot(f3 && T.frame == 1), m2 = __ballot(f3 && T.frame == 2);
+            const unsigned long long mine = T.frame == 0 ? m0 : (T.frame == 1 ? m1 : m2);
+            const double cv = dpw_sel3(T.frame, rv0, rv1, rv2);
+            const int ci = dpw_sel3i(T.frame, ri0, ri1, ri2), cn = dpw_sel3i(T.frame, rn0, rn1, rn2);
+            take(f3 && (mine & below) == 0ull && ci >= 0, cv, ci, 0, cn);
+        }
+        // ---- (4) reverse nodes: the last reverse stop of a frame before the batch (own stop of a reverse start; operon partner)
+        if (act && T.kind == 2) {
+            const int j = dpw_sel3i(T.frame, l3i0, l3i1, l3i2), ss = dpw_sel3i(T.frame, l3s0, l3s1, l3s2);
+            take(j >= 0 && j >= T.lo && ss > T.ndx, dpw_sel3(T.frame, l3v0, l3v1, l3v2) + T.cs, j, 0, dpw_sel3i(T.frame, l3n0, l3n1, l3n2));
+        } else if (act && T.kind == 3) {
+            take((T.vm & 1) && l3i0 >= 0 && l3i0 >= T.lo && l3s0 > T.ndx, l3v0 + T.x0, l3i0, 0, l3n0);
+            take((T.vm & 2) && l3i1 >= 0 && l3i1 >= T.lo && l3s1 > T.ndx, l3v1 + T.x1, l3i1, 0, l3n1);
+            take((T.vm & 4) && l3i2 >= 0 && l3i2 >= T.lo && l3s2 > T.ndx, l3v2 + T.x2, l3i2, 0, l3n2);
+        }
+        mark(3);
+        // ---- (5) reverse nodes: forward stops that overlap the 3' end of the gene, through the chain of forward stops
+        {
+            const bool r5 = act && T.kind == 2, r3 = act && T.kind == 3;
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                // a reverse start has one chain (q == 0), a reverse stop one per overlapping start
+                int j = DPW_NONE, bound = 0;
+                if (r5 && q == 0) { j = T.q2; bound = T.stop_val + DPW_MAX_OPP_OVLP - 5; }
+                if (r3 && ((T.vm >> q) & 1)) { j = dpw_sel3i(q, T.cq0, T.cq1, T.cq2); bound = dpw_sel3i(q, T.n3s0, T.n3s1, T.n3s2) + DPW_MAX_OPP_OVLP - 5; }
+                while (__any(j < i0)) {
+                    if (j < i0) {
+                        const int s_ndx = P.ndx[j];
+                        if (s_ndx >= bound) j = DPW_NONE;
+                        else {
+                            const DpwS S = load_f3_source(P, j, s_ndx);
+                            bool ok; double w; int mf;
+                            dpw_pair(S, T, M, ok, w, mf);
+                            take(ok, S.score + w, j, mf + 1, s_ndx);
+                            j = P.q2[j];
+                        }
+                    }
+                }
+            }
+        }
+        mark(4);
+        // ---- (6) the walk: lane k is final when the walk reaches source i0 + k
+        {
+            const int kmax = min(63, n - 1 - i0);
+            SrcRegs R;
+            R.pack = T.kind | (T.frame << 2) | (T.vm << 4); R.ndx = T.ndx; R.stop_val = T.stop_val; R.cs = T.cs; R.x0 = T.x0; R.x1 = T.x1; R.x2 = T.x2;
+            for (int k = 0; k < kmax; k++) {
+                const int tagk = rl_i32(L.tag, k);
+                const int sk = rl_i32(R.pack, k) & 3;
+                if ((sk == 1 || sk == 2) && tagk < 0) continue;          // a gene end that was never reached connects to nothing
+                R.score = L.val;                                         // lane k's value is final now
+                // inside the batch the window test is "a later lane": the window reaches back at least 500 nodes
+                wave_step(R, k, i0 + k, W.act & (~0ull << (k + 1)), LT, W, key_r5, L, M, [&]() {
+                    const int tbk = tagk & DPW_TAG_MASK;
+                    return tbk >= i0 ? rl_i32(T.ndx, tbk - i0) : rl_i32(tbn_pre, k);
+                });
+            }
+        }
+        mark(5);
+        // ---- (7) the batch is final: results, block structures, carries
+        DpwBest B;
+        B.val = L.val; B.tb = dpw_tag_index(L.tag); B.ov = dpw_tag_ov(L.tag);
+        {
+            const int src = B.tb >= i0 ? B.tb - i0 : 0;
+            const int nd_in = __shfl(T.ndx, src, 64);
+            B.tbn = B.tb < 0 ? -1 : (B.tb >= i0 ? nd_in : tbn_pre);
+        }
+        if (act) {
+            P.score[T.i] = B.val; P.traceb[T.i] = B.tb; P.tbn[T.i] = B.tbn; P.ov[T.i] = (int8_t)B.ov;
+            if ((T.kind == 1 || T.kind == 2) && B.val >= end_best) { end_best = B.val; end_idx = T.i; end_tb = B.tb; }
+        }
+        const DpwOut O = dpw_outputs(T, kfb, B, M.negc);
+        {
+            double av = O.a; int ai = O.a > NEG_INF ? i0 + lane : -1;
+            double pv = av; int pi = ai;
+            wave_prefix_lexmax(pv, pi, lane);
+            ppv = pv; ppi = pi;
+            const double bmv = rl_f64(pv, 63); const int bmi = rl_i32(pi, 63);
+            s2v = s1v; s2i = s1i;
+            double nv = __shfl_up(s1v, 1, 64); int ni = __shfl_up(s1i, 1, 64);
+            if (lane == 0) { nv = NEG_INF; ni = -1; }
+            lex_max(nv, ni, bmv, bmi);
+            s1v = nv; s1i = ni;
+            if (long_chain) {
+                wave_suffix_lexmax(av, ai, lane);
+                if (act) { P.sfxv[T.i] = av; P.sfxi[T.i] = ai; }
+            }
+        }
+        {
+            const bool f3 = act && T.kind == 1, r3n = act && T.kind == 3;
+#pragma unroll
+            for (int f = 0; f < 3; f++) {
+                // forward stops of the frame restart the running maximum; what follows them in the batch joins it
+                const unsigned long long mf = __ballot(f3 && T.frame == f);
+                const int u = mf ? 63 - __builtin_clzll(mf) : -1;
+                double v = f == 0 ? O.v0 : (f == 1 ? O.v1 : O.v2);
+                if (lane <= u) v = NEG_INF;
+                int vi = v > NEG_INF ? i0 + lane : -1;
+                if (__any(vi >= 0)) {
+                    wave_all_lexmax(v, vi);
+                    // the same in every lane: keep them in scalar registers
+                    v = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+                    vi = __builtin_amdgcn_readfirstlane(vi);
+                    const int vn = rl_i32(T.ndx, vi & 63);
+                    double& rv = f == 0 ? rv0 : (f == 1 ? rv1 : rv2);
+                    int& ri = f == 0 ? ri0 : (f == 1 ? ri1 : ri2);
+                    int& rn = f == 0 ? rn0 : (f == 1 ? rn1 : rn2);
+                    if (u >= 0 || v >= rv) { rv = v; ri = vi; rn = vn; }        // ascending indices: a later node wins a tie
+                } else if (u >= 0) {
+                    if (f == 0) { rv0 = NEG_INF; ri0 = -1; rn0 = -1; } else if (f == 1) { rv1 = NEG_INF; ri1 = -1; rn1 = -1; } else { rv2 = NEG_INF; ri2 = -1; rn2 = -1; }
+                }
+                const unsigned long long mr = __ballot(r3n && T.frame == f);
+                if (mr) {
+                    const int w = 63 - __builtin_clzll(mr);
+                    const int li = i0 + w, ls = rl_i32(T.stop_val, w), ln = rl_i32(T.ndx, w); const double lv = rl_f64(B.val, w);
+                    if (f == 0) { l3i0 = li; l3s0 = ls; l3n0 = ln; l3v0 = lv; } else if (f == 1) { l3i1 = li; l3s1 = ls; l3n1 = ln; l3v1 = lv; }
+                    else { l3i2 = li; l3s2 = ls; l3n2 = ln; l3v2 = lv; }
+                }
+            }
+        }
+        mark(6);
+        if (prof && lane == 0) buf.prof[7] += 1;
+    }
+    // highest score among gene ends, ties to the largest index (ref: lib.pyx:1239-1251, 1311)
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double ob = __shfl_xor(end_best, m, 64);
+        const int oi = __shfl_xor(end_idx, m, 64), ot = __shfl_xor(end_tb, m, 64);
+        if (ob > end_best || (ob == end_best && oi > end_idx)) { end_best = ob; end_idx = oi; end_tb = ot; }
+    }
+    if (lane == 0) {
+        buf.max_index[blockIdx.x] = end_idx; buf.max_score[blockIdx.x] = end_idx >= 0 ? end_best : 0.0;
+        buf.ipath[blockIdx.x] = (end_idx >= 0 && end_tb != -1) ? end_idx : -1;
+    }
+}
+
+}  // namespace
+
+void pga_launch_dpw_topo(const DpwTopoArrays& ta, const uint8_t* type, const int8_t* strand, const int32_t* d_cbase, int n_contigs, int n_nodes,
+                         hipStream_t st) {
+    if (n_nodes <= 0) return;
+    hipLaunchKernelGGL(k_dpw_topo, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, st, ta.ndx, ta.stop_val, type, strand, d_cbase,
+                       n_contigs, n_nodes, ta);
+}
+
+void pga_launch_dpw_chain(const ChainDesc* d_chains, int n_chains, int64_t node_begin, int64_t total_nodes, const NodeArrays& nodes,
+                          const DpwTopoArrays& ta, const ModelConst* d_models, const DpwBuffers& wb, hipStream_t st) {
+    if (total_nodes <= 0) return;
+    hipLaunchKernelGGL(k_dpw_chain, dim3((unsigned)((total_nodes + 255) / 256)), dim3(256), 0, st, d_chains, n_chains, node_begin, total_nodes,
+                       nodes, ta, d_models, wb.cs, wb.ext);
+}
+
+void pga_launch_dp_wave(const ChainDesc* d_chains, int n_chains, const DpwGroupPtrs& groups, const ModelConst* d_models, DpBuffers buf,
+                        const DpwBuffers& wb, hipStream_t st) {
+    if (n_chains <= 0) return;
+    hipLaunchKernelGGL(k_dp_wave, dim3((unsigned)n_chains), dim3(64), 0, st, d_chains, groups, (const double*)wb.cs, (const DpwExt*)wb.ext,
+                       d_models, buf, wb.sfxv, wb.sfxi);
+}

@@ -7,6 +7,7 @@
 // models' nodes brought home).
 #include "pga_internal.h"
 #include "pipeline.h"
+#include "dpw_core.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -1022,6 +1023,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                 const int g = f->model_group[m];
                 const int32_t* cb = h_cbase + (size_t)g * (NC + 1);
                 ChainDesc ch{0, cb[i], cb[i + 1] - cb[i], m, i, t.trans_table != tt_prev ? 1 : 0};
+                ch.group = g;
                 tt_prev = t.trans_table;
                 gch[g].push_back(ch);
             }
@@ -1062,18 +1064,35 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         }
         // few long chains: their walks are cut into segments that run side by side (dp.hip "segmented chains")
         DpSegPlan seg_plan;
-        const bool segmented = stage == 0 && pga_dp_plan(chains.data(), NCH, tot_chain_nodes, seg_plan);
+        // many chains: one wavefront each, records and far-field structures of dp_wave.hip
+        const bool use_wave = stage == 0 && pga_dp_use_wave(NCH);
+        const bool segmented = stage == 0 && !use_wave && pga_dp_plan(chains.data(), NCH, tot_chain_nodes, seg_plan);
         const int64_t dp_cap = tot_chain_nodes + seg_plan.extra + 1;
         const int64_t dp_slots = NCH + (int64_t)seg_plan.segs.size() + 1;
+        const int64_t tree_cap = use_wave ? 1 : dp_cap;          // records and far-field arrays of the tree / chain kernels
         DpBuffers dp;
         {
-            DEVBUF(b0, DpSrc, "dp_src", dp_cap) DEVBUF(b1, DpTgt, "dp_tgt", dp_cap)
+            DEVBUF(b0, DpSrc, "dp_src", tree_cap) DEVBUF(b1, DpTgt, "dp_tgt", tree_cap)
             DEVBUF(b2, double, "dp_score", dp_cap) DEVBUF(b3, int32_t, "dp_traceb", dp_cap)
             DEVBUF(b4, int32_t, "dp_tbn", dp_cap) DEVBUF(b5, int8_t, "dp_ov", dp_cap)
             DEVBUF(b6, int32_t, "dp_maxidx", dp_slots) DEVBUF(b7, double, "dp_maxscore", dp_slots) DEVBUF(b8, int32_t, "dp_ipath", dp_slots)
-            DEVBUF(b9, double, "dp_A", dp_cap) DEVBUF(b10, double, "dp_V0", dp_cap) DEVBUF(b11, double, "dp_V1", dp_cap)
-            DEVBUF(b12, double, "dp_V2", dp_cap) DEVBUF(b13, double, "dp_hv", dp_cap) DEVBUF(b14, int32_t, "dp_hi", dp_cap)
+            DEVBUF(b9, double, "dp_A", tree_cap) DEVBUF(b10, double, "dp_V0", tree_cap) DEVBUF(b11, double, "dp_V1", tree_cap)
+            DEVBUF(b12, double, "dp_V2", tree_cap) DEVBUF(b13, double, "dp_hv", tree_cap) DEVBUF(b14, int32_t, "dp_hi", tree_cap)
             dp = DpBuffers{b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, {b10, b11, b12}, b13, b14, nullptr};
+        }
+        DpwGroupPtrs wgroups{};
+        DpwBuffers wbuf{};
+        if (use_wave) {
+            for (int g = 0; g < NG; g++) {
+                char nm[32];
+                const int64_t n = group_nodes[g] + 1;
+#define WBUF(field, type) { snprintf(nm, sizeof nm, "dpw_" #field "%d", g); void* p__; int rc__ = ensure_dev(c, nm, sizeof(type) * (size_t)n + 64, &p__); if (rc__) return rc__; wgroups.g[g].field = (type*)p__; }
+                WBUF(kf, uint8_t) WBUF(lo, int32_t) WBUF(q1, int32_t) WBUF(q2, int32_t)
+#undef WBUF
+                wgroups.g[g].ndx = ga[g].ndx; wgroups.g[g].stop_val = ga[g].stop_val;
+            }
+            DEVBUF(w0, double, "dpw_cs", dp_cap) DEVBUF(w1, DpwExt, "dpw_ext", dp_cap) DEVBUF(w2, double, "dpw_sfxv", dp_cap) DEVBUF(w3, int32_t, "dpw_sfxi", dp_cap)
+            wbuf = DpwBuffers{w0, w1, w2, w3};
         }
         DpSegDev seg_dev{};
         if (segmented) {
@@ -1109,7 +1128,10 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             pga_launch_score(d_chains + g_c0[g], nch, g_n0[g], nn, d_dig, d_ct, ga[g], d_models, f->d_msc, c->d_model_const, ca, sp,
                              d_chains, d_cc + (size_t)g * NC, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], f->d_sd_lut, st);
             NodeArrays na{ga[g].ndx, ga[g].stop_val, ga[g].type, ga[g].strand, ca.cscore, ca.sscore, ca.rscore, ca.uscore, ca.star_ptr};
-            if (stage == 0) pga_launch_dp_prepare(d_chains + g_c0[g], nch, g_n0[g], nn, na, c->d_model_const, dp, st);
+            if (use_wave) {
+                pga_launch_dpw_topo(wgroups.g[g], ga[g].type, ga[g].strand, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], st);
+                pga_launch_dpw_chain(d_chains + g_c0[g], nch, g_n0[g], nn, na, wgroups.g[g], c->d_model_const, wbuf, st);
+            } else if (stage == 0) pga_launch_dp_prepare(d_chains + g_c0[g], nch, g_n0[g], nn, na, c->d_model_const, dp, st);
         }
         if (stage != 0) {
             // ---- stage-level call: bring the node arrays home as they are now and stop ---------------
@@ -1162,7 +1184,8 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         }
         // one DP launch over the chains of every group: chains are independent, the more in flight the better
         HT(c, hipEventRecord(f->e_dp0[0], st));
-        pga_launch_dp(d_chains, NCH, c->d_model_const, dp, 1, st, segmented ? &seg_dev : nullptr);
+        if (use_wave) pga_launch_dp_wave(d_chains, NCH, wgroups, c->d_model_const, dp, wbuf, st);
+        else pga_launch_dp(d_chains, NCH, c->d_model_const, dp, 1, st, segmented ? &seg_dev : nullptr);
         HT(c, hipEventRecord(f->e_dp1[0], st));
         HT(c, hipMemcpyAsync(h_maxidx, dp.max_index, sizeof(int32_t) * NCH, hipMemcpyDeviceToHost, st));
         HT(c, hipMemcpyAsync(h_ipath, dp.ipath, sizeof(int32_t) * NCH, hipMemcpyDeviceToHost, st));

@@ -61,7 +61,7 @@ struct ChainDesc {
     // chain it belongs to, from node `rebase` on, and keeps its own results at `off`
     int64_t rec_off = -1;   // first DpSrc / DpTgt record of the sub-chain; -1: the chain's own, at `off`
     int32_t rebase = 0;     // chain index of the sub-chain's node 0: index fields of DpTgt are shifted down by it
-    int32_t _pad = 0;
+    int32_t group = 0;      // translation-table group of the chain's model: whose topology arrays `topo_off` indexes (dp_wave.hip)
 };
 
 // Node fields in device memory (struct of arrays; each pointer covers the whole batch).
@@ -120,6 +120,23 @@ bool pga_dp_plan(const ChainDesc* h_chains, int n_chains, int64_t tot_nodes, DpS
 // stay alive until the copies on `st` are done)
 size_t pga_dp_seg_bytes(const DpSegPlan& plan, int n_chains, int64_t tot_nodes);
 hipError_t pga_dp_seg_bind(const DpSegPlan& plan, int n_chains, int64_t tot_nodes, void* arena, hipStream_t st, DpSegDev* out);
+
+// ---- wave-batch connection scoring for launches with many chains (dp_wave.hip, dpw_core.h) ----
+struct DpwExt;
+// topology of one translation-table group: what depends on positions and kinds only, shared by every model of a contig
+struct DpwTopoArrays { const int32_t* ndx; const int32_t* stop_val; uint8_t* kf; int32_t* lo; int32_t* q1; int32_t* q2; };
+struct DpwGroupPtrs { DpwTopoArrays g[4]; };
+// per chain node: cs = cscore + sscore, a 64-byte record of extras (stop nodes only), suffix maxima of finished blocks
+struct DpwBuffers { double* cs; DpwExt* ext; double* sfxv; int32_t* sfxi; };
+// which connection scorer a final-pass launch over n_chains chains uses (PGA_DP_KERNEL overrides: wave | tree1 | tree3 | scan)
+bool pga_dp_use_wave(int n_chains);
+void pga_launch_dpw_topo(const DpwTopoArrays& ta, const uint8_t* type, const int8_t* strand, const int32_t* d_cbase, int n_contigs, int n_nodes,
+                         hipStream_t st);
+// chains[0..n_chains) of ONE group, contiguous in `off` from node_begin
+void pga_launch_dpw_chain(const ChainDesc* d_chains, int n_chains, int64_t node_begin, int64_t total_nodes, const NodeArrays& nodes,
+                          const DpwTopoArrays& ta, const ModelConst* d_models, const DpwBuffers& wb, hipStream_t st);
+void pga_launch_dp_wave(const ChainDesc* d_chains, int n_chains, const DpwGroupPtrs& groups, const ModelConst* d_models, DpBuffers buf,
+                        const DpwBuffers& wb, hipStream_t st);
 
 // kernel launchers (dp.hip)
 // chains[0..n_chains) must be contiguous in `off`; node_begin = chains[0].off, total_nodes = their node count

@@ -42,6 +42,19 @@ def estimate_work(seqs, model_gcs=None, sample=8192):
     return work
 
 
+def estimate_work_known(lengths, gcs, model_gcs=None):
+    """`estimate_work` for contigs whose length and GC are known without looking at the bases (a synthetic job, or an index
+    file next to the FASTA): every rank can plan the whole job before reading or generating a single contig."""
+    lengths, gcs = np.asarray(lengths, float), np.asarray(gcs, float)
+    bins = np.ones(len(lengths))
+    if model_gcs is not None:                               # ref: lib.pyx:5335-5336
+        mg = np.asarray(model_gcs, float)
+        low = np.minimum(0.65, 0.88495 * gcs - 0.0102337)
+        high = np.maximum(0.35, 0.86596 * gcs + 0.1131991)
+        bins = np.maximum(1, ((mg[None, :] >= low[:, None]) & (mg[None, :] <= high[:, None])).sum(axis=1))
+    return lengths * np.interp(gcs, _NODE_DENSITY_GC, _NODE_DENSITY) * bins
+
+
 def pack_contigs(work, world):
     """Static greedy bin packing, largest first (LPT): returns, per rank, the ascending list of contig indices.
 
@@ -71,24 +84,49 @@ def find_genes_sharded(ctx, seqs, dist=None, device=None, model_gcs=None, **kw):
     return gather_genes(genes, dist, device), res, mine
 
 
-def gather_genes(genes, dist=None, device=None):
-    """All-gather a structured ``pga_gene`` array across ranks; returns the concatenation in rank order."""
+def gather_genes(genes, dist=None, device=None, dst=None):
+    """Gather a structured ``pga_gene`` array across ranks; returns the concatenation in rank order.
+
+    ``dst=None``: all-gather, every rank holds the whole job's genes.  ``dst=r``: only rank ``r`` receives them (one
+    gather over xGMI, and one device-to-host copy on that rank only); the other ranks get an empty array back."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return genes
     import torch
-    world = dist.get_world_size()
+    world, rank = dist.get_world_size(), dist.get_rank()
     dev = device if device is not None else torch.device("cpu")
+    on_gpu = dev.type == "cuda"
     n = torch.tensor([len(genes)], dtype=torch.int64, device=dev)
     counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(counts, n)
     counts = [int(c.item()) for c in counts]
     width = genes.dtype.itemsize
     cap = max(max(counts), 1)
-    buf = torch.zeros(cap * width, dtype=torch.uint8, device=dev)
-    if len(genes):
-        raw = np.ascontiguousarray(genes).view(np.uint8).reshape(-1)
-        buf[: raw.size] = torch.from_numpy(raw.copy()).to(dev)
-    parts = [torch.zeros(cap * width, dtype=torch.uint8, device=dev) for _ in range(world)]
-    dist.all_gather(parts, buf)
-    out = [p[: c * width].cpu().numpy().view(genes.dtype) for p, c in zip(parts, counts)]
-    return np.concatenate(out) if out else genes
+    raw = np.ascontiguousarray(genes).view(np.uint8).reshape(-1)
+    if on_gpu:
+        # pinned staging on both sides of the exchange: the records cross PCIe at link speed
+        stage = torch.empty(cap * width, dtype=torch.uint8, pin_memory=True)
+        stage[: raw.size] = torch.from_numpy(raw)
+        buf = stage.to(dev, non_blocking=True)
+    else:
+        buf = torch.zeros(cap * width, dtype=torch.uint8)
+        buf[: raw.size] = torch.from_numpy(raw.copy())
+    if dst is None:
+        parts = [torch.empty(cap * width, dtype=torch.uint8, device=dev) for _ in range(world)]
+        dist.all_gather(parts, buf)
+    else:
+        parts = [torch.empty(cap * width, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == dst else None
+        dist.gather(buf, parts, dst=dst)
+        if rank != dst:
+            return genes[:0]
+    total = sum(counts)
+    out = np.empty(total, dtype=genes.dtype)
+    flat = out.view(np.uint8).reshape(-1)
+    host = torch.empty(total * width, dtype=torch.uint8, pin_memory=on_gpu)
+    at = 0
+    for p, c in zip(parts, counts):
+        host[at: at + c * width].copy_(p[: c * width], non_blocking=on_gpu)
+        at += c * width
+    if on_gpu:
+        torch.cuda.current_stream().synchronize()
+    flat[:] = host.numpy()
+    return out

@@ -26,6 +26,8 @@ def _worker(rank, world, port, out_dir):
     empty = distributed.gather_genes(np.zeros(0, dtype=_cabi.GENE_DTYPE), dist)
     np.save(os.path.join(out_dir, "r%d.npy" % rank), allg)
     assert len(empty) == 0
+    only0 = distributed.gather_genes(g, dist, dst=0)              # gather to one rank: the others get nothing back
+    assert (only0.tobytes() == allg.tobytes()) if rank == 0 else len(only0) == 0
     dist.barrier()
     dist.destroy_process_group()
 
@@ -88,3 +90,13 @@ def test_pack_contigs_balances_by_estimated_work():
     rr = np.array([work[distributed.shard_contigs(len(seqs), r, 8)].sum() for r in range(8)])
     lpt = np.array([work[p].sum() for p in distributed.pack_contigs(work, 8)])
     assert lpt.max() <= rr.max()
+
+
+def test_estimate_work_known_matches_the_sampled_estimate():
+    from pyrodigal_amd import benchdata, distributed
+    model_gcs = np.linspace(0.30, 0.70, 16)
+    gcs = [0.30 + 0.40 * (c % 41) / 40 for c in range(60)]
+    seqs = [benchdata.synthetic_contig(20_000, gc, 1_000_000 + c) for c, gc in enumerate(gcs)]
+    known = distributed.estimate_work_known([20_000] * 60, gcs, model_gcs)
+    sampled = distributed.estimate_work(seqs, model_gcs)
+    assert np.all(known > 0) and np.median(np.abs(known - sampled) / sampled) < 0.05

@@ -189,3 +189,20 @@ def test_both_tails_give_the_same_result(ctx, models, tail, monkeypatch):
             res = ctx.find_genes_batch(seqs, meta=meta, want_nodes=want_nodes)
             n = sum(compare_contig(res, i, s, orc.Oracle(s), models if meta else [models[2]], meta=meta) for i, s in enumerate(seqs))
             assert n > 0
+
+
+@pytest.mark.parametrize("kernel", ["wave", "tree3"])
+def test_connection_scoring_kernels_inside_the_finder(ctx, models, kernel, monkeypatch):
+    # batches this small take the chain kernel by default; forcing either kernel must not change one node field:
+    # several models per contig, two translation-table groups, empty and sub-window contigs, every node against the oracle
+    monkeypatch.setenv("PGA_DP_KERNEL", kernel)
+    ctx.set_models([m.buf for m in models])
+    seqs = [synthetic_contig(3000 + 2111 * c, 0.30 + 0.40 * (c % 41) / 40, 20_000 + c) for c in range(40)]
+    seqs += [b"", b"ATGAAATAA", synthetic_contig(70_000, 0.52, 99), read_fasta("SRR492066.fna.gz")[0][1].encode()]
+    for closed in (False, True):
+        res = ctx.find_genes_batch(seqs, meta=True, closed=closed, want_nodes=True)
+        n = sum(compare_contig(res, i, s, orc.Oracle(s), models, meta=True, closed=closed) for i, s in enumerate(seqs))
+        assert n > 100
+    ctx.set_models([models[2].buf])
+    res = ctx.find_genes_batch(seqs, meta=False, want_nodes=True)          # single mode keeps the DP pass's node fields
+    assert sum(compare_contig(res, i, s, orc.Oracle(s), [models[2]], meta=False) for i, s in enumerate(seqs)) > 100

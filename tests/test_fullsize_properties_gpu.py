@@ -102,3 +102,78 @@ def test_config2_full_size(setup):
     a = mixed.genes_of(2)
     for name in ("begin", "end", "strand", "start_ndx", "stop_ndx", "cscore", "sscore"):
         assert np.array_equal(a[name], genes[name]), name
+
+
+def test_config5_full_size_single_mode(capsys):
+    """BASELINE.json configs[4]: one 200 Mbp contig at 65 % GC, single mode with the reference's full-genome TrainingInfo
+    fixture (closed ends, as the fixture was trained): every gene tuple against the oracle (about 30 s of CPU)."""
+    import time
+    from pyrodigal_amd import _cabi, benchdata
+    from tests.util import golden_path
+    L = 200_000_000
+    seq = benchdata.synthetic_contig(L, 0.65, 5)
+    tinf = orc.Training.load(golden_path("GCF_001457455.1_NCTC11397_genomic.tinf_closed.bin.gz"))
+    ctx = _cabi.Context(0)
+    try:
+        ctx.set_models([tinf.tobytes()])
+        b = ctx.upload([seq])
+        res = ctx.find_genes(b, meta=False, closed=True)
+        t0 = time.perf_counter()
+        res2 = ctx.find_genes(b, meta=False, closed=True)
+        gpu_s = time.perf_counter() - t0
+        seg = ctx.dp_stats()
+        b.close()
+    finally:
+        ctx.close()
+    assert res2.genes.tobytes() == res.genes.tobytes()
+    genes = res.genes_of(0)
+    assert res.contigs[0]["n_nodes"] > 10_000_000 and len(genes) > 100_000
+    assert seg["chains"] == 1 and seg["segments"] > 100 and seg["serial"] == 0      # the dense chain was cut, verified, not walked serially
+    check_contig(seq, genes[:: max(1, len(genes) // 3000)], 11)
+    t0 = time.perf_counter()
+    o = orc.Oracle(seq)
+    o.find_genes_single(tinf, orc.Params(closed=True))
+    cpu_s = time.perf_counter() - t0
+    og = o.genes()
+    assert len(og) == len(genes)
+    for k in ("begin", "end", "start_ndx", "stop_ndx"):
+        assert np.array_equal(og[k], genes[k]), k
+    with capsys.disabled():
+        print("\n[config5] 1 x 200 Mbp @65%% GC single mode: %d nodes, %d genes identical to the oracle; GPU %.1f ms (connection scoring %.1f ms, "
+              "%d segments, rejected %s), oracle %.1f s on one core" % (res.contigs[0]["n_nodes"], len(genes), gpu_s * 1e3, res2.t_dp_ms,
+                                                                         seg["segments"], seg["rejected"], cpu_s))
+
+
+def test_config4_one_gpu_share(setup, capsys):
+    """BASELINE.json configs[3]: rank 0's share of the 100 000 x 20 kbp job on 8 GPUs (12 500 contigs, seeds 1 000 000 + c),
+    in one call: ORF properties on every 25th contig, idempotence, and 56 contigs against the oracle in full."""
+    import time
+    from pyrodigal_amd import benchdata
+    ctx, models, tts = setup
+    seqs = benchdata.config4_shard(0, 8)
+    assert len(seqs) == 12_500 and all(len(s) == 20_000 for s in seqs[:50])
+    res = ctx.find_genes_batch(seqs, meta=True)
+    t0 = time.perf_counter()
+    res2 = ctx.find_genes_batch(seqs, meta=True)
+    gpu_s = time.perf_counter() - t0
+    assert res2.genes.tobytes() == res.genes.tobytes() and np.array_equal(res2.contigs["model"], res.contigs["model"])
+    assert res.n_chains > 30_000 and len(res.genes) > 100_000
+    for i in range(0, len(seqs), 25):
+        c = res.contigs[i]
+        if c["model"] >= 0:
+            check_contig(seqs[i], res.genes_of(i), tts[c["model"]])
+    bins = [orc.Training(m[1]) for m in models]
+    rng = np.random.default_rng(4)
+    sample = sorted(rng.permutation(len(seqs))[:56].tolist())
+    n_genes = 0
+    for i in sample:
+        o = orc.Oracle(seqs[i])
+        assert o.find_genes_meta(bins) == res.contigs[i]["model"]
+        og, gg = o.genes(), res.genes_of(i)
+        n_genes += len(og)
+        assert len(og) == len(gg) and all(np.array_equal(og[k], gg[k]) for k in ("begin", "end", "start_ndx", "stop_ndx"))
+    assert n_genes > 500
+    with capsys.disabled():
+        print("\n[config4 share] 12 500 x 20 kbp: %d chains, %d node-passes, %d genes; %.1f ms per call incl. upload (connection scoring %.2f ms); "
+              "%d sampled contigs / %d genes identical to the oracle" % (res.n_chains, res.node_passes, len(res.genes), gpu_s * 1e3, res2.t_dp_ms,
+                                                                        len(sample), n_genes))

@@ -200,8 +200,9 @@ def test_sequence_properties_and_region_masking(lib):
     assert [(g.begin, g.end) for g in genes] == [(int(a), int(b)) for a, b in zip(og["begin"], og["end"])]
     for g in genes:                                      # no gene runs across a masked region
         assert not any(m.begin < g.end and g.begin - 1 < m.end for m in genes.sequence.masks)
-    with pytest.raises(ValueError):
-        lib.GeneFinder(t, mask=True).find_genes(lib.Sequence(text, mask=False))
+    # a Sequence built under another masking rule is re-wrapped with the finder's (ref: lib.pyx:5433-5438)
+    again = lib.GeneFinder(t, mask=True).find_genes(lib.Sequence(text, mask=False))
+    assert [(g.begin, g.end) for g in again] == [(g.begin, g.end) for g in genes] and again.sequence.mask
 
 
 @pytest.mark.gpu
