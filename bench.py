@@ -172,16 +172,19 @@ def main():
             torch.cuda.synchronize()
 
     def gather(results):
-        """This rank's gene records with job-wide contig numbers, then the one exchange of the job: a gather to rank 0."""
+        """This rank's gene records with job-wide contig numbers (renumbered in place, in the result's own memory), then the
+        one exchange of the job: a gather to rank 0.  With one rank the records already are where the job wants them --
+        one array per device call, in host memory -- and nothing is copied."""
         parts = []
         for k, r in enumerate(results):
             g = r.genes
             if len(g):
-                g = g.copy()
                 g["contig"] = mine_arr[base_of[k] + g["contig"]]
             parts.append(g)
-        g = np.concatenate(parts) if parts else np.zeros(0, _cabi.GENE_DTYPE)
-        return distributed.gather_genes(g, dist, device=xdev, dst=0)
+        if dist is None:
+            return parts
+        g = np.concatenate(parts) if len(parts) != 1 else parts[0]
+        return [distributed.gather_genes(g, dist, device=xdev, dst=0)]
 
     # Bring the device out of its idle power state before the warmup steps proper: after a pause (the host was busy
     # generating the synthetic contigs) the first ~100 ms of work run at ramping clocks.  Untimed, like the warmup.
@@ -220,7 +223,7 @@ def main():
             "config": {"workload": wname, "contigs": int(len(lengths)), "bases": job_bases, "models": 1 if single else len(models),
                        "contigs_rank0": len(seqs), "device_calls_per_step_rank0": len(batches), "sub_batch_contigs": sub,
                        "node_passes_per_step_rank0": int(passes // max(args.steps, 1)),
-                       "genes_all_ranks": int(len(all_genes)) if all_genes is not None else 0,
+                       "genes_all_ranks": int(sum(len(g) for g in all_genes)) if all_genes is not None else 0,
                        "parallelism": "contigs packed by estimated work over %d GPU(s), one gather of gene records to rank 0" % world,
                        "inputs": "resident in HBM before the timed region", "generate_s_rank0": round(t_gen, 2)},
             "host_to_host": {"value": round(job_bases * h2h_steps / h2h / 1e6, 3), "unit": "Mbp/s", "steps": h2h_steps,

@@ -90,13 +90,17 @@ __device__ __forceinline__ void wave_suffix_lexmax(double& v, int& i, const int 
         if (lane + d < 64) lex_max(v, i, ov, oi);
     }
 }
-// wave-wide lexicographic maximum, the same in every lane
-__device__ __forceinline__ void wave_all_lexmax(double& v, int& i) {
+// wave-wide maximum of v (never NaN), the same in every lane; the lane that holds it comes from a vote afterwards
+__device__ __forceinline__ double wave_max_f64(double v) {
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const double ov = __shfl_xor(v, m, 64); const int oi = __shfl_xor(i, m, 64);
-        lex_max(v, i, ov, oi);
-    }
+    for (int m = 32; m >= 1; m >>= 1) { const double o = __shfl_xor(v, m, 64); v = o > v ? o : v; }
+    return v;
+}
+// inclusive prefix maximum (lower lanes first), values only
+__device__ __forceinline__ double wave_prefix_max_f64(double v, const int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const double o = __shfl_up(v, d, 64); if (lane >= d && o > v) v = o; }
+    return v;
 }
 
 struct WavePtrs {
@@ -175,15 +179,18 @@ __device__ __forceinline__ void wave_step(const SrcRegs& R, const int u, const i
                                           const int key_r5, DpwLane& L, const DpwModel& M, TBN tbn_of) {
     const int sp = rl_i32(R.pack, u);
     const int sk = sp & 3, sf = (sp >> 2) & 3;
+    // every kind ends in the same place: `take` = the lanes that accept the source, with value `val` and tag `tag`
+    lanemask take;
+    double val;
+    int tag = j;
     if (sk == 0) {
         // forward start: only the forward stop of its ORF (ref: _connection.h:166-174)
         lanemask ok = win & pick3m(sf, W.f3f0, W.f3f1, W.f3f2);
         if (!ok) return;
         ok &= vote(T.stop_val < rl_i32(R.ndx, u));
         if (!ok) return;
-        const double val = rl_f64(R.score, u) + rl_f64(R.cs, u);
-        ok &= vote(val >= L.val);
-        if (in_mask(ok)) { L.val = val; L.tag = j; }
+        val = rl_f64(R.score, u) + rl_f64(R.cs, u);
+        take = ok & vote(val >= L.val);
     } else if (sk == 2) {
         // reverse start, a gene end: every later gene begin (ref: :125-130, 337-342)
         lanemask ok = win & W.gb;
@@ -191,11 +198,11 @@ __device__ __forceinline__ void wave_step(const SrcRegs& R, const int u, const i
         const int s_ndx = rl_i32(R.ndx, u);
         ok &= vote(s_ndx < key_r5);
         if (!ok) return;
-        double val = rl_f64(R.score, u) + M.negc;
+        const double s_score = rl_f64(R.score, u);
+        val = s_score + M.negc;
         const lanemask tab = ok & W.k3 & vote(T.ndx - s_ndx <= 3 * DPW_OPER_DIST);     // reverse stops nearby: the distance term
-        if (tab) { if (in_mask(tab)) val = rl_f64(R.score, u) + dpw_igm_apart(T.ndx - s_ndx, M.negc, M.igm); }
-        ok &= vote(val >= L.val);
-        if (in_mask(ok)) { L.val = val; L.tag = j; }
+        if (tab) { if (in_mask(tab)) val = s_score + dpw_igm_apart(T.ndx - s_ndx, M.negc, M.igm); }
+        take = ok & vote(val >= L.val);
     } else if (sk == 3) {
         // reverse stop: the reverse starts of its ORF; reverse stops inside its ORF, as an operon (ref: :228-235, 345-356)
         lanemask ok = win & (pick3m(sf, W.r5f0, W.r5f1, W.r5f2) | pick3m(sf, W.r3v0, W.r3v1, W.r3v2));
@@ -204,13 +211,12 @@ __device__ __forceinline__ void wave_step(const SrcRegs& R, const int u, const i
         if (!ok) return;
         const double s_score = rl_f64(R.score, u);
         const bool r5t = in_mask(W.k2);
-        auto finish = [&](const double w) {
-            const double val = s_score + w;
-            const lanemask tk = ok & vote(val >= L.val);
-            if (in_mask(tk)) { L.val = val; L.tag = j; }
-        };
         // sf is uniform: three scalar branches instead of a register-indexed select
-        if (sf == 0) finish(r5t ? T.cs : T.x0); else if (sf == 1) finish(r5t ? T.cs : T.x1); else finish(r5t ? T.cs : T.x2);
+        // (the empty asm statements keep the branches apart: merged, they become a select over a private array in scratch)
+        if (sf == 0) { val = s_score + (r5t ? T.cs : T.x0); asm volatile("; frame 0"); }
+        else if (sf == 1) { val = s_score + (r5t ? T.cs : T.x1); asm volatile("; frame 1"); }
+        else { val = s_score + (r5t ? T.cs : T.x2); asm volatile("; frame 2"); }
+        take = ok & vote(val >= L.val);
     } else {
         // forward stop, a gene end: all four kinds (ref: :117-124, 177-188, 238-254, 288-336); dpw_step_f3 with `win` for
         // its window test
@@ -240,9 +246,12 @@ __device__ __forceinline__ void wave_step(const SrcRegs& R, const int u, const i
                 ov1 = m + 1;
             }
         }
-        const double val = s_score + w;
-        if (ok && val >= L.val) { L.val = val; L.tag = j | (ov1 << DPW_TAG_BITS); }
+        val = s_score + w;
+        tag = j | (ov1 << DPW_TAG_BITS);
+        take = vote(ok && val >= L.val);
     }
+    if (!take) return;
+    if (in_mask(take)) { L.val = val; L.tag = tag; }
 }
 
 __global__ void __launch_bounds__(64, 4)
@@ -266,6 +275,8 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
         P.score = buf.score + cd.off; P.traceb = buf.traceb + cd.off; P.tbn = buf.tbn + cd.off; P.ov = buf.ov_mark + cd.off;
         P.sfxv = g_sfxv + cd.off; P.sfxi = g_sfxi + cd.off;
     }
+    // a launch ends when its longest chain does: long chains issue first, the short ones fill their stalls
+    if (n >= 2048) __builtin_amdgcn_s_setprio(3); else if (n >= 1536) __builtin_amdgcn_s_setprio(2); else if (n >= 1024) __builtin_amdgcn_s_setprio(1);
     const bool long_chain = n > 2 * DPW_MAX_NODE_DIST;         // only then can a window start past node 0
     double end_best = -1.0; int end_idx = -1, end_tb = -1;
     // block structures of `a` (see the head of the file): lane q of S1 = blocks [b-1-q, b-1], of S2 = blocks [b-2-q, b-2]
@@ -412,15 +423,19 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
             }
         }
         mark(4);
-        // ---- (6) the walk: lane k is final when the walk reaches source i0 + k
+        // ---- (6) the walk: lane k is final when the walk reaches source i0 + k.  A forward start whose stop lies beyond the
+        //      batch has no target here and is not visited at all
         {
             const int kmax = min(63, n - 1 - i0);
+            const int ndx_last = rl_i32(T.ndx, kmax);
+            lanemask todo = W.act & ~vote(T.kind == 0 && T.stop_val > ndx_last) & ((1ull << kmax) - 1ull);
             SrcRegs R;
             R.pack = T.kind | (T.frame << 2) | (T.vm << 4); R.ndx = T.ndx; R.stop_val = T.stop_val; R.cs = T.cs; R.x0 = T.x0; R.x1 = T.x1; R.x2 = T.x2;
-            for (int k = 0; k < kmax; k++) {
+            while (todo) {
+                const int k = __builtin_ctzll(todo);
+                todo &= todo - 1ull;
                 const int tagk = rl_i32(L.tag, k);
-                const int sk = rl_i32(R.pack, k) & 3;
-                if ((sk == 1 || sk == 2) && tagk < 0) continue;          // a gene end that was never reached connects to nothing
+                if (tagk < 0 && ((W.gb >> k) & 1ull) == 0ull) continue;  // a gene end that was never reached connects to nothing
                 R.score = L.val;                                         // lane k's value is final now
                 // inside the batch the window test is "a later lane": the window reaches back at least 500 nodes
                 wave_step(R, k, i0 + k, W.act & (~0ull << (k + 1)), LT, W, key_r5, L, M, [&]() {
@@ -444,9 +459,13 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
         }
         const DpwOut O = dpw_outputs(T, kfb, B, M.negc);
         {
-            double av = O.a; int ai = O.a > NEG_INF ? i0 + lane : -1;
-            double pv = av; int pi = ai;
-            wave_prefix_lexmax(pv, pi, lane);
+            // inclusive prefix maxima of `a` inside the block: values by a scan, the index from a vote -- lane r is a record
+            // when a[r] equals its own prefix maximum, and the prefix maximum at t sits at the LAST record at or before t
+            // (ties to the larger index, as the ascending ">=" of the reference)
+            const bool has = O.a > NEG_INF;
+            const double pv = wave_prefix_max_f64(O.a, lane);
+            const lanemask rec = vote(has && O.a == pv) & (below | (1ull << lane));
+            const int pi = rec ? i0 + 63 - __builtin_clzll(rec) : -1;
             ppv = pv; ppi = pi;
             const double bmv = rl_f64(pv, 63); const int bmi = rl_i32(pi, 63);
             s2v = s1v; s2i = s1i;
@@ -455,6 +474,7 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
             lex_max(nv, ni, bmv, bmi);
             s1v = nv; s1i = ni;
             if (long_chain) {
+                double av = O.a; int ai = has ? i0 + lane : -1;
                 wave_suffix_lexmax(av, ai, lane);
                 if (act) { P.sfxv[T.i] = av; P.sfxi[T.i] = ai; }
             }
@@ -464,25 +484,22 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
 #pragma unroll
             for (int f = 0; f < 3; f++) {
                 // forward stops of the frame restart the running maximum; what follows them in the batch joins it
-                const unsigned long long mf = __ballot(f3 && T.frame == f);
+                const lanemask mf = vote(f3 && T.frame == f);
                 const int u = mf ? 63 - __builtin_clzll(mf) : -1;
                 double v = f == 0 ? O.v0 : (f == 1 ? O.v1 : O.v2);
                 if (lane <= u) v = NEG_INF;
-                int vi = v > NEG_INF ? i0 + lane : -1;
-                if (__any(vi >= 0)) {
-                    wave_all_lexmax(v, vi);
-                    // the same in every lane: keep them in scalar registers
-                    v = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
-                    vi = __builtin_amdgcn_readfirstlane(vi);
-                    const int vn = rl_i32(T.ndx, vi & 63);
-                    double& rv = f == 0 ? rv0 : (f == 1 ? rv1 : rv2);
-                    int& ri = f == 0 ? ri0 : (f == 1 ? ri1 : ri2);
-                    int& rn = f == 0 ? rn0 : (f == 1 ? rn1 : rn2);
-                    if (u >= 0 || v >= rv) { rv = v; ri = vi; rn = vn; }        // ascending indices: a later node wins a tie
-                } else if (u >= 0) {
-                    if (f == 0) { rv0 = NEG_INF; ri0 = -1; rn0 = -1; } else if (f == 1) { rv1 = NEG_INF; ri1 = -1; rn1 = -1; } else { rv2 = NEG_INF; ri2 = -1; rn2 = -1; }
-                }
-                const unsigned long long mr = __ballot(r3n && T.frame == f);
+                const lanemask some = vote(v > NEG_INF);
+                double& rv = f == 0 ? rv0 : (f == 1 ? rv1 : rv2);
+                int& ri = f == 0 ? ri0 : (f == 1 ? ri1 : ri2);
+                int& rn = f == 0 ? rn0 : (f == 1 ? rn1 : rn2);
+                if (some) {
+                    const double m = wave_max_f64(v);
+                    const lanemask at = some & vote(v == m);               // a later node wins a tie
+                    const int wl = 63 - __builtin_clzll(at);
+                    const double mv = rl_f64(v, wl);                       // the same value, in scalar registers
+                    if (u >= 0 || mv >= rv) { rv = mv; ri = i0 + wl; rn = rl_i32(T.ndx, wl); }
+                } else if (u >= 0) { rv = NEG_INF; ri = -1; rn = -1; }
+                const lanemask mr = vote(r3n && T.frame == f);
                 if (mr) {
                     const int w = 63 - __builtin_clzll(mr);
                     const int li = i0 + w, ls = rl_i32(T.stop_val, w), ln = rl_i32(T.ndx, w); const double lv = rl_f64(B.val, w);
