@@ -91,6 +91,11 @@ struct FinderState {
     std::vector<int> model_group;   // model -> translation-table group
     std::vector<int> group_tt;
     ModelScoreConst* d_msc = nullptr;
+    double* d_model_gc = nullptr;   // GC of every loaded model, and its translation-table group: which groups a contig needs
+    int32_t* d_model_grp = nullptr;
+    // the hexamer tables (gene_dc) of each group's models interleaved: d_gil + gil_off[g], [4096][gil_stride[g]]; d_model_rank[m] = column
+    double* d_gil = nullptr; int32_t* d_model_rank = nullptr;
+    std::vector<size_t> gil_off; std::vector<int> gil_stride;
     unsigned* d_sd_lut = nullptr;   // RBS search table (pga_launch_sd_lut), filled when the context's finder state is created
     hipEvent_t e_start = nullptr, e_stop = nullptr, e_dp0[4] = {}, e_dp1[4] = {};
 };
@@ -756,6 +761,10 @@ void pga_finder_release(pga_ctx* c) {
     for (auto& kv : c->finder->dev) if (kv.second.p) hipFree(kv.second.p);
     for (auto& kv : c->finder->pin) if (kv.second.p) hipHostFree(kv.second.p);
     if (c->finder->d_msc) hipFree(c->finder->d_msc);
+    if (c->finder->d_model_gc) hipFree(c->finder->d_model_gc);
+    if (c->finder->d_model_grp) hipFree(c->finder->d_model_grp);
+    if (c->finder->d_gil) hipFree(c->finder->d_gil);
+    if (c->finder->d_model_rank) hipFree(c->finder->d_model_rank);
     if (c->finder->d_sd_lut) hipFree(c->finder->d_sd_lut);
     if (c->finder->e_start) hipEventDestroy(c->finder->e_start);
     if (c->finder->e_stop) hipEventDestroy(c->finder->e_stop);
@@ -777,6 +786,11 @@ int pga_finder_models_changed(pga_ctx* c) {
     FinderState* f = c->finder;
     f->model_group.clear(); f->group_tt.clear();
     if (f->d_msc) { hipFree(f->d_msc); f->d_msc = nullptr; }
+    if (f->d_model_gc) { hipFree(f->d_model_gc); f->d_model_gc = nullptr; }
+    if (f->d_model_grp) { hipFree(f->d_model_grp); f->d_model_grp = nullptr; }
+    if (f->d_gil) { hipFree(f->d_gil); f->d_gil = nullptr; }
+    if (f->d_model_rank) { hipFree(f->d_model_rank); f->d_model_rank = nullptr; }
+    f->gil_off.clear(); f->gil_stride.clear();
     const int nm = c->n_models;
     if (nm == 0) return PGA_OK;
     std::vector<ModelScoreConst> msc(nm);
@@ -791,6 +805,28 @@ int pga_finder_models_changed(pga_ctx* c) {
     if (f->group_tt.size() > 4) { c->err = "pga_set_models: more than 4 distinct translation tables"; return PGA_EINVAL; }
     HT(c, hipMalloc((void**)&f->d_msc, sizeof(ModelScoreConst) * nm));
     HT(c, hipMemcpy(f->d_msc, msc.data(), sizeof(ModelScoreConst) * nm, hipMemcpyHostToDevice));
+    std::vector<double> mgc(nm);
+    for (int m = 0; m < nm; m++) mgc[m] = c->models[m].gc;
+    HT(c, hipMalloc((void**)&f->d_model_gc, sizeof(double) * nm));
+    HT(c, hipMalloc((void**)&f->d_model_grp, sizeof(int32_t) * nm));
+    HT(c, hipMemcpy(f->d_model_gc, mgc.data(), sizeof(double) * nm, hipMemcpyHostToDevice));
+    HT(c, hipMemcpy(f->d_model_grp, f->model_group.data(), sizeof(int32_t) * nm, hipMemcpyHostToDevice));
+    {
+        const int ng = (int)f->group_tt.size();
+        std::vector<int32_t> rank(nm, 0), count(ng, 0);
+        for (int m = 0; m < nm; m++) rank[m] = count[f->model_group[m]]++;
+        size_t total_il = 0;
+        for (int g = 0; g < ng; g++) { f->gil_stride.push_back((count[g] + 1) & ~1); f->gil_off.push_back(total_il); total_il += (size_t)4096 * f->gil_stride[g]; }
+        std::vector<double> il(total_il + 8, 0.0);               // a pair load at the last column of the last row stays inside
+        for (int m = 0; m < nm; m++) {
+            const int g = f->model_group[m];
+            for (int h = 0; h < 4096; h++) il[f->gil_off[g] + (size_t)h * f->gil_stride[g] + rank[m]] = c->models[m].gene_dc[h];
+        }
+        HT(c, hipMalloc((void**)&f->d_gil, sizeof(double) * il.size()));
+        HT(c, hipMalloc((void**)&f->d_model_rank, sizeof(int32_t) * nm));
+        HT(c, hipMemcpy(f->d_gil, il.data(), sizeof(double) * il.size(), hipMemcpyHostToDevice));
+        HT(c, hipMemcpy(f->d_model_rank, rank.data(), sizeof(int32_t) * nm, hipMemcpyHostToDevice));
+    }
     return PGA_OK;
 }
 
@@ -989,11 +1025,19 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             }
             return publish(R, guard.r, P, out);
         }
+        // meta mode: a contig is extracted under a translation table only if a model with that table lies in its GC window
+        DEVBUF(d_enabled, uint8_t, "d_group_enabled", (size_t)NG * NC + 1);
+        PINBUF(h_enabled, uint8_t, "h_group_enabled", (size_t)NG * NC + 1);
+        if (meta_run && NM > 0) {
+            pga_launch_group_enable(d_ct, NC, d_cnt, f->d_model_gc, f->d_model_grp, NM, NG, d_enabled, st);
+            HT(c, hipMemcpyAsync(h_enabled, d_enabled, (size_t)NG * NC, hipMemcpyDeviceToHost, st));
+        }
         for (int g = 0; g < NG; g++) {
             const int tt = meta_run ? f->group_tt[g] : (stage == PGA_STAGE_EXTRACT ? tt_override : c->models[0].trans_table);
             HT(c, hipMemsetAsync(ga[g].nf_fwd, 0, (size_t)total + 1, st));
             HT(c, hipMemsetAsync(ga[g].nf_rev, 0, (size_t)total + 1, st));
-            pga_launch_extract(d_dig, total, d_ct, NC, tt, P, ga[g], d_tile, d_pre_gc, g == 0, batch->d_tiles, batch->n_tiles, d_tile_first, d_tile_last, masks, st);
+            pga_launch_extract(d_dig, total, d_ct, NC, tt, P, ga[g], d_tile, d_pre_gc, g == 0, batch->d_tiles, batch->n_tiles, d_tile_first, d_tile_last, masks, st,
+                               (meta_run && NM > 0) ? d_enabled + (size_t)g * NC : nullptr);
             hipLaunchKernelGGL(k_contig_node_base, dim3((NC + 1 + 255) / 256), dim3(256), 0, st, d_ct, NC, total, ga[g].pre_nodes, d_cbase + (size_t)g * (NC + 1));
         }
         HT(c, hipMemcpyAsync(h_cnt, d_cnt, sizeof(int32_t) * 2 * (size_t)NC, hipMemcpyDeviceToHost, st));
@@ -1021,6 +1065,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                 const pga_training& t = c->models[m];
                 if (t.gc < low || t.gc > high) continue;
                 const int g = f->model_group[m];
+                if (!h_enabled[(size_t)g * NC + i]) { c->err = "pga_find_genes: host and device disagree on a GC window"; return PGA_EDEVICE; }
                 const int32_t* cb = h_cbase + (size_t)g * (NC + 1);
                 ChainDesc ch{0, cb[i], cb[i + 1] - cb[i], m, i, t.trans_table != tt_prev ? 1 : 0};
                 ch.group = g;
@@ -1060,7 +1105,8 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             DEVBUF(a6, int32_t, "ca_star_ptr", 3 * chain_cap) DEVBUF(a7, int32_t, "ca_mot_ndx", chain_cap) DEVBUF(a8, uint8_t, "ca_rbs", 2 * chain_cap)
             DEVBUF(a9, uint8_t, "ca_edge", chain_cap) DEVBUF(a10, uint8_t, "ca_mot_len", chain_cap) DEVBUF(a11, uint8_t, "ca_mot_spacer", chain_cap)
             DEVBUF(a12, uint8_t, "ca_mot_spacendx", chain_cap)
-            ca = ChainArrays{a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12};
+            DEVBUF(a13, double, "ca_cscore_raw", chain_cap)
+            ca = ChainArrays{a0, a1, a2, a3, a4, a5, a13, a6, a7, a8, a9, a10, a11, a12};
         }
         // few long chains: their walks are cut into segments that run side by side (dp.hip "segmented chains")
         DpSegPlan seg_plan;
@@ -1126,7 +1172,8 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             const int64_t nn = g_n0[g + 1] - g_n0[g];
             if (nch == 0 || nn == 0 || stage == PGA_STAGE_EXTRACT) continue;
             pga_launch_score(d_chains + g_c0[g], nch, g_n0[g], nn, d_dig, d_ct, ga[g], d_models, f->d_msc, c->d_model_const, ca, sp,
-                             d_chains, d_cc + (size_t)g * NC, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], f->d_sd_lut, st);
+                             d_chains, d_cc + (size_t)g * NC, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], f->d_sd_lut, st, 0,
+                             meta_run ? f->d_gil + f->gil_off[g] : nullptr, meta_run ? f->gil_stride[g] : 0, f->d_model_rank);
             NodeArrays na{ga[g].ndx, ga[g].stop_val, ga[g].type, ga[g].strand, ca.cscore, ca.sscore, ca.rscore, ca.uscore, ca.star_ptr};
             if (use_wave) {
                 pga_launch_dpw_topo(wgroups.g[g], ga[g].type, ga[g].strand, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], st);
@@ -1233,6 +1280,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             if (k < 0) continue;
             if (!P.meta || chains[k].first) { fin_off[i] = chains[k].off; continue; }
             ChainDesc ch = chains[k]; ch.first = 1;
+            ch.raw_off = chains[k].off;                 // same contig, same model: the ORF walk of the winning pass stands
             rs_g[f->model_group[ch.model]].push_back(ch);
         }
         std::vector<int> r_c0(NG + 1, 0); std::vector<int64_t> r_n0(NG + 1, 0);
@@ -1251,7 +1299,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                 const int nch = r_c0[g + 1] - r_c0[g]; const int64_t nn = r_n0[g + 1] - r_n0[g];
                 if (nch == 0 || nn == 0) continue;
                 pga_launch_score(d_chains + NCH + r_c0[g], nch, r_n0[g], nn, d_dig, d_ct, ga[g], d_models, f->d_msc, c->d_model_const, ca, sp,
-                                 d_chains, d_cc + (size_t)NG * NC + (size_t)g * NC, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], f->d_sd_lut, st);
+                                 d_chains, d_cc + (size_t)NG * NC + (size_t)g * NC, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], f->d_sd_lut, st, 1);
             }
         }
         tm.mark("winners+rescore_launch");

@@ -62,6 +62,8 @@ struct ChainDesc {
     int64_t rec_off = -1;   // first DpSrc / DpTgt record of the sub-chain; -1: the chain's own, at `off`
     int32_t rebase = 0;     // chain index of the sub-chain's node 0: index fields of DpTgt are shifted down by it
     int32_t group = 0;      // translation-table group of the chain's model: whose topology arrays `topo_off` indexes (dp_wave.hip)
+    int64_t raw_off = -1;   // node scoring: read the raw coding scores of the chain at this offset (same contig, same model)
+                            // instead of the chain's own; -1: its own
 };
 
 // Node fields in device memory (struct of arrays; each pointer covers the whole batch).

@@ -30,6 +30,7 @@ struct GroupArrays {
 // Per (contig, model) chain node fields (SoA over all chains of the batch).
 struct ChainArrays {
     double* cscore; double* sscore; double* rscore; double* uscore; double* tscore; double* mot_score;
+    double* cscore_raw;    // the coding score as the ORF walk leaves it (k_coding_score); `cscore` is what Nodes._score makes of it
     int32_t* star_ptr;     // [n][3]
     int32_t* mot_ndx;
     uint8_t* rbs;          // [n][2]
@@ -58,7 +59,11 @@ void pga_launch_digitize(const char* d_seq, uint8_t* d_dig, int64_t total, const
                          int32_t* d_gc, int32_t* d_unk, hipStream_t st);
 void pga_launch_extract(const uint8_t* d_dig, int64_t total, const ContigDesc* d_ct, int n_contigs, int tt,
                         const pga_params& p, const GroupArrays& ga, int2* d_tile_sum, int32_t* d_pre_gc, int write_gc,
-                        const TileDesc* d_tiles, int n_tiles, int32_t* d_tile_first, int32_t* d_tile_last, MaskList masks, hipStream_t st);
+                        const TileDesc* d_tiles, int n_tiles, int32_t* d_tile_first, int32_t* d_tile_last, MaskList masks, hipStream_t st,
+                        const uint8_t* d_enabled = nullptr /* per contig: extract it in this group?  nullptr = every contig */);
+// per (group, contig): is any model of the group inside the contig's GC window?  (meta mode)
+void pga_launch_group_enable(const ContigDesc* d_ct, int n_contigs, const int32_t* d_gc_count, const double* d_model_gc,
+                             const int32_t* d_model_group, int n_models, int n_groups, uint8_t* d_enabled, hipStream_t st);
 // runs of unknown bases of at least min_mask positions, unordered, at most `cap` of them; *d_count is reset first
 void pga_launch_find_masks(const uint8_t* d_dig, const ContigDesc* d_ct, int n_contigs, const TileDesc* d_tiles, int n_tiles, int min_mask,
                            MaskRun* d_runs, int32_t* d_count, int cap, hipStream_t st);
@@ -71,7 +76,10 @@ void pga_launch_score(const ChainDesc* d_chains, int n_chains, int64_t node_begi
                       const ContigDesc* d_ct, const GroupArrays& ga, const pga_training* d_models,
                       const ModelScoreConst* d_msc, const ModelConst* d_mc, const ChainArrays& ca, ScoreParams sp,
                       const ChainDesc* d_all_chains /* indexed by contig_chains[].x */, const int2* d_contig_chains /* per contig: first chain, count */,
-                      const int32_t* d_node_contig_base, int n_contigs, int group_nodes, const unsigned* d_sd_lut, hipStream_t st);
+                      const int32_t* d_node_contig_base, int n_contigs, int group_nodes, const unsigned* d_sd_lut, hipStream_t st,
+                      int reuse_raw_cscore = 0 /* 1: the chains read the raw coding scores another chain left (ChainDesc::raw_off): no ORF walk */,
+                      const double* d_gil = nullptr /* hexamer tables of the group's models, interleaved: [4096][il_stride] */, int il_stride = 0,
+                      const int32_t* d_rank = nullptr /* model -> column of d_gil */);
 // the RBS search tabulated: 1920 words, filled once per context (see sd_hits in pipeline.hip)
 void pga_launch_sd_lut(unsigned* d_lut, hipStream_t st);
 int64_t pga_scan_tiles(int64_t total);

@@ -171,9 +171,10 @@ constexpr int EX_NONE_HI = 0x7fffffff; // "no stop to the right"
 // pass 1: first / last stop position of every tile, per frame
 __global__ void __launch_bounds__(256)
 k_tile_stops(const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct, const TileDesc* __restrict__ tiles, int n_tiles,
-             int tt, int32_t* __restrict__ tile_first, int32_t* __restrict__ tile_last) {
+             int tt, int32_t* __restrict__ tile_first, int32_t* __restrict__ tile_last, const uint8_t* __restrict__ enabled) {
     __shared__ int s_min[3][4], s_max[3][4];
     const TileDesc td = tiles[blockIdx.x];
+    if (enabled != nullptr && !enabled[td.contig]) return;       // no model of this translation table is scored on the contig
     const int strand = blockIdx.y == 0 ? 1 : -1;
     const ContigDesc cd = ct[td.contig];
     const int L = cd.len;
@@ -213,10 +214,11 @@ k_tile_stops(const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct,
 __global__ void __launch_bounds__(256)
 k_extract_scan(const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct, const TileDesc* __restrict__ tiles, int n_tiles,
                const int32_t* __restrict__ tile_first, const int32_t* __restrict__ tile_last,
-               int tt, int closed, int min_gene, int min_edge_gene, GroupArrays ga, MaskList masks) {
+               int tt, int closed, int min_gene, int min_edge_gene, GroupArrays ga, MaskList masks, const uint8_t* __restrict__ enabled) {
     __shared__ int s_first[3][256], s_last[3][256];
     __shared__ int s_carry_ns[3], s_carry_ps[3];
     const TileDesc td = tiles[blockIdx.x];
+    if (enabled != nullptr && !enabled[td.contig]) return;       // the contig keeps zero nodes in this group
     const int strand = blockIdx.y == 0 ? 1 : -1;
     const ContigDesc cd = ct[td.contig];
     const int L = cd.len;
@@ -530,8 +532,13 @@ __device__ __forceinline__ double length_factor(const ModelScoreConst* mc, int n
 }
 
 // one lane, one (short) ORF
+// gil / il_stride / rank: the hexamer tables of the group's models interleaved, gil[hexamer * il_stride + rank[model]].  The
+// models scored on a contig usually are neighbours in that order (a GC window over bins sorted by GC): their values for one
+// hexamer then sit side by side and come in with one 16-byte load per pair instead of one 8-byte gather per model -- every
+// lane walks its own ORF, so what a load costs is its address, not its width.
 __device__ __forceinline__ void orf_serial(const OrfCtx& o, const ChainDesc* __restrict__ chains, const pga_training* __restrict__ models,
-                           const ModelScoreConst* __restrict__ msc, const ChainArrays& ca) {
+                           const ModelScoreConst* __restrict__ msc, const ChainArrays& ca, const double* __restrict__ gil, const int il_stride,
+                           const int32_t* __restrict__ rank) {
     const uint8_t* __restrict__ d = o.d;
     const int strand = o.strand, step = o.step, p = o.p;
     for (int m0 = 0; m0 < o.cc.y; m0 += CS_MODELS) {
@@ -540,16 +547,29 @@ __device__ __forceinline__ void orf_serial(const OrfCtx& o, const ChainDesc* __r
 #pragma unroll
         for (int m = 0; m < CS_MODELS; m++) {
             const ChainDesc ch = chains[o.cc.x + m0 + (m < nm ? m : 0)];
-            gdc[m] = models[ch.model].gene_dc; csp[m] = ca.cscore + ch.off; mcp[m] = &msc[ch.model];
+            gdc[m] = models[ch.model].gene_dc; csp[m] = ca.cscore_raw + ch.off; mcp[m] = &msc[ch.model];
         }
         double sum[CS_MODELS];
 #pragma unroll
         for (int m = 0; m < CS_MODELS; m++) sum[m] = 0.0;
         int far = -1, mer = 0;
         unsigned long long sm0 = 0, sm1 = 0, sm2 = 0;           // codons that are start nodes (ncod <= CS_LONG = 192)
-        auto visit = [&](const int ci, const int j, const bool isnode) {
+        // neighbours in the interleaved table?
+        const int r0 = rank[chains[o.cc.x + m0].model];
+        bool side_by_side = gil != nullptr;
 #pragma unroll
-            for (int m = 0; m < CS_MODELS; m++) if (m < nm) sum[m] += gdc[m][mer];      // a load only where the lane has a model m
+        for (int m = 1; m < CS_MODELS; m++) if (m < nm) side_by_side = side_by_side && rank[chains[o.cc.x + m0 + m].model] == r0 + m;
+        const double* __restrict__ row0 = gil + r0;
+        auto visit = [&](const int ci, const int j, const bool isnode) {
+            if (side_by_side) {
+                struct P2 { double a, b; } u, v;
+                __builtin_memcpy(&u, row0 + (size_t)mer * il_stride, 16);
+                sum[0] += u.a; sum[1] += u.b;                     // sums of models the lane does not have are never stored
+                if (nm > 2) { __builtin_memcpy(&v, row0 + (size_t)mer * il_stride + 2, 16); sum[2] += v.a; sum[3] += v.b; }
+            } else {
+#pragma unroll
+                for (int m = 0; m < CS_MODELS; m++) if (m < nm) sum[m] += gdc[m][mer];      // a load only where the lane has a model m
+            }
             if (isnode) {
                 const int k = o.pre[j] + (strand == 1 ? 0 : o.nf_f[j]) - o.tbase;
 #pragma unroll
@@ -634,7 +654,7 @@ __device__ __forceinline__ void orf_wave(const OrfCtx& o, const int lane, const 
 #pragma unroll
         for (int m = 0; m < CS_MODELS; m++) {
             const ChainDesc ch = chains[o.cc.x + m0 + (m < nm ? m : 0)];
-            gdc[m] = models[ch.model].gene_dc; csp[m] = ca.cscore + ch.off; mcp[m] = &msc[ch.model];
+            gdc[m] = models[ch.model].gene_dc; csp[m] = ca.cscore_raw + ch.off; mcp[m] = &msc[ch.model];
         }
         double sum[CS_MODELS];
 #pragma unroll
@@ -703,7 +723,8 @@ __global__ void __launch_bounds__(256)
 k_coding_score(const ChainDesc* __restrict__ chains, const int2* __restrict__ contig_chains /* per contig: first chain, count */,
                const int32_t* __restrict__ node_contig_base, int n_contigs, int node_begin, int n_nodes,
                const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct, GroupArrays ga,
-               const pga_training* __restrict__ models, const ModelScoreConst* __restrict__ msc, ChainArrays ca) {
+               const pga_training* __restrict__ models, const ModelScoreConst* __restrict__ msc, ChainArrays ca,
+               const double* __restrict__ gil, int il_stride, const int32_t* __restrict__ rank) {
     __shared__ int s_list[256];
     __shared__ int s_wtot[4];
     const int blk0 = node_begin + blockIdx.x * blockDim.x;
@@ -748,7 +769,7 @@ k_coding_score(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
         if (o.cc.y <= 0) o.ncod = 0;
     }
     const bool is_long = mine && o.ncod > CS_LONG;
-    if (mine && !is_long && o.ncod > 0) orf_serial(o, chains, models, msc, ca);
+    if (mine && !is_long && o.ncod > 0) orf_serial(o, chains, models, msc, ca, gil, il_stride, rank);
     // long ORFs of this wave, one after the other, all 64 lanes on each
     unsigned long long longs = __ballot(is_long);
     while (longs) {
@@ -1020,7 +1041,7 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
         if (edge_in) edge_gene += 1;
         if (stop_missing) edge_gene += 1;
 
-        double tscore, uscore, rscore, sscore, cscore = ca.cscore[g];
+        double tscore, uscore, rscore, sscore, cscore = ca.cscore_raw[(ch.raw_off >= 0 ? ch.raw_off : ch.off) + i];
         if (edge_in) {
             tscore = 0.74 * st_wt / edge_gene; uscore = 0.0; rscore = 0.0;
         } else {
@@ -1177,12 +1198,13 @@ void pga_launch_find_masks(const uint8_t* d_dig, const ContigDesc* d_ct, int n_c
 
 void pga_launch_extract(const uint8_t* d_dig, int64_t total, const ContigDesc* d_ct, int n_contigs, int tt,
                         const pga_params& p, const GroupArrays& ga, int2* d_tile_sum, int32_t* d_pre_gc, int write_gc,
-                        const TileDesc* d_tiles, int n_tiles, int32_t* d_tile_first, int32_t* d_tile_last, MaskList masks, hipStream_t st) {
+                        const TileDesc* d_tiles, int n_tiles, int32_t* d_tile_first, int32_t* d_tile_last, MaskList masks, hipStream_t st,
+                        const uint8_t* d_enabled) {
     if (total <= 0) return;
     if (n_tiles > 0) {
-        hipLaunchKernelGGL(k_tile_stops, dim3(n_tiles, 2), dim3(256), 0, st, d_dig, d_ct, d_tiles, n_tiles, tt, d_tile_first, d_tile_last);
+        hipLaunchKernelGGL(k_tile_stops, dim3(n_tiles, 2), dim3(256), 0, st, d_dig, d_ct, d_tiles, n_tiles, tt, d_tile_first, d_tile_last, d_enabled);
         hipLaunchKernelGGL(k_extract_scan, dim3(n_tiles, 2), dim3(256), 0, st, d_dig, d_ct, d_tiles, n_tiles, d_tile_first, d_tile_last, tt,
-                           p.closed, p.min_gene, p.min_edge_gene, ga, masks);
+                           p.closed, p.min_gene, p.min_edge_gene, ga, masks, d_enabled);
     }
     const int tiles = (int)pga_scan_tiles(total);
     hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(256), 0, st, ga.nf_fwd, ga.nf_rev, d_dig, total, d_tile_sum);
@@ -1192,6 +1214,28 @@ void pga_launch_extract(const uint8_t* d_dig, int64_t total, const ContigDesc* d
 }
 
 int pga_extract_tile_size() { return EX_TILE; }
+
+// Which translation-table groups a contig needs at all: a group whose models all lie outside the contig's GC window
+// (ref: lib.pyx:5335-5336, the same two expressions the host evaluates when it plans the chains) is not extracted for it.
+__global__ void __launch_bounds__(256)
+k_group_enable(const ContigDesc* __restrict__ ct, int n_contigs, const int32_t* __restrict__ gc_count, const double* __restrict__ model_gc,
+               const int32_t* __restrict__ model_group, int n_models, int n_groups, uint8_t* __restrict__ enabled /* [group][contig] */) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_contigs) return;
+    const int L = ct[i].len;
+    const double gc = L > 0 ? (double)gc_count[i] / (double)L : 0.0;
+    const double low = fmin(0.65, 0.88495 * gc - 0.0102337), high = fmax(0.35, 0.86596 * gc + 0.1131991);
+    unsigned need = 0;
+    for (int m = 0; m < n_models; m++) if (!(model_gc[m] < low || model_gc[m] > high)) need |= 1u << model_group[m];
+    for (int g = 0; g < n_groups; g++) enabled[(size_t)g * n_contigs + i] = (need >> g) & 1;
+}
+void pga_launch_group_enable(const ContigDesc* d_ct, int n_contigs, const int32_t* d_gc_count, const double* d_model_gc,
+                             const int32_t* d_model_group, int n_models, int n_groups, uint8_t* d_enabled, hipStream_t st) {
+    if (n_contigs <= 0) return;
+    hipLaunchKernelGGL(k_group_enable, dim3(nblocks(n_contigs, 256)), dim3(256), 0, st, d_ct, n_contigs, d_gc_count, d_model_gc, d_model_group,
+                       n_models, n_groups, d_enabled);
+}
+
 
 void pga_launch_compact(int64_t total, const ContigDesc* d_ct, int n_contigs, const GroupArrays& ga, hipStream_t st) {
     if (total <= 0) return;
@@ -1213,12 +1257,16 @@ void pga_launch_score(const ChainDesc* d_chains, int n_chains, int64_t node_begi
                       const ContigDesc* d_ct, const GroupArrays& ga, const pga_training* d_models,
                       const ModelScoreConst* d_msc, const ModelConst* d_mc, const ChainArrays& ca, ScoreParams sp,
                       const ChainDesc* d_all_chains, const int2* d_contig_chains, const int32_t* d_node_contig_base, int n_contigs,
-                      int group_nodes, const unsigned* d_sd_lut, hipStream_t st) {
+                      int group_nodes, const unsigned* d_sd_lut, hipStream_t st, int reuse_raw_cscore, const double* d_gil, int il_stride,
+                      const int32_t* d_rank) {
     if (total <= 0 || n_chains <= 0) return;
     const dim3 grid(nblocks(total, 256)), blk(256);
-    if (group_nodes > 0)
+    // the raw coding score of a start depends on the model only, not on which model of the group was scored first on the
+    // contig: the fresh re-score of a winning model (ref: lib.pyx:5380-5394) reads it where the winning pass left it
+    // (ChainDesc::raw_off) instead of walking every ORF again
+    if (group_nodes > 0 && !reuse_raw_cscore)
         hipLaunchKernelGGL(k_coding_score, dim3(nblocks(group_nodes, 256)), blk, 0, st, d_all_chains, d_contig_chains, d_node_contig_base,
-                           n_contigs, 0, group_nodes, d_dig, d_ct, ga, d_models, d_msc, ca);
+                           n_contigs, 0, group_nodes, d_dig, d_ct, ga, d_models, d_msc, ca, d_gil, il_stride, d_rank);
     if (group_nodes > 0)
         hipLaunchKernelGGL(k_score_starts, dim3(nblocks(group_nodes, 256)), blk, 0, st, d_all_chains, d_contig_chains, d_node_contig_base, n_contigs,
                            group_nodes, d_dig, d_ct, ga, d_models, ca, sp, d_sd_lut);
