@@ -68,18 +68,50 @@ def pmc_traffic(workload):
         return None
 
 
-def timed_steps(ctx, batches, steps, warmup, sync, gather, **kw):
+class Lanes:
+    """The device calls of one pass, dealt to C contexts (one HIP stream and one set of scratch buffers each) and issued from C host
+    threads: while one call is in a host-side phase (upload, chain planning, unpacking) the other contexts' kernels run.
+    Batch k belongs to context k % C; results come back in batch order."""
+
+    def __init__(self, ctxs):
+        from concurrent.futures import ThreadPoolExecutor
+        self.ctxs = ctxs
+        self.pool = ThreadPoolExecutor(len(ctxs)) if len(ctxs) > 1 else None
+
+    def run(self, n, call):
+        """``call(ctx, k)`` for k in range(n)."""
+        C = len(self.ctxs)
+        out = [None] * n
+        if self.pool is None:
+            for k in range(n):
+                out[k] = call(self.ctxs[0], k)
+            return out
+
+        def lane(c):
+            for k in range(c, n, C):
+                out[k] = call(self.ctxs[c], k)
+        for f in [self.pool.submit(lane, c) for c in range(C)]:
+            f.result()
+        return out
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.shutdown()
+
+
+def timed_steps(lanes, batches, steps, warmup, sync, gather, **kw):
     """W untimed + K timed passes over the resident batches; returns (seconds, dp_ms, node_passes, calls, last results)."""
+    one = lambda ctx, k: ctx.find_genes(batches[k], **kw)
     res = []
     for _ in range(warmup):
-        res = [ctx.find_genes(b, **kw) for b in batches]
+        res = lanes.run(len(batches), one)
         gather(res)
     sync()
     t0 = time.perf_counter()
     dp_ms, passes, calls = 0.0, 0, 0
     genes = None
     for _ in range(steps):
-        res = [ctx.find_genes(b, **kw) for b in batches]
+        res = lanes.run(len(batches), one)
         genes = gather(res)
         for r in res:
             dp_ms += r.t_dp_ms; passes += r.node_passes; calls += 1
@@ -95,6 +127,7 @@ def main():
     ap.add_argument("--workload", default="config4", choices=["config4", "config3", "config2", "config5"])
     ap.add_argument("--contigs", type=int, default=100_000, help="config4: contigs of the whole job")
     ap.add_argument("--sub-batch", type=int, default=12_500, help="contigs per device call")
+    ap.add_argument("--contexts", type=int, default=2, help="device contexts (streams) the calls of a pass are dealt to")
     ap.add_argument("--gen-procs", type=int, default=0, help="worker processes generating the synthetic contigs (0: up to 32; 1: none, e.g. under rocprofv3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
@@ -149,19 +182,25 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from pyrodigal_amd import _cabi
-    ctx = _cabi.Context(dev_index)
+    sub = max(1, args.sub_batch)
+    groups = [seqs[i:i + sub] for i in range(0, len(seqs), sub)]
+    n_ctx = max(1, min(args.contexts, len(groups)))
+    ctxs = [_cabi.Context(dev_index) for _ in range(n_ctx)]
+    ctx = ctxs[0]
     if single:
         from tests.util import golden_path
         import gzip
         with gzip.open(golden_path("GCF_001457455.1_NCTC11397_genomic.tinf_closed.bin.gz")) as f:
-            ctx.set_models([f.read()])
+            blob = f.read()
+        for c in ctxs:
+            c.set_models([blob])
         kw = dict(meta=False, closed=True)
     else:
-        ctx.set_models([m[1] for m in models])
+        for c in ctxs:
+            c.set_models([m[1] for m in models])
         kw = dict(meta=True)
-    sub = max(1, args.sub_batch)
-    groups = [seqs[i:i + sub] for i in range(0, len(seqs), sub)]
-    batches = [ctx.upload(g) for g in groups]
+    lanes = Lanes(ctxs)
+    batches = [ctxs[k % n_ctx].upload(g) for k, g in enumerate(groups)]
     base_of = np.cumsum([0] + [len(g) for g in groups])
     mine_arr = np.asarray(mine, np.int32)
 
@@ -191,18 +230,29 @@ def main():
     t_pre = time.perf_counter()
     while batches and time.perf_counter() - t_pre < 0.5:
         ctx.find_genes(batches[0], **kw)
-    elapsed, dp_ms, passes, calls, res, all_genes = timed_steps(ctx, batches, args.steps, args.warmup, sync, gather, **kw)
+    elapsed, dp_ms, passes, calls, res, all_genes = timed_steps(lanes, batches, args.steps, args.warmup, sync, gather, **kw)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # With several contexts a kernel shares the device with the other contexts' kernels and its own duration says little about
+    # the kernel: the connection-scoring roofline is taken from the same calls issued one after the other (same batches, same
+    # HIP events on the library's stream), right after the timed region; the overlapped figure is reported next to it.
+    dp_ms_shared, passes_shared, calls_shared = dp_ms, passes, calls
+    if n_ctx > 1:
+        dp_ms, passes, calls = 0.0, 0, 0
+        for _ in range(max(1, min(args.steps, 3))):
+            for k, b in enumerate(batches):
+                r = ctxs[k % n_ctx].find_genes(b, **kw)
+                dp_ms += r.t_dp_ms; passes += r.node_passes; calls += 1
+        sync()
 
     # ---- the same loop from host memory: upload inside the timed region (SURVEY 8d's definition of the metric)
     h2h_steps = max(1, min(args.steps, 3))
     sync()
     t0 = time.perf_counter()
     for _ in range(h2h_steps):
-        gather([ctx.find_genes_batch(g, **kw) for g in groups])
+        gather(lanes.run(len(groups), lambda c, k: c.find_genes_batch(groups[k], **kw)))
     sync()
     h2h = time.perf_counter() - t0
     if dist is not None:
@@ -222,6 +272,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wname, "contigs": int(len(lengths)), "bases": job_bases, "models": 1 if single else len(models),
                        "contigs_rank0": len(seqs), "device_calls_per_step_rank0": len(batches), "sub_batch_contigs": sub,
+                       "contexts_per_gpu": n_ctx,
                        "node_passes_per_step_rank0": int(passes // max(args.steps, 1)),
                        "genes_all_ranks": int(sum(len(g) for g in all_genes)) if all_genes is not None else 0,
                        "parallelism": "contigs packed by estimated work over %d GPU(s), one gather of gene records to rank 0" % world,
@@ -231,10 +282,17 @@ def main():
                              "what": "same loop from ASCII contigs in host memory: packing, H2D, path, genes in host memory, gather"},
             "roofline": roofline(ctx, dp_ms, passes, calls, n_chains, wname),
         }
+        if n_ctx > 1:
+            out["roofline"]["measured"] = "calls issued one after the other right after the timed region (kernel alone on the device)"
+            out["roofline"]["kernel_ms_per_launch_in_timed_region"] = round(dp_ms_shared / max(calls_shared, 1), 4)
+            out["roofline"]["frac_in_timed_region"] = round(BYTES_PER_NODE_PASS * passes_shared / (dp_ms_shared * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if dp_ms_shared > 0 else 0.0
         if world == 1 and not args.no_cpu_baseline and not single:
             out["cpu_baseline"] = cpu_baseline(seqs, models, res[0] if res else None)
     for b in batches:
         b.close()
+    lanes.close()
+    for c in ctxs[1:]:
+        c.close()
     if rank == 0 and world == 1 and not args.no_secondary:
         out["secondary"] = secondary(ctx, _cabi, benchdata, models, args.workload, sync)
     ctx.close()
@@ -263,7 +321,7 @@ def secondary(ctx, _cabi, benchdata, models, headline, sync):
         else:
             ctx.set_models([m[1] for m in models])
         b = ctx.upload(seqs)
-        elapsed, dp_ms, passes, calls, res, _ = timed_steps(ctx, [b], steps, 2, sync, lambda r: None, **kw)
+        elapsed, dp_ms, passes, calls, res, _ = timed_steps(Lanes([ctx]), [b], steps, 2, sync, lambda r: None, **kw)
         bases = sum(len(s) for s in seqs)
         t1 = time.perf_counter()
         ctx.find_genes_batch(seqs, **kw)

@@ -563,9 +563,10 @@ __device__ __forceinline__ void orf_serial(const OrfCtx& o, const ChainDesc* __r
         auto visit = [&](const int ci, const int j, const bool isnode) {
             if (side_by_side) {
                 struct P2 { double a, b; } u, v;
-                __builtin_memcpy(&u, row0 + (size_t)mer * il_stride, 16);
+                const double* __restrict__ rp = row0 + (size_t)mer * il_stride;
+                __builtin_memcpy(&u, rp, 16);
                 sum[0] += u.a; sum[1] += u.b;                     // sums of models the lane does not have are never stored
-                if (nm > 2) { __builtin_memcpy(&v, row0 + (size_t)mer * il_stride + 2, 16); sum[2] += v.a; sum[3] += v.b; }
+                if (nm > 2) { __builtin_memcpy(&v, rp + 2, 16); sum[2] += v.a; sum[3] += v.b; }
             } else {
 #pragma unroll
                 for (int m = 0; m < CS_MODELS; m++) if (m < nm) sum[m] += gdc[m][mer];      // a load only where the lane has a model m
