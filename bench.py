@@ -36,12 +36,12 @@ SEGMENTED_DP_KERNELS = ["k_dp_tree_mw", "k_seg_gather", "k_seg_weights", "k_seg_
                         "k_dp_verify"]
 
 
-def roofline(ctx, dp_ms, passes, calls, n_chains, wname):
+def roofline(ctx, dp_ms, passes, calls, n_chains, wname, launch_key=None):
     """Connection scoring against the HBM roofline: 64 B x node-passes / kernel time (HIP events on the library's stream,
     summed over the calls of the timed region)."""
     achieved = BYTES_PER_NODE_PASS * passes / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
     r = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(wname),
+         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(launch_key or wname),
          "kernel": "k_dp_tree_mw" if n_chains < 2048 else ctx.dp_kernel_name(),
          "kernel_ms_per_launch": round(dp_ms / max(calls, 1), 4), "launches": calls,
          "node_passes_per_launch": int(passes // max(calls, 1)), "chains_per_launch": n_chains,
@@ -280,7 +280,9 @@ def main():
             "host_to_host": {"value": round(job_bases * h2h_steps / h2h / 1e6, 3), "unit": "Mbp/s", "steps": h2h_steps,
                              "ms_per_step": round(1e3 * h2h / h2h_steps, 3),
                              "what": "same loop from ASCII contigs in host memory: packing, H2D, path, genes in host memory, gather"},
-            "roofline": roofline(ctx, dp_ms, passes, calls, n_chains, wname),
+            # one launch = one device call = one sub-batch: the PMC passes profile exactly that (tools/collect_profiles.sh)
+            "roofline": roofline(ctx, dp_ms, passes, calls, n_chains, wname,
+                                 "%dx20kbp_gc30-70_meta" % min(sub, len(seqs)) if args.workload == "config4" else None),
         }
         if n_ctx > 1:
             out["roofline"]["measured"] = "calls issued one after the other right after the timed region (kernel alone on the device)"
