@@ -173,6 +173,9 @@ void pga_result_free(pga_result*);
  * pga_batch_create packs and uploads the contigs once, pga_find_genes runs the whole path on it. */
 typedef struct pga_batch pga_batch;
 int  pga_batch_create(pga_ctx*, int32_t n_contigs, const char* const* seqs, const int64_t* lens, pga_batch** out);
+/* The same from contigs that already lie back to back in one host buffer (offs[i + 1] == offs[i] + lens[i]), ideally pinned
+ * (pga_fasta_next_packed): no host-side packing, one DMA of the whole batch.  The buffer may be reused when the call returns. */
+int  pga_batch_create_packed(pga_ctx*, int32_t n_contigs, const char* packed, const int64_t* offs, const int64_t* lens, pga_batch** out);
 void pga_batch_free(pga_batch*);
 int  pga_find_genes(pga_ctx*, const pga_batch*, const pga_params*, pga_result** out);
 
@@ -208,6 +211,13 @@ int         pga_fasta_next(pga_fasta*, int64_t max_bases, int32_t max_records, i
                            const char* const** headers, const char* const** seqs, const int64_t** lens);
 const char* pga_fasta_error(const pga_fasta*);
 void        pga_fasta_close(pga_fasta*);
+/* The same records with their sequences packed back to back in PINNED host memory (hipHostMalloc): `*packed` holds the
+ * letters of the batch, record i at offs[i], lens[i] long, offs[i + 1] == offs[i] + lens[i].  The reader owns `n_arenas`
+ * staging arenas (2 .. 8, fixed at the first call) and fills them in turn: the arrays of a call stay valid until that arena
+ * comes up again, i.e. for the next n_arenas - 1 calls -- batch k can be on its way to the device (pga_batch_create_packed)
+ * while batch k + 1 is being parsed (ref: the reader the reference's CLI feeds its thread pool with, cli.py:287-302). */
+int         pga_fasta_next_packed(pga_fasta*, int64_t max_bases, int32_t max_records, int32_t n_arenas, int32_t* n_records,
+                                  const char* const** headers, const char** packed, const int64_t** offs, const int64_t** lens);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,7 @@ EXPORTS = [
     "pga_score_connections", "pga_score_connections_training", "pga_find_genes_batch", "pga_result_free",
     "pga_batch_create", "pga_batch_free", "pga_find_genes", "pga_nodes_stage",
     "pga_fasta_open", "pga_fasta_next", "pga_fasta_error", "pga_fasta_close", "pga_train", "pga_dp_stats", "pga_dp_plan_summary",
+    "pga_fasta_next_packed", "pga_batch_create_packed",
 ]
 STAGE_EXTRACT, STAGE_SCORE, STAGE_OVERLAP, STAGE_SEQUENCE = 1, 2, 3, 4
 
@@ -112,6 +113,10 @@ def load():
     L.pga_fasta_open.restype = ctypes.c_int; L.pga_fasta_open.argtypes = [ctypes.c_char_p, _P(vp)]
     L.pga_fasta_next.restype = ctypes.c_int
     L.pga_fasta_next.argtypes = [vp, i64, i32, _P(i32), _P(_P(ctypes.c_char_p)), _P(_P(vp)), _P(_P(i64))]
+    L.pga_fasta_next_packed.restype = ctypes.c_int
+    L.pga_fasta_next_packed.argtypes = [vp, i64, i32, i32, _P(i32), _P(_P(ctypes.c_char_p)), _P(vp), _P(_P(i64)), _P(_P(i64))]
+    L.pga_batch_create_packed.restype = ctypes.c_int
+    L.pga_batch_create_packed.argtypes = [vp, i32, vp, _P(i64), _P(i64), _P(vp)]
     L.pga_fasta_error.restype = ctypes.c_char_p; L.pga_fasta_error.argtypes = [vp]
     L.pga_fasta_close.restype = None; L.pga_fasta_close.argtypes = [vp]
     _lib = L
@@ -340,6 +345,41 @@ def _upload(self, seqs):
     return Batch(self, seqs)
 
 
+class PackedRecords:
+    """One batch of a :class:`FastaReader` in packed form: the letters of all records back to back in a pinned staging arena of
+    the reader (``ptr``), record i at ``offs[i]``, ``lens[i]`` long.  ``ids`` / ``descriptions`` are Python strings.  The arena
+    is handed back to the reader by ``release()`` (called by ``Context.upload_packed`` once the letters are on the device)."""
+
+    def __init__(self, reader, n, ids, descriptions, ptr, offs, lens, arena):
+        self.reader, self.n, self.ids, self.descriptions = reader, n, ids, descriptions
+        self.ptr, self.offs, self.lens, self.arena = ptr, offs, lens, arena
+        self.total = int(offs[n]) if n else 0
+
+    def sequence(self, i):
+        """A copy of record i's letters (only while the arena has not been released)."""
+        return ctypes.string_at(self.ptr + int(self.offs[i]), int(self.lens[i]))
+
+    def release(self):
+        if self.arena is not None:
+            self.reader._free[self.arena].set()
+            self.arena = None
+
+
+def _upload_packed(self, pb):
+    """A resident :class:`Batch` straight from a reader's pinned staging arena: no host-side packing, one DMA."""
+    b = Batch.__new__(Batch)
+    b.ctx, b.n, b.total = self, pb.n, pb.total
+    offs = (ctypes.c_int64 * max(1, pb.n + 1))(*[int(x) for x in pb.offs[:pb.n + 1]])
+    lens = (ctypes.c_int64 * max(1, pb.n))(*[int(x) for x in pb.lens[:pb.n]])
+    h = ctypes.c_void_p()
+    rc = self.L.pga_batch_create_packed(self.h, pb.n, ctypes.c_void_p(pb.ptr), offs, lens, ctypes.byref(h))
+    pb.release()
+    if rc != PGA_OK:
+        _raise(self.L, self.h, rc, "pga_batch_create_packed")
+    b.h = h
+    return b
+
+
 def _find_genes(self, batch, meta=True, closed=False, min_gene=90, min_edge_gene=60, max_overlap=60, want_nodes=False,
                 mask=False, min_mask=50):
     """``GeneFinder.find_genes`` over every contig of a resident :class:`Batch`."""
@@ -396,6 +436,7 @@ def _train(self, seq, translation_table=11, start_weight=4.35, force_nonsd=False
 
 Context.train = _train
 Context.upload = _upload
+Context.upload_packed = _upload_packed
 Context.nodes_stage = _nodes_stage
 Context.find_genes = _find_genes
 Context.find_genes_batch = _find_genes_batch
@@ -445,3 +486,35 @@ class FastaReader:
     def records(self):
         for batch in self.batches():
             yield from batch
+
+    def packed_batches(self, max_bases=64 << 20, max_records=0, n_arenas=3):
+        """Yield :class:`PackedRecords`: the reader copies every batch into one of ``n_arenas`` pinned staging arenas, filled
+        in turn.  A batch's arena is reused ``n_arenas`` batches later, and only after ``release()`` was called on it --
+        parsing batch k + 1 overlaps the upload and the device work of batch k."""
+        import threading
+        n_arenas = max(2, min(8, int(n_arenas)))
+        self._free = [threading.Event() for _ in range(n_arenas)]
+        for e in self._free:
+            e.set()
+        n = ctypes.c_int32()
+        hdr = _P(ctypes.c_char_p)(); packed = ctypes.c_void_p(); offs = _P(ctypes.c_int64)(); lens = _P(ctypes.c_int64)()
+        k = 0
+        while True:
+            arena = k % n_arenas
+            self._free[arena].wait()
+            self._free[arena].clear()
+            rc = self.L.pga_fasta_next_packed(self.h, max_bases, max_records, n_arenas, ctypes.byref(n), ctypes.byref(hdr),
+                                              ctypes.byref(packed), ctypes.byref(offs), ctypes.byref(lens))
+            if rc != PGA_OK:
+                raise (MemoryError if rc == PGA_ENOMEM else ValueError)(self.L.pga_fasta_error(self.h).decode("utf-8", "replace"))
+            if n.value == 0:
+                self._free[arena].set()
+                return
+            ids, descs = [], []
+            for i in range(n.value):
+                fields = hdr[i].decode("utf-8", "replace").split(maxsplit=1)
+                ids.append(fields[0] if fields else ""); descs.append(fields[1] if len(fields) > 1 else "")
+            o = np.ctypeslib.as_array(offs, (n.value + 1,)).copy()
+            ln = np.ctypeslib.as_array(lens, (n.value,)).copy()
+            yield PackedRecords(self, n.value, ids, descs, packed.value, o, ln, arena)
+            k += 1

@@ -6,6 +6,7 @@
 // of surrounding whitespace, is appended to the sequence; text before the first header is dropped, and a
 // file with sequence text but no header at all is not FASTA.  Records are handed out in batches bounded by a
 // base budget so that a caller can keep one batch on the device while the next one is being read.
+#include <hip/hip_runtime.h>
 #include <zlib.h>
 
 #include <cstdio>
@@ -30,6 +31,11 @@ struct pga_fasta {
     std::vector<const char*> p_hdr, p_seq;
     std::vector<int64_t> lens;
     bool pending = false;                // cur_* holds a finished record that did not fit the previous batch
+    // packed mode: staging arenas in pinned host memory, filled in turn
+    struct Arena { char* p = nullptr; size_t cap = 0; };
+    std::vector<Arena> arenas;
+    size_t next_arena = 0;
+    std::vector<int64_t> offs;
 };
 
 static bool fill(pga_fasta* f) {
@@ -74,6 +80,7 @@ extern "C" int pga_fasta_open(const char* path, pga_fasta** out) {
 extern "C" void pga_fasta_close(pga_fasta* f) {
     if (!f) return;
     if (f->gz) gzclose(f->gz);
+    for (auto& a : f->arenas) if (a.p) hipHostFree(a.p);
     delete f;
 }
 
@@ -122,5 +129,35 @@ extern "C" int pga_fasta_next(pga_fasta* f, int64_t max_bases, int32_t max_recor
     if (headers) *headers = f->p_hdr.data();
     if (seqs) *seqs = f->p_seq.data();
     if (lens) *lens = f->lens.data();
+    return PGA_OK;
+}
+
+
+// The batch of pga_fasta_next, sequences copied back to back into the next pinned staging arena.
+extern "C" int pga_fasta_next_packed(pga_fasta* f, int64_t max_bases, int32_t max_records, int32_t n_arenas, int32_t* n_records,
+                                     const char* const** headers, const char** packed, const int64_t** offs, const int64_t** lens) {
+    if (!f || !n_records || !packed || !offs) return PGA_EINVAL;
+    if (f->arenas.empty()) f->arenas.resize((size_t)(n_arenas < 2 ? 2 : (n_arenas > 8 ? 8 : n_arenas)));
+    const char* const* seqs = nullptr;
+    const int64_t* ln = nullptr;
+    const int rc = pga_fasta_next(f, max_bases, max_records, n_records, headers, &seqs, &ln);
+    if (rc != PGA_OK) return rc;
+    *packed = nullptr; *offs = nullptr;
+    if (lens) *lens = ln;
+    if (*n_records == 0) return PGA_OK;
+    size_t total = 0;
+    f->offs.assign((size_t)*n_records + 1, 0);
+    for (int32_t i = 0; i < *n_records; i++) { f->offs[(size_t)i] = (int64_t)total; total += (size_t)ln[i]; }
+    f->offs[(size_t)*n_records] = (int64_t)total;
+    pga_fasta::Arena& a = f->arenas[f->next_arena];
+    f->next_arena = (f->next_arena + 1) % f->arenas.size();
+    if (a.cap < total + 16) {
+        if (a.p) { hipHostFree(a.p); a.p = nullptr; a.cap = 0; }
+        const size_t want = total + total / 4 + 4096;
+        if (hipHostMalloc((void**)&a.p, want, hipHostMallocDefault) != hipSuccess) { a.p = nullptr; f->err = "hipHostMalloc failed for a staging arena"; return PGA_ENOMEM; }
+        a.cap = want;
+    }
+    for (int32_t i = 0; i < *n_records; i++) memcpy(a.p + f->offs[(size_t)i], seqs[i], (size_t)ln[i]);
+    *packed = a.p; *offs = f->offs.data();
     return PGA_OK;
 }

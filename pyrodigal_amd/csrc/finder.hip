@@ -95,7 +95,7 @@ struct FinderState {
     int32_t* d_model_grp = nullptr;
     // the hexamer tables (gene_dc) of each group's models interleaved: d_gil + gil_off[g], [4096][gil_stride[g]]; d_model_rank[m] = column
     double* d_gil = nullptr; int32_t* d_model_rank = nullptr;
-    std::vector<size_t> gil_off; std::vector<int> gil_stride;
+    std::vector<size_t> gil_off; std::vector<int> gil_stride; std::vector<int32_t> model_rank;
     unsigned* d_sd_lut = nullptr;   // RBS search table (pga_launch_sd_lut), filled when the context's finder state is created
     hipEvent_t e_start = nullptr, e_stop = nullptr, e_dp0[4] = {}, e_dp1[4] = {};
 };
@@ -826,6 +826,7 @@ int pga_finder_models_changed(pga_ctx* c) {
         HT(c, hipMalloc((void**)&f->d_model_rank, sizeof(int32_t) * nm));
         HT(c, hipMemcpy(f->d_gil, il.data(), sizeof(double) * il.size(), hipMemcpyHostToDevice));
         HT(c, hipMemcpy(f->d_model_rank, rank.data(), sizeof(int32_t) * nm, hipMemcpyHostToDevice));
+        f->model_rank = rank;
     }
     return PGA_OK;
 }
@@ -876,6 +877,44 @@ extern "C" int pga_batch_create(pga_ctx* c, int32_t n_contigs, const char* const
             e = hipMemcpy(b->d_tiles, tiles.data(), sizeof(TileDesc) * tiles.size(), hipMemcpyHostToDevice);
             if (e != hipSuccess) { hipFree(b->d_tiles); hipFree(b->d_seq); delete b; return pga_hip_try_(c, e, "upload of the tile list"); }
         }
+    }
+    *out = b;
+    return PGA_OK;
+}
+
+extern "C" int pga_batch_create_packed(pga_ctx* c, int32_t n_contigs, const char* packed, const int64_t* offs, const int64_t* lens, pga_batch** out) {
+    if (out) *out = nullptr;
+    if (!c || !out || n_contigs < 0 || (n_contigs > 0 && (!packed || !offs || !lens))) { if (c) c->err = "pga_batch_create_packed: bad arguments"; return PGA_EINVAL; }
+    for (int i = 0; i < n_contigs; i++) {
+        if (lens[i] < 0 || lens[i] > 0x7fff0000LL || offs[i] != offs[0] + (i ? offs[i - 1] - offs[0] + lens[i - 1] : 0)) {
+            c->err = "pga_batch_create_packed: contigs must lie back to back"; return PGA_EINVAL;
+        }
+    }
+    if (!c->finder) { int rc = pga_finder_models_changed(c); if (rc) return rc; }
+    HT(c, hipSetDevice(c->device));
+    pga_batch* b = new (std::nothrow) pga_batch();
+    if (!b) return PGA_ENOMEM;
+    b->ctx = c; b->n = n_contigs; b->d_seq = nullptr; b->d_tiles = nullptr; b->n_tiles = 0; b->ct.resize((size_t)n_contigs + 1);
+    int64_t total = 0;
+    for (int i = 0; i < n_contigs; i++) { b->ct[i].base = total; b->ct[i].len = (int32_t)lens[i]; b->ct[i]._pad = 0; total += lens[i]; }
+    b->ct[n_contigs].base = total; b->ct[n_contigs].len = 0; b->ct[n_contigs]._pad = 0;
+    b->total = total;
+    if (total >= 0x7fffffffLL) { delete b; c->err = "pga_batch_create_packed: batch larger than 2^31 bases; split it"; return PGA_EINVAL; }
+    if (total > 0) {
+        if (hipMalloc((void**)&b->d_seq, (size_t)total + 16) != hipSuccess) { delete b; c->err = "pga_batch_create_packed: hipMalloc failed"; return PGA_ENOMEM; }
+        std::vector<TileDesc> tiles;
+        const int TS = pga_extract_tile_size();
+        for (int i = 0; i < n_contigs; i++)
+            for (int64_t s0 = 0; s0 + 2 < lens[i]; s0 += TS) tiles.push_back(TileDesc{i, (int32_t)s0});
+        b->n_tiles = (int32_t)tiles.size();
+        // the letters go straight from the caller's (pinned) buffer: one DMA, overlapped with the tile list's host work above
+        hipError_t e = hipMemcpyAsync(b->d_seq, packed + offs[0], (size_t)total, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess && !tiles.empty()) {
+            if (hipMalloc((void**)&b->d_tiles, sizeof(TileDesc) * tiles.size()) != hipSuccess) e = hipErrorOutOfMemory;
+            else e = hipMemcpyAsync(b->d_tiles, tiles.data(), sizeof(TileDesc) * tiles.size(), hipMemcpyHostToDevice, c->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { if (b->d_tiles) hipFree(b->d_tiles); hipFree(b->d_seq); delete b; return pga_hip_try_(c, e, "upload of the packed batch"); }
     }
     *out = b;
     return PGA_OK;
@@ -1163,6 +1202,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         HT(c, hipMemcpyAsync(d_cc, h_cc, sizeof(int2) * (size_t)NG * NC, hipMemcpyHostToDevice, st));
 
         tm.mark("plan+alloc");
+        std::vector<int32_t> cs_tk[4], cs_en[4];
         const ScoreParams sp{P.closed, P.meta, P.max_overlap, 0};
         const pga_training* d_models = (const pga_training*)c->d_models_raw;
         for (int g = 0; g < NG; g++) {
@@ -1171,9 +1211,27 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             const int nch = g_c0[g + 1] - g_c0[g];
             const int64_t nn = g_n0[g + 1] - g_n0[g];
             if (nch == 0 || nn == 0 || stage == PGA_STAGE_EXTRACT) continue;
+            // meta mode, many contigs: the ORF walks of the coding score run from hexamer tables in LDS, contigs bucketed by the
+            // four table columns they need (PGA_CS_LDS=0: the global-memory form)
+            const void* d_cs_tasks = nullptr; const void* d_cs_entries = nullptr; int n_cs_tasks = 0;
+            const char* cs_env = getenv("PGA_CS_LDS");
+            if (meta_run && nn >= 65536 && !(cs_env && atoi(cs_env) == 0)) {
+                std::vector<int32_t>& tk = cs_tk[g]; std::vector<int32_t>& en = cs_en[g];     // alive until the stream is synchronized
+                if (pga_cs_tasks(h_cc + (size_t)g * NC, NC, chains.data(), h_cbase + (size_t)g * (NC + 1), f->model_rank.data(), 8192, tk, en) && !tk.empty()) {
+                    char nm1[32], nm2[32];
+                    snprintf(nm1, sizeof nm1, "cs_tasks%d", g); snprintf(nm2, sizeof nm2, "cs_entries%d", g);
+                    void* p1; void* p2;
+                    { int rc__ = ensure_dev(c, nm1, tk.size() * 4 + 64, &p1); if (rc__) return rc__; }
+                    { int rc__ = ensure_dev(c, nm2, en.size() * 4 + 64, &p2); if (rc__) return rc__; }
+                    HT(c, hipMemcpyAsync(p1, tk.data(), tk.size() * 4, hipMemcpyHostToDevice, st));
+                    HT(c, hipMemcpyAsync(p2, en.data(), en.size() * 4, hipMemcpyHostToDevice, st));
+                    d_cs_tasks = p1; d_cs_entries = p2; n_cs_tasks = (int)(tk.size() / 4);
+                }
+            }
             pga_launch_score(d_chains + g_c0[g], nch, g_n0[g], nn, d_dig, d_ct, ga[g], d_models, f->d_msc, c->d_model_const, ca, sp,
                              d_chains, d_cc + (size_t)g * NC, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], f->d_sd_lut, st, 0,
-                             meta_run ? f->d_gil + f->gil_off[g] : nullptr, meta_run ? f->gil_stride[g] : 0, f->d_model_rank);
+                             meta_run ? f->d_gil + f->gil_off[g] : nullptr, meta_run ? f->gil_stride[g] : 0, f->d_model_rank,
+                             d_cs_tasks, n_cs_tasks, d_cs_entries);
             NodeArrays na{ga[g].ndx, ga[g].stop_val, ga[g].type, ga[g].strand, ca.cscore, ca.sscore, ca.rscore, ca.uscore, ca.star_ptr};
             if (use_wave) {
                 pga_launch_dpw_topo(wgroups.g[g], ga[g].type, ga[g].strand, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], st);

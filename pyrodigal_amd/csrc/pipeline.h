@@ -79,7 +79,11 @@ void pga_launch_score(const ChainDesc* d_chains, int n_chains, int64_t node_begi
                       const int32_t* d_node_contig_base, int n_contigs, int group_nodes, const unsigned* d_sd_lut, hipStream_t st,
                       int reuse_raw_cscore = 0 /* 1: the chains read the raw coding scores another chain left (ChainDesc::raw_off): no ORF walk */,
                       const double* d_gil = nullptr /* hexamer tables of the group's models, interleaved: [4096][il_stride] */, int il_stride = 0,
-                      const int32_t* d_rank = nullptr /* model -> column of d_gil */);
+                      const int32_t* d_rank = nullptr /* model -> column of d_gil */,
+                      const void* d_cs_tasks = nullptr, int n_cs_tasks = 0, const void* d_cs_entries = nullptr /* pga_cs_tasks: ORF walks from LDS tables */);
+// host: the tasks of the LDS form of the coding score for one group (pipeline.hip); false = models are not neighbours in the table
+bool pga_cs_tasks(const int2* h_cc, int n_contigs, const ChainDesc* h_chains, const int32_t* h_cbase, const int32_t* model_rank, int task_nodes,
+                  std::vector<int32_t>& tasks, std::vector<int32_t>& entries);
 // the RBS search tabulated: 1920 words, filled once per context (see sd_hits in pipeline.hip)
 void pga_launch_sd_lut(unsigned* d_lut, hipStream_t st);
 int64_t pga_scan_tiles(int64_t total);

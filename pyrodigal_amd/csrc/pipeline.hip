@@ -531,6 +531,18 @@ __device__ __forceinline__ double length_factor(const ModelScoreConst* mc, int n
     return mc->lfac_tab[ncodons];
 }
 
+// codons of the ORF of a stop node at p (far end q) in walk order: x(ci) = p + step * (ci + 1), ci = 0 .. ncod-1
+__device__ __forceinline__ int orf_codons(const int p, const int q, const int strand, const int L) {
+    if (strand == 1) {
+        const int lowb = max(q + 1, 0);
+        const int xmin = lowb + (((p - lowb) % 3) + 3) % 3;
+        return xmin <= p - 3 ? (p - 3 - xmin) / 3 + 1 : 0;
+    }
+    const int highb = min(q - 1, L - 1);
+    const int xmax = highb - (((highb - p) % 3) + 3) % 3;
+    return xmax >= p + 3 ? (xmax - (p + 3)) / 3 + 1 : 0;
+}
+
 // one lane, one (short) ORF
 // gil / il_stride / rank: the hexamer tables of the group's models interleaved, gil[hexamer * il_stride + rank[model]].  The
 // models scored on a contig usually are neighbours in that order (a GC window over bins sorted by GC): their values for one
@@ -538,11 +550,13 @@ __device__ __forceinline__ double length_factor(const ModelScoreConst* mc, int n
 // lane walks its own ORF, so what a load costs is its address, not its width.
 __device__ __forceinline__ void orf_serial(const OrfCtx& o, const ChainDesc* __restrict__ chains, const pga_training* __restrict__ models,
                            const ModelScoreConst* __restrict__ msc, const ChainArrays& ca, const double* __restrict__ gil, const int il_stride,
-                           const int32_t* __restrict__ rank) {
+                           const int32_t* __restrict__ rank, const double* quad = nullptr, const int m_lo = 0, const int m_hi = 0x7fffffff) {
+    // quad != nullptr: the tables of the four models [m_lo, m_lo + 4) of the contig sit interleaved in LDS, quad[hexamer * 4 + m]
     const uint8_t* __restrict__ d = o.d;
     const int strand = o.strand, step = o.step, p = o.p;
-    for (int m0 = 0; m0 < o.cc.y; m0 += CS_MODELS) {
-        const int nm = min(CS_MODELS, o.cc.y - m0);
+    const int m_end = min(o.cc.y, m_hi);
+    for (int m0 = m_lo; m0 < m_end; m0 += CS_MODELS) {
+        const int nm = min(CS_MODELS, m_end - m0);
         const double* gdc[CS_MODELS]; double* csp[CS_MODELS]; const ModelScoreConst* mcp[CS_MODELS];
 #pragma unroll
         for (int m = 0; m < CS_MODELS; m++) {
@@ -561,7 +575,10 @@ __device__ __forceinline__ void orf_serial(const OrfCtx& o, const ChainDesc* __r
         for (int m = 1; m < CS_MODELS; m++) if (m < nm) side_by_side = side_by_side && rank[chains[o.cc.x + m0 + m].model] == r0 + m;
         const double* __restrict__ row0 = gil + r0;
         auto visit = [&](const int ci, const int j, const bool isnode) {
-            if (side_by_side) {
+            if (quad != nullptr) {
+                const double* q4 = quad + 4 * mer;               // one 32-byte row of LDS: two ds_read_b128
+                sum[0] += q4[0]; sum[1] += q4[1]; sum[2] += q4[2]; sum[3] += q4[3];
+            } else if (side_by_side) {
                 struct P2 { double a, b; } u, v;
                 const double* __restrict__ rp = row0 + (size_t)mer * il_stride;
                 __builtin_memcpy(&u, rp, 16);
@@ -646,11 +663,13 @@ __device__ __forceinline__ void orf_serial(const OrfCtx& o, const ChainDesc* __r
 
 // the whole wavefront, one (long) ORF; `o` is wave-uniform
 __device__ __forceinline__ void orf_wave(const OrfCtx& o, const int lane, const ChainDesc* __restrict__ chains, const pga_training* __restrict__ models,
-                         const ModelScoreConst* __restrict__ msc, const ChainArrays& ca) {
+                         const ModelScoreConst* __restrict__ msc, const ChainArrays& ca, const double* quad = nullptr, const int m_lo = 0,
+                         const int m_hi = 0x7fffffff) {
     const double NEG_INF = -__builtin_huge_val();
     const int strand = o.strand, step = o.step, p = o.p, ncod = o.ncod;
-    for (int m0 = 0; m0 < o.cc.y; m0 += CS_MODELS) {
-        const int nm = min(CS_MODELS, o.cc.y - m0);
+    const int m_end = min(o.cc.y, m_hi);
+    for (int m0 = m_lo; m0 < m_end; m0 += CS_MODELS) {
+        const int nm = min(CS_MODELS, m_end - m0);
         const double* gdc[CS_MODELS]; double* csp[CS_MODELS]; const ModelScoreConst* mcp[CS_MODELS];
 #pragma unroll
         for (int m = 0; m < CS_MODELS; m++) {
@@ -670,7 +689,7 @@ __device__ __forceinline__ void orf_wave(const OrfCtx& o, const int lane, const 
             const int k = fl ? o.pre[x] + (strand == 1 ? 0 : o.nf_f[x]) - o.tbase : 0;
             double v[CS_MODELS], pref[CS_MODELS];
 #pragma unroll
-            for (int m = 0; m < CS_MODELS; m++) { v[m] = (valid && m < nm) ? gdc[m][mer] : 0.0; pref[m] = 0.0; }
+            for (int m = 0; m < CS_MODELS; m++) { v[m] = (valid && m < nm) ? (quad != nullptr ? quad[4 * mer + m] : gdc[m][mer]) : 0.0; pref[m] = 0.0; }
             const int nv = min(64, ncod - c0);
             for (int l = 0; l < nv; l++) {
 #pragma unroll
@@ -789,6 +808,117 @@ k_coding_score(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
         w.ncod = __builtin_amdgcn_readlane(o.ncod, src);
         w.cc.x = __builtin_amdgcn_readlane(o.cc.x, src); w.cc.y = __builtin_amdgcn_readlane(o.cc.y, src);
         orf_wave(w, lane, chains, models, msc, ca);
+    }
+}
+
+// The same walks with the hexamer tables in LDS.  Work comes in TASKS: a run of (contig, first model) entries whose four
+// models [m0, m0 + 4) are the same four columns q .. q + 3 of the group's interleaved table (contigs with neighbouring GC
+// share them).  A workgroup copies those four columns into LDS once (128 KB, interleaved per hexamer) and then walks every
+// ORF of its contigs against them: a codon step is two ds_read_b128 instead of two 64-line gathers through the texture
+// path, which is what bounds the global-memory form (every lane walks its own ORF).
+struct CsTask { int32_t q, first, count, _pad; };      // columns q .. q+3; entries [first, first + count)
+struct CsEntry { int32_t contig, m0; };
+constexpr int CS_TASK_THREADS = 1024;
+constexpr int CS_TASK_MAX_ENTRIES = 256;
+constexpr int CS_ROUND = 6144;                         // nodes examined per round of a task
+constexpr int CS_CLASSES = 8;                          // ORF length classes of a round
+__global__ void __launch_bounds__(CS_TASK_THREADS)
+k_coding_score_quads(const CsTask* __restrict__ tasks, const CsEntry* __restrict__ entries, const ChainDesc* __restrict__ chains,
+                     const int2* __restrict__ contig_chains, const int32_t* __restrict__ node_contig_base,
+                     const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct, GroupArrays ga,
+                     const pga_training* __restrict__ models, const ModelScoreConst* __restrict__ msc, ChainArrays ca,
+                     const double* __restrict__ gil, int il_stride, const int32_t* __restrict__ rank) {
+    extern __shared__ __attribute__((aligned(16))) double s_quad[];                  // [4096][4]
+    __shared__ int s_pre[CS_TASK_MAX_ENTRIES + 1];      // first node (task-local numbering) of every entry
+    __shared__ int s_list[CS_ROUND];
+    __shared__ int s_count;
+    __shared__ int s_cls[CS_CLASSES];
+    const CsTask task = tasks[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int idx = tid; idx < 4096 * 4; idx += CS_TASK_THREADS) {
+        const int h = idx >> 2, k = idx & 3;
+        s_quad[idx] = task.q + k < il_stride ? gil[(size_t)h * il_stride + task.q + k] : 0.0;
+    }
+    if (tid == 0) {
+        int acc = 0;
+        for (int e = 0; e < task.count; e++) {
+            const int c = entries[task.first + e].contig;
+            s_pre[e] = acc; acc += node_contig_base[c + 1] - node_contig_base[c];
+        }
+        s_pre[task.count] = acc;
+    }
+    __syncthreads();
+    const int total = s_pre[task.count];
+    // Rounds of CS_ROUND nodes: every thread looks at CS_ROUND / 1024 nodes, the stop nodes among them (about one node in five) are
+    // listed in LDS, then each wave takes 64 entries of the list at a time -- all sixteen waves walk, whatever the mix of nodes.
+    for (int base = 0; base < total; base += CS_ROUND) {
+        // the stop nodes of the round, listed by length class of their ORF (longest first): the 64 lanes of a wave then walk ORFs of
+        // similar length instead of waiting for the longest of a random 64
+        if (tid < CS_CLASSES) s_cls[tid] = 0;
+        __syncthreads();
+        int my_cls[CS_ROUND / CS_TASK_THREADS];
+#pragma unroll
+        for (int r = 0; r < CS_ROUND / CS_TASK_THREADS; r++) {
+            const int local = base + tid + r * CS_TASK_THREADS;
+            my_cls[r] = -1;
+            if (local >= total) continue;
+            int lo = 0, hi = task.count - 1;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_pre[mid] <= local) lo = mid; else hi = mid - 1; }
+            const int c = entries[task.first + lo].contig;
+            const int t = node_contig_base[c] + (local - s_pre[lo]);
+            if (ga.type[t] != PGA_T_STOP) continue;
+            const int ncod = orf_codons(ga.ndx[t], ga.stop_val[t], ga.strand[t], ct[c].len);
+            if (ncod <= 0) continue;
+            my_cls[r] = ncod > CS_LONG ? 0 : (ncod > 128 ? 1 : (ncod > 64 ? 2 : (ncod > 32 ? 3 : (ncod > 16 ? 4 : (ncod > 8 ? 5 : 6)))));
+            atomicAdd(&s_cls[my_cls[r]], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int acc = 0;
+            for (int k = 0; k < CS_CLASSES; k++) { const int n = s_cls[k]; s_cls[k] = acc; acc += n; }
+            s_count = acc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < CS_ROUND / CS_TASK_THREADS; r++)
+            if (my_cls[r] >= 0) s_list[atomicAdd(&s_cls[my_cls[r]], 1)] = base + tid + r * CS_TASK_THREADS;
+        __syncthreads();
+        const int cnt = s_count, n_long = s_cls[0];       // after the placement s_cls[k] is where class k ends
+        auto orf_of = [&](const int loc, int& m0) {
+            OrfCtx o{};
+            int lo = 0, hi = task.count - 1;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_pre[mid] <= loc) lo = mid; else hi = mid - 1; }
+            const CsEntry en = entries[task.first + lo];
+            const int c = en.contig;
+            m0 = en.m0;
+            const int tt = node_contig_base[c] + (loc - s_pre[lo]);
+            o.cc = contig_chains[c];
+            const ContigDesc cd = ct[c];
+            o.d = dig + cd.base;
+            o.strand = ga.strand[tt];
+            o.nf = (o.strand == 1 ? ga.nf_fwd : ga.nf_rev) + cd.base; o.nf_f = ga.nf_fwd + cd.base;
+            o.pre = ga.pre_nodes + cd.base;
+            o.tbase = node_contig_base[c];
+            o.p = ga.ndx[tt]; o.q = ga.stop_val[tt]; o.L = cd.len;
+            o.step = o.strand == 1 ? -3 : 3;
+            o.ncod = o.cc.y <= 0 ? 0 : orf_codons(o.p, o.q, o.strand, o.L);
+            return o;
+        };
+        // long ORFs (the first n_long entries): one per wave at a time, dealt round-robin, all 64 lanes on each
+        for (int k = wv; k < n_long; k += CS_TASK_THREADS / 64) {
+            int m0;
+            const OrfCtx w = orf_of(s_list[k], m0);          // the same entry in every lane
+            if (w.ncod > 0) orf_wave(w, lane, chains, models, msc, ca, s_quad, m0, m0 + 4);
+        }
+        // the others, 64 of similar length per wave
+        for (int lb = n_long + wv * 64; lb < cnt; lb += CS_TASK_THREADS) {
+            if (lb + lane < cnt) {
+                int m0;
+                const OrfCtx o = orf_of(s_list[lb + lane], m0);
+                if (o.ncod > 0) orf_serial(o, chains, models, msc, ca, nullptr, 0, rank, s_quad, m0, m0 + 4);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -1216,6 +1346,39 @@ void pga_launch_extract(const uint8_t* d_dig, int64_t total, const ContigDesc* d
 
 int pga_extract_tile_size() { return EX_TILE; }
 
+// Tasks of k_coding_score_quads for one translation-table group: contigs whose models [m0, m0 + 4) are the same four columns
+// of the group's interleaved table, in runs of about `task_nodes` nodes.  Returns false (and leaves the outputs empty) when
+// some contig's models are not neighbours in the table: the caller then takes the global-memory form.
+bool pga_cs_tasks(const int2* h_cc /* per contig: first chain, count */, int n_contigs, const ChainDesc* h_chains, const int32_t* h_cbase,
+                  const int32_t* model_rank, int task_nodes, std::vector<int32_t>& tasks /* 4 per task */, std::vector<int32_t>& entries /* 2 per entry */) {
+    tasks.clear(); entries.clear();
+    std::vector<std::vector<int32_t>> bucket(64);
+    for (int i = 0; i < n_contigs; i++) {
+        const int2 cc = h_cc[i];
+        if (cc.y <= 0 || h_cbase[i + 1] == h_cbase[i]) continue;
+        const int r0 = model_rank[h_chains[cc.x].model];
+        for (int m = 1; m < cc.y; m++) if (model_rank[h_chains[cc.x + m].model] != r0 + m) return false;
+        for (int m0 = 0; m0 < cc.y; m0 += 4) {
+            if (r0 + m0 >= 64) return false;
+            bucket[(size_t)(r0 + m0)].push_back(i); bucket[(size_t)(r0 + m0)].push_back(m0);
+        }
+    }
+    for (int q = 0; q < 64; q++) {
+        const std::vector<int32_t>& b = bucket[(size_t)q];
+        int first = (int)(entries.size() / 2), count = 0, nodes = 0;
+        for (size_t k = 0; k < b.size(); k += 2) {
+            entries.push_back(b[k]); entries.push_back(b[k + 1]);
+            count++; nodes += h_cbase[b[k] + 1] - h_cbase[b[k]];
+            if (nodes >= task_nodes || count == CS_TASK_MAX_ENTRIES) {
+                tasks.push_back(q); tasks.push_back(first); tasks.push_back(count); tasks.push_back(0);
+                first += count; count = 0; nodes = 0;
+            }
+        }
+        if (count > 0) { tasks.push_back(q); tasks.push_back(first); tasks.push_back(count); tasks.push_back(0); }
+    }
+    return true;
+}
+
 // Which translation-table groups a contig needs at all: a group whose models all lie outside the contig's GC window
 // (ref: lib.pyx:5335-5336, the same two expressions the host evaluates when it plans the chains) is not extracted for it.
 __global__ void __launch_bounds__(256)
@@ -1259,9 +1422,19 @@ void pga_launch_score(const ChainDesc* d_chains, int n_chains, int64_t node_begi
                       const ModelScoreConst* d_msc, const ModelConst* d_mc, const ChainArrays& ca, ScoreParams sp,
                       const ChainDesc* d_all_chains, const int2* d_contig_chains, const int32_t* d_node_contig_base, int n_contigs,
                       int group_nodes, const unsigned* d_sd_lut, hipStream_t st, int reuse_raw_cscore, const double* d_gil, int il_stride,
-                      const int32_t* d_rank) {
+                      const int32_t* d_rank, const void* d_cs_tasks, int n_cs_tasks, const void* d_cs_entries) {
     if (total <= 0 || n_chains <= 0) return;
     const dim3 grid(nblocks(total, 256)), blk(256);
+    if (group_nodes > 0 && !reuse_raw_cscore && n_cs_tasks > 0) {
+        // the ORF walks against hexamer tables in LDS (tasks built by the caller, pga_cs_tasks)
+        static bool once = false;
+        const size_t lds = sizeof(double) * 4096 * 4;
+        if (!once) { hipFuncSetAttribute((const void*)k_coding_score_quads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+        hipLaunchKernelGGL(k_coding_score_quads, dim3((unsigned)n_cs_tasks), dim3(CS_TASK_THREADS), lds, st, (const CsTask*)d_cs_tasks,
+                           (const CsEntry*)d_cs_entries, d_all_chains, d_contig_chains, d_node_contig_base, d_dig, d_ct, ga, d_models, d_msc, ca,
+                           d_gil, il_stride, d_rank);
+        reuse_raw_cscore = 1;           // done: skip the global-memory form below
+    }
     // the raw coding score of a start depends on the model only, not on which model of the group was scored first on the
     // contig: the fresh re-score of a winning model (ref: lib.pyx:5380-5394) reads it where the winning pass left it
     // (ChainDesc::raw_off) instead of walking every ORF again

@@ -71,3 +71,75 @@ def find_genes_stream(batches, model_blobs, n_contexts=2, device=0, **find_kw):
             t.join()
         for c in ctxs:
             c.close()
+
+
+def find_genes_fasta(path, model_blobs, n_contexts=2, device=0, max_bases=64 << 20, **find_kw):
+    """Genes of every record of a (gzipped) FASTA file: yields ``(ids, descriptions, lengths, BatchResult)`` per batch, in file order.
+
+    The reader (C, zlib) parses batch k + 1 into a pinned staging arena while batch k is uploaded from its own arena with one
+    DMA (no host-side packing) and processed; ``n_contexts`` contexts keep the device busy across batches
+    (ref: what the reference's CLI does with a thread pool over records, cli.py:287-302)."""
+    ctxs = [_cabi.Context(device) for _ in range(max(1, n_contexts))]
+    for c in ctxs:
+        c.set_models(list(model_blobs))
+    todo = queue.Queue(maxsize=len(ctxs))
+    done, failure = {}, []
+    cv = threading.Condition()
+
+    def worker(ctx):
+        while True:
+            item = todo.get()
+            if item is None:
+                return
+            i, pb = item
+            try:
+                meta = (pb.ids, pb.descriptions, pb.lens)
+                b = ctx.upload_packed(pb)                 # releases the arena
+                try:
+                    res = (meta, ctx.find_genes(b, **find_kw))
+                finally:
+                    b.close()
+            except BaseException as e:
+                pb.release()
+                res = e
+                failure.append(e)
+            with cv:
+                done[i] = res
+                cv.notify_all()
+
+    threads = [threading.Thread(target=worker, args=(c,), daemon=True) for c in ctxs]
+    for t in threads:
+        t.start()
+    reader = _cabi.FastaReader(path)
+    try:
+        nxt, submitted = 0, 0
+        it = reader.packed_batches(max_bases=max_bases, n_arenas=len(ctxs) + 2)
+        exhausted = False
+        while True:
+            while not exhausted and submitted - nxt < len(ctxs) + 1 and not failure:
+                try:
+                    pb = next(it)
+                except StopIteration:
+                    exhausted = True
+                    break
+                todo.put((submitted, pb))
+                submitted += 1
+            if nxt == submitted and exhausted:
+                break
+            with cv:
+                while nxt not in done:
+                    cv.wait()
+                res = done.pop(nxt)
+            nxt += 1
+            if isinstance(res, BaseException):
+                raise res
+            (ids, descs, lens), r = res
+            yield ids, descs, lens, r
+    finally:
+        for _ in threads:
+            todo.put(None)
+        for t in threads:
+            t.join()
+        reader.close()
+        for c in ctxs:
+            c.close()

@@ -4,6 +4,7 @@ Host-side code: runs without a GPU."""
 import gzip
 import os
 
+import numpy as np
 import pytest
 
 from tests.util import golden_path
@@ -85,3 +86,51 @@ def test_long_lines_multi_member_gzip_and_batches(tmp_path):
         sizes = [[len(s) for _, _, s in b] for b in r.batches(max_bases=100)]
     assert sizes == [[5, 70, 71], [100000], [9_000_000], [1, 33]]
     assert sum(len(b) for b in sizes) == len(recs)
+
+
+@pytest.mark.gpu
+def test_fasta_file_to_genes_through_pinned_staging(tmp_path):
+    """gzipped multi-record FASTA -> reader (pinned staging arenas, filled in turn) -> one DMA per batch ->
+    genes; every record must get exactly the genes of a call on that record alone, whatever the batch it travelled in."""
+    import gzip
+    from pyrodigal_amd import _cabi, benchdata, pipeline
+    from tests.util import read_fasta
+    recs = []
+    for name in ("SRR492066", "KK037166", "MIIJ01000039", "GCF_001457455.1_NCTC11397_genomic_100kb"):
+        recs += [(h.split()[0], s) for h, s in read_fasta(name + ".fna.gz")]
+    recs += [("synthetic_%d" % c, benchdata.synthetic_contig(3000 + 977 * c, 0.30 + 0.40 * (c % 41) / 40, 5000 + c).decode()) for c in range(60)]
+    recs.insert(3, ("empty_record", ""))
+    path = tmp_path / "mixed.fna.gz"
+    with gzip.open(path, "wt") as f:
+        for rid, seq in recs:
+            f.write(">%s some description\n" % rid)
+            for k in range(0, len(seq), 70):
+                f.write(seq[k:k + 70] + "\n")
+    models = [b for _, b in benchdata.load_model_set()]
+    got = {}
+    n_batches = 0
+    for ids, descs, lens, res in pipeline.find_genes_fasta(str(path), models, n_contexts=2, max_bases=200_000, meta=True):
+        n_batches += 1
+        assert all(d == "some description" for d in descs)
+        for i, rid in enumerate(ids):
+            g = res.genes_of(i)
+            got[rid] = (int(lens[i]), int(res.contigs[i]["model"]), g[["begin", "end", "strand", "start_ndx", "stop_ndx"]].tolist())
+    assert n_batches >= 4 and list(got) == [r[0] for r in recs]
+    ctx = _cabi.Context(0)
+    try:
+        ctx.set_models(models)
+        for rid, seq in recs[::5] + recs[:6]:
+            res = ctx.find_genes_batch([seq], meta=True)
+            want = (len(seq), int(res.contigs[0]["model"]), res.genes[["begin", "end", "strand", "start_ndx", "stop_ndx"]].tolist())
+            assert got[rid] == want, rid
+        # the packed upload on its own: same batch, same result as the pointer-per-contig upload
+        rd = _cabi.FastaReader(str(path))
+        pb = next(rd.packed_batches(max_bases=0))
+        seqs = [pb.sequence(i) for i in range(pb.n)]
+        b = ctx.upload_packed(pb)
+        a = ctx.find_genes(b, meta=True)
+        b.close(); rd.close()
+        w = ctx.find_genes_batch(seqs, meta=True)
+        assert a.genes.tobytes() == w.genes.tobytes() and np.array_equal(a.contigs["model"], w.contigs["model"])
+    finally:
+        ctx.close()
