@@ -190,6 +190,22 @@ int  pga_find_genes(pga_ctx*, const pga_batch*, const pga_params*, pga_result** 
 #define PGA_STAGE_SEQUENCE 4  /* Sequence.__init__ only: gc, n_unknown and masks per contig, no nodes (ref: lib.pyx:664-713) */
 int pga_nodes_stage(pga_ctx*, const pga_batch*, const pga_params*, int stage, int translation_table, pga_result** out);
 
+/* ---- translation -------------------------------------------------------------- */
+/* Protein translations of gene records, computed on the device from a resident batch: one thread per codon
+ * (ref: lib.pyx:2932-3047 `Gene.translate`, 770-789 `Sequence._amino`, _translation.h:4-42 the genetic codes).
+ *   genes[g]         records of a pga_result of THIS batch (contig, begin, end, strand, partial flags are read)
+ *   table_of_contig  translation table of every contig of the batch (what the winning model was trained with, or the caller's
+ *                    choice); one of the NCBI tables the reference knows (1-6, 9-16, 21-26, 29, 30, 32, 33)
+ *   unknown_residue  the letter of a codon with an unknown base ('X' in the reference)
+ *   include_stop     0: a complete gene loses its final `*`
+ *   strict           0: a codon with one unknown base in second or third position reads the residue all four completions agree on
+ *   offsets[g]       first letter of gene g in `out`: offsets[g + 1] - offsets[g] must be (end - begin + 1) / 3, minus 1 for a
+ *                    gene whose stop is not at an edge when include_stop == 0; offsets[n_genes] letters are written to `out`
+ * As in the reference the first codon of a gene that does not start at an edge reads M when it is a start codon of the table,
+ * and a stop codon of the table reads `*`. */
+int pga_translate_genes(pga_ctx*, const pga_batch*, int64_t n_genes, const pga_gene* genes, const int32_t* table_of_contig,
+                        int unknown_residue, int include_stop, int strict, const int64_t* offsets, char* out);
+
 /* ---- training --------------------------------------------------------------- */
 /* Single-genome training (ref: lib.pyx:5236-5279 `GeneFinder._train`): `batch` holds exactly ONE sequence (several
  * training sequences are joined by the caller with the reference's TTAATTAATTAA spacer, lib.pyx:5510-5532); closed,

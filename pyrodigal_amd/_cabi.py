@@ -19,7 +19,7 @@ EXPORTS = [
     "pga_score_connections", "pga_score_connections_training", "pga_find_genes_batch", "pga_result_free",
     "pga_batch_create", "pga_batch_free", "pga_find_genes", "pga_nodes_stage",
     "pga_fasta_open", "pga_fasta_next", "pga_fasta_error", "pga_fasta_close", "pga_train", "pga_dp_stats", "pga_dp_plan_summary",
-    "pga_fasta_next_packed", "pga_batch_create_packed",
+    "pga_fasta_next_packed", "pga_batch_create_packed", "pga_translate_genes",
 ]
 STAGE_EXTRACT, STAGE_SCORE, STAGE_OVERLAP, STAGE_SEQUENCE = 1, 2, 3, 4
 
@@ -117,6 +117,8 @@ def load():
     L.pga_fasta_next_packed.argtypes = [vp, i64, i32, i32, _P(i32), _P(_P(ctypes.c_char_p)), _P(vp), _P(_P(i64)), _P(_P(i64))]
     L.pga_batch_create_packed.restype = ctypes.c_int
     L.pga_batch_create_packed.argtypes = [vp, i32, vp, _P(i64), _P(i64), _P(vp)]
+    L.pga_translate_genes.restype = ctypes.c_int
+    L.pga_translate_genes.argtypes = [vp, vp, i64, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]
     L.pga_fasta_error.restype = ctypes.c_char_p; L.pga_fasta_error.argtypes = [vp]
     L.pga_fasta_close.restype = None; L.pga_fasta_close.argtypes = [vp]
     _lib = L
@@ -434,6 +436,35 @@ def _train(self, seq, translation_table=11, start_weight=4.35, force_nonsd=False
         b.close()
 
 
+def _translate_genes(self, batch, result, tables=None, unknown_residue="X", include_stop=True, strict=True):
+    """Proteins of ``result.genes`` (a result of ``find_genes`` on the resident ``batch``), translated on the device.
+
+    ``tables``: translation table per contig (default: the table of the model that won the contig).  Returns
+    ``(letters, offsets)``: gene g is ``letters[offsets[g]:offsets[g + 1]]`` (a uint8 array of ASCII codes)."""
+    genes = np.ascontiguousarray(result.genes)
+    n = len(genes)
+    if tables is None:
+        tts = [int(np.frombuffer(m[8:12].tobytes(), np.int32)[0]) for m in self._models]
+        tables = [tts[c["model"]] if c["model"] >= 0 else 11 for c in result.contigs]
+    tables = np.ascontiguousarray(tables, np.int32)
+    stop_edge = np.where(genes["strand"] == 1, genes["partial_end"], genes["partial_begin"]).astype(bool)
+    lens = (genes["end"].astype(np.int64) - genes["begin"] + 1) // 3
+    if not include_stop:
+        lens = np.maximum(lens - (~stop_edge), 0)
+    off = np.zeros(n + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    out = np.zeros(max(int(off[-1]), 1), np.uint8)
+    unk = unknown_residue.encode("ascii") if isinstance(unknown_residue, str) else bytes(unknown_residue)
+    if len(unk) != 1:
+        raise ValueError("`unknown_residue` must be a single character")
+    rc = self.L.pga_translate_genes(self.h, batch.h, n, genes.ctypes.data, tables.ctypes.data, unk[0], int(include_stop), int(strict),
+                                    off.ctypes.data, out.ctypes.data)
+    if rc != PGA_OK:
+        _raise(self.L, self.h, rc, "pga_translate_genes")
+    return out[:int(off[-1])], off
+
+
+Context.translate_genes = _translate_genes
 Context.train = _train
 Context.upload = _upload
 Context.upload_packed = _upload_packed

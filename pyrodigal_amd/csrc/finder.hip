@@ -920,6 +920,10 @@ extern "C" int pga_batch_create_packed(pga_ctx* c, int32_t n_contigs, const char
     return PGA_OK;
 }
 
+// what translate.hip needs of a batch
+struct pga_batch_view { pga_ctx* ctx; int32_t n; int64_t total; const ContigDesc* ct; const char* d_seq; };
+pga_batch_view pga_batch_peek(const pga_batch* b) { return pga_batch_view{b->ctx, b->n, b->total, b->ct.data(), b->d_seq}; }
+
 extern "C" void pga_batch_free(pga_batch* b) {
     if (!b) return;
     if (b->d_seq) { hipSetDevice(b->ctx->device); hipFree(b->d_seq); }

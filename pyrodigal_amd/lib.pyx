@@ -110,6 +110,9 @@ cdef extern from "pyrodigal_amd.h" nogil:
     int pga_find_genes_batch(pga_ctx*, int32_t n, const char* const* seqs, const int64_t* lens,
                              const pga_params*, pga_result** out)
     void pga_result_free(pga_result*)
+    int pga_find_genes(pga_ctx*, const pga_batch*, const pga_params*, pga_result** out)
+    int pga_translate_genes(pga_ctx*, const pga_batch*, int64_t n_genes, const pga_gene* genes, const int32_t* table_of_contig,
+                            int unknown_residue, int include_stop, int strict, const int64_t* offsets, char* out)
     int pga_batch_create(pga_ctx*, int32_t n, const char* const* seqs, const int64_t* lens, pga_batch** out)
     void pga_batch_free(pga_batch*)
     int PGA_STAGE_EXTRACT, PGA_STAGE_SCORE, PGA_STAGE_OVERLAP, PGA_STAGE_SEQUENCE
@@ -842,6 +845,7 @@ cdef class Gene:
     """A single predicted gene (ref: lib.pyx:2610-3047)."""
     cdef readonly Genes owner
     cdef pga_gene g
+    cdef ssize_t _index        # position in the owner's list (-1: unknown), for the owner's device-side translations
 
     @property
     def begin(self):
@@ -967,6 +971,9 @@ cdef class Gene:
         cdef bytes unk = unknown_residue.encode("ascii") if isinstance(unknown_residue, str) else bytes(unknown_residue)
         if len(unk) != 1:
             raise ValueError("`unknown_residue` must be a single character")
+        if (self.owner._prot is not None and self._index >= 0 and tt == owner_tt and unk == b"X" and include_stop and strict):
+            # translated on the device together with the gene calls (GeneFinder.find_genes_batch(..., translate=True))
+            return self.owner._prot[self.owner._prot_off[self._index]:self.owner._prot_off[self._index + 1]].decode("ascii")
         cdef bytes nuc = self.owner.sequence.data[self.g.begin - 1:self.g.end]
         if self.g.strand != 1:
             nuc = nuc.translate(_COMPLEMENT_ANY)[::-1]
@@ -1025,6 +1032,8 @@ cdef class Genes:
     cdef readonly double score
     cdef readonly ssize_t _num_seq
     cdef list _genes
+    cdef object _prot          # proteins of all genes back to back, translated on the device with the default arguments, or None
+    cdef object _prot_off      # int64[len + 1] offsets into _prot
 
     def __len__(self):
         return len(self._genes)
@@ -1323,8 +1332,12 @@ cdef class GeneFinder:
         """Find all the genes in the input DNA sequence (ref: lib.pyx:5400-5469)."""
         return self.find_genes_batch([sequence])[0]
 
-    def find_genes_batch(self, object sequences):
-        """`find_genes` for many sequences in one device pass; returns one `Genes` per input, in order."""
+    def find_genes_batch(self, object sequences, *, bint translate=False):
+        """`find_genes` for many sequences in one device pass; returns one `Genes` per input, in order.
+
+        `translate=True` also translates every gene on the device while the batch is resident (one thread per codon, the
+        translation table of the model that called the gene): `Gene.translate()` with its default arguments and
+        `Genes.write_translations` then read those proteins instead of translating codon by codon on the host."""
         if not self.meta and self.training_info is None:
             raise RuntimeError("cannot find genes without having trained in single mode")
         # the reference always re-wraps with the finder's masking rule (ref: lib.pyx:5433-5438); a Sequence that already
@@ -1342,10 +1355,14 @@ cdef class GeneFinder:
         cdef int64_t* lens = <int64_t*> malloc(sizeof(int64_t) * max(n, 1))
         cdef pga_params p
         cdef pga_result* res = NULL
+        cdef pga_batch* batch = NULL
         cdef list out = []
         cdef Genes genes
         cdef Gene gene
         cdef pga_contig_result* cr
+        cdef object prot = None, prot_off = None, tables
+        cdef size_t p_tab, p_off, p_out
+        cdef int64_t ng
         if ptrs == NULL or lens == NULL:
             free(ptrs); free(lens)
             raise MemoryError()
@@ -1360,10 +1377,41 @@ cdef class GeneFinder:
                 self._ensure_models()
                 first_id = self._num_seq
                 self._num_seq += n
-                with nogil:
-                    rc = pga_find_genes_batch(self.ctx, n, ptrs, lens, &p, &res)
-                if rc != PGA_OK:
-                    _raise_for(self.ctx, rc, "pga_find_genes_batch")
+                if not translate:
+                    with nogil:
+                        rc = pga_find_genes_batch(self.ctx, n, ptrs, lens, &p, &res)
+                    if rc != PGA_OK:
+                        _raise_for(self.ctx, rc, "pga_find_genes_batch")
+                else:
+                    rc = pga_batch_create(self.ctx, n, ptrs, lens, &batch)
+                    if rc != PGA_OK:
+                        _raise_for(self.ctx, rc, "pga_batch_create")
+                    try:
+                        with nogil:
+                            rc = pga_find_genes(self.ctx, batch, &p, &res)
+                        if rc != PGA_OK:
+                            _raise_for(self.ctx, rc, "pga_find_genes")
+                        prot_off = np.zeros(res.n_genes + 1, np.int64)
+                        tables = np.full(max(n, 1), 11, np.int32)
+                        for i in range(n):
+                            cr = &res.contigs[i]
+                            if self.meta:
+                                if cr.model >= 0:
+                                    tables[i] = (<MetagenomicBin> self.metagenomic_bins[cr.model]).training_info.translation_table
+                            else:
+                                tables[i] = (<TrainingInfo> self.training_info).translation_table
+                        for j in range(res.n_genes):
+                            prot_off[j + 1] = prot_off[j] + (res.genes[j].end - res.genes[j].begin + 1) // 3
+                        prot = np.zeros(max(int(prot_off[res.n_genes]), 1), np.uint8)
+                        p_tab = tables.ctypes.data; p_off = prot_off.ctypes.data; p_out = prot.ctypes.data
+                        ng = res.n_genes
+                        with nogil:
+                            rc = pga_translate_genes(self.ctx, batch, ng, res.genes, <const int32_t*> p_tab, 88, 1, 1,
+                                                     <const int64_t*> p_off, <char*> p_out)
+                        if rc != PGA_OK:
+                            _raise_for(self.ctx, rc, "pga_translate_genes")
+                    finally:
+                        pga_batch_free(batch)
             for i in range(n):
                 cr = &res.contigs[i]
                 genes = Genes.__new__(Genes)
@@ -1389,10 +1437,15 @@ cdef class GeneFinder:
                     genes.training_info = self.training_info
                 genes.nodes = _copy_nodes(&res.nodes[i]) if (self.keep_nodes and res.nodes != NULL) else None
                 genes._genes = []
+                genes._prot = None; genes._prot_off = None
+                if prot is not None:
+                    genes._prot = prot[prot_off[cr.gene_begin]:prot_off[cr.gene_begin + cr.n_genes]].tobytes()
+                    genes._prot_off = (prot_off[cr.gene_begin:cr.gene_begin + cr.n_genes + 1] - prot_off[cr.gene_begin]).copy()
                 for j in range(cr.n_genes):
                     gene = Gene.__new__(Gene)
                     gene.owner = genes
                     gene.g = res.genes[cr.gene_begin + j]
+                    gene._index = j
                     genes._genes.append(gene)
                 out.append(genes)
         finally:

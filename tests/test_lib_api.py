@@ -355,3 +355,67 @@ def test_find_genes_rewraps_a_sequence_with_the_finders_masking(lib):
     assert a == b
     genes = masked_finder.find_genes(plain)
     assert genes.sequence.mask and [(m.begin, m.end) for m in genes.sequence.masks] == [(10000, 10080)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["SRR492066", "KK037166", "MIIJ01000039"])
+def test_device_translation_reproduces_the_reference_proteins(lib, name):
+    """the proteins translated on the device while the batch is resident (one thread per codon) are the
+    reference's `*.single.faa` files byte for byte, through `Genes.write_translations` and `Gene.translate()`."""
+    import gzip
+    from oracle import oracle as orc
+    hdr, seq = read_fasta(name + ".fna.gz")[0]
+    seq_id = hdr.split()[0]
+    tinf = lib.TrainingInfo(raw=orc.Oracle(seq).train().tobytes())
+    genes = lib.GeneFinder(tinf).find_genes_batch([seq], translate=True)[0]
+    out = io.StringIO()
+    genes.write_translations(out, seq_id)
+    assert out.getvalue() == gzip.open(golden_path(name + ".single.faa.gz"), "rt").read()
+    plain = lib.GeneFinder(tinf).find_genes(seq)
+    assert [g.translate() for g in genes] == [g.translate() for g in plain]                 # device == host, gene by gene
+    assert genes[0].translate(include_stop=False) == plain[0].translate(include_stop=False)   # other arguments: the host path
+
+
+@pytest.mark.gpu
+def test_device_translation_options_and_tables_against_the_host_translation(lib):
+    """pga_translate_genes with every option: unknown bases (strict and not), no stop letter, a table with other codons,
+    reverse-strand and edge genes, against the host restatement of `Gene.translate` (ref: lib.pyx:2932-3047)."""
+    from pyrodigal_amd import _cabi, benchdata
+    models = benchdata.load_model_set()
+    rng = np.random.default_rng(12)
+    seqs = []
+    for c in range(30):
+        s = bytearray(benchdata.synthetic_contig(4000 + 900 * c, 0.35 + 0.01 * c, 4400 + c))
+        for _ in range(12):
+            at = int(rng.integers(0, len(s) - 3)); s[at] = ord("N")
+        seqs.append(bytes(s))
+    ctx = _cabi.Context(0)
+    try:
+        ctx.set_models([b for _, b in models])
+        batch = ctx.upload(seqs)
+        res = ctx.find_genes(batch, meta=True)
+        bins = lib.MetagenomicBins([lib.MetagenomicBin(lib.TrainingInfo(raw=b), n) for n, b in models])
+        host = lib.GeneFinder(meta=True, metagenomic_bins=bins).find_genes_batch(seqs)
+        assert sum(len(g) for g in host) == len(res.genes) > 200
+        for kw in (dict(), dict(include_stop=False), dict(strict=False), dict(unknown_residue="?", strict=False, include_stop=False)):
+            letters, off = ctx.translate_genes(batch, res, **kw)
+            k = 0
+            for genes in host:
+                for g in genes:
+                    assert letters[off[k]:off[k + 1]].tobytes().decode() == g.translate(**kw), (k, kw)
+                    k += 1
+        # another genetic code for every contig (table 4 reads TGA as W; the host warns about the changed stop codons)
+        import warnings
+        letters, off = ctx.translate_genes(batch, res, tables=[4] * len(seqs))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            k = 0
+            for genes in host:
+                for g in genes:
+                    assert letters[off[k]:off[k + 1]].tobytes().decode() == g.translate(translation_table=4), k
+                    k += 1
+        with pytest.raises(ValueError):
+            ctx.translate_genes(batch, res, tables=[7] * len(seqs))
+        batch.close()
+    finally:
+        ctx.close()
