@@ -239,10 +239,32 @@ def test_writers_reproduce_reference_output_files(lib, name):
     f = lines[3].split("\t")
     assert f[0] == seq_id and f[2] == "CDS" and (int(f[3]), int(f[4])) == (genes[0].begin, genes[0].end)
     assert f[5] == "%.1f" % genes[0].score and f[8].startswith("ID=%s_1;partial=" % seq_id) and ";conf=" in f[8]
+    # ... and every numeric field of every line against the oracle's nodes and genes
+    o = orc.Oracle(seq)
+    otinf = orc.Oracle(seq).train()
+    o.find_genes_single(otinf)
+    on, og = o.nodes(), o.genes()
+    recs = orc.gene_records(og, on, otinf)
+    assert len(recs) == len(genes)
+    for line, rec, g in zip(lines[3:], recs, og):
+        f = line.split("\t")
+        sn = on[g["start_ndx"]]
+        assert (int(f[3]), int(f[4]), f[6]) == (rec[0], rec[1], "+" if rec[2] == 1 else "-") and f[7] == "0"
+        assert f[5] == "%.1f" % (sn["cscore"] + sn["sscore"])
+        attrs = dict(kv.split("=", 1) for kv in f[8].rstrip(";").split(";"))
+        assert (attrs["partial"], attrs["start_type"], attrs["rbs_motif"], attrs["rbs_spacer"], attrs["gc_cont"]) == rec[3:8]
+        for key in ("cscore", "sscore", "rscore", "uscore", "tscore"):
+            assert attrs[key] == "%.2f" % sn[key], key
+        assert attrs["score"] == "%.2f" % (sn["cscore"] + sn["sscore"]) and 50.0 <= float(attrs["conf"]) <= 100.0
     out = io.StringIO(); genes.write_scores(out, seq_id)
     rows = [r for r in out.getvalue().splitlines()[3:] if r]
     starts = genes.nodes.array("type") != 3
     assert len(rows) == int(starts.sum()) and all(len(r.split("\t")) == 13 for r in rows)
+    # the score table lists every start node; its numeric columns against the oracle's nodes (same multiset of rows)
+    want = sorted(("%.2f" % (n["cscore"] + n["sscore"]), "%.2f" % n["cscore"], "%.2f" % n["sscore"], "%.2f" % n["uscore"],
+                   "%.2f" % n["tscore"], "%.3f" % n["gc_cont"]) for n in on if n["type"] != 3)
+    got = sorted((c[3], c[4], c[5], c[10], c[11], c[12]) for c in (r.split("\t") for r in rows))
+    assert got == want
     import datetime
     out = io.StringIO(); genes.write_genbank(out, seq_id, date=datetime.date(2024, 1, 2))
     gb = out.getvalue()
