@@ -1207,7 +1207,10 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
 
         tm.mark("plan+alloc");
         std::vector<int32_t> cs_tk[4], cs_en[4];
-        const ScoreParams sp{P.closed, P.meta, P.max_overlap, 0};
+        ScoreParams sp{P.closed, P.meta, P.max_overlap, 0, nullptr};
+        DEVBUF(d_conv, uint8_t, "d_conv_flag", (size_t)NG * NC + 1);
+        PINBUF(h_conv, uint8_t, "h_conv_flag", (size_t)NG * NC + 1);
+        if (meta_run) HT(c, hipMemsetAsync(d_conv, 0, (size_t)NG * NC, st));
         const pga_training* d_models = (const pga_training*)c->d_models_raw;
         for (int g = 0; g < NG; g++) {
             pga_launch_compact(total, d_ct, NC, ga[g], st);
@@ -1232,6 +1235,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                     d_cs_tasks = p1; d_cs_entries = p2; n_cs_tasks = (int)(tk.size() / 4);
                 }
             }
+            sp.conv_flag = meta_run ? d_conv + (size_t)g * NC : nullptr;
             pga_launch_score(d_chains + g_c0[g], nch, g_n0[g], nn, d_dig, d_ct, ga[g], d_models, f->d_msc, c->d_model_const, ca, sp,
                              d_chains, d_cc + (size_t)g * NC, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], f->d_sd_lut, st, 0,
                              meta_run ? f->d_gil + f->gil_off[g] : nullptr, meta_run ? f->gil_stride[g] : 0, f->d_model_rank,
@@ -1299,6 +1303,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         HT(c, hipMemcpyAsync(h_maxidx, dp.max_index, sizeof(int32_t) * NCH, hipMemcpyDeviceToHost, st));
         HT(c, hipMemcpyAsync(h_ipath, dp.ipath, sizeof(int32_t) * NCH, hipMemcpyDeviceToHost, st));
         HT(c, hipMemcpyAsync(h_maxscore, dp.max_score, sizeof(double) * NCH, hipMemcpyDeviceToHost, st));
+        if (meta_run) HT(c, hipMemcpyAsync(h_conv, d_conv, (size_t)NG * NC, hipMemcpyDeviceToHost, st));
         PINBUF(h_segflags, int32_t, "h_segflags", (size_t)PGA_SEG_ROUNDS * NCH + NCH + 1);
         if (segmented) {
             HT(c, hipMemcpyAsync(h_segflags, seg_dev.flags, sizeof(int32_t) * PGA_SEG_ROUNDS * NCH, hipMemcpyDeviceToHost, st));
@@ -1340,7 +1345,9 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         for (int i = 0; i < NC; i++) {
             const int k = win_chain[i];
             if (k < 0) continue;
-            if (!P.meta || chains[k].first) { fin_off[i] = chains[k].off; continue; }
+            // a later model of a run sees the edge flags its predecessors left (lib.pyx:2424-2434); where the contig has no start
+            // node that scoring turns into an edge node, that state is the fresh one and the winning pass already is the re-score
+            if (!P.meta || chains[k].first || !h_conv[(size_t)f->model_group[chains[k].model] * NC + i]) { fin_off[i] = chains[k].off; continue; }
             ChainDesc ch = chains[k]; ch.first = 1;
             ch.raw_off = chains[k].off;                 // same contig, same model: the ORF walk of the winning pass stands
             rs_g[f->model_group[ch.model]].push_back(ch);
@@ -1357,6 +1364,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             for (size_t k = 0; k < rescore.size(); k++)
                 h_cc2[(size_t)f->model_group[rescore[k].model] * NC + rescore[k].contig] = make_int2(NCH + (int)k, 1);
             HT(c, hipMemcpyAsync(d_cc + (size_t)NG * NC, h_cc2, sizeof(int2) * (size_t)NG * NC, hipMemcpyHostToDevice, st));
+            sp.conv_flag = nullptr;
             for (int g = 0; g < NG; g++) {
                 const int nch = r_c0[g + 1] - r_c0[g]; const int64_t nn = r_n0[g + 1] - r_n0[g];
                 if (nch == 0 || nn == 0) continue;

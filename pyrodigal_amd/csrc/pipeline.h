@@ -53,6 +53,9 @@ struct MaskRun { int32_t contig, begin, end, _pad; };
 
 struct ScoreParams {
     int32_t closed, is_meta, max_overlap, _pad;
+    uint8_t* conv_flag;      // per contig (of the group being scored), or nullptr: set when the contig holds a start node that the
+                             // reference turns into an edge node while scoring (lib.pyx:2424-2434) -- only such contigs are scored
+                             // differently by the first and by a later model of a run
 };
 
 void pga_launch_digitize(const char* d_seq, uint8_t* d_dig, int64_t total, const ContigDesc* d_ct, int n_contigs,

@@ -927,25 +927,72 @@ k_coding_score_quads(const CsTask* __restrict__ tasks, const CsEntry* __restrict
 // bit masks; bit u describes the base at position start - u.  Every model scored on the contig then
 // searches the same registers.
 struct UpWin {
-    unsigned long long lo, hi;     // 2-bit code of the base (digit & 3 after strand mapping; unknown -> 2 as in the reference)
-    unsigned long long isA, isG;   // exact identity on this strand (unknown bases match nothing)
-    unsigned long long inr;        // position exists (>= 0)
-    __device__ __forceinline__ int code(int u) const { return (int)(((hi >> u) & 1ull) << 1 | ((lo >> u) & 1ull)); }
+    unsigned long long p0, p1;     // 2-bit code of the base at start - u (digit & 3 after strand mapping; unknown -> 2 as in the reference) at bits 2u, 2u + 1; p1: u >= 32
+    unsigned long long zm;         // the same codes for u = 1 .. 21 in falling order: base u at bits 2 (21 - u) -- a motif read downstream is one shift
+    unsigned isA, isG;             // u = 1 .. 20: exact identity on this strand, position inside the sequence (unknown bases match nothing)
+    __device__ __forceinline__ int code(int u) const { return (int)(((u < 32 ? p0 : p1) >> (2 * (u & 31))) & 3ull); }
 };
 
+// 2-bit codes of four digit bytes, byte t at bits 2t (comp: the reverse strand reads the complement; an unknown base stays 2)
+__device__ __forceinline__ unsigned pack4(const unsigned w, const bool comp) {
+    unsigned c = w & 0x03030303u;
+    if (comp) { const unsigned nm = (w >> 2) & 0x01010101u; c = (c ^ 0x03030303u) ^ (nm | (nm << 1)); }
+    return (c | (c >> 6) | (c >> 12) | (c >> 18)) & 0xffu;
+}
+__device__ __forceinline__ unsigned long long pack16(const uint4 v, const bool comp) {      // byte t at bits 2t, 32 bits
+    return (unsigned long long)(pack4(v.x, comp) | (pack4(v.y, comp) << 8) | (pack4(v.z, comp) << 16) | (pack4(v.w, comp) << 24));
+}
+__device__ __forceinline__ unsigned long long pairrev64(unsigned long long x) {              // pair t -> pair 31 - t
+    x = __brevll(x);
+    return ((x & 0x5555555555555555ull) << 1) | ((x >> 1) & 0x5555555555555555ull);
+}
+__device__ __forceinline__ unsigned even_bits(unsigned long long x) {                        // bit 2u of x -> bit u
+    x &= 0x5555555555555555ull;
+    x = (x | (x >> 1)) & 0x3333333333333333ull;
+    x = (x | (x >> 2)) & 0x0f0f0f0f0f0f0f0full;
+    x = (x | (x >> 4)) & 0x00ff00ff00ff00ffull;
+    x = (x | (x >> 8)) & 0x0000ffff0000ffffull;
+    return (unsigned)(x | (x >> 16));
+}
+
 __device__ __forceinline__ UpWin load_upwin(const uint8_t* __restrict__ d, int L, int start, int strand) {
-    UpWin w{0, 0, 0, 0, 0};
-#pragma unroll 9
-    for (int u = 1; u <= 45; u++) {
-        const int p = start - u;
-        if (p < 0) break;
-        const int raw = strand == 1 ? d[p] : d[L - 1 - p];
-        const int b = strand == 1 ? raw : (raw ^ 3);                       // ref: _sequence.h:45-55
-        const int c2 = (strand == 1 ? raw : comp2(raw)) & 3;               // ref: _sequence.h:207-220
-        w.inr |= 1ull << u;
-        w.lo |= (unsigned long long)(c2 & 1) << u; w.hi |= (unsigned long long)(c2 >> 1) << u;
-        w.isA |= (unsigned long long)(b == NA) << u; w.isG |= (unsigned long long)(b == NG) << u;
+    UpWin w;
+    if (start >= 48) {
+        // 48 bytes in address order, three unaligned 16-byte loads (every lane reads its own window: an instruction costs the
+        // address path 64 lines whatever its width): byte t at bits 2t of q0 (t < 32) / q1
+        const uint8_t* __restrict__ a = strand == 1 ? d + (start - 48) : d + (L - start);
+        uint4 v0, v1, v2;
+        __builtin_memcpy(&v0, a, 16); __builtin_memcpy(&v1, a + 16, 16); __builtin_memcpy(&v2, a + 32, 16);
+        const bool comp = strand != 1;
+        const unsigned long long q0 = pack16(v0, comp) | (pack16(v1, comp) << 32), q1 = pack16(v2, comp);
+        if (comp) {
+            // byte t is the base at u = t + 1
+            w.p0 = q0 << 2; w.p1 = (q1 << 2) | (q0 >> 62);
+            w.zm = pairrev64(q0) >> 22;                  // pair t -> pair 31 - t, u = t + 1 <= 21 wanted at pair 21 - u = 20 - t
+        } else {
+            // byte t is the base at u = 48 - t
+            const unsigned long long r = pairrev64(q0);                    // t < 32 -> pair 31 - t = u - 17
+            const unsigned long long s2 = pairrev64(q1) >> 32;             // t = 32 .. 47 -> pair 47 - t = u - 1
+            const unsigned long long lo = s2 | (r << 32), hi = r >> 32;    // base u at pair u - 1
+            w.p0 = lo << 2; w.p1 = (hi << 2) | (lo >> 62);
+            w.zm = (q0 >> 54) | (q1 << 10);              // u <= 21 <=> t >= 27: pair t -> pair t - 27 = 21 - u
+        }
+        w.zm &= (1ull << 42) - 1ull;
+    } else {
+        w.p0 = w.p1 = w.zm = 0;
+        for (int u = 1; u <= 45; u++) {
+            const int p = start - u;
+            if (p < 0) break;
+            const int raw = strand == 1 ? d[p] : d[L - 1 - p];
+            const unsigned long long c2 = (unsigned long long)((strand == 1 ? raw : comp2(raw)) & 3);   // ref: _sequence.h:207-220
+            if (u < 32) w.p0 |= c2 << (2 * u); else w.p1 |= c2 << (2 * (u - 32));
+            if (u <= 21) w.zm |= c2 << (2 * (21 - u));
+        }
     }
+    // identity on this strand (ref: _sequence.h:45-55): A is code 0, G code 1 after the strand mapping; an unknown base is code 2
+    const unsigned lo = even_bits(w.p0), hi = even_bits(w.p0 >> 1);
+    const unsigned inr = start >= 31 ? 0xfffffffeu : ((2u << start) - 2u);          // u = 1 .. min(start, 31)
+    w.isA = ~lo & ~hi & inr; w.isG = lo & ~hi & inr;
     return w;
 }
 
@@ -1040,7 +1087,7 @@ __device__ __forceinline__ int sd_pick(unsigned hits, const double* __restrict__
 // The reference mutates node.edge while it scans (lib.pyx:2424-2434) and the flag survives into
 // the next model of a meta run; `first` and the index comparisons below reproduce the value each
 // read would have seen.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 5)
 k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ contig_chains,
                const int32_t* __restrict__ node_contig_base, int n_contigs, int n_nodes,
                const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct, GroupArrays ga,
@@ -1086,6 +1133,7 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
         return (x <= 2 && s == 1) || (x >= L - 3 && s == -1);
     };
     const bool conv = convertible(i);
+    if (conv && sp.conv_flag != nullptr) sp.conv_flag[c] = 1;
     const int start = strand == 1 ? ndx : L - 1 - ndx;     // strand-local start position
     const UpWin W = load_upwin(d, L, start, strand);
     const long orf = ndx > sv ? ndx - sv : sv - ndx;
@@ -1111,8 +1159,10 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
     }
     int tt_cached = -1; bool stop_missing = false;
 
-    bool have_hits = false;
-    unsigned hit_e[15], hit_m[15];       // per search window: the RBS bins that match exactly / with one mismatch
+    // per search window of the RBS search: the six "is the A / G of AGGAGG there" bits (five windows per word); the bins that
+    // match come from the table in LDS when a model asks
+    bool have_pats = false;
+    unsigned pats[3] = {0u, 0u, 0u};
     for (int m = 0; m < cc.y; m++) {
         const ChainDesc ch = chains[cc.x + m];
         const int64_t g = ch.off + i;
@@ -1128,40 +1178,43 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
         double m_score = 0.0;
         if (!edge_in) {
             if (tm->uses_sd) {
-                if (!have_hits) {
-                    have_hits = true;
-                    const unsigned long long hasA = W.isA & W.inr, hasG = W.isG & W.inr;
+                if (!have_pats) {
+                    have_pats = true;
+                    const unsigned hasA = W.isA, hasG = W.isG;
 #pragma unroll
                     for (int q = 0; q < 15; q++) {
-                        const int j = start - 20 + q;
-                        // the reference skips windows starting before the sequence on the forward strand only; on the reverse
-                        // strand it tests "j >= slen", never true, so windows hanging off the end are searched with the missing
-                        // bases matching nothing (ref: lib.pyx:2256-2275)
-                        const bool skip = j < 0 && strand == 1;
                         // base i of the window is bit 5 - i of the six bits from position start - (j + 5) up
-                        const unsigned a6 = (unsigned)(hasA >> (15 - q)) & 63u, g6 = (unsigned)(hasG >> (15 - q)) & 63u;
+                        const unsigned a6 = (hasA >> (15 - q)) & 63u, g6 = (hasG >> (15 - q)) & 63u;
                         const unsigned pat = ((a6 >> 5) & 1u) | (((g6 >> 4) & 1u) << 1) | (((g6 >> 3) & 1u) << 2) | (((a6 >> 2) & 1u) << 3) |
                                              (((g6 >> 1) & 1u) << 4) | ((g6 & 1u) << 5);
-                        hit_e[q] = skip ? 0u : s_lut[(q << 6) | pat];
-                        hit_m[q] = skip ? 0u : s_lut[((15 + q) << 6) | pat];
+                        pats[q / 5] |= pat << (6 * (q % 5));
                     }
                 }
 #pragma unroll
                 for (int q = 0; q < 15; q++) {
-                    if (hit_e[q] > 1u) { const int a = sd_pick(hit_e[q], tm->rbs_wt); if (a > rbs0) rbs0 = a; }
-                    if (hit_m[q] > 1u) { const int b = sd_pick(hit_m[q], tm->rbs_wt); if (b > rbs1) rbs1 = b; }
+                    // the reference skips windows starting before the sequence on the forward strand only; on the reverse
+                    // strand it tests "j >= slen", never true, so windows hanging off the end are searched with the missing
+                    // bases matching nothing (ref: lib.pyx:2256-2275)
+                    if (start - 20 + q < 0 && strand == 1) continue;
+                    const unsigned pat = (pats[q / 5] >> (6 * (q % 5))) & 63u;
+                    const unsigned he = s_lut[(q << 6) | pat], hm = s_lut[((15 + q) << 6) | pat];
+                    if (he > 1u) { const int a = sd_pick(he, tm->rbs_wt); if (a > rbs0) rbs0 = a; }
+                    if (hm > 1u) { const int b = sd_pick(hm, tm->rbs_wt); if (b > rbs1) rbs1 = b; }
                 }
             } else {
                 double bsc = -100.0; int bsp = 0, bsi = 0, blen = 0, bndx = 0;
+                // the motif of k + 3 bases whose first base sits u0 upstream (the reference's j = start - u0, ascending j):
+                // every shift and spacer class below is a constant of the unrolled body
+#pragma unroll 1
                 for (int k = 3; k >= 0; k--) {
-                    for (int j = start - 18 - k; j < start - 5 - k; j++) {
-                        if (j < 0) continue;
-                        int si;
-                        if (j <= start - 16 - k) si = 3; else if (j <= start - 14 - k) si = 2; else if (j >= start - 7 - k) si = 1; else si = 0;
-                        int idx = 0;
-                        for (int q = 0; q < k + 3; q++) idx |= W.code(start - j - q) << (2 * q);
+#pragma unroll
+                    for (int t = 0; t < 13; t++) {
+                        const int u0 = 18 + k - t;
+                        if (u0 > start) continue;
+                        const int si = u0 >= 16 + k ? 3 : (u0 >= 14 + k ? 2 : (u0 <= 7 + k ? 1 : 0));
+                        const int idx = (int)((W.zm >> (2 * (21 - u0))) & ((1ull << (2 * (k + 3))) - 1ull));
                         const double sc = tm->mot_wt[k][si][idx];
-                        if (sc > bsc) { bsc = sc; bsi = si; bsp = start - j - k - 3; bndx = idx; blen = k + 3; }
+                        if (sc > bsc) { bsc = sc; bsi = si; bsp = u0 - k - 3; bndx = idx; blen = k + 3; }
                     }
                 }
                 if (bsc == -4.0 || bsc < tm->no_mot + 0.69) { m_score = tm->no_mot; }
@@ -1182,7 +1235,9 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
             if (tm->uses_sd) rscore = sd;
             else { rscore = st_wt * m_score; if (rscore < sd && tm->no_mot > -0.5) rscore = sd; }
             int cnt = 0; double u = 0.0;
+#pragma unroll
             for (int k = 1; k < 3; k++) { if (k > start) break; u += 0.4 * st_wt * tm->ups_comp[cnt][W.code(k)]; cnt++; }
+#pragma unroll 10
             for (int k = 15; k < 45; k++) { if (k > start) break; u += 0.4 * st_wt * tm->ups_comp[cnt][W.code(k)]; cnt++; }
             uscore = u;
             if (ups_near_edge || (ch.first ? ups_first : ups_later)) uscore += -1.00 * st_wt;
