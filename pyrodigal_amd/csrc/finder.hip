@@ -699,13 +699,6 @@ k_emit_genes(const TailDesc* __restrict__ td, int n_contigs, int64_t n_slots, Ou
 
 #include "tail.inl"
 
-__global__ void k_contig_node_base(const ContigDesc* __restrict__ ct, int n_contigs, int64_t total, const int32_t* __restrict__ pre_nodes,
-                                   int32_t* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c > n_contigs) return;
-    out[c] = pre_nodes[c < n_contigs ? ct[c].base : total];
-}
-
 struct ResultOwner {
     pga_result pub;
     std::vector<pga_contig_result> contigs;
@@ -838,8 +831,32 @@ struct pga_batch {
     std::vector<ContigDesc> ct;   // n + 1 entries
     char* d_seq;                  // packed ASCII, resident in HBM
     TileDesc* d_tiles;            // extraction tiles of every contig
+    int32_t* d_tile0;             // first tile of every contig, n + 1 entries (behind d_tiles, one allocation)
     int32_t n_tiles;
 };
+
+// Tiles of a batch: every position of a contig of at least three bases lies in one tile.  Host vectors for one upload.
+static void batch_tiles(const pga_batch* b, std::vector<TileDesc>& tiles, std::vector<int32_t>& tile0) {
+    const int TS = pga_extract_tile_size();
+    tile0.resize((size_t)b->n + 1);
+    for (int i = 0; i < b->n; i++) {
+        tile0[i] = (int32_t)tiles.size();
+        const int64_t L = b->ct[i].len;
+        if (L >= 3) for (int64_t s0 = 0; s0 < L; s0 += TS) tiles.push_back(TileDesc{i, (int32_t)s0});
+    }
+    tile0[b->n] = (int32_t)tiles.size();
+}
+// one device allocation: tiles, then the per-contig first-tile table
+static hipError_t batch_upload_tiles(pga_batch* b, const std::vector<TileDesc>& tiles, const std::vector<int32_t>& tile0, hipStream_t st) {
+    b->n_tiles = (int32_t)tiles.size();
+    const size_t tb = sizeof(TileDesc) * tiles.size(), zb = sizeof(int32_t) * tile0.size();
+    if (hipMalloc((void**)&b->d_tiles, tb + zb + 64) != hipSuccess) { b->d_tiles = nullptr; return hipErrorOutOfMemory; }
+    b->d_tile0 = (int32_t*)((char*)b->d_tiles + tb);
+    hipError_t e = hipSuccess;
+    if (tb) e = hipMemcpyAsync(b->d_tiles, tiles.data(), tb, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(b->d_tile0, tile0.data(), zb, hipMemcpyHostToDevice, st);
+    return e;
+}
 
 extern "C" int pga_batch_create(pga_ctx* c, int32_t n_contigs, const char* const* seqs, const int64_t* lens, pga_batch** out) {
     if (out) *out = nullptr;
@@ -848,7 +865,7 @@ extern "C" int pga_batch_create(pga_ctx* c, int32_t n_contigs, const char* const
     HT(c, hipSetDevice(c->device));
     pga_batch* b = new (std::nothrow) pga_batch();
     if (!b) return PGA_ENOMEM;
-    b->ctx = c; b->n = n_contigs; b->d_seq = nullptr; b->d_tiles = nullptr; b->n_tiles = 0; b->ct.resize((size_t)n_contigs + 1);
+    b->ctx = c; b->n = n_contigs; b->d_seq = nullptr; b->d_tiles = nullptr; b->d_tile0 = nullptr; b->n_tiles = 0; b->ct.resize((size_t)n_contigs + 1);
     int64_t total = 0;
     for (int i = 0; i < n_contigs; i++) {
         if (lens[i] < 0 || lens[i] > 0x7fff0000LL || (lens[i] > 0 && !seqs[i])) { delete b; c->err = "pga_batch_create: bad contig length"; return PGA_EINVAL; }
@@ -867,16 +884,11 @@ extern "C" int pga_batch_create(pga_ctx* c, int32_t n_contigs, const char* const
         hipError_t e = hipMemcpyAsync(b->d_seq, h_seq, (size_t)total, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { hipFree(b->d_seq); delete b; return pga_hip_try_(c, e, "upload of the batch"); }
-        std::vector<TileDesc> tiles;
-        const int TS = pga_extract_tile_size();
-        for (int i = 0; i < n_contigs; i++)
-            for (int64_t s0 = 0; s0 + 2 < lens[i]; s0 += TS) tiles.push_back(TileDesc{i, (int32_t)s0});
-        b->n_tiles = (int32_t)tiles.size();
-        if (!tiles.empty()) {
-            if (hipMalloc((void**)&b->d_tiles, sizeof(TileDesc) * tiles.size()) != hipSuccess) { hipFree(b->d_seq); delete b; c->err = "pga_batch_create: hipMalloc failed"; return PGA_ENOMEM; }
-            e = hipMemcpy(b->d_tiles, tiles.data(), sizeof(TileDesc) * tiles.size(), hipMemcpyHostToDevice);
-            if (e != hipSuccess) { hipFree(b->d_tiles); hipFree(b->d_seq); delete b; return pga_hip_try_(c, e, "upload of the tile list"); }
-        }
+        std::vector<TileDesc> tiles; std::vector<int32_t> tile0;
+        batch_tiles(b, tiles, tile0);
+        e = batch_upload_tiles(b, tiles, tile0, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { if (b->d_tiles) hipFree(b->d_tiles); hipFree(b->d_seq); delete b; return pga_hip_try_(c, e, "upload of the tile list"); }
     }
     *out = b;
     return PGA_OK;
@@ -894,7 +906,7 @@ extern "C" int pga_batch_create_packed(pga_ctx* c, int32_t n_contigs, const char
     HT(c, hipSetDevice(c->device));
     pga_batch* b = new (std::nothrow) pga_batch();
     if (!b) return PGA_ENOMEM;
-    b->ctx = c; b->n = n_contigs; b->d_seq = nullptr; b->d_tiles = nullptr; b->n_tiles = 0; b->ct.resize((size_t)n_contigs + 1);
+    b->ctx = c; b->n = n_contigs; b->d_seq = nullptr; b->d_tiles = nullptr; b->d_tile0 = nullptr; b->n_tiles = 0; b->ct.resize((size_t)n_contigs + 1);
     int64_t total = 0;
     for (int i = 0; i < n_contigs; i++) { b->ct[i].base = total; b->ct[i].len = (int32_t)lens[i]; b->ct[i]._pad = 0; total += lens[i]; }
     b->ct[n_contigs].base = total; b->ct[n_contigs].len = 0; b->ct[n_contigs]._pad = 0;
@@ -902,17 +914,11 @@ extern "C" int pga_batch_create_packed(pga_ctx* c, int32_t n_contigs, const char
     if (total >= 0x7fffffffLL) { delete b; c->err = "pga_batch_create_packed: batch larger than 2^31 bases; split it"; return PGA_EINVAL; }
     if (total > 0) {
         if (hipMalloc((void**)&b->d_seq, (size_t)total + 16) != hipSuccess) { delete b; c->err = "pga_batch_create_packed: hipMalloc failed"; return PGA_ENOMEM; }
-        std::vector<TileDesc> tiles;
-        const int TS = pga_extract_tile_size();
-        for (int i = 0; i < n_contigs; i++)
-            for (int64_t s0 = 0; s0 + 2 < lens[i]; s0 += TS) tiles.push_back(TileDesc{i, (int32_t)s0});
-        b->n_tiles = (int32_t)tiles.size();
-        // the letters go straight from the caller's (pinned) buffer: one DMA, overlapped with the tile list's host work above
+        // the letters go straight from the caller's (pinned) buffer: one DMA, overlapped with the tile list's host work
         hipError_t e = hipMemcpyAsync(b->d_seq, packed + offs[0], (size_t)total, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess && !tiles.empty()) {
-            if (hipMalloc((void**)&b->d_tiles, sizeof(TileDesc) * tiles.size()) != hipSuccess) e = hipErrorOutOfMemory;
-            else e = hipMemcpyAsync(b->d_tiles, tiles.data(), sizeof(TileDesc) * tiles.size(), hipMemcpyHostToDevice, c->stream);
-        }
+        std::vector<TileDesc> tiles; std::vector<int32_t> tile0;
+        batch_tiles(b, tiles, tile0);
+        if (e == hipSuccess) e = batch_upload_tiles(b, tiles, tile0, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { if (b->d_tiles) hipFree(b->d_tiles); hipFree(b->d_seq); delete b; return pga_hip_try_(c, e, "upload of the packed batch"); }
     }
@@ -1007,12 +1013,15 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         DEVBUF(d_dig, uint8_t, "d_dig", total + 16);
         DEVBUF(d_ct, ContigDesc, "d_ct", NC + 1);
         DEVBUF(d_cnt, int32_t, "d_cnt", 2 * (size_t)NC);
-        DEVBUF(d_pre_gc, int32_t, "d_pre_gc", total + 1);
-        const int64_t tiles = pga_scan_tiles(total);
-        DEVBUF(d_tile, int2, "d_tile", tiles);
+        const int64_t gc_blocks = pga_gc_blocks(total);
+        DEVBUF(d_p16, int32_t, "d_gc_p16", total / 16 + 2);
+        DEVBUF(d_gc_bsum, int32_t, "d_gc_bsum", gc_blocks + 1);
+        DEVBUF(d_gc_boff, int32_t, "d_gc_boff", gc_blocks + 1);
         DEVBUF(d_cbase, int32_t, "d_cbase", (size_t)NG * (NC + 1));
         DEVBUF(d_tile_first, int32_t, "d_tile_first", (size_t)6 * batch->n_tiles);
         DEVBUF(d_tile_last, int32_t, "d_tile_last", (size_t)6 * batch->n_tiles);
+        DEVBUF(d_tile_count, int32_t, "d_tile_count", (size_t)NG * (batch->n_tiles + 1));
+        DEVBUF(d_tile_off, int32_t, "d_tile_off", (size_t)NG * (batch->n_tiles + 1));
         PINBUF(h_cnt, int32_t, "h_cnt", 2 * (size_t)NC);
         PINBUF(h_cbase, int32_t, "h_cbase", (size_t)NG * (NC + 1));
 
@@ -1021,9 +1030,8 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             char nm[32];
 #define GBUF(field, type, count) { snprintf(nm, sizeof nm, #field "%d", g); void* p__; int rc__ = ensure_dev(c, nm, sizeof(type) * (size_t)(count) + 64, &p__); if (rc__) return rc__; ga[g].field = (type*)p__; }
             GBUF(nf_fwd, uint8_t, total + 1) GBUF(nf_rev, uint8_t, total + 1)
-            GBUF(tsv_fwd, int32_t, total + 1) GBUF(tsv_rev, int32_t, total + 1)
-            GBUF(tinfo_fwd, uint8_t, total + 1) GBUF(tinfo_rev, uint8_t, total + 1)
             GBUF(pre_nodes, int32_t, total + 2)
+            GBUF(st_ndx, int32_t, 2 * total + 2) GBUF(st_sv, int32_t, 2 * total + 2) GBUF(st_info, uint8_t, 2 * total + 2)
             ga[g].ndx = nullptr; ga[g].stop_val = nullptr; ga[g].type = nullptr; ga[g].strand = nullptr; ga[g].edge0 = nullptr; ga[g].gc_cont = nullptr;
         }
 
@@ -1031,6 +1039,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         HT(c, hipMemcpyAsync(d_ct, ct.data(), sizeof(ContigDesc) * (NC + 1), hipMemcpyHostToDevice, st));
         HT(c, hipMemsetAsync(d_cnt, 0, sizeof(int32_t) * 2 * (size_t)NC, st));
         pga_launch_digitize(d_seq, d_dig, total, d_ct, NC, d_cnt, d_cnt + NC, st);
+        pga_launch_gc_prefix(d_dig, total, d_gc_bsum, d_gc_boff, d_p16, st);
         MaskList masks{nullptr, nullptr};
         if (P.mask) {
             // masked regions: found on the device, ordered on the host (a handful of intervals)
@@ -1077,11 +1086,9 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         }
         for (int g = 0; g < NG; g++) {
             const int tt = meta_run ? f->group_tt[g] : (stage == PGA_STAGE_EXTRACT ? tt_override : c->models[0].trans_table);
-            HT(c, hipMemsetAsync(ga[g].nf_fwd, 0, (size_t)total + 1, st));
-            HT(c, hipMemsetAsync(ga[g].nf_rev, 0, (size_t)total + 1, st));
-            pga_launch_extract(d_dig, total, d_ct, NC, tt, P, ga[g], d_tile, d_pre_gc, g == 0, batch->d_tiles, batch->n_tiles, d_tile_first, d_tile_last, masks, st,
-                               (meta_run && NM > 0) ? d_enabled + (size_t)g * NC : nullptr);
-            hipLaunchKernelGGL(k_contig_node_base, dim3((NC + 1 + 255) / 256), dim3(256), 0, st, d_ct, NC, total, ga[g].pre_nodes, d_cbase + (size_t)g * (NC + 1));
+            pga_launch_extract(d_dig, total, d_ct, NC, tt, P, ga[g], batch->d_tiles, batch->n_tiles, batch->d_tile0, d_tile_first, d_tile_last,
+                               d_tile_count + (size_t)g * (batch->n_tiles + 1), d_tile_off + (size_t)g * (batch->n_tiles + 1), d_cbase + (size_t)g * (NC + 1),
+                               masks, st, (meta_run && NM > 0) ? d_enabled + (size_t)g * NC : nullptr);
         }
         HT(c, hipMemcpyAsync(h_cnt, d_cnt, sizeof(int32_t) * 2 * (size_t)NC, hipMemcpyDeviceToHost, st));
         HT(c, hipMemcpyAsync(h_cbase, d_cbase, sizeof(int32_t) * (size_t)NG * (NC + 1), hipMemcpyDeviceToHost, st));
@@ -1213,8 +1220,8 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         if (meta_run) HT(c, hipMemsetAsync(d_conv, 0, (size_t)NG * NC, st));
         const pga_training* d_models = (const pga_training*)c->d_models_raw;
         for (int g = 0; g < NG; g++) {
-            pga_launch_compact(total, d_ct, NC, ga[g], st);
-            pga_launch_orf_gc(d_ct, NC, d_pre_gc, ga[g], (int)group_nodes[g], d_cbase + (size_t)g * (NC + 1), st);
+            pga_launch_place(d_ct, batch->d_tiles, batch->n_tiles, d_tile_off + (size_t)g * (batch->n_tiles + 1), ga[g], st);
+            pga_launch_orf_gc(d_ct, NC, d_dig, d_p16, ga[g], (int)group_nodes[g], d_cbase + (size_t)g * (NC + 1), st);
             const int nch = g_c0[g + 1] - g_c0[g];
             const int64_t nn = g_n0[g + 1] - g_n0[g];
             if (nch == 0 || nn == 0 || stage == PGA_STAGE_EXTRACT) continue;

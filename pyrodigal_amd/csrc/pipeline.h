@@ -9,7 +9,7 @@ struct ContigDesc {
     int32_t _pad;
 };
 
-// One 3072-position tile of one contig (strand-local coordinates) for the extraction kernels.
+// One 3072-position tile of one contig (forward coordinates; every position of a contig of three bases or more lies in one) for the extraction kernels.
 struct TileDesc {
     int32_t contig;
     int32_t start;
@@ -19,10 +19,11 @@ struct TileDesc {
 // (fields that do not depend on the model), indexed by global node number.
 struct GroupArrays {
     // per position (whole batch)
-    uint8_t* nf_fwd;  uint8_t* nf_rev;       // 1 = a forward / reverse node has its ndx here
-    int32_t* tsv_fwd; int32_t* tsv_rev;      // stop_val of that node
-    uint8_t* tinfo_fwd; uint8_t* tinfo_rev;  // type | edge << 2
-    int32_t* pre_nodes;                      // [total+1] exclusive prefix of nf_fwd + nf_rev
+    uint8_t* nf_fwd;  uint8_t* nf_rev;       // 1 = a forward / reverse node has its ndx here (written densely by the tile that owns the position)
+    int32_t* pre_nodes;                      // at a position with a node: the index of its first node (forward before reverse)
+    // staging, two slots per position: the nodes of the tile that starts at global position g, packed in order from slot 2 g
+    int32_t* st_ndx; int32_t* st_sv;         // ndx, stop_val
+    uint8_t* st_info;                        // type | edge << 2 | reverse << 3
     // per node, in (contig, ndx, strand) order
     int32_t* ndx; int32_t* stop_val; uint8_t* type; int8_t* strand; uint8_t* edge0; float* gc_cont;
 };
@@ -60,10 +61,18 @@ struct ScoreParams {
 
 void pga_launch_digitize(const char* d_seq, uint8_t* d_dig, int64_t total, const ContigDesc* d_ct, int n_contigs,
                          int32_t* d_gc, int32_t* d_unk, hipStream_t st);
+// GC-or-unknown bases before every 16th position of the batch (d_p16: total / 16 + 2 entries); scratch of pga_gc_blocks(total) + 1 entries each
+int64_t pga_gc_blocks(int64_t total);
+void pga_launch_gc_prefix(const uint8_t* d_dig, int64_t total, int32_t* d_block_sum, int32_t* d_block_off, int32_t* d_p16, hipStream_t st);
+// nodes of one translation-table group: staged per tile, counted (d_tile_count[n_tiles], d_tile_off[n_tiles + 1]), first node of
+// every contig in d_cbase[n_contigs + 1]; d_tile0[c] = first tile of contig c (n_contigs + 1 entries).  pga_launch_place moves the
+// staged nodes to ga.ndx .. ga.edge0 once those are allocated.
 void pga_launch_extract(const uint8_t* d_dig, int64_t total, const ContigDesc* d_ct, int n_contigs, int tt,
-                        const pga_params& p, const GroupArrays& ga, int2* d_tile_sum, int32_t* d_pre_gc, int write_gc,
-                        const TileDesc* d_tiles, int n_tiles, int32_t* d_tile_first, int32_t* d_tile_last, MaskList masks, hipStream_t st,
+                        const pga_params& p, const GroupArrays& ga, const TileDesc* d_tiles, int n_tiles, const int32_t* d_tile0,
+                        int32_t* d_tile_first, int32_t* d_tile_last, int32_t* d_tile_count, int32_t* d_tile_off, int32_t* d_cbase,
+                        MaskList masks, hipStream_t st,
                         const uint8_t* d_enabled = nullptr /* per contig: extract it in this group?  nullptr = every contig */);
+void pga_launch_place(const ContigDesc* d_ct, const TileDesc* d_tiles, int n_tiles, const int32_t* d_tile_off, const GroupArrays& ga, hipStream_t st);
 // per (group, contig): is any model of the group inside the contig's GC window?  (meta mode)
 void pga_launch_group_enable(const ContigDesc* d_ct, int n_contigs, const int32_t* d_gc_count, const double* d_model_gc,
                              const int32_t* d_model_group, int n_models, int n_groups, uint8_t* d_enabled, hipStream_t st);
@@ -71,8 +80,7 @@ void pga_launch_group_enable(const ContigDesc* d_ct, int n_contigs, const int32_
 void pga_launch_find_masks(const uint8_t* d_dig, const ContigDesc* d_ct, int n_contigs, const TileDesc* d_tiles, int n_tiles, int min_mask,
                            MaskRun* d_runs, int32_t* d_count, int cap, hipStream_t st);
 int pga_extract_tile_size();
-void pga_launch_compact(int64_t total, const ContigDesc* d_ct, int n_contigs, const GroupArrays& ga, hipStream_t st);
-void pga_launch_orf_gc(const ContigDesc* d_ct, int n_contigs, const int32_t* d_pre_gc, const GroupArrays& ga,
+void pga_launch_orf_gc(const ContigDesc* d_ct, int n_contigs, const uint8_t* d_dig, const int32_t* d_p16, const GroupArrays& ga,
                        int n_nodes_total, const int32_t* d_node_contig_base, hipStream_t st);
 // chains[0..n_chains): the chains of ONE translation-table group, contiguous in `off` from node_begin
 void pga_launch_score(const ChainDesc* d_chains, int n_chains, int64_t node_begin, int64_t total, const uint8_t* d_dig,
@@ -89,4 +97,3 @@ bool pga_cs_tasks(const int2* h_cc, int n_contigs, const ChainDesc* h_chains, co
                   std::vector<int32_t>& tasks, std::vector<int32_t>& entries);
 // the RBS search tabulated: 1920 words, filled once per context (see sd_hits in pipeline.hip)
 void pga_launch_sd_lut(unsigned* d_lut, hipStream_t st);
-int64_t pga_scan_tiles(int64_t total);

@@ -60,7 +60,7 @@ __device__ __forceinline__ int comp2(int d) { return d <= 3 ? (d ^ 3) : NN; }
 __device__ __forceinline__ int is_gc_n(int d) { return d != NA && d != NT; }   // ref: _sequence.h:35-43
 
 // ref: _sequence.h:117-157
-__device__ __forceinline__ bool codon_is_stop(int x0, int x1, int x2, int tt) {
+__host__ __device__ __forceinline__ bool codon_is_stop(int x0, int x1, int x2, int tt) {
     if (x0 != NT) {
         if (tt == 2) return x0 == NA && x1 == NG && (x2 == NA || x2 == NG);
         return false;
@@ -80,7 +80,7 @@ __device__ __forceinline__ bool codon_is_stop(int x0, int x1, int x2, int tt) {
     return false;
 }
 // ref: _sequence.h:45-73
-__device__ __forceinline__ bool codon_is_start(int x0, int x1, int x2, int tt) {
+__host__ __device__ __forceinline__ bool codon_is_start(int x0, int x1, int x2, int tt) {
     if (x1 != NT || x2 != NG) return false;
     if (x0 == NA) return true;
     if (tt == 6 || tt == 10 || tt == 14 || tt == 15 || tt == 16 || tt == 2) return false;
@@ -168,295 +168,473 @@ constexpr int EX_TILE = 3072;          // positions per tile (256 threads x 12)
 constexpr int EX_PER_THREAD = 12;
 constexpr int EX_NONE_HI = 0x7fffffff; // "no stop to the right"
 
-// pass 1: first / last stop position of every tile, per frame
+// 2-bit codes of four digit bytes, byte t at bits 2t (comp: the reverse strand reads the complement; an unknown base stays 2)
+__device__ __forceinline__ unsigned pack4(const unsigned w, const bool comp) {
+    unsigned c = w & 0x03030303u;
+    if (comp) { const unsigned nm = (w >> 2) & 0x01010101u; c = (c ^ 0x03030303u) ^ (nm | (nm << 1)); }
+    return (c | (c >> 6) | (c >> 12) | (c >> 18)) & 0xffu;
+}
+__device__ __forceinline__ unsigned long long pack16(const uint4 v, const bool comp) {      // byte t at bits 2t, 32 bits
+    return (unsigned long long)(pack4(v.x, comp) | (pack4(v.y, comp) << 8) | (pack4(v.z, comp) << 16) | (pack4(v.w, comp) << 24));
+}
+__device__ __forceinline__ unsigned long long pairrev64(unsigned long long x) {              // pair t -> pair 31 - t
+    x = __brevll(x);
+    return ((x & 0x5555555555555555ull) << 1) | ((x >> 1) & 0x5555555555555555ull);
+}
+
+// Geometry: one block per tile of EX_TILE forward positions [a, a + len) of one contig, BOTH strands.  The reverse strand is
+// handled in its own (strand-local) coordinates i = L - 1 - pos, i.e. over the mirrored range [L - a - len, L - a): thread t owns
+// 12 consecutive strand-local positions of each strand.  Tile summaries (first / last stop of a frame) are kept per strand in
+// strand-local positions; "the tiles to the right" of a reverse range are the tiles with SMALLER index.
+struct TileGeom {
+    int L, a, len;
+    __device__ __forceinline__ int lo(const int strand) const { return strand == 1 ? a : L - a - len; }     // first strand-local position
+};
+__device__ __forceinline__ TileGeom tile_geom(const TileDesc td, const int L) { return TileGeom{L, td.start, min(EX_TILE, L - td.start)}; }
+
+// pass 1: first / last stop position of every tile, per strand and frame
 __global__ void __launch_bounds__(256)
 k_tile_stops(const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct, const TileDesc* __restrict__ tiles, int n_tiles,
              int tt, int32_t* __restrict__ tile_first, int32_t* __restrict__ tile_last, const uint8_t* __restrict__ enabled) {
-    __shared__ int s_min[3][4], s_max[3][4];
+    __shared__ int s_min[2][3][4], s_max[2][3][4];
     const TileDesc td = tiles[blockIdx.x];
     if (enabled != nullptr && !enabled[td.contig]) return;       // no model of this translation table is scored on the contig
-    const int strand = blockIdx.y == 0 ? 1 : -1;
     const ContigDesc cd = ct[td.contig];
+    const TileGeom G = tile_geom(td, cd.len);
     const int L = cd.len;
     const uint8_t* __restrict__ d = dig + cd.base;
-    const int i0 = td.start + threadIdx.x * EX_PER_THREAD;
-    int mn[3] = {EX_NONE_HI, EX_NONE_HI, EX_NONE_HI}, mx[3] = {-1, -1, -1};
-    if (i0 <= L - 3) {
-        int c[EX_PER_THREAD + 2];
 #pragma unroll
-        for (int q = 0; q < EX_PER_THREAD + 2; q++) c[q] = (i0 + q < L) ? sbase(d, L, i0 + q, strand) : NN;
+    for (int s = 0; s < 2; s++) {
+        const int strand = s == 0 ? 1 : -1;
+        const int lo = G.lo(strand), i0 = lo + threadIdx.x * EX_PER_THREAD, end = lo + G.len;
+        int mn[3] = {EX_NONE_HI, EX_NONE_HI, EX_NONE_HI}, mx[3] = {-1, -1, -1};
+        if (i0 < end && i0 <= L - 3) {
+            int c[EX_PER_THREAD + 2];
 #pragma unroll
-        for (int q = 0; q < EX_PER_THREAD; q++) {
-            const int i = i0 + q;
-            if (i <= L - 3 && codon_is_stop(c[q], c[q + 1], c[q + 2], tt)) {
-                const int f = i % 3;
-                mn[f] = min(mn[f], i); mx[f] = max(mx[f], i);
+            for (int q = 0; q < EX_PER_THREAD + 2; q++) c[q] = (i0 + q < L) ? sbase(d, L, i0 + q, strand) : NN;
+#pragma unroll
+            for (int q = 0; q < EX_PER_THREAD; q++) {
+                const int i = i0 + q;
+                if (i < end && i <= L - 3 && codon_is_stop(c[q], c[q + 1], c[q + 2], tt)) {
+                    const int f = i % 3;
+                    mn[f] = min(mn[f], i); mx[f] = max(mx[f], i);
+                }
             }
         }
-    }
 #pragma unroll
-    for (int f = 0; f < 3; f++) {
-        int a = mn[f], b = mx[f];
+        for (int f = 0; f < 3; f++) {
+            int a = mn[f], b = mx[f];
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { a = min(a, __shfl_xor(a, m, 64)); b = max(b, __shfl_xor(b, m, 64)); }
-        if ((threadIdx.x & 63) == 0) { s_min[f][threadIdx.x >> 6] = a; s_max[f][threadIdx.x >> 6] = b; }
+            for (int m = 32; m >= 1; m >>= 1) { a = min(a, __shfl_xor(a, m, 64)); b = max(b, __shfl_xor(b, m, 64)); }
+            if ((threadIdx.x & 63) == 0) { s_min[s][f][threadIdx.x >> 6] = a; s_max[s][f][threadIdx.x >> 6] = b; }
+        }
     }
     __syncthreads();
-    if (threadIdx.x < 3) {
-        const int f = threadIdx.x;
-        const int64_t o = ((int64_t)blockIdx.y * n_tiles + blockIdx.x) * 3 + f;
-        tile_first[o] = min(min(s_min[f][0], s_min[f][1]), min(s_min[f][2], s_min[f][3]));
-        tile_last[o] = max(max(s_max[f][0], s_max[f][1]), max(s_max[f][2], s_max[f][3]));
+    if (threadIdx.x < 6) {
+        const int s = threadIdx.x / 3, f = threadIdx.x % 3;
+        const int64_t o = ((int64_t)s * n_tiles + blockIdx.x) * 3 + f;
+        tile_first[o] = min(min(s_min[s][f][0], s_min[s][f][1]), min(s_min[s][f][2], s_min[s][f][3]));
+        tile_last[o] = max(max(s_max[s][f][0], s_max[s][f][1]), max(s_max[s][f][2], s_max[s][f][3]));
     }
 }
 
-// pass 2: every position decides
-__global__ void __launch_bounds__(256)
-k_extract_scan(const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct, const TileDesc* __restrict__ tiles, int n_tiles,
-               const int32_t* __restrict__ tile_first, const int32_t* __restrict__ tile_last,
-               int tt, int closed, int min_gene, int min_edge_gene, GroupArrays ga, MaskList masks, const uint8_t* __restrict__ enabled) {
-    __shared__ int s_first[3][256], s_last[3][256];
-    __shared__ int s_carry_ns[3], s_carry_ps[3];
-    const TileDesc td = tiles[blockIdx.x];
-    if (enabled != nullptr && !enabled[td.contig]) return;       // the contig keeps zero nodes in this group
-    const int strand = blockIdx.y == 0 ? 1 : -1;
-    const ContigDesc cd = ct[td.contig];
-    const int L = cd.len;
-    const int64_t base = cd.base;
-    const uint8_t* __restrict__ d = dig + base;
-    const int t = threadIdx.x;
-    const int i0 = td.start + t * EX_PER_THREAD;
-    // tile carries: nearest stop of each frame in the following / preceding tiles of the same contig
+// pass 2: every position decides, the tile packs its nodes.
+// A start node is decided at its own position from NS / PS (next / previous in-frame stop).  The stop node of an ORF exists
+// when the ORF holds at least one start node; the thread that owns the stop position decides that from LSC(x) = the last
+// in-frame start codon at or before x: a start at i counts when stop - i + 3 >= min_gene, i.e. i <= x = stop + 3 - min_gene,
+// and i lies after the previous stop and outside the ORF's mask, so the ORF has one iff LSC(x) >= that lower bound (plus the
+// edge start of an open contig, lib.pyx:1975-1982, 2070-2077).  LSC comes from a third scan over the tile; where it has to
+// look left of the tile (the stop sits in the tile's first min_gene positions) the thread walks back codon by codon -- a
+// start codon turns up every twenty codons or so.
+struct ExShared {
+    int lsc[3][256];                   // last start codon of relative frame r at or before the thread's positions (strand-local order)
+    int scm[256];                      // the thread's 12 positions: bit q = start codon at i0 + q
+    int32_t sv[2][EX_PER_THREAD][256]; // stop_val of the node at the thread's k-th forward position, per strand
+    int wmin[3][4], wmax[3][4], wlsc[3][4];
+    int carry_ns[3], carry_ps[3];
+    int wsum[4];
+};
+
+// stop_codons / start_codons: bit (b0 | b1 << 2 | b2 << 4) set when the codon of 2-bit digits b0 b1 b2 is one (codon_is_stop /
+// codon_is_start tabulated by the host for the translation table; a codon with an unknown base is neither)
+struct ExParams { int tt, closed, min_gene, min_edge_gene; unsigned long long stop_codons, start_codons; };
+
+__device__ __forceinline__ unsigned pairrev32(unsigned x) {      // pair t -> pair 15 - t
+    x = __brev(x);
+    return ((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u);
+}
+__device__ __forceinline__ unsigned unknown4(const unsigned w) {  // bit t: byte t is an unknown base (digit 6, or 5 after the complement)
+    const unsigned n = (w >> 2) & 0x01010101u;
+    return (n | (n >> 7) | (n >> 14) | (n >> 21)) & 0xfu;
+}
+
+// The nodes of one strand among the thread's twelve forward positions a + 12 t + k: bit k of `nodes`, type | edge << 2 in the
+// k-th nibble of `infos`, stop_val in S.sv[strand][k][t].  Thread t owns the SAME forward positions on both strands; on the
+// reverse strand they are the strand-local positions i0 .. i0 + 11 with i0 = (L - 1 - a) - 12 t - 11, so strand-local order runs
+// against t.  Frames are counted relative to i0 (r = q % 3; i0 % 3 is the same for every thread of the tile).
+template <int STRAND>
+__device__ __forceinline__ void extract_strand(ExShared& S, const TileGeom G, const uint8_t* __restrict__ d, const int64_t base, const int64_t total,
+                                               const int tile, const TileDesc* __restrict__ tiles, const int n_tiles,
+                                               const int32_t* __restrict__ tile_first, const int32_t* __restrict__ tile_last, const ExParams P,
+                                               const int n_masks, const int2* __restrict__ mv, unsigned& nodes, unsigned long long& infos) {
+    constexpr bool FWD = STRAND == 1;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, L = G.L, s = FWD ? 0 : 1;
+    const int lo = G.lo(STRAND), end = lo + G.len;
+    const int top = FWD ? G.a : L - 1 - G.a - (EX_PER_THREAD - 1);        // i0 of thread 0
+    const int i0 = FWD ? top + t * EX_PER_THREAD : top - t * EX_PER_THREAD;
+    const int f0 = ((top % 3) + 3) % 3;                                    // absolute frame of relative frame 0
+    nodes = 0; infos = 0;
+    // tile carries: nearest stop of each frame in the tiles that follow / precede in strand-local order (same contig)
     if (t < 6) {
         const int f = t % 3;
-        const int64_t so = (int64_t)blockIdx.y * n_tiles;
+        const int64_t so = (int64_t)s * n_tiles;
+        const int contig = tiles[tile].contig;
+        const int up = FWD ? 1 : -1;                    // tile index step towards larger strand-local positions
         if (t < 3) {
             int v = EX_NONE_HI;
-            for (int k = blockIdx.x + 1; k < n_tiles && tiles[k].contig == td.contig; k++) {
+            for (int k = tile + up; k >= 0 && k < n_tiles && tiles[k].contig == contig; k += up) {
                 v = tile_first[(so + k) * 3 + f];
                 if (v != EX_NONE_HI) break;
             }
-            s_carry_ns[f] = v;
+            S.carry_ns[f] = v;
         } else {
             int v = -1;
-            for (int k = (int)blockIdx.x - 1; k >= 0 && tiles[k].contig == td.contig; k--) {
+            for (int k = tile - up; k >= 0 && k < n_tiles && tiles[k].contig == contig; k -= up) {
                 v = tile_last[(so + k) * 3 + f];
                 if (v != -1) break;
             }
-            s_carry_ps[f] = v;
+            S.carry_ps[f] = v;
         }
     }
-    int c[EX_PER_THREAD + 2];
-    bool st[EX_PER_THREAD];
-    int mn[3] = {EX_NONE_HI, EX_NONE_HI, EX_NONE_HI}, mx[3] = {-1, -1, -1};
-#pragma unroll
-    for (int q = 0; q < EX_PER_THREAD + 2; q++) c[q] = (i0 + q < L) ? sbase(d, L, i0 + q, strand) : NN;
-#pragma unroll
-    for (int q = 0; q < EX_PER_THREAD; q++) {
-        const int i = i0 + q;
-        st[q] = i <= L - 3 && codon_is_stop(c[q], c[q + 1], c[q + 2], tt);
-        if (st[q]) { const int f = i % 3; mn[f] = min(mn[f], i); mx[f] = max(mx[f], i); }
-    }
-#pragma unroll
-    for (int f = 0; f < 3; f++) { s_first[f][t] = mn[f]; s_last[f][t] = mx[f]; }
-    __syncthreads();
-    // exclusive suffix-min of s_first / exclusive prefix-max of s_last over the 256 threads (Hillis-Steele in LDS)
-    for (int off = 1; off < 256; off <<= 1) {
-        int a[3], b[3];
-#pragma unroll
-        for (int f = 0; f < 3; f++) {
-            a[f] = t + off < 256 ? s_first[f][t + off] : EX_NONE_HI;
-            b[f] = t - off >= 0 ? s_last[f][t - off] : -1;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int f = 0; f < 3; f++) { s_first[f][t] = min(s_first[f][t], a[f]); s_last[f][t] = max(s_last[f][t], b[f]); }
-        __syncthreads();
-    }
-    int nxt[3], prv[3];
-#pragma unroll
-    for (int f = 0; f < 3; f++) {
-        nxt[f] = t + 1 < 256 ? s_first[f][t + 1] : EX_NONE_HI;       // inclusive scans shifted by one thread
-        prv[f] = t >= 1 ? s_last[f][t - 1] : -1;
-        if (nxt[f] == EX_NONE_HI) nxt[f] = s_carry_ns[f];
-        if (prv[f] == -1) prv[f] = s_carry_ps[f];
-    }
-    if (i0 > L - 3) return;
-    // previous stop of every position (ascending), then decisions (descending, tracking the next stop)
-    int ps[EX_PER_THREAD];
-#pragma unroll
-    for (int q = 0; q < EX_PER_THREAD; q++) {
-        const int f = (i0 + q) % 3;
-        ps[q] = prv[f];
-        if (st[q]) prv[f] = i0 + q;
-    }
-    uint8_t* __restrict__ nf = strand == 1 ? ga.nf_fwd : ga.nf_rev;
-    int32_t* __restrict__ tsv = strand == 1 ? ga.tsv_fwd : ga.tsv_rev;
-    uint8_t* __restrict__ tinfo = strand == 1 ? ga.tinfo_fwd : ga.tinfo_rev;
-    const int n_masks = masks.off ? masks.off[td.contig + 1] - masks.off[td.contig] : 0;
-    const int2* __restrict__ mv = masks.off ? masks.iv + masks.off[td.contig] : nullptr;
-#pragma unroll
-    for (int q = EX_PER_THREAD - 1; q >= 0; q--) {
-        const int i = i0 + q, f = i % 3;
-        if (i > L - 3) continue;
-        if (st[q]) { nxt[f] = i; continue; }
-        int last = nxt[f];
-        bool real = last != EX_NONE_HI;
-        if (!real) {
-            if (closed) continue;                       // closed ends: nothing runs off the right edge
-            last = L - 3 - ((L - 3 - f) % 3);           // virtual right end: last full codon position of the frame
-            if (last < i) continue;
-        }
-        // region masks (ref: lib.pyx:1959-1966, 2053-2061).  The reference keeps one mask pointer per frame that
-        // follows the ORF's stop and tests that single mask: forward, the last mask beginning at or before the stop;
-        // reverse, the first mask ending at or after the stop's forward coordinate.
-        if (n_masks > 0) {
-            bool hit = false;
-            if (strand == 1) {
-                int a = 0, b = n_masks;                 // first mask with begin > last
-                while (a < b) { const int m = (a + b) >> 1; if (mv[m].x <= last) a = m + 1; else b = m; }
-                if (a > 0) { const int2 m = mv[a - 1]; hit = m.x < last && i < m.y; }
-            } else {
-                const int x = L - last - 1, e = L - i - 1;
-                int a = 0, b = n_masks;                 // first mask with end >= x
-                while (a < b) { const int m = (a + b) >> 1; if (mv[m].y < x) a = m + 1; else b = m; }
-                if (a < n_masks) { const int2 m = mv[a]; hit = m.x < e && x < m.y; }
+    // the thread's positions that exist and can start a codon inside the tile: q in [qa, qb]
+    const int qa = max(0, lo - i0), qb = min(EX_PER_THREAD - 1, min(end - 1, L - 3) - i0);
+    const unsigned inm = qb >= qa ? ((2u << qb) - 1u) & ~((1u << qa) - 1u) : 0u;
+    // 2-bit digits of positions i0 .. i0 + 15 (pair q), unknown or missing bases in `unk` (bit q)
+    unsigned cw = 0, unk = 0xffffu;
+    if (inm) {
+        const int64_t ga0 = FWD ? base + i0 : base + (L - 1 - i0 - 15);     // lowest byte read
+        if (ga0 >= 0 && ga0 <= total) {
+            uint4 v; __builtin_memcpy(&v, (FWD ? d + i0 : d + (L - 1 - i0 - 15)), 16);
+            const unsigned q0 = (unsigned)pack16(v, !FWD);
+            const unsigned n0 = unknown4(v.x) | (unknown4(v.y) << 4) | (unknown4(v.z) << 8) | (unknown4(v.w) << 12);
+            cw = FWD ? q0 : pairrev32(q0);
+            unk = FWD ? n0 : (__brev(n0) >> 16);
+        } else {
+            unk = 0;
+            for (int q = 0; q < 16; q++) {
+                const int i = i0 + q;
+                const int b = (i >= 0 && i < L) ? sbase(d, L, i, STRAND) : NN;
+                if (b > 3) unk |= 1u << q; else cw |= (unsigned)b << (2 * q);
             }
-            if (hit) continue;
         }
-        const int mind = real ? min_gene : min_edge_gene;
-        int type = -1, edge = 0;
-        if (last - i + 3 >= mind && codon_is_start(c[q], c[q + 1], c[q + 2], tt)) type = c[q] == NA ? 0 : (c[q] == NT ? 2 : 1);
-        else if (i <= 2 && !closed && last - i > min_edge_gene) { type = 0; edge = 1; }
-        if (type < 0) continue;
-        const int pos = strand == 1 ? i : L - 1 - i;
-        nf[base + pos] = 1;
-        tsv[base + pos] = strand == 1 ? last : L - 1 - last;
-        tinfo[base + pos] = (uint8_t)(type | (edge << 2));
-        // the stop node of this ORF (every start of the ORF writes the same bytes)
-        const int lpos = strand == 1 ? last : L - 1 - last;
-        const int left = ps[q];
-        int sv;
-        if (strand == 1) sv = left >= 0 ? left : f - 6;
-        else sv = left >= 0 ? L - 1 - left : L - f + 5;
-        nf[base + lpos] = 1;
-        tsv[base + lpos] = sv;
-        tinfo[base + lpos] = (uint8_t)(PGA_T_STOP | ((real ? 0 : 1) << 2));
+        // positions outside the contig
+        if (i0 < 0) unk |= (1u << min(16, -i0)) - 1u;
+        if (i0 + 16 > L) unk |= ~((1u << max(0, L - i0)) - 1u) & 0xffffu;
     }
-}
-
-// --------------------------------------------------------------------------- prefix sums
-// Exclusive scan of (node count, GC-or-unknown count) per position over the whole batch.
-// 3 passes: per-block totals, scan of block totals (single block), final write.
-constexpr int SCAN_TILE = 2048;   // positions per block (256 threads x 8)
-
-__device__ __forceinline__ void tile_counts(const uint8_t* __restrict__ nf_fwd, const uint8_t* __restrict__ nf_rev,
-                                            const uint8_t* __restrict__ dig, int64_t start, int64_t total,
-                                            int cn[8], int cg[8]) {
+    unsigned stm = 0, scm = 0;          // stop codon / start codon at i0 + q
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int64_t g = start + k;
-        if (g < total) { cn[k] = nf_fwd[g] + nf_rev[g]; cg[k] = is_gc_n(dig[g]); }
-        else { cn[k] = 0; cg[k] = 0; }
+    for (int q = 0; q < EX_PER_THREAD; q++) {
+        const unsigned idx = (cw >> (2 * q)) & 63u;
+        const unsigned ok = ((unk >> q) & 7u) == 0u ? 1u : 0u;
+        stm |= ((unsigned)(P.stop_codons >> idx) & ok) << q;
+        scm |= ((unsigned)(P.start_codons >> idx) & ok) << q;
     }
-}
-
-__global__ void __launch_bounds__(256)
-k_scan_tiles(const uint8_t* __restrict__ nf_fwd, const uint8_t* __restrict__ nf_rev, const uint8_t* __restrict__ dig,
-             int64_t total, int2* __restrict__ tile_sum) {
-    __shared__ int2 s_w[4];
-    int cn[8], cg[8];
-    tile_counts(nf_fwd, nf_rev, dig, (int64_t)blockIdx.x * SCAN_TILE + threadIdx.x * 8, total, cn, cg);
-    int a = 0, b = 0;
+    stm &= inm; scm &= inm;
+    int mn[3], mx[3], ls[3];
 #pragma unroll
-    for (int k = 0; k < 8; k++) { a += cn[k]; b += cg[k]; }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = make_int2(a, b);
-    __syncthreads();
-    if (threadIdx.x == 0) tile_sum[blockIdx.x] = make_int2(s_w[0].x + s_w[1].x + s_w[2].x + s_w[3].x, s_w[0].y + s_w[1].y + s_w[2].y + s_w[3].y);
-}
-
-__global__ void __launch_bounds__(1024)
-k_scan_tile_sums(int2* __restrict__ tile_sum, int n_tiles) {
-    __shared__ int2 s_part[1024];
-    __shared__ int2 s_carry;
-    if (threadIdx.x == 0) s_carry = make_int2(0, 0);
-    __syncthreads();
-    for (int base = 0; base < n_tiles; base += 1024) {
-        const int i = base + threadIdx.x;
-        int2 v = i < n_tiles ? tile_sum[i] : make_int2(0, 0);
-        s_part[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            int2 t = make_int2(0, 0);
-            if ((int)threadIdx.x >= off) t = s_part[threadIdx.x - off];
-            __syncthreads();
-            s_part[threadIdx.x].x += t.x; s_part[threadIdx.x].y += t.y;
-            __syncthreads();
-        }
-        const int2 incl = s_part[threadIdx.x], carry = s_carry;
-        if (i < n_tiles) tile_sum[i] = make_int2(carry.x + incl.x - v.x, carry.y + incl.y - v.y);   // exclusive
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry = make_int2(carry.x + incl.x, carry.y + incl.y);
-        __syncthreads();
+    for (int r = 0; r < 3; r++) {
+        const unsigned fr = 0x249u << r;
+        const unsigned a = stm & fr, b = scm & fr;
+        mn[r] = a ? i0 + __builtin_ctz(a) : EX_NONE_HI;
+        mx[r] = a ? i0 + 31 - __builtin_clz(a) : -1;
+        ls[r] = b ? i0 + 31 - __builtin_clz(b) : -1;
     }
-}
-
-__global__ void __launch_bounds__(256)
-k_scan_final(const uint8_t* __restrict__ nf_fwd, const uint8_t* __restrict__ nf_rev, const uint8_t* __restrict__ dig,
-             int64_t total, const int2* __restrict__ tile_sum, int32_t* __restrict__ pre_nodes, int32_t* __restrict__ pre_gc,
-             int write_gc) {
-    __shared__ int2 s_w[4];
-    int cn[8], cg[8];
-    const int64_t start = (int64_t)blockIdx.x * SCAN_TILE + threadIdx.x * 8;
-    tile_counts(nf_fwd, nf_rev, dig, start, total, cn, cg);
-    int a = 0, b = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) { a += cn[k]; b += cg[k]; }
-    // inclusive scan of the per-thread sums across the wave, then across the 4 waves
-    int ia = a, ib = b;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // scans over the 256 threads in strand-local order (FWD: rising t): within the wavefront by shuffles, across the four
+    // wavefronts through LDS.  mn: inclusive min towards larger positions; mx, ls: inclusive max towards smaller positions.
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        const int ta = __shfl_up(ia, off, 64), tb = __shfl_up(ib, off, 64);
-        if (lane >= off) { ia += ta; ib += tb; }
-    }
-    if (lane == 63) s_w[w] = make_int2(ia, ib);
-    __syncthreads();
-    int ca = tile_sum[blockIdx.x].x, cb = tile_sum[blockIdx.x].y;
-    for (int k = 0; k < w; k++) { ca += s_w[k].x; cb += s_w[k].y; }
-    int ra = ca + ia - a, rb = cb + ib - b;     // exclusive prefix at this thread's first position
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int64_t g = start + k;
-        if (g <= total) { pre_nodes[g] = ra; if (write_gc) pre_gc[g] = rb; }
-        ra += cn[k]; rb += cg[k];
+        for (int r = 0; r < 3; r++) {
+            const int a = FWD ? __shfl_down(mn[r], off, 64) : __shfl_up(mn[r], off, 64);
+            const int b = FWD ? __shfl_up(mx[r], off, 64) : __shfl_down(mx[r], off, 64);
+            const int e = FWD ? __shfl_up(ls[r], off, 64) : __shfl_down(ls[r], off, 64);
+            const bool has_up = FWD ? lane + off < 64 : lane >= off, has_dn = FWD ? lane >= off : lane + off < 64;
+            if (has_up) mn[r] = min(mn[r], a);
+            if (has_dn) { mx[r] = max(mx[r], b); ls[r] = max(ls[r], e); }
+        }
+    }
+    if (lane == (FWD ? 0 : 63)) { for (int r = 0; r < 3; r++) S.wmin[r][w] = mn[r]; }
+    if (lane == (FWD ? 63 : 0)) { for (int r = 0; r < 3; r++) { S.wmax[r][w] = mx[r]; S.wlsc[r][w] = ls[r]; } }
+    S.scm[t] = (int)scm;
+    __syncthreads();
+    int nxt[3], prv[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        // exclusive: the neighbour's inclusive value, then the wavefronts beyond it, then the tile carry
+        int a = FWD ? __shfl_down(mn[r], 1, 64) : __shfl_up(mn[r], 1, 64);
+        if (FWD ? lane == 63 : lane == 0) a = EX_NONE_HI;
+        int b = FWD ? __shfl_up(mx[r], 1, 64) : __shfl_down(mx[r], 1, 64);
+        if (FWD ? lane == 0 : lane == 63) b = -1;
+        int e = ls[r];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool up_side = FWD ? k > w : k < w, dn_side = FWD ? k < w : k > w;
+            if (up_side) a = min(a, S.wmin[r][k]);
+            if (dn_side) { b = max(b, S.wmax[r][k]); e = max(e, S.wlsc[r][k]); }
+        }
+        const int f = (f0 + r) % 3;
+        nxt[r] = a == EX_NONE_HI ? S.carry_ns[f] : a;
+        prv[r] = b == -1 ? S.carry_ps[f] : b;
+        S.lsc[r][t] = e;
+    }
+    __syncthreads();
+    // region masks (ref: lib.pyx:1959-1966, 2053-2061).  The reference keeps one mask pointer per frame that follows the ORF's
+    // stop and tests that single mask: forward, the last mask beginning at or before the stop; reverse, the first mask ending
+    // at or after the stop's forward coordinate.  Either way a start at i of the ORF ending at `last` is masked iff i < bound.
+    auto mask_bound = [&](const int last) -> int {
+        if (n_masks <= 0) return INT_MIN;
+        if (FWD) {
+            int a = 0, b = n_masks;                 // first mask with begin > last
+            while (a < b) { const int m = (a + b) >> 1; if (mv[m].x <= last) a = m + 1; else b = m; }
+            if (a > 0) { const int2 m = mv[a - 1]; if (m.x < last) return m.y; }
+        } else {
+            const int x = L - last - 1;
+            int a = 0, b = n_masks;                 // first mask with end >= x
+            while (a < b) { const int m = (a + b) >> 1; if (mv[m].y < x) a = m + 1; else b = m; }
+            if (a < n_masks) { const int2 m = mv[a]; if (x < m.y) return L - 1 - m.x; }
+        }
+        return INT_MIN;
+    };
+    // the last start codon of relative frame r (absolute f) at or before x, not looking below `lower`; -1: none
+    auto last_start_codon = [&](const int r, const int f, const int x, const int lower) -> int {
+        int y;                                      // where the codon-by-codon walk to the left starts
+        if (x >= lo) {
+            const int tx = FWD ? (x - top) / EX_PER_THREAD : (top + EX_PER_THREAD - 1 - x) / EX_PER_THREAD;
+            const int i0x = FWD ? top + tx * EX_PER_THREAD : top - tx * EX_PER_THREAD;
+            const unsigned m = (unsigned)S.scm[tx] & ((2u << (x - i0x)) - 1u) & (0x249u << r);
+            if (m) return i0x + 31 - __builtin_clz(m);
+            const int nb = FWD ? tx - 1 : tx + 1;   // the thread before in strand-local order
+            const int v = (nb >= 0 && nb < 256) ? S.lsc[r][nb] : -1;
+            if (v >= 0) return v;
+            y = lo - 1 - ((lo - 1 - f) % 3 + 3) % 3;
+        } else y = x - ((x - f) % 3 + 3) % 3;
+        for (int i = y; i >= lower && i >= 0; i -= 3)
+            if (codon_is_start(sbase(d, L, i, STRAND), sbase(d, L, i + 1, STRAND), sbase(d, L, i + 2, STRAND), P.tt)) return i;
+        return -1;
+    };
+    // does the ORF of frame f that ends at `last` (previous stop `left`) hold a start node?
+    auto orf_has_start = [&](const int r, const int f, const int last, const int left, const bool real) -> bool {
+        const int mb = mask_bound(last);
+        const int lower = max(left + 1, mb);
+        const int mind = real ? P.min_gene : P.min_edge_gene;
+        const int x = min(last + 3 - mind, last - 3);
+        if (x >= lower && last_start_codon(r, f, x, lower) >= lower) return true;
+        // the edge start of an open contig (i = f <= 2)
+        return !P.closed && left < 0 && f < last && last - f > P.min_edge_gene && f >= mb;
+    };
+    auto put = [&](const int q, const int info, const int sv) {
+        const int k = FWD ? q : EX_PER_THREAD - 1 - q;
+        nodes |= 1u << k;
+        infos |= (unsigned long long)info << (4 * k);
+        S.sv[s][k][t] = sv;
+    };
+    // candidates: stop codons, start codons, the first position of each frame (edge starts) and the last (virtual stops)
+    unsigned cand = stm | scm;
+    if (!P.closed) {
+        if (i0 <= 2 && i0 + EX_PER_THREAD > 0) cand |= (i0 >= 0 ? 7u >> i0 : 7u << -i0) & inm;        // i <= 2
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const int f = (f0 + r) % 3;
+            const int q = (L - 3 - ((L - 3 - f) % 3)) - i0;
+            if (q >= 0 && q < EX_PER_THREAD) cand |= (1u << q) & inm;
+        }
+    }
+    while (cand) {
+        const int q = __builtin_ctz(cand);
+        cand &= cand - 1u;
+        const int i = i0 + q;
+        const int r = q % 3, f = (f0 + r) % 3;
+        const unsigned fr = 0x249u << r;
+        const bool is_stop = (stm >> q) & 1u;
+        // the stop to the right: among the thread's own positions, else from the scan
+        const unsigned above = stm & fr & ~((2u << q) - 1u);
+        const unsigned below = stm & fr & ((1u << q) - 1u);
+        const int left = below ? i0 + 31 - __builtin_clz(below) : (r == 0 ? prv[0] : (r == 1 ? prv[1] : prv[2]));
+        const int sv_stop = FWD ? (left >= 0 ? left : f - 6) : (left >= 0 ? L - 1 - left : L - f + 5);
+        if (is_stop) {
+            if (orf_has_start(r, f, i, left, true)) put(q, PGA_T_STOP, sv_stop);
+            continue;
+        }
+        int last = above ? i0 + __builtin_ctz(above) : (r == 0 ? nxt[0] : (r == 1 ? nxt[1] : nxt[2]));
+        const bool real = last != EX_NONE_HI;
+        if (!real) {
+            if (P.closed) continue;                     // closed ends: nothing runs off the right edge
+            last = L - 3 - ((L - 3 - f) % 3);           // virtual right end: last full codon position of the frame
+            if (last < i) continue;
+            if (last == i) {                            // the virtual stop node itself
+                if (orf_has_start(r, f, i, left, false)) put(q, PGA_T_STOP | (1 << 2), sv_stop);
+                continue;
+            }
+        }
+        if (n_masks > 0 && i < mask_bound(last)) continue;
+        const int mind = real ? P.min_gene : P.min_edge_gene;
+        int type = -1, edge = 0;
+        const int c0 = (int)((cw >> (2 * q)) & 3u);
+        if (last - i + 3 >= mind && ((scm >> q) & 1u)) type = c0 == NA ? 0 : (c0 == NT ? 2 : 1);
+        else if (i <= 2 && !P.closed && last - i > P.min_edge_gene) { type = 0; edge = 1; }
+        if (type < 0) continue;
+        put(q, type | (edge << 2), FWD ? last : L - 1 - last);
     }
 }
 
-// ------------------------------------------------------------------------- compaction
-// Writes the topology arrays in (ndx, strand) order; forward sorts before reverse at equal ndx
-// (Prodigal compare_nodes; ref: lib.pyx:2489-2493).
 __global__ void __launch_bounds__(256)
-k_compact_nodes(int64_t total, const ContigDesc* __restrict__ ct, int n_contigs, GroupArrays ga) {
-    __shared__ int s_c0;
-    const int64_t blk0 = (int64_t)blockIdx.x * blockDim.x;
-    const int64_t g = blk0 + threadIdx.x;
-    const int c = block_contig(ct, n_contigs, blk0, g < total ? g : blk0, &s_c0);
-    if (g >= total) return;
-    const int f = ga.nf_fwd[g], r = ga.nf_rev[g];
-    if (!(f | r)) return;
-    const int pos = (int)(g - ct[c].base);
-    const int idx = ga.pre_nodes[g];
-    if (f) {
-        const int info = ga.tinfo_fwd[g];
-        ga.ndx[idx] = pos; ga.stop_val[idx] = ga.tsv_fwd[g]; ga.type[idx] = info & 3; ga.strand[idx] = 1; ga.edge0[idx] = (info >> 2) & 1;
+k_extract_tile(const uint8_t* __restrict__ dig, int64_t total, const ContigDesc* __restrict__ ct, const TileDesc* __restrict__ tiles, int n_tiles,
+               const int32_t* __restrict__ tile_first, const int32_t* __restrict__ tile_last, ExParams P, GroupArrays ga, MaskList masks,
+               const uint8_t* __restrict__ enabled, int32_t* __restrict__ tile_count) {
+    __shared__ ExShared S;
+    const int tile = blockIdx.x, t = threadIdx.x;
+    const TileDesc td = tiles[tile];
+    if (enabled != nullptr && !enabled[td.contig]) { if (t == 0) tile_count[tile] = 0; return; }     // the contig keeps zero nodes in this group
+    const ContigDesc cd = ct[td.contig];
+    const TileGeom G = tile_geom(td, cd.len);
+    const uint8_t* __restrict__ d = dig + cd.base;
+    const int n_masks = masks.off ? masks.off[td.contig + 1] - masks.off[td.contig] : 0;
+    const int2* __restrict__ mv = masks.off ? masks.iv + masks.off[td.contig] : nullptr;
+    unsigned nf, nr; unsigned long long inf_f, inf_r;
+    extract_strand<1>(S, G, d, cd.base, total, tile, tiles, n_tiles, tile_first, tile_last, P, n_masks, mv, nf, inf_f);
+    __syncthreads();
+    extract_strand<-1>(S, G, d, cd.base, total, tile, tiles, n_tiles, tile_first, tile_last, P, n_masks, mv, nr, inf_r);
+    // pack: nodes in (position, strand) order -- forward sorts before reverse at equal ndx (Prodigal compare_nodes;
+    // ref: lib.pyx:2489-2493) -- into the tile's staging slots; the per-position flags of the ORF walks
+    const int r0 = t * EX_PER_THREAD;
+    const int cnt = __popc(nf) + __popc(nr);
+    int inc = cnt;
+    const int lane = t & 63, w = t >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off, 64); if (lane >= off) inc += v; }
+    if (lane == 63) S.wsum[w] = inc;
+    __syncthreads();
+    int nbase = inc - cnt;
+    for (int k = 0; k < w; k++) nbase += S.wsum[k];
+    if (t == 255) tile_count[tile] = nbase + cnt;
+    const int64_t g0 = cd.base + G.a;
+    if (r0 < G.len) {
+        // the flags of the thread's twelve positions, bytewise up to the next 4-byte boundary, then as words
+        const int nk = min(EX_PER_THREAD, G.len - r0);
+        for (int k = 0; k < nk; k++) { ga.nf_fwd[g0 + r0 + k] = (nf >> k) & 1u; ga.nf_rev[g0 + r0 + k] = (nr >> k) & 1u; }
     }
-    if (r) {
-        const int info = ga.tinfo_rev[g], k = idx + f;
-        ga.ndx[k] = pos; ga.stop_val[k] = ga.tsv_rev[g]; ga.type[k] = info & 3; ga.strand[k] = -1; ga.edge0[k] = (info >> 2) & 1;
+    int64_t slot = 2 * g0 + nbase;
+    unsigned both = nf | nr;
+    while (both) {
+        const int k = __builtin_ctz(both);
+        both &= both - 1u;
+        if ((nf >> k) & 1u) { ga.st_ndx[slot] = G.a + r0 + k; ga.st_sv[slot] = S.sv[0][k][t]; ga.st_info[slot] = (uint8_t)((inf_f >> (4 * k)) & 7); slot++; }
+        if ((nr >> k) & 1u) { ga.st_ndx[slot] = G.a + r0 + k; ga.st_sv[slot] = S.sv[1][k][t]; ga.st_info[slot] = (uint8_t)(((inf_r >> (4 * k)) & 7) | 8); slot++; }
     }
+}
+
+// Exclusive scan of n counts into n + 1 offsets, one workgroup: 8 elements per thread and round.
+__global__ void __launch_bounds__(1024)
+k_scan_counts(const int32_t* __restrict__ cnt, int n, int32_t* __restrict__ off) {
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 8192) {
+        const int i0 = base + t * 8;
+        int v[8], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { v[k] = i0 + k < n ? cnt[i0 + k] : 0; sum += v[k]; }
+        int inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(inc, o, 64); if (lane >= o) inc += x; }
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        int run = s_carry + inc - sum;
+        for (int k = 0; k < w; k++) run += s_w[k];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { if (i0 + k < n) off[i0 + k] = run; run += v[k]; }
+        __syncthreads();
+        if (t == 1023) s_carry = run;
+        __syncthreads();
+    }
+    if (t == 0) off[n] = s_carry;
+}
+
+// first node of every contig (n_contigs + 1 entries) from the tile offsets
+__global__ void k_contig_node_base(const int32_t* __restrict__ tile0, int n_contigs, const int32_t* __restrict__ tile_off, int32_t* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c <= n_contigs) out[c] = tile_off[tile0[c]];
+}
+
+// ------------------------------------------------------------------------- placement
+// The staged nodes of every tile go to their final index; the position of a node learns the index of its first node
+// (the ORF walks of the coding score turn positions into node indices through it).
+__global__ void __launch_bounds__(128)
+k_place_nodes(const ContigDesc* __restrict__ ct, const TileDesc* __restrict__ tiles, const int32_t* __restrict__ tile_off, GroupArrays ga) {
+    const TileDesc td = tiles[blockIdx.x];
+    const int off = tile_off[blockIdx.x], cnt = tile_off[blockIdx.x + 1] - off;
+    if (cnt <= 0) return;
+    const int64_t base = ct[td.contig].base;
+    const int64_t s0 = 2 * (base + td.start);
+    for (int j = threadIdx.x; j < cnt; j += blockDim.x) {
+        const int ndx = ga.st_ndx[s0 + j], info = ga.st_info[s0 + j], k = off + j;
+        ga.ndx[k] = ndx; ga.stop_val[k] = ga.st_sv[s0 + j]; ga.type[k] = info & 3; ga.strand[k] = (info >> 3) & 1 ? -1 : 1; ga.edge0[k] = (info >> 2) & 1;
+        if (j == 0 || ga.st_ndx[s0 + j - 1] != ndx) ga.pre_nodes[base + ndx] = k;
+    }
+}
+
+// ------------------------------------------------------------------------- GC prefix
+// Count of GC-or-unknown bases before every 16th position of the batch (k_orf_gc adds the bases of the last, partial group
+// itself): per 4096-position block a sum, a scan of the sums, the prefix per group of 16.
+__device__ __forceinline__ int gcn16(const uint4 v, const int nbytes /* leading bytes that count, 0 .. 16 */) {
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    int n = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        // a digit is G, C or unknown (1, 2, 6) iff its two low bits differ (A 0, T 3)
+        unsigned b = (w[q] ^ (w[q] >> 1)) & 0x01010101u;
+        const int keep = nbytes - 4 * q;
+        if (keep <= 0) b = 0; else if (keep < 4) b &= (1u << (8 * keep)) - 1u;
+        n += __popc(b);
+    }
+    return n;
+}
+__global__ void __launch_bounds__(256)
+k_gcp_blocks(const uint8_t* __restrict__ dig, int64_t total, int32_t* __restrict__ block_sum) {
+    __shared__ int s_w[4];
+    const int64_t g0 = (int64_t)blockIdx.x * 4096 + (int64_t)threadIdx.x * 16;
+    int n = 0;
+    if (g0 < total) n = gcn16(*reinterpret_cast<const uint4*>(dig + g0), (int)min((int64_t)16, total - g0));
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) n += __shfl_xor(n, m, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ void __launch_bounds__(256)
+k_gcp_final(const uint8_t* __restrict__ dig, int64_t total, const int32_t* __restrict__ block_off, int32_t* __restrict__ p16) {
+    __shared__ int s_w[4];
+    const int64_t g0 = (int64_t)blockIdx.x * 4096 + (int64_t)threadIdx.x * 16;
+    int n = 0;
+    if (g0 < total) n = gcn16(*reinterpret_cast<const uint4*>(dig + g0), (int)min((int64_t)16, total - g0));
+    int inc = n;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off, 64); if (lane >= off) inc += v; }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    int run = block_off[blockIdx.x] + inc - n;
+    for (int k = 0; k < w; k++) run += s_w[k];
+    if (g0 <= total) p16[g0 >> 4] = run;
+}
+// GC-or-unknown bases before global position x
+__device__ __forceinline__ int gc_prefix(const uint8_t* __restrict__ dig, const int32_t* __restrict__ p16, const int64_t x) {
+    const int r = (int)(x & 15);
+    int n = p16[x >> 4];
+    if (r) n += gcn16(*reinterpret_cast<const uint4*>(dig + (x - r)), r);
+    return n;
 }
 
 // ------------------------------------------------------------------------- ORF GC content
@@ -464,8 +642,8 @@ k_compact_nodes(int64_t total, const ContigDesc* __restrict__ ct, int n_contigs,
 // the ORF; with a prefix count of GC-or-unknown bases every start reads its count in O(1).
 // The reverse strand keeps the reference's shifted range (codons counted at j..j+2).
 __global__ void __launch_bounds__(256)
-k_orf_gc(const ContigDesc* __restrict__ ct, int n_contigs, const int32_t* __restrict__ pre_gc, GroupArrays ga, int n_nodes_total,
-         const int32_t* __restrict__ node_contig_base /* per contig: first node idx */) {
+k_orf_gc(const ContigDesc* __restrict__ ct, int n_contigs, const uint8_t* __restrict__ dig, const int32_t* __restrict__ p16, GroupArrays ga,
+         int n_nodes_total, const int32_t* __restrict__ node_contig_base /* per contig: first node idx */) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes_total) return;
     if (ga.type[i] == PGA_T_STOP) { ga.gc_cont[i] = 0.f; return; }
@@ -473,14 +651,15 @@ k_orf_gc(const ContigDesc* __restrict__ ct, int n_contigs, const int32_t* __rest
     int lo = 0, hi = n_contigs - 1;
     while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (node_contig_base[mid] <= i) lo = mid; else hi = mid - 1; }
     const int L = ct[lo].len;
-    const int32_t* __restrict__ P = pre_gc + ct[lo].base;
+    const int64_t base = ct[lo].base;
+    auto P = [&](const int x) { return gc_prefix(dig, p16, base + x); };
     const int ndx = ga.ndx[i], sv = ga.stop_val[i];
     int cnt;
     if (ga.strand[i] == 1) {
-        cnt = P[sv + 3] - P[ndx];
+        cnt = P(sv + 3) - P(ndx);
     } else {
         const int hi2 = min(ndx + 2, L - 1);
-        cnt = (P[sv + 1] - P[sv - 2]) + (hi2 >= sv + 3 ? P[hi2 + 1] - P[sv + 3] : 0);
+        cnt = (P(sv + 1) - P(sv - 2)) + (hi2 >= sv + 3 ? P(hi2 + 1) - P(sv + 3) : 0);
     }
     const double gsize = abs(sv - ndx) + 3.0;
     ga.gc_cont[i] = (float)((double)cnt / gsize);
@@ -933,19 +1112,6 @@ struct UpWin {
     __device__ __forceinline__ int code(int u) const { return (int)(((u < 32 ? p0 : p1) >> (2 * (u & 31))) & 3ull); }
 };
 
-// 2-bit codes of four digit bytes, byte t at bits 2t (comp: the reverse strand reads the complement; an unknown base stays 2)
-__device__ __forceinline__ unsigned pack4(const unsigned w, const bool comp) {
-    unsigned c = w & 0x03030303u;
-    if (comp) { const unsigned nm = (w >> 2) & 0x01010101u; c = (c ^ 0x03030303u) ^ (nm | (nm << 1)); }
-    return (c | (c >> 6) | (c >> 12) | (c >> 18)) & 0xffu;
-}
-__device__ __forceinline__ unsigned long long pack16(const uint4 v, const bool comp) {      // byte t at bits 2t, 32 bits
-    return (unsigned long long)(pack4(v.x, comp) | (pack4(v.y, comp) << 8) | (pack4(v.z, comp) << 16) | (pack4(v.w, comp) << 24));
-}
-__device__ __forceinline__ unsigned long long pairrev64(unsigned long long x) {              // pair t -> pair 31 - t
-    x = __brevll(x);
-    return ((x & 0x5555555555555555ull) << 1) | ((x >> 1) & 0x5555555555555555ull);
-}
 __device__ __forceinline__ unsigned even_bits(unsigned long long x) {                        // bit 2u of x -> bit u
     x &= 0x5555555555555555ull;
     x = (x | (x >> 1)) & 0x3333333333333333ull;
@@ -1325,7 +1491,7 @@ k_overlapping_starts(const ChainDesc* __restrict__ chains, int n_chains, int64_t
 // ------------------------------------------------------------------------------ launchers
 static inline unsigned nblocks(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
 
-int64_t pga_scan_tiles(int64_t total) { return (total + 1 + SCAN_TILE - 1) / SCAN_TILE; }
+int64_t pga_gc_blocks(int64_t total) { return (total + 1 + 4095) / 4096; }
 
 void pga_launch_digitize(const char* d_seq, uint8_t* d_dig, int64_t total, const ContigDesc* d_ct, int n_contigs,
                          int32_t* d_gc, int32_t* d_unk, hipStream_t st) {
@@ -1382,21 +1548,36 @@ void pga_launch_find_masks(const uint8_t* d_dig, const ContigDesc* d_ct, int n_c
                        d_runs, d_count, cap);
 }
 
-void pga_launch_extract(const uint8_t* d_dig, int64_t total, const ContigDesc* d_ct, int n_contigs, int tt,
-                        const pga_params& p, const GroupArrays& ga, int2* d_tile_sum, int32_t* d_pre_gc, int write_gc,
-                        const TileDesc* d_tiles, int n_tiles, int32_t* d_tile_first, int32_t* d_tile_last, MaskList masks, hipStream_t st,
-                        const uint8_t* d_enabled) {
+void pga_launch_gc_prefix(const uint8_t* d_dig, int64_t total, int32_t* d_block_sum, int32_t* d_block_off, int32_t* d_p16, hipStream_t st) {
     if (total <= 0) return;
+    const int nb = (int)pga_gc_blocks(total);
+    hipLaunchKernelGGL(k_gcp_blocks, dim3(nb), dim3(256), 0, st, d_dig, total, d_block_sum);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, d_block_sum, nb, d_block_off);
+    hipLaunchKernelGGL(k_gcp_final, dim3(nb), dim3(256), 0, st, d_dig, total, d_block_off, d_p16);
+}
+
+void pga_launch_extract(const uint8_t* d_dig, int64_t total, const ContigDesc* d_ct, int n_contigs, int tt,
+                        const pga_params& p, const GroupArrays& ga, const TileDesc* d_tiles, int n_tiles, const int32_t* d_tile0,
+                        int32_t* d_tile_first, int32_t* d_tile_last, int32_t* d_tile_count, int32_t* d_tile_off, int32_t* d_cbase,
+                        MaskList masks, hipStream_t st, const uint8_t* d_enabled) {
     if (n_tiles > 0) {
-        hipLaunchKernelGGL(k_tile_stops, dim3(n_tiles, 2), dim3(256), 0, st, d_dig, d_ct, d_tiles, n_tiles, tt, d_tile_first, d_tile_last, d_enabled);
-        hipLaunchKernelGGL(k_extract_scan, dim3(n_tiles, 2), dim3(256), 0, st, d_dig, d_ct, d_tiles, n_tiles, d_tile_first, d_tile_last, tt,
-                           p.closed, p.min_gene, p.min_edge_gene, ga, masks, d_enabled);
+        hipLaunchKernelGGL(k_tile_stops, dim3(n_tiles), dim3(256), 0, st, d_dig, d_ct, d_tiles, n_tiles, tt, d_tile_first, d_tile_last, d_enabled);
+        ExParams P{tt, p.closed, p.min_gene, p.min_edge_gene, 0ull, 0ull};
+        for (int idx = 0; idx < 64; idx++) {
+            const int b0 = idx & 3, b1 = (idx >> 2) & 3, b2 = (idx >> 4) & 3;
+            if (codon_is_stop(b0, b1, b2, tt)) P.stop_codons |= 1ull << idx;
+            if (codon_is_start(b0, b1, b2, tt)) P.start_codons |= 1ull << idx;
+        }
+        hipLaunchKernelGGL(k_extract_tile, dim3(n_tiles), dim3(256), 0, st, d_dig, total, d_ct, d_tiles, n_tiles, d_tile_first, d_tile_last, P, ga, masks,
+                           d_enabled, d_tile_count);
     }
-    const int tiles = (int)pga_scan_tiles(total);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(256), 0, st, ga.nf_fwd, ga.nf_rev, d_dig, total, d_tile_sum);
-    hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(1024), 0, st, d_tile_sum, tiles);
-    hipLaunchKernelGGL(k_scan_final, dim3(tiles), dim3(256), 0, st, ga.nf_fwd, ga.nf_rev, d_dig, total, d_tile_sum,
-                       ga.pre_nodes, d_pre_gc, write_gc);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, d_tile_count, n_tiles, d_tile_off);
+    hipLaunchKernelGGL(k_contig_node_base, dim3((n_contigs + 1 + 255) / 256), dim3(256), 0, st, d_tile0, n_contigs, d_tile_off, d_cbase);
+}
+
+void pga_launch_place(const ContigDesc* d_ct, const TileDesc* d_tiles, int n_tiles, const int32_t* d_tile_off, const GroupArrays& ga, hipStream_t st) {
+    if (n_tiles <= 0) return;
+    hipLaunchKernelGGL(k_place_nodes, dim3(n_tiles), dim3(128), 0, st, d_ct, d_tiles, d_tile_off, ga);
 }
 
 int pga_extract_tile_size() { return EX_TILE; }
@@ -1456,15 +1637,11 @@ void pga_launch_group_enable(const ContigDesc* d_ct, int n_contigs, const int32_
 }
 
 
-void pga_launch_compact(int64_t total, const ContigDesc* d_ct, int n_contigs, const GroupArrays& ga, hipStream_t st) {
-    if (total <= 0) return;
-    hipLaunchKernelGGL(k_compact_nodes, dim3(nblocks(total, 256)), dim3(256), 0, st, total, d_ct, n_contigs, ga);
-}
 
-void pga_launch_orf_gc(const ContigDesc* d_ct, int n_contigs, const int32_t* d_pre_gc, const GroupArrays& ga,
+void pga_launch_orf_gc(const ContigDesc* d_ct, int n_contigs, const uint8_t* d_dig, const int32_t* d_p16, const GroupArrays& ga,
                        int n_nodes_total, const int32_t* d_node_contig_base, hipStream_t st) {
     if (n_nodes_total <= 0) return;
-    hipLaunchKernelGGL(k_orf_gc, dim3(nblocks(n_nodes_total, 256)), dim3(256), 0, st, d_ct, n_contigs, d_pre_gc, ga,
+    hipLaunchKernelGGL(k_orf_gc, dim3(nblocks(n_nodes_total, 256)), dim3(256), 0, st, d_ct, n_contigs, d_dig, d_p16, ga,
                        n_nodes_total, d_node_contig_base);
 }
 

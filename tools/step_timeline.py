@@ -8,7 +8,7 @@ s = idx[-1]; t0 = rows[s][1]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 busy = 0
 for r in rows[s:s + n]:
-    name = r[0].split('(')[0].split('::')[-1]
+    name = r[0].replace('(anonymous namespace)::', '').split('(')[0]
     d = (r[2] - r[1]) / 1e3; busy += d
     if d >= 50:
         print(f"{(r[1]-t0)/1e3:9.1f} {d:8.1f} {name[:34]:34s} grid={r[3]} wg={r[4]} vgpr={r[5]} lds={r[6]}")
