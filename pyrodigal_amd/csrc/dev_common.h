@@ -27,3 +27,14 @@ __device__ __forceinline__ int find_chain(const ChainDesc* __restrict__ chains, 
     }
     return lo;
 }
+
+// The same for every thread of a workgroup whose first element is block_first: one binary search per workgroup (thread 0), then
+// a short forward walk per thread (a workgroup rarely spans more than two chains) -- a search per thread is sixteen dependent
+// loads that nothing hides.  Every thread of the workgroup must call it (barrier inside).
+__device__ __forceinline__ int find_chain_block(const ChainDesc* __restrict__ chains, int n_chains, int64_t block_first, int64_t g, int* s_slot) {
+    if (threadIdx.x == 0) *s_slot = find_chain(chains, n_chains, block_first);
+    __syncthreads();
+    int c = *s_slot;
+    while (c + 1 < n_chains && chains[c + 1].off <= g) c++;
+    return c;
+}

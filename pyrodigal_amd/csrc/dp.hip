@@ -67,10 +67,12 @@ __device__ __forceinline__ double igm_apart(int d, double negc, const double* s_
 __global__ void __launch_bounds__(256)
 k_dp_prepare(const ChainDesc* __restrict__ chains, int n_chains, int64_t node_begin, int64_t total,
              NodeArrays nd, const ModelConst* __restrict__ models, DpSrc* __restrict__ src, DpTgt* __restrict__ tgt, int final) {
-    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= total) return;
-    g += node_begin;
-    const int c = find_chain(chains, n_chains, g);
+    __shared__ int s_c0;
+    const int64_t blk0 = node_begin + (int64_t)blockIdx.x * blockDim.x;
+    const int64_t g = blk0 + threadIdx.x;
+    const bool in_range = g < node_begin + total;
+    const int c = find_chain_block(chains, n_chains, blk0, in_range ? g : blk0, &s_c0);
+    if (!in_range) return;
     const int64_t off = chains[c].off, toff = chains[c].topo_off;
     const int i = (int)(g - off);
     const ModelConst* mc = &models[chains[c].model];

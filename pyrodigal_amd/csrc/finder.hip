@@ -406,11 +406,18 @@ struct OutArrays {
 __global__ void __launch_bounds__(256)
 k_gather_winners(const WinDesc* __restrict__ wd, int n_win, int64_t out_begin, int64_t total, GroupArrays ga, ChainArrays ca,
                  DpBuffers dp, OutArrays o) {
-    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= total) return;
-    g += out_begin;
-    int lo = 0, hi = n_win - 1;
-    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (wd[mid].out_off <= g) lo = mid; else hi = mid - 1; }
+    __shared__ int s_w0;
+    const int64_t blk0 = out_begin + (int64_t)blockIdx.x * blockDim.x;
+    const int64_t g = blk0 + threadIdx.x;
+    if (threadIdx.x == 0) {             // one search per workgroup, then a short walk per thread
+        int lo = 0, hi = n_win - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (wd[mid].out_off <= blk0) lo = mid; else hi = mid - 1; }
+        s_w0 = lo;
+    }
+    __syncthreads();
+    if (g >= out_begin + total) return;
+    int lo = s_w0;
+    while (lo + 1 < n_win && wd[lo + 1].out_off <= g) lo++;
     const WinDesc w = wd[lo];
     const int i = (int)(g - w.out_off);
     const int64_t t = w.topo_off + i, a = w.dp_off + i, f = w.fin_off + i;

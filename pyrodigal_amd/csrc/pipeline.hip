@@ -192,52 +192,7 @@ struct TileGeom {
 };
 __device__ __forceinline__ TileGeom tile_geom(const TileDesc td, const int L) { return TileGeom{L, td.start, min(EX_TILE, L - td.start)}; }
 
-// pass 1: first / last stop position of every tile, per strand and frame
-__global__ void __launch_bounds__(256)
-k_tile_stops(const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct, const TileDesc* __restrict__ tiles, int n_tiles,
-             int tt, int32_t* __restrict__ tile_first, int32_t* __restrict__ tile_last, const uint8_t* __restrict__ enabled) {
-    __shared__ int s_min[2][3][4], s_max[2][3][4];
-    const TileDesc td = tiles[blockIdx.x];
-    if (enabled != nullptr && !enabled[td.contig]) return;       // no model of this translation table is scored on the contig
-    const ContigDesc cd = ct[td.contig];
-    const TileGeom G = tile_geom(td, cd.len);
-    const int L = cd.len;
-    const uint8_t* __restrict__ d = dig + cd.base;
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-        const int strand = s == 0 ? 1 : -1;
-        const int lo = G.lo(strand), i0 = lo + threadIdx.x * EX_PER_THREAD, end = lo + G.len;
-        int mn[3] = {EX_NONE_HI, EX_NONE_HI, EX_NONE_HI}, mx[3] = {-1, -1, -1};
-        if (i0 < end && i0 <= L - 3) {
-            int c[EX_PER_THREAD + 2];
-#pragma unroll
-            for (int q = 0; q < EX_PER_THREAD + 2; q++) c[q] = (i0 + q < L) ? sbase(d, L, i0 + q, strand) : NN;
-#pragma unroll
-            for (int q = 0; q < EX_PER_THREAD; q++) {
-                const int i = i0 + q;
-                if (i < end && i <= L - 3 && codon_is_stop(c[q], c[q + 1], c[q + 2], tt)) {
-                    const int f = i % 3;
-                    mn[f] = min(mn[f], i); mx[f] = max(mx[f], i);
-                }
-            }
-        }
-#pragma unroll
-        for (int f = 0; f < 3; f++) {
-            int a = mn[f], b = mx[f];
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) { a = min(a, __shfl_xor(a, m, 64)); b = max(b, __shfl_xor(b, m, 64)); }
-            if ((threadIdx.x & 63) == 0) { s_min[s][f][threadIdx.x >> 6] = a; s_max[s][f][threadIdx.x >> 6] = b; }
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-        const int s = threadIdx.x / 3, f = threadIdx.x % 3;
-        const int64_t o = ((int64_t)s * n_tiles + blockIdx.x) * 3 + f;
-        tile_first[o] = min(min(s_min[s][f][0], s_min[s][f][1]), min(s_min[s][f][2], s_min[s][f][3]));
-        tile_last[o] = max(max(s_max[s][f][0], s_max[s][f][1]), max(s_max[s][f][2], s_max[s][f][3]));
-    }
-}
-
+// pass 1: first / last stop position of every tile, per strand and frame (k_tile_stops, below the helpers of pass 2)
 // pass 2: every position decides, the tile packs its nodes.
 // A start node is decided at its own position from NS / PS (next / previous in-frame stop).  The stop node of an ORF exists
 // when the ORF holds at least one start node; the thread that owns the stop position decides that from LSC(x) = the last
@@ -266,6 +221,50 @@ __device__ __forceinline__ unsigned pairrev32(unsigned x) {      // pair t -> pa
 __device__ __forceinline__ unsigned unknown4(const unsigned w) {  // bit t: byte t is an unknown base (digit 6, or 5 after the complement)
     const unsigned n = (w >> 2) & 0x01010101u;
     return (n | (n >> 7) | (n >> 14) | (n >> 21)) & 0xfu;
+}
+
+// Thread-level view of one strand: the twelve strand-local positions i0 .. i0 + 11.  inm: the positions that lie in the tile and
+// can start a codon; cw: 2-bit digits of i0 .. i0 + 15 (pair q); stm / scm: stop / start codon at i0 + q (within inm).
+template <int STRAND>
+__device__ __forceinline__ void strand_codon_masks(const TileGeom G, const uint8_t* __restrict__ d, const int64_t base, const int64_t total, const int i0,
+                                                   const unsigned long long stop_codons, const unsigned long long start_codons,
+                                                   unsigned& inm, unsigned& cw, unsigned& stm, unsigned& scm) {
+    constexpr bool FWD = STRAND == 1;
+    const int L = G.L, lo = G.lo(STRAND), end = lo + G.len;
+    // the thread's positions that exist and can start a codon inside the tile: q in [qa, qb]
+    const int qa = max(0, lo - i0), qb = min(EX_PER_THREAD - 1, min(end - 1, L - 3) - i0);
+    inm = qb >= qa ? ((2u << qb) - 1u) & ~((1u << qa) - 1u) : 0u;
+    // 2-bit digits of positions i0 .. i0 + 15 (pair q), unknown or missing bases in `unk` (bit q)
+    cw = 0; unsigned unk = 0xffffu;
+    if (inm) {
+        const int64_t ga0 = FWD ? base + i0 : base + (L - 1 - i0 - 15);     // lowest byte read
+        if (ga0 >= 0 && ga0 <= total) {
+            uint4 v; __builtin_memcpy(&v, (FWD ? d + i0 : d + (L - 1 - i0 - 15)), 16);
+            const unsigned q0 = (unsigned)pack16(v, !FWD);
+            const unsigned n0 = unknown4(v.x) | (unknown4(v.y) << 4) | (unknown4(v.z) << 8) | (unknown4(v.w) << 12);
+            cw = FWD ? q0 : pairrev32(q0);
+            unk = FWD ? n0 : (__brev(n0) >> 16);
+        } else {
+            unk = 0;
+            for (int q = 0; q < 16; q++) {
+                const int i = i0 + q;
+                const int b = (i >= 0 && i < L) ? sbase(d, L, i, STRAND) : NN;
+                if (b > 3) unk |= 1u << q; else cw |= (unsigned)b << (2 * q);
+            }
+        }
+        // positions outside the contig
+        if (i0 < 0) unk |= (1u << min(16, -i0)) - 1u;
+        if (i0 + 16 > L) unk |= ~((1u << max(0, L - i0)) - 1u) & 0xffffu;
+    }
+    stm = 0; scm = 0;
+#pragma unroll
+    for (int q = 0; q < EX_PER_THREAD; q++) {
+        const unsigned idx = (cw >> (2 * q)) & 63u;
+        const unsigned ok = ((unk >> q) & 7u) == 0u ? 1u : 0u;
+        stm |= ((unsigned)(stop_codons >> idx) & ok) << q;
+        scm |= ((unsigned)(start_codons >> idx) & ok) << q;
+    }
+    stm &= inm; scm &= inm;
 }
 
 // The nodes of one strand among the thread's twelve forward positions a + 12 t + k: bit k of `nodes`, type | edge << 2 in the
@@ -306,40 +305,8 @@ __device__ __forceinline__ void extract_strand(ExShared& S, const TileGeom G, co
             S.carry_ps[f] = v;
         }
     }
-    // the thread's positions that exist and can start a codon inside the tile: q in [qa, qb]
-    const int qa = max(0, lo - i0), qb = min(EX_PER_THREAD - 1, min(end - 1, L - 3) - i0);
-    const unsigned inm = qb >= qa ? ((2u << qb) - 1u) & ~((1u << qa) - 1u) : 0u;
-    // 2-bit digits of positions i0 .. i0 + 15 (pair q), unknown or missing bases in `unk` (bit q)
-    unsigned cw = 0, unk = 0xffffu;
-    if (inm) {
-        const int64_t ga0 = FWD ? base + i0 : base + (L - 1 - i0 - 15);     // lowest byte read
-        if (ga0 >= 0 && ga0 <= total) {
-            uint4 v; __builtin_memcpy(&v, (FWD ? d + i0 : d + (L - 1 - i0 - 15)), 16);
-            const unsigned q0 = (unsigned)pack16(v, !FWD);
-            const unsigned n0 = unknown4(v.x) | (unknown4(v.y) << 4) | (unknown4(v.z) << 8) | (unknown4(v.w) << 12);
-            cw = FWD ? q0 : pairrev32(q0);
-            unk = FWD ? n0 : (__brev(n0) >> 16);
-        } else {
-            unk = 0;
-            for (int q = 0; q < 16; q++) {
-                const int i = i0 + q;
-                const int b = (i >= 0 && i < L) ? sbase(d, L, i, STRAND) : NN;
-                if (b > 3) unk |= 1u << q; else cw |= (unsigned)b << (2 * q);
-            }
-        }
-        // positions outside the contig
-        if (i0 < 0) unk |= (1u << min(16, -i0)) - 1u;
-        if (i0 + 16 > L) unk |= ~((1u << max(0, L - i0)) - 1u) & 0xffffu;
-    }
-    unsigned stm = 0, scm = 0;          // stop codon / start codon at i0 + q
-#pragma unroll
-    for (int q = 0; q < EX_PER_THREAD; q++) {
-        const unsigned idx = (cw >> (2 * q)) & 63u;
-        const unsigned ok = ((unk >> q) & 7u) == 0u ? 1u : 0u;
-        stm |= ((unsigned)(P.stop_codons >> idx) & ok) << q;
-        scm |= ((unsigned)(P.start_codons >> idx) & ok) << q;
-    }
-    stm &= inm; scm &= inm;
+    unsigned inm, cw, stm, scm;
+    strand_codon_masks<STRAND>(G, d, base, total, i0, P.stop_codons, P.start_codons, inm, cw, stm, scm);
     int mn[3], mx[3], ls[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
@@ -484,6 +451,44 @@ __device__ __forceinline__ void extract_strand(ExShared& S, const TileGeom G, co
         else if (i <= 2 && !P.closed && last - i > P.min_edge_gene) { type = 0; edge = 1; }
         if (type < 0) continue;
         put(q, type | (edge << 2), FWD ? last : L - 1 - last);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_tile_stops(const uint8_t* __restrict__ dig, int64_t total, const ContigDesc* __restrict__ ct, const TileDesc* __restrict__ tiles, int n_tiles,
+             unsigned long long stop_codons, int32_t* __restrict__ tile_first, int32_t* __restrict__ tile_last, const uint8_t* __restrict__ enabled) {
+    __shared__ int s_min[2][3][4], s_max[2][3][4];
+    const TileDesc td = tiles[blockIdx.x];
+    if (enabled != nullptr && !enabled[td.contig]) return;       // no model of this translation table is scored on the contig
+    const ContigDesc cd = ct[td.contig];
+    const TileGeom G = tile_geom(td, cd.len);
+    const int L = cd.len, t = threadIdx.x;
+    const uint8_t* __restrict__ d = dig + cd.base;
+    int f0s[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        const int top = s == 0 ? G.a : L - 1 - G.a - (EX_PER_THREAD - 1);
+        const int i0 = s == 0 ? top + t * EX_PER_THREAD : top - t * EX_PER_THREAD;
+        f0s[s] = ((top % 3) + 3) % 3;
+        unsigned inm, cw, stm, scm;
+        if (s == 0) strand_codon_masks<1>(G, d, cd.base, total, i0, stop_codons, 0ull, inm, cw, stm, scm);
+        else strand_codon_masks<-1>(G, d, cd.base, total, i0, stop_codons, 0ull, inm, cw, stm, scm);
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const unsigned m = stm & (0x249u << r);
+            int a = m ? i0 + __builtin_ctz(m) : EX_NONE_HI, b = m ? i0 + 31 - __builtin_clz(m) : -1;
+#pragma unroll
+            for (int k = 32; k >= 1; k >>= 1) { a = min(a, __shfl_xor(a, k, 64)); b = max(b, __shfl_xor(b, k, 64)); }
+            if ((t & 63) == 0) { s_min[s][r][t >> 6] = a; s_max[s][r][t >> 6] = b; }
+        }
+    }
+    __syncthreads();
+    if (t < 6) {
+        const int s = t / 3, r = t % 3;
+        const int f = (f0s[s] + r) % 3;                          // relative frame r of the threads is frame f of the strand
+        const int64_t o = ((int64_t)s * n_tiles + blockIdx.x) * 3 + f;
+        tile_first[o] = min(min(s_min[s][r][0], s_min[s][r][1]), min(s_min[s][r][2], s_min[s][r][3]));
+        tile_last[o] = max(max(s_max[s][r][0], s_max[s][r][1]), max(s_max[s][r][2], s_max[s][r][3]));
     }
 }
 
@@ -779,8 +784,13 @@ __device__ __forceinline__ void orf_serial(const OrfCtx& o, const ChainDesc* __r
         // Five codons at a time: their 15 bases and the start flags of those positions are 16 contiguous bytes each, one
         // (unaligned) load per array instead of four byte loads per codon -- every lane walks its own ORF, so each load
         // instruction costs the address path 64 distinct lines whatever its width.
+        struct W16 { unsigned long long a, b; };
+        auto group_lo = [&](const int c0) { return strand == 1 ? p - 3 * (c0 + 5) : p + 3 * c0 + 1; };       // lowest position of the group
+        // the loads of a group are issued one group ahead: a lone walk would otherwise wait out a memory round trip per five codons
+        W16 Bn{0, 0}, Fn{0, 0};
+        if (o.ncod > 1 && group_lo(1) >= 0) { __builtin_memcpy(&Bn, d + group_lo(1), 16); __builtin_memcpy(&Fn, o.nf + group_lo(1), 16); }
         for (int c0 = 1; c0 < o.ncod; c0 += 5) {
-            const int lo = strand == 1 ? p - 3 * (c0 + 5) : p + 3 * c0 + 1;         // lowest position of the group
+            const int lo = group_lo(c0);
             if (lo < 0) {
                 // the group hangs over the contig's first base (only codons beyond the ORF do): byte loads
                 for (int ci = c0; ci < min(c0 + 5, o.ncod); ci++) {
@@ -791,9 +801,11 @@ __device__ __forceinline__ void orf_serial(const OrfCtx& o, const ChainDesc* __r
                 }
                 continue;
             }
-            struct W16 { unsigned long long a, b; } B, F;
-            __builtin_memcpy(&B, d + lo, 16);
-            __builtin_memcpy(&F, o.nf + lo, 16);
+            const W16 B = Bn, F = Fn;
+            if (c0 + 5 < o.ncod) {
+                const int lo1 = group_lo(c0 + 5);
+                if (lo1 >= 0) { __builtin_memcpy(&Bn, d + lo1, 16); __builtin_memcpy(&Fn, o.nf + lo1, 16); }
+            }
             auto bytes_at = [](const W16& w, const int k) {          // the (up to 8) bytes from offset k on, k <= 13
                 return k < 8 ? (w.a >> (8 * k)) | (k ? w.b << (64 - 8 * k) : 0ull) : w.b >> (8 * (k - 8));
             };
@@ -999,7 +1011,8 @@ struct CsTask { int32_t q, first, count, _pad; };      // columns q .. q+3; entr
 struct CsEntry { int32_t contig, m0; };
 constexpr int CS_TASK_THREADS = 1024;
 constexpr int CS_TASK_MAX_ENTRIES = 256;
-constexpr int CS_ROUND = 6144;                         // nodes examined per round of a task
+constexpr int CS_ROUND = 8192;                         // nodes examined per round of a task (= the task size pga_cs_tasks aims at)
+constexpr int CS_LIST = 6144;                          // stop nodes of a round: at most half of its nodes (every ORF with a stop node has a start node) + a few at its edges
 constexpr int CS_CLASSES = 8;                          // ORF length classes of a round
 __global__ void __launch_bounds__(CS_TASK_THREADS)
 k_coding_score_quads(const CsTask* __restrict__ tasks, const CsEntry* __restrict__ entries, const ChainDesc* __restrict__ chains,
@@ -1009,8 +1022,8 @@ k_coding_score_quads(const CsTask* __restrict__ tasks, const CsEntry* __restrict
                      const double* __restrict__ gil, int il_stride, const int32_t* __restrict__ rank) {
     extern __shared__ __attribute__((aligned(16))) double s_quad[];                  // [4096][4]
     __shared__ int s_pre[CS_TASK_MAX_ENTRIES + 1];      // first node (task-local numbering) of every entry
-    __shared__ int s_list[CS_ROUND];
-    __shared__ int s_count;
+    __shared__ int s_list[CS_LIST];
+    __shared__ int s_count, s_next_long, s_next;
     __shared__ int s_cls[CS_CLASSES];
     const CsTask task = tasks[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1055,7 +1068,8 @@ k_coding_score_quads(const CsTask* __restrict__ tasks, const CsEntry* __restrict
         if (tid == 0) {
             int acc = 0;
             for (int k = 0; k < CS_CLASSES; k++) { const int n = s_cls[k]; s_cls[k] = acc; acc += n; }
-            s_count = acc;
+            if (acc > CS_LIST) __builtin_trap();             // cannot happen (see CS_LIST); never write past the list
+            s_count = acc; s_next_long = 0; s_next = s_cls[1];   // s_cls[1] = number of long ORFs = where the others begin
         }
         __syncthreads();
 #pragma unroll
@@ -1083,14 +1097,23 @@ k_coding_score_quads(const CsTask* __restrict__ tasks, const CsEntry* __restrict
             o.ncod = o.cc.y <= 0 ? 0 : orf_codons(o.p, o.q, o.strand, o.L);
             return o;
         };
-        // long ORFs (the first n_long entries): one per wave at a time, dealt round-robin, all 64 lanes on each
-        for (int k = wv; k < n_long; k += CS_TASK_THREADS / 64) {
+        // Waves pull work until the round is empty (no wave waits for another before the end of the round).
+        // long ORFs (the first n_long entries): one per wave at a time, all 64 lanes on each
+        for (;;) {
+            int k = 0;
+            if (lane == 0) k = atomicAdd(&s_next_long, 1);
+            k = __builtin_amdgcn_readfirstlane(k);
+            if (k >= n_long) break;
             int m0;
             const OrfCtx w = orf_of(s_list[k], m0);          // the same entry in every lane
             if (w.ncod > 0) orf_wave(w, lane, chains, models, msc, ca, s_quad, m0, m0 + 4);
         }
-        // the others, 64 of similar length per wave
-        for (int lb = n_long + wv * 64; lb < cnt; lb += CS_TASK_THREADS) {
+        // the others, 64 of similar length per wave, longest class first
+        for (;;) {
+            int lb = 0;
+            if (lane == 0) lb = atomicAdd(&s_next, 64);
+            lb = __builtin_amdgcn_readfirstlane(lb);
+            if (lb >= cnt) break;
             if (lb + lane < cnt) {
                 int m0;
                 const OrfCtx o = orf_of(s_list[lb + lane], m0);
@@ -1371,7 +1394,7 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
                 double bsc = -100.0; int bsp = 0, bsi = 0, blen = 0, bndx = 0;
                 // the motif of k + 3 bases whose first base sits u0 upstream (the reference's j = start - u0, ascending j):
                 // every shift and spacer class below is a constant of the unrolled body
-#pragma unroll 1
+#pragma unroll 2
                 for (int k = 3; k >= 0; k--) {
 #pragma unroll
                     for (int t = 0; t < 13; t++) {
@@ -1561,13 +1584,13 @@ void pga_launch_extract(const uint8_t* d_dig, int64_t total, const ContigDesc* d
                         int32_t* d_tile_first, int32_t* d_tile_last, int32_t* d_tile_count, int32_t* d_tile_off, int32_t* d_cbase,
                         MaskList masks, hipStream_t st, const uint8_t* d_enabled) {
     if (n_tiles > 0) {
-        hipLaunchKernelGGL(k_tile_stops, dim3(n_tiles), dim3(256), 0, st, d_dig, d_ct, d_tiles, n_tiles, tt, d_tile_first, d_tile_last, d_enabled);
         ExParams P{tt, p.closed, p.min_gene, p.min_edge_gene, 0ull, 0ull};
         for (int idx = 0; idx < 64; idx++) {
             const int b0 = idx & 3, b1 = (idx >> 2) & 3, b2 = (idx >> 4) & 3;
             if (codon_is_stop(b0, b1, b2, tt)) P.stop_codons |= 1ull << idx;
             if (codon_is_start(b0, b1, b2, tt)) P.start_codons |= 1ull << idx;
         }
+        hipLaunchKernelGGL(k_tile_stops, dim3(n_tiles), dim3(256), 0, st, d_dig, total, d_ct, d_tiles, n_tiles, P.stop_codons, d_tile_first, d_tile_last, d_enabled);
         hipLaunchKernelGGL(k_extract_tile, dim3(n_tiles), dim3(256), 0, st, d_dig, total, d_ct, d_tiles, n_tiles, d_tile_first, d_tile_last, P, ga, masks,
                            d_enabled, d_tile_count);
     }
@@ -1603,12 +1626,14 @@ bool pga_cs_tasks(const int2* h_cc /* per contig: first chain, count */, int n_c
         const std::vector<int32_t>& b = bucket[(size_t)q];
         int first = (int)(entries.size() / 2), count = 0, nodes = 0;
         for (size_t k = 0; k < b.size(); k += 2) {
-            entries.push_back(b[k]); entries.push_back(b[k + 1]);
-            count++; nodes += h_cbase[b[k] + 1] - h_cbase[b[k]];
-            if (nodes >= task_nodes || count == CS_TASK_MAX_ENTRIES) {
+            const int nc = h_cbase[b[k] + 1] - h_cbase[b[k]];
+            // a task is one round of the kernel (task_nodes nodes) unless a single contig is larger
+            if (count > 0 && (nodes + nc > task_nodes || count == CS_TASK_MAX_ENTRIES)) {
                 tasks.push_back(q); tasks.push_back(first); tasks.push_back(count); tasks.push_back(0);
                 first += count; count = 0; nodes = 0;
             }
+            entries.push_back(b[k]); entries.push_back(b[k + 1]);
+            count++; nodes += nc;
         }
         if (count > 0) { tasks.push_back(q); tasks.push_back(first); tasks.push_back(count); tasks.push_back(0); }
     }
