@@ -1486,24 +1486,59 @@ k_overlapping_starts(const ChainDesc* __restrict__ chains, int n_chains, int64_t
         const double* __restrict__ rs = ca.rscore + ch.off; const double* __restrict__ us = ca.uscore + ch.off;
         const int my = ndx[i];
         double best = -100;
-        if (str[i] == 1) {
-            for (int j = i + 3; j >= 0; j--) {
-                if (j >= n || ndx[j] > my + 2) continue;
-                if (ndx[j] + maxov < my) break;
-                if (str[j] != 1 || typ[j] == PGA_T_STOP) continue;
-                if (stv[j] <= my) continue;
-                const double v = cs[j] + ss[j] + igm_same_dev(my, 1, rs[i], us[i], ndx[j], rs[j], us[j], mc->st_wt, mc->igm);
-                if (v > best) { const int f = ndx[j] % 3; if (f == 0) sp0 = j; else if (f == 1) sp1 = j; else sp2 = j; best = v; }
+        const bool fwd = str[i] == 1;
+        const double rs_i = rs[i], us_i = us[i];
+        // The reference walks the neighbours one by one (forward stop: j = i + 3 downwards; reverse stop: j = i - 3 upwards) until
+        // it leaves the overlap window.  Which neighbours count is decided by positions, strands and types alone: the first
+        // OV_SPEC of them are read at once (one memory round trip instead of one or two per neighbour), then only the ones
+        // that count are priced, in the reference's order.
+        constexpr int OV_SPEC = 16;
+        bool ended = false;
+        unsigned elig = 0;
+#pragma unroll
+        for (int k = 0; k < OV_SPEC; k++) {
+            const int j = fwd ? i + 3 - k : i - 3 + k;
+            const int jj = min(max(j, 0), n - 1);
+            const int nd = ndx[jj], sv = stv[jj], ty = typ[jj], sd = str[jj];       // unconditional: every load of the loop can be in flight at once
+            bool stop_here, ok;
+            if (fwd) {
+                stop_here = j < 0 || (j < n && nd <= my + 2 && nd + maxov < my);
+                ok = j >= 0 && j < n && nd <= my + 2 && sd == 1 && ty != PGA_T_STOP && sv > my;
+            } else {
+                stop_here = j >= n || (j >= 0 && nd >= my - 2 && nd - maxov > my);
+                ok = j >= 0 && j < n && nd >= my - 2 && sd == -1 && ty != PGA_T_STOP && sv < my;
             }
-        } else {
-            for (int j = i - 3; j < n; j++) {
-                if (j < 0 || ndx[j] < my - 2) continue;
-                if (ndx[j] - maxov > my) break;
-                if (str[j] != -1 || typ[j] == PGA_T_STOP) continue;
-                if (stv[j] >= my) continue;
-                const double v = cs[j] + ss[j] + igm_same_dev(ndx[j], -1, rs[j], us[j], my, rs[i], us[i], mc->st_wt, mc->igm);
-                if (v > best) { const int f = ndx[j] % 3; if (f == 0) sp0 = j; else if (f == 1) sp1 = j; else sp2 = j; best = v; }
+            ended = ended || stop_here;
+            if (ok && !ended) elig |= 1u << k;
+        }
+        int js = fwd ? i + 3 - OV_SPEC : i - 3 + OV_SPEC;        // where the one-by-one walk goes on if the window is not done by then
+        bool more = !ended;
+        for (;;) {
+            int j = -1;
+            if (elig) {
+                const int k = __builtin_ctz(elig);
+                elig &= elig - 1u;
+                j = fwd ? i + 3 - k : i - 3 + k;
+            } else {
+                while (more) {
+                    if (fwd ? js < 0 : js >= n) { more = false; break; }
+                    const int jq = js;
+                    js += fwd ? -1 : 1;
+                    if (jq < 0 || jq >= n) continue;
+                    const int nq = ndx[jq];
+                    if (fwd ? nq > my + 2 : nq < my - 2) continue;
+                    if (fwd ? nq + maxov < my : nq - maxov > my) { more = false; break; }
+                    if (str[jq] != (fwd ? 1 : -1) || typ[jq] == PGA_T_STOP) continue;
+                    if (fwd ? stv[jq] <= my : stv[jq] >= my) continue;
+                    j = jq;
+                    break;
+                }
+                if (j < 0) break;
             }
+            const int nj = ndx[j];
+            const double v = fwd ? cs[j] + ss[j] + igm_same_dev(my, 1, rs_i, us_i, nj, rs[j], us[j], mc->st_wt, mc->igm)
+                                 : cs[j] + ss[j] + igm_same_dev(nj, -1, rs[j], us[j], my, rs_i, us_i, mc->st_wt, mc->igm);
+            if (v > best) { const int f = nj % 3; if (f == 0) sp0 = j; else if (f == 1) sp1 = j; else sp2 = j; best = v; }
         }
     }
     ca.star_ptr[3 * g] = sp0; ca.star_ptr[3 * g + 1] = sp1; ca.star_ptr[3 * g + 2] = sp2;
