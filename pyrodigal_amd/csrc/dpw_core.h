@@ -122,14 +122,24 @@ DPW_HD DpwTopo dpw_topo_node(const int32_t* ndx, const int32_t* stopv, const uin
 // ------------------------------------------------------------------------------------------------------------------------
 // Per-chain pass: cs = cscore + sscore of every node; the extras of a stop node (third-node terms folded in,
 // ref: _connection.h:166-176, 296-325, 345-356).
+DPW_HD void dpw_chain_ext_sp(const int32_t* ndx, const int32_t* stopv, const int8_t* strand, const int32_t* topo_q2, const double* cscore,
+                             const double* sscore, const double* rscore, const double* uscore, const int (&sp)[3], const int i,
+                             const bool rev, const DpwModel& M, DpwExt& e);
 DPW_HD void dpw_chain_ext(const int32_t* ndx, const int32_t* stopv, const int8_t* strand, const int32_t* topo_q2, const double* cscore,
                           const double* sscore, const double* rscore, const double* uscore, const int32_t* star_ptr /* [n][3] */, const int i,
                           const bool rev, const DpwModel& M, DpwExt& e) {
+    const int sp[3] = {star_ptr[3 * i], star_ptr[3 * i + 1], star_ptr[3 * i + 2]};
+    dpw_chain_ext_sp(ndx, stopv, strand, topo_q2, cscore, sscore, rscore, uscore, sp, i, rev, M, e);
+}
+// the same with the three overlapping starts of node i handed over
+DPW_HD void dpw_chain_ext_sp(const int32_t* ndx, const int32_t* stopv, const int8_t* strand, const int32_t* topo_q2, const double* cscore,
+                             const double* sscore, const double* rscore, const double* uscore, const int (&sp)[3], const int i,
+                             const bool rev, const DpwModel& M, DpwExt& e) {
     e.vm = 0;
     const int my_ndx = ndx[i];
     for (int k = 0; k < 3; k++) {
         e.x[k] = 0.0; e.n3n[k] = 0; e.n3s[k] = 0; e.cq[k] = DPW_NONE;
-        const int p = star_ptr[3 * i + k];
+        const int p = sp[k];
         if (p < 0) continue;
         e.vm |= 1 << k;
         const double cs3 = cscore[p] + sscore[p];

@@ -1029,6 +1029,10 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         DEVBUF(d_tile_last, int32_t, "d_tile_last", (size_t)6 * batch->n_tiles);
         DEVBUF(d_tile_count, int32_t, "d_tile_count", (size_t)NG * (batch->n_tiles + 1));
         DEVBUF(d_tile_off, int32_t, "d_tile_off", (size_t)NG * (batch->n_tiles + 1));
+        DEVBUF(d_tile_scount, int32_t, "d_tile_scount", (size_t)NG * (batch->n_tiles + 1));
+        DEVBUF(d_tile_soff, int32_t, "d_tile_soff", (size_t)NG * (batch->n_tiles + 1));
+        DEVBUF(d_sbase, int32_t, "d_sbase", (size_t)NG * (NC + 1));
+        PINBUF(h_sbase, int32_t, "h_sbase", (size_t)NG * (NC + 1));
         PINBUF(h_cnt, int32_t, "h_cnt", 2 * (size_t)NC);
         PINBUF(h_cbase, int32_t, "h_cbase", (size_t)NG * (NC + 1));
 
@@ -1095,10 +1099,12 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             const int tt = meta_run ? f->group_tt[g] : (stage == PGA_STAGE_EXTRACT ? tt_override : c->models[0].trans_table);
             pga_launch_extract(d_dig, total, d_ct, NC, tt, P, ga[g], batch->d_tiles, batch->n_tiles, batch->d_tile0, d_tile_first, d_tile_last,
                                d_tile_count + (size_t)g * (batch->n_tiles + 1), d_tile_off + (size_t)g * (batch->n_tiles + 1), d_cbase + (size_t)g * (NC + 1),
+                               d_tile_scount + (size_t)g * (batch->n_tiles + 1), d_tile_soff + (size_t)g * (batch->n_tiles + 1), d_sbase + (size_t)g * (NC + 1),
                                masks, st, (meta_run && NM > 0) ? d_enabled + (size_t)g * NC : nullptr);
         }
         HT(c, hipMemcpyAsync(h_cnt, d_cnt, sizeof(int32_t) * 2 * (size_t)NC, hipMemcpyDeviceToHost, st));
         HT(c, hipMemcpyAsync(h_cbase, d_cbase, sizeof(int32_t) * (size_t)NG * (NC + 1), hipMemcpyDeviceToHost, st));
+        HT(c, hipMemcpyAsync(h_sbase, d_sbase, sizeof(int32_t) * (size_t)NG * (NC + 1), hipMemcpyDeviceToHost, st));
         HT(c, hipGetLastError());
         HT(c, hipStreamSynchronize(st));
 
@@ -1133,10 +1139,18 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         std::vector<ChainDesc> chains;
         std::vector<int> g_c0(NG + 1, 0);
         std::vector<int64_t> g_n0(NG + 1, 0);
-        int64_t tot_chain_nodes = 0;
+        int64_t tot_chain_nodes = 0, tot_chain_stops = 0;
+        std::vector<int64_t> g_s0(NG + 1, 0);            // (chain, stop node) pairs before the chains of group g
         for (int g = 0; g < NG; g++) {
             g_c0[g] = (int)chains.size(); g_n0[g] = tot_chain_nodes;
-            for (ChainDesc ch : gch[g]) { ch.off = tot_chain_nodes; tot_chain_nodes += ch.n; chains.push_back(ch); }
+            for (ChainDesc ch : gch[g]) {
+                ch.off = tot_chain_nodes; tot_chain_nodes += ch.n;
+                ch.soff = tot_chain_stops;
+                const int32_t* sb = h_sbase + (size_t)(meta_run ? g : 0) * (NC + 1);
+                tot_chain_stops += sb[ch.contig + 1] - sb[ch.contig];
+                chains.push_back(ch);
+            }
+            g_s0[g + 1] = tot_chain_stops;
         }
         g_c0[NG] = (int)chains.size(); g_n0[NG] = tot_chain_nodes;
         const int NCH = (int)chains.size();
@@ -1154,6 +1168,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             group_nodes[g] = h_cbase[(size_t)g * (NC + 1) + NC];
             const int64_t n = group_nodes[g] + 1;
             GBUF(ndx, int32_t, n) GBUF(stop_val, int32_t, n) GBUF(type, uint8_t, n) GBUF(strand, int8_t, n) GBUF(edge0, uint8_t, n) GBUF(gc_cont, float, n)
+            GBUF(stop_list, int32_t, (int64_t)h_sbase[(size_t)g * (NC + 1) + NC] + 1)
         }
         ChainArrays ca;
         {
@@ -1221,13 +1236,14 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
 
         tm.mark("plan+alloc");
         std::vector<int32_t> cs_tk[4], cs_en[4];
-        ScoreParams sp{P.closed, P.meta, P.max_overlap, 0, nullptr};
+        ScoreParams sp{P.closed, P.meta, P.max_overlap, 0, nullptr, nullptr};
         DEVBUF(d_conv, uint8_t, "d_conv_flag", (size_t)NG * NC + 1);
         PINBUF(h_conv, uint8_t, "h_conv_flag", (size_t)NG * NC + 1);
         if (meta_run) HT(c, hipMemsetAsync(d_conv, 0, (size_t)NG * NC, st));
         const pga_training* d_models = (const pga_training*)c->d_models_raw;
         for (int g = 0; g < NG; g++) {
-            pga_launch_place(d_ct, batch->d_tiles, batch->n_tiles, d_tile_off + (size_t)g * (batch->n_tiles + 1), ga[g], st);
+            pga_launch_place(d_ct, batch->d_tiles, batch->n_tiles, d_tile_off + (size_t)g * (batch->n_tiles + 1),
+                             d_tile_soff + (size_t)g * (batch->n_tiles + 1), ga[g], st);
             pga_launch_orf_gc(d_ct, NC, d_dig, d_p16, ga[g], (int)group_nodes[g], d_cbase + (size_t)g * (NC + 1), st);
             const int nch = g_c0[g + 1] - g_c0[g];
             const int64_t nn = g_n0[g + 1] - g_n0[g];
@@ -1250,15 +1266,21 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                 }
             }
             sp.conv_flag = meta_run ? d_conv + (size_t)g * NC : nullptr;
+            // overlapping starts over (chain, stop node) pairs; for the wave-batch scorer the same pass builds the stops' extras and
+            // the start scorer leaves cscore + sscore, so its per-chain preparation is done when scoring is
+            StopLaunch sl;
+            sl.sbase = d_sbase + (size_t)g * (NC + 1); sl.soff_begin = g_s0[g]; sl.n_pairs = g_s0[g + 1] - g_s0[g];
+            sp.cs_out = nullptr;
+            if (use_wave) {
+                pga_launch_dpw_topo(wgroups.g[g], ga[g].type, ga[g].strand, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], st);
+                sl.topo_q2 = wgroups.g[g].q2; sl.ext = wbuf.ext; sp.cs_out = wbuf.cs;
+            }
             pga_launch_score(d_chains + g_c0[g], nch, g_n0[g], nn, d_dig, d_ct, ga[g], d_models, f->d_msc, c->d_model_const, ca, sp,
                              d_chains, d_cc + (size_t)g * NC, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], f->d_sd_lut, st, 0,
                              meta_run ? f->d_gil + f->gil_off[g] : nullptr, meta_run ? f->gil_stride[g] : 0, f->d_model_rank,
-                             d_cs_tasks, n_cs_tasks, d_cs_entries);
+                             d_cs_tasks, n_cs_tasks, d_cs_entries, &sl);
             NodeArrays na{ga[g].ndx, ga[g].stop_val, ga[g].type, ga[g].strand, ca.cscore, ca.sscore, ca.rscore, ca.uscore, ca.star_ptr};
-            if (use_wave) {
-                pga_launch_dpw_topo(wgroups.g[g], ga[g].type, ga[g].strand, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], st);
-                pga_launch_dpw_chain(d_chains + g_c0[g], nch, g_n0[g], nn, na, wgroups.g[g], c->d_model_const, wbuf, st);
-            } else if (stage == 0) pga_launch_dp_prepare(d_chains + g_c0[g], nch, g_n0[g], nn, na, c->d_model_const, dp, st);
+            if (!use_wave && stage == 0) pga_launch_dp_prepare(d_chains + g_c0[g], nch, g_n0[g], nn, na, c->d_model_const, dp, st);
         }
         if (stage != 0) {
             // ---- stage-level call: bring the node arrays home as they are now and stop ---------------
@@ -1378,7 +1400,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             for (size_t k = 0; k < rescore.size(); k++)
                 h_cc2[(size_t)f->model_group[rescore[k].model] * NC + rescore[k].contig] = make_int2(NCH + (int)k, 1);
             HT(c, hipMemcpyAsync(d_cc + (size_t)NG * NC, h_cc2, sizeof(int2) * (size_t)NG * NC, hipMemcpyHostToDevice, st));
-            sp.conv_flag = nullptr;
+            sp.conv_flag = nullptr; sp.cs_out = nullptr;
             for (int g = 0; g < NG; g++) {
                 const int nch = r_c0[g + 1] - r_c0[g]; const int64_t nn = r_n0[g + 1] - r_n0[g];
                 if (nch == 0 || nn == 0) continue;

@@ -64,6 +64,7 @@ struct ChainDesc {
     int32_t group = 0;      // translation-table group of the chain's model: whose topology arrays `topo_off` indexes (dp_wave.hip)
     int64_t raw_off = -1;   // node scoring: read the raw coding scores of the chain at this offset (same contig, same model)
                             // instead of the chain's own; -1: its own
+    int64_t soff = 0;       // stop nodes of the chains before this one (in launch order): its first slot in a launch over (chain, stop) pairs
 };
 
 // Node fields in device memory (struct of arrays; each pointer covers the whole batch).

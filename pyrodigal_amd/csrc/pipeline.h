@@ -24,6 +24,7 @@ struct GroupArrays {
     // staging, two slots per position: the nodes of the tile that starts at global position g, packed in order from slot 2 g
     int32_t* st_ndx; int32_t* st_sv;         // ndx, stop_val
     uint8_t* st_info;                        // type | edge << 2 | reverse << 3
+    int32_t* stop_list;                      // the stop nodes of the group in node order (node indices); contig c owns [sbase[c], sbase[c + 1])
     // per node, in (contig, ndx, strand) order
     int32_t* ndx; int32_t* stop_val; uint8_t* type; int8_t* strand; uint8_t* edge0; float* gc_cont;
 };
@@ -54,6 +55,7 @@ struct MaskRun { int32_t contig, begin, end, _pad; };
 
 struct ScoreParams {
     int32_t closed, is_meta, max_overlap, _pad;
+    double* cs_out;          // or nullptr: cscore + sscore of every node, indexed like the chain arrays (what the wave-batch connection scorer reads)
     uint8_t* conv_flag;      // per contig (of the group being scored), or nullptr: set when the contig holds a start node that the
                              // reference turns into an edge node while scoring (lib.pyx:2424-2434) -- only such contigs are scored
                              // differently by the first and by a later model of a run
@@ -70,9 +72,18 @@ void pga_launch_gc_prefix(const uint8_t* d_dig, int64_t total, int32_t* d_block_
 void pga_launch_extract(const uint8_t* d_dig, int64_t total, const ContigDesc* d_ct, int n_contigs, int tt,
                         const pga_params& p, const GroupArrays& ga, const TileDesc* d_tiles, int n_tiles, const int32_t* d_tile0,
                         int32_t* d_tile_first, int32_t* d_tile_last, int32_t* d_tile_count, int32_t* d_tile_off, int32_t* d_cbase,
+                        int32_t* d_tile_scount, int32_t* d_tile_soff, int32_t* d_sbase /* the same three for stop nodes only */,
                         MaskList masks, hipStream_t st,
                         const uint8_t* d_enabled = nullptr /* per contig: extract it in this group?  nullptr = every contig */);
-void pga_launch_place(const ContigDesc* d_ct, const TileDesc* d_tiles, int n_tiles, const int32_t* d_tile_off, const GroupArrays& ga, hipStream_t st);
+void pga_launch_place(const ContigDesc* d_ct, const TileDesc* d_tiles, int n_tiles, const int32_t* d_tile_off, const int32_t* d_tile_soff,
+                      const GroupArrays& ga, hipStream_t st);
+// Overlapping starts over (chain, stop node) pairs instead of over every chain node (pga_launch_score with `stops`):
+struct StopLaunch {
+    const int32_t* sbase = nullptr;     // per contig of the group: first entry of ga.stop_list (n_contigs + 1)
+    int64_t soff_begin = 0, n_pairs = 0; // ChainDesc::soff of the launch's first chain; (chain, stop) pairs of its chains
+    // the wave-batch scorer's 64-byte extras of every stop node, built in the same pass (nullptr: not wanted)
+    const int32_t* topo_q2 = nullptr; void* ext = nullptr;
+};
 // per (group, contig): is any model of the group inside the contig's GC window?  (meta mode)
 void pga_launch_group_enable(const ContigDesc* d_ct, int n_contigs, const int32_t* d_gc_count, const double* d_model_gc,
                              const int32_t* d_model_group, int n_models, int n_groups, uint8_t* d_enabled, hipStream_t st);
@@ -91,7 +102,8 @@ void pga_launch_score(const ChainDesc* d_chains, int n_chains, int64_t node_begi
                       int reuse_raw_cscore = 0 /* 1: the chains read the raw coding scores another chain left (ChainDesc::raw_off): no ORF walk */,
                       const double* d_gil = nullptr /* hexamer tables of the group's models, interleaved: [4096][il_stride] */, int il_stride = 0,
                       const int32_t* d_rank = nullptr /* model -> column of d_gil */,
-                      const void* d_cs_tasks = nullptr, int n_cs_tasks = 0, const void* d_cs_entries = nullptr /* pga_cs_tasks: ORF walks from LDS tables */);
+                      const void* d_cs_tasks = nullptr, int n_cs_tasks = 0, const void* d_cs_entries = nullptr /* pga_cs_tasks: ORF walks from LDS tables */,
+                      const StopLaunch* stops = nullptr);
 // host: the tasks of the LDS form of the coding score for one group (pipeline.hip); false = models are not neighbours in the table
 bool pga_cs_tasks(const int2* h_cc, int n_contigs, const ChainDesc* h_chains, const int32_t* h_cbase, const int32_t* model_rank, int task_nodes,
                   std::vector<int32_t>& tasks, std::vector<int32_t>& entries);

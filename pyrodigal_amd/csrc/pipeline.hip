@@ -18,6 +18,7 @@
 #include "pga_internal.h"
 #include "pipeline.h"
 #include "dev_common.h"
+#include "dpw_core.h"
 
 namespace {
 
@@ -495,11 +496,13 @@ k_tile_stops(const uint8_t* __restrict__ dig, int64_t total, const ContigDesc* _
 __global__ void __launch_bounds__(256)
 k_extract_tile(const uint8_t* __restrict__ dig, int64_t total, const ContigDesc* __restrict__ ct, const TileDesc* __restrict__ tiles, int n_tiles,
                const int32_t* __restrict__ tile_first, const int32_t* __restrict__ tile_last, ExParams P, GroupArrays ga, MaskList masks,
-               const uint8_t* __restrict__ enabled, int32_t* __restrict__ tile_count) {
+               const uint8_t* __restrict__ enabled, int32_t* __restrict__ tile_count, int32_t* __restrict__ tile_scount) {
     __shared__ ExShared S;
+    __shared__ int s_stops;
     const int tile = blockIdx.x, t = threadIdx.x;
     const TileDesc td = tiles[tile];
-    if (enabled != nullptr && !enabled[td.contig]) { if (t == 0) tile_count[tile] = 0; return; }     // the contig keeps zero nodes in this group
+    if (enabled != nullptr && !enabled[td.contig]) { if (t == 0) { tile_count[tile] = 0; tile_scount[tile] = 0; } return; }     // the contig keeps zero nodes in this group
+    if (t == 0) s_stops = 0;
     const ContigDesc cd = ct[td.contig];
     const TileGeom G = tile_geom(td, cd.len);
     const uint8_t* __restrict__ d = dig + cd.base;
@@ -530,12 +533,24 @@ k_extract_tile(const uint8_t* __restrict__ dig, int64_t total, const ContigDesc*
     }
     int64_t slot = 2 * g0 + nbase;
     unsigned both = nf | nr;
+    int n_stop = 0;
     while (both) {
         const int k = __builtin_ctz(both);
         both &= both - 1u;
-        if ((nf >> k) & 1u) { ga.st_ndx[slot] = G.a + r0 + k; ga.st_sv[slot] = S.sv[0][k][t]; ga.st_info[slot] = (uint8_t)((inf_f >> (4 * k)) & 7); slot++; }
-        if ((nr >> k) & 1u) { ga.st_ndx[slot] = G.a + r0 + k; ga.st_sv[slot] = S.sv[1][k][t]; ga.st_info[slot] = (uint8_t)(((inf_r >> (4 * k)) & 7) | 8); slot++; }
+        if ((nf >> k) & 1u) {
+            const int info = (int)((inf_f >> (4 * k)) & 7);
+            ga.st_ndx[slot] = G.a + r0 + k; ga.st_sv[slot] = S.sv[0][k][t]; ga.st_info[slot] = (uint8_t)info; slot++; n_stop += (info & 3) == PGA_T_STOP;
+        }
+        if ((nr >> k) & 1u) {
+            const int info = (int)((inf_r >> (4 * k)) & 7);
+            ga.st_ndx[slot] = G.a + r0 + k; ga.st_sv[slot] = S.sv[1][k][t]; ga.st_info[slot] = (uint8_t)(info | 8); slot++; n_stop += (info & 3) == PGA_T_STOP;
+        }
     }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) n_stop += __shfl_xor(n_stop, m, 64);
+    if (lane == 0 && n_stop) atomicAdd(&s_stops, n_stop);
+    __syncthreads();
+    if (t == 0) tile_scount[tile] = s_stops;
 }
 
 // Exclusive scan of n counts into n + 1 offsets, one workgroup: 8 elements per thread and round.
@@ -577,16 +592,33 @@ __global__ void k_contig_node_base(const int32_t* __restrict__ tile0, int n_cont
 // The staged nodes of every tile go to their final index; the position of a node learns the index of its first node
 // (the ORF walks of the coding score turn positions into node indices through it).
 __global__ void __launch_bounds__(128)
-k_place_nodes(const ContigDesc* __restrict__ ct, const TileDesc* __restrict__ tiles, const int32_t* __restrict__ tile_off, GroupArrays ga) {
+k_place_nodes(const ContigDesc* __restrict__ ct, const TileDesc* __restrict__ tiles, const int32_t* __restrict__ tile_off,
+              const int32_t* __restrict__ tile_soff, GroupArrays ga) {
+    __shared__ int s_w[2];
     const TileDesc td = tiles[blockIdx.x];
     const int off = tile_off[blockIdx.x], cnt = tile_off[blockIdx.x + 1] - off;
     if (cnt <= 0) return;
     const int64_t base = ct[td.contig].base;
     const int64_t s0 = 2 * (base + td.start);
-    for (int j = threadIdx.x; j < cnt; j += blockDim.x) {
-        const int ndx = ga.st_ndx[s0 + j], info = ga.st_info[s0 + j], k = off + j;
-        ga.ndx[k] = ndx; ga.stop_val[k] = ga.st_sv[s0 + j]; ga.type[k] = info & 3; ga.strand[k] = (info >> 3) & 1 ? -1 : 1; ga.edge0[k] = (info >> 2) & 1;
-        if (j == 0 || ga.st_ndx[s0 + j - 1] != ndx) ga.pre_nodes[base + ndx] = k;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int srun = tile_soff[blockIdx.x];                       // next free entry of the stop list
+    for (int j0 = 0; j0 < cnt; j0 += 128) {
+        const int j = j0 + threadIdx.x;
+        bool is_stop = false;
+        int k = 0;
+        if (j < cnt) {
+            const int ndx = ga.st_ndx[s0 + j], info = ga.st_info[s0 + j];
+            k = off + j;
+            ga.ndx[k] = ndx; ga.stop_val[k] = ga.st_sv[s0 + j]; ga.type[k] = info & 3; ga.strand[k] = (info >> 3) & 1 ? -1 : 1; ga.edge0[k] = (info >> 2) & 1;
+            if (j == 0 || ga.st_ndx[s0 + j - 1] != ndx) ga.pre_nodes[base + ndx] = k;
+            is_stop = (info & 3) == PGA_T_STOP;
+        }
+        const unsigned long long bal = __ballot(is_stop);
+        if (lane == 0) s_w[wv] = __popcll(bal);
+        __syncthreads();
+        if (is_stop) ga.stop_list[srun + (wv ? s_w[0] : 0) + __popcll(bal & ((1ull << lane) - 1ull))] = k;
+        srun += s_w[0] + s_w[1];
+        __syncthreads();
     }
 }
 
@@ -1308,6 +1340,7 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
             ca.edge[g] = (uint8_t)e0;
             ca.cscore[g] = 0.0; ca.sscore[g] = 0.0; ca.rscore[g] = 0.0; ca.uscore[g] = 0.0; ca.tscore[g] = 0.0; ca.mot_score[g] = 0.0;
             ca.mot_ndx[g] = 0; ca.mot_len[g] = 0; ca.mot_spacer[g] = 0; ca.mot_spacendx[g] = 0; ca.rbs[2 * g] = 0; ca.rbs[2 * g + 1] = 0;
+            if (sp.cs_out != nullptr) sp.cs_out[g] = 0.0;
         }
         return;
     }
@@ -1460,11 +1493,83 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
         ca.mot_len[g] = (uint8_t)m_len; ca.mot_spacer[g] = (uint8_t)m_sp; ca.mot_spacendx[g] = (uint8_t)m_si;
         ca.rbs[2 * g] = (uint8_t)rbs0; ca.rbs[2 * g + 1] = (uint8_t)rbs1;
         ca.edge[g] = (uint8_t)edge_now;
+        if (sp.cs_out != nullptr) sp.cs_out[g] = cscore + sscore;
     }
 }
 
 // ------------------------------------------------------------------- overlapping starts
 // ref: lib.pyx:2279-2329 (Nodes._record_overlapping_starts with flag = 1)
+// The three overlapping starts of stop node i (not an edge stop) of a chain.
+struct OvlChain {
+    const int32_t* __restrict__ ndx; const int32_t* __restrict__ stv; const uint8_t* __restrict__ typ; const int8_t* __restrict__ str;   // topology of the contig
+    const double* __restrict__ cs; const double* __restrict__ ss; const double* __restrict__ rs; const double* __restrict__ us;           // the chain's scores
+    int n;
+};
+__device__ __forceinline__ void overlapping_starts_of(const OvlChain& C, const int i, const ModelConst* __restrict__ mc, const int maxov,
+                                                      int& sp0, int& sp1, int& sp2) {
+    const int32_t* __restrict__ ndx = C.ndx; const int32_t* __restrict__ stv = C.stv;
+    const uint8_t* __restrict__ typ = C.typ; const int8_t* __restrict__ str = C.str;
+    const double* __restrict__ cs = C.cs; const double* __restrict__ ss = C.ss; const double* __restrict__ rs = C.rs; const double* __restrict__ us = C.us;
+    const int n = C.n;
+    const int my = ndx[i];
+    double best = -100;
+    const bool fwd = str[i] == 1;
+    const double rs_i = rs[i], us_i = us[i];
+    // The reference walks the neighbours one by one (forward stop: j = i + 3 downwards; reverse stop: j = i - 3 upwards) until
+    // it leaves the overlap window.  Which neighbours count is decided by positions, strands and types alone: the first
+    // OV_SPEC of them are read at once (one memory round trip instead of one or two per neighbour), then only the ones
+    // that count are priced, in the reference's order.
+    constexpr int OV_SPEC = 16;
+    bool ended = false;
+    unsigned elig = 0;
+#pragma unroll
+    for (int k = 0; k < OV_SPEC; k++) {
+        const int j = fwd ? i + 3 - k : i - 3 + k;
+        const int jj = min(max(j, 0), n - 1);
+        const int nd = ndx[jj], sv = stv[jj], ty = typ[jj], sd = str[jj];       // unconditional: every load of the loop can be in flight at once
+        bool stop_here, ok;
+        if (fwd) {
+            stop_here = j < 0 || (j < n && nd <= my + 2 && nd + maxov < my);
+            ok = j >= 0 && j < n && nd <= my + 2 && sd == 1 && ty != PGA_T_STOP && sv > my;
+        } else {
+            stop_here = j >= n || (j >= 0 && nd >= my - 2 && nd - maxov > my);
+            ok = j >= 0 && j < n && nd >= my - 2 && sd == -1 && ty != PGA_T_STOP && sv < my;
+        }
+        ended = ended || stop_here;
+        if (ok && !ended) elig |= 1u << k;
+    }
+    int js = fwd ? i + 3 - OV_SPEC : i - 3 + OV_SPEC;        // where the one-by-one walk goes on if the window is not done by then
+    bool more = !ended;
+    for (;;) {
+        int j = -1;
+        if (elig) {
+            const int k = __builtin_ctz(elig);
+            elig &= elig - 1u;
+            j = fwd ? i + 3 - k : i - 3 + k;
+        } else {
+            while (more) {
+                if (fwd ? js < 0 : js >= n) { more = false; break; }
+                const int jq = js;
+                js += fwd ? -1 : 1;
+                if (jq < 0 || jq >= n) continue;
+                const int nq = ndx[jq];
+                if (fwd ? nq > my + 2 : nq < my - 2) continue;
+                if (fwd ? nq + maxov < my : nq - maxov > my) { more = false; break; }
+                if (str[jq] != (fwd ? 1 : -1) || typ[jq] == PGA_T_STOP) continue;
+                if (fwd ? stv[jq] <= my : stv[jq] >= my) continue;
+                j = jq;
+                break;
+            }
+            if (j < 0) break;
+        }
+        const int nj = ndx[j];
+        const double v = fwd ? cs[j] + ss[j] + igm_same_dev(my, 1, rs_i, us_i, nj, rs[j], us[j], mc->st_wt, mc->igm)
+                             : cs[j] + ss[j] + igm_same_dev(nj, -1, rs[j], us[j], my, rs_i, us_i, mc->st_wt, mc->igm);
+        if (v > best) { const int f = nj % 3; if (f == 0) sp0 = j; else if (f == 1) sp1 = j; else sp2 = j; best = v; }
+    }
+}
+
+// one thread per chain node
 __global__ void __launch_bounds__(256)
 k_overlapping_starts(const ChainDesc* __restrict__ chains, int n_chains, int64_t node_begin, int64_t total,
                      GroupArrays ga, const ModelConst* __restrict__ mcs, ChainArrays ca, int maxov) {
@@ -1475,73 +1580,56 @@ k_overlapping_starts(const ChainDesc* __restrict__ chains, int n_chains, int64_t
     const int c = block_chain(chains, n_chains, blk0, in_range ? g : blk0, &s_c0);
     if (!in_range) return;
     const ChainDesc ch = chains[c];
-    const int i = (int)(g - ch.off), n = ch.n;
+    const int i = (int)(g - ch.off);
     const int64_t tb = ch.topo_off;
     int sp0 = -1, sp1 = -1, sp2 = -1;
     if (ga.type[tb + i] == PGA_T_STOP && ga.edge0[tb + i] != 1) {
-        const ModelConst* __restrict__ mc = &mcs[ch.model];
-        const int32_t* __restrict__ ndx = ga.ndx + tb; const int32_t* __restrict__ stv = ga.stop_val + tb;
-        const uint8_t* __restrict__ typ = ga.type + tb; const int8_t* __restrict__ str = ga.strand + tb;
-        const double* __restrict__ cs = ca.cscore + ch.off; const double* __restrict__ ss = ca.sscore + ch.off;
-        const double* __restrict__ rs = ca.rscore + ch.off; const double* __restrict__ us = ca.uscore + ch.off;
-        const int my = ndx[i];
-        double best = -100;
-        const bool fwd = str[i] == 1;
-        const double rs_i = rs[i], us_i = us[i];
-        // The reference walks the neighbours one by one (forward stop: j = i + 3 downwards; reverse stop: j = i - 3 upwards) until
-        // it leaves the overlap window.  Which neighbours count is decided by positions, strands and types alone: the first
-        // OV_SPEC of them are read at once (one memory round trip instead of one or two per neighbour), then only the ones
-        // that count are priced, in the reference's order.
-        constexpr int OV_SPEC = 16;
-        bool ended = false;
-        unsigned elig = 0;
-#pragma unroll
-        for (int k = 0; k < OV_SPEC; k++) {
-            const int j = fwd ? i + 3 - k : i - 3 + k;
-            const int jj = min(max(j, 0), n - 1);
-            const int nd = ndx[jj], sv = stv[jj], ty = typ[jj], sd = str[jj];       // unconditional: every load of the loop can be in flight at once
-            bool stop_here, ok;
-            if (fwd) {
-                stop_here = j < 0 || (j < n && nd <= my + 2 && nd + maxov < my);
-                ok = j >= 0 && j < n && nd <= my + 2 && sd == 1 && ty != PGA_T_STOP && sv > my;
-            } else {
-                stop_here = j >= n || (j >= 0 && nd >= my - 2 && nd - maxov > my);
-                ok = j >= 0 && j < n && nd >= my - 2 && sd == -1 && ty != PGA_T_STOP && sv < my;
-            }
-            ended = ended || stop_here;
-            if (ok && !ended) elig |= 1u << k;
-        }
-        int js = fwd ? i + 3 - OV_SPEC : i - 3 + OV_SPEC;        // where the one-by-one walk goes on if the window is not done by then
-        bool more = !ended;
-        for (;;) {
-            int j = -1;
-            if (elig) {
-                const int k = __builtin_ctz(elig);
-                elig &= elig - 1u;
-                j = fwd ? i + 3 - k : i - 3 + k;
-            } else {
-                while (more) {
-                    if (fwd ? js < 0 : js >= n) { more = false; break; }
-                    const int jq = js;
-                    js += fwd ? -1 : 1;
-                    if (jq < 0 || jq >= n) continue;
-                    const int nq = ndx[jq];
-                    if (fwd ? nq > my + 2 : nq < my - 2) continue;
-                    if (fwd ? nq + maxov < my : nq - maxov > my) { more = false; break; }
-                    if (str[jq] != (fwd ? 1 : -1) || typ[jq] == PGA_T_STOP) continue;
-                    if (fwd ? stv[jq] <= my : stv[jq] >= my) continue;
-                    j = jq;
-                    break;
-                }
-                if (j < 0) break;
-            }
-            const int nj = ndx[j];
-            const double v = fwd ? cs[j] + ss[j] + igm_same_dev(my, 1, rs_i, us_i, nj, rs[j], us[j], mc->st_wt, mc->igm)
-                                 : cs[j] + ss[j] + igm_same_dev(nj, -1, rs[j], us[j], my, rs_i, us_i, mc->st_wt, mc->igm);
-            if (v > best) { const int f = nj % 3; if (f == 0) sp0 = j; else if (f == 1) sp1 = j; else sp2 = j; best = v; }
-        }
+        const OvlChain C{ga.ndx + tb, ga.stop_val + tb, ga.type + tb, ga.strand + tb, ca.cscore + ch.off, ca.sscore + ch.off, ca.rscore + ch.off,
+                         ca.uscore + ch.off, ch.n};
+        overlapping_starts_of(C, i, &mcs[ch.model], maxov, sp0, sp1, sp2);
     }
     ca.star_ptr[3 * g] = sp0; ca.star_ptr[3 * g + 1] = sp1; ca.star_ptr[3 * g + 2] = sp2;
+}
+
+// One thread per (chain, stop node) pair: stop nodes are one node in five, and a wavefront of the kernel above waits for its
+// few stop lanes.  The pairs of a chain are ChainDesc::soff .. ; the k-th stop of a contig is ga.stop_list[sbase[contig] + k].
+// star_ptr of the other nodes is -1 (the launcher fills the range first).  With `ext` the 64-byte extras record of the
+// wave-batch connection scorer is built from the three starts while they are at hand (dpw_core.h, dpw_chain_ext).
+__global__ void __launch_bounds__(256)
+k_ovl_stops(const ChainDesc* __restrict__ chains, int n_chains, int64_t soff_begin, int64_t n_pairs, GroupArrays ga,
+            const int32_t* __restrict__ cbase, const int32_t* __restrict__ sbase, const ModelConst* __restrict__ mcs, ChainArrays ca, int maxov,
+            const int32_t* __restrict__ topo_q2, DpwExt* __restrict__ ext) {
+    __shared__ int s_c0;
+    const int64_t blk0 = soff_begin + (int64_t)blockIdx.x * blockDim.x;
+    const int64_t p = blk0 + threadIdx.x;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = n_chains - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (chains[mid].soff <= blk0) lo = mid; else hi = mid - 1; }
+        s_c0 = lo;
+    }
+    __syncthreads();
+    if (p >= soff_begin + n_pairs) return;
+    int c = s_c0;
+    while (c + 1 < n_chains && chains[c + 1].soff <= p) c++;
+    const ChainDesc ch = chains[c];
+    const int64_t tb = ch.topo_off;
+    const int i = ga.stop_list[sbase[ch.contig] + (int)(p - ch.soff)] - cbase[ch.contig];
+    const int64_t g = ch.off + i;
+    const ModelConst* __restrict__ mc = &mcs[ch.model];
+    int sp[3] = {-1, -1, -1};
+    if (ga.edge0[tb + i] != 1) {
+        const OvlChain C{ga.ndx + tb, ga.stop_val + tb, ga.type + tb, ga.strand + tb, ca.cscore + ch.off, ca.sscore + ch.off, ca.rscore + ch.off,
+                         ca.uscore + ch.off, ch.n};
+        overlapping_starts_of(C, i, mc, maxov, sp[0], sp[1], sp[2]);
+        ca.star_ptr[3 * g] = sp[0]; ca.star_ptr[3 * g + 1] = sp[1]; ca.star_ptr[3 * g + 2] = sp[2];
+    }
+    if (ext != nullptr) {
+        const DpwModel M{mc->st_wt, mc->negc, mc->igm};
+        DpwExt e;
+        dpw_chain_ext_sp(ga.ndx + tb, ga.stop_val + tb, ga.strand + tb, topo_q2 + tb, ca.cscore + ch.off, ca.sscore + ch.off, ca.rscore + ch.off,
+                         ca.uscore + ch.off, sp, i, ga.strand[tb + i] != 1, M, e);
+        ext[g] = e;
+    }
 }
 
 }  // namespace
@@ -1617,7 +1705,7 @@ void pga_launch_gc_prefix(const uint8_t* d_dig, int64_t total, int32_t* d_block_
 void pga_launch_extract(const uint8_t* d_dig, int64_t total, const ContigDesc* d_ct, int n_contigs, int tt,
                         const pga_params& p, const GroupArrays& ga, const TileDesc* d_tiles, int n_tiles, const int32_t* d_tile0,
                         int32_t* d_tile_first, int32_t* d_tile_last, int32_t* d_tile_count, int32_t* d_tile_off, int32_t* d_cbase,
-                        MaskList masks, hipStream_t st, const uint8_t* d_enabled) {
+                        int32_t* d_tile_scount, int32_t* d_tile_soff, int32_t* d_sbase, MaskList masks, hipStream_t st, const uint8_t* d_enabled) {
     if (n_tiles > 0) {
         ExParams P{tt, p.closed, p.min_gene, p.min_edge_gene, 0ull, 0ull};
         for (int idx = 0; idx < 64; idx++) {
@@ -1627,15 +1715,18 @@ void pga_launch_extract(const uint8_t* d_dig, int64_t total, const ContigDesc* d
         }
         hipLaunchKernelGGL(k_tile_stops, dim3(n_tiles), dim3(256), 0, st, d_dig, total, d_ct, d_tiles, n_tiles, P.stop_codons, d_tile_first, d_tile_last, d_enabled);
         hipLaunchKernelGGL(k_extract_tile, dim3(n_tiles), dim3(256), 0, st, d_dig, total, d_ct, d_tiles, n_tiles, d_tile_first, d_tile_last, P, ga, masks,
-                           d_enabled, d_tile_count);
+                           d_enabled, d_tile_count, d_tile_scount);
     }
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, d_tile_count, n_tiles, d_tile_off);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, d_tile_scount, n_tiles, d_tile_soff);
     hipLaunchKernelGGL(k_contig_node_base, dim3((n_contigs + 1 + 255) / 256), dim3(256), 0, st, d_tile0, n_contigs, d_tile_off, d_cbase);
+    hipLaunchKernelGGL(k_contig_node_base, dim3((n_contigs + 1 + 255) / 256), dim3(256), 0, st, d_tile0, n_contigs, d_tile_soff, d_sbase);
 }
 
-void pga_launch_place(const ContigDesc* d_ct, const TileDesc* d_tiles, int n_tiles, const int32_t* d_tile_off, const GroupArrays& ga, hipStream_t st) {
+void pga_launch_place(const ContigDesc* d_ct, const TileDesc* d_tiles, int n_tiles, const int32_t* d_tile_off, const int32_t* d_tile_soff,
+                      const GroupArrays& ga, hipStream_t st) {
     if (n_tiles <= 0) return;
-    hipLaunchKernelGGL(k_place_nodes, dim3(n_tiles), dim3(128), 0, st, d_ct, d_tiles, d_tile_off, ga);
+    hipLaunchKernelGGL(k_place_nodes, dim3(n_tiles), dim3(128), 0, st, d_ct, d_tiles, d_tile_off, d_tile_soff, ga);
 }
 
 int pga_extract_tile_size() { return EX_TILE; }
@@ -1714,7 +1805,7 @@ void pga_launch_score(const ChainDesc* d_chains, int n_chains, int64_t node_begi
                       const ModelScoreConst* d_msc, const ModelConst* d_mc, const ChainArrays& ca, ScoreParams sp,
                       const ChainDesc* d_all_chains, const int2* d_contig_chains, const int32_t* d_node_contig_base, int n_contigs,
                       int group_nodes, const unsigned* d_sd_lut, hipStream_t st, int reuse_raw_cscore, const double* d_gil, int il_stride,
-                      const int32_t* d_rank, const void* d_cs_tasks, int n_cs_tasks, const void* d_cs_entries) {
+                      const int32_t* d_rank, const void* d_cs_tasks, int n_cs_tasks, const void* d_cs_entries, const StopLaunch* stops) {
     if (total <= 0 || n_chains <= 0) return;
     const dim3 grid(nblocks(total, 256)), blk(256);
     if (group_nodes > 0 && !reuse_raw_cscore && n_cs_tasks > 0) {
@@ -1736,5 +1827,10 @@ void pga_launch_score(const ChainDesc* d_chains, int n_chains, int64_t node_begi
     if (group_nodes > 0)
         hipLaunchKernelGGL(k_score_starts, dim3(nblocks(group_nodes, 256)), blk, 0, st, d_all_chains, d_contig_chains, d_node_contig_base, n_contigs,
                            group_nodes, d_dig, d_ct, ga, d_models, ca, sp, d_sd_lut);
-    hipLaunchKernelGGL(k_overlapping_starts, grid, blk, 0, st, d_chains, n_chains, node_begin, total, ga, d_mc, ca, sp.max_overlap);
+    if (stops != nullptr) {
+        (void)hipMemsetAsync(ca.star_ptr + 3 * node_begin, 0xff, sizeof(int32_t) * 3 * (size_t)total, st);
+        if (stops->n_pairs > 0)
+            hipLaunchKernelGGL(k_ovl_stops, dim3(nblocks(stops->n_pairs, 256)), blk, 0, st, d_chains, n_chains, stops->soff_begin, stops->n_pairs, ga,
+                               d_node_contig_base, stops->sbase, d_mc, ca, sp.max_overlap, stops->topo_q2, (DpwExt*)stops->ext);
+    } else hipLaunchKernelGGL(k_overlapping_starts, grid, blk, 0, st, d_chains, n_chains, node_begin, total, ga, d_mc, ca, sp.max_overlap);
 }
