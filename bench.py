@@ -122,7 +122,7 @@ def timed_steps(lanes, batches, steps, warmup, sync, gather, **kw):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="config4", choices=["config4", "config3", "config2", "config5"])
     ap.add_argument("--contigs", type=int, default=100_000, help="config4: contigs of the whole job")

@@ -256,7 +256,8 @@ __device__ __forceinline__ void wave_step(const SrcRegs& R, const int u, const i
     if (in_mask(take)) { L.val = val; L.tag = tag; }
 }
 
-__global__ void __launch_bounds__(64, 4)
+template <int OCC>      // wavefronts per SIMD the register budget is cut for
+__global__ void __launch_bounds__(64, OCC)
 k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const double* __restrict__ g_cs, const DpwExt* __restrict__ g_ext,
           const ModelConst* __restrict__ models, DpBuffers buf, double* __restrict__ g_sfxv, int32_t* __restrict__ g_sfxi) {
     __shared__ double s_igm[64];
@@ -545,6 +546,12 @@ void pga_launch_dpw_chain(const ChainDesc* d_chains, int n_chains, int64_t node_
 void pga_launch_dp_wave(const ChainDesc* d_chains, int n_chains, const DpwGroupPtrs& groups, const ModelConst* d_models, DpBuffers buf,
                         const DpwBuffers& wb, hipStream_t st) {
     if (n_chains <= 0) return;
-    hipLaunchKernelGGL(k_dp_wave, dim3((unsigned)n_chains), dim3(64), 0, st, d_chains, groups, (const double*)wb.cs, (const DpwExt*)wb.ext,
-                       d_models, buf, wb.sfxv, wb.sfxi);
+    static int occ = 0;
+    if (!occ) { const char* e = getenv("PGA_DPW_OCC"); occ = e ? atoi(e) : 6; if (occ < 4 || occ > 6) occ = 6; }
+    if (occ == 5) hipLaunchKernelGGL(k_dp_wave<5>, dim3((unsigned)n_chains), dim3(64), 0, st, d_chains, groups, (const double*)wb.cs, (const DpwExt*)wb.ext,
+                                     d_models, buf, wb.sfxv, wb.sfxi);
+    else if (occ == 6) hipLaunchKernelGGL(k_dp_wave<6>, dim3((unsigned)n_chains), dim3(64), 0, st, d_chains, groups, (const double*)wb.cs, (const DpwExt*)wb.ext,
+                                          d_models, buf, wb.sfxv, wb.sfxi);
+    else hipLaunchKernelGGL(k_dp_wave<4>, dim3((unsigned)n_chains), dim3(64), 0, st, d_chains, groups, (const double*)wb.cs, (const DpwExt*)wb.ext,
+                            d_models, buf, wb.sfxv, wb.sfxi);
 }

@@ -1041,7 +1041,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             char nm[32];
 #define GBUF(field, type, count) { snprintf(nm, sizeof nm, #field "%d", g); void* p__; int rc__ = ensure_dev(c, nm, sizeof(type) * (size_t)(count) + 64, &p__); if (rc__) return rc__; ga[g].field = (type*)p__; }
             GBUF(nf_fwd, uint8_t, total + 1) GBUF(nf_rev, uint8_t, total + 1)
-            GBUF(pre_nodes, int32_t, total + 2)
+            GBUF(pre_nodes, int32_t, total + 2) GBUF(pre_rev, int32_t, total + 2)
             GBUF(st_ndx, int32_t, 2 * total + 2) GBUF(st_sv, int32_t, 2 * total + 2) GBUF(st_info, uint8_t, 2 * total + 2)
             ga[g].ndx = nullptr; ga[g].stop_val = nullptr; ga[g].type = nullptr; ga[g].strand = nullptr; ga[g].edge0 = nullptr; ga[g].gc_cont = nullptr;
         }
@@ -1177,8 +1177,11 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             DEVBUF(a6, int32_t, "ca_star_ptr", 3 * chain_cap) DEVBUF(a7, int32_t, "ca_mot_ndx", chain_cap) DEVBUF(a8, uint8_t, "ca_rbs", 2 * chain_cap)
             DEVBUF(a9, uint8_t, "ca_edge", chain_cap) DEVBUF(a10, uint8_t, "ca_mot_len", chain_cap) DEVBUF(a11, uint8_t, "ca_mot_spacer", chain_cap)
             DEVBUF(a12, uint8_t, "ca_mot_spacendx", chain_cap)
-            DEVBUF(a13, double, "ca_cscore_raw", chain_cap)
-            ca = ChainArrays{a0, a1, a2, a3, a4, a5, a13, a6, a7, a8, a9, a10, a11, a12};
+            int64_t max_contig_nodes = 0;
+            for (int g = 0; g < NG; g++) for (int i = 0; i < NC; i++)
+                max_contig_nodes = std::max<int64_t>(max_contig_nodes, h_cbase[(size_t)g * (NC + 1) + i + 1] - h_cbase[(size_t)g * (NC + 1) + i]);
+            DEVBUF(a13, double, "ca_cscore_raw", chain_cap + max_contig_nodes + 64)
+            ca = ChainArrays{a0, a1, a2, a3, a4, a5, a13, a6, a7, a8, a9, a10, a11, a12, a13 + chain_cap};
         }
         // few long chains: their walks are cut into segments that run side by side (dp.hip "segmented chains")
         DpSegPlan seg_plan;
@@ -1252,9 +1255,11 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             // four table columns they need (PGA_CS_LDS=0: the global-memory form)
             const void* d_cs_tasks = nullptr; const void* d_cs_entries = nullptr; int n_cs_tasks = 0;
             const char* cs_env = getenv("PGA_CS_LDS");
+            const char* cs_tn = getenv("PGA_CS_TASK_NODES");
+            const int cs_task_nodes = cs_tn && atoi(cs_tn) >= 256 && atoi(cs_tn) <= 8192 ? atoi(cs_tn) : 8192;
             if (meta_run && nn >= 65536 && !(cs_env && atoi(cs_env) == 0)) {
                 std::vector<int32_t>& tk = cs_tk[g]; std::vector<int32_t>& en = cs_en[g];     // alive until the stream is synchronized
-                if (pga_cs_tasks(h_cc + (size_t)g * NC, NC, chains.data(), h_cbase + (size_t)g * (NC + 1), f->model_rank.data(), 8192, tk, en) && !tk.empty()) {
+                if (pga_cs_tasks(h_cc + (size_t)g * NC, NC, chains.data(), h_cbase + (size_t)g * (NC + 1), f->model_rank.data(), cs_task_nodes, tk, en) && !tk.empty()) {
                     char nm1[32], nm2[32];
                     snprintf(nm1, sizeof nm1, "cs_tasks%d", g); snprintf(nm2, sizeof nm2, "cs_entries%d", g);
                     void* p1; void* p2;

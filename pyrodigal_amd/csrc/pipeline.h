@@ -20,7 +20,7 @@ struct TileDesc {
 struct GroupArrays {
     // per position (whole batch)
     uint8_t* nf_fwd;  uint8_t* nf_rev;       // 1 = a forward / reverse node has its ndx here (written densely by the tile that owns the position)
-    int32_t* pre_nodes;                      // at a position with a node: the index of its first node (forward before reverse)
+    int32_t* pre_nodes; int32_t* pre_rev;    // at a position with a forward / reverse node: the index of that node
     // staging, two slots per position: the nodes of the tile that starts at global position g, packed in order from slot 2 g
     int32_t* st_ndx; int32_t* st_sv;         // ndx, stop_val
     uint8_t* st_info;                        // type | edge << 2 | reverse << 3
@@ -38,6 +38,8 @@ struct ChainArrays {
     uint8_t* rbs;          // [n][2]
     uint8_t* edge;         // edge flag after Nodes._score's conversion
     uint8_t* mot_len; uint8_t* mot_spacer; uint8_t* mot_spacendx;
+    double* cs_sink = nullptr;   // as many doubles as the largest contig has nodes: where the ORF walks of k_coding_score_quads store the sums of
+                                 // table columns a contig has no model for (unconditional stores instead of a divergent branch per column)
 };
 
 // Host-computed per-model constants of the node scorer (libm log/pow stay on the host).

@@ -610,7 +610,7 @@ k_place_nodes(const ContigDesc* __restrict__ ct, const TileDesc* __restrict__ ti
             const int ndx = ga.st_ndx[s0 + j], info = ga.st_info[s0 + j];
             k = off + j;
             ga.ndx[k] = ndx; ga.stop_val[k] = ga.st_sv[s0 + j]; ga.type[k] = info & 3; ga.strand[k] = (info >> 3) & 1 ? -1 : 1; ga.edge0[k] = (info >> 2) & 1;
-            if (j == 0 || ga.st_ndx[s0 + j - 1] != ndx) ga.pre_nodes[base + ndx] = k;
+            ((info >> 3) & 1 ? ga.pre_rev : ga.pre_nodes)[base + ndx] = k;
             is_stop = (info & 3) == PGA_T_STOP;
         }
         const unsigned long long bal = __ballot(is_stop);
@@ -727,7 +727,7 @@ constexpr int CS_MODELS = 4;
 constexpr int CS_LONG = 192;
 
 struct OrfCtx {
-    const uint8_t* d; const uint8_t* nf; const uint8_t* nf_f; const int32_t* pre;
+    const uint8_t* d; const uint8_t* nf; const int32_t* pre;      // digits, node flags and node indices of the ORF's strand, by position
     int tbase, p, q, L, strand, step, ncod;
     int2 cc;
 };
@@ -783,14 +783,15 @@ __device__ __forceinline__ void orf_serial(const OrfCtx& o, const ChainDesc* __r
 #pragma unroll
         for (int m = 0; m < CS_MODELS; m++) sum[m] = 0.0;
         int far = -1, mer = 0;
-        unsigned long long sm0 = 0, sm1 = 0, sm2 = 0;           // codons that are start nodes (ncod <= CS_LONG = 192)
+        unsigned long long sm0 = 0, sm1 = 0, sm2 = 0;           // codons below CS_LONG = 192 that are start nodes; beyond, the second pass reads the flags again
         // neighbours in the interleaved table?
         const int r0 = rank[chains[o.cc.x + m0].model];
         bool side_by_side = gil != nullptr;
 #pragma unroll
         for (int m = 1; m < CS_MODELS; m++) if (m < nm) side_by_side = side_by_side && rank[chains[o.cc.x + m0 + m].model] == r0 + m;
         const double* __restrict__ row0 = gil + r0;
-        auto visit = [&](const int ci, const int j, const bool isnode) {
+        // one codon: its hexamer `mer` joins the sums; a start node (k = its index in the contig) keeps the sums so far
+        auto visit = [&](const int ci, const bool isnode, const int k) {
             if (quad != nullptr) {
                 const double* q4 = quad + 4 * mer;               // one 32-byte row of LDS: two ds_read_b128
                 sum[0] += q4[0]; sum[1] += q4[1]; sum[2] += q4[2]; sum[3] += q4[3];
@@ -805,38 +806,64 @@ __device__ __forceinline__ void orf_serial(const OrfCtx& o, const ChainDesc* __r
                 for (int m = 0; m < CS_MODELS; m++) if (m < nm) sum[m] += gdc[m][mer];      // a load only where the lane has a model m
             }
             if (isnode) {
-                const int k = o.pre[j] + (strand == 1 ? 0 : o.nf_f[j]) - o.tbase;
 #pragma unroll
                 for (int m = 0; m < CS_MODELS; m++) if (m < nm) csp[m][k] = sum[m];
                 far = ci;
-                if (ci < 64) sm0 |= 1ull << ci; else if (ci < 128) sm1 |= 1ull << (ci - 64); else sm2 |= 1ull << (ci - 128);
+                if (ci < 64) sm0 |= 1ull << ci; else if (ci < 128) sm1 |= 1ull << (ci - 64); else if (ci < CS_LONG) sm2 |= 1ull << (ci - 128);
             }
         };
-        if (o.ncod > 0) { const int j = p + step; mer = hexamer(d, j, strand); visit(0, j, o.nf[j] != 0); }
+        if (o.ncod > 0) {
+            const int j = p + step; mer = hexamer(d, j, strand);
+            const bool isnode = o.nf[j] != 0;
+            visit(0, isnode, isnode ? o.pre[j] - o.tbase : 0);
+        }
         // Five codons at a time: their 15 bases and the start flags of those positions are 16 contiguous bytes each, one
         // (unaligned) load per array instead of four byte loads per codon -- every lane walks its own ORF, so each load
-        // instruction costs the address path 64 distinct lines whatever its width.
+        // instruction costs the address path 64 distinct lines whatever its width.  Nothing a group needs is loaded while the
+        // group is walked: its bases were asked for one group earlier, its flags two groups earlier, and the node indices of its
+        // flagged positions one group earlier (from the flags, by then in registers) -- in lock step some lane meets a start
+        // node at nearly every codon, and a load there would make every codon wait out a memory round trip.
         struct W16 { unsigned long long a, b; };
         auto group_lo = [&](const int c0) { return strand == 1 ? p - 3 * (c0 + 5) : p + 3 * c0 + 1; };       // lowest position of the group
-        // the loads of a group are issued one group ahead: a lone walk would otherwise wait out a memory round trip per five codons
-        W16 Bn{0, 0}, Fn{0, 0};
-        if (o.ncod > 1 && group_lo(1) >= 0) { __builtin_memcpy(&Bn, d + group_lo(1), 16); __builtin_memcpy(&Fn, o.nf + group_lo(1), 16); }
-        for (int c0 = 1; c0 < o.ncod; c0 += 5) {
+        auto byte_of = [](const W16& w, const int k) { return (unsigned)((k < 8 ? w.a >> (8 * k) : w.b >> (8 * (k - 8))) & 0xffull); };
+        auto flag_off = [&](const int u) { return strand == 1 ? 12 - 3 * u : 3 * u + 2; };                 // offset of codon u's node flag in the group
+        W16 B1{0, 0}, F1{0, 0}, F2{0, 0};
+        int kq[5] = {0, 0, 0, 0, 0};
+        const int ncod = o.ncod;
+        // prologue: bases and flags of the first group, flags of the second; then the node indices of the first
+        if (ncod > 1 && group_lo(1) >= 0) { __builtin_memcpy(&B1, d + group_lo(1), 16); __builtin_memcpy(&F1, o.nf + group_lo(1), 16); }
+        if (ncod > 6 && group_lo(6) >= 0) __builtin_memcpy(&F2, o.nf + group_lo(6), 16);
+        if (ncod > 1 && group_lo(1) >= 0) {
+#pragma unroll
+            for (int u = 0; u < 5; u++) if (1 + u < ncod && byte_of(F1, flag_off(u))) kq[u] = o.pre[group_lo(1) + flag_off(u)];
+        }
+        for (int c0 = 1; c0 < ncod; c0 += 5) {
             const int lo = group_lo(c0);
             if (lo < 0) {
                 // the group hangs over the contig's first base (only codons beyond the ORF do): byte loads
-                for (int ci = c0; ci < min(c0 + 5, o.ncod); ci++) {
+                for (int ci = c0; ci < min(c0 + 5, ncod); ci++) {
                     const int j = p + step * (ci + 1);
                     const int lo3 = (d[j] & 3) | ((d[j + 1] & 3) << 2) | ((d[j + 2] & 3) << 4);          // strand == 1 here
                     mer = ((mer << 6) & 0xfc0) | lo3;
-                    visit(ci, j, o.nf[j] != 0);
+                    const bool isnode = o.nf[j] != 0;
+                    visit(ci, isnode, isnode ? o.pre[j] - o.tbase : 0);
                 }
                 continue;
             }
-            const W16 B = Bn, F = Fn;
-            if (c0 + 5 < o.ncod) {
+            // everything of this group is here; ask for what the next groups need
+            const W16 B = B1, F = F1;
+            int kc[5];
+#pragma unroll
+            for (int u = 0; u < 5; u++) kc[u] = kq[u] - o.tbase;
+            F1 = F2;
+            if (c0 + 5 < ncod) {
                 const int lo1 = group_lo(c0 + 5);
-                if (lo1 >= 0) { __builtin_memcpy(&Bn, d + lo1, 16); __builtin_memcpy(&Fn, o.nf + lo1, 16); }
+                if (lo1 >= 0) {
+                    __builtin_memcpy(&B1, d + lo1, 16);
+#pragma unroll
+                    for (int u = 0; u < 5; u++) if (c0 + 5 + u < ncod && byte_of(F1, flag_off(u))) kq[u] = o.pre[lo1 + flag_off(u)];
+                }
+                if (c0 + 10 < ncod) { const int lo2 = group_lo(c0 + 10); if (lo2 >= 0) __builtin_memcpy(&F2, o.nf + lo2, 16); }
             }
             auto bytes_at = [](const W16& w, const int k) {          // the (up to 8) bytes from offset k on, k <= 13
                 return k < 8 ? (w.a >> (8 * k)) | (k ? w.b << (64 - 8 * k) : 0ull) : w.b >> (8 * (k - 8));
@@ -844,7 +871,7 @@ __device__ __forceinline__ void orf_serial(const OrfCtx& o, const ChainDesc* __r
 #pragma unroll
             for (int u = 0; u < 5; u++) {
                 const int ci = c0 + u;
-                if (ci >= o.ncod) break;
+                if (ci >= ncod) break;
                 const int k = strand == 1 ? 12 - 3 * u : 3 * u;             // offset of the codon's lowest position
                 const unsigned t3 = (unsigned)bytes_at(B, k);
                 const int b0 = t3 & 0xff, b1 = (t3 >> 8) & 0xff, b2 = (t3 >> 16) & 0xff;
@@ -852,36 +879,210 @@ __device__ __forceinline__ void orf_serial(const OrfCtx& o, const ChainDesc* __r
                 const int lo3 = strand == 1 ? (b0 & 3) | ((b1 & 3) << 2) | ((b2 & 3) << 4)
                                             : (comp2(b2) & 3) | ((comp2(b1) & 3) << 2) | ((comp2(b0) & 3) << 4);
                 mer = ((mer << 6) & 0xfc0) | lo3;
-                const int kn = strand == 1 ? k : k + 2;                        // offset of the position the node flag sits at
-                visit(ci, lo + kn, ((unsigned)bytes_at(F, kn) & 0xff) != 0);
+                visit(ci, byte_of(F, flag_off(u)) != 0, kc[u]);
             }
         }
         if (far < 0) continue;
         double run_c[CS_MODELS], run_l[CS_MODELS];
 #pragma unroll
         for (int m = 0; m < CS_MODELS; m++) { run_c[m] = -10000.0; run_l[m] = -10000.0; }
-        for (int wsel = 2; wsel >= 0; wsel--) {                 // outermost start first
-            unsigned long long bits = wsel == 2 ? sm2 : (wsel == 1 ? sm1 : sm0);
-            while (bits) {
-                const int bp = 63 - __builtin_clzll(bits);
-                bits &= ~(1ull << bp);
-                const int ci = wsel * 64 + bp;
-                const int j = p + step * (ci + 1);
-                const int k = o.pre[j] + (strand == 1 ? 0 : o.nf_f[j]) - o.tbase;
-#pragma unroll
-                for (int m = 0; m < CS_MODELS; m++) {
-                    if (m >= nm) continue;
-                    double cs = csp[m][k];
-                    if (cs > run_c[m]) run_c[m] = cs; else cs -= (run_c[m] - cs);
-                    double lfac = length_factor(mcp[m], ci + 2);
-                    if (lfac > run_l[m]) run_l[m] = lfac; else lfac -= fmax(fmin(run_l[m] - lfac, lfac), 0.0);
-                    if (lfac > 3.0 && cs < 0.5 * lfac) cs = 0.5 * lfac;
-                    cs += lfac;
-                    csp[m][k] = cs;
+        // the start nodes from the outermost inwards: codons from CS_LONG on by their flags (one 16-byte load per group of five, as
+        // in the first pass), the others from the masks
+        int ci = far, fc0 = -1;
+        W16 G2{0, 0};
+        while (ci >= 0) {
+            if (ci >= CS_LONG) {
+                const int c0 = 1 + 5 * ((ci - 1) / 5), u = ci - c0;
+                const int lo = group_lo(c0);
+                bool isnode;
+                if (lo < 0) isnode = o.nf[p + step * (ci + 1)] != 0;
+                else {
+                    if (c0 != fc0) { __builtin_memcpy(&G2, o.nf + lo, 16); fc0 = c0; }
+                    const int kn = strand == 1 ? 12 - 3 * u : 3 * u + 2;
+                    isnode = ((kn < 8 ? G2.a >> (8 * kn) : G2.b >> (8 * (kn - 8))) & 0xffull) != 0;
                 }
+                if (!isnode) { ci--; continue; }
+            } else {
+                const int wsel = ci >> 6;
+                const unsigned long long bits = (wsel == 2 ? sm2 : (wsel == 1 ? sm1 : sm0)) & ((2ull << (ci & 63)) - 1ull);
+                if (!bits) { ci = wsel * 64 - 1; continue; }
+                ci = wsel * 64 + 63 - __builtin_clzll(bits);
             }
+            const int j = p + step * (ci + 1);
+            const int k = o.pre[j] - o.tbase;
+#pragma unroll
+            for (int m = 0; m < CS_MODELS; m++) {
+                if (m >= nm) continue;
+                double cs = csp[m][k];
+                if (cs > run_c[m]) run_c[m] = cs; else cs -= (run_c[m] - cs);
+                double lfac = length_factor(mcp[m], ci + 2);
+                if (lfac > run_l[m]) run_l[m] = lfac; else lfac -= fmax(fmin(run_l[m] - lfac, lfac), 0.0);
+                if (lfac > 3.0 && cs < 0.5 * lfac) cs = 0.5 * lfac;
+                cs += lfac;
+                csp[m][k] = cs;
+            }
+            ci--;
         }
     }
+}
+
+// orf_serial for k_coding_score_quads: the four table columns [m0, m0 + 4) of the contig's quad sit in LDS (quad[hexamer * 4 + m]).
+// Same sums, same order; written for instruction count, because 64 ORFs walk in lock step and whatever one lane needs at a
+// codon every lane pays for: a group's 16 bases become sixteen 2-bit digits once (in walk order on either strand), its flags
+// sixteen bits; a start node stores all four sums without asking which columns the contig has (the others go to
+// ChainArrays::cs_sink); nothing is loaded inside a group (see orf_serial).
+__device__ __forceinline__ void orf_serial_quad(const OrfCtx& o, const ChainDesc* __restrict__ chains, const ModelScoreConst* __restrict__ msc,
+                                                const ChainArrays& ca, const double* __restrict__ quad, const int m0,
+                                                unsigned long long* __restrict__ prof = nullptr) {
+    unsigned long long tq = prof ? __builtin_readcyclecounter() : 0;
+    auto qmark = [&](const int slot) {
+        if (!prof) return;
+        const unsigned long long now = __builtin_readcyclecounter();
+        if ((threadIdx.x & 63) == 0) atomicAdd(&prof[slot], now - tq);
+        tq = now;
+    };
+    const uint8_t* __restrict__ d = o.d;
+    const int strand = o.strand, step = o.step, p = o.p, ncod = o.ncod;
+    const bool fwd = strand == 1;
+    const int nm = max(0, min(CS_MODELS, o.cc.y - m0));
+    double* csp[CS_MODELS]; const ModelScoreConst* mcp[CS_MODELS];
+#pragma unroll
+    for (int m = 0; m < CS_MODELS; m++) {
+        const ChainDesc ch = chains[o.cc.x + m0 + (m < nm ? m : 0)];
+        csp[m] = m < nm ? ca.cscore_raw + ch.off : ca.cs_sink; mcp[m] = &msc[ch.model];
+    }
+    double sum[CS_MODELS];
+#pragma unroll
+    for (int m = 0; m < CS_MODELS; m++) sum[m] = 0.0;
+    int far = -1, mer = 0;
+    unsigned long long sm0 = 0, sm1 = 0, sm2 = 0;           // codons below CS_LONG = 192 that are start nodes; beyond, the second pass reads the flags again
+    // one codon (ci is the same in every lane): its hexamer joins the sums; a start node (k = its index in the contig) keeps them
+    auto visit = [&](const int ci, const bool isnode, const int k) {
+        const double* q4 = quad + 4 * mer;                   // one 32-byte row of LDS: two ds_read_b128
+        sum[0] += q4[0]; sum[1] += q4[1]; sum[2] += q4[2]; sum[3] += q4[3];
+        if (isnode) { csp[0][k] = sum[0]; csp[1][k] = sum[1]; csp[2][k] = sum[2]; csp[3][k] = sum[3]; }
+        far = isnode ? ci : far;
+        const unsigned long long bit = isnode ? 1ull << (ci & 63) : 0ull;
+        // ci is scalar: three scalar branches (the empty asm statements keep them apart; merged, the masks become a private array in scratch)
+        if (ci < 64) { sm0 |= bit; asm volatile("; mask 0"); } else if (ci < 128) { sm1 |= bit; asm volatile("; mask 1"); }
+        else if (ci < CS_LONG) { sm2 |= bit; asm volatile("; mask 2"); }
+    };
+    if (ncod > 0) {
+        const int j = p + step; mer = hexamer(d, j, strand);
+        const bool isnode = o.nf[j] != 0;
+        visit(0, isnode, isnode ? o.pre[j] - o.tbase : 0);
+    }
+    struct W16 { unsigned long long a, b; };
+    auto group_lo = [&](const int c0) { return fwd ? p - 3 * (c0 + 5) : p + 3 * c0 + 1; };       // lowest position of the group
+    // Codon u of a group: bases at offsets 12 - 3u .. 14 - 3u (forward strand, walking down) or 3u .. 3u + 2 (reverse, walking up,
+    // read back to front and complemented); its node flag at offset 12 - 3u or 3u + 2.  With the reverse strand's sixteen digits
+    // and flags turned end for end both become "13 - 3u (digits: 12 - 3u) counted from the end the walk starts at".
+    auto digits_of = [&](const W16& w) -> unsigned {
+        const uint4 v = make_uint4((unsigned)w.a, (unsigned)(w.a >> 32), (unsigned)w.b, (unsigned)(w.b >> 32));
+        const unsigned q = (unsigned)pack16(v, !fwd);
+        return fwd ? q : pairrev32(q);
+    };
+    auto flags_of = [&](const W16& w) -> unsigned {
+        auto bits4 = [](const unsigned x) { const unsigned n = x & 0x01010101u; return (n | (n >> 7) | (n >> 14) | (n >> 21)) & 0xfu; };
+        const unsigned f = bits4((unsigned)w.a) | (bits4((unsigned)(w.a >> 32)) << 4) | (bits4((unsigned)w.b) << 8) | (bits4((unsigned)(w.b >> 32)) << 12);
+        return fwd ? f : (__brev(f) >> 16);
+    };
+    const int dsh = fwd ? 24 : 26, fsh = fwd ? 12 : 13;       // codon u: digits at bit dsh - 6u, flag at bit fsh - 3u
+    const int foff0 = fwd ? 12 : 2, fstep = fwd ? -3 : 3;     // the flag's byte offset in the group as loaded: foff0 + fstep * u
+    W16 B1{0, 0}, F1{0, 0}, F2{0, 0};
+    int kq[5] = {0, 0, 0, 0, 0};
+    // prologue: bases and flags of the first group, flags of the second; then the node indices of the first
+    if (ncod > 1 && group_lo(1) >= 0) { __builtin_memcpy(&B1, d + group_lo(1), 16); __builtin_memcpy(&F1, o.nf + group_lo(1), 16); }
+    if (ncod > 6 && group_lo(6) >= 0) __builtin_memcpy(&F2, o.nf + group_lo(6), 16);
+    unsigned fb1 = flags_of(F1);
+    if (ncod > 1 && group_lo(1) >= 0) {
+#pragma unroll
+        for (int u = 0; u < 5; u++) if (1 + u < ncod && ((fb1 >> (fsh - 3 * u)) & 1u)) kq[u] = o.pre[group_lo(1) + foff0 + fstep * u];
+    }
+    qmark(10);
+    // the group counter is the same in every lane (scalar): a lane whose ORF has ended idles through the rest, loading nothing
+    int ncod_max = ncod;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) ncod_max = max(ncod_max, __shfl_xor(ncod_max, m, 64));
+    ncod_max = __builtin_amdgcn_readfirstlane(ncod_max);
+    for (int c0 = 1; c0 < ncod_max; c0 += 5) {
+        const int lo = c0 < ncod ? group_lo(c0) : 0;
+        if (lo < 0) {
+            // the group hangs over the contig's first base (only codons beyond the ORF do): byte loads
+            for (int ci = c0; ci < min(c0 + 5, ncod); ci++) {
+                const int j = p + step * (ci + 1);
+                const int lo3 = (d[j] & 3) | ((d[j + 1] & 3) << 2) | ((d[j + 2] & 3) << 4);          // forward strand here
+                mer = ((mer << 6) & 0xfc0) | lo3;
+                const bool isnode = o.nf[j] != 0;
+                visit(ci, isnode, isnode ? o.pre[j] - o.tbase : 0);
+            }
+            continue;
+        }
+        // everything of this group is here; ask for what the next groups need
+        const unsigned dg = digits_of(B1), fb = fb1;
+        int kc[5];
+#pragma unroll
+        for (int u = 0; u < 5; u++) kc[u] = kq[u] - o.tbase;
+        fb1 = flags_of(F2);
+        if (c0 + 5 < ncod) {
+            const int lo1 = group_lo(c0 + 5);
+            if (lo1 >= 0) {
+                __builtin_memcpy(&B1, d + lo1, 16);
+#pragma unroll
+                for (int u = 0; u < 5; u++) if (c0 + 5 + u < ncod && ((fb1 >> (fsh - 3 * u)) & 1u)) kq[u] = o.pre[lo1 + foff0 + fstep * u];
+            }
+            if (c0 + 10 < ncod) { const int lo2 = group_lo(c0 + 10); if (lo2 >= 0) __builtin_memcpy(&F2, o.nf + lo2, 16); }
+        }
+#pragma unroll
+        for (int u = 0; u < 5; u++) {
+            const int ci = c0 + u;
+            // a codon past the ORF's end (last group only) still joins the sums, which nobody reads any more; it is no start node
+            mer = ((mer << 6) & 0xfc0) | ((dg >> (dsh - 6 * u)) & 63u);
+            visit(ci, ci < ncod && ((fb >> (fsh - 3 * u)) & 1u), kc[u]);
+        }
+    }
+    qmark(11);
+    if (far < 0) return;
+    double run_c[CS_MODELS], run_l[CS_MODELS];
+#pragma unroll
+    for (int m = 0; m < CS_MODELS; m++) { run_c[m] = -10000.0; run_l[m] = -10000.0; }
+    // the start nodes from the outermost inwards: codons from CS_LONG on by their flags, the others from the masks
+    int ci = far, fc0 = -1;
+    W16 G2{0, 0};
+    while (ci >= 0) {
+        if (ci >= CS_LONG) {
+            const int c0 = 1 + 5 * ((ci - 1) / 5), u = ci - c0;
+            const int lo = group_lo(c0);
+            bool isnode;
+            if (lo < 0) isnode = o.nf[p + step * (ci + 1)] != 0;
+            else {
+                if (c0 != fc0) { __builtin_memcpy(&G2, o.nf + lo, 16); fc0 = c0; }
+                const int kn = foff0 + fstep * u;
+                isnode = ((kn < 8 ? G2.a >> (8 * kn) : G2.b >> (8 * (kn - 8))) & 0xffull) != 0;
+            }
+            if (!isnode) { ci--; continue; }
+        } else {
+            const int wsel = ci >> 6;
+            const unsigned long long bits = (wsel == 2 ? sm2 : (wsel == 1 ? sm1 : sm0)) & ((2ull << (ci & 63)) - 1ull);
+            if (!bits) { ci = wsel * 64 - 1; continue; }
+            ci = wsel * 64 + 63 - __builtin_clzll(bits);
+        }
+        const int j = p + step * (ci + 1);
+        const int k = o.pre[j] - o.tbase;
+#pragma unroll
+        for (int m = 0; m < CS_MODELS; m++) {
+            if (m >= nm) continue;
+            double cs = csp[m][k];
+            if (cs > run_c[m]) run_c[m] = cs; else cs -= (run_c[m] - cs);
+            double lfac = length_factor(mcp[m], ci + 2);
+            if (lfac > run_l[m]) run_l[m] = lfac; else lfac -= fmax(fmin(run_l[m] - lfac, lfac), 0.0);
+            if (lfac > 3.0 && cs < 0.5 * lfac) cs = 0.5 * lfac;
+            cs += lfac;
+            csp[m][k] = cs;
+        }
+        ci--;
+    }
+    qmark(12);
 }
 
 // the whole wavefront, one (long) ORF; `o` is wave-uniform
@@ -909,7 +1110,7 @@ __device__ __forceinline__ void orf_wave(const OrfCtx& o, const int lane, const 
             const int x = p + step * (ci + 1);
             const int mer = valid ? hexamer(o.d, x, strand) : 0;
             const bool fl = valid && o.nf[x] != 0;
-            const int k = fl ? o.pre[x] + (strand == 1 ? 0 : o.nf_f[x]) - o.tbase : 0;
+            const int k = fl ? o.pre[x] - o.tbase : 0;
             double v[CS_MODELS], pref[CS_MODELS];
 #pragma unroll
             for (int m = 0; m < CS_MODELS; m++) { v[m] = (valid && m < nm) ? (quad != nullptr ? quad[4 * mer + m] : gdc[m][mer]) : 0.0; pref[m] = 0.0; }
@@ -937,7 +1138,7 @@ __device__ __forceinline__ void orf_wave(const OrfCtx& o, const int lane, const 
             const bool valid = ci < ncod;
             const int x = p + step * (ci + 1);
             const bool fl = valid && o.nf[x] != 0;
-            const int k = fl ? o.pre[x] + (strand == 1 ? 0 : o.nf_f[x]) - o.tbase : 0;
+            const int k = fl ? o.pre[x] - o.tbase : 0;
 #pragma unroll
             for (int m = 0; m < CS_MODELS; m++) {
                 if (m >= nm) break;
@@ -958,6 +1159,95 @@ __device__ __forceinline__ void orf_wave(const OrfCtx& o, const int lane, const 
                 carry_c[m] = fmax(carry_c[m], readlane_f64_pl(inc_c, 63));
                 carry_l[m] = fmax(carry_l[m], readlane_f64_pl(inc_l, 63));
             }
+        }
+    }
+}
+
+// Four long ORFs to a wavefront, sixteen lanes each (tables in LDS).  A whole wavefront per ORF (orf_wave) keeps the ordered sum
+// short but pays its 64-step accumulation for one ORF; here the same steps serve four.  `o` is the same in the sixteen lanes of
+// a group, `has` says whether the group holds an ORF at all.  Sums are the reference's: lane s of a group ends a round with
+// carry + v0 + v1 + ... + vs, added in that order.
+__device__ __forceinline__ void orf_quarter(const OrfCtx& o, const bool has, const int lane, const ChainDesc* __restrict__ chains,
+                                            const ModelScoreConst* __restrict__ msc, const ChainArrays& ca, const double* quad, const int m0) {
+    const double NEG_INF = -__builtin_huge_val();
+    const int sl = lane & 15, gb = lane & 48;
+    const int strand = o.strand, step = o.step, p = o.p, ncod = has ? o.ncod : 0;
+    const int nm = has ? max(0, min(CS_MODELS, o.cc.y - m0)) : 0;
+    double* csp[CS_MODELS]; const ModelScoreConst* mcp[CS_MODELS];
+#pragma unroll
+    for (int m = 0; m < CS_MODELS; m++) {
+        const ChainDesc ch = chains[has ? o.cc.x + m0 + (m < nm ? m : 0) : 0];
+        csp[m] = ca.cscore_raw + ch.off; mcp[m] = &msc[ch.model];
+    }
+    double carry[CS_MODELS];
+#pragma unroll
+    for (int m = 0; m < CS_MODELS; m++) carry[m] = 0.0;
+    bool any_start = false;
+    for (int c0 = 0; __any(c0 < ncod); c0 += 16) {
+        const int ci = c0 + sl;
+        const bool valid = ci < ncod;
+        const int x = p + step * (ci + 1);
+        const int mer = valid ? hexamer(o.d, x, strand) : 0;
+        const bool fl = valid && o.nf[x] != 0;
+        const int k = fl ? o.pre[x] - o.tbase : 0;
+        double v[CS_MODELS], acc[CS_MODELS];
+#pragma unroll
+        for (int m = 0; m < CS_MODELS; m++) { v[m] = (valid && m < nm) ? quad[4 * mer + m] : 0.0; acc[m] = carry[m]; }
+#pragma unroll
+        for (int l = 0; l < 16; l++) {
+            double t[CS_MODELS];
+#pragma unroll
+            for (int m = 0; m < CS_MODELS; m++) t[m] = __shfl(v[m], gb | l, 64);
+            if (sl >= l) {
+#pragma unroll
+                for (int m = 0; m < CS_MODELS; m++) acc[m] += t[m];
+            }
+        }
+        const int lastv = max(0, min(15, ncod - 1 - c0));
+#pragma unroll
+        for (int m = 0; m < CS_MODELS; m++) { const double nc = __shfl(acc[m], gb | lastv, 64); if (c0 < ncod) carry[m] = nc; }
+        if (fl) {
+#pragma unroll
+            for (int m = 0; m < CS_MODELS; m++) if (m < nm) csp[m][k] = acc[m];
+        }
+        any_start = any_start || fl;
+    }
+    // penalties from the outermost start inwards (ref: lib.pyx:2182-2239), sixteen codons of a group at a time
+    const bool grp_start = ((__ballot(any_start) >> gb) & 0xffffull) != 0ull;
+    const int top = grp_start ? ((ncod - 1) >> 4) << 4 : -16;
+    double carry_c[CS_MODELS], carry_l[CS_MODELS];
+#pragma unroll
+    for (int m = 0; m < CS_MODELS; m++) { carry_c[m] = -10000.0; carry_l[m] = -10000.0; }
+    for (int c0 = top; __any(c0 >= 0); c0 -= 16) {
+        const int ci = c0 + (15 - sl);              // lane order = outermost first
+        const bool valid = c0 >= 0 && ci < ncod;
+        const int x = p + step * (ci + 1);
+        const bool fl = valid && o.nf[x] != 0;
+        const int k = fl ? o.pre[x] - o.tbase : 0;
+#pragma unroll
+        for (int m = 0; m < CS_MODELS; m++) {
+            const bool mine = fl && m < nm;
+            const double cs0 = mine ? csp[m][k] : NEG_INF;
+            const double lf0 = mine ? length_factor(mcp[m], ci + 2) : NEG_INF;
+            double inc_c = cs0, inc_l = lf0;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                const double a = __shfl_up(inc_c, off, 16), b = __shfl_up(inc_l, off, 16);
+                if (sl >= off) { inc_c = fmax(inc_c, a); inc_l = fmax(inc_l, b); }
+            }
+            double ex_c = __shfl_up(inc_c, 1, 16), ex_l = __shfl_up(inc_l, 1, 16);
+            if (sl == 0) { ex_c = NEG_INF; ex_l = NEG_INF; }
+            const double run_c = fmax(ex_c, carry_c[m]), run_l = fmax(ex_l, carry_l[m]);
+            if (mine) {
+                double cs = cs0, lfac = lf0;
+                if (!(cs > run_c)) cs -= (run_c - cs);
+                if (!(lfac > run_l)) lfac -= fmax(fmin(run_l - lfac, lfac), 0.0);
+                if (lfac > 3.0 && cs < 0.5 * lfac) cs = 0.5 * lfac;
+                cs += lfac;
+                csp[m][k] = cs;
+            }
+            carry_c[m] = fmax(carry_c[m], __shfl(inc_c, gb | 15, 64));
+            carry_l[m] = fmax(carry_l[m], __shfl(inc_l, gb | 15, 64));
         }
     }
 }
@@ -994,8 +1284,8 @@ k_coding_score(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
         const ContigDesc cd = ct[c];
         o.d = dig + cd.base;
         o.strand = ga.strand[t];
-        o.nf = (o.strand == 1 ? ga.nf_fwd : ga.nf_rev) + cd.base; o.nf_f = ga.nf_fwd + cd.base;
-        o.pre = ga.pre_nodes + cd.base;
+        o.nf = (o.strand == 1 ? ga.nf_fwd : ga.nf_rev) + cd.base;
+        o.pre = (o.strand == 1 ? ga.pre_nodes : ga.pre_rev) + cd.base;
         o.tbase = node_contig_base[c];
         o.p = ga.ndx[t]; o.q = ga.stop_val[t]; o.L = cd.len;
         o.step = o.strand == 1 ? -3 : 3;
@@ -1019,13 +1309,13 @@ k_coding_score(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
         const int src = __builtin_ctzll(longs);
         longs &= longs - 1ull;
         OrfCtx w;
-        const unsigned long long pd = (unsigned long long)o.d, pn = (unsigned long long)o.nf, pf = (unsigned long long)o.nf_f, pp = (unsigned long long)o.pre;
+        const unsigned long long pd = (unsigned long long)o.d, pn = (unsigned long long)o.nf, pp = (unsigned long long)o.pre;
         auto bc64 = [&](unsigned long long v) {
             const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
             const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
             return ((unsigned long long)hi << 32) | lo;
         };
-        w.d = (const uint8_t*)bc64(pd); w.nf = (const uint8_t*)bc64(pn); w.nf_f = (const uint8_t*)bc64(pf); w.pre = (const int32_t*)bc64(pp);
+        w.d = (const uint8_t*)bc64(pd); w.nf = (const uint8_t*)bc64(pn); w.pre = (const int32_t*)bc64(pp);
         w.tbase = __builtin_amdgcn_readlane(o.tbase, src); w.p = __builtin_amdgcn_readlane(o.p, src); w.q = __builtin_amdgcn_readlane(o.q, src);
         w.L = __builtin_amdgcn_readlane(o.L, src); w.strand = __builtin_amdgcn_readlane(o.strand, src); w.step = __builtin_amdgcn_readlane(o.step, src);
         w.ncod = __builtin_amdgcn_readlane(o.ncod, src);
@@ -1045,20 +1335,30 @@ constexpr int CS_TASK_THREADS = 1024;
 constexpr int CS_TASK_MAX_ENTRIES = 256;
 constexpr int CS_ROUND = 8192;                         // nodes examined per round of a task (= the task size pga_cs_tasks aims at)
 constexpr int CS_LIST = 6144;                          // stop nodes of a round: at most half of its nodes (every ORF with a stop node has a start node) + a few at its edges
-constexpr int CS_CLASSES = 8;                          // ORF length classes of a round
+constexpr int CS_CLASSES = 12;                         // ORF length classes of a round
+constexpr int CS_WAVE = 2048;                          // ORFs longer than this take a whole wave (orf_wave); the others walk 64 to a wave
 __global__ void __launch_bounds__(CS_TASK_THREADS)
 k_coding_score_quads(const CsTask* __restrict__ tasks, const CsEntry* __restrict__ entries, const ChainDesc* __restrict__ chains,
                      const int2* __restrict__ contig_chains, const int32_t* __restrict__ node_contig_base,
                      const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct, GroupArrays ga,
                      const pga_training* __restrict__ models, const ModelScoreConst* __restrict__ msc, ChainArrays ca,
-                     const double* __restrict__ gil, int il_stride, const int32_t* __restrict__ rank) {
+                     const double* __restrict__ gil, int il_stride, const int32_t* __restrict__ rank, const int cs_wave, unsigned long long* __restrict__ prof) {
     extern __shared__ __attribute__((aligned(16))) double s_quad[];                  // [4096][4]
     __shared__ int s_pre[CS_TASK_MAX_ENTRIES + 1];      // first node (task-local numbering) of every entry
     __shared__ int s_list[CS_LIST];
-    __shared__ int s_count, s_next_long, s_next;
+    __shared__ int s_count, s_next_long, s_next_q, s_next, s_qend;
     __shared__ int s_cls[CS_CLASSES];
     const CsTask task = tasks[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // PGA_CS_PROFILE=1: cycles per phase, summed over the waves of all workgroups (slot 7: workgroups)
+    unsigned long long tp = prof ? __builtin_readcyclecounter() : 0;
+    auto mark = [&](const int slot) {
+        if (!prof) return;
+        const unsigned long long now = __builtin_readcyclecounter();
+        if (lane == 0) atomicAdd(&prof[slot], now - tp);
+        tp = now;
+    };
+    if (prof && tid == 0) atomicAdd(&prof[7], 1ull);
     for (int idx = tid; idx < 4096 * 4; idx += CS_TASK_THREADS) {
         const int h = idx >> 2, k = idx & 3;
         s_quad[idx] = task.q + k < il_stride ? gil[(size_t)h * il_stride + task.q + k] : 0.0;
@@ -1072,6 +1372,7 @@ k_coding_score_quads(const CsTask* __restrict__ tasks, const CsEntry* __restrict
         s_pre[task.count] = acc;
     }
     __syncthreads();
+    mark(0);
     const int total = s_pre[task.count];
     // Rounds of CS_ROUND nodes: every thread looks at CS_ROUND / 1024 nodes, the stop nodes among them (about one node in five) are
     // listed in LDS, then each wave takes 64 entries of the list at a time -- all sixteen waves walk, whatever the mix of nodes.
@@ -1093,7 +1394,8 @@ k_coding_score_quads(const CsTask* __restrict__ tasks, const CsEntry* __restrict
             if (ga.type[t] != PGA_T_STOP) continue;
             const int ncod = orf_codons(ga.ndx[t], ga.stop_val[t], ga.strand[t], ct[c].len);
             if (ncod <= 0) continue;
-            my_cls[r] = ncod > CS_LONG ? 0 : (ncod > 128 ? 1 : (ncod > 64 ? 2 : (ncod > 32 ? 3 : (ncod > 16 ? 4 : (ncod > 8 ? 5 : 6)))));
+            my_cls[r] = ncod > cs_wave ? 0 : ncod > 512 ? 1 : ncod > 384 ? 2 : ncod > 256 ? 3 : ncod > 192 ? 4 : ncod > 128 ? 5 : ncod > 96 ? 6 :
+                        ncod > 64 ? 7 : ncod > 48 ? 8 : ncod > 32 ? 9 : ncod > 16 ? 10 : 11;
             atomicAdd(&s_cls[my_cls[r]], 1);
         }
         __syncthreads();
@@ -1101,13 +1403,15 @@ k_coding_score_quads(const CsTask* __restrict__ tasks, const CsEntry* __restrict
             int acc = 0;
             for (int k = 0; k < CS_CLASSES; k++) { const int n = s_cls[k]; s_cls[k] = acc; acc += n; }
             if (acc > CS_LIST) __builtin_trap();             // cannot happen (see CS_LIST); never write past the list
-            s_count = acc; s_next_long = 0; s_next = s_cls[1];   // s_cls[1] = number of long ORFs = where the others begin
+            // classes 0: a wave each; 1 .. 4 (longer than CS_LONG): four to a wave; the others 64 to a wave
+            s_count = acc; s_next_long = 0; s_next_q = s_cls[1]; s_qend = s_cls[5]; s_next = s_cls[5];
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < CS_ROUND / CS_TASK_THREADS; r++)
             if (my_cls[r] >= 0) s_list[atomicAdd(&s_cls[my_cls[r]], 1)] = base + tid + r * CS_TASK_THREADS;
         __syncthreads();
+        mark(1);
         const int cnt = s_count, n_long = s_cls[0];       // after the placement s_cls[k] is where class k ends
         auto orf_of = [&](const int loc, int& m0) {
             OrfCtx o{};
@@ -1121,8 +1425,8 @@ k_coding_score_quads(const CsTask* __restrict__ tasks, const CsEntry* __restrict
             const ContigDesc cd = ct[c];
             o.d = dig + cd.base;
             o.strand = ga.strand[tt];
-            o.nf = (o.strand == 1 ? ga.nf_fwd : ga.nf_rev) + cd.base; o.nf_f = ga.nf_fwd + cd.base;
-            o.pre = ga.pre_nodes + cd.base;
+            o.nf = (o.strand == 1 ? ga.nf_fwd : ga.nf_rev) + cd.base;
+            o.pre = (o.strand == 1 ? ga.pre_nodes : ga.pre_rev) + cd.base;
             o.tbase = node_contig_base[c];
             o.p = ga.ndx[tt]; o.q = ga.stop_val[tt]; o.L = cd.len;
             o.step = o.strand == 1 ? -3 : 3;
@@ -1140,6 +1444,22 @@ k_coding_score_quads(const CsTask* __restrict__ tasks, const CsEntry* __restrict
             const OrfCtx w = orf_of(s_list[k], m0);          // the same entry in every lane
             if (w.ncod > 0) orf_wave(w, lane, chains, models, msc, ca, s_quad, m0, m0 + 4);
         }
+        mark(2);
+        // long ORFs, four to a wave
+        const int q_end = s_qend;
+        for (;;) {
+            int k = 0;
+            if (lane == 0) k = atomicAdd(&s_next_q, 4);
+            k = __builtin_amdgcn_readfirstlane(k);
+            if (k >= q_end) break;
+            const int e = k + (lane >> 4);
+            int m0 = 0;
+            OrfCtx o{};
+            const bool has = e < q_end;
+            if (has) o = orf_of(s_list[e], m0);
+            orf_quarter(o, has && o.ncod > 0, lane, chains, msc, ca, s_quad, m0);
+        }
+        mark(3);
         // the others, 64 of similar length per wave, longest class first
         for (;;) {
             int lb = 0;
@@ -1149,10 +1469,14 @@ k_coding_score_quads(const CsTask* __restrict__ tasks, const CsEntry* __restrict
             if (lb + lane < cnt) {
                 int m0;
                 const OrfCtx o = orf_of(s_list[lb + lane], m0);
-                if (o.ncod > 0) orf_serial(o, chains, models, msc, ca, nullptr, 0, rank, s_quad, m0, m0 + 4);
+                if (prof && lane == 0) atomicAdd(&prof[9], __builtin_readcyclecounter() - tp);
+                if (o.ncod > 0) orf_serial_quad(o, chains, msc, ca, s_quad, m0, prof);
             }
+            if (prof && lane == 0) atomicAdd(&prof[8], 1ull);
         }
+        mark(4);
         __syncthreads();
+        mark(5);
     }
 }
 
@@ -1812,10 +2136,26 @@ void pga_launch_score(const ChainDesc* d_chains, int n_chains, int64_t node_begi
         // the ORF walks against hexamer tables in LDS (tasks built by the caller, pga_cs_tasks)
         static bool once = false;
         const size_t lds = sizeof(double) * 4096 * 4;
-        if (!once) { hipFuncSetAttribute((const void*)k_coding_score_quads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+        static int cs_wave = CS_WAVE;
+        if (!once) {
+            hipFuncSetAttribute((const void*)k_coding_score_quads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true;
+            if (const char* e = getenv("PGA_CS_WAVE")) cs_wave = atoi(e) >= 64 ? atoi(e) : CS_WAVE;
+        }
+        static unsigned long long* d_prof = nullptr;
+        const bool profiling = getenv("PGA_CS_PROFILE") != nullptr;
+        if (profiling) { if (!d_prof) (void)hipMalloc((void**)&d_prof, 16 * sizeof(unsigned long long)); (void)hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), st); }
         hipLaunchKernelGGL(k_coding_score_quads, dim3((unsigned)n_cs_tasks), dim3(CS_TASK_THREADS), lds, st, (const CsTask*)d_cs_tasks,
                            (const CsEntry*)d_cs_entries, d_all_chains, d_contig_chains, d_node_contig_base, d_dig, d_ct, ga, d_models, d_msc, ca,
-                           d_gil, il_stride, d_rank);
+                           d_gil, il_stride, d_rank, cs_wave, profiling ? d_prof : nullptr);
+        if (profiling) {
+            unsigned long long h[16];
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(h, d_prof, sizeof h, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[pga cs-profile] %d tasks (%llu workgroups, %llu batches of 64): wave-cycles  stage %.3g  list %.3g  one-wave ORFs %.3g  "
+                            "four-to-a-wave %.3g  64-to-a-wave %.3g (lookup %.3g  first loads %.3g  walk %.3g  penalties %.3g)  end barrier %.3g\n",
+                    n_cs_tasks, h[7], h[8], (double)h[0], (double)h[1], (double)h[2], (double)h[3], (double)h[4], (double)h[9], (double)h[10], (double)h[11],
+                    (double)h[12], (double)h[5]);
+        }
         reuse_raw_cscore = 1;           // done: skip the global-memory form below
     }
     // the raw coding score of a start depends on the model only, not on which model of the group was scored first on the
