@@ -1330,7 +1330,7 @@ k_coding_score(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
 // ORF of its contigs against them: a codon step is two ds_read_b128 instead of two 64-line gathers through the texture
 // path, which is what bounds the global-memory form (every lane walks its own ORF).
 struct CsTask { int32_t q, first, count, _pad; };      // columns q .. q+3; entries [first, first + count)
-struct CsEntry { int32_t contig, m0; };
+struct CsEntry { int32_t contig, m0, first, count; };      // nodes [first, first + count) of the contig (a large contig is cut into several entries)
 constexpr int CS_TASK_THREADS = 1024;
 constexpr int CS_TASK_MAX_ENTRIES = 256;
 constexpr int CS_ROUND = 8192;                         // nodes examined per round of a task (= the task size pga_cs_tasks aims at)
@@ -1366,8 +1366,7 @@ k_coding_score_quads(const CsTask* __restrict__ tasks, const CsEntry* __restrict
     if (tid == 0) {
         int acc = 0;
         for (int e = 0; e < task.count; e++) {
-            const int c = entries[task.first + e].contig;
-            s_pre[e] = acc; acc += node_contig_base[c + 1] - node_contig_base[c];
+            s_pre[e] = acc; acc += entries[task.first + e].count;
         }
         s_pre[task.count] = acc;
     }
@@ -1389,8 +1388,9 @@ k_coding_score_quads(const CsTask* __restrict__ tasks, const CsEntry* __restrict
             if (local >= total) continue;
             int lo = 0, hi = task.count - 1;
             while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_pre[mid] <= local) lo = mid; else hi = mid - 1; }
-            const int c = entries[task.first + lo].contig;
-            const int t = node_contig_base[c] + (local - s_pre[lo]);
+            const CsEntry en = entries[task.first + lo];
+            const int c = en.contig;
+            const int t = node_contig_base[c] + en.first + (local - s_pre[lo]);
             if (ga.type[t] != PGA_T_STOP) continue;
             const int ncod = orf_codons(ga.ndx[t], ga.stop_val[t], ga.strand[t], ct[c].len);
             if (ncod <= 0) continue;
@@ -1420,7 +1420,7 @@ k_coding_score_quads(const CsTask* __restrict__ tasks, const CsEntry* __restrict
             const CsEntry en = entries[task.first + lo];
             const int c = en.contig;
             m0 = en.m0;
-            const int tt = node_contig_base[c] + (loc - s_pre[lo]);
+            const int tt = node_contig_base[c] + en.first + (loc - s_pre[lo]);
             o.cc = contig_chains[c];
             const ContigDesc cd = ct[c];
             o.d = dig + cd.base;
@@ -2059,7 +2059,7 @@ int pga_extract_tile_size() { return EX_TILE; }
 // of the group's interleaved table, in runs of about `task_nodes` nodes.  Returns false (and leaves the outputs empty) when
 // some contig's models are not neighbours in the table: the caller then takes the global-memory form.
 bool pga_cs_tasks(const int2* h_cc /* per contig: first chain, count */, int n_contigs, const ChainDesc* h_chains, const int32_t* h_cbase,
-                  const int32_t* model_rank, int task_nodes, std::vector<int32_t>& tasks /* 4 per task */, std::vector<int32_t>& entries /* 2 per entry */) {
+                  const int32_t* model_rank, int task_nodes, std::vector<int32_t>& tasks /* 4 per task */, std::vector<int32_t>& entries /* 4 per entry */) {
     tasks.clear(); entries.clear();
     std::vector<std::vector<int32_t>> bucket(64);
     for (int i = 0; i < n_contigs; i++) {
@@ -2074,18 +2074,23 @@ bool pga_cs_tasks(const int2* h_cc /* per contig: first chain, count */, int n_c
     }
     for (int q = 0; q < 64; q++) {
         const std::vector<int32_t>& b = bucket[(size_t)q];
-        int first = (int)(entries.size() / 2), count = 0, nodes = 0;
+        int first = (int)(entries.size() / 4), count = 0, nodes = 0;
+        auto flush = [&]() {
+            if (count > 0) { tasks.push_back(q); tasks.push_back(first); tasks.push_back(count); tasks.push_back(0); }
+            first += count; count = 0; nodes = 0;
+        };
         for (size_t k = 0; k < b.size(); k += 2) {
+            // a task is one round of the kernel (at most task_nodes nodes): a contig with more is cut into pieces, a genome becomes
+            // hundreds of tasks instead of one
             const int nc = h_cbase[b[k] + 1] - h_cbase[b[k]];
-            // a task is one round of the kernel (task_nodes nodes) unless a single contig is larger
-            if (count > 0 && (nodes + nc > task_nodes || count == CS_TASK_MAX_ENTRIES)) {
-                tasks.push_back(q); tasks.push_back(first); tasks.push_back(count); tasks.push_back(0);
-                first += count; count = 0; nodes = 0;
+            for (int f0 = 0; f0 < nc; f0 += task_nodes) {
+                const int piece = std::min(task_nodes, nc - f0);
+                if (count > 0 && (nodes + piece > task_nodes || count == CS_TASK_MAX_ENTRIES)) flush();
+                entries.push_back(b[k]); entries.push_back(b[k + 1]); entries.push_back(f0); entries.push_back(piece);
+                count++; nodes += piece;
             }
-            entries.push_back(b[k]); entries.push_back(b[k + 1]);
-            count++; nodes += nc;
         }
-        if (count > 0) { tasks.push_back(q); tasks.push_back(first); tasks.push_back(count); tasks.push_back(0); }
+        flush();
     }
     return true;
 }

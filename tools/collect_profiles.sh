@@ -21,7 +21,7 @@ for WL in config3 config4; do
     ARGS="--workload $WL $COMMON"
     [ $WL = config4 ] && ARGS="--workload config4 --contigs 12500 $COMMON"
     ( cd /tmp && timeout -k 5 240 rocprofv3 --kernel-trace --stats -d "$OUT/trace_$WL" -o t -- \
-        python "$REPO/bench.py" $ARGS --steps 6 --warmup 2 > "$OUT/bench_$WL.json" 2> "$OUT/trace_$WL.log" )
+        python "$REPO/bench.py" $ARGS --steps 4 --warmup 2 > "$OUT/bench_$WL.json" 2> "$OUT/trace_$WL.log" )
     for C in FETCH_SIZE WRITE_SIZE; do
         ( cd /tmp && timeout -k 5 240 rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_${WL}_$C" -o p -- \
             python "$REPO/bench.py" $ARGS --steps 2 --warmup 1 > /dev/null 2> "$OUT/pmc_${WL}_$C.log" )

@@ -11,6 +11,6 @@ print("# %s\n" % title)
 print("Source: `rocprofv3 --kernel-trace --stats` (durations in microseconds).\n")
 print("| kernel | calls | total us | avg us | % |\n|---|---|---|---|---|")
 for name, calls, tot, avg, pct in rows:
-    m = re.search(r"(k_\w+(<\d+>)?)", name)
-    short = m.group(1) if m else name.split("(")[0]
+    m = re.search(r"(k_\w+)(<[^>]*>)?", name)
+    short = m.group(1) if m else name.split("(")[0]          # template arguments dropped: k_dp_wave<6> is k_dp_wave
     print("| %s | %d | %.1f | %.1f | %.2f |" % (short, calls, tot, avg, pct))
