@@ -256,7 +256,9 @@ __device__ __forceinline__ void wave_step(const SrcRegs& R, const int u, const i
     if (in_mask(take)) { L.val = val; L.tag = tag; }
 }
 
-template <int OCC>      // wavefronts per SIMD the register budget is cut for
+// OCC: wavefronts per SIMD the register budget is cut for.  4 = 125 VGPRs, nothing spilled (the default); 5 and 6 (PGA_DPW_OCC) run
+// 2 % and 5 % faster on config 4 but spill 112 / 148 bytes per lane, which shows up as four times the HBM traffic.
+template <int OCC>
 __global__ void __launch_bounds__(64, OCC)
 k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const double* __restrict__ g_cs, const DpwExt* __restrict__ g_ext,
           const ModelConst* __restrict__ models, DpBuffers buf, double* __restrict__ g_sfxv, int32_t* __restrict__ g_sfxi) {
@@ -547,7 +549,7 @@ void pga_launch_dp_wave(const ChainDesc* d_chains, int n_chains, const DpwGroupP
                         const DpwBuffers& wb, hipStream_t st) {
     if (n_chains <= 0) return;
     static int occ = 0;
-    if (!occ) { const char* e = getenv("PGA_DPW_OCC"); occ = e ? atoi(e) : 6; if (occ < 4 || occ > 6) occ = 6; }
+    if (!occ) { const char* e = getenv("PGA_DPW_OCC"); occ = e ? atoi(e) : 4; if (occ < 4 || occ > 6) occ = 4; }
     if (occ == 5) hipLaunchKernelGGL(k_dp_wave<5>, dim3((unsigned)n_chains), dim3(64), 0, st, d_chains, groups, (const double*)wb.cs, (const DpwExt*)wb.ext,
                                      d_models, buf, wb.sfxv, wb.sfxi);
     else if (occ == 6) hipLaunchKernelGGL(k_dp_wave<6>, dim3((unsigned)n_chains), dim3(64), 0, st, d_chains, groups, (const double*)wb.cs, (const DpwExt*)wb.ext,
