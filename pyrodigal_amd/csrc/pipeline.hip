@@ -1632,13 +1632,28 @@ __device__ __forceinline__ int sd_pick(unsigned hits, const double* __restrict__
 // The reference mutates node.edge while it scans (lib.pyx:2424-2434) and the flag survives into
 // the next model of a meta run; `first` and the index comparisons below reproduce the value each
 // read would have seen.
-__global__ void __launch_bounds__(256, 5)
+// What the start scorer reads of a model, staged in LDS once per workgroup and model: every thread of a workgroup scores its node
+// for the same model at the same time (a workgroup is 256 consecutive nodes, nearly always of one or two contigs), so the
+// 32 upstream-composition weights, the RBS weights and the two small motif tables (3- and 4-base motifs: 26 of the 52 lookups
+// of the motif search) come from LDS instead of 60 gathers per node and model.
+struct StartModel {
+    double st_wt, no_mot;
+    int tt, uses_sd;
+    double type_wt[3];
+    double rbs_wt[28];
+    double ups[32][4];
+    double mk0[4][64];      // mot_wt[0][spacer class][3-base motif]
+    double mk1[4][256];     // mot_wt[1][spacer class][4-base motif]
+};
+
+__global__ void __launch_bounds__(256, 4)
 k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ contig_chains,
                const int32_t* __restrict__ node_contig_base, int n_contigs, int n_nodes,
                const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct, GroupArrays ga,
                const pga_training* __restrict__ models, ChainArrays ca, ScoreParams sp, const unsigned* __restrict__ sd_lut) {
-    __shared__ int s_c0;
+    __shared__ int s_c0, s_mlo, s_mhi;
     __shared__ unsigned s_lut[PGA_SD_LUT];
+    __shared__ StartModel SM;
     for (int k = threadIdx.x; k < PGA_SD_LUT; k += blockDim.x) s_lut[k] = sd_lut[k];
     const int blk0 = blockIdx.x * blockDim.x;
     const int t = blk0 + threadIdx.x;
@@ -1646,46 +1661,45 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
     if (threadIdx.x == 0) {
         int lo = 0, hi = n_contigs - 1;
         while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (node_contig_base[mid] <= blk0) lo = mid; else hi = mid - 1; }
-        s_c0 = lo;
+        s_c0 = lo; s_mlo = 0x7fffffff; s_mhi = -1;
     }
     __syncthreads();
-    if (t >= n_nodes) return;
     int c = s_c0;
-    while (c + 1 < n_contigs && node_contig_base[c + 1] <= t) c++;
-    const int2 cc = contig_chains[c];
-    if (cc.y <= 0) return;
+    const bool in_range = t < n_nodes;
+    if (in_range) while (c + 1 < n_contigs && node_contig_base[c + 1] <= t) c++;
+    const int2 cc = in_range ? contig_chains[c] : make_int2(0, 0);
+    const bool has = in_range && cc.y > 0;
+    // the models this workgroup scores: from the first model of its first chain to the last of its last
+    if (has) { atomicMin(&s_mlo, chains[cc.x].model); atomicMax(&s_mhi, chains[cc.x + cc.y - 1].model); }
     const int tbase = node_contig_base[c];
-    const int i = t - tbase, n = node_contig_base[c + 1] - tbase;
-    const int type = ga.type[t];
-    const int e0 = ga.edge0[t];
-    if (type == PGA_T_STOP) {      // stop nodes carry no start scores (reset_node_scores)
-        for (int m = 0; m < cc.y; m++) {
-            const int64_t g = chains[cc.x + m].off + i;
-            ca.edge[g] = (uint8_t)e0;
-            ca.cscore[g] = 0.0; ca.sscore[g] = 0.0; ca.rscore[g] = 0.0; ca.uscore[g] = 0.0; ca.tscore[g] = 0.0; ca.mot_score[g] = 0.0;
-            ca.mot_ndx[g] = 0; ca.mot_len[g] = 0; ca.mot_spacer[g] = 0; ca.mot_spacendx[g] = 0; ca.rbs[2 * g] = 0; ca.rbs[2 * g + 1] = 0;
-            if (sp.cs_out != nullptr) sp.cs_out[g] = 0.0;
-        }
-        return;
-    }
-    const ContigDesc cd = ct[c];
-    const int L = cd.len;
-    const uint8_t* __restrict__ d = dig + cd.base;
-    const int ndx = ga.ndx[t], sv = ga.stop_val[t], strand = ga.strand[t];
+    const int i = t - tbase, n = has ? node_contig_base[c + 1] - tbase : 1;
+    const int type = has ? ga.type[t] : PGA_T_STOP;
+    const int e0 = has ? ga.edge0[t] : 0;
+    const bool is_start = has && type != PGA_T_STOP;
     const bool closed = sp.closed != 0, is_meta = sp.is_meta != 0;
+    // ---- what does not depend on the model (start nodes only)
+    int L = 3, ndx = 0, sv = 0, strand = 1, start = 0;
+    const uint8_t* __restrict__ d = dig;
+    bool conv = false, ups_first = false, ups_later = false, ups_near_edge = false;
+    UpWin W{0, 0, 0, 0, 0};
+    long orf = 1;
+    if (is_start) {
+    const ContigDesc cd = ct[c];
+    L = cd.len;
+    d = dig + cd.base;
+    ndx = ga.ndx[t]; sv = ga.stop_val[t]; strand = ga.strand[t];
     auto convertible = [&](int k) -> bool {
         if (closed || ga.type[tbase + k] == PGA_T_STOP || ga.edge0[tbase + k]) return false;
         const int x = ga.ndx[tbase + k], s = ga.strand[tbase + k];
         return (x <= 2 && s == 1) || (x >= L - 3 && s == -1);
     };
-    const bool conv = convertible(i);
+    conv = convertible(i);
     if (conv && sp.conv_flag != nullptr) sp.conv_flag[c] = 1;
-    const int start = strand == 1 ? ndx : L - 1 - ndx;     // strand-local start position
-    const UpWin W = load_upwin(d, L, start, strand);
-    const long orf = ndx > sv ? ndx - sv : sv - ndx;
+    start = strand == 1 ? ndx : L - 1 - ndx;     // strand-local start position
+    W = load_upwin(d, L, start, strand);
+    orf = ndx > sv ? ndx - sv : sv - ndx;
     // does an edge node share this ORF?  (lib.pyx:2413-2422; the answer depends on whether the edge
     // conversion of this pass has already reached that node, hence the two variants)
-    bool ups_first = false, ups_later = false, ups_near_edge = false;
     if (!closed && ndx <= 2 && strand == 1) ups_near_edge = true;
     else if (!closed && ndx >= L - 3 && strand == -1) ups_near_edge = true;
     else if ((i < 500 && strand == 1) || (i + 500 >= n && strand == -1)) {
@@ -1703,18 +1717,47 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
             else if (convertible(j)) { if (strand == 1) ups_first = true; ups_later = true; }   // after i: counts only once an earlier model of the run converted it
         }
     }
+    }
     int tt_cached = -1; bool stop_missing = false;
-
     // per search window of the RBS search: the six "is the A / G of AGGAGG there" bits (five windows per word); the bins that
     // match come from the table in LDS when a model asks
     bool have_pats = false;
     unsigned pats[3] = {0u, 0u, 0u};
-    for (int m = 0; m < cc.y; m++) {
-        const ChainDesc ch = chains[cc.x + m];
-        const int64_t g = ch.off + i;
-        const pga_training* __restrict__ tm = &models[ch.model];
-        const double st_wt = tm->st_wt;
-        const int tt = tm->trans_table;
+    __syncthreads();
+    const int mlo = s_mlo, mhi = s_mhi;
+    int mi = 0;                                                 // the thread's next chain
+    int next_model = has ? chains[cc.x].model : 0x7fffffff;
+    for (int mm = mlo; mm <= mhi; mm++) {
+        const bool mine = next_model == mm;
+        if (!__syncthreads_or(mine)) continue;                  // nobody here scores model mm (its GC window excludes these contigs)
+        {   // stage the model
+            const pga_training* __restrict__ tmg = &models[mm];
+            const int tid = threadIdx.x;
+            if (tid == 0) { SM.st_wt = tmg->st_wt; SM.no_mot = tmg->no_mot; SM.tt = tmg->trans_table; SM.uses_sd = tmg->uses_sd; }
+            if (tid < 3) SM.type_wt[tid] = tmg->type_wt[tid];
+            if (tid < 28) SM.rbs_wt[tid] = tmg->rbs_wt[tid];
+            if (tid >= 128) (&SM.ups[0][0])[tid - 128] = (&tmg->ups_comp[0][0])[tid - 128];
+            if (!tmg->uses_sd) {
+                SM.mk0[tid >> 6][tid & 63] = tmg->mot_wt[0][tid >> 6][tid & 63];
+#pragma unroll
+                for (int r = 0; r < 4; r++) { const int e = tid + 256 * r; SM.mk1[e >> 8][e & 255] = tmg->mot_wt[1][e >> 8][e & 255]; }
+            }
+        }
+        __syncthreads();
+        if (mine) {
+            const ChainDesc ch = chains[cc.x + mi];
+            const int64_t g = ch.off + i;
+            mi++;
+            next_model = mi < cc.y ? chains[cc.x + mi].model : 0x7fffffff;
+            if (!is_start) {        // stop nodes carry no start scores (reset_node_scores)
+                ca.edge[g] = (uint8_t)e0;
+                ca.cscore[g] = 0.0; ca.sscore[g] = 0.0; ca.rscore[g] = 0.0; ca.uscore[g] = 0.0; ca.tscore[g] = 0.0; ca.mot_score[g] = 0.0;
+                ca.mot_ndx[g] = 0; ca.mot_len[g] = 0; ca.mot_spacer[g] = 0; ca.mot_spacendx[g] = 0; ca.rbs[2 * g] = 0; ca.rbs[2 * g + 1] = 0;
+                if (sp.cs_out != nullptr) sp.cs_out[g] = 0.0;
+            } else {
+        const pga_training* __restrict__ tm = &models[mm];          // the large motif tables stay in global memory
+        const double st_wt = SM.st_wt;
+        const int tt = SM.tt;
         if (tt != tt_cached) {
             tt_cached = tt;
             stop_missing = (strand == 1 && !is_stop_at(d, L, sv, 1, tt)) || (strand == -1 && !is_stop_at(d, L, L - 1 - sv, -1, tt));
@@ -1723,7 +1766,7 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
         int rbs0 = 0, rbs1 = 0, m_ndx = 0, m_len = 0, m_sp = 0, m_si = 0;
         double m_score = 0.0;
         if (!edge_in) {
-            if (tm->uses_sd) {
+            if (SM.uses_sd) {
                 if (!have_pats) {
                     have_pats = true;
                     const unsigned hasA = W.isA, hasG = W.isG;
@@ -1744,26 +1787,48 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
                     if (start - 20 + q < 0 && strand == 1) continue;
                     const unsigned pat = (pats[q / 5] >> (6 * (q % 5))) & 63u;
                     const unsigned he = s_lut[(q << 6) | pat], hm = s_lut[((15 + q) << 6) | pat];
-                    if (he > 1u) { const int a = sd_pick(he, tm->rbs_wt); if (a > rbs0) rbs0 = a; }
-                    if (hm > 1u) { const int b = sd_pick(hm, tm->rbs_wt); if (b > rbs1) rbs1 = b; }
+                    if (he > 1u) { const int a = sd_pick(he, SM.rbs_wt); if (a > rbs0) rbs0 = a; }
+                    if (hm > 1u) { const int b = sd_pick(hm, SM.rbs_wt); if (b > rbs1) rbs1 = b; }
                 }
             } else {
                 double bsc = -100.0; int bsp = 0, bsi = 0, blen = 0, bndx = 0;
-                // the motif of k + 3 bases whose first base sits u0 upstream (the reference's j = start - u0, ascending j):
-                // every shift and spacer class below is a constant of the unrolled body
-#pragma unroll 2
+                // the motif of k + 3 bases whose first base sits u0 upstream (the reference's j = start - u0, ascending j), longest
+                // motifs first: every shift and spacer class below is a constant of the unrolled body.  6- and 5-base motifs from the
+                // model's tables in global memory, 4- and 3-base motifs from LDS.
+#pragma unroll 1
                 for (int k = 3; k >= 0; k--) {
+                    const int stride = k == 0 ? 64 : (k == 1 ? 256 : 4096);        // entries per spacer class of the table read
+                    const double* __restrict__ gt = &tm->mot_wt[k][0][0];
+                    const double* lt = k == 1 ? &SM.mk1[0][0] : &SM.mk0[0][0];
+                    double scv[13];
+                    if (k >= 2) {
 #pragma unroll
-                    for (int t = 0; t < 13; t++) {
-                        const int u0 = 18 + k - t;
-                        if (u0 > start) continue;
-                        const int si = u0 >= 16 + k ? 3 : (u0 >= 14 + k ? 2 : (u0 <= 7 + k ? 1 : 0));
-                        const int idx = (int)((W.zm >> (2 * (21 - u0))) & ((1ull << (2 * (k + 3))) - 1ull));
-                        const double sc = tm->mot_wt[k][si][idx];
-                        if (sc > bsc) { bsc = sc; bsi = si; bsp = u0 - k - 3; bndx = idx; blen = k + 3; }
+                        for (int t2 = 0; t2 < 13; t2++) {
+                            const int u0 = 18 + k - t2;
+                            const int si = t2 <= 2 ? 3 : (t2 <= 4 ? 2 : (t2 >= 11 ? 1 : 0));      // u0 >= 16 + k, >= 14 + k, <= 7 + k
+                            const int idx = (int)((W.zm >> (2 * (21 - u0))) & ((1ull << (2 * (k + 3))) - 1ull));
+                            scv[t2] = u0 > start ? -1000.0 : gt[si * stride + idx];
+                        }
+                    } else {
+#pragma unroll
+                        for (int t2 = 0; t2 < 13; t2++) {
+                            const int u0 = 18 + k - t2;
+                            const int si = t2 <= 2 ? 3 : (t2 <= 4 ? 2 : (t2 >= 11 ? 1 : 0));
+                            const int idx = (int)((W.zm >> (2 * (21 - u0))) & ((1ull << (2 * (k + 3))) - 1ull));
+                            scv[t2] = u0 > start ? -1000.0 : lt[si * stride + idx];
+                        }
+                    }
+#pragma unroll
+                    for (int t2 = 0; t2 < 13; t2++) {
+                        const int u0 = 18 + k - t2;
+                        const int si = t2 <= 2 ? 3 : (t2 <= 4 ? 2 : (t2 >= 11 ? 1 : 0));
+                        if (scv[t2] > bsc) {
+                            bsc = scv[t2]; bsi = si; bsp = u0 - k - 3; blen = k + 3;
+                            bndx = (int)((W.zm >> (2 * (21 - u0))) & ((1ull << (2 * (k + 3))) - 1ull));
+                        }
                     }
                 }
-                if (bsc == -4.0 || bsc < tm->no_mot + 0.69) { m_score = tm->no_mot; }
+                if (bsc == -4.0 || bsc < SM.no_mot + 0.69) { m_score = SM.no_mot; }
                 else { m_ndx = bndx; m_len = blen; m_si = bsi; m_sp = bsp & 15; m_score = bsc; }
             }
         }
@@ -1775,16 +1840,16 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
         if (edge_in) {
             tscore = 0.74 * st_wt / edge_gene; uscore = 0.0; rscore = 0.0;
         } else {
-            tscore = tm->type_wt[type] * st_wt;
-            const double r1 = tm->rbs_wt[rbs0], r2 = tm->rbs_wt[rbs1];
+            tscore = SM.type_wt[type] * st_wt;
+            const double r1 = SM.rbs_wt[rbs0], r2 = SM.rbs_wt[rbs1];
             const double sd = fmax(r1, r2) * st_wt;
-            if (tm->uses_sd) rscore = sd;
-            else { rscore = st_wt * m_score; if (rscore < sd && tm->no_mot > -0.5) rscore = sd; }
+            if (SM.uses_sd) rscore = sd;
+            else { rscore = st_wt * m_score; if (rscore < sd && SM.no_mot > -0.5) rscore = sd; }
             int cnt = 0; double u = 0.0;
 #pragma unroll
-            for (int k = 1; k < 3; k++) { if (k > start) break; u += 0.4 * st_wt * tm->ups_comp[cnt][W.code(k)]; cnt++; }
+            for (int k = 1; k < 3; k++) { if (k > start) break; u += 0.4 * st_wt * SM.ups[cnt][W.code(k)]; cnt++; }
 #pragma unroll 10
-            for (int k = 15; k < 45; k++) { if (k > start) break; u += 0.4 * st_wt * tm->ups_comp[cnt][W.code(k)]; cnt++; }
+            for (int k = 15; k < 45; k++) { if (k > start) break; u += 0.4 * st_wt * SM.ups[cnt][W.code(k)]; cnt++; }
             uscore = u;
             if (ups_near_edge || (ch.first ? ups_first : ups_later)) uscore += -1.00 * st_wt;
         }
@@ -1818,6 +1883,9 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
         ca.rbs[2 * g] = (uint8_t)rbs0; ca.rbs[2 * g + 1] = (uint8_t)rbs1;
         ca.edge[g] = (uint8_t)edge_now;
         if (sp.cs_out != nullptr) sp.cs_out[g] = cscore + sscore;
+            }
+        }
+        __syncthreads();            // everybody is done with the staged model
     }
 }
 
