@@ -42,9 +42,13 @@ __device__ __forceinline__ int contig_of_node(const int32_t* __restrict__ cbase,
 __global__ void __launch_bounds__(256)
 k_dpw_topo(const int32_t* __restrict__ ndx, const int32_t* __restrict__ stopv, const uint8_t* __restrict__ type, const int8_t* __restrict__ strand,
            const int32_t* __restrict__ cbase, int n_contigs, int n_nodes, DpwTopoArrays ta) {
+    __shared__ int s_c0;
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (threadIdx.x == 0) s_c0 = contig_of_node(cbase, n_contigs, blockIdx.x * blockDim.x);     // one search per workgroup, then a short walk
+    __syncthreads();
     if (g >= n_nodes) return;
-    const int c = contig_of_node(cbase, n_contigs, g);
+    int c = s_c0;
+    while (c + 1 < n_contigs && cbase[c + 1] <= g) c++;
     const int b0 = cbase[c], n = cbase[c + 1] - b0;
     const DpwTopo t = dpw_topo_node(ndx + b0, stopv + b0, type + b0, strand + b0, n, g - b0);
     ta.kf[g] = t.kf; ta.lo[g] = t.lo; ta.q1[g] = t.q1; ta.q2[g] = t.q2;

@@ -92,20 +92,37 @@ DPW_HD DpwTopo dpw_topo_node(const int32_t* ndx, const int32_t* stopv, const uin
     lo = lo < DPW_MAX_NODE_DIST ? 0 : lo - DPW_MAX_NODE_DIST;
     t.lo = lo; t.q1 = 0; t.q2 = 0;
     if (kind == 0 || kind == 3) {
-        int a = 0, b = i;                       // first index in [0, i) with ndx >= my_ndx - 3 * OPER_DIST
+        // first index in [0, i) with ndx >= my_ndx - 3 * OPER_DIST (positions ascend): a handful of nodes back, so look at the
+        // eight before, then the eight before those ...: each round is eight independent loads, a binary search ten dependent ones
         const int v = my_ndx - 3 * DPW_OPER_DIST;
-        while (a < b) { const int m = (a + b) >> 1; if (ndx[m] < v) a = m + 1; else b = m; }
+        int a = i;                              // every index in [a, i) has ndx >= v
+        while (a > 0) {
+            int x[8];
+            for (int k = 0; k < 8; k++) x[k] = ndx[a - 1 - k >= 0 ? a - 1 - k : 0];
+            int k = 0;
+            while (k < 8 && a - 1 - k >= 0 && x[k] >= v) k++;
+            a -= k;
+            if (k < 8) break;
+        }
         t.q1 = a > lo ? a : lo;
     } else if (kind == 1) {
         t.q2 = n;
         int seen = 0;
-        for (int j = i + 1; j < n && seen != 7; j++) {
-            if (strand[j] != 1 || type[j] != 3) continue;
-            if (t.q2 == n) t.q2 = j;
-            const int f = ndx[j] % 3;
-            if (seen & (1 << f)) continue;
-            seen |= 1 << f;
-            if (stopv[j] < my_ndx) kf |= 1 << (4 + f);      // inside that stop's ORF: an operon candidate for it
+        // the nodes after i, eight at a time (their loads do not wait for one another), until a forward stop of every frame was met
+        for (int j0 = i + 1; j0 < n && seen != 7; j0 += 8) {
+            int xs[8], xt[8], xn[8], xv[8];
+            for (int k = 0; k < 8; k++) {
+                const int j = j0 + k < n ? j0 + k : n - 1;
+                xs[k] = strand[j]; xt[k] = type[j]; xn[k] = ndx[j]; xv[k] = stopv[j];
+            }
+            for (int k = 0; k < 8 && j0 + k < n && seen != 7; k++) {
+                if (xs[k] != 1 || xt[k] != 3) continue;
+                if (t.q2 == n) t.q2 = j0 + k;
+                const int f = xn[k] % 3;
+                if (seen & (1 << f)) continue;
+                seen |= 1 << f;
+                if (xv[k] < my_ndx) kf |= 1 << (4 + f);     // inside that stop's ORF: an operon candidate for it
+            }
         }
     } else {
         int a = 0, b = i;                       // first index in [0, i) with ndx >= my_stop - 4
