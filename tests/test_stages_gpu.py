@@ -95,6 +95,41 @@ def test_sequence_stage_gc_unknown_and_masks(ctx):
     assert r.masks[0].tolist() == [[5000, 8000], [8100, 8150]]
 
 
+@pytest.mark.parametrize("closed", [False, True])
+def test_extract_stage_contig_lengths_around_the_tile_size(ctx, closed):
+    # a workgroup owns 3072 forward positions of both strands; the last tile of a contig is ragged, one or two positions long
+    # when the length is 1 or 2 past a multiple, and the reverse strand's first codons lie in it
+    from pyrodigal_amd import _cabi
+    lens = [3, 4, 95, 3070, 3071, 3072, 3073, 3074, 3075, 6143, 6144, 6145, 6146, 9216, 9217, 9218, 12290]
+    seqs = [synthetic_contig(L, 0.35 + 0.03 * (k % 10), 400 + k) for k, L in enumerate(lens)]
+    seqs += [s.translate(bytes.maketrans(b"ACGT", b"TGCA"))[::-1] for s in seqs[3:9]]       # the same tiles seen from the other strand
+    for tt in (11, 4):
+        out = ctx.nodes_stage(seqs, _cabi.STAGE_EXTRACT, translation_table=tt, closed=closed)
+        for seq, nd in zip(seqs, out):
+            check(nd, oracle_stage(seq, 1, tt=tt, closed=closed), 1)
+
+
+def test_masks_and_nodes_with_unknown_bases_at_tile_boundaries(ctx):
+    from pyrodigal_amd import _cabi
+    base = synthetic_contig(3 * 3072 + 2, 0.5, 77)
+    seqs = []
+    for L, runs in [(3073, [(3072, 1)]), (3074, [(3072, 2)]), (6145, [(6100, 45)]), (9218, [(3060, 30), (6140, 10), (9217, 1)]), (6144, [(3071, 2), (6143, 1)])]:
+        s = bytearray(base[:L])
+        for at, n in runs: s[at:at + n] = b"N" * n
+        seqs.append(bytes(s))
+    r = ctx.nodes_stage(seqs, _cabi.STAGE_SEQUENCE, mask=True, min_mask=50)
+    # a run that reaches the end of the sequence is masked whatever its length (ref: lib.pyx:711-712), also when it is the only
+    # position of the contig's last tile
+    assert r.masks[0].tolist() == [[3072, 3073]] and r.masks[1].tolist() == [[3072, 3074]] and r.masks[2].tolist() == [[6100, 6145]]
+    assert r.masks[3].tolist() == [[9217, 9218]] and r.masks[4].tolist() == [[6143, 6144]]
+    for min_mask in (50, 0):
+        out = ctx.nodes_stage(seqs, _cabi.STAGE_EXTRACT, mask=True, min_mask=min_mask)
+        for seq, nd in zip(seqs, out):
+            o = orc.Oracle(seq, mask=True, mask_size=min_mask)
+            o.extract(11, orc.Params()); o.sort()
+            check(nd, o.nodes(), 1)
+
+
 def test_extract_stage_gene_length_options(ctx):
     from pyrodigal_amd import _cabi
     seq = synthetic_contig(50000, 0.45, 9)
