@@ -1111,6 +1111,9 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         tm.mark("extract+sync");
         // ---- plan the (contig, model) chains (ref: lib.pyx:5335-5362) ------------------------
         std::vector<std::vector<ChainDesc>> gch(NG);     // per group, in (contig, model) order
+        std::vector<double> mgc((size_t)NM); std::vector<int> mtt((size_t)NM);     // the models are 558 KB apart: keep what the loop reads together
+        for (int m = 0; m < NM; m++) { mgc[m] = c->models[m].gc; mtt[m] = c->models[m].trans_table; }
+        for (int g = 0; g < NG; g++) gch[g].reserve(meta_run ? (size_t)NC * 6 : (size_t)NC);
         for (int i = 0; i < NC; i++) {
             const int L = ct[i].len;
             const double gc = L > 0 ? (double)h_cnt[i] / (double)L : 0.0;
@@ -1125,25 +1128,25 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             const double low = fmin(0.65, 0.88495 * gc - 0.0102337), high = fmax(0.35, 0.86596 * gc + 0.1131991);
             int tt_prev = -1;
             for (int m = 0; m < NM; m++) {
-                const pga_training& t = c->models[m];
-                if (t.gc < low || t.gc > high) continue;
+                if (mgc[m] < low || mgc[m] > high) continue;
                 const int g = f->model_group[m];
                 if (!h_enabled[(size_t)g * NC + i]) { c->err = "pga_find_genes: host and device disagree on a GC window"; return PGA_EDEVICE; }
                 const int32_t* cb = h_cbase + (size_t)g * (NC + 1);
-                ChainDesc ch{0, cb[i], cb[i + 1] - cb[i], m, i, t.trans_table != tt_prev ? 1 : 0};
+                ChainDesc ch{0, cb[i], cb[i + 1] - cb[i], m, i, mtt[m] != tt_prev ? 1 : 0};
                 ch.group = g;
-                tt_prev = t.trans_table;
+                tt_prev = mtt[m];
                 gch[g].push_back(ch);
             }
         }
         std::vector<ChainDesc> chains;
+        { size_t tot = 0; for (int g = 0; g < NG; g++) tot += gch[g].size(); chains.reserve(tot); }
         std::vector<int> g_c0(NG + 1, 0);
         std::vector<int64_t> g_n0(NG + 1, 0);
         int64_t tot_chain_nodes = 0, tot_chain_stops = 0;
         std::vector<int64_t> g_s0(NG + 1, 0);            // (chain, stop node) pairs before the chains of group g
         for (int g = 0; g < NG; g++) {
             g_c0[g] = (int)chains.size(); g_n0[g] = tot_chain_nodes;
-            for (ChainDesc ch : gch[g]) {
+            for (ChainDesc& ch : gch[g]) {
                 ch.off = tot_chain_nodes; tot_chain_nodes += ch.n;
                 ch.soff = tot_chain_stops;
                 const int32_t* sb = h_sbase + (size_t)(meta_run ? g : 0) * (NC + 1);
@@ -1365,16 +1368,18 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         // ---- pick the winning model per contig (ref: lib.pyx:5364-5367, strict '>' from -100) ---
         std::vector<int> win_chain(NC, -1);
         {
-            // chains of a contig sit in several groups; visit them in model order
-            std::vector<std::vector<int>> per_contig(NC);
-            for (int k = 0; k < NCH; k++) per_contig[chains[k].contig].push_back(k);
-            for (int i = 0; i < NC; i++) {
-                auto& v = per_contig[i];
-                std::sort(v.begin(), v.end(), [&](int a, int b) { return chains[a].model < chains[b].model; });
-                if (!P.meta) { if (!v.empty()) win_chain[i] = v[0]; continue; }
-                double best = -100.0;
-                for (int k : v) {
-                    if (chains[k].n > 0 && h_ipath[k] >= 0 && h_maxscore[k] > best) { best = h_maxscore[k]; win_chain[i] = k; }
+            // the reference visits the models of a contig in model order and keeps a strictly better one: the winner is the
+            // highest score, the lowest model among equals -- one pass over the chains, whatever group they sit in
+            if (!P.meta) { for (int k = NCH - 1; k >= 0; k--) win_chain[chains[k].contig] = k; }
+            else {
+                std::vector<double> best(NC, -100.0);
+                for (int k = 0; k < NCH; k++) {
+                    const ChainDesc& ch = chains[k];
+                    if (ch.n <= 0 || h_ipath[k] < 0) continue;
+                    const int w = win_chain[ch.contig];
+                    if (h_maxscore[k] > best[ch.contig] || (w >= 0 && h_maxscore[k] == best[ch.contig] && ch.model < chains[w].model)) {
+                        best[ch.contig] = h_maxscore[k]; win_chain[ch.contig] = k;
+                    }
                 }
             }
         }
