@@ -183,6 +183,10 @@ def main():
 
     from pyrodigal_amd import _cabi
     sub = max(1, args.sub_batch)
+    if args.workload == "config4" and args.contexts > 1 and len(seqs) > 1:
+        # at least one device call per context: a rank whose share is a single sub-batch (the job on 8 GPUs) would otherwise
+        # have nothing to overlap the host-side phases of its one call with
+        sub = min(sub, -(-len(seqs) // args.contexts))
     groups = [seqs[i:i + sub] for i in range(0, len(seqs), sub)]
     n_ctx = max(1, min(args.contexts, len(groups)))
     ctxs = [_cabi.Context(dev_index) for _ in range(n_ctx)]
