@@ -1298,20 +1298,26 @@ k_seg_leaves(const ChainDesc* __restrict__ chains, const int32_t* __restrict__ b
 // (parents in earlier batches come from an LDS ring, parents in the same batch are met one after the other through
 // v_readlane), and every other node is scored afterwards, one parallel pass per height class (k_seg_leaves).
 // A later round restarts at the first node the verification rejected: everything before it is already exact.
-#define PGA_SEG_HEIGHT 4
+#define PGA_SEG_HEIGHT 4          // default; PGA_DP_SEG_HEIGHT = 2 .. 24 (seg_height()): a higher bar means a shorter spine and more leaf passes
+                                  // (measured on configs 2 and 5: 8 changes nothing, 12 and 16 are 3-8 % slower -- the spine is mostly the path itself)
+static int seg_height() {
+    static int h = 0;
+    if (!h) { const char* e = getenv("PGA_DP_SEG_HEIGHT"); h = e ? atoi(e) : PGA_SEG_HEIGHT; if (h < 2 || h > 24) h = PGA_SEG_HEIGHT; }
+    return h;
+}
 #define PGA_RS_RING 4096
 
 __device__ __forceinline__ int64_t seg_tile(const ChainDesc& cd, const int chain, const int i) { return (cd.off >> 6) + chain + (i >> 6); }
 
 __global__ void __launch_bounds__(256)
 k_spine_count(const ChainDesc* __restrict__ chains, const int32_t* __restrict__ big, const int32_t* __restrict__ gate,
-              const uint32_t* __restrict__ g_hb, unsigned long long* __restrict__ g_tmask) {
+              const uint32_t* __restrict__ g_hb, unsigned long long* __restrict__ g_tmask, const int spine_h) {
     const int chain = big[blockIdx.y];
     if (gate != nullptr && gate[chain] == 0) return;
     const ChainDesc cd = chains[chain];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i - (int)(threadIdx.x & 63) >= cd.n) return;
-    const bool spine = i < cd.n && ((g_hb[cd.off + i] >> PGA_SEG_HEIGHT) & 1u);
+    const bool spine = i < cd.n && ((g_hb[cd.off + i] >> spine_h) & 1u);
     const unsigned long long m = __ballot(spine);
     if ((threadIdx.x & 63) == 0) g_tmask[seg_tile(cd, chain, i)] = m;
 }
@@ -1422,6 +1428,8 @@ k_dp_rescore(const ChainDesc* __restrict__ chains, const int32_t* __restrict__ b
             if (early && !near) sj = __hip_atomic_load(&score[cur.tb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         double s = early ? sj + w : 0.0;
         if (__any(inb)) {
+            // (tried: every lane from t up adds entry t's term, fetched by v_readlane, so that nothing goes through LDS -- exact, but
+            // 20-30 % slower: the exec write and the SGPR hand-over per step cost more than the LDS traffic of this form)
             // the others in list order, by ONE lane (a lone wavefront issues an instruction every four cycles whatever
             // its width, so what counts is the instruction count per entry: here a scalar test, the addition, and half an LDS
             // read and write).  The parent is nearly always the entry just before: r carries the chain.  `special` entries --
@@ -1771,15 +1779,16 @@ static void launch_dp_segmented(const ChainDesc* d_chains, int n_chains, const M
         const dim3 per_node(blocks(sg.max_big_n), sg.n_big);
         hipMemsetAsync(sg.hb, 0, sizeof(uint32_t) * (size_t)sg.n_nodes, st);
         hipLaunchKernelGGL(k_seg_weights, per_node, blk, 0, st, d_chains, sg.big, gate, buf.src, buf.tgt, d_models, buf, sg.ctb, sg.cw, sg.hb);
-        for (int k = 2; k <= PGA_SEG_HEIGHT; k++)
+        const int H = seg_height();
+        for (int k = 2; k <= H; k++)
             hipLaunchKernelGGL(k_seg_height, per_node, blk, 0, st, d_chains, sg.big, gate, (const int32_t*)buf.traceb, sg.hb, k);
-        hipLaunchKernelGGL(k_spine_count, per_node, blk, 0, st, d_chains, sg.big, gate, (const uint32_t*)sg.hb, sg.tmask);
+        hipLaunchKernelGGL(k_spine_count, per_node, blk, 0, st, d_chains, sg.big, gate, (const uint32_t*)sg.hb, sg.tmask, H);
         hipLaunchKernelGGL(k_spine_scan, dim3(sg.n_big), dim3(1024), 0, st, d_chains, sg.big, gate, (const unsigned long long*)sg.tmask, sg.toff, sg.nsp);
         hipLaunchKernelGGL(k_spine_fill, per_node, blk, 0, st, d_chains, sg.big, gate, (const int32_t*)buf.traceb, (const double*)sg.cw,
                            (const unsigned long long*)sg.tmask, (const int32_t*)sg.toff, sg.sp_idx, sg.sp_tb, sg.sp_pp, sg.sp_w);
         hipLaunchKernelGGL(k_dp_rescore, dim3(sg.n_big), dim3(64), 0, st, d_chains, sg.big, gate, from, buf, (const int32_t*)sg.toff,
                            (const int32_t*)sg.nsp, (const int32_t*)sg.sp_idx, (const int32_t*)sg.sp_tb, (const int32_t*)sg.sp_pp, (const double*)sg.sp_w);
-        for (int cl = PGA_SEG_HEIGHT - 1; cl >= 0; cl--)
+        for (int cl = H - 1; cl >= 0; cl--)
             hipLaunchKernelGGL(k_seg_leaves, per_node, blk, 0, st, d_chains, sg.big, gate, from, buf, sg.cw, sg.hb, cl);
         hipLaunchKernelGGL(k_seg_build_far, per_node, blk, 0, st, d_chains, sg.big, gate, buf.src, buf.tgt, d_models, buf, sg.tv, sg.ti);
         hipLaunchKernelGGL(k_seg_build_upper, dim3(sg.n_big), blk, 0, st, d_chains, sg.big, gate, buf.src, buf.tgt, buf, sg.tv, sg.ti);
