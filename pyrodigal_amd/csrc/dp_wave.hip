@@ -22,6 +22,7 @@
 // maxima of chains longer than one window.
 
 #include "pga_internal.h"
+#include <type_traits>
 #include "dev_common.h"
 #include "dpw_core.h"
 
@@ -96,17 +97,52 @@ __device__ __forceinline__ void wave_suffix_lexmax(double& v, int& i, const int 
         if (lane + d < 64) lex_max(v, i, ov, oi);
     }
 }
+// Cross-lane moves through the data-parallel primitives of the vector ALU (DPP) instead of ds_bpermute: a lone wavefront waits out
+// the full LDS round trip of every __shfl, six of them in a row per scan, and these scans sit on the serial path of a chain.
+// CTRL: 0x111 .. 0x11f row_shr:1 .. 15, 0x138 wave_shr:1, 0x142 row_bcast15, 0x143 row_bcast31, 0x140 row_mirror, 0x141 row_half_mirror,
+// quad_perm otherwise.  Lanes that receive nothing (shifted in from outside the row, or masked out by ROW_MASK) get `old`.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp_f64(const double old, const double v) {
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int dpp_i32(const int old, const int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false); }
+__device__ __forceinline__ double fmax_nn(const double a, const double b) { return b > a ? b : a; }     // no NaNs here
+
 // wave-wide maximum of v (never NaN), the same in every lane; the lane that holds it comes from a vote afterwards
 __device__ __forceinline__ double wave_max_f64(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { const double o = __shfl_xor(v, m, 64); v = o > v ? o : v; }
-    return v;
+    const double NI = -__builtin_huge_val();
+    v = fmax_nn(v, dpp_f64<0xb1>(NI, v));             // quad_perm [1, 0, 3, 2]
+    v = fmax_nn(v, dpp_f64<0x4e>(NI, v));             // quad_perm [2, 3, 0, 1]
+    v = fmax_nn(v, dpp_f64<0x141>(NI, v));            // row_half_mirror
+    v = fmax_nn(v, dpp_f64<0x140>(NI, v));            // row_mirror: every lane holds its row's maximum
+    v = fmax_nn(v, dpp_f64<0x142, 0xa>(NI, v));       // row_bcast15 into rows 1 and 3
+    v = fmax_nn(v, dpp_f64<0x143, 0xc>(NI, v));       // row_bcast31 into rows 2 and 3: lane 63 holds the maximum
+    return rl_f64(v, 63);
 }
 // inclusive prefix maximum (lower lanes first), values only
 __device__ __forceinline__ double wave_prefix_max_f64(double v, const int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const double o = __shfl_up(v, d, 64); if (lane >= d && o > v) v = o; }
+    const double NI = -__builtin_huge_val();
+    v = fmax_nn(v, dpp_f64<0x111>(NI, v));            // row_shr:1, 2, 4, 8: the scan inside each row of sixteen lanes
+    v = fmax_nn(v, dpp_f64<0x112>(NI, v));
+    v = fmax_nn(v, dpp_f64<0x114>(NI, v));
+    v = fmax_nn(v, dpp_f64<0x118>(NI, v));
+    v = fmax_nn(v, dpp_f64<0x142, 0xa>(NI, v));       // rows 1 and 3 take the total of the row before
+    v = fmax_nn(v, dpp_f64<0x143, 0xc>(NI, v));       // rows 2 and 3 take the total of rows 0 and 1
     return v;
+}
+// wave-wide minimum of an int, the same in every lane
+__device__ __forceinline__ int wave_min_i32(int v) {
+    const int BIG = 0x7fffffff;
+    v = min(v, dpp_i32<0xb1>(BIG, v));
+    v = min(v, dpp_i32<0x4e>(BIG, v));
+    v = min(v, dpp_i32<0x141>(BIG, v));
+    v = min(v, dpp_i32<0x140>(BIG, v));
+    v = min(v, dpp_i32<0x142, 0xa>(BIG, v));
+    v = min(v, dpp_i32<0x143, 0xc>(BIG, v));
+    return rl_i32(v, 63);
 }
 
 struct WavePtrs {
@@ -260,13 +296,15 @@ __device__ __forceinline__ void wave_step(const SrcRegs& R, const int u, const i
     if (in_mask(take)) { L.val = val; L.tag = tag; }
 }
 
-// OCC: wavefronts per SIMD the register budget is cut for.  4 = 125 VGPRs, nothing spilled (the default); 5 and 6 (PGA_DPW_OCC) run
-// 2 % and 5 % faster on config 4 but spill 112 / 148 bytes per lane, which shows up as four times the HBM traffic.
+// OCC: wavefronts per SIMD the register budget is cut for (PGA_DPW_OCC).  The kernel wants 103 VGPRs: 4 spills nothing (config 4:
+// 4.53 ms per launch, HBM traffic 1.55x the algorithmic bytes), 5 (the default) spills 24 bytes per lane (4.06 ms, 1.9x), 6 spills
+// 64 bytes (3.98 ms, 3.0x).  A chain's walk is a chain of dependent instructions: a fifth wavefront per SIMD fills its gaps.
 template <int OCC>
 __global__ void __launch_bounds__(64, OCC)
 k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const double* __restrict__ g_cs, const DpwExt* __restrict__ g_ext,
-          const ModelConst* __restrict__ models, DpBuffers buf, double* __restrict__ g_sfxv, int32_t* __restrict__ g_sfxi) {
+          const ModelConst* __restrict__ models, DpBuffers buf, double* __restrict__ g_sfxv, int32_t* __restrict__ g_sfxi, const int touch_on) {
     __shared__ double s_igm[64];
+    __shared__ int s_touch[7 * 64];          // where the early loads of the next batch's records land (never read)
     const ChainDesc cd = chains[blockIdx.x];
     const int lane = threadIdx.x;
     const int n = cd.n;
@@ -310,6 +348,18 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
         const int i0 = b << 6;
         DpwT T; int kfb;
         load_target_w(T, kfb, P, i0, lane, n, M.negc);
+        if (touch_on && b + 1 < nb) {
+            // (PGA_DPW_TOUCH=1, off by default: measured 2 % slower)  ask for the next batch's records now, straight into LDS (no register
+            // waits for them): by the time the walk of this batch is over they sit in the cache
+            const int j = min(i0 + 64 + lane, n - 1);
+            auto touch = [&](const void* g, int* l, auto size) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, decltype(size)::value, 0, 0);
+            };
+            touch(P.ndx + j, s_touch, std::integral_constant<int, 4>{}); touch(P.stopv + j, s_touch + 64, std::integral_constant<int, 4>{});
+            touch(P.lo + j, s_touch + 128, std::integral_constant<int, 4>{}); touch(P.q1 + j, s_touch + 192, std::integral_constant<int, 4>{});
+            touch(P.q2 + j, s_touch + 256, std::integral_constant<int, 4>{}); touch(P.cs + j, s_touch + 320, std::integral_constant<int, 4>{});
+            touch(P.kf + j, s_touch + 384, std::integral_constant<int, 1>{});
+        }
         const DpwLT LT = dpw_lean(T);
         const WaveMasks W = wave_masks(LT);
         const int key_r5 = T.kind == 3 ? T.ndx - 2 : T.ndx;
@@ -327,8 +377,7 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
         //      p_near of a gene begin up to the batch, one wave-uniform source at a time
         {
             int jm = (act && (T.kind == 0 || T.kind == 3)) ? max(T.q1, T.lo) : i0;
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) jm = min(jm, __shfl_xor(jm, m, 64));
+            jm = wave_min_i32(jm);
             for (int t0 = jm; t0 < i0; t0 += 64) {
                 const int j = t0 + lane;
                 const bool in = j < i0;
@@ -478,8 +527,7 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
             ppv = pv; ppi = pi;
             const double bmv = rl_f64(pv, 63); const int bmi = rl_i32(pi, 63);
             s2v = s1v; s2i = s1i;
-            double nv = __shfl_up(s1v, 1, 64); int ni = __shfl_up(s1i, 1, 64);
-            if (lane == 0) { nv = NEG_INF; ni = -1; }
+            double nv = dpp_f64<0x138>(NEG_INF, s1v); int ni = dpp_i32<0x138>(-1, s1i);      // wave_shr:1, lane 0 takes the empty entry
             lex_max(nv, ni, bmv, bmi);
             s1v = nv; s1i = ni;
             if (long_chain) {
@@ -552,12 +600,13 @@ void pga_launch_dpw_chain(const ChainDesc* d_chains, int n_chains, int64_t node_
 void pga_launch_dp_wave(const ChainDesc* d_chains, int n_chains, const DpwGroupPtrs& groups, const ModelConst* d_models, DpBuffers buf,
                         const DpwBuffers& wb, hipStream_t st) {
     if (n_chains <= 0) return;
-    static int occ = 0;
-    if (!occ) { const char* e = getenv("PGA_DPW_OCC"); occ = e ? atoi(e) : 4; if (occ < 4 || occ > 6) occ = 4; }
+    static int occ = 0, touch = 0;
+    if (!occ) { const char* e = getenv("PGA_DPW_TOUCH"); if (e) touch = atoi(e) != 0; }
+    if (!occ) { const char* e = getenv("PGA_DPW_OCC"); occ = e ? atoi(e) : 5; if (occ < 4 || occ > 6) occ = 5; }
     if (occ == 5) hipLaunchKernelGGL(k_dp_wave<5>, dim3((unsigned)n_chains), dim3(64), 0, st, d_chains, groups, (const double*)wb.cs, (const DpwExt*)wb.ext,
-                                     d_models, buf, wb.sfxv, wb.sfxi);
+                                     d_models, buf, wb.sfxv, wb.sfxi, touch);
     else if (occ == 6) hipLaunchKernelGGL(k_dp_wave<6>, dim3((unsigned)n_chains), dim3(64), 0, st, d_chains, groups, (const double*)wb.cs, (const DpwExt*)wb.ext,
-                                          d_models, buf, wb.sfxv, wb.sfxi);
+                                          d_models, buf, wb.sfxv, wb.sfxi, touch);
     else hipLaunchKernelGGL(k_dp_wave<4>, dim3((unsigned)n_chains), dim3(64), 0, st, d_chains, groups, (const double*)wb.cs, (const DpwExt*)wb.ext,
-                            d_models, buf, wb.sfxv, wb.sfxi);
+                            d_models, buf, wb.sfxv, wb.sfxi, touch);
 }
