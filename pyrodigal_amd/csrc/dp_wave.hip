@@ -297,14 +297,13 @@ __device__ __forceinline__ void wave_step(const SrcRegs& R, const int u, const i
 }
 
 // OCC: wavefronts per SIMD the register budget is cut for (PGA_DPW_OCC).  The kernel wants 103 VGPRs: 4 spills nothing (config 4:
-// 4.53 ms per launch, HBM traffic 1.55x the algorithmic bytes), 5 (the default) spills 24 bytes per lane (4.06 ms, 1.9x), 6 spills
+// 4.53 ms per launch, HBM traffic 1.55x the algorithmic bytes), 5 (the default) spills 16 bytes per lane (4.06 ms, 1.9x), 6 spills
 // 64 bytes (3.98 ms, 3.0x).  A chain's walk is a chain of dependent instructions: a fifth wavefront per SIMD fills its gaps.
 template <int OCC>
 __global__ void __launch_bounds__(64, OCC)
 k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const double* __restrict__ g_cs, const DpwExt* __restrict__ g_ext,
-          const ModelConst* __restrict__ models, DpBuffers buf, double* __restrict__ g_sfxv, int32_t* __restrict__ g_sfxi, const int touch_on) {
+          const ModelConst* __restrict__ models, DpBuffers buf, double* __restrict__ g_sfxv, int32_t* __restrict__ g_sfxi) {
     __shared__ double s_igm[64];
-    __shared__ int s_touch[7 * 64];          // where the early loads of the next batch's records land (never read)
     const ChainDesc cd = chains[blockIdx.x];
     const int lane = threadIdx.x;
     const int n = cd.n;
@@ -348,18 +347,6 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
         const int i0 = b << 6;
         DpwT T; int kfb;
         load_target_w(T, kfb, P, i0, lane, n, M.negc);
-        if (touch_on && b + 1 < nb) {
-            // (PGA_DPW_TOUCH=1, off by default: measured 2 % slower)  ask for the next batch's records now, straight into LDS (no register
-            // waits for them): by the time the walk of this batch is over they sit in the cache
-            const int j = min(i0 + 64 + lane, n - 1);
-            auto touch = [&](const void* g, int* l, auto size) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, decltype(size)::value, 0, 0);
-            };
-            touch(P.ndx + j, s_touch, std::integral_constant<int, 4>{}); touch(P.stopv + j, s_touch + 64, std::integral_constant<int, 4>{});
-            touch(P.lo + j, s_touch + 128, std::integral_constant<int, 4>{}); touch(P.q1 + j, s_touch + 192, std::integral_constant<int, 4>{});
-            touch(P.q2 + j, s_touch + 256, std::integral_constant<int, 4>{}); touch(P.cs + j, s_touch + 320, std::integral_constant<int, 4>{});
-            touch(P.kf + j, s_touch + 384, std::integral_constant<int, 1>{});
-        }
         const DpwLT LT = dpw_lean(T);
         const WaveMasks W = wave_masks(LT);
         const int key_r5 = T.kind == 3 ? T.ndx - 2 : T.ndx;
@@ -600,13 +587,12 @@ void pga_launch_dpw_chain(const ChainDesc* d_chains, int n_chains, int64_t node_
 void pga_launch_dp_wave(const ChainDesc* d_chains, int n_chains, const DpwGroupPtrs& groups, const ModelConst* d_models, DpBuffers buf,
                         const DpwBuffers& wb, hipStream_t st) {
     if (n_chains <= 0) return;
-    static int occ = 0, touch = 0;
-    if (!occ) { const char* e = getenv("PGA_DPW_TOUCH"); if (e) touch = atoi(e) != 0; }
+    static int occ = 0;
     if (!occ) { const char* e = getenv("PGA_DPW_OCC"); occ = e ? atoi(e) : 5; if (occ < 4 || occ > 6) occ = 5; }
     if (occ == 5) hipLaunchKernelGGL(k_dp_wave<5>, dim3((unsigned)n_chains), dim3(64), 0, st, d_chains, groups, (const double*)wb.cs, (const DpwExt*)wb.ext,
-                                     d_models, buf, wb.sfxv, wb.sfxi, touch);
+                                     d_models, buf, wb.sfxv, wb.sfxi);
     else if (occ == 6) hipLaunchKernelGGL(k_dp_wave<6>, dim3((unsigned)n_chains), dim3(64), 0, st, d_chains, groups, (const double*)wb.cs, (const DpwExt*)wb.ext,
-                                          d_models, buf, wb.sfxv, wb.sfxi, touch);
+                                          d_models, buf, wb.sfxv, wb.sfxi);
     else hipLaunchKernelGGL(k_dp_wave<4>, dim3((unsigned)n_chains), dim3(64), 0, st, d_chains, groups, (const double*)wb.cs, (const DpwExt*)wb.ext,
-                            d_models, buf, wb.sfxv, wb.sfxi, touch);
+                            d_models, buf, wb.sfxv, wb.sfxi);
 }
