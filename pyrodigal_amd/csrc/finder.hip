@@ -1172,6 +1172,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             const int64_t n = group_nodes[g] + 1;
             GBUF(ndx, int32_t, n) GBUF(stop_val, int32_t, n) GBUF(type, uint8_t, n) GBUF(strand, int8_t, n) GBUF(edge0, uint8_t, n) GBUF(gc_cont, float, n)
             GBUF(stop_list, int32_t, (int64_t)h_sbase[(size_t)g * (NC + 1) + NC] + 1)
+            GBUF(ovl_topo, uint32_t, (int64_t)h_sbase[(size_t)g * (NC + 1) + NC] + 1)
         }
         ChainArrays ca;
         {
@@ -1278,6 +1279,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             // the start scorer leaves cscore + sscore, so its per-chain preparation is done when scoring is
             StopLaunch sl;
             sl.sbase = d_sbase + (size_t)g * (NC + 1); sl.soff_begin = g_s0[g]; sl.n_pairs = g_s0[g + 1] - g_s0[g];
+            sl.n_stops = h_sbase[(size_t)g * (NC + 1) + NC];
             sp.cs_out = nullptr;
             if (use_wave) {
                 pga_launch_dpw_topo(wgroups.g[g], ga[g].type, ga[g].strand, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], st);

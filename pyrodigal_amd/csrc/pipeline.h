@@ -25,6 +25,7 @@ struct GroupArrays {
     int32_t* st_ndx; int32_t* st_sv;         // ndx, stop_val
     uint8_t* st_info;                        // type | edge << 2 | reverse << 3
     int32_t* stop_list;                      // the stop nodes of the group in node order (node indices); contig c owns [sbase[c], sbase[c + 1])
+    uint32_t* ovl_topo;                      // per entry of stop_list: which of its first 16 neighbours can be overlapping starts (k_ovl_topo)
     // per node, in (contig, ndx, strand) order
     int32_t* ndx; int32_t* stop_val; uint8_t* type; int8_t* strand; uint8_t* edge0; float* gc_cont;
 };
@@ -83,6 +84,7 @@ void pga_launch_place(const ContigDesc* d_ct, const TileDesc* d_tiles, int n_til
 struct StopLaunch {
     const int32_t* sbase = nullptr;     // per contig of the group: first entry of ga.stop_list (n_contigs + 1)
     int64_t soff_begin = 0, n_pairs = 0; // ChainDesc::soff of the launch's first chain; (chain, stop) pairs of its chains
+    int32_t n_stops = 0;                 // stop nodes of the group (entries of ga.stop_list)
     // the wave-batch scorer's 64-byte extras of every stop node, built in the same pass (nullptr: not wanted)
     const int32_t* topo_q2 = nullptr; void* ext = nullptr;
 };

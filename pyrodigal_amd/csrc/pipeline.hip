@@ -1897,21 +1897,14 @@ struct OvlChain {
     const double* __restrict__ cs; const double* __restrict__ ss; const double* __restrict__ rs; const double* __restrict__ us;           // the chain's scores
     int n;
 };
-__device__ __forceinline__ void overlapping_starts_of(const OvlChain& C, const int i, const ModelConst* __restrict__ mc, const int maxov,
-                                                      int& sp0, int& sp1, int& sp2) {
-    const int32_t* __restrict__ ndx = C.ndx; const int32_t* __restrict__ stv = C.stv;
-    const uint8_t* __restrict__ typ = C.typ; const int8_t* __restrict__ str = C.str;
-    const double* __restrict__ cs = C.cs; const double* __restrict__ ss = C.ss; const double* __restrict__ rs = C.rs; const double* __restrict__ us = C.us;
-    const int n = C.n;
+// Which of the first OV_SPEC neighbours of stop node i count (bit k: the k-th neighbour in the reference's walking order -- forward
+// stop: j = i + 3 - k; reverse stop: j = i - 3 + k), and whether the walk ends among them (bit 31).  Positions, strands and
+// types only: the same for every model scored on the contig, so a launch over (chain, stop) pairs reads it from OvlTopo.
+constexpr int OV_SPEC = 16;
+__device__ __forceinline__ unsigned overlap_neighbours(const int32_t* __restrict__ ndx, const int32_t* __restrict__ stv, const uint8_t* __restrict__ typ,
+                                                       const int8_t* __restrict__ str, const int n, const int i, const int maxov) {
     const int my = ndx[i];
-    double best = -100;
     const bool fwd = str[i] == 1;
-    const double rs_i = rs[i], us_i = us[i];
-    // The reference walks the neighbours one by one (forward stop: j = i + 3 downwards; reverse stop: j = i - 3 upwards) until
-    // it leaves the overlap window.  Which neighbours count is decided by positions, strands and types alone: the first
-    // OV_SPEC of them are read at once (one memory round trip instead of one or two per neighbour), then only the ones
-    // that count are priced, in the reference's order.
-    constexpr int OV_SPEC = 16;
     bool ended = false;
     unsigned elig = 0;
 #pragma unroll
@@ -1930,8 +1923,25 @@ __device__ __forceinline__ void overlapping_starts_of(const OvlChain& C, const i
         ended = ended || stop_here;
         if (ok && !ended) elig |= 1u << k;
     }
+    return elig | (ended ? 0x80000000u : 0u);
+}
+
+__device__ __forceinline__ void overlapping_starts_of(const OvlChain& C, const int i, const ModelConst* __restrict__ mc, const int maxov,
+                                                      int& sp0, int& sp1, int& sp2, const unsigned neighbours) {
+    const int32_t* __restrict__ ndx = C.ndx; const int32_t* __restrict__ stv = C.stv;
+    const uint8_t* __restrict__ typ = C.typ; const int8_t* __restrict__ str = C.str;
+    const double* __restrict__ cs = C.cs; const double* __restrict__ ss = C.ss; const double* __restrict__ rs = C.rs; const double* __restrict__ us = C.us;
+    const int n = C.n;
+    const int my = ndx[i];
+    double best = -100;
+    const bool fwd = str[i] == 1;
+    const double rs_i = rs[i], us_i = us[i];
+    // The reference walks the neighbours one by one (forward stop: j = i + 3 downwards; reverse stop: j = i - 3 upwards) until
+    // it leaves the overlap window.  Which of the first OV_SPEC count is known (overlap_neighbours); only those are priced, in
+    // the reference's order; a window that is not done by then (rare) goes on one by one.
+    unsigned elig = neighbours & 0xffffu;
     int js = fwd ? i + 3 - OV_SPEC : i - 3 + OV_SPEC;        // where the one-by-one walk goes on if the window is not done by then
-    bool more = !ended;
+    bool more = !(neighbours >> 31);
     for (;;) {
         int j = -1;
         if (elig) {
@@ -1961,6 +1971,26 @@ __device__ __forceinline__ void overlapping_starts_of(const OvlChain& C, const i
     }
 }
 
+// the neighbours that count, once per stop node of a group (ga.ovl_topo, indexed like ga.stop_list)
+__global__ void __launch_bounds__(256)
+k_ovl_topo(GroupArrays ga, const int32_t* __restrict__ cbase, const int32_t* __restrict__ sbase, int n_contigs, int n_stops, int maxov) {
+    __shared__ int s_c0;
+    const int blk0 = blockIdx.x * blockDim.x, s = blk0 + threadIdx.x;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = n_contigs - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (sbase[mid] <= blk0) lo = mid; else hi = mid - 1; }
+        s_c0 = lo;
+    }
+    __syncthreads();
+    if (s >= n_stops) return;
+    int c = s_c0;
+    while (c + 1 < n_contigs && sbase[c + 1] <= s) c++;
+    const int b0 = cbase[c], n = cbase[c + 1] - b0;
+    const int i = ga.stop_list[s] - b0;
+    ga.ovl_topo[s] = ga.edge0[b0 + i] == 1 ? 0x80000000u
+                                           : overlap_neighbours(ga.ndx + b0, ga.stop_val + b0, ga.type + b0, ga.strand + b0, n, i, maxov);
+}
+
 // one thread per chain node
 __global__ void __launch_bounds__(256)
 k_overlapping_starts(const ChainDesc* __restrict__ chains, int n_chains, int64_t node_begin, int64_t total,
@@ -1978,7 +2008,7 @@ k_overlapping_starts(const ChainDesc* __restrict__ chains, int n_chains, int64_t
     if (ga.type[tb + i] == PGA_T_STOP && ga.edge0[tb + i] != 1) {
         const OvlChain C{ga.ndx + tb, ga.stop_val + tb, ga.type + tb, ga.strand + tb, ca.cscore + ch.off, ca.sscore + ch.off, ca.rscore + ch.off,
                          ca.uscore + ch.off, ch.n};
-        overlapping_starts_of(C, i, &mcs[ch.model], maxov, sp0, sp1, sp2);
+        overlapping_starts_of(C, i, &mcs[ch.model], maxov, sp0, sp1, sp2, overlap_neighbours(C.ndx, C.stv, C.typ, C.str, C.n, i, maxov));
     }
     ca.star_ptr[3 * g] = sp0; ca.star_ptr[3 * g + 1] = sp1; ca.star_ptr[3 * g + 2] = sp2;
 }
@@ -2005,14 +2035,15 @@ k_ovl_stops(const ChainDesc* __restrict__ chains, int n_chains, int64_t soff_beg
     while (c + 1 < n_chains && chains[c + 1].soff <= p) c++;
     const ChainDesc ch = chains[c];
     const int64_t tb = ch.topo_off;
-    const int i = ga.stop_list[sbase[ch.contig] + (int)(p - ch.soff)] - cbase[ch.contig];
+    const int sidx = sbase[ch.contig] + (int)(p - ch.soff);
+    const int i = ga.stop_list[sidx] - cbase[ch.contig];
     const int64_t g = ch.off + i;
     const ModelConst* __restrict__ mc = &mcs[ch.model];
     int sp[3] = {-1, -1, -1};
     if (ga.edge0[tb + i] != 1) {
         const OvlChain C{ga.ndx + tb, ga.stop_val + tb, ga.type + tb, ga.strand + tb, ca.cscore + ch.off, ca.sscore + ch.off, ca.rscore + ch.off,
                          ca.uscore + ch.off, ch.n};
-        overlapping_starts_of(C, i, mc, maxov, sp[0], sp[1], sp[2]);
+        overlapping_starts_of(C, i, mc, maxov, sp[0], sp[1], sp[2], ga.ovl_topo[sidx]);
         ca.star_ptr[3 * g] = sp[0]; ca.star_ptr[3 * g + 1] = sp[1]; ca.star_ptr[3 * g + 2] = sp[2];
     }
     if (ext != nullptr) {
@@ -2242,6 +2273,9 @@ void pga_launch_score(const ChainDesc* d_chains, int n_chains, int64_t node_begi
                            group_nodes, d_dig, d_ct, ga, d_models, ca, sp, d_sd_lut);
     if (stops != nullptr) {
         (void)hipMemsetAsync(ca.star_ptr + 3 * node_begin, 0xff, sizeof(int32_t) * 3 * (size_t)total, st);
+        if (stops->n_pairs > 0 && stops->n_stops > 0)
+            hipLaunchKernelGGL(k_ovl_topo, dim3(nblocks(stops->n_stops, 256)), blk, 0, st, ga, d_node_contig_base, stops->sbase, n_contigs, stops->n_stops,
+                               sp.max_overlap);
         if (stops->n_pairs > 0)
             hipLaunchKernelGGL(k_ovl_stops, dim3(nblocks(stops->n_pairs, 256)), blk, 0, st, d_chains, n_chains, stops->soff_begin, stops->n_pairs, ga,
                                d_node_contig_base, stops->sbase, d_mc, ca, sp.max_overlap, stops->topo_q2, (DpwExt*)stops->ext);
