@@ -105,54 +105,71 @@ __device__ __forceinline__ int digit_of(int ch, int& gc, int& unk) {
     }
 }
 
-// 16 bases per thread (one 16-byte load and store per lane); GC / unknown counts are reduced per
-// wave and added with one atomic when the whole wave sits inside one contig.
+// Four letters of a 32-bit word -> four digits (A 0, G 1, C 2, T 3, anything else 6; either case), with the number of G / C and of
+// unknown letters among them.  Byte-parallel: no per-letter branch or select chain.
+__device__ __forceinline__ unsigned digits4(const unsigned w, int& gc, int& unk) {
+    const unsigned u = w & 0xdfdfdfdfu;                           // upper case: only 'a' .. 'z' map onto 'A' .. 'Z'
+    auto eq = [](const unsigned v) {                              // 0x01 in every byte of v that is zero (exact, no borrow between bytes)
+        return (~(((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v | 0x7f7f7f7fu)) >> 7;
+    };
+    const unsigned a = eq(u ^ 0x41414141u), g = eq(u ^ 0x47474747u), c = eq(u ^ 0x43434343u), t = eq(u ^ 0x54545454u);
+    const unsigned n = ~(a | g | c | t) & 0x01010101u;
+    gc += __popc(g | c); unk += __popc(n);
+    return g | (c << 1) | t | (t << 1) | (n << 1) | (n << 2);
+}
+
+// 64 bases per thread as four 16-byte pieces 4 KB apart (the pieces of a wavefront are contiguous: coalesced, four loads in flight
+// per lane); GC / unknown counts are reduced per wavefront and piece and added with one atomic when the piece's 1 KB lies in
+// one contig.
+constexpr int DG_BLOCK = 16384;
 __global__ void __launch_bounds__(256)
 k_digitize(const char* __restrict__ seq, uint8_t* __restrict__ dig, int64_t total,
            const ContigDesc* __restrict__ ct, int n_contigs, int32_t* __restrict__ gc_count, int32_t* __restrict__ unk_count) {
     __shared__ int s_c0;
-    const int64_t blk0 = (int64_t)blockIdx.x * 4096;
-    const int64_t g0 = blk0 + (int64_t)threadIdx.x * 16;
-    const bool in = g0 < total;
-    int c = block_contig(ct, n_contigs, blk0, in ? g0 : blk0, &s_c0);
-    int gc = 0, unk = 0;
-    bool one_contig = true;
-    if (in) {
-        const int64_t next = ct[c + 1 <= n_contigs ? c + 1 : n_contigs].base;     // ct has n_contigs + 1 entries
-        if (g0 + 16 <= total && g0 + 16 <= next) {
-            const uint4 v = *reinterpret_cast<const uint4*>(seq + g0);
-            const unsigned w[4] = {v.x, v.y, v.z, v.w};
-            unsigned o[4];
+    const int64_t blk0 = (int64_t)blockIdx.x * DG_BLOCK;
+    int c = block_contig(ct, n_contigs, blk0, blk0, &s_c0);       // contig of the block's first base; pieces walk on from there
+    uint4 v[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                unsigned r = 0;
+    for (int q = 0; q < 4; q++) {
+        const int64_t g0 = blk0 + q * 4096 + (int64_t)threadIdx.x * 16;
+        v[q] = g0 + 16 <= total ? *reinterpret_cast<const uint4*>(seq + g0) : make_uint4(0, 0, 0, 0);
+    }
 #pragma unroll
-                for (int k = 0; k < 4; k++) r |= (unsigned)digit_of((w[q] >> (8 * k)) & 0xff, gc, unk) << (8 * k);
-                o[q] = r;
-            }
-            *reinterpret_cast<uint4*>(dig + g0) = make_uint4(o[0], o[1], o[2], o[3]);
-        } else {
-            one_contig = false;
-            for (int k = 0; k < 16 && g0 + k < total; k++) {
-                const int64_t g = g0 + k;
-                while (c + 1 < n_contigs && ct[c + 1].base <= g) c++;
-                int a = 0, u = 0;
-                dig[g] = (uint8_t)digit_of(seq[g], a, u);
-                if (a) atomicAdd(&gc_count[c], 1);
-                if (u) atomicAdd(&unk_count[c], 1);
+    for (int q = 0; q < 4; q++) {
+        const int64_t g0 = blk0 + q * 4096 + (int64_t)threadIdx.x * 16;
+        const bool in = g0 < total;
+        if (in) while (c + 1 < n_contigs && ct[c + 1].base <= g0) c++;
+        int gc = 0, unk = 0;
+        bool one_contig = true;
+        if (in) {
+            const int64_t next = ct[c + 1 <= n_contigs ? c + 1 : n_contigs].base;     // ct has n_contigs + 1 entries
+            if (g0 + 16 <= total && g0 + 16 <= next) {
+                const uint4 o = make_uint4(digits4(v[q].x, gc, unk), digits4(v[q].y, gc, unk), digits4(v[q].z, gc, unk), digits4(v[q].w, gc, unk));
+                *reinterpret_cast<uint4*>(dig + g0) = o;
+            } else {
+                one_contig = false;
+                int cc = c;
+                for (int k = 0; k < 16 && g0 + k < total; k++) {
+                    const int64_t g = g0 + k;
+                    while (cc + 1 < n_contigs && ct[cc + 1].base <= g) cc++;
+                    int a = 0, u = 0;
+                    dig[g] = (uint8_t)digit_of(seq[g], a, u);
+                    if (a) atomicAdd(&gc_count[cc], 1);
+                    if (u) atomicAdd(&unk_count[cc], 1);
+                }
             }
         }
-    }
-    const int c0 = __builtin_amdgcn_readfirstlane(c);
-    const bool uniform = __all(!in || (one_contig && c == c0));
-    if (uniform) {
-        int a = in ? gc : 0, u = in ? unk : 0;
+        const int c0 = __builtin_amdgcn_readfirstlane(c);
+        const bool uniform = __all(!in || (one_contig && c == c0));
+        if (uniform) {
+            int a = in ? gc : 0, u = in ? unk : 0;
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m, 64); u += __shfl_xor(u, m, 64); }
-        if ((threadIdx.x & 63) == 0) { if (a) atomicAdd(&gc_count[c0], a); if (u) atomicAdd(&unk_count[c0], u); }
-    } else if (in && one_contig) {
-        if (gc) atomicAdd(&gc_count[c], gc);
-        if (unk) atomicAdd(&unk_count[c], unk);
+            for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m, 64); u += __shfl_xor(u, m, 64); }
+            if ((threadIdx.x & 63) == 0) { if (a) atomicAdd(&gc_count[c0], a); if (u) atomicAdd(&unk_count[c0], u); }
+        } else if (in && one_contig) {
+            if (gc) atomicAdd(&gc_count[c], gc);
+            if (unk) atomicAdd(&unk_count[c], unk);
+        }
     }
 }
 
@@ -2065,7 +2082,7 @@ int64_t pga_gc_blocks(int64_t total) { return (total + 1 + 4095) / 4096; }
 void pga_launch_digitize(const char* d_seq, uint8_t* d_dig, int64_t total, const ContigDesc* d_ct, int n_contigs,
                          int32_t* d_gc, int32_t* d_unk, hipStream_t st) {
     if (total <= 0) return;
-    hipLaunchKernelGGL(k_digitize, dim3(nblocks(total, 4096)), dim3(256), 0, st, d_seq, d_dig, total, d_ct, n_contigs, d_gc, d_unk);
+    hipLaunchKernelGGL(k_digitize, dim3(nblocks(total, DG_BLOCK)), dim3(256), 0, st, d_seq, d_dig, total, d_ct, n_contigs, d_gc, d_unk);
 }
 
 // Runs of unknown bases (ref: lib.pyx:699-713, Sequence._mask): the thread that sees the first N of a run walks to
