@@ -570,33 +570,44 @@ k_extract_tile(const uint8_t* __restrict__ dig, int64_t total, const ContigDesc*
     if (t == 0) tile_scount[tile] = s_stops;
 }
 
-// Exclusive scan of n counts into n + 1 offsets, one workgroup: 8 elements per thread and round.
+// Exclusive scan of n counts into n + 1 offsets, one workgroup: 8 elements per thread and round.  Two arrays at once when cnt2
+// is given (node and stop-node counts of the tiles share the launch and its barriers).
 __global__ void __launch_bounds__(1024)
-k_scan_counts(const int32_t* __restrict__ cnt, int n, int32_t* __restrict__ off) {
-    __shared__ int s_w[16];
-    __shared__ int s_carry;
+k_scan_counts(const int32_t* __restrict__ cnt, int n, int32_t* __restrict__ off, const int32_t* __restrict__ cnt2, int32_t* __restrict__ off2) {
+    __shared__ int s_w[16], s_w2[16];
+    __shared__ int s_carry, s_carry2;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    if (t == 0) s_carry = 0;
+    const bool two = cnt2 != nullptr;
+    if (t == 0) { s_carry = 0; s_carry2 = 0; }
     __syncthreads();
     for (int base = 0; base < n; base += 8192) {
         const int i0 = base + t * 8;
-        int v[8], sum = 0;
+        int v[8], v2[8], sum = 0, sum2 = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) { v[k] = i0 + k < n ? cnt[i0 + k] : 0; sum += v[k]; }
-        int inc = sum;
+        for (int k = 0; k < 8; k++) {
+            v[k] = i0 + k < n ? cnt[i0 + k] : 0; sum += v[k];
+            v2[k] = two && i0 + k < n ? cnt2[i0 + k] : 0; sum2 += v2[k];
+        }
+        int inc = sum, inc2 = sum2;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(inc, o, 64); if (lane >= o) inc += x; }
-        if (lane == 63) s_w[w] = inc;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int x = __shfl_up(inc, o, 64), x2 = __shfl_up(inc2, o, 64);
+            if (lane >= o) { inc += x; inc2 += x2; }
+        }
+        if (lane == 63) { s_w[w] = inc; s_w2[w] = inc2; }
         __syncthreads();
-        int run = s_carry + inc - sum;
-        for (int k = 0; k < w; k++) run += s_w[k];
+        int run = s_carry + inc - sum, run2 = s_carry2 + inc2 - sum2;
+        for (int k = 0; k < w; k++) { run += s_w[k]; run2 += s_w2[k]; }
 #pragma unroll
-        for (int k = 0; k < 8; k++) { if (i0 + k < n) off[i0 + k] = run; run += v[k]; }
+        for (int k = 0; k < 8; k++) {
+            if (i0 + k < n) { off[i0 + k] = run; if (two) off2[i0 + k] = run2; }
+            run += v[k]; run2 += v2[k];
+        }
         __syncthreads();
-        if (t == 1023) s_carry = run;
+        if (t == 1023) { s_carry = run; s_carry2 = run2; }
         __syncthreads();
     }
-    if (t == 0) off[n] = s_carry;
+    if (t == 0) { off[n] = s_carry; if (two) off2[n] = s_carry2; }
 }
 
 // first node of every contig (n_contigs + 1 entries) from the tile offsets
@@ -2138,7 +2149,7 @@ void pga_launch_gc_prefix(const uint8_t* d_dig, int64_t total, int32_t* d_block_
     if (total <= 0) return;
     const int nb = (int)pga_gc_blocks(total);
     hipLaunchKernelGGL(k_gcp_blocks, dim3(nb), dim3(256), 0, st, d_dig, total, d_block_sum);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, d_block_sum, nb, d_block_off);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, d_block_sum, nb, d_block_off, (const int32_t*)nullptr, (int32_t*)nullptr);
     hipLaunchKernelGGL(k_gcp_final, dim3(nb), dim3(256), 0, st, d_dig, total, d_block_off, d_p16);
 }
 
@@ -2157,8 +2168,7 @@ void pga_launch_extract(const uint8_t* d_dig, int64_t total, const ContigDesc* d
         hipLaunchKernelGGL(k_extract_tile, dim3(n_tiles), dim3(256), 0, st, d_dig, total, d_ct, d_tiles, n_tiles, d_tile_first, d_tile_last, P, ga, masks,
                            d_enabled, d_tile_count, d_tile_scount);
     }
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, d_tile_count, n_tiles, d_tile_off);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, d_tile_scount, n_tiles, d_tile_soff);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, d_tile_count, n_tiles, d_tile_off, (const int32_t*)d_tile_scount, d_tile_soff);
     hipLaunchKernelGGL(k_contig_node_base, dim3((n_contigs + 1 + 255) / 256), dim3(256), 0, st, d_tile0, n_contigs, d_tile_off, d_cbase);
     hipLaunchKernelGGL(k_contig_node_base, dim3((n_contigs + 1 + 255) / 256), dim3(256), 0, st, d_tile0, n_contigs, d_tile_soff, d_sbase);
 }
