@@ -2,7 +2,7 @@
 # Collect the rocprofv3 evidence for bench.py on the GPU box (run through gpurun from the repo root):
 #   gpurun --timeout 900 -- 'bash tools/collect_profiles.sh r02_a'
 # Kernel trace + stats and the HBM counters are separate passes (one counter per pass, never together with a trace).
-# Workloads: config3 (1000 x 50 kbp) and one device call of the config 4 job (12 500 x 20 kbp), one context each so that a
+# Workloads: config3 (1000 x 50 kbp) and one device call of the config 4 job (6 250 x 20 kbp, bench.py's default sub-batch), one context each so that a
 # kernel's duration is its own.  Results land in gpurun_out/prof_<tag>/; tools/profiles_summary.py turns them into
 # profiles/<tag>_*.
 set -u
@@ -19,7 +19,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 for WL in config3 config4; do
     ARGS="--workload $WL $COMMON"
-    [ $WL = config4 ] && ARGS="--workload config4 --contigs 12500 $COMMON"
+    [ $WL = config4 ] && ARGS="--workload config4 --contigs 6250 $COMMON"
     ( cd /tmp && timeout -k 5 240 rocprofv3 --kernel-trace --stats -d "$OUT/trace_$WL" -o t -- \
         python "$REPO/bench.py" $ARGS --steps 4 --warmup 2 > "$OUT/bench_$WL.json" 2> "$OUT/trace_$WL.log" )
     for C in FETCH_SIZE WRITE_SIZE; do
