@@ -302,9 +302,11 @@ __device__ __forceinline__ void wave_step(const SrcRegs& R, const int u, const i
 template <int OCC>
 __global__ void __launch_bounds__(64, OCC)
 k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const double* __restrict__ g_cs, const DpwExt* __restrict__ g_ext,
-          const ModelConst* __restrict__ models, DpBuffers buf, double* __restrict__ g_sfxv, int32_t* __restrict__ g_sfxi) {
+          const ModelConst* __restrict__ models, DpBuffers buf, double* __restrict__ g_sfxv, int32_t* __restrict__ g_sfxi,
+          const int32_t* __restrict__ order /* or nullptr: workgroup b walks chain order[b] (longest chains first) */) {
     __shared__ double s_igm[64];
-    const ChainDesc cd = chains[blockIdx.x];
+    const int chain = order != nullptr ? order[blockIdx.x] : (int)blockIdx.x;
+    const ChainDesc cd = chains[chain];
     const int lane = threadIdx.x;
     const int n = cd.n;
     const ModelConst* mc = &models[cd.model];
@@ -563,8 +565,8 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
         if (ob > end_best || (ob == end_best && oi > end_idx)) { end_best = ob; end_idx = oi; end_tb = ot; }
     }
     if (lane == 0) {
-        buf.max_index[blockIdx.x] = end_idx; buf.max_score[blockIdx.x] = end_idx >= 0 ? end_best : 0.0;
-        buf.ipath[blockIdx.x] = (end_idx >= 0 && end_tb != -1) ? end_idx : -1;
+        buf.max_index[chain] = end_idx; buf.max_score[chain] = end_idx >= 0 ? end_best : 0.0;
+        buf.ipath[chain] = (end_idx >= 0 && end_tb != -1) ? end_idx : -1;
     }
 }
 
@@ -585,14 +587,14 @@ void pga_launch_dpw_chain(const ChainDesc* d_chains, int n_chains, int64_t node_
 }
 
 void pga_launch_dp_wave(const ChainDesc* d_chains, int n_chains, const DpwGroupPtrs& groups, const ModelConst* d_models, DpBuffers buf,
-                        const DpwBuffers& wb, hipStream_t st) {
+                        const DpwBuffers& wb, hipStream_t st, const int32_t* d_order) {
     if (n_chains <= 0) return;
     static int occ = 0;
     if (!occ) { const char* e = getenv("PGA_DPW_OCC"); occ = e ? atoi(e) : 5; if (occ < 4 || occ > 6) occ = 5; }
     if (occ == 5) hipLaunchKernelGGL(k_dp_wave<5>, dim3((unsigned)n_chains), dim3(64), 0, st, d_chains, groups, (const double*)wb.cs, (const DpwExt*)wb.ext,
-                                     d_models, buf, wb.sfxv, wb.sfxi);
+                                     d_models, buf, wb.sfxv, wb.sfxi, d_order);
     else if (occ == 6) hipLaunchKernelGGL(k_dp_wave<6>, dim3((unsigned)n_chains), dim3(64), 0, st, d_chains, groups, (const double*)wb.cs, (const DpwExt*)wb.ext,
-                                          d_models, buf, wb.sfxv, wb.sfxi);
+                                          d_models, buf, wb.sfxv, wb.sfxi, d_order);
     else hipLaunchKernelGGL(k_dp_wave<4>, dim3((unsigned)n_chains), dim3(64), 0, st, d_chains, groups, (const double*)wb.cs, (const DpwExt*)wb.ext,
-                            d_models, buf, wb.sfxv, wb.sfxi);
+                            d_models, buf, wb.sfxv, wb.sfxi, d_order);
 }

@@ -1225,6 +1225,21 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             HT(c, pga_dp_seg_bind(seg_plan, NCH, tot_chain_nodes, seg_arena, st, &seg_dev));
         }
         DEVBUF(d_chains, ChainDesc, "d_chains", NCH + NC + 1);
+        // start order of the wave-batch scorer: longest chains first (counting sort on nodes / 64 = walk batches)
+        int32_t* d_dp_order = nullptr;
+        std::vector<int32_t> dp_order;
+        if (use_wave && NCH > 1 && !getenv("PGA_DP_NO_ORDER")) {
+            int maxb = 0;
+            for (int k = 0; k < NCH; k++) maxb = std::max(maxb, chains[k].n >> 6);
+            std::vector<int32_t> first((size_t)maxb + 2, 0);
+            for (int k = 0; k < NCH; k++) first[(size_t)(maxb - (chains[k].n >> 6)) + 1]++;
+            for (int b = 0; b <= maxb; b++) first[(size_t)b + 1] += first[(size_t)b];
+            dp_order.resize((size_t)NCH);
+            for (int k = 0; k < NCH; k++) dp_order[(size_t)first[(size_t)(maxb - (chains[k].n >> 6))]++] = k;
+            DEVBUF(d_ord, int32_t, "d_dp_order", NCH + 1);
+            HT(c, hipMemcpyAsync(d_ord, dp_order.data(), sizeof(int32_t) * (size_t)NCH, hipMemcpyHostToDevice, st));
+            d_dp_order = d_ord;
+        }
         PINBUF(h_maxidx, int32_t, "h_maxidx", NCH + 1);
         PINBUF(h_ipath, int32_t, "h_ipath", NCH + 1);
         PINBUF(h_maxscore, double, "h_maxscore", NCH + 1);
@@ -1343,7 +1358,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         }
         // one DP launch over the chains of every group: chains are independent, the more in flight the better
         HT(c, hipEventRecord(f->e_dp0[0], st));
-        if (use_wave) pga_launch_dp_wave(d_chains, NCH, wgroups, c->d_model_const, dp, wbuf, st);
+        if (use_wave) pga_launch_dp_wave(d_chains, NCH, wgroups, c->d_model_const, dp, wbuf, st, d_dp_order);
         else pga_launch_dp(d_chains, NCH, c->d_model_const, dp, 1, st, segmented ? &seg_dev : nullptr);
         HT(c, hipEventRecord(f->e_dp1[0], st));
         HT(c, hipMemcpyAsync(h_maxidx, dp.max_index, sizeof(int32_t) * NCH, hipMemcpyDeviceToHost, st));

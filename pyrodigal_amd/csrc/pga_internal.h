@@ -138,8 +138,9 @@ void pga_launch_dpw_topo(const DpwTopoArrays& ta, const uint8_t* type, const int
 // chains[0..n_chains) of ONE group, contiguous in `off` from node_begin
 void pga_launch_dpw_chain(const ChainDesc* d_chains, int n_chains, int64_t node_begin, int64_t total_nodes, const NodeArrays& nodes,
                           const DpwTopoArrays& ta, const ModelConst* d_models, const DpwBuffers& wb, hipStream_t st);
+// d_order (optional): the order in which the chains are started -- a launch ends when its last chain does, so long chains go first
 void pga_launch_dp_wave(const ChainDesc* d_chains, int n_chains, const DpwGroupPtrs& groups, const ModelConst* d_models, DpBuffers buf,
-                        const DpwBuffers& wb, hipStream_t st);
+                        const DpwBuffers& wb, hipStream_t st, const int32_t* d_order = nullptr);
 
 // kernel launchers (dp.hip)
 // chains[0..n_chains) must be contiguous in `off`; node_begin = chains[0].off, total_nodes = their node count
