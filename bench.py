@@ -296,7 +296,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(seqs, models, res[0] if res else None)
     fasta_line = None
     if rank == 0 and world == 1 and not single and not args.no_secondary:
-        fasta_line = fasta_to_genes(seqs[:min(len(seqs), 5000)], models, dev_index, kw)
+        fasta_line = fasta_to_genes(seqs[:min(len(seqs), 20000)], models, dev_index, kw)
     for b in batches:
         b.close()
     lanes.close()
