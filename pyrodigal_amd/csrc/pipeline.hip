@@ -2198,7 +2198,8 @@ bool pga_cs_tasks(const int2* h_cc /* per contig: first chain, count */, int n_c
             bucket[(size_t)(r0 + m0)].push_back(i); bucket[(size_t)(r0 + m0)].push_back(m0);
         }
     }
-    for (int q = 0; q < 64; q++) {
+    // columns of high-GC models first: their contigs have the longest ORFs, and a launch ends when its last task does
+    for (int q = 63; q >= 0; q--) {
         const std::vector<int32_t>& b = bucket[(size_t)q];
         int first = (int)(entries.size() / 4), count = 0, nodes = 0;
         auto flush = [&]() {
