@@ -511,6 +511,53 @@ k_tail_tweak(const TailDesc* __restrict__ td, int n_contigs, int64_t n_slots, Ou
     changed[slot] = moved ? 1 : 0;
     if (moved) atomicAdd(&n_changed[c], 1);
 }
+// The same over the genes themselves instead of over their (mostly empty) slots: gene number q of the batch is gene q - gpre[c]
+// of the contig c with gpre[c] <= q < gpre[c + 1] (gpre = running sum of n_genes, k_gene_prefix).  With many short contigs the
+// genes are a few per contig: one thread per slot leaves a handful of busy lanes in each of twenty thousand wavefronts, each of
+// which takes as long as its slowest lane; packed, the same lanes fill a few hundred.
+__global__ void __launch_bounds__(1024)
+k_gene_prefix(const int32_t* __restrict__ n_genes, int n_contigs, int32_t* __restrict__ gpre) {
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_contigs; base += 1024) {
+        const int v = base + t < n_contigs ? n_genes[base + t] : 0;
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(inc, o, 64); if (lane >= o) inc += x; }
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        int run = s_carry + inc - v;
+        for (int k = 0; k < w; k++) run += s_w[k];
+        if (base + t < n_contigs) gpre[base + t] = run;
+        __syncthreads();
+        if (t == 1023) s_carry = run + v;
+        __syncthreads();
+    }
+    if (t == 0) gpre[n_contigs] = s_carry;
+}
+__global__ void __launch_bounds__(256)
+k_tail_tweak_packed(const TailDesc* __restrict__ td, int n_contigs, OutArrays o, int32_t* tracef, uint8_t* elim,
+                    const GeneRec* __restrict__ orig, GeneRec* __restrict__ out, const int32_t* __restrict__ n_genes, int maxov,
+                    uint8_t* __restrict__ changed, int32_t* __restrict__ n_changed, const int32_t* __restrict__ gpre) {
+    const int total = gpre[n_contigs];
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
+        int lo = 0, hi = n_contigs - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (gpre[mid] <= q) lo = mid; else hi = mid - 1; }
+        const int c = lo, g = q - gpre[c], ng = n_genes[c];
+        const TailDesc d = td[c];
+        const NodeView v = node_view(d, o, tracef, elim);
+        const GeneRec* base = orig + d.gene_off;
+        GeneRec cur = base[g];
+        tweak_one(v, g > 0 ? &base[g - 1] : nullptr, cur, g < ng - 1 ? &base[g + 1] : nullptr, d.st_wt, maxov);
+        out[d.gene_off + g] = cur;
+        const bool moved = cur.start_ndx != base[g].start_ndx && v.strand[cur.start_ndx] == -1;
+        changed[d.gene_off + g] = moved ? 1 : 0;
+        if (moved) atomicAdd(&n_changed[c], 1);
+    }
+}
 // tweak_one with the wavefront on ONE gene: the 200 candidate nodes are filtered and priced by the lanes (that is where the
 // memory traffic is), the few that pass are then merged one after the other in index order, as the reference's loop
 // meets them -- its two-best bookkeeping depends on that order.  Every lane returns the same record.
@@ -1691,7 +1738,12 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             if (max_n >= 32768 && NC <= 1024)       // genomes: a wavefront per gene (at most n / 2 + 2 genes per contig)
                 hipLaunchKernelGGL(k_tail_tweak_wave, dim3((unsigned)((max_n / 2 + 2 + 3) / 4), (unsigned)NC), dim3(256), 0, st, d_td, NC, o, d_tracef,
                                    d_elim, d_gene0, d_gene1, d_ngenes, P.max_overlap, d_changed, d_nchanged);
-            else
+            else if (NC >= 256 && !getenv("PGA_TWEAK_SLOTS")) {   // many contigs: one thread per gene of the batch, packed
+                DEVBUF(d_gpre, int32_t, "d_gene_prefix", NC + 2);
+                hipLaunchKernelGGL(k_gene_prefix, dim3(1), dim3(1024), 0, st, d_ngenes, NC, d_gpre);
+                hipLaunchKernelGGL(k_tail_tweak_packed, dim3(1024), dim3(256), 0, st, d_td, NC, o, d_tracef, d_elim, d_gene0, d_gene1, d_ngenes,
+                                   P.max_overlap, d_changed, d_nchanged, d_gpre);
+            } else
                 hipLaunchKernelGGL(k_tail_tweak, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, st, d_td, NC, n_slots, o, d_tracef, d_elim,
                                    d_gene0, d_gene1, d_ngenes, P.max_overlap, d_changed, d_nchanged);
             DEVBUF(d_gene2, GeneRec, "d_gene2", n_slots + 1);
