@@ -5,6 +5,7 @@
 // tests/test_dpw_model.py against the CPU oracle; nothing in the product links it.
 #include "../pyrodigal_amd/csrc/dpw_core.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -195,6 +196,37 @@ extern "C" int dpw_model_run(int n, const int32_t* ndx, const int32_t* stop_val,
                 }
             }
         }
+        // ---- (6') instead of the walk, if asked for (DPW_MODEL_FIXPOINT=1): every lane recomputes its best in-batch source from the
+        //      CURRENT values of the lanes before it, all lanes at once, until nothing changes.  Lane k is right after k + 1 rounds
+        //      at the latest (its sources are), so the rounds end, and a state that reproduces itself is the walk's result; in
+        //      practice a lane is right one round after its own best source is, i.e. after as many rounds as the longest run of
+        //      tracebs inside the batch.  stats[4] = rounds, stats[5] = batches, stats[6] = most rounds of a batch.
+        static const bool fixpoint = getenv("DPW_MODEL_FIXPOINT") != nullptr;
+        if (fixpoint) {
+            DpwLane L0[64];
+            for (int t = 0; t < 64; t++) L0[t] = L[t];
+            int rounds = 0;
+            for (;;) {
+                DpwLane Ln[64];
+                for (int t = 0; t < 64; t++) Ln[t] = L0[t];
+                for (int k = 0; k < 64 && i0 + k < n; k++) {
+                    DpwS S; memset(&S, 0, sizeof S);
+                    S.j = i0 + k; S.kind = T[k].kind; S.frame = T[k].frame; S.ndx = T[k].ndx; S.stop_val = T[k].stop_val; S.vm = T[k].vm;
+                    const int tbk = dpw_tag_index(L[k].tag);
+                    S.tbn = tbk < 0 ? -1 : (tbk >= i0 ? T[tbk - i0].ndx : tbn_pre[k]);
+                    S.score = L[k].val; S.cs = T[k].cs; S.x0 = T[k].x0; S.x1 = T[k].x1; S.x2 = T[k].x2;
+                    if ((S.kind == 1 || S.kind == 2) && tbk == -1) continue;
+                    for (int t = k + 1; t < 64; t++) dpw_step(S, LT[t], Ln[t], M);
+                }
+                rounds++;
+                bool same = true;
+                for (int t = 0; t < 64; t++) if (Ln[t].val != L[t].val || Ln[t].tag != L[t].tag) same = false;
+                for (int t = 0; t < 64; t++) L[t] = Ln[t];
+                if (same) break;
+            }
+            stats[4] += rounds; stats[5]++; if (rounds > stats[6]) stats[6] = rounds;
+            if (getenv("DPW_MODEL_ROUNDS")) fprintf(stderr, "R %d\n", rounds);
+        } else
         // ---- (6) the walk: lane k is final when the walk reaches source i0 + k
         for (int k = 0; k < 64 && i0 + k < n; k++) {
             DpwS S; memset(&S, 0, sizeof S);

@@ -35,5 +35,7 @@ for k in range(n):
         seq = bytes(s)
     m = models[int(rng.integers(len(models)))]
     nn, st = T.check(L, seq, m, closed=bool(rng.integers(2)), is_meta=bool(rng.integers(2)))
-    tot += st; nodes += nn
+    mx6 = max(int(tot[6]), int(st[6])); tot += st; tot[6] = mx6; nodes += nn
 print("ok: %d contigs, %d nodes identical to the oracle; generic far-field fallbacks %d, near steps %d, chain candidates %d + %d" % (n, nodes, tot[0], tot[1], tot[2], tot[3]))
+if tot[5]:
+    print("fixed-point mode: %.2f rounds per batch on average over %d batches, at most %d" % (tot[4] / tot[5], tot[5], tot[6]))
