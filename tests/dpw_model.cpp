@@ -225,7 +225,8 @@ extern "C" int dpw_model_run(int n, const int32_t* ndx, const int32_t* stop_val,
                 if (same) break;
             }
             stats[4] += rounds; stats[5]++; if (rounds > stats[6]) stats[6] = rounds;
-            if (getenv("DPW_MODEL_ROUNDS")) fprintf(stderr, "R %d\n", rounds);
+            static const bool log_rounds = getenv("DPW_MODEL_ROUNDS") != nullptr;
+            if (log_rounds) fprintf(stderr, "R %d\n", rounds);
         } else
         // ---- (6) the walk: lane k is final when the walk reaches source i0 + k
         for (int k = 0; k < 64 && i0 + k < n; k++) {
@@ -235,7 +236,10 @@ extern "C" int dpw_model_run(int n, const int32_t* ndx, const int32_t* stop_val,
             S.tbn = tbk < 0 ? -1 : (tbk >= i0 ? T[tbk - i0].ndx : tbn_pre[k]);
             S.score = L[k].val; S.cs = T[k].cs; S.x0 = T[k].x0; S.x1 = T[k].x1; S.x2 = T[k].x2;
             if ((S.kind == 1 || S.kind == 2) && tbk == -1) continue;
-            for (int t = k + 1; t < 64; t++) dpw_step(S, LT[t], L[t], M);
+            bool any = false;
+            for (int t = k + 1; t < 64; t++) { const DpwLane before = L[t]; dpw_step(S, LT[t], L[t], M); any = any || before.tag != L[t].tag || before.val != L[t].val; }
+            static const bool log_steps = getenv("DPW_MODEL_STEPS") != nullptr;      // "S <source kind> <taken by any lane>" per walk step
+            if (log_steps) fprintf(stderr, "S %d %d\n", S.kind, any ? 1 : 0);
         }
         // ---- (7) the batch is final: results, block structures, carries
         DpwBest B[64];
