@@ -132,6 +132,16 @@ int         pga_dp_stats(const pga_ctx*, int32_t out[8]);
  *   out[0] chains cut into segments   out[1] segments   out[2] nodes of the longest sub-chain (segment + warm-up)
  *   out[3] scratch elements behind the real chains in every per-node array */
 int         pga_dp_plan_summary(int32_t n_chains, const int32_t* nodes_per_chain, int64_t out[4]);
+/* The order in which the wave-batch connection scorer starts the chains of a launch: longest first by walk batches of 64 nodes,
+ * launch order among equals (host arithmetic only).  order[k] = index of the chain started k-th. */
+int         pga_dp_start_order(int32_t n_chains, const int32_t* nodes_per_chain, int32_t* order);
+/* How the ORF walks of the coding score (LDS-table form) of one translation-table group are cut into tasks (host arithmetic only):
+ * contig i has nodes_per_contig[i] nodes and is scored for models_per_contig[i] models whose table columns start at
+ * first_column[i] (columns of a contig are neighbours; every four of them are one walk).
+ *   out[0] tasks   out[1] entries (pieces of contigs)   out[2] nodes of the largest task   out[3] nodes over all tasks
+ *   out[4] 1 if the tasks of higher columns come first; returns PGA_EINVAL when the LDS form does not apply */
+int         pga_cs_task_summary(int32_t n_contigs, const int32_t* nodes_per_contig, const int32_t* first_column,
+                                const int32_t* models_per_contig, int32_t task_nodes, int64_t out[5]);
 
 /* ---- models (MetagenomicBins / TrainingInfo, ref: lib.pyx:4888-5069, 3898-3953) ---- */
 int pga_set_models(pga_ctx*, const pga_training* const* models, int n_models);

@@ -18,7 +18,7 @@ EXPORTS = [
     "pga_create", "pga_destroy", "pga_last_error", "pga_device_info", "pga_set_models",
     "pga_score_connections", "pga_score_connections_training", "pga_find_genes_batch", "pga_result_free",
     "pga_batch_create", "pga_batch_free", "pga_find_genes", "pga_nodes_stage",
-    "pga_fasta_open", "pga_fasta_next", "pga_fasta_error", "pga_fasta_close", "pga_train", "pga_dp_stats", "pga_dp_plan_summary",
+    "pga_fasta_open", "pga_fasta_next", "pga_fasta_error", "pga_fasta_close", "pga_train", "pga_dp_stats", "pga_dp_plan_summary", "pga_dp_start_order", "pga_cs_task_summary",
     "pga_fasta_next_packed", "pga_batch_create_packed", "pga_translate_genes",
 ]
 STAGE_EXTRACT, STAGE_SCORE, STAGE_OVERLAP, STAGE_SEQUENCE = 1, 2, 3, 4
@@ -123,6 +123,32 @@ def load():
     L.pga_fasta_close.restype = None; L.pga_fasta_close.argtypes = [vp]
     _lib = L
     return L
+
+
+def dp_start_order(nodes_per_chain):
+    """The order in which the wave-batch connection scorer starts the chains of a launch (host arithmetic, no device needed)."""
+    L = load()
+    n = len(nodes_per_chain)
+    arr = (ctypes.c_int32 * max(n, 1))(*[int(x) for x in nodes_per_chain])
+    out = (ctypes.c_int32 * max(n, 1))()
+    L.pga_dp_start_order.restype = ctypes.c_int
+    rc = L.pga_dp_start_order(ctypes.c_int32(n), arr, out)
+    if rc != PGA_OK:
+        raise ValueError("pga_dp_start_order failed (code %d)" % rc)
+    return list(out[:n])
+
+
+def cs_task_summary(nodes_per_contig, first_column, models_per_contig, task_nodes=4096):
+    """How the coding-score walks of one translation-table group are cut into tasks (host arithmetic, no device needed)."""
+    L = load()
+    n = len(nodes_per_contig)
+    mk = lambda xs: (ctypes.c_int32 * max(n, 1))(*[int(x) for x in xs])
+    out = (ctypes.c_int64 * 5)()
+    L.pga_cs_task_summary.restype = ctypes.c_int
+    rc = L.pga_cs_task_summary(ctypes.c_int32(n), mk(nodes_per_contig), mk(first_column), mk(models_per_contig), ctypes.c_int32(task_nodes), out)
+    if rc != PGA_OK:
+        raise ValueError("pga_cs_task_summary: the LDS form does not apply (code %d)" % rc)
+    return {"tasks": out[0], "entries": out[1], "largest_task": out[2], "nodes": out[3], "high_columns_first": bool(out[4])}
 
 
 def dp_plan_summary(nodes_per_chain):

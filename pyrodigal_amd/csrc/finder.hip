@@ -912,6 +912,46 @@ static hipError_t batch_upload_tiles(pga_batch* b, const std::vector<TileDesc>& 
     return e;
 }
 
+extern "C" int pga_dp_start_order(int32_t n_chains, const int32_t* nodes_per_chain, int32_t* order) {
+    if (n_chains < 0 || (n_chains > 0 && (!nodes_per_chain || !order))) return PGA_EINVAL;
+    // counting sort on walk batches (nodes / 64), most first; stable, so equals keep the launch order
+    int maxb = 0;
+    for (int k = 0; k < n_chains; k++) maxb = std::max(maxb, std::max(nodes_per_chain[k], 0) >> 6);
+    std::vector<int32_t> first((size_t)maxb + 2, 0);
+    for (int k = 0; k < n_chains; k++) first[(size_t)(maxb - (std::max(nodes_per_chain[k], 0) >> 6)) + 1]++;
+    for (int b = 0; b <= maxb; b++) first[(size_t)b + 1] += first[(size_t)b];
+    for (int k = 0; k < n_chains; k++) order[(size_t)first[(size_t)(maxb - (std::max(nodes_per_chain[k], 0) >> 6))]++] = k;
+    return PGA_OK;
+}
+
+extern "C" int pga_cs_task_summary(int32_t n_contigs, const int32_t* nodes_per_contig, const int32_t* first_column,
+                                   const int32_t* models_per_contig, int32_t task_nodes, int64_t out[5]) {
+    if (n_contigs < 0 || !out || (n_contigs > 0 && (!nodes_per_contig || !first_column || !models_per_contig)) || task_nodes < 1) return PGA_EINVAL;
+    // the inputs in the shape pga_cs_tasks plans from: one chain per (contig, model), columns = model ranks
+    std::vector<int2> cc((size_t)n_contigs); std::vector<ChainDesc> chains; std::vector<int32_t> cbase((size_t)n_contigs + 1, 0), rank;
+    int max_col = 0;
+    for (int i = 0; i < n_contigs; i++) max_col = std::max(max_col, first_column[i] + std::max(models_per_contig[i], 0));
+    rank.resize((size_t)max_col + 1);
+    for (int m = 0; m <= max_col; m++) rank[(size_t)m] = m;
+    for (int i = 0; i < n_contigs; i++) {
+        cbase[(size_t)i + 1] = cbase[(size_t)i] + std::max(nodes_per_contig[i], 0);
+        cc[(size_t)i] = make_int2((int)chains.size(), std::max(models_per_contig[i], 0));
+        for (int m = 0; m < models_per_contig[i]; m++) { ChainDesc ch{}; ch.model = first_column[i] + m; ch.contig = i; ch.n = nodes_per_contig[i]; chains.push_back(ch); }
+    }
+    std::vector<int32_t> tasks, entries;
+    if (!pga_cs_tasks(cc.data(), n_contigs, chains.data(), cbase.data(), rank.data(), task_nodes, tasks, entries)) return PGA_EINVAL;
+    const size_t nt = tasks.size() / 4, ne = entries.size() / 4;
+    int64_t biggest = 0, total = 0; bool falling = true;
+    for (size_t t = 0; t < nt; t++) {
+        int64_t nodes = 0;
+        for (int e = 0; e < tasks[4 * t + 2]; e++) nodes += entries[4 * (size_t)(tasks[4 * t + 1] + e) + 3];
+        biggest = std::max(biggest, nodes); total += nodes;
+        if (t > 0 && tasks[4 * t] > tasks[4 * (t - 1)]) falling = false;
+    }
+    out[0] = (int64_t)nt; out[1] = (int64_t)ne; out[2] = biggest; out[3] = total; out[4] = falling ? 1 : 0;
+    return PGA_OK;
+}
+
 extern "C" int pga_batch_create(pga_ctx* c, int32_t n_contigs, const char* const* seqs, const int64_t* lens, pga_batch** out) {
     if (out) *out = nullptr;
     if (!c || !out || n_contigs < 0 || (n_contigs > 0 && (!seqs || !lens))) { if (c) c->err = "pga_batch_create: bad arguments"; return PGA_EINVAL; }
@@ -1276,13 +1316,10 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         int32_t* d_dp_order = nullptr;
         std::vector<int32_t> dp_order;
         if (use_wave && NCH > 1 && !getenv("PGA_DP_NO_ORDER")) {
-            int maxb = 0;
-            for (int k = 0; k < NCH; k++) maxb = std::max(maxb, chains[k].n >> 6);
-            std::vector<int32_t> first((size_t)maxb + 2, 0);
-            for (int k = 0; k < NCH; k++) first[(size_t)(maxb - (chains[k].n >> 6)) + 1]++;
-            for (int b = 0; b <= maxb; b++) first[(size_t)b + 1] += first[(size_t)b];
+            std::vector<int32_t> lens((size_t)NCH);
+            for (int k = 0; k < NCH; k++) lens[(size_t)k] = chains[k].n;
             dp_order.resize((size_t)NCH);
-            for (int k = 0; k < NCH; k++) dp_order[(size_t)first[(size_t)(maxb - (chains[k].n >> 6))]++] = k;
+            pga_dp_start_order(NCH, lens.data(), dp_order.data());
             DEVBUF(d_ord, int32_t, "d_dp_order", NCH + 1);
             HT(c, hipMemcpyAsync(d_ord, dp_order.data(), sizeof(int32_t) * (size_t)NCH, hipMemcpyHostToDevice, st));
             d_dp_order = d_ord;
