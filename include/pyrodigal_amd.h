@@ -239,9 +239,11 @@ const char* pga_fasta_error(const pga_fasta*);
 void        pga_fasta_close(pga_fasta*);
 /* The same records with their sequences packed back to back in PINNED host memory (hipHostMalloc): `*packed` holds the
  * letters of the batch, record i at offs[i], lens[i] long, offs[i + 1] == offs[i] + lens[i].  The reader owns `n_arenas`
- * staging arenas (2 .. 8, fixed at the first call) and fills them in turn: the arrays of a call stay valid until that arena
- * comes up again, i.e. for the next n_arenas - 1 calls -- batch k can be on its way to the device (pga_batch_create_packed)
- * while batch k + 1 is being parsed (ref: the reader the reference's CLI feeds its thread pool with, cli.py:287-302). */
+ * staging arenas (2 .. 8, fixed at the first call) and fills them in turn: the LETTERS of a call (`*packed`) stay valid until
+ * that arena comes up again, i.e. for the next n_arenas - 1 calls -- batch k can be on its way to the device
+ * (pga_batch_create_packed) while batch k + 1 is being parsed (ref: the reader the reference's CLI feeds its thread pool
+ * with, cli.py:287-302).  `headers`, `offs` and `lens` belong to the reader and are only valid until the NEXT call: copy them
+ * (or hand them to pga_batch_create_packed, which copies) before asking for the next batch. */
 int         pga_fasta_next_packed(pga_fasta*, int64_t max_bases, int32_t max_records, int32_t n_arenas, int32_t* n_records,
                                   const char* const** headers, const char** packed, const int64_t** offs, const int64_t** lens);
 

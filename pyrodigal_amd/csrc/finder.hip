@@ -97,6 +97,7 @@ struct FinderState {
     double* d_gil = nullptr; int32_t* d_model_rank = nullptr;
     std::vector<size_t> gil_off; std::vector<int> gil_stride; std::vector<int32_t> model_rank;
     unsigned* d_sd_lut = nullptr;   // RBS search table (pga_launch_sd_lut), filled when the context's finder state is created
+    std::mutex spare_mu; void* spare_p = nullptr; size_t spare_cap = 0;   // the letters' allocation of the last batch that was freed
     hipEvent_t e_start = nullptr, e_stop = nullptr, e_dp0[4] = {}, e_dp1[4] = {};
 };
 
@@ -813,6 +814,7 @@ void pga_finder_release(pga_ctx* c) {
     if (c->finder->d_gil) hipFree(c->finder->d_gil);
     if (c->finder->d_model_rank) hipFree(c->finder->d_model_rank);
     if (c->finder->d_sd_lut) hipFree(c->finder->d_sd_lut);
+    if (c->finder->spare_p) hipFree(c->finder->spare_p);
     if (c->finder->e_start) hipEventDestroy(c->finder->e_start);
     if (c->finder->e_stop) hipEventDestroy(c->finder->e_stop);
     for (int i = 0; i < 4; i++) { if (c->finder->e_dp0[i]) hipEventDestroy(c->finder->e_dp0[i]); if (c->finder->e_dp1[i]) hipEventDestroy(c->finder->e_dp1[i]); }
@@ -884,6 +886,7 @@ struct pga_batch {
     int64_t total;
     std::vector<ContigDesc> ct;   // n + 1 entries
     char* d_seq;                  // packed ASCII, resident in HBM
+    size_t d_seq_cap = 0;         // bytes of that allocation (it goes back to the context's spare slot)
     TileDesc* d_tiles;            // extraction tiles of every contig
     int32_t* d_tile0;             // first tile of every contig, n + 1 entries (behind d_tiles, one allocation)
     int32_t n_tiles;
@@ -952,6 +955,33 @@ extern "C" int pga_cs_task_summary(int32_t n_contigs, const int32_t* nodes_per_c
     return PGA_OK;
 }
 
+// The letters of a batch live in one device allocation.  hipMalloc / hipFree per call cost a device-wide synchronisation each
+// (hipFree waits for every stream of the device, i.e. for the other contexts' kernels), so a context keeps the allocation of the
+// last batch it freed and hands it to the next one that fits.
+static hipError_t batch_take_dev(pga_ctx* c, size_t bytes, char** out, size_t* cap) {
+    FinderState* f = c->finder;
+    {
+        std::lock_guard<std::mutex> g(f->spare_mu);
+        if (f->spare_p && f->spare_cap >= bytes && f->spare_cap <= 2 * bytes + (64u << 20)) {
+            *out = (char*)f->spare_p; *cap = f->spare_cap; f->spare_p = nullptr; f->spare_cap = 0;
+            return hipSuccess;
+        }
+    }
+    const size_t want = bytes + bytes / 8 + 256;
+    *cap = want;
+    return hipMalloc((void**)out, want);
+}
+static void batch_give_dev(pga_ctx* c, char* p, size_t cap) {
+    if (!p) return;
+    FinderState* f = c->finder;
+    void* drop = p;
+    if (f) {
+        std::lock_guard<std::mutex> g(f->spare_mu);
+        if (!f->spare_p || f->spare_cap < cap) { drop = f->spare_p; f->spare_p = p; f->spare_cap = cap; }
+    }
+    if (drop) hipFree(drop);
+}
+
 extern "C" int pga_batch_create(pga_ctx* c, int32_t n_contigs, const char* const* seqs, const int64_t* lens, pga_batch** out) {
     if (out) *out = nullptr;
     if (!c || !out || n_contigs < 0 || (n_contigs > 0 && (!seqs || !lens))) { if (c) c->err = "pga_batch_create: bad arguments"; return PGA_EINVAL; }
@@ -973,16 +1003,44 @@ extern "C" int pga_batch_create(pga_ctx* c, int32_t n_contigs, const char* const
         void* hp; int rc = ensure_pin(c, "h_seq", (size_t)total + 16, &hp);
         if (rc) { delete b; return rc; }
         char* h_seq = (char*)hp;
-        for (int i = 0; i < n_contigs; i++) if (lens[i] > 0) memcpy(h_seq + b->ct[i].base, seqs[i], (size_t)lens[i]);
-        if (hipMalloc((void**)&b->d_seq, (size_t)total + 16) != hipSuccess) { delete b; c->err = "pga_batch_create: hipMalloc failed"; return PGA_ENOMEM; }
-        hipError_t e = hipMemcpyAsync(b->d_seq, h_seq, (size_t)total, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) { hipFree(b->d_seq); delete b; return pga_hip_try_(c, e, "upload of the batch"); }
+        if (batch_take_dev(c, (size_t)total + 16, &b->d_seq, &b->d_seq_cap) != hipSuccess) { delete b; c->err = "pga_batch_create: hipMalloc failed"; return PGA_ENOMEM; }
+        // Packing is a host memcpy per contig and the upload a DMA from the pinned copy: the contigs are cut into slices of about
+        // 8 MB, a few host threads pack slices, and each slice goes on its way to the device as soon as it is packed -- the DMA of
+        // slice k runs under the packing of the slices after it (it was: one thread packing everything, then one DMA, 12 + 3 ms
+        // per 125 Mbp).
+        std::vector<int> cut{0};
+        { int64_t acc = 0; for (int i = 0; i < n_contigs; i++) { acc += lens[i]; if (acc >= (8 << 20)) { cut.push_back(i + 1); acc = 0; } } }
+        if (cut.back() != n_contigs) cut.push_back(n_contigs);
+        const int n_slices = (int)cut.size() - 1;
+        std::atomic<int> next{0};
+        std::atomic<int> first_err{(int)hipSuccess};
+        hipStream_t st = c->stream;
+        const int dev = c->device;
+        char* d_seq = b->d_seq;
+        const ContigDesc* ct = b->ct.data();
+        std::mutex issue_mu;
+        auto work = [&]() {
+            (void)hipSetDevice(dev);
+            for (;;) {
+                const int k = next.fetch_add(1);
+                if (k >= n_slices) return;
+                for (int i = cut[k]; i < cut[k + 1]; i++) if (lens[i] > 0) memcpy(h_seq + ct[i].base, seqs[i], (size_t)lens[i]);
+                const int64_t lo = ct[cut[k]].base, hi = ct[cut[k + 1]].base;
+                if (hi > lo) {
+                    std::lock_guard<std::mutex> g(issue_mu);
+                    const hipError_t e = hipMemcpyAsync(d_seq + lo, h_seq + lo, (size_t)(hi - lo), hipMemcpyHostToDevice, st);
+                    if (e != hipSuccess) { int z = (int)hipSuccess; first_err.compare_exchange_strong(z, (int)e); }
+                }
+            }
+        };
+        const int threads = n_slices >= 2 ? std::min(n_slices, 6) : 1;
+        if (threads == 1) work(); else c->finder->pool.run(work, threads);
+        hipError_t e = (hipError_t)first_err.load();
         std::vector<TileDesc> tiles; std::vector<int32_t> tile0;
-        batch_tiles(b, tiles, tile0);
-        e = batch_upload_tiles(b, tiles, tile0, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) { if (b->d_tiles) hipFree(b->d_tiles); hipFree(b->d_seq); delete b; return pga_hip_try_(c, e, "upload of the tile list"); }
+        batch_tiles(b, tiles, tile0);             // host work under the last slices' DMA
+        if (e == hipSuccess) e = batch_upload_tiles(b, tiles, tile0, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { if (b->d_tiles) hipFree(b->d_tiles); batch_give_dev(c, b->d_seq, b->d_seq_cap); delete b; return pga_hip_try_(c, e, "upload of the batch"); }
     }
     *out = b;
     return PGA_OK;
@@ -1007,14 +1065,14 @@ extern "C" int pga_batch_create_packed(pga_ctx* c, int32_t n_contigs, const char
     b->total = total;
     if (total >= 0x7fffffffLL) { delete b; c->err = "pga_batch_create_packed: batch larger than 2^31 bases; split it"; return PGA_EINVAL; }
     if (total > 0) {
-        if (hipMalloc((void**)&b->d_seq, (size_t)total + 16) != hipSuccess) { delete b; c->err = "pga_batch_create_packed: hipMalloc failed"; return PGA_ENOMEM; }
+        if (batch_take_dev(c, (size_t)total + 16, &b->d_seq, &b->d_seq_cap) != hipSuccess) { delete b; c->err = "pga_batch_create_packed: hipMalloc failed"; return PGA_ENOMEM; }
         // the letters go straight from the caller's (pinned) buffer: one DMA, overlapped with the tile list's host work
         hipError_t e = hipMemcpyAsync(b->d_seq, packed + offs[0], (size_t)total, hipMemcpyHostToDevice, c->stream);
         std::vector<TileDesc> tiles; std::vector<int32_t> tile0;
         batch_tiles(b, tiles, tile0);
         if (e == hipSuccess) e = batch_upload_tiles(b, tiles, tile0, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) { if (b->d_tiles) hipFree(b->d_tiles); hipFree(b->d_seq); delete b; return pga_hip_try_(c, e, "upload of the packed batch"); }
+        if (e != hipSuccess) { if (b->d_tiles) hipFree(b->d_tiles); batch_give_dev(c, b->d_seq, b->d_seq_cap); delete b; return pga_hip_try_(c, e, "upload of the packed batch"); }
     }
     *out = b;
     return PGA_OK;
@@ -1026,7 +1084,7 @@ pga_batch_view pga_batch_peek(const pga_batch* b) { return pga_batch_view{b->ctx
 
 extern "C" void pga_batch_free(pga_batch* b) {
     if (!b) return;
-    if (b->d_seq) { hipSetDevice(b->ctx->device); hipFree(b->d_seq); }
+    if (b->d_seq) { hipSetDevice(b->ctx->device); batch_give_dev(b->ctx, b->d_seq, b->d_seq_cap); }
     if (b->d_tiles) hipFree(b->d_tiles);
     delete b;
 }

@@ -17,6 +17,7 @@
 
 #include "pga_internal.h"
 #include "pipeline.h"
+#include <atomic>
 #include "dev_common.h"
 #include "dpw_core.h"
 
@@ -2266,16 +2267,26 @@ void pga_launch_score(const ChainDesc* d_chains, int n_chains, int64_t node_begi
     const dim3 grid(nblocks(total, 256)), blk(256);
     if (group_nodes > 0 && !reuse_raw_cscore && n_cs_tasks > 0) {
         // the ORF walks against hexamer tables in LDS (tasks built by the caller, pga_cs_tasks)
-        static bool once = false;
+        // function attributes and allocations belong to ONE device: both are keyed by the device that is current
+        // (contexts of several GPUs may live in one process)
+        static std::atomic<bool> attr_set[64];
+        static std::atomic<unsigned long long*> prof_of[64];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        dev &= 63;
         const size_t lds = sizeof(double) * 4096 * 4;
-        static int cs_wave = CS_WAVE;
-        if (!once) {
-            hipFuncSetAttribute((const void*)k_coding_score_quads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true;
-            if (const char* e = getenv("PGA_CS_WAVE")) cs_wave = atoi(e) >= 64 ? atoi(e) : CS_WAVE;
+        int cs_wave = CS_WAVE;
+        if (const char* e = getenv("PGA_CS_WAVE")) cs_wave = atoi(e) >= 64 ? atoi(e) : CS_WAVE;
+        if (!attr_set[dev].load()) {
+            hipFuncSetAttribute((const void*)k_coding_score_quads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set[dev].store(true);
         }
-        static unsigned long long* d_prof = nullptr;
         const bool profiling = getenv("PGA_CS_PROFILE") != nullptr;
-        if (profiling) { if (!d_prof) (void)hipMalloc((void**)&d_prof, 16 * sizeof(unsigned long long)); (void)hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), st); }
+        unsigned long long* d_prof = prof_of[dev].load();
+        if (profiling) {
+            if (!d_prof) { (void)hipMalloc((void**)&d_prof, 16 * sizeof(unsigned long long)); prof_of[dev].store(d_prof); }
+            (void)hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), st);
+        }
         hipLaunchKernelGGL(k_coding_score_quads, dim3((unsigned)n_cs_tasks), dim3(CS_TASK_THREADS), lds, st, (const CsTask*)d_cs_tasks,
                            (const CsEntry*)d_cs_entries, d_all_chains, d_contig_chains, d_node_contig_base, d_dig, d_ct, ga, d_models, d_msc, ca,
                            d_gil, il_stride, d_rank, cs_wave, profiling ? d_prof : nullptr);

@@ -594,7 +594,8 @@ static int train_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, 
         std::vector<const pga_training*> ptrs;
         for (const pga_training& m : saved) ptrs.push_back(&m);
         const int rc2 = pga_set_models(c, ptrs.data(), (int)ptrs.size());
-        if (rc != PGA_OK) { c->err = err; return rc; }
+        // a failed restore must not pass unseen: the context would keep scoring with the half-trained model
+        if (rc != PGA_OK) { c->err = rc2 != PGA_OK ? err + "; and the context's models could not be restored: " + c->err : err; return rc; }
         if (rc2 != PGA_OK) return rc2;
     }
     return rc;

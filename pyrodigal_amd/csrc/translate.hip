@@ -3,6 +3,7 @@
 // _translation.h:4-42 (the genetic codes; restated here from the NCBI tables in TCAG order and re-indexed by the digit
 // alphabet of this library, A0 G1 C2 T3).
 #include "pga_internal.h"
+#include <mutex>
 #include "pipeline.h"
 
 #include <string.h>
@@ -104,7 +105,10 @@ k_translate(const char* __restrict__ seq, const ContigDesc* __restrict__ ct, con
     out[idx] = (char)(aa == 'X' ? unk : aa);
 }
 
-bool g_tables_ready = false;
+// the tables are __constant__ symbols: one copy per DEVICE, so readiness is tracked per device (several GPUs may be driven
+// from one process) and the first use on a device uploads them under a lock
+std::mutex g_tables_mu;
+bool g_tables_ready[64] = {false};
 int upload_tables() {
     static char code[34][64];
     static unsigned char known[34];
@@ -144,7 +148,11 @@ extern "C" int pga_translate_genes(pga_ctx* c, const pga_batch* batch, int64_t n
     const int64_t total = offsets[n_genes];
     if (total == 0) return PGA_OK;
     if (hipSetDevice(c->device) != hipSuccess) return PGA_EDEVICE;
-    if (!g_tables_ready) { const int rc = upload_tables(); if (rc) return rc; g_tables_ready = true; }
+    {
+        std::lock_guard<std::mutex> lk(g_tables_mu);
+        const int dev = c->device & 63;
+        if (!g_tables_ready[dev]) { const int rc = upload_tables(); if (rc) return rc; g_tables_ready[dev] = true; }
+    }
     pga_gene* d_genes = nullptr; int32_t* d_tt = nullptr; int64_t* d_off = nullptr; char* d_out = nullptr; ContigDesc* d_ct = nullptr;
     auto cleanup = [&]() { hipFree(d_genes); hipFree(d_tt); hipFree(d_off); hipFree(d_out); hipFree(d_ct); };
     hipStream_t st = c->stream;

@@ -21,6 +21,7 @@ import numpy as np
 from cpython.bytes cimport PyBytes_FromStringAndSize, PyBytes_AS_STRING
 from libc.stdint cimport int8_t, uint8_t, int32_t, int64_t
 from libc.stdlib cimport malloc, free
+from libc.string cimport memcpy, memset
 from libc.math cimport exp, fmax
 
 cdef extern from "pyrodigal_amd.h" nogil:
@@ -453,15 +454,13 @@ METAGENOMIC_BINS = MetagenomicBins()
 # --- Sequence / Nodes / Gene / Genes ----------------------------------------------------------
 
 cdef class _StageContext:
-    """One lazily created device context for the stage-level calls (`Nodes.*`, `ConnectionScorer`)."""
+    """One lazily created device context for the stage-level calls (`Nodes.*`, `ConnectionScorer`, `Sequence`)."""
     cdef pga_ctx* ctx
-    cdef object lock
     cdef object loaded        # the TrainingInfo blob currently loaded as model 0
     cdef unsigned long long loaded_version
 
     def __cinit__(self):
         self.ctx = NULL
-        self.lock = threading.Lock()
         self.loaded = None
 
     def __dealloc__(self):
@@ -491,7 +490,66 @@ cdef class _StageContext:
         self.loaded_version = tinf._version
         return 0
 
-cdef _StageContext _STAGE = _StageContext()
+
+cdef class _StagePool:
+    """The stage-level calls are re-entrant like the reference's (each builds private state, ref: lib.pyx:2528-2595): a caller takes
+    a context of its own for the duration of its device call -- up to `limit` contexts (one HIP stream and one set of scratch
+    buffers each), created on demand -- so that concurrent callers overlap instead of queueing behind one lock."""
+    cdef list idle
+    cdef int created, limit
+    cdef object cv
+
+    def __cinit__(self):
+        self.idle = []
+        self.created = 0
+        self.limit = 3
+        self.cv = threading.Condition(threading.Lock())
+
+    cdef _StageContext take(self, TrainingInfo want=None):
+        cdef _StageContext s
+        cdef ssize_t k
+        with self.cv:
+            while True:
+                if self.idle:
+                    # prefer a context that already holds the model the caller is about to use
+                    k = len(self.idle) - 1
+                    if want is not None:
+                        for j in range(len(self.idle)):
+                            s = self.idle[j]
+                            if s.loaded is want.raw and s.loaded_version == want._version:
+                                k = j
+                                break
+                    return self.idle.pop(k)
+                if self.created < self.limit:
+                    self.created += 1
+                    return _StageContext()
+                self.cv.wait()
+
+    cdef void give(self, _StageContext s):
+        with self.cv:
+            self.idle.append(s)
+            self.cv.notify()
+
+cdef _StagePool _STAGES = _StagePool()
+
+cdef class _StageLease:
+    """`with _StageLease(tinf) as S:` -- a stage context of the caller's own for one device call."""
+    cdef _StageContext s
+    cdef TrainingInfo want
+
+    def __cinit__(self, TrainingInfo want=None):
+        self.want = want
+        self.s = None
+
+    def __enter__(self):
+        self.s = _STAGES.take(self.want)
+        return self.s
+
+    def __exit__(self, *exc):
+        _STAGES.give(self.s)
+        self.s = None
+        return False
+
 
 
 cdef class Mask:
@@ -547,20 +605,21 @@ cdef class Sequence:
         cdef const char* ptr = PyBytes_AS_STRING(self.data)
         cdef int64_t length = len(self.data)
         cdef int rc, k
+        cdef _StageContext S
         if self._unknown >= 0:
             return 0
         p.closed = 0; p.min_gene = 90; p.min_edge_gene = 60; p.max_overlap = 60; p.meta = 0; p.want_nodes = 0
         p.mask = self.mask; p.min_mask = <int32_t> self.mask_size
-        with _STAGE.lock:
-            _STAGE.ensure()
-            rc = pga_batch_create(_STAGE.ctx, 1, &ptr, &length, &batch)
+        with _StageLease() as S:
+            S.ensure()
+            rc = pga_batch_create(S.ctx, 1, &ptr, &length, &batch)
             if rc != PGA_OK:
-                _raise_for(_STAGE.ctx, rc, "pga_batch_create")
+                _raise_for(S.ctx, rc, "pga_batch_create")
             try:
                 with nogil:
-                    rc = pga_nodes_stage(_STAGE.ctx, batch, &p, PGA_STAGE_SEQUENCE, 11, &res)
+                    rc = pga_nodes_stage(S.ctx, batch, &p, PGA_STAGE_SEQUENCE, 11, &res)
                 if rc != PGA_OK:
-                    _raise_for(_STAGE.ctx, rc, "pga_nodes_stage")
+                    _raise_for(S.ctx, rc, "pga_nodes_stage")
                 try:
                     self._gc = res.contigs[0].gc
                     self._unknown = res.contigs[0].n_unknown
@@ -671,23 +730,24 @@ cdef class Nodes:
         cdef const char* ptr = PyBytes_AS_STRING(seq.data)
         cdef int64_t length = len(seq.data)
         cdef int rc, tt
+        cdef _StageContext S
         kw = self._extract_kw
         p.closed = kw["closed"]; p.min_gene = kw["min_gene"]; p.min_edge_gene = kw["min_edge_gene"]
         p.max_overlap = 60; p.meta = is_meta; p.want_nodes = 1
         p.mask = seq.mask; p.min_mask = <int32_t> seq.mask_size
         tt = kw["translation_table"]
-        with _STAGE.lock:
-            _STAGE.ensure()
+        with _StageLease(tinf) as S:
+            S.ensure()
             if tinf is not None:
-                _STAGE.load(tinf)
-            rc = pga_batch_create(_STAGE.ctx, 1, &ptr, &length, &batch)
+                S.load(tinf)
+            rc = pga_batch_create(S.ctx, 1, &ptr, &length, &batch)
             if rc != PGA_OK:
-                _raise_for(_STAGE.ctx, rc, "pga_batch_create")
+                _raise_for(S.ctx, rc, "pga_batch_create")
             try:
                 with nogil:
-                    rc = pga_nodes_stage(_STAGE.ctx, batch, &p, stage, tt, &res)
+                    rc = pga_nodes_stage(S.ctx, batch, &p, stage, tt, &res)
                 if rc != PGA_OK:
-                    _raise_for(_STAGE.ctx, rc, "pga_nodes_stage")
+                    _raise_for(S.ctx, rc, "pga_nodes_stage")
                 try:
                     return _copy_nodes(&res.nodes[0])
                 finally:
@@ -785,16 +845,17 @@ cdef class ConnectionScorer:
         cdef size_t p_cs = cs.ctypes.data, p_ss = ss.ctypes.data, p_rs = rs.ctypes.data, p_us = us.ctypes.data, p_sp = sp.ctypes.data
         cdef size_t p_score = score.ctypes.data, p_tb = traceb.ctypes.data, p_ov = ov.ctypes.data
         cdef double st_wt = training_info.start_weight
-        with _STAGE.lock:
-            _STAGE.ensure()
+        cdef _StageContext S
+        with _StageLease() as S:
+            S.ensure()
             with nogil:
-                rc = pga_score_connections(_STAGE.ctx, <int32_t> n, <const int32_t*> p_ndx, <const int32_t*> p_stop,
+                rc = pga_score_connections(S.ctx, <int32_t> n, <const int32_t*> p_ndx, <const int32_t*> p_stop,
                                            <const uint8_t*> p_typ, <const int8_t*> p_strand, <const double*> p_cs,
                                            <const double*> p_ss, <const double*> p_rs, <const double*> p_us,
                                            <const int32_t*> p_sp, st_wt, 1, <double*> p_score, <int32_t*> p_tb,
                                            <int8_t*> p_ov, &mi, NULL)
             if rc != PGA_OK:
-                _raise_for(_STAGE.ctx, rc, "pga_score_connections")
+                _raise_for(S.ctx, rc, "pga_score_connections")
         f["score"] = score; f["traceb"] = traceb; f["ov_mark"] = ov
         return int(mi)
 
@@ -818,15 +879,16 @@ cdef class ConnectionScorer:
         cdef size_t p_gcs = gcs.ctypes.data, p_bias = bias.ctypes.data, p_sp = sp.ctypes.data
         cdef size_t p_score = score.ctypes.data, p_tb = traceb.ctypes.data, p_ov = ov.ctypes.data
         cdef double st_wt = training_info.start_weight
-        with _STAGE.lock:
-            _STAGE.ensure()
+        cdef _StageContext S
+        with _StageLease() as S:
+            S.ensure()
             with nogil:
-                rc = pga_score_connections_training(_STAGE.ctx, <int32_t> n, <const int32_t*> p_ndx, <const int32_t*> p_stop,
+                rc = pga_score_connections_training(S.ctx, <int32_t> n, <const int32_t*> p_ndx, <const int32_t*> p_stop,
                                                     <const uint8_t*> p_typ, <const int8_t*> p_strand, <const double*> p_gcs,
                                                     <const double*> p_bias, <const int32_t*> p_sp, st_wt, <double*> p_score,
                                                     <int32_t*> p_tb, <int8_t*> p_ov, &mi, NULL)
             if rc != PGA_OK:
-                _raise_for(_STAGE.ctx, rc, "pga_score_connections_training")
+                _raise_for(S.ctx, rc, "pga_score_connections_training")
         f["score"] = score; f["traceb"] = traceb; f["ov_mark"] = ov
         return int(mi)
 
@@ -846,6 +908,9 @@ cdef class Gene:
     cdef readonly Genes owner
     cdef pga_gene g
     cdef ssize_t _index        # position in the owner's list (-1: unknown), for the owner's device-side translations
+
+    def __cinit__(self):
+        self._index = -1
 
     @property
     def begin(self):
@@ -971,7 +1036,7 @@ cdef class Gene:
         cdef bytes unk = unknown_residue.encode("ascii") if isinstance(unknown_residue, str) else bytes(unknown_residue)
         if len(unk) != 1:
             raise ValueError("`unknown_residue` must be a single character")
-        if (self.owner._prot is not None and self._index >= 0 and tt == owner_tt and unk == b"X" and include_stop and strict):
+        if (self.owner._prot is not None and self._index >= 0 and tt == self.owner._prot_tt and unk == b"X" and include_stop and strict):
             # translated on the device together with the gene calls (GeneFinder.find_genes_batch(..., translate=True))
             return self.owner._prot[self.owner._prot_off[self._index]:self.owner._prot_off[self._index + 1]].decode("ascii")
         cdef bytes nuc = self.owner.sequence.data[self.g.begin - 1:self.g.end]
@@ -1025,27 +1090,56 @@ cdef class Gene:
 cdef class Genes:
     """The genes of one sequence (ref: lib.pyx:3049-3186)."""
     cdef readonly Sequence sequence
-    cdef readonly object nodes              # Nodes, or None when the finder was created with keep_nodes=False
     cdef readonly object training_info
     cdef readonly object metagenomic_bin
     cdef readonly bint meta
     cdef readonly double score
     cdef readonly ssize_t _num_seq
-    cdef list _genes
+    cdef list _genes           # the Gene objects, built from _recs when first asked for
+    cdef bytes _recs           # the packed gene records of this sequence as the device call returned them
+    cdef ssize_t _n
+    cdef bytes _node_blob      # the node arrays of the winning model, field after field (None: keep_nodes=False)
+    cdef ssize_t _node_n
+    cdef object _nodes
     cdef object _prot          # proteins of all genes back to back, translated on the device with the default arguments, or None
     cdef object _prot_off      # int64[len + 1] offsets into _prot
+    cdef int _prot_tt          # the translation table the device translated with
+
+    cdef list _list(self):
+        cdef ssize_t j
+        cdef Gene gene
+        cdef const pga_gene* g
+        if self._genes is None:
+            out = []
+            if self._n > 0:
+                g = <const pga_gene*> PyBytes_AS_STRING(self._recs)
+                for j in range(self._n):
+                    gene = Gene.__new__(Gene)
+                    gene.owner = self
+                    gene.g = g[j]
+                    gene._index = j
+                    out.append(gene)
+            self._genes = out
+        return self._genes
+
+    @property
+    def nodes(self):
+        """The scored nodes of the sequence (`Nodes`), or None when the finder was created with keep_nodes=False."""
+        if self._nodes is None and self._node_blob is not None:
+            self._nodes = _nodes_from_blob(self._node_blob, self._node_n)
+        return self._nodes
 
     def __len__(self):
-        return len(self._genes)
+        return self._n
 
     def __getitem__(self, index):
-        return self._genes[index]
+        return self._list()[index]
 
     def __iter__(self):
-        return iter(self._genes)
+        return iter(self._list())
 
     def __bool__(self):
-        return len(self._genes) > 0
+        return self._n > 0
 
     # --- writers (ref: lib.pyx:3405-3894): host-side formatting of the results, byte-compatible with the
     #     reference except for the tool name and version strings -------------------------------------------
@@ -1070,7 +1164,7 @@ cdef class Genes:
         n += file.write('# Sequence Data: seqnum=%d;seqlen=%d;seqhdr="%s"\n' % (self._num_seq, len(self.sequence), sequence_id))
         n += file.write('# Model Data: version=pyrodigal_amd.v%s;run_type=%s;model="%s";gc_cont=%.2f;transl_table=%d;uses_sd=%d\n'
                         % (_VERSION, run, desc, tinf.gc * 100, tinf.translation_table, int(tinf.uses_sd)))
-        for i, gene in enumerate(self._genes):
+        for i, gene in enumerate(self._list()):
             ident = gene._gene_data(sequence_id if full_id else self._num_seq, i)
             n += file.write("%s\tpyrodigal_amd%s%s\tCDS\t%d\t%d\t%.1f\t%s\t0\t%s;" % (
                 sequence_id, version_separator, _VERSION, gene.g.begin, gene.g.end, gene.g.sscore + gene.g.cscore,
@@ -1085,7 +1179,7 @@ cdef class Genes:
         """Write the nucleotide sequences of the genes to `file` in FASTA format (ref: lib.pyx:3646-3706)."""
         cdef ssize_t n = 0, i, k
         cdef Gene gene
-        for i, gene in enumerate(self._genes):
+        for i, gene in enumerate(self._list()):
             n += file.write(">%s_%d # %d # %d # %d # %s\n" % (sequence_id, i + 1, gene.g.begin, gene.g.end, gene.g.strand,
                                                               gene._gene_data(sequence_id if full_id else self._num_seq, i)))
             seq = gene.sequence()
@@ -1101,7 +1195,7 @@ cdef class Genes:
         cdef Gene gene
         if translation_table is not None and translation_table not in _CODE_BY_DIGITS:
             raise ValueError("%r is not a valid translation table index" % (translation_table,))
-        for i, gene in enumerate(self._genes):
+        for i, gene in enumerate(self._list()):
             n += file.write(">%s_%d # %d # %d # %d # %s\n" % (sequence_id, i + 1, gene.g.begin, gene.g.end, gene.g.strand,
                                                               gene._gene_data(sequence_id if full_id else self._num_seq, i)))
             prot = gene.translate(translation_table, include_stop=include_stop, strict=strict_translation)
@@ -1136,7 +1230,7 @@ cdef class Genes:
         n += file.write("  JOURNAL   BMC Bioinformatics. 2010;11:119.\n")
         n += file.write("   PUBMED   20211023\n")
         n += file.write("FEATURES             Location/Qualifiers\n")
-        for i, gene in enumerate(self._genes):
+        for i, gene in enumerate(self._list()):
             start_edge = gene.g.partial_begin if gene.g.strand == 1 else gene.g.partial_end
             stop_edge = gene.g.partial_end if gene.g.strand == 1 else gene.g.partial_begin
             begin = "<%d" % gene.g.begin if start_edge else "%d" % gene.g.begin
@@ -1213,8 +1307,44 @@ cdef class Genes:
 
 
 # --- GeneFinder (ref: lib.pyx:5073-5575) ------------------------------------------------------
+cdef class _FinderSlot:
+    """One device context of a finder: its own HIP stream, scratch buffers and copy of the models."""
+    cdef pga_ctx* ctx
+    cdef bint busy
+    cdef bint models_loaded
+    cdef object models_sig      # (id(raw), version) of every model as loaded: a TrainingInfo changed in place is reloaded
+
+    def __cinit__(self):
+        self.ctx = NULL
+        self.busy = False
+        self.models_loaded = False
+        self.models_sig = None
+
+    def __dealloc__(self):
+        if self.ctx != NULL:
+            pga_destroy(self.ctx)
+            self.ctx = NULL
+
+
+cdef class _FindRequest:
+    """The sequences of one `find_genes` / `find_genes_batch` call, waiting for a device call to ride."""
+    cdef list seqs              # Sequence objects
+    cdef bint translate
+    cdef ssize_t first_id
+    cdef int64_t bases
+    cdef list out               # one Genes per sequence, filled in by the thread that ran the device call
+    cdef object error
+    cdef bint done
+
+
 cdef class GeneFinder:
-    """A configurable gene finder for genomes and metagenomes, running on one MI355X."""
+    """A configurable gene finder for genomes and metagenomes, running on one MI355X.
+
+    Re-entrant like the reference's (lib.pyx:5424-5446, README "thread-safety"): `find_genes` may be called from any number
+    of threads (the reference's own CLI maps it over a thread pool, cli.py:289-302).  Concurrent calls do not queue behind a
+    lock: the finder owns up to `contexts` device contexts (one HIP stream each), and the calls that are waiting when a context
+    is free are packed into ONE device call (`pga_find_genes_batch` over all their sequences, at most `coalesce_bases` bases)
+    by whichever caller finds the context -- so a pool of threads rides the batch path, and a lone caller pays no wait."""
     cdef readonly bint meta
     cdef readonly bint closed
     cdef readonly bint mask
@@ -1227,20 +1357,22 @@ cdef class GeneFinder:
     cdef readonly MetagenomicBins metagenomic_bins
     cdef readonly int device
     cdef readonly bint keep_nodes
-    cdef object lock
+    cdef readonly int contexts
+    cdef readonly int64_t coalesce_bases
+    cdef readonly dict stats    # device calls, sequences and the largest number of calls packed into one (diagnostics)
+    cdef object lock            # kept for callers that serialise around a finder themselves (ref: lib.pyx:5196)
+    cdef object _cv
+    cdef list _slots
+    cdef list _pending
     cdef ssize_t _num_seq
-    cdef pga_ctx* ctx
-    cdef bint models_loaded
-    cdef object models_sig      # (id(raw), version) of every model as loaded: a TrainingInfo changed in place is reloaded
 
     def __cinit__(self):
-        self.ctx = NULL
         self._num_seq = 1
-        self.models_loaded = False
 
     def __init__(self, TrainingInfo training_info=None, *, bint meta=False, MetagenomicBins metagenomic_bins=None,
                  bint closed=False, bint mask=False, int min_mask=50, int min_gene=90, int min_edge_gene=60,
-                 int max_overlap=60, str backend="detect", int device=0, bint keep_nodes=True):
+                 int max_overlap=60, str backend="detect", int device=0, bint keep_nodes=True, int contexts=3,
+                 int64_t coalesce_bases=64 << 20):
         # argument validation as in the reference (lib.pyx:5169-5181)
         if meta and training_info is not None:
             raise ValueError("cannot use a training info in meta mode.")
@@ -1258,6 +1390,8 @@ cdef class GeneFinder:
             raise ValueError("`max_overlap` must be lower than `min_gene`")
         if backend not in ("detect", "hip"):
             raise ValueError("unsupported backend %r: this build only has the HIP (gfx950) backend" % backend)
+        if contexts < 1 or contexts > 16:
+            raise ValueError("`contexts` must be between 1 and 16")
         self.meta = meta
         self.closed = closed
         self.mask = mask
@@ -1270,18 +1404,20 @@ cdef class GeneFinder:
         self.metagenomic_bins = METAGENOMIC_BINS if metagenomic_bins is None else metagenomic_bins
         self.device = device
         self.keep_nodes = keep_nodes
+        self.contexts = contexts
+        self.coalesce_bases = max(coalesce_bases, 1)
         self.lock = threading.Lock()
-
-    def __dealloc__(self):
-        if self.ctx != NULL:
-            pga_destroy(self.ctx)
-            self.ctx = NULL
+        self._cv = threading.Condition(threading.Lock())
+        self._slots = [_FinderSlot() for _ in range(contexts)]
+        self._pending = []
+        self.stats = {"device_calls": 0, "sequences": 0, "max_calls_per_device_call": 0}
 
     def __reduce__(self):           # ref: lib.pyx:5219-5234
         return _gene_finder_from_state, (self.training_info, dict(
             meta=self.meta, metagenomic_bins=self.metagenomic_bins if self.meta else None, closed=self.closed, mask=self.mask,
             min_mask=self.min_mask, min_gene=self.min_gene, min_edge_gene=self.min_edge_gene, max_overlap=self.max_overlap,
-            backend=self.backend, device=self.device, keep_nodes=self.keep_nodes))
+            backend=self.backend, device=self.device, keep_nodes=self.keep_nodes, contexts=self.contexts,
+            coalesce_bases=self.coalesce_bases))
 
     def __repr__(self):
         parts = []
@@ -1293,14 +1429,14 @@ cdef class GeneFinder:
             parts.append("closed=True")
         return "pyrodigal_amd.lib.GeneFinder(%s)" % ", ".join(parts)
 
-    cdef int _ensure_models(self) except -1:
+    cdef int _ensure_models(self, _FinderSlot slot) except -1:
         cdef int rc, n, i
         cdef const pga_training** ptrs
         cdef list blobs
-        if self.ctx == NULL:
-            rc = pga_create(self.device, &self.ctx)
+        if slot.ctx == NULL:
+            rc = pga_create(self.device, &slot.ctx)
             if rc != PGA_OK:
-                self.ctx = NULL
+                slot.ctx = NULL
                 _raise_for(NULL, rc, "pga_create")
         cdef list tinfs
         if self.meta:
@@ -1309,7 +1445,7 @@ cdef class GeneFinder:
             tinfs = [self.training_info]
         # the reference shares the struct by pointer, so a setter takes effect at the next call: reload when one moved
         cdef tuple sig = tuple([(id((<TrainingInfo> t).raw), (<TrainingInfo> t)._version) for t in tinfs])
-        if self.models_loaded and sig == self.models_sig:
+        if slot.models_loaded and sig == slot.models_sig:
             return 0
         blobs = [(<TrainingInfo> t).raw for t in tinfs]
         n = len(blobs)
@@ -1319,18 +1455,45 @@ cdef class GeneFinder:
         try:
             for i in range(n):
                 ptrs[i] = <const pga_training*> <size_t> blobs[i].ctypes.data
-            rc = pga_set_models(self.ctx, ptrs, n)
+            rc = pga_set_models(slot.ctx, ptrs, n)
         finally:
             free(ptrs)
         if rc != PGA_OK:
-            _raise_for(self.ctx, rc, "pga_set_models")
-        self.models_loaded = True
-        self.models_sig = sig
+            _raise_for(slot.ctx, rc, "pga_set_models")
+        slot.models_loaded = True
+        slot.models_sig = sig
         return 0
 
     def find_genes(self, object sequence):
         """Find all the genes in the input DNA sequence (ref: lib.pyx:5400-5469)."""
         return self.find_genes_batch([sequence])[0]
+
+    cdef _FinderSlot _free_slot(self):
+        # a context that already exists first: a lone caller never makes a second one
+        cdef _FinderSlot s, spare = None
+        for s in self._slots:
+            if not s.busy:
+                if s.ctx != NULL:
+                    return s
+                if spare is None:
+                    spare = s
+        return spare
+
+    cdef list _take_pending(self):
+        """The waiting requests that ride the next device call: in arrival order, same options, up to the base budget."""
+        cdef _FindRequest r, head = self._pending[0]
+        cdef int64_t bases = 0
+        cdef list take = []
+        cdef ssize_t k = 0
+        while k < len(self._pending):
+            r = self._pending[k]
+            if r.translate != head.translate or (take and bases + r.bases > self.coalesce_bases):
+                break
+            take.append(r)
+            bases += r.bases
+            k += 1
+        del self._pending[:k]
+        return take
 
     def find_genes_batch(self, object sequences, *, bint translate=False):
         """`find_genes` for many sequences in one device pass; returns one `Genes` per input, in order.
@@ -1343,6 +1506,7 @@ cdef class GeneFinder:
         # the reference always re-wraps with the finder's masking rule (ref: lib.pyx:5433-5438); a Sequence that already
         # follows it is used as it is
         cdef list seqs = []
+        cdef int64_t bases = 0
         for s in sequences:
             if isinstance(s, Sequence):
                 if (<Sequence> s).mask != self.mask or (self.mask and <int> (<Sequence> s).mask_size != self.min_mask):
@@ -1350,6 +1514,67 @@ cdef class GeneFinder:
             else:
                 s = Sequence(s, mask=self.mask, mask_size=self.min_mask)
             seqs.append(s)
+            bases += len((<Sequence> s).data)
+        if not seqs:
+            return []
+        cdef _FindRequest req = _FindRequest.__new__(_FindRequest)
+        cdef _FindRequest r
+        cdef _FinderSlot slot
+        cdef list take
+        req.seqs = seqs; req.translate = translate; req.bases = bases; req.out = None; req.error = None; req.done = False
+        cv = self._cv
+        cv.acquire()
+        try:
+            req.first_id = self._num_seq
+            self._num_seq += len(seqs)
+            self._pending.append(req)
+            while not req.done:
+                slot = self._free_slot() if self._pending else None
+                if slot is None:
+                    cv.wait()
+                    continue
+                # this caller runs the next device call: for itself and for everyone who is waiting with it
+                take = self._take_pending()
+                slot.busy = True
+                cv.release()
+                try:
+                    self._run(slot, take)
+                finally:
+                    cv.acquire()
+                    slot.busy = False
+                    for r in take:
+                        r.done = True
+                    cv.notify_all()
+        finally:
+            cv.release()
+        if req.error is not None:
+            raise req.error
+        return req.out
+
+    cdef int _run(self, _FinderSlot slot, list take) except -1:
+        """One device call over the sequences of every request in `take`; each request gets its `Genes` (or the error)."""
+        cdef _FindRequest r
+        cdef list seqs = []
+        for r in take:
+            seqs.extend(r.seqs)
+        try:
+            out = self._device_call(slot, seqs, (<_FindRequest> take[0]).translate, take)
+        except BaseException as e:
+            for r in take:
+                r.error = e
+            return 0
+        cdef ssize_t k = 0
+        for r in take:
+            r.out = out[k:k + len(r.seqs)]
+            k += len(r.seqs)
+        st = self.stats
+        st["device_calls"] += 1
+        st["sequences"] += len(seqs)
+        if len(take) > st["max_calls_per_device_call"]:
+            st["max_calls_per_device_call"] = len(take)
+        return 0
+
+    cdef list _device_call(self, _FinderSlot slot, list seqs, bint translate, list take):
         cdef int n = len(seqs), i, j, rc
         cdef const char** ptrs = <const char**> malloc(sizeof(char*) * max(n, 1))
         cdef int64_t* lens = <int64_t*> malloc(sizeof(int64_t) * max(n, 1))
@@ -1357,61 +1582,64 @@ cdef class GeneFinder:
         cdef pga_result* res = NULL
         cdef pga_batch* batch = NULL
         cdef list out = []
+        cdef list ids = []
         cdef Genes genes
-        cdef Gene gene
+        cdef _FindRequest r
         cdef pga_contig_result* cr
-        cdef object prot = None, prot_off = None, tables
+        cdef object prot = None, prot_off = None, tables = None
         cdef size_t p_tab, p_off, p_out
         cdef int64_t ng
+        cdef pga_ctx* ctx
         if ptrs == NULL or lens == NULL:
             free(ptrs); free(lens)
             raise MemoryError()
         p.closed = self.closed; p.min_gene = self.min_gene; p.min_edge_gene = self.min_edge_gene
         p.max_overlap = self.max_overlap; p.meta = self.meta; p.want_nodes = self.keep_nodes
         p.mask = self.mask; p.min_mask = self.min_mask
+        for r in take:
+            for j in range(len(r.seqs)):
+                ids.append(r.first_id + j)
         try:
             for i in range(n):
                 ptrs[i] = PyBytes_AS_STRING((<Sequence> seqs[i]).data)
                 lens[i] = len((<Sequence> seqs[i]).data)
-            with self.lock:       # one context = one stream and one set of scratch buffers
-                self._ensure_models()
-                first_id = self._num_seq
-                self._num_seq += n
-                if not translate:
+            self._ensure_models(slot)
+            ctx = slot.ctx
+            if not translate:
+                with nogil:
+                    rc = pga_find_genes_batch(ctx, n, ptrs, lens, &p, &res)
+                if rc != PGA_OK:
+                    _raise_for(ctx, rc, "pga_find_genes_batch")
+            else:
+                rc = pga_batch_create(ctx, n, ptrs, lens, &batch)
+                if rc != PGA_OK:
+                    _raise_for(ctx, rc, "pga_batch_create")
+                try:
                     with nogil:
-                        rc = pga_find_genes_batch(self.ctx, n, ptrs, lens, &p, &res)
+                        rc = pga_find_genes(ctx, batch, &p, &res)
                     if rc != PGA_OK:
-                        _raise_for(self.ctx, rc, "pga_find_genes_batch")
-                else:
-                    rc = pga_batch_create(self.ctx, n, ptrs, lens, &batch)
+                        _raise_for(ctx, rc, "pga_find_genes")
+                    prot_off = np.zeros(res.n_genes + 1, np.int64)
+                    tables = np.full(max(n, 1), 11, np.int32)
+                    for i in range(n):
+                        cr = &res.contigs[i]
+                        if self.meta:
+                            if cr.model >= 0:
+                                tables[i] = (<MetagenomicBin> self.metagenomic_bins[cr.model]).training_info.translation_table
+                        else:
+                            tables[i] = (<TrainingInfo> self.training_info).translation_table
+                    for j in range(res.n_genes):
+                        prot_off[j + 1] = prot_off[j] + (res.genes[j].end - res.genes[j].begin + 1) // 3
+                    prot = np.zeros(max(int(prot_off[res.n_genes]), 1), np.uint8)
+                    p_tab = tables.ctypes.data; p_off = prot_off.ctypes.data; p_out = prot.ctypes.data
+                    ng = res.n_genes
+                    with nogil:
+                        rc = pga_translate_genes(ctx, batch, ng, res.genes, <const int32_t*> p_tab, 88, 1, 1,
+                                                 <const int64_t*> p_off, <char*> p_out)
                     if rc != PGA_OK:
-                        _raise_for(self.ctx, rc, "pga_batch_create")
-                    try:
-                        with nogil:
-                            rc = pga_find_genes(self.ctx, batch, &p, &res)
-                        if rc != PGA_OK:
-                            _raise_for(self.ctx, rc, "pga_find_genes")
-                        prot_off = np.zeros(res.n_genes + 1, np.int64)
-                        tables = np.full(max(n, 1), 11, np.int32)
-                        for i in range(n):
-                            cr = &res.contigs[i]
-                            if self.meta:
-                                if cr.model >= 0:
-                                    tables[i] = (<MetagenomicBin> self.metagenomic_bins[cr.model]).training_info.translation_table
-                            else:
-                                tables[i] = (<TrainingInfo> self.training_info).translation_table
-                        for j in range(res.n_genes):
-                            prot_off[j + 1] = prot_off[j] + (res.genes[j].end - res.genes[j].begin + 1) // 3
-                        prot = np.zeros(max(int(prot_off[res.n_genes]), 1), np.uint8)
-                        p_tab = tables.ctypes.data; p_off = prot_off.ctypes.data; p_out = prot.ctypes.data
-                        ng = res.n_genes
-                        with nogil:
-                            rc = pga_translate_genes(self.ctx, batch, ng, res.genes, <const int32_t*> p_tab, 88, 1, 1,
-                                                     <const int64_t*> p_off, <char*> p_out)
-                        if rc != PGA_OK:
-                            _raise_for(self.ctx, rc, "pga_translate_genes")
-                    finally:
-                        pga_batch_free(batch)
+                        _raise_for(ctx, rc, "pga_translate_genes")
+                finally:
+                    pga_batch_free(batch)
             for i in range(n):
                 cr = &res.contigs[i]
                 genes = Genes.__new__(Genes)
@@ -1424,7 +1652,7 @@ cdef class GeneFinder:
                         for j in range(res.mask_off[i], res.mask_off[i + 1]):
                             (<Sequence> seqs[i])._masks.append(Mask(res.masks[2 * j], res.masks[2 * j + 1]))
                 genes.meta = self.meta
-                genes._num_seq = first_id + i
+                genes._num_seq = ids[i]
                 genes.score = cr.score
                 if self.meta:
                     if cr.model >= 0:
@@ -1435,18 +1663,20 @@ cdef class GeneFinder:
                 else:
                     genes.metagenomic_bin = None
                     genes.training_info = self.training_info
-                genes.nodes = _copy_nodes(&res.nodes[i]) if (self.keep_nodes and res.nodes != NULL) else None
-                genes._genes = []
-                genes._prot = None; genes._prot_off = None
+                genes._nodes = None
+                genes._node_blob = None
+                genes._node_n = 0
+                if self.keep_nodes and res.nodes != NULL:
+                    genes._node_blob = _pack_nodes(&res.nodes[i])
+                    genes._node_n = res.nodes[i].n
+                genes._genes = None
+                genes._n = cr.n_genes
+                genes._recs = PyBytes_FromStringAndSize(<const char*> &res.genes[cr.gene_begin], cr.n_genes * sizeof(pga_gene)) if cr.n_genes > 0 else b""
+                genes._prot = None; genes._prot_off = None; genes._prot_tt = 0
                 if prot is not None:
                     genes._prot = prot[prot_off[cr.gene_begin]:prot_off[cr.gene_begin + cr.n_genes]].tobytes()
                     genes._prot_off = (prot_off[cr.gene_begin:cr.gene_begin + cr.n_genes + 1] - prot_off[cr.gene_begin]).copy()
-                for j in range(cr.n_genes):
-                    gene = Gene.__new__(Gene)
-                    gene.owner = genes
-                    gene.g = res.genes[cr.gene_begin + j]
-                    gene._index = j
-                    genes._genes.append(gene)
+                    genes._prot_tt = int(tables[i])
                 out.append(genes)
         finally:
             free(ptrs); free(lens)
@@ -1466,6 +1696,8 @@ cdef class GeneFinder:
         cdef int64_t length
         cdef int rc
         cdef object raw
+        cdef _FinderSlot slot
+        cdef pga_ctx* ctx
         if self.meta:
             raise RuntimeError("cannot use training sequence in metagenomic mode")
         if translation_table not in TRANSLATION_TABLES:
@@ -1493,25 +1725,38 @@ cdef class GeneFinder:
         cdef size_t out_ptr = raw.ctypes.data
         ptr = PyBytes_AS_STRING(seq.data)
         length = len(seq.data)
-        with self.lock:
-            if self.ctx == NULL:
-                rc = pga_create(self.device, &self.ctx)
+        # the training takes a context for itself, like a device call of find_genes
+        with self._cv:
+            while True:
+                slot = self._free_slot()
+                if slot is not None:
+                    break
+                self._cv.wait()
+            slot.busy = True
+        try:
+            if slot.ctx == NULL:
+                rc = pga_create(self.device, &slot.ctx)
                 if rc != PGA_OK:
-                    self.ctx = NULL
+                    slot.ctx = NULL
                     _raise_for(NULL, rc, "pga_create")
-            self.models_loaded = False            # the training loads its own partial models into the context
-            rc = pga_batch_create(self.ctx, 1, &ptr, &length, &batch)
+            ctx = slot.ctx
+            slot.models_loaded = False            # the training loads its own partial models into the context
+            rc = pga_batch_create(ctx, 1, &ptr, &length, &batch)
             if rc != PGA_OK:
-                _raise_for(self.ctx, rc, "pga_batch_create")
+                _raise_for(ctx, rc, "pga_batch_create")
             try:
                 with nogil:
-                    rc = pga_train(self.ctx, batch, &p, translation_table, start_weight, force_nonsd, 0, <pga_training*> out_ptr)
+                    rc = pga_train(ctx, batch, &p, translation_table, start_weight, force_nonsd, 0, <pga_training*> out_ptr)
                 if rc != PGA_OK:
-                    _raise_for(self.ctx, rc, "pga_train")
+                    _raise_for(ctx, rc, "pga_train")
             finally:
                 pga_batch_free(batch)
             tinf = TrainingInfo(raw=raw)
             self.training_info = tinf
+        finally:
+            with self._cv:
+                slot.busy = False
+                self._cv.notify_all()
         return tinf
 
 
@@ -1542,4 +1787,56 @@ cdef Nodes _copy_nodes(const pga_nodes* nd):
     f["mot_score"] = _arr(nd.mot_score, 8 * n, np.float64); f["mot_ndx"] = _arr(nd.mot_ndx, 4 * n, np.int32)
     f["mot_len"] = _arr(nd.mot_len, n, np.uint8); f["mot_spacer"] = _arr(nd.mot_spacer, n, np.uint8)
     f["mot_spacendx"] = _arr(nd.mot_spacendx, n, np.uint8)
+    return out
+
+
+# The node arrays of one contig, field after field in one bytes object: what a Genes keeps until `.nodes` is asked for.
+_NODE_BLOB_FIELDS = [
+    ("ndx", np.int32, 1), ("stop_val", np.int32, 1), ("traceb", np.int32, 1), ("tracef", np.int32, 1), ("star_ptr", np.int32, 3),
+    ("gc_cont", np.float32, 1), ("mot_ndx", np.int32, 1),
+    ("cscore", np.float64, 1), ("sscore", np.float64, 1), ("rscore", np.float64, 1), ("uscore", np.float64, 1),
+    ("tscore", np.float64, 1), ("score", np.float64, 1), ("mot_score", np.float64, 1),
+    ("type", np.uint8, 1), ("edge", np.uint8, 1), ("elim", np.uint8, 1), ("rbs", np.uint8, 2), ("strand", np.int8, 1),
+    ("ov_mark", np.int8, 1), ("mot_len", np.uint8, 1), ("mot_spacer", np.uint8, 1), ("mot_spacendx", np.uint8, 1),
+]
+
+
+cdef bytes _pack_nodes(const pga_nodes* nd):
+    cdef ssize_t n = nd.n
+    cdef const void* src[23]
+    cdef ssize_t width[23]
+    cdef ssize_t k, total = 0, at = 0
+    src[0] = nd.ndx; src[1] = nd.stop_val; src[2] = nd.traceb; src[3] = nd.tracef; src[4] = nd.star_ptr
+    src[5] = nd.gc_cont; src[6] = nd.mot_ndx
+    src[7] = nd.cscore; src[8] = nd.sscore; src[9] = nd.rscore; src[10] = nd.uscore; src[11] = nd.tscore; src[12] = nd.score
+    src[13] = nd.mot_score
+    src[14] = nd.type; src[15] = nd.edge; src[16] = nd.elim; src[17] = nd.rbs; src[18] = nd.strand; src[19] = nd.ov_mark
+    src[20] = nd.mot_len; src[21] = nd.mot_spacer; src[22] = nd.mot_spacendx
+    width[0] = 4; width[1] = 4; width[2] = 4; width[3] = 4; width[4] = 12; width[5] = 4; width[6] = 4
+    for k in range(7, 14):
+        width[k] = 8
+    for k in range(14, 23):
+        width[k] = 1
+    width[17] = 2
+    for k in range(23):
+        total += width[k] * n
+    cdef bytes blob = PyBytes_FromStringAndSize(NULL, total)
+    cdef char* dst = PyBytes_AS_STRING(blob)
+    for k in range(23):
+        if n > 0 and src[k] != NULL:
+            memcpy(dst + at, src[k], width[k] * n)
+        elif n > 0:
+            memset(dst + at, 0, width[k] * n)
+        at += width[k] * n
+    return blob
+
+
+cdef Nodes _nodes_from_blob(bytes blob, ssize_t n):
+    cdef Nodes out = Nodes()
+    cdef ssize_t at = 0
+    f = out._f
+    for name, dt, mult in _NODE_BLOB_FIELDS:
+        a = np.frombuffer(blob, dtype=dt, count=n * mult, offset=at)
+        f[name] = a.reshape(-1, mult) if mult > 1 else a
+        at += a.nbytes
     return out

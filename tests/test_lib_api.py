@@ -294,6 +294,49 @@ def test_translate_unknown_bases_and_strictness(lib):
 
 
 @pytest.mark.gpu
+def test_thread_pool_of_find_genes_calls_rides_the_batch_path(lib):
+    """The reference's calling pattern (cli.py:289-302: a ThreadPool mapping `find_genes` over the records; lib.pyx:5424-5446
+    is re-entrant): 32 threads x `find_genes` over 2 000 contigs of the config-4 job on ONE finder.  Every result is the
+    oracle's, in input order, and the calls did not run one tiny device call each: waiting callers were packed together."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as orc
+    from pyrodigal_amd import benchdata
+    models = benchdata.load_model_set()
+    bins = lib.MetagenomicBins([lib.MetagenomicBin(lib.TrainingInfo(raw=b), n) for n, b in models])
+    lengths, gcs, seeds = benchdata.config4_spec(2000)
+    seqs = benchdata.generate(lengths, gcs, seeds, procs=8)
+    finder = lib.GeneFinder(meta=True, metagenomic_bins=bins)
+
+    def call(s):
+        genes = finder.find_genes(s)
+        return (bins._bins.index(genes.metagenomic_bin) if genes.metagenomic_bin is not None else -1,
+                [(g.begin, g.end, g.strand, g.partial_begin, g.partial_end, g.start_type) for g in genes], genes._num_seq)
+
+    with ThreadPoolExecutor(32) as ex:
+        got = list(ex.map(call, seqs))
+    obins = [orc.Training(b) for _, b in models]
+
+    def expect(s):
+        o = orc.Oracle(s)                                   # ctypes releases the GIL inside the C calls
+        phase = o.find_genes_meta(obins)
+        if phase < 0:
+            return phase, []
+        recs = orc.gene_records(o.genes(), o.nodes(copy=False), obins[phase])
+        return phase, [(b, e, strand, partial[0] == "1", partial[1] == "1", start_type) for b, e, strand, partial, start_type, *_ in recs]
+
+    with ThreadPoolExecutor(min(64, os.cpu_count() or 8)) as ex:
+        want = list(ex.map(expect, seqs))
+    assert [(m, g) for m, g, _ in got] == want
+    assert sorted(n for _, _, n in got) == list(range(1, 2001))          # every call got its own sequence number
+    st = finder.stats
+    assert st["sequences"] == 2000 and st["device_calls"] < 1000 and st["max_calls_per_device_call"] > 1, st
+    # a lone caller still gets a device call of its own, at once
+    alone = lib.GeneFinder(meta=True, metagenomic_bins=bins, keep_nodes=False)
+    assert [(g.begin, g.end) for g in alone.find_genes(seqs[0])] == [(b, e) for b, e, *_ in want[0][1]]
+    assert alone.stats["device_calls"] == 1
+
+
+@pytest.mark.gpu
 def test_find_genes_is_thread_safe(lib):
     """ref: README.md:105-122 / tests/test_gene_finder.py (ThreadPool use): one finder shared by threads, and one finder
     per thread, give the single-threaded result."""
