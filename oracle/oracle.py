@@ -83,6 +83,7 @@ def lib():
         L.po_tweak_final_starts.argtypes = [vp, vp, i32]
         L.po_find_genes_single.restype = i32; L.po_find_genes_single.argtypes = [vp, vp, vp]
         L.po_find_genes_meta.restype = i32; L.po_find_genes_meta.argtypes = [vp, vp, i32, vp]
+        L.po_find_genes_meta_pool.restype = ctypes.c_int64; L.po_find_genes_meta_pool.argtypes = [vp, vp, i32, vp, i32, vp, i32]
         L.po_train.restype = i32; L.po_train.argtypes = [vp, vp, vp, i32, f64, i32]
         L.po_train_upto.restype = i32; L.po_train_upto.argtypes = [vp, vp, vp, i32, f64, i32, i32]
         assert L.po_node_size() == NODE_DTYPE.itemsize, (L.po_node_size(), NODE_DTYPE.itemsize)
@@ -291,3 +292,18 @@ def gene_records(genes, nodes, tinf):
                     NODE_TYPE[3 if s["edge"] else int(s["type"])], str(motif), str(spacer),
                     "%.3f" % s["gc_cont"]))
     return out
+
+
+def find_genes_meta_pool(seqs, bins, threads, params=None):
+    """Meta-mode gene finding of many sequences on a pool of C threads that share the models (pyrodigal's thread-pool model, ref:
+    cli.py:289-302, without the interpreter lock): returns the number of genes found.  bench.py's all-core CPU baseline."""
+    L = lib()
+    p = params or Params()
+    n = len(seqs)
+    ptrs = (ctypes.c_char_p * max(n, 1))(*seqs)
+    lens = (ctypes.c_int64 * max(n, 1))(*[len(s) for s in seqs])
+    arr = (ctypes.c_void_p * len(bins))(*[b.ptr for b in bins])
+    got = L.po_find_genes_meta_pool(ptrs, lens, n, arr, len(bins), ctypes.addressof(p), int(threads))
+    if got < 0:
+        raise RuntimeError("po_find_genes_meta_pool failed")
+    return int(got)

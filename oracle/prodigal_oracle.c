@@ -1341,3 +1341,48 @@ int po_train_upto(po_ctx* c, po_training* t, const po_params* p, int force_nonsd
 int po_train(po_ctx* c, po_training* t, const po_params* p, int force_nonsd, double start_weight, int tt) {
     return po_train_upto(c, t, p, force_nonsd, start_weight, tt, 0);
 }
+
+/* ---- all-core baseline driver (bench.py `cpu_baseline.all_cores`) ---------------------------------------------------------
+ * pyrodigal's own way of using every core is a pool of threads mapping find_genes over the records (ref: cli.py:289-302): the
+ * threads share the models (one copy of the 9 MB of tables in the caches) and every call builds private state.  This is that
+ * pool in C -- no interpreter lock, no per-call mmap / munmap (glibc is told to keep freed blocks: a process-wide munmap per
+ * contig costs a TLB shootdown on every core) -- so the figure says what the CPU path can do, not what a Python harness costs. */
+#include <malloc.h>
+#include <pthread.h>
+
+typedef struct {
+    const char* const* seqs; const int64_t* lens; int n;
+    const po_training* const* bins; int nbins; const po_params* p;
+    int next; int64_t genes; pthread_mutex_t mu;
+} po_pool_job;
+
+static void* po_pool_worker(void* arg) {
+    po_pool_job* J = (po_pool_job*)arg;
+    int64_t genes = 0;
+    for (;;) {
+        const int k = __atomic_fetch_add(&J->next, 1, __ATOMIC_RELAXED);
+        if (k >= J->n) break;
+        po_ctx* c = po_new(J->seqs[k], J->lens[k], 0, 50);
+        po_find_genes_meta(c, J->bins, J->nbins, J->p);
+        genes += po_num_genes(c);
+        po_free(c);
+    }
+    pthread_mutex_lock(&J->mu); J->genes += genes; pthread_mutex_unlock(&J->mu);
+    return NULL;
+}
+
+/* meta-mode gene finding of n sequences on `threads` threads; returns the number of genes found, -1 on failure */
+int64_t po_find_genes_meta_pool(const char* const* seqs, const int64_t* lens, int n, const po_training* const* bins, int nbins,
+                                const po_params* p, int threads) {
+    if (threads < 1) threads = 1;
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    po_pool_job J = {seqs, lens, n, bins, nbins, p, 0, 0, PTHREAD_MUTEX_INITIALIZER};
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
+    if (!th) return -1;
+    int started = 0;
+    for (int t = 0; t < threads; t++) { if (pthread_create(&th[t], NULL, po_pool_worker, &J) != 0) break; started++; }
+    for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+    free(th);
+    return started > 0 ? J.genes : -1;
+}

@@ -103,6 +103,9 @@ void po_tweak_final_starts(po_ctx*, const po_training*, int max_overlap);
 /* whole-path drivers (GeneFinder._find_genes_single/_meta/_train) */
 int  po_find_genes_single(po_ctx*, const po_training*, const po_params*);
 int  po_find_genes_meta(po_ctx*, const po_training* const* bins, int nbins, const po_params*);
+/* the same for n sequences on a pool of threads sharing the models (bench.py's all-core CPU baseline); returns the genes found */
+int64_t po_find_genes_meta_pool(const char* const* seqs, const int64_t* lens, int n, const po_training* const* bins, int nbins,
+                                const po_params* p, int threads);
 int  po_train(po_ctx*, po_training* out, const po_params*, int force_nonsd,
               double start_weight, int tt);
 int  po_train_upto(po_ctx*, po_training* out, const po_params*, int force_nonsd,

@@ -1,0 +1,271 @@
+// Lane-per-chain connection scoring (dp_lane.hip): ONE lane walks ONE (contig, model) chain node by node, 64 chains to a
+// wavefront, and every class of candidates a node has comes from a running structure that costs O(1) per node -- no lane of the
+// wave ever visits a source on behalf of another lane.  Written once for the device and for the host: tests/dpl_model.cpp runs
+// the same step function chain by chain on the CPU against the plain restatement of the reference's loop
+// (tests/test_dpl_model.py), so the case analysis is pinned before a kernel ever runs.  No intrinsics in this file.
+//
+// Same recurrence as dpw_core.h (ref: lib.pyx:1205-1237 `_score_connections`, _connection.h:94-408, impl/generic.h:29-36):
+//     score[i] = max(0, max_j (score[j] + w(j, i))) over the window [lo_i, i), ties -> largest j.
+// Kinds: 0 = F5 forward start, 1 = F3 forward stop, 2 = R5 reverse start, 3 = R3 reverse stop; F5 / R3 are gene BEGINS, F3 / R5
+// gene ENDS.  Which (source kind, target kind) pairs connect at all is what impl/generic.h:29-36 leaves:
+//     F5 <- R5 (w = -0.15 st_wt), F5 <- F3 (distance term), R3 <- R5 (distance term), R3 <- F3 (-0.15 st_wt, or through an
+//     overlapping start of the target), R3 <- R3 (operon), F3 <- F5 (same ORF), F3 <- F3 (operon), R5 <- R3 (own stop),
+//     R5 <- F3 (opposite 3' ends overlapping).
+// Where a lane finds them:
+//   * gene begins <- gene ends far away (more than 3 * OPER_DIST bases: the weight is the constant): lexicographic running
+//     maxima of a = score + (-0.15 st_wt), one per (source kind, lag):  every reverse start so far (F5 targets: the weight
+//     towards a forward start never depends on the distance), the reverse starts / forward stops that lie more than 180 bases
+//     behind the walk ("folded");
+//   * gene begins <- gene ends within 180 bases: the ends that are not folded yet sit in two small per-lane rings (forward
+//     stops, reverse starts) and are evaluated pair by pair with dpw_pair -- one or two forward stops, a handful of reverse starts;
+//   * forward stops <- the starts / operon partners of their ORF: a per-frame running maximum that restarts at every forward
+//     stop of the frame (as in dpw_core.h);
+//   * reverse starts <- their own stop, reverse stops <- the reverse stop whose ORF covers them: "last reverse stop per frame";
+//   * reverse nodes <- forward stops overlapping the 3' end of the gene: the static chains of candidates (q2 links), read back
+//     from memory (a gene length behind the walk).
+// The window [lo, i) only matters for the running maxima (every other class lies inside the window by construction, and is
+// checked anyway): a maximum whose argmax fell out of the window is rebuilt by a scan of the window (dpl_rescan) -- exact, slow,
+// and rare: scores grow along a chain, so the maxima are young.  A ring that overflows (more gene ends within 180 bases than it
+// holds) folds its oldest entry early and sends the gene begins of the next 180 bases through the same scan.
+#pragma once
+
+#include "dpw_core.h"
+
+#ifndef DPL_R5_RING
+#define DPL_R5_RING 16      // entries, a power of two (the tests also build the model with rings of 2 and 1 entries)
+#endif
+#ifndef DPL_F3_RING
+#define DPL_F3_RING 8
+#endif
+#define DPL_NEAR    (3 * DPW_OPER_DIST)
+
+struct DplEnt { double score; int32_t ndx, idx; };
+
+// lexicographic (value, index) maximum with the position of the argmax node carried along
+struct DplMax { double v; int i, n; };
+DPW_HD void dpl_max_take(DplMax& m, const double v, const int i, const int n) {
+    if (v > m.v || (v == m.v && i > m.i)) { m.v = v; m.i = i; m.n = n; }
+}
+
+struct DplState {
+    DplMax r5_all;              // a over every reached reverse start so far
+    DplMax r5_far, f3_far;      // a over the reverse starts / forward stops that left their ring (more than 180 bases behind)
+    int r5_head, r5_cnt, f3_head, f3_cnt;      // rings: the last `cnt` entries pushed, newest at head - 1 (slots modulo the ring size)
+    int r5_ovf, f3_ovf;         // an entry left its ring early: gene begins at positions <= this go through the scan
+    // forward frames: best start / operon offer since the last forward stop of the frame
+    double rv0, rv1, rv2; int ri0, ri1, ri2, rn0, rn1, rn2;
+    // last reverse stop of each frame: its score, index, stop_val, position
+    double l3v0, l3v1, l3v2; int l3i0, l3i1, l3i2, l3s0, l3s1, l3s2, l3n0, l3n1, l3n2;
+    double end_best; int end_idx, end_tb;
+};
+
+DPW_HD void dpl_init(DplState& S) {
+    const double NI = -__builtin_huge_val();
+    S.r5_all = DplMax{NI, -1, -1}; S.r5_far = DplMax{NI, -1, -1}; S.f3_far = DplMax{NI, -1, -1};
+    S.r5_head = S.r5_cnt = S.f3_head = S.f3_cnt = 0;
+    S.r5_ovf = S.f3_ovf = INT_MIN;
+    S.rv0 = S.rv1 = S.rv2 = NI; S.ri0 = S.ri1 = S.ri2 = -1; S.rn0 = S.rn1 = S.rn2 = -1;
+    S.l3v0 = S.l3v1 = S.l3v2 = 0.0; S.l3i0 = S.l3i1 = S.l3i2 = -1; S.l3s0 = S.l3s1 = S.l3s2 = 0; S.l3n0 = S.l3n1 = S.l3n2 = 0;
+    S.end_best = -1.0; S.end_idx = -1; S.end_tb = -1;
+}
+
+// What a step needs from its surroundings (the kernel: LDS rings + the chain's arrays in HBM; the host model: plain arrays):
+//   DplEnt r5_get(slot) / r5_put(slot, e) / f3_get / f3_put      the lane's rings
+//   int    kf(j), ndx(j), q2(j), tbn(j), traceb(j);  double score(j)      a FINISHED node j < i of this chain, from memory
+//   void   note(k)      diagnostics of the host model (0: a window scan, 1: near gene ends read back after a ring overflow)
+//
+// dpl_rescan: every gene end of the window against this gene begin, pair by pair (what the reference's loop does for these
+// sources), and the running maxima rebuilt over the window on the way.  `r5_first` / `f3_first`: chain index of the oldest entry
+// still in the ring (or T.i when the ring is empty): ends before it are the folded ones.
+template <class X>
+DPW_HD void dpl_rescan(DplState& S, const DpwT& T, const DpwModel& M, X& x, DpwBest& B, const int r5_first, const int f3_first) {
+    const double NI = -__builtin_huge_val();
+    DplMax all{NI, -1, -1}, r5f{NI, -1, -1}, f3f{NI, -1, -1};
+    for (int j = T.lo; j < T.i; j++) {
+        const int kf = x.kf(j);
+        const int k = DPW_KIND(kf);
+        if (k != 1 && k != 2) continue;
+        const int tbn = x.tbn(j);
+        if (x.traceb(j) == -1) continue;
+        DpwS s;
+        s.j = j; s.kind = k; s.frame = DPW_FRAME(kf); s.ndx = x.ndx(j); s.stop_val = 0; s.vm = 0; s.tbn = tbn; s.score = x.score(j);
+        s.cs = 0.0; s.x0 = s.x1 = s.x2 = 0.0;
+        bool ok; double w; int mf;
+        dpw_pair(s, T, M, ok, w, mf);
+        dpw_take(B, ok, s.score + w, j, mf, s.ndx);
+        const double a = s.score + M.negc;
+        if (k == 2) { dpl_max_take(all, a, j, s.ndx); if (j < r5_first) dpl_max_take(r5f, a, j, s.ndx); }
+        else if (j < f3_first) dpl_max_take(f3f, a, j, s.ndx);
+    }
+    S.r5_all = all; S.r5_far = r5f; S.f3_far = f3f;
+}
+
+DPW_HD double dpl_sel3(const int k, const double a, const double b, const double c) { return k == 0 ? a : (k == 1 ? b : c); }
+DPW_HD int dpl_sel3i(const int k, const int a, const int b, const int c) { return k == 0 ? a : (k == 1 ? b : c); }
+
+// A reached gene end within 180 bases of a gene begin, as one pair.  A forward stop towards a reverse stop is the plain connection
+// only (ref: _connection.h:288-336 with no overlapping start taken): the candidates that go through an overlapping start of the
+// target need the position of the source's own traceb node and are met on the chains of candidates, with a larger value.
+DPW_HD void dpl_near(DpwBest& B, const DpwT& T, const DpwModel& M, const bool r3, const int kind, const DplEnt e) {
+    if (kind == 1 && r3) {
+        const bool ok = (e.idx >= T.lo) & (e.idx < T.i) & (e.ndx + 2 < T.ndx - 2);
+        dpw_take(B, ok, e.score + M.negc, e.idx, -1, e.ndx);
+        return;
+    }
+    DpwS s;
+    s.j = e.idx; s.kind = kind; s.frame = 0; s.ndx = e.ndx; s.stop_val = 0; s.vm = 0; s.tbn = 0 /* reached */;
+    s.score = e.score; s.cs = 0.0; s.x0 = s.x1 = s.x2 = 0.0;
+    bool ok; double w; int mf;
+    dpw_pair(s, T, M, ok, w, mf);
+    dpw_take(B, ok, s.score + w, s.j, mf, s.ndx);
+}
+
+// One node: candidates -> B, then the node's own contribution to the running structures.  `kfb`: the node's topology byte.
+// Returns through B the node's score / traceb / ov_mark / position of the traceb node.
+template <class X>
+DPW_HD void dpl_step(DplState& S, const DpwT& T, const int kfb, const DpwModel& M, X& x, DpwBest& B) {
+    B.val = 0.0; B.tb = -1; B.ov = -1; B.tbn = -1;
+    const int i = T.i;
+    const int f = T.frame;
+    // ---- fold the ring entries that are more than 180 bases behind this node (they are for every later node too)
+    const int far_pos = T.ndx - DPL_NEAR;            // an end at a position below this is far
+    while (S.r5_cnt > 0) {
+        const DplEnt e = x.r5_get((S.r5_head - S.r5_cnt) & (DPL_R5_RING - 1));
+        if (e.ndx >= far_pos) break;
+        dpl_max_take(S.r5_far, e.score + M.negc, e.idx, e.ndx);
+        S.r5_cnt--;
+    }
+    while (S.f3_cnt > 0) {
+        const DplEnt e = x.f3_get((S.f3_head - S.f3_cnt) & (DPL_F3_RING - 1));
+        if (e.ndx >= far_pos) break;
+        dpl_max_take(S.f3_far, e.score + M.negc, e.idx, e.ndx);
+        S.f3_cnt--;
+    }
+    if (T.kind == 0 || T.kind == 3) {
+        // ---- a gene begin: every gene end of the window
+        const bool r3 = T.kind == 3;
+        // which running maxima this target reads, and whether their argmax still lies in the window
+        bool stale = false;
+        if (!r3) {
+            if (S.r5_all.i >= 0 && S.r5_all.i < T.lo) stale = true;
+            if (S.f3_far.i >= 0 && S.f3_far.i < T.lo) stale = true;
+        } else {
+            if (S.r5_far.i >= 0 && S.r5_far.i < T.lo) stale = true;
+            if (S.f3_far.i >= 0 && S.f3_far.i < T.lo) stale = true;
+        }
+        // an entry that left its ring early may still be near: then the near gene ends are read back from memory instead
+        const bool ovf = r3 ? (T.ndx <= S.r5_ovf || T.ndx <= S.f3_ovf) : (T.ndx <= S.f3_ovf);
+        if (stale) {
+            x.note(0);
+            const int r5_first = S.r5_cnt > 0 ? x.r5_get((S.r5_head - S.r5_cnt) & (DPL_R5_RING - 1)).idx : i;
+            const int f3_first = S.f3_cnt > 0 ? x.f3_get((S.f3_head - S.f3_cnt) & (DPL_F3_RING - 1)).idx : i;
+            dpl_rescan(S, T, M, x, B, r5_first, f3_first);
+        } else {
+            // far gene ends: the running maxima (the weight is the constant -0.15 st_wt)
+            if (!r3) { if (S.r5_all.i >= 0) dpw_take(B, true, S.r5_all.v, S.r5_all.i, -1, S.r5_all.n); }
+            else     { if (S.r5_far.i >= 0) dpw_take(B, true, S.r5_far.v, S.r5_far.i, -1, S.r5_far.n); }
+            if (S.f3_far.i >= 0) dpw_take(B, true, S.f3_far.v, S.f3_far.i, -1, S.f3_far.n);
+            // near gene ends, pair by pair: forward stops for both kinds of gene begin, reverse starts for a reverse stop
+            if (ovf) {
+                x.note(1);
+                for (int j = i - 1; j >= T.lo; j--) {
+                    const int s_ndx = x.ndx(j);
+                    if (s_ndx < far_pos) break;
+                    const int k = DPW_KIND(x.kf(j));
+                    if (!(k == 1 || (k == 2 && r3)) || x.traceb(j) == -1) continue;
+                    dpl_near(B, T, M, r3, k, DplEnt{x.score(j), s_ndx, j});
+                }
+            } else {
+                for (int k = 0; k < S.f3_cnt; k++) dpl_near(B, T, M, r3, 1, x.f3_get((S.f3_head - 1 - k) & (DPL_F3_RING - 1)));
+                if (r3) for (int k = 0; k < S.r5_cnt; k++) dpl_near(B, T, M, r3, 2, x.r5_get((S.r5_head - 1 - k) & (DPL_R5_RING - 1)));
+            }
+        }
+        if (r3) {
+            // the reverse stop whose ORF covers this one, per frame of an overlapping start: an operon (ref: :345-356)
+            if ((T.vm & 1) && S.l3i0 >= 0 && S.l3i0 >= T.lo && S.l3s0 > T.ndx) dpw_take(B, true, S.l3v0 + T.x0, S.l3i0, -1, S.l3n0);
+            if ((T.vm & 2) && S.l3i1 >= 0 && S.l3i1 >= T.lo && S.l3s1 > T.ndx) dpw_take(B, true, S.l3v1 + T.x1, S.l3i1, -1, S.l3n1);
+            if ((T.vm & 4) && S.l3i2 >= 0 && S.l3i2 >= T.lo && S.l3s2 > T.ndx) dpw_take(B, true, S.l3v2 + T.x2, S.l3i2, -1, S.l3n2);
+            // forward stops that overlap the 3' end of the gene of an overlapping start: the chain of candidates of each
+            for (int q = 0; q < 3; q++) {
+                if (!((T.vm >> q) & 1)) continue;
+                const int bound = dpl_sel3i(q, T.n3s0, T.n3s1, T.n3s2) + DPW_MAX_OPP_OVLP - 5;
+                for (int j = dpl_sel3i(q, T.cq0, T.cq1, T.cq2); j < i; j = x.q2(j)) {
+                    const int s_ndx = x.ndx(j);
+                    if (s_ndx >= bound) break;
+                    DpwS s;
+                    s.j = j; s.kind = 1; s.frame = 0; s.ndx = s_ndx; s.stop_val = 0; s.vm = 0; s.tbn = x.tbn(j); s.score = x.score(j);
+                    s.cs = 0.0; s.x0 = s.x1 = s.x2 = 0.0;
+                    bool ok; double w; int mf;
+                    dpw_pair(s, T, M, ok, w, mf);
+                    dpw_take(B, ok, s.score + w, j, mf, s_ndx);
+                }
+            }
+        }
+    } else if (T.kind == 1) {
+        // ---- a forward stop: the best start / operon partner of its ORF (ref: :166-188)
+        const int ci = dpl_sel3i(f, S.ri0, S.ri1, S.ri2);
+        if (ci >= 0) dpw_take(B, true, dpl_sel3(f, S.rv0, S.rv1, S.rv2), ci, -1, dpl_sel3i(f, S.rn0, S.rn1, S.rn2));
+    } else {
+        // ---- a reverse start: its own stop (ref: :228-235) ...
+        const int j = dpl_sel3i(f, S.l3i0, S.l3i1, S.l3i2);
+        if (j >= 0 && j >= T.lo && dpl_sel3i(f, S.l3s0, S.l3s1, S.l3s2) > T.ndx)
+            dpw_take(B, true, dpl_sel3(f, S.l3v0, S.l3v1, S.l3v2) + T.cs, j, -1, dpl_sel3i(f, S.l3n0, S.l3n1, S.l3n2));
+        // ... and the forward stops overlapping its gene's 3' end (ref: :238-254)
+        const int bound = T.stop_val + DPW_MAX_OPP_OVLP - 5;
+        for (int c = T.q2; c < i; c = x.q2(c)) {
+            const int s_ndx = x.ndx(c);
+            if (s_ndx >= bound) break;
+            DpwS s;
+            s.j = c; s.kind = 1; s.frame = 0; s.ndx = s_ndx; s.stop_val = 0; s.vm = 0; s.tbn = x.tbn(c); s.score = x.score(c);
+            s.cs = 0.0; s.x0 = s.x1 = s.x2 = 0.0;
+            bool ok; double w; int mf;
+            dpw_pair(s, T, M, ok, w, mf);
+            dpw_take(B, ok, s.score + w, c, mf, s_ndx);
+        }
+    }
+
+    // ---- the node is final: what it leaves for later nodes
+    const bool reached = B.tb != -1;
+    if ((T.kind == 1 || T.kind == 2) && B.val >= S.end_best) { S.end_best = B.val; S.end_idx = i; S.end_tb = B.tb; }
+    if (T.kind == 0) {
+        const double g = B.val + T.cs;
+        if (f == 0) { if (g >= S.rv0) { S.rv0 = g; S.ri0 = i; S.rn0 = T.ndx; } }
+        else if (f == 1) { if (g >= S.rv1) { S.rv1 = g; S.ri1 = i; S.rn1 = T.ndx; } }
+        else { if (g >= S.rv2) { S.rv2 = g; S.ri2 = i; S.rn2 = T.ndx; } }
+    } else if (T.kind == 1) {
+        const double NI = -__builtin_huge_val();
+        // the running maximum of its own frame restarts; its operon offers go to the frames whose next stop's ORF holds it
+        if (f == 0) { S.rv0 = NI; S.ri0 = -1; S.rn0 = -1; } else if (f == 1) { S.rv1 = NI; S.ri1 = -1; S.rn1 = -1; } else { S.rv2 = NI; S.ri2 = -1; S.rn2 = -1; }
+        if (reached) {
+            if ((T.vm & 1) && DPW_INORF(kfb, 0)) { const double v = B.val + T.x0; if (v >= S.rv0) { S.rv0 = v; S.ri0 = i; S.rn0 = T.ndx; } }
+            if ((T.vm & 2) && DPW_INORF(kfb, 1)) { const double v = B.val + T.x1; if (v >= S.rv1) { S.rv1 = v; S.ri1 = i; S.rn1 = T.ndx; } }
+            if ((T.vm & 4) && DPW_INORF(kfb, 2)) { const double v = B.val + T.x2; if (v >= S.rv2) { S.rv2 = v; S.ri2 = i; S.rn2 = T.ndx; } }
+            if (S.f3_cnt == DPL_F3_RING) {
+                // the ring is full of forward stops that are still near: its oldest entry is folded early, and the gene begins it is
+                // still near to go through the scan
+                const DplEnt e = x.f3_get((S.f3_head - S.f3_cnt) & (DPL_F3_RING - 1));
+                dpl_max_take(S.f3_far, e.score + M.negc, e.idx, e.ndx);
+                if (e.ndx + DPL_NEAR > S.f3_ovf) S.f3_ovf = e.ndx + DPL_NEAR;
+                S.f3_cnt--;
+            }
+            x.f3_put(S.f3_head & (DPL_F3_RING - 1), DplEnt{B.val, T.ndx, i});
+            S.f3_head = (S.f3_head + 1) & (DPL_F3_RING - 1); S.f3_cnt++;
+        }
+    } else if (T.kind == 2) {
+        if (reached) {
+            dpl_max_take(S.r5_all, B.val + M.negc, i, T.ndx);
+            if (S.r5_cnt == DPL_R5_RING) {
+                const DplEnt e = x.r5_get((S.r5_head - S.r5_cnt) & (DPL_R5_RING - 1));
+                dpl_max_take(S.r5_far, e.score + M.negc, e.idx, e.ndx);
+                if (e.ndx + DPL_NEAR > S.r5_ovf) S.r5_ovf = e.ndx + DPL_NEAR;
+                S.r5_cnt--;
+            }
+            x.r5_put(S.r5_head & (DPL_R5_RING - 1), DplEnt{B.val, T.ndx, i});
+            S.r5_head = (S.r5_head + 1) & (DPL_R5_RING - 1); S.r5_cnt++;
+        }
+    } else {
+        if (f == 0) { S.l3v0 = B.val; S.l3i0 = i; S.l3s0 = T.stop_val; S.l3n0 = T.ndx; }
+        else if (f == 1) { S.l3v1 = B.val; S.l3i1 = i; S.l3s1 = T.stop_val; S.l3n1 = T.ndx; }
+        else { S.l3v2 = B.val; S.l3i2 = i; S.l3s2 = T.stop_val; S.l3n2 = T.ndx; }
+    }
+}

@@ -1418,7 +1418,8 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             const char* cs_env = getenv("PGA_CS_LDS");
             const char* cs_tn = getenv("PGA_CS_TASK_NODES");
             const int cs_task_nodes = cs_tn && atoi(cs_tn) >= 256 && atoi(cs_tn) <= 8192 ? atoi(cs_tn) : 4096;     // several tasks per CU and launch
-            if (meta_run && nn >= 65536 && !(cs_env && atoi(cs_env) == 0)) {
+            // PGA_CS_LDS=2 (tests): the LDS form whatever the size of the launch
+            if (meta_run && (nn >= 65536 || (cs_env && atoi(cs_env) == 2)) && !(cs_env && atoi(cs_env) == 0)) {
                 std::vector<int32_t>& tk = cs_tk[g]; std::vector<int32_t>& en = cs_en[g];     // alive until the stream is synchronized
                 if (pga_cs_tasks(h_cc + (size_t)g * NC, NC, chains.data(), h_cbase + (size_t)g * (NC + 1), f->model_rank.data(), cs_task_nodes, tk, en) && !tk.empty()) {
                     char nm1[32], nm2[32];

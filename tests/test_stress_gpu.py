@@ -47,8 +47,11 @@ def test_dp_kernels_and_tails_agree_on_random_gene_dense_contigs(monkeypatch):
     ctx.set_models(models)
     runs = {}
     for name, env in (("tree+auto", {}), ("scan+host", {"PGA_DP_KERNEL": "scan", "PGA_TAIL": "host"}),
-                      ("tree1+device", {"PGA_DP_KERNEL": "tree1", "PGA_TAIL": "device"}), ("tree3+host", {"PGA_DP_KERNEL": "tree3", "PGA_TAIL": "host"})):
-        for k in ("PGA_DP_KERNEL", "PGA_TAIL"):
+                      ("tree1+device", {"PGA_DP_KERNEL": "tree1", "PGA_TAIL": "device"}), ("tree3+host", {"PGA_DP_KERNEL": "tree3", "PGA_TAIL": "host"}),
+                      # the kernels every headline number comes from, forced onto this small launch: the wave-batch connection
+                      # scorer, the lane-per-chain connection scorer and the LDS-table form of the coding score
+                      ("wave+ldscs", {"PGA_DP_KERNEL": "wave", "PGA_CS_LDS": "2"}), ("lane+ldscs", {"PGA_DP_KERNEL": "lane", "PGA_CS_LDS": "2"})):
+        for k in ("PGA_DP_KERNEL", "PGA_TAIL", "PGA_CS_LDS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -63,7 +66,7 @@ def test_dp_kernels_and_tails_agree_on_random_gene_dense_contigs(monkeypatch):
                 assert np.array_equal(a[f], b[f]), (name, f)
             assert np.array_equal(a["score"].view(np.uint64), b["score"].view(np.uint64)) and np.array_equal(a["sscore"].view(np.uint64), b["sscore"].view(np.uint64)), name
     # single mode with masking as well
-    for k in ("PGA_DP_KERNEL", "PGA_TAIL"):
+    for k in ("PGA_DP_KERNEL", "PGA_TAIL", "PGA_CS_LDS"):
         monkeypatch.delenv(k, raising=False)
     ctx.set_models(models[7:8])
     s1 = ctx.find_genes_batch(seqs, meta=False, mask=True, closed=True)
