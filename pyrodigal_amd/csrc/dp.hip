@@ -1627,8 +1627,18 @@ void pga_launch_dp_prepare(const ChainDesc* d_chains, int n_chains, int64_t node
 
 bool pga_dp_use_wave(int n_chains) {
     const char* kern = getenv("PGA_DP_KERNEL");
-    if (kern && *kern) return strcmp(kern, "wave") == 0;
+    if (kern && *kern) return strcmp(kern, "wave") == 0 || strcmp(kern, "lane") == 0;     // the lane kernel reads the wave kernel's records
     return n_chains >= 2048;
+}
+bool pga_dp_use_lane(int n_chains) {
+    const char* kern = getenv("PGA_DP_KERNEL");
+    if (kern && *kern) return strcmp(kern, "lane") == 0;
+    if (const char* e = getenv("PGA_DP_LANE")) { if (atoi(e) == 0) return false; }
+    // a wavefront holds 64 chains: below a few waves per SIMD (1024 x 64 chains each) the one-wave-per-chain kernel has more in
+    // flight and wins
+    int min_chains = 1 << 30;
+    if (const char* e = getenv("PGA_DP_LANE_MIN")) min_chains = std::max(1, atoi(e));
+    return n_chains >= min_chains;
 }
 
 static int env_int(const char* name, int dflt) {

@@ -37,9 +37,17 @@
 #ifndef DPL_F3_RING
 #define DPL_F3_RING 8
 #endif
+#ifndef DPL_CAND
+#define DPL_CAND 4          // forward stops kept per reverse frame (those within MAX_OPP_OVLP bases of the frame's last reverse stop)
+#endif
 #define DPL_NEAR    (3 * DPW_OPER_DIST)
 
 struct DplEnt { double score; int32_t ndx, idx; };
+// a finished node as memory holds it: position, next-candidate link, topology byte; position of its traceb node, traceb (-1: not
+// reached), score
+struct DplFin { int32_t ndx, q2, kf, tbn, tb; double score; };
+// a reached forward stop that can overlap the 3' end of a reverse gene: score, position, chain index, position of its traceb node
+struct DplCand { double score; int32_t ndx, idx, tbn; };
 
 // lexicographic (value, index) maximum with the position of the argmax node carried along
 struct DplMax { double v; int i, n; };
@@ -52,6 +60,7 @@ struct DplState {
     DplMax r5_far, f3_far;      // a over the reverse starts / forward stops that left their ring (more than 180 bases behind)
     int r5_head, r5_cnt, f3_head, f3_cnt;      // rings: the last `cnt` entries pushed, newest at head - 1 (slots modulo the ring size)
     int r5_ovf, f3_ovf;         // an entry left its ring early: gene begins at positions <= this go through the scan
+    int cn;                     // per reverse frame f: bits 4f .. 4f+2 = forward stops in its candidate list, bit 4f+3 = the list is incomplete
     // forward frames: best start / operon offer since the last forward stop of the frame
     double rv0, rv1, rv2; int ri0, ri1, ri2, rn0, rn1, rn2;
     // last reverse stop of each frame: its score, index, stop_val, position
@@ -64,6 +73,7 @@ DPW_HD void dpl_init(DplState& S) {
     S.r5_all = DplMax{NI, -1, -1}; S.r5_far = DplMax{NI, -1, -1}; S.f3_far = DplMax{NI, -1, -1};
     S.r5_head = S.r5_cnt = S.f3_head = S.f3_cnt = 0;
     S.r5_ovf = S.f3_ovf = INT_MIN;
+    S.cn = 0;
     S.rv0 = S.rv1 = S.rv2 = NI; S.ri0 = S.ri1 = S.ri2 = -1; S.rn0 = S.rn1 = S.rn2 = -1;
     S.l3v0 = S.l3v1 = S.l3v2 = 0.0; S.l3i0 = S.l3i1 = S.l3i2 = -1; S.l3s0 = S.l3s1 = S.l3s2 = 0; S.l3n0 = S.l3n1 = S.l3n2 = 0;
     S.end_best = -1.0; S.end_idx = -1; S.end_tb = -1;
@@ -71,8 +81,11 @@ DPW_HD void dpl_init(DplState& S) {
 
 // What a step needs from its surroundings (the kernel: LDS rings + the chain's arrays in HBM; the host model: plain arrays):
 //   DplEnt r5_get(slot) / r5_put(slot, e) / f3_get / f3_put      the lane's rings
-//   int    kf(j), ndx(j), q2(j), tbn(j), traceb(j);  double score(j)      a FINISHED node j < i of this chain, from memory
-//   void   note(k)      diagnostics of the host model (0: a window scan, 1: near gene ends read back after a ring overflow)
+//   int    f3t_get(slot) / f3t_put(slot, tbn)                   position of the traceb node of the forward stops in the ring
+//   DplCand cand_get(f, k) / cand_put(f, k, c)                  the candidate list of reverse frame f
+//   DplFin fin(j)       a FINISHED node j < i of this chain, read back from memory (topology + results in one go)
+//   void   note(k)      diagnostics of the host model (0: a window scan, 1: near gene ends read back after a ring overflow,
+//                       2: a chain of overlap candidates walked in memory)
 //
 // dpl_rescan: every gene end of the window against this gene begin, pair by pair (what the reference's loop does for these
 // sources), and the running maxima rebuilt over the window on the way.  `r5_first` / `f3_first`: chain index of the oldest entry
@@ -82,13 +95,11 @@ DPW_HD void dpl_rescan(DplState& S, const DpwT& T, const DpwModel& M, X& x, DpwB
     const double NI = -__builtin_huge_val();
     DplMax all{NI, -1, -1}, r5f{NI, -1, -1}, f3f{NI, -1, -1};
     for (int j = T.lo; j < T.i; j++) {
-        const int kf = x.kf(j);
-        const int k = DPW_KIND(kf);
-        if (k != 1 && k != 2) continue;
-        const int tbn = x.tbn(j);
-        if (x.traceb(j) == -1) continue;
+        const DplFin r = x.fin(j);
+        const int k = DPW_KIND(r.kf);
+        if ((k != 1 && k != 2) || r.tb == -1) continue;
         DpwS s;
-        s.j = j; s.kind = k; s.frame = DPW_FRAME(kf); s.ndx = x.ndx(j); s.stop_val = 0; s.vm = 0; s.tbn = tbn; s.score = x.score(j);
+        s.j = j; s.kind = k; s.frame = DPW_FRAME(r.kf); s.ndx = r.ndx; s.stop_val = 0; s.vm = 0; s.tbn = r.tbn; s.score = r.score;
         s.cs = 0.0; s.x0 = s.x1 = s.x2 = 0.0;
         bool ok; double w; int mf;
         dpw_pair(s, T, M, ok, w, mf);
@@ -118,6 +129,51 @@ DPW_HD void dpl_near(DpwBest& B, const DpwT& T, const DpwModel& M, const bool r3
     bool ok; double w; int mf;
     dpw_pair(s, T, M, ok, w, mf);
     dpw_take(B, ok, s.score + w, s.j, mf, s.ndx);
+}
+
+// a forward stop met on a chain of candidates (ref: _connection.h:238-254, 296-325), as one pair
+DPW_HD void dpl_f3_candidate(DpwBest& B, const DpwT& T, const DpwModel& M, const int j, const DplFin& r) {
+    DpwS s;
+    s.j = j; s.kind = 1; s.frame = 0; s.ndx = r.ndx; s.stop_val = 0; s.vm = 0; s.tbn = r.tb == -1 ? -1 : r.tbn; s.score = r.score;
+    s.cs = 0.0; s.x0 = s.x1 = s.x2 = 0.0;
+    bool ok; double w; int mf;
+    dpw_pair(s, T, M, ok, w, mf);
+    dpw_take(B, ok, s.score + w, j, mf, r.ndx);
+}
+
+// The forward stops that can overlap the 3' end of a reverse gene whose stop is at `stop_pos` (frame f) against target T: they lie
+// within [stop_pos - 4, stop_pos + MAX_OPP_OVLP - 5) (ref: _connection.h:238-254, 296-325).  The lane keeps those that follow the
+// LAST reverse stop of each frame in a small list, filled as the forward stops are finished; a target whose stop is not that
+// one, or whose list overflowed, walks the static chain of candidates in memory instead (first candidate `first`, q2 links).
+template <class X>
+DPW_HD void dpl_overlap_candidates(const DplState& S, const DpwT& T, const DpwModel& M, X& x, DpwBest& B, const int f, const int stop_pos,
+                                   const int first) {
+    const int l3i = dpl_sel3i(f, S.l3i0, S.l3i1, S.l3i2), l3n = dpl_sel3i(f, S.l3n0, S.l3n1, S.l3n2);
+    const int c4 = (S.cn >> (4 * f)) & 15;
+    if (l3i >= 0 && l3n == stop_pos && !(c4 & 8)) {
+        for (int k = 0; k < (c4 & 7); k++) {
+            const DplCand c = x.cand_get(f, k);
+            dpl_f3_candidate(B, T, M, c.idx, DplFin{c.ndx, 0, 1, c.tbn, 0, c.score});
+        }
+        return;
+    }
+    x.note(2);
+    const int bound = stop_pos + DPW_MAX_OPP_OVLP - 5;
+    for (int j = first; j < T.i;) {
+        const DplFin r = x.fin(j);
+        if (r.ndx >= bound) break;
+        dpl_f3_candidate(B, T, M, j, r);
+        j = r.q2;
+    }
+}
+// a reached forward stop joins the list of every reverse frame whose last stop it can overlap
+template <class X>
+DPW_HD void dpl_cand_push(DplState& S, X& x, const int f, const DplCand& c) {
+    const int c4 = (S.cn >> (4 * f)) & 15;
+    if (c4 & 8) return;
+    if ((c4 & 7) == DPL_CAND) { S.cn |= 8 << (4 * f); return; }
+    x.cand_put(f, c4 & 7, c);
+    S.cn += 1 << (4 * f);
 }
 
 // One node: candidates -> B, then the node's own contribution to the running structures.  `kfb`: the node's topology byte.
@@ -169,11 +225,11 @@ DPW_HD void dpl_step(DplState& S, const DpwT& T, const int kfb, const DpwModel& 
             if (ovf) {
                 x.note(1);
                 for (int j = i - 1; j >= T.lo; j--) {
-                    const int s_ndx = x.ndx(j);
-                    if (s_ndx < far_pos) break;
-                    const int k = DPW_KIND(x.kf(j));
-                    if (!(k == 1 || (k == 2 && r3)) || x.traceb(j) == -1) continue;
-                    dpl_near(B, T, M, r3, k, DplEnt{x.score(j), s_ndx, j});
+                    const DplFin r = x.fin(j);
+                    if (r.ndx < far_pos) break;
+                    const int k = DPW_KIND(r.kf);
+                    if (!(k == 1 || (k == 2 && r3)) || r.tb == -1) continue;
+                    dpl_near(B, T, M, r3, k, DplEnt{r.score, r.ndx, j});
                 }
             } else {
                 for (int k = 0; k < S.f3_cnt; k++) dpl_near(B, T, M, r3, 1, x.f3_get((S.f3_head - 1 - k) & (DPL_F3_RING - 1)));
@@ -185,21 +241,10 @@ DPW_HD void dpl_step(DplState& S, const DpwT& T, const int kfb, const DpwModel& 
             if ((T.vm & 1) && S.l3i0 >= 0 && S.l3i0 >= T.lo && S.l3s0 > T.ndx) dpw_take(B, true, S.l3v0 + T.x0, S.l3i0, -1, S.l3n0);
             if ((T.vm & 2) && S.l3i1 >= 0 && S.l3i1 >= T.lo && S.l3s1 > T.ndx) dpw_take(B, true, S.l3v1 + T.x1, S.l3i1, -1, S.l3n1);
             if ((T.vm & 4) && S.l3i2 >= 0 && S.l3i2 >= T.lo && S.l3s2 > T.ndx) dpw_take(B, true, S.l3v2 + T.x2, S.l3i2, -1, S.l3n2);
-            // forward stops that overlap the 3' end of the gene of an overlapping start: the chain of candidates of each
-            for (int q = 0; q < 3; q++) {
-                if (!((T.vm >> q) & 1)) continue;
-                const int bound = dpl_sel3i(q, T.n3s0, T.n3s1, T.n3s2) + DPW_MAX_OPP_OVLP - 5;
-                for (int j = dpl_sel3i(q, T.cq0, T.cq1, T.cq2); j < i; j = x.q2(j)) {
-                    const int s_ndx = x.ndx(j);
-                    if (s_ndx >= bound) break;
-                    DpwS s;
-                    s.j = j; s.kind = 1; s.frame = 0; s.ndx = s_ndx; s.stop_val = 0; s.vm = 0; s.tbn = x.tbn(j); s.score = x.score(j);
-                    s.cs = 0.0; s.x0 = s.x1 = s.x2 = 0.0;
-                    bool ok; double w; int mf;
-                    dpw_pair(s, T, M, ok, w, mf);
-                    dpw_take(B, ok, s.score + w, j, mf, s_ndx);
-                }
-            }
+            // forward stops that overlap the 3' end of the gene of an overlapping start (the start of frame q has its stop at n3s)
+            if (T.vm & 1) dpl_overlap_candidates(S, T, M, x, B, 0, T.n3s0, T.cq0);
+            if (T.vm & 2) dpl_overlap_candidates(S, T, M, x, B, 1, T.n3s1, T.cq1);
+            if (T.vm & 4) dpl_overlap_candidates(S, T, M, x, B, 2, T.n3s2, T.cq2);
         }
     } else if (T.kind == 1) {
         // ---- a forward stop: the best start / operon partner of its ORF (ref: :166-188)
@@ -211,17 +256,7 @@ DPW_HD void dpl_step(DplState& S, const DpwT& T, const int kfb, const DpwModel& 
         if (j >= 0 && j >= T.lo && dpl_sel3i(f, S.l3s0, S.l3s1, S.l3s2) > T.ndx)
             dpw_take(B, true, dpl_sel3(f, S.l3v0, S.l3v1, S.l3v2) + T.cs, j, -1, dpl_sel3i(f, S.l3n0, S.l3n1, S.l3n2));
         // ... and the forward stops overlapping its gene's 3' end (ref: :238-254)
-        const int bound = T.stop_val + DPW_MAX_OPP_OVLP - 5;
-        for (int c = T.q2; c < i; c = x.q2(c)) {
-            const int s_ndx = x.ndx(c);
-            if (s_ndx >= bound) break;
-            DpwS s;
-            s.j = c; s.kind = 1; s.frame = 0; s.ndx = s_ndx; s.stop_val = 0; s.vm = 0; s.tbn = x.tbn(c); s.score = x.score(c);
-            s.cs = 0.0; s.x0 = s.x1 = s.x2 = 0.0;
-            bool ok; double w; int mf;
-            dpw_pair(s, T, M, ok, w, mf);
-            dpw_take(B, ok, s.score + w, c, mf, s_ndx);
-        }
+        dpl_overlap_candidates(S, T, M, x, B, f, T.stop_val, T.q2);
     }
 
     // ---- the node is final: what it leaves for later nodes
@@ -249,7 +284,13 @@ DPW_HD void dpl_step(DplState& S, const DpwT& T, const int kfb, const DpwModel& 
                 S.f3_cnt--;
             }
             x.f3_put(S.f3_head & (DPL_F3_RING - 1), DplEnt{B.val, T.ndx, i});
+            x.f3t_put(S.f3_head & (DPL_F3_RING - 1), B.tbn);
             S.f3_head = (S.f3_head + 1) & (DPL_F3_RING - 1); S.f3_cnt++;
+            // it may overlap the 3' end of the reverse genes that end at the last reverse stop of a frame
+            const DplCand me{B.val, T.ndx, i, B.tbn};
+            if (S.l3i0 >= 0 && T.ndx >= S.l3n0 - 4 && T.ndx < S.l3n0 + DPW_MAX_OPP_OVLP - 5) dpl_cand_push(S, x, 0, me);
+            if (S.l3i1 >= 0 && T.ndx >= S.l3n1 - 4 && T.ndx < S.l3n1 + DPW_MAX_OPP_OVLP - 5) dpl_cand_push(S, x, 1, me);
+            if (S.l3i2 >= 0 && T.ndx >= S.l3n2 - 4 && T.ndx < S.l3n2 + DPW_MAX_OPP_OVLP - 5) dpl_cand_push(S, x, 2, me);
         }
     } else if (T.kind == 2) {
         if (reached) {
@@ -267,5 +308,14 @@ DPW_HD void dpl_step(DplState& S, const DpwT& T, const int kfb, const DpwModel& 
         if (f == 0) { S.l3v0 = B.val; S.l3i0 = i; S.l3s0 = T.stop_val; S.l3n0 = T.ndx; }
         else if (f == 1) { S.l3v1 = B.val; S.l3i1 = i; S.l3s1 = T.stop_val; S.l3n1 = T.ndx; }
         else { S.l3v2 = B.val; S.l3i2 = i; S.l3s2 = T.stop_val; S.l3n2 = T.ndx; }
+        // the candidate list of the frame starts over: the reached forward stops up to four bases before this stop are in the
+        // ring of forward stops (unless one of them left it early: then the list is incomplete and the chain in memory is walked)
+        S.cn &= ~(15 << (4 * f));
+        if (S.f3_ovf >= T.ndx - 4 + DPL_NEAR) S.cn |= 8 << (4 * f);
+        for (int k = S.f3_cnt - 1; k >= 0; k--) {            // oldest first: the list is in position order like the chain
+            const int slot = (S.f3_head - 1 - k) & (DPL_F3_RING - 1);
+            const DplEnt e = x.f3_get(slot);
+            if (e.ndx >= T.ndx - 4) dpl_cand_push(S, x, f, DplCand{e.score, e.ndx, e.idx, x.f3t_get(slot)});
+        }
     }
 }

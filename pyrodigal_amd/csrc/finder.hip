@@ -395,6 +395,7 @@ struct WinDesc {
     int64_t topo_off;
     int32_t n;
     int32_t _pad;
+    int64_t il_rec;      // >= 0: the DP pass left its results in the lane kernel's interleaved records, node i at il_rec + 64 i
 };
 struct OutArrays {
     int32_t* ndx; int32_t* stop_val; uint8_t* type; int8_t* strand; float* gc_cont;
@@ -406,7 +407,7 @@ struct OutArrays {
 
 __global__ void __launch_bounds__(256)
 k_gather_winners(const WinDesc* __restrict__ wd, int n_win, int64_t out_begin, int64_t total, GroupArrays ga, ChainArrays ca,
-                 DpBuffers dp, OutArrays o) {
+                 DpBuffers dp, OutArrays o, const int4* __restrict__ il_out) {
     __shared__ int s_w0;
     const int64_t blk0 = out_begin + (int64_t)blockIdx.x * blockDim.x;
     const int64_t g = blk0 + threadIdx.x;
@@ -426,7 +427,10 @@ k_gather_winners(const WinDesc* __restrict__ wd, int n_win, int64_t out_begin, i
     o.edge_dp[g] = ca.edge[a]; o.cscore_dp[g] = ca.cscore[a]; o.sscore_dp[g] = ca.sscore[a]; o.rscore_dp[g] = ca.rscore[a];
     o.uscore_dp[g] = ca.uscore[a]; o.tscore_dp[g] = ca.tscore[a];
     o.star_ptr[3 * g] = ca.star_ptr[3 * a]; o.star_ptr[3 * g + 1] = ca.star_ptr[3 * a + 1]; o.star_ptr[3 * g + 2] = ca.star_ptr[3 * a + 2];
-    o.traceb[g] = dp.traceb[a]; o.ov_mark[g] = dp.ov_mark[a]; o.score[g] = dp.score[a];
+    if (w.il_rec >= 0) {
+        const int4 r = il_out[w.il_rec + (int64_t)i * 64];       // {score, traceb | (ov_mark + 1) << 28 or -1, position of the traceb node}
+        o.traceb[g] = dpw_tag_index(r.z); o.ov_mark[g] = (int8_t)dpw_tag_ov(r.z); o.score[g] = __hiloint2double(r.y, r.x);
+    } else { o.traceb[g] = dp.traceb[a]; o.ov_mark[g] = dp.ov_mark[a]; o.score[g] = dp.score[a]; }
     o.edge[g] = ca.edge[f]; o.cscore[g] = ca.cscore[f]; o.sscore[g] = ca.sscore[f]; o.rscore[g] = ca.rscore[f];
     o.uscore[g] = ca.uscore[f]; o.tscore[g] = ca.tscore[f]; o.mot_score[g] = ca.mot_score[f]; o.mot_ndx[g] = ca.mot_ndx[f];
     o.rbs[2 * g] = ca.rbs[2 * f]; o.rbs[2 * g + 1] = ca.rbs[2 * f + 1];
@@ -1364,6 +1368,20 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             DEVBUF(w0, double, "dpw_cs", dp_cap) DEVBUF(w1, DpwExt, "dpw_ext", dp_cap) DEVBUF(w2, double, "dpw_sfxv", dp_cap) DEVBUF(w3, int32_t, "dpw_sfxi", dp_cap)
             wbuf = DpwBuffers{w0, w1, w2, w3};
         }
+        // very many chains: one LANE each (dp_lane.hip), on the same records; the results stay in its interleaved layout
+        const bool use_lane = use_wave && pga_dp_use_lane(NCH);
+        DplPlan lane_plan;
+        DplDev lane_dev{};
+        if (use_lane) {
+            pga_dpl_plan(chains.data(), NCH, lane_plan);
+            DEVBUF(l0, int32_t, "dpl_lane_chain", lane_plan.lane_chain.size()) DEVBUF(l1, int64_t, "dpl_wave_base", lane_plan.wave_base.size())
+            DEVBUF(l2, int32_t, "dpl_wave_steps", lane_plan.wave_steps.size())
+            DEVBUF(l3, int4, "dpl_inA", lane_plan.records + 64) DEVBUF(l4, int4, "dpl_inB", lane_plan.records + 64) DEVBUF(l5, int4, "dpl_out", lane_plan.records + 64)
+            HT(c, hipMemcpyAsync(l0, lane_plan.lane_chain.data(), sizeof(int32_t) * lane_plan.lane_chain.size(), hipMemcpyHostToDevice, st));
+            HT(c, hipMemcpyAsync(l1, lane_plan.wave_base.data(), sizeof(int64_t) * lane_plan.wave_base.size(), hipMemcpyHostToDevice, st));
+            HT(c, hipMemcpyAsync(l2, lane_plan.wave_steps.data(), sizeof(int32_t) * lane_plan.wave_steps.size(), hipMemcpyHostToDevice, st));
+            lane_dev = DplDev{l0, l1, l2, l3, l4, l5, lane_plan.n_waves, lane_plan.max_steps};
+        }
         DpSegDev seg_dev{};
         if (segmented) {
             DEVBUF(seg_arena, char, "dp_seg_arena", pga_dp_seg_bytes(seg_plan, NCH, tot_chain_nodes));
@@ -1373,7 +1391,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         // start order of the wave-batch scorer: longest chains first (counting sort on nodes / 64 = walk batches)
         int32_t* d_dp_order = nullptr;
         std::vector<int32_t> dp_order;
-        if (use_wave && NCH > 1 && !getenv("PGA_DP_NO_ORDER")) {
+        if (use_wave && !pga_dp_use_lane(NCH) && NCH > 1 && !getenv("PGA_DP_NO_ORDER")) {
             std::vector<int32_t> lens((size_t)NCH);
             for (int k = 0; k < NCH; k++) lens[(size_t)k] = chains[k].n;
             dp_order.resize((size_t)NCH);
@@ -1501,7 +1519,8 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         }
         // one DP launch over the chains of every group: chains are independent, the more in flight the better
         HT(c, hipEventRecord(f->e_dp0[0], st));
-        if (use_wave) pga_launch_dp_wave(d_chains, NCH, wgroups, c->d_model_const, dp, wbuf, st, d_dp_order);
+        if (use_lane) pga_launch_dp_lane(d_chains, wgroups, c->d_model_const, dp, wbuf, lane_dev, st);
+        else if (use_wave) pga_launch_dp_wave(d_chains, NCH, wgroups, c->d_model_const, dp, wbuf, st, d_dp_order);
         else pga_launch_dp(d_chains, NCH, c->d_model_const, dp, 1, st, segmented ? &seg_dev : nullptr);
         HT(c, hipEventRecord(f->e_dp1[0], st));
         HT(c, hipMemcpyAsync(h_maxidx, dp.max_index, sizeof(int32_t) * NCH, hipMemcpyDeviceToHost, st));
@@ -1591,7 +1610,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                 const int k = win_chain[i];
                 if (k < 0 || (P.meta ? f->model_group[chains[k].model] : 0) != g) continue;
                 out_off[i] = out_nodes;
-                wg[g].push_back(WinDesc{out_nodes, chains[k].off, fin_off[i], chains[k].topo_off, chains[k].n, 0});
+                wg[g].push_back(WinDesc{out_nodes, chains[k].off, fin_off[i], chains[k].topo_off, chains[k].n, 0, use_lane ? lane_plan.chain_rec[(size_t)k] : -1});
                 out_nodes += chains[k].n;
             }
         }
@@ -1632,7 +1651,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                 HT(c, hipMemcpyAsync(d_win + k0, wg[g].data(), sizeof(WinDesc) * wg[g].size(), hipMemcpyHostToDevice, st));
                 const int64_t nn = w_o0[g + 1] - w_o0[g];
                 if (nn > 0)
-                    hipLaunchKernelGGL(k_gather_winners, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, d_win + k0, (int)wg[g].size(), w_o0[g], nn, ga[g], ca, dp, o);
+                    hipLaunchKernelGGL(k_gather_winners, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, d_win + k0, (int)wg[g].size(), w_o0[g], nn, ga[g], ca, dp, o, (const int4*)lane_dev.out);
                 k0 += wg[g].size();
             }
         }

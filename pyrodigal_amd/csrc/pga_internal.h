@@ -142,6 +142,28 @@ void pga_launch_dpw_chain(const ChainDesc* d_chains, int n_chains, int64_t node_
 void pga_launch_dp_wave(const ChainDesc* d_chains, int n_chains, const DpwGroupPtrs& groups, const ModelConst* d_models, DpBuffers buf,
                         const DpwBuffers& wb, hipStream_t st, const int32_t* d_order = nullptr);
 
+// ---- lane-per-chain connection scoring for launches with very many chains (dp_lane.hip, dpl_core.h) ----
+// 64 chains to a wavefront, one lane each; the records of a wave are interleaved (node t of lane l at wave_base + 64 t + l)
+struct DplPlan {        // host side
+    std::vector<int32_t> lane_chain;    // [n_waves][64]: chain of every lane, -1 = none
+    std::vector<int64_t> wave_base;     // [n_waves + 1]: first record of the wave
+    std::vector<int32_t> wave_steps;    // [n_waves]: nodes of its longest chain
+    std::vector<int64_t> chain_rec;     // [n_chains]: record of node 0 of the chain (node i at chain_rec + 64 i)
+    int64_t records = 0;
+    int n_waves = 0, max_steps = 0;
+};
+struct DplDev { const int32_t* lane_chain; const int64_t* wave_base; const int32_t* wave_steps; int4* inA; int4* inB; int4* out; int n_waves, max_steps; };
+// which connection scorer a final-pass launch uses: lane-per-chain when there are chains enough to fill the chip that way
+// (PGA_DP_KERNEL=lane forces it, any other value of PGA_DP_KERNEL or PGA_DP_LANE=0 rules it out)
+bool pga_dp_use_lane(int n_chains);
+void pga_dpl_plan(const ChainDesc* h_chains, int n_chains, DplPlan& plan);
+// input records from the topology arrays + wb.cs, then the walk; results: the interleaved records L.out and buf.max_index / max_score / ipath
+void pga_launch_dp_lane(const ChainDesc* d_chains, const DpwGroupPtrs& groups, const ModelConst* d_models, DpBuffers buf, const DpwBuffers& wb,
+                        const DplDev& L, hipStream_t st);
+// buf.score / traceb / ov_mark / tbn of chains[0..n_chains) (contiguous in `off` from node_begin) from the interleaved records
+void pga_launch_dpl_unpack(const ChainDesc* d_chains, int n_chains, const int64_t* d_chain_rec, int64_t node_begin, int64_t total, const DplDev& L,
+                           DpBuffers buf, hipStream_t st);
+
 // kernel launchers (dp.hip)
 // chains[0..n_chains) must be contiguous in `off`; node_begin = chains[0].off, total_nodes = their node count
 void pga_launch_dp_prepare(const ChainDesc* d_chains, int n_chains, int64_t node_begin, int64_t total_nodes,

@@ -13,26 +13,26 @@
 namespace {
 
 struct HostX {
-    DplEnt r5[DPL_R5_RING], f3[DPL_F3_RING];
+    DplEnt r5[DPL_R5_RING], f3[DPL_F3_RING]; int f3t[DPL_F3_RING]; DplCand cand[3][DPL_CAND];
     const uint8_t* kf_; const int32_t* ndx_; const int32_t* q2_; const int32_t* tbn_; const int32_t* tb_; const double* score_;
     int64_t* stats;
     DplEnt r5_get(int s) const { return r5[s]; }
     void r5_put(int s, const DplEnt& e) { r5[s] = e; }
     DplEnt f3_get(int s) const { return f3[s]; }
     void f3_put(int s, const DplEnt& e) { f3[s] = e; }
-    int kf(int j) const { return kf_[j]; }
-    int ndx(int j) const { stats[2]++; return ndx_[j]; }
-    int q2(int j) const { return q2_[j]; }
-    int tbn(int j) const { return tbn_[j]; }
-    int traceb(int j) const { return tb_[j]; }
-    double score(int j) const { return score_[j]; }
-    void note(int k) { stats[k]++; }
+    int f3t_get(int s) const { return f3t[s]; }
+    void f3t_put(int s, int v) { f3t[s] = v; }
+    DplCand cand_get(int f, int k) const { stats[3]++; return cand[f][k]; }
+    void cand_put(int f, int k, const DplCand& c) { cand[f][k] = c; }
+    DplFin fin(int j) const { stats[2]++; return DplFin{ndx_[j], q2_[j], kf_[j], tbn_[j], tb_[j], score_[j]}; }
+    void note(int k) { stats[k == 2 ? 6 : k]++; }
 };
 
 }  // namespace
 
 // stats: [0] gene begins that went through the window scan, [1] gene begins that read their near gene ends back after a ring overflow, [2] finished nodes read back
-// from memory, [3] ring entries evaluated, [4] most reverse starts in the ring, [5] most forward stops in the ring
+// from memory, [3] candidate-list entries evaluated, [4] most reverse starts in the ring, [5] most forward stops in the ring, [6] reverse targets
+// that walked their chain of overlap candidates in memory (list not applicable or overflowed)
 extern "C" int dpl_model_run(int n, const int32_t* ndx, const int32_t* stop_val, const uint8_t* type, const int8_t* strand,
                              const double* cscore, const double* sscore, const double* rscore, const double* uscore,
                              const int32_t* star_ptr, double st_wt, double* score, int32_t* traceb, int8_t* ov_mark,

@@ -117,9 +117,10 @@ def test_training_pass_is_rejected_loudly(ctx):
         ctx.score_connections([0], [0], [0], [1], [0.0], [0.0], [0.0], [0.0], np.zeros((1, 3)), 4.35, final=False)
 
 
-@pytest.mark.parametrize("variant", ["wave", "tree1", "tree3", "scan1", "scan4", "scan16"])
+@pytest.mark.parametrize("variant", ["wave", "lane", "tree1", "tree3", "scan1", "scan4", "scan16"])
 def test_dp_kernel_variants_agree_with_oracle(ctx, variant, monkeypatch):
-    # wave = the wave-batch kernel of launches with many chains (dp_wave.hip); tree3 = the chain kernel of few long chains;
+    # wave = the wave-batch kernel of launches with many chains (dp_wave.hip); lane = the lane-per-chain kernel of launches with very
+    # many chains (dp_lane.hip); tree3 = the chain kernel of few long chains;
     # tree1 = its one-wave form; PGA_DP_KERNEL=scan selects the window-scanning kernels with 1, 4 or 16 wavefronts per chain,
     # kept as an independent cross-check
     if variant.startswith("scan"):
@@ -143,18 +144,21 @@ def test_dp_kernel_variants_agree_with_oracle(ctx, variant, monkeypatch):
     ("GCF_001457455.1_NCTC11397_genomic", "GCF_001457455.1_NCTC11397_genomic.tinf_closed.bin.gz", True),
     ("KK037166", "GCF_001457455.1_NCTC11397_genomic_100kb.tinf_closed.bin.gz", False),
 ])
-def test_wave_kernel_on_reference_fixtures(ctx, name, model_file, closed, monkeypatch):
-    # the kernel of many-chain launches, forced onto single chains: short contigs, and the full genome, whose 153 296 nodes
-    # slide the 1000-node window over 2400 blocks (suffix maxima, both block-range ends) and hit the giant-ORF windows
-    monkeypatch.setenv("PGA_DP_KERNEL", "wave")
+@pytest.mark.parametrize("kernel", ["wave", "lane"])
+def test_wave_kernel_on_reference_fixtures(ctx, name, model_file, closed, kernel, monkeypatch):
+    # the kernels of many-chain launches, forced onto single chains: short contigs, and the full genome, whose 153 296 nodes
+    # slide the 1000-node window over 2400 blocks (suffix maxima, both block-range ends; the lane kernel's running maxima against
+    # the window) and hit the giant-ORF windows
+    monkeypatch.setenv("PGA_DP_KERNEL", kernel)
     seq = read_fasta(name + ".fna.gz")[0][1]
     tinf = orc.Training.load(golden_path(model_file))
     for is_meta in (False, True):
         check(ctx, seq, tinf, closed=closed, is_meta=is_meta)
 
 
-def test_wave_kernel_on_synthetic_and_gene_dense_input(ctx, monkeypatch):
-    monkeypatch.setenv("PGA_DP_KERNEL", "wave")
+@pytest.mark.parametrize("kernel", ["wave", "lane"])
+def test_wave_kernel_on_synthetic_and_gene_dense_input(ctx, kernel, monkeypatch):
+    monkeypatch.setenv("PGA_DP_KERNEL", kernel)
     tinf = orc.Training.load(golden_path("SRR492066.training.bin.gz"))
     for k, (L, gc) in enumerate([(130, 0.45), (700, 0.5), (1500, 0.6), (20_000, 0.3), (20_000, 0.7), (64_000, 0.55), (200_000, 0.66)]):
         seq = synthetic_contig(L, gc, 7700 + k)

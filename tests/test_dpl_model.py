@@ -39,7 +39,7 @@ def model():
 
 @pytest.fixture(scope="module")
 def tiny_rings():
-    return build("_tiny", ["-DDPL_R5_RING=2", "-DDPL_F3_RING=1"])
+    return build("_tiny", ["-DDPL_R5_RING=2", "-DDPL_F3_RING=1", "-DDPL_CAND=1"])
 
 
 def run_model(L, nodes, st_wt):
