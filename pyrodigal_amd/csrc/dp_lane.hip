@@ -29,9 +29,20 @@
 
 namespace {
 
+// (2 - d / 60) * 0.15 for d = 0 .. 60, folded at compile time with the host's double arithmetic: times st_wt it is ModelConst::igm[d]
+// bit for bit (same operations in the same order, ref: _connection.h:73-75), without a per-model table in memory
+struct DplT2 { double v[64]; };
+constexpr DplT2 dpl_make_t2() {
+    DplT2 t{};
+    for (int d = 0; d <= DPW_OPER_DIST; d++) t.v[d] = (2.0 - ((double)d / DPW_OPER_DIST)) * 0.15;
+    return t;
+}
+__constant__ DplT2 c_dpl_t2 = dpl_make_t2();
+
 struct LaneX {
     int4 (*r5)[64]; int4 (*f3)[64]; int (*f3t)[64]; int4 (*cand)[64]; int (*candt)[64];
     const int4* A; const int4* O;      // this lane's column of the interleaved records: node j at [64 j]
+    const double* t2; double st_wt;
     int lane;
     __device__ __forceinline__ DplEnt r5_get(const int s) const { const int4 v = r5[s][lane]; return DplEnt{__hiloint2double(v.y, v.x), v.z, v.w}; }
     __device__ __forceinline__ void r5_put(const int s, const DplEnt& e) { r5[s][lane] = make_int4(__double2loint(e.score), __double2hiint(e.score), e.ndx, e.idx); }
@@ -51,6 +62,7 @@ struct LaneX {
         const int4 a = A[(int64_t)j * 64], o = O[(int64_t)j * 64];
         return DplFin{a.x, a.z, a.w, o.w, dpw_tag_index(o.z), __hiloint2double(o.y, o.x)};
     }
+    __device__ __forceinline__ double igm(const int d) const { return t2[d] * st_wt; }
     __device__ __forceinline__ void note(int) const {}
 };
 
@@ -110,6 +122,7 @@ k_dp_lane(const DplDev L, const ChainDesc* __restrict__ chains, const DpwExt* __
     __shared__ int s_f3t[DPL_F3_RING][64];
     __shared__ int4 s_cand[3 * DPL_CAND][64];
     __shared__ int s_candt[3 * DPL_CAND][64];
+    __shared__ double s_t2[64];
     const int w = blockIdx.x, lane = threadIdx.x;
     const int chain = L.lane_chain[(int64_t)w * 64 + lane];
     const bool have = chain >= 0;
@@ -124,7 +137,9 @@ k_dp_lane(const DplDev L, const ChainDesc* __restrict__ chains, const DpwExt* __
     const DpwExt* ext = g_ext + cd.off;
     const ModelConst* mc = &models[have ? cd.model : 0];
     const DpwModel M{mc->st_wt, mc->negc, mc->igm};
-    LaneX x{s_r5, s_f3, s_f3t, s_cand, s_candt, A, O, lane};
+    s_t2[lane] = c_dpl_t2.v[lane];
+    __syncthreads();
+    LaneX x{s_r5, s_f3, s_f3t, s_cand, s_candt, A, O, s_t2, mc->st_wt, lane};
     DplState S;
     dpl_init(S);
 

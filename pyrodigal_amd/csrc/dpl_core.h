@@ -59,6 +59,7 @@ struct DplState {
     DplMax r5_all;              // a over every reached reverse start so far
     DplMax r5_far, f3_far;      // a over the reverse starts / forward stops that left their ring (more than 180 bases behind)
     int r5_head, r5_cnt, f3_head, f3_cnt;      // rings: the last `cnt` entries pushed, newest at head - 1 (slots modulo the ring size)
+    int r5_old, f3_old;         // position of the oldest entry of each ring (INT_MAX: empty): the fold test without a read
     int r5_ovf, f3_ovf;         // an entry left its ring early: gene begins at positions <= this go through the scan
     int cn;                     // per reverse frame f: bits 4f .. 4f+2 = forward stops in its candidate list, bit 4f+3 = the list is incomplete
     // forward frames: best start / operon offer since the last forward stop of the frame
@@ -73,6 +74,7 @@ DPW_HD void dpl_init(DplState& S) {
     S.r5_all = DplMax{NI, -1, -1}; S.r5_far = DplMax{NI, -1, -1}; S.f3_far = DplMax{NI, -1, -1};
     S.r5_head = S.r5_cnt = S.f3_head = S.f3_cnt = 0;
     S.r5_ovf = S.f3_ovf = INT_MIN;
+    S.r5_old = S.f3_old = INT_MAX;
     S.cn = 0;
     S.rv0 = S.rv1 = S.rv2 = NI; S.ri0 = S.ri1 = S.ri2 = -1; S.rn0 = S.rn1 = S.rn2 = -1;
     S.l3v0 = S.l3v1 = S.l3v2 = 0.0; S.l3i0 = S.l3i1 = S.l3i2 = -1; S.l3s0 = S.l3s1 = S.l3s2 = 0; S.l3n0 = S.l3n1 = S.l3n2 = 0;
@@ -83,6 +85,7 @@ DPW_HD void dpl_init(DplState& S) {
 //   DplEnt r5_get(slot) / r5_put(slot, e) / f3_get / f3_put      the lane's rings
 //   int    f3t_get(slot) / f3t_put(slot, tbn)                   position of the traceb node of the forward stops in the ring
 //   DplCand cand_get(f, k) / cand_put(f, k, c)                  the candidate list of reverse frame f
+//   double igm(d)       the intergenic term at distance 0 <= d <= OPER_DIST: (2 - d / 60) * 0.15 * st_wt (ModelConst::igm)
 //   DplFin fin(j)       a FINISHED node j < i of this chain, read back from memory (topology + results in one go)
 //   void   note(k)      diagnostics of the host model (0: a window scan, 1: near gene ends read back after a ring overflow,
 //                       2: a chain of overlap candidates walked in memory)
@@ -114,21 +117,29 @@ DPW_HD void dpl_rescan(DplState& S, const DpwT& T, const DpwModel& M, X& x, DpwB
 DPW_HD double dpl_sel3(const int k, const double a, const double b, const double c) { return k == 0 ? a : (k == 1 ? b : c); }
 DPW_HD int dpl_sel3i(const int k, const int a, const int b, const int c) { return k == 0 ? a : (k == 1 ? b : c); }
 
-// A reached gene end within 180 bases of a gene begin, as one pair.  A forward stop towards a reverse stop is the plain connection
-// only (ref: _connection.h:288-336 with no overlapping start taken): the candidates that go through an overlapping start of the
-// target need the position of the source's own traceb node and are met on the chains of candidates, with a larger value.
-DPW_HD void dpl_near(DpwBest& B, const DpwT& T, const DpwModel& M, const bool r3, const int kind, const DplEnt e) {
-    if (kind == 1 && r3) {
-        const bool ok = (e.idx >= T.lo) & (e.idx < T.i) & (e.ndx + 2 < T.ndx - 2);
-        dpw_take(B, ok, e.score + M.negc, e.idx, -1, e.ndx);
-        return;
-    }
-    DpwS s;
-    s.j = e.idx; s.kind = kind; s.frame = 0; s.ndx = e.ndx; s.stop_val = 0; s.vm = 0; s.tbn = 0 /* reached */;
-    s.score = e.score; s.cs = 0.0; s.x0 = s.x1 = s.x2 = 0.0;
-    bool ok; double w; int mf;
-    dpw_pair(s, T, M, ok, w, mf);
-    dpw_take(B, ok, s.score + w, s.j, mf, s.ndx);
+// Lexicographic take without branches (the compiler turns it into compares and selects).
+DPW_HD void dpl_take(DpwBest& b, const bool ok, const double v, const int j, const int ov, const int n) {
+    const bool better = ok & ((v > b.val) | ((v == b.val) & (j > b.tb)));
+    b.val = better ? v : b.val; b.tb = better ? j : b.tb; b.ov = better ? ov : b.ov; b.tbn = better ? n : b.tbn;
+}
+// the intergenic term of two same-strand nodes d bases apart, 0 <= d <= 3 * OPER_DIST (ref: _connection.h:52-78 with the nodes
+// neither overlapping nor touching): the table value up to OPER_DIST, nothing beyond
+template <class X>
+DPW_HD double dpl_igm_near(X& x, const int d) { return d <= DPW_OPER_DIST ? x.igm(d) : 0.0; }
+
+// A reached gene end within 180 bases of a gene begin, as one pair (what dpw_pair gives for these kinds, spelled out):
+//   forward stop -> forward start (ref: :117-124)   ok: s + 2 < t       w: the distance term
+//   reverse start -> reverse stop (ref: :337-342)   ok: s < t - 2       w: the distance term
+//   forward stop -> reverse stop  (ref: :288-336)   ok: s + 2 < t - 2   w: -0.15 st_wt -- the plain connection only: the candidates
+//       that go through an overlapping start of the target need the position of the source's own traceb node and are met on
+//       the lists of candidates, with a larger value
+// `same`: source and target on the same strand (the first two); e.ndx >= T.ndx - 180 for every entry of a ring.
+template <class X>
+DPW_HD void dpl_near(DpwBest& B, const DpwT& T, const DpwModel& M, X& x, const bool same, const DplEnt e) {
+    const int d = T.ndx - e.ndx;
+    const bool ok = (e.idx >= T.lo) & (d > (same ? 2 : 4));
+    const double w = same ? (d > DPL_NEAR ? M.negc : dpl_igm_near(x, d < 0 ? 0 : d)) : M.negc;
+    dpl_take(B, ok, e.score + w, e.idx, -1, e.ndx);
 }
 
 // a forward stop met on a chain of candidates (ref: _connection.h:238-254, 296-325), as one pair
@@ -139,6 +150,35 @@ DPW_HD void dpl_f3_candidate(DpwBest& B, const DpwT& T, const DpwModel& M, const
     bool ok; double w; int mf;
     dpw_pair(s, T, M, ok, w, mf);
     dpw_take(B, ok, s.score + w, j, mf, r.ndx);
+}
+
+// A reached forward stop of a candidate list against a reverse start (ref: _connection.h:238-254; what dpw_pair gives, spelled out)
+DPW_HD void dpl_cand_r5(DpwBest& B, const DpwT& T, const DplCand& c) {
+    const int rel = c.ndx - T.stop_val;
+    const bool ok = (c.idx >= T.lo) & (rel > -4) & (rel + 5 < DPW_MAX_OPP_OVLP) & (rel < T.ndx - c.ndx + 3) & (rel < T.stop_val - 3 - c.tbn);
+    dpl_take(B, ok, c.score + T.csd, c.idx, -1, c.ndx);
+}
+// ... and against a reverse stop, through the best admissible overlapping start (ref: :288-336): the first q with the largest x
+DPW_HD void dpl_cand_r3(DpwBest& B, const DpwT& T, const DpwModel& M, const DplCand& c) {
+    const int left = c.ndx + 2;
+    const bool ok = (c.idx >= T.lo) & (left < T.ndx - 2);
+    double maxval = 0.0; int mf = -1;
+    {
+        const int ovlp = left - T.n3s0 + 3;
+        const bool tk = ((T.vm & 1) != 0) & (ovlp > 0) & (ovlp < DPW_MAX_OPP_OVLP) & (ovlp < T.n3n0 - left) & (ovlp < T.n3s0 - c.tbn - 2) & (T.x0 > maxval);
+        maxval = tk ? T.x0 : maxval; mf = tk ? 0 : mf;
+    }
+    {
+        const int ovlp = left - T.n3s1 + 3;
+        const bool tk = ((T.vm & 2) != 0) & (ovlp > 0) & (ovlp < DPW_MAX_OPP_OVLP) & (ovlp < T.n3n1 - left) & (ovlp < T.n3s1 - c.tbn - 2) & (T.x1 > maxval);
+        maxval = tk ? T.x1 : maxval; mf = tk ? 1 : mf;
+    }
+    {
+        const int ovlp = left - T.n3s2 + 3;
+        const bool tk = ((T.vm & 4) != 0) & (ovlp > 0) & (ovlp < DPW_MAX_OPP_OVLP) & (ovlp < T.n3n2 - left) & (ovlp < T.n3s2 - c.tbn - 2) & (T.x2 > maxval);
+        maxval = tk ? T.x2 : maxval; mf = tk ? 2 : mf;
+    }
+    dpl_take(B, ok, c.score + (mf != -1 ? maxval : M.negc), c.idx, mf, c.ndx);
 }
 
 // The forward stops that can overlap the 3' end of a reverse gene whose stop is at `stop_pos` (frame f) against target T: they lie
@@ -153,7 +193,7 @@ DPW_HD void dpl_overlap_candidates(const DplState& S, const DpwT& T, const DpwMo
     if (l3i >= 0 && l3n == stop_pos && !(c4 & 8)) {
         for (int k = 0; k < (c4 & 7); k++) {
             const DplCand c = x.cand_get(f, k);
-            dpl_f3_candidate(B, T, M, c.idx, DplFin{c.ndx, 0, 1, c.tbn, 0, c.score});
+            if (T.kind == 2) dpl_cand_r5(B, T, c); else dpl_cand_r3(B, T, M, c);
         }
         return;
     }
@@ -178,39 +218,41 @@ DPW_HD void dpl_cand_push(DplState& S, X& x, const int f, const DplCand& c) {
 
 // One node: candidates -> B, then the node's own contribution to the running structures.  `kfb`: the node's topology byte.
 // Returns through B the node's score / traceb / ov_mark / position of the traceb node.
+// Written for lanes in lock step on different kinds of node: short conditionals are selects, the per-frame state is picked and
+// written back with selects, and only the loops over ring / list entries and the rare paths (window scan, ring overflow, a
+// candidate chain walked in memory) are branches.
 template <class X>
 DPW_HD void dpl_step(DplState& S, const DpwT& T, const int kfb, const DpwModel& M, X& x, DpwBest& B) {
+    const double NI = -__builtin_huge_val();
     B.val = 0.0; B.tb = -1; B.ov = -1; B.tbn = -1;
     const int i = T.i;
     const int f = T.frame;
+    const bool k0 = T.kind == 0, k1 = T.kind == 1, k2 = T.kind == 2, k3 = T.kind == 3;
     // ---- fold the ring entries that are more than 180 bases behind this node (they are for every later node too)
     const int far_pos = T.ndx - DPL_NEAR;            // an end at a position below this is far
-    while (S.r5_cnt > 0) {
+    while (S.r5_cnt > 0 && S.r5_old < far_pos) {
         const DplEnt e = x.r5_get((S.r5_head - S.r5_cnt) & (DPL_R5_RING - 1));
-        if (e.ndx >= far_pos) break;
         dpl_max_take(S.r5_far, e.score + M.negc, e.idx, e.ndx);
         S.r5_cnt--;
+        S.r5_old = S.r5_cnt > 0 ? x.r5_get((S.r5_head - S.r5_cnt) & (DPL_R5_RING - 1)).ndx : INT_MAX;
     }
-    while (S.f3_cnt > 0) {
+    while (S.f3_cnt > 0 && S.f3_old < far_pos) {
         const DplEnt e = x.f3_get((S.f3_head - S.f3_cnt) & (DPL_F3_RING - 1));
-        if (e.ndx >= far_pos) break;
         dpl_max_take(S.f3_far, e.score + M.negc, e.idx, e.ndx);
         S.f3_cnt--;
+        S.f3_old = S.f3_cnt > 0 ? x.f3_get((S.f3_head - S.f3_cnt) & (DPL_F3_RING - 1)).ndx : INT_MAX;
     }
-    if (T.kind == 0 || T.kind == 3) {
+    // the frame's records, picked once: forward running maximum (forward stops read it), last reverse stop (reverse nodes)
+    const int l3i = dpl_sel3i(f, S.l3i0, S.l3i1, S.l3i2), l3s = dpl_sel3i(f, S.l3s0, S.l3s1, S.l3s2), l3n = dpl_sel3i(f, S.l3n0, S.l3n1, S.l3n2);
+    const double l3v = dpl_sel3(f, S.l3v0, S.l3v1, S.l3v2);
+    if (k0 | k3) {
         // ---- a gene begin: every gene end of the window
-        const bool r3 = T.kind == 3;
-        // which running maxima this target reads, and whether their argmax still lies in the window
-        bool stale = false;
-        if (!r3) {
-            if (S.r5_all.i >= 0 && S.r5_all.i < T.lo) stale = true;
-            if (S.f3_far.i >= 0 && S.f3_far.i < T.lo) stale = true;
-        } else {
-            if (S.r5_far.i >= 0 && S.r5_far.i < T.lo) stale = true;
-            if (S.f3_far.i >= 0 && S.f3_far.i < T.lo) stale = true;
-        }
+        // the running maxima this kind of target reads: a forward start every reverse start so far, a reverse stop the far ones
+        const DplMax rmax = k3 ? S.r5_far : S.r5_all;
+        // is their argmax still inside the window?
+        const bool stale = ((rmax.i >= 0) & (rmax.i < T.lo)) | ((S.f3_far.i >= 0) & (S.f3_far.i < T.lo));
         // an entry that left its ring early may still be near: then the near gene ends are read back from memory instead
-        const bool ovf = r3 ? (T.ndx <= S.r5_ovf || T.ndx <= S.f3_ovf) : (T.ndx <= S.f3_ovf);
+        const bool ovf = (T.ndx <= S.f3_ovf) | (k3 & (T.ndx <= S.r5_ovf));
         if (stale) {
             x.note(0);
             const int r5_first = S.r5_cnt > 0 ? x.r5_get((S.r5_head - S.r5_cnt) & (DPL_R5_RING - 1)).idx : i;
@@ -218,9 +260,8 @@ DPW_HD void dpl_step(DplState& S, const DpwT& T, const int kfb, const DpwModel& 
             dpl_rescan(S, T, M, x, B, r5_first, f3_first);
         } else {
             // far gene ends: the running maxima (the weight is the constant -0.15 st_wt)
-            if (!r3) { if (S.r5_all.i >= 0) dpw_take(B, true, S.r5_all.v, S.r5_all.i, -1, S.r5_all.n); }
-            else     { if (S.r5_far.i >= 0) dpw_take(B, true, S.r5_far.v, S.r5_far.i, -1, S.r5_far.n); }
-            if (S.f3_far.i >= 0) dpw_take(B, true, S.f3_far.v, S.f3_far.i, -1, S.f3_far.n);
+            dpl_take(B, rmax.i >= 0, rmax.v, rmax.i, -1, rmax.n);
+            dpl_take(B, S.f3_far.i >= 0, S.f3_far.v, S.f3_far.i, -1, S.f3_far.n);
             // near gene ends, pair by pair: forward stops for both kinds of gene begin, reverse starts for a reverse stop
             if (ovf) {
                 x.note(1);
@@ -228,86 +269,100 @@ DPW_HD void dpl_step(DplState& S, const DpwT& T, const int kfb, const DpwModel& 
                     const DplFin r = x.fin(j);
                     if (r.ndx < far_pos) break;
                     const int k = DPW_KIND(r.kf);
-                    if (!(k == 1 || (k == 2 && r3)) || r.tb == -1) continue;
-                    dpl_near(B, T, M, r3, k, DplEnt{r.score, r.ndx, j});
+                    if (!(k == 1 || (k == 2 && k3)) || r.tb == -1) continue;
+                    dpl_near(B, T, M, x, (k == 1) != k3, DplEnt{r.score, r.ndx, j});
                 }
             } else {
-                for (int k = 0; k < S.f3_cnt; k++) dpl_near(B, T, M, r3, 1, x.f3_get((S.f3_head - 1 - k) & (DPL_F3_RING - 1)));
-                if (r3) for (int k = 0; k < S.r5_cnt; k++) dpl_near(B, T, M, r3, 2, x.r5_get((S.r5_head - 1 - k) & (DPL_R5_RING - 1)));
+                for (int k = 0; k < S.f3_cnt; k++) dpl_near(B, T, M, x, k0, x.f3_get((S.f3_head - 1 - k) & (DPL_F3_RING - 1)));
+                const int nr5 = k3 ? S.r5_cnt : 0;
+                for (int k = 0; k < nr5; k++) dpl_near(B, T, M, x, true, x.r5_get((S.r5_head - 1 - k) & (DPL_R5_RING - 1)));
             }
         }
-        if (r3) {
+        if (k3) {
             // the reverse stop whose ORF covers this one, per frame of an overlapping start: an operon (ref: :345-356)
-            if ((T.vm & 1) && S.l3i0 >= 0 && S.l3i0 >= T.lo && S.l3s0 > T.ndx) dpw_take(B, true, S.l3v0 + T.x0, S.l3i0, -1, S.l3n0);
-            if ((T.vm & 2) && S.l3i1 >= 0 && S.l3i1 >= T.lo && S.l3s1 > T.ndx) dpw_take(B, true, S.l3v1 + T.x1, S.l3i1, -1, S.l3n1);
-            if ((T.vm & 4) && S.l3i2 >= 0 && S.l3i2 >= T.lo && S.l3s2 > T.ndx) dpw_take(B, true, S.l3v2 + T.x2, S.l3i2, -1, S.l3n2);
+            dpl_take(B, ((T.vm & 1) != 0) & (S.l3i0 >= 0) & (S.l3i0 >= T.lo) & (S.l3s0 > T.ndx), S.l3v0 + T.x0, S.l3i0, -1, S.l3n0);
+            dpl_take(B, ((T.vm & 2) != 0) & (S.l3i1 >= 0) & (S.l3i1 >= T.lo) & (S.l3s1 > T.ndx), S.l3v1 + T.x1, S.l3i1, -1, S.l3n1);
+            dpl_take(B, ((T.vm & 4) != 0) & (S.l3i2 >= 0) & (S.l3i2 >= T.lo) & (S.l3s2 > T.ndx), S.l3v2 + T.x2, S.l3i2, -1, S.l3n2);
             // forward stops that overlap the 3' end of the gene of an overlapping start (the start of frame q has its stop at n3s)
             if (T.vm & 1) dpl_overlap_candidates(S, T, M, x, B, 0, T.n3s0, T.cq0);
             if (T.vm & 2) dpl_overlap_candidates(S, T, M, x, B, 1, T.n3s1, T.cq1);
             if (T.vm & 4) dpl_overlap_candidates(S, T, M, x, B, 2, T.n3s2, T.cq2);
         }
-    } else if (T.kind == 1) {
+    } else if (k1) {
         // ---- a forward stop: the best start / operon partner of its ORF (ref: :166-188)
         const int ci = dpl_sel3i(f, S.ri0, S.ri1, S.ri2);
-        if (ci >= 0) dpw_take(B, true, dpl_sel3(f, S.rv0, S.rv1, S.rv2), ci, -1, dpl_sel3i(f, S.rn0, S.rn1, S.rn2));
+        dpl_take(B, ci >= 0, dpl_sel3(f, S.rv0, S.rv1, S.rv2), ci, -1, dpl_sel3i(f, S.rn0, S.rn1, S.rn2));
     } else {
         // ---- a reverse start: its own stop (ref: :228-235) ...
-        const int j = dpl_sel3i(f, S.l3i0, S.l3i1, S.l3i2);
-        if (j >= 0 && j >= T.lo && dpl_sel3i(f, S.l3s0, S.l3s1, S.l3s2) > T.ndx)
-            dpw_take(B, true, dpl_sel3(f, S.l3v0, S.l3v1, S.l3v2) + T.cs, j, -1, dpl_sel3i(f, S.l3n0, S.l3n1, S.l3n2));
+        dpl_take(B, (l3i >= 0) & (l3i >= T.lo) & (l3s > T.ndx), l3v + T.cs, l3i, -1, l3n);
         // ... and the forward stops overlapping its gene's 3' end (ref: :238-254)
         dpl_overlap_candidates(S, T, M, x, B, f, T.stop_val, T.q2);
     }
 
     // ---- the node is final: what it leaves for later nodes
     const bool reached = B.tb != -1;
-    if ((T.kind == 1 || T.kind == 2) && B.val >= S.end_best) { S.end_best = B.val; S.end_idx = i; S.end_tb = B.tb; }
-    if (T.kind == 0) {
+    const bool new_end = (k1 | k2) & (B.val >= S.end_best);
+    S.end_best = new_end ? B.val : S.end_best; S.end_idx = new_end ? i : S.end_idx; S.end_tb = new_end ? B.tb : S.end_tb;
+    // forward frames: a forward start offers score + cs to the stop of its ORF; a forward stop restarts the running maximum of its
+    // own frame and, when reached, offers score + x to the frames whose next stop's ORF holds it (operon partners)
+    if (k0 | k1) {
         const double g = B.val + T.cs;
-        if (f == 0) { if (g >= S.rv0) { S.rv0 = g; S.ri0 = i; S.rn0 = T.ndx; } }
-        else if (f == 1) { if (g >= S.rv1) { S.rv1 = g; S.ri1 = i; S.rn1 = T.ndx; } }
-        else { if (g >= S.rv2) { S.rv2 = g; S.ri2 = i; S.rn2 = T.ndx; } }
-    } else if (T.kind == 1) {
-        const double NI = -__builtin_huge_val();
-        // the running maximum of its own frame restarts; its operon offers go to the frames whose next stop's ORF holds it
-        if (f == 0) { S.rv0 = NI; S.ri0 = -1; S.rn0 = -1; } else if (f == 1) { S.rv1 = NI; S.ri1 = -1; S.rn1 = -1; } else { S.rv2 = NI; S.ri2 = -1; S.rn2 = -1; }
-        if (reached) {
-            if ((T.vm & 1) && DPW_INORF(kfb, 0)) { const double v = B.val + T.x0; if (v >= S.rv0) { S.rv0 = v; S.ri0 = i; S.rn0 = T.ndx; } }
-            if ((T.vm & 2) && DPW_INORF(kfb, 1)) { const double v = B.val + T.x1; if (v >= S.rv1) { S.rv1 = v; S.ri1 = i; S.rn1 = T.ndx; } }
-            if ((T.vm & 4) && DPW_INORF(kfb, 2)) { const double v = B.val + T.x2; if (v >= S.rv2) { S.rv2 = v; S.ri2 = i; S.rn2 = T.ndx; } }
-            if (S.f3_cnt == DPL_F3_RING) {
-                // the ring is full of forward stops that are still near: its oldest entry is folded early, and the gene begins it is
-                // still near to go through the scan
-                const DplEnt e = x.f3_get((S.f3_head - S.f3_cnt) & (DPL_F3_RING - 1));
-                dpl_max_take(S.f3_far, e.score + M.negc, e.idx, e.ndx);
-                if (e.ndx + DPL_NEAR > S.f3_ovf) S.f3_ovf = e.ndx + DPL_NEAR;
-                S.f3_cnt--;
-            }
-            x.f3_put(S.f3_head & (DPL_F3_RING - 1), DplEnt{B.val, T.ndx, i});
-            x.f3t_put(S.f3_head & (DPL_F3_RING - 1), B.tbn);
-            S.f3_head = (S.f3_head + 1) & (DPL_F3_RING - 1); S.f3_cnt++;
-            // it may overlap the 3' end of the reverse genes that end at the last reverse stop of a frame
-            const DplCand me{B.val, T.ndx, i, B.tbn};
-            if (S.l3i0 >= 0 && T.ndx >= S.l3n0 - 4 && T.ndx < S.l3n0 + DPW_MAX_OPP_OVLP - 5) dpl_cand_push(S, x, 0, me);
-            if (S.l3i1 >= 0 && T.ndx >= S.l3n1 - 4 && T.ndx < S.l3n1 + DPW_MAX_OPP_OVLP - 5) dpl_cand_push(S, x, 1, me);
-            if (S.l3i2 >= 0 && T.ndx >= S.l3n2 - 4 && T.ndx < S.l3n2 + DPW_MAX_OPP_OVLP - 5) dpl_cand_push(S, x, 2, me);
+        double o0 = NI, o1 = NI, o2 = NI;                   // this node's offer to each frame
+        bool z0 = false, z1 = false, z2 = false;            // restart the frame
+        if (k0) { o0 = f == 0 ? g : NI; o1 = f == 1 ? g : NI; o2 = f == 2 ? g : NI; }
+        else {
+            z0 = f == 0; z1 = f == 1; z2 = f == 2;
+            o0 = (reached & ((T.vm & 1) != 0) & (DPW_INORF(kfb, 0) != 0)) ? B.val + T.x0 : NI;
+            o1 = (reached & ((T.vm & 2) != 0) & (DPW_INORF(kfb, 1) != 0)) ? B.val + T.x1 : NI;
+            o2 = (reached & ((T.vm & 4) != 0) & (DPW_INORF(kfb, 2) != 0)) ? B.val + T.x2 : NI;
         }
-    } else if (T.kind == 2) {
-        if (reached) {
-            dpl_max_take(S.r5_all, B.val + M.negc, i, T.ndx);
-            if (S.r5_cnt == DPL_R5_RING) {
-                const DplEnt e = x.r5_get((S.r5_head - S.r5_cnt) & (DPL_R5_RING - 1));
-                dpl_max_take(S.r5_far, e.score + M.negc, e.idx, e.ndx);
-                if (e.ndx + DPL_NEAR > S.r5_ovf) S.r5_ovf = e.ndx + DPL_NEAR;
-                S.r5_cnt--;
-            }
-            x.r5_put(S.r5_head & (DPL_R5_RING - 1), DplEnt{B.val, T.ndx, i});
-            S.r5_head = (S.r5_head + 1) & (DPL_R5_RING - 1); S.r5_cnt++;
+        {   const double cur = z0 ? NI : S.rv0; const bool t = o0 > NI && o0 >= cur;      // a later node wins a tie
+            S.rv0 = t ? o0 : cur; S.ri0 = t ? i : (z0 ? -1 : S.ri0); S.rn0 = t ? T.ndx : (z0 ? -1 : S.rn0); }
+        {   const double cur = z1 ? NI : S.rv1; const bool t = o1 > NI && o1 >= cur;
+            S.rv1 = t ? o1 : cur; S.ri1 = t ? i : (z1 ? -1 : S.ri1); S.rn1 = t ? T.ndx : (z1 ? -1 : S.rn1); }
+        {   const double cur = z2 ? NI : S.rv2; const bool t = o2 > NI && o2 >= cur;
+            S.rv2 = t ? o2 : cur; S.ri2 = t ? i : (z2 ? -1 : S.ri2); S.rn2 = t ? T.ndx : (z2 ? -1 : S.rn2); }
+    }
+    if (k1 & reached) {
+        if (S.f3_cnt == DPL_F3_RING) {
+            // the ring is full of forward stops that are still near: its oldest entry is folded early, and the gene begins it is
+            // still near to read their near gene ends back from memory
+            const DplEnt e = x.f3_get((S.f3_head - S.f3_cnt) & (DPL_F3_RING - 1));
+            dpl_max_take(S.f3_far, e.score + M.negc, e.idx, e.ndx);
+            if (e.ndx + DPL_NEAR > S.f3_ovf) S.f3_ovf = e.ndx + DPL_NEAR;
+            S.f3_cnt--;
+            S.f3_old = S.f3_cnt > 0 ? x.f3_get((S.f3_head - S.f3_cnt) & (DPL_F3_RING - 1)).ndx : INT_MAX;
         }
-    } else {
-        if (f == 0) { S.l3v0 = B.val; S.l3i0 = i; S.l3s0 = T.stop_val; S.l3n0 = T.ndx; }
-        else if (f == 1) { S.l3v1 = B.val; S.l3i1 = i; S.l3s1 = T.stop_val; S.l3n1 = T.ndx; }
-        else { S.l3v2 = B.val; S.l3i2 = i; S.l3s2 = T.stop_val; S.l3n2 = T.ndx; }
+        x.f3_put(S.f3_head & (DPL_F3_RING - 1), DplEnt{B.val, T.ndx, i});
+        x.f3t_put(S.f3_head & (DPL_F3_RING - 1), B.tbn);
+        S.f3_head = (S.f3_head + 1) & (DPL_F3_RING - 1);
+        if (S.f3_cnt == 0) S.f3_old = T.ndx;
+        S.f3_cnt++;
+        // it may overlap the 3' end of the reverse genes that end at the last reverse stop of a frame
+        const DplCand me{B.val, T.ndx, i, B.tbn};
+        if (S.l3i0 >= 0 && T.ndx >= S.l3n0 - 4 && T.ndx < S.l3n0 + DPW_MAX_OPP_OVLP - 5) dpl_cand_push(S, x, 0, me);
+        if (S.l3i1 >= 0 && T.ndx >= S.l3n1 - 4 && T.ndx < S.l3n1 + DPW_MAX_OPP_OVLP - 5) dpl_cand_push(S, x, 1, me);
+        if (S.l3i2 >= 0 && T.ndx >= S.l3n2 - 4 && T.ndx < S.l3n2 + DPW_MAX_OPP_OVLP - 5) dpl_cand_push(S, x, 2, me);
+    }
+    if (k2 & reached) {
+        dpl_max_take(S.r5_all, B.val + M.negc, i, T.ndx);
+        if (S.r5_cnt == DPL_R5_RING) {
+            const DplEnt e = x.r5_get((S.r5_head - S.r5_cnt) & (DPL_R5_RING - 1));
+            dpl_max_take(S.r5_far, e.score + M.negc, e.idx, e.ndx);
+            if (e.ndx + DPL_NEAR > S.r5_ovf) S.r5_ovf = e.ndx + DPL_NEAR;
+            S.r5_cnt--;
+            S.r5_old = S.r5_cnt > 0 ? x.r5_get((S.r5_head - S.r5_cnt) & (DPL_R5_RING - 1)).ndx : INT_MAX;
+        }
+        x.r5_put(S.r5_head & (DPL_R5_RING - 1), DplEnt{B.val, T.ndx, i});
+        S.r5_head = (S.r5_head + 1) & (DPL_R5_RING - 1);
+        if (S.r5_cnt == 0) S.r5_old = T.ndx;
+        S.r5_cnt++;
+    }
+    if (k3) {
+        const bool w0 = f == 0, w1 = f == 1, w2 = f == 2;
+        S.l3v0 = w0 ? B.val : S.l3v0; S.l3i0 = w0 ? i : S.l3i0; S.l3s0 = w0 ? T.stop_val : S.l3s0; S.l3n0 = w0 ? T.ndx : S.l3n0;
+        S.l3v1 = w1 ? B.val : S.l3v1; S.l3i1 = w1 ? i : S.l3i1; S.l3s1 = w1 ? T.stop_val : S.l3s1; S.l3n1 = w1 ? T.ndx : S.l3n1;
+        S.l3v2 = w2 ? B.val : S.l3v2; S.l3i2 = w2 ? i : S.l3i2; S.l3s2 = w2 ? T.stop_val : S.l3s2; S.l3n2 = w2 ? T.ndx : S.l3n2;
         // the candidate list of the frame starts over: the reached forward stops up to four bases before this stop are in the
         // ring of forward stops (unless one of them left it early: then the list is incomplete and the chain in memory is walked)
         S.cn &= ~(15 << (4 * f));

@@ -15,7 +15,8 @@ namespace {
 struct HostX {
     DplEnt r5[DPL_R5_RING], f3[DPL_F3_RING]; int f3t[DPL_F3_RING]; DplCand cand[3][DPL_CAND];
     const uint8_t* kf_; const int32_t* ndx_; const int32_t* q2_; const int32_t* tbn_; const int32_t* tb_; const double* score_;
-    int64_t* stats;
+    int64_t* stats; const double* igm_;
+    double igm(int d) const { return igm_[d]; }
     DplEnt r5_get(int s) const { return r5[s]; }
     void r5_put(int s, const DplEnt& e) { r5[s] = e; }
     DplEnt f3_get(int s) const { return f3[s]; }
@@ -55,7 +56,7 @@ extern "C" int dpl_model_run(int n, const int32_t* ndx, const int32_t* stop_val,
     }
     HostX X;
     memset(X.r5, 0, sizeof X.r5); memset(X.f3, 0, sizeof X.f3);
-    X.kf_ = kf.data(); X.ndx_ = ndx; X.q2_ = q2.data(); X.tbn_ = tbn.data(); X.tb_ = traceb; X.score_ = score; X.stats = stats;
+    X.kf_ = kf.data(); X.ndx_ = ndx; X.q2_ = q2.data(); X.tbn_ = tbn.data(); X.tb_ = traceb; X.score_ = score; X.stats = stats; X.igm_ = igm;
     DplState S;
     dpl_init(S);
     for (int i = 0; i < n; i++) {
