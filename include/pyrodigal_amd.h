@@ -232,7 +232,14 @@ int pga_train(pga_ctx*, const pga_batch*, const pga_params*, int translation_tab
  * removed, not NUL-terminated.  The arrays are valid until the next call on the same reader; a batch ends
  * after max_records records or once max_bases bases are exceeded (0 = no limit); *n_records == 0 at end of file. */
 typedef struct pga_fasta pga_fasta;
+/* plain files are mapped and parsed by several threads; gzip files are inflated with zlib on one thread; a file in another
+ * compression format is rejected (PGA_EINVAL): decompress it into pga_fasta_open_callback */
 int         pga_fasta_open(const char* path, pga_fasta** out);
+/* The same reader over a byte stream the caller produces: read(user, buf, cap) fills up to cap bytes and returns their number,
+ * 0 at the end of the stream, negative on failure (ref: tests/fasta.py:16-57 `zopen` -- the reference sniffs bz2 / xz / lz4 / zstd
+ * and decompresses with Python modules; the Python layer here hands those decompressors in through this entry point). */
+typedef int64_t (*pga_fasta_read_fn)(void* user, char* buf, int64_t cap);
+int         pga_fasta_open_callback(pga_fasta_read_fn read, void* user, pga_fasta** out);
 int         pga_fasta_next(pga_fasta*, int64_t max_bases, int32_t max_records, int32_t* n_records,
                            const char* const** headers, const char* const** seqs, const int64_t** lens);
 const char* pga_fasta_error(const pga_fasta*);
