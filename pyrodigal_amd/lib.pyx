@@ -1335,6 +1335,8 @@ cdef class _FindRequest:
     cdef list out               # one Genes per sequence, filled in by the thread that ran the device call
     cdef object error
     cdef bint done
+    cdef object ev              # set when the result is there, or when `lead` holds a context for this caller to run the next device call
+    cdef object lead
 
 
 cdef class GeneFinder:
@@ -1362,6 +1364,7 @@ cdef class GeneFinder:
     cdef readonly dict stats    # device calls, sequences and the largest number of calls packed into one (diagnostics)
     cdef object lock            # kept for callers that serialise around a finder themselves (ref: lib.pyx:5196)
     cdef object _cv
+    cdef object _lock
     cdef list _slots
     cdef list _pending
     cdef ssize_t _num_seq
@@ -1407,7 +1410,8 @@ cdef class GeneFinder:
         self.contexts = contexts
         self.coalesce_bases = max(coalesce_bases, 1)
         self.lock = threading.Lock()
-        self._cv = threading.Condition(threading.Lock())
+        self._lock = threading.Lock()
+        self._cv = threading.Condition(self._lock)
         self._slots = [_FinderSlot() for _ in range(contexts)]
         self._pending = []
         self.stats = {"device_calls": 0, "sequences": 0, "max_calls_per_device_call": 0}
@@ -1519,37 +1523,69 @@ cdef class GeneFinder:
             return []
         cdef _FindRequest req = _FindRequest.__new__(_FindRequest)
         cdef _FindRequest r
-        cdef _FinderSlot slot
+        cdef _FinderSlot slot = None
         cdef list take
         req.seqs = seqs; req.translate = translate; req.bases = bases; req.out = None; req.error = None; req.done = False
-        cv = self._cv
-        cv.acquire()
-        try:
+        req.lead = None
+        req.ev = threading.Event()
+        lock = self._lock
+        # Either a context is free: this caller runs a device call right away, for itself and for everyone who is waiting.  Or it
+        # waits on an event of its own -- woken when its result is there, or when a context came free and it is this caller's
+        # turn to run the next device call over whatever is waiting by then (the baton goes to the oldest waiting request: one
+        # wake-up per device call, not one per waiting thread).
+        with lock:
             req.first_id = self._num_seq
             self._num_seq += len(seqs)
             self._pending.append(req)
-            while not req.done:
-                slot = self._free_slot() if self._pending else None
-                if slot is None:
-                    cv.wait()
-                    continue
-                # this caller runs the next device call: for itself and for everyone who is waiting with it
-                take = self._take_pending()
+            slot = self._free_slot()
+            if slot is not None:
                 slot.busy = True
-                cv.release()
-                try:
-                    self._run(slot, take)
-                finally:
-                    cv.acquire()
-                    slot.busy = False
-                    for r in take:
-                        r.done = True
-                    cv.notify_all()
-        finally:
-            cv.release()
+        while True:
+            if slot is None:
+                req.ev.wait()
+                if req.done:
+                    break
+                req.ev.clear()
+                with lock:
+                    slot = <_FinderSlot> req.lead        # the baton: a context reserved for this caller
+                    req.lead = None
+                if slot is None:
+                    continue
+            with lock:
+                take = self._take_pending() if self._pending else []
+            if take:
+                self._run(slot, take)
+            with lock:
+                for r in take:
+                    r.done = True
+                    if r is not req:
+                        r.ev.set()
+                self._release_slot(slot)
+            slot = None
+            if req.done:
+                break
+        if req.lead is not None:
+            # the request was served by somebody else's device call while a context was on its way to this caller: pass it on
+            with lock:
+                if req.lead is not None:
+                    slot = <_FinderSlot> req.lead
+                    req.lead = None
+                    self._release_slot(slot)
         if req.error is not None:
             raise req.error
         return req.out
+
+    cdef int _release_slot(self, _FinderSlot slot) except -1:
+        """(lock held) The context goes to the oldest waiting request that has no context yet, or back to the pool."""
+        cdef _FindRequest r
+        for r in self._pending:
+            if r.lead is None:
+                r.lead = slot
+                r.ev.set()
+                return 0
+        slot.busy = False
+        self._cv.notify_all()
+        return 0
 
     cdef int _run(self, _FinderSlot slot, list take) except -1:
         """One device call over the sequences of every request in `take`; each request gets its `Genes` (or the error)."""
@@ -1754,9 +1790,8 @@ cdef class GeneFinder:
             tinf = TrainingInfo(raw=raw)
             self.training_info = tinf
         finally:
-            with self._cv:
-                slot.busy = False
-                self._cv.notify_all()
+            with self._lock:
+                self._release_slot(slot)
         return tinf
 
 

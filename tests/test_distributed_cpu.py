@@ -47,6 +47,57 @@ def test_gather_genes_world2(tmp_path):
     assert a["cscore"][4] == 1 + 1 / 7.0
 
 
+def _worker8(rank, world, port, out_dir):
+    """One rank of the job as the 8-GPU run shards it: every rank computes the same packing of the job from (length, GC) alone, takes
+    its share, "finds" one record per contig of its share, renumbers to job-wide contig ids, and the records are gathered to rank 0."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pyrodigal_amd import _cabi, benchdata, distributed
+    lengths, gcs, _ = benchdata.config4_spec(37)                       # fewer contigs than make every rank busy at world 8 x ~5
+    lengths = np.array(lengths); lengths[::5] = 0                      # empty contigs: no work, no records
+    work = distributed.estimate_work_known(lengths, gcs, list(np.linspace(0.30, 0.70, 16)))
+    parts = distributed.pack_contigs(work, world)
+    mine = np.asarray(parts[rank], np.int32)
+    if rank == 3:
+        mine = mine[:0]                                                # a rank with nothing at all
+    local = np.repeat(np.arange(len(mine)), [0 if lengths[c] == 0 else 1 + c % 3 for c in mine]).astype(np.int32)   # ragged: 1-3 genes per contig
+    g = np.zeros(len(local), dtype=_cabi.GENE_DTYPE)
+    if len(g):
+        g["contig"] = mine[local]
+        g["begin"] = 1000 * g["contig"] + np.arange(len(g))
+        g["cscore"] = g["contig"] / 3.0
+    got = distributed.gather_genes(g, dist, dst=0)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "all.npy"), got)
+        np.save(os.path.join(out_dir, "parts.npy"), np.array([len(p) for p in parts]))
+    else:
+        assert len(got) == 0
+    allg = distributed.gather_genes(g, dist)                           # and the all-gather form
+    assert len(allg) == sum(0 if (lengths[c] == 0 or r == 3) else 1 + c % 3 for r in range(world) for c in parts[r])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pack_and_gather_world8_with_ragged_and_empty_ranks(tmp_path):
+    """SURVEY 8(e) at the scale the driver launches: 8 ranks, the packing computed identically on each, ragged record counts,
+    empty contigs, one rank with no contigs at all; rank 0 ends up with every record of the job, in rank order."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_worker8, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    a = np.load(tmp_path / "all.npy")
+    from pyrodigal_amd import benchdata, distributed
+    lengths, gcs, _ = benchdata.config4_spec(37)
+    lengths = np.array(lengths); lengths[::5] = 0
+    parts = distributed.pack_contigs(distributed.estimate_work_known(lengths, gcs, list(np.linspace(0.30, 0.70, 16))), 8)
+    want = [c for r, p in enumerate(parts) if r != 3 for c in p for _ in range(0 if lengths[c] == 0 else 1 + c % 3)]
+    assert list(a["contig"]) == want and len(want) > 20
+    assert np.array_equal(a["cscore"], a["contig"] / 3.0) and np.all(a["begin"] // 1000 == a["contig"])
+    assert sorted(c for p in parts for c in p) == list(range(37))
+
+
 def test_shard_contigs_partition():
     from pyrodigal_amd import distributed
     for world in (1, 2, 4, 8):

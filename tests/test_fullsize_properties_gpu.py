@@ -84,6 +84,12 @@ def test_config3_full_size(setup):
         assert o.find_genes_meta(bins) == res.contigs[i]["model"]
         og, gg = o.genes(), res.genes_of(i)
         assert len(og) == len(gg) and all(np.array_equal(og[k], gg[k]) for k in ("begin", "end", "start_ndx", "stop_ndx"))
+        on = o.nodes()
+        for name in ("cscore", "sscore", "rscore", "uscore", "tscore", "mot_score"):      # the full-size run's own node scores, as bit patterns
+            assert np.array_equal(gg[name].view(np.uint64), on[name][gg["start_ndx"]].view(np.uint64)), (i, name)
+    from tests.test_finder_gpu import compare_contig
+    nodes_run = ctx.find_genes_batch([seqs[i] for i in pick[:12]], meta=True, want_nodes=True)
+    assert sum(compare_contig(nodes_run, k, seqs[i], orc.Oracle(seqs[i]), bins, meta=True) for k, i in enumerate(pick[:12])) > 100
 
 
 def test_config2_full_size(setup):
@@ -173,6 +179,17 @@ def test_config4_one_gpu_share(setup, capsys):
         n_genes += len(og)
         assert len(og) == len(gg) and all(np.array_equal(og[k], gg[k]) for k in ("begin", "end", "start_ndx", "stop_ndx"))
     assert n_genes > 500
+    # ... every f64 field of the genes' start nodes as the FULL-SIZE run left them (bit patterns), and then every field of every
+    # node of the sampled contigs, run as a sub-batch with want_nodes
+    from tests.test_finder_gpu import compare_contig
+    for i in sample:
+        o = orc.Oracle(seqs[i])
+        o.find_genes_meta(bins)
+        on, gg = o.nodes(), res.genes_of(i)
+        for name in ("cscore", "sscore", "rscore", "uscore", "tscore", "mot_score"):
+            assert np.array_equal(gg[name].view(np.uint64), on[name][gg["start_ndx"]].view(np.uint64)), (i, name)
+    sub = ctx.find_genes_batch([seqs[i] for i in sample], meta=True, want_nodes=True)
+    assert sum(compare_contig(sub, k, seqs[i], orc.Oracle(seqs[i]), bins, meta=True) for k, i in enumerate(sample)) > 500
     with capsys.disabled():
         print("\n[config4 share] 12 500 x 20 kbp: %d chains, %d node-passes, %d genes; %.1f ms per call incl. upload (connection scoring %.2f ms); "
               "%d sampled contigs / %d genes identical to the oracle" % (res.n_chains, res.node_passes, len(res.genes), gpu_s * 1e3, res2.t_dp_ms,

@@ -1,8 +1,8 @@
 """Turn the output of tools/collect_profiles.sh into the committed summaries under profiles/.
-usage: python tools/profiles_summary.py r02_a
+usage: python tools/profiles_summary.py r03_a [commit]
 Writes profiles/<tag>_bench_<workload>_kernel_stats.md, profiles/<tag>_bench_<workload>.json,
 profiles/pmc/<tag>_<workload>_<COUNTER>.csv (connection-scoring kernel rows only), profiles/<tag>_pmc_calibration.md and
-refreshes profiles/r02_pmc_traffic.json, which bench.py reads for roofline.traffic."""
+refreshes profiles/r03_pmc_traffic.json, which bench.py reads for roofline.traffic / roofline.valu_issue_frac."""
 import csv
 import json
 import os
@@ -11,6 +11,7 @@ import subprocess
 import sys
 
 tag = sys.argv[1]
+commit = sys.argv[2] if len(sys.argv) > 2 else subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 src = os.path.join("gpurun_out", "prof_" + tag)
 os.makedirs("profiles/pmc", exist_ok=True)
 GIB = float(1 << 30)
@@ -54,16 +55,16 @@ traffic = {
              "connection-scoring kernel; counters are in KiB.  Each counter is divided by what it reports per requested byte on "
              "known-byte-count kernels with the same access widths (profiles/%s_pmc_calibration.md: 4- and 8-byte coalesced loads / "
              "stores; MI355X_MICROARCH.md describes the same effect for 16-byte loads)." % tag,
-    "_collected": tag, "_fetch_counter_per_byte": round(f_read, 4), "_write_counter_per_byte": round(f_write, 4),
+    "_collected": tag, "collected_at_commit": commit, "_fetch_counter_per_byte": round(f_read, 4), "_write_counter_per_byte": round(f_write, 4),
 }
-for wl in ("config3", "config4"):
+for wl in ("config4", "config3", "config2", "config5"):
     bpath = os.path.join(src, "bench_%s.json" % wl)
     if not os.path.exists(bpath):
         continue
     bench = json.loads(open(bpath).read().strip().splitlines()[-1])
     json.dump(bench, open("profiles/%s_bench_%s.json" % (tag, wl), "w"), indent=1)
     roof = bench["roofline"]
-    title = "Round 2 (%s) -- bench.py --workload %s --contexts 1: %s, %.1f Mbp/s, %d chains per launch" % (
+    title = "Round 3 (%s) -- bench.py --workload %s --contexts 1: %s, %.1f Mbp/s, %d chains per launch" % (
         tag.split("_")[-1], wl, bench["config"]["workload"], bench["value"], roof["chains_per_launch"])
     md = subprocess.run([sys.executable, "tools/rocpd_stats.py", os.path.join(src, "trace_" + wl, "t_results.db"), title],
                         capture_output=True, text=True, check=True).stdout
@@ -85,22 +86,25 @@ for wl in ("config3", "config4"):
                   64.0 * roof["node_passes_per_launch"] / (tot_us / launches * 1e-6) / 8e12)
     open("profiles/%s_bench_%s_kernel_stats.md" % (tag, wl), "w").write(md)
     vals = {}
-    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
         path = os.path.join(src, "pmc_%s_%s" % (wl, c), "p_counter_collection.csv")
         if not os.path.exists(path):
             continue
         rows = list(csv.DictReader(open(path)))
+        if not rows:
+            continue
         keep = [r for r in rows if pat.search(r["Kernel_Name"]) and r["Counter_Name"] == c]
         with open("profiles/pmc/%s_%s_%s.csv" % (tag, wl, c), "w", newline="") as f:
             w = csv.DictWriter(f, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(keep)
         n = sum(1 for r in keep if re.search(r"(?<![A-Za-z0-9_])" + re.escape(once) + r"(?![A-Za-z0-9_])", r["Kernel_Name"]))
         vals[c] = sum(float(r["Counter_Value"]) for r in keep) / max(1, n)
-    if len(vals) == 2:
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
         hbm = (vals["FETCH_SIZE"] / f_read + vals["WRITE_SIZE"] / f_write) * 1024
         traffic[bench["config"]["workload"]] = {
+            "valu_insts_per_launch": int(vals["SQ_INSTS_VALU"]) if "SQ_INSTS_VALU" in vals else None,
             "kernel": roof["kernel"], "FETCH_SIZE_KiB": round(vals["FETCH_SIZE"], 1), "WRITE_SIZE_KiB": round(vals["WRITE_SIZE"], 1),
             "hbm_bytes_per_launch": int(round(hbm)), "algorithmic_bytes_per_launch": int(64 * roof["node_passes_per_launch"]),
             "ratio_to_algorithmic": round(hbm / (64.0 * roof["node_passes_per_launch"]), 3),
         }
-json.dump(traffic, open("profiles/r02_pmc_traffic.json", "w"), indent=1)
+json.dump(traffic, open("profiles/r03_pmc_traffic.json", "w"), indent=1)
 print(json.dumps(traffic, indent=1))
