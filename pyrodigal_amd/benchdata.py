@@ -56,7 +56,11 @@ def generate(lengths, gcs, seeds, procs=None):
     so the result does not depend on how the work is split)."""
     items = list(zip(lengths, gcs, seeds))
     procs = procs or min(32, os.cpu_count() or 1)
-    if procs <= 1 or len(items) < 64:
+    import sys
+    main_mod = sys.modules.get("__main__")
+    # spawned workers re-import the main module by path: a script fed through stdin (or an interactive session) has none, its
+    # workers would die on start and the pool would wait for them for ever -- generate in this process instead
+    if procs <= 1 or len(items) < 64 or not getattr(main_mod, "__file__", None) or not os.path.exists(getattr(main_mod, "__file__", "")):
         return _gen_chunk(items)
     # spawned workers (never forked: the parent may hold a HIP runtime, and a forked copy of one is not usable); they import
     # this module only, which loads nothing but numpy

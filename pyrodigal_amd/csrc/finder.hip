@@ -891,8 +891,8 @@ struct pga_batch {
     std::vector<ContigDesc> ct;   // n + 1 entries
     char* d_seq;                  // packed ASCII, resident in HBM
     size_t d_seq_cap = 0;         // bytes of that allocation (it goes back to the context's spare slot)
-    TileDesc* d_tiles;            // extraction tiles of every contig
-    int32_t* d_tile0;             // first tile of every contig, n + 1 entries (behind d_tiles, one allocation)
+    TileDesc* d_tiles;            // extraction tiles of every contig (behind the letters, in their allocation)
+    int32_t* d_tile0;             // first tile of every contig, n + 1 entries (behind d_tiles)
     int32_t n_tiles;
 };
 
@@ -907,11 +907,14 @@ static void batch_tiles(const pga_batch* b, std::vector<TileDesc>& tiles, std::v
     }
     tile0[b->n] = (int32_t)tiles.size();
 }
-// one device allocation: tiles, then the per-contig first-tile table
-static hipError_t batch_upload_tiles(pga_batch* b, const std::vector<TileDesc>& tiles, const std::vector<int32_t>& tile0, hipStream_t st) {
+// the tile list and the per-contig first-tile table live behind the letters, in the same device allocation (`at`, 256-byte aligned)
+static size_t batch_tiles_bytes(const std::vector<TileDesc>& tiles, const std::vector<int32_t>& tile0) {
+    return sizeof(TileDesc) * tiles.size() + sizeof(int32_t) * tile0.size() + 64 + 256;
+}
+static hipError_t batch_upload_tiles(pga_batch* b, char* at, const std::vector<TileDesc>& tiles, const std::vector<int32_t>& tile0, hipStream_t st) {
     b->n_tiles = (int32_t)tiles.size();
     const size_t tb = sizeof(TileDesc) * tiles.size(), zb = sizeof(int32_t) * tile0.size();
-    if (hipMalloc((void**)&b->d_tiles, tb + zb + 64) != hipSuccess) { b->d_tiles = nullptr; return hipErrorOutOfMemory; }
+    b->d_tiles = (TileDesc*)(((uintptr_t)at + 255) & ~(uintptr_t)255);
     b->d_tile0 = (int32_t*)((char*)b->d_tiles + tb);
     hipError_t e = hipSuccess;
     if (tb) e = hipMemcpyAsync(b->d_tiles, tiles.data(), tb, hipMemcpyHostToDevice, st);
@@ -1007,7 +1010,9 @@ extern "C" int pga_batch_create(pga_ctx* c, int32_t n_contigs, const char* const
         void* hp; int rc = ensure_pin(c, "h_seq", (size_t)total + 16, &hp);
         if (rc) { delete b; return rc; }
         char* h_seq = (char*)hp;
-        if (batch_take_dev(c, (size_t)total + 16, &b->d_seq, &b->d_seq_cap) != hipSuccess) { delete b; c->err = "pga_batch_create: hipMalloc failed"; return PGA_ENOMEM; }
+        std::vector<TileDesc> tiles; std::vector<int32_t> tile0;
+        batch_tiles(b, tiles, tile0);
+        if (batch_take_dev(c, (size_t)total + 16 + batch_tiles_bytes(tiles, tile0), &b->d_seq, &b->d_seq_cap) != hipSuccess) { delete b; c->err = "pga_batch_create: hipMalloc failed"; return PGA_ENOMEM; }
         // Packing is a host memcpy per contig and the upload a DMA from the pinned copy: the contigs are cut into slices of about
         // 8 MB, a few host threads pack slices, and each slice goes on its way to the device as soon as it is packed -- the DMA of
         // slice k runs under the packing of the slices after it (it was: one thread packing everything, then one DMA, 12 + 3 ms
@@ -1040,11 +1045,9 @@ extern "C" int pga_batch_create(pga_ctx* c, int32_t n_contigs, const char* const
         const int threads = n_slices >= 2 ? std::min(n_slices, 6) : 1;
         if (threads == 1) work(); else c->finder->pool.run(work, threads);
         hipError_t e = (hipError_t)first_err.load();
-        std::vector<TileDesc> tiles; std::vector<int32_t> tile0;
-        batch_tiles(b, tiles, tile0);             // host work under the last slices' DMA
-        if (e == hipSuccess) e = batch_upload_tiles(b, tiles, tile0, st);
+        if (e == hipSuccess) e = batch_upload_tiles(b, b->d_seq + total + 16, tiles, tile0, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) { if (b->d_tiles) hipFree(b->d_tiles); batch_give_dev(c, b->d_seq, b->d_seq_cap); delete b; return pga_hip_try_(c, e, "upload of the batch"); }
+        if (e != hipSuccess) { batch_give_dev(c, b->d_seq, b->d_seq_cap); delete b; return pga_hip_try_(c, e, "upload of the batch"); }
     }
     *out = b;
     return PGA_OK;
@@ -1069,14 +1072,14 @@ extern "C" int pga_batch_create_packed(pga_ctx* c, int32_t n_contigs, const char
     b->total = total;
     if (total >= 0x7fffffffLL) { delete b; c->err = "pga_batch_create_packed: batch larger than 2^31 bases; split it"; return PGA_EINVAL; }
     if (total > 0) {
-        if (batch_take_dev(c, (size_t)total + 16, &b->d_seq, &b->d_seq_cap) != hipSuccess) { delete b; c->err = "pga_batch_create_packed: hipMalloc failed"; return PGA_ENOMEM; }
-        // the letters go straight from the caller's (pinned) buffer: one DMA, overlapped with the tile list's host work
-        hipError_t e = hipMemcpyAsync(b->d_seq, packed + offs[0], (size_t)total, hipMemcpyHostToDevice, c->stream);
         std::vector<TileDesc> tiles; std::vector<int32_t> tile0;
         batch_tiles(b, tiles, tile0);
-        if (e == hipSuccess) e = batch_upload_tiles(b, tiles, tile0, c->stream);
+        if (batch_take_dev(c, (size_t)total + 16 + batch_tiles_bytes(tiles, tile0), &b->d_seq, &b->d_seq_cap) != hipSuccess) { delete b; c->err = "pga_batch_create_packed: hipMalloc failed"; return PGA_ENOMEM; }
+        // the letters go straight from the caller's (pinned) buffer: one DMA, overlapped with the tile list's host work
+        hipError_t e = hipMemcpyAsync(b->d_seq, packed + offs[0], (size_t)total, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = batch_upload_tiles(b, b->d_seq + total + 16, tiles, tile0, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) { if (b->d_tiles) hipFree(b->d_tiles); batch_give_dev(c, b->d_seq, b->d_seq_cap); delete b; return pga_hip_try_(c, e, "upload of the packed batch"); }
+        if (e != hipSuccess) { batch_give_dev(c, b->d_seq, b->d_seq_cap); delete b; return pga_hip_try_(c, e, "upload of the packed batch"); }
     }
     *out = b;
     return PGA_OK;
@@ -1089,7 +1092,6 @@ pga_batch_view pga_batch_peek(const pga_batch* b) { return pga_batch_view{b->ctx
 extern "C" void pga_batch_free(pga_batch* b) {
     if (!b) return;
     if (b->d_seq) { hipSetDevice(b->ctx->device); batch_give_dev(b->ctx, b->d_seq, b->d_seq_cap); }
-    if (b->d_tiles) hipFree(b->d_tiles);
     delete b;
 }
 

@@ -96,7 +96,12 @@ for wl in ("config4", "config3", "config2", "config5"):
         keep = [r for r in rows if pat.search(r["Kernel_Name"]) and r["Counter_Name"] == c]
         with open("profiles/pmc/%s_%s_%s.csv" % (tag, wl, c), "w", newline="") as f:
             w = csv.DictWriter(f, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(keep)
-        n = sum(1 for r in keep if re.search(r"(?<![A-Za-z0-9_])" + re.escape(once) + r"(?![A-Za-z0-9_])", r["Kernel_Name"]))
+        is_once = lambda r: re.search(r"(?<![A-Za-z0-9_])" + re.escape(once) + r"(?![A-Za-z0-9_])", r["Kernel_Name"]) is not None
+        if len(group) == 1:
+            # bench.py warms the clocks up with quarter-size calls before its steps: only the full-size launches count
+            gmax = max(int(r["Grid_Size"]) for r in keep if is_once(r))
+            keep = [r for r in keep if int(r["Grid_Size"]) == gmax]
+        n = sum(1 for r in keep if is_once(r))
         vals[c] = sum(float(r["Counter_Value"]) for r in keep) / max(1, n)
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
         hbm = (vals["FETCH_SIZE"] / f_read + vals["WRITE_SIZE"] / f_write) * 1024
@@ -106,5 +111,15 @@ for wl in ("config4", "config3", "config2", "config5"):
             "hbm_bytes_per_launch": int(round(hbm)), "algorithmic_bytes_per_launch": int(64 * roof["node_passes_per_launch"]),
             "ratio_to_algorithmic": round(hbm / (64.0 * roof["node_passes_per_launch"]), 3),
         }
+# entries of workloads that were not part of this collection stay (a later collection of one workload refreshes that one only)
+try:
+    merged = json.load(open("profiles/r03_pmc_traffic.json"))
+except (OSError, ValueError):
+    merged = {}
+for k, v in traffic.items():
+    if isinstance(v, dict):
+        v = dict(v, collected=tag, collected_at_commit=commit)
+    merged[k] = v
+traffic = merged
 json.dump(traffic, open("profiles/r03_pmc_traffic.json", "w"), indent=1)
 print(json.dumps(traffic, indent=1))
