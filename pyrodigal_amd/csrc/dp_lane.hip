@@ -15,7 +15,7 @@
 // wave.  k_dpl_pack builds the input records from the per-chain arrays (chains are dealt to lanes longest first, so the lanes
 // of a wave run out of nodes together); the results stay interleaved: only the winning chain of a contig is ever read again
 // (k_gather_winners, finder.hip), and k_dpl_unpack serves callers that want the plain arrays.
-//   input  A  {ndx, stop_val, q2, kf}             16 B     B  {cs (f64), lo, -}       16 B
+//   input  A  {ndx, stop_val, q2, kf}             16 B     B  {cs (f64), lo, index of the stop's extras record}       16 B
 //   output    {score (f64), tag = traceb | (ov_mark + 1) << 28 or -1, position of the traceb node}     16 B
 // The 64-byte extras of a stop node (dpw_core.h DpwExt) are read from the per-chain array, one step ahead of their use.
 // The rings and the candidate lists live in LDS, [slot][lane] of 16 bytes: conflict-free whatever slot each lane is at.
@@ -77,7 +77,7 @@ k_dpl_pack(const DplDev L, const ChainDesc* __restrict__ chains, const DpwGroupP
     const int chain = L.lane_chain[(int64_t)w * 64 + c];
     const int64_t rec0 = L.wave_base[w] + c;
     const int i0 = t0 + 4 * part;
-    int nd[4] = {0, 0, 0, 0}, sv[4] = {0, 0, 0, 0}, q2[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0}, kf[4] = {0, 0, 0, 0};
+    int nd[4] = {0, 0, 0, 0}, sv[4] = {0, 0, 0, 0}, q2[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0}, kf[4] = {0, 0, 0, 0}, sr[4] = {0, 1, 2, 3};
     double cs[4] = {0.0, 0.0, 0.0, 0.0};
     int n = 0;
     if (chain >= 0) {
@@ -94,12 +94,15 @@ k_dpl_pack(const DplDev L, const ChainDesc* __restrict__ chains, const DpwGroupP
             kf[0] = k4 & 255; kf[1] = (k4 >> 8) & 255; kf[2] = (k4 >> 16) & 255; kf[3] = k4 >> 24;
             double2 d; __builtin_memcpy(&d, g_cs + cd.off + i0, 16); cs[0] = d.x; cs[1] = d.y;
             __builtin_memcpy(&d, g_cs + cd.off + i0 + 2, 16); cs[2] = d.x; cs[3] = d.y;
+            if (ta.srank != nullptr) { __builtin_memcpy(&v, ta.srank + cd.topo_off + i0, 16); sr[0] = v.x; sr[1] = v.y; sr[2] = v.z; sr[3] = v.w; }
+            else { sr[0] = i0; sr[1] = i0 + 1; sr[2] = i0 + 2; sr[3] = i0 + 3; }
         } else {
             for (int k = 0; k < 4; k++) {
                 const int i = i0 + k;
                 if (i >= n) break;
                 nd[k] = ta.ndx[cd.topo_off + i]; sv[k] = ta.stop_val[cd.topo_off + i]; q2[k] = ta.q2[cd.topo_off + i]; lo[k] = ta.lo[cd.topo_off + i];
                 kf[k] = ta.kf[cd.topo_off + i]; cs[k] = g_cs[cd.off + i];
+                sr[k] = ta.srank != nullptr ? ta.srank[cd.topo_off + i] : i;
             }
         }
     }
@@ -109,7 +112,7 @@ k_dpl_pack(const DplDev L, const ChainDesc* __restrict__ chains, const DpwGroupP
         const int i = i0 + k;
         if (i >= steps) break;
         L.inA[rec0 + (int64_t)i * 64] = make_int4(nd[k], sv[k], q2[k], kf[k]);
-        L.inB[rec0 + (int64_t)i * 64] = make_int4(__double2loint(cs[k]), __double2hiint(cs[k]), lo[k], 0);
+        L.inB[rec0 + (int64_t)i * 64] = make_int4(__double2loint(cs[k]), __double2hiint(cs[k]), lo[k], sr[k]);
     }
 }
 
@@ -134,7 +137,7 @@ k_dp_lane(const DplDev L, const ChainDesc* __restrict__ chains, const DpwExt* __
     const int4* __restrict__ A = L.inA + rec0;
     const int4* __restrict__ Bp = L.inB + rec0;
     int4* O = L.out + rec0;
-    const DpwExt* ext = g_ext + cd.off;
+    const DpwExt* ext = g_ext + (L.dense_ext ? cd.soff : cd.off);      // record of a stop node: ext[B.w] (its node index, or its rank among the chain's stops)
     const ModelConst* mc = &models[have ? cd.model : 0];
     const DpwModel M{mc->st_wt, mc->negc, mc->igm};
     s_t2[lane] = c_dpl_t2.v[lane];
@@ -149,14 +152,14 @@ k_dp_lane(const DplDev L, const ChainDesc* __restrict__ chains, const DpwExt* __
     int4 a0 = steps > 0 ? A[0] : zero, b0 = steps > 0 ? Bp[0] : zero;
     int4 a1 = steps > 1 ? A[64] : zero, b1 = steps > 1 ? Bp[64] : zero;
     int4 e0 = zero, e1 = zero, e2 = zero, e3 = zero;
-    if (n > 0 && (DPW_KIND(a0.w) & 1)) { const int4* p = reinterpret_cast<const int4*>(ext); e0 = p[0]; e1 = p[1]; e2 = p[2]; e3 = p[3]; }
+    if (n > 0 && (DPW_KIND(a0.w) & 1)) { const int4* p = reinterpret_cast<const int4*>(ext + b0.w); e0 = p[0]; e1 = p[1]; e2 = p[2]; e3 = p[3]; }
     for (int t = 0; t < steps; t++) {
         const int4 a = a0, b = b0;
         const int4 x0 = e0, x1 = e1, x2 = e2, x3 = e3;
         a0 = a1; b0 = b1;
         if (t + 2 < steps) { a1 = A[(int64_t)(t + 2) * 64]; b1 = Bp[(int64_t)(t + 2) * 64]; }
         if (t + 1 < n && (DPW_KIND(a0.w) & 1)) {
-            const int4* p = reinterpret_cast<const int4*>(ext + (t + 1));
+            const int4* p = reinterpret_cast<const int4*>(ext + b0.w);
             e0 = p[0]; e1 = p[1]; e2 = p[2]; e3 = p[3];
         }
         if (t < n) {
@@ -233,8 +236,10 @@ void pga_dpl_plan(const ChainDesc* h, int n_chains, DplPlan& plan) {
 }
 
 void pga_launch_dp_lane(const ChainDesc* d_chains, const DpwGroupPtrs& groups, const ModelConst* d_models, DpBuffers buf, const DpwBuffers& wb,
-                        const DplDev& L, hipStream_t st) {
-    if (L.n_waves <= 0 || L.max_steps <= 0) return;
+                        const DplDev& L0, hipStream_t st) {
+    if (L0.n_waves <= 0 || L0.max_steps <= 0) return;
+    DplDev L = L0;
+    L.dense_ext = groups.g[0].srank != nullptr;
     hipLaunchKernelGGL(k_dpl_pack, dim3((unsigned)((L.max_steps + 15) / 16), (unsigned)L.n_waves), dim3(256), 0, st, L, d_chains, groups, (const double*)wb.cs);
     hipLaunchKernelGGL(k_dp_lane, dim3((unsigned)L.n_waves), dim3(64), 0, st, L, d_chains, (const DpwExt*)wb.ext, d_models, buf);
 }

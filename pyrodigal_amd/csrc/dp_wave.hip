@@ -149,6 +149,7 @@ struct WavePtrs {
     const int32_t* __restrict__ ndx; const int32_t* __restrict__ stopv; const uint8_t* __restrict__ kf;
     const int32_t* __restrict__ lo; const int32_t* __restrict__ q1; const int32_t* __restrict__ q2;
     const double* __restrict__ cs; const DpwExt* __restrict__ ext;
+    const int32_t* __restrict__ srank;      // or nullptr: the extras of node i are ext[i]; else ext[srank[i]]
     double* score; int32_t* traceb; int32_t* tbn; int8_t* ov; double* sfxv; int32_t* sfxi;
 };
 
@@ -172,7 +173,8 @@ __device__ __forceinline__ void load_target_w(DpwT& T, int& kfb, const WavePtrs&
     T.cs = P.cs[ii]; T.csd = T.cs + negc;
     T.vm = 0; T.x0 = T.x1 = T.x2 = 0.0;
     T.n3n0 = T.n3n1 = T.n3n2 = T.n3s0 = T.n3s1 = T.n3s2 = 0; T.cq0 = T.cq1 = T.cq2 = DPW_NONE;
-    if (act && (T.kind & 1)) load_ext(P.ext + ii, T);
+    const int er = P.srank != nullptr ? P.srank[ii] : ii;       // asked for with the other topology fields, not behind them
+    if (act && (T.kind & 1)) load_ext(P.ext + er, T);
 }
 
 // a forward stop met through a chain of candidates, as a source (its operon terms are not needed towards reverse targets)
@@ -319,7 +321,9 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
         const DpwTopoArrays& ta = groups.g[cd.group];
         P.ndx = ta.ndx + cd.topo_off; P.stopv = ta.stop_val + cd.topo_off; P.kf = ta.kf + cd.topo_off;
         P.lo = ta.lo + cd.topo_off; P.q1 = ta.q1 + cd.topo_off; P.q2 = ta.q2 + cd.topo_off;
-        P.cs = g_cs + cd.off; P.ext = g_ext + cd.off;
+        P.cs = g_cs + cd.off;
+        P.srank = ta.srank != nullptr ? ta.srank + cd.topo_off : nullptr;
+        P.ext = g_ext + (ta.srank != nullptr ? cd.soff : cd.off);
         P.score = buf.score + cd.off; P.traceb = buf.traceb + cd.off; P.tbn = buf.tbn + cd.off; P.ov = buf.ov_mark + cd.off;
         P.sfxv = g_sfxv + cd.off; P.sfxi = g_sfxi + cd.off;
     }
@@ -376,8 +380,9 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
                 SrcRegs R;
                 R.ndx = P.ndx[jj]; R.stop_val = P.stopv[jj]; R.score = P.score[jj]; R.cs = P.cs[jj];
                 const int s_tbn = P.tbn[jj];
+                const int er = P.srank != nullptr ? P.srank[jj] : jj;
                 int vm = 0; R.x0 = R.x1 = R.x2 = 0.0;
-                if (sk == 1) { const DpwExt* e = P.ext + jj; vm = e->vm; R.x0 = e->x[0]; R.x1 = e->x[1]; R.x2 = e->x[2]; }
+                if (sk == 1) { const DpwExt* e = P.ext + er; vm = e->vm; R.x0 = e->x[0]; R.x1 = e->x[1]; R.x2 = e->x[2]; }
                 R.pack = sk | (DPW_FRAME(s_kf) << 2) | (vm << 4);
                 const bool dead = (sk == 1 || sk == 2) && s_tbn == -1;
                 unsigned long long visit = __ballot(in && !dead);

@@ -1324,6 +1324,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             GBUF(ndx, int32_t, n) GBUF(stop_val, int32_t, n) GBUF(type, uint8_t, n) GBUF(strand, int8_t, n) GBUF(edge0, uint8_t, n) GBUF(gc_cont, float, n)
             GBUF(stop_list, int32_t, (int64_t)h_sbase[(size_t)g * (NC + 1) + NC] + 1)
             GBUF(ovl_topo, uint32_t, (int64_t)h_sbase[(size_t)g * (NC + 1) + NC] + 1)
+            GBUF(srank, int32_t, n + 4)
         }
         ChainArrays ca;
         {
@@ -1365,9 +1366,9 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
 #define WBUF(field, type) { snprintf(nm, sizeof nm, "dpw_" #field "%d", g); void* p__; int rc__ = ensure_dev(c, nm, sizeof(type) * (size_t)n + 64, &p__); if (rc__) return rc__; wgroups.g[g].field = (type*)p__; }
                 WBUF(kf, uint8_t) WBUF(lo, int32_t) WBUF(q1, int32_t) WBUF(q2, int32_t)
 #undef WBUF
-                wgroups.g[g].ndx = ga[g].ndx; wgroups.g[g].stop_val = ga[g].stop_val;
+                wgroups.g[g].ndx = ga[g].ndx; wgroups.g[g].stop_val = ga[g].stop_val; wgroups.g[g].srank = ga[g].srank;
             }
-            DEVBUF(w0, double, "dpw_cs", dp_cap) DEVBUF(w1, DpwExt, "dpw_ext", dp_cap) DEVBUF(w2, double, "dpw_sfxv", dp_cap) DEVBUF(w3, int32_t, "dpw_sfxi", dp_cap)
+            DEVBUF(w0, double, "dpw_cs", dp_cap) DEVBUF(w1, DpwExt, "dpw_ext", tot_chain_stops + 2)      /* one extras record per (chain, stop node) pair */ DEVBUF(w2, double, "dpw_sfxv", dp_cap) DEVBUF(w3, int32_t, "dpw_sfxi", dp_cap)
             wbuf = DpwBuffers{w0, w1, w2, w3};
         }
         // very many chains: one LANE each (dp_lane.hip), on the same records; the results stay in its interleaved layout

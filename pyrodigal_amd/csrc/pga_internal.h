@@ -127,9 +127,12 @@ hipError_t pga_dp_seg_bind(const DpSegPlan& plan, int n_chains, int64_t tot_node
 // ---- wave-batch connection scoring for launches with many chains (dp_wave.hip, dpw_core.h) ----
 struct DpwExt;
 // topology of one translation-table group: what depends on positions and kinds only, shared by every model of a contig
-struct DpwTopoArrays { const int32_t* ndx; const int32_t* stop_val; uint8_t* kf; int32_t* lo; int32_t* q1; int32_t* q2; };
+// srank: per node (stop nodes only) its rank among the stop nodes of its contig, or nullptr: then the extras record of node i of a
+// chain is ext[off + i]; with it, ext[soff + srank[i]] (one 64-byte record per (chain, stop node) pair, dense)
+struct DpwTopoArrays { const int32_t* ndx; const int32_t* stop_val; uint8_t* kf; int32_t* lo; int32_t* q1; int32_t* q2; const int32_t* srank = nullptr; };
 struct DpwGroupPtrs { DpwTopoArrays g[4]; };
-// per chain node: cs = cscore + sscore, a 64-byte record of extras (stop nodes only), suffix maxima of finished blocks
+// per chain node: cs = cscore + sscore, suffix maxima of finished blocks; per stop node a 64-byte record of extras (indexed by
+// node, or dense by (chain, stop) pair: DpwTopoArrays::srank)
 struct DpwBuffers { double* cs; DpwExt* ext; double* sfxv; int32_t* sfxi; };
 // which connection scorer a final-pass launch over n_chains chains uses (PGA_DP_KERNEL overrides: wave | tree1 | tree3 | scan)
 bool pga_dp_use_wave(int n_chains);
@@ -152,7 +155,7 @@ struct DplPlan {        // host side
     int64_t records = 0;
     int n_waves = 0, max_steps = 0;
 };
-struct DplDev { const int32_t* lane_chain; const int64_t* wave_base; const int32_t* wave_steps; int4* inA; int4* inB; int4* out; int n_waves, max_steps; };
+struct DplDev { const int32_t* lane_chain; const int64_t* wave_base; const int32_t* wave_steps; int4* inA; int4* inB; int4* out; int n_waves, max_steps; bool dense_ext = false; };
 // which connection scorer a final-pass launch uses: lane-per-chain when there are chains enough to fill the chip that way
 // (PGA_DP_KERNEL=lane forces it, any other value of PGA_DP_KERNEL or PGA_DP_LANE=0 rules it out)
 bool pga_dp_use_lane(int n_chains);

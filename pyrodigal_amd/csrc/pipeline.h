@@ -26,6 +26,8 @@ struct GroupArrays {
     uint8_t* st_info;                        // type | edge << 2 | reverse << 3
     int32_t* stop_list;                      // the stop nodes of the group in node order (node indices); contig c owns [sbase[c], sbase[c + 1])
     uint32_t* ovl_topo;                      // per entry of stop_list: which of its first 16 neighbours can be overlapping starts (k_ovl_topo)
+    int32_t* srank = nullptr;                // per node, written for stop nodes only: its rank among the stop nodes of its contig (k_ovl_topo):
+                                             // the k-th stop of a chain owns extras record ChainDesc::soff + k of the wave-batch scorer
     // per node, in (contig, ndx, strand) order
     int32_t* ndx; int32_t* stop_val; uint8_t* type; int8_t* strand; uint8_t* edge0; float* gc_cont;
 };

@@ -2016,6 +2016,7 @@ k_ovl_topo(GroupArrays ga, const int32_t* __restrict__ cbase, const int32_t* __r
     while (c + 1 < n_contigs && sbase[c + 1] <= s) c++;
     const int b0 = cbase[c], n = cbase[c + 1] - b0;
     const int i = ga.stop_list[s] - b0;
+    if (ga.srank != nullptr) ga.srank[b0 + i] = s - sbase[c];
     ga.ovl_topo[s] = ga.edge0[b0 + i] == 1 ? 0x80000000u
                                            : overlap_neighbours(ga.ndx + b0, ga.stop_val + b0, ga.type + b0, ga.strand + b0, n, i, maxov);
 }
@@ -2080,7 +2081,7 @@ k_ovl_stops(const ChainDesc* __restrict__ chains, int n_chains, int64_t soff_beg
         DpwExt e;
         dpw_chain_ext_sp(ga.ndx + tb, ga.stop_val + tb, ga.strand + tb, topo_q2 + tb, ca.cscore + ch.off, ca.sscore + ch.off, ca.rscore + ch.off,
                          ca.uscore + ch.off, sp, i, ga.strand[tb + i] != 1, M, e);
-        ext[g] = e;
+        ext[p] = e;             // dense: one record per (chain, stop node) pair, in pair order
     }
 }
 

@@ -42,7 +42,8 @@ print("# %s %s: every kernel against the HBM roofline and the VALU issue peak\n"
 print("Durations: `rocprofv3 --kernel-trace --stats` (average over the calls of the trace, microseconds).  HBM bytes per launch: separate\n"
       "`--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, full-size launches only, FETCH_SIZE / 0.5 + WRITE_SIZE / 1.0 (KiB; calibration in\n"
       "profiles/%s_pmc_calibration.md).  VALU wave-instructions per launch: `--pmc SQ_INSTS_VALU`.  Peaks: HBM 8 TB/s; VALU issue\n"
-      "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction = 1.23e12 / s (MI355X_MICROARCH.md).\n" % tag)
+      "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction = 1.23e12 / s (MI355X_MICROARCH.md).  A fraction near or above 1 (k_ovl_stops)\n"
+      "means the counters also see requests the Infinity Cache served: the kernel re-reads what the kernel before it just wrote.\n" % tag)
 print("| kernel | calls | avg us | %% of kernel time | HBM MB / launch | GB/s | frac of HBM | VALU M-instr / launch | frac of VALU issue |")
 print("|---|---|---|---|---|---|---|---|---|")
 for name, calls, total, avg in sorted(rows, key=lambda r: -r[2]):
