@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -70,6 +71,12 @@ struct pga_fasta {
     std::vector<Arena> arenas;
     size_t next_arena = 0;
 };
+
+// Pinning memory costs about as much as parsing into it (page by page, a few GB/s): the arenas of a closed reader go to a small
+// process-wide pool and the next reader takes them from there, so that a caller working through file after file pins once.
+static std::mutex g_spare_mu;
+static std::vector<pga_fasta::Arena> g_spare;
+static const size_t SPARE_MAX = 8;
 
 // ---- stream source ------------------------------------------------------------------------------------------------------
 static bool fill(pga_fasta* f) {
@@ -361,7 +368,13 @@ extern "C" void pga_fasta_close(pga_fasta* f) {
     if (f->gz) gzclose(f->gz);
     if (f->map) munmap((void*)f->map, f->map_len);
     if (f->fd >= 0) close(f->fd);
-    for (auto& a : f->arenas) if (a.p) hipHostFree(a.p);
+    {
+        std::lock_guard<std::mutex> g(g_spare_mu);
+        for (auto& a : f->arenas) {
+            if (!a.p) continue;
+            if (g_spare.size() < SPARE_MAX) g_spare.push_back(a); else hipHostFree(a.p);
+        }
+    }
     delete f;
 }
 
@@ -397,10 +410,19 @@ static char* take_arena(pga_fasta* f, size_t bytes) {
     pga_fasta::Arena& a = f->arenas[f->next_arena];
     f->next_arena = (f->next_arena + 1) % f->arenas.size();
     if (a.cap < bytes) {
-        if (a.p) { hipHostFree(a.p); a.p = nullptr; a.cap = 0; }
-        const size_t want = bytes + bytes / 4 + 4096;
-        if (hipHostMalloc((void**)&a.p, want, hipHostMallocDefault) != hipSuccess) { a.p = nullptr; f->err = "hipHostMalloc failed for a staging arena"; return nullptr; }
-        a.cap = want;
+        pga_fasta::Arena old = a;
+        a = pga_fasta::Arena();
+        {
+            std::lock_guard<std::mutex> g(g_spare_mu);
+            for (size_t k = 0; k < g_spare.size(); k++)
+                if (g_spare[k].cap >= bytes) { a = g_spare[k]; g_spare.erase(g_spare.begin() + (long)k); break; }
+            if (old.p) { if (g_spare.size() < SPARE_MAX) g_spare.push_back(old); else hipHostFree(old.p); }
+        }
+        if (!a.p) {
+            const size_t want = bytes + bytes / 4 + 4096;
+            if (hipHostMalloc((void**)&a.p, want, hipHostMallocDefault) != hipSuccess) { a.p = nullptr; a.cap = 0; f->err = "hipHostMalloc failed for a staging arena"; return nullptr; }
+            a.cap = want;
+        }
     }
     return a.p;
 }

@@ -73,15 +73,18 @@ def find_genes_stream(batches, model_blobs, n_contexts=2, device=0, **find_kw):
             c.close()
 
 
-def find_genes_fasta(path, model_blobs, n_contexts=2, device=0, max_bases=64 << 20, **find_kw):
+def find_genes_fasta(path, model_blobs, n_contexts=2, device=0, max_bases=64 << 20, contexts=None, **find_kw):
     """Genes of every record of a (gzipped) FASTA file: yields ``(ids, descriptions, lengths, BatchResult)`` per batch, in file order.
 
     The reader (C, zlib) parses batch k + 1 into a pinned staging arena while batch k is uploaded from its own arena with one
     DMA (no host-side packing) and processed; ``n_contexts`` contexts keep the device busy across batches
-    (ref: what the reference's CLI does with a thread pool over records, cli.py:287-302)."""
-    ctxs = [_cabi.Context(device) for _ in range(max(1, n_contexts))]
-    for c in ctxs:
-        c.set_models(list(model_blobs))
+    (ref: what the reference's CLI does with a thread pool over records, cli.py:287-302).  `contexts`: contexts the caller keeps
+    across files (models loaded, device buffers grown) instead of `n_contexts` fresh ones."""
+    own = contexts is None             # `contexts`: contexts the caller keeps across files (models loaded, buffers grown)
+    ctxs = [_cabi.Context(device) for _ in range(max(1, n_contexts))] if own else list(contexts)
+    if own:
+        for c in ctxs:
+            c.set_models(list(model_blobs))
     todo = queue.Queue(maxsize=len(ctxs))
     done, failure = {}, []
     cv = threading.Condition()
@@ -141,5 +144,6 @@ def find_genes_fasta(path, model_blobs, n_contexts=2, device=0, max_bases=64 << 
         for t in threads:
             t.join()
         reader.close()
-        for c in ctxs:
-            c.close()
+        if own:
+            for c in ctxs:
+                c.close()
