@@ -1650,7 +1650,7 @@ bool pga_dp_plan(const ChainDesc* h, int n_chains, int64_t tot_nodes, DpSegPlan&
     plan = DpSegPlan();
     if (n_chains <= 0 || n_chains >= 2048 || getenv("PGA_DP_KERNEL") || env_int("PGA_DP_SEG", 1) == 0) return false;
     const int min_chain = std::max(256, env_int("PGA_DP_SEG_MIN", 16384));
-    const int warm = std::max(64, env_int("PGA_DP_SEG_WARM", 2048));
+    const int warm = std::max(64, env_int("PGA_DP_SEG_WARM", 4096));      // 2048 left 8 (config 5) / 938 (config 2) nodes for a second round; 4096 none
     int64_t cand = 0;
     for (int c = 0; c < n_chains; c++) if (h[c].n >= min_chain) cand += h[c].n;
     if (cand == 0) return false;

@@ -32,7 +32,7 @@ def test_one_genome_fills_the_chip_but_not_more():
     for n in (20_000, 153_296, 1_000_000, 10_478_082):
         p = _cabi.dp_plan_summary([n])
         assert p["chains"] == 1 and 2 <= p["segments"] <= 252, (n, p)
-        assert p["max_sub_chain"] <= n // p["segments"] + 64 + 2048 + n // (4 * p["segments"]) + 64     # segment (+ merged tail) + warm-up
+        assert p["max_sub_chain"] <= n // p["segments"] + 64 + 4096 + n // (4 * p["segments"]) + 64     # segment (+ merged tail) + warm-up (PGA_DP_SEG_WARM, 4096)
         assert p["scratch"] >= n                                                                    # every segment keeps its own results
 
 

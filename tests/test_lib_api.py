@@ -337,6 +337,59 @@ def test_thread_pool_of_find_genes_calls_rides_the_batch_path(lib):
 
 
 @pytest.mark.gpu
+def test_reference_edge_cases_through_the_api(lib):
+    """ref: tests/test_gene_finder.py:198-234 (TestMeta.test_overflow / test_short_sequences / test_empty_sequence) and 366-387 (the
+    same in single mode).  The reference runs them with Prodigal's built-in bins, which are not available offline: here the same
+    inputs run with the 16-model bin set and in single mode, the gene calls are checked against the oracle, and the properties the
+    reference asserts (a gene running over both edges is an `Edge` start with both partial flags; nothing on sequences too short
+    for a gene; empty input) are asserted as the reference does."""
+    import textwrap
+    from oracle import oracle as orc
+    from pyrodigal_amd import benchdata
+    models = benchdata.load_model_set()
+    bins = lib.MetagenomicBins([lib.MetagenomicBin(lib.TrainingInfo(raw=b), n) for n, b in models])
+    obins = [orc.Training(b) for _, b in models]
+    # > 180195.SAMN03785337.LFLS01000089 (the reference's test_overflow input: one ORF running over both ends of the sequence)
+    seq = textwrap.dedent("""
+        AACCAGGGCAATATCAGTACCGCGGGCAATGCAACCCTGACTGCCGGCGGTAACCTGAAC
+        AGCACTGGCAATCTGACTGTGGGCGGTGTTACCAACGGCACTGCTACTACTGGCAACATC
+        GCACTGACCGGTAACAATGCGCTGAGCGGTCCGGTCAATCTGAATGCGTCGAATGGCACG
+        GTGACCTTGAACACGACCGGCAATACCACGCTCGGTAACGTGACGGCACAAGGCAATGTG
+        ACGACCAATGTGTCCAACGGCAGTCTGACGGTTACCGGCAATACGACAGGTGCCAACACC
+        AACCTCAGTGCCAGCGGCAACCTGACCGTGGGTAACCAGGGCAATATCAGTACCGCAGGC
+        AATGCAACCCTGACGGCCGGCGACAACCTGACGAGCACTGGCAATCTGACTGTGGGCGGC
+        GTCACCAACGGCACGGCCACCACCGGCAACATCGCGCTGACCGGTAACAATGCACTGGCT
+        GGTCCTGTCAATCTGAACGCGCCGAACGGCACCGTGACCCTGAACACAACCGGCAATACC
+        ACGCTGGGTAATGTCACCGCACAAGGCAATGTGACGACTAATGTGTCCAACGGCAGCCTG
+        ACAGTCGCTGGCAATACCACAGGTGCCAACACCAACCTGAGTGCCAGCGGCAATCTGACC
+        GTGGGCAACCAGGGCAATATCAGTACCGCGGGCAATGCAACCCTGACTGCCGGCGGTAAC
+        CTGAGC
+        """).replace("\n", "")
+    meta = lib.GeneFinder(meta=True, metagenomic_bins=bins, closed=False)
+    genes = meta.find_genes(seq)
+    o = orc.Oracle(seq.encode())
+    phase = o.find_genes_meta(obins)
+    og = o.genes()
+    assert [(g.begin, g.end) for g in genes] == [(int(a), int(b)) for a, b in zip(og["begin"], og["end"])]
+    assert (bins._bins.index(genes.metagenomic_bin) if genes.metagenomic_bin is not None else -1) == phase
+    for g in genes:
+        if g.partial_begin and g.partial_end:
+            assert g.start_type == "Edge" and g.begin == 1 and g.end >= len(seq) - 2
+    assert any(g.partial_begin and g.partial_end for g in genes)          # the one gene of the reference's test: it runs over both edges
+    # sequences too short for a gene, and the empty one: no genes, an exhausted iterator (meta and single mode)
+    short = "AATGTAGGAAAAACAGCATTTTCATTTCGCCATTTT"
+    single = lib.GeneFinder(lib.TrainingInfo.load(golden_path("SRR492066.training.bin.gz")))
+    for finder in (meta, single):
+        for i in list(range(1, len(short))) + [0]:
+            genes = finder.find_genes(short[:i])
+            assert len(genes) == 0
+            with pytest.raises(StopIteration):
+                next(iter(genes))
+    batch = meta.find_genes_batch([short[:i] for i in range(len(short))] + [seq])      # the same through one device call
+    assert [len(g) for g in batch[:-1]] == [0] * len(short) and len(batch[-1]) == len(og)
+
+
+@pytest.mark.gpu
 def test_find_genes_is_thread_safe(lib):
     """ref: README.md:105-122 / tests/test_gene_finder.py (ThreadPool use): one finder shared by threads, and one finder
     per thread, give the single-threaded result."""
