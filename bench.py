@@ -455,19 +455,19 @@ def threadpool_find_genes(seqs, models, dev_index, threads=32):
     bases = sum(len(s) for s in seqs)
     out = {"threads": threads, "contigs": len(seqs), "bases": bases, "unit": "Mbp/s",
            "what": "ThreadPoolExecutor(%d).map(finder.find_genes, contigs) on ONE GeneFinder(meta=True); host to host, one contig per call" % threads}
-    for key, keep in (("keep_nodes_false", False), ("default", True)):
+    for key, keep, nthreads in (("keep_nodes_false", False, threads), ("default", True, threads), ("keep_nodes_false_128_threads", False, 128)):
         finder = lib.GeneFinder(meta=True, metagenomic_bins=bins, keep_nodes=keep, device=dev_index)
-        with ThreadPoolExecutor(threads) as ex:
+        with ThreadPoolExecutor(nthreads) as ex:
             list(ex.map(finder.find_genes, seqs[:256]))                  # contexts, models, buffers
             finder.stats.update(device_calls=0, sequences=0, max_calls_per_device_call=0)
             t0 = time.perf_counter()
             genes = sum(len(g) for g in ex.map(finder.find_genes, seqs))
             dt = time.perf_counter() - t0
         st = finder.stats
-        out[key] = {"value": round(bases / dt / 1e6, 3), "contigs_per_s": round(len(seqs) / dt, 1), "genes": int(genes),
+        out[key] = {"value": round(bases / dt / 1e6, 3), "contigs_per_s": round(len(seqs) / dt, 1), "genes": int(genes), "threads": nthreads,
                     "device_calls": st["device_calls"], "contigs_per_device_call": round(st["sequences"] / max(st["device_calls"], 1), 1),
                     "most_calls_in_one_device_call": st["max_calls_per_device_call"]}
-        if keep:
+        if keep and nthreads == threads:
             # the lone call: one 20 kbp contig, nobody to share a device call with
             lat = []
             for s in seqs[:30]:

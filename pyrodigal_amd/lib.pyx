@@ -1335,8 +1335,20 @@ cdef class _FindRequest:
     cdef list out               # one Genes per sequence, filled in by the thread that ran the device call
     cdef object error
     cdef bint done
-    cdef object ev              # set when the result is there, or when `lead` holds a context for this caller to run the next device call
+    cdef object sem             # a lock used as a binary semaphore (C-level, no Python-side condition variable): released when the result
+                                # is there, or when `lead` holds a context for this caller to run the next device call
+    cdef bint signaled          # the semaphore was released and the owner has not looked yet (never released twice)
     cdef object lead
+
+
+cdef object _new_lock = threading.Lock
+
+
+cdef inline void _signal(_FindRequest r):
+    """(finder lock held) Wake the owner of a request: at most one release per look of the owner."""
+    if not r.signaled:
+        r.signaled = True
+        r.sem.release()
 
 
 cdef class GeneFinder:
@@ -1344,7 +1356,8 @@ cdef class GeneFinder:
 
     Re-entrant like the reference's (lib.pyx:5424-5446, README "thread-safety"): `find_genes` may be called from any number
     of threads (the reference's own CLI maps it over a thread pool, cli.py:289-302).  Concurrent calls do not queue behind a
-    lock: the finder owns up to `contexts` device contexts (one HIP stream each), and the calls that are waiting when a context
+    lock: the finder owns up to `contexts` device contexts (one HIP stream each; two by default: with one contig per call more
+    contexts only cut the same callers into smaller device calls), and the calls that are waiting when a context
     is free are packed into ONE device call (`pga_find_genes_batch` over all their sequences, at most `coalesce_bases` bases)
     by whichever caller finds the context -- so a pool of threads rides the batch path, and a lone caller pays no wait."""
     cdef readonly bint meta
@@ -1374,7 +1387,7 @@ cdef class GeneFinder:
 
     def __init__(self, TrainingInfo training_info=None, *, bint meta=False, MetagenomicBins metagenomic_bins=None,
                  bint closed=False, bint mask=False, int min_mask=50, int min_gene=90, int min_edge_gene=60,
-                 int max_overlap=60, str backend="detect", int device=0, bint keep_nodes=True, int contexts=3,
+                 int max_overlap=60, str backend="detect", int device=0, bint keep_nodes=True, int contexts=2,
                  int64_t coalesce_bases=64 << 20):
         # argument validation as in the reference (lib.pyx:5169-5181)
         if meta and training_info is not None:
@@ -1527,10 +1540,12 @@ cdef class GeneFinder:
         cdef list take
         req.seqs = seqs; req.translate = translate; req.bases = bases; req.out = None; req.error = None; req.done = False
         req.lead = None
-        req.ev = threading.Event()
+        req.signaled = False
+        req.sem = _new_lock()
+        req.sem.acquire()
         lock = self._lock
         # Either a context is free: this caller runs a device call right away, for itself and for everyone who is waiting.  Or it
-        # waits on an event of its own -- woken when its result is there, or when a context came free and it is this caller's
+        # waits on a semaphore of its own -- woken when its result is there, or when a context came free and it is this caller's
         # turn to run the next device call over whatever is waiting by then (the baton goes to the oldest waiting request: one
         # wake-up per device call, not one per waiting thread).
         with lock:
@@ -1542,14 +1557,14 @@ cdef class GeneFinder:
                 slot.busy = True
         while True:
             if slot is None:
-                req.ev.wait()
-                if req.done:
-                    break
-                req.ev.clear()
+                req.sem.acquire()                        # blocks without the GIL until somebody signals this request
                 with lock:
-                    slot = <_FinderSlot> req.lead        # the baton: a context reserved for this caller
+                    req.signaled = False
+                    slot = <_FinderSlot> req.lead        # the baton: a context reserved for this caller (or None: the result is there)
                     req.lead = None
                 if slot is None:
+                    if req.done:
+                        break
                     continue
             with lock:
                 take = self._take_pending() if self._pending else []
@@ -1559,18 +1574,11 @@ cdef class GeneFinder:
                 for r in take:
                     r.done = True
                     if r is not req:
-                        r.ev.set()
+                        _signal(r)
                 self._release_slot(slot)
             slot = None
             if req.done:
                 break
-        if req.lead is not None:
-            # the request was served by somebody else's device call while a context was on its way to this caller: pass it on
-            with lock:
-                if req.lead is not None:
-                    slot = <_FinderSlot> req.lead
-                    req.lead = None
-                    self._release_slot(slot)
         if req.error is not None:
             raise req.error
         return req.out
@@ -1581,7 +1589,7 @@ cdef class GeneFinder:
         for r in self._pending:
             if r.lead is None:
                 r.lead = slot
-                r.ev.set()
+                _signal(r)
                 return 0
         slot.busy = False
         self._cv.notify_all()
