@@ -1191,8 +1191,8 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         for (int g = 0; g < NG; g++) {
             char nm[32];
 #define GBUF(field, type, count) { snprintf(nm, sizeof nm, #field "%d", g); void* p__; int rc__ = ensure_dev(c, nm, sizeof(type) * (size_t)(count) + 64, &p__); if (rc__) return rc__; ga[g].field = (type*)p__; }
-            GBUF(nf_fwd, uint8_t, total + 1) GBUF(nf_rev, uint8_t, total + 1)
-            GBUF(pre_nodes, int32_t, total + 2) GBUF(pre_rev, int32_t, total + 2)
+            GBUF(df, uint8_t, total + 16)
+            GBUF(pre, int32_t, total + 2)
             GBUF(st_ndx, int32_t, 2 * total + 2) GBUF(st_sv, int32_t, 2 * total + 2) GBUF(st_info, uint8_t, 2 * total + 2)
             ga[g].ndx = nullptr; ga[g].stop_val = nullptr; ga[g].type = nullptr; ga[g].strand = nullptr; ga[g].edge0 = nullptr; ga[g].gc_cont = nullptr;
         }
@@ -1321,7 +1321,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             char nm[32];
             group_nodes[g] = h_cbase[(size_t)g * (NC + 1) + NC];
             const int64_t n = group_nodes[g] + 1;
-            GBUF(ndx, int32_t, n) GBUF(stop_val, int32_t, n) GBUF(type, uint8_t, n) GBUF(strand, int8_t, n) GBUF(edge0, uint8_t, n) GBUF(gc_cont, float, n)
+            GBUF(ndx, int32_t, n) GBUF(stop_val, int32_t, n) GBUF(type, uint8_t, n) GBUF(strand, int8_t, n) GBUF(edge0, uint8_t, n) GBUF(gc_cont, float, n) GBUF(contig_of, int32_t, n)
             GBUF(stop_list, int32_t, (int64_t)h_sbase[(size_t)g * (NC + 1) + NC] + 1)
             GBUF(ovl_topo, uint32_t, (int64_t)h_sbase[(size_t)g * (NC + 1) + NC] + 1)
             GBUF(srank, int32_t, n + 4)
@@ -1421,7 +1421,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
 
         tm.mark("plan+alloc");
         std::vector<int32_t> cs_tk[4], cs_en[4];
-        ScoreParams sp{P.closed, P.meta, P.max_overlap, 0, nullptr, nullptr};
+        ScoreParams sp{P.closed, P.meta, P.max_overlap, NM, nullptr, nullptr};
         DEVBUF(d_conv, uint8_t, "d_conv_flag", (size_t)NG * NC + 1);
         PINBUF(h_conv, uint8_t, "h_conv_flag", (size_t)NG * NC + 1);
         if (meta_run) HT(c, hipMemsetAsync(d_conv, 0, (size_t)NG * NC, st));

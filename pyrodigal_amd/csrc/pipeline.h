@@ -19,8 +19,10 @@ struct TileDesc {
 // (fields that do not depend on the model), indexed by global node number.
 struct GroupArrays {
     // per position (whole batch)
-    uint8_t* nf_fwd;  uint8_t* nf_rev;       // 1 = a forward / reverse node has its ndx here (written densely by the tile that owns the position)
-    int32_t* pre_nodes; int32_t* pre_rev;    // at a position with a forward / reverse node: the index of that node
+    uint8_t* df;                             // the digit of the position (bits 0-2) | 16 = a forward node has its ndx here | 32 = a reverse node has
+                                             // (written densely by the tile that owns the position): all an ORF walk reads of a position is one byte
+    int32_t* pre;                            // at a position with a node: the index of its first node (the forward one when both strands have
+                                             // one there: the reverse node then is the next, ref: lib.pyx:2489-2493)
     // staging, two slots per position: the nodes of the tile that starts at global position g, packed in order from slot 2 g
     int32_t* st_ndx; int32_t* st_sv;         // ndx, stop_val
     uint8_t* st_info;                        // type | edge << 2 | reverse << 3
@@ -30,6 +32,7 @@ struct GroupArrays {
                                              // the k-th stop of a chain owns extras record ChainDesc::soff + k of the wave-batch scorer
     // per node, in (contig, ndx, strand) order
     int32_t* ndx; int32_t* stop_val; uint8_t* type; int8_t* strand; uint8_t* edge0; float* gc_cont;
+    int32_t* contig_of = nullptr;            // the node's contig (k_place_nodes): kernels over nodes read it instead of searching the contigs' first nodes
 };
 
 // Per (contig, model) chain node fields (SoA over all chains of the batch).
@@ -59,11 +62,12 @@ struct MaskList {
 struct MaskRun { int32_t contig, begin, end, _pad; };
 
 struct ScoreParams {
-    int32_t closed, is_meta, max_overlap, _pad;
+    int32_t closed, is_meta, max_overlap, n_models;       // n_models: entries of the model array the chains index
     double* cs_out;          // or nullptr: cscore + sscore of every node, indexed like the chain arrays (what the wave-batch connection scorer reads)
     uint8_t* conv_flag;      // per contig (of the group being scored), or nullptr: set when the contig holds a start node that the
                              // reference turns into an edge node while scoring (lib.pyx:2424-2434) -- only such contigs are scored
                              // differently by the first and by a later model of a run
+    unsigned long long* prof = nullptr;   // PGA_SS_PROFILE=1: wave-cycles per phase of k_score_starts (16 slots), or nullptr
 };
 
 void pga_launch_digitize(const char* d_seq, uint8_t* d_dig, int64_t total, const ContigDesc* d_ct, int n_contigs,

@@ -545,9 +545,18 @@ k_extract_tile(const uint8_t* __restrict__ dig, int64_t total, const ContigDesc*
     if (t == 255) tile_count[tile] = nbase + cnt;
     const int64_t g0 = cd.base + G.a;
     if (r0 < G.len) {
-        // the flags of the thread's twelve positions, bytewise up to the next 4-byte boundary, then as words
+        // what the ORF walks read of the thread's twelve positions: digit | forward-node flag << 4 | reverse-node flag << 5
         const int nk = min(EX_PER_THREAD, G.len - r0);
-        for (int k = 0; k < nk; k++) { ga.nf_fwd[g0 + r0 + k] = (nf >> k) & 1u; ga.nf_rev[g0 + r0 + k] = (nr >> k) & 1u; }
+        auto spread4 = [](const unsigned x) { return ((x & 15u) * 0x00204081u) & 0x01010101u; };       // bit k -> bit 0 of byte k
+        if (nk == EX_PER_THREAD) {
+            unsigned w[3];
+            __builtin_memcpy(w, dig + g0 + r0, 12);
+#pragma unroll
+            for (int q = 0; q < 3; q++) w[q] = (w[q] & 0x07070707u) | (spread4(nf >> (4 * q)) << 4) | (spread4(nr >> (4 * q)) << 5);
+            __builtin_memcpy(ga.df + g0 + r0, w, 12);
+        } else {
+            for (int k = 0; k < nk; k++) ga.df[g0 + r0 + k] = (uint8_t)((dig[g0 + r0 + k] & 7u) | (((nf >> k) & 1u) << 4) | (((nr >> k) & 1u) << 5));
+        }
     }
     int64_t slot = 2 * g0 + nbase;
     unsigned both = nf | nr;
@@ -639,7 +648,9 @@ k_place_nodes(const ContigDesc* __restrict__ ct, const TileDesc* __restrict__ ti
             const int ndx = ga.st_ndx[s0 + j], info = ga.st_info[s0 + j];
             k = off + j;
             ga.ndx[k] = ndx; ga.stop_val[k] = ga.st_sv[s0 + j]; ga.type[k] = info & 3; ga.strand[k] = (info >> 3) & 1 ? -1 : 1; ga.edge0[k] = (info >> 2) & 1;
-            ((info >> 3) & 1 ? ga.pre_rev : ga.pre_nodes)[base + ndx] = k;
+            ga.contig_of[k] = td.contig;
+            // the position learns its first node: a reverse node right after the forward node of the same position is the second
+            if (!((info >> 3) & 1) || j == 0 || ga.st_ndx[s0 + j - 1] != ndx) ga.pre[base + ndx] = k;
             is_stop = (info & 3) == PGA_T_STOP;
         }
         const unsigned long long bal = __ballot(is_stop);
@@ -713,9 +724,7 @@ k_orf_gc(const ContigDesc* __restrict__ ct, int n_contigs, const uint8_t* __rest
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes_total) return;
     if (ga.type[i] == PGA_T_STOP) { ga.gc_cont[i] = 0.f; return; }
-    // contig of this node: binary search on first-node offsets
-    int lo = 0, hi = n_contigs - 1;
-    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (node_contig_base[mid] <= i) lo = mid; else hi = mid - 1; }
+    const int lo = ga.contig_of[i];
     const int L = ct[lo].len;
     const int64_t base = ct[lo].base;
     auto P = [&](const int x) { return gc_prefix(dig, p16, base + x); };
@@ -738,7 +747,7 @@ k_orf_gc(const ContigDesc* __restrict__ ct, int n_contigs, const uint8_t* __rest
 __device__ __forceinline__ int hexamer(const uint8_t* __restrict__ d, int pos, int strand) {
     int v = 0;   // ref: _sequence.h:207-220; pos = forward coordinate of the first base read
     if (strand == 1) { for (int j = 0; j < 6; j++) v |= (d[pos + j] & 3) << (2 * j); }
-    else             { for (int j = 0; j < 6; j++) v |= (comp2(d[pos - j]) & 3) << (2 * j); }
+    else             { for (int j = 0; j < 6; j++) v |= (comp2(d[pos - j] & 7) & 3) << (2 * j); }       // & 7: GroupArrays::df carries node flags above the digit
     return v;
 }
 
@@ -756,9 +765,13 @@ constexpr int CS_MODELS = 4;
 constexpr int CS_LONG = 192;
 
 struct OrfCtx {
-    const uint8_t* d; const uint8_t* nf; const int32_t* pre;      // digits, node flags and node indices of the ORF's strand, by position
+    const uint8_t* d;             // GroupArrays::df of the contig: digit | forward-node flag << 4 | reverse-node flag << 5, by position
+    const int32_t* pre;           // GroupArrays::pre of the contig: index of the first node of a position
     int tbase, p, q, L, strand, step, ncod;
     int2 cc;
+    // the walk's own strand has a node at position j / that node's index in the contig
+    __device__ __forceinline__ bool node_at(const int j) const { return (d[j] >> (strand == 1 ? 4 : 5)) & 1; }
+    __device__ __forceinline__ int node_index(const int j) const { return pre[j] - tbase + (strand == 1 ? 0 : (d[j] >> 4) & 1); }
 };
 
 __device__ __forceinline__ double wave_incl_max(double v, int lane) {
@@ -843,28 +856,31 @@ __device__ __forceinline__ void orf_serial(const OrfCtx& o, const ChainDesc* __r
         };
         if (o.ncod > 0) {
             const int j = p + step; mer = hexamer(d, j, strand);
-            const bool isnode = o.nf[j] != 0;
-            visit(0, isnode, isnode ? o.pre[j] - o.tbase : 0);
+            const bool isnode = o.node_at(j);
+            visit(0, isnode, isnode ? o.node_index(j) : 0);
         }
-        // Five codons at a time: their 15 bases and the start flags of those positions are 16 contiguous bytes each, one
-        // (unaligned) load per array instead of four byte loads per codon -- every lane walks its own ORF, so each load
+        // Five codons at a time: their 15 bases and the start flags of those positions are 16 contiguous bytes of GroupArrays::df,
+        // one (unaligned) load instead of four byte loads per codon -- every lane walks its own ORF, so each load
         // instruction costs the address path 64 distinct lines whatever its width.  Nothing a group needs is loaded while the
-        // group is walked: its bases were asked for one group earlier, its flags two groups earlier, and the node indices of its
-        // flagged positions one group earlier (from the flags, by then in registers) -- in lock step some lane meets a start
-        // node at nearly every codon, and a load there would make every codon wait out a memory round trip.
+        // group is walked: its bytes were asked for two groups earlier, and the node indices of its flagged positions one group
+        // earlier (from the flags, by then in registers) -- in lock step some lane meets a start node at nearly every codon, and
+        // a load there would make every codon wait out a memory round trip.
         struct W16 { unsigned long long a, b; };
         auto group_lo = [&](const int c0) { return strand == 1 ? p - 3 * (c0 + 5) : p + 3 * c0 + 1; };       // lowest position of the group
         auto byte_of = [](const W16& w, const int k) { return (unsigned)((k < 8 ? w.a >> (8 * k) : w.b >> (8 * (k - 8))) & 0xffull); };
         auto flag_off = [&](const int u) { return strand == 1 ? 12 - 3 * u : 3 * u + 2; };                 // offset of codon u's node flag in the group
-        W16 B1{0, 0}, F1{0, 0}, F2{0, 0};
+        const int fbit = strand == 1 ? 4 : 5;
+        // the index of the walk's node at offset k of a group starting at lo: a reverse node follows the forward node of its position
+        auto node_of = [&](const W16& w, const int lo, const int k) { return o.pre[lo + k] + (strand == 1 ? 0 : (int)((byte_of(w, k) >> 4) & 1u)); };
+        W16 D1{0, 0}, D2{0, 0};
         int kq[5] = {0, 0, 0, 0, 0};
         const int ncod = o.ncod;
-        // prologue: bases and flags of the first group, flags of the second; then the node indices of the first
-        if (ncod > 1 && group_lo(1) >= 0) { __builtin_memcpy(&B1, d + group_lo(1), 16); __builtin_memcpy(&F1, o.nf + group_lo(1), 16); }
-        if (ncod > 6 && group_lo(6) >= 0) __builtin_memcpy(&F2, o.nf + group_lo(6), 16);
+        // prologue: the bytes of the first and the second group; then the node indices of the first
+        if (ncod > 1 && group_lo(1) >= 0) __builtin_memcpy(&D1, d + group_lo(1), 16);
+        if (ncod > 6 && group_lo(6) >= 0) __builtin_memcpy(&D2, d + group_lo(6), 16);
         if (ncod > 1 && group_lo(1) >= 0) {
 #pragma unroll
-            for (int u = 0; u < 5; u++) if (1 + u < ncod && byte_of(F1, flag_off(u))) kq[u] = o.pre[group_lo(1) + flag_off(u)];
+            for (int u = 0; u < 5; u++) if (1 + u < ncod && ((byte_of(D1, flag_off(u)) >> fbit) & 1u)) kq[u] = node_of(D1, group_lo(1), flag_off(u));
         }
         for (int c0 = 1; c0 < ncod; c0 += 5) {
             const int lo = group_lo(c0);
@@ -874,25 +890,24 @@ __device__ __forceinline__ void orf_serial(const OrfCtx& o, const ChainDesc* __r
                     const int j = p + step * (ci + 1);
                     const int lo3 = (d[j] & 3) | ((d[j + 1] & 3) << 2) | ((d[j + 2] & 3) << 4);          // strand == 1 here
                     mer = ((mer << 6) & 0xfc0) | lo3;
-                    const bool isnode = o.nf[j] != 0;
-                    visit(ci, isnode, isnode ? o.pre[j] - o.tbase : 0);
+                    const bool isnode = o.node_at(j);
+                    visit(ci, isnode, isnode ? o.node_index(j) : 0);
                 }
                 continue;
             }
             // everything of this group is here; ask for what the next groups need
-            const W16 B = B1, F = F1;
+            const W16 B = D1;
             int kc[5];
 #pragma unroll
             for (int u = 0; u < 5; u++) kc[u] = kq[u] - o.tbase;
-            F1 = F2;
+            D1 = D2;
             if (c0 + 5 < ncod) {
                 const int lo1 = group_lo(c0 + 5);
                 if (lo1 >= 0) {
-                    __builtin_memcpy(&B1, d + lo1, 16);
 #pragma unroll
-                    for (int u = 0; u < 5; u++) if (c0 + 5 + u < ncod && byte_of(F1, flag_off(u))) kq[u] = o.pre[lo1 + flag_off(u)];
+                    for (int u = 0; u < 5; u++) if (c0 + 5 + u < ncod && ((byte_of(D1, flag_off(u)) >> fbit) & 1u)) kq[u] = node_of(D1, lo1, flag_off(u));
                 }
-                if (c0 + 10 < ncod) { const int lo2 = group_lo(c0 + 10); if (lo2 >= 0) __builtin_memcpy(&F2, o.nf + lo2, 16); }
+                if (c0 + 10 < ncod) { const int lo2 = group_lo(c0 + 10); if (lo2 >= 0) __builtin_memcpy(&D2, d + lo2, 16); }
             }
             auto bytes_at = [](const W16& w, const int k) {          // the (up to 8) bytes from offset k on, k <= 13
                 return k < 8 ? (w.a >> (8 * k)) | (k ? w.b << (64 - 8 * k) : 0ull) : w.b >> (8 * (k - 8));
@@ -903,12 +918,12 @@ __device__ __forceinline__ void orf_serial(const OrfCtx& o, const ChainDesc* __r
                 if (ci >= ncod) break;
                 const int k = strand == 1 ? 12 - 3 * u : 3 * u;             // offset of the codon's lowest position
                 const unsigned t3 = (unsigned)bytes_at(B, k);
-                const int b0 = t3 & 0xff, b1 = (t3 >> 8) & 0xff, b2 = (t3 >> 16) & 0xff;
+                const int b0 = t3 & 7, b1 = (t3 >> 8) & 7, b2 = (t3 >> 16) & 7;
                 // rolling update: the three bases nearest to the walk direction are new (ref: _sequence.h:207-220)
                 const int lo3 = strand == 1 ? (b0 & 3) | ((b1 & 3) << 2) | ((b2 & 3) << 4)
                                             : (comp2(b2) & 3) | ((comp2(b1) & 3) << 2) | ((comp2(b0) & 3) << 4);
                 mer = ((mer << 6) & 0xfc0) | lo3;
-                visit(ci, byte_of(F, flag_off(u)) != 0, kc[u]);
+                visit(ci, ((byte_of(B, flag_off(u)) >> fbit) & 1u) != 0, kc[u]);
             }
         }
         if (far < 0) continue;
@@ -924,11 +939,11 @@ __device__ __forceinline__ void orf_serial(const OrfCtx& o, const ChainDesc* __r
                 const int c0 = 1 + 5 * ((ci - 1) / 5), u = ci - c0;
                 const int lo = group_lo(c0);
                 bool isnode;
-                if (lo < 0) isnode = o.nf[p + step * (ci + 1)] != 0;
+                if (lo < 0) isnode = o.node_at(p + step * (ci + 1));
                 else {
-                    if (c0 != fc0) { __builtin_memcpy(&G2, o.nf + lo, 16); fc0 = c0; }
+                    if (c0 != fc0) { __builtin_memcpy(&G2, d + lo, 16); fc0 = c0; }
                     const int kn = strand == 1 ? 12 - 3 * u : 3 * u + 2;
-                    isnode = ((kn < 8 ? G2.a >> (8 * kn) : G2.b >> (8 * (kn - 8))) & 0xffull) != 0;
+                    isnode = ((byte_of(G2, kn) >> fbit) & 1u) != 0;
                 }
                 if (!isnode) { ci--; continue; }
             } else {
@@ -938,7 +953,7 @@ __device__ __forceinline__ void orf_serial(const OrfCtx& o, const ChainDesc* __r
                 ci = wsel * 64 + 63 - __builtin_clzll(bits);
             }
             const int j = p + step * (ci + 1);
-            const int k = o.pre[j] - o.tbase;
+            const int k = o.node_index(j);
 #pragma unroll
             for (int m = 0; m < CS_MODELS; m++) {
                 if (m >= nm) continue;
@@ -998,8 +1013,8 @@ __device__ __forceinline__ void orf_serial_quad(const OrfCtx& o, const ChainDesc
     };
     if (ncod > 0) {
         const int j = p + step; mer = hexamer(d, j, strand);
-        const bool isnode = o.nf[j] != 0;
-        visit(0, isnode, isnode ? o.pre[j] - o.tbase : 0);
+        const bool isnode = o.node_at(j);
+        visit(0, isnode, isnode ? o.node_index(j) : 0);
     }
     struct W16 { unsigned long long a, b; };
     auto group_lo = [&](const int c0) { return fwd ? p - 3 * (c0 + 5) : p + 3 * c0 + 1; };       // lowest position of the group
@@ -1011,22 +1026,26 @@ __device__ __forceinline__ void orf_serial_quad(const OrfCtx& o, const ChainDesc
         const unsigned q = (unsigned)pack16(v, !fwd);
         return fwd ? q : pairrev32(q);
     };
-    auto flags_of = [&](const W16& w) -> unsigned {
-        auto bits4 = [](const unsigned x) { const unsigned n = x & 0x01010101u; return (n | (n >> 7) | (n >> 14) | (n >> 21)) & 0xfu; };
+    // bit `bit` of the sixteen bytes as sixteen bits (4: forward-node flags, 5: reverse-node flags)
+    auto flags_of = [&](const W16& w, const int bit) -> unsigned {
+        auto bits4 = [&](const unsigned x) { const unsigned n = (x >> bit) & 0x01010101u; return (n | (n >> 7) | (n >> 14) | (n >> 21)) & 0xfu; };
         const unsigned f = bits4((unsigned)w.a) | (bits4((unsigned)(w.a >> 32)) << 4) | (bits4((unsigned)w.b) << 8) | (bits4((unsigned)(w.b >> 32)) << 12);
         return fwd ? f : (__brev(f) >> 16);
     };
+    const int fbit = fwd ? 4 : 5;
     const int dsh = fwd ? 24 : 26, fsh = fwd ? 12 : 13;       // codon u: digits at bit dsh - 6u, flag at bit fsh - 3u
     const int foff0 = fwd ? 12 : 2, fstep = fwd ? -3 : 3;     // the flag's byte offset in the group as loaded: foff0 + fstep * u
-    W16 B1{0, 0}, F1{0, 0}, F2{0, 0};
+    W16 D1{0, 0}, D2{0, 0};
     int kq[5] = {0, 0, 0, 0, 0};
-    // prologue: bases and flags of the first group, flags of the second; then the node indices of the first
-    if (ncod > 1 && group_lo(1) >= 0) { __builtin_memcpy(&B1, d + group_lo(1), 16); __builtin_memcpy(&F1, o.nf + group_lo(1), 16); }
-    if (ncod > 6 && group_lo(6) >= 0) __builtin_memcpy(&F2, o.nf + group_lo(6), 16);
-    unsigned fb1 = flags_of(F1);
+    // prologue: the bytes of the first and of the second group; then the node indices of the first (a reverse node follows the
+    // forward node of its position: ff1 = the forward flags where the walk is a reverse one)
+    if (ncod > 1 && group_lo(1) >= 0) __builtin_memcpy(&D1, d + group_lo(1), 16);
+    if (ncod > 6 && group_lo(6) >= 0) __builtin_memcpy(&D2, d + group_lo(6), 16);
+    unsigned fb1 = flags_of(D1, fbit), ff1 = fwd ? 0u : flags_of(D1, 4);
     if (ncod > 1 && group_lo(1) >= 0) {
 #pragma unroll
-        for (int u = 0; u < 5; u++) if (1 + u < ncod && ((fb1 >> (fsh - 3 * u)) & 1u)) kq[u] = o.pre[group_lo(1) + foff0 + fstep * u];
+        for (int u = 0; u < 5; u++)
+            if (1 + u < ncod && ((fb1 >> (fsh - 3 * u)) & 1u)) kq[u] = o.pre[group_lo(1) + foff0 + fstep * u] + (int)((ff1 >> (fsh - 3 * u)) & 1u);
     }
     qmark(10);
     // the group counter is the same in every lane (scalar): a lane whose ORF has ended idles through the rest, loading nothing
@@ -1042,25 +1061,26 @@ __device__ __forceinline__ void orf_serial_quad(const OrfCtx& o, const ChainDesc
                 const int j = p + step * (ci + 1);
                 const int lo3 = (d[j] & 3) | ((d[j + 1] & 3) << 2) | ((d[j + 2] & 3) << 4);          // forward strand here
                 mer = ((mer << 6) & 0xfc0) | lo3;
-                const bool isnode = o.nf[j] != 0;
-                visit(ci, isnode, isnode ? o.pre[j] - o.tbase : 0);
+                const bool isnode = o.node_at(j);
+                visit(ci, isnode, isnode ? o.node_index(j) : 0);
             }
             continue;
         }
         // everything of this group is here; ask for what the next groups need
-        const unsigned dg = digits_of(B1), fb = fb1;
+        const unsigned dg = digits_of(D1), fb = fb1;
         int kc[5];
 #pragma unroll
         for (int u = 0; u < 5; u++) kc[u] = kq[u] - o.tbase;
-        fb1 = flags_of(F2);
+        D1 = D2;
+        fb1 = flags_of(D1, fbit); ff1 = fwd ? 0u : flags_of(D1, 4);
         if (c0 + 5 < ncod) {
             const int lo1 = group_lo(c0 + 5);
             if (lo1 >= 0) {
-                __builtin_memcpy(&B1, d + lo1, 16);
 #pragma unroll
-                for (int u = 0; u < 5; u++) if (c0 + 5 + u < ncod && ((fb1 >> (fsh - 3 * u)) & 1u)) kq[u] = o.pre[lo1 + foff0 + fstep * u];
+                for (int u = 0; u < 5; u++)
+                    if (c0 + 5 + u < ncod && ((fb1 >> (fsh - 3 * u)) & 1u)) kq[u] = o.pre[lo1 + foff0 + fstep * u] + (int)((ff1 >> (fsh - 3 * u)) & 1u);
             }
-            if (c0 + 10 < ncod) { const int lo2 = group_lo(c0 + 10); if (lo2 >= 0) __builtin_memcpy(&F2, o.nf + lo2, 16); }
+            if (c0 + 10 < ncod) { const int lo2 = group_lo(c0 + 10); if (lo2 >= 0) __builtin_memcpy(&D2, d + lo2, 16); }
         }
 #pragma unroll
         for (int u = 0; u < 5; u++) {
@@ -1083,11 +1103,11 @@ __device__ __forceinline__ void orf_serial_quad(const OrfCtx& o, const ChainDesc
             const int c0 = 1 + 5 * ((ci - 1) / 5), u = ci - c0;
             const int lo = group_lo(c0);
             bool isnode;
-            if (lo < 0) isnode = o.nf[p + step * (ci + 1)] != 0;
+            if (lo < 0) isnode = o.node_at(p + step * (ci + 1));
             else {
-                if (c0 != fc0) { __builtin_memcpy(&G2, o.nf + lo, 16); fc0 = c0; }
+                if (c0 != fc0) { __builtin_memcpy(&G2, d + lo, 16); fc0 = c0; }
                 const int kn = foff0 + fstep * u;
-                isnode = ((kn < 8 ? G2.a >> (8 * kn) : G2.b >> (8 * (kn - 8))) & 0xffull) != 0;
+                isnode = (((kn < 8 ? G2.a >> (8 * kn) : G2.b >> (8 * (kn - 8))) >> fbit) & 1ull) != 0;
             }
             if (!isnode) { ci--; continue; }
         } else {
@@ -1097,7 +1117,7 @@ __device__ __forceinline__ void orf_serial_quad(const OrfCtx& o, const ChainDesc
             ci = wsel * 64 + 63 - __builtin_clzll(bits);
         }
         const int j = p + step * (ci + 1);
-        const int k = o.pre[j] - o.tbase;
+        const int k = o.node_index(j);
 #pragma unroll
         for (int m = 0; m < CS_MODELS; m++) {
             if (m >= nm) continue;
@@ -1138,8 +1158,8 @@ __device__ __forceinline__ void orf_wave(const OrfCtx& o, const int lane, const 
             const bool valid = ci < ncod;
             const int x = p + step * (ci + 1);
             const int mer = valid ? hexamer(o.d, x, strand) : 0;
-            const bool fl = valid && o.nf[x] != 0;
-            const int k = fl ? o.pre[x] - o.tbase : 0;
+            const bool fl = valid && o.node_at(x);
+            const int k = fl ? o.node_index(x) : 0;
             double v[CS_MODELS], pref[CS_MODELS];
 #pragma unroll
             for (int m = 0; m < CS_MODELS; m++) { v[m] = (valid && m < nm) ? (quad != nullptr ? quad[4 * mer + m] : gdc[m][mer]) : 0.0; pref[m] = 0.0; }
@@ -1166,8 +1186,8 @@ __device__ __forceinline__ void orf_wave(const OrfCtx& o, const int lane, const 
             const int ci = c0 + (63 - lane);            // lane order = outermost first
             const bool valid = ci < ncod;
             const int x = p + step * (ci + 1);
-            const bool fl = valid && o.nf[x] != 0;
-            const int k = fl ? o.pre[x] - o.tbase : 0;
+            const bool fl = valid && o.node_at(x);
+            const int k = fl ? o.node_index(x) : 0;
 #pragma unroll
             for (int m = 0; m < CS_MODELS; m++) {
                 if (m >= nm) break;
@@ -1217,8 +1237,8 @@ __device__ __forceinline__ void orf_quarter(const OrfCtx& o, const bool has, con
         const bool valid = ci < ncod;
         const int x = p + step * (ci + 1);
         const int mer = valid ? hexamer(o.d, x, strand) : 0;
-        const bool fl = valid && o.nf[x] != 0;
-        const int k = fl ? o.pre[x] - o.tbase : 0;
+        const bool fl = valid && o.node_at(x);
+        const int k = fl ? o.node_index(x) : 0;
         double v[CS_MODELS], acc[CS_MODELS];
 #pragma unroll
         for (int m = 0; m < CS_MODELS; m++) { v[m] = (valid && m < nm) ? quad[4 * mer + m] : 0.0; acc[m] = carry[m]; }
@@ -1251,8 +1271,8 @@ __device__ __forceinline__ void orf_quarter(const OrfCtx& o, const bool has, con
         const int ci = c0 + (15 - sl);              // lane order = outermost first
         const bool valid = c0 >= 0 && ci < ncod;
         const int x = p + step * (ci + 1);
-        const bool fl = valid && o.nf[x] != 0;
-        const int k = fl ? o.pre[x] - o.tbase : 0;
+        const bool fl = valid && o.node_at(x);
+        const int k = fl ? o.node_index(x) : 0;
 #pragma unroll
         for (int m = 0; m < CS_MODELS; m++) {
             const bool mine = fl && m < nm;
@@ -1311,10 +1331,9 @@ k_coding_score(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
         const int c = lo;
         o.cc = contig_chains[c];
         const ContigDesc cd = ct[c];
-        o.d = dig + cd.base;
+        o.d = ga.df + cd.base;
         o.strand = ga.strand[t];
-        o.nf = (o.strand == 1 ? ga.nf_fwd : ga.nf_rev) + cd.base;
-        o.pre = (o.strand == 1 ? ga.pre_nodes : ga.pre_rev) + cd.base;
+        o.pre = ga.pre + cd.base;
         o.tbase = node_contig_base[c];
         o.p = ga.ndx[t]; o.q = ga.stop_val[t]; o.L = cd.len;
         o.step = o.strand == 1 ? -3 : 3;
@@ -1338,13 +1357,13 @@ k_coding_score(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
         const int src = __builtin_ctzll(longs);
         longs &= longs - 1ull;
         OrfCtx w;
-        const unsigned long long pd = (unsigned long long)o.d, pn = (unsigned long long)o.nf, pp = (unsigned long long)o.pre;
+        const unsigned long long pd = (unsigned long long)o.d, pp = (unsigned long long)o.pre;
         auto bc64 = [&](unsigned long long v) {
             const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
             const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
             return ((unsigned long long)hi << 32) | lo;
         };
-        w.d = (const uint8_t*)bc64(pd); w.nf = (const uint8_t*)bc64(pn); w.pre = (const int32_t*)bc64(pp);
+        w.d = (const uint8_t*)bc64(pd); w.pre = (const int32_t*)bc64(pp);
         w.tbase = __builtin_amdgcn_readlane(o.tbase, src); w.p = __builtin_amdgcn_readlane(o.p, src); w.q = __builtin_amdgcn_readlane(o.q, src);
         w.L = __builtin_amdgcn_readlane(o.L, src); w.strand = __builtin_amdgcn_readlane(o.strand, src); w.step = __builtin_amdgcn_readlane(o.step, src);
         w.ncod = __builtin_amdgcn_readlane(o.ncod, src);
@@ -1363,7 +1382,11 @@ struct CsEntry { int32_t contig, m0, first, count; };      // nodes [first, firs
 constexpr int CS_TASK_THREADS = 1024;
 constexpr int CS_TASK_MAX_ENTRIES = 256;
 constexpr int CS_ROUND = 8192;                         // nodes examined per round of a task (= the task size pga_cs_tasks aims at)
-constexpr int CS_LIST = 6144;                          // stop nodes of a round: at most half of its nodes (every ORF with a stop node has a start node) + a few at its edges
+constexpr int CS_LIST = 5120;                          // stop nodes of a round: at most half of its nodes (every ORF with a stop node has a start node), plus
+                                                       // up to twelve where a task holds a PIECE of a contig (ORFs across the cut; pga_cs_tasks allows CS_TASK_MAX_CUTS)
+constexpr int CS_TASK_MAX_CUTS = 64;
+// what the walks of a task need of one of its entries, staged in LDS once (a stop node then costs one round trip, not four)
+struct CsEnt { int64_t base; int32_t len, tbase, ccx, ccy, m0, first; };
 constexpr int CS_CLASSES = 12;                         // ORF length classes of a round
 constexpr int CS_WAVE = 2048;                          // ORFs longer than this take a whole wave (orf_wave); the others walk 64 to a wave
 __global__ void __launch_bounds__(CS_TASK_THREADS)
@@ -1374,7 +1397,8 @@ k_coding_score_quads(const CsTask* __restrict__ tasks, const CsEntry* __restrict
                      const double* __restrict__ gil, int il_stride, const int32_t* __restrict__ rank, const int cs_wave, unsigned long long* __restrict__ prof) {
     extern __shared__ __attribute__((aligned(16))) double s_quad[];                  // [4096][4]
     __shared__ int s_pre[CS_TASK_MAX_ENTRIES + 1];      // first node (task-local numbering) of every entry
-    __shared__ int s_list[CS_LIST];
+    __shared__ int s_list[CS_LIST];                     // node of the round (bits 0-12) | entry << 13
+    __shared__ CsEnt s_ent[CS_TASK_MAX_ENTRIES];
     __shared__ int s_count, s_next_long, s_next_q, s_next, s_qend;
     __shared__ int s_cls[CS_CLASSES];
     const CsTask task = tasks[blockIdx.x];
@@ -1392,12 +1416,29 @@ k_coding_score_quads(const CsTask* __restrict__ tasks, const CsEntry* __restrict
         const int h = idx >> 2, k = idx & 3;
         s_quad[idx] = task.q + k < il_stride ? gil[(size_t)h * il_stride + task.q + k] : 0.0;
     }
-    if (tid == 0) {
-        int acc = 0;
-        for (int e = 0; e < task.count; e++) {
-            s_pre[e] = acc; acc += entries[task.first + e].count;
+    if (tid <= CS_TASK_MAX_ENTRIES) {
+        int cnt = 0;
+        if (tid < task.count) {
+            const CsEntry en = entries[task.first + tid];
+            const ContigDesc cd = ct[en.contig];
+            const int2 cc = contig_chains[en.contig];
+            s_ent[tid] = CsEnt{cd.base, cd.len, node_contig_base[en.contig], cc.x, cc.y, en.m0, en.first};
+            cnt = en.count;
         }
-        s_pre[task.count] = acc;
+        s_pre[tid] = cnt;
+    }
+    __syncthreads();
+    if (wv == 0) {          // counts -> first nodes: four entries per lane
+        int v[4], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { v[q] = s_pre[4 * lane + q]; sum += v[q]; }
+        int inc = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int x = __shfl_up(inc, off, 64); if (lane >= off) inc += x; }
+        int run = inc - sum;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { s_pre[4 * lane + q] = run; run += v[q]; }
+        if (lane == 63) s_pre[CS_TASK_MAX_ENTRIES] = run;
     }
     __syncthreads();
     mark(0);
@@ -1409,7 +1450,7 @@ k_coding_score_quads(const CsTask* __restrict__ tasks, const CsEntry* __restrict
         // similar length instead of waiting for the longest of a random 64
         if (tid < CS_CLASSES) s_cls[tid] = 0;
         __syncthreads();
-        int my_cls[CS_ROUND / CS_TASK_THREADS];
+        int my_cls[CS_ROUND / CS_TASK_THREADS];             // length class | entry << 4, or -1
 #pragma unroll
         for (int r = 0; r < CS_ROUND / CS_TASK_THREADS; r++) {
             const int local = base + tid + r * CS_TASK_THREADS;
@@ -1417,15 +1458,14 @@ k_coding_score_quads(const CsTask* __restrict__ tasks, const CsEntry* __restrict
             if (local >= total) continue;
             int lo = 0, hi = task.count - 1;
             while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_pre[mid] <= local) lo = mid; else hi = mid - 1; }
-            const CsEntry en = entries[task.first + lo];
-            const int c = en.contig;
-            const int t = node_contig_base[c] + en.first + (local - s_pre[lo]);
+            const int t = s_ent[lo].tbase + s_ent[lo].first + (local - s_pre[lo]);
             if (ga.type[t] != PGA_T_STOP) continue;
-            const int ncod = orf_codons(ga.ndx[t], ga.stop_val[t], ga.strand[t], ct[c].len);
+            const int ncod = orf_codons(ga.ndx[t], ga.stop_val[t], ga.strand[t], s_ent[lo].len);
             if (ncod <= 0) continue;
             my_cls[r] = ncod > cs_wave ? 0 : ncod > 512 ? 1 : ncod > 384 ? 2 : ncod > 256 ? 3 : ncod > 192 ? 4 : ncod > 128 ? 5 : ncod > 96 ? 6 :
                         ncod > 64 ? 7 : ncod > 48 ? 8 : ncod > 32 ? 9 : ncod > 16 ? 10 : 11;
             atomicAdd(&s_cls[my_cls[r]], 1);
+            my_cls[r] |= lo << 4;
         }
         __syncthreads();
         if (tid == 0) {
@@ -1438,26 +1478,22 @@ k_coding_score_quads(const CsTask* __restrict__ tasks, const CsEntry* __restrict
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < CS_ROUND / CS_TASK_THREADS; r++)
-            if (my_cls[r] >= 0) s_list[atomicAdd(&s_cls[my_cls[r]], 1)] = base + tid + r * CS_TASK_THREADS;
+            if (my_cls[r] >= 0) s_list[atomicAdd(&s_cls[my_cls[r] & 15], 1)] = (tid + r * CS_TASK_THREADS) | ((my_cls[r] >> 4) << 13);
         __syncthreads();
         mark(1);
         const int cnt = s_count, n_long = s_cls[0];       // after the placement s_cls[k] is where class k ends
-        auto orf_of = [&](const int loc, int& m0) {
+        auto orf_of = [&](const int packed, int& m0) {
             OrfCtx o{};
-            int lo = 0, hi = task.count - 1;
-            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_pre[mid] <= loc) lo = mid; else hi = mid - 1; }
-            const CsEntry en = entries[task.first + lo];
-            const int c = en.contig;
+            const int lo = packed >> 13, loc = base + (packed & 8191);
+            const CsEnt en = s_ent[lo];
             m0 = en.m0;
-            const int tt = node_contig_base[c] + en.first + (loc - s_pre[lo]);
-            o.cc = contig_chains[c];
-            const ContigDesc cd = ct[c];
-            o.d = dig + cd.base;
+            const int tt = en.tbase + en.first + (loc - s_pre[lo]);
+            o.cc = make_int2(en.ccx, en.ccy);
+            o.d = ga.df + en.base;
             o.strand = ga.strand[tt];
-            o.nf = (o.strand == 1 ? ga.nf_fwd : ga.nf_rev) + cd.base;
-            o.pre = (o.strand == 1 ? ga.pre_nodes : ga.pre_rev) + cd.base;
-            o.tbase = node_contig_base[c];
-            o.p = ga.ndx[tt]; o.q = ga.stop_val[tt]; o.L = cd.len;
+            o.pre = ga.pre + en.base;
+            o.tbase = en.tbase;
+            o.p = ga.ndx[tt]; o.q = ga.stop_val[tt]; o.L = en.len;
             o.step = o.strand == 1 ? -3 : 3;
             o.ncod = o.cc.y <= 0 ? 0 : orf_codons(o.p, o.q, o.strand, o.L);
             return o;
@@ -1675,127 +1711,231 @@ struct StartModel {
     double mk1[4][256];     // mot_wt[1][spacer class][4-base motif]
 };
 
-__global__ void __launch_bounds__(256, 4)
+constexpr int SS_EDGE_SPAN = 12;        // the edge nodes of a contig are among its first and its last twelve nodes (see the scan below)
+constexpr int SS_EDGE_CONTIGS = 4;      // contigs of a workgroup whose edge candidates are staged in LDS (the others read global memory)
+constexpr int SS_MASK_WORDS = 8;        // models per pass over the workgroup's model set: 512
+
+// What the scan for an edge node of the same ORF needs of candidate q of a contig (nodes [tb, tb + nn), length Lc): its stop_val
+// and 4 (it exists) | 1 (edge node) | 2 (this pass converts it to one, ref: lib.pyx:2424-2434).
+__device__ __forceinline__ int2 edge_candidate(const GroupArrays& ga, const int tb, const int nn, const int Lc, const int q, const bool closed) {
+    const int j = q < SS_EDGE_SPAN ? q : nn - 2 * SS_EDGE_SPAN + q;
+    if (j < 0 || j >= nn || (q >= SS_EDGE_SPAN && j < SS_EDGE_SPAN)) return make_int2(0, 0);       // short contig: each node once
+    const int svj = ga.stop_val[tb + j], ej = ga.edge0[tb + j], ty = ga.type[tb + j], x = ga.ndx[tb + j], sj = ga.strand[tb + j];
+    const bool cv = !closed && ty != PGA_T_STOP && !ej && ((x <= 2 && sj == 1) || (x >= Lc - 3 && sj == -1));
+    return make_int2(svj, 4 | (ej ? 1 : 0) | (cv ? 2 : 0));
+}
+
+// The model loop keeps TWO staged models: while the workgroup scores its nodes for one, the next one it will need (known from a
+// bit set of the models its contigs have) is on its way into the other buffer -- one barrier per model.
+template <int OCC>
+__global__ void __launch_bounds__(256, OCC)
 k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ contig_chains,
                const int32_t* __restrict__ node_contig_base, int n_contigs, int n_nodes,
                const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct, GroupArrays ga,
                const pga_training* __restrict__ models, ChainArrays ca, ScoreParams sp, const unsigned* __restrict__ sd_lut) {
-    __shared__ int s_c0, s_mlo, s_mhi;
+    __shared__ unsigned long long s_present[SS_MASK_WORDS];
     __shared__ unsigned s_lut[PGA_SD_LUT];
-    __shared__ StartModel SM;
-    for (int k = threadIdx.x; k < PGA_SD_LUT; k += blockDim.x) s_lut[k] = sd_lut[k];
+    __shared__ int2 s_edge[SS_EDGE_CONTIGS][2 * SS_EDGE_SPAN];
+    __shared__ StartModel SMB[2];
+    unsigned long long* __restrict__ prof = sp.prof;
+    unsigned long long tp = prof ? __builtin_readcyclecounter() : 0;
+    // the first active lane books the time since the wave's last mark; conv: all lanes are here again, some may have skipped marks
+    auto mark = [&](const int slot, const bool conv = false) {
+        if (!prof) return;
+        if (conv) {
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) { const unsigned long long o = __shfl_xor(tp, m, 64); tp = o > tp ? o : tp; }
+        }
+        const unsigned long long now = __builtin_readcyclecounter();
+        if ((int)(threadIdx.x & 63) == __builtin_ctzll(__ballot(1))) atomicAdd(&prof[slot], now - tp);
+        tp = now;
+    };
+    const int tid = threadIdx.x;
     const int blk0 = blockIdx.x * blockDim.x;
-    const int t = blk0 + threadIdx.x;
-    // contig of the block's first node, then a short forward walk
-    if (threadIdx.x == 0) {
-        int lo = 0, hi = n_contigs - 1;
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (node_contig_base[mid] <= blk0) lo = mid; else hi = mid - 1; }
-        s_c0 = lo; s_mlo = 0x7fffffff; s_mhi = -1;
-    }
-    __syncthreads();
-    int c = s_c0;
+    const int t = blk0 + tid;
+    const bool closed = sp.closed != 0, is_meta = sp.is_meta != 0;
+    if (tid < SS_MASK_WORDS) s_present[tid] = 0ull;
     const bool in_range = t < n_nodes;
-    if (in_range) while (c + 1 < n_contigs && node_contig_base[c + 1] <= t) c++;
+    const int c0 = ga.contig_of[blk0];                   // blk0 < n_nodes; the same address in every thread
+    const int c = in_range ? ga.contig_of[t] : c0;
     const int2 cc = in_range ? contig_chains[c] : make_int2(0, 0);
     const bool has = in_range && cc.y > 0;
-    // the models this workgroup scores: from the first model of its first chain to the last of its last
-    if (has) { atomicMin(&s_mlo, chains[cc.x].model); atomicMax(&s_mhi, chains[cc.x + cc.y - 1].model); }
+    // (the model set is empty from here on)  A launch over the re-scored winners finds most workgroups without a chain.
+    if (!__syncthreads_or(has)) return;
+    for (int k = tid; k < PGA_SD_LUT; k += blockDim.x) s_lut[k] = sd_lut[k];
+    // the thread's next chain (what the scorer reads of its descriptor), fetched one model ahead
+    int64_t ch_off = 0, ch_raw = -1; int ch_model = 0x7fffffff, ch_first = 0;
+    auto fetch_chain = [&](const int k) { const ChainDesc* __restrict__ q = &chains[k]; ch_off = q->off; ch_model = q->model; ch_first = q->first; ch_raw = q->raw_off; };
+    if (has) fetch_chain(cc.x);
     const int tbase = node_contig_base[c];
     const int i = t - tbase, n = has ? node_contig_base[c + 1] - tbase : 1;
     const int type = has ? ga.type[t] : PGA_T_STOP;
     const int e0 = has ? ga.edge0[t] : 0;
     const bool is_start = has && type != PGA_T_STOP;
-    const bool closed = sp.closed != 0, is_meta = sp.is_meta != 0;
+    // the models the workgroup scores, as a bit set (models [mb, mb + 512)): the first thread of every contig enters its chains
+    auto enter_models = [&](const int mb) {
+        if (!(has && (tid == 0 || i == 0))) return;
+        for (int m = 0; m < cc.y; m++) {
+            const int rel = chains[cc.x + m].model - mb;
+            if (rel >= 0 && rel < 64 * SS_MASK_WORDS) atomicOr(&s_present[rel >> 6], 1ull << (rel & 63));
+        }
+    };
+    enter_models(0);
+    // the edge candidates of the workgroup's first contigs
+    if (tid < SS_EDGE_CONTIGS * 2 * SS_EDGE_SPAN) {
+        const int ec = c0 + tid / (2 * SS_EDGE_SPAN), q = tid % (2 * SS_EDGE_SPAN);
+        int2 e = make_int2(0, 0);
+        if (ec < n_contigs) { const int tb = node_contig_base[ec]; e = edge_candidate(ga, tb, node_contig_base[ec + 1] - tb, ct[ec].len, q, closed); }
+        s_edge[tid / (2 * SS_EDGE_SPAN)][q] = e;
+    }
+    mark(0, true);
     // ---- what does not depend on the model (start nodes only)
     int L = 3, ndx = 0, sv = 0, strand = 1, start = 0;
     const uint8_t* __restrict__ d = dig;
     bool conv = false, ups_first = false, ups_later = false, ups_near_edge = false;
     UpWin W{0, 0, 0, 0, 0};
     long orf = 1;
+    int stop3 = 0;
     if (is_start) {
-    const ContigDesc cd = ct[c];
-    L = cd.len;
-    d = dig + cd.base;
-    ndx = ga.ndx[t]; sv = ga.stop_val[t]; strand = ga.strand[t];
-    auto convertible = [&](int k) -> bool {
-        if (closed || ga.type[tbase + k] == PGA_T_STOP || ga.edge0[tbase + k]) return false;
-        const int x = ga.ndx[tbase + k], s = ga.strand[tbase + k];
-        return (x <= 2 && s == 1) || (x >= L - 3 && s == -1);
-    };
-    conv = convertible(i);
-    if (conv && sp.conv_flag != nullptr) sp.conv_flag[c] = 1;
-    start = strand == 1 ? ndx : L - 1 - ndx;     // strand-local start position
-    W = load_upwin(d, L, start, strand);
-    orf = ndx > sv ? ndx - sv : sv - ndx;
-    // does an edge node share this ORF?  (lib.pyx:2413-2422; the answer depends on whether the edge
-    // conversion of this pass has already reached that node, hence the two variants)
-    if (!closed && ndx <= 2 && strand == 1) ups_near_edge = true;
-    else if (!closed && ndx >= L - 3 && strand == -1) ups_near_edge = true;
-    else if ((i < 500 && strand == 1) || (i + 500 >= n && strand == -1)) {
-        // The reference scans the 500 nodes before a forward start (after a reverse one) for an edge node, or one that this
-        // pass converts to an edge node, of the same ORF.  Such nodes sit on the first or last three positions of the contig
-        // (ref: lib.pyx:2413-2434, node.c add_nodes), i.e. among the first or last PGA_EDGE_SPAN nodes (one node per position
-        // and strand): those are the only candidates worth a look.
-        constexpr int PGA_EDGE_SPAN = 12;
-        for (int q = 0; q < 2 * PGA_EDGE_SPAN; q++) {
-            const int j = q < PGA_EDGE_SPAN ? q : n - 2 * PGA_EDGE_SPAN + q;
-            if (j < 0 || j >= n || (q >= PGA_EDGE_SPAN && j < PGA_EDGE_SPAN)) continue;       // short contig: each node once
-            if (strand == 1 ? j >= i : j <= i) continue;
-            if (sv != ga.stop_val[tbase + j]) continue;
-            if (ga.edge0[tbase + j]) { ups_first = ups_later = true; }
-            else if (convertible(j)) { if (strand == 1) ups_first = true; ups_later = true; }   // after i: counts only once an earlier model of the run converted it
+        const ContigDesc cd = ct[c];
+        L = cd.len;
+        d = dig + cd.base;
+        ndx = ga.ndx[t]; sv = ga.stop_val[t]; strand = ga.strand[t];
+        // does this pass turn the node into an edge node?  (ref: lib.pyx:2424-2434)
+        conv = !closed && !e0 && ((ndx <= 2 && strand == 1) || (ndx >= L - 3 && strand == -1));
+        if (conv && sp.conv_flag != nullptr) sp.conv_flag[c] = 1;
+        start = strand == 1 ? ndx : L - 1 - ndx;     // strand-local start position
+        W = load_upwin(d, L, start, strand);
+        orf = ndx > sv ? ndx - sv : sv - ndx;
+        // the three bases at the ORF's stop, strand-local order: whether they are a stop codon depends on the model's table
+        const int s0 = strand == 1 ? sv : L - 1 - sv;
+        stop3 = sbase(d, L, s0, strand) | (sbase(d, L, s0 + 1, strand) << 8) | (sbase(d, L, s0 + 2, strand) << 16);
+    }
+    mark(1, true);
+    __syncthreads();            // the model set and the edge candidates are complete
+    if (is_start) {
+        // does an edge node share this ORF?  (lib.pyx:2413-2422; the answer depends on whether the edge
+        // conversion of this pass has already reached that node, hence the two variants)
+        if (!closed && ndx <= 2 && strand == 1) ups_near_edge = true;
+        else if (!closed && ndx >= L - 3 && strand == -1) ups_near_edge = true;
+        else if ((i < 500 && strand == 1) || (i + 500 >= n && strand == -1)) {
+            // The reference scans the 500 nodes before a forward start (after a reverse one) for an edge node, or one that this
+            // pass converts to an edge node, of the same ORF.  Such nodes sit on the first or last three positions of the contig
+            // (ref: lib.pyx:2413-2434, node.c add_nodes), i.e. among the first or last SS_EDGE_SPAN nodes (one node per position
+            // and strand): those are the only candidates worth a look.
+            const int ecx = c - c0;
+            for (int q = 0; q < 2 * SS_EDGE_SPAN; q++) {
+                const int j = q < SS_EDGE_SPAN ? q : n - 2 * SS_EDGE_SPAN + q;
+                if (strand == 1 ? j >= i : j <= i) continue;
+                const int2 e = ecx < SS_EDGE_CONTIGS ? s_edge[ecx][q] : edge_candidate(ga, tbase, n, L, q, closed);
+                if (!(e.y & 4) || sv != e.x) continue;
+                if (e.y & 1) { ups_first = ups_later = true; }
+                else if (e.y & 2) { if (strand == 1) ups_first = true; ups_later = true; }   // after i: counts only once an earlier model of the run converted it
+            }
         }
     }
-    }
+    mark(2, true);
     int tt_cached = -1; bool stop_missing = false;
     // per search window of the RBS search: the six "is the A / G of AGGAGG there" bits (five windows per word); the bins that
     // match come from the table in LDS when a model asks
     bool have_pats = false;
     unsigned pats[3] = {0u, 0u, 0u};
-    __syncthreads();
-    const int mlo = s_mlo, mhi = s_mhi;
     int mi = 0;                                                 // the thread's next chain
-    int next_model = has ? chains[cc.x].model : 0x7fffffff;
-    for (int mm = mlo; mm <= mhi; mm++) {
-        const bool mine = next_model == mm;
-        if (!__syncthreads_or(mine)) continue;                  // nobody here scores model mm (its GC window excludes these contigs)
-        {   // stage the model
-            const pga_training* __restrict__ tmg = &models[mm];
-            const int tid = threadIdx.x;
-            if (tid == 0) { SM.st_wt = tmg->st_wt; SM.no_mot = tmg->no_mot; SM.tt = tmg->trans_table; SM.uses_sd = tmg->uses_sd; }
-            if (tid < 3) SM.type_wt[tid] = tmg->type_wt[tid];
-            if (tid < 28) SM.rbs_wt[tid] = tmg->rbs_wt[tid];
-            if (tid >= 128) (&SM.ups[0][0])[tid - 128] = (&tmg->ups_comp[0][0])[tid - 128];
-            if (!tmg->uses_sd) {
-                SM.mk0[tid >> 6][tid & 63] = tmg->mot_wt[0][tid >> 6][tid & 63];
-#pragma unroll
-                for (int r = 0; r < 4; r++) { const int e = tid + 256 * r; SM.mk1[e >> 8][e & 255] = tmg->mot_wt[1][e >> 8][e & 255]; }
-            }
+    // the lowest model of the set above `after` (relative to mb), or -1
+    auto next_present = [&](const int after) {
+        for (int w = (after + 1) >> 6; w < SS_MASK_WORDS; w++) {
+            unsigned long long bits = s_present[w];
+            if (w == (after + 1) >> 6) bits &= ~0ull << ((after + 1) & 63);
+            if (bits) return w * 64 + __builtin_ctzll(bits);
         }
+        return -1;
+    };
+    // staging a model: every thread fetches its share (r0: the scalars, the RBS / type / upstream weights; r1: one entry of the
+    // 3-base motif table) early and stores it late; the 4-base motif table (four entries per thread) goes through in one piece
+    struct StageRegs { double r0, r1; int sd; };
+    auto stage_fetch = [&](const int model) {
+        const pga_training* __restrict__ tmg = &models[model];
+        StageRegs R{0.0, 0.0, tmg->uses_sd};
+        if (tid == 0) R.r0 = tmg->st_wt;
+        else if (tid == 1) R.r0 = tmg->no_mot;
+        else if (tid == 2) R.r0 = __hiloint2double(tmg->uses_sd, tmg->trans_table);
+        else if (tid >= 4 && tid < 7) R.r0 = tmg->type_wt[tid - 4];
+        else if (tid >= 32 && tid < 60) R.r0 = tmg->rbs_wt[tid - 32];
+        else if (tid >= 128) R.r0 = (&tmg->ups_comp[0][0])[tid - 128];
+        R.r1 = tmg->mot_wt[0][tid >> 6][tid & 63];          // asked for whatever uses_sd says: no load waits for another
+        return R;
+    };
+    auto stage_store = [&](const int model, const StageRegs& R, StartModel& S) {
+        if (tid == 0) S.st_wt = R.r0;
+        else if (tid == 1) S.no_mot = R.r0;
+        else if (tid == 2) { S.tt = __double2loint(R.r0); S.uses_sd = __double2hiint(R.r0); }
+        else if (tid >= 4 && tid < 7) S.type_wt[tid - 4] = R.r0;
+        else if (tid >= 32 && tid < 60) S.rbs_wt[tid - 32] = R.r0;
+        else if (tid >= 128) (&S.ups[0][0])[tid - 128] = R.r0;
+        if (!R.sd) {
+            const pga_training* __restrict__ tmg = &models[model];
+            S.mk0[tid >> 6][tid & 63] = R.r1;
+            double v[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) { const int e = tid + 256 * r; v[r] = tmg->mot_wt[1][e >> 8][e & 255]; }
+#pragma unroll
+            for (int r = 0; r < 4; r++) { const int e = tid + 256 * r; S.mk1[e >> 8][e & 255] = v[r]; }
+        }
+    };
+    int buf = 0;
+    for (int mb = 0; ; ) {
+        int rel = next_present(-1);
+        if (rel >= 0) { const StageRegs R = stage_fetch(mb + rel); stage_store(mb + rel, R, SMB[buf]); }
         __syncthreads();
-        if (mine) {
-            const ChainDesc ch = chains[cc.x + mi];
-            const int64_t g = ch.off + i;
-            mi++;
-            next_model = mi < cc.y ? chains[cc.x + mi].model : 0x7fffffff;
-            if (!is_start) {        // stop nodes carry no start scores (reset_node_scores)
-                ca.edge[g] = (uint8_t)e0;
-                ca.cscore[g] = 0.0; ca.sscore[g] = 0.0; ca.rscore[g] = 0.0; ca.uscore[g] = 0.0; ca.tscore[g] = 0.0; ca.mot_score[g] = 0.0;
-                ca.mot_ndx[g] = 0; ca.mot_len[g] = 0; ca.mot_spacer[g] = 0; ca.mot_spacendx[g] = 0; ca.rbs[2 * g] = 0; ca.rbs[2 * g + 1] = 0;
-                if (sp.cs_out != nullptr) sp.cs_out[g] = 0.0;
-            } else {
-        const pga_training* __restrict__ tm = &models[mm];          // the large motif tables stay in global memory
+        while (rel >= 0) {
+            const int cur = mb + rel;
+            const int nrel = next_present(rel);
+            StageRegs RN{0.0, 0.0, 1};
+            if (nrel >= 0) RN = stage_fetch(mb + nrel);
+            const StartModel& SM = SMB[buf];
+            const bool mine = has && ch_model == cur;
+            mark(3, true);
+            if (mine) {
+                const int64_t g = ch_off + i;
+                const int first = ch_first;
+                const double cs_raw = is_start ? ca.cscore_raw[(ch_raw >= 0 ? ch_raw : ch_off) + i] : 0.0;
+                mi++;
+                if (mi < cc.y) fetch_chain(cc.x + mi); else ch_model = 0x7fffffff;
+                if (!is_start) {        // stop nodes carry no start scores (reset_node_scores)
+                    ca.edge[g] = (uint8_t)e0;
+                    ca.cscore[g] = 0.0; ca.sscore[g] = 0.0; ca.rscore[g] = 0.0; ca.uscore[g] = 0.0; ca.tscore[g] = 0.0; ca.mot_score[g] = 0.0;
+                    ca.mot_ndx[g] = 0; ca.mot_len[g] = 0; ca.mot_spacer[g] = 0; ca.mot_spacendx[g] = 0; ca.rbs[2 * g] = 0; ca.rbs[2 * g + 1] = 0;
+                    if (sp.cs_out != nullptr) sp.cs_out[g] = 0.0;
+                } else {
+        const pga_training* __restrict__ tm = &models[cur];          // the large motif tables stay in global memory
         const double st_wt = SM.st_wt;
         const int tt = SM.tt;
         if (tt != tt_cached) {
             tt_cached = tt;
-            stop_missing = (strand == 1 && !is_stop_at(d, L, sv, 1, tt)) || (strand == -1 && !is_stop_at(d, L, L - 1 - sv, -1, tt));
+            stop_missing = !codon_is_stop(stop3 & 0xff, (stop3 >> 8) & 0xff, (stop3 >> 16) & 0xff, tt);
         }
-        const bool edge_in = e0 || (conv && !ch.first);
+        const bool edge_in = e0 || (conv && !first);
+        mark(4);
         int rbs0 = 0, rbs1 = 0, m_ndx = 0, m_len = 0, m_sp = 0, m_si = 0;
         double m_score = 0.0;
-        if (!edge_in) {
-            if (SM.uses_sd) {
+        const bool search_sd = !edge_in && SM.uses_sd, search_mot = !edge_in && !SM.uses_sd;
+        // The motif of k + 3 bases whose first base sits u0 = 18 + k - t2 upstream (the reference's j = start - u0, ascending j),
+        // longest motifs first: every shift and spacer class below is a constant of the unrolled bodies.  6- and 5-base motifs come
+        // from the model's tables in global memory, 4- and 3-base motifs from LDS.  (Asking for both batches of gathers at once, or
+        // computing the upstream composition under the first, costs more in spilled registers than the overlap returns.)
+        auto midx = [&](const int k, const int t2) { return (int)((W.zm >> (2 * (21 - (18 + k - t2)))) & ((1ull << (2 * (k + 3))) - 1ull)); };
+        auto msi = [](const int t2) { return t2 <= 2 ? 3 : (t2 <= 4 ? 2 : (t2 >= 11 ? 1 : 0)); };      // u0 >= 16 + k, >= 14 + k, <= 7 + k
+        // upstream composition (ref: lib.pyx:1618-1650)
+        auto upstream = [&]() {
+            int cnt = 0; double v = 0.0;
+#pragma unroll
+            for (int k = 1; k < 3; k++) { if (k > start) break; v += 0.4 * st_wt * SM.ups[cnt][W.code(k)]; cnt++; }
+#pragma unroll 10
+            for (int k = 15; k < 45; k++) { if (k > start) break; v += 0.4 * st_wt * SM.ups[cnt][W.code(k)]; cnt++; }
+            return v;
+        };
+        double u = 0.0;
+        if (search_sd) {
                 if (!have_pats) {
                     have_pats = true;
                     const unsigned hasA = W.isA, hasG = W.isG;
@@ -1819,53 +1959,35 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
                     if (he > 1u) { const int a = sd_pick(he, SM.rbs_wt); if (a > rbs0) rbs0 = a; }
                     if (hm > 1u) { const int b = sd_pick(hm, SM.rbs_wt); if (b > rbs1) rbs1 = b; }
                 }
-            } else {
-                double bsc = -100.0; int bsp = 0, bsi = 0, blen = 0, bndx = 0;
-                // the motif of k + 3 bases whose first base sits u0 upstream (the reference's j = start - u0, ascending j), longest
-                // motifs first: every shift and spacer class below is a constant of the unrolled body.  6- and 5-base motifs from the
-                // model's tables in global memory, 4- and 3-base motifs from LDS.
+        } else if (search_mot) {
+            double bsc = -100.0; int bsp = 0, bsi = 0, blen = 0, bndx = 0;
 #pragma unroll 1
-                for (int k = 3; k >= 0; k--) {
-                    const int stride = k == 0 ? 64 : (k == 1 ? 256 : 4096);        // entries per spacer class of the table read
-                    const double* __restrict__ gt = &tm->mot_wt[k][0][0];
-                    const double* lt = k == 1 ? &SM.mk1[0][0] : &SM.mk0[0][0];
-                    double scv[13];
-                    if (k >= 2) {
+            for (int k = 3; k >= 0; k--) {
+                const int stride = k == 0 ? 64 : (k == 1 ? 256 : 4096);        // entries per spacer class of the table read
+                const double* __restrict__ gt = &tm->mot_wt[k][0][0];
+                const double* lt = k == 1 ? &SM.mk1[0][0] : &SM.mk0[0][0];
+                double scv[13];
+                if (k >= 2) {
 #pragma unroll
-                        for (int t2 = 0; t2 < 13; t2++) {
-                            const int u0 = 18 + k - t2;
-                            const int si = t2 <= 2 ? 3 : (t2 <= 4 ? 2 : (t2 >= 11 ? 1 : 0));      // u0 >= 16 + k, >= 14 + k, <= 7 + k
-                            const int idx = (int)((W.zm >> (2 * (21 - u0))) & ((1ull << (2 * (k + 3))) - 1ull));
-                            scv[t2] = u0 > start ? -1000.0 : gt[si * stride + idx];
-                        }
-                    } else {
+                    for (int t2 = 0; t2 < 13; t2++) scv[t2] = 18 + k - t2 > start ? -1000.0 : gt[msi(t2) * stride + midx(k, t2)];
+                } else {
 #pragma unroll
-                        for (int t2 = 0; t2 < 13; t2++) {
-                            const int u0 = 18 + k - t2;
-                            const int si = t2 <= 2 ? 3 : (t2 <= 4 ? 2 : (t2 >= 11 ? 1 : 0));
-                            const int idx = (int)((W.zm >> (2 * (21 - u0))) & ((1ull << (2 * (k + 3))) - 1ull));
-                            scv[t2] = u0 > start ? -1000.0 : lt[si * stride + idx];
-                        }
-                    }
-#pragma unroll
-                    for (int t2 = 0; t2 < 13; t2++) {
-                        const int u0 = 18 + k - t2;
-                        const int si = t2 <= 2 ? 3 : (t2 <= 4 ? 2 : (t2 >= 11 ? 1 : 0));
-                        if (scv[t2] > bsc) {
-                            bsc = scv[t2]; bsi = si; bsp = u0 - k - 3; blen = k + 3;
-                            bndx = (int)((W.zm >> (2 * (21 - u0))) & ((1ull << (2 * (k + 3))) - 1ull));
-                        }
-                    }
+                    for (int t2 = 0; t2 < 13; t2++) scv[t2] = 18 + k - t2 > start ? -1000.0 : lt[msi(t2) * stride + midx(k, t2)];
                 }
-                if (bsc == -4.0 || bsc < SM.no_mot + 0.69) { m_score = SM.no_mot; }
-                else { m_ndx = bndx; m_len = blen; m_si = bsi; m_sp = bsp & 15; m_score = bsc; }
+#pragma unroll
+                for (int t2 = 0; t2 < 13; t2++)
+                    if (scv[t2] > bsc) { bsc = scv[t2]; bsi = msi(t2); bsp = 15 - t2; blen = k + 3; bndx = midx(k, t2); }
             }
+            if (bsc == -4.0 || bsc < SM.no_mot + 0.69) { m_score = SM.no_mot; }
+            else { m_ndx = bndx; m_len = blen; m_si = bsi; m_sp = bsp & 15; m_score = bsc; }
         }
+        if (!edge_in) u = upstream();
+        mark(5);
         double edge_gene = 0;
         if (edge_in) edge_gene += 1;
         if (stop_missing) edge_gene += 1;
 
-        double tscore, uscore, rscore, sscore, cscore = ca.cscore_raw[(ch.raw_off >= 0 ? ch.raw_off : ch.off) + i];
+        double tscore, uscore, rscore, sscore, cscore = cs_raw;
         if (edge_in) {
             tscore = 0.74 * st_wt / edge_gene; uscore = 0.0; rscore = 0.0;
         } else {
@@ -1874,14 +1996,10 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
             const double sd = fmax(r1, r2) * st_wt;
             if (SM.uses_sd) rscore = sd;
             else { rscore = st_wt * m_score; if (rscore < sd && SM.no_mot > -0.5) rscore = sd; }
-            int cnt = 0; double u = 0.0;
-#pragma unroll
-            for (int k = 1; k < 3; k++) { if (k > start) break; u += 0.4 * st_wt * SM.ups[cnt][W.code(k)]; cnt++; }
-#pragma unroll 10
-            for (int k = 15; k < 45; k++) { if (k > start) break; u += 0.4 * st_wt * SM.ups[cnt][W.code(k)]; cnt++; }
             uscore = u;
-            if (ups_near_edge || (ch.first ? ups_first : ups_later)) uscore += -1.00 * st_wt;
+            if (ups_near_edge || (first ? ups_first : ups_later)) uscore += -1.00 * st_wt;
         }
+        mark(6);
         bool edge_now = edge_in;
         if (conv && !edge_in) {
             edge_gene += 1; edge_now = true; tscore = 0.0;
@@ -1912,9 +2030,22 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
         ca.rbs[2 * g] = (uint8_t)rbs0; ca.rbs[2 * g + 1] = (uint8_t)rbs1;
         ca.edge[g] = (uint8_t)edge_now;
         if (sp.cs_out != nullptr) sp.cs_out[g] = cscore + sscore;
+                }
             }
+            mark(8, true);
+            if (nrel >= 0) stage_store(mb + nrel, RN, SMB[buf ^ 1]);
+            mark(9, true);
+            __syncthreads();            // everybody is done with this model, and the next one is staged
+            mark(10, true);
+            buf ^= 1; rel = nrel;
         }
-        __syncthreads();            // everybody is done with the staged model
+        mb += 64 * SS_MASK_WORDS;
+        if (mb >= sp.n_models) break;
+        // (more than 512 models: the next 512)
+        if (tid < SS_MASK_WORDS) s_present[tid] = 0ull;
+        __syncthreads();
+        enter_models(mb);
+        __syncthreads();
     }
 }
 
@@ -2203,10 +2334,10 @@ bool pga_cs_tasks(const int2* h_cc /* per contig: first chain, count */, int n_c
     // columns of high-GC models first: their contigs have the longest ORFs, and a launch ends when its last task does
     for (int q = 63; q >= 0; q--) {
         const std::vector<int32_t>& b = bucket[(size_t)q];
-        int first = (int)(entries.size() / 4), count = 0, nodes = 0;
+        int first = (int)(entries.size() / 4), count = 0, nodes = 0, cuts = 0;
         auto flush = [&]() {
             if (count > 0) { tasks.push_back(q); tasks.push_back(first); tasks.push_back(count); tasks.push_back(0); }
-            first += count; count = 0; nodes = 0;
+            first += count; count = 0; nodes = 0; cuts = 0;
         };
         for (size_t k = 0; k < b.size(); k += 2) {
             // a task is one round of the kernel (at most task_nodes nodes): a contig with more is cut into pieces, a genome becomes
@@ -2214,9 +2345,10 @@ bool pga_cs_tasks(const int2* h_cc /* per contig: first chain, count */, int n_c
             const int nc = h_cbase[b[k] + 1] - h_cbase[b[k]];
             for (int f0 = 0; f0 < nc; f0 += task_nodes) {
                 const int piece = std::min(task_nodes, nc - f0);
-                if (count > 0 && (nodes + piece > task_nodes || count == CS_TASK_MAX_ENTRIES)) flush();
+                // (a piece of a contig may list a few stop nodes more than half its nodes: see CS_LIST)
+                if (count > 0 && (nodes + piece > task_nodes || count == CS_TASK_MAX_ENTRIES || (piece != nc && cuts == CS_TASK_MAX_CUTS))) flush();
                 entries.push_back(b[k]); entries.push_back(b[k + 1]); entries.push_back(f0); entries.push_back(piece);
-                count++; nodes += piece;
+                count++; nodes += piece; cuts += piece != nc;
             }
         }
         flush();
@@ -2308,9 +2440,30 @@ void pga_launch_score(const ChainDesc* d_chains, int n_chains, int64_t node_begi
     if (group_nodes > 0 && !reuse_raw_cscore)
         hipLaunchKernelGGL(k_coding_score, dim3(nblocks(group_nodes, 256)), blk, 0, st, d_all_chains, d_contig_chains, d_node_contig_base,
                            n_contigs, 0, group_nodes, d_dig, d_ct, ga, d_models, d_msc, ca, d_gil, il_stride, d_rank);
-    if (group_nodes > 0)
-        hipLaunchKernelGGL(k_score_starts, dim3(nblocks(group_nodes, 256)), blk, 0, st, d_all_chains, d_contig_chains, d_node_contig_base, n_contigs,
+    if (group_nodes > 0) {
+        // PGA_SS_PROFILE=1: wave-cycles per phase of the start scorer (a synchronising debug aid)
+        static std::atomic<unsigned long long*> ss_prof_of[64];
+        const bool ss_profiling = getenv("PGA_SS_PROFILE") != nullptr;
+        if (ss_profiling) {
+            int dev = 0; (void)hipGetDevice(&dev); dev &= 63;
+            unsigned long long* d_prof = ss_prof_of[dev].load();
+            if (!d_prof) { (void)hipMalloc((void**)&d_prof, 16 * sizeof(unsigned long long)); ss_prof_of[dev].store(d_prof); }
+            (void)hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), st);
+            sp.prof = d_prof;
+        }
+        // (a fifth wavefront per SIMD costs 96 bytes of scratch per lane and 10 % of the kernel's time: four)
+        hipLaunchKernelGGL(k_score_starts<4>, dim3(nblocks(group_nodes, 256)), blk, 0, st, d_all_chains, d_contig_chains, d_node_contig_base, n_contigs,
                            group_nodes, d_dig, d_ct, ga, d_models, ca, sp, d_sd_lut);
+        if (ss_profiling) {
+            unsigned long long h[16];
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(h, sp.prof, sizeof h, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[pga ss-profile] %d nodes: wave-cycles  locate %.3g  node + upstream window %.3g  barrier + edge scan %.3g | per model: next model %.3g  "
+                            "chain %.3g  upstream + RBS / motif search %.3g  scores %.3g  finish + stores (slot 8) %.3g  stage %.3g  barrier %.3g (slot 7 unused %.3g)\n",
+                    group_nodes, (double)h[0], (double)h[1], (double)h[2], (double)h[3], (double)h[4], (double)h[5], (double)h[6], (double)h[8],
+                    (double)h[9], (double)h[10], (double)h[7]);
+        }
+    }
     if (stops != nullptr) {
         (void)hipMemsetAsync(ca.star_ptr + 3 * node_begin, 0xff, sizeof(int32_t) * 3 * (size_t)total, st);
         if (stops->n_pairs > 0 && stops->n_stops > 0)
