@@ -58,6 +58,15 @@ def roofline(ctx, dp_ms, passes, calls, n_chains, wname, launch_key=None):
         per_s = pmc["valu_insts_per_launch"] * max(calls, 1) / (dp_ms * 1e-3)
         r["valu_issue_frac"] = round(per_s / VALU_ISSUE_PEAK, 4)
         r["valu_insts_per_node_pass"] = round(pmc["valu_insts_per_launch"] * max(calls, 1) / max(passes, 1), 2)
+    # ... and what the pipes say themselves (SQ_ACTIVE_INST_VALU / _SCA of a --pmc pass, x 4 = SIMD-cycles with a vector / scalar
+    # instruction of the kernel executing) over the SIMD-cycles of this run's kernel time: a wave64 f64 or cross-lane instruction
+    # holds the pipe longer than the two cycles the issue peak above assumes, so this is the figure that says "issue-bound"
+    if pmc.get("valu_busy_simd_cycles_per_launch") and dp_ms > 0:
+        simd_cycles = 1024 * 2.4e9 * dp_ms * 1e-3
+        r["valu_busy_frac"] = round(pmc["valu_busy_simd_cycles_per_launch"] * max(calls, 1) / simd_cycles, 4)
+        r["scalar_busy_frac"] = round(pmc["scalar_busy_simd_cycles_per_launch"] * max(calls, 1) / simd_cycles, 4)
+        r["salu_insts_per_node_pass"] = round(pmc["salu_insts_per_launch"] * max(calls, 1) / max(passes, 1), 2)
+        r["branch_insts_per_node_pass"] = round(pmc["branch_insts_per_launch"] * max(calls, 1) / max(passes, 1), 2)
     seg = ctx.dp_stats()
     if seg["chains"] > 0:
         # few long chains: the connection scoring is one group of kernels (speculative segment walks, exact

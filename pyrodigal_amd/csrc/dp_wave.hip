@@ -341,12 +341,12 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
 
     const int nb = (n + 63) >> 6;
     // optional phase timing of chain 0 (PGA_DP_PROFILE through the scorer-level call): cycles per batch phase
-    const bool prof = buf.prof != nullptr && blockIdx.x == 0;
+    const bool prof = buf.prof != nullptr && (blockIdx.x & 63) == 0;      // one chain alone, or every 64th of a launch
     unsigned long long tp = prof ? __builtin_readcyclecounter() : 0;
     auto mark = [&](const int slot) {
         if (!prof) return;
         const unsigned long long now = __builtin_readcyclecounter();
-        if (lane == 0) buf.prof[slot] += now - tp;
+        if (lane == 0) atomicAdd(&buf.prof[slot], now - tp);
         tp = now;
     };
     for (int b = 0; b < nb; b++) {
@@ -560,7 +560,7 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
             }
         }
         mark(6);
-        if (prof && lane == 0) buf.prof[7] += 1;
+        if (prof && lane == 0) atomicAdd(&buf.prof[7], 1ull);
     }
     // highest score among gene ends, ties to the largest index (ref: lib.pyx:1239-1251, 1311)
 #pragma unroll

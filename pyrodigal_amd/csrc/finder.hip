@@ -1523,7 +1523,25 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         // one DP launch over the chains of every group: chains are independent, the more in flight the better
         HT(c, hipEventRecord(f->e_dp0[0], st));
         if (use_lane) pga_launch_dp_lane(d_chains, wgroups, c->d_model_const, dp, wbuf, lane_dev, st);
-        else if (use_wave) pga_launch_dp_wave(d_chains, NCH, wgroups, c->d_model_const, dp, wbuf, st, d_dp_order);
+        else if (use_wave) {
+            // PGA_DP_PROFILE=1: cycles per batch phase of every 64th chain (a synchronising debug aid)
+            if (getenv("PGA_DP_PROFILE")) {
+                DEVBUF(d_prof, unsigned long long, "dp_prof", 16);
+                HT(c, hipMemsetAsync(d_prof, 0, 128, st));
+                dp.prof = d_prof;
+            }
+            pga_launch_dp_wave(d_chains, NCH, wgroups, c->d_model_const, dp, wbuf, st, d_dp_order);
+            if (dp.prof != nullptr) {
+                unsigned long long pr[16];
+                HT(c, hipStreamSynchronize(st));
+                HT(c, hipMemcpy(pr, dp.prof, 128, hipMemcpyDeviceToHost));
+                const double nbp = pr[7] ? (double)pr[7] : 1.0;
+                fprintf(stderr, "[pga dp profile] k_dp_wave, %d chains, batches sampled=%llu, cycles/batch: load=%.0f near steps=%.0f far gene ends=%.0f "
+                                "carries=%.0f chains=%.0f walk=%.0f finalize=%.0f | total=%.0f\n", NCH, pr[7], pr[0] / nbp, pr[1] / nbp, pr[2] / nbp, pr[3] / nbp,
+                        pr[4] / nbp, pr[5] / nbp, pr[6] / nbp, (pr[0] + pr[1] + pr[2] + pr[3] + pr[4] + pr[5] + pr[6]) / nbp);
+                dp.prof = nullptr;
+            }
+        }
         else pga_launch_dp(d_chains, NCH, c->d_model_const, dp, 1, st, segmented ? &seg_dev : nullptr);
         HT(c, hipEventRecord(f->e_dp1[0], st));
         HT(c, hipMemcpyAsync(h_maxidx, dp.max_index, sizeof(int32_t) * NCH, hipMemcpyDeviceToHost, st));
