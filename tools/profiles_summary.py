@@ -119,6 +119,9 @@ except (OSError, ValueError):
 for k, v in traffic.items():
     if isinstance(v, dict):
         v = dict(v, collected=tag, collected_at_commit=commit)
+        # what other collections added to the entry (the SQ pipe counters of tools/sq_counters.py) stays
+        if isinstance(merged.get(k), dict):
+            v = dict({kk: vv for kk, vv in merged[k].items() if kk not in v}, **v)
     merged[k] = v
 traffic = merged
 json.dump(traffic, open("profiles/r03_pmc_traffic.json", "w"), indent=1)
