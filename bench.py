@@ -153,7 +153,7 @@ def main():
     ap.add_argument("--workload", default="config4", choices=["config4", "config3", "config2", "config5"])
     ap.add_argument("--contigs", type=int, default=100_000, help="config4: contigs of the whole job")
     ap.add_argument("--sub-batch", type=int, default=6_250, help="contigs per device call")
-    ap.add_argument("--contexts", type=int, default=8, help="device contexts (streams) the calls of a pass are dealt to")
+    ap.add_argument("--contexts", type=int, default=12, help="device contexts (streams) the calls of a pass are dealt to")
     ap.add_argument("--gen-procs", type=int, default=0, help="worker processes generating the synthetic contigs (0: up to 32; 1: none, e.g. under rocprofv3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
@@ -357,14 +357,20 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not single:
             out["cpu_baseline"] = cpu_baseline(seqs, models, res[0] if res else None, args.contigs if args.workload == "config4" else 0)
     fasta_line = pool_line = None
-    if rank == 0 and world == 1 and not single and not args.no_secondary:
-        fasta_line = fasta_to_genes(seqs[:min(len(seqs), 20000)], models, dev_index, kw)
-        pool_line = threadpool_find_genes(seqs[:min(len(seqs), 8000)], models, dev_index)
+    try:
+        free_b, total_b = torch.cuda.mem_get_info(dev_index)
+        out["config"]["hbm_in_use_GB"] = round((total_b - free_b) / 1e9, 1)        # the contexts' buffers + the resident batches, at their peak
+    except Exception:
+        pass
+    # the job's contexts and batches go before the secondary workloads create theirs
     for b in batches:
         b.close()
     lanes.close()
     for c in ctxs[1:]:
         c.close()
+    if rank == 0 and world == 1 and not single and not args.no_secondary:
+        fasta_line = fasta_to_genes(seqs[:min(len(seqs), 20000)], models, dev_index, kw)
+        pool_line = threadpool_find_genes(seqs[:min(len(seqs), 8000)], models, dev_index)
     if rank == 0 and world == 1 and not args.no_secondary:
         out["secondary"] = secondary(ctx, _cabi, benchdata, models, args.workload, sync)
         if fasta_line:
