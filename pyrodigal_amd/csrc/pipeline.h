@@ -68,6 +68,7 @@ struct ScoreParams {
                              // reference turns into an edge node while scoring (lib.pyx:2424-2434) -- only such contigs are scored
                              // differently by the first and by a later model of a run
     unsigned long long* prof = nullptr;   // PGA_SS_PROFILE=1: wave-cycles per phase of k_score_starts (16 slots), or nullptr
+    int32_t models_per_pass = 512;        // k_score_starts walks a workgroup's models in sets of this many (<= 512; PGA_SS_MODELS_PER_PASS: tests)
 };
 
 void pga_launch_digitize(const char* d_seq, uint8_t* d_dig, int64_t total, const ContigDesc* d_ct, int n_contigs,

@@ -1777,7 +1777,7 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
         if (!(has && (tid == 0 || i == 0))) return;
         for (int m = 0; m < cc.y; m++) {
             const int rel = chains[cc.x + m].model - mb;
-            if (rel >= 0 && rel < 64 * SS_MASK_WORDS) atomicOr(&s_present[rel >> 6], 1ull << (rel & 63));
+            if (rel >= 0 && rel < sp.models_per_pass) atomicOr(&s_present[rel >> 6], 1ull << (rel & 63));
         }
     };
     enter_models(0);
@@ -2039,9 +2039,9 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
             mark(10, true);
             buf ^= 1; rel = nrel;
         }
-        mb += 64 * SS_MASK_WORDS;
+        mb += sp.models_per_pass;
         if (mb >= sp.n_models) break;
-        // (more than 512 models: the next 512)
+        // (more models than a pass holds: the next set)
         if (tid < SS_MASK_WORDS) s_present[tid] = 0ull;
         __syncthreads();
         enter_models(mb);
@@ -2441,6 +2441,7 @@ void pga_launch_score(const ChainDesc* d_chains, int n_chains, int64_t node_begi
         hipLaunchKernelGGL(k_coding_score, dim3(nblocks(group_nodes, 256)), blk, 0, st, d_all_chains, d_contig_chains, d_node_contig_base,
                            n_contigs, 0, group_nodes, d_dig, d_ct, ga, d_models, d_msc, ca, d_gil, il_stride, d_rank);
     if (group_nodes > 0) {
+        if (const char* e = getenv("PGA_SS_MODELS_PER_PASS")) { const int v = atoi(e); if (v >= 1 && v <= 512) sp.models_per_pass = v; }
         // PGA_SS_PROFILE=1: wave-cycles per phase of the start scorer (a synchronising debug aid)
         static std::atomic<unsigned long long*> ss_prof_of[64];
         const bool ss_profiling = getenv("PGA_SS_PROFILE") != nullptr;

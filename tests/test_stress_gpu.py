@@ -50,8 +50,10 @@ def test_dp_kernels_and_tails_agree_on_random_gene_dense_contigs(monkeypatch):
                       ("tree1+device", {"PGA_DP_KERNEL": "tree1", "PGA_TAIL": "device"}), ("tree3+host", {"PGA_DP_KERNEL": "tree3", "PGA_TAIL": "host"}),
                       # the kernels every headline number comes from, forced onto this small launch: the wave-batch connection
                       # scorer, the lane-per-chain connection scorer and the LDS-table form of the coding score
-                      ("wave+ldscs", {"PGA_DP_KERNEL": "wave", "PGA_CS_LDS": "2"}), ("lane+ldscs", {"PGA_DP_KERNEL": "lane", "PGA_CS_LDS": "2"})):
-        for k in ("PGA_DP_KERNEL", "PGA_TAIL", "PGA_CS_LDS"):
+                      ("wave+ldscs", {"PGA_DP_KERNEL": "wave", "PGA_CS_LDS": "2"}), ("lane+ldscs", {"PGA_DP_KERNEL": "lane", "PGA_CS_LDS": "2"}),
+                      # the start scorer walking a workgroup's models three to a pass (its path for more than 512 models)
+                      ("tree+3models/pass", {"PGA_SS_MODELS_PER_PASS": "3"})):
+        for k in ("PGA_DP_KERNEL", "PGA_TAIL", "PGA_CS_LDS", "PGA_SS_MODELS_PER_PASS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -65,8 +67,10 @@ def test_dp_kernels_and_tails_agree_on_random_gene_dense_contigs(monkeypatch):
             for f in ("traceb", "tracef", "ov_mark", "elim"):
                 assert np.array_equal(a[f], b[f]), (name, f)
             assert np.array_equal(a["score"].view(np.uint64), b["score"].view(np.uint64)) and np.array_equal(a["sscore"].view(np.uint64), b["sscore"].view(np.uint64)), name
+            for f in ("cscore", "rscore", "uscore", "tscore"):
+                assert np.array_equal(a[f].view(np.uint64), b[f].view(np.uint64)), (name, f)
     # single mode with masking as well
-    for k in ("PGA_DP_KERNEL", "PGA_TAIL", "PGA_CS_LDS"):
+    for k in ("PGA_DP_KERNEL", "PGA_TAIL", "PGA_CS_LDS", "PGA_SS_MODELS_PER_PASS"):
         monkeypatch.delenv(k, raising=False)
     ctx.set_models(models[7:8])
     s1 = ctx.find_genes_batch(seqs, meta=False, mask=True, closed=True)
