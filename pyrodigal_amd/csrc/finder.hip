@@ -395,6 +395,10 @@ struct TailDesc {          // one per contig
     int32_t n;             // nodes (0: no winning model)
     int32_t mx;            // _find_max_index of the winning pass
     double  st_wt;
+    // where the winner's final-pass node fields and its topology sit in the arrays the scorers wrote (k_emit_genes reads the
+    // two nodes of a gene from there when the winners were gathered without them)
+    int64_t fin_off, topo_off;
+    int32_t group, _pad;
 };
 // ---- gather kernel: pack the winning chains' node fields contiguously for one D2H per field ----
 struct WinDesc {
@@ -406,6 +410,7 @@ struct WinDesc {
     int32_t _pad;
     int64_t il_rec;      // >= 0: the DP pass left its results in the lane kernel's interleaved records, node i at il_rec + 64 i
 };
+struct GcPtrs { const float* p[4]; };      // GroupArrays::gc_cont of every translation-table group
 struct OutArrays {
     int32_t* ndx; int32_t* stop_val; uint8_t* type; int8_t* strand; float* gc_cont;
     uint8_t* edge_dp; double* cscore_dp; double* sscore_dp; double* rscore_dp; double* uscore_dp; double* tscore_dp;
@@ -416,7 +421,7 @@ struct OutArrays {
 
 __global__ void __launch_bounds__(256)
 k_gather_winners(const WinDesc* __restrict__ wd, int n_win, int64_t out_begin, int64_t total, GroupArrays ga, ChainArrays ca,
-                 DpBuffers dp, OutArrays o, const int4* __restrict__ il_out) {
+                 DpBuffers dp, OutArrays o, const int4* __restrict__ il_out, const int lean /* 1: only what the device tail walks */) {
     __shared__ int s_w0;
     const int64_t blk0 = out_begin + (int64_t)blockIdx.x * blockDim.x;
     const int64_t g = blk0 + threadIdx.x;
@@ -432,7 +437,7 @@ k_gather_winners(const WinDesc* __restrict__ wd, int n_win, int64_t out_begin, i
     const WinDesc w = wd[lo];
     const int i = (int)(g - w.out_off);
     const int64_t t = w.topo_off + i, a = w.dp_off + i, f = w.fin_off + i;
-    o.ndx[g] = ga.ndx[t]; o.stop_val[g] = ga.stop_val[t]; o.type[g] = ga.type[t]; o.strand[g] = ga.strand[t]; o.gc_cont[g] = ga.gc_cont[t];
+    o.ndx[g] = ga.ndx[t]; o.stop_val[g] = ga.stop_val[t]; o.type[g] = ga.type[t]; o.strand[g] = ga.strand[t];
     o.edge_dp[g] = ca.edge[a]; o.cscore_dp[g] = ca.cscore[a]; o.sscore_dp[g] = ca.sscore[a]; o.rscore_dp[g] = ca.rscore[a];
     o.uscore_dp[g] = ca.uscore[a]; o.tscore_dp[g] = ca.tscore[a];
     o.star_ptr[3 * g] = ca.star_ptr[3 * a]; o.star_ptr[3 * g + 1] = ca.star_ptr[3 * a + 1]; o.star_ptr[3 * g + 2] = ca.star_ptr[3 * a + 2];
@@ -440,6 +445,10 @@ k_gather_winners(const WinDesc* __restrict__ wd, int n_win, int64_t out_begin, i
         const int4 r = il_out[w.il_rec + (int64_t)i * 64];       // {score, traceb | (ov_mark + 1) << 28 or -1, position of the traceb node}
         o.traceb[g] = dpw_tag_index(r.z); o.ov_mark[g] = (int8_t)dpw_tag_ov(r.z); o.score[g] = __hiloint2double(r.y, r.x);
     } else { o.traceb[g] = dp.traceb[a]; o.ov_mark[g] = dp.ov_mark[a]; o.score[g] = dp.score[a]; }
+    // the final-pass fields: fourteen of the thirty per node.  Only the two nodes of a gene are ever looked at unless the caller
+    // wants the node arrays, and k_emit_genes can fetch those from where the scorer left them
+    if (lean) return;
+    o.gc_cont[g] = ga.gc_cont[t];
     o.edge[g] = ca.edge[f]; o.cscore[g] = ca.cscore[f]; o.sscore[g] = ca.sscore[f]; o.rscore[g] = ca.rscore[f];
     o.uscore[g] = ca.uscore[f]; o.tscore[g] = ca.tscore[f]; o.mot_score[g] = ca.mot_score[f]; o.mot_ndx[g] = ca.mot_ndx[f];
     o.rbs[2 * g] = ca.rbs[2 * f]; o.rbs[2 * g + 1] = ca.rbs[2 * f + 1];
@@ -739,7 +748,8 @@ k_tail_tweak_fixup(const TailDesc* __restrict__ td, int n_contigs, OutArrays o, 
 // The public gene records, packed in (contig, gene) order (ref: lib.pyx:2644-2830 for what Gene reads).
 __global__ void __launch_bounds__(256)
 k_emit_genes(const TailDesc* __restrict__ td, int n_contigs, int64_t n_slots, OutArrays o, const GeneRec* __restrict__ fin,
-             const int32_t* __restrict__ n_genes, const int64_t* __restrict__ gene_begin, int single, pga_gene* __restrict__ out) {
+             const int32_t* __restrict__ n_genes, const int64_t* __restrict__ gene_begin, int single, pga_gene* __restrict__ out,
+             const int lean, ChainArrays ca, GcPtrs gcs) {
     const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n_slots) return;
     const int c = contig_of_slot(td, n_contigs, slot);
@@ -753,6 +763,21 @@ k_emit_genes(const TailDesc* __restrict__ td, int n_contigs, int64_t n_slots, Ou
     G.contig = c; G.begin = gr.begin; G.end = gr.end; G.start_ndx = gr.start_ndx; G.stop_ndx = gr.stop_ndx;
     G.strand = o.strand[sn];
     // single mode keeps the nodes of the DP pass (ref: lib.pyx:5296-5311); meta mode re-scores (5380-5394)
+    if (lean) {
+        // the winners were gathered without their final-pass fields: the start node's sit where the scorer wrote them
+        const int64_t fs = d.fin_off + gr.start_ndx, fe = d.fin_off + gr.stop_ndx;
+        const uint8_t se = single ? o.edge_dp[sn] : ca.edge[fs], ee = single ? o.edge_dp[en] : ca.edge[fe];
+        G.partial_begin = G.strand == 1 ? se : ee; G.partial_end = G.strand == 1 ? ee : se;
+        G.start_type = se ? 3 : o.type[sn];
+        G.rbs[0] = ca.rbs[2 * fs]; G.rbs[1] = ca.rbs[2 * fs + 1];
+        G.mot_len = ca.mot_len[fs]; G.mot_spacer = ca.mot_spacer[fs]; G.mot_ndx = ca.mot_ndx[fs]; G.mot_score = ca.mot_score[fs];
+        G.gc_cont = gcs.p[d.group][d.topo_off + gr.start_ndx];
+        G.cscore = single ? o.cscore_dp[sn] : ca.cscore[fs]; G.sscore = single ? o.sscore_dp[sn] : ca.sscore[fs];
+        G.rscore = single ? o.rscore_dp[sn] : ca.rscore[fs]; G.uscore = single ? o.uscore_dp[sn] : ca.uscore[fs];
+        G.tscore = single ? o.tscore_dp[sn] : ca.tscore[fs];
+        out[gene_begin[c] + g] = G;
+        return;
+    }
     const uint8_t se = single ? o.edge_dp[sn] : o.edge[sn], ee = single ? o.edge_dp[en] : o.edge[en];
     G.partial_begin = G.strand == 1 ? se : ee; G.partial_end = G.strand == 1 ? ee : se;
     G.start_type = se ? 3 : o.type[sn];
@@ -1629,6 +1654,9 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         }
         tm.mark("winners+rescore_launch");
         // ---- gather the winners and bring them home ------------------------------------------------
+        // the winners' final-pass fields only travel to the gathered arrays when somebody reads more of them than the two nodes
+        // of every gene: the caller (node arrays) or the host tail's attribute fetch (PGA_FULL_GATHER=1 keeps the full gather: tests)
+        const bool lean_gather = !P.want_nodes && !(getenv("PGA_TAIL") && strcmp(getenv("PGA_TAIL"), "host") == 0) && !getenv("PGA_FULL_GATHER");
         std::vector<std::vector<WinDesc>> wg(NG);
         std::vector<int64_t> out_off(NC, 0);
         int64_t out_nodes = 0;
@@ -1681,7 +1709,8 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                 HT(c, hipMemcpyAsync(d_win + k0, wg[g].data(), sizeof(WinDesc) * wg[g].size(), hipMemcpyHostToDevice, st));
                 const int64_t nn = w_o0[g + 1] - w_o0[g];
                 if (nn > 0)
-                    hipLaunchKernelGGL(k_gather_winners, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, d_win + k0, (int)wg[g].size(), w_o0[g], nn, ga[g], ca, dp, o, (const int4*)lane_dev.out);
+                    hipLaunchKernelGGL(k_gather_winners, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, d_win + k0, (int)wg[g].size(), w_o0[g], nn, ga[g], ca, dp, o,
+                                       (const int4*)lane_dev.out, lean_gather ? 1 : 0);
                 k0 += wg[g].size();
             }
         }
@@ -1825,6 +1854,8 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                 d.out_off = k >= 0 ? out_off[i] : 0; d.gene_off = n_slots;
                 d.n = k >= 0 ? chains[k].n : 0; d.mx = k >= 0 ? h_maxidx[k] : -1;
                 d.st_wt = k >= 0 ? c->models[chains[k].model].st_wt : 0.0;
+                d.fin_off = k >= 0 ? fin_off[i] : 0; d.topo_off = k >= 0 ? chains[k].topo_off : 0;
+                d.group = k >= 0 && P.meta ? f->model_group[chains[k].model] : 0; d._pad = 0;
                 n_slots += d.n / 2 + 2;
             }
             DEVBUF(d_td, TailDesc, "d_taildesc", NC + 1);
@@ -1915,8 +1946,10 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             if (ngenes > 0) {
                 DEVBUF(d_genes, pga_gene, "d_genes_out", ngenes + 1);
                 HT(c, hipMemcpyAsync(d_gbegin, h_gbegin, sizeof(int64_t) * NC, hipMemcpyHostToDevice, st));
+                GcPtrs gcs{};
+                for (int g = 0; g < NG; g++) gcs.p[g] = ga[g].gc_cont;
                 hipLaunchKernelGGL(k_emit_genes, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, st, d_td, NC, n_slots, o, d_gene2, d_ngenes,
-                                   d_gbegin, P.meta ? 0 : 1, d_genes);
+                                   d_gbegin, P.meta ? 0 : 1, d_genes, lean_gather ? 1 : 0, ca, gcs);
                 HT(c, hipMemcpyAsync(R->genes.data(), d_genes, sizeof(pga_gene) * (size_t)ngenes, hipMemcpyDeviceToHost, st));
             }
             if (P.want_nodes && out_nodes > 0) {

@@ -69,6 +69,10 @@ def test_dp_kernels_and_tails_agree_on_random_gene_dense_contigs(monkeypatch):
             assert np.array_equal(a["score"].view(np.uint64), b["score"].view(np.uint64)) and np.array_equal(a["sscore"].view(np.uint64), b["sscore"].view(np.uint64)), name
             for f in ("cscore", "rscore", "uscore", "tscore"):
                 assert np.array_equal(a[f].view(np.uint64), b[f].view(np.uint64)), (name, f)
+    # without the node arrays the winners are gathered without their final-pass fields and the gene records fetch them per gene
+    for k in ("PGA_DP_KERNEL", "PGA_TAIL", "PGA_CS_LDS", "PGA_SS_MODELS_PER_PASS"):
+        monkeypatch.delenv(k, raising=False)
+    assert ctx.find_genes_batch(seqs, meta=True).genes.tobytes() == base.genes.tobytes()
     # single mode with masking as well
     for k in ("PGA_DP_KERNEL", "PGA_TAIL", "PGA_CS_LDS", "PGA_SS_MODELS_PER_PASS"):
         monkeypatch.delenv(k, raising=False)
