@@ -1467,14 +1467,15 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             const int nch = g_c0[g + 1] - g_c0[g];
             const int64_t nn = g_n0[g + 1] - g_n0[g];
             if (nch == 0 || nn == 0 || stage == PGA_STAGE_EXTRACT) continue;
-            // meta mode, many contigs: the ORF walks of the coding score run from hexamer tables in LDS, contigs bucketed by the
+            // many nodes: the ORF walks of the coding score run from hexamer tables in LDS, contigs bucketed by the
             // four table columns they need (PGA_CS_LDS=0: the global-memory form)
             const void* d_cs_tasks = nullptr; const void* d_cs_entries = nullptr; int n_cs_tasks = 0;
             const char* cs_env = getenv("PGA_CS_LDS");
             const char* cs_tn = getenv("PGA_CS_TASK_NODES");
             const int cs_task_nodes = cs_tn && atoi(cs_tn) >= 256 && atoi(cs_tn) <= 8192 ? atoi(cs_tn) : 4096;     // several tasks per CU and launch
             // PGA_CS_LDS=2 (tests): the LDS form whatever the size of the launch
-            if (meta_run && (nn >= 65536 || (cs_env && atoi(cs_env) == 2)) && !(cs_env && atoi(cs_env) == 0)) {
+            // (single mode as well: one table column, a genome is cut into tasks of `cs_task_nodes` nodes)
+            if ((nn >= 65536 || (cs_env && atoi(cs_env) == 2)) && !(cs_env && atoi(cs_env) == 0) && !f->gil_stride.empty()) {
                 std::vector<int32_t>& tk = cs_tk[g]; std::vector<int32_t>& en = cs_en[g];     // alive until the stream is synchronized
                 if (pga_cs_tasks(h_cc + (size_t)g * NC, NC, chains.data(), h_cbase + (size_t)g * (NC + 1), f->model_rank.data(), cs_task_nodes, tk, en) && !tk.empty()) {
                     char nm1[32], nm2[32];
@@ -1500,7 +1501,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             }
             pga_launch_score(d_chains + g_c0[g], nch, g_n0[g], nn, d_dig, d_ct, ga[g], d_models, f->d_msc, c->d_model_const, ca, sp,
                              d_chains, d_cc + (size_t)g * NC, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], f->d_sd_lut, st, 0,
-                             meta_run ? f->d_gil + f->gil_off[g] : nullptr, meta_run ? f->gil_stride[g] : 0, f->d_model_rank,
+                             (meta_run || n_cs_tasks > 0) ? f->d_gil + f->gil_off[g] : nullptr, (meta_run || n_cs_tasks > 0) ? f->gil_stride[g] : 0, f->d_model_rank,
                              d_cs_tasks, n_cs_tasks, d_cs_entries, &sl);
             NodeArrays na{ga[g].ndx, ga[g].stop_val, ga[g].type, ga[g].strand, ca.cscore, ca.sscore, ca.rscore, ca.uscore, ca.star_ptr};
             if (!use_wave && stage == 0) pga_launch_dp_prepare(d_chains + g_c0[g], nch, g_n0[g], nn, na, c->d_model_const, dp, st);

@@ -81,6 +81,11 @@ def test_dp_kernels_and_tails_agree_on_random_gene_dense_contigs(monkeypatch):
     monkeypatch.setenv("PGA_DP_KERNEL", "scan"); monkeypatch.setenv("PGA_TAIL", "host")
     s2 = ctx.find_genes_batch(seqs, meta=False, mask=True, closed=True)
     assert s1.genes.tobytes() == s2.genes.tobytes() and len(s1.genes) > 500
+    # ... and with the LDS-table form of the coding score (what a single-mode genome of more than 65 536 nodes runs)
+    monkeypatch.delenv("PGA_DP_KERNEL"); monkeypatch.delenv("PGA_TAIL"); monkeypatch.setenv("PGA_CS_LDS", "2")
+    s3 = ctx.find_genes_batch(seqs, meta=False, mask=True, closed=True)
+    monkeypatch.delenv("PGA_CS_LDS")
+    assert s3.genes.tobytes() == s1.genes.tobytes()
     # and the oracle on a sample of the meta-mode run
     bins = [orc.Training(b) for b in models]
     for i in range(0, len(seqs), 9):
