@@ -135,6 +135,7 @@ k_digitize(const char* __restrict__ seq, uint8_t* __restrict__ dig, int64_t tota
         const int64_t g0 = blk0 + q * 4096 + (int64_t)threadIdx.x * 16;
         v[q] = g0 + 16 <= total ? *reinterpret_cast<const uint4*>(seq + g0) : make_uint4(0, 0, 0, 0);
     }
+    int acc_c = -1, acc_gc = 0, acc_unk = 0;            // wave-uniform: what the wavefront holds back for contig acc_c
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int64_t g0 = blk0 + q * 4096 + (int64_t)threadIdx.x * 16;
@@ -166,10 +167,32 @@ k_digitize(const char* __restrict__ seq, uint8_t* __restrict__ dig, int64_t tota
             int a = in ? gc : 0, u = in ? unk : 0;
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m, 64); u += __shfl_xor(u, m, 64); }
-            if ((threadIdx.x & 63) == 0) { if (a) atomicAdd(&gc_count[c0], a); if (u) atomicAdd(&unk_count[c0], u); }
+            // a wavefront's pieces of one contig are added up before they leave it (one contig of 200 Mbp is 195 000 pieces: that many
+            // atomics on one address took longer than the digitising)
+            if (acc_c != c0) {
+                if ((threadIdx.x & 63) == 0 && acc_c >= 0) { if (acc_gc) atomicAdd(&gc_count[acc_c], acc_gc); if (acc_unk) atomicAdd(&unk_count[acc_c], acc_unk); }
+                acc_c = c0; acc_gc = 0; acc_unk = 0;
+            }
+            acc_gc += a; acc_unk += u;
         } else if (in && one_contig) {
             if (gc) atomicAdd(&gc_count[c], gc);
             if (unk) atomicAdd(&unk_count[c], unk);
+        }
+    }
+    // the wavefronts of a block that ended on the same contig leave together
+    __shared__ int s_c[4], s_g[4], s_u[4];
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_c[wv] = acc_c; s_g[wv] = acc_gc; s_u[wv] = acc_unk; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            if (s_c[w] < 0) continue;
+            int g = s_g[w], u = s_u[w];
+#pragma unroll
+            for (int v = w + 1; v < 4; v++) if (s_c[v] == s_c[w]) { g += s_g[v]; u += s_u[v]; s_c[v] = -1; }
+            if (g) atomicAdd(&gc_count[s_c[w]], g);
+            if (u) atomicAdd(&unk_count[s_c[w]], u);
         }
     }
 }
