@@ -1,4 +1,4 @@
-"""Randomised sweep on the GPU box: `python tools/stress_score.py` -- the scoring stage (Nodes.score: coding scores, RBS bins / upstream motifs,
+"""Randomised sweep on the GPU box: `python tools/stress_score.py [SECONDS]` -- the scoring stage (Nodes.score: coding scores, RBS bins / upstream motifs,
 start scores, edge conversion) and the overlapping-start stage against the oracle, field by field, on short and odd sequences, SD and motif models,
 is_meta on and off, open and closed ends."""
 import importlib.util
@@ -19,7 +19,10 @@ ctx = _cabi.Context(0)
 rng = np.random.default_rng(9)
 letters = np.frombuffer(b"ACGTN", np.uint8)
 total = 0
+import time
+t_begin = time.time(); budget = float(sys.argv[1]) if len(sys.argv) > 1 else 1e18      # optional: stop after this many seconds
 for rnd in range(160):
+    if time.time() - t_begin > budget: break
     seqs = []
     for k in range(100):
         L = int(rng.choice([0, 3, 30, 95, 130, 260, 700, 1499, 1501, 2999, 3001, 9000]))
