@@ -113,8 +113,10 @@ k_dp_prepare(const ChainDesc* __restrict__ chains, int n_chains, int64_t node_be
     // then another 500.  The reference's walk-down stops at the highest index whose ndx equals
     // stop_val, or at 0; positions are sorted, so a binary search finds the same index.
     int lo = i < PGA_MAX_NODE_DIST ? 0 : i - PGA_MAX_NODE_DIST;
+    // (positions ascend and a position holds at most two nodes: node k - 2 d - 2 and everything before it lies more than d
+    //  positions left of node k -- a search for position v starts there, not at 0: ten steps instead of twenty-three on a genome)
     if ((kind == 2 || kind == 1) && ndx[lo] > my_stop) {
-        int a = 0, b = lo;            // find last p in [0, lo) with ndx[p] <= my_stop
+        int a = max(0, lo - 2 * max(0, ndx[lo] - my_stop) - 2), b = lo;            // find last p in [0, lo) with ndx[p] <= my_stop
         while (a < b) { int m = (a + b) >> 1; if (ndx[m] <= my_stop) a = m + 1; else b = m; }
         lo = (a > 0 && ndx[a - 1] == my_stop) ? a - 1 : 0;
     }
@@ -122,8 +124,9 @@ k_dp_prepare(const ChainDesc* __restrict__ chains, int n_chains, int64_t node_be
     t.lo = lo; t.p_near = lo;
     for (int k = 0; k < 3; k++) { t.a[k] = 0; t.b[k] = 0; t.c[k] = -1; t._pad[k] = 0; }
     // static index ranges over the sorted positions of nodes [0, i)
-    auto lower = [&](int v) { int a = 0, b = i; while (a < b) { const int m = (a + b) >> 1; if (ndx[m] < v) a = m + 1; else b = m; } return a; };   // first ndx >= v
-    auto upper = [&](int v) { int a = 0, b = i; while (a < b) { const int m = (a + b) >> 1; if (ndx[m] <= v) a = m + 1; else b = m; } return a; };  // first ndx > v
+    auto first_of = [&](int v) { return max(0, i - 2 * max(0, my_ndx - v) - 2); };      // every node before this index lies left of position v
+    auto lower = [&](int v) { int a = first_of(v), b = i; while (a < b) { const int m = (a + b) >> 1; if (ndx[m] < v) a = m + 1; else b = m; } return a; };   // first ndx >= v
+    auto upper = [&](int v) { int a = first_of(v), b = i; while (a < b) { const int m = (a + b) >> 1; if (ndx[m] <= v) a = m + 1; else b = m; } return a; };  // first ndx > v
     if (kind == 0 || kind == 3) t.p_near = max(lo, lower(my_ndx - 3 * PGA_OPER_DIST));
     if (kind == 1) t.a[0] = max(lo, upper(my_stop));
     if (kind == 2) {

@@ -85,7 +85,9 @@ DPW_HD DpwTopo dpw_topo_node(const int32_t* ndx, const int32_t* stopv, const uin
     int lo = i < DPW_MAX_NODE_DIST ? 0 : i - DPW_MAX_NODE_DIST;
     if ((kind == 2 || kind == 1) && ndx[lo] > my_stop) {
         // the reference walks down to the highest index whose position equals stop_val, or to 0
-        int a = 0, b = lo;
+        // (a position holds at most two nodes: everything before node lo - 2 d - 2 lies more than d positions left of node lo)
+        int a = lo - 2 * (ndx[lo] - my_stop) - 2, b = lo;
+        if (a < 0) a = 0;
         while (a < b) { const int m = (a + b) >> 1; if (ndx[m] <= my_stop) a = m + 1; else b = m; }
         lo = (a > 0 && ndx[a - 1] == my_stop) ? a - 1 : 0;
     }
@@ -125,8 +127,9 @@ DPW_HD DpwTopo dpw_topo_node(const int32_t* ndx, const int32_t* stopv, const uin
             }
         }
     } else {
-        int a = 0, b = i;                       // first index in [0, i) with ndx >= my_stop - 4
         const int v = my_stop - 4;
+        int a = i - 2 * (my_ndx > v ? my_ndx - v : 0) - 2, b = i;                       // first index in [0, i) with ndx >= my_stop - 4
+        if (a < 0) a = 0;
         while (a < b) { const int m = (a + b) >> 1; if (ndx[m] < v) a = m + 1; else b = m; }
         t.q2 = DPW_NONE;
         for (int j = a; j < i && ndx[j] < my_stop + DPW_MAX_OPP_OVLP - 5; j++)
