@@ -3,7 +3,7 @@
 
   python tools/sq_counters.py <dir with */p_counter_collection.csv> <trace t_results.db> <title>  > profiles/<tag>_config4_sq_counters.md
 
-The passes are gpurun_in/r3_sq.sh's (three passes of eight SQ counters; never together with a trace).  SQ_ACTIVE_INST_* and
+The passes are tools/collect_sq_counters.sh's (three passes of eight SQ counters; never together with a trace).  SQ_ACTIVE_INST_* and
 SQ_WAVE_CYCLES / SQ_WAIT_* count in units of four cycles, summed over the chip's SIMDs, so
   busy fraction of a pipe = 4 x SQ_ACTIVE_INST_<pipe> / (1024 SIMDs x kernel cycles at 2.4 GHz),
   share of a wave's resident cycles spent waiting = SQ_WAIT_* / SQ_WAVE_CYCLES,
