@@ -244,7 +244,7 @@ cdef object _raise_for(pga_ctx* ctx, int rc, str what):
 # --- TrainingInfo / MetagenomicBins (ref: lib.pyx:3898-4282, 4888-5069) -------------------
 cdef class TrainingInfo:
     """The parameters of one gene model: the reference's 558 392-byte ``struct _training``."""
-    cdef readonly object raw      # numpy uint8[558392]
+    cdef object _raw              # numpy uint8[558392]; `raw` hands out a read-only view
     cdef readonly unsigned long long _version   # bumped by every setter: device copies of the model are reloaded when it moves
 
     def __init__(self, double gc=0.5, *, int translation_table=11, double start_weight=4.35, object raw=None):
@@ -252,11 +252,11 @@ cdef class TrainingInfo:
             arr = np.frombuffer(bytes(raw), dtype=np.uint8).copy()
             if arr.size != TRAINING_INFO_SIZE:
                 raise ValueError("a raw training info must be %d bytes (got %d)" % (TRAINING_INFO_SIZE, arr.size))
-            self.raw = arr
+            self._raw = arr
         else:
             if translation_table not in TRANSLATION_TABLES:
                 raise ValueError("%d is not a valid translation table index" % translation_table)
-            self.raw = np.zeros(TRAINING_INFO_SIZE, dtype=np.uint8)
+            self._raw = np.zeros(TRAINING_INFO_SIZE, dtype=np.uint8)
             self._f64(0)[0] = gc
             self._i32(8)[0] = translation_table
             self._f64(16)[0] = start_weight
@@ -277,13 +277,20 @@ cdef class TrainingInfo:
 
     def dump(self, fp):
         """Write the raw structure to a file object -- ref: lib.pyx:4865-4885."""
-        fp.write(self.raw.tobytes())
+        fp.write(self._raw.tobytes())
+
+    @property
+    def raw(self):
+        """The 558 392 bytes of the structure, read-only: the setters are what tells a device copy of the model that it is stale."""
+        v = self._raw.view()
+        v.setflags(write=False)
+        return v
 
     def _f64(self, int off, int n=1):
-        return self.raw[off:off + 8 * n].view(np.float64)
+        return self._raw[off:off + 8 * n].view(np.float64)
 
     def _i32(self, int off):
-        return self.raw[off:off + 4].view(np.int32)
+        return self._raw[off:off + 4].view(np.int32)
 
     def __repr__(self):
         return "<pyrodigal_amd.lib.TrainingInfo gc=%r start_weight=%r translation_table=%r uses_sd=%r>" % (
@@ -394,10 +401,10 @@ cdef class TrainingInfo:
         self._f64(525624, 4096)[:] = np.asarray(v, np.float64).reshape(-1)
 
     def __eq__(self, other):
-        return isinstance(other, TrainingInfo) and np.array_equal(self.raw, (<TrainingInfo> other).raw)
+        return isinstance(other, TrainingInfo) and np.array_equal(self._raw, (<TrainingInfo> other)._raw)
 
     def __reduce__(self):           # pickling (ref: lib.pyx:4024-4035)
-        return _training_info_from_bytes, (self.raw.tobytes(),)
+        return _training_info_from_bytes, (self._raw.tobytes(),)
 
 
 def _training_info_from_bytes(bytes raw):
@@ -480,13 +487,13 @@ cdef class _StageContext:
     cdef int load(self, TrainingInfo tinf) except -1:
         cdef const pga_training* ptr
         cdef int rc
-        if self.loaded is tinf.raw and self.loaded_version == tinf._version:
+        if self.loaded is tinf._raw and self.loaded_version == tinf._version:
             return 0
-        ptr = <const pga_training*> <size_t> tinf.raw.ctypes.data
+        ptr = <const pga_training*> <size_t> tinf._raw.ctypes.data
         rc = pga_set_models(self.ctx, &ptr, 1)
         if rc != PGA_OK:
             _raise_for(self.ctx, rc, "pga_set_models")
-        self.loaded = tinf.raw
+        self.loaded = tinf._raw
         self.loaded_version = tinf._version
         return 0
 
@@ -516,7 +523,7 @@ cdef class _StagePool:
                     if want is not None:
                         for j in range(len(self.idle)):
                             s = self.idle[j]
-                            if s.loaded is want.raw and s.loaded_version == want._version:
+                            if s.loaded is want._raw and s.loaded_version == want._version:
                                 k = j
                                 break
                     return self.idle.pop(k)
@@ -1461,10 +1468,10 @@ cdef class GeneFinder:
         else:
             tinfs = [self.training_info]
         # the reference shares the struct by pointer, so a setter takes effect at the next call: reload when one moved
-        cdef tuple sig = tuple([(id((<TrainingInfo> t).raw), (<TrainingInfo> t)._version) for t in tinfs])
+        cdef tuple sig = tuple([(id((<TrainingInfo> t)._raw), (<TrainingInfo> t)._version) for t in tinfs])
         if slot.models_loaded and sig == slot.models_sig:
             return 0
-        blobs = [(<TrainingInfo> t).raw for t in tinfs]
+        blobs = [(<TrainingInfo> t)._raw for t in tinfs]
         n = len(blobs)
         ptrs = <const pga_training**> malloc(sizeof(void*) * max(n, 1))
         if ptrs == NULL:

@@ -55,6 +55,11 @@ def test_training_info_roundtrip_and_fields(lib):
     buf = io.BytesIO(); t.dump(buf)
     t2 = lib.TrainingInfo.load(io.BytesIO(buf.getvalue()))
     assert np.array_equal(t.raw, t2.raw)
+    # the bytes are handed out read-only: only the setters change a model, and they are what marks its device copies stale
+    with pytest.raises(ValueError):
+        t.raw[16] = 0
+    t2.start_weight = 4.0
+    assert t2.start_weight == 4.0 and t2 != t
     with pytest.raises(EOFError):
         lib.TrainingInfo.load(io.BytesIO(b"abc"))
     with pytest.raises(ValueError):
