@@ -242,74 +242,43 @@ k_tp_extract(TpWork w, const TailDesc* __restrict__ td, OutArrays o, const int32
     auto val_b = [&](int r) { const int p = pl[cnt - 1 - r]; return v.strand[p] == 1 ? v.ndx[p] + 1 : v.ndx[p] - 1; };
     auto val_e = [&](int r) { const int p = pl[cnt - 1 - r]; return v.strand[p] == 1 ? v.ndx[p] + 3 : v.ndx[p] + 1; };
     const int nthr = blockDim.x;
-    // TP_EPT consecutive path entries per thread and round: their loads are in flight together, and a genome's path (two entries
-    // per gene) is a quarter of the rounds -- a round is three barriers with one workgroup on the whole contig
-    constexpr int TP_EPT = 4;
-    for (int r0 = 0; r0 < cnt; r0 += nthr * TP_EPT) {
-        int pidx[TP_EPT];
-        bool live[TP_EPT], fwd[TP_EPT], stp[TP_EPT];
-#pragma unroll
-        for (int e = 0; e < TP_EPT; e++) { const int r = r0 + t * TP_EPT + e; pidx[e] = r < cnt ? pl[cnt - 1 - r] : -1; }
-#pragma unroll
-        for (int e = 0; e < TP_EPT; e++) {
-            const int p = pidx[e];
-            live[e] = false; fwd[e] = false; stp[e] = false;
-            if (p >= 0) { live[e] = el[p] != 1; fwd[e] = v.strand[p] == 1; stp[e] = is_stop_n(v, p); }
+    for (int r0 = 0; r0 < cnt; r0 += nthr) {
+        const int r = r0 + t;
+        bool live = false, fwd = false, stp = false;
+        if (r < cnt) {
+            const int p = pl[cnt - 1 - r];
+            live = el[p] != 1; fwd = v.strand[p] == 1; stp = is_stop_n(v, p);
         }
-        // who sets what (ref: the four branches of Genes._extract): running maxima of the setters' positions, entry by entry
-        int lm[TP_EPT][4], le[TP_EPT];
-        int m[4] = {-1, -1, -1, -1};
-        int e1 = 0;
-#pragma unroll
-        for (int e = 0; e < TP_EPT; e++) {
-            const int r = r0 + t * TP_EPT + e;
-            const bool set_b = live[e] && ((fwd[e] && !stp[e]) || (!fwd[e] && stp[e]));       // forward start: begin; reverse stop: begin
-            const bool set_e = live[e] && ((fwd[e] && stp[e]) || (!fwd[e] && !stp[e]));       // forward stop: end;   reverse start: end
-            const bool set_s = live[e] && !stp[e];                                          // start node
-            const bool set_t = live[e] && stp[e];                                           // stop node
-            const bool emit = set_e;
-            if (set_b) m[0] = r;
-            if (set_e) m[1] = r;
-            if (set_s) m[2] = r;
-            if (set_t) m[3] = r;
-            e1 += emit ? 1 : 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) lm[e][k] = m[k];
-            le[e] = emit ? e1 : 0;                  // 1-based rank of the emitting entry inside the thread, 0: does not emit
-        }
-        // inclusive scans of the threads' aggregates over the wavefront, then over the wavefronts before, then the carry
-        int am[4] = {m[0], m[1], m[2], m[3]};
-        int ae = e1;
+        // who sets what (ref: the four branches of Genes._extract)
+        const bool set_b = live && ((fwd && !stp) || (!fwd && stp));       // forward start: begin; reverse stop: begin
+        const bool set_e = live && ((fwd && stp) || (!fwd && !stp));       // forward stop: end;   reverse start: end
+        const bool set_s = live && !stp;                                    // start node
+        const bool set_t = live && stp;                                     // stop node
+        const bool emit = live && ((fwd && stp) || (!fwd && !stp));
+        int m[4] = {set_b ? r : -1, set_e ? r : -1, set_s ? r : -1, set_t ? r : -1};
+        int e1 = emit ? 1 : 0;
 #pragma unroll
         for (int dd = 1; dd < 64; dd <<= 1) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) { const int o2 = __shfl_up(am[k], dd, 64); if (lane >= dd) am[k] = max(am[k], o2); }
-            const int o3 = __shfl_up(ae, dd, 64); if (lane >= dd) ae += o3;
+            for (int k = 0; k < 4; k++) { const int o2 = __shfl_up(m[k], dd, 64); if (lane >= dd) m[k] = max(m[k], o2); }
+            const int o3 = __shfl_up(e1, dd, 64); if (lane >= dd) e1 += o3;
         }
-        if (lane == 63) { for (int k = 0; k < 4; k++) s_sc[wave][k] = am[k]; s_cnt[wave] = ae; }
+        if (lane == 63) { for (int k = 0; k < 4; k++) s_sc[wave][k] = m[k]; s_cnt[wave] = e1; }
         __syncthreads();
-        // what lies before this thread: the lanes before it, the wavefronts before its own, the rounds before this one
-        int pm[4]; int pe = __shfl_up(ae, 1, 64);
-#pragma unroll
-        for (int k = 0; k < 4; k++) { pm[k] = __shfl_up(am[k], 1, 64); if (lane == 0) pm[k] = -1; }
-        if (lane == 0) pe = 0;
-        int eoff = s_ng + pe;
+        int eoff = s_ng;
         for (int k2 = 0; k2 < wave; k2++) {
-            for (int k = 0; k < 4; k++) pm[k] = max(pm[k], s_sc[k2][k]);
+            for (int k = 0; k < 4; k++) m[k] = max(m[k], s_sc[k2][k]);
             eoff += s_cnt[k2];
         }
-        for (int k = 0; k < 4; k++) pm[k] = max(pm[k], s_carry[k]);
-#pragma unroll
-        for (int e = 0; e < TP_EPT; e++) {
-            if (!le[e]) continue;
-            const int f0 = max(pm[0], lm[e][0]), f1 = max(pm[1], lm[e][1]), f2 = max(pm[2], lm[e][2]), f3 = max(pm[3], lm[e][3]);
+        for (int k = 0; k < 4; k++) m[k] = max(m[k], s_carry[k]);
+        if (emit) {
             GeneRec gr;
-            gr.begin = f0 >= 0 ? val_b(f0) : 0; gr.end = f1 >= 0 ? val_e(f1) : 0;
-            gr.start_ndx = f2 >= 0 ? pl[cnt - 1 - f2] : 0; gr.stop_ndx = f3 >= 0 ? pl[cnt - 1 - f3] : 0;
-            out[eoff + le[e] - 1] = gr;
+            gr.begin = m[0] >= 0 ? val_b(m[0]) : 0; gr.end = m[1] >= 0 ? val_e(m[1]) : 0;
+            gr.start_ndx = m[2] >= 0 ? pl[cnt - 1 - m[2]] : 0; gr.stop_ndx = m[3] >= 0 ? pl[cnt - 1 - m[3]] : 0;
+            out[eoff + e1 - 1] = gr;
         }
         __syncthreads();
-        if (t == nthr - 1) { for (int k = 0; k < 4; k++) s_carry[k] = max(pm[k], m[k]); s_ng = eoff + e1; }
+        if (t == nthr - 1) { for (int k = 0; k < 4; k++) s_carry[k] = m[k]; s_ng = eoff + e1; }
         __syncthreads();
     }
     if (t == 0) n_genes[s.contig] = s_ng;
