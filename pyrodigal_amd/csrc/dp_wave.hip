@@ -475,18 +475,42 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
             }
         }
         mark(4);
-        // ---- (6) the walk: lane k is final when the walk reaches source i0 + k.  A forward start whose stop lies beyond the
-        //      batch has no target here and is not visited at all
+        // ---- (6) the walk: lane k is final when the walk reaches source i0 + k.  Forward starts are not walked: a forward start
+        //      only ever offers itself to the forward stop of its own ORF (ref: _connection.h:166-174), so that stop PULLS the
+        //      starts of its ORF that sit before it in the batch when the walk reaches it -- the starts are final by then -- instead
+        //      of every start taking a step of the whole wavefront (there are four starts to a stop).  (value, index) decides, ties
+        //      to the larger index, as everywhere between classes of candidates.
         {
             const int kmax = min(63, n - 1 - i0);
-            const int ndx_last = rl_i32(T.ndx, kmax);
-            lanemask todo = W.act & ~vote(T.kind == 0 && T.stop_val > ndx_last) & ((1ull << kmax) - 1ull);
+            const bool f5 = act && T.kind == 0;
+            const lanemask f5f0 = vote(f5 && T.frame == 0), f5f1 = vote(f5 && T.frame == 1), f5f2 = vote(f5 && T.frame == 2);
+            lanemask todo = W.act & ~(f5f0 | f5f1 | f5f2) & ((1ull << kmax) - 1ull);
             SrcRegs R;
             R.pack = T.kind | (T.frame << 2) | (T.vm << 4); R.ndx = T.ndx; R.stop_val = T.stop_val; R.cs = T.cs; R.x0 = T.x0; R.x1 = T.x1; R.x2 = T.x2;
+            // the forward starts of lane k's ORF before it in the batch, onto lane k (a forward stop of frame fk); returns its tag
+            auto pull_starts = [&](const int k, const int fk, int tagk) {
+                lanemask cand = pick3m(fk, f5f0, f5f1, f5f2) & ((1ull << k) - 1ull);
+                if (!cand) return tagk;
+                cand &= vote(T.ndx > rl_i32(T.stop_val, k));
+                if (!cand) return tagk;
+                double bv = rl_f64(L.val, k);
+                int bi = tagk < 0 ? -1 : (tagk & DPW_TAG_MASK), bt = tagk;
+                bool changed = false;
+                while (cand) {
+                    const int c = __builtin_ctzll(cand);
+                    cand &= cand - 1ull;
+                    const double v = rl_f64(L.val, c) + rl_f64(T.cs, c);
+                    if (v > bv || (v == bv && i0 + c > bi)) { bv = v; bi = i0 + c; bt = i0 + c; changed = true; }
+                }
+                if (changed && lane == k) { L.val = bv; L.tag = bt; }
+                return bt;
+            };
             while (todo) {
                 const int k = __builtin_ctzll(todo);
                 todo &= todo - 1ull;
-                const int tagk = rl_i32(L.tag, k);
+                int tagk = rl_i32(L.tag, k);
+                const int pk = rl_i32(R.pack, k);
+                if ((pk & 3) == 1) tagk = pull_starts(k, (pk >> 2) & 3, tagk);
                 if (tagk < 0 && ((W.gb >> k) & 1ull) == 0ull) continue;  // a gene end that was never reached connects to nothing
                 R.score = L.val;                                         // lane k's value is final now
                 // inside the batch the window test is "a later lane": the window reaches back at least 500 nodes
@@ -494,6 +518,11 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
                     const int tbk = tagk & DPW_TAG_MASK;
                     return tbk >= i0 ? rl_i32(T.ndx, tbk - i0) : rl_i32(tbn_pre, k);
                 });
+            }
+            // the last lane is nobody's source, but a forward stop there still has its starts to take
+            {
+                const int pk = rl_i32(R.pack, kmax);
+                if ((pk & 3) == 1) pull_starts(kmax, (pk >> 2) & 3, rl_i32(L.tag, kmax));
             }
         }
         mark(5);
