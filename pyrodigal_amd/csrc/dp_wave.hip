@@ -496,10 +496,11 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
                 double bv = rl_f64(L.val, k);
                 int bi = tagk < 0 ? -1 : (tagk & DPW_TAG_MASK), bt = tagk;
                 bool changed = false;
+                const double offer = L.val + T.cs;                  // what each lane would offer as a forward start (one vector add)
                 while (cand) {
                     const int c = __builtin_ctzll(cand);
                     cand &= cand - 1ull;
-                    const double v = rl_f64(L.val, c) + rl_f64(T.cs, c);
+                    const double v = rl_f64(offer, c);
                     if (v > bv || (v == bv && i0 + c > bi)) { bv = v; bi = i0 + c; bt = i0 + c; changed = true; }
                 }
                 if (changed && lane == k) { L.val = bv; L.tag = bt; }
