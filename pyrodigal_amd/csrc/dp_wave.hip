@@ -385,7 +385,9 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
                 if (sk == 1) { const DpwExt* e = P.ext + er; vm = e->vm; R.x0 = e->x[0]; R.x1 = e->x[1]; R.x2 = e->x[2]; }
                 R.pack = sk | (DPW_FRAME(s_kf) << 2) | (vm << 4);
                 const bool dead = (sk == 1 || sk == 2) && s_tbn == -1;
-                unsigned long long visit = __ballot(in && !dead);
+                // (forward starts before the batch take no step: all they can offer goes to the forward stop of their ORF, and the
+                //  per-frame running maximum of (3) carries exactly that)
+                unsigned long long visit = __ballot(in && !dead && sk != 0);
                 while (visit) {
                     const int u = __builtin_ctzll(visit);
                     visit &= visit - 1;
