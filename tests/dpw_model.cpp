@@ -115,6 +115,7 @@ extern "C" int dpw_model_run(int n, const int32_t* ndx, const int32_t* stop_val,
         for (int j = jmin; j < i0; j++) {
             const DpwS S = load_source(C, j);
             if ((S.kind == 1 || S.kind == 2) && S.tbn == -1) continue;
+            if (S.kind == 0) continue;          // as the kernel: a forward start before the batch offers nothing that the frame carries of (3) do not hold
             stats[1]++;
             for (int t = 0; t < 64; t++) dpw_step(S, LT[t], L[t], M);
         }
@@ -232,6 +233,17 @@ extern "C" int dpw_model_run(int n, const int32_t* ndx, const int32_t* stop_val,
         for (int k = 0; k < 64 && i0 + k < n; k++) {
             DpwS S; memset(&S, 0, sizeof S);
             S.j = i0 + k; S.kind = T[k].kind; S.frame = T[k].frame; S.ndx = T[k].ndx; S.stop_val = T[k].stop_val; S.vm = T[k].vm;
+            // as the kernel: forward starts take no step; a forward stop pulls the forward starts of its ORF that sit before it in
+            // the batch when the walk reaches it (they are final by then), (value, index) deciding, ties to the larger index
+            if (S.kind == 0) continue;
+            if (S.kind == 1) {
+                for (int c = 0; c < k; c++) {
+                    if (!(T[c].kind == 0 && T[c].frame == T[k].frame && T[c].ndx > T[k].stop_val)) continue;
+                    const double v = L[c].val + T[c].cs;
+                    const int bi = dpw_tag_index(L[k].tag);
+                    if (v > L[k].val || (v == L[k].val && i0 + c > bi)) { L[k].val = v; L[k].tag = i0 + c; }
+                }
+            }
             const int tbk = dpw_tag_index(L[k].tag);
             S.tbn = tbk < 0 ? -1 : (tbk >= i0 ? T[tbk - i0].ndx : tbn_pre[k]);
             S.score = L[k].val; S.cs = T[k].cs; S.x0 = T[k].x0; S.x1 = T[k].x1; S.x2 = T[k].x2;
