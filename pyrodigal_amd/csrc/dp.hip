@@ -1630,8 +1630,15 @@ void pga_launch_dp_prepare(const ChainDesc* d_chains, int n_chains, int64_t node
 
 bool pga_dp_use_wave(int n_chains) {
     const char* kern = getenv("PGA_DP_KERNEL");
-    if (kern && *kern) return strcmp(kern, "wave") == 0 || strcmp(kern, "lane") == 0;     // the lane kernel reads the wave kernel's records
+    if (kern && *kern) return strcmp(kern, "wave") == 0 || strcmp(kern, "lane") == 0 || strcmp(kern, "contig") == 0;     // the lane and contig kernels read the wave kernel's records
     return n_chains >= 2048;
+}
+bool pga_dp_use_contig(int n_chains) {
+    const char* kern = getenv("PGA_DP_KERNEL");
+    if (kern && *kern) return strcmp(kern, "contig") == 0;
+    // opt-in until it beats the one-wave-per-chain kernel on the clock (PGA_DP_CONTIG=1)
+    if (const char* e = getenv("PGA_DP_CONTIG")) return atoi(e) != 0 && n_chains >= 2048;
+    return false;
 }
 bool pga_dp_use_lane(int n_chains) {
     const char* kern = getenv("PGA_DP_KERNEL");

@@ -1400,13 +1400,24 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
 #define WBUF(field, type) { snprintf(nm, sizeof nm, "dpw_" #field "%d", g); void* p__; int rc__ = ensure_dev(c, nm, sizeof(type) * (size_t)n + 64, &p__); if (rc__) return rc__; wgroups.g[g].field = (type*)p__; }
                 WBUF(kf, uint8_t) WBUF(lo, int32_t) WBUF(q1, int32_t) WBUF(q2, int32_t)
 #undef WBUF
+                { snprintf(nm, sizeof nm, "dpw_tp%d", g); void* p__; int rc__ = ensure_dev(c, nm, sizeof(int4) * 2 * (size_t)n + 64, &p__); if (rc__) return rc__; wgroups.g[g].tp = (int4*)p__; }
                 wgroups.g[g].ndx = ga[g].ndx; wgroups.g[g].stop_val = ga[g].stop_val; wgroups.g[g].srank = ga[g].srank;
             }
-            DEVBUF(w0, double, "dpw_cs", dp_cap) DEVBUF(w1, DpwExt, "dpw_ext", tot_chain_stops + 2)      /* one extras record per (chain, stop node) pair */ DEVBUF(w2, double, "dpw_sfxv", dp_cap) DEVBUF(w3, int32_t, "dpw_sfxi", dp_cap)
+            DEVBUF(w0, double, "dpw_cs", dp_cap + 2) DEVBUF(w1, DpwExt, "dpw_ext", tot_chain_stops + 4)      /* one extras record per (chain, stop node) pair */ DEVBUF(w2, double, "dpw_sfxv", dp_cap) DEVBUF(w3, int32_t, "dpw_sfxi", dp_cap)
             wbuf = DpwBuffers{w0, w1, w2, w3};
         }
         // very many chains: one LANE each (dp_lane.hip), on the same records; the results stay in its interleaved layout
-        const bool use_lane = use_wave && pga_dp_use_lane(NCH);
+        // many contigs: one wavefront per (contig, group), its lanes the contig's models (dp_contig.hip), on the same records
+        const bool use_contig = use_wave && pga_dp_use_contig(NCH);
+        std::vector<int2> contig_waves;
+        int2* d_contig_waves = nullptr;
+        if (use_contig) {
+            pga_dpc_plan(chains.data(), NCH, contig_waves);
+            DEVBUF(cw, int2, "dpc_waves", contig_waves.size() + 1);
+            HT(c, hipMemcpyAsync(cw, contig_waves.data(), sizeof(int2) * contig_waves.size(), hipMemcpyHostToDevice, st));
+            d_contig_waves = cw;
+        }
+        const bool use_lane = use_wave && !use_contig && pga_dp_use_lane(NCH);
         DplPlan lane_plan;
         DplDev lane_dev{};
         if (use_lane) {
@@ -1428,7 +1439,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         // start order of the wave-batch scorer: longest chains first (counting sort on nodes / 64 = walk batches)
         int32_t* d_dp_order = nullptr;
         std::vector<int32_t> dp_order;
-        if (use_wave && !pga_dp_use_lane(NCH) && NCH > 1 && !getenv("PGA_DP_NO_ORDER")) {
+        if (use_wave && !use_contig && !use_lane && NCH > 1 && !getenv("PGA_DP_NO_ORDER")) {
             std::vector<int32_t> lens((size_t)NCH);
             for (int k = 0; k < NCH; k++) lens[(size_t)k] = chains[k].n;
             dp_order.resize((size_t)NCH);
@@ -1557,7 +1568,8 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         }
         // one DP launch over the chains of every group: chains are independent, the more in flight the better
         HT(c, hipEventRecord(f->e_dp0[0], st));
-        if (use_lane) pga_launch_dp_lane(d_chains, wgroups, c->d_model_const, dp, wbuf, lane_dev, st);
+        if (use_contig) pga_launch_dp_contig(d_contig_waves, (int)contig_waves.size(), d_chains, wgroups, c->d_model_const, dp, wbuf, st);
+        else if (use_lane) pga_launch_dp_lane(d_chains, wgroups, c->d_model_const, dp, wbuf, lane_dev, st);
         else if (use_wave) {
             // PGA_DP_PROFILE=1: cycles per batch phase of every 64th chain (a synchronising debug aid)
             if (getenv("PGA_DP_PROFILE")) {

@@ -129,7 +129,8 @@ struct DpwExt;
 // topology of one translation-table group: what depends on positions and kinds only, shared by every model of a contig
 // srank: per node (stop nodes only) its rank among the stop nodes of its contig, or nullptr: then the extras record of node i of a
 // chain is ext[off + i]; with it, ext[soff + srank[i]] (one 64-byte record per (chain, stop node) pair, dense)
-struct DpwTopoArrays { const int32_t* ndx; const int32_t* stop_val; uint8_t* kf; int32_t* lo; int32_t* q1; int32_t* q2; const int32_t* srank = nullptr; };
+// tp (optional): the same fields packed for the contig-per-wavefront scorer, two int4 per node: {ndx, stop_val, lo, q1}, {q2, kf, 0, 0}
+struct DpwTopoArrays { const int32_t* ndx; const int32_t* stop_val; uint8_t* kf; int32_t* lo; int32_t* q1; int32_t* q2; const int32_t* srank = nullptr; int4* tp = nullptr; };
 struct DpwGroupPtrs { DpwTopoArrays g[4]; };
 // per chain node: cs = cscore + sscore, suffix maxima of finished blocks; per stop node a 64-byte record of extras (indexed by
 // node, or dense by (chain, stop) pair: DpwTopoArrays::srank)
@@ -166,6 +167,15 @@ void pga_launch_dp_lane(const ChainDesc* d_chains, const DpwGroupPtrs& groups, c
 // buf.score / traceb / ov_mark / tbn of chains[0..n_chains) (contiguous in `off` from node_begin) from the interleaved records
 void pga_launch_dpl_unpack(const ChainDesc* d_chains, int n_chains, const int64_t* d_chain_rec, int64_t node_begin, int64_t total, const DplDev& L,
                            DpBuffers buf, hipStream_t st);
+
+// ---- contig-per-wavefront connection scoring for launches with many contigs (dp_contig.hip, dpc_core.h) ----
+// one wavefront per (contig, translation-table group), its lanes the models scored on the contig; reads the wave-batch scorer's
+// records (topology arrays, cs, extras of the stop nodes)
+bool pga_dp_use_contig(int n_chains);
+// waves[k] = (first chain, number of chains) of a run of chains on one contig and group, longest contigs first
+void pga_dpc_plan(const ChainDesc* h_chains, int n_chains, std::vector<int2>& waves);
+void pga_launch_dp_contig(const int2* d_waves, int n_waves, const ChainDesc* d_chains, const DpwGroupPtrs& groups, const ModelConst* d_models,
+                          DpBuffers buf, const DpwBuffers& wb, hipStream_t st);
 
 // kernel launchers (dp.hip)
 // chains[0..n_chains) must be contiguous in `off`; node_begin = chains[0].off, total_nodes = their node count

@@ -51,6 +51,7 @@ def test_dp_kernels_and_tails_agree_on_random_gene_dense_contigs(monkeypatch):
                       # the kernels every headline number comes from, forced onto this small launch: the wave-batch connection
                       # scorer, the lane-per-chain connection scorer and the LDS-table form of the coding score
                       ("wave+ldscs", {"PGA_DP_KERNEL": "wave", "PGA_CS_LDS": "2"}), ("lane+ldscs", {"PGA_DP_KERNEL": "lane", "PGA_CS_LDS": "2"}),
+                      ("contig+ldscs", {"PGA_DP_KERNEL": "contig", "PGA_CS_LDS": "2"}),
                       # the start scorer walking a workgroup's models three to a pass (its path for more than 512 models)
                       ("tree+3models/pass", {"PGA_SS_MODELS_PER_PASS": "3"})):
         for k in ("PGA_DP_KERNEL", "PGA_TAIL", "PGA_CS_LDS", "PGA_SS_MODELS_PER_PASS"):
