@@ -5,7 +5,7 @@
 // code of its own kind, and loops over near nodes / candidates have the same trip count in every lane.  What differs per lane
 // is values: scores, the extras of a stop node (through star_ptr), running maxima and their argmax.
 //
-// The case analysis is the lane kernel's (dpl_core.h, pinned against the oracle): every class of candidates of a node comes
+// The case analysis is the lane kernel's (dpl_core.h, pinned against the plain restatement of the reference on the CPU): every class of candidates of a node comes
 // from a running structure that costs O(1) per node.  What changes with a uniform topology:
 //   * the "rings" of near gene ends are not copies but an index range: the nodes [fp, i) not folded into the far maxima yet,
 //     fp = the first node within 3 * OPER_DIST bases of the last gene begin (DpwTopo::q1); their values come from a short
@@ -25,7 +25,7 @@
 // the reference's own loop over the whole window, pair by pair, with every source read back from memory: exact for any node,
 // rare, and the only place that knows about windows that cut running maxima, overflowed lists and deep near zones), then
 // dpc_finish_*: what the node leaves for later ones.  Written once for the device and the host: tests/dpc_model.cpp runs the
-// same routines model by model against the oracle.
+// same routines model by model against the plain restatement of the reference's loop on the CPU.
 //
 // Same recurrence (ref: lib.pyx:1205-1237 `_score_connections`, _connection.h:94-408, impl/generic.h:29-36):
 //     score[i] = max(0, max_j (score[j] + w(j, i))) over the window [lo_i, i), ties -> largest j.
