@@ -245,7 +245,7 @@ static int score_connections_impl(pga_ctx* c, int32_t n, const int32_t* ndx, con
         DpwBuffers wb{};
         int32_t* d_cbase;
         const int32_t h_cbase[2] = {0, n};
-        HIP_TRY(c, db.alloc(&wg.g[0].tp, 2 * N)); HIP_TRY(c, db.alloc(&wg.g[0].kf, N)); HIP_TRY(c, db.alloc(&wg.g[0].lo, N)); HIP_TRY(c, db.alloc(&wg.g[0].q1, N)); HIP_TRY(c, db.alloc(&wg.g[0].q2, N));
+        HIP_TRY(c, db.alloc(&wg.g[0].tp, 2 * N)); HIP_TRY(c, db.alloc(&wg.g[0].prog, 4 * N)); HIP_TRY(c, db.alloc(&wg.g[0].kf, N)); HIP_TRY(c, db.alloc(&wg.g[0].lo, N)); HIP_TRY(c, db.alloc(&wg.g[0].q1, N)); HIP_TRY(c, db.alloc(&wg.g[0].q2, N));
         HIP_TRY(c, db.alloc(&wb.cs, N + 2)); HIP_TRY(c, db.alloc(&wb.ext, N + 4)); HIP_TRY(c, db.alloc(&wb.sfxv, N)); HIP_TRY(c, db.alloc(&wb.sfxi, N));
         HIP_TRY(c, db.alloc(&d_cbase, 2));
         HIP_TRY(c, hipMemcpyAsync(d_cbase, h_cbase, sizeof h_cbase, hipMemcpyHostToDevice, st));
@@ -253,6 +253,7 @@ static int score_connections_impl(pga_ctx* c, int32_t n, const int32_t* ndx, con
         pga_launch_dpw_topo(wg.g[0], nd.type, nd.strand, d_cbase, 1, n, st);
         pga_launch_dpw_chain(d_chain, 1, 0, n, na, wg.g[0], d_mc, wb, st);
         if (pga_dp_use_contig(1)) {
+            pga_launch_dpc_compile(wg.g[0], d_cbase, 1, st);
             // PGA_DP_KERNEL=contig: the contig-per-wavefront kernel on a wave whose one lane is this chain (tests)
             std::vector<int2> waves;
             pga_dpc_plan(&ch, 1, waves);

@@ -67,62 +67,34 @@ __device__ __forceinline__ void wait_vm4(const int k) {
 }
 __device__ __forceinline__ lanemask bits_range(const int lo, const int hi) { return (~0ull >> (64 - hi)) & (~0ull << lo); }     // 0 <= lo < hi <= 64
 
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef const v4i __attribute__((address_space(4)))* prog_ptr;      // the compiled records: read with scalar loads
+
 template <int LW>
 struct CmX {
     int4 (*hist_)[LW];          // [DPC_HIST][LW]: {score as a source (lo, hi), position of the traceb node (forward stops), tag}
     int4 (*cand_)[LW];          // [3 * DPC_CAND][LW]: {score as a source (lo, hi), position of the traceb node, -}
     int4 (*carry_)[LW];         // [3][LW]: forward carry of each frame {v (lo, hi), i, n}
     double (*l3v_)[LW];         // [3][LW]: score of the last reverse stop of each frame
-    int ndx_c, ndx_p;           // positions of the current / previous batch, lane = node
-    lanemask f3_c, r5_c, f3_p, r5_p;       // forward stops / reverse starts of the current / previous batch
-    int i0, cur;                // first node of the current batch; the node being walked
+    prog_ptr prog;              // the contig's records
+    int cur;                    // the node being walked
     int cidx, cndx;             // candidate lists: lane 8 f + k holds entry k of reverse frame f (uniform values parked in a VGPR)
-    int l3i_, l3s_, l3n_;       // last reverse stop of frame f -- index, stop_val, position -- in lane f (uniform values parked in VGPRs)
     double st_wt;
     int ml;                     // lane % LW: this lane's model
     bool writer;                // lane < LW
-    // memory (rare paths; the per-lane addresses are formed there: no registers held for them)
+    // memory (slow path; the per-lane addresses are formed there: no registers held for them)
     const int4* g_tp; const int32_t* g_srank; const double* g_cs; const DpwExt* g_ext; const double* g_score; const int32_t* g_tb; int64_t off;
 
-    __device__ __forceinline__ int reach() const { return i0 >= 64 ? i0 - 64 : 0; }
-    template <class F> __device__ __forceinline__ void seg(const int a, const int b, const int base, const lanemask km, const int ndxv, F f) {
-        const int lo_l = max(a, base) - base, hi_l = min(b, base + 64) - base;
-        if (hi_l > lo_l) {
-            lanemask m = km & bits_range(lo_l, hi_l);
-            while (m) {
-                const int u = __builtin_ctzll(m);
-                m &= m - 1ull;
-                f(base + u, rl(ndxv, u));
-            }
-        }
-    }
-    // [a, b) from reach() on: in the current batch or the one before
-    template <class F> __device__ __forceinline__ void for_near(const int a, const int b, const int kind, F f) {
-        if (a < i0) seg(a, b, i0 - 64, kind == DPC_K_F3 ? f3_p : r5_p, ndx_p, f);
-        seg(a, b, i0, kind == DPC_K_F3 ? f3_c : r5_c, ndx_c, f);
-    }
-    // a gene end of the last DPC_HIST nodes
     __device__ __forceinline__ DpcHist hist(const int j) const {
         const int4 v = hist_[j & (DPC_HIST - 1)][ml];
         return DpcHist{__hiloint2double(v.y, v.x), v.z};
     }
-    // ... or an older one, whose results have been written out (by other lanes of this wave)
-    __device__ __forceinline__ DpcHist hist_deep(const int j) const {
-        if (j > cur - DPC_HIST) return hist(j);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        const int tb = g_tb[off + j];
-        return DpcHist{tb == -1 ? -__builtin_huge_val() : g_score[off + j], tb == -1 ? -1 : g_tp[2 * tb].x};
-    }
-    __device__ __forceinline__ int ndx_of(const int j) const { return j >= i0 ? rl(ndx_c, j - i0) : rl(ndx_p, j - i0 + 64); }
+    __device__ __forceinline__ int ndx_of(const int j) const { return prog[4 * j].y; }
     __device__ __forceinline__ void hist_put(const int i, const double sv, const int tbn, const int tag) {
         if (writer) hist_[i & (DPC_HIST - 1)][ml] = make_int4(__double2loint(sv), __double2hiint(sv), tbn, tag);
     }
     __device__ __forceinline__ DpcCarry carry(const int f) const { const int4 v = carry_[f][ml]; return DpcCarry{__hiloint2double(v.y, v.x), v.z, v.w}; }
     __device__ __forceinline__ void set_carry(const int f, const DpcCarry& c) { if (writer) carry_[f][ml] = make_int4(__double2loint(c.v), __double2hiint(c.v), c.i, c.n); }
-    __device__ __forceinline__ int l3i(const int f) const { return rl(l3i_, f); }
-    __device__ __forceinline__ int l3s(const int f) const { return rl(l3s_, f); }
-    __device__ __forceinline__ int l3n(const int f) const { return rl(l3n_, f); }
-    __device__ __forceinline__ void set_l3(const int f, const int i, const int s, const int n) { l3i_ = wl(i, f, l3i_); l3s_ = wl(s, f, l3s_); l3n_ = wl(n, f, l3n_); }
     __device__ __forceinline__ double l3v(const int f) const { return l3v_[f][ml]; }
     __device__ __forceinline__ void set_l3v(const int f, const double v) { if (writer) l3v_[f][ml] = v; }
     // any finished node as a source, from memory (slow path)
@@ -161,22 +133,44 @@ struct CmX {
     __device__ __forceinline__ bool any(const bool p) const { return __ballot(p) != 0ull; }
 };
 
-// The same accessor for a gene begin whose unfolded range reaches back beyond the history (a dense stretch: rare): its own copy of
-// the fast routines, so that the loads from memory -- and the waits for them -- stay out of the common path.
-template <int LW>
-struct CmXDeep : CmX<LW> {
-    __device__ __forceinline__ DpcHist hist(const int j) const { return this->hist_deep(j); }
-};
+__device__ __forceinline__ DpcProg load_prog(prog_ptr prog, const int i) {
+    DpcProg P;
+    const v4i a = prog[4 * i], b = prog[4 * i + 1], c = prog[4 * i + 2], d = prog[4 * i + 3];
+    P.w[0] = a.x; P.w[1] = a.y; P.w[2] = a.z; P.w[3] = a.w; P.w[4] = b.x; P.w[5] = b.y; P.w[6] = b.z; P.w[7] = b.w;
+    P.w[8] = c.x; P.w[9] = c.y; P.w[10] = c.z; P.w[11] = c.w; P.w[12] = d.x; P.w[13] = d.y; P.w[14] = d.z; P.w[15] = d.w;
+    return P;
+}
 
-// packed topology of 64 nodes, lane = node: a = {ndx, stop_val, lo, q1}, b = {q2, kf}
-struct TopoRegs { int4 a; int2 b; };
-__device__ __forceinline__ TopoRegs load_topo(const int4* __restrict__ tp, const int i0, const int lane, const int n) {
-    TopoRegs r;
-    const int ii = min(i0 + lane, n - 1);
-    r.a = tp[2 * ii];
-    const int4 b = tp[2 * ii + 1];
-    r.b = make_int2(b.x, b.y);
-    return r;
+// The topology of every contig of a group, compiled (dpc_compile_node): one wavefront per contig, lane = node, 64 nodes a pass; the
+// last reverse stop of each frame before a node comes from ballots over the pass and a carry from the passes before.
+__global__ void __launch_bounds__(64)
+k_dpc_compile(const int32_t* __restrict__ cbase, DpwTopoArrays ta) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const int b0 = cbase[c], n = cbase[c + 1] - b0;
+    const int32_t* ndx = ta.ndx + b0; const int32_t* stopv = ta.stop_val + b0; const uint8_t* kf = ta.kf + b0;
+    const int32_t* lo = ta.lo + b0; const int32_t* q1 = ta.q1 + b0; const int32_t* q2 = ta.q2 + b0;
+    int carry0 = -1, carry1 = -1, carry2 = -1;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const bool act = i < n;
+        const int k = act ? kf[i] : 0;
+        const bool r3 = act && DPW_KIND(k) == 3;
+        const lanemask m0 = __ballot(r3 && DPW_FRAME(k) == 0), m1 = __ballot(r3 && DPW_FRAME(k) == 1), m2 = __ballot(r3 && DPW_FRAME(k) == 2);
+        const lanemask below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+        const int l0 = (m0 & below) ? i0 + 63 - __builtin_clzll(m0 & below) : carry0;
+        const int l1 = (m1 & below) ? i0 + 63 - __builtin_clzll(m1 & below) : carry1;
+        const int l2 = (m2 & below) ? i0 + 63 - __builtin_clzll(m2 & below) : carry2;
+        if (act) {
+            DpcProg P;
+            dpc_compile_node(ndx, stopv, kf, lo, q1, q2, i, l0, l1, l2, P);
+            int4* out = ta.prog + 4 * ((int64_t)b0 + i);
+            out[0] = make_int4(P.w[0], P.w[1], P.w[2], P.w[3]); out[1] = make_int4(P.w[4], P.w[5], P.w[6], P.w[7]);
+            out[2] = make_int4(P.w[8], P.w[9], P.w[10], P.w[11]); out[3] = make_int4(P.w[12], P.w[13], P.w[14], P.w[15]);
+        }
+        if (m0) carry0 = i0 + 63 - __builtin_clzll(m0);
+        if (m1) carry1 = i0 + 63 - __builtin_clzll(m1);
+        if (m2) carry2 = i0 + 63 - __builtin_clzll(m2);
+    }
 }
 
 template <int LW>
@@ -184,7 +178,7 @@ __global__ void __launch_bounds__(64)
 k_dp_contig(const int2* __restrict__ waves, const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const double* __restrict__ g_cs,
             const DpwExt* __restrict__ g_ext, const ModelConst* __restrict__ models, DpBuffers buf) {
     static_assert(LW == 8, "cs staging: 32 lanes x 16 bytes = 8 nodes x 8 models");
-    static_assert(DPC_HIST == 2 * DPC_FLUSH && 64 % DPC_FLUSH == 0, "the history holds a flush unit of unflushed results and one being read");
+    static_assert(DPC_HIST == 2 * DPC_FLUSH && 64 % DPC_FLUSH == 0 && DPC_REACH == DPC_HIST, "the history holds a flush unit of unflushed results and one being read");
     constexpr int NPG = 64 / LW;                    // nodes per load of cs
     constexpr int MPF = 64 / DPC_FLUSH;             // models per store instruction of a flush
     __shared__ int4 s_hist[DPC_HIST][LW];
@@ -205,6 +199,7 @@ k_dp_contig(const int2* __restrict__ waves, const ChainDesc* __restrict__ chains
     const int grp = rfl(cd.group);
     const int64_t toff = ((int64_t)rfl((int)(cd.topo_off >> 32)) << 32) | (uint32_t)rfl((int)cd.topo_off);
     const int4* __restrict__ tp = groups.g[grp].tp + 2 * toff;
+    const prog_ptr prog = (prog_ptr)(const void*)(groups.g[grp].prog + 4 * toff);
     const bool dense = groups.g[grp].srank != nullptr;
     const ModelConst* mc = &models[cd.model];
     const double st_wt = mc->st_wt, negc = mc->negc;
@@ -213,19 +208,24 @@ k_dp_contig(const int2* __restrict__ waves, const ChainDesc* __restrict__ chains
     const DpwExt* __restrict__ my_ext = g_ext + (dense ? cd.soff : cd.off);
     const int off_lo = (int)cd.off, off_hi = (int)(cd.off >> 32);
 
-    CmXDeep<LW> xd;                                // (the deep variant only overrides hist)
-    CmX<LW>& x = xd;
-    x.hist_ = s_hist; x.cand_ = s_cand; x.carry_ = s_carry; x.l3v_ = s_l3v;
-    x.ndx_c = 0; x.ndx_p = 0; x.f3_c = x.r5_c = x.f3_p = x.r5_p = 0ull; x.i0 = 0; x.cur = 0; x.cidx = 0; x.cndx = 0; x.l3i_ = -1; x.l3s_ = 0; x.l3n_ = 0;
+    CmX<LW> x;
+    x.hist_ = s_hist; x.cand_ = s_cand; x.carry_ = s_carry; x.l3v_ = s_l3v; x.prog = prog;
+    x.cur = 0; x.cidx = 0; x.cndx = 0;
     x.st_wt = st_wt; x.ml = ml; x.writer = lane < LW;
     x.g_tp = tp; x.g_srank = dense ? groups.g[grp].srank + toff : nullptr; x.g_cs = my_cs; x.g_ext = my_ext;
     x.g_score = buf.score; x.g_tb = buf.traceb; x.off = cd.off;
 
-    DpcRegs R; DpcUni U;
-    dpc_init(R, U, x);
+    // what this lane has asked memory for so far has to be here before the walk starts: a wait for it that the compiler leaves inside
+    // the loop would also wait for the loads the loop issues behind its back (lds_dma16)
+    {
+        int a0 = __double2loint(st_wt), a1 = __double2hiint(st_wt), a2 = __double2loint(negc), a3 = __double2hiint(negc), a4 = off_lo, a5 = off_hi;
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    DpcRegs R;
+    dpc_init(R, x);
     if (n >= 1024) __builtin_amdgcn_s_setprio(2); else if (n >= 768) __builtin_amdgcn_s_setprio(1);      // a launch ends when its longest contig does
 
-    TopoRegs cur{}, nxt = load_topo(tp, 0, lane, n);
     // cs = cscore + sscore of this lane's model, 64 / LW nodes per group, asked for one group ahead, straight into LDS: lane
     // (node pair p, model m) brings the two nodes of its pair (16 bytes; the array has two doubles of slack behind its last chain)
     auto ask_cs = [&](const int g) {
@@ -235,11 +235,8 @@ k_dp_contig(const int2* __restrict__ waves, const ChainDesc* __restrict__ chains
     ask_cs(0);
     int cs_stop = 0;                                // stop nodes walked when the group on its way was asked for
     // The extras of the stop nodes (64 bytes per stop and model): dense records by stop rank, asked for three stops ahead, straight
-    // into LDS (global_load_lds: no registers held across the nodes in between, nothing to wait for until the stop is reached)
+    // into LDS (no registers held across the nodes in between, nothing to wait for until the stop is reached)
     int nstop = 0;                                  // stop nodes walked so far
-#ifdef DPC_PROFILE
-    unsigned long long pc_wait = 0, pc_cswait = 0; int pc_slow = 0, pc_deep = 0, pc_slowsrc = 0;
-#endif
     auto ask_ext = [&](const int rec, const int slot) {
         if (lane < LW) {
             const char* p = reinterpret_cast<const char*>(my_ext + rec);
@@ -250,13 +247,7 @@ k_dp_contig(const int2* __restrict__ waves, const ChainDesc* __restrict__ chains
     // the record of the stop being walked: parts 0, 1 and 3 for a forward stop (x[], vm), all four for a reverse stop
     auto read_ext = [&](DpcExt& E, const int slot, const bool all) {
         // the two records asked for after this one -- four loads each -- may still be on their way
-#ifdef DPC_PROFILE
-        const unsigned long long w0 = __builtin_readcyclecounter();
-#endif
         if (dense) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef DPC_PROFILE
-        pc_wait += __builtin_readcyclecounter() - w0;
-#endif
         const int4 a = s_ext[slot][0][ml], bq = s_ext[slot][1][ml], d = s_ext[slot][3][ml];
         E.x[0] = __hiloint2double(a.y, a.x); E.x[1] = __hiloint2double(a.w, a.z); E.x[2] = __hiloint2double(bq.y, bq.x); E.vm = d.w;
         E.n3n[0] = bq.z; E.n3n[1] = bq.w; E.cq[0] = d.x; E.cq[1] = d.y; E.cq[2] = d.z;
@@ -282,123 +273,82 @@ k_dp_contig(const int2* __restrict__ waves, const ChainDesc* __restrict__ chains
         }
     };
 
-#ifdef DPC_PROFILE
-    unsigned long long pc_cyc[5] = {0, 0, 0, 0, 0}; int pc_cnt[5] = {0, 0, 0, 0, 0};
-#endif
+    DpcProg Pn = load_prog(prog, 0);
     for (int i = 0; i < n; i++) {
-#ifdef DPC_PROFILE
-        const unsigned long long pc_t0 = __builtin_readcyclecounter();
-#endif
-        const int t = i & 63;
-        if (t == 0) {
-            // this batch's topology arrives, the next one is asked for
-            x.ndx_p = x.ndx_c; x.f3_p = x.f3_c; x.r5_p = x.r5_c;
-            cur = nxt;
-            if (i + 64 < n) nxt = load_topo(tp, i + 64, lane, n);
-            const bool act = i + lane < n;
-            const int k = DPW_KIND(cur.b.y);
-            x.f3_c = __ballot(act && k == 1); x.r5_c = __ballot(act && k == 2);
-            x.ndx_c = cur.a.x; x.i0 = i;
-        }
+        // this node's record arrived while the node before it was walked; the next one's is asked for
+        const DpcProg P = Pn;
+        if (i + 1 < n) Pn = load_prog(prog, i + 1);
         if ((i % DPC_FLUSH) == 0 && i > 0) flush(i - DPC_FLUSH, i);
         if ((i % NPG) == 0) {
             // this group's cs has arrived (asked for a group ago), the next group's is asked for
             // (every stop node walked since has asked for a record of extras: four loads each, all of them later than this group's)
-#ifdef DPC_PROFILE
-            const unsigned long long w0 = __builtin_readcyclecounter();
-#endif
             wait_vm4(dense ? nstop - cs_stop : 0);
-#ifdef DPC_PROFILE
-            pc_cswait += __builtin_readcyclecounter() - w0;
-#endif
             ask_cs(i / NPG + 1);
             cs_stop = nstop;
         }
-        DpcNode N;
-        N.i = i; N.kfb = rl(cur.b.y, t); N.kind = DPW_KIND(N.kfb); N.frame = DPW_FRAME(N.kfb);
-        N.ndx = rl(cur.a.x, t); N.stop_val = 0; N.lo = rl(cur.a.z, t); N.q1 = 0; N.q2 = 0;
         x.cur = i;
-#ifdef DPC_PROFILE
-        const unsigned long long pc_t1 = __builtin_readcyclecounter();
-        pc_cyc[4] += pc_t1 - pc_t0; pc_cnt[4]++;
-#endif
+        const int kind = dpc_prog_kind(P), f = dpc_prog_frame(P);
         // A node the fast routines do not cover (rare) goes through the reference's loop over its whole window; every other node
         // through the branch of its kind, from its loads to what it leaves in the history: nothing but the loop-carried state
         // crosses from one branch to the next.  (dpc_need_slow_* are uniform by construction; the readfirstlane tells the compiler.)
         const int slot = nstop & 3;
         DpcExt E;
         bool slow;
-        if (N.kind == 0) { N.q1 = rl(cur.a.w, t); slow = dpc_need_slow_begin(R, U, N, x); }
-        else if (N.kind == 2) { N.stop_val = rl(cur.a.y, t); N.q2 = rl(cur.b.x, t); slow = dpc_need_slow_r5(U, N, x); }
-        else if (N.kind == 1) { if (!dense) ask_ext(i, slot); read_ext(E, slot, false); slow = false; }
+        if (kind == 0) slow = dpc_need_slow_begin(R, P, x);
+        else if (kind == 2) slow = (P.w[0] & DPC_F_SLOW) != 0;
+        else if (kind == 1) { if (!dense) ask_ext(i, slot); read_ext(E, slot, false); slow = false; }
         else {
-            N.stop_val = rl(cur.a.y, t); N.q1 = rl(cur.a.w, t);
             if (!dense) ask_ext(i, slot);
             read_ext(E, slot, true);
-            slow = dpc_need_slow_begin(R, U, N, x) || dpc_need_slow_r3(U, N, E, x);
+            slow = dpc_need_slow_begin(R, P, x) || dpc_need_slow_r3(P, i, E, x);
         }
-        if (N.kind & 1) { nstop++; if (dense) ask_ext(nstop + 2, (nstop + 2) & 3); }     // (three records of slack behind the last chain's)
+        if (kind & 1) { nstop++; if (dense) ask_ext(nstop + 2, (nstop + 2) & 3); }     // (three records of slack behind the last chain's)
         if (__builtin_expect(rfl((int)slow), 0)) {
-#ifdef DPC_PROFILE
-            pc_slow++; pc_slowsrc += i - N.lo;
-#endif
-            N.stop_val = rl(cur.a.y, t); N.q1 = rl(cur.a.w, t); N.q2 = rl(cur.b.x, t);
+            DpcNode N;
+            N.i = i; N.kind = kind; N.frame = f; N.kfb = P.w[0] & 255; N.ndx = P.w[1]; N.stop_val = P.w[2]; N.lo = P.w[3];
+            N.q1 = rfl(tp[2 * i].w); N.q2 = rfl(tp[2 * i + 1].x);
             const double cs = s_cs[(i / NPG) & 1][(((i % NPG) >> 1) * LW + ml) * 2 + (i & 1)];
             DpcOut B{0.0, -1, -1, 0.0, -1};
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // results written out by this wave are read back
-            dpc_cand_slow(R, U, N, cs, E, M, x, B);
-            if (N.kind == 0) dpc_finish_f5(N, cs, x.carry(N.frame), x, B);
-            else if (N.kind == 2) dpc_finish_r5(R, N, negc, B);
-            else dpc_finish_r3(U, N, x, B);
+            dpc_cand_slow(R, N, cs, E, M, x, B);
+            {
+                // what the slow routine read from memory is waited for HERE (an empty statement that uses the values): left to the point
+                // where the branches meet, the wait would sit on every node's path and catch the loads in flight behind the compiler's back
+                int v0 = __double2loint(B.val), v1 = __double2hiint(B.val), v2 = __double2loint(R.r5_all.v), v3 = __double2hiint(R.r5_all.v),
+                    v4 = __double2loint(R.r5_far.v), v5 = __double2hiint(R.r5_far.v), v6 = __double2loint(R.f3_far.v), v7 = __double2hiint(R.f3_far.v);
+                asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(B.tb), "+v"(B.ov), "+v"(R.r5_all.i),
+                             "+v"(R.r5_far.i), "+v"(R.f3_far.i));
+                B.val = __hiloint2double(v1, v0); R.r5_all.v = __hiloint2double(v3, v2); R.r5_far.v = __hiloint2double(v5, v4); R.f3_far.v = __hiloint2double(v7, v6);
+            }
+            if (kind == 0) dpc_finish_f5(P, i, cs, x.carry(f), x, B);
+            else if (kind == 2) dpc_finish_r5(R, i, negc, B);
+            else dpc_finish_r3(P, i, x, B);
             x.hist_put(i, B.sv, -1, B.tb < 0 ? -1 : (B.tb | ((B.ov + 1) << DPW_TAG_BITS)));
-        } else if (__builtin_expect((N.kind == 0 || N.kind == 3) && U.fp <= i - DPC_HIST, 0)) {
-#ifdef DPC_PROFILE
-            pc_deep++;
-#endif
-            // a gene begin whose unfolded range reaches back beyond the history: the same routines on the accessor that reads older
-            // gene ends back from memory (a dense stretch of the contig: rare)
+        } else if (kind == 0) {
             const double cs = s_cs[(i / NPG) & 1][(((i % NPG) >> 1) * LW + ml) * 2 + (i & 1)];
+            const DpcCarry c = x.carry(f);
             DpcOut B{0.0, -1, -1, 0.0, -1};
-            if (N.kind == 0) { const DpcCarry c = x.carry(N.frame); dpc_cand_f5(R, U, N, M, xd, B); dpc_finish_f5(N, cs, c, x, B); }
-            else { dpc_cand_r3(R, U, N, E, M, xd, B); dpc_finish_r3(U, N, x, B); }
-            x.hist_put(i, B.val, -1, B.tb < 0 ? -1 : (B.tb | ((B.ov + 1) << DPW_TAG_BITS)));
-        } else if (N.kind == 0) {
-            const double cs = s_cs[(i / NPG) & 1][(((i % NPG) >> 1) * LW + ml) * 2 + (i & 1)];
-            const DpcCarry c = x.carry(N.frame);
-            DpcOut B{0.0, -1, -1, 0.0, -1};
-            dpc_cand_f5(R, U, N, M, x, B);
-            dpc_finish_f5(N, cs, c, x, B);
+            dpc_cand_f5(R, P, i, M, x, B);
+            dpc_finish_f5(P, i, cs, c, x, B);
             x.hist_put(i, B.val, -1, B.tb);
-        } else if (N.kind == 2) {
+        } else if (kind == 2) {
             const double cs = s_cs[(i / NPG) & 1][(((i % NPG) >> 1) * LW + ml) * 2 + (i & 1)];
             DpcOut B{0.0, -1, -1, 0.0, -1};
-            dpc_cand_r5(U, N, cs, negc, x, B);
-            dpc_finish_r5(R, N, negc, B);
+            dpc_cand_r5(P, cs, negc, x, B);
+            dpc_finish_r5(R, i, negc, B);
             x.hist_put(i, B.sv, -1, B.tb);
-        } else if (N.kind == 1) {
+        } else if (kind == 1) {
             DpcOut B{0.0, -1, -1, 0.0, -1};
-            dpc_cand_f3(x.carry(N.frame), B);
-            dpc_finish_f3(R, U, N, E, x, B);
+            dpc_cand_f3(x.carry(f), B);
+            dpc_finish_f3(R, P, i, E, x, B);
             x.hist_put(i, B.sv, B.tbn, B.tb);
         } else {
             DpcOut B{0.0, -1, -1, 0.0, -1};
-            dpc_cand_r3(R, U, N, E, M, x, B);
-            dpc_finish_r3(U, N, x, B);
+            dpc_cand_r3(R, P, i, E, M, x, B);
+            dpc_finish_r3(P, i, x, B);
             x.hist_put(i, B.val, -1, B.tb < 0 ? -1 : (B.tb | ((B.ov + 1) << DPW_TAG_BITS)));
         }
-#ifdef DPC_PROFILE
-        pc_cyc[N.kind] += __builtin_readcyclecounter() - pc_t1; pc_cnt[N.kind]++;
-#endif
     }
-#ifdef DPC_PROFILE
-    if (blockIdx.x == 100 && lane == 0)
-        printf("[dpc profile] ext wait per stop %.0f, cs wait per group %.0f\n", (double)pc_wait / (pc_cnt[1] + pc_cnt[3] + 1), (double)pc_cswait / (n / 8 + 1));
-    if ((pc_slow || pc_deep) && lane == 0 && (blockIdx.x % 64) == 0) printf("[dpc profile] wave %d n=%d: slow %d (sources %d) deep %d\n", (int)blockIdx.x, n, pc_slow, pc_slowsrc, pc_deep);
-    if (blockIdx.x == 100 && lane == 0)
-        printf("[dpc profile] wave 100: n=%d models=%d | cycles per node: head %.0f | F5 %.0f (x%d) F3 %.0f (x%d) R5 %.0f (x%d) R3 %.0f (x%d)\n", n, count,
-               (double)pc_cyc[4] / pc_cnt[4], (double)pc_cyc[0] / (pc_cnt[0] ? pc_cnt[0] : 1), pc_cnt[0], (double)pc_cyc[1] / (pc_cnt[1] ? pc_cnt[1] : 1), pc_cnt[1],
-               (double)pc_cyc[2] / (pc_cnt[2] ? pc_cnt[2] : 1), pc_cnt[2], (double)pc_cyc[3] / (pc_cnt[3] ? pc_cnt[3] : 1), pc_cnt[3]);
-#endif
     flush((n - 1) & ~(DPC_FLUSH - 1), n);
     // highest score among gene ends, ties to the largest index (ref: lib.pyx:1239-1251, 1311)
     if (lane < count) {
@@ -422,6 +372,11 @@ void pga_dpc_plan(const ChainDesc* h, int n_chains, std::vector<int2>& waves) {
         k = e;
     }
     std::stable_sort(waves.begin(), waves.end(), [&](const int2& a, const int2& b) { return h[a.x].n > h[b.x].n; });
+}
+
+void pga_launch_dpc_compile(const DpwTopoArrays& ta, const int32_t* d_cbase, int n_contigs, hipStream_t st) {
+    if (n_contigs <= 0 || ta.prog == nullptr) return;
+    hipLaunchKernelGGL(k_dpc_compile, dim3((unsigned)n_contigs), dim3(64), 0, st, d_cbase, ta);
 }
 
 void pga_launch_dp_contig(const int2* d_waves, int n_waves, const ChainDesc* d_chains, const DpwGroupPtrs& groups, const ModelConst* d_models,

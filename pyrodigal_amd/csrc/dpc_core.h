@@ -19,7 +19,7 @@
 // Where the state lives: the far maxima and the best gene end so far in registers (DpcRegs: every node touches them); what is
 // indexed by a frame -- the forward carries, the score of a frame's last reverse stop -- behind the accessor (the kernel keeps
 // them in LDS, [frame][lane]: a node reads its frame's record at an address that is a scalar offset, no selects, no copy of the
-// code per frame); the uniform records in DpcUni.
+// code per frame).  Nothing uniform is carried along: what a node has to do comes compiled in its record (DpcProg, below).
 // A node is done in two halves: its candidates -> B (dpc_cand_*: the FAST routines, which assume that the nodes they read are
 // within reach of the history and that the candidate lists apply -- dpc_need_slow_* say when they do not -- or dpc_cand_slow:
 // the reference's own loop over the whole window, pair by pair, with every source read back from memory: exact for any node,
@@ -41,13 +41,13 @@
 #endif
 
 #ifndef DPC_CAND
-#define DPC_CAND 6          // forward stops kept per reverse frame (at most 7: three bits of DpcUni::cn)
+#define DPC_CAND 6          // forward stops kept per reverse frame (at most 6: the slot masks of DpcProg)
 #endif
 #ifndef DPC_HIST
 #define DPC_HIST 32         // nodes of history a lane keeps (a power of two)
 #endif
 
-// a node's topology (wave-uniform)
+// a node's topology (wave-uniform; the slow routine's view of it)
 struct DpcNode { int i, kind, frame, kfb, ndx, stop_val, lo, q1, q2; };
 // what a lane keeps of a finished gene end: its score as a SOURCE (-inf: never reached) and, for a forward stop, the position of
 // its traceb node
@@ -67,38 +67,24 @@ struct DpcRegs {
     DpcMax r5_far, f3_far;      // a over the reached reverse starts / forward stops before fp (more than 180 bases behind)
     double end_best; int end_idx, end_tb;
 };
-// uniform (the last reverse stop of each frame -- index, stop_val, position -- is uniform as well and lives behind the accessor:
-// indexed by a frame, it would drag this struct into scratch memory on the device)
-struct DpcUni {
-    int fp;                     // nodes before fp are folded into the far maxima
-    int cn;                     // per reverse frame f: bits 4f .. 4f+2 = entries of its candidate list, bit 4f+3 = the list is incomplete
-};
 
-// What the routines need from their surroundings (the kernel: topology of the batch in registers; history, lists and the
-// per-frame records in LDS; everything else in HBM; the host model: plain arrays):
-//   int reach()                 the oldest node whose topology is at hand (uniform): the fast routines only look at nodes from there on
-//   for_near(a, b, kind, f)     f(j, ndx_j) for the nodes j of [a, b), ascending, of the ONE kind named (DPC_K_F3 or DPC_K_R5)
-//                               (a, b uniform, a >= reach())
-//   DpcHist hist(j)             a finished gene end j >= reach(), j uniform (the last DPC_HIST nodes from the history, older ones
-//                               read back from memory)
-//   int ndx_of(j)               position of node j >= reach() (uniform)
+// What the routines need from their surroundings (the kernel: history, lists and the per-frame records in LDS, everything else in
+// HBM; the host model: plain arrays):
+//   DpcHist hist(j)             a finished gene end j of the last DPC_HIST nodes (j uniform)
+//   int ndx_of(j)               position of node j (uniform)
 //   DpcCarry carry(f) / set_carry(f, c);  double l3v(f) / set_l3v(f, v)         the per-frame records (f uniform), per lane
-//   int l3i(f), l3s(f), l3n(f) / set_l3(f, i, s, n)     the last reverse stop of frame f: index (-1: none), stop_val, position (uniform)
 //   cand_put(f, k, idx, ndx, sv, tbn) / cand_idx(f, k) / cand_ndx(f, k) (uniform) / cand_val(f, k) -> DpcHist (per lane)
 //   double igm(d)               the intergenic term at distance 0 <= d <= OPER_DIST (d uniform)
 //   DpwS src(j)                 ANY finished node j < i as a source, read back from memory (slow path; j uniform):
 //                               kind, frame, ndx, stop_val, score, tbn (-1: never reached), cs, vm, x0..x2
 //   bool any(p)                 p holds in some lane of the wave
-#define DPC_K_F3 1
-#define DPC_K_R5 2
 
 template <class X>
-DPW_HD void dpc_init(DpcRegs& R, DpcUni& U, X& x) {
+DPW_HD void dpc_init(DpcRegs& R, X& x) {
     const double NI = -__builtin_huge_val();
     R.r5_all = DpcMax{NI, -1}; R.r5_far = DpcMax{NI, -1}; R.f3_far = DpcMax{NI, -1};
     R.end_best = -1.0; R.end_idx = -1; R.end_tb = -1;
-    U.fp = 0; U.cn = 0;
-    DPC_UNROLL for (int f = 0; f < 3; f++) { x.set_l3(f, -1, 0, 0); x.set_carry(f, DpcCarry{NI, -1, -1}); x.set_l3v(f, 0.0); }
+    DPC_UNROLL for (int f = 0; f < 3; f++) { x.set_carry(f, DpcCarry{NI, -1, -1}); x.set_l3v(f, 0.0); }
 }
 
 // ascending take: candidates arrive in index order, so ">=" is the whole tie rule
@@ -117,45 +103,143 @@ DPW_HD void dpc_take_lex(DpcOut& B, const bool ok, const double v, const int j) 
     B.val = t ? v : B.val; B.tb = t ? j : B.tb; B.ov = t ? -1 : B.ov;
 }
 
-// nodes [U.fp, upto) leave the near zone: the reached gene ends among them join the far maxima (each kind in chain order)
-template <class X>
-DPW_HD void dpc_fold(DpcRegs& R, DpcUni& U, const int upto, const double negc, X& x) {
-    const double NI = -__builtin_huge_val();
-    if (upto > U.fp) {
-        x.for_near(U.fp, upto, DPC_K_R5, [&](const int j, const int) { const DpcHist h = x.hist(j); dpc_max_take_asc(R.r5_far, h.sv > NI, h.sv + negc, j); });
-        x.for_near(U.fp, upto, DPC_K_F3, [&](const int j, const int) { const DpcHist h = x.hist(j); dpc_max_take_asc(R.f3_far, h.sv > NI, h.sv + negc, j); });
-        U.fp = upto;
+// ------------------------------------------------------------------------------------------------------------------------
+// The topology of a contig, compiled: one 64-byte record per node that says what the node's fast routine has to do -- which of
+// the 32 nodes before it to fold or to pair with (bit k of a mask = node i - 1 - k), which slots of which candidate list apply,
+// where the last reverse stop of each frame is -- so that the serial walk makes no topological decision of its own: it reads
+// the record (scalar loads, one node ahead) and does the per-lane arithmetic.  dpc_compile_node is run once per node and
+// translation-table group by a parallel pass (k_dpc_compile; the models of a contig share the records).
+struct DpcProg { int32_t w[16]; };
+//  w0   kf (kind | frame << 2 | in-ORF bits << 4) | flags << 8 | (reverse stop: mask of the forward stops to re-enter, << 16)
+//  w1   ndx        w2   stop_val        w3   lo
+//  forward start:   w4 fold R5   w5 fold F3   w6 near F3   w7 near F3 within OPER_DIST bases (the distance term is the table's)
+//  reverse stop:    w4 fold R5   w5 fold F3   w6 near F3   w7 near R5   w8 near R5 within OPER_DIST bases
+//                   w9-11 index of the last reverse stop of frame 0..2 (-1: none)   w12-14 its position
+//                   w15 operon bits (3) | list incomplete bits (3) << 3 | list slot masks (3 x 6) << 6
+//  reverse start:   w4 index of its own stop (the last reverse stop of its frame)   w5 list slot mask (6)
+//  forward stop:    w4 enter-the-list bits (3) | slot in the list of frame q << (3 + 3 q)
+#define DPC_F_SLOW    (1 << 8)      // the fast routine does not apply (see dpc_compile_node): dpc_cand_slow
+#define DPC_F_OWN     (1 << 9)      // reverse start: its own stop is a candidate
+#define DPC_F_WINDOW  (1 << 10)     // gene begin: lo > 0, the running maxima have to be checked against the window
+#ifndef DPC_REACH
+#define DPC_REACH 32                // a mask reaches this many nodes back: the history's depth
+#endif
+
+DPW_HD int dpc_prog_kind(const DpcProg& P) { return P.w[0] & 3; }
+DPW_HD int dpc_prog_frame(const DpcProg& P) { return (P.w[0] >> 2) & 3; }
+
+// The forward stops of the candidate list of the reverse stop `l3` (position l3n) as node i sees it: those at positions
+// [l3n - 4, l3n + MAX_OPP_OVLP - 5) with an index below i, in chain order; f(slot, c) for the first DPC_CAND of them; returns how
+// many there are (more than DPC_CAND: the list is incomplete).
+template <class F>
+DPW_HD int dpc_list_walk(const int32_t* ndx, const uint8_t* kf, const int l3, const int i, F f) {
+    const int l3n = ndx[l3];
+    int c = l3;
+    while (c > 0 && ndx[c - 1] >= l3n - 4) c--;
+    int s = 0;
+    for (; c < i && ndx[c] < l3n + DPW_MAX_OPP_OVLP - 5; c++) {
+        if (DPW_KIND(kf[c]) != 1) continue;
+        if (s < DPC_CAND) f(s, c);
+        s++;
     }
+    return s;
+}
+
+// kf / lo / q1 / q2: DpwTopo of every node of the contig (dpw_topo_node); l3i[q]: the last reverse stop of frame q before node i
+DPW_HD void dpc_compile_node(const int32_t* ndx, const int32_t* stopv, const uint8_t* kf, const int32_t* lo, const int32_t* q1, const int32_t* q2,
+                             const int i, const int l3i0, const int l3i1, const int l3i2, DpcProg& P) {
+    for (int k = 0; k < 16; k++) P.w[k] = 0;
+    const int kind = DPW_KIND(kf[i]), f = DPW_FRAME(kf[i]);
+    const int my = ndx[i];
+    int w0 = kf[i];
+    P.w[1] = my; P.w[2] = stopv[i]; P.w[3] = lo[i];
+    if (kind == 0 || kind == 3) {
+        // what is folded here: the gene ends between the near zone of the gene begin before this one and this one's
+        int pg = i - 1;
+        while (pg >= 0 && pg >= i - DPC_REACH - 1 && (DPW_KIND(kf[pg]) == 1 || DPW_KIND(kf[pg]) == 2)) pg--;
+        const bool found = pg >= 0 && pg >= i - DPC_REACH - 1;
+        const int fpb = found ? q1[pg] : (pg < 0 ? 0 : -1);
+        if (fpb < 0 || fpb < i - DPC_REACH) w0 |= DPC_F_SLOW;
+        else {
+            for (int j = fpb; j < q1[i]; j++) {
+                const int k = DPW_KIND(kf[j]);
+                if (k == 2) P.w[4] |= 1 << (i - 1 - j); else if (k == 1) P.w[5] |= 1 << (i - 1 - j);
+            }
+            for (int j = q1[i] > fpb ? q1[i] : fpb; j < i; j++) {
+                const int k = DPW_KIND(kf[j]), d = my - ndx[j];
+                if (k == 1 && d > (kind == 0 ? 2 : 4)) { P.w[6] |= 1 << (i - 1 - j); if (kind == 0 && d <= DPW_OPER_DIST) P.w[7] |= 1 << (i - 1 - j); }
+                if (kind == 3 && k == 2 && d > 2) { P.w[7] |= 1 << (i - 1 - j); if (d <= DPW_OPER_DIST) P.w[8] |= 1 << (i - 1 - j); }
+            }
+        }
+        if (lo[i] > 0) w0 |= DPC_F_WINDOW;
+    }
+    if (kind == 3) {
+        const int l3[3] = {l3i0, l3i1, l3i2};
+        int w15 = 0;
+        for (int q = 0; q < 3; q++) {
+            P.w[9 + q] = l3[q]; P.w[12 + q] = l3[q] >= 0 ? ndx[l3[q]] : INT_MIN;
+            if (l3[q] < 0) continue;
+            if (l3[q] >= lo[i] && stopv[l3[q]] > my) w15 |= 1 << q;
+            int m = 0;
+            const int cnt = dpc_list_walk(ndx, kf, l3[q], i, [&](const int s, const int c) { if (c >= lo[i] && ndx[c] + 2 < my - 2) m |= 1 << s; });
+            if (cnt > DPC_CAND) w15 |= 8 << q;
+            w15 |= m << (6 + 6 * q);
+        }
+        P.w[15] = w15;
+        // the forward stops up to four bases before this stop start its frame's list over (at most five positions, two nodes each)
+        int rp = 0;
+        for (int j = i - 1; j >= 0 && j >= i - 16 && ndx[j] >= my - 4; j--) if (DPW_KIND(kf[j]) == 1) rp |= 1 << (i - 1 - j);
+        w0 |= rp << 16;
+    } else if (kind == 2) {
+        const int l3 = f == 0 ? l3i0 : (f == 1 ? l3i1 : l3i2);
+        P.w[4] = l3;
+        bool usable = false;
+        if (l3 >= 0) {
+            if (l3 >= lo[i] && stopv[l3] > my) w0 |= DPC_F_OWN;
+            if (ndx[l3] == stopv[i]) {
+                int m = 0;
+                const int cnt = dpc_list_walk(ndx, kf, l3, i, [&](const int s, const int c) {
+                    const int rel = ndx[c] - stopv[i];
+                    if (c >= lo[i] && rel > -4 && rel + 5 < DPW_MAX_OPP_OVLP && rel < my - ndx[c] + 3) m |= 1 << s;
+                });
+                usable = cnt <= DPC_CAND;
+                P.w[5] = m;
+            }
+        }
+        if (!usable && q2[i] < i) w0 |= DPC_F_SLOW;
+    } else if (kind == 1) {
+        const int l3[3] = {l3i0, l3i1, l3i2};
+        int w4 = 0;
+        for (int q = 0; q < 3; q++) {
+            if (l3[q] < 0) continue;
+            const int l3n = ndx[l3[q]];
+            if (!(my >= l3n - 4 && my < l3n + DPW_MAX_OPP_OVLP - 5)) continue;
+            const int slot = dpc_list_walk(ndx, kf, l3[q], i, [](int, int) {});
+            if (slot < DPC_CAND) w4 |= (1 << q) | (slot << (3 + 3 * q));
+        }
+        P.w[4] = w4;
+    }
+    P.w[0] = w0;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// When the fast routines do not apply to node N (uniform over the wave: `any` of the lanes is enough to send all of them
-// through the slow routine, which is exact for every lane):
-//   * a gene begin whose unfolded range reaches back beyond the nodes whose topology is at hand (the batch before this one);
-//   * a gene begin whose window start has passed the argmax of a running maximum it reads (it only can from node 1000 on);
-//   * a reverse node whose overlap candidates are not the list of its frame (its stop is not the frame's last reverse stop --
-//     the window cut it off --, or the list overflowed) while the static chain of candidates is not empty.
+// What the record cannot know: the window start has passed the argmax of a running maximum the node reads (it only can from node
+// 1000 on), or a lane's overlapping start belongs to a gene whose stop is not the last reverse stop of its frame (or whose list is
+// incomplete) while its static chain of candidates is not empty.  `any` lane is enough to send all of them through the slow routine.
 template <class X>
-DPW_HD bool dpc_need_slow_begin(const DpcRegs& R, const DpcUni& U, const DpcNode& N, X& x) {
-    if (U.fp < x.reach()) return true;
-    if (N.lo <= 0) return false;
-    const DpcMax& rmax = N.kind == 3 ? R.r5_far : R.r5_all;
-    return x.any(((rmax.i >= 0) & (rmax.i < N.lo)) | ((R.f3_far.i >= 0) & (R.f3_far.i < N.lo)));
+DPW_HD bool dpc_need_slow_begin(const DpcRegs& R, const DpcProg& P, X& x) {
+    if (P.w[0] & DPC_F_SLOW) return true;
+    if (!(P.w[0] & DPC_F_WINDOW)) return false;
+    const int lo = P.w[3];
+    const DpcMax& rmax = dpc_prog_kind(P) == 3 ? R.r5_far : R.r5_all;
+    return x.any(((rmax.i >= 0) & (rmax.i < lo)) | ((R.f3_far.i >= 0) & (R.f3_far.i < lo)));
 }
 template <class X>
-DPW_HD bool dpc_need_slow_r5(const DpcUni& U, const DpcNode& N, X& x) {
-    const int f = N.frame;
-    const int c4 = (U.cn >> (4 * f)) & 15;
-    const bool list = x.l3i(f) >= 0 && x.l3n(f) == N.stop_val && !(c4 & 8);
-    return !list && N.q2 < N.i;
-}
-template <class X>
-DPW_HD bool dpc_need_slow_r3(const DpcUni& U, const DpcNode& N, const DpcExt& e, X& x) {
+DPW_HD bool dpc_need_slow_r3(const DpcProg& P, const int i, const DpcExt& e, X& x) {
     bool slow = false;
     DPC_UNROLL for (int q = 0; q < 3; q++) {
-        const int c4 = (U.cn >> (4 * q)) & 15;
-        const bool list = (x.l3i(q) >= 0) & (x.l3n(q) == e.n3s[q]) & !(c4 & 8);
-        slow = slow | (((e.vm >> q) & 1) & !list & (e.cq[q] < N.i));
+        const bool list = (P.w[9 + q] >= 0) & (P.w[12 + q] == e.n3s[q]) & !((P.w[15] >> (3 + q)) & 1);
+        slow = slow | (((e.vm >> q) & 1) & !list & (e.cq[q] < i));
     }
     return x.any(slow);
 }
@@ -177,14 +261,14 @@ DPW_HD DpwT dpc_target(const DpcNode& N, const double cs, const double negc, con
 
 // The slow routine: every node of the window against this node, pair by pair, in chain order -- the reference's loop
 // (ref: lib.pyx:1221-1237 over _connection.h:94-408).  For a gene begin the running maxima are rebuilt over the window on the way
-// and the unfolded range restarts at q1 (what lies before the window is dropped: windows of gene begins only move forward).
+// (split at q1: what the next gene begin folds starts there; what lies before the window is dropped: windows of gene begins only
+// move forward).
 template <class X>
-DPW_HD void dpc_cand_slow(DpcRegs& R, DpcUni& U, const DpcNode& N, const double cs, const DpcExt& e, const DpwModel& M, X& x, DpcOut& B) {
+DPW_HD void dpc_cand_slow(DpcRegs& R, const DpcNode& N, const double cs, const DpcExt& e, const DpwModel& M, X& x, DpcOut& B) {
     const double NI = -__builtin_huge_val();
     const DpwT T = dpc_target(N, cs, M.negc, e);
     const bool begin = N.kind == 0 || N.kind == 3;
-    const int fp = begin ? (N.q1 > U.fp ? N.q1 : U.fp) : U.fp;
-    if (begin) { R.r5_all = DpcMax{NI, -1}; R.r5_far = DpcMax{NI, -1}; R.f3_far = DpcMax{NI, -1}; U.fp = fp; }
+    if (begin) { R.r5_all = DpcMax{NI, -1}; R.r5_far = DpcMax{NI, -1}; R.f3_far = DpcMax{NI, -1}; }
     DpwBest W{0.0, -1, -1, -1};
     for (int j = N.lo; j < N.i; j++) {
         const DpwS s = x.src(j);
@@ -194,29 +278,44 @@ DPW_HD void dpc_cand_slow(DpcRegs& R, DpcUni& U, const DpcNode& N, const double 
         if (begin && (s.kind == 1 || s.kind == 2)) {
             const bool reached = s.tbn != -1;
             const double a = s.score + M.negc;
-            if (s.kind == 2) { dpc_max_take_asc(R.r5_all, reached, a, j); dpc_max_take_asc(R.r5_far, reached & (j < fp), a, j); }
-            else dpc_max_take_asc(R.f3_far, reached & (j < fp), a, j);
+            if (s.kind == 2) { dpc_max_take_asc(R.r5_all, reached, a, j); dpc_max_take_asc(R.r5_far, reached & (j < N.q1), a, j); }
+            else dpc_max_take_asc(R.f3_far, reached & (j < N.q1), a, j);
         }
     }
     B.val = W.val; B.tb = W.tb; B.ov = W.ov;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// Fast candidates.
+// Fast candidates, driven by the node's record.  Bit k of a mask is node i - 1 - k: walking the set bits from the top is chain
+// order.
+template <class F>
+DPW_HD void dpc_bits_desc(unsigned m, F f) {
+    while (m) {
+        const int k = 31 - __builtin_clz(m);
+        m &= ~(1u << k);
+        f(k);
+    }
+}
+// the gene ends that leave the near zone join the far maxima (each kind in chain order)
+template <class X>
+DPW_HD void dpc_fold(DpcRegs& R, const DpcProg& P, const int i, const double negc, X& x) {
+    const double NI = -__builtin_huge_val();
+    dpc_bits_desc((unsigned)P.w[4], [&](const int k) { const int j = i - 1 - k; const DpcHist h = x.hist(j); dpc_max_take_asc(R.r5_far, h.sv > NI, h.sv + negc, j); });
+    dpc_bits_desc((unsigned)P.w[5], [&](const int k) { const int j = i - 1 - k; const DpcHist h = x.hist(j); dpc_max_take_asc(R.f3_far, h.sv > NI, h.sv + negc, j); });
+}
 
 // a forward start: every gene end of the window (ref: _connection.h:117-130)
 template <class X>
-DPW_HD void dpc_cand_f5(DpcRegs& R, DpcUni& U, const DpcNode& N, const DpwModel& M, X& x, DpcOut& B) {
-    dpc_fold(R, U, N.q1, M.negc, x);
+DPW_HD void dpc_cand_f5(DpcRegs& R, const DpcProg& P, const int i, const DpwModel& M, X& x, DpcOut& B) {
+    dpc_fold(R, P, i, M.negc, x);
     // forward stops, in chain order: the far ones, then those within 3 * OPER_DIST bases pair by pair
     dpc_take_asc(B, true, R.f3_far.v, R.f3_far.i);
-    x.for_near(U.fp > N.lo ? U.fp : N.lo, N.i, DPC_K_F3, [&](const int j, const int nj) {
-        const int d = N.ndx - nj;
-        if (d > 2) {
-            const DpcHist h = x.hist(j);
-            const double w = d > DPL_NEAR ? M.negc : (d <= DPW_OPER_DIST ? x.igm(d) : 0.0);
-            dpc_take_asc(B, true, h.sv + w, j);
-        }
+    const unsigned tab = (unsigned)P.w[7];
+    dpc_bits_desc((unsigned)P.w[6], [&](const int k) {
+        const int j = i - 1 - k;
+        const DpcHist h = x.hist(j);
+        const double w = ((tab >> k) & 1) ? x.igm(P.w[1] - x.ndx_of(j)) : 0.0;
+        dpc_take_asc(B, true, h.sv + w, j);
     });
     // every reverse start so far: the weight towards a forward start never depends on the distance
     dpc_take_lex(B, true, R.r5_all.v, R.r5_all.i);
@@ -228,80 +327,67 @@ DPW_HD void dpc_cand_f3(const DpcCarry& c, DpcOut& B) {
     B.val = reached ? c.v : 0.0; B.tb = reached ? c.i : -1; B.tbn = reached ? c.n : -1;
 }
 
-// A reached forward stop of a candidate list against a reverse start (ref: _connection.h:238-254; dpl_cand_r5 with the uniform part
-// of the test hoisted): rel = c.ndx - stop_val
-DPW_HD void dpc_list_r5(DpcOut& B, const DpcNode& N, const double csd, const double c_sv, const int c_tbn, const int c_idx, const int c_ndx) {
-    const int rel = c_ndx - N.stop_val;
-    const bool uni = (c_idx >= N.lo) & (rel > -4) & (rel + 5 < DPW_MAX_OPP_OVLP) & (rel < N.ndx - c_ndx + 3);
-    if (uni) dpc_take_asc(B, c_tbn < N.stop_val - 3 - rel, c_sv + csd, c_idx);
-}
-// ... and against a reverse stop, through the best admissible overlapping start (ref: :288-336): the first q with the largest x
-DPW_HD void dpc_list_r3(DpcOut& B, const DpcNode& N, const DpcExt& e, const bool have, const double negc, const double c_sv, const int c_tbn,
-                        const int c_idx, const int c_ndx) {
-    const int left = c_ndx + 2;
-    if ((c_idx >= N.lo) & (left < N.ndx - 2)) {
-        double maxval = 0.0; int mf = -1;
-        DPC_UNROLL for (int q = 0; q < 3; q++) {
-            const int ovlp = left - e.n3s[q] + 3;
-            const bool tk = ((e.vm & (1 << q)) != 0) & (ovlp > 0) & (ovlp < DPW_MAX_OPP_OVLP) & (ovlp < e.n3n[q] - left) & (ovlp < e.n3s[q] - c_tbn - 2) & (e.x[q] > maxval);
-            maxval = tk ? e.x[q] : maxval; mf = tk ? q : mf;
-        }
-        const double v = c_sv + (mf != -1 ? maxval : negc);
-        const bool t = have & ((v > B.val) | ((v == B.val) & (c_idx > B.tb)));
-        B.val = t ? v : B.val; B.tb = t ? c_idx : B.tb; B.ov = t ? mf : B.ov;
-    }
-}
-
-// a reverse start of frame f: its own stop (ref: :228-235) and the forward stops overlapping its gene's 3' end (ref: :238-254)
+// a reverse start of frame f: its own stop (ref: :228-235) and the forward stops overlapping its gene's 3' end (ref: :238-254; the
+// tests that only look at positions are in the record's slot mask): rel = c.ndx - stop_val, tbn < stop_val - 3 - rel
 template <class X>
-DPW_HD void dpc_cand_r5(const DpcUni& U, const DpcNode& N, const double cs, const double negc, X& x, DpcOut& B) {
-    const int f = N.frame;
-    const int l3i = x.l3i(f), l3s = x.l3s(f), l3n = x.l3n(f);
-    if ((l3i >= 0) & (l3i >= N.lo) & (l3s > N.ndx)) dpc_take_asc(B, true, x.l3v(f) + cs, l3i);
-    const int c4 = (U.cn >> (4 * f)) & 15;
-    if ((l3i >= 0) & (l3n == N.stop_val) & !(c4 & 8)) {
+DPW_HD void dpc_cand_r5(const DpcProg& P, const double cs, const double negc, X& x, DpcOut& B) {
+    const int f = dpc_prog_frame(P);
+    if (P.w[0] & DPC_F_OWN) dpc_take_asc(B, true, x.l3v(f) + cs, P.w[4]);
+    if (P.w[5]) {
         // (the list follows the frame's last reverse stop: in chain order, after the stop itself)
         const double csd = cs + negc;
-        for (int k = 0; k < (c4 & 7); k++) {
+        unsigned m = (unsigned)P.w[5];
+        while (m) {
+            const int k = __builtin_ctz(m);
+            m &= m - 1;
             const DpcHist v = x.cand_val(f, k);
-            dpc_list_r5(B, N, csd, v.sv, v.tbn, x.cand_idx(f, k), x.cand_ndx(f, k));
+            dpc_take_asc(B, v.tbn < 2 * P.w[2] - 3 - x.cand_ndx(f, k), v.sv + csd, x.cand_idx(f, k));
         }
     }
 }
 
 // a reverse stop: every gene end of the window (ref: :288-342), the reverse stop whose ORF covers it (ref: :345-356)
 template <class X>
-DPW_HD void dpc_cand_r3(DpcRegs& R, DpcUni& U, const DpcNode& N, const DpcExt& e, const DpwModel& M, X& x, DpcOut& B) {
-    dpc_fold(R, U, N.q1, M.negc, x);
+DPW_HD void dpc_cand_r3(DpcRegs& R, const DpcProg& P, const int i, const DpcExt& e, const DpwModel& M, X& x, DpcOut& B) {
+    dpc_fold(R, P, i, M.negc, x);
     // the far gene ends (the weight is the constant): both kinds, either order
     dpc_take_asc(B, true, R.r5_far.v, R.r5_far.i);
     dpc_take_lex(B, true, R.f3_far.v, R.f3_far.i);
     // near gene ends, pair by pair: reverse starts with the distance term, forward stops the plain connection (a forward stop's
     // offer through an overlapping start of this stop is met on the candidate lists, and is larger)
-    const int a0 = U.fp > N.lo ? U.fp : N.lo;
-    x.for_near(a0, N.i, DPC_K_R5, [&](const int j, const int nj) {
-        const int d = N.ndx - nj;
-        if (d > 2) {
-            const DpcHist h = x.hist(j);
-            const double w = d > DPL_NEAR ? M.negc : (d <= DPW_OPER_DIST ? x.igm(d) : 0.0);
-            dpc_take_lex(B, true, h.sv + w, j);
-        }
+    const unsigned tab = (unsigned)P.w[8];
+    dpc_bits_desc((unsigned)P.w[7], [&](const int k) {
+        const int j = i - 1 - k;
+        const DpcHist h = x.hist(j);
+        const double w = ((tab >> k) & 1) ? x.igm(P.w[1] - x.ndx_of(j)) : 0.0;
+        dpc_take_lex(B, true, h.sv + w, j);
     });
-    x.for_near(a0, N.i, DPC_K_F3, [&](const int j, const int nj) {
-        if (N.ndx - nj > 4) { const DpcHist h = x.hist(j); dpc_take_lex(B, true, h.sv + M.negc, j); }
-    });
+    dpc_bits_desc((unsigned)P.w[6], [&](const int k) { const int j = i - 1 - k; const DpcHist h = x.hist(j); dpc_take_lex(B, true, h.sv + M.negc, j); });
     // the reverse stop whose ORF covers this one, per frame of an overlapping start: an operon (ref: :345-356)
     DPC_UNROLL for (int q = 0; q < 3; q++)
-        if ((x.l3i(q) >= 0) & (x.l3i(q) >= N.lo) & (x.l3s(q) > N.ndx)) dpc_take_lex(B, (e.vm & (1 << q)) != 0, x.l3v(q) + e.x[q], x.l3i(q));
-    // forward stops that overlap the 3' end of the gene of an overlapping start (the start of frame q has its stop at n3s[q]):
-    // the list of frame q where it is that stop's
+        if ((P.w[15] >> q) & 1) dpc_take_lex(B, (e.vm & (1 << q)) != 0, x.l3v(q) + e.x[q], P.w[9 + q]);
+    // forward stops that overlap the 3' end of the gene of an overlapping start (ref: :288-336).  The start of frame q has its stop
+    // at n3s[q]; where that is the last reverse stop of frame q, the forward stops that can overlap it are that frame's list.  A
+    // forward stop c goes through start q when  ovlp = c.ndx + 5 - n3s[q]  is in (0, MAX_OPP_OVLP) -- what the list holds --,
+    // ovlp < n3n[q] - (c.ndx + 2),  ovlp < n3s[q] - c.tbn - 2  and x[q] > 0; of the starts it can go through the reference keeps the
+    // first with the largest x, and of the forward stops the last with the largest value: the lexicographic maximum over the
+    // (stop, start) pairs, walked start by start, a later start only on a strictly larger value.
     DPC_UNROLL for (int q = 0; q < 3; q++) {
-        const int c4 = (U.cn >> (4 * q)) & 15;
-        if ((x.l3i(q) >= 0) & !(c4 & 8)) {
-            const bool have = ((e.vm & (1 << q)) != 0) & (x.l3n(q) == e.n3s[q]);
-            for (int k = 0; k < (c4 & 7); k++) {
-                const DpcHist v = x.cand_val(q, k);
-                dpc_list_r3(B, N, e, have, M.negc, v.sv, v.tbn, x.cand_idx(q, k), x.cand_ndx(q, k));
+        unsigned m = ((unsigned)P.w[15] >> (6 + 6 * q)) & 63u;
+        if (m) {
+            const int l3n = P.w[12 + q];
+            const bool have = ((e.vm & (1 << q)) != 0) & (l3n == e.n3s[q]) & (e.x[q] > 0.0);
+            if (x.any(have)) {
+                while (m) {
+                    const int k = __builtin_ctz(m);
+                    m &= m - 1;
+                    const DpcHist c = x.cand_val(q, k);
+                    const int c_ndx = x.cand_ndx(q, k), c_idx = x.cand_idx(q, k);
+                    const int ovlp = c_ndx + 5 - l3n;
+                    const double v = c.sv + e.x[q];
+                    const bool t = have & (e.n3n[q] > ovlp + c_ndx + 2) & (c.tbn < l3n - 2 - ovlp) & ((v > B.val) | ((v == B.val) & (c_idx > B.tb)));
+                    B.val = t ? v : B.val; B.tb = t ? c_idx : B.tb; B.ov = t ? q : B.ov;
+                }
             }
         }
     }
@@ -313,61 +399,52 @@ DPW_HD void dpc_note_end(DpcRegs& R, const DpcOut& B, const int i) {
     const bool new_end = B.val >= R.end_best;
     R.end_best = new_end ? B.val : R.end_best; R.end_idx = new_end ? i : R.end_idx; R.end_tb = new_end ? B.tb : R.end_tb;
 }
-template <class X>
-DPW_HD void dpc_cand_push(DpcUni& U, X& x, const int f, const int idx, const int ndx, const double sv, const int tbn) {
-    const int c4 = (U.cn >> (4 * f)) & 15;
-    if (!(c4 & 8)) {
-        if ((c4 & 7) == DPC_CAND) U.cn |= 8 << (4 * f);
-        else { x.cand_put(f, c4 & 7, idx, ndx, sv, tbn); U.cn += 1 << (4 * f); }
-    }
-}
 // a forward start offers score + cs to the stop of its ORF (a later node wins a tie); `c`: the carry of its frame
 template <class X>
-DPW_HD void dpc_finish_f5(const DpcNode& N, const double cs, const DpcCarry& c, X& x, DpcOut& B) {
+DPW_HD void dpc_finish_f5(const DpcProg& P, const int i, const double cs, const DpcCarry& c, X& x, DpcOut& B) {
     const double g = B.val + cs;
     const bool t = g >= c.v;
-    x.set_carry(N.frame, DpcCarry{t ? g : c.v, t ? N.i : c.i, t ? N.ndx : c.n});
+    x.set_carry(dpc_prog_frame(P), DpcCarry{t ? g : c.v, t ? i : c.i, t ? P.w[1] : c.n});
     B.sv = B.val; B.tbn = -1;
 }
 // a forward stop restarts the running maximum of its own frame and, when reached, offers score + x to the frames whose next stop's
-// ORF holds it (operon partners); it may overlap the 3' end of the reverse genes that end at the last reverse stop of a frame
+// ORF holds it (operon partners); it enters the candidate lists of the reverse stops whose genes' 3' ends it can overlap
 template <class X>
-DPW_HD void dpc_finish_f3(DpcRegs& R, DpcUni& U, const DpcNode& N, const DpcExt& e, X& x, DpcOut& B) {
+DPW_HD void dpc_finish_f3(DpcRegs& R, const DpcProg& P, const int i, const DpcExt& e, X& x, DpcOut& B) {
     const double NI = -__builtin_huge_val();
     const bool reached = B.tb != -1;
     B.sv = reached ? B.val : NI;
-    dpc_note_end(R, B, N.i);
-    x.set_carry(N.frame, DpcCarry{NI, -1, -1});
+    dpc_note_end(R, B, i);
+    x.set_carry(dpc_prog_frame(P), DpcCarry{NI, -1, -1});
     DPC_UNROLL for (int q = 0; q < 3; q++) {
-        if (DPW_INORF(N.kfb, q)) {
+        if (DPW_INORF(P.w[0], q)) {
             const DpcCarry c = x.carry(q);
             const double o = B.val + e.x[q];
             const bool t = reached & ((e.vm & (1 << q)) != 0) & (o >= c.v);
-            x.set_carry(q, DpcCarry{t ? o : c.v, t ? N.i : c.i, t ? N.ndx : c.n});
+            x.set_carry(q, DpcCarry{t ? o : c.v, t ? i : c.i, t ? P.w[1] : c.n});
         }
     }
     DPC_UNROLL for (int q = 0; q < 3; q++)
-        if (x.l3i(q) >= 0 && N.ndx >= x.l3n(q) - 4 && N.ndx < x.l3n(q) + DPW_MAX_OPP_OVLP - 5) dpc_cand_push(U, x, q, N.i, N.ndx, B.sv, B.tbn);
+        if ((P.w[4] >> q) & 1) x.cand_put(q, (P.w[4] >> (3 + 3 * q)) & 7, i, P.w[1], B.sv, B.tbn);
 }
-DPW_HD void dpc_finish_r5(DpcRegs& R, const DpcNode& N, const double negc, DpcOut& B) {
+DPW_HD void dpc_finish_r5(DpcRegs& R, const int i, const double negc, DpcOut& B) {
     const double NI = -__builtin_huge_val();
     const bool reached = B.tb != -1;
     B.sv = reached ? B.val : NI; B.tbn = -1;
-    dpc_note_end(R, B, N.i);
-    dpc_max_take_asc(R.r5_all, reached, B.val + negc, N.i);
+    dpc_note_end(R, B, i);
+    dpc_max_take_asc(R.r5_all, reached, B.val + negc, i);
 }
 // a reverse stop becomes the last one of its frame; the frame's candidate list starts over with the forward stops up to four bases
-// before it (oldest first: the list is in position order like the chain); they are near, i.e. not folded yet
+// before it (oldest first: the list is in position order like the chain)
 template <class X>
-DPW_HD void dpc_finish_r3(DpcUni& U, const DpcNode& N, X& x, DpcOut& B) {
+DPW_HD void dpc_finish_r3(const DpcProg& P, const int i, X& x, DpcOut& B) {
     B.sv = B.val; B.tbn = -1;
-    const int f = N.frame;
+    const int f = dpc_prog_frame(P);
     x.set_l3v(f, B.val);
-    x.set_l3(f, N.i, N.stop_val, N.ndx);
-    U.cn &= ~(15 << (4 * f));
-    int a0 = U.fp > N.i - 16 ? U.fp : N.i - 16;             // at most five positions, two nodes each: ten nodes
-    if (a0 < x.reach()) { a0 = x.reach(); if (x.ndx_of(a0) >= N.ndx - 4) U.cn |= 8 << (4 * f); }      // (a reach this short only exists in the tests)
-    x.for_near(a0, N.i, DPC_K_F3, [&](const int j, const int nj) {
-        if (nj >= N.ndx - 4) { const DpcHist h = x.hist(j); dpc_cand_push(U, x, f, j, nj, h.sv, h.tbn); }
+    int slot = 0;
+    dpc_bits_desc((unsigned)P.w[0] >> 16, [&](const int k) {
+        const int j = i - 1 - k;
+        if (slot < DPC_CAND) { const DpcHist h = x.hist(j); x.cand_put(f, slot, j, x.ndx_of(j), h.sv, h.tbn); }
+        slot++;
     });
 }

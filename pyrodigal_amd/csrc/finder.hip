@@ -1401,6 +1401,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                 WBUF(kf, uint8_t) WBUF(lo, int32_t) WBUF(q1, int32_t) WBUF(q2, int32_t)
 #undef WBUF
                 { snprintf(nm, sizeof nm, "dpw_tp%d", g); void* p__; int rc__ = ensure_dev(c, nm, sizeof(int4) * 2 * (size_t)n + 64, &p__); if (rc__) return rc__; wgroups.g[g].tp = (int4*)p__; }
+                { snprintf(nm, sizeof nm, "dpw_prog%d", g); void* p__; int rc__ = ensure_dev(c, nm, sizeof(int4) * 4 * (size_t)n + 64, &p__); if (rc__) return rc__; wgroups.g[g].prog = (int4*)p__; }
                 wgroups.g[g].ndx = ga[g].ndx; wgroups.g[g].stop_val = ga[g].stop_val; wgroups.g[g].srank = ga[g].srank;
             }
             DEVBUF(w0, double, "dpw_cs", dp_cap + 2) DEVBUF(w1, DpwExt, "dpw_ext", tot_chain_stops + 4)      /* one extras record per (chain, stop node) pair */ DEVBUF(w2, double, "dpw_sfxv", dp_cap) DEVBUF(w3, int32_t, "dpw_sfxi", dp_cap)
@@ -1508,6 +1509,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             sp.cs_out = nullptr;
             if (use_wave) {
                 pga_launch_dpw_topo(wgroups.g[g], ga[g].type, ga[g].strand, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], st);
+                if (pga_dp_use_contig(NCH)) pga_launch_dpc_compile(wgroups.g[g], d_cbase + (size_t)g * (NC + 1), NC, st);
                 sl.topo_q2 = wgroups.g[g].q2; sl.ext = wbuf.ext; sp.cs_out = wbuf.cs;
             }
             pga_launch_score(d_chains + g_c0[g], nch, g_n0[g], nn, d_dig, d_ct, ga[g], d_models, f->d_msc, c->d_model_const, ca, sp,

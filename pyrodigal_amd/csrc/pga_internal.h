@@ -129,8 +129,9 @@ struct DpwExt;
 // topology of one translation-table group: what depends on positions and kinds only, shared by every model of a contig
 // srank: per node (stop nodes only) its rank among the stop nodes of its contig, or nullptr: then the extras record of node i of a
 // chain is ext[off + i]; with it, ext[soff + srank[i]] (one 64-byte record per (chain, stop node) pair, dense)
+// prog (optional): the topology compiled for the contig-per-wavefront scorer, four int4 per node (dpc_core.h DpcProg)
 // tp (optional): the same fields packed for the contig-per-wavefront scorer, two int4 per node: {ndx, stop_val, lo, q1}, {q2, kf, 0, 0}
-struct DpwTopoArrays { const int32_t* ndx; const int32_t* stop_val; uint8_t* kf; int32_t* lo; int32_t* q1; int32_t* q2; const int32_t* srank = nullptr; int4* tp = nullptr; };
+struct DpwTopoArrays { const int32_t* ndx; const int32_t* stop_val; uint8_t* kf; int32_t* lo; int32_t* q1; int32_t* q2; const int32_t* srank = nullptr; int4* tp = nullptr; int4* prog = nullptr; };
 struct DpwGroupPtrs { DpwTopoArrays g[4]; };
 // per chain node: cs = cscore + sscore, suffix maxima of finished blocks; per stop node a 64-byte record of extras (indexed by
 // node, or dense by (chain, stop) pair: DpwTopoArrays::srank)
@@ -174,6 +175,8 @@ void pga_launch_dpl_unpack(const ChainDesc* d_chains, int n_chains, const int64_
 bool pga_dp_use_contig(int n_chains);
 // waves[k] = (first chain, number of chains) of a run of chains on one contig and group, longest contigs first
 void pga_dpc_plan(const ChainDesc* h_chains, int n_chains, std::vector<int2>& waves);
+// compiles the topology of every contig of a group into ta.prog (after pga_launch_dpw_topo; d_cbase: first node of every contig)
+void pga_launch_dpc_compile(const DpwTopoArrays& ta, const int32_t* d_cbase, int n_contigs, hipStream_t st);
 void pga_launch_dp_contig(const int2* d_waves, int n_waves, const ChainDesc* d_chains, const DpwGroupPtrs& groups, const ModelConst* d_models,
                           DpBuffers buf, const DpwBuffers& wb, hipStream_t st);
 

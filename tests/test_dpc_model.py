@@ -41,7 +41,7 @@ def model():
 
 @pytest.fixture(scope="module")
 def tiny():
-    return build("_tiny", ["-DDPC_HIST=4", "-DDPC_CAND=1", "-DDPC_TB=4"])
+    return build("_tiny", ["-DDPC_HIST=4", "-DDPC_REACH=4", "-DDPC_CAND=1"])
 
 
 def run_model(L, nodes, st_wt):
@@ -92,7 +92,7 @@ def test_model_on_reference_fixtures(model, tiny, name, model_file, closed):
     tinf = orc.Training.load(golden_path(model_file))
     for is_meta in (False, True):
         n, stats = check(model, seq, tinf, closed=closed, is_meta=is_meta)
-        assert n > 1000 and stats[0] < n // 500 and stats[7] == 0, stats      # the slow routine is the rare exception; the fast ones stay within reach
+        assert n > 1000 and stats[0] < n // 200 and stats[7] == 0, stats      # the slow routine is the rare exception (a near zone deeper than the history on this dense genome); the fast ones stay within reach
         n, stats = check(tiny, seq, tinf, closed=closed, is_meta=is_meta)
         assert stats[0] > n // 10 and stats[7] == 0, stats   # ... a four-node history and one-entry lists: the slow routine carries the load
 

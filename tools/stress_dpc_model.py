@@ -10,7 +10,7 @@ from pyrodigal_amd import benchdata
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 tiny = len(sys.argv) > 2 and sys.argv[2] == "tiny"
-L = T.build("_tiny", ["-DDPC_HIST=4", "-DDPC_CAND=1", "-DDPC_TB=4"]) if tiny else T.build("", [])
+L = T.build("_tiny", ["-DDPC_HIST=4", "-DDPC_REACH=4", "-DDPC_CAND=1"]) if tiny else T.build("", [])
 models = [orc.Training(m[1]) for m in benchdata.load_model_set()]
 rng = np.random.default_rng(int(time.time()))
 tot = np.zeros(8, np.int64); nodes = 0
