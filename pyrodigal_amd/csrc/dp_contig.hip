@@ -129,7 +129,7 @@ struct CmX {
         const int4 v = cand_[f * DPC_CAND + k][ml];
         return DpcHist{__hiloint2double(v.y, v.x), v.z};
     }
-    __device__ __forceinline__ double igm(const int d) const { return c_dpc_t2.v[d] * st_wt; }
+    __device__ __forceinline__ double igm(const int d) const { return c_dpc_t2.v[d] * st_wt; }      // (the assembly block reads the table's LDS copy)
     __device__ __forceinline__ bool any(const bool p) const { return __ballot(p) != 0ull; }
 };
 
@@ -173,7 +173,19 @@ k_dpc_compile(const int32_t* __restrict__ cbase, DpwTopoArrays ta) {
     }
 }
 
+// everything the walk keeps in LDS (the assembly block addresses it by offsets from the struct's start)
 template <int LW>
+struct DpcLds {
+    int4 hist[DPC_HIST][LW];        // {score as a source (lo, hi), position of the traceb node (forward stops), tag}: the last DPC_HIST nodes
+    int4 cand[3 * DPC_CAND][LW];    // {score as a source (lo, hi), position of the traceb node, -}: the candidate list of each reverse frame
+    int4 carry[3][LW];              // forward carry of each frame {v (lo, hi), i, n}
+    double l3v[3][LW];              // score of the last reverse stop of each frame
+    double cs[2][64];               // cs of 64 / LW nodes x LW models, two groups: [group parity][(node pair, model)][node of the pair]
+    int4 ext[4][4][LW];             // the extras of the next stop nodes: [stop rank & 3][16-byte part][lane]
+    double t2[64];                  // (2 - d / 60) * 0.15, d = 0 .. 60
+};
+
+template <int LW, bool ASM>
 __global__ void __launch_bounds__(64)
 k_dp_contig(const int2* __restrict__ waves, const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const double* __restrict__ g_cs,
             const DpwExt* __restrict__ g_ext, const ModelConst* __restrict__ models, DpBuffers buf) {
@@ -181,12 +193,11 @@ k_dp_contig(const int2* __restrict__ waves, const ChainDesc* __restrict__ chains
     static_assert(DPC_HIST == 2 * DPC_FLUSH && 64 % DPC_FLUSH == 0 && DPC_REACH == DPC_HIST, "the history holds a flush unit of unflushed results and one being read");
     constexpr int NPG = 64 / LW;                    // nodes per load of cs
     constexpr int MPF = 64 / DPC_FLUSH;             // models per store instruction of a flush
-    __shared__ int4 s_hist[DPC_HIST][LW];
-    __shared__ int4 s_cand[3 * DPC_CAND][LW];
-    __shared__ int4 s_carry[3][LW];
-    __shared__ double s_l3v[3][LW];
-    __shared__ double s_cs[2][64];                  // cs of 64 / LW nodes x LW models, two groups: [group parity][(node pair, model)][node of the pair]
-    __shared__ int4 s_ext[4][4][LW];                // the extras of the next stop nodes: [stop rank & 3][16-byte part][lane]
+    __shared__ DpcLds<LW> L;
+    static_assert(offsetof(DpcLds<LW>, hist) == 0 && offsetof(DpcLds<LW>, cand) == 4096 && offsetof(DpcLds<LW>, carry) == 6400 && offsetof(DpcLds<LW>, l3v) == 6784 &&
+                  offsetof(DpcLds<LW>, cs) == 6976 && offsetof(DpcLds<LW>, ext) == 8000 && offsetof(DpcLds<LW>, t2) == 10048 && DPC_CAND == 6,
+                  "tools/gen_dpc_walk.py knows this layout");
+    auto& s_hist = L.hist; auto& s_cs = L.cs; auto& s_ext = L.ext;
     const int lane = threadIdx.x, ml = lane % LW;
     const int2 wv = waves[blockIdx.x];              // first chain, number of chains (<= LW)
     const int first = wv.x, count = wv.y;
@@ -209,7 +220,8 @@ k_dp_contig(const int2* __restrict__ waves, const ChainDesc* __restrict__ chains
     const int off_lo = (int)cd.off, off_hi = (int)(cd.off >> 32);
 
     CmX<LW> x;
-    x.hist_ = s_hist; x.cand_ = s_cand; x.carry_ = s_carry; x.l3v_ = s_l3v; x.prog = prog;
+    x.hist_ = L.hist; x.cand_ = L.cand; x.carry_ = L.carry; x.l3v_ = L.l3v; x.prog = prog;
+    L.t2[lane] = c_dpc_t2.v[lane];
     x.cur = 0; x.cidx = 0; x.cndx = 0;
     x.st_wt = st_wt; x.ml = ml; x.writer = lane < LW;
     x.g_tp = tp; x.g_srank = dense ? groups.g[grp].srank + toff : nullptr; x.g_cs = my_cs; x.g_ext = my_ext;
@@ -273,19 +285,10 @@ k_dp_contig(const int2* __restrict__ waves, const ChainDesc* __restrict__ chains
         }
     };
 
-    DpcProg Pn = load_prog(prog, 0);
-    for (int i = 0; i < n; i++) {
-        // this node's record arrived while the node before it was walked; the next one's is asked for
-        const DpcProg P = Pn;
-        if (i + 1 < n) Pn = load_prog(prog, i + 1);
-        if ((i % DPC_FLUSH) == 0 && i > 0) flush(i - DPC_FLUSH, i);
-        if ((i % NPG) == 0) {
-            // this group's cs has arrived (asked for a group ago), the next group's is asked for
-            // (every stop node walked since has asked for a record of extras: four loads each, all of them later than this group's)
-            wait_vm4(dense ? nstop - cs_stop : 0);
-            ask_cs(i / NPG + 1);
-            cs_stop = nstop;
-        }
+    // one node with the C++ routines (dpc_core.h): any node when the assembly block is not used, the nodes it stops in front of
+    // otherwise
+    auto node_cpp = [&](const int i) {
+        const DpcProg P = load_prog(prog, i);
         x.cur = i;
         const int kind = dpc_prog_kind(P), f = dpc_prog_frame(P);
         // A node the fast routines do not cover (rare) goes through the reference's loop over its whole window; every other node
@@ -348,6 +351,52 @@ k_dp_contig(const int2* __restrict__ waves, const ChainDesc* __restrict__ chains
             dpc_finish_r3(P, i, x, B);
             x.hist_put(i, B.val, -1, B.tb < 0 ? -1 : (B.tb | ((B.ov + 1) << DPW_TAG_BITS)));
         }
+    };
+    // what happens between runs of nodes: results leave every DPC_FLUSH nodes, the next group of cs is asked for every 64 / LW
+    auto service = [&](const int i) {
+        if ((i % DPC_FLUSH) == 0 && i > 0) flush(i - DPC_FLUSH, i);
+        // this group's cs has arrived (asked for a group ago), the next group's is asked for
+        // (every stop node walked since has asked for a record of extras: four loads each, all of them later than this group's)
+        wait_vm4(dense ? nstop - cs_stop : 0);
+        ask_cs(i / NPG + 1);
+        cs_stop = nstop;
+    };
+    if (ASM) {
+        // runs of 64 / LW nodes through the assembly block (tools/gen_dpc_walk.py); it stops in front of a node its routines do not cover
+        const unsigned long long progbits = (unsigned long long)(const void*)(groups.g[grp].prog + 4 * toff);
+        const unsigned long long extbits = (unsigned long long)my_ext;
+        int w_i = 0, w_nstop = 0;
+        int w_tid = lane, w_negc_lo = __double2loint(negc), w_negc_hi = __double2hiint(negc), w_stwt_lo = __double2loint(st_wt), w_stwt_hi = __double2hiint(st_wt);
+        int w_extp_lo = (int)extbits, w_extp_hi = (int)(extbits >> 32);
+        const int w_prog_lo = rfl((int)progbits), w_prog_hi = rfl((int)(progbits >> 32)), w_base = (int)lds_offset(&L);
+        while (w_i < n) {
+            if ((w_i % NPG) == 0) service(w_i);
+            const int w_end = min(n, (w_i | (NPG - 1)) + 1);
+            int w_r5a_lo = __double2loint(R.r5_all.v), w_r5a_hi = __double2hiint(R.r5_all.v), w_r5a_i = R.r5_all.i;
+            int w_r5f_lo = __double2loint(R.r5_far.v), w_r5f_hi = __double2hiint(R.r5_far.v), w_r5f_i = R.r5_far.i;
+            int w_f3f_lo = __double2loint(R.f3_far.v), w_f3f_hi = __double2hiint(R.f3_far.v), w_f3f_i = R.f3_far.i;
+            int w_end_lo = __double2loint(R.end_best), w_end_hi = __double2hiint(R.end_best), w_end_i = R.end_idx, w_end_tb = R.end_tb;
+            int w_cidx = x.cidx, w_cndx = x.cndx;
+            w_nstop = nstop;
+#include "dpc_walk_gfx950.inc"
+            R.r5_all.v = __hiloint2double(w_r5a_hi, w_r5a_lo); R.r5_all.i = w_r5a_i;
+            R.r5_far.v = __hiloint2double(w_r5f_hi, w_r5f_lo); R.r5_far.i = w_r5f_i;
+            R.f3_far.v = __hiloint2double(w_f3f_hi, w_f3f_lo); R.f3_far.i = w_f3f_i;
+            R.end_best = __hiloint2double(w_end_hi, w_end_lo); R.end_idx = w_end_i; R.end_tb = w_end_tb;
+            x.cidx = w_cidx; x.cndx = w_cndx;
+            nstop = w_nstop;
+            if (w_i < w_end) {
+                // a node for the slow routine (or for the fast ones, in C++, when the block's own test was the cautious one)
+                node_cpp(w_i);
+                w_i++;
+                if (w_i < n && (w_i % NPG) == 0) { /* its group's service runs at the top of the loop */ }
+            }
+        }
+    } else {
+        for (int i = 0; i < n; i++) {
+            if ((i % NPG) == 0) service(i);
+            node_cpp(i);
+        }
     }
     flush((n - 1) & ~(DPC_FLUSH - 1), n);
     // highest score among gene ends, ties to the largest index (ref: lib.pyx:1239-1251, 1311)
@@ -382,6 +431,13 @@ void pga_launch_dpc_compile(const DpwTopoArrays& ta, const int32_t* d_cbase, int
 void pga_launch_dp_contig(const int2* d_waves, int n_waves, const ChainDesc* d_chains, const DpwGroupPtrs& groups, const ModelConst* d_models,
                           DpBuffers buf, const DpwBuffers& wb, hipStream_t st) {
     if (n_waves <= 0) return;
-    hipLaunchKernelGGL(k_dp_contig<DPC_LW>, dim3((unsigned)n_waves), dim3(64), 0, st, d_waves, d_chains, groups, (const double*)wb.cs,
-                       (const DpwExt*)wb.ext, d_models, buf);
+    // the assembly walk needs the extras dense by stop rank (the finder's layout); PGA_DPC_ASM=0: the C++ routines everywhere
+    static int use_asm = -1;
+    if (use_asm < 0) { const char* e = getenv("PGA_DPC_ASM"); use_asm = e ? atoi(e) != 0 : 1; }
+    if (use_asm && groups.g[0].srank != nullptr)
+        hipLaunchKernelGGL((k_dp_contig<DPC_LW, true>), dim3((unsigned)n_waves), dim3(64), 0, st, d_waves, d_chains, groups, (const double*)wb.cs,
+                           (const DpwExt*)wb.ext, d_models, buf);
+    else
+        hipLaunchKernelGGL((k_dp_contig<DPC_LW, false>), dim3((unsigned)n_waves), dim3(64), 0, st, d_waves, d_chains, groups, (const double*)wb.cs,
+                           (const DpwExt*)wb.ext, d_models, buf);
 }
