@@ -108,6 +108,19 @@ def test_config2_full_size(setup):
     a = mixed.genes_of(2)
     for name in ("begin", "end", "strand", "start_ndx", "stop_ndx", "cscore", "sscore"):
         assert np.array_equal(a[name], genes[name]), name
+    # the whole contig against the oracle (the segmented scorer on the workload it is benchmarked on): the winning model, every gene,
+    # and the scores of every gene's start node as bit patterns
+    bins = [orc.Training(m[1]) for m in models]
+    o = orc.Oracle(seq)
+    assert o.find_genes_meta(bins) == res.contigs[0]["model"]
+    og = o.genes()
+    assert len(og) == len(genes)
+    for name in ("begin", "end", "start_ndx", "stop_ndx"):
+        assert np.array_equal(og[name], genes[name]), name
+    on = o.nodes()
+    assert np.array_equal(on["strand"][genes["start_ndx"]], genes["strand"])
+    for name in ("cscore", "sscore", "rscore", "uscore", "tscore", "mot_score"):
+        assert np.array_equal(genes[name].view(np.uint64), on[name][genes["start_ndx"]].view(np.uint64)), name
 
 
 def test_config5_full_size_single_mode(capsys):
