@@ -1909,6 +1909,12 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                     HT(c, hipMemsetAsync(tp_cnt, 0, sizeof(int32_t) * segs.size(), st));
                     const TpWork tw{tp_seg, (int)segs.size(), out_nodes, levels, tp_up, tp_mark, tp_slots, tp_ins, tp_excl, tp_bsum, tp_cnt};
                     const dim3 grid(nblk), blk(256);
+                    const bool tp_steps = getenv("PGA_TP_STEPS") != nullptr;      // the many-launch form also for short chains (cross-check)
+                    if (max_n <= TP_SMALL_MAX && !tp_steps) {
+                        const int cap = (int)((max_n + 63) & ~63ll);
+                        hipLaunchKernelGGL(k_tp_small, dim3((unsigned)segs.size()), dim3(max_n <= 2048 ? 64 : 256), sizeof(int32_t) * 3 * (size_t)cap, st, tw, d_td, o,
+                                           d_tracef, d_elim, d_gene0, d_ngenes, cap);
+                    } else {
                     hipLaunchKernelGGL(k_tp_init, grid, blk, 0, st, tw, d_td, o);
                     for (int k = 0; k < levels; k++)
                         hipLaunchKernelGGL(k_tp_jump, grid, blk, 0, st, tw, (const int32_t*)(tp_up + (size_t)(k & 1) * out_nodes),
@@ -1924,6 +1930,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                     // a workgroup per contig: wide for genomes, narrow when there are many short paths
                     hipLaunchKernelGGL(k_tp_extract, dim3((unsigned)segs.size()), dim3(max_n >= 32768 ? 1024 : 256), 0, st, tw, d_td, o, d_path, d_elim,
                                        d_gene0, d_ngenes);
+                    }
                 }
             }
             if (max_n >= 32768 && NC <= 1024)       // genomes: a wavefront per gene (at most n / 2 + 2 genes per contig)

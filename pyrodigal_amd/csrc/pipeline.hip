@@ -603,24 +603,35 @@ k_extract_tile(const uint8_t* __restrict__ dig, int64_t total, const ContigDesc*
     if (t == 0) tile_scount[tile] = s_stops;
 }
 
-// Exclusive scan of n counts into n + 1 offsets, one workgroup: 8 elements per thread and round.  Two arrays at once when cnt2
-// is given (node and stop-node counts of the tiles share the launch and its barriers).
+// Exclusive scan of n counts into n + 1 offsets, one workgroup, 4096 counts per round.  One compute unit moves every byte, and what
+// limits it is memory instructions that touch one 32-byte sector per lane: counts are therefore read and offsets written with
+// lane-consecutive addresses and change hands through LDS (a thread scans four neighbours).  Two arrays at once when cnt2 is given
+// (node and stop-node counts of the tiles share the launch and its barriers).
+constexpr int SCAN_E = 4;
+__device__ __forceinline__ int scan_pad(const int i) { return i + (i >> 5); }
 __global__ void __launch_bounds__(1024)
 k_scan_counts(const int32_t* __restrict__ cnt, int n, int32_t* __restrict__ off, const int32_t* __restrict__ cnt2, int32_t* __restrict__ off2) {
+    __shared__ int s_a[SCAN_E * 1024 + SCAN_E * 32], s_b[SCAN_E * 1024 + SCAN_E * 32];
     __shared__ int s_w[16], s_w2[16];
     __shared__ int s_carry, s_carry2;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const bool two = cnt2 != nullptr;
     if (t == 0) { s_carry = 0; s_carry2 = 0; }
     __syncthreads();
-    for (int base = 0; base < n; base += 8192) {
-        const int i0 = base + t * 8;
-        int v[8], v2[8], sum = 0, sum2 = 0;
+    for (int base = 0; base < n; base += SCAN_E * 1024) {
+        int c[SCAN_E], c2[SCAN_E];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            v[k] = i0 + k < n ? cnt[i0 + k] : 0; sum += v[k];
-            v2[k] = two && i0 + k < n ? cnt2[i0 + k] : 0; sum2 += v2[k];
+        for (int k = 0; k < SCAN_E; k++) {
+            const int g = base + k * 1024 + t;
+            c[k] = g < n ? cnt[g] : 0;
+            c2[k] = two && g < n ? cnt2[g] : 0;
         }
+#pragma unroll
+        for (int k = 0; k < SCAN_E; k++) { s_a[scan_pad(k * 1024 + t)] = c[k]; s_b[scan_pad(k * 1024 + t)] = c2[k]; }
+        __syncthreads();
+        int v[SCAN_E], v2[SCAN_E], sum = 0, sum2 = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_E; k++) { v[k] = s_a[scan_pad(t * SCAN_E + k)]; v2[k] = s_b[scan_pad(t * SCAN_E + k)]; sum += v[k]; sum2 += v2[k]; }
         int inc = sum, inc2 = sum2;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -632,11 +643,16 @@ k_scan_counts(const int32_t* __restrict__ cnt, int n, int32_t* __restrict__ off,
         int run = s_carry + inc - sum, run2 = s_carry2 + inc2 - sum2;
         for (int k = 0; k < w; k++) { run += s_w[k]; run2 += s_w2[k]; }
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            if (i0 + k < n) { off[i0 + k] = run; if (two) off2[i0 + k] = run2; }
+        for (int k = 0; k < SCAN_E; k++) {
+            s_a[scan_pad(t * SCAN_E + k)] = run; s_b[scan_pad(t * SCAN_E + k)] = run2;       // the thread's own four slots
             run += v[k]; run2 += v2[k];
         }
         __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SCAN_E; k++) {
+            const int g = base + k * 1024 + t;
+            if (g < n) { off[g] = s_a[scan_pad(k * 1024 + t)]; if (two) off2[g] = s_b[scan_pad(k * 1024 + t)]; }
+        }
         if (t == 1023) { s_carry = run; s_carry2 = run2; }
         __syncthreads();
     }

@@ -283,3 +283,154 @@ k_tp_extract(TpWork w, const TailDesc* __restrict__ td, OutArrays o, const int32
     }
     if (t == 0) n_genes[s.contig] = s_ng;
 }
+
+// ---- all of the above in ONE launch when every winning chain fits the LDS of a workgroup (batches of short contigs) ----
+// A workgroup per contig.  The chain's traceb goes to LDS in one coalesced pass; ONE lane then follows it from the best gene end
+// to the head of the path -- a pointer chase, but through LDS (a path of a 20 kbp contig is some sixty nodes: a few microseconds) --
+// and what it lists IS the path in walk order, so marks, pointer doubling and the prefix sum over all nodes of the batch (twenty
+// launches over every node of every winning chain) are not needed: the splices are counted per path position, a prefix sum over
+// the path places them, and the passes that follow (links, the two elimination loops, the gene list) run over the final path in
+// LDS.  Same rules, same order of the floating-point additions as k_tp_slots .. k_tp_extract.
+constexpr int TP_SMALL_MAX = 4096;        // nodes of the longest chain: 3 arrays of int32 in LDS (48 KB)
+constexpr int TP_SPLICED_STOP = 1 << 30;  // tag of a path entry: the reverse stop the first untangling pass splices in (its ov_mark is reset)
+
+__device__ inline int tp_block_excl_scan(int v, int* s_w, int& total) {     // exclusive scan over the workgroup; total = sum
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nwv = blockDim.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) { const int x = __shfl_up(inc, dd, 64); if (lane >= dd) inc += x; }
+    __syncthreads();                        // s_w may still be read from the previous round
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    int off = 0; total = 0;
+    for (int k = 0; k < nwv; k++) { if (k < wave) off += s_w[k]; total += s_w[k]; }
+    return off + inc - v;
+}
+
+__global__ void __launch_bounds__(256)
+k_tp_small(TpWork w, const TailDesc* __restrict__ td, OutArrays o, int32_t* __restrict__ tracef, uint8_t* __restrict__ elim,
+           GeneRec* __restrict__ genes, int32_t* __restrict__ n_genes, const int cap) {
+    extern __shared__ int32_t s_dyn[];
+    int32_t* s_tb = s_dyn; int32_t* s_base = s_dyn + cap; int32_t* s_pl = s_dyn + 2 * cap;
+    __shared__ int s_w[4], s_m;
+    __shared__ int s_sc[4][4], s_cnt[4], s_carry[4], s_ng;
+    const int si = blockIdx.x;
+    const TpSeg s = w.seg[si];
+    const TailDesc d = td[s.contig];
+    const int n = s.n, t = threadIdx.x, nthr = blockDim.x, lane = t & 63, wave = t >> 6, nwv = nthr >> 6;
+    NodeView v = node_view(d, o, tracef, elim);
+    for (int i = t; i < n; i += nthr) s_tb[i] = v.traceb[i];
+    if (t == 0) { s_ng = 0; s_m = 0; }
+    if (t < 4) s_carry[t] = -1;
+    __syncthreads();
+    if (t == 0 && d.mx >= 0) { int m = 0; for (int p = d.mx; p != -1; p = s_tb[p]) s_base[m++] = p; s_m = m; }
+    __syncthreads();
+    const int m = s_m;
+    // what the two untangling passes splice in after path node p (edge p -> nx); ref: lib.pyx:1253-1295
+    int cnt = 0;
+    for (int k0 = 0; k0 < m; k0 += nthr) {
+        const int k = k0 + t;
+        int slots = 0, i0 = -1, i1 = -1, p = -1;
+        if (k < m) {
+            slots = 1; p = s_base[k];
+            const int nx = s_tb[p];
+            if (nx != -1) {
+                const int sp = v.strand[p], sn = v.strand[nx], ov = v.ov_mark[p], np = v.ndx[p], nn = v.ndx[nx];
+                const bool stp = is_stop_n(v, p), stn = is_stop_n(v, nx);
+                if ((sp == -1) & stp & (sn == 1) & stn & (ov != -1) & (np > nn)) {
+                    i0 = v.star_ptr[3 * p + ov];
+                    i1 = walk_down_to(v, i0, v.stop_val[i0]);
+                    slots = 3;
+                } else {
+                    const bool p_rb = sp == -1 && !stp, p_fs = sp == 1 && stp, p_rs = sp == -1 && stp;
+                    const bool n_fs = sn == 1 && stn, n_rs = sn == -1 && stn;
+                    if (p_rb && n_fs) i0 = walk_down_to(v, p, v.stop_val[p]);
+                    if (p_fs && n_fs) i0 = v.star_ptr[3 * nx + np % 3];
+                    if (p_rs && n_rs) i0 = v.star_ptr[3 * p + nn % 3];
+                    if (i0 != -1) slots = 2;
+                }
+            }
+        }
+        int total;
+        const int q = cnt + tp_block_excl_scan(slots, s_w, total);
+        if (q + slots <= cap) {           // always: the spliced-in nodes are nodes of the chain that are not on the path
+            if (slots >= 1) s_pl[q] = p;
+            if (slots >= 2) s_pl[q + 1] = i0;
+            if (slots == 3) s_pl[q + 2] = i1 | TP_SPLICED_STOP;
+        }
+        cnt += total;
+    }
+    cnt = min(cnt, cap);
+    __syncthreads();
+    // ov_mark of the spliced-in reverse stops (after every splice was decided: the decisions read ov_mark), traceb / tracef along the path
+    for (int q = t; q < cnt; q += nthr) {
+        const int e = s_pl[q];
+        if (e & TP_SPLICED_STOP) { v.ov_mark[e & ~TP_SPLICED_STOP] = -1; s_pl[q] = e & ~TP_SPLICED_STOP; }
+    }
+    __syncthreads();
+    for (int q = t; q + 1 < cnt; q += nthr) { const int x = s_pl[q], y = s_pl[q + 1]; v.traceb[x] = y; v.tracef[y] = x; }
+    if (cnt < 2) { if (t == 0) n_genes[s.contig] = 0; return; }          // the best gene end has no traceb (ref: lib.pyx:1311)
+    // Prodigal dprog.c eliminate_bad_genes, first loop: a node's start score receives at most two terms, in path order
+    for (int q = t; q < cnt; q += nthr) {
+        const int x = s_pl[q];
+        if (q + 1 <= cnt - 1) {
+            const int p = s_pl[q + 1];
+            if (v.strand[p] == 1 && is_stop_n(v, p)) v.sscore[x] += igm_h(v, p, x, d.st_wt);
+        }
+        if (q >= 1 && v.strand[x] == -1 && !is_stop_n(v, x)) v.sscore[x] += igm_h(v, x, s_pl[q - 1], d.st_wt);
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int q = 1 + t; q < cnt; q += nthr) {
+        const int p = s_pl[q], f = s_pl[q - 1];
+        const int sp = v.strand[p]; const bool stp = is_stop_n(v, p);
+        const double gp = v.cscore[p] + v.sscore[p], gf = v.cscore[f] + v.sscore[f];
+        if ((sp == 1 && !stp && gp < 0) || (sp == -1 && stp && gf < 0)) { v.elim[p] = 1; v.elim[f] = 1; }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // Genes._extract (ref: lib.pyx:3231-3270), as k_tp_extract
+    GeneRec* out = genes + d.gene_off;
+    auto val_b = [&](int r) { const int p = s_pl[cnt - 1 - r]; return v.strand[p] == 1 ? v.ndx[p] + 1 : v.ndx[p] - 1; };
+    auto val_e = [&](int r) { const int p = s_pl[cnt - 1 - r]; return v.strand[p] == 1 ? v.ndx[p] + 3 : v.ndx[p] + 1; };
+    for (int r0 = 0; r0 < cnt; r0 += nthr) {
+        const int r = r0 + t;
+        bool live = false, fwd = false, stp = false;
+        if (r < cnt) {
+            const int p = s_pl[cnt - 1 - r];
+            live = v.elim[p] != 1; fwd = v.strand[p] == 1; stp = is_stop_n(v, p);
+        }
+        const bool set_b = live && ((fwd && !stp) || (!fwd && stp));
+        const bool set_e = live && ((fwd && stp) || (!fwd && !stp));
+        const bool set_s = live && !stp;
+        const bool set_t = live && stp;
+        const bool emit = live && ((fwd && stp) || (!fwd && !stp));
+        int mm[4] = {set_b ? r : -1, set_e ? r : -1, set_s ? r : -1, set_t ? r : -1};
+        int e1 = emit ? 1 : 0;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const int o2 = __shfl_up(mm[k], dd, 64); if (lane >= dd) mm[k] = max(mm[k], o2); }
+            const int o3 = __shfl_up(e1, dd, 64); if (lane >= dd) e1 += o3;
+        }
+        if (lane == 63) { for (int k = 0; k < 4; k++) s_sc[wave][k] = mm[k]; s_cnt[wave] = e1; }
+        __syncthreads();
+        int eoff = s_ng;
+        for (int k2 = 0; k2 < wave; k2++) {
+            for (int k = 0; k < 4; k++) mm[k] = max(mm[k], s_sc[k2][k]);
+            eoff += s_cnt[k2];
+        }
+        for (int k = 0; k < 4; k++) mm[k] = max(mm[k], s_carry[k]);
+        if (emit) {
+            GeneRec gr;
+            gr.begin = mm[0] >= 0 ? val_b(mm[0]) : 0; gr.end = mm[1] >= 0 ? val_e(mm[1]) : 0;
+            gr.start_ndx = mm[2] >= 0 ? s_pl[cnt - 1 - mm[2]] : 0; gr.stop_ndx = mm[3] >= 0 ? s_pl[cnt - 1 - mm[3]] : 0;
+            out[eoff + e1 - 1] = gr;
+        }
+        __syncthreads();
+        if (t == nthr - 1) { for (int k = 0; k < 4; k++) s_carry[k] = mm[k]; s_ng = eoff + e1; }
+        __syncthreads();
+    }
+    if (t == 0) n_genes[s.contig] = s_ng;
+    (void)nwv;
+}

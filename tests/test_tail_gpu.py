@@ -89,3 +89,27 @@ def test_many_contigs_with_frequent_start_tweaks(ctx, monkeypatch):
     bins = [orc.Training(b) for b in models]
     for i in (0, 2, 7, 13):
         compare_contig(runs["par"], i, seqs[i], orc.Oracle(seqs[i]), bins, meta=True)
+
+
+def test_short_contigs_one_launch_tail(ctx, monkeypatch):
+    """Batches whose chains all fit a workgroup's LDS take the one-launch tail (k_tp_small): every node field and every gene against
+    the oracle, and against the many-launch form (PGA_TP_STEPS), the one-thread-per-contig tail and the host tail."""
+    from pyrodigal_amd import benchdata
+    models = [b for _, b in benchdata.load_model_set()]
+    ctx.set_models(models)
+    bins = [orc.Training(b) for b in models]
+    seqs = [synthetic_contig(3_000 + 977 * (k % 23), 0.30 + 0.40 * (k % 41) / 40, 4000 + k) for k in range(96)]
+    seqs += [planted(40_000, 0.45, 7), planted(9_000, 0.62, 8), b"", b"ATG" + b"GCA" * 60 + b"TAA", synthetic_contig(70_000, 0.5, 9)]
+    runs = run_modes(ctx, monkeypatch, seqs, meta=True)
+    monkeypatch.setenv("PGA_TP_STEPS", "1")
+    runs["steps"] = ctx.find_genes_batch(seqs, want_nodes=True, meta=True)
+    monkeypatch.delenv("PGA_TP_STEPS")
+    assert max(c["n_nodes"] for c in runs["par"].contigs) <= 4096           # or the batch would not take the one-launch form
+    total = sum(compare_contig(runs["par"], i, s, orc.Oracle(s), bins, meta=True) for i, s in enumerate(seqs))
+    assert total > 500
+    for mode in ("steps", "device", "host"):
+        assert runs[mode].genes.tobytes() == runs["par"].genes.tobytes(), mode
+        for i in range(len(seqs)):
+            for k in ("traceb", "tracef", "ov_mark", "elim"):
+                assert np.array_equal(runs[mode].nodes[i][k], runs["par"].nodes[i][k]), (mode, i, k)
+            assert np.array_equal(runs[mode].nodes[i]["sscore"].view(np.uint64), runs["par"].nodes[i]["sscore"].view(np.uint64)), (mode, i)
