@@ -308,17 +308,22 @@ __host__ __device__ void tweak_one(const NodeView& v, const GeneRec* prev, GeneR
         if (v.strand[ndx] == -1 && next_rev) ig = igm_same_h(v, ndx, next->stop_ndx, w);
         int mi[2] = {-1, -1}; double ms[2] = {0, 0}, mg[2] = {0, 0};
         const int sv_ndx = v.stop_val[ndx];
-        // the 200 neighbours eight at a time: what rules nearly all of them out (a stop node, or a node of another ORF) is asked for
-        // in one go -- one memory round trip per eight candidates instead of one per candidate, on the device one thread walks them
-        for (int j0 = ndx - 100; j0 < ndx + 100; j0 += 8) {
-          int svq[8]; bool stq[8];
+        // the 200 neighbours forty at a time: what rules nearly all of them out (a stop node, or a node of another ORF) is asked for
+        // in one go -- one memory round trip per forty candidates instead of one per candidate, on the device one thread walks them
+        constexpr int TWB = 40;             // 200 = 5 x 40
+        for (int j0 = ndx - 100; j0 < ndx + 100; j0 += TWB) {
+          unsigned long long pass = 0;          // start nodes of the gene's own ORF among the forty, then taken in index order
 #pragma unroll
-          for (int q = 0; q < 8; q++) { const int jj = j0 + q < 0 ? 0 : (j0 + q >= nn ? nn - 1 : j0 + q); svq[q] = v.stop_val[jj]; stq[q] = is_stop_n(v, jj); }
-#pragma unroll
-          for (int q = 0; q < 8; q++) {
+          for (int q = 0; q < TWB; q++) {
             const int j = j0 + q;
-            if (j < 0 || j >= nn || j == ndx) continue;
-            if (stq[q] | (svq[q] != sv_ndx)) continue;
+            const int jj = j < 0 ? 0 : (j >= nn ? nn - 1 : j);
+            const bool ok = !(is_stop_n(v, jj) | (v.stop_val[jj] != sv_ndx)) && j >= 0 && j < nn && j != ndx;
+            pass |= (unsigned long long)ok << q;
+          }
+          while (pass) {
+            const int q = __builtin_ctzll(pass);
+            pass &= pass - 1ull;
+            const int j = j0 + q;
             double tg = 0.0;
             if (v.strand[j] == 1 && prev_fwd) {
                 if (v.ndx[prev->stop_ndx] - v.ndx[j] > maxov) continue;
