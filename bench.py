@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_PER_NODE_PASS = 64.0     # compulsory SoA bytes per DP node-pass
 VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2.0   # wave64 VALU instructions per second the chip can issue (256 CUs x 4 SIMD-32)
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+PMC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_traffic.json", "r03_pmc_traffic.json")]     # newest first
 
 # every kernel of a segmented connection-scoring launch (pga_launch_dp with a plan), for the rocprof summaries
 SEGMENTED_DP_KERNELS = ["k_dp_tree_mw", "k_seg_gather", "k_seg_weights", "k_seg_height", "k_spine_count",
@@ -45,7 +45,7 @@ def roofline(ctx, dp_ms, passes, calls, n_chains, wname, launch_key=None):
     pmc = pmc_entry(launch_key or wname)
     r = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc.get("hbm_bytes_per_launch"),
-         "traffic_source": ("profiles/r03_pmc_traffic.json (separate rocprofv3 --pmc passes, collected at commit %s)" % pmc.get("collected_at_commit"))
+         "traffic_source": ("%s (separate rocprofv3 --pmc passes, collected at commit %s)" % (pmc.get("_file"), pmc.get("collected_at_commit")))
                            if pmc.get("hbm_bytes_per_launch") else None,
          "kernel": "k_dp_tree_mw" if n_chains < 2048 else ctx.dp_kernel_name(),
          "kernel_ms_per_launch": round(dp_ms / max(calls, 1), 4), "launches": calls,
@@ -84,14 +84,34 @@ def pmc_entry(workload):
     (profiles/r03_pmc_traffic.json: HBM bytes and VALU wave-instructions per launch, the commit they were collected at and how
     they were corrected).  Counters cannot be collected inside a timed run, so this is a lookup: it is only valid while the
     kernel has not changed since `collected_at_commit`, which the JSON line repeats."""
-    try:
-        with open(PMC_FILE) as f:
-            d = json.load(f)
-        e = dict(d.get(workload, {}))
+    for path in PMC_FILES:
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if workload not in d:
+            continue
+        e = dict(d[workload])
         e.setdefault("collected_at_commit", d.get("collected_at_commit"))        # per entry since the file is refreshed one workload at a time
+        e["_file"] = os.path.relpath(path, ROOT)
         return e
-    except OSError:
-        return {}
+    return {}
+
+
+def pipeline_entry(workload):
+    """SURVEY 8(d)'s whole-pipeline figures of one device call of this workload -- HBM bytes per base over ALL kernels of the call
+    and every kernel's milliseconds per call -- as tools/pipeline_traffic.py computed them from the kernel trace and the
+    FETCH_SIZE / WRITE_SIZE passes of tools/collect_profiles.sh.  A lookup like `pmc_entry`, valid for `collected_at_commit`."""
+    e = pmc_entry("pipeline:" + workload)
+    if not e:
+        return None
+    kern = e.get("kernels", {})
+    return {"pipeline_hbm_bytes_per_bp": e.get("pipeline_hbm_bytes_per_bp"), "kernel_ms_per_call": e.get("kernel_ms_per_call"),
+            "hbm_GB_per_call": e.get("pipeline_hbm_GB_per_call"), "bases_per_call": e.get("bases_per_call"),
+            "kernel_ms": {k: v["ms_per_call"] for k, v in kern.items() if v["ms_per_call"] >= 0.02},
+            "kernel_hbm_MB": {k: v["hbm_MB_per_call"] for k, v in kern.items() if v["hbm_MB_per_call"] >= 50.0},
+            "source": "%s (%s, collected at commit %s)" % (e.get("_file"), e.get("method", ""), e.get("collected_at_commit"))}
 
 
 class Lanes:
@@ -350,12 +370,19 @@ def main():
         }
         if per_rank is not None:
             out["config"]["per_rank"] = per_rank
+        pl = pipeline_entry("%dx20kbp_gc30-70_meta" % min(sub, len(seqs)) if args.workload == "config4" else wname)
+        if pl is not None:
+            out["pipeline_hbm_bytes_per_bp"] = pl["pipeline_hbm_bytes_per_bp"]         # all kernels of a device call
+            out["pipeline"] = pl
         if n_ctx > 1:
             out["roofline"]["measured"] = "calls issued one after the other right after the timed region (kernel alone on the device)"
             out["roofline"]["kernel_ms_per_launch_in_timed_region"] = round(dp_ms_shared / max(calls_shared, 1), 4)
             out["roofline"]["frac_in_timed_region"] = round(BYTES_PER_NODE_PASS * passes_shared / (dp_ms_shared * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if dp_ms_shared > 0 else 0.0
         if world == 1 and not args.no_cpu_baseline and not single:
             out["cpu_baseline"] = cpu_baseline(seqs, models, res[0] if res else None, args.contigs if args.workload == "config4" else 0)
+            if len(seqs) > 1:
+                # (i) one thread above, (ii) every host core here -- its own top-level object
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(seqs, models)
     fasta_line = pool_line = None
     try:
         free_b, total_b = torch.cuda.mem_get_info(dev_index)
@@ -528,35 +555,86 @@ def cpu_baseline(seqs, models, gpu_res, n_job=0):
            "sample": "%d contig(s), %d bp, same 16 models, meta mode, 1 thread (%s)" % (i + (done >= budget_bases), done, _cpu_name()),
            "gene_calls_identical_to_gpu": match, "genes_in_sample": total_genes, "host_cpus": os.cpu_count()}
     out["avx2"] = True      # oracle/Makefile: -O2 -mavx2 -ftree-vectorize; gcc vectorises the byte pre-filter loop (32-byte vectors)
-    if len(seqs) > 1:
-        out["all_cores"] = cpu_baseline_all_cores(seqs, models)
     return out
 
 
 def cpu_baseline_all_cores(seqs, models):
-    """The same oracle on every host core: a pool of C threads sharing the models, one contig per call (pyrodigal's own pool model,
-    ref: cli.py:289-302, without an interpreter lock in the way; oracle/prodigal_oracle.c `po_find_genes_meta_pool`).  Timed on
-    both all logical CPUs and one thread per physical core; `value` is the better of the two."""
+    """SURVEY 8(d)'s line (ii): the same CPU checker on the host's cores -- a pool of C threads sharing the models, one contig per call
+    (pyrodigal's own pool model, ref: cli.py:289-302, without an interpreter lock in the way; oracle/prodigal_oracle.c
+    `po_find_genes_meta_pool_pinned`) -- as a curve over the thread count: threads pinned one per physical core, spread over the
+    sockets, hardware siblings only once the cores are used up; every point runs for about five seconds (the sample's contigs gone
+    over as often as that takes).  `cpu_busy` = CPU time the threads got / (threads x wall time): below 1 the threads were not
+    running (a CPU quota of the container, or waiting), at 1 with a falling rate per thread they were running slower (shared caches,
+    memory, clocks).  `value` is the best point."""
     from oracle import oracle as orc
     bins = [orc.Training(m[1]) for m in models]
-    logical = os.cpu_count() or 1
-    physical = _physical_cores() or logical
-    out = {"unit": "Mbp/s", "physical_cores": physical, "logical_cpus": logical, "avx2": True, "runs": []}
-    for threads in sorted({physical, logical}):
-        sample = seqs[:min(len(seqs), 60 * threads)]
-        bases = sum(len(s) for s in sample)
-        orc.find_genes_meta_pool(sample[:2 * threads], bins, threads)          # threads' arenas, page cache of the tables
+    order, physical = _pin_order()
+    logical = len(order)
+    out = {"unit": "Mbp/s", "kind": "port", "physical_cores": physical, "logical_cpus": logical, "os_cpu_count": os.cpu_count(),
+           "cpu_quota_cores": _cpu_quota(), "cpu": _cpu_name(), "avx2": True, "pinned": True, "curve": []}
+    sample = seqs[:min(len(seqs), 4096)]
+    mean_len = sum(len(s) for s in sample) / max(len(sample), 1)
+    orc.find_genes_meta_pool_pinned(sample[:64], bins, min(8, logical), cpus=order)          # page cache of the tables, the library
+    per_thread = None                  # contigs per second and thread at the previous point
+    for threads in sorted({t for t in (1, 8, 32, 64, 128, physical, logical) if t <= logical}):
+        if per_thread is None:
+            t0 = time.perf_counter()
+            orc.find_genes_meta_pool_pinned(sample[:24], bins, 1, cpus=order)
+            per_thread = 24 / (time.perf_counter() - t0)
+        total = int(max(threads * 8, per_thread * threads * 5.5))
         t0 = time.perf_counter()
-        genes = orc.find_genes_meta_pool(sample, bins, threads)
+        genes, cpu_s = orc.find_genes_meta_pool_pinned(sample, bins, threads, total=total, cpus=order)
         dt = time.perf_counter() - t0
-        out["runs"].append({"threads": threads, "value": round(bases / dt / 1e6, 3), "seconds": round(dt, 2), "contigs": len(sample), "bases": bases,
-                            "genes_in_sample": genes})
-    best = max(out["runs"], key=lambda r: r["value"])
-    out.update(value=best["value"], cores=best["threads"],
-               sample="%d contigs, %d bp, one contig per call on a pool of %d C threads sharing the 16 models; oracle built -O2 -mavx2 (the byte "
-                      "pre-filter of the connection scoring is auto-vectorised with 32-byte vectors, like the reference's AVX2 backend)"
-                      % (best["contigs"], best["bases"], best["threads"]))
+        calls = max(total, len(sample))
+        per_thread = calls / dt / threads
+        out["curve"].append({"threads": threads, "value": round(calls * mean_len / dt / 1e6, 3), "seconds": round(dt, 2), "calls": calls,
+                             "Mbp_s_per_thread": round(calls * mean_len / dt / 1e6 / threads, 3), "cpu_busy": round(cpu_s / (dt * threads), 3),
+                             "genes": genes})
+    best = max(out["curve"], key=lambda r: r["value"])
+    one = out["curve"][0]
+    out.update(value=best["value"], cores=best["threads"], scaling_vs_one_thread=round(best["value"] / max(one["value"], 1e-9), 1),
+               sample="%d contigs of the job (%.0f bp on average) gone over for about 5 s per point, one contig per call on a pool of pinned C threads "
+                      "sharing the 16 models; built -O2 -mavx2 (the byte pre-filter of the connection scoring is auto-vectorised with 32-byte "
+                      "vectors, like the reference's AVX2 backend)" % (len(sample), mean_len))
     return out
+
+
+def _pin_order():
+    """Logical CPUs this process may use, ordered for pinning: one per physical core first, alternating between the sockets, then the
+    hardware siblings in the same order.  Returns (order, number of physical cores among them)."""
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    cores = {}
+    for c in allowed:
+        try:
+            base = "/sys/devices/system/cpu/cpu%d/topology/" % c
+            key = (int(open(base + "physical_package_id").read()), int(open(base + "core_id").read()))
+        except (OSError, ValueError):
+            key = (0, c)
+        cores.setdefault(key, []).append(c)
+    by_pkg = {}
+    for key in sorted(cores):
+        by_pkg.setdefault(key[0], []).append(cores[key])
+    firsts, rest = [], []
+    lists = [by_pkg[k] for k in sorted(by_pkg)]
+    for i in range(max(len(l) for l in lists)):
+        for l in lists:
+            if i < len(l):
+                firsts.append(l[i][0]); rest.extend(l[i][1:])
+    return firsts + rest, len(firsts)
+
+
+def _cpu_quota():
+    """CPUs the container's CPU controller lets this process use at once (cgroup v2 cpu.max or v1 cfs quota), None when unlimited."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(p), 2)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / p, 2)
+    except (OSError, ValueError):
+        return None
 
 
 def _physical_cores():

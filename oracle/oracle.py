@@ -84,6 +84,8 @@ def lib():
         L.po_find_genes_single.restype = i32; L.po_find_genes_single.argtypes = [vp, vp, vp]
         L.po_find_genes_meta.restype = i32; L.po_find_genes_meta.argtypes = [vp, vp, i32, vp]
         L.po_find_genes_meta_pool.restype = ctypes.c_int64; L.po_find_genes_meta_pool.argtypes = [vp, vp, i32, vp, i32, vp, i32]
+        L.po_find_genes_meta_pool_pinned.restype = ctypes.c_int64
+        L.po_find_genes_meta_pool_pinned.argtypes = [vp, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp]
         L.po_train.restype = i32; L.po_train.argtypes = [vp, vp, vp, i32, f64, i32]
         L.po_train_upto.restype = i32; L.po_train_upto.argtypes = [vp, vp, vp, i32, f64, i32, i32]
         assert L.po_node_size() == NODE_DTYPE.itemsize, (L.po_node_size(), NODE_DTYPE.itemsize)
@@ -307,3 +309,21 @@ def find_genes_meta_pool(seqs, bins, threads, params=None):
     if got < 0:
         raise RuntimeError("po_find_genes_meta_pool failed")
     return int(got)
+
+
+def find_genes_meta_pool_pinned(seqs, bins, threads, total=None, cpus=None, params=None):
+    """`find_genes_meta_pool` making `total` calls (the list gone over as often as that takes), thread t pinned to logical CPU
+    cpus[t % len(cpus)] when a list is given: returns (genes found, CPU seconds the threads used)."""
+    L = lib()
+    p = params or Params()
+    n = len(seqs)
+    ptrs = (ctypes.c_char_p * max(n, 1))(*seqs)
+    lens = (ctypes.c_int64 * max(n, 1))(*[len(s) for s in seqs])
+    arr = (ctypes.c_void_p * len(bins))(*[b.ptr for b in bins])
+    cl = (ctypes.c_int * max(len(cpus or []), 1))(*(cpus or [0]))
+    cpu_s = ctypes.c_double(0.0)
+    got = L.po_find_genes_meta_pool_pinned(ptrs, lens, n, arr, len(bins), ctypes.addressof(p), int(threads), int(total or n),
+                                           ctypes.addressof(cl) if cpus else None, len(cpus or []), ctypes.addressof(cpu_s))
+    if got < 0:
+        raise RuntimeError("po_find_genes_meta_pool_pinned failed")
+    return int(got), float(cpu_s.value)

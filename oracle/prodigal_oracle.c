@@ -5,6 +5,7 @@
  * reference's x86-64 build.  All "ref:" citations are relative to
  * /root/reference/src/pyrodigal unless another root is given.
  */
+#define _GNU_SOURCE          /* CPU_SET, pthread_setaffinity_np (the all-core baseline driver at the end of the file) */
 #include "prodigal_oracle.h"
 
 #include <math.h>
@@ -1349,40 +1350,61 @@ int po_train(po_ctx* c, po_training* t, const po_params* p, int force_nonsd, dou
  * contig costs a TLB shootdown on every core) -- so the figure says what the CPU path can do, not what a Python harness costs. */
 #include <malloc.h>
 #include <pthread.h>
+#include <sched.h>
+#include <time.h>
 
 typedef struct {
     const char* const* seqs; const int64_t* lens; int n;
     const po_training* const* bins; int nbins; const po_params* p;
     int next; int64_t genes; pthread_mutex_t mu;
+    int total;                  /* calls to make: the list is gone over as often as that takes (total >= n) */
+    const int* cpus; int ncpus; /* thread t runs on logical CPU cpus[t % ncpus] (or anywhere) */
+    int started;                /* threads that took their number */
+    double cpu_seconds;         /* CPU time the threads spent, summed */
 } po_pool_job;
 
 static void* po_pool_worker(void* arg) {
     po_pool_job* J = (po_pool_job*)arg;
+    const int t = __atomic_fetch_add(&J->started, 1, __ATOMIC_RELAXED);
+    if (J->cpus != NULL && J->ncpus > 0) {
+        cpu_set_t set; CPU_ZERO(&set); CPU_SET(J->cpus[t % J->ncpus], &set);
+        pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+    }
     int64_t genes = 0;
     for (;;) {
         const int k = __atomic_fetch_add(&J->next, 1, __ATOMIC_RELAXED);
-        if (k >= J->n) break;
-        po_ctx* c = po_new(J->seqs[k], J->lens[k], 0, 50);
+        if (k >= J->total) break;
+        po_ctx* c = po_new(J->seqs[k % J->n], J->lens[k % J->n], 0, 50);
         po_find_genes_meta(c, J->bins, J->nbins, J->p);
         genes += po_num_genes(c);
         po_free(c);
     }
-    pthread_mutex_lock(&J->mu); J->genes += genes; pthread_mutex_unlock(&J->mu);
+    struct timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    pthread_mutex_lock(&J->mu); J->genes += genes; J->cpu_seconds += (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; pthread_mutex_unlock(&J->mu);
     return NULL;
 }
 
-/* meta-mode gene finding of n sequences on `threads` threads; returns the number of genes found, -1 on failure */
-int64_t po_find_genes_meta_pool(const char* const* seqs, const int64_t* lens, int n, const po_training* const* bins, int nbins,
-                                const po_params* p, int threads) {
+/* `total` calls (the n sequences, gone over as often as that takes) on `threads` threads, thread t pinned to cpus[t % ncpus] when a
+ * list is given; *cpu_seconds receives the CPU time the threads used.  Returns the number of genes found, -1 on failure. */
+int64_t po_find_genes_meta_pool_pinned(const char* const* seqs, const int64_t* lens, int n, const po_training* const* bins, int nbins,
+                                       const po_params* p, int threads, int total, const int* cpus, int ncpus, double* cpu_seconds) {
     if (threads < 1) threads = 1;
+    if (n < 1) return 0;
     mallopt(M_MMAP_THRESHOLD, 1 << 30);
     mallopt(M_TRIM_THRESHOLD, 1 << 30);
-    po_pool_job J = {seqs, lens, n, bins, nbins, p, 0, 0, PTHREAD_MUTEX_INITIALIZER};
+    po_pool_job J = {seqs, lens, n, bins, nbins, p, 0, 0, PTHREAD_MUTEX_INITIALIZER, total > n ? total : n, cpus, ncpus, 0, 0.0};
     pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
     if (!th) return -1;
     int started = 0;
     for (int t = 0; t < threads; t++) { if (pthread_create(&th[t], NULL, po_pool_worker, &J) != 0) break; started++; }
     for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
     free(th);
+    if (cpu_seconds) *cpu_seconds = J.cpu_seconds;
     return started > 0 ? J.genes : -1;
+}
+
+/* meta-mode gene finding of n sequences on `threads` threads; returns the number of genes found, -1 on failure */
+int64_t po_find_genes_meta_pool(const char* const* seqs, const int64_t* lens, int n, const po_training* const* bins, int nbins,
+                                const po_params* p, int threads) {
+    return po_find_genes_meta_pool_pinned(seqs, lens, n, bins, nbins, p, threads, n, NULL, 0, NULL);
 }
