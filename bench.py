@@ -520,6 +520,23 @@ def threadpool_find_genes(seqs, models, dev_index, threads=32):
             lat.sort()
             out["lone_call_ms"] = {"median": round(1e3 * lat[len(lat) // 2], 3), "min": round(1e3 * lat[0], 3), "contig_bp": len(seqs[0])}
         del finder
+    # the reference's harness itself: multiprocessing.pool.ThreadPool(jobs).map(process, records) with map's own chunking
+    # (cli.py:289-302; a chunk of len / (4 jobs) records per task, so a thread makes its calls back to back)
+    from multiprocessing.pool import ThreadPool
+    for nthreads in (32, 128):
+        finder = lib.GeneFinder(meta=True, metagenomic_bins=bins, keep_nodes=False, device=dev_index)
+        with ThreadPool(nthreads) as pool:
+            pool.map(finder.find_genes, seqs[:256])
+            finder.stats.update(device_calls=0, sequences=0, max_calls_per_device_call=0)
+            t0 = time.perf_counter()
+            genes = sum(len(g) for g in pool.map(finder.find_genes, seqs))
+            dt = time.perf_counter() - t0
+        st = finder.stats
+        out["threadpool_map_%d_threads" % nthreads] = {
+            "value": round(bases / dt / 1e6, 3), "contigs_per_s": round(len(seqs) / dt, 1), "genes": int(genes), "threads": nthreads,
+            "device_calls": st["device_calls"], "contigs_per_device_call": round(st["sequences"] / max(st["device_calls"], 1), 1),
+            "what": "multiprocessing.pool.ThreadPool(%d).map(finder.find_genes, contigs), keep_nodes=False" % nthreads}
+        del finder
     out["value"] = out["keep_nodes_false"]["value"]
     return out
 

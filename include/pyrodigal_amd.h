@@ -233,7 +233,9 @@ int pga_train(pga_ctx*, const pga_batch*, const pga_params*, int translation_tab
  * after max_records records or once max_bases bases are exceeded (0 = no limit); *n_records == 0 at end of file. */
 typedef struct pga_fasta pga_fasta;
 /* plain files are mapped and parsed by several threads; gzip files are inflated with zlib on one thread; a file in another
- * compression format is rejected (PGA_EINVAL): decompress it into pga_fasta_open_callback */
+ * compression format is rejected (PGA_EINVAL): decompress it into pga_fasta_open_callback.  A mapped file must not be truncated by
+ * another process while it is read: the kernel answers a read behind the new end with SIGBUS, which no return code can stand for
+ * (feed files that may shrink through pga_fasta_open_callback and read() instead). */
 int         pga_fasta_open(const char* path, pga_fasta** out);
 /* The same reader over a byte stream the caller produces: read(user, buf, cap) fills up to cap bytes and returns their number,
  * 0 at the end of the stream, negative on failure (ref: tests/fasta.py:16-57 `zopen` -- the reference sniffs bz2 / xz / lz4 / zstd
@@ -244,6 +246,9 @@ int         pga_fasta_next(pga_fasta*, int64_t max_bases, int32_t max_records, i
                            const char* const** headers, const char* const** seqs, const int64_t** lens);
 const char* pga_fasta_error(const pga_fasta*);
 void        pga_fasta_close(pga_fasta*);
+/* The pinned staging arenas of closed readers wait in a process-wide pool for the next reader (at most eight arenas and 512 MB,
+ * allocated hipHostMallocPortable, so a reader on any device can take them); this gives them back to the system. */
+void        pga_fasta_release_spare(void);
 /* The same records with their sequences packed back to back in PINNED host memory (hipHostMalloc): `*packed` holds the
  * letters of the batch, record i at offs[i], lens[i] long, offs[i + 1] == offs[i] + lens[i].  The reader owns `n_arenas`
  * staging arenas (2 .. 8, fixed at the first call) and fills them in turn: the LETTERS of a call (`*packed`) stay valid until

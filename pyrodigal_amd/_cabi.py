@@ -19,7 +19,7 @@ EXPORTS = [
     "pga_score_connections", "pga_score_connections_training", "pga_find_genes_batch", "pga_result_free",
     "pga_batch_create", "pga_batch_free", "pga_find_genes", "pga_nodes_stage",
     "pga_fasta_open", "pga_fasta_next", "pga_fasta_error", "pga_fasta_close", "pga_train", "pga_dp_stats", "pga_dp_plan_summary", "pga_dp_start_order", "pga_cs_task_summary",
-    "pga_fasta_next_packed", "pga_batch_create_packed", "pga_translate_genes", "pga_fasta_open_callback",
+    "pga_fasta_next_packed", "pga_batch_create_packed", "pga_translate_genes", "pga_fasta_open_callback", "pga_fasta_release_spare",
 ]
 STAGE_EXTRACT, STAGE_SCORE, STAGE_OVERLAP, STAGE_SEQUENCE = 1, 2, 3, 4
 
@@ -123,6 +123,7 @@ def load():
     L.pga_translate_genes.argtypes = [vp, vp, i64, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]
     L.pga_fasta_error.restype = ctypes.c_char_p; L.pga_fasta_error.argtypes = [vp]
     L.pga_fasta_close.restype = None; L.pga_fasta_close.argtypes = [vp]
+    L.pga_fasta_release_spare.restype = None; L.pga_fasta_release_spare.argtypes = []
     _lib = L
     return L
 
@@ -514,7 +515,7 @@ class FastaReader:
     def __init__(self, path):
         self.L = load()
         self.h = ctypes.c_void_p()
-        self._stream = self._cb = None
+        self._stream = self._cb = self._cb_error = None
         with open(path, "rb") as f:
             head = f.read(8)
         module = next((m for magic, m in self._MAGIC if head.startswith(magic)), None)
@@ -532,9 +533,13 @@ class FastaReader:
             stream = self._stream
 
             def read(_user, buf, cap):
+                # ctypes swallows whatever a callback raises (KeyboardInterrupt included) and hands 0 -- "end of stream" -- to the C
+                # reader: a truncated record set without an error.  So everything is caught here, kept, and reported as a failure;
+                # batches() / packed_batches() raise it again, chained.
                 try:
                     data = stream.read(int(cap))
-                except Exception:                       # a corrupt stream: the reader reports the failure
+                except BaseException as err:
+                    self._cb_error = err
                     return -1
                 ctypes.memmove(buf, data, len(data))
                 return len(data)
@@ -565,7 +570,7 @@ class FastaReader:
         while True:
             rc = self.L.pga_fasta_next(self.h, max_bases, max_records, ctypes.byref(n), ctypes.byref(hdr), ctypes.byref(seq), ctypes.byref(lens))
             if rc != PGA_OK:
-                raise ValueError(self.L.pga_fasta_error(self.h).decode("utf-8", "replace"))
+                self._raise(rc)
             if n.value == 0:
                 return
             out = []
@@ -573,6 +578,16 @@ class FastaReader:
                 fields = hdr[i].decode("utf-8", "replace").split(maxsplit=1)
                 out.append((fields[0] if fields else "", fields[1] if len(fields) > 1 else "", ctypes.string_at(seq[i], lens[i])))
             yield out
+
+    def _raise(self, rc):
+        """The reader's error; what the decompressor raised inside the read callback comes with it (an interrupt comes back as itself)."""
+        cause, self._cb_error = self._cb_error, None
+        if cause is not None and not isinstance(cause, Exception):
+            raise cause
+        err = (MemoryError if rc == PGA_ENOMEM else ValueError)(self.L.pga_fasta_error(self.h).decode("utf-8", "replace"))
+        if cause is not None:
+            raise err from cause
+        raise err
 
     def records(self):
         for batch in self.batches():
@@ -597,7 +612,8 @@ class FastaReader:
             rc = self.L.pga_fasta_next_packed(self.h, max_bases, max_records, n_arenas, ctypes.byref(n), ctypes.byref(hdr),
                                               ctypes.byref(packed), ctypes.byref(offs), ctypes.byref(lens))
             if rc != PGA_OK:
-                raise (MemoryError if rc == PGA_ENOMEM else ValueError)(self.L.pga_fasta_error(self.h).decode("utf-8", "replace"))
+                self._free[arena].set()
+                self._raise(rc)
             if n.value == 0:
                 self._free[arena].set()
                 return

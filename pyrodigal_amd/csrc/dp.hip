@@ -1646,6 +1646,8 @@ bool pga_dp_use_lane(int n_chains) {
     if (const char* e = getenv("PGA_DP_LANE")) { if (atoi(e) == 0) return false; }
     // a wavefront holds 64 chains: below a few waves per SIMD (1024 x 64 chains each) the one-wave-per-chain kernel has more in
     // flight and wins
+    // (41.5 KB of LDS per wavefront: three wavefronts per compute unit on gfx950's 160 KB, the only part this library runs on --
+    //  pga_create refuses any other)
     int min_chains = 1 << 30;
     if (const char* e = getenv("PGA_DP_LANE_MIN")) min_chains = std::max(1, atoi(e));
     return n_chains >= min_chains;

@@ -70,8 +70,8 @@ struct LaneX {
 // grid (tiles of 16 node indices, waves); a thread owns four consecutive nodes of one lane's chain: 16-byte loads from the
 // per-chain arrays, 16-byte stores that are contiguous over the sixteen lanes of a quarter workgroup
 __global__ void __launch_bounds__(256)
-k_dpl_pack(const DplDev L, const ChainDesc* __restrict__ chains, const DpwGroupPtrs groups, const double* __restrict__ g_cs) {
-    const int w = blockIdx.y, t0 = blockIdx.x * 16;
+k_dpl_pack(const DplDev L, const ChainDesc* __restrict__ chains, const DpwGroupPtrs groups, const double* __restrict__ g_cs, const int wave0) {
+    const int w = wave0 + blockIdx.y, t0 = blockIdx.x * 16;
     if (t0 >= L.wave_steps[w]) return;
     const int c = threadIdx.x & 63, part = threadIdx.x >> 6;       // lane of the wave; which four nodes of the tile
     const int chain = L.lane_chain[(int64_t)w * 64 + c];
@@ -240,8 +240,12 @@ void pga_launch_dp_lane(const ChainDesc* d_chains, const DpwGroupPtrs& groups, c
     if (L0.n_waves <= 0 || L0.max_steps <= 0) return;
     DplDev L = L0;
     L.dense_ext = groups.g[0].srank != nullptr;
-    hipLaunchKernelGGL(k_dpl_pack, dim3((unsigned)((L.max_steps + 15) / 16), (unsigned)L.n_waves), dim3(256), 0, st, L, d_chains, groups, (const double*)wb.cs);
+    // grid.y holds at most 65 535 workgroups (4.19 M chains): more waves than that are packed in slices
+    for (int w0 = 0; w0 < L.n_waves; w0 += 65535)
+        hipLaunchKernelGGL(k_dpl_pack, dim3((unsigned)((L.max_steps + 15) / 16), (unsigned)std::min(65535, L.n_waves - w0)), dim3(256), 0, st, L, d_chains,
+                           groups, (const double*)wb.cs, w0);
     hipLaunchKernelGGL(k_dp_lane, dim3((unsigned)L.n_waves), dim3(64), 0, st, L, d_chains, (const DpwExt*)wb.ext, d_models, buf);
+    // (the callers check hipGetLastError() once behind the launches of a device call; a launch that was refused shows up there)
 }
 
 void pga_launch_dpl_unpack(const ChainDesc* d_chains, int n_chains, const int64_t* d_chain_rec, int64_t node_begin, int64_t total, const DplDev& L,

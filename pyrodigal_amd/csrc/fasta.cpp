@@ -74,9 +74,27 @@ struct pga_fasta {
 
 // Pinning memory costs about as much as parsing into it (page by page, a few GB/s): the arenas of a closed reader go to a small
 // process-wide pool and the next reader takes them from there, so that a caller working through file after file pins once.
+// The pool is bounded by bytes (SPARE_MAX_BYTES of pinned memory at most wait there), its arenas are allocated portable -- pinned
+// for every device, whichever was current when a reader made them -- and pga_fasta_release_spare() gives them back.
 static std::mutex g_spare_mu;
 static std::vector<pga_fasta::Arena> g_spare;
+static size_t g_spare_bytes = 0;
 static const size_t SPARE_MAX = 8;
+static const size_t SPARE_MAX_BYTES = (size_t)512 << 20;
+
+// (g_spare_mu held) an arena nobody uses goes to the pool, or back to the system when the pool is full
+static void spare_put(const pga_fasta::Arena& a) {
+    if (!a.p) return;
+    if (g_spare.size() < SPARE_MAX && g_spare_bytes + a.cap <= SPARE_MAX_BYTES) { g_spare.push_back(a); g_spare_bytes += a.cap; }
+    else hipHostFree(a.p);
+}
+
+extern "C" void pga_fasta_release_spare(void) {
+    std::lock_guard<std::mutex> g(g_spare_mu);
+    for (auto& a : g_spare) hipHostFree(a.p);
+    g_spare.clear();
+    g_spare_bytes = 0;
+}
 
 // ---- stream source ------------------------------------------------------------------------------------------------------
 static bool fill(pga_fasta* f) {
@@ -225,7 +243,9 @@ static int next_mapped(pga_fasta* f, int64_t max_bases, int32_t max_records, Are
     }
     if (f->map_pos >= f->map_len) return PGA_OK;
     const char* const b0 = fb + f->map_pos;               // at a header line
-    size_t window = max_bases > 0 ? (size_t)max_bases + (size_t)max_bases / 32 + (1u << 20) : f->map_len;
+    // the window that is measured: the budget plus room for line ends and header lines, doubled below when that was not enough (no
+    // fixed floor: a caller asking for one short record at a time must not pay for a megabyte per call)
+    size_t window = max_bases > 0 ? (size_t)max_bases + (size_t)max_bases / 32 + 4096 : f->map_len;
     if (max_records > 0 && max_bases <= 0) window = std::min(window, (size_t)max_records * (1u << 16));
     for (;;) {
         const char* we = (size_t)(fe - b0) <= window ? fe : next_header(b0 + window, fe, fb);
@@ -370,10 +390,7 @@ extern "C" void pga_fasta_close(pga_fasta* f) {
     if (f->fd >= 0) close(f->fd);
     {
         std::lock_guard<std::mutex> g(g_spare_mu);
-        for (auto& a : f->arenas) {
-            if (!a.p) continue;
-            if (g_spare.size() < SPARE_MAX) g_spare.push_back(a); else hipHostFree(a.p);
-        }
+        for (auto& a : f->arenas) spare_put(a);
     }
     delete f;
 }
@@ -415,12 +432,12 @@ static char* take_arena(pga_fasta* f, size_t bytes) {
         {
             std::lock_guard<std::mutex> g(g_spare_mu);
             for (size_t k = 0; k < g_spare.size(); k++)
-                if (g_spare[k].cap >= bytes) { a = g_spare[k]; g_spare.erase(g_spare.begin() + (long)k); break; }
-            if (old.p) { if (g_spare.size() < SPARE_MAX) g_spare.push_back(old); else hipHostFree(old.p); }
+                if (g_spare[k].cap >= bytes) { a = g_spare[k]; g_spare_bytes -= a.cap; g_spare.erase(g_spare.begin() + (long)k); break; }
+            spare_put(old);
         }
         if (!a.p) {
             const size_t want = bytes + bytes / 4 + 4096;
-            if (hipHostMalloc((void**)&a.p, want, hipHostMallocDefault) != hipSuccess) { a.p = nullptr; a.cap = 0; f->err = "hipHostMalloc failed for a staging arena"; return nullptr; }
+            if (hipHostMalloc((void**)&a.p, want, hipHostMallocPortable) != hipSuccess) { a.p = nullptr; a.cap = 0; f->err = "hipHostMalloc failed for a staging arena"; return nullptr; }
             a.cap = want;
         }
     }

@@ -1192,6 +1192,11 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
     hipStream_t st = c->stream;
     const int NC = n_contigs, NM = c->n_models, NG = meta_run ? (int)f->group_tt.size() : 1;
     if (NG > 4) { c->err = "pga_find_genes: more than 4 distinct translation tables loaded"; return PGA_EINVAL; }
+    if (const char* fault = getenv("PGA_FAULT_CONTIG_LEN")) {
+        // diagnostics: a call that carries a contig of exactly this many bases fails (the host layer's error paths under test)
+        const long fl = atol(fault);
+        for (int i = 0; i < NC; i++) if ((long)batch->ct[i].len == fl) { c->err = "pga_find_genes: fault injected by PGA_FAULT_CONTIG_LEN"; return PGA_EDEVICE; }
+    }
 
     ResultOwner* R = new (std::nothrow) ResultOwner();
     if (!R) return PGA_ENOMEM;

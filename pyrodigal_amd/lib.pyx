@@ -1562,30 +1562,48 @@ cdef class GeneFinder:
             slot = self._free_slot()
             if slot is not None:
                 slot.busy = True
-        while True:
-            if slot is None:
-                req.sem.acquire()                        # blocks without the GIL until somebody signals this request
-                with lock:
-                    req.signaled = False
-                    slot = <_FinderSlot> req.lead        # the baton: a context reserved for this caller (or None: the result is there)
-                    req.lead = None
+        try:
+            while True:
                 if slot is None:
-                    if req.done:
-                        break
-                    continue
+                    req.sem.acquire()                        # blocks without the GIL until somebody signals this request
+                    with lock:
+                        req.signaled = False
+                        slot = <_FinderSlot> req.lead        # the baton: a context reserved for this caller (or None: the result is there)
+                        req.lead = None
+                    if slot is None:
+                        if req.done:
+                            break
+                        continue
+                with lock:
+                    take = self._take_pending() if self._pending else []
+                try:
+                    if take:
+                        self._run(slot, take)
+                finally:
+                    # whatever happened to this caller, the requests it took get their wake-up and the context moves on
+                    with lock:
+                        for r in take:
+                            if not r.done and r.out is None and r.error is None:
+                                r.error = RuntimeError("the device call this request rode was interrupted in another thread")
+                            r.done = True
+                            if r is not req:
+                                _signal(r)
+                        self._release_slot(slot)
+                    slot = None
+                if req.done:
+                    break
+        except BaseException:
+            # a caller interrupted while it waits (KeyboardInterrupt in `acquire`) leaves nothing behind: its request leaves the queue,
+            # a context that was handed to it in the meantime goes to the next waiting request
             with lock:
-                take = self._take_pending() if self._pending else []
-            if take:
-                self._run(slot, take)
-            with lock:
-                for r in take:
-                    r.done = True
-                    if r is not req:
-                        _signal(r)
-                self._release_slot(slot)
-            slot = None
-            if req.done:
-                break
+                if req in self._pending:
+                    self._pending.remove(req)
+                if slot is None and req.lead is not None:
+                    slot = <_FinderSlot> req.lead
+                    req.lead = None
+                if slot is not None:
+                    self._release_slot(slot)
+            raise
         if req.error is not None:
             raise req.error
         return req.out
@@ -1608,17 +1626,32 @@ cdef class GeneFinder:
         cdef list seqs = []
         for r in take:
             seqs.extend(r.seqs)
+        cdef bint translate = (<_FindRequest> take[0]).translate
+        st = self.stats
         try:
-            out = self._device_call(slot, seqs, (<_FindRequest> take[0]).translate, take)
-        except BaseException as e:
+            out = self._device_call(slot, seqs, translate, take)
+        except Exception as e:
+            if len(take) == 1:
+                (<_FindRequest> take[0]).error = e
+                return 0
+            # A device call that carries the sequences of several callers failed.  The reference's calls have private state: one
+            # caller's bad input never fails another's.  So every request rides a device call of its own now, and gets its own
+            # result or its own error.
+            st["device_calls_retried_per_request"] = st.get("device_calls_retried_per_request", 0) + 1
             for r in take:
-                r.error = e
+                try:
+                    r.out = self._device_call(slot, r.seqs, translate, [r])
+                    st["device_calls"] += 1
+                    st["sequences"] += len(r.seqs)
+                except Exception as e1:
+                    r.error = e1
             return 0
+        # (anything else -- KeyboardInterrupt, SystemExit -- is this thread being stopped: it goes up, and the caller's clean-up tells
+        #  the passengers that their device call was interrupted)
         cdef ssize_t k = 0
         for r in take:
             r.out = out[k:k + len(r.seqs)]
             k += len(r.seqs)
-        st = self.stats
         st["device_calls"] += 1
         st["sequences"] += len(seqs)
         if len(take) > st["max_calls_per_device_call"]:

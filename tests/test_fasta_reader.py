@@ -95,6 +95,24 @@ def test_missing_and_unsupported_files(tmp_path):
             read_all(str(p))
 
 
+def test_a_broken_compressed_stream_is_an_error_not_a_short_file(tmp_path):
+    """What the decompressor raises inside the read callback must reach the caller: a bz2 file cut in the middle gives a ValueError
+    whose cause is the decompressor's own exception -- not a silently truncated record set (ctypes would turn the exception into
+    "end of stream")."""
+    import bz2
+    rng = np.random.default_rng(5)
+    text = b"".join(b">r%d some words\n%s\n" % (k, bytes(rng.choice(list(b"ACGT"), 5000).astype(np.uint8))) for k in range(400))
+    whole = bz2.compress(text)
+    good = tmp_path / "good.fa.bz2"
+    good.write_bytes(whole)
+    assert len(read_all(str(good))) == 400
+    cut = tmp_path / "cut.fa.bz2"
+    cut.write_bytes(whole[:len(whole) // 2])
+    with pytest.raises(ValueError) as info:
+        read_all(str(cut))
+    assert isinstance(info.value.__cause__, (EOFError, OSError))
+
+
 @pytest.mark.gpu
 def test_packed_batches_hold_the_same_records(tmp_path):
     """pga_fasta_next_packed (pinned staging arenas): same records, from the mapped and from the stream source."""

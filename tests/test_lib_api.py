@@ -342,6 +342,44 @@ def test_thread_pool_of_find_genes_calls_rides_the_batch_path(lib):
 
 
 @pytest.mark.gpu
+def test_a_failing_device_call_only_fails_the_request_that_caused_it(lib, monkeypatch):
+    """Waiting `find_genes` calls ride one device call.  When that call fails, every request is retried in a device call of its own:
+    the caller whose input made it fail gets the error, the others get their genes -- the reference's calls have private state and
+    never fail each other (ref: lib.pyx:5400-5469).  The failure is injected by contig length (PGA_FAULT_CONTIG_LEN)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from pyrodigal_amd import benchdata
+    models = benchdata.load_model_set()
+    bins = lib.MetagenomicBins([lib.MetagenomicBin(lib.TrainingInfo(raw=b), n) for n, b in models])
+    seqs = [benchdata.synthetic_contig(12_000 + 10 * k, 0.35 + 0.3 * (k % 11) / 10, 7000 + k) for k in range(400)]
+    bad = {37, 151, 152, 390}
+    for k in bad:
+        seqs[k] = seqs[k][:11_111]
+    ref = lib.GeneFinder(meta=True, metagenomic_bins=bins, keep_nodes=False)
+    want = [[(g.begin, g.end, g.strand) for g in genes] for genes in ref.find_genes_batch(seqs)]
+    monkeypatch.setenv("PGA_FAULT_CONTIG_LEN", "11111")
+    finder = lib.GeneFinder(meta=True, metagenomic_bins=bins, keep_nodes=False)
+
+    def call(k):
+        try:
+            return [(g.begin, g.end, g.strand) for g in finder.find_genes(seqs[k])]
+        except RuntimeError as e:
+            return str(e)
+
+    with ThreadPoolExecutor(32) as ex:
+        got = list(ex.map(call, range(len(seqs))))
+    for k, g in enumerate(got):
+        if k in bad:
+            assert isinstance(g, str) and "PGA_FAULT_CONTIG_LEN" in g, (k, g)
+        else:
+            assert g == want[k], k
+    st = finder.stats
+    assert st["max_calls_per_device_call"] > 1 and st.get("device_calls_retried_per_request", 0) >= 1, st
+    # the finder is as good as new afterwards
+    monkeypatch.delenv("PGA_FAULT_CONTIG_LEN")
+    assert [(g.begin, g.end, g.strand) for g in finder.find_genes(seqs[37])] == want[37]
+
+
+@pytest.mark.gpu
 def test_reference_edge_cases_through_the_api(lib):
     """ref: tests/test_gene_finder.py:198-234 (TestMeta.test_overflow / test_short_sequences / test_empty_sequence) and 366-387 (the
     same in single mode).  The reference runs them with Prodigal's built-in bins, which are not available offline: here the same
