@@ -85,6 +85,7 @@ private:
 };
 
 struct FinderState {
+    bool stage_full = false;        // a batch of this context did not fit the half-density staging of the extraction: full staging from then on
     LastRun last;
     WorkerPool pool;
     std::map<std::string, Buf> dev, pin;
@@ -125,7 +126,8 @@ int ensure_dev(pga_ctx* c, const char* name, size_t bytes, void** out) {
     Buf& b = c->finder->dev[name];
     if (b.cap < bytes || !b.p) {
         if (b.p) { hipFree(b.p); b.p = nullptr; b.cap = 0; }
-        size_t want = bytes + bytes / 4 + 256;
+        // room to grow: the calls of a job are about the same size, so the big buffers get a sixteenth on top, the small ones a quarter
+        size_t want = bytes + (bytes >= ((size_t)64 << 20) ? bytes / 16 : bytes / 4) + 256;
         HT(c, hipMalloc(&b.p, want));
         b.cap = want;
     }
@@ -849,6 +851,14 @@ void fill_model_score_const(ModelScoreConst* m, const pga_training* t) {   // re
 
 void pga_finder_release(pga_ctx* c) {
     if (!c->finder) return;
+    if (getenv("PGA_PRINT_BUFFERS")) {
+        // diagnostics: what this context held on the device, largest first
+        std::vector<std::pair<size_t, std::string>> v; size_t tot = 0;
+        for (auto& kv : c->finder->dev) if (kv.second.p) { v.push_back({kv.second.cap, kv.first}); tot += kv.second.cap; }
+        std::sort(v.begin(), v.end(), [](const std::pair<size_t, std::string>& a, const std::pair<size_t, std::string>& b) { return a.first > b.first; });
+        fprintf(stderr, "[pga] context buffers: %.2f GB in %zu allocations\n", tot / 1e9, v.size());
+        for (size_t k = 0; k < v.size() && k < 48; k++) fprintf(stderr, "[pga]   %-22s %9.1f MB\n", v[k].second.c_str(), v[k].first / 1e6);
+    }
     for (auto& kv : c->finder->dev) if (kv.second.p) hipFree(kv.second.p);
     for (auto& kv : c->finder->pin) if (kv.second.p) hipHostFree(kv.second.p);
     if (c->finder->d_msc) hipFree(c->finder->d_msc);
@@ -1237,7 +1247,6 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
 #define GBUF(field, type, count) { snprintf(nm, sizeof nm, #field "%d", g); void* p__; int rc__ = ensure_dev(c, nm, sizeof(type) * (size_t)(count) + 64, &p__); if (rc__) return rc__; ga[g].field = (type*)p__; }
             GBUF(df, uint8_t, total + 16)
             GBUF(pre, int32_t, total + 2)
-            GBUF(st_ndx, int32_t, 2 * total + 2) GBUF(st_sv, int32_t, 2 * total + 2) GBUF(st_info, uint8_t, 2 * total + 2)
             ga[g].ndx = nullptr; ga[g].stop_val = nullptr; ga[g].type = nullptr; ga[g].strand = nullptr; ga[g].edge0 = nullptr; ga[g].gc_cont = nullptr;
         }
 
@@ -1290,18 +1299,39 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             pga_launch_group_enable(d_ct, NC, d_cnt, f->d_model_gc, f->d_model_grp, NM, NG, d_enabled, st);
             HT(c, hipMemcpyAsync(h_enabled, d_enabled, (size_t)NG * NC, hipMemcpyDeviceToHost, st));
         }
-        for (int g = 0; g < NG; g++) {
-            const int tt = meta_run ? f->group_tt[g] : (stage == PGA_STAGE_EXTRACT ? tt_override : c->models[0].trans_table);
-            pga_launch_extract(d_dig, total, d_ct, NC, tt, P, ga[g], batch->d_tiles, batch->n_tiles, batch->d_tile0, d_tile_first, d_tile_last,
-                               d_tile_count + (size_t)g * (batch->n_tiles + 1), d_tile_off + (size_t)g * (batch->n_tiles + 1), d_cbase + (size_t)g * (NC + 1),
-                               d_tile_scount + (size_t)g * (batch->n_tiles + 1), d_tile_soff + (size_t)g * (batch->n_tiles + 1), d_sbase + (size_t)g * (NC + 1),
-                               masks, st, (meta_run && NM > 0) ? d_enabled + (size_t)g * NC : nullptr);
+        // Staging of the extraction: one slot per two positions of a tile (sequence has a node every 25 positions or so; the full
+        // two-slots-per-position staging was half of a context's memory).  A tile that does not fit raises a flag, the batch is then
+        // extracted again with full staging, and the context keeps that (PGA_STAGE_FULL=1: from the start).
+        DEVBUF(d_st_overflow, int32_t, "d_st_overflow", 4);
+        PINBUF(h_st_overflow, int32_t, "h_st_overflow", 4);
+        if (getenv("PGA_STAGE_FULL")) f->stage_full = true;
+        for (;;) {
+            const bool half = !f->stage_full;
+            // (PGA_STAGE_SHIFT=5: one slot per 32 positions, so that ordinary sequence overflows and the tests see the second pass)
+            const int shift = half ? std::max(1, std::min(8, getenv("PGA_STAGE_SHIFT") ? atoi(getenv("PGA_STAGE_SHIFT")) : 1)) : 0;
+            const int64_t st_slots = half ? (total >> shift) + 8 : 2 * total + 2;
+            for (int g = 0; g < NG; g++) {
+                char nm[32];
+                GBUF(st_ndx, int32_t, st_slots) GBUF(st_sv, int32_t, st_slots) GBUF(st_info, uint8_t, st_slots)
+                ga[g].st_half = shift; ga[g].st_overflow = d_st_overflow;
+            }
+            HT(c, hipMemsetAsync(d_st_overflow, 0, sizeof(int32_t), st));
+            for (int g = 0; g < NG; g++) {
+                const int tt = meta_run ? f->group_tt[g] : (stage == PGA_STAGE_EXTRACT ? tt_override : c->models[0].trans_table);
+                pga_launch_extract(d_dig, total, d_ct, NC, tt, P, ga[g], batch->d_tiles, batch->n_tiles, batch->d_tile0, d_tile_first, d_tile_last,
+                                   d_tile_count + (size_t)g * (batch->n_tiles + 1), d_tile_off + (size_t)g * (batch->n_tiles + 1), d_cbase + (size_t)g * (NC + 1),
+                                   d_tile_scount + (size_t)g * (batch->n_tiles + 1), d_tile_soff + (size_t)g * (batch->n_tiles + 1), d_sbase + (size_t)g * (NC + 1),
+                                   masks, st, (meta_run && NM > 0) ? d_enabled + (size_t)g * NC : nullptr);
+            }
+            HT(c, hipMemcpyAsync(h_st_overflow, d_st_overflow, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HT(c, hipMemcpyAsync(h_cnt, d_cnt, sizeof(int32_t) * 2 * (size_t)NC, hipMemcpyDeviceToHost, st));
+            HT(c, hipMemcpyAsync(h_cbase, d_cbase, sizeof(int32_t) * (size_t)NG * (NC + 1), hipMemcpyDeviceToHost, st));
+            HT(c, hipMemcpyAsync(h_sbase, d_sbase, sizeof(int32_t) * (size_t)NG * (NC + 1), hipMemcpyDeviceToHost, st));
+            HT(c, hipGetLastError());
+            HT(c, hipStreamSynchronize(st));
+            if (!half || h_st_overflow[0] == 0) break;
+            f->stage_full = true;
         }
-        HT(c, hipMemcpyAsync(h_cnt, d_cnt, sizeof(int32_t) * 2 * (size_t)NC, hipMemcpyDeviceToHost, st));
-        HT(c, hipMemcpyAsync(h_cbase, d_cbase, sizeof(int32_t) * (size_t)NG * (NC + 1), hipMemcpyDeviceToHost, st));
-        HT(c, hipMemcpyAsync(h_sbase, d_sbase, sizeof(int32_t) * (size_t)NG * (NC + 1), hipMemcpyDeviceToHost, st));
-        HT(c, hipGetLastError());
-        HT(c, hipStreamSynchronize(st));
 
         tm.mark("extract+sync");
         // ---- plan the (contig, model) chains (ref: lib.pyx:5335-5362) ------------------------
@@ -1410,8 +1440,11 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
 #define WBUF(field, type) { snprintf(nm, sizeof nm, "dpw_" #field "%d", g); void* p__; int rc__ = ensure_dev(c, nm, sizeof(type) * (size_t)n + 64, &p__); if (rc__) return rc__; wgroups.g[g].field = (type*)p__; }
                 WBUF(kf, uint8_t) WBUF(lo, int32_t) WBUF(q1, int32_t) WBUF(q2, int32_t)
 #undef WBUF
-                { snprintf(nm, sizeof nm, "dpw_tp%d", g); void* p__; int rc__ = ensure_dev(c, nm, sizeof(int4) * 2 * (size_t)n + 64, &p__); if (rc__) return rc__; wgroups.g[g].tp = (int4*)p__; }
-                { snprintf(nm, sizeof nm, "dpw_prog%d", g); void* p__; int rc__ = ensure_dev(c, nm, sizeof(int4) * 4 * (size_t)n + 64, &p__); if (rc__) return rc__; wgroups.g[g].prog = (int4*)p__; }
+                wgroups.g[g].tp = nullptr; wgroups.g[g].prog = nullptr;
+                if (pga_dp_use_contig(NCH)) {       // the packed topology and the compiled records of the contig-per-wavefront scorer (opt-in)
+                    { snprintf(nm, sizeof nm, "dpw_tp%d", g); void* p__; int rc__ = ensure_dev(c, nm, sizeof(int4) * 2 * (size_t)n + 64, &p__); if (rc__) return rc__; wgroups.g[g].tp = (int4*)p__; }
+                    { snprintf(nm, sizeof nm, "dpw_prog%d", g); void* p__; int rc__ = ensure_dev(c, nm, sizeof(int4) * 4 * (size_t)n + 64, &p__); if (rc__) return rc__; wgroups.g[g].prog = (int4*)p__; }
+                }
                 wgroups.g[g].ndx = ga[g].ndx; wgroups.g[g].stop_val = ga[g].stop_val; wgroups.g[g].srank = ga[g].srank;
             }
             DEVBUF(w0, double, "dpw_cs", dp_cap + 2) DEVBUF(w1, DpwExt, "dpw_ext", tot_chain_stops + 4)      /* one extras record per (chain, stop node) pair */ DEVBUF(w2, double, "dpw_sfxv", dp_cap) DEVBUF(w3, int32_t, "dpw_sfxi", dp_cap)
@@ -1911,16 +1944,18 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                     int levels = 1;
                     while ((1ll << levels) < max_n) levels++;
                     const unsigned nblk = (unsigned)((out_nodes + 255) / 256);
-                    DEVBUF(tp_seg, TpSeg, "tp_seg", segs.size()) DEVBUF(tp_up, int32_t, "tp_up", (size_t)2 * out_nodes)
-                    DEVBUF(tp_mark, uint8_t, "tp_mark", out_nodes) DEVBUF(tp_slots, int32_t, "tp_slots", out_nodes)
-                    DEVBUF(tp_ins, int32_t, "tp_ins", 2 * out_nodes) DEVBUF(tp_excl, int32_t, "tp_excl", out_nodes + 1)
+                    const bool tp_steps = getenv("PGA_TP_STEPS") != nullptr;      // the many-launch form also for short chains (cross-check)
+                    const bool tp_one = max_n <= TP_SMALL_MAX && !tp_steps;
+                    const int64_t tpn = tp_one ? 0 : out_nodes;                   // the per-node work arrays of the many-launch form
+                    DEVBUF(tp_seg, TpSeg, "tp_seg", segs.size()) DEVBUF(tp_up, int32_t, "tp_up", (size_t)2 * tpn)
+                    DEVBUF(tp_mark, uint8_t, "tp_mark", tpn) DEVBUF(tp_slots, int32_t, "tp_slots", tpn)
+                    DEVBUF(tp_ins, int32_t, "tp_ins", 2 * tpn) DEVBUF(tp_excl, int32_t, "tp_excl", tpn + 1)
                     DEVBUF(tp_bsum, int32_t, "tp_bsum", nblk + 1) DEVBUF(tp_cnt, int32_t, "tp_cnt", segs.size())
                     HT(c, hipMemcpyAsync(tp_seg, segs.data(), sizeof(TpSeg) * segs.size(), hipMemcpyHostToDevice, st));
-                    HT(c, hipMemsetAsync(tp_cnt, 0, sizeof(int32_t) * segs.size(), st));
+                    if (!tp_one) HT(c, hipMemsetAsync(tp_cnt, 0, sizeof(int32_t) * segs.size(), st));
                     const TpWork tw{tp_seg, (int)segs.size(), out_nodes, levels, tp_up, tp_mark, tp_slots, tp_ins, tp_excl, tp_bsum, tp_cnt};
                     const dim3 grid(nblk), blk(256);
-                    const bool tp_steps = getenv("PGA_TP_STEPS") != nullptr;      // the many-launch form also for short chains (cross-check)
-                    if (max_n <= TP_SMALL_MAX && !tp_steps) {
+                    if (tp_one) {
                         const int cap = (int)((max_n + 63) & ~63ll);
                         hipLaunchKernelGGL(k_tp_small, dim3((unsigned)segs.size()), dim3(max_n <= 2048 ? 64 : 256), sizeof(int32_t) * 3 * (size_t)cap, st, tw, d_td, o,
                                            d_tracef, d_elim, d_gene0, d_ngenes, cap);

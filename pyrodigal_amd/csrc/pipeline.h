@@ -23,9 +23,13 @@ struct GroupArrays {
                                              // (written densely by the tile that owns the position): all an ORF walk reads of a position is one byte
     int32_t* pre;                            // at a position with a node: the index of its first node (the forward one when both strands have
                                              // one there: the reverse node then is the next, ref: lib.pyx:2489-2493)
-    // staging, two slots per position: the nodes of the tile that starts at global position g, packed in order from slot 2 g
+    // staging: the nodes of the tile that starts at global position g, packed in order from slot 2 g (two slots per position: every
+    // position can hold a node on either strand) -- or, st_half = s > 0, from slot g >> s with room for one node per 2^s positions
+    // of the tile (s = 1 in production: sequence has a node every 25 positions or so, periodic worst cases reach one in two); a
+    // tile that does not fit says so in *st_overflow and the caller extracts again with the full staging
     int32_t* st_ndx; int32_t* st_sv;         // ndx, stop_val
     uint8_t* st_info;                        // type | edge << 2 | reverse << 3
+    int32_t st_half = 0; int32_t* st_overflow = nullptr;
     int32_t* stop_list;                      // the stop nodes of the group in node order (node indices); contig c owns [sbase[c], sbase[c + 1])
     uint32_t* ovl_topo;                      // per entry of stop_list: which of its first 16 neighbours can be overlapping starts (k_ovl_topo)
     int32_t* srank = nullptr;                // per node, written for stop nodes only: its rank among the stop nodes of its contig (k_ovl_topo):

@@ -581,7 +581,11 @@ k_extract_tile(const uint8_t* __restrict__ dig, int64_t total, const ContigDesc*
             for (int k = 0; k < nk; k++) ga.df[g0 + r0 + k] = (uint8_t)((dig[g0 + r0 + k] & 7u) | (((nf >> k) & 1u) << 4) | (((nr >> k) & 1u) << 5));
         }
     }
-    int64_t slot = 2 * g0 + nbase;
+    const int64_t stage0 = ga.st_half ? (g0 >> ga.st_half) : 2 * g0;
+    const int room = ga.st_half ? (G.len >> ga.st_half) : 2 * G.len;   // staging slots of the tile
+    if (t == 255 && nbase + cnt > room) atomicOr(ga.st_overflow, 1);   // (only with st_half) the caller extracts again, full staging
+    int64_t slot = stage0 + nbase;
+    const int64_t slot_end = stage0 + room;
     unsigned both = nf | nr;
     int n_stop = 0;
     while (both) {
@@ -589,11 +593,13 @@ k_extract_tile(const uint8_t* __restrict__ dig, int64_t total, const ContigDesc*
         both &= both - 1u;
         if ((nf >> k) & 1u) {
             const int info = (int)((inf_f >> (4 * k)) & 7);
-            ga.st_ndx[slot] = G.a + r0 + k; ga.st_sv[slot] = S.sv[0][k][t]; ga.st_info[slot] = (uint8_t)info; slot++; n_stop += (info & 3) == PGA_T_STOP;
+            if (slot < slot_end) { ga.st_ndx[slot] = G.a + r0 + k; ga.st_sv[slot] = S.sv[0][k][t]; ga.st_info[slot] = (uint8_t)info; }
+            slot++; n_stop += (info & 3) == PGA_T_STOP;
         }
         if ((nr >> k) & 1u) {
             const int info = (int)((inf_r >> (4 * k)) & 7);
-            ga.st_ndx[slot] = G.a + r0 + k; ga.st_sv[slot] = S.sv[1][k][t]; ga.st_info[slot] = (uint8_t)(info | 8); slot++; n_stop += (info & 3) == PGA_T_STOP;
+            if (slot < slot_end) { ga.st_ndx[slot] = G.a + r0 + k; ga.st_sv[slot] = S.sv[1][k][t]; ga.st_info[slot] = (uint8_t)(info | 8); }
+            slot++; n_stop += (info & 3) == PGA_T_STOP;
         }
     }
 #pragma unroll
@@ -676,7 +682,7 @@ k_place_nodes(const ContigDesc* __restrict__ ct, const TileDesc* __restrict__ ti
     const int off = tile_off[blockIdx.x], cnt = tile_off[blockIdx.x + 1] - off;
     if (cnt <= 0) return;
     const int64_t base = ct[td.contig].base;
-    const int64_t s0 = 2 * (base + td.start);
+    const int64_t s0 = ga.st_half ? ((base + td.start) >> ga.st_half) : 2 * (base + td.start);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int srun = tile_soff[blockIdx.x];                       // next free entry of the stop list
     for (int j0 = 0; j0 < cnt; j0 += 128) {

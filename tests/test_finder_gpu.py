@@ -206,3 +206,33 @@ def test_connection_scoring_kernels_inside_the_finder(ctx, models, kernel, monke
     ctx.set_models([models[2].buf])
     res = ctx.find_genes_batch(seqs, meta=False, want_nodes=True)          # single mode keeps the DP pass's node fields
     assert sum(compare_contig(res, i, s, orc.Oracle(s), [models[2]], meta=False) for i, s in enumerate(seqs)) > 100
+
+
+def test_extraction_staging_overflow_takes_the_full_staging(models, monkeypatch):
+    """The extraction stages the nodes of a tile in one slot per two positions and extracts again with two slots per position when
+    a tile does not fit (GroupArrays::st_half).  Same results from the default, from a staging so small that ordinary sequence
+    overflows it (PGA_STAGE_SHIFT=5: the second pass runs), and from full staging from the start; the node-densest periodic
+    sequences (one node per two positions) go through the default."""
+    from pyrodigal_amd import _cabi
+    seqs = [synthetic_contig(20000 + 997 * c, 0.30 + 0.40 * (c % 41) / 40, 20000 + c) for c in range(24)]
+    seqs += [(b"TGCA" * 4000)[:15000], (b"CATG" * 3000)[:9001], (b"CATGTG" * 2000)[:9000], b"TGCA" * 20]
+    results = {}
+    for mode, env in (("default", {}), ("tiny", {"PGA_STAGE_SHIFT": "5"}), ("full", {"PGA_STAGE_FULL": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = _cabi.Context(0)
+        c.set_models([m.buf for m in models])
+        results[mode] = [c.find_genes_batch(seqs, meta=True, want_nodes=True) for _ in range(2)]      # the second call: the context's sticky choice
+        c.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    ref = results["full"][0]
+    for i, s in enumerate(seqs):
+        compare_contig(ref, i, s, orc.Oracle(s), models, meta=True)
+    for mode in ("default", "tiny"):
+        for r in results[mode]:
+            assert r.genes.tobytes() == ref.genes.tobytes(), mode
+            assert np.array_equal(r.contigs["model"], ref.contigs["model"]) and np.array_equal(r.contigs["n_nodes"], ref.contigs["n_nodes"]), mode
+            for i in range(len(seqs)):
+                for k in ("ndx", "stop_val", "type", "strand"):
+                    assert np.array_equal(r.nodes[i][k], ref.nodes[i][k]), (mode, i, k)
