@@ -1522,15 +1522,17 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             const int nch = g_c0[g + 1] - g_c0[g];
             const int64_t nn = g_n0[g + 1] - g_n0[g];
             if (nch == 0 || nn == 0 || stage == PGA_STAGE_EXTRACT) continue;
-            // many nodes: the ORF walks of the coding score run from hexamer tables in LDS, contigs bucketed by the
-            // four table columns they need (PGA_CS_LDS=0: the global-memory form)
+            // the ORF walks of the coding score run from hexamer tables in LDS, contigs bucketed by the four table columns they need
+            // (PGA_CS_LDS=0: the global-memory form)
             const void* d_cs_tasks = nullptr; const void* d_cs_entries = nullptr; int n_cs_tasks = 0;
             const char* cs_env = getenv("PGA_CS_LDS");
             const char* cs_tn = getenv("PGA_CS_TASK_NODES");
             const int cs_task_nodes = cs_tn && atoi(cs_tn) >= 256 && atoi(cs_tn) <= 8192 ? atoi(cs_tn) : 4096;     // several tasks per CU and launch
             // PGA_CS_LDS=2 (tests): the LDS form whatever the size of the launch
             // (single mode as well: one table column, a genome is cut into tasks of `cs_task_nodes` nodes)
-            if ((nn >= 65536 || (cs_env && atoi(cs_env) == 2)) && !(cs_env && atoi(cs_env) == 0) && !f->gil_stride.empty()) {
+            // (the global-memory form walks every ORF on one lane through the texture path: a launch takes as long as its longest ORF,
+            //  a few hundred microseconds on high-GC sequence whatever its size -- so small launches take the LDS form as well)
+            if (!(cs_env && atoi(cs_env) == 0) && !f->gil_stride.empty()) {
                 std::vector<int32_t>& tk = cs_tk[g]; std::vector<int32_t>& en = cs_en[g];     // alive until the stream is synchronized
                 if (pga_cs_tasks(h_cc + (size_t)g * NC, NC, chains.data(), h_cbase + (size_t)g * (NC + 1), f->model_rank.data(), cs_task_nodes, tk, en) && !tk.empty()) {
                     char nm1[32], nm2[32];

@@ -52,6 +52,8 @@ def test_dp_kernels_and_tails_agree_on_random_gene_dense_contigs(monkeypatch):
                       # scorer, the lane-per-chain connection scorer and the LDS-table form of the coding score
                       ("wave+ldscs", {"PGA_DP_KERNEL": "wave", "PGA_CS_LDS": "2"}), ("lane+ldscs", {"PGA_DP_KERNEL": "lane", "PGA_CS_LDS": "2"}),
                       ("contig+ldscs", {"PGA_DP_KERNEL": "contig", "PGA_CS_LDS": "2"}),
+                      # the coding score by per-lane table gathers (the fallback when a contig's models are not neighbours in the table)
+                      ("tree+globalcs", {"PGA_CS_LDS": "0"}), ("scan+globalcs", {"PGA_DP_KERNEL": "scan", "PGA_TAIL": "host", "PGA_CS_LDS": "0"}),
                       # the start scorer walking a workgroup's models three to a pass (its path for more than 512 models)
                       ("tree+3models/pass", {"PGA_SS_MODELS_PER_PASS": "3"})):
         for k in ("PGA_DP_KERNEL", "PGA_TAIL", "PGA_CS_LDS", "PGA_SS_MODELS_PER_PASS"):
@@ -82,8 +84,8 @@ def test_dp_kernels_and_tails_agree_on_random_gene_dense_contigs(monkeypatch):
     monkeypatch.setenv("PGA_DP_KERNEL", "scan"); monkeypatch.setenv("PGA_TAIL", "host")
     s2 = ctx.find_genes_batch(seqs, meta=False, mask=True, closed=True)
     assert s1.genes.tobytes() == s2.genes.tobytes() and len(s1.genes) > 500
-    # ... and with the LDS-table form of the coding score (what a single-mode genome of more than 65 536 nodes runs)
-    monkeypatch.delenv("PGA_DP_KERNEL"); monkeypatch.delenv("PGA_TAIL"); monkeypatch.setenv("PGA_CS_LDS", "2")
+    # ... and with the other form of the coding score (per-lane table gathers)
+    monkeypatch.delenv("PGA_DP_KERNEL"); monkeypatch.delenv("PGA_TAIL"); monkeypatch.setenv("PGA_CS_LDS", "0")
     s3 = ctx.find_genes_batch(seqs, meta=False, mask=True, closed=True)
     monkeypatch.delenv("PGA_CS_LDS")
     assert s3.genes.tobytes() == s1.genes.tobytes()
