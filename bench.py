@@ -173,7 +173,7 @@ def main():
     ap.add_argument("--workload", default="config4", choices=["config4", "config3", "config2", "config5"])
     ap.add_argument("--contigs", type=int, default=100_000, help="config4: contigs of the whole job")
     ap.add_argument("--sub-batch", type=int, default=6_250, help="contigs per device call")
-    ap.add_argument("--contexts", type=int, default=12, help="device contexts (streams) the calls of a pass are dealt to")
+    ap.add_argument("--contexts", type=int, default=8, help="device contexts (streams) the calls of a pass are dealt to")
     ap.add_argument("--gen-procs", type=int, default=0, help="worker processes generating the synthetic contigs (0: up to 32; 1: none, e.g. under rocprofv3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")

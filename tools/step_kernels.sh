@@ -1,8 +1,8 @@
 #!/bin/bash
 # every kernel of ONE device call of the config 4 job (6 250 contigs, one context), in launch order with its duration:
-#   gpurun -- 'bash tools/step_kernels.sh tag'   ->  gpurun_out/sk_<tag>/step.txt
-TAG=${1:-q}; REPO=$(pwd); OUT=$REPO/gpurun_out/sk_$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
-( cd /tmp && timeout -k 5 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -o t -- python "$REPO/bench.py" --workload config4 --contigs 6250 \
+#   gpurun -- 'bash tools/step_kernels.sh tag [config4|config2|config3|config5]'   ->  gpurun_out/sk_<tag>/step.txt
+TAG=${1:-q}; WL=${2:-config4}; REPO=$(pwd); OUT=$REPO/gpurun_out/sk_$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
+( cd /tmp && timeout -k 5 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -o t -- python "$REPO/bench.py" --workload $WL --contigs 6250 \
     --no-cpu-baseline --no-secondary --contexts 1 --gen-procs 1 --steps 3 --warmup 1 > "$OUT/bench.json" 2> "$OUT/log.txt" )
 python - <<PY
 import csv, glob, re
