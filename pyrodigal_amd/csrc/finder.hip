@@ -406,6 +406,7 @@ struct TailDesc {          // one per contig
     // two nodes of a gene from there when the winners were gathered without them)
     int64_t fin_off, topo_off;
     int32_t group, _pad;
+    int64_t dp_off;        // the winning pass's chain offset (what the connection scoring saw)
 };
 // ---- gather kernel: pack the winning chains' node fields contiguously for one D2H per field ----
 struct WinDesc {
@@ -424,6 +425,13 @@ struct OutArrays {
     int32_t* star_ptr; int32_t* traceb; int8_t* ov_mark; double* score;
     uint8_t* edge; double* cscore; double* sscore; double* rscore; double* uscore; double* tscore; double* mot_score;
     int32_t* mot_ndx; uint8_t* rbs; uint8_t* mot_len; uint8_t* mot_spacer; uint8_t* mot_spacendx;
+    // direct != 0 (nobody reads the node arrays after the call): only the fields the tail WRITES -- sscore_dp, traceb, ov_mark -- are
+    // gathered; what it only reads stays where the scorers left it: the topology of the contig's group at TailDesc::topo_off, the
+    // DP pass's node fields and scores at TailDesc::dp_off
+    int32_t direct;
+    const int32_t* g_ndx[4]; const int32_t* g_stop_val[4]; const uint8_t* g_type[4]; const int8_t* g_strand[4];
+    const uint8_t* c_edge; const double* c_cscore; const double* c_rscore; const double* c_uscore; const double* c_tscore;
+    const int32_t* c_star_ptr; const double* d_score;
 };
 
 __global__ void __launch_bounds__(256)
@@ -444,6 +452,7 @@ k_gather_winners(const WinDesc* __restrict__ wd, int n_win, int64_t out_begin, i
     const WinDesc w = wd[lo];
     const int i = (int)(g - w.out_off);
     const int64_t t = w.topo_off + i, a = w.dp_off + i, f = w.fin_off + i;
+    if (o.direct) { o.sscore_dp[g] = ca.sscore[a]; o.traceb[g] = dp.traceb[a]; o.ov_mark[g] = dp.ov_mark[a]; return; }
     o.ndx[g] = ga.ndx[t]; o.stop_val[g] = ga.stop_val[t]; o.type[g] = ga.type[t]; o.strand[g] = ga.strand[t];
     o.edge_dp[g] = ca.edge[a]; o.cscore_dp[g] = ca.cscore[a]; o.sscore_dp[g] = ca.sscore[a]; o.rscore_dp[g] = ca.rscore[a];
     o.uscore_dp[g] = ca.uscore[a]; o.tscore_dp[g] = ca.tscore[a];
@@ -484,6 +493,12 @@ k_gather_gene_nodes(const int64_t* __restrict__ idx, int n, OutArrays o, GeneNod
 
 __device__ inline NodeView node_view(const TailDesc& d, const OutArrays& o, int32_t* tracef, uint8_t* elim) {
     const int64_t oo = d.out_off;
+    if (o.direct) {
+        const int64_t t = d.topo_off, a = d.dp_off; const int g = d.group;
+        return NodeView{d.n, o.g_ndx[g] + t, o.g_stop_val[g] + t, o.g_type[g] + t, o.g_strand[g] + t, o.c_edge + a,
+                        const_cast<double*>(o.c_cscore) + a, o.sscore_dp + oo, o.c_rscore + a, o.c_uscore + a, o.c_tscore + a,
+                        o.c_star_ptr + 3 * a, o.traceb + oo, tracef + oo, o.ov_mark + oo, o.d_score + a, elim + oo};
+    }
     return NodeView{d.n, o.ndx + oo, o.stop_val + oo, o.type + oo, o.strand + oo, o.edge_dp + oo,
                     o.cscore_dp + oo, o.sscore_dp + oo, o.rscore_dp + oo, o.uscore_dp + oo, o.tscore_dp + oo,
                     o.star_ptr + 3 * oo, o.traceb + oo, tracef + oo, o.ov_mark + oo, o.score + oo, elim + oo};
@@ -768,6 +783,23 @@ k_emit_genes(const TailDesc* __restrict__ td, int n_contigs, int64_t n_slots, Ou
     pga_gene G;
     memset(&G, 0, sizeof G);
     G.contig = c; G.begin = gr.begin; G.end = gr.end; G.start_ndx = gr.start_ndx; G.stop_ndx = gr.stop_ndx;
+    if (o.direct) {
+        // (lean as well) the DP pass's read-only fields were not gathered either
+        const int64_t ts = d.topo_off + gr.start_ndx, as = d.dp_off + gr.start_ndx, ae = d.dp_off + gr.stop_ndx;
+        const int64_t fs = d.fin_off + gr.start_ndx, fe = d.fin_off + gr.stop_ndx;
+        G.strand = o.g_strand[d.group][ts];
+        const uint8_t se = single ? o.c_edge[as] : ca.edge[fs], ee = single ? o.c_edge[ae] : ca.edge[fe];
+        G.partial_begin = G.strand == 1 ? se : ee; G.partial_end = G.strand == 1 ? ee : se;
+        G.start_type = se ? 3 : o.g_type[d.group][ts];
+        G.rbs[0] = ca.rbs[2 * fs]; G.rbs[1] = ca.rbs[2 * fs + 1];
+        G.mot_len = ca.mot_len[fs]; G.mot_spacer = ca.mot_spacer[fs]; G.mot_ndx = ca.mot_ndx[fs]; G.mot_score = ca.mot_score[fs];
+        G.gc_cont = gcs.p[d.group][ts];
+        G.cscore = single ? o.c_cscore[as] : ca.cscore[fs]; G.sscore = single ? o.sscore_dp[sn] : ca.sscore[fs];
+        G.rscore = single ? o.c_rscore[as] : ca.rscore[fs]; G.uscore = single ? o.c_uscore[as] : ca.uscore[fs];
+        G.tscore = single ? o.c_tscore[as] : ca.tscore[fs];
+        out[gene_begin[c] + g] = G;
+        return;
+    }
     G.strand = o.strand[sn];
     // single mode keeps the nodes of the DP pass (ref: lib.pyx:5296-5311); meta mode re-scores (5380-5394)
     if (lean) {
@@ -1760,6 +1792,16 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             OB(edge, uint8_t) OB(cscore, double) OB(sscore, double) OB(rscore, double) OB(uscore, double) OB(tscore, double) OB(mot_score, double)
             OB(mot_ndx, int32_t) OB(rbs, uint8_t) OB(mot_len, uint8_t) OB(mot_spacer, uint8_t) OB(mot_spacendx, uint8_t)
         }
+        // lean, the device tail, and no lane kernel (its results sit in interleaved records): gather only what the tail writes
+        o.direct = (lean_gather && !use_lane && !getenv("PGA_GATHER_ALL_DP")) ? 1 : 0;
+        for (int g = 0; g < 4; g++) {
+            const bool in = g < NG;
+            o.g_ndx[g] = in ? ga[g].ndx : nullptr; o.g_stop_val[g] = in ? ga[g].stop_val : nullptr;
+            o.g_type[g] = in ? ga[g].type : nullptr; o.g_strand[g] = in ? ga[g].strand : nullptr;
+        }
+        o.c_edge = ca.edge; o.c_cscore = ca.cscore; o.c_rscore = ca.rscore; o.c_uscore = ca.uscore; o.c_tscore = ca.tscore;
+        o.c_star_ptr = ca.star_ptr; o.d_score = dp.score;
+        h.direct = 0;
         size_t nwin = 0; for (int g = 0; g < NG; g++) nwin += wg[g].size();
         DEVBUF(d_win, WinDesc, "d_win", nwin + 1);
         {
@@ -1916,6 +1958,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                 d.st_wt = k >= 0 ? c->models[chains[k].model].st_wt : 0.0;
                 d.fin_off = k >= 0 ? fin_off[i] : 0; d.topo_off = k >= 0 ? chains[k].topo_off : 0;
                 d.group = k >= 0 && P.meta ? f->model_group[chains[k].model] : 0; d._pad = 0;
+                d.dp_off = k >= 0 ? chains[k].off : 0;
                 n_slots += d.n / 2 + 2;
             }
             DEVBUF(d_td, TailDesc, "d_taildesc", NC + 1);
