@@ -1337,8 +1337,9 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         DEVBUF(d_st_overflow, int32_t, "d_st_overflow", 4);
         PINBUF(h_st_overflow, int32_t, "h_st_overflow", 4);
         if (getenv("PGA_STAGE_FULL")) f->stage_full = true;
+        bool stage_full = f->stage_full;
         for (;;) {
-            const bool half = !f->stage_full;
+            const bool half = !stage_full;
             // (PGA_STAGE_SHIFT=5: one slot per 32 positions, so that ordinary sequence overflows and the tests see the second pass)
             const int shift = half ? std::max(1, std::min(8, getenv("PGA_STAGE_SHIFT") ? atoi(getenv("PGA_STAGE_SHIFT")) : 1)) : 0;
             const int64_t st_slots = half ? (total >> shift) + 8 : 2 * total + 2;
@@ -1362,7 +1363,8 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             HT(c, hipGetLastError());
             HT(c, hipStreamSynchronize(st));
             if (!half || h_st_overflow[0] == 0) break;
-            f->stage_full = true;
+            stage_full = true;
+            if (!getenv("PGA_STAGE_SHIFT")) f->stage_full = true;       // (the test knob leaves the context as it was)
         }
 
         tm.mark("extract+sync");
@@ -1588,6 +1590,9 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                 pga_launch_dpw_topo(wgroups.g[g], ga[g].type, ga[g].strand, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], st);
                 if (pga_dp_use_contig(NCH)) pga_launch_dpc_compile(wgroups.g[g], d_cbase + (size_t)g * (NC + 1), NC, st);
                 sl.topo_q2 = wgroups.g[g].q2; sl.ext = wbuf.ext; sp.cs_out = wbuf.cs;
+                // (the same condition as the lean gather's direct mode further down: the node arrays stay on the device)
+                sl.fill_star_ptr = !(stage == 0 && !P.want_nodes && !use_lane && !(getenv("PGA_TAIL") && strcmp(getenv("PGA_TAIL"), "host") == 0) &&
+                                     !getenv("PGA_FULL_GATHER") && !getenv("PGA_GATHER_ALL_DP"));
             }
             pga_launch_score(d_chains + g_c0[g], nch, g_n0[g], nn, d_dig, d_ct, ga[g], d_models, f->d_msc, c->d_model_const, ca, sp,
                              d_chains, d_cc + (size_t)g * NC, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], f->d_sd_lut, st, 0,

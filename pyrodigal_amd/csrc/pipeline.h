@@ -98,6 +98,9 @@ struct StopLaunch {
     int32_t n_stops = 0;                 // stop nodes of the group (entries of ga.stop_list)
     // the wave-batch scorer's 64-byte extras of every stop node, built in the same pass (nullptr: not wanted)
     const int32_t* topo_q2 = nullptr; void* ext = nullptr;
+    // star_ptr of the nodes that are no stop nodes is -1: the launcher fills the chains' range first -- unless nobody will read it
+    // (the wave-batch scorer takes the extras, the tail asks for stop nodes only, the caller does not want the node arrays)
+    bool fill_star_ptr = true;
 };
 // per (group, contig): is any model of the group inside the contig's GC window?  (meta mode)
 void pga_launch_group_enable(const ContigDesc* d_ct, int n_contigs, const int32_t* d_gc_count, const double* d_model_gc,

@@ -2511,7 +2511,7 @@ void pga_launch_score(const ChainDesc* d_chains, int n_chains, int64_t node_begi
         }
     }
     if (stops != nullptr) {
-        (void)hipMemsetAsync(ca.star_ptr + 3 * node_begin, 0xff, sizeof(int32_t) * 3 * (size_t)total, st);
+        if (stops->fill_star_ptr) (void)hipMemsetAsync(ca.star_ptr + 3 * node_begin, 0xff, sizeof(int32_t) * 3 * (size_t)total, st);
         if (stops->n_pairs > 0 && stops->n_stops > 0)
             hipLaunchKernelGGL(k_ovl_topo, dim3(nblocks(stops->n_stops, 256)), blk, 0, st, ga, d_node_contig_base, stops->sbase, n_contigs, stops->n_stops,
                                sp.max_overlap);

@@ -1,5 +1,5 @@
 """Randomised sweep on the GPU box: `python tools/stress_nodes.py SEED0 SEED1 [SECONDS]` (the connection scorer and the coding-score form
-are drawn per seed: default / wave / lane, LDS tables forced or not) -- every node field of every contig (scores, RBS bins,
+are drawn per seed: default / wave / lane / contig, LDS tables or per-lane gathers for the coding score) -- every node field of every contig (scores, RBS bins,
 motifs, traceback, elimination flags) and every gene against the CPU oracle, in meta and single mode, open and closed ends, with
 and without masking."""
 import importlib.util
@@ -27,11 +27,11 @@ kinds = {}
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     if time.time() - t0 > budget: break
     rng = np.random.default_rng(seed)
-    kern = [None, 'wave', 'lane'][seed % 3]
+    kern = [None, 'wave', 'lane', 'contig'][seed % 4]
     for k_ in ('PGA_DP_KERNEL', 'PGA_CS_LDS'): os.environ.pop(k_, None)
     if kern: os.environ['PGA_DP_KERNEL'] = kern
-    if seed % 2: os.environ['PGA_CS_LDS'] = '2'
-    kinds[(kern or 'default', seed % 2)] = kinds.get((kern or 'default', seed % 2), 0) + 1
+    if (seed // 4) % 2: os.environ['PGA_CS_LDS'] = '0'           # the coding score by per-lane table gathers instead of the LDS tables
+    kinds[(kern or 'default', (seed // 4) % 2)] = kinds.get((kern or 'default', (seed // 4) % 2), 0) + 1
     seqs = []
     for k in range(120):
         L = int(rng.choice([60, 300, 900, 2500, 7000, 20000], p=[0.05, 0.1, 0.2, 0.25, 0.25, 0.15]))
@@ -53,5 +53,5 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         with ThreadPoolExecutor(32) as ex:
             ngenes += sum(ex.map(one, range(len(seqs))))
         ncontigs += len(seqs)
-print("kernels drawn (dp, lds coding score): ", kinds)
+print("kernels drawn (dp, coding score by gathers): ", kinds)
 print("seeds from", sys.argv[1], ":", ncontigs, "contig runs, every node field and", ngenes, "genes identical to the oracle; %.0f s" % (time.time() - t0))
