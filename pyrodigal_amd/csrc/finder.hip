@@ -1522,6 +1522,18 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             for (int k = 0; k < NCH; k++) lens[(size_t)k] = chains[k].n;
             dp_order.resize((size_t)NCH);
             pga_dp_start_order(NCH, lens.data(), dp_order.data());
+            // Workgroups go to the eight XCDs in turn (b % 8), each with an L2 of its own; the chains of a contig stand next to each
+            // other in the order (same length, stable sort) and read the same topology arrays.  So runs of four neighbours are dealt to
+            // the same XCD: position p -> workgroup ((p / 4 / 8) * 4 + p % 4) * 8 + (p / 4) % 8 (PGA_DP_XCD=0: the order as it is).
+            if (!(getenv("PGA_DP_XCD") && atoi(getenv("PGA_DP_XCD")) == 0)) {
+                const int G = 4, whole = NCH / (8 * G) * (8 * G);
+                std::vector<int32_t> by_block(dp_order);
+                for (int p_ = 0; p_ < whole; p_++) {
+                    const int grp = p_ / G, x = grp % 8, k = (grp / 8) * G + p_ % G;
+                    by_block[(size_t)k * 8 + (size_t)x] = dp_order[(size_t)p_];
+                }
+                dp_order.swap(by_block);
+            }
             DEVBUF(d_ord, int32_t, "d_dp_order", NCH + 1);
             HT(c, hipMemcpyAsync(d_ord, dp_order.data(), sizeof(int32_t) * (size_t)NCH, hipMemcpyHostToDevice, st));
             d_dp_order = d_ord;
