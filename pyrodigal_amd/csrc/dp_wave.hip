@@ -309,6 +309,7 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
           const int32_t* __restrict__ order /* or nullptr: workgroup b walks chain order[b] (longest chains first) */) {
     __shared__ double s_igm[64];
     const int chain = order != nullptr ? order[blockIdx.x] : (int)blockIdx.x;
+    if (chain < 0) return;                          // a filler: the per-XCD queues of the start order are not equally long
     const ChainDesc cd = chains[chain];
     const int lane = threadIdx.x;
     const int n = cd.n;
@@ -625,14 +626,15 @@ void pga_launch_dpw_chain(const ChainDesc* d_chains, int n_chains, int64_t node_
 }
 
 void pga_launch_dp_wave(const ChainDesc* d_chains, int n_chains, const DpwGroupPtrs& groups, const ModelConst* d_models, DpBuffers buf,
-                        const DpwBuffers& wb, hipStream_t st, const int32_t* d_order) {
+                        const DpwBuffers& wb, hipStream_t st, const int32_t* d_order, int n_blocks) {
     if (n_chains <= 0) return;
+    if (n_blocks <= 0 || d_order == nullptr) n_blocks = n_chains;
     static int occ = 0;
     if (!occ) { const char* e = getenv("PGA_DPW_OCC"); occ = e ? atoi(e) : 5; if (occ < 4 || occ > 6) occ = 5; }
-    if (occ == 5) hipLaunchKernelGGL(k_dp_wave<5>, dim3((unsigned)n_chains), dim3(64), 0, st, d_chains, groups, (const double*)wb.cs, (const DpwExt*)wb.ext,
+    if (occ == 5) hipLaunchKernelGGL(k_dp_wave<5>, dim3((unsigned)n_blocks), dim3(64), 0, st, d_chains, groups, (const double*)wb.cs, (const DpwExt*)wb.ext,
                                      d_models, buf, wb.sfxv, wb.sfxi, d_order);
-    else if (occ == 6) hipLaunchKernelGGL(k_dp_wave<6>, dim3((unsigned)n_chains), dim3(64), 0, st, d_chains, groups, (const double*)wb.cs, (const DpwExt*)wb.ext,
+    else if (occ == 6) hipLaunchKernelGGL(k_dp_wave<6>, dim3((unsigned)n_blocks), dim3(64), 0, st, d_chains, groups, (const double*)wb.cs, (const DpwExt*)wb.ext,
                                           d_models, buf, wb.sfxv, wb.sfxi, d_order);
-    else hipLaunchKernelGGL(k_dp_wave<4>, dim3((unsigned)n_chains), dim3(64), 0, st, d_chains, groups, (const double*)wb.cs, (const DpwExt*)wb.ext,
+    else hipLaunchKernelGGL(k_dp_wave<4>, dim3((unsigned)n_blocks), dim3(64), 0, st, d_chains, groups, (const double*)wb.cs, (const DpwExt*)wb.ext,
                             d_models, buf, wb.sfxv, wb.sfxi, d_order);
 }

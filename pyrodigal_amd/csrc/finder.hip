@@ -1522,20 +1522,28 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             for (int k = 0; k < NCH; k++) lens[(size_t)k] = chains[k].n;
             dp_order.resize((size_t)NCH);
             pga_dp_start_order(NCH, lens.data(), dp_order.data());
-            // Workgroups go to the eight XCDs in turn (b % 8), each with an L2 of its own; the chains of a contig stand next to each
-            // other in the order (same length, stable sort) and read the same topology arrays.  So runs of four neighbours are dealt to
-            // the same XCD: position p -> workgroup ((p / 4 / 8) * 4 + p % 4) * 8 + (p / 4) % 8 (PGA_DP_XCD=0: the order as it is).
-            if (!(getenv("PGA_DP_XCD") && atoi(getenv("PGA_DP_XCD")) == 0)) {
-                const int G = 4, whole = NCH / (8 * G) * (8 * G);
-                std::vector<int32_t> by_block(dp_order);
-                for (int p_ = 0; p_ < whole; p_++) {
-                    const int grp = p_ / G, x = grp % 8, k = (grp / 8) * G + p_ % G;
-                    by_block[(size_t)k * 8 + (size_t)x] = dp_order[(size_t)p_];
+            // Workgroups go to the eight XCDs in turn (b % 8), each with an L2 of its own, and the chains of a contig (one per model of
+            // the same translation table) read the same topology arrays.  So every (contig, table) goes to ONE XCD -- the one with
+            // the fewest nodes so far, in start order -- and workgroup 8 k + x takes the k-th chain of XCD x's queue; queues that end
+            // early are filled up with -1 (the workgroup returns at once).  PGA_DP_XCD=0: the order as it is.
+            if (!(getenv("PGA_DP_XCD") && atoi(getenv("PGA_DP_XCD")) == 0) && NCH >= 64) {
+                std::vector<int32_t> queue[8];
+                int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                std::vector<int8_t> xcd_of((size_t)NC * (size_t)NG, (int8_t)-1);
+                for (int p_ = 0; p_ < NCH; p_++) {
+                    const ChainDesc& ch = chains[(size_t)dp_order[(size_t)p_]];
+                    int8_t& x = xcd_of[(size_t)ch.group * NC + (size_t)ch.contig];
+                    if (x < 0) { int best = 0; for (int q = 1; q < 8; q++) if (load[q] < load[best]) best = q; x = (int8_t)best; }
+                    queue[x].push_back(dp_order[(size_t)p_]);
+                    load[x] += ch.n;
                 }
-                dp_order.swap(by_block);
+                size_t longest = 0;
+                for (int q = 0; q < 8; q++) longest = std::max(longest, queue[q].size());
+                dp_order.assign(longest * 8, -1);
+                for (int q = 0; q < 8; q++) for (size_t k = 0; k < queue[q].size(); k++) dp_order[k * 8 + (size_t)q] = queue[q][k];
             }
-            DEVBUF(d_ord, int32_t, "d_dp_order", NCH + 1);
-            HT(c, hipMemcpyAsync(d_ord, dp_order.data(), sizeof(int32_t) * (size_t)NCH, hipMemcpyHostToDevice, st));
+            DEVBUF(d_ord, int32_t, "d_dp_order", dp_order.size() + 1);
+            HT(c, hipMemcpyAsync(d_ord, dp_order.data(), sizeof(int32_t) * dp_order.size(), hipMemcpyHostToDevice, st));
             d_dp_order = d_ord;
         }
         PINBUF(h_maxidx, int32_t, "h_maxidx", NCH + 1);
@@ -1673,7 +1681,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                 HT(c, hipMemsetAsync(d_prof, 0, 128, st));
                 dp.prof = d_prof;
             }
-            pga_launch_dp_wave(d_chains, NCH, wgroups, c->d_model_const, dp, wbuf, st, d_dp_order);
+            pga_launch_dp_wave(d_chains, NCH, wgroups, c->d_model_const, dp, wbuf, st, d_dp_order, (int)dp_order.size());
             if (dp.prof != nullptr) {
                 unsigned long long pr[16];
                 HT(c, hipStreamSynchronize(st));

@@ -145,7 +145,7 @@ void pga_launch_dpw_chain(const ChainDesc* d_chains, int n_chains, int64_t node_
                           const DpwTopoArrays& ta, const ModelConst* d_models, const DpwBuffers& wb, hipStream_t st);
 // d_order (optional): the order in which the chains are started -- a launch ends when its last chain does, so long chains go first
 void pga_launch_dp_wave(const ChainDesc* d_chains, int n_chains, const DpwGroupPtrs& groups, const ModelConst* d_models, DpBuffers buf,
-                        const DpwBuffers& wb, hipStream_t st, const int32_t* d_order = nullptr);
+                        const DpwBuffers& wb, hipStream_t st, const int32_t* d_order = nullptr, int n_blocks = 0 /* entries of d_order; < 0 = filler */);
 
 // ---- lane-per-chain connection scoring for launches with very many chains (dp_lane.hip, dpl_core.h) ----
 // 64 chains to a wavefront, one lane each; the records of a wave are interleaved (node t of lane l at wave_base + 64 t + l)
