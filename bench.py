@@ -592,18 +592,18 @@ def cpu_baseline_all_cores(seqs, models):
     sample = seqs[:min(len(seqs), 4096)]
     mean_len = sum(len(s) for s in sample) / max(len(sample), 1)
     orc.find_genes_meta_pool_pinned(sample[:64], bins, min(8, logical), cpus=order)          # page cache of the tables, the library
-    per_thread = None                  # contigs per second and thread at the previous point
-    for threads in sorted({t for t in (1, 8, 32, 64, 128, physical, logical) if t <= logical}):
-        if per_thread is None:
-            t0 = time.perf_counter()
-            orc.find_genes_meta_pool_pinned(sample[:24], bins, 1, cpus=order)
-            per_thread = 24 / (time.perf_counter() - t0)
-        total = int(max(threads * 8, per_thread * threads * 5.5))
+    quota = out["cpu_quota_cores"]
+    points = {1, 8, 32, 64, 128, physical, logical} | ({max(1, int(quota))} if quota else set())
+    t0 = time.perf_counter()
+    orc.find_genes_meta_pool_pinned(sample[:24], bins, 1, cpus=order)
+    one_thread = 24 / (time.perf_counter() - t0)             # contigs per second of one thread
+    for threads in sorted(t for t in points if t <= logical):
+        running = min(threads, quota) if quota else threads  # threads that can be on a CPU at once
+        total = int(max(threads * 8, one_thread * running * 5.5))
         t0 = time.perf_counter()
         genes, cpu_s = orc.find_genes_meta_pool_pinned(sample, bins, threads, total=total, cpus=order)
         dt = time.perf_counter() - t0
-        calls = max(total, len(sample))
-        per_thread = calls / dt / threads
+        calls = total
         out["curve"].append({"threads": threads, "value": round(calls * mean_len / dt / 1e6, 3), "seconds": round(dt, 2), "calls": calls,
                              "Mbp_s_per_thread": round(calls * mean_len / dt / 1e6 / threads, 3), "cpu_busy": round(cpu_s / (dt * threads), 3),
                              "genes": genes})

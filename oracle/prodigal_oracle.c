@@ -1357,7 +1357,7 @@ typedef struct {
     const char* const* seqs; const int64_t* lens; int n;
     const po_training* const* bins; int nbins; const po_params* p;
     int next; int64_t genes; pthread_mutex_t mu;
-    int total;                  /* calls to make: the list is gone over as often as that takes (total >= n) */
+    int total;                  /* calls to make: the list is gone over as often as that takes (or only its head) */
     const int* cpus; int ncpus; /* thread t runs on logical CPU cpus[t % ncpus] (or anywhere) */
     int started;                /* threads that took their number */
     double cpu_seconds;         /* CPU time the threads spent, summed */
@@ -1392,7 +1392,7 @@ int64_t po_find_genes_meta_pool_pinned(const char* const* seqs, const int64_t* l
     if (n < 1) return 0;
     mallopt(M_MMAP_THRESHOLD, 1 << 30);
     mallopt(M_TRIM_THRESHOLD, 1 << 30);
-    po_pool_job J = {seqs, lens, n, bins, nbins, p, 0, 0, PTHREAD_MUTEX_INITIALIZER, total > n ? total : n, cpus, ncpus, 0, 0.0};
+    po_pool_job J = {seqs, lens, n, bins, nbins, p, 0, 0, PTHREAD_MUTEX_INITIALIZER, total > 0 ? total : n, cpus, ncpus, 0, 0.0};
     pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
     if (!th) return -1;
     int started = 0;
