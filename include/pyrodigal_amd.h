@@ -135,6 +135,11 @@ int         pga_dp_plan_summary(int32_t n_chains, const int32_t* nodes_per_chain
 /* The order in which the wave-batch connection scorer starts the chains of a launch: longest first by walk batches of 64 nodes,
  * launch order among equals (host arithmetic only).  order[k] = index of the chain started k-th. */
 int         pga_dp_start_order(int32_t n_chains, const int32_t* nodes_per_chain, int32_t* order);
+/* ... and that order made XCD-aware (workgroup b runs on XCD b % 8): chains with the same key -- a contig under one translation
+ * table, i.e. the same topology arrays -- all go to one XCD, the one with the fewest nodes so far; out[8 k + x] is the k-th chain of
+ * XCD x, -1 where a queue has ended.  Returns the entries written (a multiple of 8) or a negative PGA_E* code. */
+int64_t     pga_dp_xcd_order(int32_t n_chains, const int32_t* order, const int32_t* nodes_per_chain, const int32_t* key_of_chain,
+                             int32_t n_keys, int32_t* out, int64_t out_cap);
 /* How the ORF walks of the coding score (LDS-table form) of one translation-table group are cut into tasks (host arithmetic only):
  * contig i has nodes_per_contig[i] nodes and is scored for models_per_contig[i] models whose table columns start at
  * first_column[i] (columns of a contig are neighbours; every four of them are one walk).

@@ -19,7 +19,7 @@ EXPORTS = [
     "pga_score_connections", "pga_score_connections_training", "pga_find_genes_batch", "pga_result_free",
     "pga_batch_create", "pga_batch_free", "pga_find_genes", "pga_nodes_stage",
     "pga_fasta_open", "pga_fasta_next", "pga_fasta_error", "pga_fasta_close", "pga_train", "pga_dp_stats", "pga_dp_plan_summary", "pga_dp_start_order", "pga_cs_task_summary",
-    "pga_fasta_next_packed", "pga_batch_create_packed", "pga_translate_genes", "pga_fasta_open_callback", "pga_fasta_release_spare",
+    "pga_fasta_next_packed", "pga_batch_create_packed", "pga_translate_genes", "pga_fasta_open_callback", "pga_fasta_release_spare", "pga_dp_xcd_order",
 ]
 STAGE_EXTRACT, STAGE_SCORE, STAGE_OVERLAP, STAGE_SEQUENCE = 1, 2, 3, 4
 
@@ -139,6 +139,23 @@ def dp_start_order(nodes_per_chain):
     if rc != PGA_OK:
         raise ValueError("pga_dp_start_order failed (code %d)" % rc)
     return list(out[:n])
+
+
+def dp_xcd_order(nodes_per_chain, key_of_chain, order=None):
+    """The start order dealt to the eight XCDs (host arithmetic, no device needed): entry 8 k + x is the k-th chain of XCD x, -1 a filler."""
+    L = load()
+    n = len(nodes_per_chain)
+    order = dp_start_order(nodes_per_chain) if order is None else list(order)
+    nk = (max(key_of_chain) + 1) if n else 0
+    i32 = ctypes.c_int32
+    out = (i32 * max(8 * n, 1))()
+    L.pga_dp_xcd_order.restype = ctypes.c_int64
+    L.pga_dp_xcd_order.argtypes = [i32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, i32, ctypes.c_void_p, ctypes.c_int64]
+    got = L.pga_dp_xcd_order(n, (i32 * max(n, 1))(*order), (i32 * max(n, 1))(*[int(x) for x in nodes_per_chain]),
+                             (i32 * max(n, 1))(*[int(x) for x in key_of_chain]), nk, out, 8 * n)
+    if got < 0:
+        raise ValueError("pga_dp_xcd_order failed (code %d)" % -got)
+    return list(out[:got])
 
 
 def cs_task_summary(nodes_per_contig, first_column, models_per_contig, task_nodes=4096):

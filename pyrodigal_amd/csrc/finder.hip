@@ -1015,6 +1015,32 @@ extern "C" int pga_dp_start_order(int32_t n_chains, const int32_t* nodes_per_cha
     return PGA_OK;
 }
 
+// The start order made XCD-aware: workgroup b runs on XCD b % 8, and chains that share a key (a contig under one translation table:
+// the same topology arrays) should meet in one XCD's L2.  `order` is a start order (pga_dp_start_order); every key goes to the XCD
+// with the fewest nodes so far, in that order; out[8 k + x] = k-th chain of XCD x, -1 where a queue has ended.  Returns the number
+// of entries written (a multiple of 8, at most 8 * n_chains), or a negative error code.
+extern "C" int64_t pga_dp_xcd_order(int32_t n_chains, const int32_t* order, const int32_t* nodes_per_chain, const int32_t* key_of_chain, int32_t n_keys,
+                                    int32_t* out, int64_t out_cap) {
+    if (n_chains < 0 || n_keys < 0 || (n_chains > 0 && (!order || !nodes_per_chain || !key_of_chain || !out))) return -(int64_t)PGA_EINVAL;
+    std::vector<int32_t> queue[8];
+    int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<int8_t> xcd_of((size_t)n_keys, (int8_t)-1);
+    for (int p = 0; p < n_chains; p++) {
+        const int c = order[p];
+        if (c < 0 || c >= n_chains || key_of_chain[c] < 0 || key_of_chain[c] >= n_keys) return -(int64_t)PGA_EINVAL;
+        int8_t& x = xcd_of[(size_t)key_of_chain[c]];
+        if (x < 0) { int best = 0; for (int q = 1; q < 8; q++) if (load[q] < load[best]) best = q; x = (int8_t)best; }
+        queue[x].push_back(c);
+        load[x] += std::max(nodes_per_chain[c], 0);
+    }
+    size_t longest = 0;
+    for (int q = 0; q < 8; q++) longest = std::max(longest, queue[q].size());
+    if ((int64_t)(longest * 8) > out_cap) return -(int64_t)PGA_EINVAL;
+    for (size_t k = 0; k < longest * 8; k++) out[k] = -1;
+    for (int q = 0; q < 8; q++) for (size_t k = 0; k < queue[q].size(); k++) out[k * 8 + (size_t)q] = queue[q][k];
+    return (int64_t)(longest * 8);
+}
+
 extern "C" int pga_cs_task_summary(int32_t n_contigs, const int32_t* nodes_per_contig, const int32_t* first_column,
                                    const int32_t* models_per_contig, int32_t task_nodes, int64_t out[5]) {
     if (n_contigs < 0 || !out || (n_contigs > 0 && (!nodes_per_contig || !first_column || !models_per_contig)) || task_nodes < 1) return PGA_EINVAL;
@@ -1527,20 +1553,10 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             // the fewest nodes so far, in start order -- and workgroup 8 k + x takes the k-th chain of XCD x's queue; queues that end
             // early are filled up with -1 (the workgroup returns at once).  PGA_DP_XCD=0: the order as it is.
             if (!(getenv("PGA_DP_XCD") && atoi(getenv("PGA_DP_XCD")) == 0) && NCH >= 64) {
-                std::vector<int32_t> queue[8];
-                int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                std::vector<int8_t> xcd_of((size_t)NC * (size_t)NG, (int8_t)-1);
-                for (int p_ = 0; p_ < NCH; p_++) {
-                    const ChainDesc& ch = chains[(size_t)dp_order[(size_t)p_]];
-                    int8_t& x = xcd_of[(size_t)ch.group * NC + (size_t)ch.contig];
-                    if (x < 0) { int best = 0; for (int q = 1; q < 8; q++) if (load[q] < load[best]) best = q; x = (int8_t)best; }
-                    queue[x].push_back(dp_order[(size_t)p_]);
-                    load[x] += ch.n;
-                }
-                size_t longest = 0;
-                for (int q = 0; q < 8; q++) longest = std::max(longest, queue[q].size());
-                dp_order.assign(longest * 8, -1);
-                for (int q = 0; q < 8; q++) for (size_t k = 0; k < queue[q].size(); k++) dp_order[k * 8 + (size_t)q] = queue[q][k];
+                std::vector<int32_t> key((size_t)NCH), by_xcd((size_t)NCH * 8);
+                for (int k = 0; k < NCH; k++) key[(size_t)k] = chains[(size_t)k].group * NC + chains[(size_t)k].contig;
+                const int64_t nb = pga_dp_xcd_order(NCH, dp_order.data(), lens.data(), key.data(), NC * NG, by_xcd.data(), (int64_t)by_xcd.size());
+                if (nb > 0) { by_xcd.resize((size_t)nb); dp_order.swap(by_xcd); }
             }
             DEVBUF(d_ord, int32_t, "d_dp_order", dp_order.size() + 1);
             HT(c, hipMemcpyAsync(d_ord, dp_order.data(), sizeof(int32_t) * dp_order.size(), hipMemcpyHostToDevice, st));

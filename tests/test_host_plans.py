@@ -49,3 +49,32 @@ def test_contigs_without_nodes_or_models_make_no_task():
     assert s["nodes"] == 300 and s["tasks"] == 1
     with pytest.raises(ValueError):
         _cabi.cs_task_summary([100], [64], [1], 4096)                           # a column a task cannot name: the global-memory form is used
+
+
+def test_xcd_order_keeps_the_chains_of_a_contig_on_one_xcd():
+    """`pga_dp_xcd_order`: workgroup b runs on XCD b % 8; all chains of a key (a contig under one translation table) must land on the
+    same XCD, every chain exactly once, queues in start order (longest first), loads balanced, fillers only at the queues' ends."""
+    rng = np.random.default_rng(3)
+    keys, nodes = [], []
+    for contig in range(700):
+        n = int(rng.integers(100, 1500))
+        for _ in range(int(rng.integers(1, 7))):
+            keys.append(contig); nodes.append(n)
+    for contig in range(0, 700, 2):                    # a second translation table on every other contig: its own key
+        keys.append(700 + contig); nodes.append(int(rng.integers(100, 1500)))
+    out = _cabi.dp_xcd_order(nodes, keys)
+    assert len(out) % 8 == 0 and sorted(c for c in out if c >= 0) == list(range(len(nodes)))
+    xcd_of_key = {}
+    load = [0] * 8
+    for b, c in enumerate(out):
+        if c < 0:
+            assert all(o < 0 for o in out[b::8])       # a filler is never followed by a chain in its queue
+            continue
+        assert xcd_of_key.setdefault(keys[c], b % 8) == b % 8
+        load[b % 8] += nodes[c]
+    assert max(load) < 1.05 * min(load)
+    for x in range(8):
+        q = [nodes[c] >> 6 for c in out[x::8] if c >= 0]
+        assert q == sorted(q, reverse=True)             # every queue starts its longest chains first
+    assert _cabi.dp_xcd_order([], []) == []
+    assert _cabi.dp_xcd_order([5], [0]) == [0, -1, -1, -1, -1, -1, -1, -1]
