@@ -2059,6 +2059,15 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                     hipLaunchKernelGGL(k_tp_elim_a, grid, blk, 0, st, tw, d_td, o, d_path);
                     hipLaunchKernelGGL(k_tp_elim_b, grid, blk, 0, st, tw, d_td, o, d_path, d_elim);
                     // a workgroup per contig: wide for genomes, narrow when there are many short paths
+                    if (max_n >= 32768 && segs.size() <= 64 && !getenv("PGA_TP_EXTRACT_ONE")) {
+                        // genomes: a workgroup per chunk of 1024 path positions (k_tp_extract: one workgroup per contig, 400 rounds)
+                        const int chunks = (max_n + 1023) / 1024;
+                        DEVBUF(tp_xsum, TpChunkSum, "tp_xsum", (size_t)chunks * segs.size() + 1);
+                        const dim3 xg((unsigned)chunks, (unsigned)segs.size());
+                        hipLaunchKernelGGL(k_tp_extract_sum, xg, dim3(1024), 0, st, tw, d_td, o, d_path, d_elim, tp_xsum, chunks);
+                        hipLaunchKernelGGL(k_tp_extract_chunk, xg, dim3(1024), 0, st, tw, d_td, o, d_path, d_elim, (const TpChunkSum*)tp_xsum, chunks, d_gene0,
+                                           d_ngenes);
+                    } else
                     hipLaunchKernelGGL(k_tp_extract, dim3((unsigned)segs.size()), dim3(max_n >= 32768 ? 1024 : 256), 0, st, tw, d_td, o, d_path, d_elim,
                                        d_gene0, d_ngenes);
                     }

@@ -434,3 +434,118 @@ k_tp_small(TpWork w, const TailDesc* __restrict__ td, OutArrays o, int32_t* __re
     if (t == 0) n_genes[s.contig] = s_ng;
     (void)nwv;
 }
+
+// ---- Genes._extract for genomes: the path cut into chunks of 1024 positions, a workgroup per chunk -----------------------------
+// k_tp_extract is one workgroup per contig; a genome's path has some 400 000 positions, i.e. 400 rounds of one workgroup while
+// the rest of the chip idles (1.5 ms on config 5).  Here every chunk first reports what it sets -- the last position (in
+// processing order) that sets begin / end / start node / stop node, and how many genes it emits (k_tp_extract_sum) -- and then
+// emits its genes with the carries of the chunks before it, which it combines itself (k_tp_extract_chunk).
+struct TpChunkSum { int32_t m[4]; int32_t emits; int32_t _pad[3]; };
+
+struct TpExtractItem { bool live, fwd, stp; };
+__device__ inline TpExtractItem tp_extract_item(const NodeView& v, const int32_t* __restrict__ pl, const uint8_t* __restrict__ el, const int cnt, const int r) {
+    TpExtractItem it{false, false, false};
+    if (r < cnt) { const int p = pl[cnt - 1 - r]; it.live = el[p] != 1; it.fwd = v.strand[p] == 1; it.stp = is_stop_n(v, p); }
+    return it;
+}
+
+__global__ void __launch_bounds__(1024)
+k_tp_extract_sum(TpWork w, const TailDesc* __restrict__ td, OutArrays o, const int32_t* __restrict__ path, const uint8_t* __restrict__ elim,
+                 TpChunkSum* __restrict__ sums, const int chunks_per_seg) {
+    __shared__ int s_sc[16][5];
+    const int si = blockIdx.y, b = blockIdx.x;
+    const TpSeg s = w.seg[si];
+    const int cnt = w.cnt[si];
+    if (cnt < 2 || b * 1024 >= cnt) return;
+    const TailDesc d = td[s.contig];
+    const NodeView v = node_view(d, o, nullptr, nullptr);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r = b * 1024 + t;
+    const TpExtractItem it = tp_extract_item(v, path + s.off, elim + s.off, cnt, r);
+    int m[5] = {(it.live && ((it.fwd && !it.stp) || (!it.fwd && it.stp))) ? r : -1, (it.live && ((it.fwd && it.stp) || (!it.fwd && !it.stp))) ? r : -1,
+                (it.live && !it.stp) ? r : -1, (it.live && it.stp) ? r : -1, (it.live && ((it.fwd && it.stp) || (!it.fwd && !it.stp))) ? 1 : 0};
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) m[k] = max(m[k], __shfl_xor(m[k], dd, 64));
+        m[4] += __shfl_xor(m[4], dd, 64);
+    }
+    if (lane == 0) for (int k = 0; k < 5; k++) s_sc[wave][k] = m[k];
+    __syncthreads();
+    if (t == 0) {
+        TpChunkSum cs{{-1, -1, -1, -1}, 0, {0, 0, 0}};
+        for (int k2 = 0; k2 < 16; k2++) { for (int k = 0; k < 4; k++) cs.m[k] = max(cs.m[k], s_sc[k2][k]); cs.emits += s_sc[k2][4]; }
+        sums[(size_t)si * chunks_per_seg + b] = cs;
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+k_tp_extract_chunk(TpWork w, const TailDesc* __restrict__ td, OutArrays o, const int32_t* __restrict__ path, const uint8_t* __restrict__ elim,
+                   const TpChunkSum* __restrict__ sums, const int chunks_per_seg, GeneRec* __restrict__ genes, int32_t* __restrict__ n_genes) {
+    __shared__ int s_sc[16][5];
+    __shared__ int s_carry[5];
+    const int si = blockIdx.y, b = blockIdx.x;
+    const TpSeg s = w.seg[si];
+    const int cnt = w.cnt[si];
+    if (cnt < 2) { if (b == 0 && threadIdx.x == 0) n_genes[s.contig] = 0; return; }
+    if (b * 1024 >= cnt) return;
+    const TailDesc d = td[s.contig];
+    const NodeView v = node_view(d, o, nullptr, nullptr);
+    const int32_t* pl = path + s.off;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // what the chunks before this one leave behind
+    {
+        int c[5] = {-1, -1, -1, -1, 0};
+        for (int k = t; k < b; k += 1024) {
+            const TpChunkSum cs = sums[(size_t)si * chunks_per_seg + k];
+            for (int q = 0; q < 4; q++) c[q] = max(c[q], cs.m[q]);
+            c[4] += cs.emits;
+        }
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) c[q] = max(c[q], __shfl_xor(c[q], dd, 64));
+            c[4] += __shfl_xor(c[4], dd, 64);
+        }
+        if (lane == 0) for (int q = 0; q < 5; q++) s_sc[wave][q] = c[q];
+        __syncthreads();
+        if (t == 0) {
+            int cc[5] = {-1, -1, -1, -1, 0};
+            for (int k2 = 0; k2 < 16; k2++) { for (int q = 0; q < 4; q++) cc[q] = max(cc[q], s_sc[k2][q]); cc[4] += s_sc[k2][4]; }
+            for (int q = 0; q < 5; q++) s_carry[q] = cc[q];
+        }
+        __syncthreads();
+    }
+    GeneRec* out = genes + d.gene_off;
+    auto val_b = [&](int r) { const int p = pl[cnt - 1 - r]; return v.strand[p] == 1 ? v.ndx[p] + 1 : v.ndx[p] - 1; };
+    auto val_e = [&](int r) { const int p = pl[cnt - 1 - r]; return v.strand[p] == 1 ? v.ndx[p] + 3 : v.ndx[p] + 1; };
+    const int r = b * 1024 + t;
+    const TpExtractItem it = tp_extract_item(v, pl, elim + s.off, cnt, r);
+    const bool set_b = it.live && ((it.fwd && !it.stp) || (!it.fwd && it.stp));
+    const bool set_e = it.live && ((it.fwd && it.stp) || (!it.fwd && !it.stp));
+    const bool emit = set_e;
+    int mm[4] = {set_b ? r : -1, set_e ? r : -1, (it.live && !it.stp) ? r : -1, (it.live && it.stp) ? r : -1};
+    int e1 = emit ? 1 : 0;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int o2 = __shfl_up(mm[k], dd, 64); if (lane >= dd) mm[k] = max(mm[k], o2); }
+        const int o3 = __shfl_up(e1, dd, 64); if (lane >= dd) e1 += o3;
+    }
+    __syncthreads();                                   // s_sc is read above
+    if (lane == 63) { for (int k = 0; k < 4; k++) s_sc[wave][k] = mm[k]; s_sc[wave][4] = e1; }
+    __syncthreads();
+    int eoff = s_carry[4];
+    for (int k2 = 0; k2 < wave; k2++) {
+        for (int k = 0; k < 4; k++) mm[k] = max(mm[k], s_sc[k2][k]);
+        eoff += s_sc[k2][4];
+    }
+    for (int k = 0; k < 4; k++) mm[k] = max(mm[k], s_carry[k]);
+    if (emit) {
+        GeneRec gr;
+        gr.begin = mm[0] >= 0 ? val_b(mm[0]) : 0; gr.end = mm[1] >= 0 ? val_e(mm[1]) : 0;
+        gr.start_ndx = mm[2] >= 0 ? pl[cnt - 1 - mm[2]] : 0; gr.stop_ndx = mm[3] >= 0 ? pl[cnt - 1 - mm[3]] : 0;
+        out[eoff + e1 - 1] = gr;
+    }
+    if (r == cnt - 1) n_genes[s.contig] = eoff + e1;      // the last position of the path closes the count
+}
