@@ -254,6 +254,9 @@ void        pga_fasta_close(pga_fasta*);
 /* The pinned staging arenas of closed readers wait in a process-wide pool for the next reader (at most eight arenas and 512 MB,
  * allocated hipHostMallocPortable, so a reader on any device can take them); this gives them back to the system. */
 void        pga_fasta_release_spare(void);
+/* Device and pinned buffers of destroyed contexts wait in a process-wide cache for the next context (at most PGA_CACHE_GB, default
+ * 16 GB, of device memory and 2 GB of pinned memory; 0 turns the cache off); this gives them back to the system. */
+void        pga_release_cached(void);
 /* The same records with their sequences packed back to back in PINNED host memory (hipHostMalloc): `*packed` holds the
  * letters of the batch, record i at offs[i], lens[i] long, offs[i + 1] == offs[i] + lens[i].  The reader owns `n_arenas`
  * staging arenas (2 .. 8, fixed at the first call) and fills them in turn: the LETTERS of a call (`*packed`) stay valid until

@@ -19,7 +19,7 @@ EXPORTS = [
     "pga_score_connections", "pga_score_connections_training", "pga_find_genes_batch", "pga_result_free",
     "pga_batch_create", "pga_batch_free", "pga_find_genes", "pga_nodes_stage",
     "pga_fasta_open", "pga_fasta_next", "pga_fasta_error", "pga_fasta_close", "pga_train", "pga_dp_stats", "pga_dp_plan_summary", "pga_dp_start_order", "pga_cs_task_summary",
-    "pga_fasta_next_packed", "pga_batch_create_packed", "pga_translate_genes", "pga_fasta_open_callback", "pga_fasta_release_spare", "pga_dp_xcd_order",
+    "pga_fasta_next_packed", "pga_batch_create_packed", "pga_translate_genes", "pga_fasta_open_callback", "pga_fasta_release_spare", "pga_dp_xcd_order", "pga_release_cached",
 ]
 STAGE_EXTRACT, STAGE_SCORE, STAGE_OVERLAP, STAGE_SEQUENCE = 1, 2, 3, 4
 
@@ -124,6 +124,7 @@ def load():
     L.pga_fasta_error.restype = ctypes.c_char_p; L.pga_fasta_error.argtypes = [vp]
     L.pga_fasta_close.restype = None; L.pga_fasta_close.argtypes = [vp]
     L.pga_fasta_release_spare.restype = None; L.pga_fasta_release_spare.argtypes = []
+    L.pga_release_cached.restype = None; L.pga_release_cached.argtypes = []
     _lib = L
     return L
 

@@ -122,13 +122,52 @@ struct StageTimer {
 
 #define HT(ctx, expr) do { int rc__ = pga_hip_try_(ctx, (expr), #expr); if (rc__ != PGA_OK) return rc__; } while (0)
 
+// Buffers of destroyed contexts wait in a process-wide cache for the next context: a caller that makes a context per file pays the
+// 120 allocations of a context (50 ms, and as much again to free them) once.  Blocks enter the cache only when their context is
+// released, after its stream has drained; the cache is bounded (PGA_CACHE_GB, default 16 GB of device and 2 GB of pinned memory)
+// and pga_release_cached() empties it.
+struct CachedBlock { void* p; size_t cap; int dev; };
+static std::mutex g_cache_mu;
+static std::vector<CachedBlock> g_cache[2];          // 0: device, 1: pinned
+static size_t g_cached[2] = {0, 0};
+static size_t cache_limit(int kind) {
+    static const size_t gb = [] { const char* e = getenv("PGA_CACHE_GB"); return e ? (size_t)std::max(0, atoi(e)) : (size_t)16; }();
+    return kind == 0 ? gb << 30 : std::min<size_t>(gb << 30, (size_t)2 << 30);
+}
+static void* cache_take(int kind, int dev, size_t want, size_t* cap) {
+    std::lock_guard<std::mutex> g(g_cache_mu);
+    std::vector<CachedBlock>& v = g_cache[kind];
+    int best = -1;
+    for (int k = 0; k < (int)v.size(); k++)
+        if (v[k].dev == dev && v[k].cap >= want && v[k].cap <= 2 * want + ((size_t)1 << 20) && (best < 0 || v[k].cap < v[best].cap)) best = k;
+    if (best < 0) return nullptr;
+    void* p = v[best].p; *cap = v[best].cap;
+    g_cached[kind] -= v[best].cap;
+    v.erase(v.begin() + best);
+    return p;
+}
+static bool cache_put(int kind, int dev, void* p, size_t cap) {
+    std::lock_guard<std::mutex> g(g_cache_mu);
+    if (g_cached[kind] + cap > cache_limit(kind) || g_cache[kind].size() >= 4096) return false;
+    g_cache[kind].push_back(CachedBlock{p, cap, dev});
+    g_cached[kind] += cap;
+    return true;
+}
+extern "C" void pga_release_cached(void) {
+    std::lock_guard<std::mutex> g(g_cache_mu);
+    for (auto& b : g_cache[0]) hipFree(b.p);
+    for (auto& b : g_cache[1]) hipHostFree(b.p);
+    g_cache[0].clear(); g_cache[1].clear(); g_cached[0] = g_cached[1] = 0;
+}
+
 int ensure_dev(pga_ctx* c, const char* name, size_t bytes, void** out) {
     Buf& b = c->finder->dev[name];
     if (b.cap < bytes || !b.p) {
-        if (b.p) { hipFree(b.p); b.p = nullptr; b.cap = 0; }
+        if (b.p) { hipFree(b.p); b.p = nullptr; b.cap = 0; }     // (not to the cache: kernels of this call may still read it; hipFree waits)
         // room to grow: the calls of a job are about the same size, so the big buffers get a sixteenth on top, the small ones a quarter
         size_t want = bytes + (bytes >= ((size_t)64 << 20) ? bytes / 16 : bytes / 4) + 256;
-        HT(c, hipMalloc(&b.p, want));
+        b.p = cache_take(0, c->device, want, &want);
+        if (!b.p) HT(c, hipMalloc(&b.p, want));
         b.cap = want;
     }
     *out = b.p;
@@ -139,7 +178,8 @@ int ensure_pin(pga_ctx* c, const char* name, size_t bytes, void** out) {
     if (b.cap < bytes || !b.p) {
         if (b.p) { hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
         size_t want = bytes + bytes / 4 + 256;
-        HT(c, hipHostMalloc(&b.p, want, hipHostMallocDefault));
+        b.p = cache_take(1, c->device, want, &want);
+        if (!b.p) HT(c, hipHostMalloc(&b.p, want, hipHostMallocDefault));
         b.cap = want;
     }
     *out = b.p;
@@ -891,8 +931,9 @@ void pga_finder_release(pga_ctx* c) {
         fprintf(stderr, "[pga] context buffers: %.2f GB in %zu allocations\n", tot / 1e9, v.size());
         for (size_t k = 0; k < v.size() && k < 48; k++) fprintf(stderr, "[pga]   %-22s %9.1f MB\n", v[k].second.c_str(), v[k].first / 1e6);
     }
-    for (auto& kv : c->finder->dev) if (kv.second.p) hipFree(kv.second.p);
-    for (auto& kv : c->finder->pin) if (kv.second.p) hipHostFree(kv.second.p);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);        // nothing of this context still reads what goes to the cache
+    for (auto& kv : c->finder->dev) if (kv.second.p && !cache_put(0, c->device, kv.second.p, kv.second.cap)) hipFree(kv.second.p);
+    for (auto& kv : c->finder->pin) if (kv.second.p && !cache_put(1, c->device, kv.second.p, kv.second.cap)) hipHostFree(kv.second.p);
     if (c->finder->d_msc) hipFree(c->finder->d_msc);
     if (c->finder->d_model_gc) hipFree(c->finder->d_model_gc);
     if (c->finder->d_model_grp) hipFree(c->finder->d_model_grp);
