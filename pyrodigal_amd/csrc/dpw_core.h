@@ -144,7 +144,7 @@ DPW_HD DpwTopo dpw_topo_node(const int32_t* ndx, const int32_t* stopv, const uin
 // ref: _connection.h:166-176, 296-325, 345-356).
 DPW_HD void dpw_chain_ext_sp(const int32_t* ndx, const int32_t* stopv, const int8_t* strand, const int32_t* topo_q2, const double* cscore,
                              const double* sscore, const double* rscore, const double* uscore, const int (&sp)[3], const int i,
-                             const bool rev, const DpwModel& M, DpwExt& e);
+                             const bool rev, const DpwModel& M, DpwExt& e, const double* css = nullptr);
 DPW_HD void dpw_chain_ext(const int32_t* ndx, const int32_t* stopv, const int8_t* strand, const int32_t* topo_q2, const double* cscore,
                           const double* sscore, const double* rscore, const double* uscore, const int32_t* star_ptr /* [n][3] */, const int i,
                           const bool rev, const DpwModel& M, DpwExt& e) {
@@ -154,7 +154,7 @@ DPW_HD void dpw_chain_ext(const int32_t* ndx, const int32_t* stopv, const int8_t
 // the same with the three overlapping starts of node i handed over
 DPW_HD void dpw_chain_ext_sp(const int32_t* ndx, const int32_t* stopv, const int8_t* strand, const int32_t* topo_q2, const double* cscore,
                              const double* sscore, const double* rscore, const double* uscore, const int (&sp)[3], const int i,
-                             const bool rev, const DpwModel& M, DpwExt& e) {
+                             const bool rev, const DpwModel& M, DpwExt& e, const double* css /* or nullptr: cscore + sscore, already added */) {
     e.vm = 0;
     const int my_ndx = ndx[i];
     for (int k = 0; k < 3; k++) {
@@ -162,7 +162,7 @@ DPW_HD void dpw_chain_ext_sp(const int32_t* ndx, const int32_t* stopv, const int
         const int p = sp[k];
         if (p < 0) continue;
         e.vm |= 1 << k;
-        const double cs3 = cscore[p] + sscore[p];
+        const double cs3 = css != nullptr ? css[p] : cscore[p] + sscore[p];
         double ig;
         if (!rev)   // F3 source j = i, n3 = forward start: igm(j, n3)       (ref: _connection.h:170-174)
             ig = (strand[p] == 1) ? dpw_igm_same(my_ndx, 1, rscore[i], uscore[i], ndx[p], rscore[p], uscore[p], M.st_wt, M.igm) : M.negc;

@@ -2101,6 +2101,7 @@ struct OvlChain {
     const int32_t* __restrict__ ndx; const int32_t* __restrict__ stv; const uint8_t* __restrict__ typ; const int8_t* __restrict__ str;   // topology of the contig
     const double* __restrict__ cs; const double* __restrict__ ss; const double* __restrict__ rs; const double* __restrict__ us;           // the chain's scores
     int n;
+    const double* __restrict__ css = nullptr;    // or: cscore + sscore as the start scorer left it for the wave-batch scorer (one load instead of two)
 };
 // Which of the first OV_SPEC neighbours of stop node i count (bit k: the k-th neighbour in the reference's walking order -- forward
 // stop: j = i + 3 - k; reverse stop: j = i - 3 + k), and whether the walk ends among them (bit 31).  Positions, strands and
@@ -2170,8 +2171,9 @@ __device__ __forceinline__ void overlapping_starts_of(const OvlChain& C, const i
             if (j < 0) break;
         }
         const int nj = ndx[j];
-        const double v = fwd ? cs[j] + ss[j] + igm_same_dev(my, 1, rs_i, us_i, nj, rs[j], us[j], mc->st_wt, mc->igm)
-                             : cs[j] + ss[j] + igm_same_dev(nj, -1, rs[j], us[j], my, rs_i, us_i, mc->st_wt, mc->igm);
+        const double csj = C.css != nullptr ? C.css[j] : cs[j] + ss[j];
+        const double v = fwd ? csj + igm_same_dev(my, 1, rs_i, us_i, nj, rs[j], us[j], mc->st_wt, mc->igm)
+                             : csj + igm_same_dev(nj, -1, rs[j], us[j], my, rs_i, us_i, mc->st_wt, mc->igm);
         if (v > best) { const int f = nj % 3; if (f == 0) sp0 = j; else if (f == 1) sp1 = j; else sp2 = j; best = v; }
     }
 }
@@ -2226,7 +2228,7 @@ k_overlapping_starts(const ChainDesc* __restrict__ chains, int n_chains, int64_t
 __global__ void __launch_bounds__(256)
 k_ovl_stops(const ChainDesc* __restrict__ chains, int n_chains, int64_t soff_begin, int64_t n_pairs, GroupArrays ga,
             const int32_t* __restrict__ cbase, const int32_t* __restrict__ sbase, const ModelConst* __restrict__ mcs, ChainArrays ca, int maxov,
-            const int32_t* __restrict__ topo_q2, DpwExt* __restrict__ ext) {
+            const int32_t* __restrict__ topo_q2, DpwExt* __restrict__ ext, const double* __restrict__ css /* or nullptr: cscore + sscore per chain node */) {
     __shared__ int s_c0;
     const int64_t blk0 = soff_begin + (int64_t)blockIdx.x * blockDim.x;
     const int64_t p = blk0 + threadIdx.x;
@@ -2248,7 +2250,7 @@ k_ovl_stops(const ChainDesc* __restrict__ chains, int n_chains, int64_t soff_beg
     int sp[3] = {-1, -1, -1};
     if (ga.edge0[tb + i] != 1) {
         const OvlChain C{ga.ndx + tb, ga.stop_val + tb, ga.type + tb, ga.strand + tb, ca.cscore + ch.off, ca.sscore + ch.off, ca.rscore + ch.off,
-                         ca.uscore + ch.off, ch.n};
+                         ca.uscore + ch.off, ch.n, css != nullptr ? css + ch.off : nullptr};
         overlapping_starts_of(C, i, mc, maxov, sp[0], sp[1], sp[2], ga.ovl_topo[sidx]);
         ca.star_ptr[3 * g] = sp[0]; ca.star_ptr[3 * g + 1] = sp[1]; ca.star_ptr[3 * g + 2] = sp[2];
     }
@@ -2256,7 +2258,7 @@ k_ovl_stops(const ChainDesc* __restrict__ chains, int n_chains, int64_t soff_beg
         const DpwModel M{mc->st_wt, mc->negc, mc->igm};
         DpwExt e;
         dpw_chain_ext_sp(ga.ndx + tb, ga.stop_val + tb, ga.strand + tb, topo_q2 + tb, ca.cscore + ch.off, ca.sscore + ch.off, ca.rscore + ch.off,
-                         ca.uscore + ch.off, sp, i, ga.strand[tb + i] != 1, M, e);
+                         ca.uscore + ch.off, sp, i, ga.strand[tb + i] != 1, M, e, css != nullptr ? css + ch.off : nullptr);
         ext[p] = e;             // dense: one record per (chain, stop node) pair, in pair order
     }
 }
@@ -2517,6 +2519,7 @@ void pga_launch_score(const ChainDesc* d_chains, int n_chains, int64_t node_begi
                                sp.max_overlap);
         if (stops->n_pairs > 0)
             hipLaunchKernelGGL(k_ovl_stops, dim3(nblocks(stops->n_pairs, 256)), blk, 0, st, d_chains, n_chains, stops->soff_begin, stops->n_pairs, ga,
-                               d_node_contig_base, stops->sbase, d_mc, ca, sp.max_overlap, stops->topo_q2, (DpwExt*)stops->ext);
+                               d_node_contig_base, stops->sbase, d_mc, ca, sp.max_overlap, stops->topo_q2, (DpwExt*)stops->ext,
+                               stops->ext != nullptr ? (const double*)sp.cs_out : nullptr);
     } else hipLaunchKernelGGL(k_overlapping_starts, grid, blk, 0, st, d_chains, n_chains, node_begin, total, ga, d_mc, ca, sp.max_overlap);
 }
