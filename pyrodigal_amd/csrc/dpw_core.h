@@ -164,10 +164,14 @@ DPW_HD void dpw_chain_ext_sp(const int32_t* ndx, const int32_t* stopv, const int
         e.vm |= 1 << k;
         const double cs3 = css != nullptr ? css[p] : cscore[p] + sscore[p];
         double ig;
+        // (of the RBS / upstream scores only the start's enter, and only when the two nodes are adjacent: _connection.h:60-66)
+        const int pn = ndx[p];
+        const bool adj = !rev ? (my_ndx + 2 == pn || my_ndx == pn + 1) : (pn + 2 == my_ndx || pn == my_ndx + 1);
+        const double pr = adj ? rscore[p] : 0.0, pu = adj ? uscore[p] : 0.0;
         if (!rev)   // F3 source j = i, n3 = forward start: igm(j, n3)       (ref: _connection.h:170-174)
-            ig = (strand[p] == 1) ? dpw_igm_same(my_ndx, 1, rscore[i], uscore[i], ndx[p], rscore[p], uscore[p], M.st_wt, M.igm) : M.negc;
+            ig = (strand[p] == 1) ? dpw_igm_same(my_ndx, 1, 0.0, 0.0, pn, pr, pu, M.st_wt, M.igm) : M.negc;
         else        // R3 target i, n3 = reverse start: igm(n3, i)          (ref: _connection.h:313-320, 353-355)
-            ig = (strand[p] == -1) ? dpw_igm_same(ndx[p], -1, rscore[p], uscore[p], my_ndx, rscore[i], uscore[i], M.st_wt, M.igm) : M.negc;
+            ig = (strand[p] == -1) ? dpw_igm_same(pn, -1, pr, pu, my_ndx, 0.0, 0.0, M.st_wt, M.igm) : M.negc;
         e.x[k] = cs3 + ig;
         e.n3n[k] = ndx[p]; e.n3s[k] = stopv[p];
         // the overlapping start of a reverse stop is a reverse start: its own first candidate is this pair's (same stop_val)

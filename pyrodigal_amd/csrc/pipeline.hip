@@ -2141,7 +2141,7 @@ __device__ __forceinline__ void overlapping_starts_of(const OvlChain& C, const i
     const int my = ndx[i];
     double best = -100;
     const bool fwd = str[i] == 1;
-    const double rs_i = rs[i], us_i = us[i];
+    const double rs_i = 0.0, us_i = 0.0;        // (the stop's own RBS / upstream scores never enter: the start's do, when adjacent)
     // The reference walks the neighbours one by one (forward stop: j = i + 3 downwards; reverse stop: j = i - 3 upwards) until
     // it leaves the overlap window.  Which of the first OV_SPEC count is known (overlap_neighbours); only those are priced, in
     // the reference's order; a window that is not done by then (rare) goes on one by one.
@@ -2172,8 +2172,11 @@ __device__ __forceinline__ void overlapping_starts_of(const OvlChain& C, const i
         }
         const int nj = ndx[j];
         const double csj = C.css != nullptr ? C.css[j] : cs[j] + ss[j];
-        const double v = fwd ? csj + igm_same_dev(my, 1, rs_i, us_i, nj, rs[j], us[j], mc->st_wt, mc->igm)
-                             : csj + igm_same_dev(nj, -1, rs[j], us[j], my, rs_i, us_i, mc->st_wt, mc->igm);
+        // the RBS / upstream scores of the start only enter when the two nodes are adjacent (_connection.h:60-66): asked for then only
+        const bool adj = fwd ? (my + 2 == nj || my == nj + 1) : (nj + 2 == my || nj == my + 1);
+        const double rj = adj ? rs[j] : 0.0, uj = adj ? us[j] : 0.0;
+        const double v = fwd ? csj + igm_same_dev(my, 1, rs_i, us_i, nj, rj, uj, mc->st_wt, mc->igm)
+                             : csj + igm_same_dev(nj, -1, rj, uj, my, rs_i, us_i, mc->st_wt, mc->igm);
         if (v > best) { const int f = nj % 3; if (f == 0) sp0 = j; else if (f == 1) sp1 = j; else sp2 = j; best = v; }
     }
 }
