@@ -40,18 +40,58 @@ __device__ __forceinline__ int contig_of_node(const int32_t* __restrict__ cbase,
     return lo;
 }
 
+// One thread per topology node.  The expensive kind is the forward stop: it needs the next forward stop of every frame after it (q2 and
+// the operon bits), some forty nodes ahead on average -- and every lane of a wave pays for that walk, whatever its own kind.  So the
+// workgroup first turns the forward-stop flags of its 256 nodes and of the 192 behind them into three bit masks (one per frame) in
+// LDS, and a forward stop finds its three successors with a few bit scans; only when a frame has none inside the masks and the
+// contig goes on behind them does it walk (dpw_topo_node without a hint).  PGA_DPW_TOPO_WALK=1: always walk (cross-check).
+constexpr int TOPO_AHEAD = 192, TOPO_WORDS = (256 + TOPO_AHEAD) / 64;
 __global__ void __launch_bounds__(256)
 k_dpw_topo(const int32_t* __restrict__ ndx, const int32_t* __restrict__ stopv, const uint8_t* __restrict__ type, const int8_t* __restrict__ strand,
-           const int32_t* __restrict__ cbase, int n_contigs, int n_nodes, DpwTopoArrays ta) {
+           const int32_t* __restrict__ cbase, int n_contigs, int n_nodes, DpwTopoArrays ta, const int use_masks) {
     __shared__ int s_c0;
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (threadIdx.x == 0) s_c0 = contig_of_node(cbase, n_contigs, blockIdx.x * blockDim.x);     // one search per workgroup, then a short walk
+    __shared__ unsigned long long s_m[3][TOPO_WORDS];
+    const int g0 = blockIdx.x * blockDim.x, g = g0 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_c0 = contig_of_node(cbase, n_contigs, g0);     // one search per workgroup, then a short walk
+    if (use_masks) {
+        auto flags = [&](const int idx, const int word) {
+            const bool in = idx < n_nodes;
+            const bool f3 = in && type[in ? idx : 0] == 3 && strand[in ? idx : 0] == 1;
+            const int fr = in ? ndx[idx] % 3 : 0;
+#pragma unroll
+            for (int f = 0; f < 3; f++) { const unsigned long long m = __ballot(f3 && fr == f); if (lane == 0) s_m[f][word] = m; }
+        };
+        flags(g, wave);
+        if (wave < TOPO_AHEAD / 64) flags(g0 + 256 + threadIdx.x, 4 + wave);
+    }
     __syncthreads();
     if (g >= n_nodes) return;
     int c = s_c0;
     while (c + 1 < n_contigs && cbase[c + 1] <= g) c++;
     const int b0 = cbase[c], n = cbase[c + 1] - b0;
-    const DpwTopo t = dpw_topo_node(ndx + b0, stopv + b0, type + b0, strand + b0, n, g - b0);
+    DpwF3Hint hint{0, 0};
+    bool have = false;
+    if (use_masks && type[g] == 3 && strand[g] == 1) {
+        const int k = g - g0, e = b0 + n, my_ndx = ndx[g];
+        const bool covered = g0 + 64 * TOPO_WORDS >= e;       // the masks reach the end of the contig
+        int q2 = n; have = true;
+#pragma unroll
+        for (int f = 0; f < 3; f++) {
+            int j = -1;
+            for (int w = (k + 1) >> 6; w < TOPO_WORDS && j < 0; w++) {
+                unsigned long long m = s_m[f][w];
+                if (w == (k + 1) >> 6) m &= ~0ull << ((k + 1) & 63);
+                if (m) j = g0 + 64 * w + __builtin_ctzll(m);
+            }
+            if (j < 0) { if (!covered) have = false; continue; }
+            if (j >= e) continue;                              // the frame has no forward stop behind this one on the contig
+            q2 = min(q2, j - b0);
+            if (stopv[j] < my_ndx) hint.bits |= 1 << (4 + f);   // inside that stop's ORF: an operon candidate for it
+        }
+        hint.q2 = q2;
+    }
+    const DpwTopo t = dpw_topo_node(ndx + b0, stopv + b0, type + b0, strand + b0, n, g - b0, have ? &hint : nullptr);
     ta.kf[g] = t.kf; ta.lo[g] = t.lo; ta.q1[g] = t.q1; ta.q2[g] = t.q2;
     if (ta.tp != nullptr) { ta.tp[2 * (int64_t)g] = make_int4(ndx[g], stopv[g], t.lo, t.q1); ta.tp[2 * (int64_t)g + 1] = make_int4(t.q2, t.kf, 0, 0); }
 }
@@ -614,8 +654,9 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
 void pga_launch_dpw_topo(const DpwTopoArrays& ta, const uint8_t* type, const int8_t* strand, const int32_t* d_cbase, int n_contigs, int n_nodes,
                          hipStream_t st) {
     if (n_nodes <= 0) return;
+    const int walk = getenv("PGA_DPW_TOPO_WALK") ? atoi(getenv("PGA_DPW_TOPO_WALK")) : 0;
     hipLaunchKernelGGL(k_dpw_topo, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, st, ta.ndx, ta.stop_val, type, strand, d_cbase,
-                       n_contigs, n_nodes, ta);
+                       n_contigs, n_nodes, ta, walk ? 0 : 1);
 }
 
 void pga_launch_dpw_chain(const ChainDesc* d_chains, int n_chains, int64_t node_begin, int64_t total_nodes, const NodeArrays& nodes,

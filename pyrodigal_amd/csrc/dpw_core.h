@@ -76,7 +76,11 @@ DPW_HD double dpw_igm_same(int a_ndx, int a_strand, double a_r, double a_u, int 
 //        the 3' end of this gene (DPW_NONE: none before stop_val + MAX_OPP_OVLP)
 struct DpwTopo { uint8_t kf; int32_t lo, q1, q2; };
 
-DPW_HD DpwTopo dpw_topo_node(const int32_t* ndx, const int32_t* stopv, const uint8_t* type, const int8_t* strand, const int n, const int i) {
+// `f3` (device, optional): a forward stop's q2 and operon bits when the caller has them already (k_dpw_topo finds the next forward stop
+// of every frame from bit masks of its workgroup's nodes instead of walking the nodes eight at a time)
+struct DpwF3Hint { int q2, bits; };
+DPW_HD DpwTopo dpw_topo_node(const int32_t* ndx, const int32_t* stopv, const uint8_t* type, const int8_t* strand, const int n, const int i,
+                             const DpwF3Hint* f3 = nullptr) {
     DpwTopo t;
     const int my_ndx = ndx[i], my_stop = stopv[i];
     const bool rev = strand[i] != 1, stop = type[i] == 3;
@@ -107,6 +111,8 @@ DPW_HD DpwTopo dpw_topo_node(const int32_t* ndx, const int32_t* stopv, const uin
             if (k < 8) break;
         }
         t.q1 = a > lo ? a : lo;
+    } else if (kind == 1 && f3 != nullptr) {
+        t.q2 = f3->q2; kf |= f3->bits;
     } else if (kind == 1) {
         t.q2 = n;
         int seen = 0;
