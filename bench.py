@@ -140,6 +140,39 @@ class Lanes:
             f.result()
         return out
 
+    def run_back_to_back(self, steps, n, call, done):
+        """`steps` passes of n calls without a join between them: context c goes on with its first call of pass s + 1 as soon as it
+        has made its last of pass s, and ``done(results of pass s)`` runs (in pass order, on the caller's thread) as soon as the
+        last call of pass s has returned -- the pipeline of calls is filled once, not once per pass."""
+        import threading
+        C = len(self.ctxs)
+        out = [[None] * n for _ in range(steps)]
+        left = [n] * steps
+        cv = threading.Condition()
+
+        def lane(c):
+            for j in range(c, steps * n, C):
+                s_, k = divmod(j, n)
+                r = call(self.ctxs[c % C], k)
+                with cv:
+                    out[s_][k] = r
+                    left[s_] -= 1
+                    if left[s_] == 0:
+                        cv.notify_all()
+        if self.pool is None:
+            for s_ in range(steps):
+                done([call(self.ctxs[0], k) for k in range(n)])
+            return
+        futs = [self.pool.submit(lane, c) for c in range(C)]
+        for s_ in range(steps):
+            with cv:
+                while left[s_] > 0:
+                    cv.wait()
+            done(out[s_])
+            out[s_] = None
+        for f in futs:
+            f.result()
+
     def close(self):
         if self.pool is not None:
             self.pool.shutdown()
@@ -323,6 +356,17 @@ def main():
                     "estimated_work_share": [round(w_ / max(sum(wsum), 1e-9), 4) for w_ in wsum],
                     "lpt_imbalance": round(max(wsum) / max(sum(wsum) / world, 1e-9), 4)}
 
+    # ---- the same K passes issued back to back (one rank only; reported next to `value`, never as it): a step of the loop above ends
+    #      with a join of all contexts, so the pipeline of calls drains and refills once per step; a caller that streams batch after
+    #      batch does not pay that.  Every pass still ends with its own gather, in order.
+    b2b_elapsed = None
+    if dist is None and n_ctx > 1 and len(groups) > 1:
+        sync()
+        t0b = time.perf_counter()
+        lanes.run_back_to_back(args.steps, len(groups), h2h_call, gather)
+        sync()
+        b2b_elapsed = time.perf_counter() - t0b
+
     # ---- the same loop with the contigs resident in HBM (no packing, no upload): the rate of the path alone
     batches = [ctxs[k % n_ctx].upload(g) for k, g in enumerate(groups)]
     res_steps = max(1, min(args.steps, 5))
@@ -363,6 +407,7 @@ def main():
                        "resident_Mbp_s": round(job_bases * res_steps / r_elapsed / 1e6, 3), "resident_steps": res_steps,
                        "resident_ms_per_step": round(1e3 * r_elapsed / res_steps, 3),
                        "gather_ms_per_step_rank0": round(1e3 * gather_s / args.steps, 3),
+                       "host_to_host_back_to_back_Mbp_s": round(job_bases * args.steps / b2b_elapsed / 1e6, 3) if b2b_elapsed else None,
                        "generate_s_rank0": round(t_gen, 2)},
             # one launch = one device call = one sub-batch: the PMC passes profile exactly that (tools/collect_profiles.sh)
             "roofline": roofline(ctx, dp_ms, passes, calls, n_chains, wname,
