@@ -150,15 +150,24 @@ class Lanes:
         left = [n] * steps
         cv = threading.Condition()
 
+        failed = []
+
         def lane(c):
-            for j in range(c, steps * n, C):
-                s_, k = divmod(j, n)
-                r = call(self.ctxs[c % C], k)
+            try:
+                for j in range(c, steps * n, C):
+                    if failed:
+                        return
+                    s_, k = divmod(j, n)
+                    r = call(self.ctxs[c % C], k)
+                    with cv:
+                        out[s_][k] = r
+                        left[s_] -= 1
+                        if left[s_] == 0:
+                            cv.notify_all()
+            except BaseException as err:          # a failed call must not leave the caller waiting for its pass
                 with cv:
-                    out[s_][k] = r
-                    left[s_] -= 1
-                    if left[s_] == 0:
-                        cv.notify_all()
+                    failed.append(err)
+                    cv.notify_all()
         if self.pool is None:
             for s_ in range(steps):
                 done([call(self.ctxs[0], k) for k in range(n)])
@@ -166,12 +175,16 @@ class Lanes:
         futs = [self.pool.submit(lane, c) for c in range(C)]
         for s_ in range(steps):
             with cv:
-                while left[s_] > 0:
+                while left[s_] > 0 and not failed:
                     cv.wait()
+            if failed:
+                break
             done(out[s_])
             out[s_] = None
         for f in futs:
             f.result()
+        if failed:
+            raise failed[0]
 
     def close(self):
         if self.pool is not None:
