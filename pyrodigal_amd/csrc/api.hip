@@ -245,49 +245,16 @@ static int score_connections_impl(pga_ctx* c, int32_t n, const int32_t* ndx, con
         DpwBuffers wb{};
         int32_t* d_cbase;
         const int32_t h_cbase[2] = {0, n};
-        HIP_TRY(c, db.alloc(&wg.g[0].tp, 2 * N)); HIP_TRY(c, db.alloc(&wg.g[0].prog, 4 * N)); HIP_TRY(c, db.alloc(&wg.g[0].kf, N)); HIP_TRY(c, db.alloc(&wg.g[0].lo, N)); HIP_TRY(c, db.alloc(&wg.g[0].q1, N)); HIP_TRY(c, db.alloc(&wg.g[0].q2, N));
+        HIP_TRY(c, db.alloc(&wg.g[0].kf, N)); HIP_TRY(c, db.alloc(&wg.g[0].lo, N)); HIP_TRY(c, db.alloc(&wg.g[0].q1, N)); HIP_TRY(c, db.alloc(&wg.g[0].q2, N));
         HIP_TRY(c, db.alloc(&wb.cs, N + 2)); HIP_TRY(c, db.alloc(&wb.ext, N + 4)); HIP_TRY(c, db.alloc(&wb.sfxv, N)); HIP_TRY(c, db.alloc(&wb.sfxi, N));
         HIP_TRY(c, db.alloc(&d_cbase, 2));
         HIP_TRY(c, hipMemcpyAsync(d_cbase, h_cbase, sizeof h_cbase, hipMemcpyHostToDevice, st));
         wg.g[0].ndx = nd.ndx; wg.g[0].stop_val = nd.stop_val;
         pga_launch_dpw_topo(wg.g[0], nd.type, nd.strand, d_cbase, 1, n, st);
         pga_launch_dpw_chain(d_chain, 1, 0, n, na, wg.g[0], d_mc, wb, st);
-        if (pga_dp_use_contig(1)) {
-            pga_launch_dpc_compile(wg.g[0], d_cbase, 1, st);
-            // PGA_DP_KERNEL=contig: the contig-per-wavefront kernel on a wave whose one lane is this chain (tests)
-            std::vector<int2> waves;
-            pga_dpc_plan(&ch, 1, waves);
-            int2* d_w;
-            HIP_TRY(c, db.alloc(&d_w, waves.size()));
-            HIP_TRY(c, hipMemcpyAsync(d_w, waves.data(), sizeof(int2) * waves.size(), hipMemcpyHostToDevice, st));
-            HIP_TRY(c, hipEventRecord(c->ev0, st));
-            pga_launch_dp_contig(d_w, (int)waves.size(), d_chain, wg, d_mc, buf, wb, st);
-            HIP_TRY(c, hipEventRecord(c->ev1, st));
-            HIP_TRY(c, hipStreamSynchronize(st));              // the plan lives on this stack frame
-        } else if (pga_dp_use_lane(1)) {
-            // PGA_DP_KERNEL=lane: the lane-per-chain kernel on a wave that holds this one chain (tests)
-            DplPlan plan;
-            pga_dpl_plan(&ch, 1, plan);
-            DplDev L{};
-            int32_t* d_lc; int64_t* d_wb; int32_t* d_ws; int64_t* d_cr;
-            HIP_TRY(c, db.alloc(&d_lc, plan.lane_chain.size())); HIP_TRY(c, db.alloc(&d_wb, plan.wave_base.size()));
-            HIP_TRY(c, db.alloc(&d_ws, plan.wave_steps.size())); HIP_TRY(c, db.alloc(&d_cr, plan.chain_rec.size()));
-            HIP_TRY(c, db.alloc(&L.inA, (size_t)plan.records + 64)); HIP_TRY(c, db.alloc(&L.inB, (size_t)plan.records + 64)); HIP_TRY(c, db.alloc(&L.out, (size_t)plan.records + 64));
-            HIP_TRY(c, hipMemcpyAsync(d_lc, plan.lane_chain.data(), 4 * plan.lane_chain.size(), hipMemcpyHostToDevice, st));
-            HIP_TRY(c, hipMemcpyAsync(d_wb, plan.wave_base.data(), 8 * plan.wave_base.size(), hipMemcpyHostToDevice, st));
-            HIP_TRY(c, hipMemcpyAsync(d_ws, plan.wave_steps.data(), 4 * plan.wave_steps.size(), hipMemcpyHostToDevice, st));
-            HIP_TRY(c, hipMemcpyAsync(d_cr, plan.chain_rec.data(), 8 * plan.chain_rec.size(), hipMemcpyHostToDevice, st));
-            L.lane_chain = d_lc; L.wave_base = d_wb; L.wave_steps = d_ws; L.n_waves = plan.n_waves; L.max_steps = plan.max_steps;
-            HIP_TRY(c, hipEventRecord(c->ev0, st));
-            pga_launch_dp_lane(d_chain, wg, d_mc, buf, wb, L, st);
-            HIP_TRY(c, hipEventRecord(c->ev1, st));
-            pga_launch_dpl_unpack(d_chain, 1, d_cr, 0, n, L, buf, st);
-            HIP_TRY(c, hipStreamSynchronize(st));              // the plan lives on this stack frame
-        } else {
-            HIP_TRY(c, hipEventRecord(c->ev0, st));
-            pga_launch_dp_wave(d_chain, 1, wg, d_mc, buf, wb, st);
-            HIP_TRY(c, hipEventRecord(c->ev1, st));
-        }
+        HIP_TRY(c, hipEventRecord(c->ev0, st));
+        pga_launch_dp_wave(d_chain, 1, wg, d_mc, buf, wb, st);
+        HIP_TRY(c, hipEventRecord(c->ev1, st));
         HIP_TRY(c, hipStreamSynchronize(st));                  // h_cbase lives on this stack frame
     } else {
         pga_launch_dp_prepare(d_chain, 1, 0, n, na, d_mc, buf, st, final);

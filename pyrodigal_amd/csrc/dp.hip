@@ -1630,29 +1630,9 @@ void pga_launch_dp_prepare(const ChainDesc* d_chains, int n_chains, int64_t node
 
 bool pga_dp_use_wave(int n_chains) {
     const char* kern = getenv("PGA_DP_KERNEL");
-    if (kern && *kern) return strcmp(kern, "wave") == 0 || strcmp(kern, "lane") == 0 || strcmp(kern, "contig") == 0;     // the lane and contig kernels read the wave kernel's records
+    if (kern && *kern) return strcmp(kern, "wave") == 0;
     return n_chains >= 2048;
 }
-bool pga_dp_use_contig(int n_chains) {
-    const char* kern = getenv("PGA_DP_KERNEL");
-    if (kern && *kern) return strcmp(kern, "contig") == 0;
-    // opt-in until it beats the one-wave-per-chain kernel on the clock (PGA_DP_CONTIG=1)
-    if (const char* e = getenv("PGA_DP_CONTIG")) return atoi(e) != 0 && n_chains >= 2048;
-    return false;
-}
-bool pga_dp_use_lane(int n_chains) {
-    const char* kern = getenv("PGA_DP_KERNEL");
-    if (kern && *kern) return strcmp(kern, "lane") == 0;
-    if (const char* e = getenv("PGA_DP_LANE")) { if (atoi(e) == 0) return false; }
-    // a wavefront holds 64 chains: below a few waves per SIMD (1024 x 64 chains each) the one-wave-per-chain kernel has more in
-    // flight and wins
-    // (41.5 KB of LDS per wavefront: three wavefronts per compute unit on gfx950's 160 KB, the only part this library runs on --
-    //  pga_create refuses any other)
-    int min_chains = 1 << 30;
-    if (const char* e = getenv("PGA_DP_LANE_MIN")) min_chains = std::max(1, atoi(e));
-    return n_chains >= min_chains;
-}
-
 static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return (e && *e) ? atoi(e) : dflt;

@@ -93,7 +93,6 @@ k_dpw_topo(const int32_t* __restrict__ ndx, const int32_t* __restrict__ stopv, c
     }
     const DpwTopo t = dpw_topo_node(ndx + b0, stopv + b0, type + b0, strand + b0, n, g - b0, have ? &hint : nullptr);
     ta.kf[g] = t.kf; ta.lo[g] = t.lo; ta.q1[g] = t.q1; ta.q2[g] = t.q2;
-    if (ta.tp != nullptr) { ta.tp[2 * (int64_t)g] = make_int4(ndx[g], stopv[g], t.lo, t.q1); ta.tp[2 * (int64_t)g + 1] = make_int4(t.q2, t.kf, 0, 0); }
 }
 
 __global__ void __launch_bounds__(256)

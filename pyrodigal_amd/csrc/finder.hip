@@ -456,7 +456,6 @@ struct WinDesc {
     int64_t topo_off;
     int32_t n;
     int32_t _pad;
-    int64_t il_rec;      // >= 0: the DP pass left its results in the lane kernel's interleaved records, node i at il_rec + 64 i
 };
 struct GcPtrs { const float* p[4]; };      // GroupArrays::gc_cont of every translation-table group
 struct OutArrays {
@@ -476,7 +475,7 @@ struct OutArrays {
 
 __global__ void __launch_bounds__(256)
 k_gather_winners(const WinDesc* __restrict__ wd, int n_win, int64_t out_begin, int64_t total, GroupArrays ga, ChainArrays ca,
-                 DpBuffers dp, OutArrays o, const int4* __restrict__ il_out, const int lean /* 1: only what the device tail walks */) {
+                 DpBuffers dp, OutArrays o, const int lean /* 1: only what the device tail walks */) {
     __shared__ int s_w0;
     const int64_t blk0 = out_begin + (int64_t)blockIdx.x * blockDim.x;
     const int64_t g = blk0 + threadIdx.x;
@@ -497,10 +496,7 @@ k_gather_winners(const WinDesc* __restrict__ wd, int n_win, int64_t out_begin, i
     o.edge_dp[g] = ca.edge[a]; o.cscore_dp[g] = ca.cscore[a]; o.sscore_dp[g] = ca.sscore[a]; o.rscore_dp[g] = ca.rscore[a];
     o.uscore_dp[g] = ca.uscore[a]; o.tscore_dp[g] = ca.tscore[a];
     o.star_ptr[3 * g] = ca.star_ptr[3 * a]; o.star_ptr[3 * g + 1] = ca.star_ptr[3 * a + 1]; o.star_ptr[3 * g + 2] = ca.star_ptr[3 * a + 2];
-    if (w.il_rec >= 0) {
-        const int4 r = il_out[w.il_rec + (int64_t)i * 64];       // {score, traceb | (ov_mark + 1) << 28 or -1, position of the traceb node}
-        o.traceb[g] = dpw_tag_index(r.z); o.ov_mark[g] = (int8_t)dpw_tag_ov(r.z); o.score[g] = __hiloint2double(r.y, r.x);
-    } else { o.traceb[g] = dp.traceb[a]; o.ov_mark[g] = dp.ov_mark[a]; o.score[g] = dp.score[a]; }
+    o.traceb[g] = dp.traceb[a]; o.ov_mark[g] = dp.ov_mark[a]; o.score[g] = dp.score[a];
     // the final-pass fields: fourteen of the thirty per node.  Only the two nodes of a gene are ever looked at unless the caller
     // wants the node arrays, and k_emit_genes can fetch those from where the scorer left them
     if (lean) return;
@@ -1541,39 +1537,10 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
 #define WBUF(field, type) { snprintf(nm, sizeof nm, "dpw_" #field "%d", g); void* p__; int rc__ = ensure_dev(c, nm, sizeof(type) * (size_t)n + 64, &p__); if (rc__) return rc__; wgroups.g[g].field = (type*)p__; }
                 WBUF(kf, uint8_t) WBUF(lo, int32_t) WBUF(q1, int32_t) WBUF(q2, int32_t)
 #undef WBUF
-                wgroups.g[g].tp = nullptr; wgroups.g[g].prog = nullptr;
-                if (pga_dp_use_contig(NCH)) {       // the packed topology and the compiled records of the contig-per-wavefront scorer (opt-in)
-                    { snprintf(nm, sizeof nm, "dpw_tp%d", g); void* p__; int rc__ = ensure_dev(c, nm, sizeof(int4) * 2 * (size_t)n + 64, &p__); if (rc__) return rc__; wgroups.g[g].tp = (int4*)p__; }
-                    { snprintf(nm, sizeof nm, "dpw_prog%d", g); void* p__; int rc__ = ensure_dev(c, nm, sizeof(int4) * 4 * (size_t)n + 64, &p__); if (rc__) return rc__; wgroups.g[g].prog = (int4*)p__; }
-                }
                 wgroups.g[g].ndx = ga[g].ndx; wgroups.g[g].stop_val = ga[g].stop_val; wgroups.g[g].srank = ga[g].srank;
             }
             DEVBUF(w0, double, "dpw_cs", dp_cap + 2) DEVBUF(w1, DpwExt, "dpw_ext", tot_chain_stops + 4)      /* one extras record per (chain, stop node) pair */ DEVBUF(w2, double, "dpw_sfxv", dp_cap) DEVBUF(w3, int32_t, "dpw_sfxi", dp_cap)
             wbuf = DpwBuffers{w0, w1, w2, w3};
-        }
-        // very many chains: one LANE each (dp_lane.hip), on the same records; the results stay in its interleaved layout
-        // many contigs: one wavefront per (contig, group), its lanes the contig's models (dp_contig.hip), on the same records
-        const bool use_contig = use_wave && pga_dp_use_contig(NCH);
-        std::vector<int2> contig_waves;
-        int2* d_contig_waves = nullptr;
-        if (use_contig) {
-            pga_dpc_plan(chains.data(), NCH, contig_waves);
-            DEVBUF(cw, int2, "dpc_waves", contig_waves.size() + 1);
-            HT(c, hipMemcpyAsync(cw, contig_waves.data(), sizeof(int2) * contig_waves.size(), hipMemcpyHostToDevice, st));
-            d_contig_waves = cw;
-        }
-        const bool use_lane = use_wave && !use_contig && pga_dp_use_lane(NCH);
-        DplPlan lane_plan;
-        DplDev lane_dev{};
-        if (use_lane) {
-            pga_dpl_plan(chains.data(), NCH, lane_plan);
-            DEVBUF(l0, int32_t, "dpl_lane_chain", lane_plan.lane_chain.size()) DEVBUF(l1, int64_t, "dpl_wave_base", lane_plan.wave_base.size())
-            DEVBUF(l2, int32_t, "dpl_wave_steps", lane_plan.wave_steps.size())
-            DEVBUF(l3, int4, "dpl_inA", lane_plan.records + 64) DEVBUF(l4, int4, "dpl_inB", lane_plan.records + 64) DEVBUF(l5, int4, "dpl_out", lane_plan.records + 64)
-            HT(c, hipMemcpyAsync(l0, lane_plan.lane_chain.data(), sizeof(int32_t) * lane_plan.lane_chain.size(), hipMemcpyHostToDevice, st));
-            HT(c, hipMemcpyAsync(l1, lane_plan.wave_base.data(), sizeof(int64_t) * lane_plan.wave_base.size(), hipMemcpyHostToDevice, st));
-            HT(c, hipMemcpyAsync(l2, lane_plan.wave_steps.data(), sizeof(int32_t) * lane_plan.wave_steps.size(), hipMemcpyHostToDevice, st));
-            lane_dev = DplDev{l0, l1, l2, l3, l4, l5, lane_plan.n_waves, lane_plan.max_steps};
         }
         DpSegDev seg_dev{};
         if (segmented) {
@@ -1584,7 +1551,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         // start order of the wave-batch scorer: longest chains first (counting sort on nodes / 64 = walk batches)
         int32_t* d_dp_order = nullptr;
         std::vector<int32_t> dp_order;
-        if (use_wave && !use_contig && !use_lane && NCH > 1 && !getenv("PGA_DP_NO_ORDER")) {
+        if (use_wave && NCH > 1 && !getenv("PGA_DP_NO_ORDER")) {
             std::vector<int32_t> lens((size_t)NCH);
             for (int k = 0; k < NCH; k++) lens[(size_t)k] = chains[k].n;
             dp_order.resize((size_t)NCH);
@@ -1665,10 +1632,9 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             sp.cs_out = nullptr;
             if (use_wave) {
                 pga_launch_dpw_topo(wgroups.g[g], ga[g].type, ga[g].strand, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], st);
-                if (pga_dp_use_contig(NCH)) pga_launch_dpc_compile(wgroups.g[g], d_cbase + (size_t)g * (NC + 1), NC, st);
                 sl.topo_q2 = wgroups.g[g].q2; sl.ext = wbuf.ext; sp.cs_out = wbuf.cs;
                 // (the same condition as the lean gather's direct mode further down: the node arrays stay on the device)
-                sl.fill_star_ptr = !(stage == 0 && !P.want_nodes && !use_lane && !(getenv("PGA_TAIL") && strcmp(getenv("PGA_TAIL"), "host") == 0) &&
+                sl.fill_star_ptr = !(stage == 0 && !P.want_nodes && !(getenv("PGA_TAIL") && strcmp(getenv("PGA_TAIL"), "host") == 0) &&
                                      !getenv("PGA_FULL_GATHER") && !getenv("PGA_GATHER_ALL_DP"));
             }
             pga_launch_score(d_chains + g_c0[g], nch, g_n0[g], nn, d_dig, d_ct, ga[g], d_models, f->d_msc, c->d_model_const, ca, sp,
@@ -1729,9 +1695,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         }
         // one DP launch over the chains of every group: chains are independent, the more in flight the better
         HT(c, hipEventRecord(f->e_dp0[0], st));
-        if (use_contig) pga_launch_dp_contig(d_contig_waves, (int)contig_waves.size(), d_chains, wgroups, c->d_model_const, dp, wbuf, st);
-        else if (use_lane) pga_launch_dp_lane(d_chains, wgroups, c->d_model_const, dp, wbuf, lane_dev, st);
-        else if (use_wave) {
+        if (use_wave) {
             // PGA_DP_PROFILE=1: cycles per batch phase of every 64th chain (a synchronising debug aid)
             if (getenv("PGA_DP_PROFILE")) {
                 DEVBUF(d_prof, unsigned long long, "dp_prof", 16);
@@ -1842,7 +1806,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                 const int k = win_chain[i];
                 if (k < 0 || (P.meta ? f->model_group[chains[k].model] : 0) != g) continue;
                 out_off[i] = out_nodes;
-                wg[g].push_back(WinDesc{out_nodes, chains[k].off, fin_off[i], chains[k].topo_off, chains[k].n, 0, use_lane ? lane_plan.chain_rec[(size_t)k] : -1});
+                wg[g].push_back(WinDesc{out_nodes, chains[k].off, fin_off[i], chains[k].topo_off, chains[k].n, 0});
                 out_nodes += chains[k].n;
             }
         }
@@ -1874,8 +1838,8 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             OB(edge, uint8_t) OB(cscore, double) OB(sscore, double) OB(rscore, double) OB(uscore, double) OB(tscore, double) OB(mot_score, double)
             OB(mot_ndx, int32_t) OB(rbs, uint8_t) OB(mot_len, uint8_t) OB(mot_spacer, uint8_t) OB(mot_spacendx, uint8_t)
         }
-        // lean, the device tail, and no lane kernel (its results sit in interleaved records): gather only what the tail writes
-        o.direct = (lean_gather && !use_lane && !getenv("PGA_GATHER_ALL_DP")) ? 1 : 0;
+        // lean and the device tail: gather only what the tail writes
+        o.direct = (lean_gather && !getenv("PGA_GATHER_ALL_DP")) ? 1 : 0;
         for (int g = 0; g < 4; g++) {
             const bool in = g < NG;
             o.g_ndx[g] = in ? ga[g].ndx : nullptr; o.g_stop_val[g] = in ? ga[g].stop_val : nullptr;
@@ -1893,8 +1857,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                 HT(c, hipMemcpyAsync(d_win + k0, wg[g].data(), sizeof(WinDesc) * wg[g].size(), hipMemcpyHostToDevice, st));
                 const int64_t nn = w_o0[g + 1] - w_o0[g];
                 if (nn > 0)
-                    hipLaunchKernelGGL(k_gather_winners, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, d_win + k0, (int)wg[g].size(), w_o0[g], nn, ga[g], ca, dp, o,
-                                       (const int4*)lane_dev.out, lean_gather ? 1 : 0);
+                    hipLaunchKernelGGL(k_gather_winners, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, d_win + k0, (int)wg[g].size(), w_o0[g], nn, ga[g], ca, dp, o, lean_gather ? 1 : 0);
                 k0 += wg[g].size();
             }
         }

@@ -129,9 +129,7 @@ struct DpwExt;
 // topology of one translation-table group: what depends on positions and kinds only, shared by every model of a contig
 // srank: per node (stop nodes only) its rank among the stop nodes of its contig, or nullptr: then the extras record of node i of a
 // chain is ext[off + i]; with it, ext[soff + srank[i]] (one 64-byte record per (chain, stop node) pair, dense)
-// prog (optional): the topology compiled for the contig-per-wavefront scorer, four int4 per node (dpc_core.h DpcProg)
-// tp (optional): the same fields packed for the contig-per-wavefront scorer, two int4 per node: {ndx, stop_val, lo, q1}, {q2, kf, 0, 0}
-struct DpwTopoArrays { const int32_t* ndx; const int32_t* stop_val; uint8_t* kf; int32_t* lo; int32_t* q1; int32_t* q2; const int32_t* srank = nullptr; int4* tp = nullptr; int4* prog = nullptr; };
+struct DpwTopoArrays { const int32_t* ndx; const int32_t* stop_val; uint8_t* kf; int32_t* lo; int32_t* q1; int32_t* q2; const int32_t* srank = nullptr; };
 struct DpwGroupPtrs { DpwTopoArrays g[4]; };
 // per chain node: cs = cscore + sscore, suffix maxima of finished blocks; per stop node a 64-byte record of extras (indexed by
 // node, or dense by (chain, stop) pair: DpwTopoArrays::srank)
@@ -146,39 +144,6 @@ void pga_launch_dpw_chain(const ChainDesc* d_chains, int n_chains, int64_t node_
 // d_order (optional): the order in which the chains are started -- a launch ends when its last chain does, so long chains go first
 void pga_launch_dp_wave(const ChainDesc* d_chains, int n_chains, const DpwGroupPtrs& groups, const ModelConst* d_models, DpBuffers buf,
                         const DpwBuffers& wb, hipStream_t st, const int32_t* d_order = nullptr, int n_blocks = 0 /* entries of d_order; < 0 = filler */);
-
-// ---- lane-per-chain connection scoring for launches with very many chains (dp_lane.hip, dpl_core.h) ----
-// 64 chains to a wavefront, one lane each; the records of a wave are interleaved (node t of lane l at wave_base + 64 t + l)
-struct DplPlan {        // host side
-    std::vector<int32_t> lane_chain;    // [n_waves][64]: chain of every lane, -1 = none
-    std::vector<int64_t> wave_base;     // [n_waves + 1]: first record of the wave
-    std::vector<int32_t> wave_steps;    // [n_waves]: nodes of its longest chain
-    std::vector<int64_t> chain_rec;     // [n_chains]: record of node 0 of the chain (node i at chain_rec + 64 i)
-    int64_t records = 0;
-    int n_waves = 0, max_steps = 0;
-};
-struct DplDev { const int32_t* lane_chain; const int64_t* wave_base; const int32_t* wave_steps; int4* inA; int4* inB; int4* out; int n_waves, max_steps; bool dense_ext = false; };
-// which connection scorer a final-pass launch uses: lane-per-chain when there are chains enough to fill the chip that way
-// (PGA_DP_KERNEL=lane forces it, any other value of PGA_DP_KERNEL or PGA_DP_LANE=0 rules it out)
-bool pga_dp_use_lane(int n_chains);
-void pga_dpl_plan(const ChainDesc* h_chains, int n_chains, DplPlan& plan);
-// input records from the topology arrays + wb.cs, then the walk; results: the interleaved records L.out and buf.max_index / max_score / ipath
-void pga_launch_dp_lane(const ChainDesc* d_chains, const DpwGroupPtrs& groups, const ModelConst* d_models, DpBuffers buf, const DpwBuffers& wb,
-                        const DplDev& L, hipStream_t st);
-// buf.score / traceb / ov_mark / tbn of chains[0..n_chains) (contiguous in `off` from node_begin) from the interleaved records
-void pga_launch_dpl_unpack(const ChainDesc* d_chains, int n_chains, const int64_t* d_chain_rec, int64_t node_begin, int64_t total, const DplDev& L,
-                           DpBuffers buf, hipStream_t st);
-
-// ---- contig-per-wavefront connection scoring for launches with many contigs (dp_contig.hip, dpc_core.h) ----
-// one wavefront per (contig, translation-table group), its lanes the models scored on the contig; reads the wave-batch scorer's
-// records (topology arrays, cs, extras of the stop nodes)
-bool pga_dp_use_contig(int n_chains);
-// waves[k] = (first chain, number of chains) of a run of chains on one contig and group, longest contigs first
-void pga_dpc_plan(const ChainDesc* h_chains, int n_chains, std::vector<int2>& waves);
-// compiles the topology of every contig of a group into ta.prog (after pga_launch_dpw_topo; d_cbase: first node of every contig)
-void pga_launch_dpc_compile(const DpwTopoArrays& ta, const int32_t* d_cbase, int n_contigs, hipStream_t st);
-void pga_launch_dp_contig(const int2* d_waves, int n_waves, const ChainDesc* d_chains, const DpwGroupPtrs& groups, const ModelConst* d_models,
-                          DpBuffers buf, const DpwBuffers& wb, hipStream_t st);
 
 // kernel launchers (dp.hip)
 // chains[0..n_chains) must be contiguous in `off`; node_begin = chains[0].off, total_nodes = their node count

@@ -117,11 +117,9 @@ def test_training_pass_is_rejected_loudly(ctx):
         ctx.score_connections([0], [0], [0], [1], [0.0], [0.0], [0.0], [0.0], np.zeros((1, 3)), 4.35, final=False)
 
 
-@pytest.mark.parametrize("variant", ["contig", "wave", "lane", "tree1", "tree3", "scan1", "scan4", "scan16"])
+@pytest.mark.parametrize("variant", ["wave", "tree1", "tree3", "scan1", "scan4", "scan16"])
 def test_dp_kernel_variants_agree_with_oracle(ctx, variant, monkeypatch):
-    # contig = the contig-per-wavefront kernel of launches with many contigs (dp_contig.hip: lanes = the models of a contig);
-    # wave = the wave-batch kernel of launches with many chains (dp_wave.hip); lane = the lane-per-chain kernel of launches with very
-    # many chains (dp_lane.hip); tree3 = the chain kernel of few long chains;
+    # wave = the wave-batch kernel of launches with many chains (dp_wave.hip); tree3 = the chain kernel of few long chains;
     # tree1 = its one-wave form; PGA_DP_KERNEL=scan selects the window-scanning kernels with 1, 4 or 16 wavefronts per chain,
     # kept as an independent cross-check
     if variant.startswith("scan"):
@@ -145,7 +143,7 @@ def test_dp_kernel_variants_agree_with_oracle(ctx, variant, monkeypatch):
     ("GCF_001457455.1_NCTC11397_genomic", "GCF_001457455.1_NCTC11397_genomic.tinf_closed.bin.gz", True),
     ("KK037166", "GCF_001457455.1_NCTC11397_genomic_100kb.tinf_closed.bin.gz", False),
 ])
-@pytest.mark.parametrize("kernel", ["contig", "wave", "lane"])
+@pytest.mark.parametrize("kernel", ["wave"])
 def test_wave_kernel_on_reference_fixtures(ctx, name, model_file, closed, kernel, monkeypatch):
     # the kernels of many-chain launches, forced onto single chains: short contigs, and the full genome, whose 153 296 nodes
     # slide the 1000-node window over 2400 blocks (suffix maxima, both block-range ends; the lane kernel's running maxima against
@@ -157,7 +155,7 @@ def test_wave_kernel_on_reference_fixtures(ctx, name, model_file, closed, kernel
         check(ctx, seq, tinf, closed=closed, is_meta=is_meta)
 
 
-@pytest.mark.parametrize("kernel", ["contig", "wave", "lane"])
+@pytest.mark.parametrize("kernel", ["wave"])
 def test_wave_kernel_on_synthetic_and_gene_dense_input(ctx, kernel, monkeypatch):
     monkeypatch.setenv("PGA_DP_KERNEL", kernel)
     tinf = orc.Training.load(golden_path("SRR492066.training.bin.gz"))

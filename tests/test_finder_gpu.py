@@ -191,7 +191,7 @@ def test_both_tails_give_the_same_result(ctx, models, tail, monkeypatch):
             assert n > 0
 
 
-@pytest.mark.parametrize("kernel", ["contig", "wave", "lane", "tree3"])
+@pytest.mark.parametrize("kernel", ["wave", "tree3"])
 def test_connection_scoring_kernels_inside_the_finder(ctx, models, kernel, monkeypatch):
     # batches this small take the chain kernel by default; forcing either kernel must not change one node field:
     # several models per contig, two translation-table groups, empty and sub-window contigs, every node against the oracle

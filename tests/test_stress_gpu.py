@@ -49,9 +49,8 @@ def test_dp_kernels_and_tails_agree_on_random_gene_dense_contigs(monkeypatch):
     for name, env in (("tree+auto", {}), ("scan+host", {"PGA_DP_KERNEL": "scan", "PGA_TAIL": "host"}),
                       ("tree1+device", {"PGA_DP_KERNEL": "tree1", "PGA_TAIL": "device"}), ("tree3+host", {"PGA_DP_KERNEL": "tree3", "PGA_TAIL": "host"}),
                       # the kernels every headline number comes from, forced onto this small launch: the wave-batch connection
-                      # scorer, the lane-per-chain connection scorer and the LDS-table form of the coding score
-                      ("wave+ldscs", {"PGA_DP_KERNEL": "wave", "PGA_CS_LDS": "2"}), ("lane+ldscs", {"PGA_DP_KERNEL": "lane", "PGA_CS_LDS": "2"}),
-                      ("contig+ldscs", {"PGA_DP_KERNEL": "contig", "PGA_CS_LDS": "2"}),
+                      # scorer and the LDS-table form of the coding score
+                      ("wave+ldscs", {"PGA_DP_KERNEL": "wave", "PGA_CS_LDS": "2"}),
                       # the coding score by per-lane table gathers (the fallback when a contig's models are not neighbours in the table)
                       ("wave+topowalk", {"PGA_DP_KERNEL": "wave", "PGA_DPW_TOPO_WALK": "1"}),
                       ("tree+globalcs", {"PGA_CS_LDS": "0"}), ("scan+globalcs", {"PGA_DP_KERNEL": "scan", "PGA_TAIL": "host", "PGA_CS_LDS": "0"}),

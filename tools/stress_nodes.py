@@ -1,5 +1,5 @@
 """Randomised sweep on the GPU box: `python tools/stress_nodes.py SEED0 SEED1 [SECONDS]` (the connection scorer and the coding-score form
-are drawn per seed: default / wave / lane / contig, LDS tables or per-lane gathers for the coding score) -- every node field of every contig (scores, RBS bins,
+are drawn per seed: default / wave, LDS tables or per-lane gathers for the coding score) -- every node field of every contig (scores, RBS bins,
 motifs, traceback, elimination flags) and every gene against the CPU oracle, in meta and single mode, open and closed ends, with
 and without masking."""
 import importlib.util
@@ -27,7 +27,7 @@ kinds = {}
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     if time.time() - t0 > budget: break
     rng = np.random.default_rng(seed)
-    kern = [None, 'wave', 'lane', 'contig'][seed % 4]
+    kern = [None, 'wave'][seed % 2]
     for k_ in ('PGA_DP_KERNEL', 'PGA_CS_LDS'): os.environ.pop(k_, None)
     if kern: os.environ['PGA_DP_KERNEL'] = kern
     if (seed // 4) % 2: os.environ['PGA_CS_LDS'] = '0'           # the coding score by per-lane table gathers instead of the LDS tables

@@ -33,7 +33,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         ctx.set_models(models if meta else models[int(rng.integers(0, 16)):][:1])
         res = []
         for env in ({}, {"PGA_DP_KERNEL": "scan", "PGA_TAIL": "host"}, {"PGA_DP_KERNEL": "tree1", "PGA_TAIL": "device"}, {"PGA_DP_KERNEL": "tree3", "PGA_TAIL": "device"},
-                    {"PGA_DP_KERNEL": "wave"}, {"PGA_DP_KERNEL": "lane", "PGA_CS_LDS": "0"}, {"PGA_DP_KERNEL": "contig"},
+                    {"PGA_DP_KERNEL": "wave"}, {"PGA_DP_KERNEL": "wave", "PGA_CS_LDS": "0"},
                     {"PGA_DP_KERNEL": "wave", "PGA_TP_STEPS": "1", "PGA_STAGE_SHIFT": "5", "PGA_DPW_TOPO_WALK": "1"}):
             for k in ("PGA_DP_KERNEL", "PGA_TAIL", "PGA_CS_LDS", "PGA_TP_STEPS", "PGA_STAGE_SHIFT", "PGA_DPW_TOPO_WALK"): os.environ.pop(k, None)
             os.environ.update(env)
@@ -42,4 +42,4 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
             if r.genes.tobytes() != res[0].genes.tobytes() or not np.array_equal(r.contigs["model"], res[0].contigs["model"]):
                 print("MISMATCH seed", seed, meta, mask, closed); sys.exit(1)
         tot += len(res[0].genes)
-print("seeds", sys.argv[1], "+", seeds_done, ": eight kernel / tail / staging variants x three modes agree on", 900 * seeds_done, "contig runs;", tot, "genes; %.0f s" % (time.time() - t0))
+print("seeds", sys.argv[1], "+", seeds_done, ": seven kernel / tail / staging variants x three modes agree on", 900 * seeds_done, "contig runs;", tot, "genes; %.0f s" % (time.time() - t0))
