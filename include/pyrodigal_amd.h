@@ -125,7 +125,9 @@ int         pga_device_info(const pga_ctx*, char* name, int name_len, int* cus, 
  * context ran (diagnostics; no counterpart in the reference, whose dynamic programme is one serial loop):
  *   out[0] chains that were cut into segments (0: every chain was walked serially)   out[1] segments
  *   out[2..4] nodes whose speculative result the verification rounds 1..3 rejected
- *   out[5] chains that were walked serially in the end because they never verified clean */
+ *   out[5] chains that were walked serially in the end because they never verified clean
+ *   out[6] 32-byte slots the step schedule of the wave-batch scorer took (0: no schedule)   out[7] 64-node batches whose schedule
+ *          did not fit its buffer (> 0: the launch was repeated by the kernel that works the lane masks out per chain) */
 int         pga_dp_stats(const pga_ctx*, int32_t out[8]);
 /* How a connection-scoring launch over chains of these node counts would be cut (host arithmetic only, no device needed;
  * the PGA_DP_SEG* environment variables of INTEGRATION.md apply):

@@ -234,7 +234,8 @@ class Context:
         rc = self.L.pga_dp_stats(self.h, out)
         if rc != PGA_OK:
             _raise(self.L, self.h, rc, "pga_dp_stats")
-        return {"chains": out[0], "segments": out[1], "rejected": [out[2], out[3], out[4]], "serial": out[5]}
+        return {"chains": out[0], "segments": out[1], "rejected": [out[2], out[3], out[4]], "serial": out[5],
+                "sched_slots": out[6], "sched_missed": out[7]}
 
     @staticmethod
     def dp_kernel_name():

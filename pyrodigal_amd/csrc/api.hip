@@ -252,8 +252,23 @@ static int score_connections_impl(pga_ctx* c, int32_t n, const int32_t* ndx, con
         wg.g[0].ndx = nd.ndx; wg.g[0].stop_val = nd.stop_val;
         pga_launch_dpw_topo(wg.g[0], nd.type, nd.strand, d_cbase, 1, n, st);
         pga_launch_dpw_chain(d_chain, 1, 0, n, na, wg.g[0], d_mc, wb, st);
+        bool sched = pga_dpw_use_sched();
+        if (sched) {
+            // the step schedule of this one contig (the chain's sched_b0 is 0); a buffer it does not fit sends the launch to k_dpw_dyn
+            int32_t* d_bbase;
+            const int nbat = (n + 63) >> 6;
+            const int32_t h_bbase[2] = {0, nbat};
+            uint32_t h_cur[2] = {0, 0};
+            HIP_TRY(c, db.alloc(&wg.g[0].shdr, (size_t)nbat + 1)); HIP_TRY(c, db.alloc(&wg.g[0].sent, 2 * (size_t)DPW_SCHED_STRIDE * ((size_t)nbat + 1) + 8)); HIP_TRY(c, db.alloc(&wg.g[0].scur, 16));
+            HIP_TRY(c, db.alloc(&d_bbase, 2));
+            HIP_TRY(c, hipMemcpyAsync(d_bbase, h_bbase, sizeof h_bbase, hipMemcpyHostToDevice, st));
+            pga_launch_dpw_sched(wg.g[0], d_cbase, d_bbase, 1, nbat, st);
+            HIP_TRY(c, hipMemcpyAsync(h_cur, wg.g[0].scur, sizeof h_cur, hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
+            if (h_cur[1] != 0) sched = false;
+        }
         HIP_TRY(c, hipEventRecord(c->ev0, st));
-        pga_launch_dp_wave(d_chain, 1, wg, d_mc, buf, wb, st);
+        pga_launch_dp_wave(d_chain, 1, wg, d_mc, buf, wb, st, nullptr, 0, sched);
         HIP_TRY(c, hipEventRecord(c->ev1, st));
         HIP_TRY(c, hipStreamSynchronize(st));                  // h_cbase lives on this stack frame
     } else {

@@ -25,6 +25,7 @@
 #include <type_traits>
 #include "dev_common.h"
 #include "dpw_core.h"
+#include "dpw_walk_gfx950.inc"     // DPW_ASM_NEAR / DPW_ASM_WALK: the pair steps of k_dp_wave in gfx950 assembly (tools/gen_dpw_walk.py)
 
 namespace {
 
@@ -338,12 +339,97 @@ __device__ __forceinline__ void wave_step(const SrcRegs& R, const int u, const i
     if (in_mask(take)) { L.val = val; L.tag = tag; }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The step schedule of a group (dpw_core.h "Step schedule"): for every 64-node batch of a contig, which sources take a pair step
+// onto it and which lanes each of them can reach -- once per (contig, translation table) instead of once per step of every model's
+// chain.  One workgroup per contig (and per run of 16 batches of a long one), a wavefront per batch; batch g of the group owns the
+// DPW_SCHED_STRIDE 32-byte slots from g * DPW_SCHED_STRIDE on, so nothing is counted, searched or handed out by an atomic (the
+// first form took one slot counter for the launch: 70 000 atomics on one address were two thirds of a millisecond).  A batch needs
+// one slot per reverse node that reaches a lane and two per forward stop; 55 on config-4 contigs.  One whose bound (by kinds alone)
+// does not fit is marked and counted in scur[1], and the launch then falls back to k_dpw_dyn.
+__global__ void __launch_bounds__(256)
+k_dpw_sched(const int32_t* __restrict__ cbase, const int32_t* __restrict__ bbase, const DpwTopoArrays ta) {
+    const int c = blockIdx.x, lane = threadIdx.x & 63;
+    const int base = cbase[c], n = cbase[c + 1] - base;
+    const int b = (blockIdx.y << 4) + (threadIdx.x >> 6) * 4;      // this wavefront's four batches: b .. b + 3
+    const int32_t* __restrict__ ndx = ta.ndx + base; const int32_t* __restrict__ stopv = ta.stop_val + base;
+    const uint8_t* __restrict__ kfp = ta.kf + base;
+    const int bb0 = bbase[c];
+    for (int bi = b; bi < b + 4 && (bi << 6) < n; bi++) {
+        const int i0 = bi << 6, bg = bb0 + bi;
+        const int i = i0 + lane;
+        const bool act = i < n;
+        const int ii = act ? i : n - 1;
+        const int my_kf = kfp[ii];
+        const DpwST T = dpw_st(act ? i : -1, my_kf, ndx[ii], stopv[ii], ta.lo[base + ii]);
+        const bool gb = act && (T.kind == 0 || T.kind == 3);
+        const int jm = wave_min_i32(gb ? max(ta.q1[base + ii], T.lo) : i0);
+        // slots: an upper bound from the kinds alone
+        unsigned ub = __popcll(vote(act && T.kind != 0)) + __popcll(vote(act && T.kind == 1));
+        for (int t0 = jm; t0 < i0; t0 += 64) {
+            const int j = t0 + lane;
+            const int k = j < i0 ? DPW_KIND(kfp[j]) : 0;
+            ub += __popcll(vote(k != 0)) + __popcll(vote(k == 1));
+        }
+        if (ub > DPW_SCHED_STRIDE) {
+            if (lane == 0) { atomicAdd(&ta.scur[1], 1u); ta.shdr[bg] = DpwSchedHdr{DPW_SCHED_NONE, 0u, jm, 0}; }
+            continue;
+        }
+        const unsigned off = (unsigned)bg * DPW_SCHED_STRIDE;
+        uint4* out = ta.sent + 2 * (size_t)off;
+        auto emit = [&](const int j, const int u, const int ukf, const int s_ndx, const int s_stop, const bool in_batch) -> int {
+            const int sk = DPW_KIND(ukf), sf = DPW_FRAME(ukf);
+            const unsigned bits = dpw_static_bits(T, j, sk, sf, s_ndx, s_stop);
+            const lanemask m0 = vote((bits & 1u) != 0), m1 = vote((bits & 2u) != 0);
+            lanemask m2 = 0, m3 = 0, m4 = 0, m5 = 0;
+            if (sk == 1) {
+                m2 = vote((bits & 4u) != 0); m3 = vote((bits & 8u) != 0); m4 = vote((bits & 16u) != 0);
+                if (in_batch) m5 = vote(lane < u && dpw_static_pull(T, sf, s_stop));
+            }
+            if (!(m0 | m1 | m2 | m3 | m4 | m5)) return 0;
+            if (lane == 0) {
+                out[0] = make_uint4((unsigned)u, (unsigned)s_ndx, DPW_E_CODE(sk, sf), (unsigned)j);
+                out[1] = make_uint4((unsigned)m0, (unsigned)(m0 >> 32), (unsigned)m1, (unsigned)(m1 >> 32));
+                if (sk == 1) {
+                    out[2] = make_uint4((unsigned)m2, (unsigned)(m2 >> 32), (unsigned)m3, (unsigned)(m3 >> 32));
+                    out[3] = make_uint4((unsigned)m4, (unsigned)(m4 >> 32), (unsigned)m5, (unsigned)(m5 >> 32));
+                }
+            }
+            out += 2 * DPW_E_SLOTS(sk);
+            return 1;
+        };
+        int n_near = 0, n_own = 0;
+        for (int t0 = jm; t0 < i0; t0 += 64) {
+            const int j = t0 + lane;
+            const bool in = j < i0;
+            const int jj = in ? j : i0 - 1;
+            const int s_kf = kfp[jj], s_nd = ndx[jj], s_sv = stopv[jj];
+            lanemask visit = vote(in && DPW_KIND(s_kf) != 0);
+            while (visit) {
+                const int u = __builtin_ctzll(visit);
+                visit &= visit - 1;
+                n_near += emit(t0 + u, u, rl_i32(s_kf, u), rl_i32(s_nd, u), rl_i32(s_sv, u), false);
+            }
+        }
+        {
+            lanemask visit = vote(act && T.kind != 0);
+            while (visit) {
+                const int u = __builtin_ctzll(visit);
+                visit &= visit - 1;
+                n_own += emit(i0 + u, u, rl_i32(my_kf, u), rl_i32(T.ndx, u), rl_i32(T.stop_val, u), true);
+            }
+        }
+        if (lane == 0) ta.shdr[bg] = DpwSchedHdr{off, (unsigned)n_near | ((unsigned)n_own << 16), jm, 0};
+    }
+}
+
 // OCC: wavefronts per SIMD the register budget is cut for (PGA_DPW_OCC).  The kernel wants 103 VGPRs: 4 spills nothing (config 4:
 // 4.53 ms per launch, HBM traffic 1.55x the algorithmic bytes), 5 (the default) spills 16 bytes per lane (4.06 ms, 1.9x), 6 spills
 // 64 bytes (3.98 ms, 3.0x).  A chain's walk is a chain of dependent instructions: a fifth wavefront per SIMD fills its gaps.
 template <int OCC>
 __global__ void __launch_bounds__(64, OCC)
-k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const double* __restrict__ g_cs, const DpwExt* __restrict__ g_ext,
+k_dpw_dyn(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const double* __restrict__ g_cs, const DpwExt* __restrict__ g_ext,
           const ModelConst* __restrict__ models, DpBuffers buf, double* __restrict__ g_sfxv, int32_t* __restrict__ g_sfxi,
           const int32_t* __restrict__ order /* or nullptr: workgroup b walks chain order[b] (longest chains first) */) {
     __shared__ double s_igm[64];
@@ -648,6 +734,396 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// k_dp_wave: the same batch structure as k_dpw_dyn above, its pair steps -- the near steps (2) and the in-batch walk (6) --
+// driven by the group's step schedule.  An entry arrives through scalar loads (the schedule is read through the constant address
+// space: it was written by an earlier launch) and carries the lanes the source can reach; a step is the source's value
+// (v_readlane), one add, one compare under the entry's mask.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) u32x4 k_uint4;
+__device__ __forceinline__ lanemask mk64(const unsigned lo, const unsigned hi) { return (lanemask)lo | ((lanemask)hi << 32); }
+
+// ASM: the steps as the assembly blocks of dpw_walk_gfx950.inc; else as the C++ lambdas below (the readable statement of the same
+// steps, kept as a cross-check: PGA_DPW_ASM=0)
+template <int OCC, bool ASM>
+__global__ void __launch_bounds__(64, OCC)
+k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const double* __restrict__ g_cs, const DpwExt* __restrict__ g_ext,
+          const ModelConst* __restrict__ models, DpBuffers buf, double* __restrict__ g_sfxv, int32_t* __restrict__ g_sfxi,
+          const int32_t* __restrict__ order /* or nullptr: workgroup b walks chain order[b] (longest chains first) */) {
+    __shared__ double s_igm[64];
+    const int chain = order != nullptr ? order[blockIdx.x] : (int)blockIdx.x;
+    if (chain < 0) return;                          // a filler: the per-XCD queues of the start order are not equally long
+    const ChainDesc cd = chains[chain];
+    const int lane = threadIdx.x;
+    const int n = cd.n;
+    const ModelConst* mc = &models[cd.model];
+    s_igm[lane] = mc->igm[lane];
+    __syncthreads();
+    const double NEG_INF = -__builtin_huge_val();
+    const DpwModel M{mc->st_wt, mc->negc, s_igm};
+    WavePtrs P;
+    k_uint4* s_hdr; k_uint4* s_ent;
+    {
+        const DpwTopoArrays& ta = groups.g[cd.group];
+        P.ndx = ta.ndx + cd.topo_off; P.stopv = ta.stop_val + cd.topo_off; P.kf = ta.kf + cd.topo_off;
+        P.lo = ta.lo + cd.topo_off; P.q1 = ta.q1 + cd.topo_off; P.q2 = ta.q2 + cd.topo_off;
+        P.cs = g_cs + cd.off;
+        P.srank = ta.srank != nullptr ? ta.srank + cd.topo_off : nullptr;
+        P.ext = g_ext + (ta.srank != nullptr ? cd.soff : cd.off);
+        P.score = buf.score + cd.off; P.traceb = buf.traceb + cd.off; P.tbn = buf.tbn + cd.off; P.ov = buf.ov_mark + cd.off;
+        P.sfxv = g_sfxv + cd.off; P.sfxi = g_sfxi + cd.off;
+        s_hdr = (k_uint4*)(ta.shdr) + cd.sched_b0;
+        s_ent = (k_uint4*)(ta.sent);
+    }
+    // a launch ends when its longest chain does: long chains issue first, the short ones fill their stalls
+    if (n >= 2048) __builtin_amdgcn_s_setprio(3); else if (n >= 1536) __builtin_amdgcn_s_setprio(2); else if (n >= 1024) __builtin_amdgcn_s_setprio(1);
+    const bool long_chain = n > 2 * DPW_MAX_NODE_DIST;         // only then can a window start past node 0
+    double end_best = -1.0; int end_idx = -1, end_tb = -1;
+    double s1v = NEG_INF, s2v = NEG_INF, ppv = NEG_INF; int s1i = -1, s2i = -1, ppi = -1;
+    double rv0 = NEG_INF, rv1 = NEG_INF, rv2 = NEG_INF; int ri0 = -1, ri1 = -1, ri2 = -1, rn0 = -1, rn1 = -1, rn2 = -1;
+    int l3i0 = -1, l3i1 = -1, l3i2 = -1, l3s0 = 0, l3s1 = 0, l3s2 = 0, l3n0 = 0, l3n1 = 0, l3n2 = 0;
+    double l3v0 = 0.0, l3v1 = 0.0, l3v2 = 0.0;
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));      // lanes before this one
+
+    const int nb = (n + 63) >> 6;
+    const bool prof = buf.prof != nullptr && (blockIdx.x & 63) == 0;
+    unsigned long long tp = prof ? __builtin_readcyclecounter() : 0;
+    auto mark = [&](const int slot) {
+        if (!prof) return;
+        const unsigned long long now = __builtin_readcyclecounter();
+        if (lane == 0) atomicAdd(&buf.prof[slot], now - tp);
+        tp = now;
+    };
+    for (int b = 0; b < nb; b++) {
+        const int i0 = b << 6;
+        const u32x4 hdr = s_hdr[b];                 // {first slot, near entries | own entries << 16, jm, -}
+        DpwT T; int kfb;
+        load_target_w(T, kfb, P, i0, lane, n, M.negc);
+        const DpwLT LT = dpw_lean(T);
+        const bool act = T.i >= 0;
+        // reverse stops with an overlapping start in frame f: the one lane mask of a step that depends on the model
+        const lanemask r3v0 = vote(act && T.kind == 3 && (T.vm & 1)), r3v1 = vote(act && T.kind == 3 && (T.vm & 2)), r3v2 = vote(act && T.kind == 3 && (T.vm & 4));
+        // what a reverse-stop source adds: a reverse start of its frame takes its own cs, a reverse stop the x of that frame
+        const double xs0 = (T.kind == 2 && T.frame == 0) ? T.cs : T.x0, xs1 = (T.kind == 2 && T.frame == 1) ? T.cs : T.x1,
+                     xs2 = (T.kind == 2 && T.frame == 2) ? T.cs : T.x2;
+        const int fbit = 1 << T.frame;
+        mark(0);
+        DpwLane L{0.0, -1};
+        int tbn_pre = -1;                   // position of the traceb node while it is older than the batch
+        auto take = [&](const bool ok, const double val, const int j, const int ov1, const int s_ndx) {
+            const int cur = dpw_tag_index(L.tag);
+            if (ok && (val > L.val || (val == L.val && j > cur))) { L.val = val; L.tag = j | (ov1 << DPW_TAG_BITS); tbn_pre = s_ndx; }
+        };
+        // One scheduled step.  h = {lane, s_ndx, code, j}; the source's values come from lane u of the registers handed in (a tile
+        // of finished nodes for the near steps; the batch itself for the walk); s_tbn() = position of the source's own traceb node.
+        // A step only works out WHICH lanes take the source (tk), at what value and tag; the caller commits with three selects,
+        // whatever the kind -- straight-line code between an entry's loads and the next entry's.
+        auto step_r5 = [&](const u32x4 h, const u32x4 ma, const double s_score, lanemask& tk, double& val) {
+            const lanemask m0 = mk64(ma.x, ma.y), m1 = mk64(ma.z, ma.w);
+            val = s_score + M.negc;
+            if (m1) { if (in_mask(m1)) { const int d = T.ndx - (int)h.y; val = s_score + (d <= DPW_OPER_DIST ? s_igm[d] : 0.0); } }
+            tk = m0 & vote(val >= L.val);
+        };
+        auto step_r3 = [&](const u32x4 h, const u32x4 ma, const double s_score, lanemask& tk, double& val) {
+            const int sf = DPW_E_FRAME(h.z);
+            const lanemask ok = mk64(ma.x, ma.y) | (mk64(ma.z, ma.w) & pick3m(sf, r3v0, r3v1, r3v2));
+            if (sf == 0) { val = s_score + xs0; asm volatile("; frame 0"); }
+            else if (sf == 1) { val = s_score + xs1; asm volatile("; frame 1"); }
+            else { val = s_score + xs2; asm volatile("; frame 2"); }
+            tk = ok & vote(val >= L.val);
+        };
+        auto step_f3 = [&](const u32x4 h, const u32x4 ma, const u32x4 mb, const u32x4 mcq, const double s_score, const int s_vm,
+                           const double s_x0, const double s_x1, const double s_x2, auto s_tbn, lanemask& tk, double& val, int& tag) {
+            const lanemask mF5 = mk64(ma.x, ma.y), mF5t = mk64(ma.z, ma.w), mF3 = mk64(mb.x, mb.y), mR5 = mk64(mb.z, mb.w), mR3 = mk64(mcq.x, mcq.y);
+            const int s_ndx = (int)h.y;
+            lanemask okm = mF5;
+            double w = M.negc;
+            if (mF5t) { if (in_mask(mF5t)) { const int d = T.ndx - s_ndx; w = d <= DPW_OPER_DIST ? s_igm[d] : 0.0; } }
+            if (mF3) {
+                const lanemask o3 = mF3 & vote((s_vm & fbit) != 0);
+                if (o3) { okm |= o3; if (in_mask(o3)) w = dpw_sel3(T.frame, s_x0, s_x1, s_x2); }
+            }
+            if (mR5 | mR3) {
+                const int lhs = s_tbn() + s_ndx + 7;
+                if (mR5) { okm |= mR5 & vote(lhs < LT.drhs0); if (in_mask(mR5)) w = T.csd; }
+                if (mR3) {
+                    okm |= mR3;
+                    if (in_mask(mR3)) {
+                        const bool c0 = (s_ndx > LT.dlo0) & (s_ndx < LT.dhi0) & (lhs < LT.drhs0);
+                        const bool c1 = (s_ndx > LT.dlo1) & (s_ndx < LT.dhi1) & (lhs < LT.drhs1);
+                        const bool c2 = (s_ndx > LT.dlo2) & (s_ndx < LT.dhi2) & (lhs < LT.drhs2);
+                        double mv = 0.0; int m = -1;
+                        if (c0 & (T.x0 > mv)) { mv = T.x0; m = 0; }
+                        if (c1 & (T.x1 > mv)) { mv = T.x1; m = 1; }
+                        if (c2 & (T.x2 > mv)) { mv = T.x2; m = 2; }
+                        w = m >= 0 ? mv : M.negc;
+                        tag |= (m + 1) << DPW_TAG_BITS;
+                    }
+                }
+            }
+            val = s_score + w;
+            tk = okm & vote(val >= L.val);
+        };
+
+        k_uint4* ep = s_ent + 2 * (size_t)hdr.x;
+        // operands of the assembly blocks (names fixed by tools/gen_dpw_walk.py)
+        unsigned long long a_ep = (unsigned long long)(uintptr_t)ep;
+        double& a_lv = L.val; int& a_lt = L.tag;
+        const double a_x0 = T.x0, a_x1 = T.x1, a_x2 = T.x2, a_cs = T.cs, a_csd = T.csd, a_negc = M.negc;
+        const int a_ndx = T.ndx, a_fbit = fbit, a_vm = T.vm, a_i0 = i0;
+        const int a_drhs0 = LT.drhs0, a_drhs1 = LT.drhs1, a_drhs2 = LT.drhs2, a_dlo0 = LT.dlo0, a_dlo1 = LT.dlo1, a_dlo2 = LT.dlo2,
+                  a_dhi0 = LT.dhi0, a_dhi1 = LT.dhi1, a_dhi2 = LT.dhi2;
+        const lanemask a_r3v0 = r3v0, a_r3v1 = r3v1, a_r3v2 = r3v2;
+        const unsigned a_igmb = (unsigned)(uintptr_t)s_igm;
+        // ---- (2) near steps first (ascending sources onto an empty state: ">=" is the whole tie rule), from the schedule
+        {
+            int left = (int)(hdr.y & 0xffffu);
+            for (int t0 = (int)hdr.z; left > 0 && t0 < i0; t0 += 64) {
+                const int j = t0 + lane;
+                const int jj = j < i0 ? j : i0 - 1;
+                const int s_tb = P.tbn[jj];
+                const double t_score = P.score[jj];
+                const int er = P.srank != nullptr ? P.srank[jj] : jj;
+                int t_vm = 0; double t_x0 = 0.0, t_x1 = 0.0, t_x2 = 0.0;
+                if (DPW_KIND(P.kf[jj]) == 1) { const DpwExt* e = P.ext + er; t_vm = e->vm; t_x0 = e->x[0]; t_x1 = e->x[1]; t_x2 = e->x[2]; }
+                if constexpr (ASM) {
+                    int a_left = left;
+                    const int a_tend = t0 + 64;
+                    const double a_ns = t_score, a_nx0 = t_x0, a_nx1 = t_x1, a_nx2 = t_x2;
+                    const int a_nb = s_tb, a_nvm = t_vm;
+                    DPW_ASM_NEAR();
+                    left = a_left;
+                } else {
+                    while (left > 0) {
+                        const u32x4 h = ep[0];
+                        if ((int)h.w >= t0 + 64) break;             // the entry's source sits in the next tile
+                        const u32x4 ma = ep[1];
+                        const int sk = DPW_E_KIND(h.z), u = (int)h.x;
+                        left--;
+                        lanemask tk = 0; double val = 0.0; int tag = (int)h.w;
+                        const int tbu = rl_i32(s_tb, u);
+                        const double s_score = rl_f64(t_score, u);
+                        if (sk == 1) {
+                            const u32x4 mb = ep[2], mcq = ep[3];
+                            ep += 4;
+                            // (a gene end that was never reached is no source)
+                            if (tbu != -1) step_f3(h, ma, mb, mcq, s_score, rl_i32(t_vm, u), rl_f64(t_x0, u), rl_f64(t_x1, u), rl_f64(t_x2, u), [&]() { return tbu; }, tk, val, tag);
+                        } else {
+                            ep += 2;
+                            if (sk == 2) { if (tbu != -1) step_r5(h, ma, s_score, tk, val); }
+                            else step_r3(h, ma, s_score, tk, val);
+                        }
+                        const bool t = in_mask(tk);
+                        L.val = t ? val : L.val; L.tag = t ? tag : L.tag;
+                    }
+                }
+            }
+            if (L.tag >= 0) tbn_pre = P.ndx[dpw_tag_index(L.tag)];
+        }
+        mark(1);
+        // ---- (1) gene begins: far gene ends, `a` over [lo, min(p_near, i0))
+        {
+            const bool gb = act && (T.kind == 0 || T.kind == 3);
+            const int lo = T.lo, hi = min(T.q1, i0);
+            const bool want = gb && hi > lo;
+            const int rb = hi >> 6, part = hi & 63, Bl = lo >> 6, lpart = lo & 63;
+            const int x = lpart ? Bl + 1 : Bl;                 // first whole block
+            bool generic = want && !(rb == b || (rb == b - 1 && !(Bl >= rb && part > 0 && lpart != 0)));
+            const int q = rb - 1 - x;                          // whole blocks [x, rb): lane q of S1 (rb == b) or S2 (rb == b - 1)
+            const bool whole = want && !generic && x < rb;
+            if (whole && q >= 64) generic = true;
+            const int qs = whole ? (q & 63) : 0;
+            const double w1v = __shfl(s1v, qs, 64), w2v = __shfl(s2v, qs, 64);
+            const int w1i = __shfl(s1i, qs, 64), w2i = __shfl(s2i, qs, 64);
+            const int ps = (part - 1) & 63;
+            const double pv = __shfl(ppv, ps, 64); const int pi = __shfl(ppi, ps, 64);
+            double rv = NEG_INF; int ri = -1;
+            if (want && !generic) {
+                if (whole) { if (rb == b) lex_max(rv, ri, w1v, w1i); else lex_max(rv, ri, w2v, w2i); }
+                if (rb == b - 1 && part > 0 && (Bl < rb || lpart == 0)) lex_max(rv, ri, pv, pi);
+                if (lpart != 0 && Bl < rb) lex_max(rv, ri, P.sfxv[lo], P.sfxi[lo]);
+            }
+            if (__any(generic)) {
+                if (generic) {
+                    rv = NEG_INF; ri = -1;
+                    for (int j = lo; j < hi; j++) {
+                        const int k = DPW_KIND(P.kf[j]);
+                        if ((k == 1 || k == 2) && P.traceb[j] != -1) lex_max(rv, ri, P.score[j] + M.negc, j);
+                    }
+                }
+            }
+            if (ri >= 0) take(true, rv, ri, 0, P.ndx[ri]);
+        }
+        mark(2);
+        // ---- (3) forward stops: the running maximum of their frame, for the first forward stop of the frame in the batch
+        {
+            const bool f3 = act && T.kind == 1;
+            const unsigned long long m0 = __ballot(f3 && T.frame == 0), m1 = __ballot(f3 && T.frame == 1), m2 = __ballot(f3 && T.frame == 2);
+            const unsigned long long mine = T.frame == 0 ? m0 : (T.frame == 1 ? m1 : m2);
+            const double cv = dpw_sel3(T.frame, rv0, rv1, rv2);
+            const int ci = dpw_sel3i(T.frame, ri0, ri1, ri2), cn = dpw_sel3i(T.frame, rn0, rn1, rn2);
+            take(f3 && (mine & below) == 0ull && ci >= 0, cv, ci, 0, cn);
+        }
+        // ---- (4) reverse nodes: the last reverse stop of a frame before the batch (own stop of a reverse start; operon partner)
+        if (act && T.kind == 2) {
+            const int j = dpw_sel3i(T.frame, l3i0, l3i1, l3i2), ss = dpw_sel3i(T.frame, l3s0, l3s1, l3s2);
+            take(j >= 0 && j >= T.lo && ss > T.ndx, dpw_sel3(T.frame, l3v0, l3v1, l3v2) + T.cs, j, 0, dpw_sel3i(T.frame, l3n0, l3n1, l3n2));
+        } else if (act && T.kind == 3) {
+            take((T.vm & 1) && l3i0 >= 0 && l3i0 >= T.lo && l3s0 > T.ndx, l3v0 + T.x0, l3i0, 0, l3n0);
+            take((T.vm & 2) && l3i1 >= 0 && l3i1 >= T.lo && l3s1 > T.ndx, l3v1 + T.x1, l3i1, 0, l3n1);
+            take((T.vm & 4) && l3i2 >= 0 && l3i2 >= T.lo && l3s2 > T.ndx, l3v2 + T.x2, l3i2, 0, l3n2);
+        }
+        mark(3);
+        // ---- (5) reverse nodes: forward stops that overlap the 3' end of the gene, through the chain of forward stops
+        {
+            const bool r5 = act && T.kind == 2, r3 = act && T.kind == 3;
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                int j = DPW_NONE, bound = 0;
+                if (r5 && q == 0) { j = T.q2; bound = T.stop_val + DPW_MAX_OPP_OVLP - 5; }
+                if (r3 && ((T.vm >> q) & 1)) { j = dpw_sel3i(q, T.cq0, T.cq1, T.cq2); bound = dpw_sel3i(q, T.n3s0, T.n3s1, T.n3s2) + DPW_MAX_OPP_OVLP - 5; }
+                while (__any(j < i0)) {
+                    if (j < i0) {
+                        const int s_ndx = P.ndx[j];
+                        if (s_ndx >= bound) j = DPW_NONE;
+                        else {
+                            const DpwS S = load_f3_source(P, j, s_ndx);
+                            bool ok; double w; int mf;
+                            dpw_pair(S, T, M, ok, w, mf);
+                            take(ok, S.score + w, j, mf + 1, s_ndx);
+                            j = P.q2[j];
+                        }
+                    }
+                }
+            }
+        }
+        mark(4);
+        // ---- (6) the walk, from the schedule: lane k is final when the walk reaches its entry.  A forward stop first pulls the
+        //      forward starts of its ORF that sit before it in the batch (the entry's `pull` lanes; they are final by then).
+        {
+            if constexpr (ASM) {
+                int a_left = (int)(hdr.y >> 16);
+                const int a_tbnpre = tbn_pre;
+                DPW_ASM_WALK();
+            } else {
+                const double offer_cs = T.cs;
+                const int my_vm = T.vm;
+                for (int left = (int)(hdr.y >> 16); left > 0; left--) {
+                    const u32x4 h = ep[0];
+                    const u32x4 ma = ep[1];
+                    const int sk = DPW_E_KIND(h.z), k = (int)h.x;
+                    lanemask tk = 0; double val = 0.0; int tag = (int)h.w;
+                    int tagk = rl_i32(L.tag, k);
+                    if (sk == 1) {
+                        const u32x4 mb = ep[2], mcq = ep[3];
+                        ep += 4;
+                        lanemask cand = mk64(mcq.z, mcq.w);
+                        if (cand) {
+                            double bv = rl_f64(L.val, k);
+                            int bi = tagk < 0 ? -1 : (tagk & DPW_TAG_MASK);
+                            const double offer = L.val + offer_cs;                  // what each lane would offer as a forward start
+                            while (cand) {
+                                const int c = __builtin_ctzll(cand);
+                                cand &= cand - 1ull;
+                                const double v = rl_f64(offer, c);
+                                if (v > bv || (v == bv && i0 + c > bi)) { bv = v; bi = i0 + c; tagk = i0 + c; }
+                            }
+                            const bool me = lane == k;
+                            L.val = me ? bv : L.val; L.tag = me ? tagk : L.tag;
+                        }
+                        // (a gene end that was never reached connects to nothing)
+                        if (tagk >= 0)
+                            step_f3(h, ma, mb, mcq, rl_f64(L.val, k), rl_i32(my_vm, k), rl_f64(T.x0, k), rl_f64(T.x1, k), rl_f64(T.x2, k), [&]() {
+                                const int tbk = tagk & DPW_TAG_MASK;
+                                return tbk >= i0 ? rl_i32(T.ndx, tbk - i0) : rl_i32(tbn_pre, k);
+                            }, tk, val, tag);
+                    } else {
+                        ep += 2;
+                        const double s_score = rl_f64(L.val, k);
+                        if (sk == 2) { if (tagk >= 0) step_r5(h, ma, s_score, tk, val); }
+                        else step_r3(h, ma, s_score, tk, val);
+                    }
+                    const bool t = in_mask(tk);
+                    L.val = t ? val : L.val; L.tag = t ? tag : L.tag;
+                }
+            }
+        }
+        mark(5);
+        // ---- (7) the batch is final: results, block structures, carries
+        DpwBest B;
+        B.val = L.val; B.tb = dpw_tag_index(L.tag); B.ov = dpw_tag_ov(L.tag);
+        {
+            const int src = B.tb >= i0 ? B.tb - i0 : 0;
+            const int nd_in = __shfl(T.ndx, src, 64);
+            B.tbn = B.tb < 0 ? -1 : (B.tb >= i0 ? nd_in : tbn_pre);
+        }
+        if (act) {
+            P.score[T.i] = B.val; P.traceb[T.i] = B.tb; P.tbn[T.i] = B.tbn; P.ov[T.i] = (int8_t)B.ov;
+            if ((T.kind == 1 || T.kind == 2) && B.val >= end_best) { end_best = B.val; end_idx = T.i; end_tb = B.tb; }
+        }
+        const DpwOut O = dpw_outputs(T, kfb, B, M.negc);
+        {
+            const bool has = O.a > NEG_INF;
+            const double pv = wave_prefix_max_f64(O.a, lane);
+            const lanemask rec = vote(has && O.a == pv) & (below | (1ull << lane));
+            const int pi = rec ? i0 + 63 - __builtin_clzll(rec) : -1;
+            ppv = pv; ppi = pi;
+            const double bmv = rl_f64(pv, 63); const int bmi = rl_i32(pi, 63);
+            s2v = s1v; s2i = s1i;
+            double nv = dpp_f64<0x138>(NEG_INF, s1v); int ni = dpp_i32<0x138>(-1, s1i);      // wave_shr:1, lane 0 takes the empty entry
+            lex_max(nv, ni, bmv, bmi);
+            s1v = nv; s1i = ni;
+            if (long_chain) {
+                double av = O.a; int ai = has ? i0 + lane : -1;
+                wave_suffix_lexmax(av, ai, lane);
+                if (act) { P.sfxv[T.i] = av; P.sfxi[T.i] = ai; }
+            }
+        }
+        {
+            const bool f3 = act && T.kind == 1, r3n = act && T.kind == 3;
+#pragma unroll
+            for (int f = 0; f < 3; f++) {
+                const lanemask mf = vote(f3 && T.frame == f);
+                const int u = mf ? 63 - __builtin_clzll(mf) : -1;
+                double v = f == 0 ? O.v0 : (f == 1 ? O.v1 : O.v2);
+                if (lane <= u) v = NEG_INF;
+                const lanemask some = vote(v > NEG_INF);
+                double& rv = f == 0 ? rv0 : (f == 1 ? rv1 : rv2);
+                int& ri = f == 0 ? ri0 : (f == 1 ? ri1 : ri2);
+                int& rn = f == 0 ? rn0 : (f == 1 ? rn1 : rn2);
+                if (some) {
+                    const double m = wave_max_f64(v);
+                    const lanemask at = some & vote(v == m);               // a later node wins a tie
+                    const int wl = 63 - __builtin_clzll(at);
+                    const double mv = rl_f64(v, wl);                       // the same value, in scalar registers
+                    if (u >= 0 || mv >= rv) { rv = mv; ri = i0 + wl; rn = rl_i32(T.ndx, wl); }
+                } else if (u >= 0) { rv = NEG_INF; ri = -1; rn = -1; }
+                const lanemask mr = vote(r3n && T.frame == f);
+                if (mr) {
+                    const int w = 63 - __builtin_clzll(mr);
+                    const int li = i0 + w, ls = rl_i32(T.stop_val, w), ln = rl_i32(T.ndx, w); const double lv = rl_f64(B.val, w);
+                    if (f == 0) { l3i0 = li; l3s0 = ls; l3n0 = ln; l3v0 = lv; } else if (f == 1) { l3i1 = li; l3s1 = ls; l3n1 = ln; l3v1 = lv; }
+                    else { l3i2 = li; l3s2 = ls; l3n2 = ln; l3v2 = lv; }
+                }
+            }
+        }
+        mark(6);
+        if (prof && lane == 0) atomicAdd(&buf.prof[7], 1ull);
+    }
+    // highest score among gene ends, ties to the largest index (ref: lib.pyx:1239-1251, 1311)
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double ob = __shfl_xor(end_best, m, 64);
+        const int oi = __shfl_xor(end_idx, m, 64), ot = __shfl_xor(end_tb, m, 64);
+        if (ob > end_best || (ob == end_best && oi > end_idx)) { end_best = ob; end_idx = oi; end_tb = ot; }
+    }
+    if (lane == 0) {
+        buf.max_index[chain] = end_idx; buf.max_score[chain] = end_idx >= 0 ? end_best : 0.0;
+        buf.ipath[chain] = (end_idx >= 0 && end_tb != -1) ? end_idx : -1;
+    }
+}
+
 }  // namespace
 
 void pga_launch_dpw_topo(const DpwTopoArrays& ta, const uint8_t* type, const int8_t* strand, const int32_t* d_cbase, int n_contigs, int n_nodes,
@@ -665,16 +1141,30 @@ void pga_launch_dpw_chain(const ChainDesc* d_chains, int n_chains, int64_t node_
                        nodes, ta, d_models, wb.cs, wb.ext);
 }
 
+bool pga_dpw_use_sched() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PGA_DPW_SCHED"); v = e ? (atoi(e) != 0) : 1; }
+    return v != 0;
+}
+
+void pga_launch_dpw_sched(const DpwTopoArrays& ta, const int32_t* d_cbase, const int32_t* d_bbase, int n_contigs, int max_batches, hipStream_t st) {
+    hipMemsetAsync(ta.scur, 0, 2 * sizeof(uint32_t), st);
+    if (n_contigs <= 0 || max_batches <= 0) return;
+    hipLaunchKernelGGL(k_dpw_sched, dim3((unsigned)n_contigs, (unsigned)((max_batches + 15) / 16)), dim3(256), 0, st, d_cbase, d_bbase, ta);
+}
+
 void pga_launch_dp_wave(const ChainDesc* d_chains, int n_chains, const DpwGroupPtrs& groups, const ModelConst* d_models, DpBuffers buf,
-                        const DpwBuffers& wb, hipStream_t st, const int32_t* d_order, int n_blocks) {
+                        const DpwBuffers& wb, hipStream_t st, const int32_t* d_order, int n_blocks, bool scheduled) {
     if (n_chains <= 0) return;
     if (n_blocks <= 0 || d_order == nullptr) n_blocks = n_chains;
     static int occ = 0;
     if (!occ) { const char* e = getenv("PGA_DPW_OCC"); occ = e ? atoi(e) : 5; if (occ < 4 || occ > 6) occ = 5; }
-    if (occ == 5) hipLaunchKernelGGL(k_dp_wave<5>, dim3((unsigned)n_blocks), dim3(64), 0, st, d_chains, groups, (const double*)wb.cs, (const DpwExt*)wb.ext,
-                                     d_models, buf, wb.sfxv, wb.sfxi, d_order);
-    else if (occ == 6) hipLaunchKernelGGL(k_dp_wave<6>, dim3((unsigned)n_blocks), dim3(64), 0, st, d_chains, groups, (const double*)wb.cs, (const DpwExt*)wb.ext,
-                                          d_models, buf, wb.sfxv, wb.sfxi, d_order);
-    else hipLaunchKernelGGL(k_dp_wave<4>, dim3((unsigned)n_blocks), dim3(64), 0, st, d_chains, groups, (const double*)wb.cs, (const DpwExt*)wb.ext,
-                            d_models, buf, wb.sfxv, wb.sfxi, d_order);
+#define DPW_LAUNCH(K) hipLaunchKernelGGL(K, dim3((unsigned)n_blocks), dim3(64), 0, st, d_chains, groups, (const double*)wb.cs, (const DpwExt*)wb.ext, \
+                                         d_models, buf, wb.sfxv, wb.sfxi, d_order)
+    static int use_asm = -1;
+    if (use_asm < 0) { const char* e = getenv("PGA_DPW_ASM"); use_asm = e ? (atoi(e) != 0) : 1; }
+    if (scheduled && use_asm) { if (occ == 5) DPW_LAUNCH((k_dp_wave<5, true>)); else if (occ == 6) DPW_LAUNCH((k_dp_wave<6, true>)); else DPW_LAUNCH((k_dp_wave<4, true>)); }
+    else if (scheduled) { if (occ == 5) DPW_LAUNCH((k_dp_wave<5, false>)); else if (occ == 6) DPW_LAUNCH((k_dp_wave<6, false>)); else DPW_LAUNCH((k_dp_wave<4, false>)); }
+    else { if (occ == 5) DPW_LAUNCH(k_dpw_dyn<5>); else if (occ == 6) DPW_LAUNCH(k_dpw_dyn<6>); else DPW_LAUNCH(k_dpw_dyn<4>); }
+#undef DPW_LAUNCH
 }

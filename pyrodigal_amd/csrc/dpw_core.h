@@ -410,3 +410,97 @@ DPW_HD void dpw_step(const DpwS& S, const DpwLT& T, DpwLane& L, const DpwModel& 
     else if (S.kind == 3) dpw_take_ge(L, dpw_ok_r3(T, S.j, S.frame, S.stop_val), S.score + dpw_w_r3(T, S.frame), S.j);
     else dpw_step_f3(T, L, S.j, S.ndx, S.vm, S.tbn, S.score, S.x0, S.x1, S.x2, M);
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Step schedule.  Which sources take a pair step onto a batch of 64 targets, in which order, and which lanes each of them can
+// reach at all is TOPOLOGY: kinds, frames, positions, stop positions, windows -- the same for every model scored on the contig
+// under one translation table (ref: the six skip conditions of impl/generic.h:29-36 and the static tests of _connection.h:94-367
+// read nothing else).  It is therefore compiled once per (contig, table) into a list of entries per batch (k_dpw_sched; the host
+// loop of tests/dpw_model.cpp builds the same list), and a chain's walk reads the entries with scalar loads: per step what is left
+// is the source's value, one add, one compare against the lanes' running values under the entry's lane mask -- plus, for the few
+// relations that depend on a model (the overlapping starts of a stop node: star_ptr), the dynamic tests listed with each kind.
+//
+// A batch's entries: first the NEAR sources (older than the batch, from the earliest p_near of a gene begin of the batch: `jm`),
+// ascending, then the batch's own nodes as sources, ascending.  Forward starts never step (a forward stop pulls the starts of
+// its ORF, see `pull`).  An entry whose masks are all empty is left out.
+//   header, 16 bytes:  lane (of the source inside its 64-node tile / inside the batch), s_ndx (its position),
+//                      code = kind | frame << 2, j (its chain index)
+//   R5 (32 bytes):  m0 = gene begins in the window with s_ndx < key_r5            (ref: _connection.h:125-130, 337-342)
+//                   m1 = those of m0 that are reverse stops within 3 * OPER_DIST bases (the distance term)
+//   R3 (32 bytes):  m0 = reverse starts of the source's frame inside its ORF      (ref: :228-235)
+//                   m1 = reverse stops inside its ORF; dynamic: the lane has an overlapping start in the source's frame (:345-356)
+//   F3 (64 bytes):  mF5 = forward starts behind it (:117-124), mF5t = those within 3 * OPER_DIST bases,
+//                   mF3 = forward stops whose ORF holds it; dynamic: the SOURCE has an overlapping start in the lane's frame (:177-188),
+//                   mR5 = reverse starts whose static interval holds s_ndx; dynamic: tbn + s_ndx + 7 < drhs0 (:238-254),
+//                   mR3 = reverse stops with s_ndx < ndx - 4; dynamic: the candidates through the lane's overlapping starts (:288-336),
+//                   pull = (batch sources only) the forward starts of its ORF that sit before it in the batch (:166-174)
+struct DpwSchedHdr { uint32_t off; uint32_t cnt; int32_t jm; int32_t spare; };   // off: first 32-byte slot; cnt = near entries | batch entries << 16
+#define DPW_SCHED_STRIDE 112u                                                      // slots a batch owns (its entries sit at batch * stride)
+#define DPW_SCHED_NONE 0xffffffffu                                                // off: the entries did not fit (the caller falls back)
+#define DPW_E_CODE(kind, frame) ((uint32_t)((kind) | ((frame) << 2)))
+#define DPW_E_KIND(c)  ((int)((c) & 3))
+#define DPW_E_FRAME(c) ((int)(((c) >> 2) & 3))
+#define DPW_E_SLOTS(kind) ((kind) == 1 ? 2 : 1)
+
+// what the topology fixes of a target
+struct DpwST { int i, kind, frame, ndx, stop_val, lo, dlo0, dhi0; };
+DPW_HD DpwST dpw_st(const int i /* -1: no node */, const int kf, const int ndx, const int stop_val, const int lo) {
+    DpwST T;
+    T.i = i; T.kind = i >= 0 ? DPW_KIND(kf) : -1; T.frame = DPW_FRAME(kf); T.ndx = ndx; T.stop_val = stop_val; T.lo = i >= 0 ? lo : INT_MAX;
+    T.dlo0 = INT_MAX; T.dhi0 = INT_MIN;
+    if (T.kind == 2) {          // as dpw_lean
+        T.dlo0 = stop_val - 4;
+        T.dhi0 = stop_val + DPW_MAX_OPP_OVLP - 5;
+        const int h2 = (ndx + stop_val + 4) >> 1;
+        if (h2 < T.dhi0) T.dhi0 = h2;
+    }
+    return T;
+}
+// the static bits of source (j, kind sk, frame sf, position s_ndx, stop_val s_stop) towards target T, in the order of the entry's masks
+DPW_HD unsigned dpw_static_bits(const DpwST& T, const int j, const int sk, const int sf, const int s_ndx, const int s_stop) {
+    if (!((j >= T.lo) & (j < T.i))) return 0u;
+    unsigned b = 0;
+    if (sk == 2) {
+        const bool ok = ((T.kind == 0) & (s_ndx < T.ndx)) | ((T.kind == 3) & (s_ndx < T.ndx - 2));
+        if (ok) b = 1u | (((T.kind == 3) & (T.ndx - s_ndx <= 3 * DPW_OPER_DIST)) ? 2u : 0u);
+    } else if (sk == 3) {
+        if (s_stop > T.ndx) b = (((T.kind == 2) & (T.frame == sf)) ? 1u : 0u) | (T.kind == 3 ? 2u : 0u);
+    } else if (sk == 1) {
+        if (T.kind == 0) { if (s_ndx + 2 < T.ndx) b = 1u | (T.ndx - s_ndx <= 3 * DPW_OPER_DIST ? 2u : 0u); }
+        else if (T.kind == 1) { if (T.stop_val < s_ndx) b = 4u; }
+        else if (T.kind == 2) { if ((s_ndx > T.dlo0) & (s_ndx < T.dhi0)) b = 8u; }
+        else if (T.kind == 3) { if (s_ndx < T.ndx - 4) b = 16u; }
+    }
+    return b;
+}
+// lane c (target record Tc) is a forward start that forward stop k (frame fk, stop_val s_stop) pulls
+DPW_HD bool dpw_static_pull(const DpwST& Tc, const int fk, const int s_stop) { return (Tc.kind == 0) & (Tc.frame == fk) & (Tc.ndx > s_stop); }
+
+// The dynamic half of a step, per lane.  `b`: the lane's static bits of the entry.
+// reverse start: the value it offers this lane
+DPW_HD double dpw_sval_r5(const DpwLT& T, const unsigned b, const int s_ndx, const double s_score, const DpwModel& M) {
+    return (b & 2u) ? s_score + dpw_igm_apart(T.ndx - s_ndx, M.negc, M.igm) : s_score + M.negc;
+}
+// reverse stop of frame sf
+DPW_HD bool dpw_sok_r3(const DpwLT& T, const unsigned b, const int sf) { return (b & 1u) | ((b & 2u) && ((T.vm >> sf) & 1)); }
+// forward stop: dpw_step_f3 with the static tests taken from the entry
+DPW_HD void dpw_sstep_f3(const DpwLT& T, DpwLane& L, const unsigned b, const int j, const int s_ndx, const int s_vm, const int s_tbn, const double s_score,
+                         const double s_x0, const double s_x1, const double s_x2, const DpwModel& M) {
+    bool ok = false;
+    double w = 0.0; int ov1 = 0;
+    if (b & 1u) { ok = true; w = (b & 2u) ? dpw_igm_apart(T.ndx - s_ndx, M.negc, M.igm) : M.negc; }
+    else if (b & 4u) { ok = ((s_vm >> T.frame) & 1) != 0; w = dpw_sel3(T.frame, s_x0, s_x1, s_x2); }
+    else if (b & 8u) { ok = s_tbn + s_ndx + 7 < T.drhs0; w = T.csd; }
+    else if (b & 16u) {
+        const int lhs = s_tbn + s_ndx + 7;
+        const bool c0 = (s_ndx > T.dlo0) & (s_ndx < T.dhi0) & (lhs < T.drhs0);
+        const bool c1 = (s_ndx > T.dlo1) & (s_ndx < T.dhi1) & (lhs < T.drhs1);
+        const bool c2 = (s_ndx > T.dlo2) & (s_ndx < T.dhi2) & (lhs < T.drhs2);
+        double mv = 0.0; int m = -1;
+        if (c0 & (T.x0 > mv)) { mv = T.x0; m = 0; }
+        if (c1 & (T.x1 > mv)) { mv = T.x1; m = 1; }
+        if (c2 & (T.x2 > mv)) { mv = T.x2; m = 2; }
+        ok = true; w = m >= 0 ? mv : M.negc; ov1 = m + 1;
+    }
+    dpw_take_ge(L, ok, s_score + w, j | (ov1 << DPW_TAG_BITS));
+}

@@ -1514,6 +1514,22 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         DpSegPlan seg_plan;
         // many chains: one wavefront each, records and far-field structures of dp_wave.hip
         const bool use_wave = stage == 0 && pga_dp_use_wave(NCH);
+        // the step schedule of the wave-batch scorer: one header per 64-node batch of every contig of a group (dpw_core.h)
+        const bool use_sched = use_wave && pga_dpw_use_sched();
+        std::vector<int32_t> h_bbase;
+        if (use_sched) {
+            h_bbase.resize((size_t)NG * (NC + 1));
+            for (int g = 0; g < NG; g++) {
+                const int32_t* cb = h_cbase + (size_t)g * (NC + 1);
+                int32_t* bb = h_bbase.data() + (size_t)g * (NC + 1);
+                bb[0] = 0;
+                for (int i = 0; i < NC; i++) bb[i + 1] = bb[i] + ((cb[i + 1] - cb[i] + 63) >> 6);
+            }
+            for (ChainDesc& ch : chains) ch.sched_b0 = h_bbase[(size_t)ch.group * (NC + 1) + ch.contig];
+        }
+        int max_batches[4] = {0, 0, 0, 0};
+        if (use_sched) for (int g = 0; g < NG; g++) for (int i = 0; i < NC; i++)
+            max_batches[g] = std::max(max_batches[g], h_bbase[(size_t)g * (NC + 1) + i + 1] - h_bbase[(size_t)g * (NC + 1) + i]);
         const bool segmented = stage == 0 && !use_wave && pga_dp_plan(chains.data(), NCH, tot_chain_nodes, seg_plan);
         const int64_t dp_cap = tot_chain_nodes + seg_plan.extra + 1;
         const int64_t dp_slots = NCH + (int64_t)seg_plan.segs.size() + 1;
@@ -1538,6 +1554,15 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                 WBUF(kf, uint8_t) WBUF(lo, int32_t) WBUF(q1, int32_t) WBUF(q2, int32_t)
 #undef WBUF
                 wgroups.g[g].ndx = ga[g].ndx; wgroups.g[g].stop_val = ga[g].stop_val; wgroups.g[g].srank = ga[g].srank;
+                if (use_sched) {
+                    // headers: one per batch; entries: DPW_SCHED_STRIDE 32-byte slots per batch (what does not fit is counted and the launch
+                    // falls back to k_dpw_dyn)
+                    const int64_t nbat = h_bbase[(size_t)g * (NC + 1) + NC];
+                    void* p__; int rc__;
+                    snprintf(nm, sizeof nm, "dpw_shdr%d", g); rc__ = ensure_dev(c, nm, sizeof(DpwSchedHdr) * (size_t)(nbat + 1), &p__); if (rc__) return rc__; wgroups.g[g].shdr = (DpwSchedHdr*)p__;
+                    snprintf(nm, sizeof nm, "dpw_sent%d", g); rc__ = ensure_dev(c, nm, 32 * (size_t)DPW_SCHED_STRIDE * (size_t)(nbat + 1) + 128, &p__); if (rc__) return rc__; wgroups.g[g].sent = (uint4*)p__;
+                    snprintf(nm, sizeof nm, "dpw_scur%d", g); rc__ = ensure_dev(c, nm, 64, &p__); if (rc__) return rc__; wgroups.g[g].scur = (uint32_t*)p__;
+                }
             }
             DEVBUF(w0, double, "dpw_cs", dp_cap + 2) DEVBUF(w1, DpwExt, "dpw_ext", tot_chain_stops + 4)      /* one extras record per (chain, stop node) pair */ DEVBUF(w2, double, "dpw_sfxv", dp_cap) DEVBUF(w3, int32_t, "dpw_sfxi", dp_cap)
             wbuf = DpwBuffers{w0, w1, w2, w3};
@@ -1574,6 +1599,13 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         PINBUF(h_ipath, int32_t, "h_ipath", NCH + 1);
         PINBUF(h_maxscore, double, "h_maxscore", NCH + 1);
         HT(c, hipMemcpyAsync(d_chains, chains.data(), sizeof(ChainDesc) * NCH, hipMemcpyHostToDevice, st));
+        int32_t* d_bbase = nullptr;
+        PINBUF(h_scur, uint32_t, "h_dpw_scur", 16);
+        if (use_sched) {
+            DEVBUF(d_bb, int32_t, "d_dpw_bbase", h_bbase.size() + 1);
+            HT(c, hipMemcpyAsync(d_bb, h_bbase.data(), sizeof(int32_t) * h_bbase.size(), hipMemcpyHostToDevice, st));
+            d_bbase = d_bb;
+        }
         // per group and contig: the contiguous run of chains (models) scored on that contig
         DEVBUF(d_cc, int2, "d_cc", (size_t)2 * NG * NC + 1);
         PINBUF(h_cc, int2, "h_cc", (size_t)2 * NG * NC + 1);
@@ -1632,6 +1664,10 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             sp.cs_out = nullptr;
             if (use_wave) {
                 pga_launch_dpw_topo(wgroups.g[g], ga[g].type, ga[g].strand, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], st);
+                if (use_sched) {
+                    pga_launch_dpw_sched(wgroups.g[g], d_cbase + (size_t)g * (NC + 1), d_bbase + (size_t)g * (NC + 1), NC, max_batches[g], st);
+                    HT(c, hipMemcpyAsync(h_scur + 2 * g, wgroups.g[g].scur, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                }
                 sl.topo_q2 = wgroups.g[g].q2; sl.ext = wbuf.ext; sp.cs_out = wbuf.cs;
                 // (the same condition as the lean gather's direct mode further down: the node arrays stay on the device)
                 sl.fill_star_ptr = !(stage == 0 && !P.want_nodes && !(getenv("PGA_TAIL") && strcmp(getenv("PGA_TAIL"), "host") == 0) &&
@@ -1702,14 +1738,14 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                 HT(c, hipMemsetAsync(d_prof, 0, 128, st));
                 dp.prof = d_prof;
             }
-            pga_launch_dp_wave(d_chains, NCH, wgroups, c->d_model_const, dp, wbuf, st, d_dp_order, (int)dp_order.size());
+            pga_launch_dp_wave(d_chains, NCH, wgroups, c->d_model_const, dp, wbuf, st, d_dp_order, (int)dp_order.size(), use_sched);
             if (dp.prof != nullptr) {
                 unsigned long long pr[16];
                 HT(c, hipStreamSynchronize(st));
                 HT(c, hipMemcpy(pr, dp.prof, 128, hipMemcpyDeviceToHost));
                 const double nbp = pr[7] ? (double)pr[7] : 1.0;
-                fprintf(stderr, "[pga dp profile] k_dp_wave, %d chains, batches sampled=%llu, cycles/batch: load=%.0f near steps=%.0f far gene ends=%.0f "
-                                "carries=%.0f chains=%.0f walk=%.0f finalize=%.0f | total=%.0f\n", NCH, pr[7], pr[0] / nbp, pr[1] / nbp, pr[2] / nbp, pr[3] / nbp,
+                fprintf(stderr, "[pga dp profile] %s, %d chains, batches sampled=%llu, cycles/batch: load=%.0f near steps=%.0f far gene ends=%.0f "
+                                "carries=%.0f chains=%.0f walk=%.0f finalize=%.0f | total=%.0f\n", use_sched ? "k_dp_wave" : "k_dpw_dyn", NCH, pr[7], pr[0] / nbp, pr[1] / nbp, pr[2] / nbp, pr[3] / nbp,
                         pr[4] / nbp, pr[5] / nbp, pr[6] / nbp, (pr[0] + pr[1] + pr[2] + pr[3] + pr[4] + pr[5] + pr[6]) / nbp);
                 dp.prof = nullptr;
             }
@@ -1727,7 +1763,27 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         }
         HT(c, hipGetLastError());
         HT(c, hipStreamSynchronize(st));
+        uint32_t sched_missed = 0, sched_slots = 0;
+        if (use_sched) {
+            // a schedule that did not fit its buffer (node-dense input: more than two slots per node on average): the same launch again
+            // with the kernel that works the lane masks out itself
+            uint32_t missed = 0;
+            for (int g = 0; g < NG; g++) if (g_c0[g + 1] > g_c0[g] && g_n0[g + 1] > g_n0[g]) { missed += h_scur[2 * g + 1]; sched_slots += h_scur[2 * g]; }
+            sched_missed = missed;
+            if (getenv("PGA_DPW_SCHED_DEBUG")) for (int g = 0; g < NG; g++) fprintf(stderr, "[pga dpw sched] group %d: %u batches missed\n", g, h_scur[2 * g + 1]);
+            if (missed) {
+                HT(c, hipEventRecord(f->e_dp0[0], st));
+                pga_launch_dp_wave(d_chains, NCH, wgroups, c->d_model_const, dp, wbuf, st, d_dp_order, (int)dp_order.size(), false);
+                HT(c, hipEventRecord(f->e_dp1[0], st));
+                HT(c, hipMemcpyAsync(h_maxidx, dp.max_index, sizeof(int32_t) * NCH, hipMemcpyDeviceToHost, st));
+                HT(c, hipMemcpyAsync(h_ipath, dp.ipath, sizeof(int32_t) * NCH, hipMemcpyDeviceToHost, st));
+                HT(c, hipMemcpyAsync(h_maxscore, dp.max_score, sizeof(double) * NCH, hipMemcpyDeviceToHost, st));
+                HT(c, hipGetLastError());
+                HT(c, hipStreamSynchronize(st));
+            }
+        }
         pga_dp_note_stats(c, segmented ? &seg_plan : nullptr, h_segflags, NCH);
+        c->dp_stats[6] = (int32_t)std::min<uint32_t>(sched_slots, 0x7fffffffu); c->dp_stats[7] = (int32_t)sched_missed;
         if (segmented && getenv("PGA_DP_SEG_DEBUG")) {
             fprintf(stderr, "[pga dp-seg] %d chains cut into %d segments (<= %d nodes each); nodes rejected per round: %d %d %d; walked serially: %d; spine:",
                     seg_dev.n_big, seg_dev.n_segs, seg_dev.max_seg_nodes, c->dp_stats[2], c->dp_stats[3], c->dp_stats[4], c->dp_stats[5]);

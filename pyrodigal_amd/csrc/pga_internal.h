@@ -65,6 +65,8 @@ struct ChainDesc {
     int64_t raw_off = -1;   // node scoring: read the raw coding scores of the chain at this offset (same contig, same model)
                             // instead of the chain's own; -1: its own
     int64_t soff = 0;       // stop nodes of the chains before this one (in launch order): its first slot in a launch over (chain, stop) pairs
+    int32_t sched_b0 = 0;   // wave-batch scorer: first 64-node batch of the chain's contig in its group's step schedule (dpw_core.h)
+    int32_t _pad0 = 0;
 };
 
 // Node fields in device memory (struct of arrays; each pointer covers the whole batch).
@@ -129,7 +131,11 @@ struct DpwExt;
 // topology of one translation-table group: what depends on positions and kinds only, shared by every model of a contig
 // srank: per node (stop nodes only) its rank among the stop nodes of its contig, or nullptr: then the extras record of node i of a
 // chain is ext[off + i]; with it, ext[soff + srank[i]] (one 64-byte record per (chain, stop node) pair, dense)
-struct DpwTopoArrays { const int32_t* ndx; const int32_t* stop_val; uint8_t* kf; int32_t* lo; int32_t* q1; int32_t* q2; const int32_t* srank = nullptr; };
+// shdr / sent / scur (optional): the step schedule of the group (dpw_core.h "Step schedule"): one header per 64-node batch of every
+// contig, the entries in 32-byte slots (DPW_SCHED_STRIDE per batch), scur[1] = batches whose entries did not fit
+struct DpwSchedHdr;
+struct DpwTopoArrays { const int32_t* ndx; const int32_t* stop_val; uint8_t* kf; int32_t* lo; int32_t* q1; int32_t* q2; const int32_t* srank = nullptr;
+                       DpwSchedHdr* shdr = nullptr; uint4* sent = nullptr; uint32_t* scur = nullptr; };
 struct DpwGroupPtrs { DpwTopoArrays g[4]; };
 // per chain node: cs = cscore + sscore, suffix maxima of finished blocks; per stop node a 64-byte record of extras (indexed by
 // node, or dense by (chain, stop) pair: DpwTopoArrays::srank)
@@ -138,12 +144,19 @@ struct DpwBuffers { double* cs; DpwExt* ext; double* sfxv; int32_t* sfxi; };
 bool pga_dp_use_wave(int n_chains);
 void pga_launch_dpw_topo(const DpwTopoArrays& ta, const uint8_t* type, const int8_t* strand, const int32_t* d_cbase, int n_contigs, int n_nodes,
                          hipStream_t st);
+// the step schedule of a group (after pga_launch_dpw_topo): d_bbase[c] = 64-node batches of the contigs before contig c; max_batches: of
+// the contig with the most nodes; ta.sent holds DPW_SCHED_STRIDE slots per batch; clears ta.scur first
+void pga_launch_dpw_sched(const DpwTopoArrays& ta, const int32_t* d_cbase, const int32_t* d_bbase, int n_contigs, int max_batches, hipStream_t st);
 // chains[0..n_chains) of ONE group, contiguous in `off` from node_begin
 void pga_launch_dpw_chain(const ChainDesc* d_chains, int n_chains, int64_t node_begin, int64_t total_nodes, const NodeArrays& nodes,
                           const DpwTopoArrays& ta, const ModelConst* d_models, const DpwBuffers& wb, hipStream_t st);
 // d_order (optional): the order in which the chains are started -- a launch ends when its last chain does, so long chains go first
+// scheduled: every group carries a step schedule (k_dp_wave); else the steps' lane masks are worked out by every chain (k_dpw_dyn:
+// the fallback when a schedule did not fit its buffer, and a cross-check: PGA_DPW_SCHED=0)
 void pga_launch_dp_wave(const ChainDesc* d_chains, int n_chains, const DpwGroupPtrs& groups, const ModelConst* d_models, DpBuffers buf,
-                        const DpwBuffers& wb, hipStream_t st, const int32_t* d_order = nullptr, int n_blocks = 0 /* entries of d_order; < 0 = filler */);
+                        const DpwBuffers& wb, hipStream_t st, const int32_t* d_order = nullptr, int n_blocks = 0 /* entries of d_order; < 0 = filler */,
+                        bool scheduled = false);
+bool pga_dpw_use_sched();
 
 // kernel launchers (dp.hip)
 // chains[0..n_chains) must be contiguous in `off`; node_begin = chains[0].off, total_nodes = their node count

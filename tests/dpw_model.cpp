@@ -55,6 +55,43 @@ DpwS load_source(const Chain& C, const int j) {
     return S;
 }
 
+
+// ---- step schedule (dpw_core.h "Step schedule"): the host loop that builds a batch's entries; k_dpw_sched builds the same on the device
+struct Entry { int lane, s_ndx; uint32_t code; int j; uint64_t m[6]; };
+struct BatchSched { int jm; std::vector<Entry> near, walk; };
+
+BatchSched compile_batch(const Chain& C, const int b) {
+    BatchSched S;
+    const int i0 = b << 6;
+    DpwST T[64];
+    for (int t = 0; t < 64; t++) {
+        const int i = i0 + t;
+        T[t] = i < C.n ? dpw_st(i, C.kf[i], C.ndx[i], C.stopv[i], C.lo[i]) : dpw_st(-1, 0, 0, 0, 0);
+    }
+    S.jm = i0;
+    for (int t = 0; t < 64; t++) if (T[t].i >= 0 && (T[t].kind == 0 || T[t].kind == 3)) S.jm = std::min(S.jm, std::max(C.q1[T[t].i], T[t].lo));
+    auto entry_of = [&](const int j, const int lane, const bool in_batch, Entry& e) {
+        const int kf = C.kf[j], sk = DPW_KIND(kf), sf = DPW_FRAME(kf);
+        if (sk == 0) return false;
+        e.lane = lane; e.code = DPW_E_CODE(sk, sf); e.s_ndx = C.ndx[j]; e.j = j;
+        const int s_stop = C.stopv[j];
+        for (int q = 0; q < 6; q++) e.m[q] = 0;
+        for (int t = 0; t < 64; t++) {
+            const unsigned bits = dpw_static_bits(T[t], j, sk, sf, e.s_ndx, s_stop);
+            for (int q = 0; q < 5; q++) if ((bits >> q) & 1u) e.m[q] |= 1ull << t;
+            if (in_batch && sk == 1 && t < lane && dpw_static_pull(T[t], sf, s_stop)) e.m[5] |= 1ull << t;
+        }
+        uint64_t any = 0;
+        for (int q = 0; q < 6; q++) any |= e.m[q];
+        return any != 0;
+    };
+    Entry e;
+    for (int j = S.jm; j < i0; j++) if (entry_of(j, (j - S.jm) & 63, false, e)) S.near.push_back(e);
+    for (int k = 0; k < 64 && i0 + k < C.n; k++) if (entry_of(i0 + k, k, true, e)) S.walk.push_back(e);
+    return S;
+}
+inline unsigned lane_bits(const Entry& e, const int t) { unsigned b = 0; for (int q = 0; q < 6; q++) b |= (unsigned)((e.m[q] >> t) & 1ull) << q; return b; }
+
 }  // namespace
 
 extern "C" int dpw_model_run(int n, const int32_t* ndx, const int32_t* stop_val, const uint8_t* type, const int8_t* strand,
@@ -110,6 +147,20 @@ extern "C" int dpw_model_run(int n, const int32_t* ndx, const int32_t* stop_val,
 
         // ---- (2) near steps first (ascending sources onto an empty state: ">=" is the whole rule): the sources from the
         //      earliest p_near of a gene begin up to the batch, one at a time
+        static const bool legacy = getenv("DPW_MODEL_LEGACY") != nullptr;      // the steps as the kernel made them before the schedule
+        const BatchSched SC = legacy ? BatchSched() : compile_batch(C, b);
+        // one scheduled step: source values (score, traceb position, the extras of a forward stop) from the caller
+        auto sched_step = [&](const Entry& e, const DpwS& S) {
+            const int sk = DPW_E_KIND(e.code), sf = DPW_E_FRAME(e.code);
+            for (int t = 0; t < 64; t++) {
+                const unsigned bits = lane_bits(e, t) & 31u;
+                if (!bits) continue;
+                if (sk == 2) dpw_take_ge(L[t], true, dpw_sval_r5(LT[t], bits, e.s_ndx, S.score, M), e.j);
+                else if (sk == 3) dpw_take_ge(L[t], dpw_sok_r3(LT[t], bits, sf), S.score + dpw_w_r3(LT[t], sf), e.j);
+                else dpw_sstep_f3(LT[t], L[t], bits, e.j, e.s_ndx, S.vm, S.tbn, S.score, S.x0, S.x1, S.x2, M);
+            }
+        };
+        if (legacy) {
         int jmin = i0;
         for (int t = 0; t < 64; t++) if (T[t].i >= 0 && (T[t].kind == 0 || T[t].kind == 3)) jmin = std::min(jmin, std::max(T[t].q1, T[t].lo));
         for (int j = jmin; j < i0; j++) {
@@ -118,6 +169,15 @@ extern "C" int dpw_model_run(int n, const int32_t* ndx, const int32_t* stop_val,
             if (S.kind == 0) continue;          // as the kernel: a forward start before the batch offers nothing that the frame carries of (3) do not hold
             stats[1]++;
             for (int t = 0; t < 64; t++) dpw_step(S, LT[t], L[t], M);
+        }
+        } else {
+            stats[7] += (int64_t)SC.near.size() + (int64_t)SC.walk.size();
+            for (const Entry& e : SC.near) {
+                const DpwS S = load_source(C, e.j);
+                if ((S.kind == 1 || S.kind == 2) && S.tbn == -1) continue;
+                stats[1]++;
+                sched_step(e, S);
+            }
         }
         for (int t = 0; t < 64; t++) if (L[t].tag >= 0) tbn_pre[t] = ndx[dpw_tag_index(L[t].tag)];
         // ---- (1) gene begins: far gene ends, `a` over [lo, min(p_near, i0))
@@ -228,6 +288,27 @@ extern "C" int dpw_model_run(int n, const int32_t* ndx, const int32_t* stop_val,
             stats[4] += rounds; stats[5]++; if (rounds > stats[6]) stats[6] = rounds;
             static const bool log_rounds = getenv("DPW_MODEL_ROUNDS") != nullptr;
             if (log_rounds) fprintf(stderr, "R %d\n", rounds);
+        } else
+        if (!legacy) {
+            // ---- (6) the walk from the schedule: the batch's own entries in lane order
+            for (const Entry& e : SC.walk) {
+                const int k = e.lane, sk = DPW_E_KIND(e.code);
+                if (sk == 1) {
+                    for (int c = 0; c < k; c++) {
+                        if (!((e.m[5] >> c) & 1ull)) continue;
+                        const double v = L[c].val + T[c].cs;
+                        const int bi = dpw_tag_index(L[k].tag);
+                        if (v > L[k].val || (v == L[k].val && i0 + c > bi)) { L[k].val = v; L[k].tag = i0 + c; }
+                    }
+                }
+                const int tbk = dpw_tag_index(L[k].tag);
+                if ((sk == 1 || sk == 2) && tbk == -1) continue;
+                DpwS S; memset(&S, 0, sizeof S);
+                S.j = i0 + k; S.kind = sk; S.vm = T[k].vm;
+                S.tbn = tbk < 0 ? -1 : (tbk >= i0 ? T[tbk - i0].ndx : tbn_pre[k]);
+                S.score = L[k].val; S.x0 = T[k].x0; S.x1 = T[k].x1; S.x2 = T[k].x2;
+                sched_step(e, S);
+            }
         } else
         // ---- (6) the walk: lane k is final when the walk reaches source i0 + k
         for (int k = 0; k < 64 && i0 + k < n; k++) {
