@@ -259,7 +259,7 @@ static int score_connections_impl(pga_ctx* c, int32_t n, const int32_t* ndx, con
             const int nbat = (n + 63) >> 6;
             const int32_t h_bbase[2] = {0, nbat};
             uint32_t h_cur[2] = {0, 0};
-            HIP_TRY(c, db.alloc(&wg.g[0].shdr, (size_t)nbat + 1)); HIP_TRY(c, db.alloc(&wg.g[0].sent, 2 * (size_t)DPW_SCHED_STRIDE * ((size_t)nbat + 1) + 8)); HIP_TRY(c, db.alloc(&wg.g[0].scur, 16));
+            HIP_TRY(c, db.alloc(&wg.g[0].shdr, (size_t)nbat + 1)); HIP_TRY(c, db.alloc(&wg.g[0].sent, 2 * (size_t)DPW_SCHED_STRIDE * ((size_t)nbat + 1) + 16)); HIP_TRY(c, db.alloc(&wg.g[0].scur, 16));
             HIP_TRY(c, db.alloc(&d_bbase, 2));
             HIP_TRY(c, hipMemcpyAsync(d_bbase, h_bbase, sizeof h_bbase, hipMemcpyHostToDevice, st));
             pga_launch_dpw_sched(wg.g[0], d_cbase, d_bbase, 1, nbat, st);

@@ -344,10 +344,12 @@ __device__ __forceinline__ void wave_step(const SrcRegs& R, const int u, const i
 // The step schedule of a group (dpw_core.h "Step schedule"): for every 64-node batch of a contig, which sources take a pair step
 // onto it and which lanes each of them can reach -- once per (contig, translation table) instead of once per step of every model's
 // chain.  One workgroup per contig (and per run of 16 batches of a long one), a wavefront per batch; batch g of the group owns the
-// DPW_SCHED_STRIDE 32-byte slots from g * DPW_SCHED_STRIDE on, so nothing is counted, searched or handed out by an atomic (the
-// first form took one slot counter for the launch: 70 000 atomics on one address were two thirds of a millisecond).  A batch needs
-// one slot per reverse node that reaches a lane and two per forward stop; 55 on config-4 contigs.  One whose bound (by kinds alone)
-// does not fit is marked and counted in scur[1], and the launch then falls back to k_dpw_dyn.
+// DPW_SCHED_STRIDE slots from g * DPW_SCHED_STRIDE on, so nothing is counted, searched or handed out by an atomic (the first
+// form took one counter for the launch: 70 000 atomics on one address were two thirds of a millisecond).  A batch whose entries
+// (bounded by its kinds alone) do not fit is marked and counted in scur[1], and the launch then falls back to k_dpw_dyn.
+// The lane masks are the tests of dpw_static_bits (dpw_core.h; the host model builds its entries with that function and the two are
+// compared through the kernels' results), taken apart by source kind so that a source costs a few vector compares: per batch the
+// kinds / frames of the targets are lane masks in scalar registers, a source contributes one compare per position test.
 __global__ void __launch_bounds__(256)
 k_dpw_sched(const int32_t* __restrict__ cbase, const int32_t* __restrict__ bbase, const DpwTopoArrays ta) {
     const int c = blockIdx.x, lane = threadIdx.x & 63;
@@ -356,49 +358,80 @@ k_dpw_sched(const int32_t* __restrict__ cbase, const int32_t* __restrict__ bbase
     const int32_t* __restrict__ ndx = ta.ndx + base; const int32_t* __restrict__ stopv = ta.stop_val + base;
     const uint8_t* __restrict__ kfp = ta.kf + base;
     const int bb0 = bbase[c];
+    const lanemask me = 1ull << lane, below = me - 1ull;
     for (int bi = b; bi < b + 4 && (bi << 6) < n; bi++) {
         const int i0 = bi << 6, bg = bb0 + bi;
         const int i = i0 + lane;
         const bool act = i < n;
         const int ii = act ? i : n - 1;
-        const int my_kf = kfp[ii];
-        const DpwST T = dpw_st(act ? i : -1, my_kf, ndx[ii], stopv[ii], ta.lo[base + ii]);
-        const bool gb = act && (T.kind == 0 || T.kind == 3);
-        const int jm = wave_min_i32(gb ? max(ta.q1[base + ii], T.lo) : i0);
-        // slots: an upper bound from the kinds alone
-        unsigned ub = __popcll(vote(act && T.kind != 0)) + __popcll(vote(act && T.kind == 1));
+        const int my_kf = kfp[ii], t_ndx = ndx[ii], t_stop = stopv[ii];
+        const int t_lo = act ? ta.lo[base + ii] : INT_MAX;
+        const int kind = act ? DPW_KIND(my_kf) : -1, frame = DPW_FRAME(my_kf);
+        // the targets' kinds and frames as lane masks
+        const lanemask k0 = vote(kind == 0), k1 = vote(kind == 1), k2 = vote(kind == 2), k3 = vote(kind == 3);
+        const lanemask fr0 = vote(frame == 0), fr1 = vote(frame == 1), fr2 = vote(frame == 2);
+        const lanemask gbm = k0 | k3;
+        const int jm = wave_min_i32((kind == 0 || kind == 3) ? max(ta.q1[base + ii], t_lo) : i0);
+        // per-lane constants of the position tests (dpw_st / dpw_static_bits)
+        const int key_r5 = kind == 3 ? t_ndx - 2 : t_ndx;                     // a reverse start precedes this gene begin when s_ndx < key_r5
+        int dlo0 = INT_MAX, dhi0 = INT_MIN;
+        if (kind == 2) { dlo0 = t_stop - 4; dhi0 = min(t_stop + DPW_MAX_OPP_OVLP - 5, (t_ndx + t_stop + 4) >> 1); }
+        // slots: an upper bound from the kinds alone (a reverse node one slot; a forward stop a line and perhaps a pad; END, and the
+        // rest of its line)
+        const lanemask own = k1 | k2 | k3;
+        unsigned ub = __popcll(own) + 2 * __popcll(k1) + 2;
         for (int t0 = jm; t0 < i0; t0 += 64) {
             const int j = t0 + lane;
             const int k = j < i0 ? DPW_KIND(kfp[j]) : 0;
-            ub += __popcll(vote(k != 0)) + __popcll(vote(k == 1));
+            ub += __popcll(vote(k != 0)) + 2 * __popcll(vote(k == 1)) + 2;
         }
         if (ub > DPW_SCHED_STRIDE) {
             if (lane == 0) { atomicAdd(&ta.scur[1], 1u); ta.shdr[bg] = DpwSchedHdr{DPW_SCHED_NONE, 0u, jm, 0}; }
             continue;
         }
         const unsigned off = (unsigned)bg * DPW_SCHED_STRIDE;
-        uint4* out = ta.sent + 2 * (size_t)off;
-        auto emit = [&](const int j, const int u, const int ukf, const int s_ndx, const int s_stop, const bool in_batch) -> int {
+        uint4* const out0 = ta.sent + 2 * (size_t)off;                       // 32-byte slots
+        unsigned slot = 0;
+        // one source; `win`: the lanes whose window holds it and that lie behind it.  Returns 1 when an entry was written.
+        auto emit = [&](const int j, const int u, const int ukf, const int s_ndx, const int s_stop, const lanemask win, const bool in_batch) -> int {
             const int sk = DPW_KIND(ukf), sf = DPW_FRAME(ukf);
-            const unsigned bits = dpw_static_bits(T, j, sk, sf, s_ndx, s_stop);
-            const lanemask m0 = vote((bits & 1u) != 0), m1 = vote((bits & 2u) != 0);
-            lanemask m2 = 0, m3 = 0, m4 = 0, m5 = 0;
-            if (sk == 1) {
-                m2 = vote((bits & 4u) != 0); m3 = vote((bits & 8u) != 0); m4 = vote((bits & 16u) != 0);
-                if (in_batch) m5 = vote(lane < u && dpw_static_pull(T, sf, s_stop));
+            lanemask m0, m1, m2 = 0, m3 = 0, m4 = 0, m5 = 0;
+            bool close = false;             // some lane of m1 lies within OPER_DIST bases: its distance term comes from the table
+            if (sk == 2) {
+                m0 = win & gbm & vote(s_ndx < key_r5);
+                if (!m0) return 0;
+                m1 = m0 & k3 & vote(t_ndx - s_ndx <= 3 * DPW_OPER_DIST);
+                close = (m1 & vote(t_ndx - s_ndx <= DPW_OPER_DIST)) != 0;
+            } else if (sk == 3) {
+                const lanemask in_orf = win & vote(s_stop > t_ndx);
+                m0 = in_orf & k2 & pick3m(sf, fr0, fr1, fr2);
+                m1 = in_orf & k3;
+                if (!(m0 | m1)) return 0;
+            } else {
+                m0 = win & k0 & vote(s_ndx + 2 < t_ndx);
+                m1 = m0 & vote(t_ndx - s_ndx <= 3 * DPW_OPER_DIST);
+                close = (m1 & vote(t_ndx - s_ndx <= DPW_OPER_DIST)) != 0;
+                m2 = win & k1 & vote(t_stop < s_ndx);
+                m3 = win & k2 & vote((s_ndx > dlo0) & (s_ndx < dhi0));
+                m4 = win & k3 & vote(s_ndx < t_ndx - 4);
+                if (in_batch) m5 = k0 & pick3m(sf, fr0, fr1, fr2) & ((1ull << u) - 1ull) & vote(t_ndx > s_stop);
+                if (!(m0 | m2 | m3 | m4 | m5)) return 0;
+                if (slot & 1u) { if (lane == 0) out0[2 * slot] = make_uint4(0u, 0u, DPW_E_NOP, 0u); slot++; }      // a forward stop takes a whole line
             }
-            if (!(m0 | m1 | m2 | m3 | m4 | m5)) return 0;
             if (lane == 0) {
-                out[0] = make_uint4((unsigned)u, (unsigned)s_ndx, DPW_E_CODE(sk, sf), (unsigned)j);
+                uint4* out = out0 + 2 * slot;
+                out[0] = make_uint4((unsigned)u, (unsigned)s_ndx, DPW_E_CODE(sk, sf) | (close ? DPW_E_CLOSE : 0u), (unsigned)j);
                 out[1] = make_uint4((unsigned)m0, (unsigned)(m0 >> 32), (unsigned)m1, (unsigned)(m1 >> 32));
                 if (sk == 1) {
                     out[2] = make_uint4((unsigned)m2, (unsigned)(m2 >> 32), (unsigned)m3, (unsigned)(m3 >> 32));
                     out[3] = make_uint4((unsigned)m4, (unsigned)(m4 >> 32), (unsigned)m5, (unsigned)(m5 >> 32));
                 }
             }
-            out += 2 * DPW_E_SLOTS(sk);
+            slot += sk == 1 ? 2 : 1;
             return 1;
         };
+        // END closes a list; the next list starts on the next line
+        auto emit_end = [&]() { if (lane == 0) out0[2 * slot] = make_uint4(0u, 0u, DPW_E_END, 0x7fffffffu); slot = (slot + 2) & ~1u; };
         int n_near = 0, n_own = 0;
         for (int t0 = jm; t0 < i0; t0 += 64) {
             const int j = t0 + lane;
@@ -409,16 +442,21 @@ k_dpw_sched(const int32_t* __restrict__ cbase, const int32_t* __restrict__ bbase
             while (visit) {
                 const int u = __builtin_ctzll(visit);
                 visit &= visit - 1;
-                n_near += emit(t0 + u, u, rl_i32(s_kf, u), rl_i32(s_nd, u), rl_i32(s_sv, u), false);
+                const int js = t0 + u;
+                n_near += emit(js, u, rl_i32(s_kf, u), rl_i32(s_nd, u), rl_i32(s_sv, u), vote(js >= t_lo), false);      // (t_lo of a lane without a node is INT_MAX)
             }
+            emit_end();
         }
         {
-            lanemask visit = vote(act && T.kind != 0);
+            // inside the batch the window test is "a later lane": a window reaches back at least MAX_NODE_DIST nodes
+            lanemask visit = own;
+            const lanemask actm = k0 | own;
             while (visit) {
                 const int u = __builtin_ctzll(visit);
                 visit &= visit - 1;
-                n_own += emit(i0 + u, u, rl_i32(my_kf, u), rl_i32(T.ndx, u), rl_i32(T.stop_val, u), true);
+                n_own += emit(i0 + u, u, rl_i32(my_kf, u), rl_i32(t_ndx, u), rl_i32(t_stop, u), actm & (~1ull << u), true);
             }
+            emit_end();
         }
         if (lane == 0) ta.shdr[bg] = DpwSchedHdr{off, (unsigned)n_near | ((unsigned)n_own << 16), jm, 0};
     }
@@ -737,21 +775,19 @@ k_dpw_dyn(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
 
 // ------------------------------------------------------------------------------------------------------------------------
 // k_dp_wave: the same batch structure as k_dpw_dyn above, its pair steps -- the near steps (2) and the in-batch walk (6) --
-// driven by the group's step schedule.  An entry arrives through scalar loads (the schedule is read through the constant address
-// space: it was written by an earlier launch) and carries the lanes the source can reach; a step is the source's value
-// (v_readlane), one add, one compare under the entry's mask.
+// driven by the group's step schedule and written in gfx950 assembly (dpw_walk_gfx950.inc, generated by tools/gen_dpw_walk.py,
+// which also states the steps; k_dpw_dyn's wave_step is the same logic in C++).  An entry arrives through scalar loads and
+// carries the lanes the source can reach; a step is the source's value (v_readlane), one add, one compare under the entry's mask.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) u32x4 k_uint4;
-__device__ __forceinline__ lanemask mk64(const unsigned lo, const unsigned hi) { return (lanemask)lo | ((lanemask)hi << 32); }
 
-// ASM: the steps as the assembly blocks of dpw_walk_gfx950.inc; else as the C++ lambdas below (the readable statement of the same
-// steps, kept as a cross-check: PGA_DPW_ASM=0)
-template <int OCC, bool ASM>
+template <int OCC>
 __global__ void __launch_bounds__(64, OCC)
 k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const double* __restrict__ g_cs, const DpwExt* __restrict__ g_ext,
           const ModelConst* __restrict__ models, DpBuffers buf, double* __restrict__ g_sfxv, int32_t* __restrict__ g_sfxi,
           const int32_t* __restrict__ order /* or nullptr: workgroup b walks chain order[b] (longest chains first) */) {
     __shared__ double s_igm[64];
+    __shared__ int s_pf[64];                        // where the look-ahead loads of the schedule land (never read)
     const int chain = order != nullptr ? order[blockIdx.x] : (int)blockIdx.x;
     if (chain < 0) return;                          // a filler: the per-XCD queues of the start order are not equally long
     const ChainDesc cd = chains[chain];
@@ -763,7 +799,7 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
     const double NEG_INF = -__builtin_huge_val();
     const DpwModel M{mc->st_wt, mc->negc, s_igm};
     WavePtrs P;
-    k_uint4* s_hdr; k_uint4* s_ent;
+    k_uint4* s_hdr; k_uint4* s_ent; const uint4* g_sent;
     {
         const DpwTopoArrays& ta = groups.g[cd.group];
         P.ndx = ta.ndx + cd.topo_off; P.stopv = ta.stop_val + cd.topo_off; P.kf = ta.kf + cd.topo_off;
@@ -774,7 +810,7 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
         P.score = buf.score + cd.off; P.traceb = buf.traceb + cd.off; P.tbn = buf.tbn + cd.off; P.ov = buf.ov_mark + cd.off;
         P.sfxv = g_sfxv + cd.off; P.sfxi = g_sfxi + cd.off;
         s_hdr = (k_uint4*)(ta.shdr) + cd.sched_b0;
-        s_ent = (k_uint4*)(ta.sent);
+        s_ent = (k_uint4*)(ta.sent); g_sent = ta.sent;
     }
     // a launch ends when its longest chain does: long chains issue first, the short ones fill their stalls
     if (n >= 2048) __builtin_amdgcn_s_setprio(3); else if (n >= 1536) __builtin_amdgcn_s_setprio(2); else if (n >= 1024) __builtin_amdgcn_s_setprio(1);
@@ -797,16 +833,23 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
     };
     for (int b = 0; b < nb; b++) {
         const int i0 = b << 6;
-        const u32x4 hdr = s_hdr[b];                 // {first slot, near entries | own entries << 16, jm, -}
+        const u32x4 hdr = s_hdr[b];                 // {first entry, near entries | own entries << 16, jm, -}
+        {
+            // The batch's entries are read line by line through the scalar cache, each a dependent round trip; the first model of a
+            // contig to come by finds them in HBM (2 000 cycles per line).  One vector instruction asks for all of them now: lane l
+            // touches line l of the batch's slots (4 bytes, straight to LDS, into a scratch row nobody reads), which puts the lines in this
+            // XCD's L2 by the time the steps get to them.
+            const char* line = (const char*)g_sent + ((size_t)(cd.sched_b0 + b) * DPW_SCHED_STRIDE * sizeof(DpwSlot) + (size_t)lane * 64);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(line), "s"((unsigned)(uintptr_t)s_pf) : "memory");
+        }
         DpwT T; int kfb;
         load_target_w(T, kfb, P, i0, lane, n, M.negc);
         const DpwLT LT = dpw_lean(T);
         const bool act = T.i >= 0;
         // reverse stops with an overlapping start in frame f: the one lane mask of a step that depends on the model
         const lanemask r3v0 = vote(act && T.kind == 3 && (T.vm & 1)), r3v1 = vote(act && T.kind == 3 && (T.vm & 2)), r3v2 = vote(act && T.kind == 3 && (T.vm & 4));
-        // what a reverse-stop source adds: a reverse start of its frame takes its own cs, a reverse stop the x of that frame
-        const double xs0 = (T.kind == 2 && T.frame == 0) ? T.cs : T.x0, xs1 = (T.kind == 2 && T.frame == 1) ? T.cs : T.x1,
-                     xs2 = (T.kind == 2 && T.frame == 2) ? T.cs : T.x2;
         const int fbit = 1 << T.frame;
         mark(0);
         DpwLane L{0.0, -1};
@@ -815,58 +858,7 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
             const int cur = dpw_tag_index(L.tag);
             if (ok && (val > L.val || (val == L.val && j > cur))) { L.val = val; L.tag = j | (ov1 << DPW_TAG_BITS); tbn_pre = s_ndx; }
         };
-        // One scheduled step.  h = {lane, s_ndx, code, j}; the source's values come from lane u of the registers handed in (a tile
-        // of finished nodes for the near steps; the batch itself for the walk); s_tbn() = position of the source's own traceb node.
-        // A step only works out WHICH lanes take the source (tk), at what value and tag; the caller commits with three selects,
-        // whatever the kind -- straight-line code between an entry's loads and the next entry's.
-        auto step_r5 = [&](const u32x4 h, const u32x4 ma, const double s_score, lanemask& tk, double& val) {
-            const lanemask m0 = mk64(ma.x, ma.y), m1 = mk64(ma.z, ma.w);
-            val = s_score + M.negc;
-            if (m1) { if (in_mask(m1)) { const int d = T.ndx - (int)h.y; val = s_score + (d <= DPW_OPER_DIST ? s_igm[d] : 0.0); } }
-            tk = m0 & vote(val >= L.val);
-        };
-        auto step_r3 = [&](const u32x4 h, const u32x4 ma, const double s_score, lanemask& tk, double& val) {
-            const int sf = DPW_E_FRAME(h.z);
-            const lanemask ok = mk64(ma.x, ma.y) | (mk64(ma.z, ma.w) & pick3m(sf, r3v0, r3v1, r3v2));
-            if (sf == 0) { val = s_score + xs0; asm volatile("; frame 0"); }
-            else if (sf == 1) { val = s_score + xs1; asm volatile("; frame 1"); }
-            else { val = s_score + xs2; asm volatile("; frame 2"); }
-            tk = ok & vote(val >= L.val);
-        };
-        auto step_f3 = [&](const u32x4 h, const u32x4 ma, const u32x4 mb, const u32x4 mcq, const double s_score, const int s_vm,
-                           const double s_x0, const double s_x1, const double s_x2, auto s_tbn, lanemask& tk, double& val, int& tag) {
-            const lanemask mF5 = mk64(ma.x, ma.y), mF5t = mk64(ma.z, ma.w), mF3 = mk64(mb.x, mb.y), mR5 = mk64(mb.z, mb.w), mR3 = mk64(mcq.x, mcq.y);
-            const int s_ndx = (int)h.y;
-            lanemask okm = mF5;
-            double w = M.negc;
-            if (mF5t) { if (in_mask(mF5t)) { const int d = T.ndx - s_ndx; w = d <= DPW_OPER_DIST ? s_igm[d] : 0.0; } }
-            if (mF3) {
-                const lanemask o3 = mF3 & vote((s_vm & fbit) != 0);
-                if (o3) { okm |= o3; if (in_mask(o3)) w = dpw_sel3(T.frame, s_x0, s_x1, s_x2); }
-            }
-            if (mR5 | mR3) {
-                const int lhs = s_tbn() + s_ndx + 7;
-                if (mR5) { okm |= mR5 & vote(lhs < LT.drhs0); if (in_mask(mR5)) w = T.csd; }
-                if (mR3) {
-                    okm |= mR3;
-                    if (in_mask(mR3)) {
-                        const bool c0 = (s_ndx > LT.dlo0) & (s_ndx < LT.dhi0) & (lhs < LT.drhs0);
-                        const bool c1 = (s_ndx > LT.dlo1) & (s_ndx < LT.dhi1) & (lhs < LT.drhs1);
-                        const bool c2 = (s_ndx > LT.dlo2) & (s_ndx < LT.dhi2) & (lhs < LT.drhs2);
-                        double mv = 0.0; int m = -1;
-                        if (c0 & (T.x0 > mv)) { mv = T.x0; m = 0; }
-                        if (c1 & (T.x1 > mv)) { mv = T.x1; m = 1; }
-                        if (c2 & (T.x2 > mv)) { mv = T.x2; m = 2; }
-                        w = m >= 0 ? mv : M.negc;
-                        tag |= (m + 1) << DPW_TAG_BITS;
-                    }
-                }
-            }
-            val = s_score + w;
-            tk = okm & vote(val >= L.val);
-        };
-
-        k_uint4* ep = s_ent + 2 * (size_t)hdr.x;
+        k_uint4* ep = s_ent + 2 * (size_t)hdr.x;                  // 32-byte slots
         // operands of the assembly blocks (names fixed by tools/gen_dpw_walk.py)
         unsigned long long a_ep = (unsigned long long)(uintptr_t)ep;
         double& a_lv = L.val; int& a_lt = L.tag;
@@ -878,46 +870,19 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
         const unsigned a_igmb = (unsigned)(uintptr_t)s_igm;
         // ---- (2) near steps first (ascending sources onto an empty state: ">=" is the whole tie rule), from the schedule
         {
-            int left = (int)(hdr.y & 0xffffu);
-            for (int t0 = (int)hdr.z; left > 0 && t0 < i0; t0 += 64) {
+            for (int t0 = (int)hdr.z; t0 < i0; t0 += 64) {
                 const int j = t0 + lane;
                 const int jj = j < i0 ? j : i0 - 1;
                 const int s_tb = P.tbn[jj];
                 const double t_score = P.score[jj];
                 const int er = P.srank != nullptr ? P.srank[jj] : jj;
                 int t_vm = 0; double t_x0 = 0.0, t_x1 = 0.0, t_x2 = 0.0;
-                if (DPW_KIND(P.kf[jj]) == 1) { const DpwExt* e = P.ext + er; t_vm = e->vm; t_x0 = e->x[0]; t_x1 = e->x[1]; t_x2 = e->x[2]; }
-                if constexpr (ASM) {
-                    int a_left = left;
-                    const int a_tend = t0 + 64;
-                    const double a_ns = t_score, a_nx0 = t_x0, a_nx1 = t_x1, a_nx2 = t_x2;
-                    const int a_nb = s_tb, a_nvm = t_vm;
-                    DPW_ASM_NEAR();
-                    left = a_left;
-                } else {
-                    while (left > 0) {
-                        const u32x4 h = ep[0];
-                        if ((int)h.w >= t0 + 64) break;             // the entry's source sits in the next tile
-                        const u32x4 ma = ep[1];
-                        const int sk = DPW_E_KIND(h.z), u = (int)h.x;
-                        left--;
-                        lanemask tk = 0; double val = 0.0; int tag = (int)h.w;
-                        const int tbu = rl_i32(s_tb, u);
-                        const double s_score = rl_f64(t_score, u);
-                        if (sk == 1) {
-                            const u32x4 mb = ep[2], mcq = ep[3];
-                            ep += 4;
-                            // (a gene end that was never reached is no source)
-                            if (tbu != -1) step_f3(h, ma, mb, mcq, s_score, rl_i32(t_vm, u), rl_f64(t_x0, u), rl_f64(t_x1, u), rl_f64(t_x2, u), [&]() { return tbu; }, tk, val, tag);
-                        } else {
-                            ep += 2;
-                            if (sk == 2) { if (tbu != -1) step_r5(h, ma, s_score, tk, val); }
-                            else step_r3(h, ma, s_score, tk, val);
-                        }
-                        const bool t = in_mask(tk);
-                        L.val = t ? val : L.val; L.tag = t ? tag : L.tag;
-                    }
-                }
+                const int s_kind = DPW_KIND(P.kf[jj]);
+                if (s_kind == 1) { const DpwExt* e = P.ext + er; t_vm = e->vm; t_x0 = e->x[0]; t_x1 = e->x[1]; t_x2 = e->x[2]; }
+                // (a gene end that was never reached is no source: it offers -inf, which no lane takes)
+                const double a_ns = (s_tb == -1 && (s_kind == 1 || s_kind == 2)) ? NEG_INF : t_score, a_nx0 = t_x0, a_nx1 = t_x1, a_nx2 = t_x2;
+                const int a_nb = s_tb, a_nvm = t_vm;
+                DPW_ASM_NEAR();
             }
             if (L.tag >= 0) tbn_pre = P.ndx[dpw_tag_index(L.tag)];
         }
@@ -1002,52 +967,9 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
         // ---- (6) the walk, from the schedule: lane k is final when the walk reaches its entry.  A forward stop first pulls the
         //      forward starts of its ORF that sit before it in the batch (the entry's `pull` lanes; they are final by then).
         {
-            if constexpr (ASM) {
-                int a_left = (int)(hdr.y >> 16);
-                const int a_tbnpre = tbn_pre;
-                DPW_ASM_WALK();
-            } else {
-                const double offer_cs = T.cs;
-                const int my_vm = T.vm;
-                for (int left = (int)(hdr.y >> 16); left > 0; left--) {
-                    const u32x4 h = ep[0];
-                    const u32x4 ma = ep[1];
-                    const int sk = DPW_E_KIND(h.z), k = (int)h.x;
-                    lanemask tk = 0; double val = 0.0; int tag = (int)h.w;
-                    int tagk = rl_i32(L.tag, k);
-                    if (sk == 1) {
-                        const u32x4 mb = ep[2], mcq = ep[3];
-                        ep += 4;
-                        lanemask cand = mk64(mcq.z, mcq.w);
-                        if (cand) {
-                            double bv = rl_f64(L.val, k);
-                            int bi = tagk < 0 ? -1 : (tagk & DPW_TAG_MASK);
-                            const double offer = L.val + offer_cs;                  // what each lane would offer as a forward start
-                            while (cand) {
-                                const int c = __builtin_ctzll(cand);
-                                cand &= cand - 1ull;
-                                const double v = rl_f64(offer, c);
-                                if (v > bv || (v == bv && i0 + c > bi)) { bv = v; bi = i0 + c; tagk = i0 + c; }
-                            }
-                            const bool me = lane == k;
-                            L.val = me ? bv : L.val; L.tag = me ? tagk : L.tag;
-                        }
-                        // (a gene end that was never reached connects to nothing)
-                        if (tagk >= 0)
-                            step_f3(h, ma, mb, mcq, rl_f64(L.val, k), rl_i32(my_vm, k), rl_f64(T.x0, k), rl_f64(T.x1, k), rl_f64(T.x2, k), [&]() {
-                                const int tbk = tagk & DPW_TAG_MASK;
-                                return tbk >= i0 ? rl_i32(T.ndx, tbk - i0) : rl_i32(tbn_pre, k);
-                            }, tk, val, tag);
-                    } else {
-                        ep += 2;
-                        const double s_score = rl_f64(L.val, k);
-                        if (sk == 2) { if (tagk >= 0) step_r5(h, ma, s_score, tk, val); }
-                        else step_r3(h, ma, s_score, tk, val);
-                    }
-                    const bool t = in_mask(tk);
-                    L.val = t ? val : L.val; L.tag = t ? tag : L.tag;
-                }
-            }
+            const int a_tbnpre = tbn_pre;
+            double a_sv = L.tag >= 0 ? L.val : NEG_INF;      // what a lane offers as a gene-end source: -inf while it was never reached
+            DPW_ASM_WALK();
         }
         mark(5);
         // ---- (7) the batch is final: results, block structures, carries
@@ -1161,10 +1083,7 @@ void pga_launch_dp_wave(const ChainDesc* d_chains, int n_chains, const DpwGroupP
     if (!occ) { const char* e = getenv("PGA_DPW_OCC"); occ = e ? atoi(e) : 5; if (occ < 4 || occ > 6) occ = 5; }
 #define DPW_LAUNCH(K) hipLaunchKernelGGL(K, dim3((unsigned)n_blocks), dim3(64), 0, st, d_chains, groups, (const double*)wb.cs, (const DpwExt*)wb.ext, \
                                          d_models, buf, wb.sfxv, wb.sfxi, d_order)
-    static int use_asm = -1;
-    if (use_asm < 0) { const char* e = getenv("PGA_DPW_ASM"); use_asm = e ? (atoi(e) != 0) : 1; }
-    if (scheduled && use_asm) { if (occ == 5) DPW_LAUNCH((k_dp_wave<5, true>)); else if (occ == 6) DPW_LAUNCH((k_dp_wave<6, true>)); else DPW_LAUNCH((k_dp_wave<4, true>)); }
-    else if (scheduled) { if (occ == 5) DPW_LAUNCH((k_dp_wave<5, false>)); else if (occ == 6) DPW_LAUNCH((k_dp_wave<6, false>)); else DPW_LAUNCH((k_dp_wave<4, false>)); }
+    if (scheduled) { if (occ == 5) DPW_LAUNCH(k_dp_wave<5>); else if (occ == 6) DPW_LAUNCH(k_dp_wave<6>); else DPW_LAUNCH(k_dp_wave<4>); }
     else { if (occ == 5) DPW_LAUNCH(k_dpw_dyn<5>); else if (occ == 6) DPW_LAUNCH(k_dpw_dyn<6>); else DPW_LAUNCH(k_dpw_dyn<4>); }
 #undef DPW_LAUNCH
 }

@@ -421,26 +421,34 @@ DPW_HD void dpw_step(const DpwS& S, const DpwLT& T, DpwLane& L, const DpwModel& 
 // relations that depend on a model (the overlapping starts of a stop node: star_ptr), the dynamic tests listed with each kind.
 //
 // A batch's entries: first the NEAR sources (older than the batch, from the earliest p_near of a gene begin of the batch: `jm`),
-// ascending, then the batch's own nodes as sources, ascending.  Forward starts never step (a forward stop pulls the starts of
-// its ORF, see `pull`).  An entry whose masks are all empty is left out.
-//   header, 16 bytes:  lane (of the source inside its 64-node tile / inside the batch), s_ndx (its position),
-//                      code = kind | frame << 2, j (its chain index)
-//   R5 (32 bytes):  m0 = gene begins in the window with s_ndx < key_r5            (ref: _connection.h:125-130, 337-342)
-//                   m1 = those of m0 that are reverse stops within 3 * OPER_DIST bases (the distance term)
-//   R3 (32 bytes):  m0 = reverse starts of the source's frame inside its ORF      (ref: :228-235)
-//                   m1 = reverse stops inside its ORF; dynamic: the lane has an overlapping start in the source's frame (:345-356)
-//   F3 (64 bytes):  mF5 = forward starts behind it (:117-124), mF5t = those within 3 * OPER_DIST bases,
-//                   mF3 = forward stops whose ORF holds it; dynamic: the SOURCE has an overlapping start in the lane's frame (:177-188),
-//                   mR5 = reverse starts whose static interval holds s_ndx; dynamic: tbn + s_ndx + 7 < drhs0 (:238-254),
-//                   mR3 = reverse stops with s_ndx < ndx - 4; dynamic: the candidates through the lane's overlapping starts (:288-336),
-//                   pull = (batch sources only) the forward starts of its ORF that sit before it in the batch (:166-174)
-struct DpwSchedHdr { uint32_t off; uint32_t cnt; int32_t jm; int32_t spare; };   // off: first 32-byte slot; cnt = near entries | batch entries << 16
-#define DPW_SCHED_STRIDE 112u                                                      // slots a batch owns (its entries sit at batch * stride)
-#define DPW_SCHED_NONE 0xffffffffu                                                // off: the entries did not fit (the caller falls back)
-#define DPW_E_CODE(kind, frame) ((uint32_t)((kind) | ((frame) << 2)))
+// ascending, in tiles of 64 nodes from jm on, one list per tile; then the batch's own nodes as sources, ascending, one more list.
+// Forward starts never step (a forward stop pulls the starts of its ORF, see `pull`).  An entry whose masks are all empty is left
+// out.  Layout: 32-byte slots, two to a 64-byte line; the walk takes a LINE per scalar load (s_load_dwordx16: the round trip
+// through the scalar cache is what a step waits for, so a load carries two steps), asks for line e + 1 before it looks at line e,
+// and finds no counter: a list starts on a line and ends with an END slot.
+//   slot, 32 bytes:  lane (of the source inside its 64-node tile / inside the batch), s_ndx (its position),
+//                    code = kind | frame << 2 | 16 if not a reverse start | 64 (DPW_E_CLOSE); 16 alone = END, 48 = NOP (a pad), j (its chain index),
+//                    m[0], m[1]
+//   R5, one slot:    m[0] = gene begins in the window with s_ndx < key_r5                     (ref: _connection.h:125-130, 337-342)
+//                    m[1] = those of m[0] that are reverse stops within 3 * OPER_DIST bases (the distance term)
+//   R3, one slot:    m[0] = reverse starts of the source's frame inside its ORF               (ref: :228-235)
+//                    m[1] = reverse stops inside its ORF; dynamic: the lane has an overlapping start in the source's frame (:345-356)
+//   F3, one LINE (a NOP slot in front of it where it would start in the middle of one): the slot's m[0] = mF5 = forward starts behind
+//        it (:117-124), m[1] = mF5t = those within 3 * OPER_DIST bases, then four more masks:
+//        mF3 = forward stops whose ORF holds it; dynamic: the SOURCE has an overlapping start in the lane's frame (:177-188),
+//        mR5 = reverse starts whose static interval holds s_ndx; dynamic: tbn + s_ndx + 7 < drhs0 (:238-254),
+//        mR3 = reverse stops with s_ndx < ndx - 4; dynamic: the candidates through the lane's overlapping starts (:288-336),
+//        pull = (batch sources only) the forward starts of its ORF that sit before it in the batch (:166-174)
+struct DpwSchedHdr { uint32_t off; uint32_t cnt; int32_t jm; int32_t spare; };   // off: first slot; cnt = near entries | batch entries << 16 (END / NOP not counted)
+struct DpwSlot { uint32_t lane; int32_t s_ndx; uint32_t code; int32_t j; uint64_t m[2]; };
+#define DPW_SCHED_STRIDE 128u                                                     // slots a batch owns (its lists sit at batch * stride)
+#define DPW_SCHED_NONE 0xffffffffu                                                // off: the lists did not fit (the caller falls back)
+#define DPW_E_CODE(kind, frame) ((uint32_t)((kind) | ((frame) << 2) | ((kind) != 2 ? 16 : 0)))
+#define DPW_E_END 16u
+#define DPW_E_NOP 48u
+#define DPW_E_CLOSE 64u      // R5 / F3: some lane of m[1] lies within OPER_DIST bases of the source (its distance term needs the table; 0 otherwise)
 #define DPW_E_KIND(c)  ((int)((c) & 3))
 #define DPW_E_FRAME(c) ((int)(((c) >> 2) & 3))
-#define DPW_E_SLOTS(kind) ((kind) == 1 ? 2 : 1)
 
 // what the topology fixes of a target
 struct DpwST { int i, kind, frame, ndx, stop_val, lo, dlo0, dhi0; };

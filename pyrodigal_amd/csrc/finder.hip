@@ -1555,12 +1555,12 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
 #undef WBUF
                 wgroups.g[g].ndx = ga[g].ndx; wgroups.g[g].stop_val = ga[g].stop_val; wgroups.g[g].srank = ga[g].srank;
                 if (use_sched) {
-                    // headers: one per batch; entries: DPW_SCHED_STRIDE 32-byte slots per batch (what does not fit is counted and the launch
+                    // headers: one per batch; lists: DPW_SCHED_STRIDE 32-byte slots per batch (what does not fit is counted and the launch
                     // falls back to k_dpw_dyn)
                     const int64_t nbat = h_bbase[(size_t)g * (NC + 1) + NC];
                     void* p__; int rc__;
                     snprintf(nm, sizeof nm, "dpw_shdr%d", g); rc__ = ensure_dev(c, nm, sizeof(DpwSchedHdr) * (size_t)(nbat + 1), &p__); if (rc__) return rc__; wgroups.g[g].shdr = (DpwSchedHdr*)p__;
-                    snprintf(nm, sizeof nm, "dpw_sent%d", g); rc__ = ensure_dev(c, nm, 32 * (size_t)DPW_SCHED_STRIDE * (size_t)(nbat + 1) + 128, &p__); if (rc__) return rc__; wgroups.g[g].sent = (uint4*)p__;
+                    snprintf(nm, sizeof nm, "dpw_sent%d", g); rc__ = ensure_dev(c, nm, sizeof(DpwSlot) * (size_t)DPW_SCHED_STRIDE * (size_t)(nbat + 1) + 256, &p__); if (rc__) return rc__; wgroups.g[g].sent = (uint4*)p__;
                     snprintf(nm, sizeof nm, "dpw_scur%d", g); rc__ = ensure_dev(c, nm, 64, &p__); if (rc__) return rc__; wgroups.g[g].scur = (uint32_t*)p__;
                 }
             }

@@ -132,7 +132,7 @@ struct DpwExt;
 // srank: per node (stop nodes only) its rank among the stop nodes of its contig, or nullptr: then the extras record of node i of a
 // chain is ext[off + i]; with it, ext[soff + srank[i]] (one 64-byte record per (chain, stop node) pair, dense)
 // shdr / sent / scur (optional): the step schedule of the group (dpw_core.h "Step schedule"): one header per 64-node batch of every
-// contig, the entries in 32-byte slots (DPW_SCHED_STRIDE per batch), scur[1] = batches whose entries did not fit
+// contig, 32-byte slots (DPW_SCHED_STRIDE per batch), scur[1] = batches whose entries did not fit
 struct DpwSchedHdr;
 struct DpwTopoArrays { const int32_t* ndx; const int32_t* stop_val; uint8_t* kf; int32_t* lo; int32_t* q1; int32_t* q2; const int32_t* srank = nullptr;
                        DpwSchedHdr* shdr = nullptr; uint4* sent = nullptr; uint32_t* scur = nullptr; };

@@ -20,7 +20,7 @@ for r in csv.DictReader(open(fs[0])):
     m=re.search(r'(k_\w+)', r['Kernel_Name']); nm=m.group(1) if m else r['Kernel_Name'][:20]
     agg[(nm,int(r['Grid_Size']),r['Counter_Name'])].append(float(r['Counter_Value']))
 for k in sorted(agg):
-    if k[0] in ('k_dp_wave','k_score_starts','k_coding_score_quads','k_extract_tile') and len(agg[k])>=2:
+    if k[0] in ('k_dp_wave','k_dpw_sched','k_dpw_dyn','k_score_starts','k_coding_score_quads','k_extract_tile') and len(agg[k])>=2:
         v=agg[k]; print("%-22s grid %9d %-26s n=%2d avg %.4g"%(k[0],k[1],k[2],len(v),sum(v)/len(v)))
 PY
 }
