@@ -352,6 +352,7 @@ __device__ __forceinline__ void wave_step(const SrcRegs& R, const int u, const i
 // kinds / frames of the targets are lane masks in scalar registers, a source contributes one compare per position test.
 __global__ void __launch_bounds__(256)
 k_dpw_sched(const int32_t* __restrict__ cbase, const int32_t* __restrict__ bbase, const DpwTopoArrays ta) {
+    __shared__ int s_nd[4][64];                     // per wavefront: the positions of its batch's nodes (ascending with the lane)
     const int c = blockIdx.x, lane = threadIdx.x & 63;
     const int base = cbase[c], n = cbase[c + 1] - base;
     const int b = (blockIdx.y << 4) + (threadIdx.x >> 6) * 4;      // this wavefront's four batches: b .. b + 3
@@ -393,7 +394,7 @@ k_dpw_sched(const int32_t* __restrict__ cbase, const int32_t* __restrict__ bbase
         uint4* const out0 = ta.sent + 2 * (size_t)off;                       // 32-byte slots
         unsigned slot = 0;
         // one source; `win`: the lanes whose window holds it and that lie behind it.  Returns 1 when an entry was written.
-        auto emit = [&](const int j, const int u, const int ukf, const int s_ndx, const int s_stop, const lanemask win, const bool in_batch) -> int {
+        auto emit = [&](const int j, const int u, const int ukf, const int s_ndx, const int s_stop, const lanemask win, const bool in_batch) -> int {      // (in_batch: always written)
             const int sk = DPW_KIND(ukf), sf = DPW_FRAME(ukf);
             lanemask m0, m1, m2 = 0, m3 = 0, m4 = 0, m5 = 0;
             bool close = false;             // some lane of m1 lies within OPER_DIST bases: its distance term comes from the table
@@ -415,7 +416,7 @@ k_dpw_sched(const int32_t* __restrict__ cbase, const int32_t* __restrict__ bbase
                 m3 = win & k2 & vote((s_ndx > dlo0) & (s_ndx < dhi0));
                 m4 = win & k3 & vote(s_ndx < t_ndx - 4);
                 if (in_batch) m5 = k0 & pick3m(sf, fr0, fr1, fr2) & ((1ull << u) - 1ull) & vote(t_ndx > s_stop);
-                if (!(m0 | m2 | m3 | m4 | m5)) return 0;
+                if (!in_batch && !(m0 | m2 | m3 | m4 | m5)) return 0;
                 if (slot & 1u) { if (lane == 0) out0[2 * slot] = make_uint4(0u, 0u, DPW_E_NOP, 0u); slot++; }      // a forward stop takes a whole line
             }
             if (lane == 0) {
@@ -448,14 +449,72 @@ k_dpw_sched(const int32_t* __restrict__ cbase, const int32_t* __restrict__ bbase
             emit_end();
         }
         {
-            // inside the batch the window test is "a later lane": a window reaches back at least MAX_NODE_DIST nodes
-            lanemask visit = own;
+            // The batch's own nodes as sources.  Inside the batch the window test is "a later lane" (a window reaches back at least
+            // MAX_NODE_DIST nodes), positions ascend with the lane, and every test of a REVERSE source is a threshold on the target's
+            // position: its masks are lane ranges cut out of the kind masks.  So the reverse nodes are not visited one by one: every
+            // lane finds the thresholds of its own node by binary search over the batch's positions (in LDS), builds its two masks in
+            // vector registers and writes its own slot; only the forward stops (an eighth of the nodes, with masks that are no
+            // ranges) go through emit().
             const lanemask actm = k0 | own;
-            while (visit) {
-                const int u = __builtin_ctzll(visit);
-                visit &= visit - 1;
-                n_own += emit(i0 + u, u, rl_i32(my_kf, u), rl_i32(t_ndx, u), rl_i32(t_stop, u), actm & (~1ull << u), true);
+            int* const nd = s_nd[threadIdx.x >> 6];
+            nd[lane] = act ? t_ndx : INT_MAX;
+            __builtin_amdgcn_wave_barrier();
+            auto rank = [&](const int x) {              // lanes whose position is <= x = the first lane whose position is > x
+                int r = 0;
+#pragma unroll
+                for (int st = 32; st >= 1; st >>= 1) if (nd[r + st - 1] <= x) r += st;
+                return r + (nd[r] <= x ? 1 : 0);
+            };
+            auto ge = [](const int r) -> lanemask { return r >= 64 ? 0ull : (~0ull << r); };
+            auto lt = [](const int r) -> lanemask { return r >= 64 ? ~0ull : ((1ull << r) - 1ull); };
+            lanemask v0 = 0, v1 = 0;                    // this lane's masks as a source
+            bool close = false;
+            if (k2 | k3) {
+                const int r1 = rank(kind == 2 ? t_ndx : t_stop - 1);
+                if (kind == 3) {
+                    const lanemask in_orf = (~1ull << lane) & lt(r1);          // later lanes whose position lies before the far end of the ORF
+                    v0 = in_orf & k2 & pick3m(frame, fr0, fr1, fr2);
+                    v1 = in_orf & k3;
+                }
+                if (k2) {
+                    const int r2 = rank(t_ndx + 2), r3 = rank(t_ndx + 3 * DPW_OPER_DIST), r4 = rank(t_ndx + DPW_OPER_DIST);
+                    if (kind == 2) {
+                        const lanemask far3 = k3 & ge(r2);
+                        v0 = (k0 & ge(r1)) | far3;
+                        v1 = far3 & lt(r3);
+                        close = (far3 & lt(min(r3, r4))) != 0ull;
+                    }
+                }
             }
+            const bool emit_rev = (kind == 2 && v0 != 0ull) || (kind == 3 && (v0 | v1) != 0ull);
+            const lanemask e1 = vote(emit_rev);
+            // slots in lane order: a reverse node one, a forward stop a line (with a NOP in front where it would start in the middle of one)
+            lanemask f3s = k1, pad = 0;
+            int prev = 0;
+            const unsigned own_base = slot;
+            unsigned pos = slot;
+            while (f3s) {
+                const int u = __builtin_ctzll(f3s);
+                f3s &= f3s - 1;
+                pos += __popcll(e1 & ~((1ull << prev) - 1ull) & ((1ull << u) - 1ull));
+                if (pos & 1u) pad |= 1ull << u;
+                slot = pos;
+                // (a forward stop that reaches nothing and pulls nothing is written all the same: the slots behind it do not wait for its masks)
+                emit(i0 + u, u, rl_i32(my_kf, u), rl_i32(t_ndx, u), rl_i32(t_stop, u), actm & (~1ull << u), true);
+                pos = slot;
+                prev = u + 1;
+                n_own++;
+            }
+            if (prev < 64) pos += __popcll(e1 & ~((1ull << prev) - 1ull));      // (a forward stop in the last lane leaves nothing behind it)
+            if (emit_rev) {
+                const lanemask below_me = (1ull << lane) - 1ull;
+                const unsigned my = __popcll(e1 & below_me) + 2 * __popcll(k1 & below_me) + __popcll(pad & below_me);
+                uint4* o = out0 + 2 * (size_t)(own_base + my);
+                o[0] = make_uint4((unsigned)lane, (unsigned)t_ndx, DPW_E_CODE(kind, frame) | (close ? DPW_E_CLOSE : 0u), (unsigned)i);
+                o[1] = make_uint4((unsigned)v0, (unsigned)(v0 >> 32), (unsigned)v1, (unsigned)(v1 >> 32));
+            }
+            n_own += __popcll(e1);
+            slot = pos;
             emit_end();
         }
         if (lane == 0) ta.shdr[bg] = DpwSchedHdr{off, (unsigned)n_near | ((unsigned)n_own << 16), jm, 0};
