@@ -126,9 +126,13 @@ int         pga_device_info(const pga_ctx*, char* name, int name_len, int* cus, 
  *   out[0] chains that were cut into segments (0: every chain was walked serially)   out[1] segments
  *   out[2..4] nodes whose speculative result the verification rounds 1..3 rejected
  *   out[5] chains that were walked serially in the end because they never verified clean
- *   out[6] 32-byte slots the step schedule of the wave-batch scorer took (0: no schedule)   out[7] 64-node batches whose schedule
- *          did not fit its buffer (> 0: the launch was repeated by the kernel that works the lane masks out per chain) */
+ *   out[6] 1 when the wave-batch scorer ran from a step schedule   out[7] 64-node batches whose schedule did not fit its
+ *          buffer (> 0: the launch was repeated by the kernel that works the lane masks out per chain) */
 int         pga_dp_stats(const pga_ctx*, int32_t out[8]);
+/* How the node extraction of the last pga_find_genes / pga_find_genes_batch / pga_nodes_stage call on this context ran (diagnostics):
+ *   out[0] extraction passes (1; 2 when a tile of the batch did not fit the half-density staging and the batch was extracted again)
+ *   out[1] reserved (0) */
+int         pga_extract_stats(const pga_ctx*, int32_t out[2]);
 /* How a connection-scoring launch over chains of these node counts would be cut (host arithmetic only, no device needed;
  * the PGA_DP_SEG* environment variables of INTEGRATION.md apply):
  *   out[0] chains cut into segments   out[1] segments   out[2] nodes of the longest sub-chain (segment + warm-up)

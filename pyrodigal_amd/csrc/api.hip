@@ -75,6 +75,12 @@ extern "C" int pga_dp_stats(const pga_ctx* c, int32_t out[8]) {
     return PGA_OK;
 }
 
+extern "C" int pga_extract_stats(const pga_ctx* c, int32_t out[2]) {
+    if (!c || !out) return PGA_EINVAL;
+    out[0] = c->extract_passes; out[1] = 0;
+    return PGA_OK;
+}
+
 void pga_dp_note_stats(pga_ctx* c, const DpSegPlan* plan, const int32_t* h_flags, int stride) {
     memset(c->dp_stats, 0, sizeof c->dp_stats);
     if (!plan || plan->segs.empty()) return;

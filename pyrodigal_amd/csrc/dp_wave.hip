@@ -351,7 +351,7 @@ __device__ __forceinline__ void wave_step(const SrcRegs& R, const int u, const i
 // compared through the kernels' results), taken apart by source kind so that a source costs a few vector compares: per batch the
 // kinds / frames of the targets are lane masks in scalar registers, a source contributes one compare per position test.
 __global__ void __launch_bounds__(256)
-k_dpw_sched(const int32_t* __restrict__ cbase, const int32_t* __restrict__ bbase, const DpwTopoArrays ta) {
+k_dpw_sched(const int32_t* __restrict__ cbase, const int32_t* __restrict__ bbase, const DpwTopoArrays ta, const int force_miss /* tests: every batch reports that it did not fit */) {
     __shared__ int s_nd[4][64];                     // per wavefront: the positions of its batch's nodes (ascending with the lane)
     const int c = blockIdx.x, lane = threadIdx.x & 63;
     const int base = cbase[c], n = cbase[c + 1] - base;
@@ -386,7 +386,7 @@ k_dpw_sched(const int32_t* __restrict__ cbase, const int32_t* __restrict__ bbase
             const int k = j < i0 ? DPW_KIND(kfp[j]) : 0;
             ub += __popcll(vote(k != 0)) + 2 * __popcll(vote(k == 1)) + 2;
         }
-        if (ub > DPW_SCHED_STRIDE) {
+        if (ub > DPW_SCHED_STRIDE || force_miss) {
             if (lane == 0) { atomicAdd(&ta.scur[1], 1u); ta.shdr[bg] = DpwSchedHdr{DPW_SCHED_NONE, 0u, jm, 0}; }
             continue;
         }
@@ -1123,15 +1123,15 @@ void pga_launch_dpw_chain(const ChainDesc* d_chains, int n_chains, int64_t node_
 }
 
 bool pga_dpw_use_sched() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("PGA_DPW_SCHED"); v = e ? (atoi(e) != 0) : 1; }
-    return v != 0;
+    const char* e = getenv("PGA_DPW_SCHED");        // 0: every launch by k_dpw_dyn (cross-check)
+    return e ? (atoi(e) != 0) : true;
 }
 
 void pga_launch_dpw_sched(const DpwTopoArrays& ta, const int32_t* d_cbase, const int32_t* d_bbase, int n_contigs, int max_batches, hipStream_t st) {
     hipMemsetAsync(ta.scur, 0, 2 * sizeof(uint32_t), st);
     if (n_contigs <= 0 || max_batches <= 0) return;
-    hipLaunchKernelGGL(k_dpw_sched, dim3((unsigned)n_contigs, (unsigned)((max_batches + 15) / 16)), dim3(256), 0, st, d_cbase, d_bbase, ta);
+    const char* fm = getenv("PGA_DPW_SCHED_MISS");
+    hipLaunchKernelGGL(k_dpw_sched, dim3((unsigned)n_contigs, (unsigned)((max_batches + 15) / 16)), dim3(256), 0, st, d_cbase, d_bbase, ta, (fm && atoi(fm)) ? 1 : 0);
 }
 
 void pga_launch_dp_wave(const ChainDesc* d_chains, int n_chains, const DpwGroupPtrs& groups, const ModelConst* d_models, DpBuffers buf,

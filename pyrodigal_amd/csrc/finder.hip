@@ -1401,11 +1401,12 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         PINBUF(h_st_overflow, int32_t, "h_st_overflow", 4);
         if (getenv("PGA_STAGE_FULL")) f->stage_full = true;
         bool stage_full = f->stage_full;
+        c->extract_passes = 0;
         for (;;) {
             const bool half = !stage_full;
             // (PGA_STAGE_SHIFT=5: one slot per 32 positions, so that ordinary sequence overflows and the tests see the second pass)
             const int shift = half ? std::max(1, std::min(8, getenv("PGA_STAGE_SHIFT") ? atoi(getenv("PGA_STAGE_SHIFT")) : 1)) : 0;
-            const int64_t st_slots = half ? (total >> shift) + 8 : 2 * total + 2;
+            const int64_t st_slots = half ? (total >> shift) + (int64_t)PGA_STAGE_SLACK * batch->n_tiles + 8 : 2 * total + 2;
             for (int g = 0; g < NG; g++) {
                 char nm[32];
                 GBUF(st_ndx, int32_t, st_slots) GBUF(st_sv, int32_t, st_slots) GBUF(st_info, uint8_t, st_slots)
@@ -1425,6 +1426,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             HT(c, hipMemcpyAsync(h_sbase, d_sbase, sizeof(int32_t) * (size_t)NG * (NC + 1), hipMemcpyDeviceToHost, st));
             HT(c, hipGetLastError());
             HT(c, hipStreamSynchronize(st));
+            c->extract_passes++;
             if (!half || h_st_overflow[0] == 0) break;
             stage_full = true;
             if (!getenv("PGA_STAGE_SHIFT")) f->stage_full = true;       // (the test knob leaves the context as it was)
@@ -1763,12 +1765,12 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         }
         HT(c, hipGetLastError());
         HT(c, hipStreamSynchronize(st));
-        uint32_t sched_missed = 0, sched_slots = 0;
+        uint32_t sched_missed = 0;
         if (use_sched) {
             // a schedule that did not fit its buffer (node-dense input: more than two slots per node on average): the same launch again
             // with the kernel that works the lane masks out itself
             uint32_t missed = 0;
-            for (int g = 0; g < NG; g++) if (g_c0[g + 1] > g_c0[g] && g_n0[g + 1] > g_n0[g]) { missed += h_scur[2 * g + 1]; sched_slots += h_scur[2 * g]; }
+            for (int g = 0; g < NG; g++) if (g_c0[g + 1] > g_c0[g] && g_n0[g + 1] > g_n0[g]) missed += h_scur[2 * g + 1];
             sched_missed = missed;
             if (getenv("PGA_DPW_SCHED_DEBUG")) for (int g = 0; g < NG; g++) fprintf(stderr, "[pga dpw sched] group %d: %u batches missed\n", g, h_scur[2 * g + 1]);
             if (missed) {
@@ -1783,7 +1785,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             }
         }
         pga_dp_note_stats(c, segmented ? &seg_plan : nullptr, h_segflags, NCH);
-        c->dp_stats[6] = (int32_t)std::min<uint32_t>(sched_slots, 0x7fffffffu); c->dp_stats[7] = (int32_t)sched_missed;
+        c->dp_stats[6] = use_sched ? 1 : 0; c->dp_stats[7] = (int32_t)sched_missed;
         if (segmented && getenv("PGA_DP_SEG_DEBUG")) {
             fprintf(stderr, "[pga dp-seg] %d chains cut into %d segments (<= %d nodes each); nodes rejected per round: %d %d %d; walked serially: %d; spine:",
                     seg_dev.n_big, seg_dev.n_segs, seg_dev.max_seg_nodes, c->dp_stats[2], c->dp_stats[3], c->dp_stats[4], c->dp_stats[5]);

@@ -180,6 +180,7 @@ struct pga_ctx {
     ModelConst* d_model_const = nullptr;
     int n_models = 0;
     int32_t dp_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // pga_dp_stats
+    int32_t extract_passes = 0;                        // pga_extract_stats: extraction passes of the last call (2: a tile overflowed the half-density staging)
 };
 // summary of a segmented launch's flags (host copy, [PGA_SEG_ROUNDS][stride]) into pga_ctx::dp_stats
 void pga_dp_note_stats(pga_ctx* c, const DpSegPlan* plan, const int32_t* h_flags, int stride);

@@ -10,6 +10,7 @@ struct ContigDesc {
 };
 
 // One 3072-position tile of one contig (forward coordinates; every position of a contig of three bases or more lies in one) for the extraction kernels.
+#define PGA_STAGE_SLACK 8     // extra staging slots of every tile under GroupArrays::st_half
 struct TileDesc {
     int32_t contig;
     int32_t start;

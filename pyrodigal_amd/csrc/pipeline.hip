@@ -581,8 +581,10 @@ k_extract_tile(const uint8_t* __restrict__ dig, int64_t total, const ContigDesc*
             for (int k = 0; k < nk; k++) ga.df[g0 + r0 + k] = (uint8_t)((dig[g0 + r0 + k] & 7u) | (((nf >> k) & 1u) << 4) | (((nr >> k) & 1u) << 5));
         }
     }
-    const int64_t stage0 = ga.st_half ? (g0 >> ga.st_half) : 2 * g0;
-    const int room = ga.st_half ? (G.len >> ga.st_half) : 2 * G.len;   // staging slots of the tile
+    // (with st_half every tile gets PGA_STAGE_SLACK slots on top of its share: the last tile of a contig can be a few bases long and
+    //  still hold the six edge nodes of an open end)
+    const int64_t stage0 = ga.st_half ? (g0 >> ga.st_half) + (int64_t)PGA_STAGE_SLACK * tile : 2 * g0;
+    const int room = ga.st_half ? (G.len >> ga.st_half) + PGA_STAGE_SLACK : 2 * G.len;   // staging slots of the tile
     if (t == 255 && nbase + cnt > room) atomicOr(ga.st_overflow, 1);   // (only with st_half) the caller extracts again, full staging
     int64_t slot = stage0 + nbase;
     const int64_t slot_end = stage0 + room;
@@ -682,7 +684,7 @@ k_place_nodes(const ContigDesc* __restrict__ ct, const TileDesc* __restrict__ ti
     const int off = tile_off[blockIdx.x], cnt = tile_off[blockIdx.x + 1] - off;
     if (cnt <= 0) return;
     const int64_t base = ct[td.contig].base;
-    const int64_t s0 = ga.st_half ? ((base + td.start) >> ga.st_half) : 2 * (base + td.start);
+    const int64_t s0 = ga.st_half ? ((base + td.start) >> ga.st_half) + (int64_t)PGA_STAGE_SLACK * blockIdx.x : 2 * (base + td.start);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int srun = tile_soff[blockIdx.x];                       // next free entry of the stop list
     for (int j0 = 0; j0 < cnt; j0 += 128) {

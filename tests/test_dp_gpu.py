@@ -117,14 +117,26 @@ def test_training_pass_is_rejected_loudly(ctx):
         ctx.score_connections([0], [0], [0], [1], [0.0], [0.0], [0.0], [0.0], np.zeros((1, 3)), 4.35, final=False)
 
 
-@pytest.mark.parametrize("variant", ["wave", "tree1", "tree3", "scan1", "scan4", "scan16"])
+def _wave_env(monkeypatch, kernel):
+    """wave: k_dp_wave (step schedule + assembly steps); wavedyn: k_dpw_dyn, the lane masks worked out per step (PGA_DPW_SCHED=0);
+    wavemiss: a schedule that reports it did not fit, i.e. the fallback from the one to the other (PGA_DPW_SCHED_MISS=1)"""
+    monkeypatch.setenv("PGA_DP_KERNEL", "wave")
+    if kernel == "wavedyn":
+        monkeypatch.setenv("PGA_DPW_SCHED", "0")
+    if kernel == "wavemiss":
+        monkeypatch.setenv("PGA_DPW_SCHED_MISS", "1")
+
+
+@pytest.mark.parametrize("variant", ["wave", "wavedyn", "wavemiss", "tree1", "tree3", "scan1", "scan4", "scan16"])
 def test_dp_kernel_variants_agree_with_oracle(ctx, variant, monkeypatch):
-    # wave = the wave-batch kernel of launches with many chains (dp_wave.hip); tree3 = the chain kernel of few long chains;
+    # wave = the wave-batch kernel of launches with many chains (dp_wave.hip; see _wave_env); tree3 = the chain kernel of few long chains;
     # tree1 = its one-wave form; PGA_DP_KERNEL=scan selects the window-scanning kernels with 1, 4 or 16 wavefronts per chain,
     # kept as an independent cross-check
     if variant.startswith("scan"):
         monkeypatch.setenv("PGA_DP_KERNEL", "scan")
         monkeypatch.setenv("PGA_DP_WAVES", variant[4:])
+    elif variant.startswith("wave"):
+        _wave_env(monkeypatch, variant)
     else:
         monkeypatch.setenv("PGA_DP_KERNEL", variant)     # tree1: one wave per chain; tree3: three cooperating waves
     seq = read_fasta("MIIJ01000039.fna.gz")[0][1]
@@ -143,21 +155,20 @@ def test_dp_kernel_variants_agree_with_oracle(ctx, variant, monkeypatch):
     ("GCF_001457455.1_NCTC11397_genomic", "GCF_001457455.1_NCTC11397_genomic.tinf_closed.bin.gz", True),
     ("KK037166", "GCF_001457455.1_NCTC11397_genomic_100kb.tinf_closed.bin.gz", False),
 ])
-@pytest.mark.parametrize("kernel", ["wave"])
+@pytest.mark.parametrize("kernel", ["wave", "wavedyn"])
 def test_wave_kernel_on_reference_fixtures(ctx, name, model_file, closed, kernel, monkeypatch):
     # the kernels of many-chain launches, forced onto single chains: short contigs, and the full genome, whose 153 296 nodes
-    # slide the 1000-node window over 2400 blocks (suffix maxima, both block-range ends; the lane kernel's running maxima against
-    # the window) and hit the giant-ORF windows
-    monkeypatch.setenv("PGA_DP_KERNEL", kernel)
+    # slide the 1000-node window over 2400 blocks (suffix maxima, both block-range ends) and hit the giant-ORF windows
+    _wave_env(monkeypatch, kernel)
     seq = read_fasta(name + ".fna.gz")[0][1]
     tinf = orc.Training.load(golden_path(model_file))
     for is_meta in (False, True):
         check(ctx, seq, tinf, closed=closed, is_meta=is_meta)
 
 
-@pytest.mark.parametrize("kernel", ["wave"])
+@pytest.mark.parametrize("kernel", ["wave", "wavedyn"])
 def test_wave_kernel_on_synthetic_and_gene_dense_input(ctx, kernel, monkeypatch):
-    monkeypatch.setenv("PGA_DP_KERNEL", kernel)
+    _wave_env(monkeypatch, kernel)
     tinf = orc.Training.load(golden_path("SRR492066.training.bin.gz"))
     for k, (L, gc) in enumerate([(130, 0.45), (700, 0.5), (1500, 0.6), (20_000, 0.3), (20_000, 0.7), (64_000, 0.55), (200_000, 0.66)]):
         seq = synthetic_contig(L, gc, 7700 + k)

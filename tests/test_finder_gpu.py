@@ -191,11 +191,17 @@ def test_both_tails_give_the_same_result(ctx, models, tail, monkeypatch):
             assert n > 0
 
 
-@pytest.mark.parametrize("kernel", ["wave", "tree3"])
+@pytest.mark.parametrize("kernel", ["wave", "wavedyn", "wavemiss", "tree3"])
 def test_connection_scoring_kernels_inside_the_finder(ctx, models, kernel, monkeypatch):
     # batches this small take the chain kernel by default; forcing either kernel must not change one node field:
     # several models per contig, two translation-table groups, empty and sub-window contigs, every node against the oracle
-    monkeypatch.setenv("PGA_DP_KERNEL", kernel)
+    # (wave: step schedule + assembly steps; wavedyn: PGA_DPW_SCHED=0; wavemiss: the schedule reports it did not fit and the launch
+    #  is repeated by k_dpw_dyn)
+    monkeypatch.setenv("PGA_DP_KERNEL", "wave" if kernel.startswith("wave") else kernel)
+    if kernel == "wavedyn":
+        monkeypatch.setenv("PGA_DPW_SCHED", "0")
+    if kernel == "wavemiss":
+        monkeypatch.setenv("PGA_DPW_SCHED_MISS", "1")
     ctx.set_models([m.buf for m in models])
     seqs = [synthetic_contig(3000 + 2111 * c, 0.30 + 0.40 * (c % 41) / 40, 20_000 + c) for c in range(40)]
     seqs += [b"", b"ATGAAATAA", synthetic_contig(70_000, 0.52, 99), read_fasta("SRR492066.fna.gz")[0][1].encode()]
@@ -206,6 +212,8 @@ def test_connection_scoring_kernels_inside_the_finder(ctx, models, kernel, monke
     ctx.set_models([models[2].buf])
     res = ctx.find_genes_batch(seqs, meta=False, want_nodes=True)          # single mode keeps the DP pass's node fields
     assert sum(compare_contig(res, i, s, orc.Oracle(s), [models[2]], meta=False) for i, s in enumerate(seqs)) > 100
+    if kernel.startswith("wave"):
+        assert (ctx.dp_stats()["sched_missed"] > 0) == (kernel == "wavemiss")
 
 
 def test_extraction_staging_overflow_takes_the_full_staging(models, monkeypatch):
@@ -236,3 +244,19 @@ def test_extraction_staging_overflow_takes_the_full_staging(models, monkeypatch)
             for i in range(len(seqs)):
                 for k in ("ndx", "stop_val", "type", "strand"):
                     assert np.array_equal(r.nodes[i][k], ref.nodes[i][k]), (mode, i, k)
+
+
+def test_short_last_tiles_do_not_overflow_the_staging(models):
+    """A contig's last extraction tile can be a few bases long (length = k * 3072 + 1 .. 8) and still hold the six edge nodes of an
+    open end: every tile carries constant slack on top of its one-slot-per-two-positions share, so ordinary lengths stay on one pass."""
+    from pyrodigal_amd import _cabi
+    tile = 3072
+    seqs = [synthetic_contig(k * tile + r, 0.35 + 0.3 * (r % 5) / 4, 4100 + 10 * k + r) for k in (1, 2, 5) for r in range(1, 9)]
+    seqs += [synthetic_contig(L, 0.5, 4200 + L) for L in (7, 61, 130, 3071, 3073, 20000)]
+    c = _cabi.Context(0)
+    c.set_models([m.buf for m in models])
+    res = c.find_genes_batch(seqs, meta=True, want_nodes=True)
+    assert c.extract_stats()["passes"] == 1
+    n = sum(compare_contig(res, i, s, orc.Oracle(s), models, meta=True) for i, s in enumerate(seqs))
+    assert n > 100
+    c.close()

@@ -1,5 +1,5 @@
 """Randomised sweep on the GPU box: `python tools/stress_nodes.py SEED0 SEED1 [SECONDS]` (the connection scorer and the coding-score form
-are drawn per seed: default / wave, LDS tables or per-lane gathers for the coding score) -- every node field of every contig (scores, RBS bins,
+are drawn per seed: default / wave / wave without the step schedule, LDS tables or per-lane gathers for the coding score) -- every node field of every contig (scores, RBS bins,
 motifs, traceback, elimination flags) and every gene against the CPU oracle, in meta and single mode, open and closed ends, with
 and without masking."""
 import importlib.util
@@ -27,9 +27,10 @@ kinds = {}
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     if time.time() - t0 > budget: break
     rng = np.random.default_rng(seed)
-    kern = [None, 'wave'][seed % 2]
-    for k_ in ('PGA_DP_KERNEL', 'PGA_CS_LDS'): os.environ.pop(k_, None)
-    if kern: os.environ['PGA_DP_KERNEL'] = kern
+    kern = [None, 'wave', 'wavedyn'][seed % 3]
+    for k_ in ('PGA_DP_KERNEL', 'PGA_CS_LDS', 'PGA_DPW_SCHED'): os.environ.pop(k_, None)
+    if kern: os.environ['PGA_DP_KERNEL'] = 'wave'
+    if kern == 'wavedyn': os.environ['PGA_DPW_SCHED'] = '0'
     if (seed // 4) % 2: os.environ['PGA_CS_LDS'] = '0'           # the coding score by per-lane table gathers instead of the LDS tables
     kinds[(kern or 'default', (seed // 4) % 2)] = kinds.get((kern or 'default', (seed // 4) % 2), 0) + 1
     seqs = []

@@ -33,9 +33,9 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         ctx.set_models(models if meta else models[int(rng.integers(0, 16)):][:1])
         res = []
         for env in ({}, {"PGA_DP_KERNEL": "scan", "PGA_TAIL": "host"}, {"PGA_DP_KERNEL": "tree1", "PGA_TAIL": "device"}, {"PGA_DP_KERNEL": "tree3", "PGA_TAIL": "device"},
-                    {"PGA_DP_KERNEL": "wave"}, {"PGA_DP_KERNEL": "wave", "PGA_CS_LDS": "0"},
+                    {"PGA_DP_KERNEL": "wave"}, {"PGA_DP_KERNEL": "wave", "PGA_DPW_SCHED": "0", "PGA_CS_LDS": "0"},
                     {"PGA_DP_KERNEL": "wave", "PGA_TP_STEPS": "1", "PGA_STAGE_SHIFT": "5", "PGA_DPW_TOPO_WALK": "1"}):
-            for k in ("PGA_DP_KERNEL", "PGA_TAIL", "PGA_CS_LDS", "PGA_TP_STEPS", "PGA_STAGE_SHIFT", "PGA_DPW_TOPO_WALK"): os.environ.pop(k, None)
+            for k in ("PGA_DP_KERNEL", "PGA_TAIL", "PGA_CS_LDS", "PGA_TP_STEPS", "PGA_STAGE_SHIFT", "PGA_DPW_TOPO_WALK", "PGA_DPW_SCHED"): os.environ.pop(k, None)
             os.environ.update(env)
             res.append(ctx.find_genes_batch(seqs, meta=meta, mask=mask, closed=closed))
         for r in res[1:]:
