@@ -441,6 +441,8 @@ def main():
             if len(seqs) > 1:
                 # (i) one thread above, (ii) every host core here -- its own top-level object
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(seqs, models)
+                # ... and its last row: the job that was timed, checked across every device call and context
+                out["parity"] = parity_sample(seqs, models, res, base_of, n_ctx)
     fasta_line = pool_line = None
     try:
         free_b, total_b = torch.cuda.mem_get_info(dev_index)
@@ -631,6 +633,49 @@ def cpu_baseline(seqs, models, gpu_res, n_job=0):
            "gene_calls_identical_to_gpu": match, "genes_in_sample": total_genes, "host_cpus": os.cpu_count()}
     out["avx2"] = True      # oracle/Makefile: -O2 -mavx2 -ftree-vectorize; gcc vectorises the byte pre-filter loop (32-byte vectors)
     return out
+
+
+def parity_sample(seqs, models, res, base_of, n_ctx, every=40, threads=16):
+    """SURVEY 8(d) "parity checks in the bench run": a stratified sample of the job that was just timed -- every `every`-th contig,
+    hence contigs of EVERY device call and every context -- through the CPU checker (oracle/, one contig per call on a few Python
+    threads; the C side runs without the interpreter lock), compared with the gene records the timed passes produced: the gene tuples
+    (begin, end, strand, start and stop node, partial flags, start type), the chosen bin per contig, and the largest absolute
+    difference over the five score fields of the genes' start nodes (0.0 = bit-identical)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as orc
+    bins = [orc.Training(m[1]) for m in models]
+    picks = list(range(0, len(seqs), every))
+
+    def one(i):
+        o = orc.Oracle(seqs[i])
+        return i, o.find_genes_meta(bins), o.genes()
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        got = list(ex.map(one, picks))
+    tuple_fields = ("begin", "end", "strand", "start_ndx", "stop_ndx", "partial_begin", "partial_end", "start_type")
+    score_fields = ("cscore", "sscore", "rscore", "uscore", "tscore")
+    calls, n_genes, bad_tuples, bad_models, max_diff = set(), 0, 0, 0, 0.0
+    for i, phase, og in got:
+        k = int(np.searchsorted(base_of, i, side="right") - 1)
+        calls.add(k)
+        r = res[k]
+        li = i - int(base_of[k])
+        gg = r.genes_of(li)
+        n_genes += len(og)
+        if int(r.contigs[li]["model"]) != phase:
+            bad_models += 1
+        if len(og) != len(gg) or not all(np.array_equal(og[f], gg[f]) for f in tuple_fields):
+            bad_tuples += 1
+            continue
+        for f in score_fields:
+            if len(og):
+                max_diff = max(max_diff, float(np.max(np.abs(og[f] - gg[f]))))
+    return {"contigs": len(picks), "every": every, "device_calls_covered": len(calls), "contexts_covered": len({k % n_ctx for k in calls}),
+            "genes": n_genes, "tuples_identical": bad_tuples == 0, "chosen_bin_identical": bad_models == 0,
+            "contigs_with_different_tuples": bad_tuples, "contigs_with_different_bin": bad_models,
+            "tuple_fields": list(tuple_fields), "score_fields": list(score_fields), "max_abs_score_diff": max_diff,
+            "checker": "oracle/ (CPU restatement, pinned on the reference's fixtures)", "seconds": round(time.perf_counter() - t0, 2)}
 
 
 def cpu_baseline_all_cores(seqs, models):

@@ -45,3 +45,23 @@ def test_two_ranks_on_one_device_report_the_same_job():
     # a rank's contexts follow its share: 2000 contigs are one device call, so one context
     assert two["config"]["contexts_per_gpu"] == 1 and two["config"]["contigs_rank0"] == pr["contigs"][0]
     assert two["value"] > 0 and two["ms_per_step"] > 0 and two["roofline"]["frac"] > 0
+
+
+def test_eight_ranks_on_one_device_split_a_job_like_an_eight_gpu_node():
+    """The shape of the driver's 8-GPU run (verdict r4, item 9): eight ranks, a 16 000-contig job, every rank its 2 000-contig share
+    as one device call on one context; the packing within 2 % of even; the job's genes as a one-rank run finds them.  (Eight ranks
+    sharing one GPU say nothing about scaling: no scaling number exists)"""
+    env = dict(os.environ, PGA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = ["--contigs", "16000", "--steps", "1", "--warmup", "1", "--no-secondary", "--no-cpu-baseline", "--gen-procs", "1"]
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    eight = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                   "--master-port", str(port), "bench.py", "--gpus", "8"] + args, env)
+    one = _line([sys.executable, "bench.py", "--gpus", "1"] + args, env)
+    pr = eight["config"]["per_rank"]
+    assert eight["n_gpus"] == 8 and all(len(pr[k]) == 8 for k in ("step_ms", "gather_ms", "contigs", "estimated_work_share"))
+    assert sum(pr["contigs"]) == 16000 and min(pr["contigs"]) > 1700 and pr["lpt_imbalance"] < 1.02
+    assert eight["config"]["contexts_per_gpu"] == 1 and eight["config"]["device_calls_per_step_rank0"] == 1
+    assert eight["config"]["genes_all_ranks"] == one["config"]["genes_all_ranks"] > 0
+    assert eight["config"]["bases"] == one["config"]["bases"] == 16000 * 20000

@@ -94,3 +94,30 @@ def test_region_masks_match_reference_vectors():
     assert len(orc.Oracle(s, mask=False).masks()) == 0
     assert orc.Oracle(s, mask=True, mask_size=0).masks().tolist() == [[4, 14], [18, 26]]
     assert orc.Oracle(s, mask=True, mask_size=10).masks().tolist() == [[4, 14]]
+
+
+
+def test_the_oracle_is_built_without_fused_multiply_adds(tmp_path):
+    """The checker is compiled -O2 -mavx2; what stands between it and an FMA (one rounding where the reference makes two) is
+    -ffp-contract=off.  The flag must stay in oracle/Makefile, and an -O0 build of the same source must produce the same bytes
+    (every score of every node and gene of a fixture genome, single mode with training)."""
+    import hashlib, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    flags = [ln for ln in open(os.path.join(root, "oracle", "Makefile")).read().splitlines() if ln.startswith("CFLAGS")][0]
+    assert "-ffp-contract=off" in flags
+    so = str(tmp_path / "libprodigal_oracle_O0.so")
+    subprocess.run(["gcc", "-O0", "-ffp-contract=off", "-fPIC", "-std=gnu11", "-shared", "-pthread", "-o", so,
+                    os.path.join(root, "oracle", "prodigal_oracle.c"), "-lm"], check=True)
+    script = (
+        "import sys, hashlib; sys.path.insert(0, %r)\n"
+        "from oracle import oracle as orc\n"
+        "if len(sys.argv) > 1: orc._LIB_PATH = sys.argv[1]; orc.build = lambda force=False: orc._LIB_PATH\n"
+        "from tests.util import golden_path, read_fasta\n"
+        "seq = read_fasta('SRR492066.fna.gz')[0][1]\n"
+        "tinf = orc.Training.load(golden_path('SRR492066.training.bin.gz'))\n"
+        "o = orc.Oracle(seq); o.extract(tinf.trans_table, orc.Params()); o.sort(); o.reset_scores(); o.score_nodes(tinf, False, False)\n"
+        "o.overlapping_starts(tinf, 1, 60); o.dprog_raw(tinf, True)\n"
+        "print(len(o.nodes()), hashlib.sha256(o.nodes().tobytes()).hexdigest())\n" % root)
+    a = subprocess.run([sys.executable, "-c", script], check=True, capture_output=True, text=True).stdout
+    b = subprocess.run([sys.executable, "-c", script, so], check=True, capture_output=True, text=True).stdout
+    assert a == b and int(a.split()[0]) > 1000
