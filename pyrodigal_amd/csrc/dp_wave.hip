@@ -892,7 +892,8 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
     };
     for (int b = 0; b < nb; b++) {
         const int i0 = b << 6;
-        const u32x4 hdr = s_hdr[b];                 // {first entry, near entries | own entries << 16, jm, -}
+        const u32x4 hdr = s_hdr[b];                 // {first slot, near entries | own entries << 16, jm, -}
+        if (hdr.x == DPW_SCHED_NONE) return;          // the batch's lists did not fit: the host repeats the launch with k_dpw_dyn
         {
             // The batch's entries are read line by line through the scalar cache, each a dependent round trip; the first model of a
             // contig to come by finds them in HBM (2 000 cycles per line).  One vector instruction asks for all of them now: lane l

@@ -258,5 +258,5 @@ def test_short_last_tiles_do_not_overflow_the_staging(models):
     res = c.find_genes_batch(seqs, meta=True, want_nodes=True)
     assert c.extract_stats()["passes"] == 1
     n = sum(compare_contig(res, i, s, orc.Oracle(s), models, meta=True) for i, s in enumerate(seqs))
-    assert n > 100
+    assert n > 20
     c.close()
