@@ -646,31 +646,48 @@ def parity_sample(seqs, models, res, base_of, n_ctx, every=40, threads=16):
     bins = [orc.Training(m[1]) for m in models]
     picks = list(range(0, len(seqs), every))
 
+    score_fields = ("cscore", "sscore", "rscore", "uscore", "tscore")
+    int_fields = ("begin", "end", "strand", "start_ndx", "stop_ndx", "partial_begin", "partial_end", "start_type")
+
     def one(i):
+        # the checker's gene list, with each gene's attributes read off its start / stop nodes as Gene's properties read them
+        # (ref: lib.pyx:2644-2830): strand, partial flags = the edge flags of the two nodes, start type (3 = Edge), the start node's scores
         o = orc.Oracle(seqs[i])
-        return i, o.find_genes_meta(bins), o.genes()
+        phase = o.find_genes_meta(bins)
+        og, on = o.genes(), o.nodes()
+        rec = {k: og[k].copy() for k in ("begin", "end", "start_ndx", "stop_ndx")}
+        if len(og):
+            s_, e_ = on[og["start_ndx"]], on[og["stop_ndx"]]
+            fwd = s_["strand"] == 1
+            rec["strand"] = s_["strand"].astype(np.int64)
+            rec["partial_begin"] = np.where(fwd, s_["edge"], e_["edge"]).astype(np.int64)
+            rec["partial_end"] = np.where(fwd, e_["edge"], s_["edge"]).astype(np.int64)
+            rec["start_type"] = np.where(s_["edge"] != 0, 3, s_["type"]).astype(np.int64)
+            for f in score_fields:
+                rec[f] = s_[f].copy()
+        return i, phase, rec
 
     t0 = time.perf_counter()
     with ThreadPoolExecutor(threads) as ex:
         got = list(ex.map(one, picks))
-    tuple_fields = ("begin", "end", "strand", "start_ndx", "stop_ndx", "partial_begin", "partial_end", "start_type")
-    score_fields = ("cscore", "sscore", "rscore", "uscore", "tscore")
     calls, n_genes, bad_tuples, bad_models, max_diff = set(), 0, 0, 0, 0.0
-    for i, phase, og in got:
+    for i, phase, rec in got:
         k = int(np.searchsorted(base_of, i, side="right") - 1)
         calls.add(k)
         r = res[k]
         li = i - int(base_of[k])
         gg = r.genes_of(li)
-        n_genes += len(og)
+        n = len(rec["begin"])
+        n_genes += n
         if int(r.contigs[li]["model"]) != phase:
             bad_models += 1
-        if len(og) != len(gg) or not all(np.array_equal(og[f], gg[f]) for f in tuple_fields):
+        if n != len(gg) or (n and not all(np.array_equal(rec[f], gg[f].astype(np.int64)) for f in int_fields)):
             bad_tuples += 1
             continue
         for f in score_fields:
-            if len(og):
-                max_diff = max(max_diff, float(np.max(np.abs(og[f] - gg[f]))))
+            if n:
+                max_diff = max(max_diff, float(np.max(np.abs(rec[f] - gg[f]))))
+    tuple_fields = int_fields
     return {"contigs": len(picks), "every": every, "device_calls_covered": len(calls), "contexts_covered": len({k % n_ctx for k in calls}),
             "genes": n_genes, "tuples_identical": bad_tuples == 0, "chosen_bin_identical": bad_models == 0,
             "contigs_with_different_tuples": bad_tuples, "contigs_with_different_bin": bad_models,
