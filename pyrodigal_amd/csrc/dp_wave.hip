@@ -150,7 +150,8 @@ __device__ __forceinline__ double dpp_f64(const double old, const double v) {
 }
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ int dpp_i32(const int old, const int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false); }
-__device__ __forceinline__ double fmax_nn(const double a, const double b) { return b > a ? b : a; }     // no NaNs here
+// (no NaNs, and a zero of either sign is never compared with the other here: v_max_f64 gives what `b > a ? b : a` gives, in one instruction)
+__device__ __forceinline__ double fmax_nn(const double a, const double b) { return __builtin_fmax(a, b); }
 
 // wave-wide maximum of v (never NaN), the same in every lane; the lane that holds it comes from a vote afterwards
 __device__ __forceinline__ double wave_max_f64(double v) {
