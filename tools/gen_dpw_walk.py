@@ -48,7 +48,7 @@ ST = {"EP": "s[34:35]", "EP_lo": "s34", "EP_hi": "s35",
       "SC": "s[52:53]", "SC_lo": "s52", "SC_hi": "s53", "TAGK": "s54", "TMP": "s55", "TM": "s[56:57]", "OK": "s[58:59]",
       "C0": "s[60:61]", "C1": "s[62:63]", "C2": "s[64:65]",
       "SX0": "s[60:61]", "SX0_lo": "s60", "SX0_hi": "s61", "SX1_lo": "s62", "SX1_hi": "s63", "SX2_lo": "s64", "SX2_hi": "s65",
-      "SV": "s[60:61]", "SV_lo": "s60", "SV_hi": "s61", "BVS_lo": "s62", "BVS_hi": "s63", "CM": "s[64:65]", "BI": "s55", "CI": "s66",
+      "SV": "s[60:61]", "SV_lo": "s60", "SV_hi": "s61", "BVS_lo": "s62", "BVS_hi": "s63", "CM": "s[64:65]", "C2b": "s[56:57]", "BI": "s55", "CI": "s66",
       "TBN": "s66", "LHS": "s67", "SVM": "s68"}
 S_CLOBBER = ["s%d" % i for i in range(36, 88)] + ["vcc"]
 
@@ -143,27 +143,51 @@ def body(near, a, nxt, other, slot):
             a("s_mov_b64 {CM}, {MF}")
             a("v_mov_b32_e32 {W_lo}, {BVS_lo}")      # the running best, uniform in a VGPR pair (a VALU compare takes one scalar operand)
             a("v_mov_b32_e32 {W_hi}, {BVS_hi}")
-            a("Lpull_%=:")
+            # A candidate wins a tie when its index lies behind the current traceb's.  Candidates come in ascending order, so that is
+            # every candidate after the first one taken, and before that the lanes behind lane BI - i0: loop A (strict >) over the lanes
+            # at or below it until something is taken, loop B (>=) over everything else.
+            a("s_sub_i32 {CI}, {BI}, %[i0]")
+            a("s_add_i32 {CI}, {CI}, 1")
+            a("s_max_i32 {CI}, {CI}, 0")
+            a("s_bfm_b64 {C2b}, {CI}, 0")            # lanes below lane BI - i0 + 1 (BI < i0 + 63 here; before the batch: none)
+            a("s_and_b64 {C2b}, {C2b}, {CM}")
+            a("s_andn2_b64 {CM}, {CM}, {C2b}")
+            a("s_cmp_eq_u64 {C2b}, 0")
+            a("s_cbranch_scc1 LpullB_%=")
+            a("LpullA_%=:")
+            a("s_ff1_i32_b64 {CI}, {C2b}")
+            a("s_bitset0_b64 {C2b}, {CI}")
+            a("v_readlane_b32 {SV_lo}, {MV_lo}, {CI}")
+            a("v_readlane_b32 {SV_hi}, {MV_hi}, {CI}")
+            a("s_cmp_lg_u64 {C2b}, 0")
+            a("s_nop 0")
+            a("v_cmp_gt_f64_e32 vcc, {SV}, {W}")
+            a("s_cbranch_vccnz LptakeA_%=")
+            a("s_cbranch_scc1 LpullA_%=")
+            a("s_branch LpullB_%=")
+            a("LptakeA_%=:")
+            a("v_mov_b32_e32 {W_lo}, {SV_lo}")
+            a("v_mov_b32_e32 {W_hi}, {SV_hi}")
+            a("s_add_i32 {TAGK}, {CI}, %[i0]")
+            a("s_or_b64 {CM}, {CM}, {C2b}")           # what is left of loop A's lanes goes on in loop B
+            a("LpullB_%=:")
+            a("s_cmp_eq_u64 {CM}, 0")
+            a("s_cbranch_scc1 LpullE_%=")
+            a("LpullB1_%=:")
             a("s_ff1_i32_b64 {CI}, {CM}")
             a("s_bitset0_b64 {CM}, {CI}")
             a("v_readlane_b32 {SV_lo}, {MV_lo}, {CI}")
             a("v_readlane_b32 {SV_hi}, {MV_hi}, {CI}")
-            a("s_add_i32 {CI}, {CI}, %[i0]")
-            a("s_nop 0")
-            a("v_cmp_gt_f64_e32 vcc, {SV}, {W}")
-            a("s_cbranch_vccnz Lptake_%=")
-            a("v_cmp_eq_f64_e32 vcc, {SV}, {W}")
-            a("s_cbranch_vccz Lpnext_%=")
-            a("s_cmp_gt_i32 {CI}, {BI}")
-            a("s_cbranch_scc0 Lpnext_%=")
-            a("Lptake_%=:")
+            a("s_nop 1")
+            a("v_cmp_ge_f64_e32 vcc, {SV}, {W}")
+            a("s_cbranch_vccz LpullB2_%=")
             a("v_mov_b32_e32 {W_lo}, {SV_lo}")
             a("v_mov_b32_e32 {W_hi}, {SV_hi}")
-            a("s_mov_b32 {BI}, {CI}")
-            a("s_mov_b32 {TAGK}, {CI}")
-            a("Lpnext_%=:")
+            a("s_add_i32 {TAGK}, {CI}, %[i0]")
+            a("LpullB2_%=:")
             a("s_cmp_lg_u64 {CM}, 0")
-            a("s_cbranch_scc1 Lpull_%=")
+            a("s_cbranch_scc1 LpullB1_%=")
+            a("LpullE_%=:")
             a("s_cmp_lt_i32 {TAGK}, 0")              # a gene end that was never reached connects to nothing
             a("s_cbranch_scc1 " + other)
             a("s_lshl_b64 {TM}, 1, {E0}")            # (v_writelane with a scalar value AND a scalar lane select is over the constant-bus limit)
@@ -232,6 +256,15 @@ def body(near, a, nxt, other, slot):
         a("s_cmp_eq_u64 {ME}, 0")                    # reverse stops: through the best admissible overlapping start of the LANE, or directly
         a("s_cbranch_scc1 Lf3d_%=")
         a("s_or_b64 {OK}, {OK}, {ME}")
+        # (a candidate is admissible only for dlo < s_ndx < dhi: where no lane's widest interval holds s_ndx, every reverse stop takes
+        #  the source directly -- the constant term W already holds -- and the three-candidate evaluation below is skipped)
+        a("v_min3_i32 {A}, %[dlo0], %[dlo1], %[dlo2]")
+        a("v_cmp_gt_i32_e64 {C0}, {E1}, {A}")
+        a("v_max3_i32 {A}, %[dhi0], %[dhi1], %[dhi2]")
+        a("v_cmp_lt_i32_e32 vcc, {E1}, {A}")
+        a("s_and_b64 {C0}, {C0}, vcc")
+        a("s_and_b64 {C0}, {C0}, {ME}")
+        a("s_cbranch_scc0 Lf3d_%=")
         a("s_mov_b64 exec, {ME}")
         for q in range(3):
             a("v_cmp_gt_i32_e64 {C%d}, {E1}, %%[dlo%d]" % (q, q))
