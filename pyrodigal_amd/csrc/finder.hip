@@ -1187,10 +1187,21 @@ extern "C" int pga_batch_create(pga_ctx* c, int32_t n_contigs, const char* const
             }
         };
         const int threads = n_slices >= 2 ? std::min(n_slices, 6) : 1;
-        if (threads == 1) work(); else c->finder->pool.run(work, threads);
-        hipError_t e = (hipError_t)first_err.load();
-        if (e == hipSuccess) e = batch_upload_tiles(b, b->d_seq + total + 16, tiles, tile0, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        hipError_t e;
+        {
+            // One upload at a time per process: several contexts that start their calls together (a job dealt to eight contexts) would
+            // otherwise share the host's memory bandwidth and the PCIe link eight ways, every batch would arrive late, and the device
+            // would idle until the first one is complete.  In turn, the first batch is on the device after one eighth of that time and
+            // the uploads of the others run under its kernels.  (PGA_UPLOAD_TURNS=0: no turns.)
+            static std::mutex upload_turn;
+            static const bool turns = !(getenv("PGA_UPLOAD_TURNS") && atoi(getenv("PGA_UPLOAD_TURNS")) == 0);
+            std::unique_lock<std::mutex> turn(upload_turn, std::defer_lock);
+            if (turns && total >= (8 << 20)) turn.lock();
+            if (threads == 1) work(); else c->finder->pool.run(work, threads);
+            e = (hipError_t)first_err.load();
+            if (e == hipSuccess) e = batch_upload_tiles(b, b->d_seq + total + 16, tiles, tile0, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+        }
         if (e != hipSuccess) { batch_give_dev(c, b->d_seq, b->d_seq_cap); delete b; return pga_hip_try_(c, e, "upload of the batch"); }
     }
     *out = b;
