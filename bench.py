@@ -218,6 +218,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="config4", choices=["config4", "config3", "config2", "config5"])
     ap.add_argument("--contigs", type=int, default=100_000, help="config4: contigs of the whole job")
+    ap.add_argument("--series", default="iid", choices=["iid", "planted"],
+                    help="config4: i.i.d. bases (BASELINE.json's generator) or planted ORFs (SURVEY 8d's metagenome-like series)")
     ap.add_argument("--sub-batch", type=int, default=6_250, help="contigs per device call")
     ap.add_argument("--contexts", type=int, default=8, help="device contexts (streams) the calls of a pass are dealt to")
     ap.add_argument("--gen-procs", type=int, default=0, help="worker processes generating the synthetic contigs (0: up to 32; 1: none, e.g. under rocprofv3)")
@@ -255,7 +257,10 @@ def main():
     work = distributed.estimate_work_known(lengths, gcs, None if single else model_gcs)
     mine = distributed.pack_contigs(work, world)[rank]        # a single contig does not shard: ranks > 0 idle on configs 2 / 5
     t_gen = time.perf_counter()
-    seqs = benchdata.generate(lengths[mine], gcs[mine], seeds[mine], procs=args.gen_procs or None)
+    planted = args.workload == "config4" and args.series == "planted"
+    if planted:
+        wname += "_planted"
+    seqs = benchdata.generate(lengths[mine], gcs[mine], seeds[mine], procs=args.gen_procs or None, planted=planted)
     t_gen = time.perf_counter() - t_gen
     job_bases = int(np.sum(lengths))
 
@@ -478,7 +483,13 @@ def secondary(ctx, _cabi, benchdata, models, headline, sync):
     import gzip
     from tests.util import golden_path
     out = {}
-    plans = [("config2", "1x5Mbp_gc50_meta", lambda: benchdata.config2(0), dict(meta=True), 10),
+    def planted4():
+        lengths, gcs, seeds = benchdata.config4_spec(6250)
+        return benchdata.generate(lengths, gcs, seeds, planted=True)
+
+    # config4_planted: one device call of the headline job's size on the planted-ORF series (about 0.06 nodes per base: real density)
+    plans = [("config4_planted", "6250x20kbp_gc30-70_meta_planted", planted4, dict(meta=True), 10),
+             ("config2", "1x5Mbp_gc50_meta", lambda: benchdata.config2(0), dict(meta=True), 10),
              ("config3", "1000x50kbp_gc30-70_meta", lambda: benchdata.generate(*_config3_spec()), dict(meta=True), 10),
              ("config5", "1x200Mbp_gc65_single", benchdata.config5, dict(meta=False, closed=True), 3)]
     for key, wname, make, kw, steps in plans:
@@ -500,6 +511,9 @@ def secondary(ctx, _cabi, benchdata, models, headline, sync):
                     "ms_per_step": round(1e3 * elapsed / steps, 3), "genes": int(len(res[0].genes)),
                     "host_to_host_Mbp_s": round(bases / h2h / 1e6, 3),
                     "roofline": roofline(ctx, dp_ms, passes, calls, res[0].n_chains, wname)}
+        if key == "config4_planted":
+            out[key]["nodes_per_bp"] = round(float(np.sum(res[0].contigs["n_nodes"])) / bases, 4)
+            out[key]["node_passes_per_call"] = int(passes // max(calls, 1))
         b.close()
     return out
 

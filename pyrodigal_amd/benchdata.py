@@ -21,6 +21,33 @@ def synthetic_contig(length, gc, seed):
     return _ACGT[rng.choice(4, size=length, p=p)].tobytes()
 
 
+_COMP = bytes.maketrans(b"ACGT", b"TGCA")
+
+
+def planted_contig(length, gc, seed):
+    """"Metagenome-like" sequence (the planted-ORF series): spacers of i.i.d. bases (geometric, mean 120) between open reading
+    frames on either strand -- ATG, a geometric number of sense codons (mean 300) drawn with the codon's base frequencies, TAA.  Real
+    node density (about 0.06 nodes per base) and long real ORFs: where windows, operon steps and start tweaks fire."""
+    rng = np.random.default_rng(seed)
+    pb = np.array([(1 - gc) / 2, gc / 2, gc / 2, (1 - gc) / 2])          # A C G T
+    codons = [(a, b, c) for a in range(4) for b in range(4) for c in range(4)]
+    stops = {(3, 0, 0), (3, 0, 2), (3, 2, 0)}                             # TAA TAG TGA (A0 C1 G2 T3)
+    sense = [cd for cd in codons if cd not in stops]
+    w = np.array([pb[a] * pb[b] * pb[c] for a, b, c in sense]); w /= w.sum()
+    sense_arr = np.array(sense, np.uint8)
+    parts, n = [], 0
+    while n < length:
+        sp = rng.geometric(1 / 120.0)
+        parts.append(_ACGT[rng.choice(4, size=sp, p=pb)].tobytes()); n += sp
+        L = rng.geometric(1 / 300.0)
+        body = _ACGT[sense_arr[rng.choice(len(sense), size=L, p=w)].reshape(-1)].tobytes()
+        orf = b"ATG" + body + b"TAA"
+        if rng.random() < 0.5:
+            orf = orf.translate(_COMP)[::-1]
+        parts.append(orf); n += len(orf)
+    return b"".join(parts)[:length]
+
+
 def config2(rank=0):
     """One 5 Mbp contig, 50 % GC (BASELINE.json configs[1]); other ranks get their own seed."""
     return [synthetic_contig(5_000_000, 0.50, 1234 + rank)]
@@ -48,13 +75,13 @@ def config5():
 
 
 def _gen_chunk(args):
-    return [synthetic_contig(int(n), float(gc), int(seed)) for n, gc, seed in args]
+    return [(planted_contig if len(a) > 3 and a[3] else synthetic_contig)(int(a[0]), float(a[1]), int(a[2])) for a in args]
 
 
-def generate(lengths, gcs, seeds, procs=None):
-    """`synthetic_contig` for many contigs on several host cores (the generator itself is the spec's, one seed per contig,
-    so the result does not depend on how the work is split)."""
-    items = list(zip(lengths, gcs, seeds))
+def generate(lengths, gcs, seeds, procs=None, planted=False):
+    """`synthetic_contig` (or `planted_contig`) for many contigs on several host cores (the generator itself is the spec's, one seed
+    per contig, so the result does not depend on how the work is split)."""
+    items = [(n, gc, seed, bool(planted)) for n, gc, seed in zip(lengths, gcs, seeds)]
     procs = procs or min(32, os.cpu_count() or 1)
     import sys
     main_mod = sys.modules.get("__main__")

@@ -23,26 +23,7 @@ OUT = os.path.join(ROOT, "tests", "golden", "models")
 COMP = bytes.maketrans(b"ACGT", b"TGCA")
 
 
-def planted_genome(length, gc, seed):
-    rng = np.random.default_rng(seed)
-    pb = np.array([(1 - gc) / 2, gc / 2, gc / 2, (1 - gc) / 2])          # A C G T
-    letters = np.frombuffer(b"ACGT", np.uint8)
-    codons = [(a, b, c) for a in range(4) for b in range(4) for c in range(4)]
-    stops = {(3, 0, 0), (3, 0, 2), (3, 2, 0)}                             # TAA TAG TGA (A0 C1 G2 T3)
-    sense = [cd for cd in codons if cd not in stops]
-    w = np.array([pb[a] * pb[b] * pb[c] for a, b, c in sense]); w /= w.sum()
-    sense_arr = np.array(sense, np.uint8)
-    parts, n = [], 0
-    while n < length:
-        sp = rng.geometric(1 / 120.0)
-        parts.append(letters[rng.choice(4, size=sp, p=pb)].tobytes()); n += sp
-        L = rng.geometric(1 / 300.0)
-        body = letters[sense_arr[rng.choice(len(sense), size=L, p=w)].reshape(-1)].tobytes()
-        orf = b"ATG" + body + b"TAA"
-        if rng.random() < 0.5:
-            orf = orf.translate(COMP)[::-1]
-        parts.append(orf); n += len(orf)
-    return b"".join(parts)[:length]
+from pyrodigal_amd.benchdata import planted_contig as planted_genome  # noqa: E402  (the generator lives with the other workload generators)
 
 
 def main():

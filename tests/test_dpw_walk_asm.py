@@ -23,8 +23,9 @@ def test_wait_states_hold_over_the_control_flow_graph():
 def test_the_check_sees_a_missing_wait_state(tmp_path):
     # the same generator with one pad taken out must fail its check (the checker is not vacuous)
     src = open(GEN).read()
-    assert src.count('        a("s_nop 1")\n') == 1
+    good = 'else "%[vm]"))\n        a("s_nop 1")\n'
+    assert src.count(good) == 1
     bad = tmp_path / "gen_bad.py"
-    bad.write_text(src.replace('        a("s_nop 1")\n', '', 1))
+    bad.write_text(src.replace(good, 'else "%[vm]"))\n        a("s_nop 0")\n'))
     r = subprocess.run([sys.executable, str(bad), "--check"], capture_output=True, text=True)
     assert r.returncode != 0 and "needs 2" in r.stderr

@@ -1,6 +1,8 @@
 """GPU parity of the finder-level C-ABI call (`pga_find_genes_batch`) against the CPU oracle:
 gene calls bit-identical, winning model identical, every returned node field bit-identical
 (north_star tolerance is 1e-6 on scores; we assert exact equality)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -260,3 +262,21 @@ def test_short_last_tiles_do_not_overflow_the_staging(models):
     n = sum(compare_contig(res, i, s, orc.Oracle(s), models, meta=True) for i, s in enumerate(seqs))
     assert n > 20
     c.close()
+
+
+def test_planted_orf_series_against_the_oracle(ctx, models):
+    """SURVEY 8(d)'s metagenome-like series (bench.py --series planted / secondary.config4_planted): fifty 20 kbp contigs of planted
+    ORFs -- real node density, long real ORFs, operon steps, overlapping 3' ends, start tweaks -- every node field and every gene
+    against the oracle, through the many-chain kernels the bench runs them on."""
+    from pyrodigal_amd import benchdata
+    lengths, gcs, seeds = benchdata.config4_spec(50)
+    seqs = benchdata.generate(lengths, gcs, seeds, planted=True)
+    ctx.set_models([m.buf for m in models])
+    os.environ["PGA_DP_KERNEL"] = "wave"
+    try:
+        res = ctx.find_genes_batch(seqs, meta=True, want_nodes=True)
+    finally:
+        del os.environ["PGA_DP_KERNEL"]
+    n = sum(compare_contig(res, i, s, orc.Oracle(s), models, meta=True) for i, s in enumerate(seqs))
+    dens = float(np.sum(res.contigs["n_nodes"])) / sum(len(s) for s in seqs)
+    assert n > 300 and dens > 0.035, (n, dens)
