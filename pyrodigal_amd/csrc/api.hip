@@ -256,7 +256,7 @@ static int score_connections_impl(pga_ctx* c, int32_t n, const int32_t* ndx, con
         HIP_TRY(c, db.alloc(&d_cbase, 2));
         HIP_TRY(c, hipMemcpyAsync(d_cbase, h_cbase, sizeof h_cbase, hipMemcpyHostToDevice, st));
         wg.g[0].ndx = nd.ndx; wg.g[0].stop_val = nd.stop_val;
-        pga_launch_dpw_topo(wg.g[0], nd.type, nd.strand, d_cbase, 1, n, st);
+        pga_launch_dpw_topo(wg.g[0], nd.type, nd.strand, d_cbase, 1, n, st, n);
         pga_launch_dpw_chain(d_chain, 1, 0, n, na, wg.g[0], d_mc, wb, st);
         bool sched = pga_dpw_use_sched();
         if (sched) {

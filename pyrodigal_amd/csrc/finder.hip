@@ -1676,7 +1676,9 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             sl.n_stops = h_sbase[(size_t)g * (NC + 1) + NC];
             sp.cs_out = nullptr;
             if (use_wave) {
-                pga_launch_dpw_topo(wgroups.g[g], ga[g].type, ga[g].strand, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], st);
+                int max_nodes_g = 0;
+                for (int i = 0; i < NC; i++) max_nodes_g = std::max(max_nodes_g, h_cbase[(size_t)g * (NC + 1) + i + 1] - h_cbase[(size_t)g * (NC + 1) + i]);
+                pga_launch_dpw_topo(wgroups.g[g], ga[g].type, ga[g].strand, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], st, max_nodes_g);
                 if (use_sched) {
                     pga_launch_dpw_sched(wgroups.g[g], d_cbase + (size_t)g * (NC + 1), d_bbase + (size_t)g * (NC + 1), NC, max_batches[g], st);
                     HT(c, hipMemcpyAsync(h_scur + 2 * g, wgroups.g[g].scur, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));

@@ -142,8 +142,9 @@ struct DpwGroupPtrs { DpwTopoArrays g[4]; };
 struct DpwBuffers { double* cs; DpwExt* ext; double* sfxv; int32_t* sfxi; };
 // which connection scorer a final-pass launch over n_chains chains uses (PGA_DP_KERNEL overrides: wave | tree1 | tree3 | scan)
 bool pga_dp_use_wave(int n_chains);
+// max_contig_nodes (0: unknown): the most nodes any contig of the group holds -- contigs that fit are staged in LDS, a workgroup each
 void pga_launch_dpw_topo(const DpwTopoArrays& ta, const uint8_t* type, const int8_t* strand, const int32_t* d_cbase, int n_contigs, int n_nodes,
-                         hipStream_t st);
+                         hipStream_t st, int max_contig_nodes = 0);
 // the step schedule of a group (after pga_launch_dpw_topo): d_bbase[c] = 64-node batches of the contigs before contig c; max_batches: of
 // the contig with the most nodes; ta.sent holds DPW_SCHED_STRIDE slots per batch; clears ta.scur first
 void pga_launch_dpw_sched(const DpwTopoArrays& ta, const int32_t* d_cbase, const int32_t* d_bbase, int n_contigs, int max_batches, hipStream_t st);

@@ -24,7 +24,7 @@ def main():
     kd = [t for t in tabs if "kernel_dispatch" in t][0]
     ks = [t for t in tabs if "kernel_symbol" in t][0]
     dur = {}
-    for r in cur.execute(f"select s.kernel_name, d.grid_size_x, avg(d.end-d.start)/1e3 from {kd} d join {ks} s on d.kernel_id=s.id group by s.kernel_name, d.grid_size_x"):
+    for r in cur.execute(f"select s.kernel_name, d.grid_size_x * d.grid_size_y * d.grid_size_z, avg(d.end-d.start)/1e3 from {kd} d join {ks} s on d.kernel_id=s.id group by s.kernel_name, d.grid_size_x * d.grid_size_y * d.grid_size_z"):
         m = re.search(r"(k_\w+?)(I|E)", r[0])
         dur[(m.group(1) if m else r[0][:30], r[1])] = r[2]
     rows = []
