@@ -579,7 +579,7 @@ k_dpw_sched(const int32_t* __restrict__ cbase, const int32_t* __restrict__ bbase
             slot = pos;
             emit_end();
         }
-        if (lane == 0) ta.shdr[bg] = DpwSchedHdr{off, (unsigned)n_near | ((unsigned)n_own << 16), jm, 0};
+        if (lane == 0) ta.shdr[bg] = DpwSchedHdr{off, (unsigned)n_near | ((unsigned)n_own << 16), jm, (int)slot};     // slot: slots in use, END / NOP included
     }
 }
 
@@ -961,10 +961,14 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
             // contig to come by finds them in HBM (2 000 cycles per line).  One vector instruction asks for all of them now: lane l
             // touches line l of the batch's slots (4 bytes, straight to LDS, into a scratch row nobody reads), which puts the lines in this
             // XCD's L2 by the time the steps get to them.
+            // (only the lines the batch's lists take: a batch owns DPW_SCHED_STRIDE slots and uses half of them or fewer, and what the
+            //  first model of a contig touches comes from HBM)
             const char* line = (const char*)g_sent + ((size_t)(cd.sched_b0 + b) * DPW_SCHED_STRIDE * sizeof(DpwSlot) + (size_t)lane * 64);
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(line), "s"((unsigned)(uintptr_t)s_pf) : "memory");
+            if (2 * lane < (int)hdr.w) {
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(line), "s"((unsigned)(uintptr_t)s_pf) : "memory");
+            }
         }
         DpwT T; int kfb;
         load_target_w(T, kfb, P, i0, lane, n, M.negc);

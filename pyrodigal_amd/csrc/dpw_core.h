@@ -439,7 +439,7 @@ DPW_HD void dpw_step(const DpwS& S, const DpwLT& T, DpwLane& L, const DpwModel& 
 //        mR5 = reverse starts whose static interval holds s_ndx; dynamic: tbn + s_ndx + 7 < drhs0 (:238-254),
 //        mR3 = reverse stops with s_ndx < ndx - 4; dynamic: the candidates through the lane's overlapping starts (:288-336),
 //        pull = (batch sources only) the forward starts of its ORF that sit before it in the batch (:166-174)
-struct DpwSchedHdr { uint32_t off; uint32_t cnt; int32_t jm; int32_t spare; };   // off: first slot; cnt = near entries | batch entries << 16 (END / NOP not counted)
+struct DpwSchedHdr { uint32_t off; uint32_t cnt; int32_t jm; int32_t used; };    // off: first slot; cnt = near entries | batch entries << 16 (END / NOP not counted); used: slots the lists take, END / NOP included
 struct DpwSlot { uint32_t lane; int32_t s_ndx; uint32_t code; int32_t j; uint64_t m[2]; };
 #define DPW_SCHED_STRIDE 128u                                                     // slots a batch owns (its lists sit at batch * stride)
 #define DPW_SCHED_NONE 0xffffffffu                                                // off: the lists did not fit (the caller falls back)

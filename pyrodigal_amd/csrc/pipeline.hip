@@ -458,13 +458,12 @@ __device__ __forceinline__ void extract_strand(ExShared& S, const TileGeom G, co
             if (q >= 0 && q < EX_PER_THREAD) cand |= (1u << q) & inm;
         }
     }
-    while (cand) {
-        const int q = __builtin_ctz(cand);
-        cand &= cand - 1u;
+    // One candidate.  Stop codons and the rest go through loops of their own (below): lanes of a wavefront that sit in the same
+    // iteration then run the same path -- in one loop over all candidates an iteration cost both paths whenever the lanes' kinds differed.
+    auto candidate = [&](const int q, const bool is_stop) {
         const int i = i0 + q;
         const int r = q % 3, f = (f0 + r) % 3;
         const unsigned fr = 0x249u << r;
-        const bool is_stop = (stm >> q) & 1u;
         // the stop to the right: among the thread's own positions, else from the scan
         const unsigned above = stm & fr & ~((2u << q) - 1u);
         const unsigned below = stm & fr & ((1u << q) - 1u);
@@ -472,28 +471,32 @@ __device__ __forceinline__ void extract_strand(ExShared& S, const TileGeom G, co
         const int sv_stop = FWD ? (left >= 0 ? left : f - 6) : (left >= 0 ? L - 1 - left : L - f + 5);
         if (is_stop) {
             if (orf_has_start(r, f, i, left, true)) put(q, PGA_T_STOP, sv_stop);
-            continue;
+            return;
         }
         int last = above ? i0 + __builtin_ctz(above) : (r == 0 ? nxt[0] : (r == 1 ? nxt[1] : nxt[2]));
         const bool real = last != EX_NONE_HI;
         if (!real) {
-            if (P.closed) continue;                     // closed ends: nothing runs off the right edge
+            if (P.closed) return;                     // closed ends: nothing runs off the right edge
             last = L - 3 - ((L - 3 - f) % 3);           // virtual right end: last full codon position of the frame
-            if (last < i) continue;
+            if (last < i) return;
             if (last == i) {                            // the virtual stop node itself
                 if (orf_has_start(r, f, i, left, false)) put(q, PGA_T_STOP | (1 << 2), sv_stop);
-                continue;
+                return;
             }
         }
-        if (n_masks > 0 && i < mask_bound(last)) continue;
+        if (n_masks > 0 && i < mask_bound(last)) return;
         const int mind = real ? P.min_gene : P.min_edge_gene;
         int type = -1, edge = 0;
         const int c0 = (int)((cw >> (2 * q)) & 3u);
         if (last - i + 3 >= mind && ((scm >> q) & 1u)) type = c0 == NA ? 0 : (c0 == NT ? 2 : 1);
         else if (i <= 2 && !P.closed && last - i > P.min_edge_gene) { type = 0; edge = 1; }
-        if (type < 0) continue;
+        if (type < 0) return;
         put(q, type | (edge << 2), FWD ? last : L - 1 - last);
-    }
+    };
+    unsigned stops = stm;
+    while (stops) { const int q = __builtin_ctz(stops); stops &= stops - 1u; candidate(q, true); }
+    cand &= ~stm;
+    while (cand) { const int q = __builtin_ctz(cand); cand &= cand - 1u; candidate(q, false); }
 }
 
 __global__ void __launch_bounds__(256)
