@@ -302,11 +302,11 @@ __device__ __forceinline__ void strand_codon_masks(const TileGeom G, const uint8
 #pragma unroll
     for (int q = 0; q < EX_PER_THREAD; q++) {
         const unsigned idx = (cw >> (2 * q)) & 63u;
-        const unsigned ok = ((unk >> q) & 7u) == 0u ? 1u : 0u;
-        stm |= ((unsigned)(stop_codons >> idx) & ok) << q;
-        scm |= ((unsigned)(start_codons >> idx) & ok) << q;
+        stm |= ((unsigned)(stop_codons >> idx) & 1u) << q;
+        scm |= ((unsigned)(start_codons >> idx) & 1u) << q;
     }
-    stm &= inm; scm &= inm;
+    const unsigned okm = inm & ~(unk | (unk >> 1) | (unk >> 2));      // positions whose three bases are all known
+    stm &= okm; scm &= okm;
 }
 
 // The nodes of one strand among the thread's twelve forward positions a + 12 t + k: bit k of `nodes`, type | edge << 2 in the
@@ -358,33 +358,40 @@ __device__ __forceinline__ void extract_strand(ExShared& S, const TileGeom G, co
         mx[r] = a ? i0 + 31 - __builtin_clz(a) : -1;
         ls[r] = b ? i0 + 31 - __builtin_clz(b) : -1;
     }
-    // scans over the 256 threads in strand-local order (FWD: rising t): within the wavefront by shuffles, across the four
-    // wavefronts through LDS.  mn: inclusive min towards larger positions; mx, ls: inclusive max towards smaller positions.
+    // Next / previous stop and last start codon of every frame over the 256 threads in strand-local order (FWD: rising t).  Positions
+    // rise with the strand-local order, so "the next stop after my positions" is the first stop of the NEAREST later thread that has one:
+    // a vote says which lanes have a stop of the frame, a bit scan over the lanes on the proper side picks the neighbour, one
+    // shuffle fetches its value (six rounds of three shuffles per frame before: a third of the kernel's vector instructions);
+    // across the four wavefronts through LDS as before.
+    const unsigned long long lanes_up = FWD ? (~1ull << lane) : ((1ull << lane) - 1ull);      // the lanes later in strand-local order
+    const unsigned long long lanes_dn = FWD ? ((1ull << lane) - 1ull) : (~1ull << lane);      // ... and earlier
+    int xa[3], xb[3], xe[3];                // exclusive next stop, exclusive previous stop, inclusive last start codon -- within the wavefront
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-            const int a = FWD ? __shfl_down(mn[r], off, 64) : __shfl_up(mn[r], off, 64);
-            const int b = FWD ? __shfl_up(mx[r], off, 64) : __shfl_down(mx[r], off, 64);
-            const int e = FWD ? __shfl_up(ls[r], off, 64) : __shfl_down(ls[r], off, 64);
-            const bool has_up = FWD ? lane + off < 64 : lane >= off, has_dn = FWD ? lane >= off : lane + off < 64;
-            if (has_up) mn[r] = min(mn[r], a);
-            if (has_dn) { mx[r] = max(mx[r], b); ls[r] = max(ls[r], e); }
-        }
+    for (int r = 0; r < 3; r++) {
+        const unsigned long long hs = __ballot(mx[r] >= 0), hc = __ballot(ls[r] >= 0);
+        const unsigned long long mu = hs & lanes_up, md = hs & lanes_dn, mc = hc & lanes_dn;
+        // nearest lane on that side (any lane when there is none: the value is not used)
+        const int su = mu ? (FWD ? __builtin_ctzll(mu) : 63 - __builtin_clzll(mu)) : lane;
+        const int sd = md ? (FWD ? 63 - __builtin_clzll(md) : __builtin_ctzll(md)) : lane;
+        const int sc = mc ? (FWD ? 63 - __builtin_clzll(mc) : __builtin_ctzll(mc)) : lane;
+        const int va = __shfl(mn[r], su, 64), vb = __shfl(mx[r], sd, 64), ve = __shfl(ls[r], sc, 64);
+        xa[r] = mu ? va : EX_NONE_HI;
+        xb[r] = md ? vb : -1;
+        xe[r] = ls[r] >= 0 ? ls[r] : (mc ? ve : -1);
+        // the wavefront's own first / last stop and last start codon, for the other wavefronts
+        const int l_first = hs ? (FWD ? __builtin_ctzll(hs) : 63 - __builtin_clzll(hs)) : 0;
+        const int l_last = hs ? (FWD ? 63 - __builtin_clzll(hs) : __builtin_ctzll(hs)) : 0;
+        const int l_lastc = hc ? (FWD ? 63 - __builtin_clzll(hc) : __builtin_ctzll(hc)) : 0;
+        const int w_mn = __shfl(mn[r], l_first, 64), w_mx = __shfl(mx[r], l_last, 64), w_ls = __shfl(ls[r], l_lastc, 64);
+        if (lane == 0) { S.wmin[r][w] = hs ? w_mn : EX_NONE_HI; S.wmax[r][w] = hs ? w_mx : -1; S.wlsc[r][w] = hc ? w_ls : -1; }
     }
-    if (lane == (FWD ? 0 : 63)) { for (int r = 0; r < 3; r++) S.wmin[r][w] = mn[r]; }
-    if (lane == (FWD ? 63 : 0)) { for (int r = 0; r < 3; r++) { S.wmax[r][w] = mx[r]; S.wlsc[r][w] = ls[r]; } }
     S.scm[t] = (int)scm;
     __syncthreads();
     int nxt[3], prv[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-        // exclusive: the neighbour's inclusive value, then the wavefronts beyond it, then the tile carry
-        int a = FWD ? __shfl_down(mn[r], 1, 64) : __shfl_up(mn[r], 1, 64);
-        if (FWD ? lane == 63 : lane == 0) a = EX_NONE_HI;
-        int b = FWD ? __shfl_up(mx[r], 1, 64) : __shfl_down(mx[r], 1, 64);
-        if (FWD ? lane == 0 : lane == 63) b = -1;
-        int e = ls[r];
+        // then the wavefronts beyond this one, then the tile carry
+        int a = xa[r], b = xb[r], e = xe[r];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const bool up_side = FWD ? k > w : k < w, dn_side = FWD ? k < w : k > w;
@@ -521,10 +528,12 @@ k_tile_stops(const uint8_t* __restrict__ dig, int64_t total, const ContigDesc* _
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             const unsigned m = stm & (0x249u << r);
-            int a = m ? i0 + __builtin_ctz(m) : EX_NONE_HI, b = m ? i0 + 31 - __builtin_clz(m) : -1;
-#pragma unroll
-            for (int k = 32; k >= 1; k >>= 1) { a = min(a, __shfl_xor(a, k, 64)); b = max(b, __shfl_xor(b, k, 64)); }
-            if ((t & 63) == 0) { s_min[s][r][t >> 6] = a; s_max[s][r][t >> 6] = b; }
+            const int a = m ? i0 + __builtin_ctz(m) : EX_NONE_HI, b = m ? i0 + 31 - __builtin_clz(m) : -1;
+            // positions rise (s == 0) or fall (s == 1) with the lane: the wavefront's first stop is the first stop of its first lane that has one
+            const unsigned long long hs = __ballot(m != 0u);
+            const int l_lo = hs ? __builtin_ctzll(hs) : 0, l_hi = hs ? 63 - __builtin_clzll(hs) : 0;
+            const int wa = __shfl(a, s == 0 ? l_lo : l_hi, 64), wb = __shfl(b, s == 0 ? l_hi : l_lo, 64);
+            if ((t & 63) == 0) { s_min[s][r][t >> 6] = hs ? wa : EX_NONE_HI; s_max[s][r][t >> 6] = hs ? wb : -1; }
         }
     }
     __syncthreads();

@@ -5,10 +5,11 @@ T=${1:-r05_q}
 TESTS=${2:-tests/test_stages_gpu.py tests/test_dp_gpu.py tests/test_finder_gpu.py}
 mkdir -p gpurun_out/$T
 timeout 400 python -m pytest $TESTS -x -q -m gpu > gpurun_out/$T/pytest.log 2>&1; tail -3 gpurun_out/$T/pytest.log
-B="python bench.py --no-cpu-baseline --no-secondary"
+R=$(pwd)
+B="python $R/bench.py --no-cpu-baseline --no-secondary"
 cd /tmp; export TMPDIR=/tmp
-timeout 200 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$T/trace -o t -- $B --contigs 6250 --contexts 1 --gen-procs 1 --steps 4 --warmup 2 > $GRAFT_REPO_ROOT/gpurun_out/$T/c1.json 2> $GRAFT_REPO_ROOT/gpurun_out/$T/c1.err
-cd $GRAFT_REPO_ROOT
+timeout 200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$T/trace -o t -- $B --contigs 6250 --contexts 1 --gen-procs 1 --steps 4 --warmup 2 > $R/gpurun_out/$T/c1.json 2> $R/gpurun_out/$T/c1.err
+cd $R
 python tools/rocpd_stats.py $(find gpurun_out/$T/trace -name "*.db" | head -1) 2>/dev/null | head -24
 timeout 300 $B > gpurun_out/$T/d8.json 2> gpurun_out/$T/d8.err
 python - <<PY
