@@ -1744,6 +1744,8 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             }
             return publish(R, guard.r, P, out);
         }
+        PINBUF(h_segflags, int32_t, "h_segflags", (size_t)(PGA_SEG_ROUNDS + 2) * NCH + 1);      // [rounds][chains] flags, [chains] spine sizes, [chains] a round's verdict
+        if (segmented && !(getenv("PGA_DP_SEG_READBACK") && atoi(getenv("PGA_DP_SEG_READBACK")) == 0)) seg_dev.h_round = h_segflags + (size_t)(PGA_SEG_ROUNDS + 1) * NCH;
         // one DP launch over the chains of every group: chains are independent, the more in flight the better
         HT(c, hipEventRecord(f->e_dp0[0], st));
         if (use_wave) {
@@ -1771,7 +1773,6 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         HT(c, hipMemcpyAsync(h_ipath, dp.ipath, sizeof(int32_t) * NCH, hipMemcpyDeviceToHost, st));
         HT(c, hipMemcpyAsync(h_maxscore, dp.max_score, sizeof(double) * NCH, hipMemcpyDeviceToHost, st));
         if (meta_run) HT(c, hipMemcpyAsync(h_conv, d_conv, (size_t)NG * NC, hipMemcpyDeviceToHost, st));
-        PINBUF(h_segflags, int32_t, "h_segflags", (size_t)PGA_SEG_ROUNDS * NCH + NCH + 1);
         if (segmented) {
             HT(c, hipMemcpyAsync(h_segflags, seg_dev.flags, sizeof(int32_t) * PGA_SEG_ROUNDS * NCH, hipMemcpyDeviceToHost, st));
             HT(c, hipMemcpyAsync(h_segflags + (size_t)PGA_SEG_ROUNDS * NCH, seg_dev.nsp, sizeof(int32_t) * NCH, hipMemcpyDeviceToHost, st));

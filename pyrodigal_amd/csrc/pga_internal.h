@@ -118,6 +118,7 @@ struct DpSegDev {        // device copies + workspace; all owned by the caller
     int32_t* sp_idx; int32_t* sp_tb; int32_t* sp_pp; double* sp_w;   // the spine lists (one element per node at most)
     int64_t n_nodes;     // elements of the real chains in the per-node arrays
     int32_t n_segs, n_p1, n_big, max_seg_nodes, max_seg_len, max_big_n;
+    int32_t* h_round = nullptr;   // or: pinned host memory, n_chains ints -- the launcher reads a round's verdict back and stops when every chain passed
 };
 // false: nothing to segment (plan left empty)
 bool pga_dp_plan(const ChainDesc* h_chains, int n_chains, int64_t tot_nodes, DpSegPlan& plan);
