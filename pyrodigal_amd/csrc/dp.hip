@@ -1449,14 +1449,30 @@ k_dp_rescore(const ChainDesc* __restrict__ chains, const int32_t* __restrict__ b
 #pragma unroll
                 for (int t = 0; t < 64; t++) xs[t] = s_term[t];
                 double r = 0.0;
+                // Eight entries at a time.  A group without a special entry (nine in ten: 1.5 % of the entries are special) is eight
+                // additions back to back, each waiting only for the one before, and their results leave for LDS behind them; with a
+                // test, a branch and a store between any two additions (the form kept for the other groups) an entry cost some 55
+                // cycles of a lone wavefront -- 5.7 ms for the 224 000 spine entries of config 5.
 #pragma unroll
-                for (int t = 0; t < 64; t++) {
-                    const double x = xs[t];
-                    if (__builtin_expect((int)((special >> t) & 1ull), 0)) {
-                        const int c = s_code[t];
-                        r = c < 0 ? x : s_out[c] + x;
-                    } else r = r + x;
-                    s_out[t] = r;
+                for (int t0 = 0; t0 < 64; t0 += 8) {
+                    const unsigned sp8 = (unsigned)(special >> t0) & 0xffu;
+                    if (__builtin_expect(sp8 == 0u, 1)) {
+                        const double r0 = r + xs[t0], r1 = r0 + xs[t0 + 1], r2 = r1 + xs[t0 + 2], r3 = r2 + xs[t0 + 3];
+                        const double r4 = r3 + xs[t0 + 4], r5 = r4 + xs[t0 + 5], r6 = r5 + xs[t0 + 6], r7 = r6 + xs[t0 + 7];
+                        s_out[t0] = r0; s_out[t0 + 1] = r1; s_out[t0 + 2] = r2; s_out[t0 + 3] = r3;
+                        s_out[t0 + 4] = r4; s_out[t0 + 5] = r5; s_out[t0 + 6] = r6; s_out[t0 + 7] = r7;
+                        r = r7;
+                    } else {
+#pragma unroll
+                        for (int t = t0; t < t0 + 8; t++) {
+                            const double x = xs[t];
+                            if (__builtin_expect((int)((special >> t) & 1ull), 0)) {
+                                const int c = s_code[t];
+                                r = c < 0 ? x : s_out[c] + x;
+                            } else r = r + x;
+                            s_out[t] = r;
+                        }
+                    }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
