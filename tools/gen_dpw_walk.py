@@ -43,14 +43,20 @@ def line_regs(base, slot):
     return d
 
 
-LBASE = (36, 72)                                    # two sets of sixteen: the line at hand, and the next one on its way (ping-pong)
-ST = {"EP": "s[34:35]", "EP_lo": "s34", "EP_hi": "s35",
-      "SC": "s[52:53]", "SC_lo": "s52", "SC_hi": "s53", "TAGK": "s54", "TMP": "s55", "TM": "s[56:57]", "OK": "s[58:59]",
-      "C0": "s[60:61]", "C1": "s[62:63]", "C2": "s[64:65]",
-      "SX0": "s[60:61]", "SX0_lo": "s60", "SX0_hi": "s61", "SX1_lo": "s62", "SX1_hi": "s63", "SX2_lo": "s64", "SX2_hi": "s65",
-      "SV": "s[60:61]", "SV_lo": "s60", "SV_hi": "s61", "BVS_lo": "s62", "BVS_hi": "s63", "CM": "s[64:65]", "C2b": "s[56:57]", "BI": "s55", "CI": "s66",
-      "TBN": "s66", "LHS": "s67", "SVM": "s68"}
-S_CLOBBER = ["s%d" % i for i in range(36, 88)] + ["vcc"]
+EP_REGS = "s[16:17]"
+def lbase(near):
+    """sixteen scalar registers per line in flight.  Near lists are a line or two long: the line at hand and the next one.  The walk's
+    list is some twenty lines, and a scalar load that misses the scalar cache takes longer than two slots' steps: TWO lines at hand and
+    two on their way (scalar loads return out of order, so every wait is for all of them: what is in flight is half the sets)."""
+    return (36, 52) if near else (36, 52, 68, 84)
+ST = {"EP": EP_REGS, "EP_lo": "s16", "EP_hi": "s17",
+      "SC": "s[18:19]", "SC_lo": "s18", "SC_hi": "s19", "TAGK": "s20", "TMP": "s21", "TM": "s[22:23]", "OK": "s[24:25]",
+      "C0": "s[26:27]", "C1": "s[28:29]", "C2": "s[30:31]",
+      "SX0": "s[26:27]", "SX0_lo": "s26", "SX0_hi": "s27", "SX1_lo": "s28", "SX1_hi": "s29", "SX2_lo": "s30", "SX2_hi": "s31",
+      "SV": "s[26:27]", "SV_lo": "s26", "SV_hi": "s27", "BVS_lo": "s28", "BVS_hi": "s29", "CM": "s[30:31]", "C2b": "s[22:23]", "BI": "s21", "CI": "s35",
+      "TBN": "s35", "LHS": "s14", "SVM": "s15"}         # (s32 - s34 and s100 / s101 are the compiler's: stack and frame pointers, scratch)
+def s_clobber(near):
+    return ["s%d" % i for i in range(18, 32)] + ["s35", "s14", "s15"] + ["s%d" % i for i in range(36, 36 + 16 * len(lbase(near)))] + ["vcc"]
 
 
 def body(near, a, nxt, other, slot):
@@ -89,8 +95,14 @@ def body(near, a, nxt, other, slot):
     a("Lr5c_%=:")
     a("v_cmp_ge_f64_e32 vcc, {W}, {LV}")
     a("s_and_b64 vcc, vcc, {MA}")
-    a("s_cbranch_vccz " + nxt)
+    a("s_cbranch_vccnz Lr5take_%=")              # nobody takes it (two steps in three): straight on into the next slot, no branch taken
+    # ---- everything below is out of line: the slots of a line, and the lines of a round, follow each other in the order they are met,
+    #      and a reverse start that changes nothing -- the commonest step -- falls from one slot into the next
+    a = c
+    a("Lr5take_%=:")
     commit("{E3}")
+    rest = []
+    a = rest.append                              # (the reverse stop's piece comes first: the dispatch of a stop node falls into it)
     c("Lr5tab_%=:")                              # reverse stops within 3 * OPER_DIST bases: the distance term instead of the constant
     c("v_add_f64 {W}, {SC}, %[negc]")
     for l in igm_lookup("{MV}", "{MB}", "Lr5t0_%="): c(l)
@@ -292,62 +304,84 @@ def body(near, a, nxt, other, slot):
         a("s_and_b64 vcc, vcc, {OK}")
         a("s_cbranch_vccz " + other)
         commit("{TG}", other)
-    return cold
+    return rest + cold
 
 
 def block(near):
     """the instruction list of one block; names in {} are substituted (registers above, %[operand] for the statement's operands).
     Slots are 32 bytes, two to a line; a list starts on a line and ends with an END slot, so the loop has no counter and a line's
-    address does not depend on the one before: the loop runs two lines per round, each in its own register set, and asks for line
-    e + 1 before it looks at line e (a step is some twenty instructions; the round trip of a scalar load several hundred cycles)."""
+    address does not depend on the one before.  The line sets form two halves: while the lines of one half are worked on, the loads
+    of the other half's lines are in flight (a step is some twenty instructions; the round trip of a scalar load several hundred
+    cycles); every half begins with one s_waitcnt for all of them."""
+    LB = lbase(near)
+    n = len(LB); h = n // 2                     # lines per half
     out = []
-    out.append("s_load_dwordx16 {LINE@0.0}, {EP}, 0x0")
-    for half in (0, 1):
-        other = "LtopH%d_%%=" % (1 - half)
+    cold_all = []
+    for q in range(h):
+        out.append("s_load_dwordx16 {LINE@%d.0}, {EP}, 0x%x" % (q, 64 * q))
+    for q in range(n):
+        nxt_line = ("LtopH%d_%%=" if (q + 1) % h == 0 else "LlineH%d_%%=") % ((q + 1) % n)      # where the line after this one begins
         for slot in (0, 1):
             L = []
             a = L.append
-            nxt = "Lslot1_%=" if slot == 0 else other       # where a slot's step goes when it is done
+            nxt = "Lslot1_%=" if slot == 0 else nxt_line       # where a slot's step goes when it is done
             if slot == 0:
-                a("Ltop_%=:")
-                a("s_waitcnt lgkmcnt(0)")
-                if half == 0:
-                    a("s_load_dwordx16 {LINE@other}, {EP}, 0x40")
+                if q % h == 0:
+                    a("Ltop_%=:")
+                    a("s_waitcnt lgkmcnt(0)")
+                    # the other half's lines: the first half's sit at EP + 64 q; the second half's were loaded relative to the old EP
+                    for r in range(h):
+                        t = (q + h + r) % n                                   # the set that is free now
+                        off = 64 * (h + r) if q == 0 else 64 * (n + r)       # q == 0: lines h .. n-1 of this round; q == h: lines 0 .. h-1 of the next
+                        a("s_load_dwordx16 {LINE@%d.0}, {EP}, 0x%x" % (t, off))
+                    if q == h:
+                        a("s_add_u32 {EP_lo}, {EP_lo}, %d" % (64 * n))
+                        a("s_addc_u32 {EP_hi}, {EP_hi}, 0")
                 else:
-                    a("s_load_dwordx16 {LINE@other}, {EP}, 0x80")
-                    a("s_add_u32 {EP_lo}, {EP_lo}, 128")
-                    a("s_addc_u32 {EP_hi}, {EP_hi}, 0")
+                    a("Lline_%=:")
             else:
                 a("Lslot1_%=:")
             a("s_bitcmp1_b32 {E2}, 4")           # word 2 = kind | frame << 2 | 16 if not a reverse start; 16 = END, 48 = NOP; kinds 1 = F3, 2 = R5, 3 = R3
             a("s_cbranch_scc1 Lother_%=")
             if EXP in ("noop", "nor5"): a("s_branch " + nxt)
-            cold = body(near, a, nxt, other, slot)
-            a("Lother_%=:")
-            a("s_bitcmp1_b32 {E2}, 0")           # bit 0 set: a stop node
-            a("s_cbranch_scc1 Lstop_%=")
-            a("s_bitcmp1_b32 {E2}, 5")           # NOP: on to the next slot; else END
-            a("s_cbranch_scc1 " + nxt)
-            a("s_branch Lend%d_%%=" % half)
-            a("Lstop_%=:")
+            C = []                               # the slot's out-of-line code
+            b = C.append
+            b("Lother_%=:")
+            b("s_bitcmp1_b32 {E2}, 0")           # bit 0 set: a stop node
+            b("s_cbranch_scc1 Lstop_%=")
+            b("s_bitcmp1_b32 {E2}, 5")           # NOP: on to the next slot; else END
+            b("s_cbranch_scc1 " + nxt)
+            b("s_branch Lend%d_%%=" % q)
+            b("Lstop_%=:")
             if slot == 0:
-                a("s_bitcmp0_b32 {E2}, 1")       # bit 1 clear: F3 (a whole line)
-                a("s_cbranch_scc1 " + (other if EXP in ("noop", "nof3") else "Lf3_%="))
-            a("s_branch " + (nxt if EXP in ("noop", "nor3") else "Lr3_%="))
-            L += cold
-            for l in L:
-                l = re.sub(r"(L\w+?)_%=", lambda m: ("%sH%dS%d_%%=" % (m.group(1), half, slot) if m.group(1) not in ("Ltop", "Lslot1") else "%sH%d_%%=" % (m.group(1), half))
-                           if not re.fullmatch(r"Lend\d?|LtopH\d", m.group(1)) else m.group(0), l)
-                l = l.replace("{LINE@other}", "{LINE@%d.0}" % (1 - half))
-                l = re.sub(r"\{(E[0-3]|M[A-F])\}", lambda m: "{%s@%d.%d}" % (m.group(1), half, slot), l)
-                out.append(l)
-    # the END slot is consumed: the pointer moves to the line behind it (half 0: the line at hand sits at EP; half 1: EP was moved on already)
-    out.append("Lend0_%=:")
-    out.append("s_add_u32 {EP_lo}, {EP_lo}, 64")
-    out.append("s_addc_u32 {EP_hi}, {EP_hi}, 0")
-    out.append("Lend1_%=:")
-    out.append("s_waitcnt lgkmcnt(0)")            # the load that is still in flight writes registers this statement hands back
+                b("s_bitcmp0_b32 {E2}, 1")       # bit 1 clear: F3 (a whole line)
+                b("s_cbranch_scc1 " + (nxt_line if EXP in ("noop", "nof3") else "Lf3_%="))
+            if EXP in ("noop", "nor3"): b("s_branch " + nxt)
+            C += body(near, a, nxt, nxt_line, slot)          # (its first piece is the reverse stop's: Lstop falls into it)
+            if q == n - 1 and slot == 1: a("s_branch LtopH0_%=")          # the round's last slot: back to the first line's set
+            def rename(l):
+                l = re.sub(r"(L\w+?)_%=", lambda m: ("%sH%dS%d_%%=" % (m.group(1), q, slot) if m.group(1) not in ("Ltop", "Lline", "Lslot1") else "%sH%d_%%=" % (m.group(1), q))
+                           if not re.fullmatch(r"Lend\d?|LtopH\d|LlineH\d", m.group(1)) else m.group(0), l)
+                return re.sub(r"\{(E[0-3]|M[A-F])\}", lambda m: "{%s@%d.%d}" % (m.group(1), q, slot), l)
+            out += [rename(l) for l in L]
+            cold_all += [rename(l) for l in C]
+    out += cold_all
+    # the END slot is consumed: the pointer moves to the line behind it.  Line q of the first half sits at EP + 64 q; when a line of the
+    # second half is at hand EP has moved on by a whole round already.
+    for q in range(n):
+        out.append("Lend%d_%%=:" % q)
+        d = 64 * (q + 1) if q < h else 64 * (q + 1) - 64 * n
+        if d > 0:
+            out.append("s_add_u32 {EP_lo}, {EP_lo}, %d" % d); out.append("s_addc_u32 {EP_hi}, {EP_hi}, 0")
+        elif d < 0:
+            out.append("s_sub_u32 {EP_lo}, {EP_lo}, %d" % -d); out.append("s_subb_u32 {EP_hi}, {EP_hi}, 0")
+        if q < n - 1: out.append("s_branch Ldone_%=")
+    out.append("Ldone_%=:")
+    out.append("s_waitcnt lgkmcnt(0)")            # the loads that are still in flight write registers this statement hands back
     return out
+
+
+NEAR_NOW = [None]       # which block is being substituted (the line sets differ)
 
 
 def subst(line):
@@ -356,7 +390,7 @@ def subst(line):
         if "@" in k:
             nm, _, st = k.partition("@")
             h, _, sl = st.partition(".")
-            return line_regs(LBASE[int(h)], int(sl))[nm]
+            return line_regs(lbase(NEAR_NOW[0])[int(h)], int(sl))[nm]
         if k in VT: return VT[k]
         if k in ST: return ST[k]
         raise KeyError(k)
@@ -378,6 +412,7 @@ def regs_of(tok):
 
 
 def check(lines, name):
+    NEAR_NOW[0] = name == "near"
     ins = []
     labels = {}
     for l in lines:
@@ -451,6 +486,7 @@ def check(lines, name):
 
 
 def statement(near):
+    NEAR_NOW[0] = near
     return [subst(l) for l in block(near)]
 
 
@@ -460,7 +496,7 @@ def c_statement(near):
     s = ["#define %s() \\" % nm, "    asm volatile( \\"]
     for l in body:
         s.append('        "%s\\n\\t" \\' % l)
-    outs = ['"+{v[64:65]}"(a_lv)', '"+{v66}"(a_lt)', '"+{s[34:35]}"(a_ep)']
+    outs = ['"+{v[64:65]}"(a_lv)', '"+{v66}"(a_lt)', '"+{%s}"(a_ep)' % EP_REGS]
     if not near: outs.append('"+{v[92:93]}"(a_sv)')
     ins = ['"{v[68:69]}"(a_x0)', '"{v[70:71]}"(a_x1)', '"{v[72:73]}"(a_x2)']
     if near:
@@ -472,7 +508,7 @@ def c_statement(near):
         ins += ['[drhs%d] "v"(a_drhs%d)' % (q, q), '[dlo%d] "v"(a_dlo%d)' % (q, q), '[dhi%d] "v"(a_dhi%d)' % (q, q), '[r3v%d] "s"(a_r3v%d)' % (q, q)]
     s.append("        : " + ", ".join(outs) + " \\")
     s.append("        : " + ", ".join(ins) + " \\")
-    s.append("        : " + ", ".join('"%s"' % r for r in V_CLOBBER + S_CLOBBER) + ', "memory")')
+    s.append("        : " + ", ".join('"%s"' % r for r in V_CLOBBER + s_clobber(near)) + ', "memory")')
     return "\n".join(s)
 
 
