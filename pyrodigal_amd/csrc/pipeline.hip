@@ -827,6 +827,7 @@ struct OrfCtx {
     const uint8_t* d;             // GroupArrays::df of the contig: digit | forward-node flag << 4 | reverse-node flag << 5, by position
     const int32_t* pre;           // GroupArrays::pre of the contig: index of the first node of a position
     int tbase, p, q, L, strand, step, ncod;
+    int kstop;                    // index of the ORF's stop node in its contig
     int2 cc;
     // the walk's own strand has a node at position j / that node's index in the contig
     __device__ __forceinline__ bool node_at(const int j) const { return (d[j] >> (strand == 1 ? 4 : 5)) & 1; }
@@ -1070,10 +1071,24 @@ __device__ __forceinline__ void orf_serial_quad(const OrfCtx& o, const ChainDesc
         if (ci < 64) { sm0 |= bit; asm volatile("; mask 0"); } else if (ci < 128) { sm1 |= bit; asm volatile("; mask 1"); }
         else if (ci < CS_LONG) { sm2 |= bit; asm volatile("; mask 2"); }
     };
+    // Where a start node sits in the contig's node list is a COUNT: nodes are in (position, strand) order, the stop node's index is
+    // known, and the bytes the walk reads anyway carry the node flags of EVERY position it passes, either strand (bits 4 and 5).
+    // A forward walk runs down from the stop: a start at x has index kstop - (nodes at positions x .. p - 1); a reverse walk runs up:
+    // index (nodes before p) + (nodes at p .. x) - 1, the reverse node of a position being its last.  kb = the count at the boundary
+    // of the group at hand, cnt = the nodes met inside it so far.  (Until round 5 the index came from GroupArrays::pre, one gather
+    // per start node asked for a group ahead: 14 % of the kernel.)
+    int kb = 0;
+    const int ksgn = fwd ? -1 : 1, koff = fwd ? 0 : -1;
     if (ncod > 0) {
         const int j = p + step; mer = hexamer(d, j, strand);
-        const bool isnode = o.node_at(j);
-        visit(0, isnode, isnode ? o.node_index(j) : 0);
+        unsigned w4; __builtin_memcpy(&w4, fwd ? d + (p - 3) : d + p, 4);      // positions p - 3 .. p (forward) / p .. p + 3 (reverse)
+        const int c012 = __popc(w4 & 0x00303030u);
+        // codon 0 at p - 3 (p + 3); the group behind it begins where it ends
+        int k0;
+        if (fwd) { k0 = o.kstop - c012; kb = k0; }
+        else { const int base = o.kstop - (int)((w4 >> 4) & 1u); k0 = base + c012 + (int)((w4 >> 28) & 1u); kb = base + __popc(w4 & 0x30303030u); }
+        const bool isnode = ((w4 >> (fwd ? 4 : 29)) & 1u) != 0;              // forward: byte 0 (p - 3), bit 4; reverse: byte 3 (p + 3), bit 5
+        visit(0, isnode, k0);
     }
     struct W16 { unsigned long long a, b; };
     auto group_lo = [&](const int c0) { return fwd ? p - 3 * (c0 + 5) : p + 3 * c0 + 1; };       // lowest position of the group
@@ -1094,18 +1109,11 @@ __device__ __forceinline__ void orf_serial_quad(const OrfCtx& o, const ChainDesc
     const int fbit = fwd ? 4 : 5;
     const int dsh = fwd ? 24 : 26, fsh = fwd ? 12 : 13;       // codon u: digits at bit dsh - 6u, flag at bit fsh - 3u
     const int foff0 = fwd ? 12 : 2, fstep = fwd ? -3 : 3;     // the flag's byte offset in the group as loaded: foff0 + fstep * u
+    const unsigned m3 = 0x00070007u << fsh;                   // the three positions of codon 0 in either half of (forward | reverse << 16) flags
     W16 D1{0, 0}, D2{0, 0};
-    int kq[5] = {0, 0, 0, 0, 0};
-    // prologue: the bytes of the first and of the second group; then the node indices of the first (a reverse node follows the
-    // forward node of its position: ff1 = the forward flags where the walk is a reverse one)
+    // prologue: the bytes of the first and of the second group
     if (ncod > 1 && group_lo(1) >= 0) __builtin_memcpy(&D1, d + group_lo(1), 16);
     if (ncod > 6 && group_lo(6) >= 0) __builtin_memcpy(&D2, d + group_lo(6), 16);
-    unsigned fb1 = flags_of(D1, fbit), ff1 = fwd ? 0u : flags_of(D1, 4);
-    if (ncod > 1 && group_lo(1) >= 0) {
-#pragma unroll
-        for (int u = 0; u < 5; u++)
-            if (1 + u < ncod && ((fb1 >> (fsh - 3 * u)) & 1u)) kq[u] = o.pre[group_lo(1) + foff0 + fstep * u] + (int)((ff1 >> (fsh - 3 * u)) & 1u);
-    }
     qmark(10);
     // the group counter is the same in every lane (scalar): a lane whose ORF has ended idles through the rest, loading nothing
     int ncod_max = ncod;
@@ -1125,29 +1133,22 @@ __device__ __forceinline__ void orf_serial_quad(const OrfCtx& o, const ChainDesc
             }
             continue;
         }
-        // everything of this group is here; ask for what the next groups need
-        const unsigned dg = digits_of(D1), fb = fb1;
-        int kc[5];
-#pragma unroll
-        for (int u = 0; u < 5; u++) kc[u] = kq[u] - o.tbase;
+        // everything of this group is here; ask for what the group after the next needs
+        const unsigned dg = digits_of(D1);
+        const unsigned f4 = flags_of(D1, 4), f5 = flags_of(D1, 5);
+        const unsigned fb = fwd ? f4 : f5, ff = f4 | (f5 << 16);
         D1 = D2;
-        fb1 = flags_of(D1, fbit); ff1 = fwd ? 0u : flags_of(D1, 4);
-        if (c0 + 5 < ncod) {
-            const int lo1 = group_lo(c0 + 5);
-            if (lo1 >= 0) {
-#pragma unroll
-                for (int u = 0; u < 5; u++)
-                    if (c0 + 5 + u < ncod && ((fb1 >> (fsh - 3 * u)) & 1u)) kq[u] = o.pre[lo1 + foff0 + fstep * u] + (int)((ff1 >> (fsh - 3 * u)) & 1u);
-            }
-            if (c0 + 10 < ncod) { const int lo2 = group_lo(c0 + 10); if (lo2 >= 0) __builtin_memcpy(&D2, d + lo2, 16); }
-        }
+        if (c0 + 10 < ncod) { const int lo2 = group_lo(c0 + 10); if (lo2 >= 0) __builtin_memcpy(&D2, d + lo2, 16); }
+        int cnt = 0;
 #pragma unroll
         for (int u = 0; u < 5; u++) {
             const int ci = c0 + u;
             // a codon past the ORF's end (last group only) still joins the sums, which nobody reads any more; it is no start node
             mer = ((mer << 6) & 0xfc0) | ((dg >> (dsh - 6 * u)) & 63u);
-            visit(ci, ci < ncod && ((fb >> (fsh - 3 * u)) & 1u), kc[u]);
+            cnt += __popc(ff & (m3 >> (3 * u)));                  // the nodes at the codon's three positions
+            visit(ci, ci < ncod && ((fb >> (fsh - 3 * u)) & 1u), kb + ksgn * cnt + koff);
         }
+        kb += ksgn * cnt;
     }
     qmark(11);
     if (far < 0) return;
@@ -1552,7 +1553,7 @@ k_coding_score_quads(const CsTask* __restrict__ tasks, const CsEntry* __restrict
             o.strand = ga.strand[tt];
             o.pre = ga.pre + en.base;
             o.tbase = en.tbase;
-            o.p = ga.ndx[tt]; o.q = ga.stop_val[tt]; o.L = en.len;
+            o.p = ga.ndx[tt]; o.q = ga.stop_val[tt]; o.L = en.len; o.kstop = tt - en.tbase;
             o.step = o.strand == 1 ? -3 : 3;
             o.ncod = o.cc.y <= 0 ? 0 : orf_codons(o.p, o.q, o.strand, o.L);
             return o;
