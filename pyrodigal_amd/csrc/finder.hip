@@ -159,6 +159,22 @@ extern "C" void pga_release_cached(void) {
     for (auto& b : g_cache[1]) hipHostFree(b.p);
     g_cache[0].clear(); g_cache[1].clear(); g_cached[0] = g_cached[1] = 0;
 }
+// An allocation that fails while blocks are parked here (a cached block only serves requests of about its own size) gets a second
+// try after the parked blocks of that kind have gone back to the runtime.
+template <class Alloc>
+static hipError_t alloc_or_evict(int kind, Alloc alloc) {
+    hipError_t e = alloc();
+    if (e != hipErrorOutOfMemory) return e;
+    (void)hipGetLastError();                          // the failed attempt is not this call's error
+    bool had;
+    {
+        std::lock_guard<std::mutex> g(g_cache_mu);
+        had = !g_cache[kind].empty();
+        for (auto& b : g_cache[kind]) { if (kind == 0) hipFree(b.p); else hipHostFree(b.p); }
+        g_cache[kind].clear(); g_cached[kind] = 0;
+    }
+    return had ? alloc() : e;
+}
 
 int ensure_dev(pga_ctx* c, const char* name, size_t bytes, void** out) {
     Buf& b = c->finder->dev[name];
@@ -167,7 +183,7 @@ int ensure_dev(pga_ctx* c, const char* name, size_t bytes, void** out) {
         // room to grow: the calls of a job are about the same size, so the big buffers get a sixteenth on top, the small ones a quarter
         size_t want = bytes + (bytes >= ((size_t)64 << 20) ? bytes / 16 : bytes / 4) + 256;
         b.p = cache_take(0, c->device, want, &want);
-        if (!b.p) HT(c, hipMalloc(&b.p, want));
+        if (!b.p) HT(c, alloc_or_evict(0, [&] { return hipMalloc(&b.p, want); }));
         b.cap = want;
     }
     *out = b.p;
@@ -179,7 +195,7 @@ int ensure_pin(pga_ctx* c, const char* name, size_t bytes, void** out) {
         if (b.p) { hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
         size_t want = bytes + bytes / 4 + 256;
         b.p = cache_take(1, c->device, want, &want);
-        if (!b.p) HT(c, hipHostMalloc(&b.p, want, hipHostMallocDefault));
+        if (!b.p) HT(c, alloc_or_evict(1, [&] { return hipHostMalloc(&b.p, want, hipHostMallocDefault); }));
         b.cap = want;
     }
     *out = b.p;
@@ -1544,6 +1560,11 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         if (use_sched) for (int g = 0; g < NG; g++) for (int i = 0; i < NC; i++)
             max_batches[g] = std::max(max_batches[g], h_bbase[(size_t)g * (NC + 1) + i + 1] - h_bbase[(size_t)g * (NC + 1) + i]);
         const bool segmented = stage == 0 && !use_wave && pga_dp_plan(chains.data(), NCH, tot_chain_nodes, seg_plan);
+        // lean: the tail runs on the device and nobody asked for node arrays, so only what the tail writes is gathered; direct: it
+        // also reads the winners' node fields where the scorers left them.  (One definition: the scorers skip the star_ptr fill under
+        // exactly the condition under which the tail never looks at it.)
+        const bool lean_gather = !P.want_nodes && !(getenv("PGA_TAIL") && strcmp(getenv("PGA_TAIL"), "host") == 0) && !getenv("PGA_FULL_GATHER");
+        const bool direct_gather = lean_gather && !getenv("PGA_GATHER_ALL_DP");
         const int64_t dp_cap = tot_chain_nodes + seg_plan.extra + 1;
         const int64_t dp_slots = NCH + (int64_t)seg_plan.segs.size() + 1;
         const int64_t tree_cap = use_wave ? 1 : dp_cap;          // records and far-field arrays of the tree / chain kernels
@@ -1598,11 +1619,18 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             // the same translation table) read the same topology arrays.  So every (contig, table) goes to ONE XCD -- the one with
             // the fewest nodes so far, in start order -- and workgroup 8 k + x takes the k-th chain of XCD x's queue; queues that end
             // early are filled up with -1 (the workgroup returns at once).  PGA_DP_XCD=0: the order as it is.
-            if (!(getenv("PGA_DP_XCD") && atoi(getenv("PGA_DP_XCD")) == 0) && NCH >= 64) {
+            // Only where the premise holds -- a device of eight XCDs (an MI355X in its default SPX mode; a partitioned one reports fewer) --
+            // and where the queues come out even: a handful of keys, or one contig far longer than the rest, would leave XCDs idle
+            // behind one long queue, and the plain longest-first order is the better one then.
+            static const int n_xcc = [] { int dev = 0, v = 0; (void)hipGetDevice(&dev); return (hipDeviceGetAttribute(&v, hipDeviceAttributeNumberOfXccs, dev) == hipSuccess && v > 0) ? v : 8; }();
+            if (!(getenv("PGA_DP_XCD") && atoi(getenv("PGA_DP_XCD")) == 0) && NCH >= 64 && n_xcc == 8) {
                 std::vector<int32_t> key((size_t)NCH), by_xcd((size_t)NCH * 8);
                 for (int k = 0; k < NCH; k++) key[(size_t)k] = chains[(size_t)k].group * NC + chains[(size_t)k].contig;
                 const int64_t nb = pga_dp_xcd_order(NCH, dp_order.data(), lens.data(), key.data(), NC * NG, by_xcd.data(), (int64_t)by_xcd.size());
-                if (nb > 0) { by_xcd.resize((size_t)nb); dp_order.swap(by_xcd); }
+                int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0}, total = 0, heaviest = 0;
+                for (int64_t k = 0; k < nb; k++) if (by_xcd[(size_t)k] >= 0) { load[k & 7] += lens[(size_t)by_xcd[(size_t)k]]; total += lens[(size_t)by_xcd[(size_t)k]]; }
+                for (int q = 0; q < 8; q++) heaviest = std::max(heaviest, load[q]);
+                if (nb > 0 && heaviest * 8 <= total + total * 3 / 10) { by_xcd.resize((size_t)nb); dp_order.swap(by_xcd); }       // within 1.3 x the mean
             }
             DEVBUF(d_ord, int32_t, "d_dp_order", dp_order.size() + 1);
             HT(c, hipMemcpyAsync(d_ord, dp_order.data(), sizeof(int32_t) * dp_order.size(), hipMemcpyHostToDevice, st));
@@ -1684,9 +1712,8 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                     HT(c, hipMemcpyAsync(h_scur + 2 * g, wgroups.g[g].scur, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
                 }
                 sl.topo_q2 = wgroups.g[g].q2; sl.ext = wbuf.ext; sp.cs_out = wbuf.cs;
-                // (the same condition as the lean gather's direct mode further down: the node arrays stay on the device)
-                sl.fill_star_ptr = !(stage == 0 && !P.want_nodes && !(getenv("PGA_TAIL") && strcmp(getenv("PGA_TAIL"), "host") == 0) &&
-                                     !getenv("PGA_FULL_GATHER") && !getenv("PGA_GATHER_ALL_DP"));
+                // (direct mode: the tail reads star_ptr only at the stop nodes, which k_ovl_stops always writes)
+                sl.fill_star_ptr = !(stage == 0 && direct_gather);
             }
             pga_launch_score(d_chains + g_c0[g], nch, g_n0[g], nn, d_dig, d_ct, ga[g], d_models, f->d_msc, c->d_model_const, ca, sp,
                              d_chains, d_cc + (size_t)g * NC, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], f->d_sd_lut, st, 0,
@@ -1866,7 +1893,6 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         // ---- gather the winners and bring them home ------------------------------------------------
         // the winners' final-pass fields only travel to the gathered arrays when somebody reads more of them than the two nodes
         // of every gene: the caller (node arrays) or the host tail's attribute fetch (PGA_FULL_GATHER=1 keeps the full gather: tests)
-        const bool lean_gather = !P.want_nodes && !(getenv("PGA_TAIL") && strcmp(getenv("PGA_TAIL"), "host") == 0) && !getenv("PGA_FULL_GATHER");
         std::vector<std::vector<WinDesc>> wg(NG);
         std::vector<int64_t> out_off(NC, 0);
         int64_t out_nodes = 0;
@@ -1911,7 +1937,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             OB(mot_ndx, int32_t) OB(rbs, uint8_t) OB(mot_len, uint8_t) OB(mot_spacer, uint8_t) OB(mot_spacendx, uint8_t)
         }
         // lean and the device tail: gather only what the tail writes
-        o.direct = (lean_gather && !getenv("PGA_GATHER_ALL_DP")) ? 1 : 0;
+        o.direct = direct_gather ? 1 : 0;
         for (int g = 0; g < 4; g++) {
             const bool in = g < NG;
             o.g_ndx[g] = in ? ga[g].ndx : nullptr; o.g_stop_val[g] = in ? ga[g].stop_val : nullptr;

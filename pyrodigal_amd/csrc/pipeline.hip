@@ -2270,8 +2270,8 @@ k_ovl_stops(const ChainDesc* __restrict__ chains, int n_chains, int64_t soff_beg
         const OvlChain C{ga.ndx + tb, ga.stop_val + tb, ga.type + tb, ga.strand + tb, ca.cscore + ch.off, ca.sscore + ch.off, ca.rscore + ch.off,
                          ca.uscore + ch.off, ch.n, css != nullptr ? css + ch.off : nullptr};
         overlapping_starts_of(C, i, mc, maxov, sp[0], sp[1], sp[2], ga.ovl_topo[sidx]);
-        ca.star_ptr[3 * g] = sp[0]; ca.star_ptr[3 * g + 1] = sp[1]; ca.star_ptr[3 * g + 2] = sp[2];
     }
+    ca.star_ptr[3 * g] = sp[0]; ca.star_ptr[3 * g + 1] = sp[1]; ca.star_ptr[3 * g + 2] = sp[2];      // (an edge stop: -1, never what an earlier call left there)
     if (ext != nullptr) {
         const DpwModel M{mc->st_wt, mc->negc, mc->igm};
         DpwExt e;
