@@ -20,17 +20,20 @@ import sys
 EXP = os.environ.get("DPW_EXP", "")          # timing experiments (results wrong): noop | nof3 | nor5 | nor3 | nopull
 
 # ---- fixed registers -------------------------------------------------------------------------------------------------------
+VB = int(os.environ.get("DPW_VBASE", "40"))          # the first of the thirty vector registers the statements name (v40 .. v69: with them at v64 .. v93 the
+                                                     # kernel spilled 36 bytes per lane at five waves per SIMD, here 12 -- 1.22 -> 1.19 ms per launch -- and could not be built for six)
+def _v(k, n=1): return "v%d" % (VB + k) if n == 1 else "v[%d:%d]" % (VB + k, VB + k + n - 1)
 PIN = {  # C variable -> pinned VGPRs (both blocks)
-    "LV": "v[64:65]", "LT": "v66", "X0": "v[68:69]", "X1": "v[70:71]", "X2": "v[72:73]",
+    "LV": _v(0, 2), "LT": _v(2), "X0": _v(4, 2), "X1": _v(6, 2), "X2": _v(8, 2),
 }
-PIN_WALK = {"SVL": "v[92:93]"}
-PIN_NEAR = {"NS": "v[82:83]", "NB": "v84", "NVM": "v85", "NX0": "v[86:87]", "NX1": "v[88:89]", "NX2": "v[90:91]"}
-VT = {"W": "v[74:75]", "W_lo": "v74", "W_hi": "v75", "TG": "v76", "A": "v77", "MV": "v[78:79]", "MV_lo": "v78", "MV_hi": "v79", "MI": "v80",
-      "LV_lo": "v64", "LV_hi": "v65", "X0_lo": "v68", "X0_hi": "v69", "X1_lo": "v70", "X1_hi": "v71", "X2_lo": "v72", "X2_hi": "v73",
-      "NS_lo": "v82", "NS_hi": "v83", "NX0_lo": "v86", "NX0_hi": "v87", "NX1_lo": "v88", "NX1_hi": "v89", "NX2_lo": "v90", "NX2_hi": "v91"}
-VT.update({"SVL_lo": "v92", "SVL_hi": "v93"})
+PIN_WALK = {"SVL": _v(28, 2)}
+PIN_NEAR = {"NS": _v(18, 2), "NB": _v(20), "NVM": _v(21), "NX0": _v(22, 2), "NX1": _v(24, 2), "NX2": _v(26, 2)}
+VT = {"W": _v(10, 2), "W_lo": _v(10), "W_hi": _v(11), "TG": _v(12), "A": _v(13), "MV": _v(14, 2), "MV_lo": _v(14), "MV_hi": _v(15), "MI": _v(16),
+      "LV_lo": _v(0), "LV_hi": _v(1), "X0_lo": _v(4), "X0_hi": _v(5), "X1_lo": _v(6), "X1_hi": _v(7), "X2_lo": _v(8), "X2_hi": _v(9),
+      "NS_lo": _v(18), "NS_hi": _v(19), "NX0_lo": _v(22), "NX0_hi": _v(23), "NX1_lo": _v(24), "NX1_hi": _v(25), "NX2_lo": _v(26), "NX2_hi": _v(27)}
+VT.update({"SVL_lo": _v(28), "SVL_hi": _v(29)})
 VT.update(PIN); VT.update(PIN_NEAR); VT.update(PIN_WALK)
-V_CLOBBER = ["v74", "v75", "v76", "v77", "v78", "v79", "v80"]
+V_CLOBBER = [_v(k) for k in range(10, 17)]
 def line_regs(base, slot):
     """names of a slot's words inside the sixteen scalar registers of a line from s<base> on: lane, s_ndx, code, j, m[0], m[1]; for a
     forward stop (slot 0 only, the whole line) four more masks behind them"""
@@ -496,11 +499,12 @@ def c_statement(near):
     s = ["#define %s() \\" % nm, "    asm volatile( \\"]
     for l in body:
         s.append('        "%s\\n\\t" \\' % l)
-    outs = ['"+{v[64:65]}"(a_lv)', '"+{v66}"(a_lt)', '"+{%s}"(a_ep)' % EP_REGS]
-    if not near: outs.append('"+{v[92:93]}"(a_sv)')
-    ins = ['"{v[68:69]}"(a_x0)', '"{v[70:71]}"(a_x1)', '"{v[72:73]}"(a_x2)']
+    outs = ['"+{%s}"(a_lv)' % PIN["LV"], '"+{%s}"(a_lt)' % PIN["LT"], '"+{%s}"(a_ep)' % EP_REGS]
+    if not near: outs.append('"+{%s}"(a_sv)' % PIN_WALK["SVL"])
+    ins = ['"{%s}"(a_x0)' % PIN["X0"], '"{%s}"(a_x1)' % PIN["X1"], '"{%s}"(a_x2)' % PIN["X2"]]
     if near:
-        ins += ['"{v[82:83]}"(a_ns)', '"{v84}"(a_nb)', '"{v85}"(a_nvm)', '"{v[86:87]}"(a_nx0)', '"{v[88:89]}"(a_nx1)', '"{v[90:91]}"(a_nx2)']
+        ins += ['"{%s}"(a_ns)' % PIN_NEAR["NS"], '"{%s}"(a_nb)' % PIN_NEAR["NB"], '"{%s}"(a_nvm)' % PIN_NEAR["NVM"], '"{%s}"(a_nx0)' % PIN_NEAR["NX0"],
+                '"{%s}"(a_nx1)' % PIN_NEAR["NX1"], '"{%s}"(a_nx2)' % PIN_NEAR["NX2"]]
     else:
         ins += ['[vm] "v"(a_vm)', '[tbnpre] "v"(a_tbnpre)', '[i0] "s"(a_i0)']
     ins += ['[ndx] "v"(a_ndx)', '[fbit] "v"(a_fbit)', '[cs] "v"(a_cs)', '[csd] "v"(a_csd)', '[negc] "v"(a_negc)', '[igmb] "s"(a_igmb)']
