@@ -583,9 +583,10 @@ k_dpw_sched(const int32_t* __restrict__ cbase, const int32_t* __restrict__ bbase
     }
 }
 
-// OCC: wavefronts per SIMD the register budget is cut for (PGA_DPW_OCC).  The kernel wants 103 VGPRs: 4 spills nothing (config 4:
-// 4.53 ms per launch, HBM traffic 1.55x the algorithmic bytes), 5 (the default) spills 16 bytes per lane (4.06 ms, 1.9x), 6 spills
-// 64 bytes (3.98 ms, 3.0x).  A chain's walk is a chain of dependent instructions: a fifth wavefront per SIMD fills its gaps.
+// OCC: wavefronts per SIMD the register budget is cut for (PGA_DPW_OCC).  k_dpw_dyn wants 103 VGPRs: 4 spills nothing, 5 (the default)
+// spills 16 bytes per lane, 6 spills 64 bytes (round 2, 12 500-contig launches: 4.53 / 4.06 / 3.98 ms at 1.55 / 1.9 / 3.0 x the algorithmic
+// HBM bytes).  A chain's walk is a chain of dependent instructions: a fifth wavefront per SIMD fills its gaps.  k_dp_wave (round 5, 6 250-contig
+// launches): 4: no scratch, 1.34 ms; 5: 12 bytes of scratch per lane, 1.19 ms; 6: 80 VGPRs and 72 bytes, 1.22 ms.
 template <int OCC>
 __global__ void __launch_bounds__(64, OCC)
 k_dpw_dyn(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const double* __restrict__ g_cs, const DpwExt* __restrict__ g_ext,
