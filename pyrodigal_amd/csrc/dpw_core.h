@@ -424,8 +424,8 @@ DPW_HD void dpw_step(const DpwS& S, const DpwLT& T, DpwLane& L, const DpwModel& 
 // ascending, in tiles of 64 nodes from jm on, one list per tile; then the batch's own nodes as sources, ascending, one more list.
 // Forward starts never step (a forward stop pulls the starts of its ORF, see `pull`).  An entry whose masks are all empty is left
 // out.  Layout: 32-byte slots, two to a 64-byte line; the walk takes a LINE per scalar load (s_load_dwordx16: the round trip
-// through the scalar cache is what a step waits for, so a load carries two steps), asks for line e + 1 before it looks at line e,
-// and finds no counter: a list starts on a line and ends with an END slot.
+// through the scalar cache is what a step waits for, so a load carries two steps), keeps lines in flight while it works on the ones at
+// hand (near lists: one and one; the batch's own list: two and two), and finds no counter: a list starts on a line and ends with an END slot.
 //   slot, 32 bytes:  lane (of the source inside its 64-node tile / inside the batch), s_ndx (its position),
 //                    code = kind | frame << 2 | 16 if not a reverse start | 64 (DPW_E_CLOSE); 16 alone = END, 48 = NOP (a pad), j (its chain index),
 //                    m[0], m[1]
