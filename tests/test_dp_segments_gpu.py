@@ -13,7 +13,7 @@ from tests.util import golden_path, read_fasta, synthetic_contig
 
 pytestmark = pytest.mark.gpu
 
-SEG_ENV = ("PGA_DP_SEG", "PGA_DP_SEG_MIN", "PGA_DP_SEG_LEN", "PGA_DP_SEG_WARM", "PGA_DP_SEG_SLOTS")
+SEG_ENV = ("PGA_DP_SEG", "PGA_DP_SEG_MIN", "PGA_DP_SEG_LEN", "PGA_DP_SEG_WARM", "PGA_DP_SEG_SLOTS", "PGA_DP_SEG_READBACK")
 
 
 @pytest.fixture(scope="module")
@@ -135,6 +135,20 @@ def test_find_genes_reports_segments_and_matches_serial(ctx):
         assert c2.dp_stats()["chains"] == 0
         assert a.genes.tobytes() == b.genes.tobytes() and len(a.genes) > 100
         assert np.array_equal(a.contigs["model"], b.contigs["model"])
+        # the finder reads the first round's verdict back and stops issuing rounds (round 5); the gated launches of all three rounds
+        # are the other way to the same result -- also when the first round rejects nodes (64-node warm-up) and the repair rounds run
+        for env in ({}, {"PGA_DP_SEG_MIN": "300", "PGA_DP_SEG_LEN": "2048", "PGA_DP_SEG_WARM": "64"}):
+            got = []
+            for readback in ("1", "0"):
+                os.environ.pop("PGA_DP_SEG", None)
+                os.environ.update(env)
+                os.environ["PGA_DP_SEG_READBACK"] = readback
+                r = c2.find_genes_batch([seq], meta=True)
+                got.append((r.genes.tobytes(), dict(c2.dp_stats())))
+            assert got[0][0] == got[1][0] == a.genes.tobytes()
+            assert got[0][1]["rejected"] == got[1][1]["rejected"] and got[0][1]["serial"] == got[1][1]["serial"]
+            if env:
+                assert sum(got[0][1]["rejected"]) > 0
     finally:
         c2.close()
 
