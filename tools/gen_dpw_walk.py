@@ -384,16 +384,14 @@ def block(near):
     return out
 
 
-NEAR_NOW = [None]       # which block is being substituted (the line sets differ)
-
-
-def subst(line):
+def subst(line, near):
+    """register names for the {NAME} / {NAME@set.slot} placeholders of a line of block `near` (the two blocks have different line sets)"""
     def rep(m):
         k = m.group(1)
         if "@" in k:
             nm, _, st = k.partition("@")
             h, _, sl = st.partition(".")
-            return line_regs(lbase(NEAR_NOW[0])[int(h)], int(sl))[nm]
+            return line_regs(lbase(near)[int(h)], int(sl))[nm]
         if k in VT: return VT[k]
         if k in ST: return ST[k]
         raise KeyError(k)
@@ -415,11 +413,10 @@ def regs_of(tok):
 
 
 def check(lines, name):
-    NEAR_NOW[0] = name == "near"
     ins = []
     labels = {}
     for l in lines:
-        l = subst(l)
+        l = subst(l, name == "near")
         if l.endswith(":"):
             labels[l[:-1]] = len(ins)
             continue
@@ -489,8 +486,7 @@ def check(lines, name):
 
 
 def statement(near):
-    NEAR_NOW[0] = near
-    return [subst(l) for l in block(near)]
+    return [subst(l, near) for l in block(near)]
 
 
 def c_statement(near):
