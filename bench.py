@@ -222,7 +222,7 @@ def main():
     ap.add_argument("--series", default="iid", choices=["iid", "planted"],
                     help="config4: i.i.d. bases (BASELINE.json's generator) or planted ORFs (SURVEY 8d's metagenome-like series)")
     ap.add_argument("--sub-batch", type=int, default=6_250, help="contigs per device call")
-    ap.add_argument("--contexts", type=int, default=8, help="device contexts (streams) the calls of a pass are dealt to")
+    ap.add_argument("--contexts", type=int, default=4, help="device contexts (streams) the calls of a pass are dealt to (four: DESIGN 5.1, round 5)")
     ap.add_argument("--gen-procs", type=int, default=0, help="worker processes generating the synthetic contigs (0: up to 32; 1: none, e.g. under rocprofv3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
@@ -460,7 +460,7 @@ def main():
         out["config"]["hbm_in_use_GB"] = round((total_b - free_b) / 1e9, 1)        # the contexts' buffers + the resident batches, at their peak
     except Exception:
         pass
-    # (the job's twelve contexts hold about 160 GB; the two workloads below add about 30 GB while they run.  Closing the job's
+    # (the job's contexts hold tens of GB -- 160 GB in round 3 --; the two workloads below add about 30 GB while they run.  Closing the job's
     # contexts first makes the FASTA pass that creates its contexts inside the timed region wait for 160 GB of frees.)
     if rank == 0 and world == 1 and not single and not args.no_secondary:
         fasta_line = fasta_to_genes(seqs[:min(len(seqs), 20000)], models, dev_index, kw)
