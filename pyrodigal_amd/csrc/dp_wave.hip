@@ -102,59 +102,87 @@ k_dpw_topo(const int32_t* __restrict__ ndx, const int32_t* __restrict__ stopv, c
 // dependent loads per node; from global memory the kernel above spends two thirds of its wave time waiting for them
 // (profiles/r04_c_config4_sq_counters.md).  One workgroup stages its contig's four node arrays (10 bytes per node) and runs the
 // very same routine (dpw_topo_node) on the LDS copies.
+// Round 5: each of the four kinds of node takes a path of its own through that routine, and 64 neighbouring nodes are a mix of all
+// four, so a wavefront ran every path at a quarter of its lanes.  The workgroup now lists its contig's nodes BY KIND first (two more
+// bytes of LDS per node) and walks the list: a wavefront's 64 nodes are of one kind except where two kinds meet.  The forward stops
+// find the next forward stop of every frame in bit masks over the WHOLE contig (one word per 64 nodes and frame, built once).
 constexpr int TOPO_LDS_NODES = 6144;
 __global__ void __launch_bounds__(256)
 k_dpw_topo_lds(const int32_t* __restrict__ ndx, const int32_t* __restrict__ stopv, const uint8_t* __restrict__ type, const int8_t* __restrict__ strand,
                const int32_t* __restrict__ cbase, DpwTopoArrays ta) {
     extern __shared__ int s_topo[];
-    __shared__ unsigned long long s_m[3][TOPO_WORDS];
-    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ unsigned long long s_m[3][TOPO_LDS_NODES / 64];
+    __shared__ int s_cnt[4];
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int b0 = cbase[c], n = cbase[c + 1] - b0;
     if (n <= 0) return;
     int32_t* const l_ndx = s_topo; int32_t* const l_stop = s_topo + n;
     uint8_t* const l_type = (uint8_t*)(s_topo + 2 * n); int8_t* const l_strand = (int8_t*)(l_type + n);
+    uint16_t* const l_perm = (uint16_t*)(s_topo + 2 * n + ((2 * n + 3) >> 2));      // behind the two byte arrays, 4-byte aligned
+    if (tid < 4) s_cnt[tid] = 0;
     for (int i = tid; i < n; i += 256) { l_ndx[i] = ndx[b0 + i]; l_stop[i] = stopv[b0 + i]; l_type[i] = type[b0 + i]; l_strand[i] = strand[b0 + i]; }
     __syncthreads();
-    for (int i0 = 0; i0 < n; i0 += 256) {
-        // the forward stops of the block and of the 192 nodes behind it, by frame, as bit masks (see k_dpw_topo)
-        auto flags = [&](const int idx, const int word) {
-            const bool in = idx < n;
-            const bool f3 = in && l_type[in ? idx : 0] == 3 && l_strand[in ? idx : 0] == 1;
-            const int fr = in ? l_ndx[idx] % 3 : 0;
+    // the forward stops of the contig by frame as bit masks, and how many nodes of each kind there are
+    const int n_round = (n + 255) & ~255;
+    for (int i = tid; i < n_round; i += 256) {
+        const bool in = i < n;
+        const bool rev = in && l_strand[in ? i : 0] != 1, stop = in && l_type[in ? i : 0] == 3;
+        const int fr = in ? l_ndx[i] % 3 : 0;
+        const bool f3 = in && stop && !rev;
 #pragma unroll
-            for (int f = 0; f < 3; f++) { const unsigned long long m = __ballot(f3 && fr == f); if (lane == 0) s_m[f][word] = m; }
-        };
-        flags(i0 + tid, wave);
-        if (wave < TOPO_AHEAD / 64) flags(i0 + 256 + tid, 4 + wave);
-        __syncthreads();
-        const int i = i0 + tid;
-        if (i < n) {
-            DpwF3Hint hint{0, 0};
-            bool have = false;
-            if (l_type[i] == 3 && l_strand[i] == 1) {
-                const int k = tid, my_ndx = l_ndx[i];
-                const bool covered = i0 + 64 * TOPO_WORDS >= n;       // the masks reach the end of the contig
-                int q2 = n; have = true;
+        for (int f = 0; f < 3; f++) { const unsigned long long m = __ballot(f3 && fr == f); if (lane == 0) s_m[f][i >> 6] = m; }
 #pragma unroll
-                for (int f = 0; f < 3; f++) {
-                    int j = -1;
-                    for (int w = (k + 1) >> 6; w < TOPO_WORDS && j < 0; w++) {
-                        unsigned long long m = s_m[f][w];
-                        if (w == (k + 1) >> 6) m &= ~0ull << ((k + 1) & 63);
-                        if (m) j = i0 + 64 * w + __builtin_ctzll(m);
-                    }
-                    if (j < 0) { if (!covered) have = false; continue; }
-                    if (j >= n) continue;                              // the frame has no forward stop behind this one on the contig
-                    q2 = min(q2, j);
-                    if (l_stop[j] < my_ndx) hint.bits |= 1 << (4 + f);  // inside that stop's ORF: an operon candidate for it
-                }
-                hint.q2 = q2;
-            }
-            const DpwTopo t = dpw_topo_node(l_ndx, l_stop, l_type, l_strand, n, i, have ? &hint : nullptr);
-            const int g = b0 + i;
-            ta.kf[g] = t.kf; ta.lo[g] = t.lo; ta.q1[g] = t.q1; ta.q2[g] = t.q2;
+        for (int k = 0; k < 4; k++) {
+            const unsigned long long m = __ballot(in && ((rev ? 2 : 0) | (stop ? 1 : 0)) == k);
+            if (lane == 0 && m) atomicAdd(&s_cnt[k], __popcll(m));
         }
-        __syncthreads();
+    }
+    __syncthreads();
+    // list position of every node: its kind's range, in any order inside it (a node's result does not depend on the others')
+    const int c0 = s_cnt[0], c1 = s_cnt[1], c2 = s_cnt[2];
+    __syncthreads();
+    if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = c0; s_cnt[2] = c0 + c1; s_cnt[3] = c0 + c1 + c2; }
+    __syncthreads();
+    for (int i = tid; i < n_round; i += 256) {
+        const bool in = i < n;
+        const bool rev = in && l_strand[in ? i : 0] != 1, stop = in && l_type[in ? i : 0] == 3;
+        const int kind = (rev ? 2 : 0) | (stop ? 1 : 0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned long long m = __ballot(in && kind == k);
+            if (!m) continue;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_cnt[k], __popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (in && kind == k) l_perm[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
+        }
+    }
+    __syncthreads();
+    const int n_words = (n + 63) >> 6;
+    for (int p = tid; p < n; p += 256) {
+        const int i = l_perm[p];
+        DpwF3Hint hint{0, 0};
+        bool have = false;
+        if (l_type[i] == 3 && l_strand[i] == 1) {
+            const int my_ndx = l_ndx[i];
+            int q2 = n; have = true;
+#pragma unroll
+            for (int f = 0; f < 3; f++) {
+                int j = -1;
+                for (int w = (i + 1) >> 6; w < n_words && j < 0; w++) {
+                    unsigned long long m = s_m[f][w];
+                    if (w == (i + 1) >> 6) m &= ~0ull << ((i + 1) & 63);
+                    if (m) j = 64 * w + __builtin_ctzll(m);
+                }
+                if (j < 0) continue;                                   // the frame has no forward stop behind this one on the contig
+                q2 = min(q2, j);
+                if (l_stop[j] < my_ndx) hint.bits |= 1 << (4 + f);      // inside that stop's ORF: an operon candidate for it
+            }
+            hint.q2 = q2;
+        }
+        const DpwTopo t = dpw_topo_node(l_ndx, l_stop, l_type, l_strand, n, i, have ? &hint : nullptr);
+        const int g = b0 + i;
+        ta.kf[g] = t.kf; ta.lo[g] = t.lo; ta.q1[g] = t.q1; ta.q2[g] = t.q2;
     }
 }
 __global__ void __launch_bounds__(256)
@@ -1182,7 +1210,7 @@ void pga_launch_dpw_topo(const DpwTopoArrays& ta, const uint8_t* type, const int
     // contigs that fit: a workgroup per contig on LDS copies of its node arrays (PGA_DPW_TOPO_LDS=0: the per-node kernel on global memory)
     const bool lds = max_contig_nodes > 0 && max_contig_nodes <= TOPO_LDS_NODES && !walk && !(getenv("PGA_DPW_TOPO_LDS") && atoi(getenv("PGA_DPW_TOPO_LDS")) == 0);
     if (lds) {
-        hipLaunchKernelGGL(k_dpw_topo_lds, dim3((unsigned)n_contigs), dim3(256), (size_t)10 * max_contig_nodes + 16, st, ta.ndx, ta.stop_val, type, strand, d_cbase, ta);
+        hipLaunchKernelGGL(k_dpw_topo_lds, dim3((unsigned)n_contigs), dim3(256), (size_t)12 * max_contig_nodes + 32, st, ta.ndx, ta.stop_val, type, strand, d_cbase, ta);
         return;
     }
     hipLaunchKernelGGL(k_dpw_topo, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, st, ta.ndx, ta.stop_val, type, strand, d_cbase,
