@@ -1523,6 +1523,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             const int64_t n = group_nodes[g] + 1;
             GBUF(ndx, int32_t, n) GBUF(stop_val, int32_t, n) GBUF(type, uint8_t, n) GBUF(strand, int8_t, n) GBUF(edge0, uint8_t, n) GBUF(gc_cont, float, n) GBUF(contig_of, int32_t, n)
             GBUF(stop_list, int32_t, (int64_t)h_sbase[(size_t)g * (NC + 1) + NC] + 1)
+            GBUF(start_list, int32_t, group_nodes[g] - (int64_t)h_sbase[(size_t)g * (NC + 1) + NC] + 1)
             GBUF(ovl_topo, uint32_t, (int64_t)h_sbase[(size_t)g * (NC + 1) + NC] + 1)
             GBUF(srank, int32_t, n + 4)
         }
@@ -1702,6 +1703,9 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             StopLaunch sl;
             sl.sbase = d_sbase + (size_t)g * (NC + 1); sl.soff_begin = g_s0[g]; sl.n_pairs = g_s0[g + 1] - g_s0[g];
             sl.n_stops = h_sbase[(size_t)g * (NC + 1) + NC];
+            // (the path proper; a stage-level call returns the node arrays after any stage, so there every node keeps its thread)
+            sl.starts_only = stage == 0 && !(getenv("PGA_SS_STARTS_ONLY") && atoi(getenv("PGA_SS_STARTS_ONLY")) == 0);
+            sl.n_starts = (int32_t)(group_nodes[g] - sl.n_stops);
             sp.cs_out = nullptr;
             if (use_wave) {
                 int max_nodes_g = 0;

@@ -32,6 +32,7 @@ struct GroupArrays {
     uint8_t* st_info;                        // type | edge << 2 | reverse << 3
     int32_t st_half = 0; int32_t* st_overflow = nullptr;
     int32_t* stop_list;                      // the stop nodes of the group in node order (node indices); contig c owns [sbase[c], sbase[c + 1])
+    int32_t* start_list = nullptr;           // the other nodes of the group in node order (k_place_nodes; nullptr: not wanted): the start scorer's work list
     uint32_t* ovl_topo;                      // per entry of stop_list: which of its first 16 neighbours can be overlapping starts (k_ovl_topo)
     int32_t* srank = nullptr;                // per node, written for stop nodes only: its rank among the stop nodes of its contig (k_ovl_topo):
                                              // the k-th stop of a chain owns extras record ChainDesc::soff + k of the wave-batch scorer
@@ -102,6 +103,9 @@ struct StopLaunch {
     // star_ptr of the nodes that are no stop nodes is -1: the launcher fills the chains' range first -- unless nobody will read it
     // (the wave-batch scorer takes the extras, the tail asks for stop nodes only, the caller does not want the node arrays)
     bool fill_star_ptr = true;
+    // the start scorer runs over ga.start_list (n_starts entries) instead of over every node (its workgroups clear the fields of the
+    // stop nodes between their start nodes at the end)
+    bool starts_only = false; int32_t n_starts = 0;
 };
 // per (group, contig): is any model of the group inside the contig's GC window?  (meta mode)
 void pga_launch_group_enable(const ContigDesc* d_ct, int n_contigs, const int32_t* d_gc_count, const double* d_model_gc,

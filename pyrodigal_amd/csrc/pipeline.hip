@@ -699,6 +699,7 @@ k_place_nodes(const ContigDesc* __restrict__ ct, const TileDesc* __restrict__ ti
     const int64_t s0 = ga.st_half ? ((base + td.start) >> ga.st_half) + (int64_t)PGA_STAGE_SLACK * blockIdx.x : 2 * (base + td.start);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int srun = tile_soff[blockIdx.x];                       // next free entry of the stop list
+    const int start0 = off - srun;                          // start nodes before this tile = nodes before it - stop nodes before it
     for (int j0 = 0; j0 < cnt; j0 += 128) {
         const int j = j0 + threadIdx.x;
         bool is_stop = false;
@@ -715,7 +716,9 @@ k_place_nodes(const ContigDesc* __restrict__ ct, const TileDesc* __restrict__ ti
         const unsigned long long bal = __ballot(is_stop);
         if (lane == 0) s_w[wv] = __popcll(bal);
         __syncthreads();
-        if (is_stop) ga.stop_list[srun + (wv ? s_w[0] : 0) + __popcll(bal & ((1ull << lane) - 1ull))] = k;
+        const int stops_before = srun + (wv ? s_w[0] : 0) + __popcll(bal & ((1ull << lane) - 1ull));      // stop-list entries before node j
+        if (is_stop) ga.stop_list[stops_before] = k;
+        else if (j < cnt && ga.start_list != nullptr) ga.start_list[start0 + j - (stops_before - tile_soff[blockIdx.x])] = k;
         srun += s_w[0] + s_w[1];
         __syncthreads();
     }
@@ -1792,7 +1795,12 @@ __global__ void __launch_bounds__(256, OCC)
 k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ contig_chains,
                const int32_t* __restrict__ node_contig_base, int n_contigs, int n_nodes,
                const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct, GroupArrays ga,
-               const pga_training* __restrict__ models, ChainArrays ca, ScoreParams sp, const unsigned* __restrict__ sd_lut) {
+               const pga_training* __restrict__ models, ChainArrays ca, ScoreParams sp, const unsigned* __restrict__ sd_lut,
+               const int32_t* __restrict__ start_list /* or nullptr */, const int n_items) {
+    // start_list: a thread per START node of the group (n_items of them; GroupArrays::start_list) instead of a thread per node.  A
+    // stop node only gets its fields zeroed, and on sequence with short ORFs nearly half of the nodes are stop nodes: with a thread per
+    // node every wavefront dragged them through the model loop, and the kernel's time is its workgroup count times the latency of
+    // that loop.  The stop nodes' zeros are written by the workgroup at the end, a thread per node of its range (see there).
     __shared__ unsigned long long s_present[SS_MASK_WORDS];
     __shared__ unsigned s_lut[PGA_SD_LUT];
     __shared__ int2 s_edge[SS_EDGE_CONTIGS][2 * SS_EDGE_SPAN];
@@ -1812,16 +1820,18 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
     };
     const int tid = threadIdx.x;
     const int blk0 = blockIdx.x * blockDim.x;
-    const int t = blk0 + tid;
+    const bool listed = start_list != nullptr;
+    const int n_work = listed ? n_items : n_nodes;
+    const bool in_range = blk0 + tid < n_work;
+    const int t = listed ? start_list[min(blk0 + tid, n_work - 1)] : blk0 + tid;       // the node this thread scores
     const bool closed = sp.closed != 0, is_meta = sp.is_meta != 0;
     if (tid < SS_MASK_WORDS) s_present[tid] = 0ull;
-    const bool in_range = t < n_nodes;
-    const int c0 = ga.contig_of[blk0];                   // blk0 < n_nodes; the same address in every thread
+    const int c0 = ga.contig_of[listed ? start_list[blk0] : blk0];                     // blk0 < n_work; the same address in every thread
     const int c = in_range ? ga.contig_of[t] : c0;
     const int2 cc = in_range ? contig_chains[c] : make_int2(0, 0);
     const bool has = in_range && cc.y > 0;
     // (the model set is empty from here on)  A launch over the re-scored winners finds most workgroups without a chain.
-    if (!__syncthreads_or(has)) return;
+    if (!__syncthreads_or(has) && !listed) return;      // (with a work list the workgroup still has the stop nodes of its range to clear)
     for (int k = tid; k < PGA_SD_LUT; k += blockDim.x) s_lut[k] = sd_lut[k];
     // the thread's next chain (what the scorer reads of its descriptor), fetched one model ahead
     int64_t ch_off = 0, ch_raw = -1; int ch_model = 0x7fffffff, ch_first = 0;
@@ -1833,8 +1843,11 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
     const int e0 = has ? ga.edge0[t] : 0;
     const bool is_start = has && type != PGA_T_STOP;
     // the models the workgroup scores, as a bit set (models [mb, mb + 512)): the first thread of every contig enters its chains
+    // (with a work list the first node of a contig may be a stop node: there the thread whose neighbour sits on another contig enters)
+    const int c_prev = __shfl_up(c, 1, 64);
+    const bool enters = has && (listed ? ((tid & 63) == 0 || c != c_prev) : (tid == 0 || i == 0));
     auto enter_models = [&](const int mb) {
-        if (!(has && (tid == 0 || i == 0))) return;
+        if (!enters) return;
         for (int m = 0; m < cc.y; m++) {
             const int rel = chains[cc.x + m].model - mb;
             if (rel >= 0 && rel < sp.models_per_pass) atomicOr(&s_present[rel >> 6], 1ull << (rel & 63));
@@ -2091,6 +2104,7 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
         ca.edge[g] = (uint8_t)edge_now;
         if (sp.cs_out != nullptr) sp.cs_out[g] = cscore + sscore;
                 }
+
             }
             mark(8, true);
             if (nrel >= 0) stage_store(mb + nrel, RN, SMB[buf ^ 1]);
@@ -2106,6 +2120,28 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
         __syncthreads();
         enter_models(mb);
         __syncthreads();
+    }
+    // (listed) The stop nodes: no start scores (reset_node_scores), in every chain of their contig.  The workgroup answers for the nodes
+    // behind the last start node of the workgroup before it up to its own last start node (the last workgroup: to the end), its
+    // threads take them in node order -- the same stores the stop nodes' own threads made when every node had one, without the trip
+    // through the model loop.
+    if (listed) {
+        const int z0 = blk0 == 0 ? 0 : start_list[blk0 - 1] + 1;
+        const int z1 = blk0 + 256 >= n_work ? n_nodes : start_list[blk0 + 255] + 1;
+        for (int z = z0 + tid; z < z1; z += 256) {
+            if (ga.type[z] != PGA_T_STOP) continue;
+            const int cz = ga.contig_of[z];
+            const int2 zc = contig_chains[cz];
+            const int zb = node_contig_base[cz];
+            const uint8_t ez = ga.edge0[z];
+            for (int m = 0; m < zc.y; m++) {
+                const int64_t gz = chains[zc.x + m].off + (z - zb);
+                ca.edge[gz] = ez;
+                ca.cscore[gz] = 0.0; ca.sscore[gz] = 0.0; ca.rscore[gz] = 0.0; ca.uscore[gz] = 0.0; ca.tscore[gz] = 0.0; ca.mot_score[gz] = 0.0;
+                ca.mot_ndx[gz] = 0; ca.mot_len[gz] = 0; ca.mot_spacer[gz] = 0; ca.mot_spacendx[gz] = 0; ca.rbs[2 * gz] = 0; ca.rbs[2 * gz + 1] = 0;
+                if (sp.cs_out != nullptr) sp.cs_out[gz] = 0.0;
+            }
+        }
     }
 }
 
@@ -2518,8 +2554,11 @@ void pga_launch_score(const ChainDesc* d_chains, int n_chains, int64_t node_begi
             sp.prof = d_prof;
         }
         // (a fifth wavefront per SIMD costs 96 bytes of scratch per lane and 10 % of the kernel's time: four)
-        hipLaunchKernelGGL(k_score_starts<4>, dim3(nblocks(group_nodes, 256)), blk, 0, st, d_all_chains, d_contig_chains, d_node_contig_base, n_contigs,
-                           group_nodes, d_dig, d_ct, ga, d_models, ca, sp, d_sd_lut);
+        const bool listed = stops != nullptr && stops->starts_only && ga.start_list != nullptr;
+        const int n_items = listed ? stops->n_starts : group_nodes;
+        if (n_items > 0)
+            hipLaunchKernelGGL(k_score_starts<4>, dim3(nblocks(n_items, 256)), blk, 0, st, d_all_chains, d_contig_chains, d_node_contig_base, n_contigs,
+                               group_nodes, d_dig, d_ct, ga, d_models, ca, sp, d_sd_lut, listed ? (const int32_t*)ga.start_list : (const int32_t*)nullptr, n_items);
         if (ss_profiling) {
             unsigned long long h[16];
             (void)hipStreamSynchronize(st);
