@@ -57,8 +57,10 @@ def test_dp_kernels_and_tails_agree_on_random_gene_dense_contigs(monkeypatch):
                       ("wave+topoglobal", {"PGA_DP_KERNEL": "wave", "PGA_DPW_TOPO_LDS": "0"}),
                       ("tree+globalcs", {"PGA_CS_LDS": "0"}), ("scan+globalcs", {"PGA_DP_KERNEL": "scan", "PGA_TAIL": "host", "PGA_CS_LDS": "0"}),
                       # the start scorer walking a workgroup's models three to a pass (its path for more than 512 models)
-                      ("tree+3models/pass", {"PGA_SS_MODELS_PER_PASS": "3"})):
-        for k in ("PGA_DP_KERNEL", "PGA_TAIL", "PGA_CS_LDS", "PGA_SS_MODELS_PER_PASS", "PGA_DPW_TOPO_WALK", "PGA_DPW_SCHED", "PGA_DPW_TOPO_LDS"):
+                      ("tree+3models/pass", {"PGA_SS_MODELS_PER_PASS": "3"}),
+                      # the start scorer with a thread per node (what stage-level calls run) instead of over the list of start nodes
+                      ("wave+thread-per-node", {"PGA_DP_KERNEL": "wave", "PGA_SS_STARTS_ONLY": "0"})):
+        for k in ("PGA_DP_KERNEL", "PGA_TAIL", "PGA_CS_LDS", "PGA_SS_MODELS_PER_PASS", "PGA_DPW_TOPO_WALK", "PGA_DPW_SCHED", "PGA_DPW_TOPO_LDS", "PGA_SS_STARTS_ONLY"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -75,11 +77,11 @@ def test_dp_kernels_and_tails_agree_on_random_gene_dense_contigs(monkeypatch):
             for f in ("cscore", "rscore", "uscore", "tscore"):
                 assert np.array_equal(a[f].view(np.uint64), b[f].view(np.uint64)), (name, f)
     # without the node arrays the winners are gathered without their final-pass fields and the gene records fetch them per gene
-    for k in ("PGA_DP_KERNEL", "PGA_TAIL", "PGA_CS_LDS", "PGA_SS_MODELS_PER_PASS", "PGA_DPW_TOPO_WALK", "PGA_DPW_SCHED", "PGA_DPW_TOPO_LDS"):
+    for k in ("PGA_DP_KERNEL", "PGA_TAIL", "PGA_CS_LDS", "PGA_SS_MODELS_PER_PASS", "PGA_DPW_TOPO_WALK", "PGA_DPW_SCHED", "PGA_DPW_TOPO_LDS", "PGA_SS_STARTS_ONLY"):
         monkeypatch.delenv(k, raising=False)
     assert ctx.find_genes_batch(seqs, meta=True).genes.tobytes() == base.genes.tobytes()
     # single mode with masking as well
-    for k in ("PGA_DP_KERNEL", "PGA_TAIL", "PGA_CS_LDS", "PGA_SS_MODELS_PER_PASS", "PGA_DPW_TOPO_WALK", "PGA_DPW_SCHED", "PGA_DPW_TOPO_LDS"):
+    for k in ("PGA_DP_KERNEL", "PGA_TAIL", "PGA_CS_LDS", "PGA_SS_MODELS_PER_PASS", "PGA_DPW_TOPO_WALK", "PGA_DPW_SCHED", "PGA_DPW_TOPO_LDS", "PGA_SS_STARTS_ONLY"):
         monkeypatch.delenv(k, raising=False)
     ctx.set_models(models[7:8])
     s1 = ctx.find_genes_batch(seqs, meta=False, mask=True, closed=True)
