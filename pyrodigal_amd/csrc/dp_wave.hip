@@ -431,17 +431,18 @@ __device__ __forceinline__ void wave_step(const SrcRegs& R, const int u, const i
 
 
 // ------------------------------------------------------------------------------------------------------------------------
-// The step schedule of a group (dpw_core.h "Step schedule"): for every 64-node batch of a contig, which sources take a pair step
-// onto it and which lanes each of them can reach -- once per (contig, translation table) instead of once per step of every model's
-// chain.  One workgroup per contig (and per run of 16 batches of a long one), a wavefront per batch; batch g of the group owns the
-// DPW_SCHED_STRIDE slots from g * DPW_SCHED_STRIDE on, so nothing is counted, searched or handed out by an atomic (the first
-// form took one counter for the launch: 70 000 atomics on one address were two thirds of a millisecond).  A batch whose entries
-// (bounded by its kinds alone) do not fit is marked and counted in scur[1], and the launch then falls back to k_dpw_dyn.
-// The lane masks are the tests of dpw_static_bits (dpw_core.h; the host model builds its entries with that function and the two are
-// compared through the kernels' results), taken apart by source kind so that a source costs a few vector compares: per batch the
-// kinds / frames of the targets are lane masks in scalar registers, a source contributes one compare per position test.
+// The step schedule of a group (dpw_core.h "Step schedule"): which lanes of its own 64-node batch, and of the batch behind it, a
+// node reaches as the source of a pair step -- once per (contig, translation table) instead of once per step of every model's chain.
+// Round 6: per NODE four 64-bit words (32 bytes: W0, W1 towards its own batch, N0, N1 towards the next one) that k_dp_wave's lanes
+// load with two coalesced 16-byte reads; no lists, no slots, nothing that the walk has to fetch.  One workgroup per contig (and per
+// run of 16 batches of a long one), a wavefront per four batches; batch g of the group owns the 64 records from 64 g on.  The wave of
+// batch g writes the W words of its own nodes and the N words of the nodes of batch g - 1 (the near sources: from the earliest p_near
+// of a gene begin of the batch on; they must all lie in the batch before -- else the batch is marked, counted in scur[1], and the
+// launch falls back to k_dpw_dyn: never on sequence, forced in the tests).
+// The lane masks are the tests of dpw_static_bits (dpw_core.h; the host model builds its words with that function and the two are
+// compared through the kernels' results), taken apart by source kind so that a source costs a few vector compares.
 __global__ void __launch_bounds__(256)
-k_dpw_sched(const int32_t* __restrict__ cbase, const int32_t* __restrict__ bbase, const DpwTopoArrays ta, const int force_miss /* tests: every batch reports that it did not fit */) {
+k_dpw_sched(const int32_t* __restrict__ cbase, const int32_t* __restrict__ bbase, const DpwTopoArrays ta, const int force_miss /* tests: every batch reports a miss */) {
     __shared__ int s_nd[4][64];                     // per wavefront: the positions of its batch's nodes (ascending with the lane)
     const int c = blockIdx.x, lane = threadIdx.x & 63;
     const int base = cbase[c], n = cbase[c + 1] - base;
@@ -449,7 +450,6 @@ k_dpw_sched(const int32_t* __restrict__ cbase, const int32_t* __restrict__ bbase
     const int32_t* __restrict__ ndx = ta.ndx + base; const int32_t* __restrict__ stopv = ta.stop_val + base;
     const uint8_t* __restrict__ kfp = ta.kf + base;
     const int bb0 = bbase[c];
-    const lanemask me = 1ull << lane, below = me - 1ull;
     for (int bi = b; bi < b + 4 && (bi << 6) < n; bi++) {
         const int i0 = bi << 6, bg = bb0 + bi;
         const int i = i0 + lane;
@@ -463,89 +463,54 @@ k_dpw_sched(const int32_t* __restrict__ cbase, const int32_t* __restrict__ bbase
         const lanemask fr0 = vote(frame == 0), fr1 = vote(frame == 1), fr2 = vote(frame == 2);
         const lanemask gbm = k0 | k3;
         const int jm = wave_min_i32((kind == 0 || kind == 3) ? max(ta.q1[base + ii], t_lo) : i0);
+        if (jm < i0 - 64 || force_miss) {
+            if (lane == 0) { atomicAdd(&ta.scur[1], 1u); ta.shdr[bg] = DpwSchedHdr{DPW_SCHED_NONE, 0u, jm, 0}; }
+            continue;
+        }
         // per-lane constants of the position tests (dpw_st / dpw_static_bits)
         const int key_r5 = kind == 3 ? t_ndx - 2 : t_ndx;                     // a reverse start precedes this gene begin when s_ndx < key_r5
         int dlo0 = INT_MAX, dhi0 = INT_MIN;
         if (kind == 2) { dlo0 = t_stop - 4; dhi0 = min(t_stop + DPW_MAX_OPP_OVLP - 5, (t_ndx + t_stop + 4) >> 1); }
-        // slots: an upper bound from the kinds alone (a reverse node one slot; a forward stop a line and perhaps a pad; END, and the
-        // rest of its line)
-        const lanemask own = k1 | k2 | k3;
-        unsigned ub = __popcll(own) + 2 * __popcll(k1) + 2;
-        for (int t0 = jm; t0 < i0; t0 += 64) {
-            const int j = t0 + lane;
-            const int k = j < i0 ? DPW_KIND(kfp[j]) : 0;
-            ub += __popcll(vote(k != 0)) + 2 * __popcll(vote(k == 1)) + 2;
-        }
-        if (ub > DPW_SCHED_STRIDE || force_miss) {
-            if (lane == 0) { atomicAdd(&ta.scur[1], 1u); ta.shdr[bg] = DpwSchedHdr{DPW_SCHED_NONE, 0u, jm, 0}; }
-            continue;
-        }
-        const unsigned off = (unsigned)bg * DPW_SCHED_STRIDE;
-        uint4* const out0 = ta.sent + 2 * (size_t)off;                       // 32-byte slots
-        unsigned slot = 0;
-        // one source; `win`: the lanes whose window holds it and that lie behind it.  Returns 1 when an entry was written.
-        auto emit = [&](const int j, const int u, const int ukf, const int s_ndx, const int s_stop, const lanemask win, const bool in_batch) -> int {      // (in_batch: always written)
+        // the words of one source (wave-uniform): r0 = every lane it reaches, by any relation (+ the forward starts a forward stop of the
+        // batch pulls), r1 = the lanes whose distance term comes from the table.  `win`: the lanes whose window holds it and that lie behind it.
+        auto words = [&](const int u, const int ukf, const int s_ndx, const int s_stop, const lanemask win, const bool in_batch, lanemask& r0, lanemask& r1) {
             const int sk = DPW_KIND(ukf), sf = DPW_FRAME(ukf);
-            lanemask m0, m1, m2 = 0, m3 = 0, m4 = 0, m5 = 0;
-            bool close = false;             // some lane of m1 lies within OPER_DIST bases: its distance term comes from the table
             if (sk == 2) {
-                m0 = win & gbm & vote(s_ndx < key_r5);
-                if (!m0) return 0;
-                m1 = m0 & k3 & vote(t_ndx - s_ndx <= 3 * DPW_OPER_DIST);
-                close = (m1 & vote(t_ndx - s_ndx <= DPW_OPER_DIST)) != 0;
+                r0 = win & gbm & vote(s_ndx < key_r5);
+                r1 = r0 & k3 & vote(t_ndx - s_ndx <= 3 * DPW_OPER_DIST);
             } else if (sk == 3) {
-                const lanemask in_orf = win & vote(s_stop > t_ndx);
-                m0 = in_orf & k2 & pick3m(sf, fr0, fr1, fr2);
-                m1 = in_orf & k3;
-                if (!(m0 | m1)) return 0;
+                r0 = win & vote(s_stop > t_ndx) & ((k2 & pick3m(sf, fr0, fr1, fr2)) | k3);
+                r1 = 0;
             } else {
-                m0 = win & k0 & vote(s_ndx + 2 < t_ndx);
-                m1 = m0 & vote(t_ndx - s_ndx <= 3 * DPW_OPER_DIST);
-                close = (m1 & vote(t_ndx - s_ndx <= DPW_OPER_DIST)) != 0;
-                m2 = win & k1 & vote(t_stop < s_ndx);
-                m3 = win & k2 & vote((s_ndx > dlo0) & (s_ndx < dhi0));
-                m4 = win & k3 & vote(s_ndx < t_ndx - 4);
-                if (in_batch) m5 = k0 & pick3m(sf, fr0, fr1, fr2) & ((1ull << u) - 1ull) & vote(t_ndx > s_stop);
-                if (!in_batch && !(m0 | m2 | m3 | m4 | m5)) return 0;
-                if (slot & 1u) { if (lane == 0) out0[2 * slot] = make_uint4(0u, 0u, DPW_E_NOP, 0u); slot++; }      // a forward stop takes a whole line
+                const lanemask m0 = win & k0 & vote(s_ndx + 2 < t_ndx);
+                r1 = m0 & vote(t_ndx - s_ndx <= 3 * DPW_OPER_DIST);
+                r0 = m0 | (win & k1 & vote(t_stop < s_ndx)) | (win & k2 & vote((s_ndx > dlo0) & (s_ndx < dhi0))) | (win & k3 & vote(s_ndx < t_ndx - 4));
+                if (in_batch) r0 |= k0 & pick3m(sf, fr0, fr1, fr2) & ((1ull << u) - 1ull) & vote(t_ndx > s_stop);
             }
-            if (lane == 0) {
-                uint4* out = out0 + 2 * slot;
-                out[0] = make_uint4((unsigned)u, (unsigned)s_ndx, DPW_E_CODE(sk, sf) | (close ? DPW_E_CLOSE : 0u), (unsigned)j);
-                out[1] = make_uint4((unsigned)m0, (unsigned)(m0 >> 32), (unsigned)m1, (unsigned)(m1 >> 32));
-                if (sk == 1) {
-                    out[2] = make_uint4((unsigned)m2, (unsigned)(m2 >> 32), (unsigned)m3, (unsigned)(m3 >> 32));
-                    out[3] = make_uint4((unsigned)m4, (unsigned)(m4 >> 32), (unsigned)m5, (unsigned)(m5 >> 32));
-                }
-            }
-            slot += sk == 1 ? 2 : 1;
-            return 1;
         };
-        // END closes a list; the next list starts on the next line
-        auto emit_end = [&]() { if (lane == 0) out0[2 * slot] = make_uint4(0u, 0u, DPW_E_END, 0x7fffffffu); slot = (slot + 2) & ~1u; };
-        int n_near = 0, n_own = 0;
-        for (int t0 = jm; t0 < i0; t0 += 64) {
-            const int j = t0 + lane;
-            const bool in = j < i0;
-            const int jj = in ? j : i0 - 1;
-            const int s_kf = kfp[jj], s_nd = ndx[jj], s_sv = stopv[jj];
-            lanemask visit = vote(in && DPW_KIND(s_kf) != 0);
+        uint4* const rec = ta.sent + (size_t)bg * 128;                          // 64 records of two uint4
+        // ---- the batch before as near sources: lane u = node i0 - 64 + u, from jm on
+        if (bi > 0) {
+            const int j = i0 - 64 + lane;
+            const int s_kf = kfp[j], s_nd = ndx[j], s_sv = stopv[j];
+            lanemask n0 = 0, n1 = 0;
+            lanemask visit = vote(j >= jm && DPW_KIND(s_kf) != 0);
             while (visit) {
                 const int u = __builtin_ctzll(visit);
                 visit &= visit - 1;
-                const int js = t0 + u;
-                n_near += emit(js, u, rl_i32(s_kf, u), rl_i32(s_nd, u), rl_i32(s_sv, u), vote(js >= t_lo), false);      // (t_lo of a lane without a node is INT_MAX)
+                lanemask r0, r1;
+                words(u, rl_i32(s_kf, u), rl_i32(s_nd, u), rl_i32(s_sv, u), vote(i0 - 64 + u >= t_lo), false, r0, r1);      // (t_lo of a lane without a node is INT_MAX)
+                if (lane == u) { n0 = r0; n1 = r1; }
             }
-            emit_end();
+            rec[2 * (lane - 64) + 1] = make_uint4((unsigned)n0, (unsigned)(n0 >> 32), (unsigned)n1, (unsigned)(n1 >> 32));
         }
         {
             // The batch's own nodes as sources.  Inside the batch the window test is "a later lane" (a window reaches back at least
             // MAX_NODE_DIST nodes), positions ascend with the lane, and every test of a REVERSE source is a threshold on the target's
             // position: its masks are lane ranges cut out of the kind masks.  So the reverse nodes are not visited one by one: every
-            // lane finds the thresholds of its own node by binary search over the batch's positions (in LDS), builds its two masks in
-            // vector registers and writes its own slot; only the forward stops (an eighth of the nodes, with masks that are no
-            // ranges) go through emit().
-            const lanemask actm = k0 | own;
+            // lane finds the thresholds of its own node by binary search over the batch's positions (in LDS) and builds its own
+            // words; only the forward stops (an eighth of the nodes, with masks that are no ranges) are visited.
+            const lanemask own = k1 | k2 | k3, actm = k0 | own;
             int* const nd = s_nd[threadIdx.x >> 6];
             nd[lane] = act ? t_ndx : INT_MAX;
             __builtin_amdgcn_wave_barrier();
@@ -557,57 +522,34 @@ k_dpw_sched(const int32_t* __restrict__ cbase, const int32_t* __restrict__ bbase
             };
             auto ge = [](const int r) -> lanemask { return r >= 64 ? 0ull : (~0ull << r); };
             auto lt = [](const int r) -> lanemask { return r >= 64 ? ~0ull : ((1ull << r) - 1ull); };
-            lanemask v0 = 0, v1 = 0;                    // this lane's masks as a source
-            bool close = false;
+            lanemask w0 = 0, w1 = 0;                    // this lane's words as a source
             if (k2 | k3) {
                 const int r1 = rank(kind == 2 ? t_ndx : t_stop - 1);
                 if (kind == 3) {
                     const lanemask in_orf = (~1ull << lane) & lt(r1);          // later lanes whose position lies before the far end of the ORF
-                    v0 = in_orf & k2 & pick3m(frame, fr0, fr1, fr2);
-                    v1 = in_orf & k3;
+                    w0 = in_orf & ((k2 & pick3m(frame, fr0, fr1, fr2)) | k3);
                 }
                 if (k2) {
-                    const int r2 = rank(t_ndx + 2), r3 = rank(t_ndx + 3 * DPW_OPER_DIST), r4 = rank(t_ndx + DPW_OPER_DIST);
+                    const int r2 = rank(t_ndx + 2), r3 = rank(t_ndx + 3 * DPW_OPER_DIST);
                     if (kind == 2) {
                         const lanemask far3 = k3 & ge(r2);
-                        v0 = (k0 & ge(r1)) | far3;
-                        v1 = far3 & lt(r3);
-                        close = (far3 & lt(min(r3, r4))) != 0ull;
+                        w0 = (k0 & ge(r1)) | far3;
+                        w1 = far3 & lt(r3);
                     }
                 }
             }
-            const bool emit_rev = (kind == 2 && v0 != 0ull) || (kind == 3 && (v0 | v1) != 0ull);
-            const lanemask e1 = vote(emit_rev);
-            // slots in lane order: a reverse node one, a forward stop a line (with a NOP in front where it would start in the middle of one)
-            lanemask f3s = k1, pad = 0;
-            int prev = 0;
-            const unsigned own_base = slot;
-            unsigned pos = slot;
+            lanemask f3s = k1;
             while (f3s) {
                 const int u = __builtin_ctzll(f3s);
                 f3s &= f3s - 1;
-                pos += __popcll(e1 & ~((1ull << prev) - 1ull) & ((1ull << u) - 1ull));
-                if (pos & 1u) pad |= 1ull << u;
-                slot = pos;
-                // (a forward stop that reaches nothing and pulls nothing is written all the same: the slots behind it do not wait for its masks)
-                emit(i0 + u, u, rl_i32(my_kf, u), rl_i32(t_ndx, u), rl_i32(t_stop, u), actm & (~1ull << u), true);
-                pos = slot;
-                prev = u + 1;
-                n_own++;
+                lanemask r0, r1;
+                words(u, rl_i32(my_kf, u), rl_i32(t_ndx, u), rl_i32(t_stop, u), actm & (~1ull << u), true, r0, r1);
+                if (lane == u) { w0 = r0; w1 = r1; }
             }
-            if (prev < 64) pos += __popcll(e1 & ~((1ull << prev) - 1ull));      // (a forward stop in the last lane leaves nothing behind it)
-            if (emit_rev) {
-                const lanemask below_me = (1ull << lane) - 1ull;
-                const unsigned my = __popcll(e1 & below_me) + 2 * __popcll(k1 & below_me) + __popcll(pad & below_me);
-                uint4* o = out0 + 2 * (size_t)(own_base + my);
-                o[0] = make_uint4((unsigned)lane, (unsigned)t_ndx, DPW_E_CODE(kind, frame) | (close ? DPW_E_CLOSE : 0u), (unsigned)i);
-                o[1] = make_uint4((unsigned)v0, (unsigned)(v0 >> 32), (unsigned)v1, (unsigned)(v1 >> 32));
-            }
-            n_own += __popcll(e1);
-            slot = pos;
-            emit_end();
+            __builtin_amdgcn_wave_barrier();            // (the next batch of this wave rewrites nd)
+            rec[2 * lane] = make_uint4((unsigned)w0, (unsigned)(w0 >> 32), (unsigned)w1, (unsigned)(w1 >> 32));
         }
-        if (lane == 0) ta.shdr[bg] = DpwSchedHdr{off, (unsigned)n_near | ((unsigned)n_own << 16), jm, (int)slot};     // slot: slots in use, END / NOP included
+        if (lane == 0) ta.shdr[bg] = DpwSchedHdr{0u, 0u, jm, 0};
     }
 }
 
@@ -931,13 +873,43 @@ k_dpw_dyn(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) u32x4 k_uint4;
 
+// Round 6: the wave-uniform carries of a chain live in LDS (a workgroup is one wavefront), not in scalar registers.  The assembly of
+// the pair steps takes most of the scalar register file, so the compiler kept the 27 registers of these carries -- and the pointers
+// next to them -- in lanes of a spill VGPR: a v_writelane / v_readlane each per batch, 350 of the 2 240 vector instructions of the
+// loop.  From LDS a lane reads the record of ITS frame with one ds_read_b128 (it was three v_readlane and a chain of selects), and
+// the lane that sets a record writes it itself.
+struct alignas(16) DpwCarR { double v; int i, n; };          // frame f since its last forward stop: best offer to the next one, its index, its position
+struct alignas(16) DpwCarL { double v; int i, s, n, pad; };  // the last reverse stop of frame f: its score, index, stop_val, position
+// wave-wide maximum into an LDS double: every lane of EXEC offers its value (the compiler's own atomics become a loop of
+// v_readlane over the lanes when the address is uniform)
+__device__ __forceinline__ void lds_fmax_f64(double* p, const double v) {
+    asm volatile("ds_max_f64 %0, %1" :: "v"((unsigned)(uintptr_t)p), "v"(v) : "memory");
+}
+// v_max_f64 without the canonicalising v_max_f64 x, x, x the compiler puts in front of fmax's operands (never a NaN here)
+__device__ __forceinline__ double vmax_f64(const double a, const double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double wave_prefix_max_f64_lean(double v) {
+    const double NI = -__builtin_huge_val();
+    v = vmax_f64(v, dpp_f64<0x111>(NI, v));
+    v = vmax_f64(v, dpp_f64<0x112>(NI, v));
+    v = vmax_f64(v, dpp_f64<0x114>(NI, v));
+    v = vmax_f64(v, dpp_f64<0x118>(NI, v));
+    v = vmax_f64(v, dpp_f64<0x142, 0xa>(NI, v));
+    v = vmax_f64(v, dpp_f64<0x143, 0xc>(NI, v));
+    return v;
+}
+
 template <int OCC>
 __global__ void __launch_bounds__(64, OCC)
 k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const double* __restrict__ g_cs, const DpwExt* __restrict__ g_ext,
           const ModelConst* __restrict__ models, DpBuffers buf, double* __restrict__ g_sfxv, int32_t* __restrict__ g_sfxi,
           const int32_t* __restrict__ order /* or nullptr: workgroup b walks chain order[b] (longest chains first) */) {
     __shared__ double s_igm[64];
-    __shared__ int s_pf[64];                        // where the look-ahead loads of the schedule land (never read)
+    __shared__ DpwCarR s_cr[3];                     // the carries of the chain (see DpwCarR)
+    __shared__ DpwCarL s_cl[3];
     const int chain = order != nullptr ? order[blockIdx.x] : (int)blockIdx.x;
     if (chain < 0) return;                          // a filler: the per-XCD queues of the start order are not equally long
     const ChainDesc cd = chains[chain];
@@ -945,11 +917,12 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
     const int n = cd.n;
     const ModelConst* mc = &models[cd.model];
     s_igm[lane] = mc->igm[lane];
-    __syncthreads();
     const double NEG_INF = -__builtin_huge_val();
+    if (lane < 3) { s_cr[lane] = DpwCarR{NEG_INF, -1, -1}; s_cl[lane] = DpwCarL{0.0, -1, 0, 0, 0}; }
+    __syncthreads();
     const DpwModel M{mc->st_wt, mc->negc, s_igm};
     WavePtrs P;
-    k_uint4* s_hdr; k_uint4* s_ent; const uint4* g_sent;
+    const __attribute__((address_space(4))) uint32_t* s_hdr; const uint4* g_words;
     {
         const DpwTopoArrays& ta = groups.g[cd.group];
         P.ndx = ta.ndx + cd.topo_off; P.stopv = ta.stop_val + cd.topo_off; P.kf = ta.kf + cd.topo_off;
@@ -959,18 +932,17 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
         P.ext = g_ext + (ta.srank != nullptr ? cd.soff : cd.off);
         P.score = buf.score + cd.off; P.traceb = buf.traceb + cd.off; P.tbn = buf.tbn + cd.off; P.ov = buf.ov_mark + cd.off;
         P.sfxv = g_sfxv + cd.off; P.sfxi = g_sfxi + cd.off;
-        s_hdr = (k_uint4*)(ta.shdr) + cd.sched_b0;
-        s_ent = (k_uint4*)(ta.sent); g_sent = ta.sent;
+        s_hdr = (const __attribute__((address_space(4))) uint32_t*)(ta.shdr + cd.sched_b0);
+        g_words = ta.sent + (size_t)cd.sched_b0 * (2 * DPW_SCHED_STRIDE) + 2 * lane;       // this lane's record of batch 0: {W0, W1}, {N0, N1}
     }
     // a launch ends when its longest chain does: long chains issue first, the short ones fill their stalls
     if (n >= 2048) __builtin_amdgcn_s_setprio(3); else if (n >= 1536) __builtin_amdgcn_s_setprio(2); else if (n >= 1024) __builtin_amdgcn_s_setprio(1);
     const bool long_chain = n > 2 * DPW_MAX_NODE_DIST;         // only then can a window start past node 0
     double end_best = -1.0; int end_idx = -1, end_tb = -1;
     double s1v = NEG_INF, s2v = NEG_INF, ppv = NEG_INF; int s1i = -1, s2i = -1, ppi = -1;
-    double rv0 = NEG_INF, rv1 = NEG_INF, rv2 = NEG_INF; int ri0 = -1, ri1 = -1, ri2 = -1, rn0 = -1, rn1 = -1, rn2 = -1;
-    int l3i0 = -1, l3i1 = -1, l3i2 = -1, l3s0 = 0, l3s1 = 0, l3s2 = 0, l3n0 = 0, l3n1 = 0, l3n2 = 0;
-    double l3v0 = 0.0, l3v1 = 0.0, l3v2 = 0.0;
     const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));      // lanes before this one
+    // the batch before, as the source of this batch's near steps: lane l held node i0 - 64 + l then, and keeps what that node offers
+    double p_ns = NEG_INF, p_x0 = 0.0, p_x1 = 0.0, p_x2 = 0.0; int p_tbn = -1, p_kinfo = 0x80, p_ndx = 0;
 
     const int nb = (n + 63) >> 6;
     const bool prof = buf.prof != nullptr && (blockIdx.x & 63) == 0;
@@ -983,29 +955,22 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
     };
     for (int b = 0; b < nb; b++) {
         const int i0 = b << 6;
-        const u32x4 hdr = s_hdr[b];                 // {first slot, near entries | own entries << 16, jm, -}
-        if (hdr.x == DPW_SCHED_NONE) return;          // the batch's lists did not fit: the host repeats the launch with k_dpw_dyn
-        {
-            // The batch's entries are read line by line through the scalar cache, each a dependent round trip; the first model of a
-            // contig to come by finds them in HBM (2 000 cycles per line).  One vector instruction asks for all of them now: lane l
-            // touches line l of the batch's slots (4 bytes, straight to LDS, into a scratch row nobody reads), which puts the lines in this
-            // XCD's L2 by the time the steps get to them.
-            // (only the lines the batch's lists take: a batch owns DPW_SCHED_STRIDE slots and uses half of them or fewer, and what the
-            //  first model of a contig touches comes from HBM)
-            const char* line = (const char*)g_sent + ((size_t)(cd.sched_b0 + b) * DPW_SCHED_STRIDE * sizeof(DpwSlot) + (size_t)lane * 64);
-            if (2 * lane < (int)hdr.w) {
-                unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(line), "s"((unsigned)(uintptr_t)s_pf) : "memory");
-            }
-        }
+        if (s_hdr[4 * b] == DPW_SCHED_NONE) return;   // the batch's near sources reach past the batch before: the host repeats the launch with k_dpw_dyn
+        // the batch's words of the step schedule (dpw_core.h): this lane's node as a source towards its own batch, and the node this lane
+        // held one batch ago towards this batch
+        const uint4 ww = g_words[(size_t)b * (2 * DPW_SCHED_STRIDE)];
+        uint4 nw = make_uint4(0u, 0u, 0u, 0u);
+        if (b > 0) nw = g_words[(size_t)(b - 1) * (2 * DPW_SCHED_STRIDE) + 1];
         DpwT T; int kfb;
         load_target_w(T, kfb, P, i0, lane, n, M.negc);
         const DpwLT LT = dpw_lean(T);
         const bool act = T.i >= 0;
-        // reverse stops with an overlapping start in frame f: the one lane mask of a step that depends on the model
-        const lanemask r3v0 = vote(act && T.kind == 3 && (T.vm & 1)), r3v1 = vote(act && T.kind == 3 && (T.vm & 2)), r3v2 = vote(act && T.kind == 3 && (T.vm & 4));
+        // (a forward start keeps cs in the x[] of its frame: what it offers the forward stop of its ORF is score + x[frame], as a forward
+        //  stop's offer to an operon partner of frame f is score + x[f] -- one form for the carries of (7); no step reads a start's x[])
+        if (T.kind == 0) { if (T.frame == 0) T.x0 = T.cs; else if (T.frame == 1) T.x1 = T.cs; else T.x2 = T.cs; }
         const int fbit = 1 << T.frame;
+        // what the assembly's lane masks come from: kind | frame << 2 | vm << 8, 0x80 for a lane without a node
+        const int kinfo = act ? (T.kind | (T.frame << 2) | (T.vm << 8)) : 0x80;
         mark(0);
         DpwLane L{0.0, -1};
         int tbn_pre = -1;                   // position of the traceb node while it is older than the batch
@@ -1013,33 +978,24 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
             const int cur = dpw_tag_index(L.tag);
             if (ok && (val > L.val || (val == L.val && j > cur))) { L.val = val; L.tag = j | (ov1 << DPW_TAG_BITS); tbn_pre = s_ndx; }
         };
-        k_uint4* ep = s_ent + 2 * (size_t)hdr.x;                  // 32-byte slots
         // operands of the assembly blocks (names fixed by tools/gen_dpw_walk.py)
-        unsigned long long a_ep = (unsigned long long)(uintptr_t)ep;
         double& a_lv = L.val; int& a_lt = L.tag;
-        const double a_x0 = T.x0, a_x1 = T.x1, a_x2 = T.x2, a_cs = T.cs, a_csd = T.csd, a_negc = M.negc;
-        const int a_ndx = T.ndx, a_fbit = fbit, a_vm = T.vm, a_i0 = i0;
+        const double a_x0 = T.x0, a_x1 = T.x1, a_x2 = T.x2, a_cs = T.cs, a_negc = M.negc;
+        const int a_ndx = T.ndx, a_i0 = i0, a_kinfo = kinfo;
         const int a_drhs0 = LT.drhs0, a_drhs1 = LT.drhs1, a_drhs2 = LT.drhs2, a_dlo0 = LT.dlo0, a_dlo1 = LT.dlo1, a_dlo2 = LT.dlo2,
                   a_dhi0 = LT.dhi0, a_dhi1 = LT.dhi1, a_dhi2 = LT.dhi2;
-        const lanemask a_r3v0 = r3v0, a_r3v1 = r3v1, a_r3v2 = r3v2;
         const unsigned a_igmb = (unsigned)(uintptr_t)s_igm;
-        // ---- (2) near steps first (ascending sources onto an empty state: ">=" is the whole tie rule), from the schedule
+        // ---- (2) near steps first (ascending sources onto an empty state: ">=" is the whole tie rule): the nodes of the batch before
+        //      that the schedule lists for this batch, their values from the registers this wave left them in
         {
-            for (int t0 = (int)hdr.z; t0 < i0; t0 += 64) {
-                const int j = t0 + lane;
-                const int jj = j < i0 ? j : i0 - 1;
-                const int s_tb = P.tbn[jj];
-                const double t_score = P.score[jj];
-                const int er = P.srank != nullptr ? P.srank[jj] : jj;
-                int t_vm = 0; double t_x0 = 0.0, t_x1 = 0.0, t_x2 = 0.0;
-                const int s_kind = DPW_KIND(P.kf[jj]);
-                if (s_kind == 1) { const DpwExt* e = P.ext + er; t_vm = e->vm; t_x0 = e->x[0]; t_x1 = e->x[1]; t_x2 = e->x[2]; }
-                // (a gene end that was never reached is no source: it offers -inf, which no lane takes)
-                const double a_ns = (s_tb == -1 && (s_kind == 1 || s_kind == 2)) ? NEG_INF : t_score, a_nx0 = t_x0, a_nx1 = t_x1, a_nx2 = t_x2;
-                const int a_nb = s_tb, a_nvm = t_vm;
-                DPW_ASM_NEAR();
-            }
-            if (L.tag >= 0) tbn_pre = P.ndx[dpw_tag_index(L.tag)];
+            const unsigned long long a_w0 = ((unsigned long long)nw.y << 32) | nw.x, a_w1 = ((unsigned long long)nw.w << 32) | nw.z;
+            const double a_ns = p_ns, a_nx0 = p_x0, a_nx1 = p_x1, a_nx2 = p_x2;
+            const int a_nb = p_tbn, a_pk = p_kinfo, a_pndx = p_ndx;
+            DPW_ASM_NEAR();
+            // the position of the traceb node: a node of the batch before, i.e. a lane of p_ndx
+            const int src = L.tag >= 0 ? (dpw_tag_index(L.tag) & 63) : 0;
+            const int nd_prev = __shfl(p_ndx, src, 64);
+            if (L.tag >= 0) tbn_pre = nd_prev;
         }
         mark(1);
         // ---- (1) gene begins: far gene ends, `a` over [lo, min(p_near, i0))
@@ -1077,45 +1033,62 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
         }
         mark(2);
         // ---- (3) forward stops: the running maximum of their frame, for the first forward stop of the frame in the batch
+        const bool f3 = act && T.kind == 1;
+        const lanemask f3f0 = vote(f3 && T.frame == 0), f3f1 = vote(f3 && T.frame == 1), f3f2 = vote(f3 && T.frame == 2);
         {
-            const bool f3 = act && T.kind == 1;
-            const unsigned long long m0 = __ballot(f3 && T.frame == 0), m1 = __ballot(f3 && T.frame == 1), m2 = __ballot(f3 && T.frame == 2);
-            const unsigned long long mine = T.frame == 0 ? m0 : (T.frame == 1 ? m1 : m2);
-            const double cv = dpw_sel3(T.frame, rv0, rv1, rv2);
-            const int ci = dpw_sel3i(T.frame, ri0, ri1, ri2), cn = dpw_sel3i(T.frame, rn0, rn1, rn2);
-            take(f3 && (mine & below) == 0ull && ci >= 0, cv, ci, 0, cn);
+            const lanemask mine = T.frame == 0 ? f3f0 : (T.frame == 1 ? f3f1 : f3f2);
+            const DpwCarR r = s_cr[T.frame];                 // every lane the record of its own frame
+            take(f3 && (mine & below) == 0ull && r.i >= 0, r.v, r.i, 0, r.n);
         }
         // ---- (4) reverse nodes: the last reverse stop of a frame before the batch (own stop of a reverse start; operon partner)
         if (act && T.kind == 2) {
-            const int j = dpw_sel3i(T.frame, l3i0, l3i1, l3i2), ss = dpw_sel3i(T.frame, l3s0, l3s1, l3s2);
-            take(j >= 0 && j >= T.lo && ss > T.ndx, dpw_sel3(T.frame, l3v0, l3v1, l3v2) + T.cs, j, 0, dpw_sel3i(T.frame, l3n0, l3n1, l3n2));
+            const DpwCarL l = s_cl[T.frame];
+            take(l.i >= 0 && l.i >= T.lo && l.s > T.ndx, l.v + T.cs, l.i, 0, l.n);
         } else if (act && T.kind == 3) {
-            take((T.vm & 1) && l3i0 >= 0 && l3i0 >= T.lo && l3s0 > T.ndx, l3v0 + T.x0, l3i0, 0, l3n0);
-            take((T.vm & 2) && l3i1 >= 0 && l3i1 >= T.lo && l3s1 > T.ndx, l3v1 + T.x1, l3i1, 0, l3n1);
-            take((T.vm & 4) && l3i2 >= 0 && l3i2 >= T.lo && l3s2 > T.ndx, l3v2 + T.x2, l3i2, 0, l3n2);
+            const DpwCarL l0 = s_cl[0], l1 = s_cl[1], l2 = s_cl[2];
+            take((T.vm & 1) && l0.i >= 0 && l0.i >= T.lo && l0.s > T.ndx, l0.v + T.x0, l0.i, 0, l0.n);
+            take((T.vm & 2) && l1.i >= 0 && l1.i >= T.lo && l1.s > T.ndx, l1.v + T.x1, l1.i, 0, l1.n);
+            take((T.vm & 4) && l2.i >= 0 && l2.i >= T.lo && l2.s > T.ndx, l2.v + T.x2, l2.i, 0, l2.n);
         }
         mark(3);
-        // ---- (5) reverse nodes: forward stops that overlap the 3' end of the gene, through the chain of forward stops
+        // ---- (5) reverse nodes: forward stops that overlap the 3' end of the gene, through the chain of forward stops.  Round 6: a
+        //      candidate is priced through the chain's OWN overlapping start only, by the interval tests of dpw_lean (a pair that is
+        //      admissible through another overlapping start lies on that start's chain as well, and the plain connection is what the far gene
+        //      ends / the near steps hold already); a lane walks its chains one after the other in ONE loop of the wavefront.
         {
             const bool r5 = act && T.kind == 2, r3 = act && T.kind == 3;
-#pragma unroll
-            for (int q = 0; q < 3; q++) {
-                int j = DPW_NONE, bound = 0;
-                if (r5 && q == 0) { j = T.q2; bound = T.stop_val + DPW_MAX_OPP_OVLP - 5; }
-                if (r3 && ((T.vm >> q) & 1)) { j = dpw_sel3i(q, T.cq0, T.cq1, T.cq2); bound = dpw_sel3i(q, T.n3s0, T.n3s1, T.n3s2) + DPW_MAX_OPP_OVLP - 5; }
-                while (__any(j < i0)) {
-                    if (j < i0) {
-                        const int s_ndx = P.ndx[j];
-                        if (s_ndx >= bound) j = DPW_NONE;
-                        else {
-                            const DpwS S = load_f3_source(P, j, s_ndx);
-                            bool ok; double w; int mf;
-                            dpw_pair(S, T, M, ok, w, mf);
-                            take(ok, S.score + w, j, mf + 1, s_ndx);
-                            j = P.q2[j];
+            int q = 0, j = DPW_NONE, dlo = INT_MAX, dhi = INT_MIN, drhs = INT_MIN;
+            double xq = 0.0;
+            // the chain of candidate q, or the next one that exists
+            auto open_chain = [&]() {
+                j = DPW_NONE;
+                if (r5) { if (q == 0) { j = T.q2; dlo = LT.dlo0; dhi = LT.dhi0; drhs = LT.drhs0; xq = T.csd; } q = 3; }
+                else if (r3) {
+                    while (q < 3 && j == DPW_NONE) {
+                        const int lo_q = dpw_sel3i(q, LT.dlo0, LT.dlo1, LT.dlo2);
+                        if (lo_q != INT_MAX) {          // (an overlapping start worth nothing is never taken: dpw_lean leaves its interval empty)
+                            j = dpw_sel3i(q, T.cq0, T.cq1, T.cq2); dlo = lo_q; dhi = dpw_sel3i(q, LT.dhi0, LT.dhi1, LT.dhi2);
+                            drhs = dpw_sel3i(q, LT.drhs0, LT.drhs1, LT.drhs2); xq = dpw_sel3(q, T.x0, T.x1, T.x2);
                         }
+                        q++;
+                    }
+                } else q = 3;
+            };
+            open_chain();
+            while (__any(j < i0 || q < 3)) {
+                if (j < i0) {
+                    const int s_ndx = P.ndx[j];
+                    // a reverse start's chain ends at stop_val + MAX_OPP_OVLP - 5 = dlo0 + MAX_OPP_OVLP - 1, a reverse stop's at n3s + MAX_OPP_OVLP - 5 = dlo + MAX_OPP_OVLP
+                    if (s_ndx >= dlo + DPW_MAX_OPP_OVLP - (r5 ? 1 : 0)) j = DPW_NONE;
+                    else {
+                        const int tbj = P.tbn[j];
+                        const double sj = P.score[j];
+                        const bool ok = (j >= T.lo) & (tbj != -1) & (s_ndx > dlo) & (s_ndx < dhi) & (tbj + s_ndx + 7 < drhs);
+                        take(ok, sj + xq, j, r5 ? 0 : q, s_ndx);          // (q was advanced when the chain was opened: ov_mark + 1)
+                        j = P.q2[j];
                     }
                 }
+                if (j >= i0 && q < 3) open_chain();
             }
         }
         mark(4);
@@ -1123,27 +1096,34 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
         //      forward starts of its ORF that sit before it in the batch (the entry's `pull` lanes; they are final by then).
         {
             const int a_tbnpre = tbn_pre;
+            const unsigned long long a_w0 = ((unsigned long long)ww.y << 32) | ww.x, a_w1 = ((unsigned long long)ww.w << 32) | ww.z;
             double a_sv = L.tag >= 0 ? L.val : NEG_INF;      // what a lane offers as a gene-end source: -inf while it was never reached
             DPW_ASM_WALK();
         }
         mark(5);
         // ---- (7) the batch is final: results, block structures, carries
-        DpwBest B;
-        B.val = L.val; B.tb = dpw_tag_index(L.tag); B.ov = dpw_tag_ov(L.tag);
+        const bool alive = L.tag >= 0;
+        const int tb = alive ? (L.tag & DPW_TAG_MASK) : -1;
         {
-            const int src = B.tb >= i0 ? B.tb - i0 : 0;
+            const int src = tb >= i0 ? tb - i0 : 0;
             const int nd_in = __shfl(T.ndx, src, 64);
-            B.tbn = B.tb < 0 ? -1 : (B.tb >= i0 ? nd_in : tbn_pre);
+            const int tbn = !alive ? -1 : (tb >= i0 ? nd_in : tbn_pre);
+            // what this node offers the next batch as a near source (a gene end that was never reached: -inf, which no lane takes)
+            p_ns = (!alive && (T.kind == 1 || T.kind == 2)) ? NEG_INF : L.val; p_tbn = tbn; p_kinfo = kinfo; p_ndx = T.ndx;
+            p_x0 = T.x0; p_x1 = T.x1; p_x2 = T.x2;
+            if (act) {
+                P.score[T.i] = L.val; P.traceb[T.i] = tb; P.tbn[T.i] = tbn; P.ov[T.i] = (int8_t)dpw_tag_ov(L.tag);
+                if ((T.kind == 1 || T.kind == 2) && L.val >= end_best) { end_best = L.val; end_idx = T.i; end_tb = tb; }
+            }
         }
-        if (act) {
-            P.score[T.i] = B.val; P.traceb[T.i] = B.tb; P.tbn[T.i] = B.tbn; P.ov[T.i] = (int8_t)B.ov;
-            if ((T.kind == 1 || T.kind == 2) && B.val >= end_best) { end_best = B.val; end_idx = T.i; end_tb = B.tb; }
-        }
-        const DpwOut O = dpw_outputs(T, kfb, B, M.negc);
         {
-            const bool has = O.a > NEG_INF;
-            const double pv = wave_prefix_max_f64(O.a, lane);
-            const lanemask rec = vote(has && O.a == pv) & (below | (1ull << lane));
+            // `a`: what a reached gene end offers the far gene begins behind it (dpw_outputs).  Inclusive prefix maxima inside the
+            // block: values by a scan, the index from a vote -- lane r is a record when a[r] equals its own prefix maximum, and the
+            // prefix maximum at t sits at the LAST record at or before t (ties to the larger index, as the ascending ">=")
+            const bool has = act && alive && (T.kind == 1 || T.kind == 2);
+            const double av = has ? L.val + M.negc : NEG_INF;
+            const double pv = wave_prefix_max_f64_lean(av);
+            const lanemask rec = vote(has && av == pv) & (below | (1ull << lane));
             const int pi = rec ? i0 + 63 - __builtin_clzll(rec) : -1;
             ppv = pv; ppi = pi;
             const double bmv = rl_f64(pv, 63); const int bmi = rl_i32(pi, 63);
@@ -1152,37 +1132,37 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
             lex_max(nv, ni, bmv, bmi);
             s1v = nv; s1i = ni;
             if (long_chain) {
-                double av = O.a; int ai = has ? i0 + lane : -1;
-                wave_suffix_lexmax(av, ai, lane);
-                if (act) { P.sfxv[T.i] = av; P.sfxi[T.i] = ai; }
+                double sv = av; int si = has ? i0 + lane : -1;
+                wave_suffix_lexmax(sv, si, lane);
+                if (act) { P.sfxv[T.i] = sv; P.sfxi[T.i] = si; }
             }
         }
         {
-            const bool f3 = act && T.kind == 1, r3n = act && T.kind == 3;
+            // The carries (LDS).  What a finished lane offers the next forward stop of frame f: a forward start of that frame its score +
+            // cs (x[frame] of a forward start holds cs since the load); a reached forward stop inside that stop's ORF its score + x[f]
+            // where it has an overlapping start of frame f (dpw_outputs v0 .. v2).  A forward stop of the frame restarts the running
+            // maximum; what follows it in the batch joins it; ties go to the later node.  The maximum itself is one ds_max_f64 over the
+            // offering lanes (it was six rounds of cross-lane moves per frame), the lane that holds it then writes the record.
+            const int vout = !act ? 0 : (T.kind == 0 ? fbit : ((T.kind == 1 && alive) ? (T.vm & (kfb >> 4)) : 0));
+            const bool r3n = act && T.kind == 3;
 #pragma unroll
             for (int f = 0; f < 3; f++) {
-                const lanemask mf = vote(f3 && T.frame == f);
-                const int u = mf ? 63 - __builtin_clzll(mf) : -1;
-                double v = f == 0 ? O.v0 : (f == 1 ? O.v1 : O.v2);
-                if (lane <= u) v = NEG_INF;
-                const lanemask some = vote(v > NEG_INF);
-                double& rv = f == 0 ? rv0 : (f == 1 ? rv1 : rv2);
-                int& ri = f == 0 ? ri0 : (f == 1 ? ri1 : ri2);
-                int& rn = f == 0 ? rn0 : (f == 1 ? rn1 : rn2);
-                if (some) {
-                    const double m = wave_max_f64(v);
-                    const lanemask at = some & vote(v == m);               // a later node wins a tie
-                    const int wl = 63 - __builtin_clzll(at);
-                    const double mv = rl_f64(v, wl);                       // the same value, in scalar registers
-                    if (u >= 0 || mv >= rv) { rv = mv; ri = i0 + wl; rn = rl_i32(T.ndx, wl); }
-                } else if (u >= 0) { rv = NEG_INF; ri = -1; rn = -1; }
-                const lanemask mr = vote(r3n && T.frame == f);
-                if (mr) {
-                    const int w = 63 - __builtin_clzll(mr);
-                    const int li = i0 + w, ls = rl_i32(T.stop_val, w), ln = rl_i32(T.ndx, w); const double lv = rl_f64(B.val, w);
-                    if (f == 0) { l3i0 = li; l3s0 = ls; l3n0 = ln; l3v0 = lv; } else if (f == 1) { l3i1 = li; l3s1 = ls; l3n1 = ln; l3v1 = lv; }
-                    else { l3i2 = li; l3s2 = ls; l3n2 = ln; l3v2 = lv; }
+                const lanemask mf = f == 0 ? f3f0 : (f == 1 ? f3f1 : f3f2);
+                lanemask cand = vote((vout >> f) & 1);
+                if (mf) {
+                    const int u = 63 - __builtin_clzll(mf);
+                    cand &= ~((2ull << u) - 1ull);                     // the lanes behind the frame's last forward stop
+                    if (lane == 0) s_cr[f] = DpwCarR{NEG_INF, -1, -1};
                 }
+                if (cand) {
+                    const double v = L.val + (f == 0 ? T.x0 : (f == 1 ? T.x1 : T.x2));
+                    if (in_mask(cand)) lds_fmax_f64(&s_cr[f].v, v);
+                    const double m = s_cr[f].v;
+                    const lanemask at = cand & vote(v == m);           // (empty: an earlier batch holds the maximum, its record stays)
+                    if (at) { const int wl = 63 - __builtin_clzll(at); if (lane == wl) s_cr[f] = DpwCarR{v, i0 + lane, T.ndx}; }
+                }
+                const lanemask mr = vote(r3n && T.frame == f);
+                if (mr) { const int w = 63 - __builtin_clzll(mr); if (lane == w) s_cl[f] = DpwCarL{L.val, i0 + lane, T.stop_val, T.ndx, 0}; }
             }
         }
         mark(6);

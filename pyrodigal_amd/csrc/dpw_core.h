@@ -415,38 +415,38 @@ DPW_HD void dpw_step(const DpwS& S, const DpwLT& T, DpwLane& L, const DpwModel& 
 // Step schedule.  Which sources take a pair step onto a batch of 64 targets, in which order, and which lanes each of them can
 // reach at all is TOPOLOGY: kinds, frames, positions, stop positions, windows -- the same for every model scored on the contig
 // under one translation table (ref: the six skip conditions of impl/generic.h:29-36 and the static tests of _connection.h:94-367
-// read nothing else).  It is therefore compiled once per (contig, table) into a list of entries per batch (k_dpw_sched; the host
-// loop of tests/dpw_model.cpp builds the same list), and a chain's walk reads the entries with scalar loads: per step what is left
-// is the source's value, one add, one compare against the lanes' running values under the entry's lane mask -- plus, for the few
-// relations that depend on a model (the overlapping starts of a stop node: star_ptr), the dynamic tests listed with each kind.
+// read nothing else).  It is therefore compiled once per (contig, table) into lane masks (k_dpw_sched; the host loop of
+// tests/dpw_model.cpp builds the same words): per step what is left is the source's value, one add, one compare against the lanes'
+// running values under the step's lane mask -- plus, for the few relations that depend on a model (the overlapping starts of a stop
+// node: star_ptr), the dynamic tests listed with each kind.
 //
-// A batch's entries: first the NEAR sources (older than the batch, from the earliest p_near of a gene begin of the batch: `jm`),
-// ascending, in tiles of 64 nodes from jm on, one list per tile; then the batch's own nodes as sources, ascending, one more list.
-// Forward starts never step (a forward stop pulls the starts of its ORF, see `pull`).  An entry whose masks are all empty is left
-// out.  Layout: 32-byte slots, two to a 64-byte line; the walk takes a LINE per scalar load (s_load_dwordx16: the round trip
-// through the scalar cache is what a step waits for, so a load carries two steps), keeps lines in flight while it works on the ones at
-// hand (near lists: one and one; the batch's own list: two and two), and finds no counter: a list starts on a line and ends with an END slot.
-//   slot, 32 bytes:  lane (of the source inside its 64-node tile / inside the batch), s_ndx (its position),
-//                    code = kind | frame << 2 | 16 if not a reverse start | 64 (DPW_E_CLOSE); 16 alone = END, 48 = NOP (a pad), j (its chain index),
-//                    m[0], m[1]
-//   R5, one slot:    m[0] = gene begins in the window with s_ndx < key_r5                     (ref: _connection.h:125-130, 337-342)
-//                    m[1] = those of m[0] that are reverse stops within 3 * OPER_DIST bases (the distance term)
-//   R3, one slot:    m[0] = reverse starts of the source's frame inside its ORF               (ref: :228-235)
-//                    m[1] = reverse stops inside its ORF; dynamic: the lane has an overlapping start in the source's frame (:345-356)
-//   F3, one LINE (a NOP slot in front of it where it would start in the middle of one): the slot's m[0] = mF5 = forward starts behind
-//        it (:117-124), m[1] = mF5t = those within 3 * OPER_DIST bases, then four more masks:
-//        mF3 = forward stops whose ORF holds it; dynamic: the SOURCE has an overlapping start in the lane's frame (:177-188),
-//        mR5 = reverse starts whose static interval holds s_ndx; dynamic: tbn + s_ndx + 7 < drhs0 (:238-254),
-//        mR3 = reverse stops with s_ndx < ndx - 4; dynamic: the candidates through the lane's overlapping starts (:288-336),
-//        pull = (batch sources only) the forward starts of its ORF that sit before it in the batch (:166-174)
-struct DpwSchedHdr { uint32_t off; uint32_t cnt; int32_t jm; int32_t used; };    // off: first slot; cnt = near entries | batch entries << 16 (END / NOP not counted); used: slots the lists take, END / NOP included
-struct DpwSlot { uint32_t lane; int32_t s_ndx; uint32_t code; int32_t j; uint64_t m[2]; };
-#define DPW_SCHED_STRIDE 128u                                                     // slots a batch owns (its lists sit at batch * stride)
-#define DPW_SCHED_NONE 0xffffffffu                                                // off: the lists did not fit (the caller falls back)
-#define DPW_E_CODE(kind, frame) ((uint32_t)((kind) | ((frame) << 2) | ((kind) != 2 ? 16 : 0)))
-#define DPW_E_END 16u
-#define DPW_E_NOP 48u
-#define DPW_E_CLOSE 64u      // R5 / F3: some lane of m[1] lies within OPER_DIST bases of the source (its distance term needs the table; 0 otherwise)
+// Round 6 -- the schedule is per NODE, not per batch: node j (lane l = j & 63 of its batch) carries four 64-bit words,
+//   W0   the lanes of its OWN batch it reaches as a source, by any relation (the relations are disjoint by the target's kind, so the
+//        step takes the word apart with the lane masks of the batch's kinds); for a forward stop also the forward starts it PULLS,
+//        which are forward-start lanes BEFORE it (the ones it reaches lie behind it)
+//   W1   the lanes among them whose intergenic term depends on the distance (R5 source: reverse stops within 3 * OPER_DIST bases;
+//        F3 source: forward starts within 3 * OPER_DIST bases)
+//   N0, N1  the same towards the batch BEHIND its own (the near steps of that batch: sources from the earliest p_near of one of its
+//        gene begins on, `jm`; a batch whose jm lies before the batch in front of it is marked DPW_SCHED_NONE and the launch repeated
+//        by k_dpw_dyn -- more than 64 nodes within 3 * OPER_DIST bases, never on sequence)
+// and a chain's wavefront loads them with two coalesced 16-byte reads per lane -- the near sources of a batch sit in the lanes the
+// wave held them in one batch earlier, so their values stay in registers.  (Rounds 5's form was a list of 32-byte slots per batch,
+// read line by line through the scalar cache: ten dependent scalar-load round trips per batch, 12 200 of the walk's 20 000 cycles.)
+//   source kind      reaches (W0)                                                       dynamic part of the step
+//   R5               gene begins in the window with s_ndx < key_r5 (ref: :125-130, 337-342)   --
+//   R3               reverse starts of its frame inside its ORF (:228-235);                    --
+//                    reverse stops inside its ORF (:345-356)                                   the lane has an overlapping start in its frame
+//   F3               forward starts behind it (:117-124)                                       --
+//                    forward stops whose ORF holds it (:177-188)                               the SOURCE has an overlapping start in the lane's frame
+//                    reverse starts whose static interval holds s_ndx (:238-254)               tbn + s_ndx + 7 < drhs0
+//                    reverse stops with s_ndx < ndx - 4 (:288-336)                             the candidates through the lane's overlapping starts
+//                    (batch sources only) the forward starts of its ORF before it (:166-174)   pulled: (value, index) maximum
+// Forward starts never step (a forward stop pulls the starts of its ORF).
+struct DpwSchedHdr { uint32_t off; uint32_t cnt; int32_t jm; int32_t used; };    // per batch: off = 0, or DPW_SCHED_NONE (the batch's near sources did not fit); jm
+struct DpwSlot { uint64_t w0, w1, n0, n1; };                                      // per node
+#define DPW_SCHED_STRIDE 64u                                                      // records a batch owns (one per lane)
+#define DPW_SCHED_NONE 0xffffffffu
+#define DPW_E_CODE(kind, frame) ((uint32_t)((kind) | ((frame) << 2) | ((kind) != 2 ? 16 : 0)))      // (host model: kind / frame of an entry)
 #define DPW_E_KIND(c)  ((int)((c) & 3))
 #define DPW_E_FRAME(c) ((int)(((c) >> 2) & 3))
 

@@ -56,41 +56,76 @@ DpwS load_source(const Chain& C, const int j) {
 }
 
 
-// ---- step schedule (dpw_core.h "Step schedule"): the host loop that builds a batch's entries; k_dpw_sched builds the same on the device
+// ---- step schedule (dpw_core.h "Step schedule", round 6): per NODE two pairs of 64-bit words -- which lanes of its own batch (W0, W1)
+// and of the batch behind it (N0, N1) it reaches as a source.  The host loop below builds the words from dpw_static_bits and takes them
+// apart again with the kind masks of the target batch exactly as the kernel's assembly does (tools/gen_dpw_walk.py); k_dpw_sched
+// builds the same words on the device.
 struct Entry { int lane, s_ndx; uint32_t code; int j; uint64_t m[6]; };
-struct BatchSched { int jm; std::vector<Entry> near, walk; };
+struct BatchSched { bool miss; std::vector<Entry> near, walk; };
+struct NodeWords { uint64_t w0, w1, n0, n1; };
+
+// words of source j towards the 64 targets T[] (in_batch: a node of the batch itself, lane `lane`): r0 = every lane it reaches by any
+// relation (for a forward stop of the batch also the forward starts it pulls, which sit BEFORE it), r1 = the lanes whose distance term
+// comes from the table (R5 source: reverse stops nearby; F3 source: forward starts nearby)
+void words_of(const Chain& C, const DpwST* T, const int j, const int lane, const bool in_batch, uint64_t& r0, uint64_t& r1) {
+    r0 = r1 = 0;
+    const int kf = C.kf[j], sk = DPW_KIND(kf), sf = DPW_FRAME(kf);
+    if (sk == 0) return;
+    const int s_ndx = C.ndx[j], s_stop = C.stopv[j];
+    for (int t = 0; t < 64; t++) {
+        const unsigned bits = dpw_static_bits(T[t], j, sk, sf, s_ndx, s_stop);
+        if (sk == 3 ? bits != 0u : (bits & ~2u) != 0u) r0 |= 1ull << t;
+        if ((sk == 2 || sk == 1) && (bits & 2u)) r1 |= 1ull << t;
+        if (in_batch && sk == 1 && t < lane && dpw_static_pull(T[t], sf, s_stop)) r0 |= 1ull << t;
+    }
+}
+// and back: the masks of a step from the words and the kinds of the target lanes (k[q] = lanes of kind q)
+Entry entry_from(const Chain& C, const int j, const int lane, const uint64_t r0, const uint64_t r1, const uint64_t* k, const bool in_batch) {
+    Entry e; memset(&e, 0, sizeof e);
+    const int kf = C.kf[j], sk = DPW_KIND(kf), sf = DPW_FRAME(kf);
+    e.lane = lane; e.code = DPW_E_CODE(sk, sf); e.s_ndx = C.ndx[j]; e.j = j;
+    if (sk == 2) { e.m[0] = r0; e.m[1] = r1; }
+    else if (sk == 3) { e.m[0] = r0 & k[2]; e.m[1] = r0 & k[3]; }
+    else {
+        const uint64_t later = in_batch ? (lane >= 63 ? 0ull : (~0ull << (lane + 1))) : ~0ull;
+        e.m[0] = r0 & k[0] & later; e.m[1] = r1; e.m[2] = r0 & k[1]; e.m[3] = r0 & k[2]; e.m[4] = r0 & k[3];
+        e.m[5] = in_batch ? (r0 & k[0] & ~later) : 0ull;
+    }
+    return e;
+}
 
 BatchSched compile_batch(const Chain& C, const int b) {
-    BatchSched S;
+    BatchSched S; S.miss = false;
     const int i0 = b << 6;
     DpwST T[64];
+    uint64_t k[4] = {0, 0, 0, 0};
     for (int t = 0; t < 64; t++) {
         const int i = i0 + t;
         T[t] = i < C.n ? dpw_st(i, C.kf[i], C.ndx[i], C.stopv[i], C.lo[i]) : dpw_st(-1, 0, 0, 0, 0);
+        if (T[t].i >= 0) k[T[t].kind] |= 1ull << t;
     }
-    S.jm = i0;
-    for (int t = 0; t < 64; t++) if (T[t].i >= 0 && (T[t].kind == 0 || T[t].kind == 3)) S.jm = std::min(S.jm, std::max(C.q1[T[t].i], T[t].lo));
-    auto entry_of = [&](const int j, const int lane, const bool in_batch, Entry& e) {
-        const int kf = C.kf[j], sk = DPW_KIND(kf), sf = DPW_FRAME(kf);
-        if (sk == 0) return false;
-        e.lane = lane; e.code = DPW_E_CODE(sk, sf); e.s_ndx = C.ndx[j]; e.j = j;
-        const int s_stop = C.stopv[j];
-        for (int q = 0; q < 6; q++) e.m[q] = 0;
-        for (int t = 0; t < 64; t++) {
-            const unsigned bits = dpw_static_bits(T[t], j, sk, sf, e.s_ndx, s_stop);
-            for (int q = 0; q < 5; q++) if ((bits >> q) & 1u) e.m[q] |= 1ull << t;
-            if (in_batch && sk == 1 && t < lane && dpw_static_pull(T[t], sf, s_stop)) e.m[5] |= 1ull << t;
-        }
-        uint64_t any = 0;
-        for (int q = 0; q < 6; q++) any |= e.m[q];
-        return any != 0;
-    };
-    Entry e;
-    for (int j = S.jm; j < i0; j++) if (entry_of(j, (j - S.jm) & 63, false, e)) S.near.push_back(e);
-    for (int k = 0; k < 64 && i0 + k < C.n; k++) if (entry_of(i0 + k, k, true, e)) S.walk.push_back(e);
+    int jm = i0;
+    for (int t = 0; t < 64; t++) if (T[t].i >= 0 && (T[t].kind == 0 || T[t].kind == 3)) jm = std::min(jm, std::max(C.q1[T[t].i], T[t].lo));
+    if (jm < i0 - 64) { S.miss = true; return S; }          // near sources older than the batch before: the launch falls back (k_dpw_dyn)
+    uint64_t r0, r1;
+    for (int j = jm; j < i0; j++) {
+        words_of(C, T, j, j - (i0 - 64), false, r0, r1);
+        if (r0 | r1) S.near.push_back(entry_from(C, j, j - (i0 - 64), r0, r1, k, false));
+    }
+    for (int l = 0; l < 64 && i0 + l < C.n; l++) {
+        words_of(C, T, i0 + l, l, true, r0, r1);
+        if (r0) S.walk.push_back(entry_from(C, i0 + l, l, r0, r1, k, true));
+    }
     return S;
 }
-inline unsigned lane_bits(const Entry& e, const int t) { unsigned b = 0; for (int q = 0; q < 6; q++) b |= (unsigned)((e.m[q] >> t) & 1ull) << q; return b; }
+inline unsigned lane_bits(const Entry& e, const int t) {
+    // the bits of dpw_static_bits again, from the step's masks (m[0] / m[1] of a reverse stop are its reverse-start / reverse-stop lanes)
+    const int sk = DPW_E_KIND(e.code);
+    unsigned b = 0;
+    if (sk == 3) { if ((e.m[0] >> t) & 1ull) b |= 1u; if ((e.m[1] >> t) & 1ull) b |= 2u; return b; }
+    for (int q = 0; q < 6; q++) b |= (unsigned)((e.m[q] >> t) & 1ull) << q;
+    return b;
+}
 
 }  // namespace
 
@@ -148,7 +183,9 @@ extern "C" int dpw_model_run(int n, const int32_t* ndx, const int32_t* stop_val,
         // ---- (2) near steps first (ascending sources onto an empty state: ">=" is the whole rule): the sources from the
         //      earliest p_near of a gene begin up to the batch, one at a time
         static const bool legacy = getenv("DPW_MODEL_LEGACY") != nullptr;      // the steps as the kernel made them before the schedule
-        const BatchSched SC = legacy ? BatchSched() : compile_batch(C, b);
+        BatchSched SC = legacy ? BatchSched() : compile_batch(C, b);
+        const bool legacy_b = legacy || SC.miss;        // (a batch whose near sources reach past the batch before: as the kernel's fallback does it)
+        if (SC.miss) stats[0]++;
         // one scheduled step: source values (score, traceb position, the extras of a forward stop) from the caller
         auto sched_step = [&](const Entry& e, const DpwS& S) {
             const int sk = DPW_E_KIND(e.code), sf = DPW_E_FRAME(e.code);
@@ -160,7 +197,7 @@ extern "C" int dpw_model_run(int n, const int32_t* ndx, const int32_t* stop_val,
                 else dpw_sstep_f3(LT[t], L[t], bits, e.j, e.s_ndx, S.vm, S.tbn, S.score, S.x0, S.x1, S.x2, M);
             }
         };
-        if (legacy) {
+        if (legacy_b) {
         int jmin = i0;
         for (int t = 0; t < 64; t++) if (T[t].i >= 0 && (T[t].kind == 0 || T[t].kind == 3)) jmin = std::min(jmin, std::max(T[t].q1, T[t].lo));
         for (int j = jmin; j < i0; j++) {
@@ -236,23 +273,32 @@ extern "C" int dpw_model_run(int n, const int32_t* ndx, const int32_t* stop_val,
                         take(t, true, L3score[f] + dpw_sel3(f, T[t].x0, T[t].x1, T[t].x2), L3i[f], 0, L3ndx[f]);
             }
         }
-        // ---- (5) reverse nodes: forward stops that overlap the 3' end of the gene (chains of forward stops)
+        // ---- (5) reverse nodes: forward stops that overlap the 3' end of the gene (chains of forward stops).  Round 6: a candidate
+        //      is priced through the chain's OWN overlapping start only (interval form of dpw_lean): a pair that is admissible through
+        //      another overlapping start q' lies on chain q' as well, and the plain connection (no overlapping start) is what the far
+        //      gene ends / the near steps already hold.
         for (int t = 0; t < 64; t++) {
             if (T[t].i < 0) continue;
             if (T[t].kind == 2) {
                 for (int j = T[t].q2; j < i0; j = C.q2[j]) {
                     if (ndx[j] >= T[t].stop_val + DPW_MAX_OPP_OVLP - 5) break;
                     stats[2]++;
-                    apply(load_source(C, j), t);
+                    const int s_ndx = ndx[j], tbj = C.tbn[j];
+                    const bool ok = j >= T[t].lo && tbj != -1 && s_ndx > LT[t].dlo0 && s_ndx < LT[t].dhi0 && tbj + s_ndx + 7 < LT[t].drhs0;
+                    take(t, ok, C.score[j] + T[t].csd, j, 0, s_ndx);
                 }
             } else if (T[t].kind == 3) {
                 for (int q = 0; q < 3; q++) {
                     if (!((T[t].vm >> q) & 1)) continue;
-                    const int n3s = dpw_sel3i(q, T[t].n3s0, T[t].n3s1, T[t].n3s2);
+                    const int dlo = dpw_sel3i(q, LT[t].dlo0, LT[t].dlo1, LT[t].dlo2), dhi = dpw_sel3i(q, LT[t].dhi0, LT[t].dhi1, LT[t].dhi2),
+                              drhs = dpw_sel3i(q, LT[t].drhs0, LT[t].drhs1, LT[t].drhs2);
+                    if (dlo == INT_MAX) continue;                       // an overlapping start worth nothing (x <= 0) is never taken
                     for (int j = dpw_sel3i(q, T[t].cq0, T[t].cq1, T[t].cq2); j < i0; j = C.q2[j]) {
-                        if (ndx[j] >= n3s + DPW_MAX_OPP_OVLP - 5) break;
+                        const int s_ndx = ndx[j], tbj = C.tbn[j];
+                        if (s_ndx >= dlo + DPW_MAX_OPP_OVLP) break;     // dlo = n3s - 5: the chain ends at n3s + MAX_OPP_OVLP - 5
                         stats[3]++;
-                        apply(load_source(C, j), t);
+                        const bool ok = j >= T[t].lo && tbj != -1 && s_ndx > dlo && s_ndx < dhi && tbj + s_ndx + 7 < drhs;
+                        take(t, ok, C.score[j] + dpw_sel3(q, T[t].x0, T[t].x1, T[t].x2), j, q + 1, s_ndx);
                     }
                 }
             }
@@ -289,7 +335,7 @@ extern "C" int dpw_model_run(int n, const int32_t* ndx, const int32_t* stop_val,
             static const bool log_rounds = getenv("DPW_MODEL_ROUNDS") != nullptr;
             if (log_rounds) fprintf(stderr, "R %d\n", rounds);
         } else
-        if (!legacy) {
+        if (!legacy_b) {
             // ---- (6) the walk from the schedule: the batch's own entries in lane order
             for (const Entry& e : SC.walk) {
                 const int k = e.lane, sk = DPW_E_KIND(e.code);
