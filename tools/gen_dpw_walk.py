@@ -48,13 +48,13 @@ ST = {"SC": pair(18), "SC_lo": "s18", "SC_hi": "s19", "TAGK": "s20", "TMP": "s21
       "SV": pair(26), "SV_lo": "s26", "SV_hi": "s27", "BVS_lo": "s28", "BVS_hi": "s29", "CM": pair(30), "C2b": pair(22), "BI": "s21", "CI": "s35",
       "TBN": "s35", "LHS": "s14", "SVM": "s15",         # (s32 - s34 and s100 / s101 are the compiler's: stack and frame pointers, scratch)
       "TODO": pair(16),
-      "E0": "s36", "E1": "s37", "E3": "s38",            # the source: its lane, its position, its chain index
+      "E0": "s36", "E1": "s37", "E3": "s38", "PSL": "s39",      # the source: its lane, its position, its chain index; LDS address of the pull's scratch double
       "MA": pair(40), "MB": pair(42), "MB_lo": "s42", "MB_hi": "s43", "MC": pair(44), "MD": pair(46), "ME": pair(48), "MF": pair(50),
       "RW": pair(52), "RW_lo": "s52", "RW_hi": "s53",
       "K0M": pair(54), "K1M": pair(56), "K2M": pair(58), "K3M": pair(60),         # the targets' kinds as lane masks
-      "SK2": pair(62), "SK3": pair(64), "SF1": pair(66), "SF2": pair(68),         # the sources': reverse starts, reverse stops; nodes of frame 1 / 2
-      "R3V0": pair(70), "R3V1": pair(72), "R3V2": pair(74), "TABM": pair(76)}     # reverse stops with an overlapping start in frame f; sources with a W1
-S_LAST = 77
+      "SK2": pair(62), "SK3": pair(64), "SK2T": pair(66),                         # the sources': plain reverse starts, reverse stops, reverse starts with a W1 (lane 63 in none)
+      "TABM": pair(68), "GBM": pair(70)}                                          # sources with a W1; gene begins among the targets
+S_LAST = 71
 def s_clobber(near):
     return ["s14", "s15"] + ["s%d" % i for i in range(16, 32)] + ["s35"] + ["s%d" % i for i in range(36, S_LAST + 1)] + ["vcc"]
 
@@ -85,22 +85,25 @@ def block(near):
     a("v_cmp_eq_u32_e64 {K1M}, 1, {A}")
     a("v_cmp_eq_u32_e64 {K2M}, 2, {A}")
     a("v_cmp_eq_u32_e64 {K3M}, 3, {A}")
-    for f in range(3):
-        a("v_and_b32_e32 {A}, 0x%x, %%[kinfo]" % (0x100 << f))
-        a("v_cmp_ne_u32_e32 vcc, 0, {A}")
-        a("s_and_b64 {R3V%d}, vcc, {K3M}" % f)
     a("v_bfe_u32 {A}, %[kinfo], 2, 2")
     a("v_lshlrev_b32_e64 {FB}, {A}, 1")
     if near:
         a("v_and_b32_e32 {A}, 0x83, %[pk]")
         a("v_cmp_eq_u32_e64 {SK2}, 2, {A}")
         a("v_cmp_eq_u32_e64 {SK3}, 3, {A}")
-        a("v_bfe_u32 {A}, %[pk], 2, 2")
     else:
         a("s_mov_b64 {SK2}, {K2M}")
         a("s_mov_b64 {SK3}, {K3M}")
-    a("v_cmp_eq_u32_e64 {SF1}, 1, {A}")
-    a("v_cmp_eq_u32_e64 {SF2}, 2, {A}")
+    # A step never asks whether it was the last one: when the list is empty s_ff1 yields -1, which the dispatch reads as lane 63, and
+    # lane 63 is no reverse node in the masks the dispatch tests -- so the end of the list, like a real source in lane 63, arrives at
+    # the forward-stop path, which tells them apart (Llast).  SK2: the PLAIN reverse starts (no reverse stop within 3 * OPER_DIST
+    # bases): they reach every gene begin behind them, so their mask is arithmetic on the lane number, not a word to read.
+    a("s_bitset0_b64 {SK2}, 63")
+    a("s_bitset0_b64 {SK3}, 63")
+    a("s_and_b64 {SK2T}, {SK2}, {TABM}")
+    a("s_andn2_b64 {SK2}, {SK2}, {TABM}")
+    a("s_or_b64 {GBM}, {K0M}, {K3M}")
+    if not near: a("s_add_i32 {PSL}, %[igmb], 496")      # igm[62] of the LDS table: nobody reads past igm[60]
 
     def commit(to, tag, where=None):
         e = where or a
@@ -128,30 +131,31 @@ def block(near):
     a("Lloop_%=:")
     a("s_ff1_i32_b64 {E0}, {TODO}")
     a("s_bitset0_b64 {TODO}, {E0}")
-    a("v_readlane_b32 {RW_lo}, {W0_lo}, {E0}")
-    a("v_readlane_b32 {RW_hi}, {W0_hi}, {E0}")
     a("s_bitcmp1_b64 {SK2}, {E0}")
     a("s_cbranch_scc0 Lstop_%=")
-    if EXP in ("noop", "nor5"): a("s_branch " + nxt)
-    # ---- R5: a reverse start offers score + the intergenic term to the gene begins behind it (RW); to the reverse stops within
-    #      3 * OPER_DIST bases among them (W1) the distance term instead of the constant
+    if EXP in ("noop", "nor5"): a("s_branch Lloop_%=")
+    # ---- R5 (plain): a reverse start offers score + the constant intergenic term to every gene begin behind it
     a("v_readlane_b32 {SC_lo}, %s, {E0}" % sc_lo)
     a("v_readlane_b32 {SC_hi}, %s, {E0}" % sc_hi)
-    a("s_bitcmp1_b64 {TABM}, {E0}")
-    a("s_cbranch_scc1 Lr5tab_%=")
+    if not near: a("s_lshl_b64 {RW}, -2, {E0}")          # the lanes behind it (the batch before lies behind every lane)
+    a("s_nop 0" if not near else "s_nop 1")
     a("v_add_f64 {W}, {SC}, %[negc]")
-    a("Lr5c_%=:")
     a("v_cmp_ge_f64_e32 vcc, {W}, {LV}")
-    a("s_and_b64 vcc, vcc, {RW}")
-    a("s_cbranch_vccnz Lr5take_%=")              # nobody takes it (two steps in three): straight on
-    a(nxt + ":")
-    a("s_cmp_lg_u64 {TODO}, 0")
-    a("s_cbranch_scc1 Lloop_%=")
-    a("s_branch Ldone_%=")
+    if not near: a("s_and_b64 vcc, vcc, {RW}")
+    a("s_and_b64 vcc, vcc, {GBM}")
+    a("s_cbranch_vccnz Lr5take_%=")              # nobody takes it (two steps in three): straight back
+    a("s_branch Lloop_%=")
+    a(nxt + ":")                                 # (the other kinds come back here)
+    a("s_branch Lloop_%=")
     c("Lr5take_%=:")
     chain_index(c)
-    commit(nxt, "{E3}", c)
+    commit("Lloop_%=", "{E3}", c)
+    # ---- a reverse start with reverse stops within 3 * OPER_DIST bases (W1): to those the distance term instead of the constant
     c("Lr5tab_%=:")
+    c("v_readlane_b32 {RW_lo}, {W0_lo}, {E0}")
+    c("v_readlane_b32 {RW_hi}, {W0_hi}, {E0}")
+    c("v_readlane_b32 {SC_lo}, %s, {E0}" % sc_lo)
+    c("v_readlane_b32 {SC_hi}, %s, {E0}" % sc_hi)
     c("v_readlane_b32 {MB_lo}, {W1_lo}, {E0}")
     c("v_readlane_b32 {MB_hi}, {W1_hi}, {E0}")
     c("v_readlane_b32 {E1}, %s, {E0}" % src_ndx)
@@ -159,27 +163,55 @@ def block(near):
     igm_lookup(c, "{MV}", "{MB}", "Lr5t0_%=")
     c("v_add_f64 {W}, {SC}, {MV}")
     c("s_mov_b64 exec, -1")
-    c("s_branch Lr5c_%=")
+    c("v_cmp_ge_f64_e32 vcc, {W}, {LV}")
+    c("s_and_b64 vcc, vcc, {RW}")
+    c("s_cbranch_vccnz Lr5take_%=")
+    c("s_branch Lloop_%=")
     # ---- a stop node
     a("Lstop_%=:")
     a("s_bitcmp1_b64 {SK3}, {E0}")
-    a("s_cbranch_scc0 " + (nxt if EXP in ("noop", "nof3") else "Lf3_%="))
+    a("s_cbranch_scc1 Lr3_%=")
+    a("s_bitcmp1_b64 {SK2T}, {E0}")
+    a("s_cbranch_scc1 " + (nxt if EXP in ("noop", "nor5") else "Lr5tab_%="))
+    a("s_cmp_lt_u32 {E0}, 63")
+    a("s_cbranch_scc1 Lf3_%=")
+    # the end of the list (-1), or a source in lane 63 by its true kind
+    a("s_cmp_lt_i32 {E0}, 0")
+    a("s_cbranch_scc1 Ldone_%=")
+    a("v_readlane_b32 {SVM}, %s, {E0}" % kinfo)   # kind | frame << 2 | ...
+    a("s_and_b32 {TMP}, {SVM}, 0x83")
+    a("s_cmp_eq_u32 {TMP}, 3")
+    a("s_cbranch_scc1 Lr3_%=")
+    a("s_cmp_eq_u32 {TMP}, 2")
+    a("s_cbranch_scc1 Lr5tab_%=")                 # (the path that reads the words: right for a plain reverse start as well)
+    a("s_branch Lf3_%=")
+    a("Lr3_%=:")
     if EXP in ("noop", "nor3"): a("s_branch " + nxt)
+    a("v_readlane_b32 {RW_lo}, {W0_lo}, {E0}")
+    a("v_readlane_b32 {RW_hi}, {W0_hi}, {E0}")
     # ---- R3: a reverse stop offers score + cs to the reverse starts of its frame inside its ORF (MA), score + x[frame] to the reverse
     #      stops inside it that have an overlapping start in its frame (MB & r3v[frame])
     a("v_readlane_b32 {SC_lo}, %s, {E0}" % r3_lo)
     a("v_readlane_b32 {SC_hi}, %s, {E0}" % r3_hi)
+    a("v_readlane_b32 {SVM}, %s, {E0}" % kinfo)   # the source's frame: bits 2, 3
     a("s_and_b64 {MA}, {RW}, {K2M}")
     a("s_and_b64 {MB}, {RW}, {K3M}")
-    a("s_bitcmp1_b64 {SF2}, {E0}")
+    a("s_bitcmp1_b32 {SVM}, 3")
     a("s_cbranch_scc1 Lr3f2_%=")
-    a("s_bitcmp1_b64 {SF1}, {E0}")
+    a("s_bitcmp1_b32 {SVM}, 2")
     a("s_cbranch_scc1 Lr3f1_%=")
     for f, lab in ((0, None), (1, "Lr3f1_%="), (2, "Lr3f2_%=")):
         if lab: a(lab + ":")
-        a("s_and_b64 {TM}, {MB}, {R3V%d}" % f)
+        a("s_mov_b64 {TM}, {MA}")
+        a("s_cmp_eq_u64 {MB}, 0")
+        a("s_cbranch_scc1 Lr3n%d_%%=" % f)
+        a("v_and_b32_e32 {A}, 0x%x, %%[kinfo]" % (0x100 << f))      # the reverse stops among them that have an overlapping start in its frame
+        a("v_cmp_ne_u32_e32 vcc, 0, {A}")
+        a("s_and_b64 {TM}, vcc, {MB}")
         a("s_or_b64 {TM}, {TM}, {MA}")
-        a("s_cbranch_scc0 " + nxt)
+        a("Lr3n%d_%%=:" % f)
+        a("s_cmp_eq_u64 {TM}, 0")
+        a("s_cbranch_scc1 " + nxt)
         a("v_add_f64 {W}, {SC}, {X%d}" % f)
         if f < 2: a("s_branch Lr3j_%=")
     a("Lr3j_%=:")
@@ -196,6 +228,10 @@ def block(near):
     commit(nxt, "{E3}")
     # ---- F3: a forward stop; all four kinds of targets
     a("Lf3_%=:")
+    if EXP in ("noop", "nof3"): a("s_branch " + nxt)
+    a("v_readlane_b32 {RW_lo}, {W0_lo}, {E0}")
+    a("v_readlane_b32 {RW_hi}, {W0_hi}, {E0}")
+    a("s_nop 0")
     a("s_and_b64 {MA}, {RW}, {K0M}")
     a("s_and_b64 {MC}, {RW}, {K1M}")
     a("s_and_b64 {MD}, {RW}, {K2M}")
@@ -217,69 +253,49 @@ def block(near):
         a("v_readlane_b32 {TAGK}, {LT}, {E0}")
         a("s_cmp_eq_u64 {MF}, 0")
         a("s_cbranch_scc1 Lnopull_%=")
-        # pull: the forward starts of its ORF before it in the batch (final by now): (value, index) maximum, ties to the larger index
+        # pull: the forward starts of its ORF before it in the batch (final by now): (value, index) maximum, ties to the larger index.
+        # Round 6: not a loop over the candidates (ten instructions each) -- the lane's own value goes to a scratch double in LDS, the
+        # candidates' lanes add theirs with ONE ds_max_f64, every lane reads the maximum back; the candidates that hold it are a vote,
+        # the last of them the index (ties to the larger index), and whether it beats the lane's own traceb is one more compare.
         a("v_add_f64 {MV}, {LV}, %[cs]")         # what each lane offers as a forward start
-        a("v_readlane_b32 {BVS_lo}, {LV_lo}, {E0}")
-        a("v_readlane_b32 {BVS_hi}, {LV_hi}, {E0}")
+        a("v_mov_b32_e32 {A}, {PSL}")
+        a("s_lshl_b64 {TM}, 1, {E0}")
+        a("s_mov_b64 exec, {TM}")
+        a("ds_write_b64 {A}, {LV}")
+        a("s_mov_b64 exec, {MF}")
+        a("ds_max_f64 {A}, {MV}")
+        a("s_mov_b64 exec, -1")
+        a("ds_read_b64 {W}, {A}")
         a("s_and_b32 {BI}, {TAGK}, 0xfffffff")
         a("s_cmp_lt_i32 {TAGK}, 0")
         a("s_cselect_b32 {BI}, -1, {BI}")
-        a("s_mov_b64 {CM}, {MF}")
-        a("v_mov_b32_e32 {W_lo}, {BVS_lo}")      # the running best, uniform in a VGPR pair (a VALU compare takes one scalar operand)
-        a("v_mov_b32_e32 {W_hi}, {BVS_hi}")
-        # A candidate wins a tie when its index lies behind the current traceb's.  Candidates come in ascending order, so that is
-        # every candidate after the first one taken, and before that the lanes behind lane BI - i0: loop A (strict >) over the lanes
-        # at or below it until something is taken, loop B (>=) over everything else.
-        a("s_sub_i32 {CI}, {BI}, %[i0]")
-        a("s_add_i32 {CI}, {CI}, 1")
-        a("s_max_i32 {CI}, {CI}, 0")
-        a("s_bfm_b64 {C2b}, {CI}, 0")            # lanes below lane BI - i0 + 1 (BI < i0 + 63 here; before the batch: none)
-        a("s_and_b64 {C2b}, {C2b}, {CM}")
-        a("s_andn2_b64 {CM}, {CM}, {C2b}")
-        a("s_cmp_eq_u64 {C2b}, 0")
-        a("s_cbranch_scc1 LpullB_%=")
-        a("LpullA_%=:")
-        a("s_ff1_i32_b64 {CI}, {C2b}")
-        a("s_bitset0_b64 {C2b}, {CI}")
-        a("v_readlane_b32 {SV_lo}, {MV_lo}, {CI}")
+        a("s_waitcnt lgkmcnt(0)")
+        a("v_cmp_eq_f64_e32 vcc, {W}, {MV}")     # the candidates that hold the maximum
+        a("s_and_b64 {CM}, vcc, {MF}")
+        a("s_cbranch_scc0 LpullE_%=")             # none: the lane's own value is larger than every candidate's
+        a("s_flbit_i32_b64 {CI}, {CM}")
+        a("s_sub_i32 {CI}, 63, {CI}")             # the last of them
+        a("v_cmp_gt_f64_e32 vcc, {W}, {LV}")      # (in lane E0: the maximum beats the lane's own value)
+        a("s_add_i32 {TMP}, {CI}, %[i0]")
+        a("s_bitcmp1_b64 vcc, {E0}")
+        a("s_cbranch_scc1 Lptake_%=")
+        a("s_cmp_gt_i32 {TMP}, {BI}")             # equal values: the larger index
+        a("s_cbranch_scc0 LpullE_%=")
+        a("Lptake_%=:")
+        a("s_mov_b32 {TAGK}, {TMP}")
+        a("v_readlane_b32 {SV_lo}, {MV_lo}, {CI}")      # the winner's own bits
         a("v_readlane_b32 {SV_hi}, {MV_hi}, {CI}")
-        a("s_cmp_lg_u64 {C2b}, 0")
+        a("s_mov_b64 exec, {TM}")
         a("s_nop 0")
-        a("v_cmp_gt_f64_e32 vcc, {SV}, {W}")
-        a("s_cbranch_vccnz LptakeA_%=")
-        a("s_cbranch_scc1 LpullA_%=")
-        a("s_branch LpullB_%=")
-        a("LptakeA_%=:")
-        a("v_mov_b32_e32 {W_lo}, {SV_lo}")
-        a("v_mov_b32_e32 {W_hi}, {SV_hi}")
-        a("s_add_i32 {TAGK}, {CI}, %[i0]")
-        a("s_or_b64 {CM}, {CM}, {C2b}")           # what is left of loop A's lanes goes on in loop B
-        a("LpullB_%=:")
-        a("s_cmp_eq_u64 {CM}, 0")
-        a("s_cbranch_scc1 LpullE_%=")
-        a("LpullB1_%=:")
-        a("s_ff1_i32_b64 {CI}, {CM}")
-        a("s_bitset0_b64 {CM}, {CI}")
-        a("v_readlane_b32 {SV_lo}, {MV_lo}, {CI}")
-        a("v_readlane_b32 {SV_hi}, {MV_hi}, {CI}")
-        a("s_nop 1")
-        a("v_cmp_ge_f64_e32 vcc, {SV}, {W}")
-        a("s_cbranch_vccz LpullB2_%=")
-        a("v_mov_b32_e32 {W_lo}, {SV_lo}")
-        a("v_mov_b32_e32 {W_hi}, {SV_hi}")
-        a("s_add_i32 {TAGK}, {CI}, %[i0]")
-        a("LpullB2_%=:")
-        a("s_cmp_lg_u64 {CM}, 0")
-        a("s_cbranch_scc1 LpullB1_%=")
+        a("v_mov_b32_e32 {LV_lo}, {SV_lo}")
+        a("v_mov_b32_e32 {LV_hi}, {SV_hi}")
+        a("v_mov_b32_e32 {SVL_lo}, {SV_lo}")
+        a("v_mov_b32_e32 {SVL_hi}, {SV_hi}")
+        a("v_mov_b32_e32 {LT}, {TAGK}")
+        a("s_mov_b64 exec, -1")
         a("LpullE_%=:")
         a("s_cmp_lt_i32 {TAGK}, 0")              # a gene end that was never reached connects to nothing
         a("s_cbranch_scc1 " + nxt)
-        a("s_lshl_b64 {TM}, 1, {E0}")            # (v_writelane with a scalar value AND a scalar lane select is over the constant-bus limit)
-        a("s_mov_b64 exec, {TM}")
-        a("v_mov_b64_e32 {LV}, {W}")
-        a("v_mov_b64_e32 {SVL}, {W}")
-        a("v_mov_b32_e32 {LT}, {TAGK}")
-        a("s_mov_b64 exec, -1")
         a("Lnopull_%=:")
     a("s_or_b64 {TM}, {MA}, {MC}")
     a("s_or_b64 {TM}, {TM}, {MD}")
