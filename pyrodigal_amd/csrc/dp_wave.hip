@@ -464,7 +464,7 @@ k_dpw_sched(const int32_t* __restrict__ cbase, const int32_t* __restrict__ bbase
         const lanemask gbm = k0 | k3;
         const int jm = wave_min_i32((kind == 0 || kind == 3) ? max(ta.q1[base + ii], t_lo) : i0);
         if (jm < i0 - 64 || force_miss) {
-            if (lane == 0) { atomicAdd(&ta.scur[1], 1u); ta.shdr[bg] = DpwSchedHdr{DPW_SCHED_NONE, 0u, jm, 0}; }
+            if (lane == 0) { atomicAdd(&ta.scur[1], 1u); ta.shdr[bg] = DpwSchedHdr{DPW_SCHED_NONE, 0u, 0, 0}; }
             continue;
         }
         // per-lane constants of the position tests (dpw_st / dpw_static_bits)
@@ -549,7 +549,13 @@ k_dpw_sched(const int32_t* __restrict__ cbase, const int32_t* __restrict__ bbase
             __builtin_amdgcn_wave_barrier();            // (the next batch of this wave rewrites nd)
             rec[2 * lane] = make_uint4((unsigned)w0, (unsigned)(w0 >> 32), (unsigned)w1, (unsigned)(w1 >> 32));
         }
-        if (lane == 0) ta.shdr[bg] = DpwSchedHdr{0u, 0u, jm, 0};
+        {
+            // the header: which lanes hold a stop node, and the rank of the first of them among the stop nodes of the contig -- a chain's
+            // wavefront finds the extras of its stop nodes (dense by rank) from these two without reading the rank of every node first
+            const lanemask stops = k1 | k3;
+            const int r = (ta.srank != nullptr && stops) ? ta.srank[base + i0 + __builtin_ctzll(stops)] : 0;
+            if (lane == 0) ta.shdr[bg] = DpwSchedHdr{0u, (uint32_t)r, (int32_t)(uint32_t)stops, (int32_t)(uint32_t)(stops >> 32)};
+        }
     }
 }
 
@@ -922,7 +928,7 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
     __syncthreads();
     const DpwModel M{mc->st_wt, mc->negc, s_igm};
     WavePtrs P;
-    const __attribute__((address_space(4))) uint32_t* s_hdr; const uint4* g_words;
+    k_uint4* s_hdr; const uint4* g_words;
     {
         const DpwTopoArrays& ta = groups.g[cd.group];
         P.ndx = ta.ndx + cd.topo_off; P.stopv = ta.stop_val + cd.topo_off; P.kf = ta.kf + cd.topo_off;
@@ -932,7 +938,7 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
         P.ext = g_ext + (ta.srank != nullptr ? cd.soff : cd.off);
         P.score = buf.score + cd.off; P.traceb = buf.traceb + cd.off; P.tbn = buf.tbn + cd.off; P.ov = buf.ov_mark + cd.off;
         P.sfxv = g_sfxv + cd.off; P.sfxi = g_sfxi + cd.off;
-        s_hdr = (const __attribute__((address_space(4))) uint32_t*)(ta.shdr + cd.sched_b0);
+        s_hdr = (k_uint4*)(ta.shdr) + cd.sched_b0;
         g_words = ta.sent + (size_t)cd.sched_b0 * (2 * DPW_SCHED_STRIDE) + 2 * lane;       // this lane's record of batch 0: {W0, W1}, {N0, N1}
     }
     // a launch ends when its longest chain does: long chains issue first, the short ones fill their stalls
@@ -955,14 +961,32 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
     };
     for (int b = 0; b < nb; b++) {
         const int i0 = b << 6;
-        if (s_hdr[4 * b] == DPW_SCHED_NONE) return;   // the batch's near sources reach past the batch before: the host repeats the launch with k_dpw_dyn
+        const u32x4 hdr = s_hdr[b];                  // {0 or DPW_SCHED_NONE, rank of the batch's first stop node, lanes that hold a stop node (lo, hi)}
         // the batch's words of the step schedule (dpw_core.h): this lane's node as a source towards its own batch, and the node this lane
         // held one batch ago towards this batch
         const uint4 ww = g_words[(size_t)b * (2 * DPW_SCHED_STRIDE)];
         uint4 nw = make_uint4(0u, 0u, 0u, 0u);
         if (b > 0) nw = g_words[(size_t)(b - 1) * (2 * DPW_SCHED_STRIDE) + 1];
         DpwT T; int kfb;
-        load_target_w(T, kfb, P, i0, lane, n, M.negc);
+        {
+            // load_target_w with the extras' index from the header: rank of the first stop + the stop lanes before this one (the loads of the
+            // extras then go out with the topology loads, not behind the rank's)
+            const int i = i0 + lane;
+            const bool in = i < n;
+            const int ii = in ? i : n - 1;
+            const lanemask stops = ((lanemask)hdr.w << 32) | hdr.z;
+            const int er = P.srank != nullptr ? (int)hdr.y + __popcll(stops & below) : ii;
+            kfb = P.kf[ii];
+            T.i = in ? i : -1;
+            T.ndx = P.ndx[ii]; T.stop_val = P.stopv[ii]; T.lo = in ? P.lo[ii] : INT_MAX; T.q1 = P.q1[ii]; T.q2 = P.q2[ii];
+            T.cs = P.cs[ii];
+            T.vm = 0; T.x0 = T.x1 = T.x2 = 0.0;
+            T.n3n0 = T.n3n1 = T.n3n2 = T.n3s0 = T.n3s1 = T.n3s2 = 0; T.cq0 = T.cq1 = T.cq2 = DPW_NONE;
+            if (in && ((stops >> lane) & 1ull)) load_ext(P.ext + er, T);
+            if (hdr.x == DPW_SCHED_NONE) return;      // the batch's near sources reach past the batch before: the host repeats the launch with k_dpw_dyn
+            T.kind = in ? DPW_KIND(kfb) : -1; T.frame = DPW_FRAME(kfb);
+            T.csd = T.cs + M.negc;
+        }
         const DpwLT LT = dpw_lean(T);
         const bool act = T.i >= 0;
         // (a forward start keeps cs in the x[] of its frame: what it offers the forward stop of its ORF is score + x[frame], as a forward
@@ -1077,15 +1101,15 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
             open_chain();
             while (__any(j < i0 || q < 3)) {
                 if (j < i0) {
-                    const int s_ndx = P.ndx[j];
+                    // (the four loads of a hop go out together: a hop is one round trip, whether the chain ends here or not)
+                    const int s_ndx = P.ndx[j], tbj = P.tbn[j], nj = P.q2[j];
+                    const double sj = P.score[j];
                     // a reverse start's chain ends at stop_val + MAX_OPP_OVLP - 5 = dlo0 + MAX_OPP_OVLP - 1, a reverse stop's at n3s + MAX_OPP_OVLP - 5 = dlo + MAX_OPP_OVLP
                     if (s_ndx >= dlo + DPW_MAX_OPP_OVLP - (r5 ? 1 : 0)) j = DPW_NONE;
                     else {
-                        const int tbj = P.tbn[j];
-                        const double sj = P.score[j];
                         const bool ok = (j >= T.lo) & (tbj != -1) & (s_ndx > dlo) & (s_ndx < dhi) & (tbj + s_ndx + 7 < drhs);
                         take(ok, sj + xq, j, r5 ? 0 : q, s_ndx);          // (q was advanced when the chain was opened: ov_mark + 1)
-                        j = P.q2[j];
+                        j = nj;
                     }
                 }
                 if (j >= i0 && q < 3) open_chain();

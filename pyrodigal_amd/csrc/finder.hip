@@ -1711,10 +1711,6 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                 int max_nodes_g = 0;
                 for (int i = 0; i < NC; i++) max_nodes_g = std::max(max_nodes_g, h_cbase[(size_t)g * (NC + 1) + i + 1] - h_cbase[(size_t)g * (NC + 1) + i]);
                 pga_launch_dpw_topo(wgroups.g[g], ga[g].type, ga[g].strand, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], st, max_nodes_g);
-                if (use_sched) {
-                    pga_launch_dpw_sched(wgroups.g[g], d_cbase + (size_t)g * (NC + 1), d_bbase + (size_t)g * (NC + 1), NC, max_batches[g], st);
-                    HT(c, hipMemcpyAsync(h_scur + 2 * g, wgroups.g[g].scur, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-                }
                 sl.topo_q2 = wgroups.g[g].q2; sl.ext = wbuf.ext; sp.cs_out = wbuf.cs;
                 // (direct mode: the tail reads star_ptr only at the stop nodes, which k_ovl_stops always writes)
                 sl.fill_star_ptr = !(stage == 0 && direct_gather);
@@ -1723,6 +1719,11 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                              d_chains, d_cc + (size_t)g * NC, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], f->d_sd_lut, st, 0,
                              (meta_run || n_cs_tasks > 0) ? f->d_gil + f->gil_off[g] : nullptr, (meta_run || n_cs_tasks > 0) ? f->gil_stride[g] : 0, f->d_model_rank,
                              d_cs_tasks, n_cs_tasks, d_cs_entries, &sl);
+            if (use_wave && use_sched) {
+                // (behind the scoring launches: the schedule's headers carry the stop nodes' ranks, which k_ovl_topo writes there)
+                pga_launch_dpw_sched(wgroups.g[g], d_cbase + (size_t)g * (NC + 1), d_bbase + (size_t)g * (NC + 1), NC, max_batches[g], st);
+                HT(c, hipMemcpyAsync(h_scur + 2 * g, wgroups.g[g].scur, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            }
             NodeArrays na{ga[g].ndx, ga[g].stop_val, ga[g].type, ga[g].strand, ca.cscore, ca.sscore, ca.rscore, ca.uscore, ca.star_ptr};
             if (!use_wave && stage == 0) pga_launch_dp_prepare(d_chains + g_c0[g], nch, g_n0[g], nn, na, c->d_model_const, dp, st);
         }
