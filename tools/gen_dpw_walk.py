@@ -39,7 +39,8 @@ VT = {"W": _v(10, 2), "W_lo": _v(10), "W_hi": _v(11), "TG": _v(12), "A": _v(13),
       "W0_lo": _v(30), "W0_hi": _v(31), "W1_lo": _v(32), "W1_hi": _v(33)}
 VT.update({"SVL_lo": _v(28), "SVL_hi": _v(29)})
 VT.update(PIN); VT.update(PIN_NEAR); VT.update(PIN_WALK)
-V_CLOBBER = [_v(k) for k in range(10, 18)]
+VT.update({"DLM": _v(34), "DHM": _v(35)})       # per lane: the widest of the three candidate intervals (min dlo, max dhi)
+V_CLOBBER = [_v(k) for k in range(10, 18)] + [_v(34), _v(35)]
 
 def pair(n): return "s[%d:%d]" % (n, n + 1)
 ST = {"SC": pair(18), "SC_lo": "s18", "SC_hi": "s19", "TAGK": "s20", "TMP": "s21", "TM": pair(22), "OK": pair(24),
@@ -103,6 +104,8 @@ def block(near):
     a("s_and_b64 {SK2T}, {SK2}, {TABM}")
     a("s_andn2_b64 {SK2}, {SK2}, {TABM}")
     a("s_or_b64 {GBM}, {K0M}, {K3M}")
+    a("v_min3_i32 {DLM}, %[dlo0], %[dlo1], %[dlo2]")
+    a("v_max3_i32 {DHM}, %[dhi0], %[dhi1], %[dhi2]")
     if not near: a("s_add_i32 {PSL}, %[igmb], 496")      # igm[62] of the LDS table: nobody reads past igm[60]
 
     def commit(to, tag, where=None):
@@ -226,41 +229,28 @@ def block(near):
     a("s_cbranch_vccz " + nxt)
     chain_index(a)
     commit(nxt, "{E3}")
-    # ---- F3: a forward stop; all four kinds of targets
+    # ---- F3: a forward stop.  What it offers nearly every lane it reaches is score + the constant intergenic term, as a reverse start does:
+    #      that is the straight path.  The exceptions branch off only where the source's word says they exist -- forward starts within
+    #      3 * OPER_DIST bases (the distance term), forward stops whose ORF holds it (an operon through ITS overlapping start), reverse starts
+    #      whose interval holds its position, reverse stops with an admissible overlapping start -- and each prices its own lanes under EXEC.
     a("Lf3_%=:")
     if EXP in ("noop", "nof3"): a("s_branch " + nxt)
     a("v_readlane_b32 {RW_lo}, {W0_lo}, {E0}")
     a("v_readlane_b32 {RW_hi}, {W0_hi}, {E0}")
-    a("s_nop 0")
-    a("s_and_b64 {MA}, {RW}, {K0M}")
-    a("s_and_b64 {MC}, {RW}, {K1M}")
-    a("s_and_b64 {MD}, {RW}, {K2M}")
-    a("s_and_b64 {ME}, {RW}, {K3M}")
-    a("v_readlane_b32 {E1}, %s, {E0}" % src_ndx)
-    chain_index(a)
-    a("s_mov_b64 {MB}, 0")
-    a("s_bitcmp1_b64 {TABM}, {E0}")
-    a("s_cbranch_scc0 Lf3nt_%=")
-    a("v_readlane_b32 {MB_lo}, {W1_lo}, {E0}")
-    a("v_readlane_b32 {MB_hi}, {W1_hi}, {E0}")
-    a("Lf3nt_%=:")
-    if near:
-        a("v_readlane_b32 {TBN}, {NB}, {E0}")
-    else:
+    if not near:
         a("s_lshl_b64 {TM}, -1, {E0}")           # lanes from the source on: the forward starts behind it are targets, those before it are pulled
-        a("s_andn2_b64 {MF}, {MA}, {TM}")
-        a("s_and_b64 {MA}, {MA}, {TM}")
         a("v_readlane_b32 {TAGK}, {LT}, {E0}")
-        a("s_cmp_eq_u64 {MF}, 0")
-        a("s_cbranch_scc1 Lnopull_%=")
+        a("s_and_b64 {MA}, {RW}, {K0M}")
+        a("s_andn2_b64 {MF}, {MA}, {TM}")
+        a("s_cbranch_scc0 Lnopull_%=")
         # pull: the forward starts of its ORF before it in the batch (final by now): (value, index) maximum, ties to the larger index.
-        # Round 6: not a loop over the candidates (ten instructions each) -- the lane's own value goes to a scratch double in LDS, the
-        # candidates' lanes add theirs with ONE ds_max_f64, every lane reads the maximum back; the candidates that hold it are a vote,
-        # the last of them the index (ties to the larger index), and whether it beats the lane's own traceb is one more compare.
+        # Not a loop over the candidates -- the lane's own value goes to a scratch double in LDS, the candidates' lanes add theirs with
+        # ONE ds_max_f64, every lane reads the maximum back; the candidates that hold it are a vote, the last of them the index (ties
+        # to the larger index), and whether it beats the lane's own traceb is one more compare.
         a("v_add_f64 {MV}, {LV}, %[cs]")         # what each lane offers as a forward start
         a("v_mov_b32_e32 {A}, {PSL}")
-        a("s_lshl_b64 {TM}, 1, {E0}")
-        a("s_mov_b64 exec, {TM}")
+        a("s_lshl_b64 {C0}, 1, {E0}")
+        a("s_mov_b64 exec, {C0}")
         a("ds_write_b64 {A}, {LV}")
         a("s_mov_b64 exec, {MF}")
         a("ds_max_f64 {A}, {MV}")
@@ -285,8 +275,8 @@ def block(near):
         a("s_mov_b32 {TAGK}, {TMP}")
         a("v_readlane_b32 {SV_lo}, {MV_lo}, {CI}")      # the winner's own bits
         a("v_readlane_b32 {SV_hi}, {MV_hi}, {CI}")
-        a("s_mov_b64 exec, {TM}")
-        a("s_nop 0")
+        a("s_lshl_b64 {C2}, 1, {E0}")
+        a("s_mov_b64 exec, {C2}")
         a("v_mov_b32_e32 {LV_lo}, {SV_lo}")
         a("v_mov_b32_e32 {LV_hi}, {SV_hi}")
         a("v_mov_b32_e32 {SVL_lo}, {SV_lo}")
@@ -297,102 +287,136 @@ def block(near):
         a("s_cmp_lt_i32 {TAGK}, 0")              # a gene end that was never reached connects to nothing
         a("s_cbranch_scc1 " + nxt)
         a("Lnopull_%=:")
-    a("s_or_b64 {TM}, {MA}, {MC}")
-    a("s_or_b64 {TM}, {TM}, {MD}")
-    a("s_or_b64 {TM}, {TM}, {ME}")
-    a("s_cbranch_scc0 " + nxt)
     a("v_readlane_b32 {SC_lo}, %s, {E0}" % sc_lo)
     a("v_readlane_b32 {SC_hi}, %s, {E0}" % sc_hi)
-    a("s_mov_b64 {OK}, {MA}")                    # forward starts behind it: always admissible
-    a("v_mov_b64_e32 {W}, %[negc]")
-    a("v_mov_b32_e32 {TG}, {E3}")
-    a("s_cmp_eq_u64 {MB}, 0")                    # ... those within 3 * OPER_DIST bases: igm[d] up to OPER_DIST, 0 beyond
-    a("s_cbranch_scc1 Lf3a_%=")
-    igm_lookup(a, "{W}", "{MB}", "Lf3t0_%=")
-    a("s_mov_b64 exec, -1")
+    a("v_readlane_b32 {E1}, %s, {E0}" % src_ndx)
+    a("s_and_b64 {OK}, {RW}, {GBM}")             # the gene begins it reaches
+    if not near: a("s_and_b64 {OK}, {OK}, {TM}")  # (behind it; the forward starts before it were the pulled ones)
+    a("v_add_f64 {W}, {SC}, %[negc]")
+    a("s_bitcmp1_b64 {TABM}, {E0}")
+    a("s_cbranch_scc1 Lf3tab_%=")
     a("Lf3a_%=:")
-    a("s_cmp_eq_u64 {MC}, 0")                    # forward stops whose ORF holds it: through the SOURCE's overlapping start of the lane's frame
-    a("s_cbranch_scc1 Lf3b_%=")
-    a("v_readlane_b32 {SVM}, %s, {E0}" % kinfo)
-    a("s_lshr_b32 {SVM}, {SVM}, 8")              # vm sits in bits 8 .. 10
-    a("s_nop 0")
-    a("v_and_b32_e32 {A}, {SVM}, {FB}")
-    a("v_cmp_ne_u32_e32 vcc, 0, {A}")
-    a("s_and_b64 {TM}, vcc, {MC}")
-    a("s_cbranch_scc0 Lf3b_%=")
-    a("s_or_b64 {OK}, {OK}, {TM}")
-    xs = ("{NX0_lo}", "{NX0_hi}", "{NX1_lo}", "{NX1_hi}", "{NX2_lo}", "{NX2_hi}") if near else ("{X0_lo}", "{X0_hi}", "{X1_lo}", "{X1_hi}", "{X2_lo}", "{X2_hi}")
-    for q, nm in enumerate(("SX0_lo", "SX0_hi", "SX1_lo", "SX1_hi", "SX2_lo", "SX2_hi")):
-        a("v_readlane_b32 {%s}, %s, {E0}" % (nm, xs[q]))
-    for f in range(3):
-        if f: a("s_mov_b64 exec, -1")             # (the compare must see every lane)
-        a("v_cmp_eq_u32_e32 vcc, %d, {FB}" % (1 << f))
-        a("s_and_b64 exec, vcc, {TM}")
-        a("v_mov_b32_e32 {W_lo}, {SX%d_lo}" % f)
-        a("v_mov_b32_e32 {W_hi}, {SX%d_hi}" % f)
-    a("s_mov_b64 exec, -1")
+    a("s_and_b64 {MC}, {RW}, {K1M}")
+    a("s_cbranch_scc1 Lf3op_%=")
     a("Lf3b_%=:")
-    a("s_or_b64 {TM}, {MD}, {ME}")               # reverse targets: they need the position of the source's own traceb node
+    a("s_and_b64 {MD}, {RW}, {K2M}")
+    a("s_cbranch_scc1 Lf3md_%=")
+    a("Lf3c_%=:")
+    a("s_and_b64 {ME}, {RW}, {K3M}")
     a("s_cbranch_scc0 Lf3d_%=")
-    if not near:
-        a("s_and_b32 {TMP}, {TAGK}, 0xfffffff")
-        a("s_cmp_lt_u32 {TMP}, %[i0]")
-        a("s_cbranch_scc1 Lf3pre_%=")
-        a("v_readlane_b32 {TBN}, %[ndx], {TMP}")         # inside the batch: lane = index & 63
-        a("s_branch Lf3q_%=")
-        a("Lf3pre_%=:")
-        a("v_readlane_b32 {TBN}, %[tbnpre], {E0}")
-        a("Lf3q_%=:")
-    a("s_add_i32 {LHS}, {TBN}, {E1}")
-    a("s_add_i32 {LHS}, {LHS}, 7")
-    a("s_cmp_eq_u64 {MD}, 0")                    # reverse starts whose static interval holds s_ndx: tbn + s_ndx + 7 < drhs0
-    a("s_cbranch_scc1 Lf3r3_%=")
-    a("v_cmp_lt_i32_e32 vcc, {LHS}, %[drhs0]")
-    a("s_and_b64 {TM}, vcc, {MD}")
-    a("s_or_b64 {OK}, {OK}, {TM}")
-    a("s_mov_b64 exec, {MD}")
-    a("v_add_f64 {W}, %[cs], %[negc]")          # cs + negc
-    a("s_mov_b64 exec, -1")
-    a("Lf3r3_%=:")
-    a("s_cmp_eq_u64 {ME}, 0")                    # reverse stops: through the best admissible overlapping start of the LANE, or directly
-    a("s_cbranch_scc1 Lf3d_%=")
-    a("s_or_b64 {OK}, {OK}, {ME}")
-    # (a candidate is admissible only for dlo < s_ndx < dhi: where no lane's widest interval holds s_ndx, every reverse stop takes
-    #  the source directly -- the constant term W already holds -- and the three-candidate evaluation below is skipped)
-    a("v_min3_i32 {A}, %[dlo0], %[dlo1], %[dlo2]")
-    a("v_cmp_gt_i32_e64 {C0}, {E1}, {A}")
-    a("v_max3_i32 {A}, %[dhi0], %[dhi1], %[dhi2]")
-    a("v_cmp_lt_i32_e32 vcc, {E1}, {A}")
+    # reverse stops: directly (the constant term, W holds it), or through the best admissible overlapping start of the LANE -- admissible
+    # only for dlo < s_ndx < dhi: where no lane's widest interval holds s_ndx (DLM / DHM: per lane, once per batch) nothing is to do
+    a("v_cmp_gt_i32_e64 {C0}, {E1}, {DLM}")
+    a("v_cmp_lt_i32_e32 vcc, {E1}, {DHM}")
     a("s_and_b64 {C0}, {C0}, vcc")
     a("s_and_b64 {C0}, {C0}, {ME}")
-    a("s_cbranch_scc0 Lf3d_%=")
-    a("s_mov_b64 exec, {ME}")
-    for q in range(3):
-        a("v_cmp_gt_i32_e64 {C%d}, {E1}, %%[dlo%d]" % (q, q))
-        a("v_cmp_lt_i32_e32 vcc, {E1}, %%[dhi%d]" % q)
-        a("s_and_b64 {C%d}, {C%d}, vcc" % (q, q))
-        a("v_cmp_lt_i32_e32 vcc, {LHS}, %%[drhs%d]" % q)
-        a("s_and_b64 {C%d}, {C%d}, vcc" % (q, q))
-    a("v_mov_b64_e32 {MV}, 0")
-    a("v_mov_b32_e32 {MI}, 0")
-    for q in range(3):
-        a("v_cmp_gt_f64_e32 vcc, {X%d}, {MV}" % q)
-        a("s_and_b64 vcc, vcc, {C%d}" % q)
-        a("v_cndmask_b32_e32 {MV_lo}, {MV_lo}, {X%d_lo}, vcc" % q)
-        a("v_cndmask_b32_e32 {MV_hi}, {MV_hi}, {X%d_hi}, vcc" % q)
-        a("v_cndmask_b32_e64 {MI}, {MI}, %d, vcc" % (q + 1))
-    a("v_cmp_eq_u32_e32 vcc, 0, {MI}")
-    a("v_lshl_or_b32 {TG}, {MI}, 28, {TG}")
-    a("v_mov_b64_e32 {W}, %[negc]")
-    a("s_andn2_b64 exec, exec, vcc")
-    a("v_mov_b64_e32 {W}, {MV}")
-    a("s_mov_b64 exec, -1")
+    a("s_cbranch_scc1 Lf3cand_%=")
     a("Lf3d_%=:")
-    a("v_add_f64 {W}, {SC}, {W}")
     a("v_cmp_ge_f64_e32 vcc, {W}, {LV}")
     a("s_and_b64 vcc, vcc, {OK}")
     a("s_cbranch_vccz " + nxt)
-    commit(nxt, "{TG}")
+    chain_index(a)
+    commit(nxt, "{E3}")
+
+    def tbn_of(e):
+        # the position of the source's own traceb node
+        if near:
+            e("v_readlane_b32 {TBN}, {NB}, {E0}")
+        else:
+            e("s_and_b32 {TMP}, {TAGK}, 0xfffffff")
+            e("s_cmp_lt_u32 {TMP}, %[i0]")
+            e("s_cbranch_scc1 Lf3pre%d_%%=" % tbn_of.n)
+            e("v_readlane_b32 {TBN}, %[ndx], {TMP}")         # inside the batch: lane = index & 63
+            e("s_branch Lf3q%d_%%=" % tbn_of.n)
+            e("Lf3pre%d_%%=:" % tbn_of.n)
+            e("v_readlane_b32 {TBN}, %[tbnpre], {E0}")
+            e("Lf3q%d_%%=:" % tbn_of.n)
+            tbn_of.n += 1
+        e("s_add_i32 {LHS}, {TBN}, {E1}")
+        e("s_add_i32 {LHS}, {LHS}, 7")
+    tbn_of.n = 0
+
+    # forward starts within 3 * OPER_DIST bases: igm[d] up to OPER_DIST, 0 beyond
+    c("Lf3tab_%=:")
+    c("v_readlane_b32 {MB_lo}, {W1_lo}, {E0}")
+    c("v_readlane_b32 {MB_hi}, {W1_hi}, {E0}")
+    igm_lookup(c, "{MV}", "{MB}", "Lf3t0_%=")
+    c("v_add_f64 {W}, {SC}, {MV}")
+    c("s_mov_b64 exec, -1")
+    c("s_branch Lf3a_%=")
+    # forward stops whose ORF holds it: through the SOURCE's overlapping start of the lane's frame
+    c("Lf3op_%=:")
+    c("v_readlane_b32 {SVM}, %s, {E0}" % kinfo)
+    c("s_lshr_b32 {SVM}, {SVM}, 8")              # vm sits in bits 8 .. 10
+    c("s_nop 0")
+    c("v_and_b32_e32 {A}, {SVM}, {FB}")
+    c("v_cmp_ne_u32_e32 vcc, 0, {A}")
+    c("s_and_b64 {TM}, vcc, {MC}")
+    c("s_cbranch_scc0 Lf3b_%=")
+    c("s_or_b64 {OK}, {OK}, {TM}")
+    xs = ("{NX0}", "{NX1}", "{NX2}") if near else ("{X0}", "{X1}", "{X2}")
+    for f in range(3):
+        # the lanes of frame f among them, if the source has an overlapping start of that frame at all
+        c("s_bitcmp1_b32 {SVM}, %d" % f)
+        c("s_cbranch_scc0 Lf3o%d_%%=" % f)
+        c("v_cmp_eq_u32_e32 vcc, %d, {FB}" % (1 << f))
+        c("s_and_b64 {C1}, vcc, {TM}")
+        c("s_cbranch_scc0 Lf3o%d_%%=" % f)
+        c("v_readlane_b32 {SX0_lo}, %s, {E0}" % xs[f].replace("}", "_lo}"))
+        c("v_readlane_b32 {SX0_hi}, %s, {E0}" % xs[f].replace("}", "_hi}"))
+        c("s_mov_b64 exec, {C1}")
+        c("s_nop 0")
+        c("v_mov_b64_e32 {W}, {SX0}")            # (one scalar operand per instruction)
+        c("v_add_f64 {W}, {SC}, {W}")
+        c("s_mov_b64 exec, -1")
+        c("Lf3o%d_%%=:" % f)
+    if not near: c("s_lshl_b64 {TM}, -1, {E0}")
+    c("s_branch Lf3b_%=")
+    # reverse starts whose static interval holds s_ndx: tbn + s_ndx + 7 < drhs0
+    c("Lf3md_%=:")
+    tbn_of(c)
+    c("v_cmp_lt_i32_e32 vcc, {LHS}, %[drhs0]")
+    c("s_and_b64 {C0}, vcc, {MD}")
+    c("s_or_b64 {OK}, {OK}, {C0}")
+    c("s_mov_b64 exec, {MD}")
+    c("v_add_f64 {W}, %[cs], %[negc]")          # cs + negc
+    c("v_add_f64 {W}, {SC}, {W}")
+    c("s_mov_b64 exec, -1")
+    c("s_branch Lf3c_%=")
+    # reverse stops with an interval that may hold s_ndx: the three candidates of each lane
+    c("Lf3cand_%=:")
+    tbn_of(c)
+    c("s_mov_b64 exec, {ME}")
+    for q in range(3):
+        c("v_cmp_gt_i32_e64 {C%d}, {E1}, %%[dlo%d]" % (q, q))
+        c("v_cmp_lt_i32_e32 vcc, {E1}, %%[dhi%d]" % q)
+        c("s_and_b64 {C%d}, {C%d}, vcc" % (q, q))
+        c("v_cmp_lt_i32_e32 vcc, {LHS}, %%[drhs%d]" % q)
+        c("s_and_b64 {C%d}, {C%d}, vcc" % (q, q))
+    c("v_mov_b64_e32 {MV}, 0")
+    c("v_mov_b32_e32 {MI}, 0")
+    for q in range(3):
+        c("v_cmp_gt_f64_e32 vcc, {X%d}, {MV}" % q)
+        c("s_and_b64 vcc, vcc, {C%d}" % q)
+        c("v_cndmask_b32_e32 {MV_lo}, {MV_lo}, {X%d_lo}, vcc" % q)
+        c("v_cndmask_b32_e32 {MV_hi}, {MV_hi}, {X%d_hi}, vcc" % q)
+        c("v_cndmask_b32_e64 {MI}, {MI}, %d, vcc" % (q + 1))
+    c("s_mov_b64 exec, -1")
+    chain_index(c)
+    c("v_lshlrev_b32_e32 {TG}, 28, {MI}")
+    c("v_or_b32_e32 {TG}, {E3}, {TG}")           # the tag of a lane that takes it: index | (candidate + 1) << 28 (lanes outside ME: MI is stale, mask it)
+    c("v_cmp_ne_u32_e32 vcc, 0, {MI}")
+    c("s_and_b64 {C0}, vcc, {ME}")               # the reverse stops that go through a candidate
+    c("s_andn2_b64 {C1}, -1, {C0}")
+    c("s_mov_b64 exec, {C1}")
+    c("v_mov_b32_e32 {TG}, {E3}")                # everyone else: the plain index
+    c("s_mov_b64 exec, {C0}")
+    c("v_add_f64 {W}, {SC}, {MV}")
+    c("s_mov_b64 exec, -1")
+    c("v_cmp_ge_f64_e32 vcc, {W}, {LV}")
+    c("s_and_b64 vcc, vcc, {OK}")
+    c("s_cbranch_vccz " + nxt)
+    commit(nxt, "{TG}", c)
     out += cold
     out.append("Ldone_%=:")
     return out
