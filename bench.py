@@ -38,7 +38,7 @@ SEGMENTED_DP_KERNELS = ["k_dp_tree_mw", "k_seg_gather", "k_seg_weights", "k_seg_
                         "k_dp_verify"]
 
 
-def roofline(ctx, dp_ms, passes, calls, n_chains, wname, launch_key=None):
+def roofline(ctx, dp_ms, passes, calls, n_chains, wname, launch_key=None, aux_ms=None):
     """Connection scoring against the HBM roofline: 64 B x node-passes / kernel time (HIP events on the library's stream,
     summed over the calls of the timed region)."""
     achieved = BYTES_PER_NODE_PASS * passes / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
@@ -67,6 +67,14 @@ def roofline(ctx, dp_ms, passes, calls, n_chains, wname, launch_key=None):
         r["scalar_busy_frac"] = round(pmc["scalar_busy_simd_cycles_per_launch"] * max(calls, 1) / simd_cycles, 4)
         r["salu_insts_per_node_pass"] = round(pmc["salu_insts_per_launch"] * max(calls, 1) / max(passes, 1), 2)
         r["branch_insts_per_node_pass"] = round(pmc["branch_insts_per_launch"] * max(calls, 1) / max(passes, 1), 2)
+    if aux_ms is not None and dp_ms > 0:
+        # The lane masks of the pair steps are compiled once per (contig, translation table) by k_dpw_sched, from the topology arrays of
+        # k_dpw_topo(_lds): both run earlier in the call, outside the events of the scoring launch, and both are connection scoring
+        # (ref: ConnectionScorer.index, lib.pyx:1126-1176).  The same fraction with their time (HIP events, pga_dp_timings) counted in:
+        topo_ms, sched_ms = aux_ms
+        r["topology_kernels_ms_per_launch"] = round(topo_ms / max(calls, 1), 4)
+        r["schedule_kernels_ms_per_launch"] = round(sched_ms / max(calls, 1), 4)
+        r["frac_incl_schedule"] = round(BYTES_PER_NODE_PASS * passes / ((dp_ms + topo_ms + sched_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
     seg = ctx.dp_stats()
     if seg["chains"] > 0:
         # few long chains: the connection scoring is one group of kernels (speculative segment walks, exact
@@ -353,11 +361,29 @@ def main():
     t0 = time.perf_counter()
     dp_ms_shared, passes_shared, calls_shared = 0.0, 0, 0
     res, all_genes = [], None
-    for _ in range(args.steps):
-        res = lanes.run(len(groups), h2h_call)
-        all_genes = gather(res)
-        for r in res:
-            dp_ms_shared += r.t_dp_ms; passes_shared += r.node_passes; calls_shared += 1
+    streamed = dist is not None and n_ctx > 1 and os.environ.get("PGA_BENCH_JOIN", "0") != "1"
+    if streamed:
+        # N > 1: a rank's share is a handful of calls (four for an eighth of the job), and what a join per step costs -- the first upload
+        # with an idle device, the last calls running alone, about 14 ms per step on one GPU -- does not shrink with N.  So the K steps of
+        # a rank run back to back: a context goes on with its call of step s + 1 as soon as it has made its call of step s, and the
+        # gather of step s (in step order, on this thread; the one collective of the job) runs under the kernels of step s + 1.  Still K
+        # whole passes over the whole job, K gathers, one barrier on either side.  (PGA_BENCH_JOIN=1: a join per step as with one rank.)
+        acc = {"res": [], "genes": None}
+
+        def step_done(res_):
+            acc["genes"] = gather(res_)
+            acc["res"] = res_
+            for r in res_:
+                acc["dp"] = acc.get("dp", 0.0) + r.t_dp_ms; acc["np"] = acc.get("np", 0) + r.node_passes; acc["nc"] = acc.get("nc", 0) + 1
+        lanes.run_back_to_back(args.steps, len(groups), h2h_call, step_done)
+        res, all_genes = acc["res"], acc["genes"]
+        dp_ms_shared, passes_shared, calls_shared = acc.get("dp", 0.0), acc.get("np", 0), acc.get("nc", 0)
+    else:
+        for _ in range(args.steps):
+            res = lanes.run(len(groups), h2h_call)
+            all_genes = gather(res)
+            for r in res:
+                dp_ms_shared += r.t_dp_ms; passes_shared += r.node_passes; calls_shared += 1
     t_local = time.perf_counter() - t0            # this rank's own time, before waiting for the others
     sync()
     elapsed = time.perf_counter() - t0
@@ -402,14 +428,15 @@ def main():
     # With several contexts a kernel shares the device with the other contexts' kernels and its own duration says little about
     # the kernel: the connection-scoring roofline is taken from the same calls issued one after the other (same batches, same
     # HIP events on the library's stream), right after the timed region; the overlapped figure is reported next to it.
-    dp_ms, passes, calls = dp_ms_shared, passes_shared, calls_shared
-    if n_ctx > 1:
-        dp_ms, passes, calls = 0.0, 0, 0
-        for _ in range(max(1, min(args.steps, 3))):
-            for k, b in enumerate(batches):
-                r = ctxs[k % n_ctx].find_genes(b, **kw)
-                dp_ms += r.t_dp_ms; passes += r.node_passes; calls += 1
-        sync()
+    dp_ms, passes, calls = 0.0, 0, 0
+    topo_ms = sched_ms = 0.0
+    for _ in range(max(1, min(args.steps, 3))):
+        for k, b in enumerate(batches):
+            r = ctxs[k % n_ctx].find_genes(b, **kw)
+            dp_ms += r.t_dp_ms; passes += r.node_passes; calls += 1
+            tmg = ctxs[k % n_ctx].dp_timings()
+            topo_ms += tmg["topo_ms"]; sched_ms += tmg["sched_ms"]
+    sync()
 
     out = None
     if rank == 0:
@@ -427,6 +454,7 @@ def main():
                        "node_passes_per_step_rank0": int(passes_shared // max(args.steps, 1)),
                        "genes_all_ranks": int(sum(len(g) for g in all_genes)) if all_genes is not None else 0,
                        "parallelism": "contigs packed by estimated work over %d GPU(s), one gather of gene records to rank 0" % world,
+                       "steps_issued": "back to back (a rank's contexts go on with step s + 1 while step s is gathered)" if streamed else "a join of the contexts and a gather per step",
                        "timed": "host to host (SURVEY 8d): ASCII contigs in host memory -> pinned packing -> H2D -> path -> gene records in host memory -> gather",
                        "resident_Mbp_s": round(job_bases * res_steps / r_elapsed / 1e6, 3), "resident_steps": res_steps,
                        "resident_ms_per_step": round(1e3 * r_elapsed / res_steps, 3),
@@ -435,7 +463,8 @@ def main():
                        "generate_s_rank0": round(t_gen, 2)},
             # one launch = one device call = one sub-batch: the PMC passes profile exactly that (tools/collect_profiles.sh)
             "roofline": roofline(ctx, dp_ms, passes, calls, n_chains, wname,
-                                 "%dx20kbp_gc30-70_meta" % min(sub, len(seqs)) if args.workload == "config4" else None),
+                                 "%dx20kbp_gc30-70_meta" % min(sub, len(seqs)) if args.workload == "config4" else None,
+                                 aux_ms=(topo_ms, sched_ms) if not single and args.workload in ("config4", "config3") else None),
         }
         if per_rank is not None:
             out["config"]["per_rank"] = per_rank
@@ -443,7 +472,7 @@ def main():
         if pl is not None:
             out["pipeline_hbm_bytes_per_bp"] = pl["pipeline_hbm_bytes_per_bp"]         # all kernels of a device call
             out["pipeline"] = pl
-        if n_ctx > 1:
+        if True:
             out["roofline"]["measured"] = "calls issued one after the other right after the timed region (kernel alone on the device)"
             out["roofline"]["kernel_ms_per_launch_in_timed_region"] = round(dp_ms_shared / max(calls_shared, 1), 4)
             out["roofline"]["frac_in_timed_region"] = round(BYTES_PER_NODE_PASS * passes_shared / (dp_ms_shared * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if dp_ms_shared > 0 else 0.0
@@ -454,6 +483,42 @@ def main():
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(seqs, models)
                 # ... and its last row: the job that was timed, checked across every device call and context
                 out["parity"] = parity_sample(seqs, models, res, base_of, n_ctx)
+    share_line = None
+    if rank == 0 and world == 1 and args.workload == "config4" and not args.no_secondary and len(seqs) >= 8 * 3125:
+        # What one rank of the 8-GPU run will do, timed alone here: rank 0's share of the LPT packing (12 500 of the 100 000 contigs) with the
+        # call plan bench.py gives a rank (calls of at least 3 125 contigs on up to --contexts contexts), host to host, a join and a gather
+        # per step.  predicted_efficiency_at_8 = (this GPU's whole-job step / 8) / the share's step: what per-step fixed costs (first
+        # upload, drain and refill of the call pipeline) leave of linear scaling BEFORE the gather over xGMI.  No scaling curve: a prediction.
+        share = distributed.pack_contigs(work, 8)[0]
+        where = {int(c): i for i, c in enumerate(mine)}
+        sseqs = [seqs[where[int(c)]] for c in share]
+        ssub = min(args.sub_batch, max(min(args.sub_batch, 3125), -(-len(sseqs) // args.contexts)))
+        sgroups = [sseqs[i:i + ssub] for i in range(0, len(sseqs), ssub)]
+        slanes = Lanes(ctxs[:max(1, min(n_ctx, len(sgroups)))])
+        scall = lambda c, k: c.find_genes_batch(sgroups[k], **kw)
+        for _ in range(2):
+            slanes.run(len(sgroups), scall)
+        sync()
+        ssteps = max(3, min(args.steps, 10))
+        t0s = time.perf_counter()
+        for _ in range(ssteps):
+            [r.genes for r in slanes.run(len(sgroups), scall)]
+        sync()
+        share_ms = 1e3 * (time.perf_counter() - t0s) / ssteps
+        t0s = time.perf_counter()
+        slanes.run_back_to_back(ssteps, len(sgroups), scall, lambda res_: None)
+        sync()
+        share_b2b_ms = 1e3 * (time.perf_counter() - t0s) / ssteps
+        slanes.close()
+        whole_ms = 1e3 * elapsed / args.steps
+        share_line = {"contigs": len(sseqs), "bases": int(sum(len(x) for x in sseqs)), "device_calls_per_step": len(sgroups), "sub_batch_contigs": ssub,
+                      "contexts": len(slanes.ctxs), "steps": ssteps, "ms_per_step": round(share_ms, 3),
+                      "ms_per_step_back_to_back": round(share_b2b_ms, 3),
+                      "whole_job_ms_per_step_one_gpu": round(whole_ms, 3),
+                      "predicted_efficiency_at_8": round((whole_ms / 8.0) / share_ms, 4),
+                      "predicted_efficiency_at_8_back_to_back": round((whole_ms / 8.0) / share_b2b_ms, 4),
+                      "what": "rank 0's share of the job on 8 GPUs (LPT packing), timed alone on this GPU with a rank's own call plan; a prediction of "
+                              "per-step fixed costs, not a scaling measurement: no multi-GPU run exists"}
     fasta_line = pool_line = None
     try:
         free_b, total_b = torch.cuda.mem_get_info(dev_index)
@@ -476,6 +541,8 @@ def main():
             out["secondary"]["fasta_file_to_genes"] = fasta_line
         if pool_line:
             out["secondary"]["threadpool_find_genes"] = pool_line
+        if share_line:
+            out["secondary"]["rank_share_of_8"] = share_line
     ctx.close()
     if dist is not None:
         dist.barrier()
@@ -494,7 +561,17 @@ def secondary(ctx, _cabi, benchdata, models, headline, sync):
         return benchdata.generate(lengths, gcs, seeds, planted=True)
 
     # config4_planted: one device call of the headline job's size on the planted-ORF series (about 0.06 nodes per base: real density)
+    def ragged4():
+        # one device call's worth of contigs with ragged lengths (5 .. 60 kbp, seeded): no two tiles end alike, the extraction's staging
+        # slack and the per-contig tails are timed on something other than 6 250 equal contigs
+        rng = np.random.default_rng(20260601)
+        n = 3800
+        lengths = rng.integers(5_000, 60_001, n)
+        c = np.arange(n)
+        return benchdata.generate(lengths, 0.30 + 0.40 * (c % 41) / 40, 3_000_000 + c)
+
     plans = [("config4_planted", "6250x20kbp_gc30-70_meta_planted", planted4, dict(meta=True), 10),
+             ("config4_ragged", "3800x5-60kbp_gc30-70_meta", ragged4, dict(meta=True), 10),
              ("config2", "1x5Mbp_gc50_meta", lambda: benchdata.config2(0), dict(meta=True), 10),
              ("config3", "1000x50kbp_gc30-70_meta", lambda: benchdata.generate(*_config3_spec()), dict(meta=True), 10),
              ("config5", "1x200Mbp_gc65_single", benchdata.config5, dict(meta=False, closed=True), 3)]
@@ -521,6 +598,76 @@ def secondary(ctx, _cabi, benchdata, models, headline, sync):
             out[key]["nodes_per_bp"] = round(float(np.sum(res[0].contigs["n_nodes"])) / bases, 4)
             out[key]["node_passes_per_call"] = int(passes // max(calls, 1))
         b.close()
+    try:
+        out.update(reference_benchmarks(ctx, models))
+    except Exception as err:          # (never lose the line to a secondary figure)
+        out["reference_benchmarks_error"] = repr(err)
+    return out
+
+
+def reference_benchmarks(ctx, models):
+    """The two series the reference itself publishes, on the one genome of its test data that is here
+    (GCF_001457455.1, 2.46 Mbp, 153 296 nodes): (i) benches/connection_scoring/bench.py:38-83 -- ConnectionScorer.index +
+    score_connections(final=True) over a genome's sorted, scored nodes, one pass; (ii) benches/run_single/bench.py:37-104 --
+    GeneFinder().train(genome) + find_genes(genome).  The published figures are a laptop CPU's (i7-10710U, one thread): context, not target."""
+    import gzip
+    from oracle import oracle as orc
+    from tests.util import golden_path, read_fasta
+    from pyrodigal_amd import lib
+    seq = read_fasta("GCF_001457455.1_NCTC11397_genomic.fna.gz")[0][1]
+    seq_b = seq.encode() if isinstance(seq, str) else seq
+    tinf = orc.Training.load(golden_path("GCF_001457455.1_NCTC11397_genomic.tinf_closed.bin.gz"))
+    o = orc.Oracle(seq_b)
+    o.extract(tinf.trans_table, orc.Params(closed=True)); o.sort(); o.reset_scores()
+    o.score_nodes(tinf, True, False)
+    o.overlapping_starts(tinf, 1, 60)
+    nd = o.nodes()
+    n = len(nd)
+    args_ = (nd["ndx"], nd["stop_val"], nd["type"], nd["strand"], nd["cscore"], nd["sscore"], nd["rscore"], nd["uscore"], nd["star_ptr"], tinf.st_wt, True)
+    ctx.score_connections(*args_)
+    h2h, kern = [], []
+    for _ in range(10):
+        t0 = time.perf_counter()
+        score, traceb, ov, mi, ms = ctx.score_connections(*args_)
+        h2h.append(time.perf_counter() - t0); kern.append(ms)
+    t0 = time.perf_counter()
+    o.dprog_raw(tinf, True)
+    t_cpu = time.perf_counter() - t0
+    ref = o.nodes()
+    same = bool(np.array_equal(traceb, ref["traceb"]) and np.array_equal(score.view(np.uint64), ref["score"].view(np.uint64)))
+    h2h.sort(); kern.sort()
+    med, kmed = h2h[len(h2h) // 2], kern[len(kern) // 2] * 1e-3
+    bases = len(seq_b)
+    out = {"ref_connection_scoring": {
+        "genome": "GCF_001457455.1", "bases": bases, "nodes": int(n), "passes": 1,
+        "host_to_host_ms": round(1e3 * med, 3), "value": round(bases / med / 1e6, 2), "unit": "Mbp/s", "M_nodes_per_s": round(n / med / 1e6, 2),
+        "kernels_ms": round(1e3 * kmed, 3), "kernels_Mbp_s": round(bases / kmed / 1e6, 1), "kernels_M_nodes_per_s": round(n / kmed / 1e6, 1),
+        "identical_to_oracle": same,
+        "cpu_oracle_one_core": {"ms": round(1e3 * t_cpu, 1), "Mbp_s": round(bases / t_cpu / 1e6, 2), "M_nodes_per_s": round(n / t_cpu / 1e6, 3)},
+        "published": {"Mbp_s": 19.6, "M_nodes_per_s": 1.20, "what": "pyrodigal v3.0.0, AVX2 pre-filter, i7-10710U, one thread, 50 genomes "
+                      "(benches/connection_scoring/v3.0.0.json): published on a laptop CPU -- context, not target"},
+        "what": "pga_score_connections (= ConnectionScorer.index + score_connections(final=True)) over the genome's sorted, scored nodes in host "
+                "memory: upload, topology, connection scoring, results back; median of 10"}}
+    # (ii) train + find_genes through the drop-in host layer
+    ts = []
+    genes = 0
+    for rep_ in range(4):
+        t0 = time.perf_counter()
+        finder = lib.GeneFinder(closed=True)
+        finder.train(seq_b)
+        g = finder.find_genes(seq_b)
+        ts.append(time.perf_counter() - t0)
+        genes = len(g)
+        del finder
+    ts = sorted(ts[1:])
+    t_run = ts[len(ts) // 2]
+    out["ref_run_single"] = {
+        "genome": "GCF_001457455.1", "bases": bases, "genes": int(genes), "seconds": round(t_run, 4), "value": round(bases / t_run / 1e6, 2), "unit": "Mbp/s",
+        "first_run_seconds": None,
+        "published": {"Mbp_s": 2.16, "what": "pyrodigal v3.7.0, SSE2, i7-10710U, one thread, 50 genomes (benches/run_single/v3.7.0.json): published "
+                      "on a laptop CPU -- context, not target"},
+        "what": "pyrodigal_amd.lib: GeneFinder(closed=True).train(genome) + find_genes(genome), host to host, a new GeneFinder per run; median of "
+                "the runs after the first (BASELINE.json configs[0])"}
     return out
 
 

@@ -129,6 +129,13 @@ int         pga_device_info(const pga_ctx*, char* name, int name_len, int* cus, 
  *   out[6] 1 when the wave-batch scorer ran from a step schedule   out[7] 64-node batches whose schedule did not fit its
  *          buffer (> 0: the launch was repeated by the kernel that works the lane masks out per chain) */
 int         pga_dp_stats(const pga_ctx*, int32_t out[8]);
+/* Device time (HIP events on the context's stream, milliseconds) of the connection scoring of the last pga_find_genes /
+ * pga_find_genes_batch call on this context, by part (diagnostics; the reference's counterpart of all three is ConnectionScorer.index +
+ * score_connections, src/pyrodigal/lib.pyx:1126-1176, 1205-1237):
+ *   out[0] the connection-scoring launch(es) themselves (= pga_result.t_dp_ms; both launches when a schedule miss repeated the launch)
+ *   out[1] the topology kernels of every translation-table group (windows, near-zone starts, candidate links)
+ *   out[2] the step-schedule kernels of every group   out[3] reserved (0) */
+int         pga_dp_timings(const pga_ctx*, double out[4]);
 /* How the node extraction of the last pga_find_genes / pga_find_genes_batch / pga_nodes_stage call on this context ran (diagnostics):
  *   out[0] extraction passes (1; 2 when a tile of the batch did not fit the half-density staging and the batch was extracted again)
  *   out[1] reserved (0) */

@@ -18,7 +18,7 @@ EXPORTS = [
     "pga_create", "pga_destroy", "pga_last_error", "pga_device_info", "pga_set_models",
     "pga_score_connections", "pga_score_connections_training", "pga_find_genes_batch", "pga_result_free",
     "pga_batch_create", "pga_batch_free", "pga_find_genes", "pga_nodes_stage",
-    "pga_fasta_open", "pga_fasta_next", "pga_fasta_error", "pga_fasta_close", "pga_train", "pga_dp_stats", "pga_extract_stats", "pga_dp_plan_summary", "pga_dp_start_order", "pga_cs_task_summary",
+    "pga_fasta_open", "pga_fasta_next", "pga_fasta_error", "pga_fasta_close", "pga_train", "pga_dp_stats", "pga_dp_timings", "pga_extract_stats", "pga_dp_plan_summary", "pga_dp_start_order", "pga_cs_task_summary",
     "pga_fasta_next_packed", "pga_batch_create_packed", "pga_translate_genes", "pga_fasta_open_callback", "pga_fasta_release_spare", "pga_dp_xcd_order", "pga_release_cached",
 ]
 STAGE_EXTRACT, STAGE_SCORE, STAGE_OVERLAP, STAGE_SEQUENCE = 1, 2, 3, 4
@@ -91,6 +91,7 @@ def load():
     L.pga_destroy.restype = None; L.pga_destroy.argtypes = [vp]
     L.pga_last_error.restype = ctypes.c_char_p; L.pga_last_error.argtypes = [vp]
     L.pga_dp_stats.restype = ctypes.c_int; L.pga_dp_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
+    L.pga_dp_timings.restype = ctypes.c_int; L.pga_dp_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
     L.pga_extract_stats.restype = ctypes.c_int; L.pga_extract_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
     L.pga_dp_plan_summary.restype = ctypes.c_int
     L.pga_dp_plan_summary.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)]
@@ -237,6 +238,15 @@ class Context:
             _raise(self.L, self.h, rc, "pga_dp_stats")
         return {"chains": out[0], "segments": out[1], "rejected": [out[2], out[3], out[4]], "serial": out[5],
                 "sched": out[6], "sched_missed": out[7]}
+
+    def dp_timings(self):
+        """Device milliseconds of the last find_genes call's connection scoring by part: the scoring launch(es), the topology kernels,
+        the step-schedule kernels (HIP events on the context's stream)."""
+        out = (ctypes.c_double * 4)()
+        rc = self.L.pga_dp_timings(self.h, out)
+        if rc != PGA_OK:
+            _raise(self.L, self.h, rc, "pga_dp_timings")
+        return {"dp_ms": out[0], "topo_ms": out[1], "sched_ms": out[2]}
 
     def extract_stats(self):
         """How the last node extraction ran: passes (2: a tile overflowed the half-density staging and the batch was extracted again)."""

@@ -75,6 +75,12 @@ extern "C" int pga_dp_stats(const pga_ctx* c, int32_t out[8]) {
     return PGA_OK;
 }
 
+extern "C" int pga_dp_timings(const pga_ctx* c, double out[4]) {
+    if (!c || !out) return PGA_EINVAL;
+    memcpy(out, c->dp_timings, sizeof c->dp_timings);
+    return PGA_OK;
+}
+
 extern "C" int pga_extract_stats(const pga_ctx* c, int32_t out[2]) {
     if (!c || !out) return PGA_EINVAL;
     out[0] = c->extract_passes; out[1] = 0;

@@ -1812,7 +1812,7 @@ static void launch_dp_segmented(const ChainDesc* d_chains, int n_chains, const M
         hipLaunchKernelGGL(k_seg_build_upper, dim3(sg.n_big), blk, 0, st, d_chains, sg.big, gate, buf.src, buf.tgt, buf, sg.tv, sg.ti);
         hipLaunchKernelGGL(k_dp_verify, per_node, blk, 0, st, d_chains, sg.big, gate, buf.src, buf.tgt, d_models, buf, sg.ctb,
                            sg.flags + (size_t)r * n_chains, sg.first_bad + (size_t)r * n_chains, from);
-        if (sg.h_round != nullptr) {
+        if (sg.h_round != nullptr && r == 0) {       // (after round 0 only, the common clean case: the later rounds run gated on the device, without a host round trip each)
             // Nearly every launch passes its first verification (configs 2 and 5: no rejection with the 4096-node warm-up), and the
             // rounds behind it then are sixteen gated launches each that find their gate shut -- 5 us apiece, 0.17 ms of a 3.3 ms
             // call.  One small read-back instead: the host sees the round's verdict and stops issuing.

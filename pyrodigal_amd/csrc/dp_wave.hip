@@ -22,6 +22,7 @@
 // maxima of chains longer than one window.
 
 #include "pga_internal.h"
+#include <atomic>
 #include <type_traits>
 #include "dev_common.h"
 #include "dpw_core.h"
@@ -1214,6 +1215,15 @@ void pga_launch_dpw_topo(const DpwTopoArrays& ta, const uint8_t* type, const int
     // contigs that fit: a workgroup per contig on LDS copies of its node arrays (PGA_DPW_TOPO_LDS=0: the per-node kernel on global memory)
     const bool lds = max_contig_nodes > 0 && max_contig_nodes <= TOPO_LDS_NODES && !walk && !(getenv("PGA_DPW_TOPO_LDS") && atoi(getenv("PGA_DPW_TOPO_LDS")) == 0);
     if (lds) {
+        // (up to 12 * TOPO_LDS_NODES + 32 bytes of dynamic LDS next to 2.3 KB of static: past the 64 KB a kernel may use unasked)
+        static std::atomic<bool> attr_set[64];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        dev &= 63;
+        if (!attr_set[dev].load()) {
+            (void)hipFuncSetAttribute((const void*)k_dpw_topo_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 12 * TOPO_LDS_NODES + 32);
+            attr_set[dev].store(true);
+        }
         hipLaunchKernelGGL(k_dpw_topo_lds, dim3((unsigned)n_contigs), dim3(256), (size_t)12 * max_contig_nodes + 32, st, ta.ndx, ta.stop_val, type, strand, d_cbase, ta);
         return;
     }

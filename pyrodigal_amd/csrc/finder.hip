@@ -100,6 +100,7 @@ struct FinderState {
     unsigned* d_sd_lut = nullptr;   // RBS search table (pga_launch_sd_lut), filled when the context's finder state is created
     std::mutex spare_mu; void* spare_p = nullptr; size_t spare_cap = 0;   // the letters' allocation of the last batch that was freed
     hipEvent_t e_start = nullptr, e_stop = nullptr, e_dp0[4] = {}, e_dp1[4] = {};
+    hipEvent_t e_aux[20] = {};      // around the topology / schedule launches of each group (pga_dp_timings), and the first of two connection-scoring launches
 };
 
 namespace {
@@ -956,6 +957,7 @@ void pga_finder_release(pga_ctx* c) {
     if (c->finder->e_start) hipEventDestroy(c->finder->e_start);
     if (c->finder->e_stop) hipEventDestroy(c->finder->e_stop);
     for (int i = 0; i < 4; i++) { if (c->finder->e_dp0[i]) hipEventDestroy(c->finder->e_dp0[i]); if (c->finder->e_dp1[i]) hipEventDestroy(c->finder->e_dp1[i]); }
+    for (int i = 0; i < 20; i++) if (c->finder->e_aux[i]) hipEventDestroy(c->finder->e_aux[i]);
     delete c->finder;
     c->finder = nullptr;
 }
@@ -966,6 +968,7 @@ int pga_finder_models_changed(pga_ctx* c) {
         if (!c->finder) return PGA_ENOMEM;
         HT(c, hipEventCreate(&c->finder->e_start)); HT(c, hipEventCreate(&c->finder->e_stop));
         for (int i = 0; i < 4; i++) { HT(c, hipEventCreate(&c->finder->e_dp0[i])); HT(c, hipEventCreate(&c->finder->e_dp1[i])); }
+        for (int i = 0; i < 20; i++) HT(c, hipEventCreate(&c->finder->e_aux[i]));
         HT(c, hipMalloc((void**)&c->finder->d_sd_lut, sizeof(unsigned) * 1920));
         pga_launch_sd_lut(c->finder->d_sd_lut, c->stream);
         HT(c, hipStreamSynchronize(c->stream));
@@ -1209,9 +1212,9 @@ extern "C" int pga_batch_create(pga_ctx* c, int32_t n_contigs, const char* const
             // otherwise share the host's memory bandwidth and the PCIe link eight ways, every batch would arrive late, and the device
             // would idle until the first one is complete.  In turn, the first batch is on the device after one eighth of that time and
             // the uploads of the others run under its kernels.  (PGA_UPLOAD_TURNS=0: no turns.)
-            static std::mutex upload_turn;
+            static std::mutex upload_turns[64];        // one per device: only contexts that share a link take turns
             static const bool turns = !(getenv("PGA_UPLOAD_TURNS") && atoi(getenv("PGA_UPLOAD_TURNS")) == 0);
-            std::unique_lock<std::mutex> turn(upload_turn, std::defer_lock);
+            std::unique_lock<std::mutex> turn(upload_turns[c->device & 63], std::defer_lock);
             if (turns && total >= (8 << 20)) turn.lock();
             if (threads == 1) work(); else c->finder->pool.run(work, threads);
             e = (hipError_t)first_err.load();
@@ -1623,7 +1626,13 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             // Only where the premise holds -- a device of eight XCDs (an MI355X in its default SPX mode; a partitioned one reports fewer) --
             // and where the queues come out even: a handful of keys, or one contig far longer than the rest, would leave XCDs idle
             // behind one long queue, and the plain longest-first order is the better one then.
-            static const int n_xcc = [] { int dev = 0, v = 0; (void)hipGetDevice(&dev); return (hipDeviceGetAttribute(&v, hipDeviceAttributeNumberOfXccs, dev) == hipSuccess && v > 0) ? v : 8; }();
+            static std::atomic<int> xcc_of[64];      // per device: 0 = not asked yet
+            int n_xcc = xcc_of[c->device & 63].load();
+            if (n_xcc == 0) {
+                int v = 0;
+                n_xcc = (hipDeviceGetAttribute(&v, hipDeviceAttributeNumberOfXccs, c->device) == hipSuccess && v > 0) ? v : 8;
+                xcc_of[c->device & 63].store(n_xcc);
+            }
             if (!(getenv("PGA_DP_XCD") && atoi(getenv("PGA_DP_XCD")) == 0) && NCH >= 64 && n_xcc == 8) {
                 std::vector<int32_t> key((size_t)NCH), by_xcd((size_t)NCH * 8);
                 for (int k = 0; k < NCH; k++) key[(size_t)k] = chains[(size_t)k].group * NC + chains[(size_t)k].contig;
@@ -1710,7 +1719,9 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             if (use_wave) {
                 int max_nodes_g = 0;
                 for (int i = 0; i < NC; i++) max_nodes_g = std::max(max_nodes_g, h_cbase[(size_t)g * (NC + 1) + i + 1] - h_cbase[(size_t)g * (NC + 1) + i]);
+                if (g < 4) HT(c, hipEventRecord(f->e_aux[4 * g], st));
                 pga_launch_dpw_topo(wgroups.g[g], ga[g].type, ga[g].strand, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], st, max_nodes_g);
+                if (g < 4) HT(c, hipEventRecord(f->e_aux[4 * g + 1], st));
                 sl.topo_q2 = wgroups.g[g].q2; sl.ext = wbuf.ext; sp.cs_out = wbuf.cs;
                 // (direct mode: the tail reads star_ptr only at the stop nodes, which k_ovl_stops always writes)
                 sl.fill_star_ptr = !(stage == 0 && direct_gather);
@@ -1721,7 +1732,9 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                              d_cs_tasks, n_cs_tasks, d_cs_entries, &sl);
             if (use_wave && use_sched) {
                 // (behind the scoring launches: the schedule's headers carry the stop nodes' ranks, which k_ovl_topo writes there)
+                if (g < 4) HT(c, hipEventRecord(f->e_aux[4 * g + 2], st));
                 pga_launch_dpw_sched(wgroups.g[g], d_cbase + (size_t)g * (NC + 1), d_bbase + (size_t)g * (NC + 1), NC, max_batches[g], st);
+                if (g < 4) HT(c, hipEventRecord(f->e_aux[4 * g + 3], st));
                 HT(c, hipMemcpyAsync(h_scur + 2 * g, wgroups.g[g].scur, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             }
             NodeArrays na{ga[g].ndx, ga[g].stop_val, ga[g].type, ga[g].strand, ca.cscore, ca.sscore, ca.rscore, ca.uscore, ca.star_ptr};
@@ -1812,6 +1825,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         HT(c, hipGetLastError());
         HT(c, hipStreamSynchronize(st));
         uint32_t sched_missed = 0;
+        double dp_first_ms = 0.0;
         if (use_sched) {
             // a schedule that did not fit its buffer (node-dense input: more than two slots per node on average): the same launch again
             // with the kernel that works the lane masks out itself
@@ -1820,6 +1834,8 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             sched_missed = missed;
             if (getenv("PGA_DPW_SCHED_DEBUG")) for (int g = 0; g < NG; g++) fprintf(stderr, "[pga dpw sched] group %d: %u batches missed\n", g, h_scur[2 * g + 1]);
             if (missed) {
+                // (the first launch's time counts: t_dp_ms covers both)
+                { float ms = 0; HT(c, hipEventElapsedTime(&ms, f->e_dp0[0], f->e_dp1[0])); dp_first_ms = ms; }
                 HT(c, hipEventRecord(f->e_dp0[0], st));
                 pga_launch_dp_wave(d_chains, NCH, wgroups, c->d_model_const, dp, wbuf, st, d_dp_order, (int)dp_order.size(), false);
                 HT(c, hipEventRecord(f->e_dp1[0], st));
@@ -1838,7 +1854,14 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             for (int k : seg_plan.big) fprintf(stderr, " %d/%d", h_segflags[(size_t)PGA_SEG_ROUNDS * NCH + k], chains[(size_t)k].n);
             fprintf(stderr, "\n");
         }
-        { float ms = 0; HT(c, hipEventElapsedTime(&ms, f->e_dp0[0], f->e_dp1[0])); R->pub.t_dp_ms = NCH > 0 ? ms : 0.0; }
+        { float ms = 0; HT(c, hipEventElapsedTime(&ms, f->e_dp0[0], f->e_dp1[0])); R->pub.t_dp_ms = NCH > 0 ? ms + dp_first_ms : 0.0; }
+        c->dp_timings[0] = R->pub.t_dp_ms; c->dp_timings[1] = c->dp_timings[2] = c->dp_timings[3] = 0.0;
+        if (use_wave) for (int g = 0; g < NG && g < 4; g++) {
+            if (!(g_c0[g + 1] > g_c0[g] && g_n0[g + 1] > g_n0[g])) continue;
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, f->e_aux[4 * g], f->e_aux[4 * g + 1]) == hipSuccess) c->dp_timings[1] += ms;
+            if (use_sched && hipEventElapsedTime(&ms, f->e_aux[4 * g + 2], f->e_aux[4 * g + 3]) == hipSuccess) c->dp_timings[2] += ms;
+        }
 
         tm.mark("score+dp+sync");
         // ---- pick the winning model per contig (ref: lib.pyx:5364-5367, strict '>' from -100) ---

@@ -182,6 +182,7 @@ struct pga_ctx {
     ModelConst* d_model_const = nullptr;
     int n_models = 0;
     int32_t dp_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // pga_dp_stats
+    double dp_timings[4] = {0, 0, 0, 0};               // pga_dp_timings
     int32_t extract_passes = 0;                        // pga_extract_stats: extraction passes of the last call (2: a tile overflowed the half-density staging)
 };
 // summary of a segmented launch's flags (host copy, [PGA_SEG_ROUNDS][stride]) into pga_ctx::dp_stats

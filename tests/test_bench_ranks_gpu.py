@@ -65,3 +65,24 @@ def test_eight_ranks_on_one_device_split_a_job_like_an_eight_gpu_node():
     assert eight["config"]["contexts_per_gpu"] == 1 and eight["config"]["device_calls_per_step_rank0"] == 1
     assert eight["config"]["genes_all_ranks"] == one["config"]["genes_all_ranks"] > 0
     assert eight["config"]["bases"] == one["config"]["bases"] == 16000 * 20000
+
+
+def test_two_ranks_with_several_contexts_run_their_steps_back_to_back():
+    """A rank whose share is several device calls (three calls on three contexts here, four on four for an eighth of the headline job)
+    runs its K steps back to back, every step's gather under the next step's kernels (bench.py, `streamed`): the same job, the same
+    genes, K gathers in step order."""
+    env = dict(os.environ, PGA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = ["--contigs", "16000", "--steps", "3", "--warmup", "1", "--no-secondary", "--no-cpu-baseline", "--gen-procs", "1"]
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    two = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                 "--master-port", str(port), "bench.py", "--gpus", "2"] + args, env)
+    one = _line([sys.executable, "bench.py", "--gpus", "1"] + args, env)
+    assert two["n_gpus"] == 2 and two["config"]["contexts_per_gpu"] >= 2 and two["config"]["device_calls_per_step_rank0"] >= 2
+    assert two["config"]["steps_issued"].startswith("back to back") and one["config"]["steps_issued"].startswith("a join")
+    assert two["config"]["genes_all_ranks"] == one["config"]["genes_all_ranks"] > 0
+    assert two["config"]["node_passes_per_step_rank0"] > 0 and two["roofline"]["frac"] > 0 and two["roofline"]["frac_incl_schedule"] > 0
+    joined = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                    "--master-port", str(port), "bench.py", "--gpus", "2"] + args, dict(env, PGA_BENCH_JOIN="1"))
+    assert joined["config"]["steps_issued"].startswith("a join") and joined["config"]["genes_all_ranks"] == one["config"]["genes_all_ranks"]

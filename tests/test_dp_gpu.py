@@ -185,3 +185,30 @@ def test_wave_kernel_on_synthetic_and_gene_dense_input(ctx, kernel, monkeypatch)
     for closed in (False, True):
         n, _ = check(ctx, b"".join(parts), tinf, closed=closed)
         assert n > 3000
+
+
+def test_topology_from_lds_near_its_node_limit(ctx, monkeypatch):
+    # k_dpw_topo_lds stages a contig's node arrays in LDS (12 bytes per node + 2.3 KB): between 5 300 and 6 144 nodes that is more than
+    # the 64 KB a kernel may use without asking (hipFuncAttributeMaxDynamicSharedMemorySize); same results as the global-memory kernel
+    _wave_env(monkeypatch, "wave")
+    tinf = orc.Training.load(golden_path("SRR492066.training.bin.gz"))
+    seen = []
+    for L, gc, seed in ((150_000, 0.50, 31), (143_000, 0.48, 32), (120_000, 0.58, 33)):
+        seq = synthetic_contig(L, gc, seed)
+        n, _ = check(ctx, seq, tinf, is_meta=True)
+        seen.append(n)
+        monkeypatch.setenv("PGA_DPW_TOPO_LDS", "0")
+        check(ctx, seq, tinf, is_meta=True)
+        monkeypatch.delenv("PGA_DPW_TOPO_LDS")
+    assert any(5300 <= n <= 6144 for n in seen), seen
+
+
+def test_schedule_miss_on_node_dense_sequence(ctx, monkeypatch):
+    # more than 64 nodes within 3 * OPER_DIST bases: the near sources of a batch reach past the batch before it, the step schedule
+    # reports the batch and the launch falls back to k_dpw_dyn -- unforced (the other tests force it with PGA_DPW_SCHED_MISS)
+    _wave_env(monkeypatch, "wave")
+    tinf = orc.Training.load(golden_path("SRR492066.training.bin.gz"))
+    seq = (b"ATGCATCAC" * 150) + b"TAATTA" + (b"GTGCACCAT" * 100) + b"TAGCTA" + synthetic_contig(3000, 0.5, 77)
+    for closed in (False, True):
+        n, _ = check(ctx, seq, tinf, closed=closed)
+        assert n > 500

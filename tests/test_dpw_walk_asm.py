@@ -23,9 +23,9 @@ def test_wait_states_hold_over_the_control_flow_graph():
 def test_the_check_sees_a_missing_wait_state(tmp_path):
     # the same generator with one pad taken out must fail its check (the checker is not vacuous)
     src = open(GEN).read()
-    good = 'else "%[vm]"))\n        a("s_nop 1")\n'
+    good = 'a("s_nop 0" if not near else "s_nop 1")'
     assert src.count(good) == 1
     bad = tmp_path / "gen_bad.py"
-    bad.write_text(src.replace(good, 'else "%[vm]"))\n        a("s_nop 0")\n'))
+    bad.write_text(src.replace(good, 'a("s_nop 0")'))
     r = subprocess.run([sys.executable, str(bad), "--check"], capture_output=True, text=True)
     assert r.returncode != 0 and "needs 2" in r.stderr

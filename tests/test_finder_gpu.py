@@ -218,6 +218,18 @@ def test_connection_scoring_kernels_inside_the_finder(ctx, models, kernel, monke
         assert (ctx.dp_stats()["sched_missed"] > 0) == (kernel == "wavemiss")
 
 
+def test_schedule_miss_inside_the_finder_unforced(ctx, models, monkeypatch):
+    # a node-dense contig (more than 64 nodes within 3 * OPER_DIST bases) among ordinary ones: its schedule reports a miss and the
+    # launch is repeated by k_dpw_dyn; every node of every contig against the oracle
+    monkeypatch.setenv("PGA_DP_KERNEL", "wave")
+    ctx.set_models([m.buf for m in models])
+    dense = (b"ATGCATCAC" * 150) + b"TAATTA" + (b"GTGCACCAT" * 100) + b"TAGCTA" + synthetic_contig(2500, 0.5, 78)
+    seqs = [synthetic_contig(9000 + 1300 * c, 0.35 + 0.03 * c, 30_000 + c) for c in range(8)] + [dense]
+    res = ctx.find_genes_batch(seqs, meta=True, want_nodes=True)
+    assert sum(compare_contig(res, i, s, orc.Oracle(s), models, meta=True) for i, s in enumerate(seqs)) > 10
+    assert ctx.dp_stats()["sched_missed"] > 0
+
+
 def test_extraction_staging_overflow_takes_the_full_staging(models, monkeypatch):
     """The extraction stages the nodes of a tile in one slot per two positions and extracts again with two slots per position when
     a tile does not fit (GroupArrays::st_half).  Same results from the default, from a staging so small that ordinary sequence
