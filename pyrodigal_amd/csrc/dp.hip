@@ -1750,10 +1750,16 @@ hipError_t pga_dp_seg_bind(const DpSegPlan& plan, int n_chains, int64_t tot_node
     d.sp_w = (double*)(b + L.sp_w);
     d.n_nodes = tot_nodes; d.n_segs = (int32_t)plan.segs.size(); d.n_p1 = (int32_t)plan.p1_chains.size(); d.n_big = (int32_t)plan.big.size();
     d.max_seg_nodes = plan.max_seg_nodes; d.max_seg_len = plan.max_seg_len; d.max_big_n = plan.max_big_n;
-    hipError_t e = hipMemcpyAsync(b + L.segs, plan.segs.data(), sizeof(DpSeg) * plan.segs.size(), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(b + L.p1_chains, plan.p1_chains.data(), sizeof(ChainDesc) * plan.p1_chains.size(), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(b + L.p1_slot, plan.p1_slot.data(), 4 * plan.p1_slot.size(), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(b + L.big, plan.big.data(), 4 * plan.big.size(), hipMemcpyHostToDevice, st);
+    // the plan and the cleared verification flags (flags: 0, first_bad: 0x7f7f7f7f) in ONE copy: they are the head of the workspace
+    // (it was four copies here and two memsets in the launcher; the staging lives in the plan, which outlives the copy)
+    plan.stage.assign(L.ctb, 0);
+    char* h = plan.stage.data();
+    if (!plan.segs.empty()) memcpy(h + L.segs, plan.segs.data(), sizeof(DpSeg) * plan.segs.size());
+    if (!plan.p1_chains.empty()) memcpy(h + L.p1_chains, plan.p1_chains.data(), sizeof(ChainDesc) * plan.p1_chains.size());
+    if (!plan.p1_slot.empty()) memcpy(h + L.p1_slot, plan.p1_slot.data(), 4 * plan.p1_slot.size());
+    if (!plan.big.empty()) memcpy(h + L.big, plan.big.data(), 4 * plan.big.size());
+    memset(h + L.first_bad, 0x7f, L.ctb - L.first_bad);
+    hipError_t e = hipMemcpyAsync(b, h, L.ctb, hipMemcpyHostToDevice, st);
     *out = d;
     return e;
 }
@@ -1786,8 +1792,7 @@ static void launch_dp_segmented(const ChainDesc* d_chains, int n_chains, const M
                                 const DpSegDev& sg) {
     const dim3 blk(256);
     auto blocks = [](int n) { return (unsigned)((n + 255) / 256); };
-    hipMemsetAsync(sg.flags, 0, sizeof(int32_t) * PGA_SEG_ROUNDS * (size_t)n_chains, st);
-    hipMemsetAsync(sg.first_bad, 0x7f, sizeof(int32_t) * PGA_SEG_ROUNDS * (size_t)n_chains, st);
+    // (flags and first_bad arrive cleared with the plan: pga_dp_seg_bind)
     hipLaunchKernelGGL(k_dp_tree_mw, dim3(sg.n_p1), dim3(64 * PGA_MW_WAVES), 0, st, sg.p1_chains, buf.src, buf.tgt, d_models, buf,
                        (const int32_t*)nullptr, sg.p1_slot);
     hipLaunchKernelGGL(k_seg_gather, dim3(blocks(sg.max_seg_len), sg.n_segs), blk, 0, st, sg.segs, d_chains, buf.traceb, sg.ctb);

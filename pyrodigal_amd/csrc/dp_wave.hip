@@ -55,6 +55,7 @@ k_dpw_topo(const int32_t* __restrict__ ndx, const int32_t* __restrict__ stopv, c
     __shared__ unsigned long long s_m[3][TOPO_WORDS];
     const int g0 = blockIdx.x * blockDim.x, g = g0 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && ta.scur != nullptr) { ta.scur[0] = 0u; ta.scur[1] = 0u; }      // the schedule's miss counter (k_dpw_sched runs behind this kernel)
     if (threadIdx.x == 0) s_c0 = contig_of_node(cbase, n_contigs, g0);     // one search per workgroup, then a short walk
     if (use_masks) {
         auto flags = [&](const int idx, const int word) {
@@ -115,6 +116,7 @@ k_dpw_topo_lds(const int32_t* __restrict__ ndx, const int32_t* __restrict__ stop
     __shared__ unsigned long long s_m[3][TOPO_LDS_NODES / 64];
     __shared__ int s_cnt[4];
     const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    if (c == 0 && tid == 0 && ta.scur != nullptr) { ta.scur[0] = 0u; ta.scur[1] = 0u; }      // the schedule's miss counter (k_dpw_sched runs behind this kernel)
     const int b0 = cbase[c], n = cbase[c + 1] - b0;
     if (n <= 0) return;
     int32_t* const l_ndx = s_topo; int32_t* const l_stop = s_topo + n;
@@ -560,10 +562,11 @@ k_dpw_sched(const int32_t* __restrict__ cbase, const int32_t* __restrict__ bbase
     }
 }
 
-// OCC: wavefronts per SIMD the register budget is cut for (PGA_DPW_OCC).  k_dpw_dyn wants 103 VGPRs: 4 spills nothing, 5 (the default)
+// OCC: wavefronts per SIMD the register budget is cut for (PGA_DPW_OCC).  k_dpw_dyn wants 103 VGPRs: 4 spills nothing, 5
 // spills 16 bytes per lane, 6 spills 64 bytes (round 2, 12 500-contig launches: 4.53 / 4.06 / 3.98 ms at 1.55 / 1.9 / 3.0 x the algorithmic
-// HBM bytes).  A chain's walk is a chain of dependent instructions: a fifth wavefront per SIMD fills its gaps.  k_dp_wave (round 5, 6 250-contig
-// launches): 4: no scratch, 1.34 ms; 5: 12 bytes of scratch per lane, 1.19 ms; 6: 80 VGPRs and 72 bytes, 1.22 ms.
+// HBM bytes).  k_dp_wave, 6 250-contig launches -- round 5: 4: no scratch, 1.34 ms; 5: 12 bytes of scratch per lane, 1.19 ms; 6: 80 VGPRs and
+// 72 bytes, 1.22 ms.  Round 6 (block structures, the chain's best gene end and the previous batch's x[] in LDS: 94 VGPRs wanted): 4: 1.085,
+// 5: 1.103, 6: 80 VGPRs and 24 bytes of scratch, 1.057 ms -- the default.
 template <int OCC>
 __global__ void __launch_bounds__(64, OCC)
 k_dpw_dyn(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const double* __restrict__ g_cs, const DpwExt* __restrict__ g_ext,
@@ -917,6 +920,14 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
     __shared__ double s_igm[64];
     __shared__ DpwCarR s_cr[3];                     // the carries of the chain (see DpwCarR)
     __shared__ DpwCarL s_cl[3];
+    // Round 6, the register diet (101 -> under 80 vector registers: six wavefronts per SIMD instead of five).  Per-lane state that a
+    // batch touches once or twice lives in LDS, 4.5 KB per wavefront: the block structures of the far gene ends (S1 / S2 as two buffers
+    // that swap roles -- the new S1 is written over the old S2 --, the prefix maxima of the last block), what the forward stops of the
+    // batch before offer an operon partner (x[3]), and the chain's best gene end.
+    __shared__ double s_blkv[2][64]; __shared__ int s_blki[2][64];      // [p]: S1, [p ^ 1]: S2 (p flips per batch)
+    __shared__ double s_ppv[64]; __shared__ int s_ppi[64];
+    __shared__ double s_px[64][3];
+    __shared__ double s_endv; __shared__ int s_endi[2];                 // best gene end: value; index, traceb
     const int chain = order != nullptr ? order[blockIdx.x] : (int)blockIdx.x;
     if (chain < 0) return;                          // a filler: the per-XCD queues of the start order are not equally long
     const ChainDesc cd = chains[chain];
@@ -926,6 +937,8 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
     s_igm[lane] = mc->igm[lane];
     const double NEG_INF = -__builtin_huge_val();
     if (lane < 3) { s_cr[lane] = DpwCarR{NEG_INF, -1, -1}; s_cl[lane] = DpwCarL{0.0, -1, 0, 0, 0}; }
+    s_blkv[0][lane] = s_blkv[1][lane] = s_ppv[lane] = NEG_INF; s_blki[0][lane] = s_blki[1][lane] = s_ppi[lane] = -1;
+    if (lane == 0) { s_endv = -1.0; s_endi[0] = -1; s_endi[1] = -1; }
     __syncthreads();
     const DpwModel M{mc->st_wt, mc->negc, s_igm};
     WavePtrs P;
@@ -945,11 +958,11 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
     // a launch ends when its longest chain does: long chains issue first, the short ones fill their stalls
     if (n >= 2048) __builtin_amdgcn_s_setprio(3); else if (n >= 1536) __builtin_amdgcn_s_setprio(2); else if (n >= 1024) __builtin_amdgcn_s_setprio(1);
     const bool long_chain = n > 2 * DPW_MAX_NODE_DIST;         // only then can a window start past node 0
-    double end_best = -1.0; int end_idx = -1, end_tb = -1;
-    double s1v = NEG_INF, s2v = NEG_INF, ppv = NEG_INF; int s1i = -1, s2i = -1, ppi = -1;
-    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));      // lanes before this one
+    // lanes of a mask before this one, counted (v_mbcnt): what `mask & below` was for
+    auto before = [&](const lanemask m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
     // the batch before, as the source of this batch's near steps: lane l held node i0 - 64 + l then, and keeps what that node offers
-    double p_ns = NEG_INF, p_x0 = 0.0, p_x1 = 0.0, p_x2 = 0.0; int p_tbn = -1, p_kinfo = 0x80, p_ndx = 0;
+    // (the x[] of a forward stop, which only an operon step asks for, in LDS: s_px)
+    double p_ns = NEG_INF; int p_tbn = -1, p_kinfo = 0x80, p_ndx = 0;
 
     const int nb = (n + 63) >> 6;
     const bool prof = buf.prof != nullptr && (blockIdx.x & 63) == 0;
@@ -965,7 +978,6 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
         const u32x4 hdr = s_hdr[b];                  // {0 or DPW_SCHED_NONE, rank of the batch's first stop node, lanes that hold a stop node (lo, hi)}
         // the batch's words of the step schedule (dpw_core.h): this lane's node as a source towards its own batch, and the node this lane
         // held one batch ago towards this batch
-        const uint4 ww = g_words[(size_t)b * (2 * DPW_SCHED_STRIDE)];
         uint4 nw = make_uint4(0u, 0u, 0u, 0u);
         if (b > 0) nw = g_words[(size_t)(b - 1) * (2 * DPW_SCHED_STRIDE) + 1];
         DpwT T; int kfb;
@@ -976,7 +988,7 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
             const bool in = i < n;
             const int ii = in ? i : n - 1;
             const lanemask stops = ((lanemask)hdr.w << 32) | hdr.z;
-            const int er = P.srank != nullptr ? (int)hdr.y + __popcll(stops & below) : ii;
+            const int er = P.srank != nullptr ? (int)hdr.y + before(stops) : ii;
             kfb = P.kf[ii];
             T.i = in ? i : -1;
             T.ndx = P.ndx[ii]; T.stop_val = P.stopv[ii]; T.lo = in ? P.lo[ii] : INT_MAX; T.q1 = P.q1[ii]; T.q2 = P.q2[ii];
@@ -986,16 +998,16 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
             if (in && ((stops >> lane) & 1ull)) load_ext(P.ext + er, T);
             if (hdr.x == DPW_SCHED_NONE) return;      // the batch's near sources reach past the batch before: the host repeats the launch with k_dpw_dyn
             T.kind = in ? DPW_KIND(kfb) : -1; T.frame = DPW_FRAME(kfb);
-            T.csd = T.cs + M.negc;
+            T.csd = 0.0;
         }
         const DpwLT LT = dpw_lean(T);
         const bool act = T.i >= 0;
         // (a forward start keeps cs in the x[] of its frame: what it offers the forward stop of its ORF is score + x[frame], as a forward
         //  stop's offer to an operon partner of frame f is score + x[f] -- one form for the carries of (7); no step reads a start's x[])
         if (T.kind == 0) { if (T.frame == 0) T.x0 = T.cs; else if (T.frame == 1) T.x1 = T.cs; else T.x2 = T.cs; }
-        const int fbit = 1 << T.frame;
-        // what the assembly's lane masks come from: kind | frame << 2 | vm << 8, 0x80 for a lane without a node
-        const int kinfo = act ? (T.kind | (T.frame << 2) | (T.vm << 8)) : 0x80;
+        // what the assembly's lane masks come from: kind | frame << 2 | vm << 8, 0x80 for a lane without a node (bits 12 .. 14, for the
+        // carries of (7): the node lies in the ORF of the next forward stop of frame f)
+        const int kinfo = act ? (T.kind | (T.frame << 2) | (T.vm << 8) | ((kfb >> 4) << 12)) : 0x80;
         mark(0);
         DpwLane L{0.0, -1};
         int tbn_pre = -1;                   // position of the traceb node while it is older than the batch
@@ -1014,14 +1026,17 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
         //      that the schedule lists for this batch, their values from the registers this wave left them in
         {
             const unsigned long long a_w0 = ((unsigned long long)nw.y << 32) | nw.x, a_w1 = ((unsigned long long)nw.w << 32) | nw.z;
-            const double a_ns = p_ns, a_nx0 = p_x0, a_nx1 = p_x1, a_nx2 = p_x2;
+            const double a_ns = p_ns;
             const int a_nb = p_tbn, a_pk = p_kinfo, a_pndx = p_ndx;
+            const unsigned a_pxb = (unsigned)(uintptr_t)&s_px[0][0];
             DPW_ASM_NEAR();
             // the position of the traceb node: a node of the batch before, i.e. a lane of p_ndx
             const int src = L.tag >= 0 ? (dpw_tag_index(L.tag) & 63) : 0;
             const int nd_prev = __shfl(p_ndx, src, 64);
             if (L.tag >= 0) tbn_pre = nd_prev;
         }
+        // (asked for here, not with the other loads of the batch: the words of the near steps and these share the assembly's registers)
+        const uint4 ww = g_words[(size_t)b * (2 * DPW_SCHED_STRIDE)];
         mark(1);
         // ---- (1) gene begins: far gene ends, `a` over [lo, min(p_near, i0))
         {
@@ -1035,13 +1050,14 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
             const bool whole = want && !generic && x < rb;
             if (whole && q >= 64) generic = true;
             const int qs = whole ? (q & 63) : 0;
-            const double w1v = __shfl(s1v, qs, 64), w2v = __shfl(s2v, qs, 64);
-            const int w1i = __shfl(s1i, qs, 64), w2i = __shfl(s2i, qs, 64);
+            const int pb = b & 1;                              // S1 sits in buffer pb, S2 in the other one
+            const int wb = rb == b ? pb : pb ^ 1;
+            const double wv = s_blkv[wb][qs]; const int wi = s_blki[wb][qs];
             const int ps = (part - 1) & 63;
-            const double pv = __shfl(ppv, ps, 64); const int pi = __shfl(ppi, ps, 64);
+            const double pv = s_ppv[ps]; const int pi = s_ppi[ps];
             double rv = NEG_INF; int ri = -1;
             if (want && !generic) {
-                if (whole) { if (rb == b) lex_max(rv, ri, w1v, w1i); else lex_max(rv, ri, w2v, w2i); }
+                if (whole) lex_max(rv, ri, wv, wi);
                 if (rb == b - 1 && part > 0 && (Bl < rb || lpart == 0)) lex_max(rv, ri, pv, pi);
                 if (lpart != 0 && Bl < rb) lex_max(rv, ri, P.sfxv[lo], P.sfxi[lo]);
             }
@@ -1063,7 +1079,7 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
         {
             const lanemask mine = T.frame == 0 ? f3f0 : (T.frame == 1 ? f3f1 : f3f2);
             const DpwCarR r = s_cr[T.frame];                 // every lane the record of its own frame
-            take(f3 && (mine & below) == 0ull && r.i >= 0, r.v, r.i, 0, r.n);
+            take(f3 && before(mine) == 0 && r.i >= 0, r.v, r.i, 0, r.n);
         }
         // ---- (4) reverse nodes: the last reverse stop of a frame before the batch (own stop of a reverse start; operon partner)
         if (act && T.kind == 2) {
@@ -1087,7 +1103,7 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
             // the chain of candidate q, or the next one that exists
             auto open_chain = [&]() {
                 j = DPW_NONE;
-                if (r5) { if (q == 0) { j = T.q2; dlo = LT.dlo0; dhi = LT.dhi0; drhs = LT.drhs0; xq = T.csd; } q = 3; }
+                if (r5) { if (q == 0) { j = T.q2; dlo = LT.dlo0; dhi = LT.dhi0; drhs = LT.drhs0; xq = T.cs + M.negc; } q = 3; }
                 else if (r3) {
                     while (q < 3 && j == DPW_NONE) {
                         const int lo_q = dpw_sel3i(q, LT.dlo0, LT.dlo1, LT.dlo2);
@@ -1135,10 +1151,18 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
             const int tbn = !alive ? -1 : (tb >= i0 ? nd_in : tbn_pre);
             // what this node offers the next batch as a near source (a gene end that was never reached: -inf, which no lane takes)
             p_ns = (!alive && (T.kind == 1 || T.kind == 2)) ? NEG_INF : L.val; p_tbn = tbn; p_kinfo = kinfo; p_ndx = T.ndx;
-            p_x0 = T.x0; p_x1 = T.x1; p_x2 = T.x2;
+            if (act && T.kind == 1) { s_px[lane][0] = T.x0; s_px[lane][1] = T.x1; s_px[lane][2] = T.x2; }
             if (act) {
                 P.score[T.i] = L.val; P.traceb[T.i] = tb; P.tbn[T.i] = tbn; P.ov[T.i] = (int8_t)dpw_tag_ov(L.tag);
-                if ((T.kind == 1 || T.kind == 2) && L.val >= end_best) { end_best = L.val; end_idx = T.i; end_tb = tb; }
+            }
+            // the chain's best gene end so far (ref: lib.pyx:1239-1251: the highest score, ties to the largest index): one ds_max_f64 of the
+            // batch's gene ends; the last lane that holds the maximum -- if any does: an earlier batch's may be larger -- writes its index
+            const lanemask ge = vote(act && (T.kind == 1 || T.kind == 2));
+            if (ge) {
+                if (in_mask(ge)) lds_fmax_f64(&s_endv, L.val);
+                const double m = s_endv;
+                const lanemask at = ge & vote(L.val == m);
+                if (at) { const int wl = 63 - __builtin_clzll(at); if (lane == wl) { s_endv = L.val; s_endi[0] = T.i; s_endi[1] = tb; } }
             }
         }
         {
@@ -1148,14 +1172,16 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
             const bool has = act && alive && (T.kind == 1 || T.kind == 2);
             const double av = has ? L.val + M.negc : NEG_INF;
             const double pv = wave_prefix_max_f64_lean(av);
-            const lanemask rec = vote(has && av == pv) & (below | (1ull << lane));
+            const lanemask upto = (2ull << lane) - 1ull;        // the lanes up to this one
+            const lanemask rec = vote(has && av == pv) & upto;
             const int pi = rec ? i0 + 63 - __builtin_clzll(rec) : -1;
-            ppv = pv; ppi = pi;
+            s_ppv[lane] = pv; s_ppi[lane] = pi;
             const double bmv = rl_f64(pv, 63); const int bmi = rl_i32(pi, 63);
-            s2v = s1v; s2i = s1i;
-            double nv = dpp_f64<0x138>(NEG_INF, s1v); int ni = dpp_i32<0x138>(-1, s1i);      // wave_shr:1, lane 0 takes the empty entry
+            // S2 := S1, S1 := S1 moved up a lane with the block's maximum merged in: the new S1 goes where S2 was, the buffers swap roles
+            const int pb = b & 1;
+            double nv = lane > 0 ? s_blkv[pb][(lane - 1) & 63] : NEG_INF; int ni = lane > 0 ? s_blki[pb][(lane - 1) & 63] : -1;
             lex_max(nv, ni, bmv, bmi);
-            s1v = nv; s1i = ni;
+            s_blkv[pb ^ 1][lane] = nv; s_blki[pb ^ 1][lane] = ni;
             if (long_chain) {
                 double sv = av; int si = has ? i0 + lane : -1;
                 wave_suffix_lexmax(sv, si, lane);
@@ -1168,7 +1194,7 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
             // where it has an overlapping start of frame f (dpw_outputs v0 .. v2).  A forward stop of the frame restarts the running
             // maximum; what follows it in the batch joins it; ties go to the later node.  The maximum itself is one ds_max_f64 over the
             // offering lanes (it was six rounds of cross-lane moves per frame), the lane that holds it then writes the record.
-            const int vout = !act ? 0 : (T.kind == 0 ? fbit : ((T.kind == 1 && alive) ? (T.vm & (kfb >> 4)) : 0));
+            const int vout = !act ? 0 : (T.kind == 0 ? (1 << T.frame) : ((T.kind == 1 && alive) ? (T.vm & (kinfo >> 12)) : 0));
             const bool r3n = act && T.kind == 3;
 #pragma unroll
             for (int f = 0; f < 3; f++) {
@@ -1193,13 +1219,8 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
         mark(6);
         if (prof && lane == 0) atomicAdd(&buf.prof[7], 1ull);
     }
-    // highest score among gene ends, ties to the largest index (ref: lib.pyx:1239-1251, 1311)
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const double ob = __shfl_xor(end_best, m, 64);
-        const int oi = __shfl_xor(end_idx, m, 64), ot = __shfl_xor(end_tb, m, 64);
-        if (ob > end_best || (ob == end_best && oi > end_idx)) { end_best = ob; end_idx = oi; end_tb = ot; }
-    }
+    // highest score among gene ends, ties to the largest index (ref: lib.pyx:1239-1251, 1311): kept in LDS as the batches went by
+    const double end_best = s_endv; const int end_idx = s_endi[0], end_tb = s_endi[1];
     if (lane == 0) {
         buf.max_index[chain] = end_idx; buf.max_score[chain] = end_idx >= 0 ? end_best : 0.0;
         buf.ipath[chain] = (end_idx >= 0 && end_tb != -1) ? end_idx : -1;
@@ -1244,7 +1265,7 @@ bool pga_dpw_use_sched() {
 }
 
 void pga_launch_dpw_sched(const DpwTopoArrays& ta, const int32_t* d_cbase, const int32_t* d_bbase, int n_contigs, int max_batches, hipStream_t st) {
-    hipMemsetAsync(ta.scur, 0, 2 * sizeof(uint32_t), st);
+    // (ta.scur is cleared by the topology kernel, which always runs in front of this one)
     if (n_contigs <= 0 || max_batches <= 0) return;
     const char* fm = getenv("PGA_DPW_SCHED_MISS");
     hipLaunchKernelGGL(k_dpw_sched, dim3((unsigned)n_contigs, (unsigned)((max_batches + 15) / 16)), dim3(256), 0, st, d_cbase, d_bbase, ta, (fm && atoi(fm)) ? 1 : 0);
@@ -1255,7 +1276,7 @@ void pga_launch_dp_wave(const ChainDesc* d_chains, int n_chains, const DpwGroupP
     if (n_chains <= 0) return;
     if (n_blocks <= 0 || d_order == nullptr) n_blocks = n_chains;
     static int occ = 0;
-    if (!occ) { const char* e = getenv("PGA_DPW_OCC"); occ = e ? atoi(e) : 5; if (occ < 4 || occ > 6) occ = 5; }
+    if (!occ) { const char* e = getenv("PGA_DPW_OCC"); occ = e ? atoi(e) : 6; if (occ < 4 || occ > 6) occ = 6; }
 #define DPW_LAUNCH(K) hipLaunchKernelGGL(K, dim3((unsigned)n_blocks), dim3(64), 0, st, d_chains, groups, (const double*)wb.cs, (const DpwExt*)wb.ext, \
                                          d_models, buf, wb.sfxv, wb.sfxi, d_order)
     if (scheduled) { if (occ == 5) DPW_LAUNCH(k_dp_wave<5>); else if (occ == 6) DPW_LAUNCH(k_dp_wave<6>); else DPW_LAUNCH(k_dp_wave<4>); }

@@ -613,6 +613,17 @@ k_tail_tweak(const TailDesc* __restrict__ td, int n_contigs, int64_t n_slots, Ou
 // of the contig c with gpre[c] <= q < gpre[c + 1] (gpre = running sum of n_genes, k_gene_prefix).  With many short contigs the
 // genes are a few per contig: one thread per slot leaves a handful of busy lanes in each of twenty thousand wavefronts, each of
 // which takes as long as its slowest lane; packed, the same lanes fill a few hundred.
+// the tail's starting state in one launch (it was four or five memsets): tracef = -1, elim = 0 for every gathered node; the per-contig
+// counters of changed genes and of genes; the per-chain counters of the many-launch path
+__global__ void __launch_bounds__(256)
+k_tail_init(int32_t* __restrict__ tracef, uint8_t* __restrict__ elim, const int64_t n_nodes, int32_t* __restrict__ nchanged, int32_t* __restrict__ ngenes /* or nullptr */,
+            const int n_contigs, int32_t* __restrict__ seg_cnt /* or nullptr */, const int n_segs) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = t; k <= n_nodes; k += stride) { tracef[k] = -1; elim[k] = 0; }
+    for (int64_t k = t; k <= n_contigs; k += stride) { nchanged[k] = 0; if (ngenes != nullptr) ngenes[k] = 0; }
+    if (seg_cnt != nullptr) for (int64_t k = t; k < n_segs; k += stride) seg_cnt[k] = 0;
+}
+
 __global__ void __launch_bounds__(1024)
 k_gene_prefix(const int32_t* __restrict__ n_genes, int n_contigs, int32_t* __restrict__ gpre) {
     __shared__ int s_w[16];
@@ -1349,22 +1360,29 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         const char* d_seq = batch->d_seq;
         DEVBUF(d_dig, uint8_t, "d_dig", total + 16);
         DEVBUF(d_ct, ContigDesc, "d_ct", NC + 1);
-        DEVBUF(d_cnt, int32_t, "d_cnt", 2 * (size_t)NC);
+        // What the host reads back after the extraction -- the staging-overflow flag, the contigs' GC / unknown counts, the node and stop-node
+        // offsets of every group, the groups a contig is extracted under -- sits in ONE device allocation and ONE pinned one with the same
+        // layout: one read-back instead of five, one memset instead of two (round 6: a lone 20 kbp call was 56 launches, 31 of them the
+        // runtime's own copy and fill kernels).
+        const size_t xa_cnt = 4, xa_cbase = xa_cnt + 2 * (size_t)NC, xa_sbase = xa_cbase + (size_t)NG * (NC + 1), xa_en = xa_sbase + (size_t)NG * (NC + 1);
+        const size_t xa_words = xa_en + ((size_t)NG * NC + 3) / 4 + 1;
+        DEVBUF(d_xa, int32_t, "d_extract_info", xa_words);
+        PINBUF(h_xa, int32_t, "h_extract_info", xa_words);
+        int32_t* const d_st_overflow = d_xa; int32_t* const h_st_overflow = h_xa;
+        int32_t* const d_cnt = d_xa + xa_cnt; int32_t* const h_cnt = h_xa + xa_cnt;
         const int64_t gc_blocks = pga_gc_blocks(total);
         DEVBUF(d_p16, int32_t, "d_gc_p16", total / 16 + 2);
         DEVBUF(d_gc_bsum, int32_t, "d_gc_bsum", gc_blocks + 1);
         DEVBUF(d_gc_boff, int32_t, "d_gc_boff", gc_blocks + 1);
-        DEVBUF(d_cbase, int32_t, "d_cbase", (size_t)NG * (NC + 1));
+        int32_t* const d_cbase = d_xa + xa_cbase; int32_t* const h_cbase = h_xa + xa_cbase;
         DEVBUF(d_tile_first, int32_t, "d_tile_first", (size_t)6 * batch->n_tiles);
         DEVBUF(d_tile_last, int32_t, "d_tile_last", (size_t)6 * batch->n_tiles);
         DEVBUF(d_tile_count, int32_t, "d_tile_count", (size_t)NG * (batch->n_tiles + 1));
         DEVBUF(d_tile_off, int32_t, "d_tile_off", (size_t)NG * (batch->n_tiles + 1));
         DEVBUF(d_tile_scount, int32_t, "d_tile_scount", (size_t)NG * (batch->n_tiles + 1));
         DEVBUF(d_tile_soff, int32_t, "d_tile_soff", (size_t)NG * (batch->n_tiles + 1));
-        DEVBUF(d_sbase, int32_t, "d_sbase", (size_t)NG * (NC + 1));
-        PINBUF(h_sbase, int32_t, "h_sbase", (size_t)NG * (NC + 1));
-        PINBUF(h_cnt, int32_t, "h_cnt", 2 * (size_t)NC);
-        PINBUF(h_cbase, int32_t, "h_cbase", (size_t)NG * (NC + 1));
+        int32_t* const d_sbase = d_xa + xa_sbase; int32_t* const h_sbase = h_xa + xa_sbase;
+        uint8_t* const d_enabled = (uint8_t*)(d_xa + xa_en); uint8_t* const h_enabled = (uint8_t*)(h_xa + xa_en);
 
         GroupArrays ga[4];
         for (int g = 0; g < NG; g++) {
@@ -1377,7 +1395,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
 
         HT(c, hipEventRecord(f->e_start, st));
         HT(c, hipMemcpyAsync(d_ct, ct.data(), sizeof(ContigDesc) * (NC + 1), hipMemcpyHostToDevice, st));
-        HT(c, hipMemsetAsync(d_cnt, 0, sizeof(int32_t) * 2 * (size_t)NC, st));
+        HT(c, hipMemsetAsync(d_xa, 0, sizeof(int32_t) * xa_cbase, st));          // the overflow flag and the counts
         pga_launch_digitize(d_seq, d_dig, total, d_ct, NC, d_cnt, d_cnt + NC, st);
         pga_launch_gc_prefix(d_dig, total, d_gc_bsum, d_gc_boff, d_p16, st);
         MaskList masks{nullptr, nullptr};
@@ -1418,17 +1436,10 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             return publish(R, guard.r, P, out);
         }
         // meta mode: a contig is extracted under a translation table only if a model with that table lies in its GC window
-        DEVBUF(d_enabled, uint8_t, "d_group_enabled", (size_t)NG * NC + 1);
-        PINBUF(h_enabled, uint8_t, "h_group_enabled", (size_t)NG * NC + 1);
-        if (meta_run && NM > 0) {
-            pga_launch_group_enable(d_ct, NC, d_cnt, f->d_model_gc, f->d_model_grp, NM, NG, d_enabled, st);
-            HT(c, hipMemcpyAsync(h_enabled, d_enabled, (size_t)NG * NC, hipMemcpyDeviceToHost, st));
-        }
+        if (meta_run && NM > 0) pga_launch_group_enable(d_ct, NC, d_cnt, f->d_model_gc, f->d_model_grp, NM, NG, d_enabled, st);
         // Staging of the extraction: one slot per two positions of a tile (sequence has a node every 25 positions or so; the full
         // two-slots-per-position staging was half of a context's memory).  A tile that does not fit raises a flag, the batch is then
         // extracted again with full staging, and the context keeps that (PGA_STAGE_FULL=1: from the start).
-        DEVBUF(d_st_overflow, int32_t, "d_st_overflow", 4);
-        PINBUF(h_st_overflow, int32_t, "h_st_overflow", 4);
         if (getenv("PGA_STAGE_FULL")) f->stage_full = true;
         bool stage_full = f->stage_full;
         c->extract_passes = 0;
@@ -1442,7 +1453,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                 GBUF(st_ndx, int32_t, st_slots) GBUF(st_sv, int32_t, st_slots) GBUF(st_info, uint8_t, st_slots)
                 ga[g].st_half = shift; ga[g].st_overflow = d_st_overflow;
             }
-            HT(c, hipMemsetAsync(d_st_overflow, 0, sizeof(int32_t), st));
+            if (c->extract_passes > 0) HT(c, hipMemsetAsync(d_st_overflow, 0, sizeof(int32_t), st));      // (the first pass: cleared with the counts)
             for (int g = 0; g < NG; g++) {
                 const int tt = meta_run ? f->group_tt[g] : (stage == PGA_STAGE_EXTRACT ? tt_override : c->models[0].trans_table);
                 pga_launch_extract(d_dig, total, d_ct, NC, tt, P, ga[g], batch->d_tiles, batch->n_tiles, batch->d_tile0, d_tile_first, d_tile_last,
@@ -1450,10 +1461,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                                    d_tile_scount + (size_t)g * (batch->n_tiles + 1), d_tile_soff + (size_t)g * (batch->n_tiles + 1), d_sbase + (size_t)g * (NC + 1),
                                    masks, st, (meta_run && NM > 0) ? d_enabled + (size_t)g * NC : nullptr);
             }
-            HT(c, hipMemcpyAsync(h_st_overflow, d_st_overflow, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-            HT(c, hipMemcpyAsync(h_cnt, d_cnt, sizeof(int32_t) * 2 * (size_t)NC, hipMemcpyDeviceToHost, st));
-            HT(c, hipMemcpyAsync(h_cbase, d_cbase, sizeof(int32_t) * (size_t)NG * (NC + 1), hipMemcpyDeviceToHost, st));
-            HT(c, hipMemcpyAsync(h_sbase, d_sbase, sizeof(int32_t) * (size_t)NG * (NC + 1), hipMemcpyDeviceToHost, st));
+            HT(c, hipMemcpyAsync(h_xa, d_xa, sizeof(int32_t) * xa_words, hipMemcpyDeviceToHost, st));      // flag, counts, offsets, enabled groups
             HT(c, hipGetLastError());
             HT(c, hipStreamSynchronize(st));
             c->extract_passes++;
@@ -1577,7 +1585,9 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             DEVBUF(b0, DpSrc, "dp_src", tree_cap) DEVBUF(b1, DpTgt, "dp_tgt", tree_cap)
             DEVBUF(b2, double, "dp_score", dp_cap) DEVBUF(b3, int32_t, "dp_traceb", dp_cap)
             DEVBUF(b4, int32_t, "dp_tbn", dp_cap) DEVBUF(b5, int8_t, "dp_ov", dp_cap)
-            DEVBUF(b6, int32_t, "dp_maxidx", dp_slots) DEVBUF(b7, double, "dp_maxscore", dp_slots) DEVBUF(b8, int32_t, "dp_ipath", dp_slots)
+            // (what the host reads back of a chain -- best gene end, its score, the path's start -- in one allocation: one read-back)
+            DEVBUF(b7, double, "dp_chain_results", 2 * dp_slots + 2)
+            int32_t* const b6 = (int32_t*)(b7 + dp_slots); int32_t* const b8 = b6 + dp_slots;
             DEVBUF(b9, double, "dp_A", tree_cap) DEVBUF(b10, double, "dp_V0", tree_cap) DEVBUF(b11, double, "dp_V1", tree_cap)
             DEVBUF(b12, double, "dp_V2", tree_cap) DEVBUF(b13, double, "dp_hv", tree_cap) DEVBUF(b14, int32_t, "dp_hi", tree_cap)
             dp = DpBuffers{b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, {b10, b11, b12}, b13, b14, nullptr};
@@ -1610,7 +1620,6 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             DEVBUF(seg_arena, char, "dp_seg_arena", pga_dp_seg_bytes(seg_plan, NCH, tot_chain_nodes));
             HT(c, pga_dp_seg_bind(seg_plan, NCH, tot_chain_nodes, seg_arena, st, &seg_dev));
         }
-        DEVBUF(d_chains, ChainDesc, "d_chains", NCH + NC + 1);
         // start order of the wave-batch scorer: longest chains first (counting sort on nodes / 64 = walk batches)
         int32_t* d_dp_order = nullptr;
         std::vector<int32_t> dp_order;
@@ -1642,24 +1651,26 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                 for (int q = 0; q < 8; q++) heaviest = std::max(heaviest, load[q]);
                 if (nb > 0 && heaviest * 8 <= total + total * 3 / 10) { by_xcd.resize((size_t)nb); dp_order.swap(by_xcd); }       // within 1.3 x the mean
             }
-            DEVBUF(d_ord, int32_t, "d_dp_order", dp_order.size() + 1);
-            HT(c, hipMemcpyAsync(d_ord, dp_order.data(), sizeof(int32_t) * dp_order.size(), hipMemcpyHostToDevice, st));
-            d_dp_order = d_ord;
         }
-        PINBUF(h_maxidx, int32_t, "h_maxidx", NCH + 1);
-        PINBUF(h_ipath, int32_t, "h_ipath", NCH + 1);
-        PINBUF(h_maxscore, double, "h_maxscore", NCH + 1);
-        HT(c, hipMemcpyAsync(d_chains, chains.data(), sizeof(ChainDesc) * NCH, hipMemcpyHostToDevice, st));
-        int32_t* d_bbase = nullptr;
+        PINBUF(h_maxscore, double, "h_chain_results", 2 * dp_slots + 2);
+        int32_t* const h_maxidx = (int32_t*)(h_maxscore + dp_slots); int32_t* const h_ipath = h_maxidx + dp_slots;
         PINBUF(h_scur, uint32_t, "h_dpw_scur", 16);
-        if (use_sched) {
-            DEVBUF(d_bb, int32_t, "d_dpw_bbase", h_bbase.size() + 1);
-            HT(c, hipMemcpyAsync(d_bb, h_bbase.data(), sizeof(int32_t) * h_bbase.size(), hipMemcpyHostToDevice, st));
-            d_bbase = d_bb;
-        }
+        // The plan of the call goes to the device in ONE copy (round 6; it was four copies and a memset): the cleared flags "scoring turned a
+        // start node into an edge node", per group and contig the run of chains scored on it, the batches before each contig (step
+        // schedule), the start order of the connection scoring, the chains -- one pinned staging area, one device area, the same layout.
+        // (Behind the chains the device area has room for the re-score chains of the winners, which are uploaded later.)
+        const size_t pa_conv = 0, pa_cc = (((size_t)NG * NC + 1) + 7) & ~(size_t)7, pa_bb = pa_cc + sizeof(int2) * (size_t)2 * NG * NC,
+                     pa_ord = pa_bb + ((sizeof(int32_t) * (h_bbase.size() + 1) + 7) & ~(size_t)7),
+                     pa_ch = pa_ord + ((sizeof(int32_t) * (dp_order.size() + 1) + 7) & ~(size_t)7), pa_copy = pa_ch + sizeof(ChainDesc) * (size_t)NCH;
+        DEVBUF(d_plan, char, "d_call_plan", pa_copy + sizeof(ChainDesc) * ((size_t)NC + 2));
+        PINBUF(h_plan, char, "h_call_plan", pa_copy + 64);
+        uint8_t* const d_conv = (uint8_t*)(d_plan + pa_conv);
+        int2* const d_cc = (int2*)(d_plan + pa_cc); int2* const h_cc = (int2*)(h_plan + pa_cc);
+        int32_t* const d_bbase = use_sched ? (int32_t*)(d_plan + pa_bb) : nullptr;
+        if (!dp_order.empty()) d_dp_order = (int32_t*)(d_plan + pa_ord);
+        ChainDesc* const d_chains = (ChainDesc*)(d_plan + pa_ch);
+        memset(h_plan + pa_conv, 0, pa_cc);
         // per group and contig: the contiguous run of chains (models) scored on that contig
-        DEVBUF(d_cc, int2, "d_cc", (size_t)2 * NG * NC + 1);
-        PINBUF(h_cc, int2, "h_cc", (size_t)2 * NG * NC + 1);
         for (size_t k = 0; k < (size_t)2 * NG * NC; k++) h_cc[k] = make_int2(0, 0);
         for (int k = 0; k < NCH; k++) {
             const int g = meta_run ? f->model_group[chains[k].model] : 0;
@@ -1667,14 +1678,15 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             if (e.y == 0) e.x = k;
             e.y++;
         }
-        HT(c, hipMemcpyAsync(d_cc, h_cc, sizeof(int2) * (size_t)NG * NC, hipMemcpyHostToDevice, st));
+        if (use_sched && !h_bbase.empty()) memcpy(h_plan + pa_bb, h_bbase.data(), sizeof(int32_t) * h_bbase.size());
+        if (!dp_order.empty()) memcpy(h_plan + pa_ord, dp_order.data(), sizeof(int32_t) * dp_order.size());
+        if (NCH > 0) memcpy(h_plan + pa_ch, chains.data(), sizeof(ChainDesc) * (size_t)NCH);
+        HT(c, hipMemcpyAsync(d_plan, h_plan, pa_copy, hipMemcpyHostToDevice, st));
 
         tm.mark("plan+alloc");
         std::vector<int32_t> cs_tk[4], cs_en[4];
         ScoreParams sp{P.closed, P.meta, P.max_overlap, NM, nullptr, nullptr};
-        DEVBUF(d_conv, uint8_t, "d_conv_flag", (size_t)NG * NC + 1);
         PINBUF(h_conv, uint8_t, "h_conv_flag", (size_t)NG * NC + 1);
-        if (meta_run) HT(c, hipMemsetAsync(d_conv, 0, (size_t)NG * NC, st));
         const pga_training* d_models = (const pga_training*)c->d_models_raw;
         for (int g = 0; g < NG; g++) {
             pga_launch_place(d_ct, batch->d_tiles, batch->n_tiles, d_tile_off + (size_t)g * (batch->n_tiles + 1),
@@ -1814,9 +1826,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         }
         else pga_launch_dp(d_chains, NCH, c->d_model_const, dp, 1, st, segmented ? &seg_dev : nullptr);
         HT(c, hipEventRecord(f->e_dp1[0], st));
-        HT(c, hipMemcpyAsync(h_maxidx, dp.max_index, sizeof(int32_t) * NCH, hipMemcpyDeviceToHost, st));
-        HT(c, hipMemcpyAsync(h_ipath, dp.ipath, sizeof(int32_t) * NCH, hipMemcpyDeviceToHost, st));
-        HT(c, hipMemcpyAsync(h_maxscore, dp.max_score, sizeof(double) * NCH, hipMemcpyDeviceToHost, st));
+        HT(c, hipMemcpyAsync(h_maxscore, dp.max_score, sizeof(double) * 2 * (size_t)dp_slots, hipMemcpyDeviceToHost, st));       // scores, indices, path starts
         if (meta_run) HT(c, hipMemcpyAsync(h_conv, d_conv, (size_t)NG * NC, hipMemcpyDeviceToHost, st));
         if (segmented) {
             HT(c, hipMemcpyAsync(h_segflags, seg_dev.flags, sizeof(int32_t) * PGA_SEG_ROUNDS * NCH, hipMemcpyDeviceToHost, st));
@@ -1839,9 +1849,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                 HT(c, hipEventRecord(f->e_dp0[0], st));
                 pga_launch_dp_wave(d_chains, NCH, wgroups, c->d_model_const, dp, wbuf, st, d_dp_order, (int)dp_order.size(), false);
                 HT(c, hipEventRecord(f->e_dp1[0], st));
-                HT(c, hipMemcpyAsync(h_maxidx, dp.max_index, sizeof(int32_t) * NCH, hipMemcpyDeviceToHost, st));
-                HT(c, hipMemcpyAsync(h_ipath, dp.ipath, sizeof(int32_t) * NCH, hipMemcpyDeviceToHost, st));
-                HT(c, hipMemcpyAsync(h_maxscore, dp.max_score, sizeof(double) * NCH, hipMemcpyDeviceToHost, st));
+                HT(c, hipMemcpyAsync(h_maxscore, dp.max_score, sizeof(double) * 2 * (size_t)dp_slots, hipMemcpyDeviceToHost, st));
                 HT(c, hipGetLastError());
                 HT(c, hipStreamSynchronize(st));
             }
@@ -2142,17 +2150,16 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             PINBUF(h_ngenes, int32_t, "h_ngenes", NC + 1);
             PINBUF(h_gbegin, int64_t, "h_gbegin", NC + 1);
             HT(c, hipMemcpyAsync(d_td, tdv.data(), sizeof(TailDesc) * NC, hipMemcpyHostToDevice, st));
-            HT(c, hipMemsetAsync(d_tracef, 0xff, sizeof(int32_t) * ((size_t)out_nodes + 1), st));
-            HT(c, hipMemsetAsync(d_elim, 0, (size_t)out_nodes + 1, st));
             DEVBUF(d_path, int32_t, "d_path", out_nodes + 1);
             DEVBUF(d_changed, uint8_t, "d_changed", n_slots + 1);
             DEVBUF(d_nchanged, int32_t, "d_nchanged", NC + 1);
-            HT(c, hipMemsetAsync(d_nchanged, 0, sizeof(int32_t) * ((size_t)NC + 1), st));
+            const unsigned init_blocks = (unsigned)std::min<int64_t>(2048, (std::max<int64_t>(out_nodes, NC) + 256) / 256);
             if (!par_tail) {
+                hipLaunchKernelGGL(k_tail_init, dim3(init_blocks), dim3(256), 0, st, d_tracef, d_elim, out_nodes, d_nchanged, (int32_t*)nullptr, NC, (int32_t*)nullptr, 0);
                 hipLaunchKernelGGL(k_tail_path, dim3((NC + 63) / 64), dim3(64), 0, st, d_td, NC, o, d_tracef, d_elim, d_path, d_gene0, d_ngenes);
             } else {
-                HT(c, hipMemsetAsync(d_ngenes, 0, sizeof(int32_t) * ((size_t)NC + 1), st));
                 std::vector<TpSeg> segs;
+                bool tail_inited = false;
                 for (int i = 0; i < NC; i++) if (win_chain[i] >= 0 && chains[win_chain[i]].n > 0) segs.push_back(TpSeg{out_off[i], chains[win_chain[i]].n, i});
                 std::sort(segs.begin(), segs.end(), [](const TpSeg& a, const TpSeg& b) { return a.off < b.off; });
                 if (!segs.empty() && out_nodes > 0) {
@@ -2168,7 +2175,9 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                     DEVBUF(tp_ins, int32_t, "tp_ins", 2 * tpn) DEVBUF(tp_excl, int32_t, "tp_excl", tpn + 1)
                     DEVBUF(tp_bsum, int32_t, "tp_bsum", nblk + 1) DEVBUF(tp_cnt, int32_t, "tp_cnt", segs.size())
                     HT(c, hipMemcpyAsync(tp_seg, segs.data(), sizeof(TpSeg) * segs.size(), hipMemcpyHostToDevice, st));
-                    if (!tp_one) HT(c, hipMemsetAsync(tp_cnt, 0, sizeof(int32_t) * segs.size(), st));
+                    hipLaunchKernelGGL(k_tail_init, dim3(init_blocks), dim3(256), 0, st, d_tracef, d_elim, out_nodes, d_nchanged, d_ngenes, NC,
+                                       tp_one ? (int32_t*)nullptr : tp_cnt, (int)segs.size());
+                    tail_inited = true;
                     const TpWork tw{tp_seg, (int)segs.size(), out_nodes, levels, tp_up, tp_mark, tp_slots, tp_ins, tp_excl, tp_bsum, tp_cnt};
                     const dim3 grid(nblk), blk(256);
                     if (tp_one) {
@@ -2202,6 +2211,8 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                                        d_gene0, d_ngenes);
                     }
                 }
+                // (no winning chain at all: the counters the tweaks read still start from zero)
+                if (!tail_inited) hipLaunchKernelGGL(k_tail_init, dim3(init_blocks), dim3(256), 0, st, d_tracef, d_elim, out_nodes, d_nchanged, d_ngenes, NC, (int32_t*)nullptr, 0);
             }
             if (max_n >= 32768 && NC <= 1024)       // genomes: a wavefront per gene (at most n / 2 + 2 genes per contig)
                 hipLaunchKernelGGL(k_tail_tweak_wave, dim3((unsigned)((max_n / 2 + 2 + 3) / 4), (unsigned)NC), dim3(256), 0, st, d_td, NC, o, d_tracef,

@@ -104,6 +104,7 @@ struct DpSegPlan {       // host side
     std::vector<int32_t> big;            // the segmented chains
     int64_t extra = 0;                   // scratch elements needed behind the real chains in every per-node DP array
     int32_t max_seg_nodes = 0, max_seg_len = 0, max_big_n = 0;
+    mutable std::vector<char> stage;     // pga_dp_seg_bind: the head of the device workspace as it is uploaded (plan + cleared flags), one copy
 };
 struct DpSegDev {        // device copies + workspace; all owned by the caller
     const DpSeg* segs; const ChainDesc* p1_chains; const int32_t* p1_slot; const int32_t* big;

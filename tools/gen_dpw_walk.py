@@ -32,10 +32,10 @@ PIN = {  # C variable -> pinned VGPRs (both blocks)
     "LV": _v(0, 2), "LT": _v(2), "X0": _v(4, 2), "X1": _v(6, 2), "X2": _v(8, 2), "W0": _v(30, 2), "W1": _v(32, 2),
 }
 PIN_WALK = {"SVL": _v(28, 2)}
-PIN_NEAR = {"NS": _v(18, 2), "NB": _v(20), "NX0": _v(22, 2), "NX1": _v(24, 2), "NX2": _v(26, 2)}
+PIN_NEAR = {"NS": _v(18, 2), "NB": _v(20)}
 VT = {"W": _v(10, 2), "W_lo": _v(10), "W_hi": _v(11), "TG": _v(12), "A": _v(13), "MV": _v(14, 2), "MV_lo": _v(14), "MV_hi": _v(15), "MI": _v(16), "FB": _v(17),
       "LV_lo": _v(0), "LV_hi": _v(1), "X0_lo": _v(4), "X0_hi": _v(5), "X1_lo": _v(6), "X1_hi": _v(7), "X2_lo": _v(8), "X2_hi": _v(9),
-      "NS_lo": _v(18), "NS_hi": _v(19), "NX0_lo": _v(22), "NX0_hi": _v(23), "NX1_lo": _v(24), "NX1_hi": _v(25), "NX2_lo": _v(26), "NX2_hi": _v(27),
+      "NS_lo": _v(18), "NS_hi": _v(19),
       "W0_lo": _v(30), "W0_hi": _v(31), "W1_lo": _v(32), "W1_hi": _v(33)}
 VT.update({"SVL_lo": _v(28), "SVL_hi": _v(29)})
 VT.update(PIN); VT.update(PIN_NEAR); VT.update(PIN_WALK)
@@ -354,7 +354,7 @@ def block(near):
     c("s_and_b64 {TM}, vcc, {MC}")
     c("s_cbranch_scc0 Lf3b_%=")
     c("s_or_b64 {OK}, {OK}, {TM}")
-    xs = ("{NX0}", "{NX1}", "{NX2}") if near else ("{X0}", "{X1}", "{X2}")
+    xs = ("{X0}", "{X1}", "{X2}")
     for f in range(3):
         # the lanes of frame f among them, if the source has an overlapping start of that frame at all
         c("s_bitcmp1_b32 {SVM}, %d" % f)
@@ -362,11 +362,20 @@ def block(near):
         c("v_cmp_eq_u32_e32 vcc, %d, {FB}" % (1 << f))
         c("s_and_b64 {C1}, vcc, {TM}")
         c("s_cbranch_scc0 Lf3o%d_%%=" % f)
-        c("v_readlane_b32 {SX0_lo}, %s, {E0}" % xs[f].replace("}", "_lo}"))
-        c("v_readlane_b32 {SX0_hi}, %s, {E0}" % xs[f].replace("}", "_hi}"))
-        c("s_mov_b64 exec, {C1}")
-        c("s_nop 0")
-        c("v_mov_b64_e32 {W}, {SX0}")            # (one scalar operand per instruction)
+        if near:
+            # (the x[] of a node of the batch before: in LDS, s_px[lane][3])
+            c("s_mul_i32 {TMP}, {E0}, 24")
+            c("s_add_i32 {TMP}, {TMP}, %[pxb]")
+            c("v_mov_b32_e32 {A}, {TMP}")
+            c("s_mov_b64 exec, {C1}")
+            c("ds_read_b64 {W}, {A} offset:%d" % (8 * f))
+            c("s_waitcnt lgkmcnt(0)")
+        else:
+            c("v_readlane_b32 {SX0_lo}, %s, {E0}" % xs[f].replace("}", "_lo}"))
+            c("v_readlane_b32 {SX0_hi}, %s, {E0}" % xs[f].replace("}", "_hi}"))
+            c("s_mov_b64 exec, {C1}")
+            c("s_nop 0")
+            c("v_mov_b64_e32 {W}, {SX0}")            # (one scalar operand per instruction)
         c("v_add_f64 {W}, {SC}, {W}")
         c("s_mov_b64 exec, -1")
         c("Lf3o%d_%%=:" % f)
@@ -533,8 +542,7 @@ def c_statement(near):
     if not near: outs.append('"+{%s}"(a_sv)' % PIN_WALK["SVL"])
     ins = ['"{%s}"(a_x0)' % PIN["X0"], '"{%s}"(a_x1)' % PIN["X1"], '"{%s}"(a_x2)' % PIN["X2"], '"{%s}"(a_w0)' % PIN["W0"], '"{%s}"(a_w1)' % PIN["W1"]]
     if near:
-        ins += ['"{%s}"(a_ns)' % PIN_NEAR["NS"], '"{%s}"(a_nb)' % PIN_NEAR["NB"], '"{%s}"(a_nx0)' % PIN_NEAR["NX0"],
-                '"{%s}"(a_nx1)' % PIN_NEAR["NX1"], '"{%s}"(a_nx2)' % PIN_NEAR["NX2"], '[pk] "v"(a_pk)', '[pndx] "v"(a_pndx)']
+        ins += ['"{%s}"(a_ns)' % PIN_NEAR["NS"], '"{%s}"(a_nb)' % PIN_NEAR["NB"], '[pk] "v"(a_pk)', '[pndx] "v"(a_pndx)', '[pxb] "s"(a_pxb)']
     else:
         ins += ['[tbnpre] "v"(a_tbnpre)']
     ins += ['[kinfo] "v"(a_kinfo)', '[i0] "s"(a_i0)', '[ndx] "v"(a_ndx)', '[cs] "v"(a_cs)', '[negc] "v"(a_negc)', '[igmb] "s"(a_igmb)']
