@@ -1,6 +1,8 @@
 // C-ABI entry points (include/pyrodigal_amd.h): context, models, scorer-level call.
 // Host code only; no CPU compute path exists here -- without a gfx950 device every call fails.
 #include "pga_internal.h"
+#include <malloc.h>
+#include <mutex>
 #include "dpw_core.h"
 
 #include <algorithm>
@@ -43,6 +45,19 @@ extern "C" int pga_create(int device, pga_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return PGA_EDEVICE;
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return PGA_ENODEVICE;   // this library is built for CDNA4 only
+    {
+        // The host side of a large call plans in megabyte-sized std::vectors (26 000 chain descriptors are 2.3 MB) that live for one call.
+        // glibc serves those from mmap and gives them back with munmap -- page faults on the way in, a system call on the way out, about
+        // 0.6 ms of a 9 ms call -- unless its thresholds say otherwise; they did by accident while every call also freed a 16 MB vector of
+        // gene records (round 6: those records now sit in pinned memory).  Once per process; PGA_MALLOPT=0 leaves the allocator alone.
+        static std::once_flag once;
+        std::call_once(once, [] {
+            const char* e = getenv("PGA_MALLOPT");
+            if (e && atoi(e) == 0) return;
+            mallopt(M_MMAP_THRESHOLD, 32 << 20);
+            mallopt(M_TRIM_THRESHOLD, 512 << 20);
+        });
+    }
     pga_ctx* c = new (std::nothrow) pga_ctx();
     if (!c) return PGA_ENOMEM;
     c->device = device;

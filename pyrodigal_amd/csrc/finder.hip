@@ -899,10 +899,31 @@ struct ResultOwner {
     pga_result pub;
     std::vector<pga_contig_result> contigs;
     std::vector<pga_gene> genes;
+    // Round 6: the gene records of a large result land in PINNED memory that the result owns (from the process-wide cache of pinned
+    // blocks, back to it when the result is freed): the read-back of 16 MB per 125 Mbp call is one DMA to where the records stay, where
+    // a std::vector meant a value-initialised allocation (page faults) and a copy staged through the runtime's own pinned buffers,
+    // 0.8 .. 4 ms of a 9 ms call.
+    pga_gene* pin_genes = nullptr; size_t pin_cap = 0, pin_n = 0;
     std::vector<pga_nodes> nodes;
     std::vector<int32_t> mask_off, masks;
     std::vector<void*> blocks;
-    ~ResultOwner() { for (void* b : blocks) free(b); }
+    ~ResultOwner() {
+        for (void* b : blocks) free(b);
+        if (pin_genes != nullptr && !cache_put(1, -1, pin_genes, pin_cap)) (void)hipHostFree(pin_genes);
+    }
+    // room for n gene records; pinned when the result is large enough for it to matter
+    pga_gene* gene_records(const size_t n) {
+        const size_t bytes = n * sizeof(pga_gene);
+        if (bytes < ((size_t)256 << 10) || getenv("PGA_PAGEABLE_RESULTS")) { genes.resize(n); return genes.data(); }
+        size_t cap = 0;
+        void* p = cache_take(1, -1, bytes, &cap);
+        if (p == nullptr) {
+            cap = (bytes + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1);
+            if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); genes.resize(n); return genes.data(); }
+        }
+        pin_genes = (pga_gene*)p; pin_cap = cap; pin_n = n;
+        return pin_genes;
+    }
 };
 
 // one zeroed block per contig for the SoA node arrays of a result
@@ -1298,8 +1319,8 @@ extern "C" void pga_result_free(pga_result* r) {
 // hand the result over to the caller
 static int publish(ResultOwner* R, ResultOwner*& guarded, const pga_params& P, pga_result** out) {
     R->pub.contigs = R->contigs.data();
-    R->pub.genes = R->genes.data();
-    R->pub.n_genes = (int64_t)R->genes.size();
+    R->pub.genes = R->pin_genes != nullptr ? R->pin_genes : R->genes.data();
+    R->pub.n_genes = (int64_t)(R->pin_genes != nullptr ? R->pin_n : R->genes.size());
     R->pub.nodes = !R->nodes.empty() ? R->nodes.data() : nullptr;
     R->pub.mask_off = P.mask ? R->mask_off.data() : nullptr;
     R->pub.masks = P.mask ? R->masks.data() : nullptr;
@@ -2245,7 +2266,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                 cr.model = chains[k].model; cr.n_nodes = chains[k].n;
                 cr.score = P.meta ? 0.0 : (h_ipath[k] >= 0 ? h_maxscore[k] : 0.0);
             }
-            R->genes.resize((size_t)ngenes);
+            pga_gene* const genes_out = R->gene_records((size_t)ngenes);
             if (ngenes > 0) {
                 DEVBUF(d_genes, pga_gene, "d_genes_out", ngenes + 1);
                 HT(c, hipMemcpyAsync(d_gbegin, h_gbegin, sizeof(int64_t) * NC, hipMemcpyHostToDevice, st));
@@ -2253,7 +2274,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                 for (int g = 0; g < NG; g++) gcs.p[g] = ga[g].gc_cont;
                 hipLaunchKernelGGL(k_emit_genes, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, st, d_td, NC, n_slots, o, d_gene2, d_ngenes,
                                    d_gbegin, P.meta ? 0 : 1, d_genes, lean_gather ? 1 : 0, ca, gcs);
-                HT(c, hipMemcpyAsync(R->genes.data(), d_genes, sizeof(pga_gene) * (size_t)ngenes, hipMemcpyDeviceToHost, st));
+                HT(c, hipMemcpyAsync(genes_out, d_genes, sizeof(pga_gene) * (size_t)ngenes, hipMemcpyDeviceToHost, st));
             }
             if (P.want_nodes && out_nodes > 0) {
                 tracef.resize((size_t)out_nodes + 1); elim.resize((size_t)out_nodes + 1);
