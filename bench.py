@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_PER_NODE_PASS = 64.0     # compulsory SoA bytes per DP node-pass
 VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2.0   # wave64 VALU instructions per second the chip can issue (256 CUs x 4 SIMD-32)
-PMC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json")]     # newest first
+PMC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json")]     # newest first
 
 # every kernel of a segmented connection-scoring launch (pga_launch_dp with a plan), for the rocprof summaries
 SEGMENTED_DP_KERNELS = ["k_dp_tree_mw", "k_seg_gather", "k_seg_weights", "k_seg_height", "k_spine_count",

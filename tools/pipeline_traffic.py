@@ -5,7 +5,7 @@ reads on gfx950, WRITE_SIZE 1.0; both in KiB).  A "call" is one pga_find_genes: 
 (bench.py issues full-size calls only, warm-up included).
 
 usage: python tools/pipeline_traffic.py r04_a config4 [commit]
-Writes profiles/<tag>_<workload>_pipeline.json and puts the same under "pipeline:<workload name>" in profiles/r05_pmc_traffic.json,
+Writes profiles/<tag>_<workload>_pipeline.json and puts the same under "pipeline:<workload name>" in profiles/r06_pmc_traffic.json,
 where bench.py finds it (`pipeline` in its JSON line)."""
 import collections
 import csv
@@ -74,11 +74,11 @@ out = {
 path = "profiles/%s_%s_pipeline.json" % (tag, wl)
 json.dump(out, open(path, "w"), indent=1)
 try:
-    merged = json.load(open("profiles/r05_pmc_traffic.json"))
+    merged = json.load(open("profiles/r06_pmc_traffic.json"))
 except (OSError, ValueError):
     merged = {}
 merged["pipeline:" + out["workload"]] = out
-json.dump(merged, open("profiles/r05_pmc_traffic.json", "w"), indent=1)
+json.dump(merged, open("profiles/r06_pmc_traffic.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "kernels"}, indent=1))
 for k, e in list(out["kernels"].items())[:16]:
     print("%-26s %7.3f ms  %8.1f MB  x%.0f" % (k, e["ms_per_call"], e["hbm_MB_per_call"], e["launches_per_call"]))

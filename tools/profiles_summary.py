@@ -2,7 +2,7 @@
 usage: python tools/profiles_summary.py r03_a [commit]
 Writes profiles/<tag>_bench_<workload>_kernel_stats.md, profiles/<tag>_bench_<workload>.json,
 profiles/pmc/<tag>_<workload>_<COUNTER>.csv (connection-scoring kernel rows only), profiles/<tag>_pmc_calibration.md and
-refreshes profiles/r05_pmc_traffic.json, which bench.py reads for roofline.traffic / roofline.valu_issue_frac."""
+refreshes profiles/r06_pmc_traffic.json, which bench.py reads for roofline.traffic / roofline.valu_issue_frac."""
 import csv
 import json
 import os
@@ -64,7 +64,7 @@ for wl in ("config4", "config3", "config2", "config5"):
     bench = json.loads(open(bpath).read().strip().splitlines()[-1])
     json.dump(bench, open("profiles/%s_bench_%s.json" % (tag, wl), "w"), indent=1)
     roof = bench["roofline"]
-    title = "Round 5 (%s) -- bench.py --workload %s --contexts 1: %s, %.1f Mbp/s, %d chains per launch" % (
+    title = "Round 6 (%s) -- bench.py --workload %s --contexts 1: %s, %.1f Mbp/s, %d chains per launch" % (
         tag.split("_")[-1], wl, bench["config"]["workload"], bench["value"], roof["chains_per_launch"])
     md = subprocess.run([sys.executable, "tools/rocpd_stats.py", os.path.join(src, "trace_" + wl, "t_results.db"), title],
                         capture_output=True, text=True, check=True).stdout
@@ -113,7 +113,7 @@ for wl in ("config4", "config3", "config2", "config5"):
         }
 # entries of workloads that were not part of this collection stay (a later collection of one workload refreshes that one only)
 try:
-    merged = json.load(open("profiles/r05_pmc_traffic.json"))
+    merged = json.load(open("profiles/r06_pmc_traffic.json"))
 except (OSError, ValueError):
     merged = {}
 for k, v in traffic.items():
@@ -124,5 +124,5 @@ for k, v in traffic.items():
             v = dict({kk: vv for kk, vv in merged[k].items() if kk not in v}, **v)
     merged[k] = v
 traffic = merged
-json.dump(traffic, open("profiles/r05_pmc_traffic.json", "w"), indent=1)
+json.dump(traffic, open("profiles/r06_pmc_traffic.json", "w"), indent=1)
 print(json.dumps(traffic, indent=1))
