@@ -1039,6 +1039,7 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
         const uint4 ww = g_words[(size_t)b * (2 * DPW_SCHED_STRIDE)];
         mark(1);
         // ---- (1) gene begins: far gene ends, `a` over [lo, min(p_near, i0))
+        int far_ri = -1, far_nd = 0;
         {
             const bool gb = act && (T.kind == 0 || T.kind == 3);
             const int lo = T.lo, hi = min(T.q1, i0);
@@ -1070,7 +1071,10 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
                     }
                 }
             }
-            if (ri >= 0) take(true, rv, ri, 0, P.ndx[ri]);
+            // (the position of that node -- a gather from memory -- is asked for here and used behind (5), if the node is still the lane's
+            //  traceb then: nothing waits for it in between)
+            far_ri = ri;
+            if (ri >= 0) { far_nd = P.ndx[ri]; take(true, rv, ri, 0, -2); }
         }
         mark(2);
         // ---- (3) forward stops: the running maximum of their frame, for the first forward stop of the frame in the batch
@@ -1132,6 +1136,7 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
                 if (j >= i0 && q < 3) open_chain();
             }
         }
+        if (far_ri >= 0 && L.tag >= 0 && dpw_tag_index(L.tag) == far_ri) tbn_pre = far_nd;
         mark(4);
         // ---- (6) the walk, from the schedule: lane k is final when the walk reaches its entry.  A forward stop first pulls the
         //      forward starts of its ORF that sit before it in the batch (the entry's `pull` lanes; they are final by then).
@@ -1143,6 +1148,11 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
         }
         mark(5);
         // ---- (7) the batch is final: results, block structures, carries
+        // (the lane number as the compiler cannot see through: the LDS addresses it makes of `lane` are loop-invariant, it computed them once in
+        //  front of the loop and -- out of registers at six wavefronts per SIMD -- kept them in scratch: five reloads per batch, 0.5 GB of
+        //  HBM reads per launch; one shift-or each, made here, instead)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
         const bool alive = L.tag >= 0;
         const int tb = alive ? (L.tag & DPW_TAG_MASK) : -1;
         {
@@ -1151,7 +1161,7 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
             const int tbn = !alive ? -1 : (tb >= i0 ? nd_in : tbn_pre);
             // what this node offers the next batch as a near source (a gene end that was never reached: -inf, which no lane takes)
             p_ns = (!alive && (T.kind == 1 || T.kind == 2)) ? NEG_INF : L.val; p_tbn = tbn; p_kinfo = kinfo; p_ndx = T.ndx;
-            if (act && T.kind == 1) { s_px[lane][0] = T.x0; s_px[lane][1] = T.x1; s_px[lane][2] = T.x2; }
+            if (act && T.kind == 1) { s_px[ln][0] = T.x0; s_px[ln][1] = T.x1; s_px[ln][2] = T.x2; }
             if (act) {
                 P.score[T.i] = L.val; P.traceb[T.i] = tb; P.tbn[T.i] = tbn; P.ov[T.i] = (int8_t)dpw_tag_ov(L.tag);
             }
@@ -1175,13 +1185,13 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
             const lanemask upto = (2ull << lane) - 1ull;        // the lanes up to this one
             const lanemask rec = vote(has && av == pv) & upto;
             const int pi = rec ? i0 + 63 - __builtin_clzll(rec) : -1;
-            s_ppv[lane] = pv; s_ppi[lane] = pi;
+            s_ppv[ln] = pv; s_ppi[ln] = pi;
             const double bmv = rl_f64(pv, 63); const int bmi = rl_i32(pi, 63);
             // S2 := S1, S1 := S1 moved up a lane with the block's maximum merged in: the new S1 goes where S2 was, the buffers swap roles
             const int pb = b & 1;
-            double nv = lane > 0 ? s_blkv[pb][(lane - 1) & 63] : NEG_INF; int ni = lane > 0 ? s_blki[pb][(lane - 1) & 63] : -1;
+            double nv = ln > 0 ? s_blkv[pb][(ln - 1) & 63] : NEG_INF; int ni = ln > 0 ? s_blki[pb][(ln - 1) & 63] : -1;
             lex_max(nv, ni, bmv, bmi);
-            s_blkv[pb ^ 1][lane] = nv; s_blki[pb ^ 1][lane] = ni;
+            s_blkv[pb ^ 1][ln] = nv; s_blki[pb ^ 1][ln] = ni;
             if (long_chain) {
                 double sv = av; int si = has ? i0 + lane : -1;
                 wave_suffix_lexmax(sv, si, lane);
