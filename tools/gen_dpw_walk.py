@@ -50,12 +50,13 @@ ST = {"SC": pair(18), "SC_lo": "s18", "SC_hi": "s19", "TAGK": "s20", "TMP": "s21
       "TBN": "s35", "LHS": "s14", "SVM": "s15",         # (s32 - s34 and s100 / s101 are the compiler's: stack and frame pointers, scratch)
       "TODO": pair(16),
       "E0": "s36", "E1": "s37", "E3": "s38", "PSL": "s39",      # the source: its lane, its position, its chain index; LDS address of the pull's scratch double
-      "MA": pair(40), "MB": pair(42), "MB_lo": "s42", "MB_hi": "s43", "MC": pair(44), "MD": pair(46), "ME": pair(48), "MF": pair(50),
-      "RW": pair(52), "RW_lo": "s52", "RW_hi": "s53",
-      "K0M": pair(54), "K1M": pair(56), "K2M": pair(58), "K3M": pair(60),         # the targets' kinds as lane masks
-      "SK2": pair(62), "SK3": pair(64), "SK2T": pair(66),                         # the sources': plain reverse starts, reverse stops, reverse starts with a W1 (lane 63 in none)
-      "TABM": pair(68), "GBM": pair(70)}                                          # sources with a W1; gene begins among the targets
-S_LAST = 71
+      # (MA, MC, MD, ME: one pair -- a step needs them one after the other; MB its own: a reverse stop's step holds MA and MB together)
+      "MA": pair(40), "MB": pair(42), "MB_lo": "s42", "MB_hi": "s43", "MC": pair(40), "MD": pair(40), "ME": pair(40), "MF": pair(44),
+      "RW": pair(46), "RW_lo": "s46", "RW_hi": "s47",
+      "K0M": pair(48), "K1M": pair(50), "K2M": pair(52), "K3M": pair(54),         # the targets' kinds as lane masks
+      "SK2": pair(56), "SK3": pair(58), "SK2T": pair(60),                         # the sources': plain reverse starts, reverse stops, reverse starts with a W1 (lane 63 in none)
+      "TABM": pair(62), "GBM": pair(64)}                                          # sources with a W1; gene begins among the targets
+S_LAST = 65
 def s_clobber(near):
     return ["s14", "s15"] + ["s%d" % i for i in range(16, 32)] + ["s35"] + ["s%d" % i for i in range(36, S_LAST + 1)] + ["vcc"]
 
