@@ -1758,6 +1758,8 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                 sl.topo_q2 = wgroups.g[g].q2; sl.ext = wbuf.ext; sp.cs_out = wbuf.cs;
                 // (direct mode: the tail reads star_ptr only at the stop nodes, which k_ovl_stops always writes)
                 sl.fill_star_ptr = !(stage == 0 && direct_gather);
+                // (the path proper, node arrays not asked for: a stop node's zero scores are read by nobody -- ScoreParams::lean_stops)
+                sp.lean_stops = (stage == 0 && direct_gather && sl.starts_only && !getenv("PGA_SS_FULL_STOPS")) ? 1 : 0;
             }
             pga_launch_score(d_chains + g_c0[g], nch, g_n0[g], nn, d_dig, d_ct, ga[g], d_models, f->d_msc, c->d_model_const, ca, sp,
                              d_chains, d_cc + (size_t)g * NC, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], f->d_sd_lut, st, 0,

@@ -75,6 +75,10 @@ struct ScoreParams {
                              // differently by the first and by a later model of a run
     unsigned long long* prof = nullptr;   // PGA_SS_PROFILE=1: wave-cycles per phase of k_score_starts (16 slots), or nullptr
     int32_t models_per_pass = 512;        // k_score_starts walks a workgroup's models in sets of this many (<= 512; PGA_SS_MODELS_PER_PASS: tests)
+    int32_t lean_stops = 0;               // 1: of a stop node's per-chain fields only `edge` is written (round 6).  A stop node carries no start
+                                          // scores (reset_node_scores: zeros); the wave-batch connection scorer, the overlapping-start search and the
+                                          // device tail read a stop node's `edge` and nothing else of them, so the path proper -- no node arrays asked
+                                          // for -- leaves the other twelve fields unwritten: 66 bytes per (stop node, model) pair, 0.6 GB per 125 Mbp call
 };
 
 void pga_launch_digitize(const char* d_seq, uint8_t* d_dig, int64_t total, const ContigDesc* d_ct, int n_contigs,

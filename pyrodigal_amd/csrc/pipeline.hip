@@ -2137,6 +2137,7 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
             for (int m = 0; m < zc.y; m++) {
                 const int64_t gz = chains[zc.x + m].off + (z - zb);
                 ca.edge[gz] = ez;
+                if (sp.lean_stops) continue;
                 ca.cscore[gz] = 0.0; ca.sscore[gz] = 0.0; ca.rscore[gz] = 0.0; ca.uscore[gz] = 0.0; ca.tscore[gz] = 0.0; ca.mot_score[gz] = 0.0;
                 ca.mot_ndx[gz] = 0; ca.mot_len[gz] = 0; ca.mot_spacer[gz] = 0; ca.mot_spacendx[gz] = 0; ca.rbs[2 * gz] = 0; ca.rbs[2 * gz + 1] = 0;
                 if (sp.cs_out != nullptr) sp.cs_out[gz] = 0.0;
