@@ -135,12 +135,12 @@ static size_t cache_limit(int kind) {
     static const size_t gb = [] { const char* e = getenv("PGA_CACHE_GB"); return e ? (size_t)std::max(0, atoi(e)) : (size_t)16; }();
     return kind == 0 ? gb << 30 : std::min<size_t>(gb << 30, (size_t)2 << 30);
 }
-static void* cache_take(int kind, int dev, size_t want, size_t* cap) {
+static void* cache_take(int kind, int dev, size_t want, size_t* cap, size_t roomy = 2) {
     std::lock_guard<std::mutex> g(g_cache_mu);
     std::vector<CachedBlock>& v = g_cache[kind];
     int best = -1;
     for (int k = 0; k < (int)v.size(); k++)
-        if (v[k].dev == dev && v[k].cap >= want && v[k].cap <= 2 * want + ((size_t)1 << 20) && (best < 0 || v[k].cap < v[best].cap)) best = k;
+        if (v[k].dev == dev && v[k].cap >= want && v[k].cap <= roomy * want + ((size_t)1 << 20) && (best < 0 || v[k].cap < v[best].cap)) best = k;
     if (best < 0) return nullptr;
     void* p = v[best].p; *cap = v[best].cap;
     g_cached[kind] -= v[best].cap;
@@ -153,6 +153,23 @@ static bool cache_put(int kind, int dev, void* p, size_t cap) {
     g_cache[kind].push_back(CachedBlock{p, cap, dev});
     g_cached[kind] += cap;
     return true;
+}
+// a pinned block of a freed result: always taken -- when the cache is full the oldest pinned result blocks go back to the runtime first
+// (a workload with results of another size would otherwise pay hipHostMalloc / hipHostFree on every call: round 6, seen as 7 ms steps of a
+// 4 ms workload behind a job that had filled the cache)
+static void cache_put_result(void* p, size_t cap) {
+    std::vector<void*> drop;
+    {
+        std::lock_guard<std::mutex> g(g_cache_mu);
+        std::vector<CachedBlock>& v = g_cache[1];
+        for (size_t k = 0; k < v.size() && (g_cached[1] + cap > cache_limit(1) || v.size() >= 4096); ) {
+            if (v[k].dev != -1) { k++; continue; }
+            drop.push_back(v[k].p); g_cached[1] -= v[k].cap; v.erase(v.begin() + (long)k);
+        }
+        if (g_cached[1] + cap <= cache_limit(1) && v.size() < 4096) { v.push_back(CachedBlock{p, cap, -1}); g_cached[1] += cap; p = nullptr; }
+    }
+    for (void* q : drop) (void)hipHostFree(q);
+    if (p != nullptr) (void)hipHostFree(p);
 }
 extern "C" void pga_release_cached(void) {
     std::lock_guard<std::mutex> g(g_cache_mu);
@@ -909,14 +926,14 @@ struct ResultOwner {
     std::vector<void*> blocks;
     ~ResultOwner() {
         for (void* b : blocks) free(b);
-        if (pin_genes != nullptr && !cache_put(1, -1, pin_genes, pin_cap)) (void)hipHostFree(pin_genes);
+        if (pin_genes != nullptr) cache_put_result(pin_genes, pin_cap);
     }
     // room for n gene records; pinned when the result is large enough for it to matter
     pga_gene* gene_records(const size_t n) {
         const size_t bytes = n * sizeof(pga_gene);
         if (bytes < ((size_t)256 << 10) || getenv("PGA_PAGEABLE_RESULTS")) { genes.resize(n); return genes.data(); }
         size_t cap = 0;
-        void* p = cache_take(1, -1, bytes, &cap);
+        void* p = cache_take(1, -1, bytes, &cap, 8);         // (a block up to eight times the size will do: results vary, pinned allocations cost milliseconds)
         if (p == nullptr) {
             cap = (bytes + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1);
             if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); genes.resize(n); return genes.data(); }
