@@ -481,6 +481,10 @@ k_dpw_sched(const int32_t* __restrict__ cbase, const int32_t* __restrict__ bbase
             if (sk == 2) {
                 r0 = win & gbm & vote(s_ndx < key_r5);
                 r1 = r0 & k3 & vote(t_ndx - s_ndx <= 3 * DPW_OPER_DIST);
+                // (a gene begin it does NOT reach -- a reverse stop one or two bases on, ref: _connection.h:337-342 -- goes into the second
+                //  word, outside the first: the walk's shortcut for a reverse start without a second word, "every gene begin behind it", would
+                //  take it; with the word the step reads its masks, and the first one keeps the lane out)
+                r1 |= gbm & ~r0;
             } else if (sk == 3) {
                 r0 = win & vote(s_stop > t_ndx) & ((k2 & pick3m(sf, fr0, fr1, fr2)) | k3);
                 r1 = 0;
@@ -538,6 +542,11 @@ k_dpw_sched(const int32_t* __restrict__ cbase, const int32_t* __restrict__ bbase
                         const lanemask far3 = k3 & ge(r2);
                         w0 = (k0 & ge(r1)) | far3;
                         w1 = far3 & lt(r3);
+                        // A gene begin behind this node that it does not reach (a reverse stop one or two bases on, ref: _connection.h:337-342):
+                        // the walk's shortcut for a reverse start WITHOUT a second word is "every gene begin behind it" (tools/gen_dpw_walk.py,
+                        // "R5 (plain)").  Such a lane goes into the second word -- outside the first, which masks it out again on the path that
+                        // reads the words.  (stress_variants seed 830022, contig 178: the one node in 10^8 of the sweeps where it decided a gene)
+                        w1 |= gbm & (~1ull << lane) & ~w0;
                     }
                 }
             }

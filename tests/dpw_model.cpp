@@ -78,13 +78,23 @@ void words_of(const Chain& C, const DpwST* T, const int j, const int lane, const
         if ((sk == 2 || sk == 1) && (bits & 2u)) r1 |= 1ull << t;
         if (in_batch && sk == 1 && t < lane && dpw_static_pull(T[t], sf, s_stop)) r0 |= 1ull << t;
     }
+    // A reverse start WITHOUT a W1 takes the walk's shortcut (entry_from): every gene begin behind it, no word read.  Where that is not its
+    // W0 -- a reverse stop one or two bases on, which it does not reach (ref: _connection.h:337-342) -- the lane goes into W1 (outside W0:
+    // priced by the table, masked out by W0), which sends the step down the path that reads the words.
+    if (sk == 2 && !getenv("DPW_MODEL_NO_PLAIN_FIX"))
+        for (int t = in_batch ? lane + 1 : 0; t < 64; t++)
+            if (T[t].i >= 0 && (T[t].kind == 0 || T[t].kind == 3) && !((r0 >> t) & 1ull)) r1 |= 1ull << t;
 }
 // and back: the masks of a step from the words and the kinds of the target lanes (k[q] = lanes of kind q)
 Entry entry_from(const Chain& C, const int j, const int lane, const uint64_t r0, const uint64_t r1, const uint64_t* k, const bool in_batch) {
     Entry e; memset(&e, 0, sizeof e);
     const int kf = C.kf[j], sk = DPW_KIND(kf), sf = DPW_FRAME(kf);
     e.lane = lane; e.code = DPW_E_CODE(sk, sf); e.s_ndx = C.ndx[j]; e.j = j;
-    if (sk == 2) { e.m[0] = r0; e.m[1] = r1; }
+    if (sk == 2) {
+        // as the assembly (tools/gen_dpw_walk.py, "R5 (plain)"): without a W1 the mask is arithmetic -- the gene begins behind the source
+        const uint64_t behind = in_batch ? (lane >= 63 ? 0ull : (~0ull << (lane + 1))) : ~0ull;
+        e.m[0] = r1 ? r0 : ((k[0] | k[3]) & behind); e.m[1] = r1;
+    }
     else if (sk == 3) { e.m[0] = r0 & k[2]; e.m[1] = r0 & k[3]; }
     else {
         const uint64_t later = in_batch ? (lane >= 63 ? 0ull : (~0ull << (lane + 1))) : ~0ull;
@@ -110,7 +120,7 @@ BatchSched compile_batch(const Chain& C, const int b) {
     uint64_t r0, r1;
     for (int j = jm; j < i0; j++) {
         words_of(C, T, j, j - (i0 - 64), false, r0, r1);
-        if (r0 | r1) S.near.push_back(entry_from(C, j, j - (i0 - 64), r0, r1, k, false));
+        if (r0) S.near.push_back(entry_from(C, j, j - (i0 - 64), r0, r1, k, false));
     }
     for (int l = 0; l < 64 && i0 + l < C.n; l++) {
         words_of(C, T, i0 + l, l, true, r0, r1);
@@ -192,7 +202,7 @@ extern "C" int dpw_model_run(int n, const int32_t* ndx, const int32_t* stop_val,
             for (int t = 0; t < 64; t++) {
                 const unsigned bits = lane_bits(e, t) & 31u;
                 if (!bits) continue;
-                if (sk == 2) dpw_take_ge(L[t], true, dpw_sval_r5(LT[t], bits, e.s_ndx, S.score, M), e.j);
+                if (sk == 2) dpw_take_ge(L[t], (bits & 1u) != 0u, dpw_sval_r5(LT[t], bits, e.s_ndx, S.score, M), e.j);
                 else if (sk == 3) dpw_take_ge(L[t], dpw_sok_r3(LT[t], bits, sf), S.score + dpw_w_r3(LT[t], sf), e.j);
                 else dpw_sstep_f3(LT[t], L[t], bits, e.j, e.s_ndx, S.vm, S.tbn, S.score, S.x0, S.x1, S.x2, M);
             }

@@ -187,6 +187,23 @@ def test_wave_kernel_on_synthetic_and_gene_dense_input(ctx, kernel, monkeypatch)
         assert n > 3000
 
 
+@pytest.mark.parametrize("kernel", ["wave", "wavedyn", "wavemiss", "tree1"])
+def test_reverse_start_two_bases_before_a_reverse_stop(ctx, kernel, monkeypatch):
+    # Contig 178 of tools/stress_variants.py seed 830022 (round 6): reverse start 1318 at 19849, reverse stop 1320 at 19851 -- too close to
+    # connect (ref: _connection.h:337-342) -- and no other reverse stop within 3 * OPER_DIST bases behind it, so the node had no second
+    # schedule word and the walk's shortcut for such a reverse start ("every gene begin behind it") connected the two: 2 644 of the
+    # chain's 3 989 nodes differed from the oracle.  k_dpw_sched now puts a gene begin the node does NOT reach into its second word.
+    from pyrodigal_amd import benchdata
+    if kernel.startswith("wave"):
+        _wave_env(monkeypatch, kernel)
+    else:
+        monkeypatch.setenv("PGA_DP_KERNEL", kernel)
+    seq = read_fasta("sweep_830022_178.fna.gz")[0][1]
+    tinf = orc.Training(benchdata.load_model_set()[7][1])
+    n, _ = check(ctx, seq, tinf, closed=True)
+    assert n == 3989
+
+
 def test_topology_from_lds_near_its_node_limit(ctx, monkeypatch):
     # k_dpw_topo_lds stages a contig's node arrays in LDS (12 bytes per node + 2.3 KB): between 5 300 and 6 144 nodes that is more than
     # the 64 KB a kernel may use without asking (hipFuncAttributeMaxDynamicSharedMemorySize); same results as the global-memory kernel

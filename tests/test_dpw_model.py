@@ -97,6 +97,20 @@ def test_model_on_synthetic_contigs(model, gc):
             check(model, seq, tinf, is_meta=True, closed=bool(k & 1))
 
 
+def test_model_reverse_start_two_bases_before_a_reverse_stop(model, monkeypatch):
+    # contig 178 of tools/stress_variants.py seed 830022: a reverse start two bases before a reverse stop it may not connect to, and no other
+    # reverse stop nearby -- the walk's shortcut for a reverse start without a second schedule word must not apply (see words_of); with the
+    # fix switched off the model, which takes the words apart as the assembly does, leaves the oracle exactly where the kernel did
+    from pyrodigal_amd import benchdata
+    seq = read_fasta("sweep_830022_178.fna.gz")[0][1]
+    tinf = orc.Training(benchdata.load_model_set()[7][1])
+    n, _ = check(model, seq, tinf, closed=True)
+    assert n == 3989
+    monkeypatch.setenv("DPW_MODEL_NO_PLAIN_FIX", "1")
+    with pytest.raises(AssertionError):
+        check(model, seq, tinf, closed=True)
+
+
 def test_model_on_tiny_and_degenerate_inputs(model):
     tinf = orc.Training.load(golden_path("SRR492066.training.bin.gz"))
     for L in (0, 3, 61, 100, 130, 200, 400, 700, 1000):
