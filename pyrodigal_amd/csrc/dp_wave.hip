@@ -292,7 +292,7 @@ __device__ __forceinline__ void load_ext(const DpwExt* __restrict__ e, DpwT& T) 
     const int4* p = reinterpret_cast<const int4*>(e);
     const int4 a = p[0], b = p[1], c = p[2], d = p[3];
     T.x0 = __hiloint2double(a.y, a.x); T.x1 = __hiloint2double(a.w, a.z); T.x2 = __hiloint2double(b.y, b.x);
-    T.n3n0 = b.z; T.n3n1 = b.w; T.n3n2 = c.x; T.n3s0 = c.y; T.n3s1 = c.z; T.n3s2 = c.w;
+    T.dlo0 = b.z; T.dlo1 = b.w; T.dlo2 = c.x; T.dhi0 = c.y; T.dhi1 = c.z; T.dhi2 = c.w;
     T.cq0 = d.x; T.cq1 = d.y; T.cq2 = d.z; T.vm = d.w;
 }
 
@@ -306,7 +306,7 @@ __device__ __forceinline__ void load_target_w(DpwT& T, int& kfb, const WavePtrs&
     T.ndx = P.ndx[ii]; T.stop_val = P.stopv[ii]; T.lo = act ? P.lo[ii] : INT_MAX; T.q1 = P.q1[ii]; T.q2 = P.q2[ii];
     T.cs = P.cs[ii]; T.csd = T.cs + negc;
     T.vm = 0; T.x0 = T.x1 = T.x2 = 0.0;
-    T.n3n0 = T.n3n1 = T.n3n2 = T.n3s0 = T.n3s1 = T.n3s2 = 0; T.cq0 = T.cq1 = T.cq2 = DPW_NONE;
+    T.dlo0 = T.dlo1 = T.dlo2 = INT_MAX; T.dhi0 = T.dhi1 = T.dhi2 = INT_MIN; T.cq0 = T.cq1 = T.cq2 = DPW_NONE;
     const int er = P.srank != nullptr ? P.srank[ii] : ii;       // asked for with the other topology fields, not behind them
     if (act && (T.kind & 1)) load_ext(P.ext + er, T);
 }
@@ -736,7 +736,8 @@ k_dpw_dyn(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
                 // a reverse start has one chain (q == 0), a reverse stop one per overlapping start
                 int j = DPW_NONE, bound = 0;
                 if (r5 && q == 0) { j = T.q2; bound = T.stop_val + DPW_MAX_OPP_OVLP - 5; }
-                if (r3 && ((T.vm >> q) & 1)) { j = dpw_sel3i(q, T.cq0, T.cq1, T.cq2); bound = dpw_sel3i(q, T.n3s0, T.n3s1, T.n3s2) + DPW_MAX_OPP_OVLP - 5; }
+                // (dlo = n3s - 5; an overlapping start worth nothing has no interval and is never taken: no chain to walk)
+                if (r3 && dpw_sel3i(q, T.dlo0, T.dlo1, T.dlo2) != INT_MAX) { j = dpw_sel3i(q, T.cq0, T.cq1, T.cq2); bound = dpw_sel3i(q, T.dlo0, T.dlo1, T.dlo2) + DPW_MAX_OPP_OVLP; }
                 while (__any(j < i0)) {
                     if (j < i0) {
                         const int s_ndx = P.ndx[j];
@@ -1003,7 +1004,7 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
             T.ndx = P.ndx[ii]; T.stop_val = P.stopv[ii]; T.lo = in ? P.lo[ii] : INT_MAX; T.q1 = P.q1[ii]; T.q2 = P.q2[ii];
             T.cs = P.cs[ii];
             T.vm = 0; T.x0 = T.x1 = T.x2 = 0.0;
-            T.n3n0 = T.n3n1 = T.n3n2 = T.n3s0 = T.n3s1 = T.n3s2 = 0; T.cq0 = T.cq1 = T.cq2 = DPW_NONE;
+            T.dlo0 = T.dlo1 = T.dlo2 = INT_MAX; T.dhi0 = T.dhi1 = T.dhi2 = INT_MIN; T.cq0 = T.cq1 = T.cq2 = DPW_NONE;
             if (in && ((stops >> lane) & 1ull)) load_ext(P.ext + er, T);
             if (hdr.x == DPW_SCHED_NONE) return;      // the batch's near sources reach past the batch before: the host repeats the launch with k_dpw_dyn
             T.kind = in ? DPW_KIND(kfb) : -1; T.frame = DPW_FRAME(kfb);

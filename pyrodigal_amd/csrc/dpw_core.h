@@ -33,8 +33,12 @@
 // Per-chain extras of a stop node: a 64-byte record at the node's own index (only the records of stop nodes are ever touched).
 struct alignas(64) DpwExt {
     double  x[3];      // F3 source: cs(n3_k) + igm(j, n3_k);  R3 target: cs(n3_k) + igm(n3_k, i)   (n3_k = nodes[star_ptr[k]])
-    int32_t n3n[3];    // R3: position of overlapping start k
-    int32_t n3s[3];    // R3: stop_val of overlapping start k (the far end of that gene)
+    // R3, round 6 -- the interval of forward-stop positions that can reach the node through overlapping start k, made where the extras are
+    // built (k_ovl_stops: a kernel that waits for memory) instead of by every batch of the connection scorer (dpw_lean):
+    //   dlo[k] < s_ndx < dhi[k]   with dlo = n3s - 5, dhi = min(n3s + MAX_OPP_OVLP - 5, (n3n + n3s - 6) >> 1, ndx - 4)   (n3n / n3s: position
+    //   and stop_val of overlapping start k); empty (INT_MAX, INT_MIN) where the start is worth nothing (x[k] <= 0: never taken) or absent.
+    int32_t dlo[3];
+    int32_t dhi[3];
     int32_t cq[3];     // R3: first forward stop that can overlap the 3' end of the gene of overlapping start k, or DPW_NONE
     int32_t vm;        // bit k: star_ptr[k] != -1
 };
@@ -164,7 +168,7 @@ DPW_HD void dpw_chain_ext_sp(const int32_t* ndx, const int32_t* stopv, const int
     e.vm = 0;
     const int my_ndx = ndx[i];
     for (int k = 0; k < 3; k++) {
-        e.x[k] = 0.0; e.n3n[k] = 0; e.n3s[k] = 0; e.cq[k] = DPW_NONE;
+        e.x[k] = 0.0; e.dlo[k] = INT_MAX; e.dhi[k] = INT_MIN; e.cq[k] = DPW_NONE;
         const int p = sp[k];
         if (p < 0) continue;
         e.vm |= 1 << k;
@@ -179,7 +183,14 @@ DPW_HD void dpw_chain_ext_sp(const int32_t* ndx, const int32_t* stopv, const int
         else        // R3 target i, n3 = reverse start: igm(n3, i)          (ref: _connection.h:313-320, 353-355)
             ig = (strand[p] == -1) ? dpw_igm_same(pn, -1, pr, pu, my_ndx, 0.0, 0.0, M.st_wt, M.igm) : M.negc;
         e.x[k] = cs3 + ig;
-        e.n3n[k] = ndx[p]; e.n3s[k] = stopv[p];
+        if (rev && e.x[k] > 0.0) {
+            const int n3n = ndx[p], n3s = stopv[p];
+            int hi = n3s + DPW_MAX_OPP_OVLP - 5;
+            const int h2 = (n3n + n3s - 6) >> 1;
+            if (h2 < hi) hi = h2;
+            if (my_ndx - 4 < hi) hi = my_ndx - 4;
+            e.dlo[k] = n3s - 5; e.dhi[k] = hi;
+        }
         // the overlapping start of a reverse stop is a reverse start: its own first candidate is this pair's (same stop_val)
         if (rev && strand[p] == -1) e.cq[k] = topo_q2[p];
     }
@@ -192,7 +203,7 @@ struct DpwT {
     int kind, frame, ndx, stop_val, lo, q1, q2, vm;
     double cs, csd;             // csd = cs + negc
     double x0, x1, x2;          // stops
-    int n3n0, n3n1, n3n2, n3s0, n3s1, n3s2, cq0, cq1, cq2;      // R3
+    int dlo0, dlo1, dlo2, dhi0, dhi1, dhi2, cq0, cq1, cq2;      // R3 (DpwExt)
 };
 struct DpwS {
     int j, kind, frame, ndx, stop_val, vm;
@@ -238,15 +249,13 @@ DPW_HD void dpw_pair(const DpwS& S, const DpwT& T, const DpwModel& M, bool& ok, 
                     & ((S.ndx - T.stop_val) < (T.stop_val - 3 - S.tbn));
             w = T.csd;
         } else {                      // 3'fwd -> 3'rev, possibly through one of i's overlapping starts (ref: :288-336)
-            const int left = S.ndx + 2, right = T.ndx - 2;
-            ok = ok & (left < right);
+            ok = ok & (S.ndx < T.ndx - 4);
             double maxval = 0.0;
             for (int q = 0; q < 3; q++) {
-                const int n3s = dpw_sel3i(q, T.n3s0, T.n3s1, T.n3s2), n3n = dpw_sel3i(q, T.n3n0, T.n3n1, T.n3n2);
+                const int dlo = dpw_sel3i(q, T.dlo0, T.dlo1, T.dlo2), dhi = dpw_sel3i(q, T.dhi0, T.dhi1, T.dhi2);
                 const double cur = dpw_sel3(q, T.x0, T.x1, T.x2);
-                const int ovlp = left - n3s + 3;
-                const bool tk = (((T.vm >> q) & 1) != 0) & (ovlp > 0) & (ovlp < DPW_MAX_OPP_OVLP) & (ovlp < n3n - left)
-                                & (ovlp < n3s - S.tbn - 2) & (cur > maxval);
+                // (the interval form of the reference's four overlap tests, see DpwLT; an empty interval: no such start, or one worth nothing)
+                const bool tk = (dlo != INT_MAX) & (S.ndx > dlo) & (S.ndx < dhi) & (S.tbn + S.ndx + 7 < 2 * (dlo + 5)) & (cur > maxval);
                 if (tk) { mf = q; maxval = cur; }
             }
             w = mf != -1 ? maxval : M.negc;
@@ -323,18 +332,10 @@ DPW_HD DpwLT dpw_lean(const DpwT& T) {
     L.dlo0 = L.dlo1 = L.dlo2 = INT_MAX; L.dhi0 = L.dhi1 = L.dhi2 = INT_MIN; L.drhs0 = L.drhs1 = L.drhs2 = INT_MIN;
     if (T.kind == 3) {
         L.okhi = T.ndx - 4;
-        for (int q = 0; q < 3; q++) {
-            const int n3s = dpw_sel3i(q, T.n3s0, T.n3s1, T.n3s2), n3n = dpw_sel3i(q, T.n3n0, T.n3n1, T.n3n2);
-            if (!(((T.vm >> q) & 1) && dpw_sel3(q, T.x0, T.x1, T.x2) > 0.0)) continue;
-            const int lo = n3s - 5;
-            int hi = n3s + DPW_MAX_OPP_OVLP - 5;
-            const int h2 = (n3n + n3s - 6) >> 1;
-            if (h2 < hi) hi = h2;
-            if (L.okhi < hi) hi = L.okhi;
-            const int rhs = 2 * n3s;
-            if (q == 0) { L.dlo0 = lo; L.dhi0 = hi; L.drhs0 = rhs; } else if (q == 1) { L.dlo1 = lo; L.dhi1 = hi; L.drhs1 = rhs; }
-            else { L.dlo2 = lo; L.dhi2 = hi; L.drhs2 = rhs; }
-        }
+        // (the intervals come with the extras: DpwExt)
+        L.dlo0 = T.dlo0; L.dlo1 = T.dlo1; L.dlo2 = T.dlo2; L.dhi0 = T.dhi0; L.dhi1 = T.dhi1; L.dhi2 = T.dhi2;
+        L.drhs0 = T.dlo0 != INT_MAX ? 2 * T.dlo0 + 10 : INT_MIN; L.drhs1 = T.dlo1 != INT_MAX ? 2 * T.dlo1 + 10 : INT_MIN;
+        L.drhs2 = T.dlo2 != INT_MAX ? 2 * T.dlo2 + 10 : INT_MIN;
     } else if (T.kind == 2) {
         L.dlo0 = T.stop_val - 4;
         L.dhi0 = T.stop_val + DPW_MAX_OPP_OVLP - 5;

@@ -31,6 +31,7 @@ struct Chain {
 
 DpwT load_target(const Chain& C, const int i, const double negc) {
     DpwT T; memset(&T, 0, sizeof T);
+    T.dlo0 = T.dlo1 = T.dlo2 = INT_MAX; T.dhi0 = T.dhi1 = T.dhi2 = INT_MIN;
     T.i = i < C.n ? i : -1;
     if (T.i < 0) { T.lo = INT_MAX; T.kind = -1; return T; }
     const int kf = C.kf[i];
@@ -39,7 +40,7 @@ DpwT load_target(const Chain& C, const int i, const double negc) {
     if (T.kind & 1) {
         const DpwExt& e = C.ext[i];
         T.vm = e.vm; T.x0 = e.x[0]; T.x1 = e.x[1]; T.x2 = e.x[2];
-        T.n3n0 = e.n3n[0]; T.n3n1 = e.n3n[1]; T.n3n2 = e.n3n[2]; T.n3s0 = e.n3s[0]; T.n3s1 = e.n3s[1]; T.n3s2 = e.n3s[2];
+        T.dlo0 = e.dlo[0]; T.dlo1 = e.dlo[1]; T.dlo2 = e.dlo[2]; T.dhi0 = e.dhi[0]; T.dhi1 = e.dhi[1]; T.dhi2 = e.dhi[2];
         T.cq0 = e.cq[0]; T.cq1 = e.cq[1]; T.cq2 = e.cq[2];
     }
     return T;
