@@ -28,13 +28,37 @@ __device__ __forceinline__ int find_chain(const ChainDesc* __restrict__ chains, 
     return lo;
 }
 
-// The same for every thread of a workgroup whose first element is block_first: one binary search per workgroup (thread 0), then
+// The last index in [0, n) whose key is <= x (keys ascend, key(0) <= x), found by ONE WAVEFRONT together: every lane probes one of 64
+// evenly spaced positions of what is left of the range, a ballot narrows it 64-fold -- three rounds of one load each for 262 144
+// entries, where the binary search of a lone thread is eighteen dependent loads in front of everything the workgroup does (round 6:
+// k_ovl_stops, a workgroup of 256 short threads, spent a third of its life there).  All 64 lanes of the wavefront must call it.
+template <class Key>
+__device__ __forceinline__ int wave_search_le(const Key key, const int n, const int64_t x) {
+    const int lane = threadIdx.x & 63;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int step = (hi - lo + 63) >> 6;
+        const int idx = min(lo + (lane + 1) * step, hi);           // (lane 63 probes hi)
+        const int cnt = __popcll(__ballot((int64_t)key(idx) <= x));      // a prefix of the lanes
+        const int nlo = cnt ? min(lo + cnt * step, hi) : lo;
+        if (cnt < 64) hi = min(lo + (cnt + 1) * step, hi) - 1;
+        lo = nlo;
+    }
+    return lo;
+}
+// ... once per workgroup (its first wavefront), the result in *s_slot for everybody (barrier inside: every thread must call it)
+template <class Key>
+__device__ __forceinline__ int block_search_le(const Key key, const int n, const int64_t x, int* s_slot) {
+    if (threadIdx.x < 64) { const int r = wave_search_le(key, n, x); if (threadIdx.x == 0) *s_slot = r; }
+    __syncthreads();
+    return *s_slot;
+}
+
+// The same for every thread of a workgroup whose first element is block_first: one search per workgroup (its first wavefront), then
 // a short forward walk per thread (a workgroup rarely spans more than two chains) -- a search per thread is sixteen dependent
 // loads that nothing hides.  Every thread of the workgroup must call it (barrier inside).
 __device__ __forceinline__ int find_chain_block(const ChainDesc* __restrict__ chains, int n_chains, int64_t block_first, int64_t g, int* s_slot) {
-    if (threadIdx.x == 0) *s_slot = find_chain(chains, n_chains, block_first);
-    __syncthreads();
-    int c = *s_slot;
+    int c = block_search_le([&](const int k) { return chains[k].off; }, n_chains, block_first, s_slot);
     while (c + 1 < n_chains && chains[c + 1].off <= g) c++;
     return c;
 }

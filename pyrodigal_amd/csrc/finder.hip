@@ -8,6 +8,7 @@
 #include "pga_internal.h"
 #include "pipeline.h"
 #include "dpw_core.h"
+#include "dev_common.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -513,14 +514,8 @@ k_gather_winners(const WinDesc* __restrict__ wd, int n_win, int64_t out_begin, i
     __shared__ int s_w0;
     const int64_t blk0 = out_begin + (int64_t)blockIdx.x * blockDim.x;
     const int64_t g = blk0 + threadIdx.x;
-    if (threadIdx.x == 0) {             // one search per workgroup, then a short walk per thread
-        int lo = 0, hi = n_win - 1;
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (wd[mid].out_off <= blk0) lo = mid; else hi = mid - 1; }
-        s_w0 = lo;
-    }
-    __syncthreads();
+    int lo = block_search_le([&](const int k) { return wd[k].out_off; }, n_win, blk0, &s_w0);      // one search per workgroup, then a short walk per thread
     if (g >= out_begin + total) return;
-    int lo = s_w0;
     while (lo + 1 < n_win && wd[lo + 1].out_off <= g) lo++;
     const WinDesc w = wd[lo];
     const int i = (int)(g - w.out_off);

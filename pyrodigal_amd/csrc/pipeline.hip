@@ -34,16 +34,12 @@ __device__ __forceinline__ int find_contig(const ContigDesc* __restrict__ ct, in
 // Contig / chain of element g for a block whose first element is block_first: one binary search per
 // block (thread 0), then a short forward walk per thread (blocks rarely span more than two contigs).
 __device__ __forceinline__ int block_contig(const ContigDesc* __restrict__ ct, int n, int64_t block_first, int64_t g, int* s_slot) {
-    if (threadIdx.x == 0) *s_slot = find_contig(ct, n, block_first);
-    __syncthreads();
-    int c = *s_slot;
+    int c = block_search_le([&](const int k) { return ct[k].base; }, n, block_first, s_slot);
     while (c + 1 < n && ct[c + 1].base <= g) c++;
     return c;
 }
 __device__ __forceinline__ int block_chain(const ChainDesc* __restrict__ ch, int n, int64_t block_first, int64_t g, int* s_slot) {
-    if (threadIdx.x == 0) *s_slot = find_chain(ch, n, block_first);
-    __syncthreads();
-    int c = *s_slot;
+    int c = block_search_le([&](const int k) { return ch[k].off; }, n, block_first, s_slot);
     while (c + 1 < n && ch[c + 1].off <= g) c++;
     return c;
 }
@@ -2238,14 +2234,8 @@ __global__ void __launch_bounds__(256)
 k_ovl_topo(GroupArrays ga, const int32_t* __restrict__ cbase, const int32_t* __restrict__ sbase, int n_contigs, int n_stops, int maxov) {
     __shared__ int s_c0;
     const int blk0 = blockIdx.x * blockDim.x, s = blk0 + threadIdx.x;
-    if (threadIdx.x == 0) {
-        int lo = 0, hi = n_contigs - 1;
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (sbase[mid] <= blk0) lo = mid; else hi = mid - 1; }
-        s_c0 = lo;
-    }
-    __syncthreads();
+    int c = block_search_le([&](const int k) { return sbase[k]; }, n_contigs, blk0, &s_c0);
     if (s >= n_stops) return;
-    int c = s_c0;
     while (c + 1 < n_contigs && sbase[c + 1] <= s) c++;
     const int b0 = cbase[c], n = cbase[c + 1] - b0;
     const int i = ga.stop_list[s] - b0;
@@ -2287,14 +2277,8 @@ k_ovl_stops(const ChainDesc* __restrict__ chains, int n_chains, int64_t soff_beg
     __shared__ int s_c0;
     const int64_t blk0 = soff_begin + (int64_t)blockIdx.x * blockDim.x;
     const int64_t p = blk0 + threadIdx.x;
-    if (threadIdx.x == 0) {
-        int lo = 0, hi = n_chains - 1;
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (chains[mid].soff <= blk0) lo = mid; else hi = mid - 1; }
-        s_c0 = lo;
-    }
-    __syncthreads();
+    int c = block_search_le([&](const int k) { return chains[k].soff; }, n_chains, blk0, &s_c0);
     if (p >= soff_begin + n_pairs) return;
-    int c = s_c0;
     while (c + 1 < n_chains && chains[c + 1].soff <= p) c++;
     const ChainDesc ch = chains[c];
     const int64_t tb = ch.topo_off;
