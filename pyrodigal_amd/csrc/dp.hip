@@ -1654,7 +1654,7 @@ static int env_int(const char* name, int dflt) {
     return (e && *e) ? atoi(e) : dflt;
 }
 
-bool pga_dp_plan(const ChainDesc* h, int n_chains, int64_t tot_nodes, DpSegPlan& plan) {
+bool pga_dp_plan(const ChainDesc* h, int n_chains, int64_t tot_nodes, DpSegPlan& plan, const bool wave_walk) {
     plan = DpSegPlan();
     if (n_chains <= 0 || n_chains >= 2048 || getenv("PGA_DP_KERNEL") || env_int("PGA_DP_SEG", 1) == 0) return false;
     const int min_chain = std::max(256, env_int("PGA_DP_SEG_MIN", 16384));
@@ -1680,8 +1680,10 @@ bool pga_dp_plan(const ChainDesc* h, int n_chains, int64_t tot_nodes, DpSegPlan&
     if (len <= 0) {
         // what the short chains leave of the compute units, but never less than a quarter of them: a batch of one genome and
         // hundreds of small contigs still cuts the genome (its segments then share the chip with the small chains' workgroups)
-        const int64_t slots = std::max(64, env_int("PGA_DP_SEG_SLOTS", 256) - 4);
-        const int64_t budget = std::max<int64_t>(slots / 4, slots - n_short);
+        // (wave_walk: a wavefront per segment, four to a SIMD -- 4096 at once (a wavefront takes 18.5 us per 64-node batch with two on a SIMD, 26 us with six: measured on config 5, 2048 / 4096 / 6144 segments: 11.8 / 11.4 / 11.6 ms of connection scoring), however long the chains that are not cut: those go to the chain
+        //  kernel in a launch of their own)
+        const int64_t slots = wave_walk ? std::max(64, env_int("PGA_DP_SEG_WSLOTS", 4096)) : std::max(64, env_int("PGA_DP_SEG_SLOTS", 256) - 4);
+        const int64_t budget = wave_walk ? slots : std::max<int64_t>(slots / 4, slots - n_short);
         len = std::max<int64_t>(512, ((cand + budget - 1) / budget + 63) & ~63ll);
         for (int it = 0; count_segs(len) > budget && len < cand; it++) len += it < 256 ? 64 : std::max<int64_t>(64, (len / 8) & ~63ll);
     }
@@ -1793,6 +1795,13 @@ static void launch_dp_segmented(const ChainDesc* d_chains, int n_chains, const M
     const dim3 blk(256);
     auto blocks = [](int n) { return (unsigned)((n + 255) / 256); };
     // (flags and first_bad arrive cleared with the plan: pga_dp_seg_bind)
+    if (sg.wave_groups != nullptr && sg.wave_buf != nullptr) {
+        // the segments (the first n_segs sub-chains of the plan) a wavefront each; the chains that are not cut by the chain kernel
+        pga_launch_dp_wave_sub(sg.p1_chains, sg.n_segs, *sg.wave_groups, d_models, buf, *sg.wave_buf, st, sg.p1_slot);
+        if (sg.n_p1 > sg.n_segs)
+            hipLaunchKernelGGL(k_dp_tree_mw, dim3(sg.n_p1 - sg.n_segs), dim3(64 * PGA_MW_WAVES), 0, st, sg.p1_chains + sg.n_segs, buf.src, buf.tgt, d_models, buf,
+                               (const int32_t*)nullptr, sg.p1_slot + sg.n_segs);
+    } else
     hipLaunchKernelGGL(k_dp_tree_mw, dim3(sg.n_p1), dim3(64 * PGA_MW_WAVES), 0, st, sg.p1_chains, buf.src, buf.tgt, d_models, buf,
                        (const int32_t*)nullptr, sg.p1_slot);
     hipLaunchKernelGGL(k_seg_gather, dim3(blocks(sg.max_seg_len), sg.n_segs), blk, 0, st, sg.segs, d_chains, buf.traceb, sg.ctb);

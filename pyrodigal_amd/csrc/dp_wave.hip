@@ -922,11 +922,17 @@ __device__ __forceinline__ double wave_prefix_max_f64_lean(double v) {
     return v;
 }
 
-template <int OCC>
+// SUB (round 6): the chains are SUB-CHAINS of a few long chains (dp.hip, "segments walked side by side"): sub-chain k is the nodes from
+// ChainDesc::rebase (a multiple of 64) on of the chain whose topology, schedule, extras and cs it reads in place (cs from rec_off), walked
+// from the empty state; its results go to its own region at `off`, in sub-chain indices (k_seg_gather shifts them back), its chain-level
+// results to slot order[k].  Node indices the topology holds (window start, p_near, the first forward stop of a candidate chain) are
+// shifted down on load; what lies before the sub-chain does not exist for it.  The walk of a segment is a SPECULATION that is verified
+// node by node afterwards, so a candidate chain that begins before the sub-chain is simply left out.
+template <int OCC, bool SUB = false>
 __global__ void __launch_bounds__(64, OCC)
 k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const double* __restrict__ g_cs, const DpwExt* __restrict__ g_ext,
           const ModelConst* __restrict__ models, DpBuffers buf, double* __restrict__ g_sfxv, int32_t* __restrict__ g_sfxi,
-          const int32_t* __restrict__ order /* or nullptr: workgroup b walks chain order[b] (longest chains first) */) {
+          const int32_t* __restrict__ order /* or nullptr: workgroup b walks chain order[b] (longest chains first); SUB: the result slot of sub-chain b */) {
     __shared__ double s_igm[64];
     __shared__ DpwCarR s_cr[3];                     // the carries of the chain (see DpwCarR)
     __shared__ DpwCarL s_cl[3];
@@ -938,11 +944,13 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
     __shared__ double s_ppv[64]; __shared__ int s_ppi[64];
     __shared__ double s_px[64][3];
     __shared__ double s_endv; __shared__ int s_endi[2];                 // best gene end: value; index, traceb
-    const int chain = order != nullptr ? order[blockIdx.x] : (int)blockIdx.x;
+    const int chain = SUB ? (int)blockIdx.x : (order != nullptr ? order[blockIdx.x] : (int)blockIdx.x);
     if (chain < 0) return;                          // a filler: the per-XCD queues of the start order are not equally long
     const ChainDesc cd = chains[chain];
     const int lane = threadIdx.x;
     const int n = cd.n;
+    const int rb = SUB ? cd.rebase : 0;             // the chain's node this sub-chain begins at
+    auto down = [&](const int v) { return SUB ? (v == DPW_NONE || v < rb ? DPW_NONE : v - rb) : v; };      // a node index of the topology, or DPW_NONE
     const ModelConst* mc = &models[cd.model];
     s_igm[lane] = mc->igm[lane];
     const double NEG_INF = -__builtin_huge_val();
@@ -955,15 +963,17 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
     k_uint4* s_hdr; const uint4* g_words;
     {
         const DpwTopoArrays& ta = groups.g[cd.group];
-        P.ndx = ta.ndx + cd.topo_off; P.stopv = ta.stop_val + cd.topo_off; P.kf = ta.kf + cd.topo_off;
-        P.lo = ta.lo + cd.topo_off; P.q1 = ta.q1 + cd.topo_off; P.q2 = ta.q2 + cd.topo_off;
-        P.cs = g_cs + cd.off;
-        P.srank = ta.srank != nullptr ? ta.srank + cd.topo_off : nullptr;
-        P.ext = g_ext + (ta.srank != nullptr ? cd.soff : cd.off);
+        const int64_t to = cd.topo_off + rb;
+        P.ndx = ta.ndx + to; P.stopv = ta.stop_val + to; P.kf = ta.kf + to;
+        P.lo = ta.lo + to; P.q1 = ta.q1 + to; P.q2 = ta.q2 + to;
+        P.cs = g_cs + ((SUB && cd.rec_off >= 0) ? cd.rec_off : cd.off);
+        P.srank = ta.srank != nullptr ? ta.srank + to : nullptr;
+        P.ext = g_ext + (ta.srank != nullptr ? cd.soff : cd.off);           // (SUB: by rank from the CHAIN's first stop; the schedule headers hold ranks within the contig)
         P.score = buf.score + cd.off; P.traceb = buf.traceb + cd.off; P.tbn = buf.tbn + cd.off; P.ov = buf.ov_mark + cd.off;
         P.sfxv = g_sfxv + cd.off; P.sfxi = g_sfxi + cd.off;
-        s_hdr = (k_uint4*)(ta.shdr) + cd.sched_b0;
-        g_words = ta.sent + (size_t)cd.sched_b0 * (2 * DPW_SCHED_STRIDE) + 2 * lane;       // this lane's record of batch 0: {W0, W1}, {N0, N1}
+        const int b0 = cd.sched_b0 + (rb >> 6);
+        s_hdr = (k_uint4*)(ta.shdr) + b0;
+        g_words = ta.sent + (size_t)b0 * (2 * DPW_SCHED_STRIDE) + 2 * lane;       // this lane's record of batch 0: {W0, W1}, {N0, N1}
     }
     // a launch ends when its longest chain does: long chains issue first, the short ones fill their stalls
     if (n >= 2048) __builtin_amdgcn_s_setprio(3); else if (n >= 1536) __builtin_amdgcn_s_setprio(2); else if (n >= 1024) __builtin_amdgcn_s_setprio(1);
@@ -1006,7 +1016,15 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
             T.vm = 0; T.x0 = T.x1 = T.x2 = 0.0;
             T.dlo0 = T.dlo1 = T.dlo2 = INT_MAX; T.dhi0 = T.dhi1 = T.dhi2 = INT_MIN; T.cq0 = T.cq1 = T.cq2 = DPW_NONE;
             if (in && ((stops >> lane) & 1ull)) load_ext(P.ext + er, T);
-            if (hdr.x == DPW_SCHED_NONE) return;      // the batch's near sources reach past the batch before: the host repeats the launch with k_dpw_dyn
+            if (SUB) {
+                if (in) T.lo = max(T.lo - rb, 0);
+                T.q1 = max(T.q1 - rb, 0); T.q2 = down(T.q2); T.cq0 = down(T.cq0); T.cq1 = down(T.cq1); T.cq2 = down(T.cq2);
+            }
+            if (hdr.x == DPW_SCHED_NONE) {            // the batch's near sources reach past the batch before: the host repeats the launch with k_dpw_dyn
+                // (SUB: no repeat -- the rest of the sub-chain claims nothing, the verification rejects it and the chain is repaired or walked serially)
+                if (SUB) for (int k = i0 + lane; k < n; k += 64) P.traceb[k] = -1;
+                return;
+            }
             T.kind = in ? DPW_KIND(kfb) : -1; T.frame = DPW_FRAME(kfb);
             T.csd = 0.0;
         }
@@ -1133,7 +1151,7 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
             while (__any(j < i0 || q < 3)) {
                 if (j < i0) {
                     // (the four loads of a hop go out together: a hop is one round trip, whether the chain ends here or not)
-                    const int s_ndx = P.ndx[j], tbj = P.tbn[j], nj = P.q2[j];
+                    const int s_ndx = P.ndx[j], tbj = P.tbn[j], nj = down(P.q2[j]);
                     const double sj = P.score[j];
                     // a reverse start's chain ends at stop_val + MAX_OPP_OVLP - 5 = dlo0 + MAX_OPP_OVLP - 1, a reverse stop's at n3s + MAX_OPP_OVLP - 5 = dlo + MAX_OPP_OVLP
                     if (s_ndx >= dlo + DPW_MAX_OPP_OVLP - (r5 ? 1 : 0)) j = DPW_NONE;
@@ -1242,8 +1260,9 @@ k_dp_wave(const ChainDesc* __restrict__ chains, DpwGroupPtrs groups, const doubl
     // highest score among gene ends, ties to the largest index (ref: lib.pyx:1239-1251, 1311): kept in LDS as the batches went by
     const double end_best = s_endv; const int end_idx = s_endi[0], end_tb = s_endi[1];
     if (lane == 0) {
-        buf.max_index[chain] = end_idx; buf.max_score[chain] = end_idx >= 0 ? end_best : 0.0;
-        buf.ipath[chain] = (end_idx >= 0 && end_tb != -1) ? end_idx : -1;
+        const int slot = SUB && order != nullptr ? order[chain] : chain;
+        buf.max_index[slot] = end_idx; buf.max_score[slot] = end_idx >= 0 ? end_best : 0.0;
+        buf.ipath[slot] = (end_idx >= 0 && end_tb != -1) ? end_idx : -1;
     }
 }
 
@@ -1277,6 +1296,14 @@ void pga_launch_dpw_chain(const ChainDesc* d_chains, int n_chains, int64_t node_
     if (total_nodes <= 0) return;
     hipLaunchKernelGGL(k_dpw_chain, dim3((unsigned)((total_nodes + 255) / 256)), dim3(256), 0, st, d_chains, n_chains, node_begin, total_nodes,
                        nodes, ta, d_models, wb.cs, wb.ext);
+}
+
+// the sub-chains of a segmented launch (dp.hip) by the scheduled wave-batch kernel: one wavefront each, results to slot[k]
+void pga_launch_dp_wave_sub(const ChainDesc* d_subs, int n_subs, const DpwGroupPtrs& groups, const ModelConst* d_models, DpBuffers buf,
+                            const DpwBuffers& wb, hipStream_t st, const int32_t* d_slot) {
+    if (n_subs <= 0) return;
+    hipLaunchKernelGGL((k_dp_wave<6, true>), dim3((unsigned)n_subs), dim3(64), 0, st, d_subs, groups, (const double*)wb.cs, (const DpwExt*)wb.ext,
+                       d_models, buf, wb.sfxv, wb.sfxi, d_slot);
 }
 
 bool pga_dpw_use_sched() {

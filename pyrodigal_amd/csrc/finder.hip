@@ -1588,8 +1588,23 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         DpSegPlan seg_plan;
         // many chains: one wavefront each, records and far-field structures of dp_wave.hip
         const bool use_wave = stage == 0 && pga_dp_use_wave(NCH);
+        // Round 6 -- few LONG chains whose segments the wave-batch kernel walks (dp.hip, launch_dp_segmented): a wavefront per segment, 2048
+        // segments at once where the chain kernel's workgroup per compute unit allows 252.  Every segment pays the same 4096-node warm-up and
+        // a wavefront walks a node more slowly than the sixteen of a chain-kernel workgroup, so this pays where the chains are long enough --
+        // from PGA_DP_SEG_WAVE_MIN (2.5 M) nodes in chains of 16 k nodes or more; PGA_DP_SEG_WAVE=1 / 0: always / never (tests).
+        bool seg_wave = false;
+        if (stage == 0 && !use_wave && pga_dpw_use_sched() && !getenv("PGA_DP_KERNEL")) {
+            int64_t cand = 0;
+            const int min_chain = std::max(256, getenv("PGA_DP_SEG_MIN") ? atoi(getenv("PGA_DP_SEG_MIN")) : 16384);      // (as pga_dp_plan)
+            for (int k = 0; k < NCH; k++) if (chains[(size_t)k].n >= min_chain) cand += chains[(size_t)k].n;
+            const char* e = getenv("PGA_DP_SEG_WAVE");
+            const char* m = getenv("PGA_DP_SEG_WAVE_MIN");
+            seg_wave = e ? atoi(e) != 0 : cand >= (m ? atoll(m) : 2500000ll);
+        }
+        // what the wave-batch kernel reads -- topology, step schedule, cs, extras -- is made for its own launches and for such segments
+        bool wave_prep = use_wave || seg_wave;
         // the step schedule of the wave-batch scorer: one header per 64-node batch of every contig of a group (dpw_core.h)
-        const bool use_sched = use_wave && pga_dpw_use_sched();
+        bool use_sched = wave_prep && pga_dpw_use_sched();
         std::vector<int32_t> h_bbase;
         if (use_sched) {
             h_bbase.resize((size_t)NG * (NC + 1));
@@ -1604,7 +1619,8 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         int max_batches[4] = {0, 0, 0, 0};
         if (use_sched) for (int g = 0; g < NG; g++) for (int i = 0; i < NC; i++)
             max_batches[g] = std::max(max_batches[g], h_bbase[(size_t)g * (NC + 1) + i + 1] - h_bbase[(size_t)g * (NC + 1) + i]);
-        const bool segmented = stage == 0 && !use_wave && pga_dp_plan(chains.data(), NCH, tot_chain_nodes, seg_plan);
+        bool segmented = stage == 0 && !use_wave && pga_dp_plan(chains.data(), NCH, tot_chain_nodes, seg_plan, seg_wave);
+        if (seg_wave && !segmented) { seg_wave = false; wave_prep = use_wave; use_sched = false; h_bbase.clear(); }       // (nothing to cut after all)
         // lean: the tail runs on the device and nobody asked for node arrays, so only what the tail writes is gathered; direct: it
         // also reads the winners' node fields where the scorers left them.  (One definition: the scorers skip the star_ptr fill under
         // exactly the condition under which the tail never looks at it.)
@@ -1612,7 +1628,8 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         const bool direct_gather = lean_gather && !getenv("PGA_GATHER_ALL_DP");
         const int64_t dp_cap = tot_chain_nodes + seg_plan.extra + 1;
         const int64_t dp_slots = NCH + (int64_t)seg_plan.segs.size() + 1;
-        const int64_t tree_cap = use_wave ? 1 : dp_cap;          // records and far-field arrays of the tree / chain kernels
+        // records and far-field arrays of the tree / chain kernels (sub-chains walked by the wave-batch kernel need none of their own)
+        const int64_t tree_cap = use_wave ? 1 : (seg_wave ? tot_chain_nodes + 1 : dp_cap);
         DpBuffers dp;
         {
             DEVBUF(b0, DpSrc, "dp_src", tree_cap) DEVBUF(b1, DpTgt, "dp_tgt", tree_cap)
@@ -1627,7 +1644,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         }
         DpwGroupPtrs wgroups{};
         DpwBuffers wbuf{};
-        if (use_wave) {
+        if (wave_prep) {
             for (int g = 0; g < NG; g++) {
                 char nm[32];
                 const int64_t n = group_nodes[g] + 1;
@@ -1652,6 +1669,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         if (segmented) {
             DEVBUF(seg_arena, char, "dp_seg_arena", pga_dp_seg_bytes(seg_plan, NCH, tot_chain_nodes));
             HT(c, pga_dp_seg_bind(seg_plan, NCH, tot_chain_nodes, seg_arena, st, &seg_dev));
+            if (seg_wave) { seg_dev.wave_groups = &wgroups; seg_dev.wave_buf = &wbuf; }
         }
         // start order of the wave-batch scorer: longest chains first (counting sort on nodes / 64 = walk batches)
         int32_t* d_dp_order = nullptr;
@@ -1761,23 +1779,25 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             sl.starts_only = stage == 0 && !(getenv("PGA_SS_STARTS_ONLY") && atoi(getenv("PGA_SS_STARTS_ONLY")) == 0);
             sl.n_starts = (int32_t)(group_nodes[g] - sl.n_stops);
             sp.cs_out = nullptr;
-            if (use_wave) {
+            if (wave_prep) {
                 int max_nodes_g = 0;
                 for (int i = 0; i < NC; i++) max_nodes_g = std::max(max_nodes_g, h_cbase[(size_t)g * (NC + 1) + i + 1] - h_cbase[(size_t)g * (NC + 1) + i]);
                 if (g < 4) HT(c, hipEventRecord(f->e_aux[4 * g], st));
                 pga_launch_dpw_topo(wgroups.g[g], ga[g].type, ga[g].strand, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], st, max_nodes_g);
                 if (g < 4) HT(c, hipEventRecord(f->e_aux[4 * g + 1], st));
                 sl.topo_q2 = wgroups.g[g].q2; sl.ext = wbuf.ext; sp.cs_out = wbuf.cs;
-                // (direct mode: the tail reads star_ptr only at the stop nodes, which k_ovl_stops always writes)
-                sl.fill_star_ptr = !(stage == 0 && direct_gather);
-                // (the path proper, node arrays not asked for: a stop node's zero scores are read by nobody -- ScoreParams::lean_stops)
-                sp.lean_stops = (stage == 0 && direct_gather && sl.starts_only && !getenv("PGA_SS_FULL_STOPS")) ? 1 : 0;
+                if (use_wave) {
+                    // (direct mode: the tail reads star_ptr only at the stop nodes, which k_ovl_stops always writes)
+                    sl.fill_star_ptr = !(stage == 0 && direct_gather);
+                    // (the path proper, node arrays not asked for: a stop node's zero scores are read by nobody -- ScoreParams::lean_stops)
+                    sp.lean_stops = (stage == 0 && direct_gather && sl.starts_only && !getenv("PGA_SS_FULL_STOPS")) ? 1 : 0;
+                }       // (segments walked by the wave-batch kernel: the re-scoring and verifying kernels read the node arrays in full)
             }
             pga_launch_score(d_chains + g_c0[g], nch, g_n0[g], nn, d_dig, d_ct, ga[g], d_models, f->d_msc, c->d_model_const, ca, sp,
                              d_chains, d_cc + (size_t)g * NC, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], f->d_sd_lut, st, 0,
                              (meta_run || n_cs_tasks > 0) ? f->d_gil + f->gil_off[g] : nullptr, (meta_run || n_cs_tasks > 0) ? f->gil_stride[g] : 0, f->d_model_rank,
                              d_cs_tasks, n_cs_tasks, d_cs_entries, &sl);
-            if (use_wave && use_sched) {
+            if (wave_prep && use_sched) {
                 // (behind the scoring launches: the schedule's headers carry the stop nodes' ranks, which k_ovl_topo writes there)
                 if (g < 4) HT(c, hipEventRecord(f->e_aux[4 * g + 2], st));
                 pga_launch_dpw_sched(wgroups.g[g], d_cbase + (size_t)g * (NC + 1), d_bbase + (size_t)g * (NC + 1), NC, max_batches[g], st);
@@ -1878,7 +1898,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             for (int g = 0; g < NG; g++) if (g_c0[g + 1] > g_c0[g] && g_n0[g + 1] > g_n0[g]) missed += h_scur[2 * g + 1];
             sched_missed = missed;
             if (getenv("PGA_DPW_SCHED_DEBUG")) for (int g = 0; g < NG; g++) fprintf(stderr, "[pga dpw sched] group %d: %u batches missed\n", g, h_scur[2 * g + 1]);
-            if (missed) {
+            if (missed && use_wave) {      // (segments walked by the wave-batch kernel: a missed batch ends its segment's claims, the verification does the rest)
                 // (the first launch's time counts: t_dp_ms covers both)
                 { float ms = 0; HT(c, hipEventElapsedTime(&ms, f->e_dp0[0], f->e_dp1[0])); dp_first_ms = ms; }
                 HT(c, hipEventRecord(f->e_dp0[0], st));
@@ -1899,7 +1919,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         }
         { float ms = 0; HT(c, hipEventElapsedTime(&ms, f->e_dp0[0], f->e_dp1[0])); R->pub.t_dp_ms = NCH > 0 ? ms + dp_first_ms : 0.0; }
         c->dp_timings[0] = R->pub.t_dp_ms; c->dp_timings[1] = c->dp_timings[2] = c->dp_timings[3] = 0.0;
-        if (use_wave) for (int g = 0; g < NG && g < 4; g++) {
+        if (wave_prep) for (int g = 0; g < NG && g < 4; g++) {
             if (!(g_c0[g + 1] > g_c0[g] && g_n0[g + 1] > g_n0[g])) continue;
             float ms = 0;
             if (hipEventElapsedTime(&ms, f->e_aux[4 * g], f->e_aux[4 * g + 1]) == hipSuccess) c->dp_timings[1] += ms;

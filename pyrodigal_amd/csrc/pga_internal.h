@@ -120,9 +120,14 @@ struct DpSegDev {        // device copies + workspace; all owned by the caller
     int64_t n_nodes;     // elements of the real chains in the per-node arrays
     int32_t n_segs, n_p1, n_big, max_seg_nodes, max_seg_len, max_big_n;
     int32_t* h_round = nullptr;   // or: pinned host memory, n_chains ints -- the launcher reads a round's verdict back and stops when every chain passed
+    // Round 6: the segments' speculative walk by the wave-batch kernel (dp_wave.hip, k_dp_wave<6, true>), a wavefront per segment and up to
+    // eight times as many segments as the chain kernel's one workgroup per compute unit allows; nullptr: k_dp_tree_mw walks them
+    const struct DpwGroupPtrs* wave_groups = nullptr;
+    const struct DpwBuffers* wave_buf = nullptr;
 };
-// false: nothing to segment (plan left empty)
-bool pga_dp_plan(const ChainDesc* h_chains, int n_chains, int64_t tot_nodes, DpSegPlan& plan);
+// false: nothing to segment (plan left empty).  wave_walk: the segments are walked by the wave-batch kernel (a wavefront each: PGA_DP_SEG_WSLOTS,
+// 2048, of them at once) instead of the chain kernel (a workgroup each: PGA_DP_SEG_SLOTS, 256)
+bool pga_dp_plan(const ChainDesc* h_chains, int n_chains, int64_t tot_nodes, DpSegPlan& plan, bool wave_walk = false);
 // device workspace of a segmented launch: its size, and its layout inside `arena` + the upload of the plan (the plan must
 // stay alive until the copies on `st` are done)
 size_t pga_dp_seg_bytes(const DpSegPlan& plan, int n_chains, int64_t tot_nodes);
@@ -160,6 +165,9 @@ void pga_launch_dp_wave(const ChainDesc* d_chains, int n_chains, const DpwGroupP
                         const DpwBuffers& wb, hipStream_t st, const int32_t* d_order = nullptr, int n_blocks = 0 /* entries of d_order; < 0 = filler */,
                         bool scheduled = false);
 bool pga_dpw_use_sched();
+// the sub-chains of a segmented launch (DpSegPlan::p1_chains, the first n_segs of them) by the scheduled kernel; results to d_slot[k]
+void pga_launch_dp_wave_sub(const ChainDesc* d_subs, int n_subs, const DpwGroupPtrs& groups, const ModelConst* d_models, DpBuffers buf,
+                            const DpwBuffers& wb, hipStream_t st, const int32_t* d_slot);
 
 // kernel launchers (dp.hip)
 // chains[0..n_chains) must be contiguous in `off`; node_begin = chains[0].off, total_nodes = their node count

@@ -13,7 +13,8 @@ from tests.util import golden_path, read_fasta, synthetic_contig
 
 pytestmark = pytest.mark.gpu
 
-SEG_ENV = ("PGA_DP_SEG", "PGA_DP_SEG_MIN", "PGA_DP_SEG_LEN", "PGA_DP_SEG_WARM", "PGA_DP_SEG_SLOTS", "PGA_DP_SEG_READBACK")
+SEG_ENV = ("PGA_DP_SEG", "PGA_DP_SEG_MIN", "PGA_DP_SEG_LEN", "PGA_DP_SEG_WARM", "PGA_DP_SEG_SLOTS", "PGA_DP_SEG_READBACK",
+           "PGA_DP_SEG_WAVE", "PGA_DP_SEG_WSLOTS", "PGA_DP_SEG_WAVE_MIN", "PGA_DPW_SCHED_MISS")
 
 
 @pytest.fixture(scope="module")
@@ -153,9 +154,12 @@ def test_find_genes_reports_segments_and_matches_serial(ctx):
         c2.close()
 
 
-def test_mixed_launch_segmented_and_whole_chains(ctx):
+@pytest.mark.parametrize("walker", ["chain kernel", "wave kernel"])
+def test_mixed_launch_segmented_and_whole_chains(ctx, walker):
     """One launch holds segments of the long chains next to the short chains walked whole; every node field of every contig
-    against the oracle (the segment settings are shrunk so that a batch of modest contigs has both kinds)."""
+    against the oracle (the segment settings are shrunk so that a batch of modest contigs has both kinds).  wave kernel: the
+    segments a wavefront each by k_dp_wave<6, true> (round 6), the chains that are not cut by the chain kernel in a launch of its own."""
+    os.environ["PGA_DP_SEG_WAVE"] = "1" if walker == "wave kernel" else "0"
     from pyrodigal_amd import _cabi, benchdata
     from tests.test_finder_gpu import compare_contig
     models = benchdata.load_model_set()
@@ -171,5 +175,52 @@ def test_mixed_launch_segmented_and_whole_chains(ctx):
         assert 0 < st["chains"] < res.n_chains and st["segments"] > st["chains"]       # some chains cut, others not
         total = sum(compare_contig(res, i, s, orc.Oracle(s), bins, meta=True) for i, s in enumerate(seqs))
         assert total > 300
+    finally:
+        c2.close()
+
+
+def test_segments_walked_by_the_wave_kernel(ctx):
+    """Round 6: the speculative walk of the segments by the wave-batch kernel (a wavefront per segment, up to 2048 at once) instead of the
+    chain kernel (a workgroup per compute unit): the same genes as the serial walk -- with the default plan, with a warm-up so short that
+    claims are wrong and the repair rounds run, and with a step schedule that reports every batch as missed (a segment then claims nothing:
+    every chain ends in the serial walk)."""
+    from pyrodigal_amd import _cabi, benchdata
+    models = benchdata.load_model_set()
+    c2 = _cabi.Context(0)
+    try:
+        c2.set_models([m[1] for m in models])
+        seq = synthetic_contig(1_200_000, 0.5, 77)
+        os.environ["PGA_DP_SEG"] = "0"
+        b = c2.find_genes_batch([seq], meta=True)
+        assert c2.dp_stats()["chains"] == 0 and len(b.genes) > 100
+        os.environ.pop("PGA_DP_SEG")
+        for env, want in (({}, "clean"), ({"PGA_DP_SEG_MIN": "300", "PGA_DP_SEG_LEN": "2048", "PGA_DP_SEG_WARM": "64"}, "repair"),
+                          ({"PGA_DPW_SCHED_MISS": "1"}, "serial")):
+            for k in SEG_ENV:
+                os.environ.pop(k, None)
+            os.environ["PGA_DP_SEG_WAVE"] = "1"
+            os.environ.update(env)
+            a = c2.find_genes_batch([seq], meta=True)
+            st = c2.dp_stats()
+            assert a.genes.tobytes() == b.genes.tobytes() and np.array_equal(a.contigs["model"], b.contigs["model"])
+            assert st["chains"] >= 1 and st["segments"] > st["chains"]
+            if want == "clean":
+                assert st["segments"] > 256 and st["serial"] == 0 and st["rejected"][-1] == 0       # more segments than the chain kernel could walk at once
+            elif want == "repair":
+                assert sum(st["rejected"]) > 0
+            else:
+                assert st["serial"] >= 1
+        # single mode, a real genome with its own model, every node field against the oracle
+        for k in SEG_ENV:
+            os.environ.pop(k, None)
+        os.environ["PGA_DP_SEG_WAVE"] = "1"
+        from tests.test_finder_gpu import compare_contig
+        g = read_fasta("GCF_001457455.1_NCTC11397_genomic.fna.gz")[0][1]
+        tinf = orc.Training.load(golden_path("GCF_001457455.1_NCTC11397_genomic.tinf_closed.bin.gz"))
+        c2.set_models([tinf.tobytes()])
+        res = c2.find_genes_batch([g], meta=False, closed=True, want_nodes=True)
+        st = c2.dp_stats()
+        assert st["chains"] == 1 and st["segments"] > 256 and st["serial"] == 0
+        assert compare_contig(res, 0, g, orc.Oracle(g), [tinf], meta=False, closed=True) > 2000
     finally:
         c2.close()
