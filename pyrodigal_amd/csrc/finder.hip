@@ -2241,9 +2241,16 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
                                            d_tracef, d_elim, d_gene0, d_ngenes, cap);
                     } else {
                     hipLaunchKernelGGL(k_tp_init, grid, blk, 0, st, tw, d_td, o);
-                    for (int k = 0; k < levels; k++)
-                        hipLaunchKernelGGL(k_tp_jump, grid, blk, 0, st, tw, (const int32_t*)(tp_up + (size_t)(k & 1) * out_nodes),
-                                           tp_up + (size_t)((k + 1) & 1) * out_nodes);
+                    // pointer jumping: 2^levels >= the longest chain; eight hops per launch while three levels or more are left (PGA_TP_JUMP8=0: doubling only)
+                    {
+                        const bool j8 = !(getenv("PGA_TP_JUMP8") && atoi(getenv("PGA_TP_JUMP8")) == 0);
+                        int k = 0;
+                        for (int left = levels; left > 0; k++) {
+                            const int32_t* in = tp_up + (size_t)(k & 1) * out_nodes; int32_t* outp = tp_up + (size_t)((k + 1) & 1) * out_nodes;
+                            if (j8 && left >= 3) { hipLaunchKernelGGL(k_tp_jump8, grid, blk, 0, st, tw, in, outp); left -= 3; }
+                            else { hipLaunchKernelGGL(k_tp_jump, grid, blk, 0, st, tw, in, outp); left -= 1; }
+                        }
+                    }
                     hipLaunchKernelGGL(k_tp_slots, grid, blk, 0, st, tw, d_td, o);
                     hipLaunchKernelGGL(k_tp_scan1, grid, blk, 0, st, tw);
                     hipLaunchKernelGGL(k_tp_scan2, dim3(1), dim3(1024), 0, st, tw, (int)nblk);

@@ -64,6 +64,22 @@ k_tp_jump(TpWork w, const int32_t* __restrict__ up_in, int32_t* __restrict__ up_
     if (w.mark[g]) w.mark[a] = 1;
     up_out[g] = up_in[a];
 }
+// Eight hops per launch (round 6): pointers that reach R nodes become pointers that reach 8 R, a marked node marks its ancestors at R, 2 R,
+// .. 7 R -- after round k the marks cover the first 8^(k+1) nodes of the path, six launches for a chain of 262 144 nodes where the
+// doubling form takes eighteen (a launch of this kind is 3 us of work and 4 us of gap to the next: the genome-sized calls pay per launch).
+__global__ void __launch_bounds__(256)
+k_tp_jump8(TpWork w, const int32_t* __restrict__ up_in, int32_t* __restrict__ up_out) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= w.nw) return;
+    const bool m = w.mark[g] != 0;
+    int a = up_in[g];
+#pragma unroll
+    for (int h = 0; h < 7; h++) {
+        if (m) w.mark[a] = 1;
+        a = up_in[a];
+    }
+    up_out[g] = a;
+}
 
 // what the two untangling passes splice in after path node p (edge p -> nx = traceb[p]); ref: lib.pyx:1253-1295
 __global__ void __launch_bounds__(256)

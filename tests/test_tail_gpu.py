@@ -102,12 +102,15 @@ def test_short_contigs_one_launch_tail(ctx, monkeypatch):
     seqs += [planted(40_000, 0.45, 7), planted(9_000, 0.62, 8), b"", b"ATG" + b"GCA" * 60 + b"TAA", synthetic_contig(70_000, 0.5, 9)]
     runs = run_modes(ctx, monkeypatch, seqs, meta=True)
     monkeypatch.setenv("PGA_TP_STEPS", "1")
-    runs["steps"] = ctx.find_genes_batch(seqs, want_nodes=True, meta=True)
+    runs["steps"] = ctx.find_genes_batch(seqs, want_nodes=True, meta=True)          # pointer jumping eight hops per launch (round 6)
+    monkeypatch.setenv("PGA_TP_JUMP8", "0")
+    runs["steps2"] = ctx.find_genes_batch(seqs, want_nodes=True, meta=True)         # ... and by doubling only
+    monkeypatch.delenv("PGA_TP_JUMP8")
     monkeypatch.delenv("PGA_TP_STEPS")
     assert max(c["n_nodes"] for c in runs["par"].contigs) <= 4096           # or the batch would not take the one-launch form
     total = sum(compare_contig(runs["par"], i, s, orc.Oracle(s), bins, meta=True) for i, s in enumerate(seqs))
     assert total > 500
-    for mode in ("steps", "device", "host"):
+    for mode in ("steps", "steps2", "device", "host"):
         assert runs[mode].genes.tobytes() == runs["par"].genes.tobytes(), mode
         for i in range(len(seqs)):
             for k in ("traceb", "tracef", "ov_mark", "elim"):
