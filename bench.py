@@ -33,7 +33,7 @@ VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2.0   # wave64 VALU instructions per second the
 PMC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json")]     # newest first
 
 # every kernel of a segmented connection-scoring launch (pga_launch_dp with a plan), for the rocprof summaries
-SEGMENTED_DP_KERNELS = ["k_dp_tree_mw", "k_seg_gather", "k_seg_weights", "k_seg_height", "k_spine_count",
+SEGMENTED_DP_KERNELS = ["k_dp_tree_mw", "k_dp_wave", "k_seg_gather", "k_seg_weights", "k_seg_height", "k_spine_count",
                         "k_spine_scan", "k_spine_fill", "k_dp_rescore", "k_seg_leaves", "k_seg_build_far", "k_seg_build_upper",
                         "k_dp_verify"]
 
@@ -79,7 +79,7 @@ def roofline(ctx, dp_ms, passes, calls, n_chains, wname, launch_key=None, aux_ms
     if seg["chains"] > 0:
         # few long chains: the connection scoring is one group of kernels (speculative segment walks, exact
         # re-scoring, verification; dp.hip "segmented chains"), timed as a whole by the same pair of events
-        r["kernel"] = "connection scoring, segmented (k_dp_tree_mw + k_dp_rescore + k_dp_verify + helpers)"
+        r["kernel"] = "connection scoring, segmented (k_dp_tree_mw or, for very long chains, k_dp_wave over the segments + k_dp_rescore + k_dp_verify + helpers)"
         r["kernels"] = SEGMENTED_DP_KERNELS
         r["segments"] = seg["segments"]
         r["rejected_by_verification"] = seg["rejected"]
@@ -449,8 +449,12 @@ def main():
     # HIP events on the library's stream), right after the timed region; the overlapped figure is reported next to it.
     dp_ms, passes, calls = 0.0, 0, 0
     topo_ms = sched_ms = 0.0
+    # (with a ramped call plan: the FULL-SIZE calls only -- the launch the PMC passes profile and the earlier rounds report)
+    full_size = max(len(g) for g in groups)
     for _ in range(max(1, min(args.steps, 3))):
         for k, b in enumerate(batches):
+            if len(groups[k]) != full_size:
+                continue
             r = ctxs[k % n_ctx].find_genes(b, **kw)
             dp_ms += r.t_dp_ms; passes += r.node_passes; calls += 1
             tmg = ctxs[k % n_ctx].dp_timings()
@@ -492,7 +496,7 @@ def main():
             out["pipeline_hbm_bytes_per_bp"] = pl["pipeline_hbm_bytes_per_bp"]         # all kernels of a device call
             out["pipeline"] = pl
         if True:
-            out["roofline"]["measured"] = "calls issued one after the other right after the timed region (kernel alone on the device)"
+            out["roofline"]["measured"] = "the full-size calls (%d contigs) issued one after the other right after the timed region (kernel alone on the device)" % full_size
             out["roofline"]["kernel_ms_per_launch_in_timed_region"] = round(dp_ms_shared / max(calls_shared, 1), 4)
             out["roofline"]["frac_in_timed_region"] = round(BYTES_PER_NODE_PASS * passes_shared / (dp_ms_shared * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if dp_ms_shared > 0 else 0.0
         if world == 1 and not args.no_cpu_baseline and not single:
