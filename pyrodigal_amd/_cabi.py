@@ -334,18 +334,46 @@ class BatchResult:
         return self.genes[c["gene_begin"]:c["gene_begin"] + c["n_genes"]]
 
 
+_SEQ_POINTERS = [False]
+
+
+def _seq_pointers_fn():
+    """``pyrodigal_amd.lib._seq_pointers`` (the Cython host layer's C loop over a list of bytes), or None when that module is not
+    built: argument marshalling only -- the ctypes conversions below do the same, slower."""
+    if _SEQ_POINTERS[0] is False:
+        try:
+            from . import lib as _lib
+            _SEQ_POINTERS[0] = _lib._seq_pointers
+        except Exception:
+            _SEQ_POINTERS[0] = None
+    return _SEQ_POINTERS[0]
+
+
 class Batch:
     """Contigs packed and resident in HBM (``pga_batch``)."""
 
     def __init__(self, ctx, seqs):
         self.ctx = ctx
-        seqs = [s.encode("ascii") if isinstance(s, str) else bytes(s) for s in seqs]
         self.n = len(seqs)
-        self.total = sum(len(s) for s in seqs)
-        ptrs = (ctypes.c_char_p * max(1, self.n))(*seqs)
-        lens = (ctypes.c_int64 * max(1, self.n))(*[len(s) for s in seqs])
+        fast = _seq_pointers_fn() if type(seqs) is list else None
+        arrays = None
+        if fast is not None:
+            try:
+                arrays = fast(seqs)             # every contig a bytes object: the argument arrays by one C loop
+            except TypeError:
+                arrays = None
+        if arrays is not None:
+            p_arr, l_arr, self.total = arrays
+            ptrs = p_arr.ctypes.data_as(ctypes.POINTER(ctypes.c_char_p))
+            lens = l_arr.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+        else:
+            seqs = [s.encode("ascii") if isinstance(s, str) else bytes(s) for s in seqs]
+            self.total = sum(len(s) for s in seqs)
+            ptrs = (ctypes.c_char_p * max(1, self.n))(*seqs)
+            lens = (ctypes.c_int64 * max(1, self.n))(*[len(s) for s in seqs])
         h = ctypes.c_void_p()
         rc = ctx.L.pga_batch_create(ctx.h, self.n, ptrs, lens, ctypes.byref(h))
+        del arrays
         if rc != PGA_OK:
             _raise(ctx.L, ctx.h, rc, "pga_batch_create")
         self.h = h

@@ -100,6 +100,10 @@ struct FinderState {
     std::vector<size_t> gil_off; std::vector<int> gil_stride; std::vector<int32_t> model_rank;
     unsigned* d_sd_lut = nullptr;   // RBS search table (pga_launch_sd_lut), filled when the context's finder state is created
     std::mutex spare_mu; void* spare_p = nullptr; size_t spare_cap = 0;   // the letters' allocation of the last batch that was freed
+    // Round 6: an upload (pga_batch_create) may run BESIDE a call of the same context -- a caller that keeps the next batch on its way
+    // while the current one is being worked on: double buffering of H2D against the kernels.  So the upload has a stream, a pinned
+    // staging area and a worker pool of its own and touches nothing else of the context; one upload at a time per context (up_mu).
+    std::mutex up_mu; WorkerPool up_pool; hipStream_t up_stream = nullptr; void* up_pin = nullptr; size_t up_pin_cap = 0;
     hipEvent_t e_start = nullptr, e_stop = nullptr, e_dp0[4] = {}, e_dp1[4] = {};
     hipEvent_t e_aux[20] = {};      // around the topology / schedule launches of each group (pga_dp_timings), and the first of two connection-scoring launches
 };
@@ -998,6 +1002,8 @@ void pga_finder_release(pga_ctx* c) {
     if (c->finder->d_model_rank) hipFree(c->finder->d_model_rank);
     if (c->finder->d_sd_lut) hipFree(c->finder->d_sd_lut);
     if (c->finder->spare_p) hipFree(c->finder->spare_p);
+    if (c->finder->up_stream) { (void)hipStreamSynchronize(c->finder->up_stream); (void)hipStreamDestroy(c->finder->up_stream); }
+    if (c->finder->up_pin && !cache_put(1, c->device, c->finder->up_pin, c->finder->up_pin_cap)) hipHostFree(c->finder->up_pin);
     if (c->finder->e_start) hipEventDestroy(c->finder->e_start);
     if (c->finder->e_stop) hipEventDestroy(c->finder->e_stop);
     for (int i = 0; i < 4; i++) { if (c->finder->e_dp0[i]) hipEventDestroy(c->finder->e_dp0[i]); if (c->finder->e_dp1[i]) hipEventDestroy(c->finder->e_dp1[i]); }
@@ -1196,6 +1202,22 @@ static void batch_give_dev(pga_ctx* c, char* p, size_t cap) {
     if (drop) hipFree(drop);
 }
 
+// the upload's own stream and pinned staging area (FinderState::up_*; the caller holds up_mu)
+static int upload_resources(pga_ctx* c, size_t pin_bytes, hipStream_t* st, char** pin) {
+    FinderState* f = c->finder;
+    if (!f->up_stream) HT(c, hipStreamCreateWithFlags(&f->up_stream, hipStreamNonBlocking));
+    *st = f->up_stream;
+    if (pin_bytes > 0 && (f->up_pin_cap < pin_bytes || !f->up_pin)) {
+        if (f->up_pin) { hipHostFree(f->up_pin); f->up_pin = nullptr; f->up_pin_cap = 0; }
+        size_t want = pin_bytes + pin_bytes / 4 + 256;
+        f->up_pin = cache_take(1, c->device, want, &want);
+        if (!f->up_pin) HT(c, alloc_or_evict(1, [&] { return hipHostMalloc(&f->up_pin, want, hipHostMallocDefault); }));
+        f->up_pin_cap = want;
+    }
+    if (pin) *pin = (char*)f->up_pin;
+    return PGA_OK;
+}
+
 extern "C" int pga_batch_create(pga_ctx* c, int32_t n_contigs, const char* const* seqs, const int64_t* lens, pga_batch** out) {
     if (out) *out = nullptr;
     if (!c || !out || n_contigs < 0 || (n_contigs > 0 && (!seqs || !lens))) { if (c) c->err = "pga_batch_create: bad arguments"; return PGA_EINVAL; }
@@ -1214,9 +1236,9 @@ extern "C" int pga_batch_create(pga_ctx* c, int32_t n_contigs, const char* const
     b->total = total;
     if (total >= 0x7fffffffLL) { delete b; c->err = "pga_batch_create: batch larger than 2^31 bases; split it"; return PGA_EINVAL; }
     if (total > 0) {
-        void* hp; int rc = ensure_pin(c, "h_seq", (size_t)total + 16, &hp);
-        if (rc) { delete b; return rc; }
-        char* h_seq = (char*)hp;
+        std::lock_guard<std::mutex> up(c->finder->up_mu);          // one upload at a time per context; a call of the context may run beside it
+        hipStream_t st = nullptr; char* h_seq = nullptr;
+        { const int rc = upload_resources(c, (size_t)total + 16, &st, &h_seq); if (rc) { delete b; return rc; } }
         std::vector<TileDesc> tiles; std::vector<int32_t> tile0;
         batch_tiles(b, tiles, tile0);
         if (batch_take_dev(c, (size_t)total + 16 + batch_tiles_bytes(tiles, tile0), &b->d_seq, &b->d_seq_cap) != hipSuccess) { delete b; c->err = "pga_batch_create: hipMalloc failed"; return PGA_ENOMEM; }
@@ -1230,7 +1252,6 @@ extern "C" int pga_batch_create(pga_ctx* c, int32_t n_contigs, const char* const
         const int n_slices = (int)cut.size() - 1;
         std::atomic<int> next{0};
         std::atomic<int> first_err{(int)hipSuccess};
-        hipStream_t st = c->stream;
         const int dev = c->device;
         char* d_seq = b->d_seq;
         const ContigDesc* ct = b->ct.data();
@@ -1260,7 +1281,7 @@ extern "C" int pga_batch_create(pga_ctx* c, int32_t n_contigs, const char* const
             static const bool turns = !(getenv("PGA_UPLOAD_TURNS") && atoi(getenv("PGA_UPLOAD_TURNS")) == 0);
             std::unique_lock<std::mutex> turn(upload_turns[c->device & 63], std::defer_lock);
             if (turns && total >= (8 << 20)) turn.lock();
-            if (threads == 1) work(); else c->finder->pool.run(work, threads);
+            if (threads == 1) work(); else c->finder->up_pool.run(work, threads);
             e = (hipError_t)first_err.load();
             if (e == hipSuccess) e = batch_upload_tiles(b, b->d_seq + total + 16, tiles, tile0, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -1294,9 +1315,12 @@ extern "C" int pga_batch_create_packed(pga_ctx* c, int32_t n_contigs, const char
         batch_tiles(b, tiles, tile0);
         if (batch_take_dev(c, (size_t)total + 16 + batch_tiles_bytes(tiles, tile0), &b->d_seq, &b->d_seq_cap) != hipSuccess) { delete b; c->err = "pga_batch_create_packed: hipMalloc failed"; return PGA_ENOMEM; }
         // the letters go straight from the caller's (pinned) buffer: one DMA, overlapped with the tile list's host work
-        hipError_t e = hipMemcpyAsync(b->d_seq, packed + offs[0], (size_t)total, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = batch_upload_tiles(b, b->d_seq + total + 16, tiles, tile0, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        std::lock_guard<std::mutex> up(c->finder->up_mu);
+        hipStream_t st = nullptr;
+        { const int rc = upload_resources(c, 0, &st, nullptr); if (rc) { batch_give_dev(c, b->d_seq, b->d_seq_cap); delete b; return rc; } }
+        hipError_t e = hipMemcpyAsync(b->d_seq, packed + offs[0], (size_t)total, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = batch_upload_tiles(b, b->d_seq + total + 16, tiles, tile0, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { batch_give_dev(c, b->d_seq, b->d_seq_cap); delete b; return pga_hip_try_(c, e, "upload of the packed batch"); }
     }
     *out = b;

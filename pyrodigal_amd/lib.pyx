@@ -1923,3 +1923,24 @@ cdef Nodes _nodes_from_blob(bytes blob, ssize_t n):
         f[name] = a.reshape(-1, mult) if mult > 1 else a
         at += a.nbytes
     return out
+
+
+def _seq_pointers(list seqs):
+    """The C-ABI's argument arrays for a list of ``bytes`` contigs: (addresses as uint64, lengths as int64, total bases).  What
+    `_cabi.Batch` hands to ``pga_batch_create`` -- one C loop instead of 6 000 ctypes conversions under the GIL per device call
+    (4 - 7 ms of a 6 250-contig call's host time).  The caller keeps ``seqs`` alive while the addresses are in use."""
+    cdef ssize_t n = len(seqs), i
+    cdef int64_t total = 0
+    ptrs = np.empty(max(n, 1), dtype=np.uint64)
+    lens = np.empty(max(n, 1), dtype=np.int64)
+    cdef unsigned long long[::1] p = ptrs
+    cdef int64_t[::1] l = lens
+    cdef object o
+    for i in range(n):
+        o = seqs[i]
+        if not isinstance(o, bytes):
+            raise TypeError("contigs must be bytes")
+        p[i] = <unsigned long long> <size_t> PyBytes_AS_STRING(o)
+        l[i] = len(<bytes> o)
+        total += l[i]
+    return ptrs, lens, total
