@@ -1528,6 +1528,24 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         }
 
         tm.mark("extract+sync");
+        // ---- topology buffers; the nodes go to their places and get their GC content while the host plans the chains: neither kernel
+        //      reads anything of the plan (round 6: the device sat idle through the 0.7 ms of planning of a 6 250-contig call)
+        int64_t group_nodes[4] = {0, 0, 0, 0};
+        for (int g = 0; g < NG; g++) {
+            char nm[32];
+            group_nodes[g] = h_cbase[(size_t)g * (NC + 1) + NC];
+            const int64_t n = group_nodes[g] + 1;
+            GBUF(ndx, int32_t, n) GBUF(stop_val, int32_t, n) GBUF(type, uint8_t, n) GBUF(strand, int8_t, n) GBUF(edge0, uint8_t, n) GBUF(gc_cont, float, n) GBUF(contig_of, int32_t, n)
+            GBUF(stop_list, int32_t, (int64_t)h_sbase[(size_t)g * (NC + 1) + NC] + 1)
+            GBUF(start_list, int32_t, group_nodes[g] - (int64_t)h_sbase[(size_t)g * (NC + 1) + NC] + 1)
+            GBUF(ovl_topo, uint32_t, (int64_t)h_sbase[(size_t)g * (NC + 1) + NC] + 1)
+            GBUF(srank, int32_t, n + 4)
+        }
+        for (int g = 0; g < NG; g++) {
+            pga_launch_place(d_ct, batch->d_tiles, batch->n_tiles, d_tile_off + (size_t)g * (batch->n_tiles + 1),
+                             d_tile_soff + (size_t)g * (batch->n_tiles + 1), ga[g], st);
+            pga_launch_orf_gc(d_ct, NC, d_dig, d_p16, ga[g], (int)group_nodes[g], d_cbase + (size_t)g * (NC + 1), st);
+        }
         // ---- plan the (contig, model) chains (ref: lib.pyx:5335-5362) ------------------------
         std::vector<std::vector<ChainDesc>> gch(NG);     // per group, in (contig, model) order
         std::vector<double> mgc((size_t)NM); std::vector<int> mtt((size_t)NM);     // the models are 558 KB apart: keep what the loop reads together
@@ -1583,18 +1601,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         if (meta_run) for (int g = 0; g < NG; g++) max_rescore += h_cbase[(size_t)g * (NC + 1) + NC];   // loose bound: every node once per group
         const int64_t chain_cap = tot_chain_nodes + max_rescore + 64;
 
-        // ---- topology + chain buffers ----------------------------------------------------------
-        int64_t group_nodes[4] = {0, 0, 0, 0};
-        for (int g = 0; g < NG; g++) {
-            char nm[32];
-            group_nodes[g] = h_cbase[(size_t)g * (NC + 1) + NC];
-            const int64_t n = group_nodes[g] + 1;
-            GBUF(ndx, int32_t, n) GBUF(stop_val, int32_t, n) GBUF(type, uint8_t, n) GBUF(strand, int8_t, n) GBUF(edge0, uint8_t, n) GBUF(gc_cont, float, n) GBUF(contig_of, int32_t, n)
-            GBUF(stop_list, int32_t, (int64_t)h_sbase[(size_t)g * (NC + 1) + NC] + 1)
-            GBUF(start_list, int32_t, group_nodes[g] - (int64_t)h_sbase[(size_t)g * (NC + 1) + NC] + 1)
-            GBUF(ovl_topo, uint32_t, (int64_t)h_sbase[(size_t)g * (NC + 1) + NC] + 1)
-            GBUF(srank, int32_t, n + 4)
-        }
+        // ---- chain buffers ---------------------------------------------------------------------
         ChainArrays ca;
         {
             DEVBUF(a0, double, "ca_cscore", chain_cap) DEVBUF(a1, double, "ca_sscore", chain_cap) DEVBUF(a2, double, "ca_rscore", chain_cap)
@@ -1688,6 +1695,16 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             }
             DEVBUF(w0, double, "dpw_cs", dp_cap + 2) DEVBUF(w1, DpwExt, "dpw_ext", tot_chain_stops + 4)      /* one extras record per (chain, stop node) pair */ DEVBUF(w2, double, "dpw_sfxv", dp_cap) DEVBUF(w3, int32_t, "dpw_sfxi", dp_cap)
             wbuf = DpwBuffers{w0, w1, w2, w3};
+            // the topology of every group now: it reads the placed nodes and nothing of the plan, and runs under the rest of the planning
+            // (start order, the copy of the plan, the coding-score tasks)
+            for (int g = 0; g < NG; g++) {
+                if (g_c0[g + 1] - g_c0[g] == 0 || g_n0[g + 1] - g_n0[g] == 0 || stage == PGA_STAGE_EXTRACT) continue;
+                int max_nodes_g = 0;
+                for (int i = 0; i < NC; i++) max_nodes_g = std::max(max_nodes_g, h_cbase[(size_t)g * (NC + 1) + i + 1] - h_cbase[(size_t)g * (NC + 1) + i]);
+                if (g < 4) HT(c, hipEventRecord(f->e_aux[4 * g], st));
+                pga_launch_dpw_topo(wgroups.g[g], ga[g].type, ga[g].strand, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], st, max_nodes_g);
+                if (g < 4) HT(c, hipEventRecord(f->e_aux[4 * g + 1], st));
+            }
         }
         DpSegDev seg_dev{};
         if (segmented) {
@@ -1764,9 +1781,6 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         PINBUF(h_conv, uint8_t, "h_conv_flag", (size_t)NG * NC + 1);
         const pga_training* d_models = (const pga_training*)c->d_models_raw;
         for (int g = 0; g < NG; g++) {
-            pga_launch_place(d_ct, batch->d_tiles, batch->n_tiles, d_tile_off + (size_t)g * (batch->n_tiles + 1),
-                             d_tile_soff + (size_t)g * (batch->n_tiles + 1), ga[g], st);
-            pga_launch_orf_gc(d_ct, NC, d_dig, d_p16, ga[g], (int)group_nodes[g], d_cbase + (size_t)g * (NC + 1), st);
             const int nch = g_c0[g + 1] - g_c0[g];
             const int64_t nn = g_n0[g + 1] - g_n0[g];
             if (nch == 0 || nn == 0 || stage == PGA_STAGE_EXTRACT) continue;
@@ -1804,11 +1818,6 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             sl.n_starts = (int32_t)(group_nodes[g] - sl.n_stops);
             sp.cs_out = nullptr;
             if (wave_prep) {
-                int max_nodes_g = 0;
-                for (int i = 0; i < NC; i++) max_nodes_g = std::max(max_nodes_g, h_cbase[(size_t)g * (NC + 1) + i + 1] - h_cbase[(size_t)g * (NC + 1) + i]);
-                if (g < 4) HT(c, hipEventRecord(f->e_aux[4 * g], st));
-                pga_launch_dpw_topo(wgroups.g[g], ga[g].type, ga[g].strand, d_cbase + (size_t)g * (NC + 1), NC, (int)group_nodes[g], st, max_nodes_g);
-                if (g < 4) HT(c, hipEventRecord(f->e_aux[4 * g + 1], st));
                 sl.topo_q2 = wgroups.g[g].q2; sl.ext = wbuf.ext; sp.cs_out = wbuf.cs;
                 if (use_wave) {
                     // (direct mode: the tail reads star_ptr only at the stop nodes, which k_ovl_stops always writes)
