@@ -588,6 +588,8 @@ cdef class Sequence:
     def __init__(self, object sequence, bint mask=False, size_t mask_size=50):
         if isinstance(sequence, Sequence):
             self.data = (<Sequence> sequence).data
+        elif type(sequence) is bytes:
+            self.data = sequence                      # immutable: no copy
         elif isinstance(sequence, str):
             self.data = sequence.encode("ascii", "replace")
         else:
