@@ -292,3 +292,34 @@ def test_planted_orf_series_against_the_oracle(ctx, models):
     n = sum(compare_contig(res, i, s, orc.Oracle(s), models, meta=True) for i, s in enumerate(seqs))
     dens = float(np.sum(res.contigs["n_nodes"])) / sum(len(s) for s in seqs)
     assert n > 300 and dens > 0.035, (n, dens)
+
+
+def test_upload_beside_a_call_of_the_same_context(ctx, models):
+    """`pga_batch_create` has a stream, a pinned staging area and a worker pool of its own (round 6): a second host thread may pack and
+    upload the next batch while `pga_find_genes` works on the current one, on ONE context.  Every result equals the serial one."""
+    import threading
+    ctx.set_models([m.buf for m in models])
+    rng = np.random.default_rng(61)
+    groups = [[synthetic_contig(int(rng.integers(3000, 40000)), 0.3 + 0.4 * rng.random(), 6100 + 40 * g + i) for i in range(24)] for g in range(6)]
+    # (one group large enough for the slices of the threaded packing: more than 8 MB)
+    groups.append([synthetic_contig(1_200_000, 0.3 + 0.05 * i, 6400 + i) for i in range(8)])
+    serial = [ctx.find_genes_batch(g, meta=True) for g in groups]
+    got = [None] * len(groups)
+    nxt = {"b": ctx.upload(groups[0]), "err": None}
+    for k in range(len(groups)):
+        b = nxt["b"]
+
+        def ahead(k=k):
+            try:
+                nxt["b"] = ctx.upload(groups[k + 1]) if k + 1 < len(groups) else None
+            except BaseException as e:          # noqa: BLE001 -- handed to the main thread
+                nxt["err"] = e
+        t = threading.Thread(target=ahead)
+        t.start()
+        got[k] = ctx.find_genes(b, meta=True)
+        t.join()
+        b.close()
+        assert nxt["err"] is None, nxt["err"]
+    for k, (a, r) in enumerate(zip(serial, got)):
+        assert np.array_equal(a.contigs["model"], r.contigs["model"]), k
+        assert a.genes.tobytes() == r.genes.tobytes(), k
