@@ -198,7 +198,10 @@ void pga_result_free(pga_result*);
 
 /* The same in two steps, for callers that keep a batch resident in HBM (repeated passes over the
  * same contigs with different options/models, benchmarking without the PCIe upload):
- * pga_batch_create packs and uploads the contigs once, pga_find_genes runs the whole path on it. */
+ * pga_batch_create packs and uploads the contigs once, pga_find_genes runs the whole path on it.
+ * A context runs ONE pga_find_genes / pga_find_genes_batch at a time; pga_batch_create / pga_batch_create_packed / pga_batch_free may be
+ * called from another thread while it does (the upload has a stream, a pinned staging area and a worker pool of its own: the next batch
+ * of a context can be on its way while the current one is worked on), one upload at a time per context. */
 typedef struct pga_batch pga_batch;
 int  pga_batch_create(pga_ctx*, int32_t n_contigs, const char* const* seqs, const int64_t* lens, pga_batch** out);
 /* The same from contigs that already lie back to back in one host buffer (offs[i + 1] == offs[i] + lens[i]), ideally pinned
