@@ -72,3 +72,21 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".pyx", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in text.lower() or f == "benchdata.py" and "oracle" in text.lower() and "import oracle" not in text, f
+
+
+def test_argument_arrays_of_a_batch_by_the_host_layer():
+    """`lib._seq_pointers` (what `_cabi.Batch` hands to pga_batch_create): addresses and lengths of a list of bytes, one C loop;
+    anything but bytes is the caller's to convert (TypeError -> the ctypes conversions)."""
+    from pyrodigal_amd import _cabi, lib
+    seqs = [b"ACGT" * 5, b"", b"N" * 33, bytes(range(65, 91))]
+    ptrs, lens, total = lib._seq_pointers(seqs)
+    assert total == sum(len(s) for s in seqs) and list(lens[:4]) == [len(s) for s in seqs]
+    for p, s in zip(ptrs, seqs):
+        assert ctypes.string_at(int(p), len(s)) == s
+    with pytest.raises(TypeError):
+        lib._seq_pointers([b"ACGT", "ACGT"])
+    with pytest.raises(TypeError):
+        lib._seq_pointers([b"ACGT", bytearray(b"ACGT")])
+    p0, l0, t0 = lib._seq_pointers([])
+    assert t0 == 0 and len(p0) >= 1 and len(l0) >= 1        # (never a zero-length array: the C-ABI gets a valid pointer)
+    assert _cabi._seq_pointers_fn() is lib._seq_pointers
