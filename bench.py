@@ -825,7 +825,7 @@ def cpu_baseline(seqs, models, gpu_res, n_job=0):
     return out
 
 
-def parity_sample(seqs, models, res, base_of, n_ctx, every=40, threads=16):
+def parity_sample(seqs, models, res, base_of, n_ctx, every=10, threads=16):
     """SURVEY 8(d) "parity checks in the bench run": a stratified sample of the job that was just timed -- every `every`-th contig,
     hence contigs of EVERY device call and every context -- through the CPU checker (oracle/, one contig per call on a few Python
     threads; the C side runs without the interpreter lock), compared with the gene records the timed passes produced: the gene tuples
