@@ -269,7 +269,10 @@ def main():
     planted = args.workload == "config4" and args.series == "planted"
     if planted:
         wname += "_planted"
-    seqs = benchdata.generate(lengths[mine], gcs[mine], seeds[mine], procs=args.gen_procs or None, planted=planted)
+    # (worker processes of the generator: the CPUs this process may use -- the container's quota when it has one -- shared by the ranks of
+    #  the node, at most 32: eight ranks spawning 32 interpreters each would spend longer starting them than generating)
+    gen_procs = args.gen_procs or max(2, min(32, int((_cpu_quota() or os.cpu_count() or 1) * (2 if world == 1 else 1)) // max(1, world)))
+    seqs = benchdata.generate(lengths[mine], gcs[mine], seeds[mine], procs=gen_procs, planted=planted)
     t_gen = time.perf_counter() - t_gen
     job_bases = int(np.sum(lengths))
 
