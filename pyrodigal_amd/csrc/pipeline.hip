@@ -1057,14 +1057,14 @@ __device__ __forceinline__ void orf_serial_quad(const OrfCtx& o, const ChainDesc
     double sum[CS_MODELS];
 #pragma unroll
     for (int m = 0; m < CS_MODELS; m++) sum[m] = 0.0;
-    int far = -1, mer = 0;
-    unsigned long long sm0 = 0, sm1 = 0, sm2 = 0;           // codons below CS_LONG = 192 that are start nodes; beyond, the second pass reads the flags again
+    int far = -1, kfar = 0, mer = 0;
+    unsigned long long sm0 = 0, sm1 = 0, sm2 = 0;           // the codons that are start nodes (every ORF walked here has at most CS_LONG = 192)
     // one codon (ci is the same in every lane): its hexamer joins the sums; a start node (k = its index in the contig) keeps them
     auto visit = [&](const int ci, const bool isnode, const int k) {
         const double* q4 = quad + 4 * mer;                   // one 32-byte row of LDS: two ds_read_b128
         sum[0] += q4[0]; sum[1] += q4[1]; sum[2] += q4[2]; sum[3] += q4[3];
         if (isnode) { csp[0][k] = sum[0]; csp[1][k] = sum[1]; csp[2][k] = sum[2]; csp[3][k] = sum[3]; }
-        far = isnode ? ci : far;
+        far = isnode ? ci : far; kfar = isnode ? k : kfar;
         const unsigned long long bit = isnode ? 1ull << (ci & 63) : 0ull;
         // ci is scalar: three scalar branches (the empty asm statements keep them apart; merged, the masks become a private array in scratch)
         if (ci < 64) { sm0 |= bit; asm volatile("; mask 0"); } else if (ci < 128) { sm1 |= bit; asm volatile("; mask 1"); }
@@ -1105,9 +1105,7 @@ __device__ __forceinline__ void orf_serial_quad(const OrfCtx& o, const ChainDesc
         const unsigned f = bits4((unsigned)w.a) | (bits4((unsigned)(w.a >> 32)) << 4) | (bits4((unsigned)w.b) << 8) | (bits4((unsigned)(w.b >> 32)) << 12);
         return fwd ? f : (__brev(f) >> 16);
     };
-    const int fbit = fwd ? 4 : 5;
     const int dsh = fwd ? 24 : 26, fsh = fwd ? 12 : 13;       // codon u: digits at bit dsh - 6u, flag at bit fsh - 3u
-    const int foff0 = fwd ? 12 : 2, fstep = fwd ? -3 : 3;     // the flag's byte offset in the group as loaded: foff0 + fstep * u
     const unsigned m3 = 0x00070007u << fsh;                   // the three positions of codon 0 in either half of (forward | reverse << 16) flags
     W16 D1{0, 0}, D2{0, 0};
     // prologue: the bytes of the first and of the second group
@@ -1154,41 +1152,42 @@ __device__ __forceinline__ void orf_serial_quad(const OrfCtx& o, const ChainDesc
     double run_c[CS_MODELS], run_l[CS_MODELS];
 #pragma unroll
     for (int m = 0; m < CS_MODELS; m++) { run_c[m] = -10000.0; run_l[m] = -10000.0; }
-    // the start nodes from the outermost inwards: codons from CS_LONG on by their flags, the others from the masks
-    int ci = far, fc0 = -1;
-    W16 G2{0, 0};
-    while (ci >= 0) {
-        if (ci >= CS_LONG) {
-            const int c0 = 1 + 5 * ((ci - 1) / 5), u = ci - c0;
-            const int lo = group_lo(c0);
-            bool isnode;
-            if (lo < 0) isnode = o.node_at(p + step * (ci + 1));
-            else {
-                if (c0 != fc0) { __builtin_memcpy(&G2, d + lo, 16); fc0 = c0; }
-                const int kn = foff0 + fstep * u;
-                isnode = (((kn < 8 ? G2.a >> (8 * kn) : G2.b >> (8 * (kn - 8))) >> fbit) & 1ull) != 0;
-            }
-            if (!isnode) { ci--; continue; }
-        } else {
-            const int wsel = ci >> 6;
-            const unsigned long long bits = (wsel == 2 ? sm2 : (wsel == 1 ? sm1 : sm0)) & ((2ull << (ci & 63)) - 1ull);
-            if (!bits) { ci = wsel * 64 - 1; continue; }
-            ci = wsel * 64 + 63 - __builtin_clzll(bits);
+    // The start nodes from the outermost inwards.  Every ORF that walks here has at most CS_LONG codons (the 64-to-a-wave classes
+    // of k_coding_score_quads), so the masks hold all of its start nodes and the outermost one's index is at hand (kfar).  What a
+    // start node costs is round trips: its index (two loads), then per model the sum the walk stored and the length factor.  Asked
+    // for one after the other -- a store of one model stands between the loads of the next, and the compiler must assume they
+    // meet -- that was five trips per start node; here the next start node's index is asked for first, then all of this one's
+    // sums and factors at once, and the four stores come last: one trip.  (Distinct start nodes have distinct k, the chains of a
+    // contig distinct ranges: no load below can see a store it overtakes.)
+    auto start_below = [&](int c) -> int {                    // the outermost start node at or below codon c, or -1
+        while (c >= 0) {
+            const int wsel = c >> 6;
+            const unsigned long long bits = (wsel == 2 ? sm2 : (wsel == 1 ? sm1 : sm0)) & ((2ull << (c & 63)) - 1ull);
+            if (bits) return wsel * 64 + 63 - __builtin_clzll(bits);
+            c = wsel * 64 - 1;
         }
-        const int j = p + step * (ci + 1);
-        const int k = o.node_index(j);
+        return -1;
+    };
+    if (far >= CS_LONG) __builtin_trap();                     // cannot happen (see above): never walk past the masks
+    int ci = far, k = kfar;
+    while (ci >= 0) {
+        const int cn = start_below(ci - 1);
+        int kn = 0;
+        if (cn >= 0) kn = o.node_index(p + step * (cn + 1));
+        double cs[CS_MODELS], lf[CS_MODELS];
+#pragma unroll
+        for (int m = 0; m < CS_MODELS; m++) { cs[m] = csp[m][k]; lf[m] = length_factor(mcp[m], ci + 2); }   // (columns the contig lacks: the sink, their own model)
 #pragma unroll
         for (int m = 0; m < CS_MODELS; m++) {
-            if (m >= nm) continue;
-            double cs = csp[m][k];
-            if (cs > run_c[m]) run_c[m] = cs; else cs -= (run_c[m] - cs);
-            double lfac = length_factor(mcp[m], ci + 2);
+            double c = cs[m], lfac = lf[m];
+            if (c > run_c[m]) run_c[m] = c; else c -= (run_c[m] - c);
             if (lfac > run_l[m]) run_l[m] = lfac; else lfac -= fmax(fmin(run_l[m] - lfac, lfac), 0.0);
-            if (lfac > 3.0 && cs < 0.5 * lfac) cs = 0.5 * lfac;
-            cs += lfac;
-            csp[m][k] = cs;
+            if (lfac > 3.0 && c < 0.5 * lfac) c = 0.5 * lfac;
+            cs[m] = c + lfac;
         }
-        ci--;
+#pragma unroll
+        for (int m = 0; m < CS_MODELS; m++) if (m < nm) csp[m][k] = cs[m];
+        ci = cn; k = kn;
     }
     qmark(12);
 }
@@ -1332,11 +1331,19 @@ __device__ __forceinline__ void orf_quarter(const OrfCtx& o, const bool has, con
         const int x = p + step * (ci + 1);
         const bool fl = valid && o.node_at(x);
         const int k = fl ? o.node_index(x) : 0;
+        // every model's sum and length factor asked for before the first store (a store between two loads holds the second back:
+        // the compiler must assume they meet; the chains of a contig never do)
+        double cs_in[CS_MODELS], lf_in[CS_MODELS];
 #pragma unroll
         for (int m = 0; m < CS_MODELS; m++) {
             const bool mine = fl && m < nm;
-            const double cs0 = mine ? csp[m][k] : NEG_INF;
-            const double lf0 = mine ? length_factor(mcp[m], ci + 2) : NEG_INF;
+            cs_in[m] = mine ? csp[m][k] : NEG_INF;
+            lf_in[m] = mine ? length_factor(mcp[m], ci + 2) : NEG_INF;
+        }
+#pragma unroll
+        for (int m = 0; m < CS_MODELS; m++) {
+            const bool mine = fl && m < nm;
+            const double cs0 = cs_in[m], lf0 = lf_in[m];
             double inc_c = cs0, inc_l = lf0;
 #pragma unroll
             for (int off = 1; off < 16; off <<= 1) {
