@@ -2182,7 +2182,12 @@ __device__ __forceinline__ unsigned overlap_neighbours(const int32_t* __restrict
             ok = j >= 0 && j < n && nd >= my - 2 && sd == -1 && ty != PGA_T_STOP && sv < my;
         }
         ended = ended || stop_here;
-        if (ok && !ended) elig |= 1u << k;
+        if (ok && !ended) {
+            elig |= 1u << k;
+            // bits 16 .. 30: the pair is adjacent (the start's RBS / upstream scores enter its price, _connection.h:60-66) -- only a node within
+            // two bases is, so never the sixteenth neighbour; who prices the pair knows which scores to ask for before it has the positions
+            if (k < 15 && (fwd ? (my + 2 == nd || my == nd + 1) : (nd + 2 == my || nd == my + 1))) elig |= 0x10000u << k;
+        }
     }
     return elig | (ended ? 0x80000000u : 0u);
 }
@@ -2273,10 +2278,78 @@ k_overlapping_starts(const ChainDesc* __restrict__ chains, int n_chains, int64_t
     ca.star_ptr[3 * g] = sp0; ca.star_ptr[3 * g + 1] = sp1; ca.star_ptr[3 * g + 2] = sp2;
 }
 
+// overlapping_starts_of for a kernel that does nothing but wait for memory: the first four neighbours that count are asked for AT ONCE
+// (position, cscore + sscore, RBS and upstream score, whether the pair turns out adjacent or not) and priced in the reference's order
+// afterwards; what is left of the window (a fifth neighbour: rare) goes on one by one as above.  Same values, same comparisons.
+constexpr int OV_AHEAD = 4;
+__device__ __forceinline__ void overlapping_starts_ahead(const OvlChain& C, const int i, const int my, const bool fwd, const ModelConst* __restrict__ mc,
+                                                         const int maxov, int (&sp)[3], const unsigned neighbours) {
+    const int32_t* __restrict__ ndx = C.ndx; const int32_t* __restrict__ stv = C.stv;
+    const uint8_t* __restrict__ typ = C.typ; const int8_t* __restrict__ str = C.str;
+    const double* __restrict__ cs = C.cs; const double* __restrict__ ss = C.ss; const double* __restrict__ rs = C.rs; const double* __restrict__ us = C.us;
+    const int n = C.n;
+    double best = -100;
+    unsigned elig = neighbours & 0xffffu;
+    const unsigned adjb = (neighbours >> 16) & 0x7fffu;
+    int jn[OV_AHEAD], nq[OV_AHEAD]; double cq[OV_AHEAD], rq[OV_AHEAD], uq[OV_AHEAD]; bool aq[OV_AHEAD];
+#pragma unroll
+    for (int q = 0; q < OV_AHEAD; q++) {
+        jn[q] = -1; aq[q] = false;
+        if (elig) { const int k = __builtin_ctz(elig); elig &= elig - 1u; jn[q] = fwd ? i + 3 - k : i - 3 + k; aq[q] = (adjb >> k) & 1u; }
+    }
+#pragma unroll
+    for (int q = 0; q < OV_AHEAD; q++) {
+        const int jj = jn[q] >= 0 ? jn[q] : i;              // (no neighbour: the stop node itself, read and dropped)
+        nq[q] = ndx[jj]; cq[q] = C.css != nullptr ? C.css[jj] : cs[jj] + ss[jj];
+        rq[q] = aq[q] ? rs[jj] : 0.0; uq[q] = aq[q] ? us[jj] : 0.0;          // (adjacent pairs are rare: k_ovl_topo says which, so nobody else reads these lines)
+    }
+    auto price = [&](const int j, const int nj, const double csj, const double rj0, const double uj0) {
+        // the RBS / upstream scores of the start only enter when the two nodes are adjacent (_connection.h:60-66)
+        const bool adj = fwd ? (my + 2 == nj || my == nj + 1) : (nj + 2 == my || nj == my + 1);
+        const double rj = adj ? rj0 : 0.0, uj = adj ? uj0 : 0.0;
+        const double v = fwd ? csj + igm_same_dev(my, 1, 0.0, 0.0, nj, rj, uj, mc->st_wt, mc->igm)
+                             : csj + igm_same_dev(nj, -1, rj, uj, my, 0.0, 0.0, mc->st_wt, mc->igm);
+        if (v > best) { const int f = nj % 3; sp[f] = j; best = v; }
+    };
+#pragma unroll
+    for (int q = 0; q < OV_AHEAD; q++) if (jn[q] >= 0) price(jn[q], nq[q], cq[q], rq[q], uq[q]);
+    bool more = !(neighbours >> 31);
+    if (!elig && !more) return;
+    int js = fwd ? i + 3 - OV_SPEC : i - 3 + OV_SPEC;        // where the one-by-one walk goes on if the window is not done by then
+    for (;;) {
+        int j = -1;
+        if (elig) {
+            const int k = __builtin_ctz(elig);
+            elig &= elig - 1u;
+            j = fwd ? i + 3 - k : i - 3 + k;
+        } else {
+            while (more) {
+                if (fwd ? js < 0 : js >= n) { more = false; break; }
+                const int jq = js;
+                js += fwd ? -1 : 1;
+                if (jq < 0 || jq >= n) continue;
+                const int nqq = ndx[jq];
+                if (fwd ? nqq > my + 2 : nqq < my - 2) continue;
+                if (fwd ? nqq + maxov < my : nqq - maxov > my) { more = false; break; }
+                if (str[jq] != (fwd ? 1 : -1) || typ[jq] == PGA_T_STOP) continue;
+                if (fwd ? stv[jq] <= my : stv[jq] >= my) continue;
+                j = jq;
+                break;
+            }
+            if (j < 0) break;
+        }
+        price(j, ndx[j], C.css != nullptr ? C.css[j] : cs[j] + ss[j], rs[j], us[j]);
+    }
+}
+
 // One thread per (chain, stop node) pair: stop nodes are one node in five, and a wavefront of the kernel above waits for its
 // few stop lanes.  The pairs of a chain are ChainDesc::soff .. ; the k-th stop of a contig is ga.stop_list[sbase[contig] + k].
 // star_ptr of the other nodes is -1 (the launcher fills the range first).  With `ext` the 64-byte extras record of the
 // wave-batch connection scorer is built from the three starts while they are at hand (dpw_core.h, dpw_chain_ext).
+// The kernel waits for memory and nothing else -- 0.10 of the vector pipe, eight wavefronts per SIMD, its time the depth of its chain
+// of dependent loads -- so every load is asked for as soon as its address is known: the chain of the pair (three descriptors ahead
+// instead of a walk), the contig's bases, the stop node and its neighbour mask, then the node's own fields TOGETHER with those of
+// its first four neighbours (round 6, fourth session: fourteen round trips became six).
 __global__ void __launch_bounds__(256)
 k_ovl_stops(const ChainDesc* __restrict__ chains, int n_chains, int64_t soff_begin, int64_t n_pairs, GroupArrays ga,
             const int32_t* __restrict__ cbase, const int32_t* __restrict__ sbase, const ModelConst* __restrict__ mcs, ChainArrays ca, int maxov,
@@ -2286,25 +2359,31 @@ k_ovl_stops(const ChainDesc* __restrict__ chains, int n_chains, int64_t soff_beg
     const int64_t p = blk0 + threadIdx.x;
     int c = block_search_le([&](const int k) { return chains[k].soff; }, n_chains, blk0, &s_c0);
     if (p >= soff_begin + n_pairs) return;
+    {   // a workgroup's 256 pairs rarely reach beyond the third chain after its first
+        const int64_t s1 = chains[min(c + 1, n_chains - 1)].soff, s2 = chains[min(c + 2, n_chains - 1)].soff, s3 = chains[min(c + 3, n_chains - 1)].soff;
+        const int c_in = c;
+        c += (c_in + 1 < n_chains && s1 <= p) + (c_in + 2 < n_chains && s2 <= p) + (c_in + 3 < n_chains && s3 <= p);
+    }
     while (c + 1 < n_chains && chains[c + 1].soff <= p) c++;
     const ChainDesc ch = chains[c];
     const int64_t tb = ch.topo_off;
-    const int sidx = sbase[ch.contig] + (int)(p - ch.soff);
-    const int i = ga.stop_list[sidx] - cbase[ch.contig];
+    const int sb = sbase[ch.contig], cb = cbase[ch.contig];
+    const int sidx = sb + (int)(p - ch.soff);
+    const int i = ga.stop_list[sidx] - cb;
+    const unsigned neighbours = ga.ovl_topo[sidx];            // (an edge stop: nothing counts, k_ovl_topo)
     const int64_t g = ch.off + i;
     const ModelConst* __restrict__ mc = &mcs[ch.model];
+    const int edge0 = ga.edge0[tb + i], my = ga.ndx[tb + i], my_str = ga.strand[tb + i];
     int sp[3] = {-1, -1, -1};
-    if (ga.edge0[tb + i] != 1) {
-        const OvlChain C{ga.ndx + tb, ga.stop_val + tb, ga.type + tb, ga.strand + tb, ca.cscore + ch.off, ca.sscore + ch.off, ca.rscore + ch.off,
-                         ca.uscore + ch.off, ch.n, css != nullptr ? css + ch.off : nullptr};
-        overlapping_starts_of(C, i, mc, maxov, sp[0], sp[1], sp[2], ga.ovl_topo[sidx]);
-    }
+    const OvlChain C{ga.ndx + tb, ga.stop_val + tb, ga.type + tb, ga.strand + tb, ca.cscore + ch.off, ca.sscore + ch.off, ca.rscore + ch.off,
+                     ca.uscore + ch.off, ch.n, css != nullptr ? css + ch.off : nullptr};
+    overlapping_starts_ahead(C, i, my, my_str == 1, mc, maxov, sp, edge0 != 1 ? neighbours : 0x80000000u);
     ca.star_ptr[3 * g] = sp[0]; ca.star_ptr[3 * g + 1] = sp[1]; ca.star_ptr[3 * g + 2] = sp[2];      // (an edge stop: -1, never what an earlier call left there)
     if (ext != nullptr) {
         const DpwModel M{mc->st_wt, mc->negc, mc->igm};
         DpwExt e;
         dpw_chain_ext_sp(ga.ndx + tb, ga.stop_val + tb, ga.strand + tb, topo_q2 + tb, ca.cscore + ch.off, ca.sscore + ch.off, ca.rscore + ch.off,
-                         ca.uscore + ch.off, sp, i, ga.strand[tb + i] != 1, M, e, css != nullptr ? css + ch.off : nullptr);
+                         ca.uscore + ch.off, sp, i, my_str != 1, M, e, css != nullptr ? css + ch.off : nullptr);
         ext[p] = e;             // dense: one record per (chain, stop node) pair, in pair order
     }
 }
