@@ -1747,13 +1747,18 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         PINBUF(h_maxscore, double, "h_chain_results", 2 * dp_slots + 2);
         int32_t* const h_maxidx = (int32_t*)(h_maxscore + dp_slots); int32_t* const h_ipath = h_maxidx + dp_slots;
         PINBUF(h_scur, uint32_t, "h_dpw_scur", 16);
+        // the workgroups of k_ovl_stops take 256 (chain, stop node) pairs each: the chain of a workgroup's first pair, relative to its group's
+        // first chain, comes with the plan (a search on the device was three dependent loads in front of everything the workgroup does)
+        std::vector<int64_t> ovl_blk0((size_t)NG + 1, 0);
+        for (int g = 0; g < NG; g++) ovl_blk0[(size_t)g + 1] = ovl_blk0[(size_t)g] + (g_s0[g + 1] - g_s0[g] + 255) / 256;
         // The plan of the call goes to the device in ONE copy (round 6; it was four copies and a memset): the cleared flags "scoring turned a
         // start node into an edge node", per group and contig the run of chains scored on it, the batches before each contig (step
         // schedule), the start order of the connection scoring, the chains -- one pinned staging area, one device area, the same layout.
         // (Behind the chains the device area has room for the re-score chains of the winners, which are uploaded later.)
         const size_t pa_conv = 0, pa_cc = (((size_t)NG * NC + 1) + 7) & ~(size_t)7, pa_bb = pa_cc + sizeof(int2) * (size_t)2 * NG * NC,
                      pa_ord = pa_bb + ((sizeof(int32_t) * (h_bbase.size() + 1) + 7) & ~(size_t)7),
-                     pa_ch = pa_ord + ((sizeof(int32_t) * (dp_order.size() + 1) + 7) & ~(size_t)7), pa_copy = pa_ch + sizeof(ChainDesc) * (size_t)NCH;
+                     pa_blk = pa_ord + ((sizeof(int32_t) * (dp_order.size() + 1) + 7) & ~(size_t)7),
+                     pa_ch = pa_blk + ((sizeof(int32_t) * ((size_t)ovl_blk0[NG] + 1) + 7) & ~(size_t)7), pa_copy = pa_ch + sizeof(ChainDesc) * (size_t)NCH;
         DEVBUF(d_plan, char, "d_call_plan", pa_copy + sizeof(ChainDesc) * ((size_t)NC + 2));
         PINBUF(h_plan, char, "h_call_plan", pa_copy + 64);
         uint8_t* const d_conv = (uint8_t*)(d_plan + pa_conv);
@@ -1773,6 +1778,19 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
         if (use_sched && !h_bbase.empty()) memcpy(h_plan + pa_bb, h_bbase.data(), sizeof(int32_t) * h_bbase.size());
         if (!dp_order.empty()) memcpy(h_plan + pa_ord, dp_order.data(), sizeof(int32_t) * dp_order.size());
         if (NCH > 0) memcpy(h_plan + pa_ch, chains.data(), sizeof(ChainDesc) * (size_t)NCH);
+        const int32_t* const d_ovl_blk = (const int32_t*)(d_plan + pa_blk);
+        {
+            int32_t* const h_blk = (int32_t*)(h_plan + pa_blk);
+            for (int g = 0; g < NG; g++) {
+                int k = g_c0[g];
+                const int64_t nb = ovl_blk0[(size_t)g + 1] - ovl_blk0[(size_t)g];
+                for (int64_t b = 0; b < nb; b++) {
+                    const int64_t p0 = g_s0[g] + 256 * b;
+                    while (k + 1 < g_c0[g + 1] && chains[(size_t)k + 1].soff <= p0) k++;
+                    h_blk[ovl_blk0[(size_t)g] + b] = k - g_c0[g];
+                }
+            }
+        }
         HT(c, hipMemcpyAsync(d_plan, h_plan, pa_copy, hipMemcpyHostToDevice, st));
 
         tm.mark("plan+alloc");
@@ -1816,6 +1834,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             // (the path proper; a stage-level call returns the node arrays after any stage, so there every node keeps its thread)
             sl.starts_only = stage == 0 && !(getenv("PGA_SS_STARTS_ONLY") && atoi(getenv("PGA_SS_STARTS_ONLY")) == 0);
             sl.n_starts = (int32_t)(group_nodes[g] - sl.n_stops);
+            sl.blk_chain = d_ovl_blk + ovl_blk0[(size_t)g];
             sp.cs_out = nullptr;
             if (wave_prep) {
                 sl.topo_q2 = wgroups.g[g].q2; sl.ext = wbuf.ext; sp.cs_out = wbuf.cs;

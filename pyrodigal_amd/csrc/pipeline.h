@@ -110,6 +110,9 @@ struct StopLaunch {
     // the start scorer runs over ga.start_list (n_starts entries) instead of over every node (its workgroups clear the fields of the
     // stop nodes between their start nodes at the end)
     bool starts_only = false; int32_t n_starts = 0;
+    // per workgroup of k_ovl_stops (256 pairs from soff_begin on): the chain of its first pair, relative to the launch's first chain
+    // (the caller's plan; nullptr: the workgroup searches)
+    const int32_t* blk_chain = nullptr;
 };
 // per (group, contig): is any model of the group inside the contig's GC window?  (meta mode)
 void pga_launch_group_enable(const ContigDesc* d_ct, int n_contigs, const int32_t* d_gc_count, const double* d_model_gc,

@@ -2279,19 +2279,24 @@ k_overlapping_starts(const ChainDesc* __restrict__ chains, int n_chains, int64_t
 }
 
 // overlapping_starts_of for a kernel that does nothing but wait for memory: the first four neighbours that count are asked for AT ONCE
-// (position, cscore + sscore, RBS and upstream score, whether the pair turns out adjacent or not) and priced in the reference's order
-// afterwards; what is left of the window (a fifth neighbour: rare) goes on one by one as above.  Same values, same comparisons.
+// (position, cscore + sscore; RBS and upstream score where k_ovl_topo found the pair adjacent; for the extras of a reverse stop the
+// start's stop_val and first candidate as well) and priced in the reference's order afterwards; what is left of the window (a fifth
+// neighbour: rare) goes on one by one as above.  Same values, same comparisons.  What the extras record needs of the three starts
+// that are kept -- the price (cs + intergenic term: exactly DpwExt::x), position, stop_val, first candidate -- stays in registers.
 constexpr int OV_AHEAD = 4;
+struct OvlKept { double v[3]; int nd[3], sv[3], q2[3]; };
 __device__ __forceinline__ void overlapping_starts_ahead(const OvlChain& C, const int i, const int my, const bool fwd, const ModelConst* __restrict__ mc,
-                                                         const int maxov, int (&sp)[3], const unsigned neighbours) {
+                                                         const int maxov, int (&sp)[3], OvlKept& K, const unsigned neighbours,
+                                                         const int32_t* __restrict__ q2 /* topology: first candidate of a reverse start, or nullptr (no extras wanted) */) {
     const int32_t* __restrict__ ndx = C.ndx; const int32_t* __restrict__ stv = C.stv;
     const uint8_t* __restrict__ typ = C.typ; const int8_t* __restrict__ str = C.str;
     const double* __restrict__ cs = C.cs; const double* __restrict__ ss = C.ss; const double* __restrict__ rs = C.rs; const double* __restrict__ us = C.us;
     const int n = C.n;
+    const bool rext = !fwd && q2 != nullptr;                 // the extras of a reverse stop: stop_val and first candidate of the starts as well
     double best = -100;
     unsigned elig = neighbours & 0xffffu;
     const unsigned adjb = (neighbours >> 16) & 0x7fffu;
-    int jn[OV_AHEAD], nq[OV_AHEAD]; double cq[OV_AHEAD], rq[OV_AHEAD], uq[OV_AHEAD]; bool aq[OV_AHEAD];
+    int jn[OV_AHEAD], nq[OV_AHEAD], svq[OV_AHEAD], q2q[OV_AHEAD]; double cq[OV_AHEAD], rq[OV_AHEAD], uq[OV_AHEAD]; bool aq[OV_AHEAD];
 #pragma unroll
     for (int q = 0; q < OV_AHEAD; q++) {
         jn[q] = -1; aq[q] = false;
@@ -2302,17 +2307,23 @@ __device__ __forceinline__ void overlapping_starts_ahead(const OvlChain& C, cons
         const int jj = jn[q] >= 0 ? jn[q] : i;              // (no neighbour: the stop node itself, read and dropped)
         nq[q] = ndx[jj]; cq[q] = C.css != nullptr ? C.css[jj] : cs[jj] + ss[jj];
         rq[q] = aq[q] ? rs[jj] : 0.0; uq[q] = aq[q] ? us[jj] : 0.0;          // (adjacent pairs are rare: k_ovl_topo says which, so nobody else reads these lines)
+        svq[q] = rext ? stv[jj] : 0; q2q[q] = rext ? q2[jj] : 0;
     }
-    auto price = [&](const int j, const int nj, const double csj, const double rj0, const double uj0) {
+    auto price = [&](const int j, const int nj, const double csj, const double rj0, const double uj0, const int svj, const int q2j) {
         // the RBS / upstream scores of the start only enter when the two nodes are adjacent (_connection.h:60-66)
         const bool adj = fwd ? (my + 2 == nj || my == nj + 1) : (nj + 2 == my || nj == my + 1);
         const double rj = adj ? rj0 : 0.0, uj = adj ? uj0 : 0.0;
         const double v = fwd ? csj + igm_same_dev(my, 1, 0.0, 0.0, nj, rj, uj, mc->st_wt, mc->igm)
                              : csj + igm_same_dev(nj, -1, rj, uj, my, 0.0, 0.0, mc->st_wt, mc->igm);
-        if (v > best) { const int f = nj % 3; sp[f] = j; best = v; }
+        if (v > best) {
+            const int f = nj % 3; best = v;
+            if (f == 0) { sp[0] = j; K.v[0] = v; K.nd[0] = nj; K.sv[0] = svj; K.q2[0] = q2j; }
+            else if (f == 1) { sp[1] = j; K.v[1] = v; K.nd[1] = nj; K.sv[1] = svj; K.q2[1] = q2j; }
+            else { sp[2] = j; K.v[2] = v; K.nd[2] = nj; K.sv[2] = svj; K.q2[2] = q2j; }
+        }
     };
 #pragma unroll
-    for (int q = 0; q < OV_AHEAD; q++) if (jn[q] >= 0) price(jn[q], nq[q], cq[q], rq[q], uq[q]);
+    for (int q = 0; q < OV_AHEAD; q++) if (jn[q] >= 0) price(jn[q], nq[q], cq[q], rq[q], uq[q], svq[q], q2q[q]);
     bool more = !(neighbours >> 31);
     if (!elig && !more) return;
     int js = fwd ? i + 3 - OV_SPEC : i - 3 + OV_SPEC;        // where the one-by-one walk goes on if the window is not done by then
@@ -2338,26 +2349,30 @@ __device__ __forceinline__ void overlapping_starts_ahead(const OvlChain& C, cons
             }
             if (j < 0) break;
         }
-        price(j, ndx[j], C.css != nullptr ? C.css[j] : cs[j] + ss[j], rs[j], us[j]);
+        price(j, ndx[j], C.css != nullptr ? C.css[j] : cs[j] + ss[j], rs[j], us[j], rext ? stv[j] : 0, rext ? q2[j] : 0);
     }
 }
 
 // One thread per (chain, stop node) pair: stop nodes are one node in five, and a wavefront of the kernel above waits for its
 // few stop lanes.  The pairs of a chain are ChainDesc::soff .. ; the k-th stop of a contig is ga.stop_list[sbase[contig] + k].
 // star_ptr of the other nodes is -1 (the launcher fills the range first).  With `ext` the 64-byte extras record of the
-// wave-batch connection scorer is built from the three starts while they are at hand (dpw_core.h, dpw_chain_ext).
+// wave-batch connection scorer is built from the three starts while they are at hand (dpw_core.h, dpw_chain_ext_sp: the same
+// record from the same values -- a kept start's price IS the record's x, its position and stop_val give the candidate interval).
 // The kernel waits for memory and nothing else -- 0.10 of the vector pipe, eight wavefronts per SIMD, its time the depth of its chain
 // of dependent loads -- so every load is asked for as soon as its address is known: the chain of the pair (three descriptors ahead
 // instead of a walk), the contig's bases, the stop node and its neighbour mask, then the node's own fields TOGETHER with those of
-// its first four neighbours (round 6, fourth session: fourteen round trips became six).
+// its first four neighbours, and nothing at all for the extras (round 6, fourth session: fourteen round trips became five).
 __global__ void __launch_bounds__(256)
 k_ovl_stops(const ChainDesc* __restrict__ chains, int n_chains, int64_t soff_begin, int64_t n_pairs, GroupArrays ga,
             const int32_t* __restrict__ cbase, const int32_t* __restrict__ sbase, const ModelConst* __restrict__ mcs, ChainArrays ca, int maxov,
-            const int32_t* __restrict__ topo_q2, DpwExt* __restrict__ ext, const double* __restrict__ css /* or nullptr: cscore + sscore per chain node */) {
+            const int32_t* __restrict__ topo_q2, DpwExt* __restrict__ ext, const double* __restrict__ css /* or nullptr: cscore + sscore per chain node */,
+            const int32_t* __restrict__ blk_chain /* or nullptr: the chain of every workgroup's first pair (StopLaunch::blk_chain) */) {
     __shared__ int s_c0;
     const int64_t blk0 = soff_begin + (int64_t)blockIdx.x * blockDim.x;
     const int64_t p = blk0 + threadIdx.x;
-    int c = block_search_le([&](const int k) { return chains[k].soff; }, n_chains, blk0, &s_c0);
+    int c;
+    if (blk_chain != nullptr) c = blk_chain[blockIdx.x];
+    else c = block_search_le([&](const int k) { return chains[k].soff; }, n_chains, blk0, &s_c0);
     if (p >= soff_begin + n_pairs) return;
     {   // a workgroup's 256 pairs rarely reach beyond the third chain after its first
         const int64_t s1 = chains[min(c + 1, n_chains - 1)].soff, s2 = chains[min(c + 2, n_chains - 1)].soff, s3 = chains[min(c + 3, n_chains - 1)].soff;
@@ -2374,16 +2389,34 @@ k_ovl_stops(const ChainDesc* __restrict__ chains, int n_chains, int64_t soff_beg
     const int64_t g = ch.off + i;
     const ModelConst* __restrict__ mc = &mcs[ch.model];
     const int edge0 = ga.edge0[tb + i], my = ga.ndx[tb + i], my_str = ga.strand[tb + i];
+    const bool rev = my_str != 1;
     int sp[3] = {-1, -1, -1};
+    OvlKept K{{0.0, 0.0, 0.0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     const OvlChain C{ga.ndx + tb, ga.stop_val + tb, ga.type + tb, ga.strand + tb, ca.cscore + ch.off, ca.sscore + ch.off, ca.rscore + ch.off,
                      ca.uscore + ch.off, ch.n, css != nullptr ? css + ch.off : nullptr};
-    overlapping_starts_ahead(C, i, my, my_str == 1, mc, maxov, sp, edge0 != 1 ? neighbours : 0x80000000u);
+    overlapping_starts_ahead(C, i, my, !rev, mc, maxov, sp, K, edge0 != 1 ? neighbours : 0x80000000u, ext != nullptr ? topo_q2 + tb : nullptr);
     ca.star_ptr[3 * g] = sp[0]; ca.star_ptr[3 * g + 1] = sp[1]; ca.star_ptr[3 * g + 2] = sp[2];      // (an edge stop: -1, never what an earlier call left there)
     if (ext != nullptr) {
-        const DpwModel M{mc->st_wt, mc->negc, mc->igm};
+        // dpw_chain_ext_sp (dpw_core.h) from what the search kept: a start that counts lies on the stop's own strand, so its price
+        // cs + igm IS x[k] (the same additions in the same order), and a reverse start carries its own first candidate
         DpwExt e;
-        dpw_chain_ext_sp(ga.ndx + tb, ga.stop_val + tb, ga.strand + tb, topo_q2 + tb, ca.cscore + ch.off, ca.sscore + ch.off, ca.rscore + ch.off,
-                         ca.uscore + ch.off, sp, i, my_str != 1, M, e, css != nullptr ? css + ch.off : nullptr);
+        e.vm = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            e.x[k] = 0.0; e.dlo[k] = INT_MAX; e.dhi[k] = INT_MIN; e.cq[k] = DPW_NONE;
+            if (sp[k] < 0) continue;
+            e.vm |= 1 << k;
+            e.x[k] = K.v[k];
+            if (rev && e.x[k] > 0.0) {
+                const int n3n = K.nd[k], n3s = K.sv[k];
+                int hi = n3s + DPW_MAX_OPP_OVLP - 5;
+                const int h2 = (n3n + n3s - 6) >> 1;
+                if (h2 < hi) hi = h2;
+                if (my - 4 < hi) hi = my - 4;
+                e.dlo[k] = n3s - 5; e.dhi[k] = hi;
+            }
+            if (rev) e.cq[k] = K.q2[k];
+        }
         ext[p] = e;             // dense: one record per (chain, stop node) pair, in pair order
     }
 }
@@ -2648,6 +2681,6 @@ void pga_launch_score(const ChainDesc* d_chains, int n_chains, int64_t node_begi
         if (stops->n_pairs > 0)
             hipLaunchKernelGGL(k_ovl_stops, dim3(nblocks(stops->n_pairs, 256)), blk, 0, st, d_chains, n_chains, stops->soff_begin, stops->n_pairs, ga,
                                d_node_contig_base, stops->sbase, d_mc, ca, sp.max_overlap, stops->topo_q2, (DpwExt*)stops->ext,
-                               stops->ext != nullptr ? (const double*)sp.cs_out : nullptr);
+                               stops->ext != nullptr ? (const double*)sp.cs_out : nullptr, getenv("PGA_OVL_SEARCH") ? nullptr : stops->blk_chain);
     } else hipLaunchKernelGGL(k_overlapping_starts, grid, blk, 0, st, d_chains, n_chains, node_begin, total, ga, d_mc, ca, sp.max_overlap);
 }
