@@ -1169,14 +1169,20 @@ __device__ __forceinline__ void orf_serial_quad(const OrfCtx& o, const ChainDesc
         return -1;
     };
     if (far >= CS_LONG) __builtin_trap();                     // cannot happen (see above): never walk past the masks
+    // (two start nodes ahead: while this one is priced, the next one's sums and the index of the one after it are on their way)
     int ci = far, k = kfar;
-    while (ci >= 0) {
-        const int cn = start_below(ci - 1);
-        int kn = 0;
-        if (cn >= 0) kn = o.node_index(p + step * (cn + 1));
-        double cs[CS_MODELS], lf[CS_MODELS];
+    int c1 = start_below(ci - 1), k1 = 0;
+    if (c1 >= 0) k1 = o.node_index(p + step * (c1 + 1));
+    double cs[CS_MODELS];
 #pragma unroll
-        for (int m = 0; m < CS_MODELS; m++) { cs[m] = csp[m][k]; lf[m] = length_factor(mcp[m], ci + 2); }   // (columns the contig lacks: the sink, their own model)
+    for (int m = 0; m < CS_MODELS; m++) cs[m] = csp[m][k];      // (columns the contig lacks: the sink)
+    while (ci >= 0) {
+        const int c2 = c1 >= 0 ? start_below(c1 - 1) : -1;
+        int k2 = 0;
+        if (c2 >= 0) k2 = o.node_index(p + step * (c2 + 1));
+        double csn[CS_MODELS], lf[CS_MODELS];
+#pragma unroll
+        for (int m = 0; m < CS_MODELS; m++) { csn[m] = c1 >= 0 ? csp[m][k1] : 0.0; lf[m] = length_factor(mcp[m], ci + 2); }
 #pragma unroll
         for (int m = 0; m < CS_MODELS; m++) {
             double c = cs[m], lfac = lf[m];
@@ -1187,7 +1193,9 @@ __device__ __forceinline__ void orf_serial_quad(const OrfCtx& o, const ChainDesc
         }
 #pragma unroll
         for (int m = 0; m < CS_MODELS; m++) if (m < nm) csp[m][k] = cs[m];
-        ci = cn; k = kn;
+#pragma unroll
+        for (int m = 0; m < CS_MODELS; m++) cs[m] = csn[m];
+        ci = c1; k = k1; c1 = c2; k1 = k2;
     }
     qmark(12);
 }
