@@ -323,3 +323,59 @@ def test_upload_beside_a_call_of_the_same_context(ctx, models):
     for k, (a, r) in enumerate(zip(serial, got)):
         assert np.array_equal(a.contigs["model"], r.contigs["model"]), k
         assert a.genes.tobytes() == r.genes.tobytes(), k
+
+
+def _start_dense():
+    """Start codons every four bases in rotating frames around stops on either strand: stop nodes with more than four overlapping-start
+    candidates inside max_overlap (k_ovl_stops prices the first four at once and goes on one by one)."""
+    unit = b"ATGC" * 60 + b"TAA" + b"ATGC" * 61 + b"TAG" + b"ATGC" * 62 + b"TGA"
+    fwd = unit * 3
+    rev = fwd[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA"))
+    return fwd + synthetic_contig(1500, 0.5, 4242) + rev
+
+
+def _max_overlap_candidates(on, maxov=60):
+    best = 0
+    ndx, sv, ty, st = on["ndx"], on["stop_val"], on["type"], on["strand"]
+    for i in np.nonzero(ty == 3)[0]:
+        my, fwd = ndx[i], st[i] == 1
+        js = range(i + 3, -1, -1) if fwd else range(max(i - 3, 0), len(ndx))
+        cnt = 0
+        for j in js:
+            if j < 0 or j >= len(ndx):
+                continue
+            if fwd:
+                if ndx[j] > my + 2: continue
+                if ndx[j] + maxov < my: break
+                ok = st[j] == 1 and ty[j] != 3 and sv[j] > my
+            else:
+                if ndx[j] < my - 2: continue
+                if ndx[j] - maxov > my: break
+                ok = st[j] == -1 and ty[j] != 3 and sv[j] < my
+            cnt += bool(ok)
+        best = max(best, cnt)
+    return best
+
+
+@pytest.mark.parametrize("form", ["plan", "search"])
+def test_more_than_four_overlapping_start_candidates(ctx, models, form, monkeypatch):
+    # k_ovl_stops: the first four candidates of a stop node at once, the others one by one; the workgroup's chain from the call plan
+    # or (PGA_OVL_SEARCH=1: what launches outside the finder's plan do) by a search.  With the wave-batch scorer the same pass builds the
+    # extras records from the starts it kept: every node field, star_ptr and the connection scores against the oracle.
+    if form == "search":
+        monkeypatch.setenv("PGA_OVL_SEARCH", "1")
+    dense = _start_dense()
+    o = orc.Oracle(dense)
+    o.find_genes_single(models[2], orc.Params())
+    assert _max_overlap_candidates(o.nodes()) > 6
+    seqs = [dense] + [synthetic_contig(6000 + 900 * c, 0.35 + 0.04 * c, 51_000 + c) for c in range(6)]
+    for kernel in ("wave", "tree3"):
+        monkeypatch.setenv("PGA_DP_KERNEL", kernel)
+        ctx.set_models([m.buf for m in models])
+        res = ctx.find_genes_batch(seqs, meta=True, want_nodes=True)
+        assert sum(compare_contig(res, i, s, orc.Oracle(s), models, meta=True) for i, s in enumerate(seqs)) > 10
+        res = ctx.find_genes_batch(seqs, meta=True)                           # the path proper (no node arrays: lean stores, no star_ptr fill)
+        assert sum(compare_contig(res, i, s, orc.Oracle(s), models, meta=True) for i, s in enumerate(seqs)) > 10
+        ctx.set_models([models[2].buf])
+        res = ctx.find_genes_batch(seqs, meta=False, want_nodes=True)
+        assert sum(compare_contig(res, i, s, orc.Oracle(s), [models[2]], meta=False) for i, s in enumerate(seqs)) > 10
