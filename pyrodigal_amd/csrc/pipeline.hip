@@ -1780,7 +1780,7 @@ struct StartModel {
     int tt, uses_sd;
     double type_wt[3];
     double rbs_wt[28];
-    double ups[32][4];
+    double ups[32][4];      // 0.4 * st_wt * ups_comp
     double mk0[4][64];      // mot_wt[0][spacer class][3-base motif]
     double mk1[4][256];     // mot_wt[1][spacer class][4-base motif]
 };
@@ -1878,6 +1878,7 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
     const uint8_t* __restrict__ d = dig;
     bool conv = false, ups_first = false, ups_later = false, ups_near_edge = false;
     UpWin W{0, 0, 0, 0, 0};
+    unsigned long long ucodes = 0ull; int nups = 0;
     long orf = 1;
     int stop3 = 0;
     if (is_start) {
@@ -1890,6 +1891,9 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
         if (conv && sp.conv_flag != nullptr) sp.conv_flag[c] = 1;
         start = strand == 1 ? ndx : L - 1 - ndx;     // strand-local start position
         W = load_upwin(d, L, start, strand);
+        // upstream composition (ref: lib.pyx:1618-1650): the bases at u = 1, 2 and 15 .. 44 as far as they lie inside the sequence
+        ucodes = ((W.p0 >> 2) & 0xfull) | ((W.p0 >> 30) << 4) | ((W.p1 & 0x3ffffffull) << 38);
+        nups = start >= 2 ? 2 + min(max(start - 14, 0), 30) : (start >= 1 ? 1 : 0);
         orf = ndx > sv ? ndx - sv : sv - ndx;
         // the three bases at the ORF's stop, strand-local order: whether they are a stop codon depends on the model's table
         const int s0 = strand == 1 ? sv : L - 1 - sv;
@@ -1926,8 +1930,9 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
     unsigned pats[3] = {0u, 0u, 0u};
     int mi = 0;                                                 // the thread's next chain
     // the lowest model of the set above `after` (relative to mb), or -1
+    const int present_words = min(SS_MASK_WORDS, (min(sp.models_per_pass, sp.n_models) + 63) >> 6);      // (sixteen models: one word, not eight)
     auto next_present = [&](const int after) {
-        for (int w = (after + 1) >> 6; w < SS_MASK_WORDS; w++) {
+        for (int w = (after + 1) >> 6; w < present_words; w++) {
             unsigned long long bits = s_present[w];
             if (w == (after + 1) >> 6) bits &= ~0ull << ((after + 1) & 63);
             if (bits) return w * 64 + __builtin_ctzll(bits);
@@ -1945,7 +1950,7 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
         else if (tid == 2) R.r0 = __hiloint2double(tmg->uses_sd, tmg->trans_table);
         else if (tid >= 4 && tid < 7) R.r0 = tmg->type_wt[tid - 4];
         else if (tid >= 32 && tid < 60) R.r0 = tmg->rbs_wt[tid - 32];
-        else if (tid >= 128) R.r0 = (&tmg->ups_comp[0][0])[tid - 128];
+        else if (tid >= 128) R.r0 = 0.4 * tmg->st_wt * (&tmg->ups_comp[0][0])[tid - 128];      // the term the upstream composition adds (ref: lib.pyx:1618-1650), multiplied once per workgroup and model
         R.r1 = tmg->mot_wt[0][tid >> 6][tid & 63];          // asked for whatever uses_sd says: no load waits for another
         return R;
     };
@@ -2010,12 +2015,19 @@ k_score_starts(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
         auto midx = [&](const int k, const int t2) { return (int)((W.zm >> (2 * (21 - (18 + k - t2)))) & ((1ull << (2 * (k + 3))) - 1ull)); };
         auto msi = [](const int t2) { return t2 <= 2 ? 3 : (t2 <= 4 ? 2 : (t2 >= 11 ? 1 : 0)); };      // u0 >= 16 + k, >= 14 + k, <= 7 + k
         // upstream composition (ref: lib.pyx:1618-1650)
+        // (which weight of a row: the node's codes at u = 1, 2, 15 .. 44, packed once per node -- `ucodes`, `nups` -- instead of dug out of
+        //  the window for every model; the sum is the reference's, term by term)
         auto upstream = [&]() {
-            int cnt = 0; double v = 0.0;
+            double v = 0.0;              // (SM.ups holds 0.4 * st_wt * ups_comp: stage_fetch)
+            unsigned lo = (unsigned)ucodes, hi = (unsigned)(ucodes >> 32);
+            if (nups == 32) {
 #pragma unroll
-            for (int k = 1; k < 3; k++) { if (k > start) break; v += 0.4 * st_wt * SM.ups[cnt][W.code(k)]; cnt++; }
-#pragma unroll 10
-            for (int k = 15; k < 45; k++) { if (k > start) break; v += 0.4 * st_wt * SM.ups[cnt][W.code(k)]; cnt++; }
+                for (int q = 0; q < 16; q++) { v += SM.ups[q][(lo >> (2 * q)) & 3u]; if ((q & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+                for (int q = 0; q < 16; q++) { v += SM.ups[16 + q][(hi >> (2 * q)) & 3u]; if ((q & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
+            } else {
+                for (int q = 0; q < nups; q++) v += SM.ups[q][(int)(ucodes >> (2 * q)) & 3];
+            }
             return v;
         };
         double u = 0.0;
