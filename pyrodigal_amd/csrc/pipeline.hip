@@ -821,6 +821,7 @@ __device__ __forceinline__ int hexamer(const uint8_t* __restrict__ d, int pos, i
 // A block first compacts its stop nodes into the leading lanes.
 constexpr int CS_MODELS = 4;
 constexpr int CS_LONG = 192;
+constexpr int CSQ_SERIAL_MAX = 256;                    // k_coding_score_quads: the longest ORF a lane walks on its own (four 64-bit masks of start nodes)
 
 struct OrfCtx {
     const uint8_t* d;             // GroupArrays::df of the contig: digit | forward-node flag << 4 | reverse-node flag << 5, by position
@@ -1058,7 +1059,7 @@ __device__ __forceinline__ void orf_serial_quad(const OrfCtx& o, const ChainDesc
 #pragma unroll
     for (int m = 0; m < CS_MODELS; m++) sum[m] = 0.0;
     int far = -1, kfar = 0, mer = 0;
-    unsigned long long sm0 = 0, sm1 = 0, sm2 = 0;           // the codons that are start nodes (every ORF walked here has at most CS_LONG = 192)
+    unsigned long long sm0 = 0, sm1 = 0, sm2 = 0, sm3 = 0;  // the codons that are start nodes (every ORF walked here has at most CSQ_SERIAL_MAX = 256)
     // one codon (ci is the same in every lane): its hexamer joins the sums; a start node (k = its index in the contig) keeps them
     auto visit = [&](const int ci, const bool isnode, const int k) {
         const double* q4 = quad + 4 * mer;                   // one 32-byte row of LDS: two ds_read_b128
@@ -1068,7 +1069,8 @@ __device__ __forceinline__ void orf_serial_quad(const OrfCtx& o, const ChainDesc
         const unsigned long long bit = isnode ? 1ull << (ci & 63) : 0ull;
         // ci is scalar: three scalar branches (the empty asm statements keep them apart; merged, the masks become a private array in scratch)
         if (ci < 64) { sm0 |= bit; asm volatile("; mask 0"); } else if (ci < 128) { sm1 |= bit; asm volatile("; mask 1"); }
-        else if (ci < CS_LONG) { sm2 |= bit; asm volatile("; mask 2"); }
+        else if (ci < 192) { sm2 |= bit; asm volatile("; mask 2"); }
+        else if (ci < CSQ_SERIAL_MAX) { sm3 |= bit; asm volatile("; mask 3"); }
     };
     // Where a start node sits in the contig's node list is a COUNT: nodes are in (position, strand) order, the stop node's index is
     // known, and the bytes the walk reads anyway carry the node flags of EVERY position it passes, either strand (bits 4 and 5).
@@ -1162,13 +1164,13 @@ __device__ __forceinline__ void orf_serial_quad(const OrfCtx& o, const ChainDesc
     auto start_below = [&](int c) -> int {                    // the outermost start node at or below codon c, or -1
         while (c >= 0) {
             const int wsel = c >> 6;
-            const unsigned long long bits = (wsel == 2 ? sm2 : (wsel == 1 ? sm1 : sm0)) & ((2ull << (c & 63)) - 1ull);
+            const unsigned long long bits = (wsel == 3 ? sm3 : (wsel == 2 ? sm2 : (wsel == 1 ? sm1 : sm0))) & ((2ull << (c & 63)) - 1ull);
             if (bits) return wsel * 64 + 63 - __builtin_clzll(bits);
             c = wsel * 64 - 1;
         }
         return -1;
     };
-    if (far >= CS_LONG) __builtin_trap();                     // cannot happen (see above): never walk past the masks
+    if (far >= CSQ_SERIAL_MAX) __builtin_trap();              // cannot happen (see above): never walk past the masks
     // (two start nodes ahead: while this one is priced, the next one's sums and the index of the one after it are on their way)
     int ci = far, k = kfar;
     int c1 = start_below(ci - 1), k1 = 0;
@@ -1468,7 +1470,8 @@ k_coding_score_quads(const CsTask* __restrict__ tasks, const CsEntry* __restrict
                      const int2* __restrict__ contig_chains, const int32_t* __restrict__ node_contig_base,
                      const uint8_t* __restrict__ dig, const ContigDesc* __restrict__ ct, GroupArrays ga,
                      const pga_training* __restrict__ models, const ModelScoreConst* __restrict__ msc, ChainArrays ca,
-                     const double* __restrict__ gil, int il_stride, const int32_t* __restrict__ rank, const int cs_wave, unsigned long long* __restrict__ prof) {
+                     const double* __restrict__ gil, int il_stride, const int32_t* __restrict__ rank, const int cs_wave, unsigned long long* __restrict__ prof,
+                     const int q_classes /* length classes 1 .. q_classes go four to a wave: 4 = ORFs beyond 192 codons, 3 = beyond 256 */) {
     extern __shared__ __attribute__((aligned(16))) double s_quad[];                  // [4096][4]
     __shared__ int s_pre[CS_TASK_MAX_ENTRIES + 1];      // first node (task-local numbering) of every entry
     __shared__ int s_list[CS_LIST];                     // node of the round (bits 0-12) | entry << 13
@@ -1546,8 +1549,9 @@ k_coding_score_quads(const CsTask* __restrict__ tasks, const CsEntry* __restrict
             int acc = 0;
             for (int k = 0; k < CS_CLASSES; k++) { const int n = s_cls[k]; s_cls[k] = acc; acc += n; }
             if (acc > CS_LIST) __builtin_trap();             // cannot happen (see CS_LIST); never write past the list
-            // classes 0: a wave each; 1 .. 4 (longer than CS_LONG): four to a wave; the others 64 to a wave
-            s_count = acc; s_next_long = 0; s_next_q = s_cls[1]; s_qend = s_cls[5]; s_next = s_cls[5];
+            // classes 0: a wave each; 1 .. q_classes: four to a wave (3: ORFs beyond 256 codons -- round 6, fourth session: a lane walks up to
+            // CSQ_SERIAL_MAX codons on its own, 655 -> 642 us per launch; PGA_CS_QCLASSES=4: beyond 192 as before); the others 64 to a wave
+            s_count = acc; s_next_long = 0; s_next_q = s_cls[1]; s_qend = s_cls[q_classes + 1]; s_next = s_cls[q_classes + 1];
         }
         __syncthreads();
 #pragma unroll
@@ -2647,7 +2651,7 @@ void pga_launch_score(const ChainDesc* d_chains, int n_chains, int64_t node_begi
         }
         hipLaunchKernelGGL(k_coding_score_quads, dim3((unsigned)n_cs_tasks), dim3(CS_TASK_THREADS), lds, st, (const CsTask*)d_cs_tasks,
                            (const CsEntry*)d_cs_entries, d_all_chains, d_contig_chains, d_node_contig_base, d_dig, d_ct, ga, d_models, d_msc, ca,
-                           d_gil, il_stride, d_rank, cs_wave, profiling ? d_prof : nullptr);
+                           d_gil, il_stride, d_rank, cs_wave, profiling ? d_prof : nullptr, (getenv("PGA_CS_QCLASSES") && atoi(getenv("PGA_CS_QCLASSES")) == 4) ? 4 : 3);
         if (profiling) {
             unsigned long long h[16];
             (void)hipStreamSynchronize(st);
