@@ -1807,7 +1807,7 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             const void* d_cs_tasks = nullptr; const void* d_cs_entries = nullptr; int n_cs_tasks = 0;
             const char* cs_env = getenv("PGA_CS_LDS");
             const char* cs_tn = getenv("PGA_CS_TASK_NODES");
-            const int cs_task_nodes = cs_tn && atoi(cs_tn) >= 256 && atoi(cs_tn) <= 8192 ? atoi(cs_tn) : 4096;     // several tasks per CU and launch
+            const int cs_task_nodes = cs_tn && atoi(cs_tn) >= 256 && atoi(cs_tn) <= 8192 ? atoi(cs_tn) : 5120;     // several tasks per CU and launch (swept again at the end of round 6, one box: 4096 629 us per launch, 4864 581, 5120 586, 5376 584, 5632 600, 6144 592)
             // PGA_CS_LDS=2 (tests): the LDS form whatever the size of the launch
             // (single mode as well: one table column, a genome is cut into tasks of `cs_task_nodes` nodes)
             // (the global-memory form walks every ORF on one lane through the texture path: a launch takes as long as its longest ORF,
