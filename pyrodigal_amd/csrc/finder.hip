@@ -1446,7 +1446,8 @@ static int find_impl(pga_ctx* c, const pga_batch* batch, const pga_params* pp, c
             char nm[32];
 #define GBUF(field, type, count) { snprintf(nm, sizeof nm, #field "%d", g); void* p__; int rc__ = ensure_dev(c, nm, sizeof(type) * (size_t)(count) + 64, &p__); if (rc__) return rc__; ga[g].field = (type*)p__; }
             GBUF(df, uint8_t, total + 16)
-            GBUF(pre, int32_t, total + 2)
+            GBUF(c16, int32_t, (size_t)batch->n_tiles * 192 + 2)
+            ga[g].tile0 = batch->d_tile0;
             ga[g].ndx = nullptr; ga[g].stop_val = nullptr; ga[g].type = nullptr; ga[g].strand = nullptr; ga[g].edge0 = nullptr; ga[g].gc_cont = nullptr;
         }
 

@@ -22,8 +22,12 @@ struct GroupArrays {
     // per position (whole batch)
     uint8_t* df;                             // the digit of the position (bits 0-2) | 16 = a forward node has its ndx here | 32 = a reverse node has
                                              // (written densely by the tile that owns the position): all an ORF walk reads of a position is one byte
-    int32_t* pre;                            // at a position with a node: the index of its first node (the forward one when both strands have
-                                             // one there: the reverse node then is the next, ref: lib.pyx:2489-2493)
+    // the index of a position's first node (the forward one when both strands have one there: the reverse node then is the next, ref:
+    // lib.pyx:2489-2493) is a COUNT: c16[192 tile + g] = index of the first node at or after position 16 g of the tile (k_place_nodes; a
+    // contig's tiles are consecutive from tile0[contig], so that is entry position >> 4 of the contig), and the sixteen bytes of df from
+    // there on carry the node flags of the positions in between.  (Until the end of round 6 an int32 per POSITION: 500 MB per group and
+    // call, written four bytes at a time wherever a node sat -- most of what k_place_nodes moved.)
+    int32_t* c16; const int32_t* tile0 = nullptr;
     // staging: the nodes of the tile that starts at global position g, packed in order from slot 2 g (two slots per position: every
     // position can hold a node on either strand) -- or, st_half = s > 0, from slot g >> s with room for one node per 2^s positions
     // of the tile (s = 1 in production: sequence has a node every 25 positions or so, periodic worst cases reach one in two); a

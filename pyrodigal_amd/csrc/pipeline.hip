@@ -690,8 +690,17 @@ k_place_nodes(const ContigDesc* __restrict__ ct, const TileDesc* __restrict__ ti
     __shared__ int s_w[2];
     const TileDesc td = tiles[blockIdx.x];
     const int off = tile_off[blockIdx.x], cnt = tile_off[blockIdx.x + 1] - off;
-    if (cnt <= 0) return;
-    const int64_t base = ct[td.contig].base;
+    const ContigDesc cd = ct[td.contig];
+    // c16 of the tile: entry g = the first node at or after position td.start + 16 g.  Node j answers for the groups behind its
+    // predecessor's up to its own, the last node's thread for the rest of the tile as well (their first node is the next tile's).
+    static_assert(EX_TILE == 192 * 16, "GroupArrays::c16 holds 192 entries per tile");
+    int32_t* const c16 = ga.c16 + (size_t)blockIdx.x * 192;
+    const int n_groups = (min(EX_TILE, cd.len - td.start) + 15) >> 4;
+    if (cnt <= 0) {
+        for (int g = threadIdx.x; g < n_groups; g += blockDim.x) c16[g] = off;
+        return;
+    }
+    const int64_t base = cd.base;
     const int64_t s0 = ga.st_half ? ((base + td.start) >> ga.st_half) + (int64_t)PGA_STAGE_SLACK * blockIdx.x : 2 * (base + td.start);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int srun = tile_soff[blockIdx.x];                       // next free entry of the stop list
@@ -705,8 +714,9 @@ k_place_nodes(const ContigDesc* __restrict__ ct, const TileDesc* __restrict__ ti
             k = off + j;
             ga.ndx[k] = ndx; ga.stop_val[k] = ga.st_sv[s0 + j]; ga.type[k] = info & 3; ga.strand[k] = (info >> 3) & 1 ? -1 : 1; ga.edge0[k] = (info >> 2) & 1;
             ga.contig_of[k] = td.contig;
-            // the position learns its first node: a reverse node right after the forward node of the same position is the second
-            if (!((info >> 3) & 1) || j == 0 || ga.st_ndx[s0 + j - 1] != ndx) ga.pre[base + ndx] = k;
+            const int g_hi = (ndx - td.start) >> 4, g_lo = j == 0 ? 0 : ((ga.st_ndx[s0 + j - 1] - td.start) >> 4) + 1;
+            for (int g = g_lo; g <= g_hi; g++) c16[g] = k;
+            if (j == cnt - 1) for (int g = g_hi + 1; g < n_groups; g++) c16[g] = off + cnt;
             is_stop = (info & 3) == PGA_T_STOP;
         }
         const unsigned long long bal = __ballot(is_stop);
@@ -825,13 +835,29 @@ constexpr int CSQ_SERIAL_MAX = 256;                    // k_coding_score_quads: 
 
 struct OrfCtx {
     const uint8_t* d;             // GroupArrays::df of the contig: digit | forward-node flag << 4 | reverse-node flag << 5, by position
-    const int32_t* pre;           // GroupArrays::pre of the contig: index of the first node of a position
+    const int32_t* c16;           // GroupArrays::c16 of the contig: entry g = index (in the group) of the first node at or after position 16 g
     int tbase, p, q, L, strand, step, ncod;
     int kstop;                    // index of the ORF's stop node in its contig
     int2 cc;
     // the walk's own strand has a node at position j / that node's index in the contig
     __device__ __forceinline__ bool node_at(const int j) const { return (d[j] >> (strand == 1 ? 4 : 5)) & 1; }
-    __device__ __forceinline__ int node_index(const int j) const { return pre[j] - tbase + (strand == 1 ? 0 : (d[j] >> 4) & 1); }
+    // (a count: the first node of the sixteen positions from j & ~15 on, plus the nodes -- either strand -- at the positions before j, which
+    //  the bytes of those positions carry; the reverse node of a position follows its forward node)
+    __device__ __forceinline__ int node_index(const int j) const {
+        const int r = j & 15;
+        uint4 v; __builtin_memcpy(&v, d + (j - r), 16);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+        int n = c16[j >> 4] - tbase;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int keep = r - 4 * q;                       // bytes of this word before position j
+            unsigned m = w[q] & 0x30303030u;
+            if (keep <= 0) m = 0; else if (keep < 4) m &= (1u << (8 * keep)) - 1u;
+            n += __popc(m);
+        }
+        const unsigned bj = (w[r >> 2] >> (8 * (r & 3))) & 0xffu;        // the byte of position j itself
+        return n + (strand == 1 ? 0 : (int)((bj >> 4) & 1u));
+    }
 };
 
 __device__ __forceinline__ double wave_incl_max(double v, int lane) {
@@ -931,7 +957,7 @@ __device__ __forceinline__ void orf_serial(const OrfCtx& o, const ChainDesc* __r
         auto flag_off = [&](const int u) { return strand == 1 ? 12 - 3 * u : 3 * u + 2; };                 // offset of codon u's node flag in the group
         const int fbit = strand == 1 ? 4 : 5;
         // the index of the walk's node at offset k of a group starting at lo: a reverse node follows the forward node of its position
-        auto node_of = [&](const W16& w, const int lo, const int k) { return o.pre[lo + k] + (strand == 1 ? 0 : (int)((byte_of(w, k) >> 4) & 1u)); };
+        auto node_of = [&](const W16& w, const int lo, const int k) { return o.node_index(lo + k) + o.tbase; };
         W16 D1{0, 0}, D2{0, 0};
         int kq[5] = {0, 0, 0, 0, 0};
         const int ncod = o.ncod;
@@ -1409,7 +1435,7 @@ k_coding_score(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
         const ContigDesc cd = ct[c];
         o.d = ga.df + cd.base;
         o.strand = ga.strand[t];
-        o.pre = ga.pre + cd.base;
+        o.c16 = ga.c16 + (size_t)ga.tile0[c] * 192;
         o.tbase = node_contig_base[c];
         o.p = ga.ndx[t]; o.q = ga.stop_val[t]; o.L = cd.len;
         o.step = o.strand == 1 ? -3 : 3;
@@ -1433,13 +1459,13 @@ k_coding_score(const ChainDesc* __restrict__ chains, const int2* __restrict__ co
         const int src = __builtin_ctzll(longs);
         longs &= longs - 1ull;
         OrfCtx w;
-        const unsigned long long pd = (unsigned long long)o.d, pp = (unsigned long long)o.pre;
+        const unsigned long long pd = (unsigned long long)o.d, pp = (unsigned long long)o.c16;
         auto bc64 = [&](unsigned long long v) {
             const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
             const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
             return ((unsigned long long)hi << 32) | lo;
         };
-        w.d = (const uint8_t*)bc64(pd); w.pre = (const int32_t*)bc64(pp);
+        w.d = (const uint8_t*)bc64(pd); w.c16 = (const int32_t*)bc64(pp);
         w.tbase = __builtin_amdgcn_readlane(o.tbase, src); w.p = __builtin_amdgcn_readlane(o.p, src); w.q = __builtin_amdgcn_readlane(o.q, src);
         w.L = __builtin_amdgcn_readlane(o.L, src); w.strand = __builtin_amdgcn_readlane(o.strand, src); w.step = __builtin_amdgcn_readlane(o.step, src);
         w.ncod = __builtin_amdgcn_readlane(o.ncod, src);
@@ -1462,7 +1488,7 @@ constexpr int CS_LIST = 5120;                          // stop nodes of a round:
                                                        // up to twelve where a task holds a PIECE of a contig (ORFs across the cut; pga_cs_tasks allows CS_TASK_MAX_CUTS)
 constexpr int CS_TASK_MAX_CUTS = 64;
 // what the walks of a task need of one of its entries, staged in LDS once (a stop node then costs one round trip, not four)
-struct CsEnt { int64_t base; int32_t len, tbase, ccx, ccy, m0, first; };
+struct CsEnt { int64_t base; int32_t len, tbase, ccx, ccy, m0, first, tile0, _pad; };
 constexpr int CS_CLASSES = 12;                         // ORF length classes of a round
 constexpr int CS_WAVE = 2048;                          // ORFs longer than this take a whole wave (orf_wave); the others walk 64 to a wave
 __global__ void __launch_bounds__(CS_TASK_THREADS)
@@ -1499,7 +1525,7 @@ k_coding_score_quads(const CsTask* __restrict__ tasks, const CsEntry* __restrict
             const CsEntry en = entries[task.first + tid];
             const ContigDesc cd = ct[en.contig];
             const int2 cc = contig_chains[en.contig];
-            s_ent[tid] = CsEnt{cd.base, cd.len, node_contig_base[en.contig], cc.x, cc.y, en.m0, en.first};
+            s_ent[tid] = CsEnt{cd.base, cd.len, node_contig_base[en.contig], cc.x, cc.y, en.m0, en.first, ga.tile0[en.contig], 0};
             cnt = en.count;
         }
         s_pre[tid] = cnt;
@@ -1569,7 +1595,7 @@ k_coding_score_quads(const CsTask* __restrict__ tasks, const CsEntry* __restrict
             o.cc = make_int2(en.ccx, en.ccy);
             o.d = ga.df + en.base;
             o.strand = ga.strand[tt];
-            o.pre = ga.pre + en.base;
+            o.c16 = ga.c16 + (size_t)en.tile0 * 192;
             o.tbase = en.tbase;
             o.p = ga.ndx[tt]; o.q = ga.stop_val[tt]; o.L = en.len; o.kstop = tt - en.tbase;
             o.step = o.strand == 1 ? -3 : 3;
