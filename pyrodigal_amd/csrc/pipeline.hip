@@ -502,43 +502,50 @@ __device__ __forceinline__ void extract_strand(ExShared& S, const TileGeom G, co
     while (cand) { const int q = __builtin_ctz(cand); cand &= cand - 1u; candidate(q, false); }
 }
 
-__global__ void __launch_bounds__(256)
+// Two wavefronts per tile (end of round 6; it was a thread per twelve positions, both strands: every position of the batch decoded once
+// more).  A tile's FIRST stop of a frame lies, nearly always, within its first 256 codons and its LAST within its last 256: wavefront 0
+// decodes the tile's first 768 strand-local positions of either strand, wavefront 1 its last 768, a vote and a bit scan per frame give the
+// six numbers; only where a frame has no stop there (long ORFs of GC-rich sequence) does the wavefront go on to the next 768 positions.
+__global__ void __launch_bounds__(128)
 k_tile_stops(const uint8_t* __restrict__ dig, int64_t total, const ContigDesc* __restrict__ ct, const TileDesc* __restrict__ tiles, int n_tiles,
              unsigned long long stop_codons, int32_t* __restrict__ tile_first, int32_t* __restrict__ tile_last, const uint8_t* __restrict__ enabled) {
-    __shared__ int s_min[2][3][4], s_max[2][3][4];
     const TileDesc td = tiles[blockIdx.x];
     if (enabled != nullptr && !enabled[td.contig]) return;       // no model of this translation table is scored on the contig
     const ContigDesc cd = ct[td.contig];
     const TileGeom G = tile_geom(td, cd.len);
-    const int L = cd.len, t = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool first = threadIdx.x < 64;                          // wavefront 0: the first stops; wavefront 1: the last stops
     const uint8_t* __restrict__ d = dig + cd.base;
-    int f0s[2];
+    constexpr int CHUNK = 64 * EX_PER_THREAD;
 #pragma unroll
     for (int s = 0; s < 2; s++) {
-        const int top = s == 0 ? G.a : L - 1 - G.a - (EX_PER_THREAD - 1);
-        const int i0 = s == 0 ? top + t * EX_PER_THREAD : top - t * EX_PER_THREAD;
-        f0s[s] = ((top % 3) + 3) % 3;
-        unsigned inm, cw, stm, scm;
-        if (s == 0) strand_codon_masks<1>(G, d, cd.base, total, i0, stop_codons, 0ull, inm, cw, stm, scm);
-        else strand_codon_masks<-1>(G, d, cd.base, total, i0, stop_codons, 0ull, inm, cw, stm, scm);
+        const int lo = G.lo(s == 0 ? 1 : -1), end = lo + G.len;  // the tile's strand-local positions
+        int res[3];                                               // by relative frame (position - i0) % 3; every i0 of the wavefront is the same mod 3
+        res[0] = res[1] = res[2] = first ? EX_NONE_HI : -1;
+        unsigned found = 0;
+        int fbase = 0;
+        for (int c = 0; c * CHUNK < G.len && found != 7u; c++) {
+            // lanes rise with the position (first) or fall (last): the wavefront's answer is that of its lowest lane that has one
+            const int i0 = first ? lo + c * CHUNK + lane * EX_PER_THREAD : end - c * CHUNK - (lane + 1) * EX_PER_THREAD;
+            fbase = ((i0 % 3) + 3) % 3;
+            unsigned inm, cw, stm, scm;
+            if (s == 0) strand_codon_masks<1>(G, d, cd.base, total, i0, stop_codons, 0ull, inm, cw, stm, scm);
+            else strand_codon_masks<-1>(G, d, cd.base, total, i0, stop_codons, 0ull, inm, cw, stm, scm);
 #pragma unroll
-        for (int r = 0; r < 3; r++) {
-            const unsigned m = stm & (0x249u << r);
-            const int a = m ? i0 + __builtin_ctz(m) : EX_NONE_HI, b = m ? i0 + 31 - __builtin_clz(m) : -1;
-            // positions rise (s == 0) or fall (s == 1) with the lane: the wavefront's first stop is the first stop of its first lane that has one
-            const unsigned long long hs = __ballot(m != 0u);
-            const int l_lo = hs ? __builtin_ctzll(hs) : 0, l_hi = hs ? 63 - __builtin_clzll(hs) : 0;
-            const int wa = __shfl(a, s == 0 ? l_lo : l_hi, 64), wb = __shfl(b, s == 0 ? l_hi : l_lo, 64);
-            if ((t & 63) == 0) { s_min[s][r][t >> 6] = hs ? wa : EX_NONE_HI; s_max[s][r][t >> 6] = hs ? wb : -1; }
+            for (int r = 0; r < 3; r++) {
+                const unsigned m = stm & (0x249u << r);
+                const unsigned long long hs = __ballot(m != 0u);
+                const int v = m ? (first ? i0 + __builtin_ctz(m) : i0 + 31 - __builtin_clz(m)) : 0;
+                const int wv = __shfl(v, hs ? __builtin_ctzll(hs) : 0, 64);
+                if (hs && !((found >> r) & 1u)) { res[r] = wv; found |= 1u << r; }
+            }
         }
-    }
-    __syncthreads();
-    if (t < 6) {
-        const int s = t / 3, r = t % 3;
-        const int f = (f0s[s] + r) % 3;                          // relative frame r of the threads is frame f of the strand
-        const int64_t o = ((int64_t)s * n_tiles + blockIdx.x) * 3 + f;
-        tile_first[o] = min(min(s_min[s][r][0], s_min[s][r][1]), min(s_min[s][r][2], s_min[s][r][3]));
-        tile_last[o] = max(max(s_max[s][r][0], s_max[s][r][1]), max(s_max[s][r][2], s_max[s][r][3]));
+        if (lane < 3) {
+            const int f = (fbase + lane) % 3;                     // relative frame `lane` is frame f of the strand
+            const int64_t o = ((int64_t)s * n_tiles + blockIdx.x) * 3 + f;
+            const int v = lane == 0 ? res[0] : (lane == 1 ? res[1] : res[2]);
+            if (first) tile_first[o] = v; else tile_last[o] = v;
+        }
     }
 }
 
@@ -2552,7 +2559,7 @@ void pga_launch_extract(const uint8_t* d_dig, int64_t total, const ContigDesc* d
             if (codon_is_stop(b0, b1, b2, tt)) P.stop_codons |= 1ull << idx;
             if (codon_is_start(b0, b1, b2, tt)) P.start_codons |= 1ull << idx;
         }
-        hipLaunchKernelGGL(k_tile_stops, dim3(n_tiles), dim3(256), 0, st, d_dig, total, d_ct, d_tiles, n_tiles, P.stop_codons, d_tile_first, d_tile_last, d_enabled);
+        hipLaunchKernelGGL(k_tile_stops, dim3(n_tiles), dim3(128), 0, st, d_dig, total, d_ct, d_tiles, n_tiles, P.stop_codons, d_tile_first, d_tile_last, d_enabled);
         hipLaunchKernelGGL(k_extract_tile, dim3(n_tiles), dim3(256), 0, st, d_dig, total, d_ct, d_tiles, n_tiles, d_tile_first, d_tile_last, P, ga, masks,
                            d_enabled, d_tile_count, d_tile_scount);
     }
