@@ -502,31 +502,31 @@ __device__ __forceinline__ void extract_strand(ExShared& S, const TileGeom G, co
     while (cand) { const int q = __builtin_ctz(cand); cand &= cand - 1u; candidate(q, false); }
 }
 
-// Two wavefronts per tile (end of round 6; it was a thread per twelve positions, both strands: every position of the batch decoded once
-// more).  A tile's FIRST stop of a frame lies, nearly always, within its first 256 codons and its LAST within its last 256: wavefront 0
-// decodes the tile's first 768 strand-local positions of either strand, wavefront 1 its last 768, a vote and a bit scan per frame give the
-// six numbers; only where a frame has no stop there (long ORFs of GC-rich sequence) does the wavefront go on to the next 768 positions.
-__global__ void __launch_bounds__(128)
+// One wavefront per tile (end of round 6; it was a thread per twelve positions, both strands: every position of the batch decoded once
+// more).  A tile's FIRST stop of a frame lies, nearly always, within its first 128 codons and its LAST within its last 128: lanes 0 - 31
+// decode the tile's first 384 strand-local positions of a strand, lanes 32 - 63 its last 384, a vote and a bit scan per frame and half give
+// the six numbers; only where a frame has no stop there (long ORFs of GC-rich sequence) do the lanes go on to the next 384 positions.
+__global__ void __launch_bounds__(64)
 k_tile_stops(const uint8_t* __restrict__ dig, int64_t total, const ContigDesc* __restrict__ ct, const TileDesc* __restrict__ tiles, int n_tiles,
              unsigned long long stop_codons, int32_t* __restrict__ tile_first, int32_t* __restrict__ tile_last, const uint8_t* __restrict__ enabled) {
     const TileDesc td = tiles[blockIdx.x];
     if (enabled != nullptr && !enabled[td.contig]) return;       // no model of this translation table is scored on the contig
     const ContigDesc cd = ct[td.contig];
     const TileGeom G = tile_geom(td, cd.len);
-    const int lane = threadIdx.x & 63;
-    const bool first = threadIdx.x < 64;                          // wavefront 0: the first stops; wavefront 1: the last stops
+    const int lane = threadIdx.x & 63, hl = lane & 31;
+    const bool first = lane < 32;                                 // lanes 0 - 31: the first stops; lanes 32 - 63: the last stops
     const uint8_t* __restrict__ d = dig + cd.base;
-    constexpr int CHUNK = 64 * EX_PER_THREAD;
+    constexpr int CHUNK = 32 * EX_PER_THREAD;
 #pragma unroll
     for (int s = 0; s < 2; s++) {
         const int lo = G.lo(s == 0 ? 1 : -1), end = lo + G.len;  // the tile's strand-local positions
-        int res[3];                                               // by relative frame (position - i0) % 3; every i0 of the wavefront is the same mod 3
+        int res[3];                                               // by relative frame (position - i0) % 3; every i0 of a half is the same mod 3
         res[0] = res[1] = res[2] = first ? EX_NONE_HI : -1;
-        unsigned found = 0;
+        unsigned found = 0;                                       // bits 0 - 2: the first stops, bits 3 - 5: the last stops (wave-uniform)
         int fbase = 0;
-        for (int c = 0; c * CHUNK < G.len && found != 7u; c++) {
-            // lanes rise with the position (first) or fall (last): the wavefront's answer is that of its lowest lane that has one
-            const int i0 = first ? lo + c * CHUNK + lane * EX_PER_THREAD : end - c * CHUNK - (lane + 1) * EX_PER_THREAD;
+        for (int c = 0; c * CHUNK < G.len && found != 63u; c++) {
+            // a half's lanes rise with the position (first) or fall (last): the half's answer is that of its lowest lane that has one
+            const int i0 = first ? lo + c * CHUNK + hl * EX_PER_THREAD : end - c * CHUNK - (hl + 1) * EX_PER_THREAD;
             fbase = ((i0 % 3) + 3) % 3;
             unsigned inm, cw, stm, scm;
             if (s == 0) strand_codon_masks<1>(G, d, cd.base, total, i0, stop_codons, 0ull, inm, cw, stm, scm);
@@ -535,15 +535,20 @@ k_tile_stops(const uint8_t* __restrict__ dig, int64_t total, const ContigDesc* _
             for (int r = 0; r < 3; r++) {
                 const unsigned m = stm & (0x249u << r);
                 const unsigned long long hs = __ballot(m != 0u);
+                const unsigned h_first = (unsigned)hs, h_last = (unsigned)(hs >> 32);
                 const int v = m ? (first ? i0 + __builtin_ctz(m) : i0 + 31 - __builtin_clz(m)) : 0;
-                const int wv = __shfl(v, hs ? __builtin_ctzll(hs) : 0, 64);
-                if (hs && !((found >> r) & 1u)) { res[r] = wv; found |= 1u << r; }
+                const int src = first ? (h_first ? __builtin_ctz(h_first) : 0) : (h_last ? 32 + __builtin_ctz(h_last) : 32);
+                const int wv = __shfl(v, src, 64);
+                const bool mine_has = first ? h_first != 0u : h_last != 0u;
+                const unsigned bit = first ? (1u << r) : (8u << r);
+                if (mine_has && !(found & bit)) res[r] = wv;
+                found |= (h_first ? (1u << r) : 0u) | (h_last ? (8u << r) : 0u);
             }
         }
-        if (lane < 3) {
-            const int f = (fbase + lane) % 3;                     // relative frame `lane` is frame f of the strand
+        if (hl < 3) {
+            const int f = (fbase + hl) % 3;                       // relative frame `hl` of the half is frame f of the strand
             const int64_t o = ((int64_t)s * n_tiles + blockIdx.x) * 3 + f;
-            const int v = lane == 0 ? res[0] : (lane == 1 ? res[1] : res[2]);
+            const int v = hl == 0 ? res[0] : (hl == 1 ? res[1] : res[2]);
             if (first) tile_first[o] = v; else tile_last[o] = v;
         }
     }
@@ -2225,11 +2230,15 @@ __device__ __forceinline__ unsigned overlap_neighbours(const int32_t* __restrict
     const bool fwd = str[i] == 1;
     bool ended = false;
     unsigned elig = 0;
+    // (the first OV_NEAR neighbours at once; the walk nearly always ends among them -- max_overlap is sixty bases, a node sits every
+    //  dozen -- and the others are only asked for where it does not: nothing of a neighbour behind the end of the walk is ever used)
+    constexpr int OV_NEAR = 10;
 #pragma unroll
     for (int k = 0; k < OV_SPEC; k++) {
+        if (k == OV_NEAR && ended) break;
         const int j = fwd ? i + 3 - k : i - 3 + k;
         const int jj = min(max(j, 0), n - 1);
-        const int nd = ndx[jj], sv = stv[jj], ty = typ[jj], sd = str[jj];       // unconditional: every load of the loop can be in flight at once
+        const int nd = ndx[jj], sv = stv[jj], ty = typ[jj], sd = str[jj];       // unconditional within either part: every load can be in flight at once
         bool stop_here, ok;
         if (fwd) {
             stop_here = j < 0 || (j < n && nd <= my + 2 && nd + maxov < my);
@@ -2559,7 +2568,7 @@ void pga_launch_extract(const uint8_t* d_dig, int64_t total, const ContigDesc* d
             if (codon_is_stop(b0, b1, b2, tt)) P.stop_codons |= 1ull << idx;
             if (codon_is_start(b0, b1, b2, tt)) P.start_codons |= 1ull << idx;
         }
-        hipLaunchKernelGGL(k_tile_stops, dim3(n_tiles), dim3(128), 0, st, d_dig, total, d_ct, d_tiles, n_tiles, P.stop_codons, d_tile_first, d_tile_last, d_enabled);
+        hipLaunchKernelGGL(k_tile_stops, dim3(n_tiles), dim3(64), 0, st, d_dig, total, d_ct, d_tiles, n_tiles, P.stop_codons, d_tile_first, d_tile_last, d_enabled);
         hipLaunchKernelGGL(k_extract_tile, dim3(n_tiles), dim3(256), 0, st, d_dig, total, d_ct, d_tiles, n_tiles, d_tile_first, d_tile_last, P, ga, masks,
                            d_enabled, d_tile_count, d_tile_scount);
     }
