@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical: PGA_CS_TASK_MIX was an experiment of the fourth session of round 6 in pga_cs_tasks, measured and removed -- profiles/r06_f_experiments.md; the PGA_CS_TASK_NODES rows still run)
 # experiment: task sizes of k_coding_score_quads mixed over the launch (big first, small last)
 export TMPDIR=/tmp; REPO=$(pwd)
 run() { local tag=$1; shift

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical: PGA_BENCH_SORT_GC was an experiment of the fourth session of round 6 in bench.py, measured and removed -- profiles/r06_f_experiments.md)
 # experiment: the contigs of a call in GC order (neighbours share their models) against the job's order; kernel times of 6 250-contig calls
 REPO=$(pwd); export TMPDIR=/tmp
 for S in 0 1; do
