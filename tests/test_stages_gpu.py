@@ -183,3 +183,19 @@ def test_score_stage_needs_a_model(ctx):
         ctx.nodes_stage(["ATGC" * 100], _cabi.STAGE_SCORE)
     with pytest.raises(ValueError):
         ctx.nodes_stage(["ATGC" * 100], 7)
+
+
+@pytest.mark.parametrize("closed", [False, True])
+def test_extract_stage_tiles_without_a_stop(ctx, closed):
+    # k_tile_stops looks for a tile's first / last stop of a frame in its first / last 384 positions and goes on only where there is none:
+    # 12 kb without a stop codon in any frame of either strand (GCC repeats with start codons inside) span four tiles that hold no stop
+    # at all, between ordinary sequence; and a GC-rich stretch whose ORFs run for hundreds of codons
+    from pyrodigal_amd import _cabi
+    quiet = (b"GCC" * 150 + b"ATG" + b"GCC" * 150 + b"GTG") * 13
+    seqs = [synthetic_contig(2000, 0.5, 11) + b"ATG" + quiet + b"TAA" + synthetic_contig(2500, 0.45, 12),
+            synthetic_contig(9000, 0.78, 13), quiet[:3080], b"CAT" + quiet[:6200][::-1]]
+    for tt in (11, 4):
+        out = ctx.nodes_stage(seqs, _cabi.STAGE_EXTRACT, translation_table=tt, closed=closed)
+        for seq, nd in zip(seqs, out):
+            check(nd, oracle_stage(seq, 1, tt=tt, closed=closed), 1)
+    assert out[0]["n"] > 50
